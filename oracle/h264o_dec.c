@@ -1,0 +1,424 @@
+/*
+ * oracle/h264o_dec.c -- stream driver: NAL dispatch (h264/server.go:113-166), picture
+ * boundaries (7.4.1.2.4), POC (8.2.1), reference lists (8.2.4), reference marking (8.2.5),
+ * frame output with cropping.
+ *
+ * TEST INFRASTRUCTURE ONLY (see h264o.h).
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "h264o_int.h"
+
+int h264o_fail(h264o_decoder *d, const char *fmt, ...) {
+    if (!d->info.error) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(d->err, sizeof(d->err), fmt, ap);
+        va_end(ap);
+        d->info.error = 1;
+    }
+    return -1;
+}
+const char *h264o_last_error(h264o_decoder *d) { return d->err; }
+
+h264o_decoder *h264o_decoder_create(void) { return (h264o_decoder *)calloc(1, sizeof(h264o_decoder)); }
+static void free_pics(h264o_decoder *d) {
+    for (int i = 0; i < d->n_pics; i++) free(d->pics[i].plane[0]);
+    d->n_pics = 0;
+    free(d->mb);
+    d->mb = NULL;
+}
+void h264o_decoder_destroy(h264o_decoder *d) {
+    if (!d) return;
+    free_pics(d);
+    free(d->rbsp);
+    free(d);
+}
+void h264o_set_mb_trace(h264o_decoder *d, int32_t *trace, size_t cap) {
+    d->trace = trace;
+    d->trace_cap = cap;
+    d->trace_pos = 0;
+}
+
+static int activate(h264o_decoder *d, const h264o_pps *pps) {
+    const h264o_sps *s = &d->sps[pps->seq_parameter_set_id];
+    if (!s->valid) return h264o_fail(d, "PPS %d refers to missing SPS %d", pps->pic_parameter_set_id, pps->seq_parameter_set_id);
+    if (s->chroma_format_idc != 1 || s->bit_depth_luma_minus8 || s->bit_depth_chroma_minus8 || !s->frame_mbs_only_flag ||
+        s->qpprime_y_zero_transform_bypass_flag)
+        return h264o_fail(d, "unsupported SPS (need 4:2:0 8-bit frame_mbs_only; chroma_format_idc=%d)", s->chroma_format_idc);
+    int wmb = s->pic_width_in_mbs_minus1 + 1, hmb = s->pic_height_in_map_units_minus1 + 1;
+    if (d->asps != s || wmb != d->wmb || hmb != d->hmb || !d->mb) {
+        free_pics(d);
+        d->wmb = wmb;
+        d->hmb = hmb;
+        d->mb = (h264o_mb *)calloc((size_t)wmb * hmb, sizeof(h264o_mb));
+        int n = (s->max_num_ref_frames > 0 ? s->max_num_ref_frames : 1) + 2;
+        if (n > 20) n = 20;
+        size_t ysz = (size_t)wmb * 16 * hmb * 16;
+        for (int i = 0; i < n; i++) {
+            h264o_pic *p = &d->pics[i];
+            memset(p, 0, sizeof(*p));
+            p->plane[0] = (uint8_t *)malloc(ysz * 3 / 2);
+            p->plane[1] = p->plane[0] + ysz;
+            p->plane[2] = p->plane[1] + ysz / 4;
+            p->stride[0] = wmb * 16;
+            p->stride[1] = p->stride[2] = wmb * 8;
+        }
+        d->n_pics = n;
+        d->info.coded_width = wmb * 16;
+        d->info.coded_height = hmb * 16;
+        d->info.width = wmb * 16 - 2 * (s->frame_crop_left_offset + s->frame_crop_right_offset);
+        d->info.height = hmb * 16 - 2 * (s->frame_crop_top_offset + s->frame_crop_bottom_offset);
+    }
+    d->asps = s;
+    d->apps = pps;
+    h264o_build_level_scale(d);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ 8.2.1 picture order count */
+static int compute_poc(h264o_decoder *d, const h264o_slice_header *sh) {
+    const h264o_sps *s = d->asps;
+    int max_fn = 1 << (s->log2_max_frame_num_minus4 + 4);
+    int poc = 0;
+    if (s->pic_order_cnt_type == 0) {
+        int max_lsb = 1 << (s->log2_max_pic_order_cnt_lsb_minus4 + 4);
+        int prev_msb = sh->idr_flag ? 0 : d->prev_poc_msb, prev_lsb = sh->idr_flag ? 0 : d->prev_poc_lsb, msb;
+        if (sh->pic_order_cnt_lsb < prev_lsb && prev_lsb - sh->pic_order_cnt_lsb >= max_lsb / 2)
+            msb = prev_msb + max_lsb;
+        else if (sh->pic_order_cnt_lsb > prev_lsb && sh->pic_order_cnt_lsb - prev_lsb > max_lsb / 2)
+            msb = prev_msb - max_lsb;
+        else
+            msb = prev_msb;
+        int top = msb + sh->pic_order_cnt_lsb, bot = top + sh->delta_pic_order_cnt_bottom;
+        poc = top < bot ? top : bot;
+        if (sh->nal_ref_idc) {
+            d->prev_poc_msb = msb;
+            d->prev_poc_lsb = sh->pic_order_cnt_lsb;
+        }
+    } else {
+        int fno;
+        if (sh->idr_flag)
+            fno = 0;
+        else if (d->prev_frame_num > sh->frame_num)
+            fno = d->prev_frame_num_offset + max_fn;
+        else
+            fno = d->prev_frame_num_offset;
+        if (s->pic_order_cnt_type == 1) {
+            int abs_fn = s->num_ref_frames_in_pic_order_cnt_cycle ? fno + sh->frame_num : 0;
+            if (!sh->nal_ref_idc && abs_fn > 0) abs_fn--;
+            int expected = 0;
+            if (abs_fn > 0) {
+                int cyc = (abs_fn - 1) / s->num_ref_frames_in_pic_order_cnt_cycle, in_cyc = (abs_fn - 1) % s->num_ref_frames_in_pic_order_cnt_cycle;
+                int delta_cycle = 0;
+                for (int i = 0; i < s->num_ref_frames_in_pic_order_cnt_cycle; i++) delta_cycle += s->offset_for_ref_frame[i];
+                expected = cyc * delta_cycle;
+                for (int i = 0; i <= in_cyc; i++) expected += s->offset_for_ref_frame[i];
+            }
+            if (!sh->nal_ref_idc) expected += s->offset_for_non_ref_pic;
+            int top = expected + sh->delta_pic_order_cnt[0], bot = top + s->offset_for_top_to_bottom_field + sh->delta_pic_order_cnt[1];
+            poc = top < bot ? top : bot;
+        } else
+            poc = sh->idr_flag ? 0 : (sh->nal_ref_idc ? 2 * (fno + sh->frame_num) : 2 * (fno + sh->frame_num) - 1);
+        d->prev_frame_num_offset = fno;
+    }
+    d->prev_frame_num = sh->frame_num;
+    return poc;
+}
+
+/* ------------------------------------------------------------------ 8.2.4 reference picture lists (P) */
+static int cmp_picnum_desc(const void *a, const void *b) { return (*(h264o_pic *const *)b)->pic_num - (*(h264o_pic *const *)a)->pic_num; }
+static int cmp_ltidx_asc(const void *a, const void *b) {
+    return (*(h264o_pic *const *)a)->long_term_frame_idx - (*(h264o_pic *const *)b)->long_term_frame_idx;
+}
+static int build_ref_list(h264o_decoder *d) {
+    const h264o_slice_header *sh = &d->sh;
+    int max_fn = 1 << (d->asps->log2_max_frame_num_minus4 + 4);
+    h264o_pic *st[20], *lt[20];
+    int nst = 0, nlt = 0;
+    for (int i = 0; i < d->n_pics; i++) {
+        h264o_pic *p = &d->pics[i];
+        if (p == d->cur) continue;
+        if (p->ref == 1) {
+            p->frame_num_wrap = p->frame_num > sh->frame_num ? p->frame_num - max_fn : p->frame_num;
+            p->pic_num = p->frame_num_wrap;
+            st[nst++] = p;
+        } else if (p->ref == 2) {
+            p->pic_num = p->long_term_frame_idx; /* LongTermPicNum */
+            lt[nlt++] = p;
+        }
+    }
+    qsort(st, nst, sizeof(st[0]), cmp_picnum_desc);
+    qsort(lt, nlt, sizeof(lt[0]), cmp_ltidx_asc);
+    int n = 0, nact = sh->num_ref_idx_l0_active_minus1 + 1;
+    memset(d->rpl0, 0, sizeof(d->rpl0));
+    for (int i = 0; i < nst && n < 32; i++) d->rpl0[n++] = st[i];
+    for (int i = 0; i < nlt && n < 32; i++) d->rpl0[n++] = lt[i];
+    if (n == 0) return h264o_fail(d, "P slice without reference pictures");
+    /* 8.2.4.3 modification */
+    if (sh->ref_pic_list_modification_flag_l0) {
+        int pred = sh->frame_num, idx = 0; /* picNumL0Pred = CurrPicNum */
+        for (int k = 0; k < sh->n_rplm && idx < nact; k++) {
+            h264o_pic *target = NULL;
+            if (sh->rplm_idc[k] < 2) {
+                int diff = sh->rplm_val[k] + 1;
+                if (sh->rplm_idc[k] == 0) {
+                    pred -= diff;
+                    if (pred < 0) pred += max_fn;
+                } else {
+                    pred += diff;
+                    if (pred >= max_fn) pred -= max_fn;
+                }
+                int picnum = pred > sh->frame_num ? pred - max_fn : pred;
+                for (int i = 0; i < nst; i++)
+                    if (st[i]->pic_num == picnum) target = st[i];
+            } else {
+                for (int i = 0; i < nlt; i++)
+                    if (lt[i]->pic_num == sh->rplm_val[k]) target = lt[i];
+            }
+            if (!target) return h264o_fail(d, "ref_pic_list_modification names a missing picture");
+            /* shift up, insert, remove the duplicate further down (8-37/8-38) */
+            for (int c = nact; c > idx; c--) d->rpl0[c] = d->rpl0[c - 1];
+            d->rpl0[idx++] = target;
+            int nidx = idx;
+            for (int c = idx; c <= nact; c++)
+                if (d->rpl0[c] != target) d->rpl0[nidx++] = d->rpl0[c];
+        }
+    }
+    for (int i = nact; i < 33; i++) d->rpl0[i] = NULL;
+    /* entries beyond the initial list that were never filled stay NULL; prediction from them is an error */
+    return 0;
+}
+
+/* ------------------------------------------------------------------ 8.2.5 decoded reference picture marking */
+static void mark_reference(h264o_decoder *d) {
+    const h264o_slice_header *sh = &d->first_sh;
+    h264o_pic *cur = d->cur;
+    int max_fn = 1 << (d->asps->log2_max_frame_num_minus4 + 4);
+    if (!sh->nal_ref_idc) {
+        cur->ref = 0;
+        return;
+    }
+    if (sh->idr_flag) {
+        for (int i = 0; i < d->n_pics; i++)
+            if (&d->pics[i] != cur) d->pics[i].ref = 0;
+        cur->ref = sh->long_term_reference_flag ? 2 : 1;
+        cur->long_term_frame_idx = 0;
+        return;
+    }
+    cur->ref = 1;
+    if (sh->adaptive_ref_pic_marking_mode_flag) {
+        for (int k = 0; k < sh->n_mmco; k++) {
+            int op = sh->mmco_op[k];
+            for (int i = 0; i < d->n_pics; i++) { /* refresh PicNum */
+                h264o_pic *p = &d->pics[i];
+                if (p->ref == 1) p->pic_num = p->frame_num > sh->frame_num ? p->frame_num - max_fn : p->frame_num;
+            }
+            if (op == 1 || op == 3) {
+                int picnum = sh->frame_num - (sh->mmco_arg1[k] + 1);
+                for (int i = 0; i < d->n_pics; i++) {
+                    h264o_pic *p = &d->pics[i];
+                    if (p != cur && p->ref == 1 && p->pic_num == picnum) {
+                        if (op == 1)
+                            p->ref = 0;
+                        else {
+                            for (int j = 0; j < d->n_pics; j++)
+                                if (d->pics[j].ref == 2 && d->pics[j].long_term_frame_idx == sh->mmco_arg2[k]) d->pics[j].ref = 0;
+                            p->ref = 2;
+                            p->long_term_frame_idx = sh->mmco_arg2[k];
+                        }
+                    }
+                }
+            } else if (op == 2) {
+                for (int i = 0; i < d->n_pics; i++)
+                    if (d->pics[i].ref == 2 && d->pics[i].long_term_frame_idx == sh->mmco_arg1[k]) d->pics[i].ref = 0;
+            } else if (op == 4) {
+                for (int i = 0; i < d->n_pics; i++)
+                    if (d->pics[i].ref == 2 && d->pics[i].long_term_frame_idx >= sh->mmco_arg1[k]) d->pics[i].ref = 0;
+            } else if (op == 5) {
+                for (int i = 0; i < d->n_pics; i++)
+                    if (&d->pics[i] != cur) d->pics[i].ref = 0;
+                cur->frame_num = 0;
+                d->prev_frame_num = 0;
+                d->prev_frame_num_offset = 0;
+                d->prev_poc_msb = 0;
+                d->prev_poc_lsb = 0;
+            } else if (op == 6) {
+                for (int j = 0; j < d->n_pics; j++)
+                    if (d->pics[j].ref == 2 && d->pics[j].long_term_frame_idx == sh->mmco_arg2[k]) d->pics[j].ref = 0;
+                cur->ref = 2;
+                cur->long_term_frame_idx = sh->mmco_arg2[k];
+            }
+        }
+    } else {
+        /* 8.2.5.3 sliding window */
+        int nref = 0, maxref = d->asps->max_num_ref_frames > 0 ? d->asps->max_num_ref_frames : 1;
+        h264o_pic *oldest = NULL;
+        for (int i = 0; i < d->n_pics; i++) {
+            h264o_pic *p = &d->pics[i];
+            if (p == cur || !p->ref) continue;
+            nref++;
+            if (p->ref == 1) {
+                int wrap = p->frame_num > sh->frame_num ? p->frame_num - max_fn : p->frame_num;
+                if (!oldest || wrap < oldest->frame_num_wrap) {
+                    p->frame_num_wrap = wrap;
+                    oldest = p;
+                }
+            }
+        }
+        if (nref >= maxref && oldest) oldest->ref = 0;
+    }
+}
+
+/* ------------------------------------------------------------------ picture output */
+static void emit_frame(h264o_decoder *d) {
+    h264o_pic *p = d->cur;
+    const h264o_sps *s = d->asps;
+    int cw = d->info.coded_width, ch = d->info.coded_height;
+    int w = d->crop ? d->info.width : cw, h = d->crop ? d->info.height : ch;
+    int x0 = d->crop ? 2 * s->frame_crop_left_offset : 0, y0 = d->crop ? 2 * s->frame_crop_top_offset : 0;
+    size_t need = (size_t)w * h * 3 / 2;
+    if (d->out && d->out_pos + need <= d->out_cap) {
+        uint8_t *o = d->out + d->out_pos;
+        for (int y = 0; y < h; y++) memcpy(o + (size_t)y * w, p->plane[0] + (size_t)(y + y0) * p->stride[0] + x0, w);
+        o += (size_t)w * h;
+        for (int pl = 1; pl < 3; pl++) {
+            for (int y = 0; y < h / 2; y++) memcpy(o + (size_t)y * (w / 2), p->plane[pl] + (size_t)(y + y0 / 2) * p->stride[pl] + x0 / 2, w / 2);
+            o += (size_t)(w / 2) * (h / 2);
+        }
+    }
+    d->out_pos += need;
+    d->info.n_frames++;
+}
+
+static void finish_picture(h264o_decoder *d) {
+    if (!d->cur) return;
+    /* conceal MBs never covered by a slice (not expected in scope): copy nothing, leave as is */
+    h264o_deblock_picture(d);
+    mark_reference(d);
+    emit_frame(d);
+    d->cur->in_use = 0;
+    d->cur = NULL;
+}
+
+/* 7.4.1.2.4 first VCL NAL of a new primary coded picture */
+static int is_new_picture(const h264o_decoder *d, const h264o_slice_header *a, const h264o_slice_header *b) {
+    if (a->frame_num != b->frame_num || a->pic_parameter_set_id != b->pic_parameter_set_id) return 1;
+    if ((a->nal_ref_idc == 0) != (b->nal_ref_idc == 0)) return 1;
+    if (a->idr_flag != b->idr_flag) return 1;
+    if (a->idr_flag && a->idr_pic_id != b->idr_pic_id) return 1;
+    if (d->asps->pic_order_cnt_type == 0 &&
+        (a->pic_order_cnt_lsb != b->pic_order_cnt_lsb || a->delta_pic_order_cnt_bottom != b->delta_pic_order_cnt_bottom))
+        return 1;
+    if (d->asps->pic_order_cnt_type == 1 &&
+        (a->delta_pic_order_cnt[0] != b->delta_pic_order_cnt[0] || a->delta_pic_order_cnt[1] != b->delta_pic_order_cnt[1]))
+        return 1;
+    return 0;
+}
+
+static int start_picture(h264o_decoder *d) {
+    h264o_pic *p = NULL;
+    for (int i = 0; i < d->n_pics; i++)
+        if (!d->pics[i].ref && !d->pics[i].in_use) {
+            p = &d->pics[i];
+            break;
+        }
+    if (!p) return h264o_fail(d, "DPB full");
+    d->cur = p;
+    p->in_use = 1;
+    p->id = d->next_pic_id++;
+    p->frame_num = d->sh.frame_num;
+    p->poc = compute_poc(d, &d->sh);
+    for (int i = 0; i < d->wmb * d->hmb; i++) d->mb[i].type = MBT_NONE;
+    /* deterministic content for MBs that no slice covers */
+    memset(p->plane[0], 128, (size_t)d->wmb * 16 * d->hmb * 16 * 3 / 2);
+    d->first_sh = d->sh;
+    d->slice_id = 0;
+    return 0;
+}
+
+static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_t *rbsp, size_t rlen) {
+    h264o_br_init(&d->br, rbsp, rlen);
+    h264o_slice_header sh;
+    int r = h264o_parse_slice_header(&d->br, nal->nal_ref_idc, nal->nal_unit_type, d->sps, d->pps, &sh);
+    if (r < 0) return h264o_fail(d, "slice header parse error %d", r);
+    if (sh.field_pic_flag) return h264o_fail(d, "field pictures are out of scope");
+    if (sh.slice_type != 0 && sh.slice_type != 2) return h264o_fail(d, "slice_type %d out of scope (I and P only)", sh.slice_type);
+    if (sh.redundant_pic_cnt > 0) return 0; /* redundant coded pictures are ignored */
+    const h264o_pps *pps = &d->pps[sh.pic_parameter_set_id];
+    if (d->cur && (sh.first_mb_in_slice == 0 || is_new_picture(d, &d->first_sh, &sh))) finish_picture(d);
+    if (activate(d, pps) < 0) return -1;
+    d->sh = sh;
+    if (!d->cur) {
+        if (start_picture(d) < 0) return -1;
+    } else
+        d->slice_id++;
+    if (sh.slice_type == 0 && build_ref_list(d) < 0) return -1;
+    if (sh.first_mb_in_slice >= d->wmb * d->hmb) return h264o_fail(d, "first_mb_in_slice out of range");
+    return h264o_decode_slice_data(d) < 0 ? -1 : 0;
+}
+
+/* h264/server.go:113-166 handleConnection: NAL type dispatch (7 SPS, 8 PPS, 1/5 slices; the rest
+ * ignored).  Parameter sets are looked up by id (the reference keeps only "the last": A33). */
+int h264o_decode_stream(h264o_decoder *d, const uint8_t *buf, size_t len, int crop, uint8_t *out, size_t out_cap, h264o_stream_info *info) {
+    int cap = 1 << 16, n;
+    h264o_nal *nals = (h264o_nal *)malloc(sizeof(h264o_nal) * cap);
+    n = h264o_annexb_scan(buf, len, nals, cap);
+    memset(&d->info, 0, sizeof(d->info));
+    d->err[0] = 0;
+    d->crop = crop;
+    d->out = out;
+    d->out_cap = out_cap;
+    d->out_pos = 0;
+    d->trace_pos = 0;
+    for (int i = 0; i < d->n_pics; i++) d->pics[i].ref = 0, d->pics[i].in_use = 0;
+    d->cur = NULL;
+    for (int i = 0; i < n && !d->info.error; i++) {
+        const h264o_nal *nal = &nals[i];
+        if (nal->size > d->rbsp_cap) {
+            d->rbsp_cap = nal->size * 2;
+            d->rbsp = (uint8_t *)realloc(d->rbsp, d->rbsp_cap);
+        }
+        size_t rlen = h264o_nal_to_rbsp(buf + nal->offset, nal->size, d->rbsp);
+        switch (nal->nal_unit_type) {
+        case 7: {
+            h264o_sps s;
+            if (h264o_parse_sps(d->rbsp, rlen, &s) == 0) {
+                if (d->cur) finish_picture(d);
+                if (memcmp(&d->sps[s.seq_parameter_set_id], &s, sizeof(s)) != 0) { /* repeated identical SPS: keep the DPB */
+                    if (d->asps == &d->sps[s.seq_parameter_set_id]) d->asps = NULL; /* force re-activation */
+                    d->sps[s.seq_parameter_set_id] = s;
+                }
+            } else
+                h264o_fail(d, "SPS parse error");
+            break;
+        }
+        case 8: {
+            h264o_pps p;
+            int r = h264o_parse_pps(d->rbsp, rlen, d->sps, &p);
+            if (r == 0) {
+                if (d->cur) finish_picture(d);
+                d->pps[p.pic_parameter_set_id] = p;
+            } else
+                h264o_fail(d, "PPS parse error %d", r);
+            break;
+        }
+        case 1:
+        case 5: decode_slice_nal(d, nal, d->rbsp, rlen); break;
+        case 9: /* access unit delimiter */
+        case 10:
+        case 11:
+            if (d->cur) finish_picture(d);
+            break;
+        default: break; /* SEI, filler, ... ignored (h264/server.go:147-164) */
+        }
+    }
+    if (d->cur && !d->info.error) finish_picture(d);
+    free(nals);
+    if (info) *info = d->info;
+    if (d->info.error) return -1;
+    if (out && d->out_pos > out_cap) return -2;
+    return 0;
+}

@@ -1,0 +1,961 @@
+/*
+ * oracle/h264o_entropy.c -- slice_data() (7.3.4), macroblock_layer() (7.3.5), mb_pred /
+ * sub_mb_pred (7.3.5.1/2), residual() (7.3.5.3) with CAVLC (9.2) and CABAC (9.3) parsing,
+ * plus the derivations that need neighbour state: Intra4x4/8x8PredMode (8.3.1.1/8.3.2.1) and
+ * motion vector prediction (8.4.1).
+ *
+ * TEST INFRASTRUCTURE ONLY (see h264o.h).
+ *
+ * Reference counterparts: h264/slice.go:570-830 (NewSliceData, the MB loop -- which stops before
+ * residual()), h264/slice.go:252-454 (MbPred), h264/cabac.go:439-553 (arithmetic decoding
+ * engine), h264/cabac.go:148-174 (context init), h264/cabac.go:340-428 (Table 9-34 descriptors),
+ * h264/cabac.go:557-758 (ctxIdx assignment, neighbour-dependent cases empty there).
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "h264o_int.h"
+
+/* ------------------------------------------------------------------ neighbours */
+static h264o_mb *mb_at(h264o_decoder *d, int mbx, int mby) {
+    if (mbx < 0 || mby < 0 || mbx >= d->wmb || mby >= d->hmb) return NULL;
+    h264o_mb *m = &d->mb[mby * d->wmb + mbx];
+    if (m->type == MBT_NONE || m->slice_id != d->slice_id) return NULL;
+    return m;
+}
+#define MB_A(d) mb_at(d, (d)->c.mbx - 1, (d)->c.mby)
+#define MB_B(d) mb_at(d, (d)->c.mbx, (d)->c.mby - 1)
+#define CUR(d) (&(d)->mb[(d)->c.addr])
+
+/* luma 4x4 block neighbour at (bx,by) relative to the current MB (bx,by in -1..3):
+ * returns the owning MB (NULL if unavailable) and the raster block index inside it. */
+static h264o_mb *luma_nb(h264o_decoder *d, int bx, int by, int *ridx) {
+    h264o_mb *m;
+    if (bx < 0) {
+        m = MB_A(d);
+        bx += 4;
+    } else if (by < 0) {
+        m = MB_B(d);
+        by += 4;
+    } else
+        m = CUR(d);
+    *ridx = by * 4 + bx;
+    return m;
+}
+static h264o_mb *chroma_nb(h264o_decoder *d, int cx, int cy, int *ridx) {
+    h264o_mb *m;
+    if (cx < 0) {
+        m = MB_A(d);
+        cx += 2;
+    } else if (cy < 0) {
+        m = MB_B(d);
+        cy += 2;
+    } else
+        m = CUR(d);
+    *ridx = cy * 2 + cx;
+    return m;
+}
+
+/* ------------------------------------------------------------------ CAVLC 9.2 */
+static int cavlc_coeff_token(h264o_decoder *d, int nC, int *total, int *t1s) {
+    h264o_br *b = &d->br;
+    uint32_t w = h264o_peek(b, 16);
+    if (nC == -1) {
+        for (int tc = 0; tc <= 4; tc++)
+            for (int t1 = 0; t1 <= (tc < 3 ? tc : 3); t1++) {
+                int len = h264o_chroma_dc_token_len[4 * tc + t1];
+                if (len && (w >> (16 - len)) == h264o_chroma_dc_token_bits[4 * tc + t1]) {
+                    h264o_skip(b, len);
+                    *total = tc;
+                    *t1s = t1;
+                    return 0;
+                }
+            }
+        return -1;
+    }
+    int tbl = nC < 2 ? 0 : (nC < 4 ? 1 : (nC < 8 ? 2 : 3));
+    for (int tc = 0; tc <= 16; tc++)
+        for (int t1 = 0; t1 <= (tc < 3 ? tc : 3); t1++) {
+            int len = h264o_coeff_token_len[tbl][4 * tc + t1];
+            if (len && (w >> (16 - len)) == h264o_coeff_token_bits[tbl][4 * tc + t1]) {
+                h264o_skip(b, len);
+                *total = tc;
+                *t1s = t1;
+                return 0;
+            }
+        }
+    return -1;
+}
+
+/* 9.2: residual_block_cavlc().  coef[] is filled in scan order [0..maxnum-1]. */
+static int cavlc_residual(h264o_decoder *d, int16_t *coef, int maxnum, int nC) {
+    h264o_br *b = &d->br;
+    int total, t1s;
+    memset(coef, 0, sizeof(int16_t) * maxnum);
+    if (cavlc_coeff_token(d, nC, &total, &t1s) < 0) return h264o_fail(d, "cavlc: bad coeff_token");
+    if (total == 0) return 0;
+    if (total > maxnum) return h264o_fail(d, "cavlc: TotalCoeff %d > %d", total, maxnum);
+    int level[16], run[16];
+    int suffix_len = (total > 10 && t1s < 3) ? 1 : 0;
+    for (int i = 0; i < total; i++) {
+        if (i < t1s) {
+            level[i] = 1 - 2 * (int)h264o_u(b, 1);
+            continue;
+        }
+        int prefix = 0;
+        while (h264o_u(b, 1) == 0) {
+            prefix++;
+            if (prefix > 32 || b->err) return h264o_fail(d, "cavlc: level_prefix overflow");
+        }
+        int code = (prefix < 15 ? prefix : 15) << suffix_len;
+        if (suffix_len > 0 || prefix >= 14) {
+            int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
+            if (size > 0) code += h264o_u(b, size);
+        }
+        if (prefix >= 15 && suffix_len == 0) code += 15;
+        if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+        if (i == t1s && t1s < 3) code += 2;
+        level[i] = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
+        if (suffix_len == 0) suffix_len = 1;
+        if (abs(level[i]) > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+    }
+    int zeros_left = 0;
+    if (total < maxnum) {
+        uint32_t w = h264o_peek(b, 9);
+        int found = -1;
+        if (maxnum == 4) {
+            for (int tz = 0; tz <= 4 - total; tz++) {
+                int len = h264o_chroma_dc_total_zeros_len[total - 1][tz];
+                if (len && (w >> (9 - len)) == h264o_chroma_dc_total_zeros_bits[total - 1][tz]) {
+                    found = tz;
+                    h264o_skip(b, len);
+                    break;
+                }
+            }
+        } else {
+            /* tzVlcIndex = TotalCoeff; for 15-coefficient blocks the same tables apply */
+            for (int tz = 0; tz <= 16 - total; tz++) {
+                int len = h264o_total_zeros_len[total - 1][tz];
+                if (len && (w >> (9 - len)) == h264o_total_zeros_bits[total - 1][tz]) {
+                    found = tz;
+                    h264o_skip(b, len);
+                    break;
+                }
+            }
+        }
+        if (found < 0) return h264o_fail(d, "cavlc: bad total_zeros");
+        zeros_left = found;
+    }
+    for (int i = 0; i < total - 1; i++) {
+        run[i] = 0;
+        if (zeros_left > 0) {
+            int t = (zeros_left > 7 ? 7 : zeros_left) - 1;
+            uint32_t w = h264o_peek(b, 11);
+            int found = -1;
+            for (int r = 0; r <= (t == 6 ? 14 : zeros_left); r++) {
+                int len = h264o_run_len[t][r];
+                if (len && (w >> (11 - len)) == h264o_run_bits[t][r]) {
+                    found = r;
+                    h264o_skip(b, len);
+                    break;
+                }
+            }
+            if (found < 0 || found > zeros_left) return h264o_fail(d, "cavlc: bad run_before");
+            run[i] = found;
+            zeros_left -= found;
+        }
+    }
+    run[total - 1] = zeros_left;
+    int pos = -1;
+    for (int i = total - 1; i >= 0; i--) {
+        pos += run[i] + 1;
+        if (pos >= maxnum) return h264o_fail(d, "cavlc: coefficient position overflow");
+        coef[pos] = (int16_t)level[i];
+    }
+    return total;
+}
+
+/* 9.2.1 nC for a luma block at (bx,by) */
+static int cavlc_nc_luma(h264o_decoder *d, int bx, int by) {
+    int ia, ib;
+    h264o_mb *a = luma_nb(d, bx - 1, by, &ia), *bb = luma_nb(d, bx, by - 1, &ib);
+    if (a && bb) return (a->nnz[ia] + bb->nnz[ib] + 1) >> 1;
+    if (a) return a->nnz[ia];
+    if (bb) return bb->nnz[ib];
+    return 0;
+}
+static int cavlc_nc_chroma(h264o_decoder *d, int c, int cx, int cy) {
+    int ia, ib;
+    h264o_mb *a = chroma_nb(d, cx - 1, cy, &ia), *bb = chroma_nb(d, cx, cy - 1, &ib);
+    if (a && bb) return (a->nnz[16 + 4 * c + ia] + bb->nnz[16 + 4 * c + ib] + 1) >> 1;
+    if (a) return a->nnz[16 + 4 * c + ia];
+    if (bb) return bb->nnz[16 + 4 * c + ib];
+    return 0;
+}
+
+/* ------------------------------------------------------------------ CABAC engine 9.3.1.2 / 9.3.3.2 */
+/* h264/cabac.go:439-446 initDecodingEngine */
+void h264o_cabac_init_engine(h264o_decoder *d) {
+    d->cod_range = 510;
+    d->cod_offset = h264o_u(&d->br, 9);
+}
+
+/* 9.3.1.1, (9-5): h264/cabac.go:118-121 PreCtxState, :158-164 state split.  The table set is
+ * chosen by slice type / cabac_init_idc (the reference always uses idc 0: Appendix A7). */
+static void cabac_init_contexts(h264o_decoder *d) {
+    int set = (d->sh.slice_type == 2 || d->sh.slice_type == 4) ? 0 : 1 + d->sh.cabac_init_idc;
+    int qp = h264o_clip3(0, 51, d->sh.slice_qp_y);
+    for (int i = 0; i < H264O_NCTX; i++) {
+        int m = h264o_cabac_mn[set][i][0], n = h264o_cabac_mn[set][i][1];
+        int pre = h264o_clip3(1, 126, ((m * qp) >> 4) + n);
+        if (pre <= 63)
+            d->ctx[i] = (uint8_t)((63 - pre) << 1);
+        else
+            d->ctx[i] = (uint8_t)(((pre - 64) << 1) | 1);
+    }
+}
+
+/* 9.3.3.2.1 DecodeDecision + 9.3.3.2.1.1 state transition + 9.3.3.2.2 RenormD.
+ * h264/cabac.go:521-540 (BinaryDecision: no transition, no renorm -- Appendix A10),
+ * :544-553 (StateTransitionProcess), :503-511 (RenormD). */
+int h264o_cabac_decision(h264o_decoder *d, int ctx_idx) {
+    uint8_t s = d->ctx[ctx_idx];
+    int p = s >> 1, mps = s & 1, bin;
+    uint32_t rlps = h264o_range_lps[p][(d->cod_range >> 6) & 3];
+    d->cod_range -= rlps;
+    if (d->cod_offset >= d->cod_range) {
+        bin = !mps;
+        d->cod_offset -= d->cod_range;
+        d->cod_range = rlps;
+        if (p == 0) mps = !mps;
+        p = h264o_trans_lps[p];
+    } else {
+        bin = mps;
+        if (p < 62) p++;
+    }
+    d->ctx[ctx_idx] = (uint8_t)((p << 1) | mps);
+    while (d->cod_range < 256) {
+        d->cod_range <<= 1;
+        d->cod_offset = (d->cod_offset << 1) | h264o_u(&d->br, 1);
+    }
+    d->info.n_bins++;
+    return bin;
+}
+/* 9.3.3.2.3 DecodeBypass.  h264/cabac.go:468-481 (shifts by the bit instead of OR-ing it in:
+ * Appendix A9). */
+static int cabac_bypass(h264o_decoder *d) {
+    d->cod_offset = (d->cod_offset << 1) | h264o_u(&d->br, 1);
+    d->info.n_bins++;
+    if (d->cod_offset >= d->cod_range) {
+        d->cod_offset -= d->cod_range;
+        return 1;
+    }
+    return 0;
+}
+/* 9.3.3.2.4 DecodeTerminate.  h264/cabac.go:486-499. */
+static int cabac_terminate(h264o_decoder *d) {
+    d->cod_range -= 2;
+    d->info.n_bins++;
+    if (d->cod_offset >= d->cod_range) return 1;
+    while (d->cod_range < 256) {
+        d->cod_range <<= 1;
+        d->cod_offset = (d->cod_offset << 1) | h264o_u(&d->br, 1);
+    }
+    return 0;
+}
+
+int h264o_kat_cabac_bins(const uint8_t *bytes, size_t n, int pstate, int mps, int count, uint8_t *bins) {
+    h264o_decoder *d = (h264o_decoder *)calloc(1, sizeof(*d));
+    h264o_br_init(&d->br, bytes, n);
+    h264o_cabac_init_engine(d);
+    d->ctx[0] = (uint8_t)((pstate << 1) | mps);
+    for (int i = 0; i < count; i++) bins[i] = (uint8_t)h264o_cabac_decision(d, 0);
+    int st = d->ctx[0];
+    free(d);
+    return st;
+}
+
+/* ------------------------------------------------------------------ CABAC syntax elements 9.3.2 / 9.3.3.1 */
+static int cabac_mb_skip_flag(h264o_decoder *d) {
+    h264o_mb *a = MB_A(d), *b = MB_B(d);
+    int inc = (a && a->type != MBT_PSKIP) + (b && b->type != MBT_PSKIP);
+    return h264o_cabac_decision(d, 11 + inc);
+}
+
+/* Table 9-36 I-slice mb_type bin string; `base` = 3 for I slices (bin 0 neighbour-dependent),
+ * 17 for the intra suffix in P slices.  h264/cabac.go:181-277 (binIdxMbMap). */
+static int cabac_intra_mb_type(h264o_decoder *d, int base, int islice) {
+    if (islice) {
+        h264o_mb *a = MB_A(d), *b = MB_B(d);
+        int inc = (a && a->type != MBT_I4x4 && a->type != MBT_I8x8) + (b && b->type != MBT_I4x4 && b->type != MBT_I8x8);
+        if (!h264o_cabac_decision(d, base + inc)) return 0;
+        base += 2;
+    } else if (!h264o_cabac_decision(d, base))
+        return 0;
+    if (cabac_terminate(d)) return 25;
+    int t = 1;
+    t += 12 * h264o_cabac_decision(d, base + 1);
+    if (h264o_cabac_decision(d, base + 2)) t += 4 + 4 * h264o_cabac_decision(d, base + 2 + islice);
+    t += 2 * h264o_cabac_decision(d, base + 3 + islice);
+    t += h264o_cabac_decision(d, base + 3 + 2 * islice);
+    return t;
+}
+/* Table 9-37 P mb_type; returns raw mb_type (0..4 inter, 5.. intra) */
+static int cabac_p_mb_type(h264o_decoder *d) {
+    if (!h264o_cabac_decision(d, 14)) {
+        if (!h264o_cabac_decision(d, 15)) return 3 * h264o_cabac_decision(d, 16);
+        return 2 - h264o_cabac_decision(d, 17);
+    }
+    return 5 + cabac_intra_mb_type(d, 17, 0);
+}
+static int cabac_p_sub_mb_type(h264o_decoder *d) {
+    if (h264o_cabac_decision(d, 21)) return 0;
+    if (!h264o_cabac_decision(d, 22)) return 1;
+    if (h264o_cabac_decision(d, 23)) return 2;
+    return 3;
+}
+static int cabac_transform8x8(h264o_decoder *d) {
+    h264o_mb *a = MB_A(d), *b = MB_B(d);
+    return h264o_cabac_decision(d, 399 + (a && a->t8x8) + (b && b->t8x8));
+}
+static int cabac_intra_chroma_mode(h264o_decoder *d) {
+    h264o_mb *a = MB_A(d), *b = MB_B(d);
+    int inc = (a && MB_IS_INTRA(a->type) && a->type != MBT_IPCM && a->chroma_mode != 0) +
+              (b && MB_IS_INTRA(b->type) && b->type != MBT_IPCM && b->chroma_mode != 0);
+    if (!h264o_cabac_decision(d, 64 + inc)) return 0;
+    if (!h264o_cabac_decision(d, 64 + 3)) return 1;
+    if (!h264o_cabac_decision(d, 64 + 3)) return 2;
+    return 3;
+}
+static int cabac_cbp(h264o_decoder *d) {
+    h264o_mb *a = MB_A(d), *b = MB_B(d);
+    /* cbp of neighbours as seen by 9.3.3.1.1.4: unavailable / I_PCM behave as "all set";
+     * P_Skip as 0 */
+    int cbp_a = a ? (a->type == MBT_IPCM ? 0x2F : (a->cbp_luma | (a->cbp_chroma << 4))) : 0x0F;
+    int cbp_b = b ? (b->type == MBT_IPCM ? 0x2F : (b->cbp_luma | (b->cbp_chroma << 4))) : 0x0F;
+    int cbp = 0;
+    for (int b8 = 0; b8 < 4; b8++) {
+        int ca, cb; /* bit of the neighbouring 8x8 block: 1 -> condTermFlag 0 */
+        if (b8 & 1)
+            ca = (cbp >> (b8 - 1)) & 1;
+        else
+            ca = (cbp_a >> (b8 + 1)) & 1;
+        if (b8 & 2)
+            cb = (cbp >> (b8 - 2)) & 1;
+        else
+            cb = (cbp_b >> (b8 + 2)) & 1;
+        int inc = (!ca) + 2 * (!cb);
+        cbp |= h264o_cabac_decision(d, 73 + inc) << b8;
+    }
+    /* chroma: condTermFlagN = N available && (I_PCM || cbp_chroma != 0) */
+    int ca = a && (a->type == MBT_IPCM || a->cbp_chroma != 0), cb = b && (b->type == MBT_IPCM || b->cbp_chroma != 0);
+    if (h264o_cabac_decision(d, 77 + ca + 2 * cb)) {
+        ca = a && (a->type == MBT_IPCM || a->cbp_chroma == 2);
+        cb = b && (b->type == MBT_IPCM || b->cbp_chroma == 2);
+        cbp |= (1 + h264o_cabac_decision(d, 77 + 4 + ca + 2 * cb)) << 4;
+    }
+    return cbp;
+}
+static int cabac_mb_qp_delta(h264o_decoder *d) {
+    int ctx = d->prev_dqp_nz ? 1 : 0, val = 0;
+    while (h264o_cabac_decision(d, 60 + ctx)) {
+        ctx = 2 + (ctx >> 1);
+        val++;
+        if (val > 104) return 0; /* bitstream error guard */
+    }
+    return (val & 1) ? (val + 1) >> 1 : -((val + 1) >> 1);
+}
+static int cabac_ref_idx(h264o_decoder *d, int bx, int by) {
+    /* 9.3.3.1.1.6: A/B partition refIdx > 0 */
+    int ia, ib;
+    h264o_mb *a = luma_nb(d, bx - 1, by, &ia), *b = luma_nb(d, bx, by - 1, &ib);
+    int ra = a ? a->ref[(ia >> 3) * 2 + ((ia & 3) >> 1)] : 0;
+    int rb = b ? b->ref[(ib >> 3) * 2 + ((ib & 3) >> 1)] : 0;
+    int ctx = (ra > 0) + 2 * (rb > 0), ref = 0;
+    while (h264o_cabac_decision(d, 54 + ctx)) {
+        ref++;
+        ctx = (ctx >> 2) + 4;
+        if (ref > 32) return 0;
+    }
+    return ref;
+}
+/* 9.3.2.3 UEG3, signedValFlag=1, uCoff=9; ctxIdxInc per 9.3.3.1.1.7 */
+static int cabac_mvd(h264o_decoder *d, int comp, int bx, int by) {
+    int ia, ib;
+    h264o_mb *a = luma_nb(d, bx - 1, by, &ia), *b = luma_nb(d, bx, by - 1, &ib);
+    int sum = (a ? a->mvd[ia][comp] : 0) + (b ? b->mvd[ib][comp] : 0);
+    int base = comp ? 47 : 40;
+    if (!h264o_cabac_decision(d, base + (sum > 2) + (sum > 32))) return 0;
+    int v = 1, ctx = base + 3;
+    while (v < 9 && h264o_cabac_decision(d, ctx)) {
+        if (v < 4) ctx++;
+        v++;
+    }
+    if (v >= 9) {
+        int k = 3;
+        while (cabac_bypass(d)) {
+            v += 1 << k;
+            k++;
+            if (k > 24) return 0;
+        }
+        while (k--) v += cabac_bypass(d) << k;
+    }
+    return cabac_bypass(d) ? -v : v;
+}
+
+static const int sig_off[5] = {0, 15, 29, 44, 47};
+static const int abs_off[5] = {0, 10, 20, 30, 39};
+
+/* 7.3.5.3.3 residual_block_cabac(); cbf_inc < 0: coded_block_flag not parsed (inferred 1). */
+static int cabac_residual(h264o_decoder *d, int16_t *coef, int cat, int maxnum, int cbf_inc) {
+    memset(coef, 0, sizeof(int16_t) * maxnum);
+    if (cbf_inc >= 0 && !h264o_cabac_decision(d, 85 + cat * 4 + cbf_inc)) return 0;
+    int pos[64], n = 0, last = 0;
+    for (int i = 0; i < maxnum - 1; i++) {
+        int sctx, lctx;
+        if (cat == 5) {
+            sctx = 402 + h264o_sig8x8_ctx[i];
+            lctx = 417 + h264o_last8x8_ctx[i];
+        } else {
+            int inc = cat == 3 ? (i < 2 ? i : 2) : i;
+            sctx = 105 + sig_off[cat] + inc;
+            lctx = 166 + sig_off[cat] + inc;
+        }
+        if (h264o_cabac_decision(d, sctx)) {
+            pos[n++] = i;
+            if (h264o_cabac_decision(d, lctx)) {
+                last = 1;
+                break;
+            }
+        }
+    }
+    if (!last) pos[n++] = maxnum - 1;
+    int eq1 = 0, gt1 = 0;
+    int base = cat == 5 ? 426 : 227 + abs_off[cat];
+    for (int k = n - 1; k >= 0; k--) {
+        int inc0 = gt1 ? 0 : (1 + eq1 < 4 ? 1 + eq1 : 4);
+        int a;
+        if (!h264o_cabac_decision(d, base + inc0)) {
+            a = 1;
+            eq1++;
+        } else {
+            int lim = 4 - (cat == 3);
+            int inc = 5 + (gt1 < lim ? gt1 : lim);
+            a = 2;
+            while (a < 15 && h264o_cabac_decision(d, base + inc)) a++;
+            if (a >= 15) {
+                int kk = 0;
+                while (cabac_bypass(d)) {
+                    a += 1 << kk;
+                    kk++;
+                    if (kk > 24) return h264o_fail(d, "cabac: abs level escape overflow");
+                }
+                while (kk--) a += cabac_bypass(d) << kk;
+            }
+            gt1++;
+        }
+        coef[pos[k]] = (int16_t)(cabac_bypass(d) ? -a : a);
+    }
+    return n;
+}
+
+/* coded_block_flag ctxIdxInc (9.3.3.1.1.9) */
+static int cbf_inc_from(h264o_decoder *d, h264o_mb *a, int fa, h264o_mb *b, int fb) {
+    int cur_intra = MB_IS_INTRA(d->c.type);
+    int ca = a ? fa : cur_intra, cb = b ? fb : cur_intra;
+    return ca + 2 * cb;
+}
+static int cbf_inc_luma(h264o_decoder *d, int bx, int by) {
+    int ia, ib;
+    h264o_mb *a = luma_nb(d, bx - 1, by, &ia), *b = luma_nb(d, bx, by - 1, &ib);
+    return cbf_inc_from(d, a, a ? a->nnz[ia] != 0 : 0, b, b ? b->nnz[ib] != 0 : 0);
+}
+static int cbf_inc_chroma_ac(h264o_decoder *d, int c, int cx, int cy) {
+    int ia, ib;
+    h264o_mb *a = chroma_nb(d, cx - 1, cy, &ia), *b = chroma_nb(d, cx, cy - 1, &ib);
+    return cbf_inc_from(d, a, a ? a->nnz[16 + 4 * c + ia] != 0 : 0, b, b ? b->nnz[16 + 4 * c + ib] != 0 : 0);
+}
+static int cbf_inc_dc(h264o_decoder *d, int bit) {
+    h264o_mb *a = MB_A(d), *b = MB_B(d);
+    return cbf_inc_from(d, a, a ? (a->cbf_dc >> bit) & 1 : 0, b, b ? (b->cbf_dc >> bit) & 1 : 0);
+}
+
+/* ------------------------------------------------------------------ residual() 7.3.5.3 */
+static int parse_residual(h264o_decoder *d) {
+    h264o_curmb *c = &d->c;
+    h264o_mb *m = CUR(d);
+    int cabac = d->apps->entropy_coding_mode_flag;
+    int i16 = c->type == MBT_I16x16;
+    if (i16) {
+        int n;
+        if (cabac)
+            n = cabac_residual(d, c->i16dc, 0, 16, cbf_inc_dc(d, 0));
+        else
+            n = cavlc_residual(d, c->i16dc, 16, cavlc_nc_luma(d, 0, 0));
+        if (n < 0) return n;
+        if (n > 0) m->cbf_dc |= 1;
+    }
+    for (int b8 = 0; b8 < 4; b8++) {
+        if (!(c->cbp_luma & (1 << b8))) continue;
+        if (c->t8x8 && cabac) {
+            int n = cabac_residual(d, c->luma8[b8], 5, 64, -1);
+            if (n < 0) return n;
+            int bx = (b8 & 1) * 2, by = (b8 >> 1) * 2;
+            m->nnz[by * 4 + bx] = m->nnz[by * 4 + bx + 1] = m->nnz[by * 4 + 4 + bx] = m->nnz[by * 4 + 5 + bx] = (uint8_t)n;
+            if (n) m->nzmask |= (uint16_t)(0x33 << (by * 4 + bx));
+            continue;
+        }
+        int any = 0;
+        for (int b4 = 0; b4 < 4; b4++) {
+            int idx = b8 * 4 + b4, r = h264o_blk_raster(idx), bx = r & 3, by = r >> 2, n;
+            if (i16) {
+                c->luma[idx][0] = 0;
+                if (cabac)
+                    n = cabac_residual(d, c->luma[idx] + 1, 1, 15, cbf_inc_luma(d, bx, by));
+                else
+                    n = cavlc_residual(d, c->luma[idx] + 1, 15, cavlc_nc_luma(d, bx, by));
+            } else if (cabac)
+                n = cabac_residual(d, c->luma[idx], 2, 16, cbf_inc_luma(d, bx, by));
+            else
+                n = cavlc_residual(d, c->luma[idx], 16, cavlc_nc_luma(d, bx, by));
+            if (n < 0) return n;
+            m->nnz[r] = (uint8_t)n;
+            if (n) {
+                m->nzmask |= (uint16_t)(1 << r);
+                any = 1;
+            }
+            if (c->t8x8) /* CAVLC 8x8: the four 4x4 reads interleave into one 8x8 block (7.3.5.3.2) */
+                for (int i = 0; i < 16; i++) c->luma8[b8][4 * i + b4] = c->luma[idx][i];
+        }
+        if (c->t8x8 && any) {
+            int bx = (b8 & 1) * 2, by = (b8 >> 1) * 2;
+            m->nzmask |= (uint16_t)(0x33 << (by * 4 + bx));
+        }
+    }
+    if (c->cbp_chroma) {
+        for (int cc = 0; cc < 2; cc++) {
+            int n;
+            if (cabac)
+                n = cabac_residual(d, c->cdc[cc], 3, 4, cbf_inc_dc(d, 1 + cc));
+            else
+                n = cavlc_residual(d, c->cdc[cc], 4, -1);
+            if (n < 0) return n;
+            if (n > 0) m->cbf_dc |= (uint8_t)(2 << cc);
+        }
+    }
+    if (c->cbp_chroma & 2) {
+        for (int cc = 0; cc < 2; cc++)
+            for (int b4 = 0; b4 < 4; b4++) {
+                int cx = b4 & 1, cy = b4 >> 1, n;
+                c->cac[cc][b4][0] = 0;
+                if (cabac)
+                    n = cabac_residual(d, c->cac[cc][b4] + 1, 4, 15, cbf_inc_chroma_ac(d, cc, cx, cy));
+                else
+                    n = cavlc_residual(d, c->cac[cc][b4] + 1, 15, cavlc_nc_chroma(d, cc, cx, cy));
+                if (n < 0) return n;
+                m->nnz[16 + 4 * cc + b4] = (uint8_t)n;
+            }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ intra pred mode derivation 8.3.1.1 / 8.3.2.1 */
+static int pred_intra_mode(h264o_decoder *d, int bx, int by) {
+    int ia, ib;
+    h264o_mb *a = luma_nb(d, bx - 1, by, &ia), *b = luma_nb(d, bx, by - 1, &ib);
+    int cip = d->apps->constrained_intra_pred_flag;
+    if (!a || !b || (cip && (MB_IS_INTER(a->type) || MB_IS_INTER(b->type)))) return 2; /* dcPredModePredictedFlag */
+    int ma = (a->type == MBT_I4x4 || a->type == MBT_I8x8) ? a->ipm[ia] : 2;
+    int mb = (b->type == MBT_I4x4 || b->type == MBT_I8x8) ? b->ipm[ib] : 2;
+    return ma < mb ? ma : mb;
+}
+
+/* ------------------------------------------------------------------ motion vector prediction 8.4.1.3 */
+typedef struct {
+    int avail; /* partition available (8.4.1.3.2) */
+    int ref;   /* -1: intra / not available */
+    int mv[2];
+} nbmv;
+
+static void get_nbmv(h264o_decoder *d, int bx, int by, nbmv *o) {
+    h264o_curmb *c = &d->c;
+    h264o_mb *m = NULL;
+    o->avail = 0;
+    o->ref = -1;
+    o->mv[0] = o->mv[1] = 0;
+    if (by >= 0 && bx >= 4) return; /* right MB: never available */
+    if (bx >= 0 && bx < 4 && by >= 0) {
+        if (!((d->cur_done >> (by * 4 + bx)) & 1)) return;
+        m = CUR(d);
+    } else {
+        int mx = c->mbx + (bx < 0 ? -1 : (bx >= 4 ? 1 : 0)), my = c->mby + (by < 0 ? -1 : 0);
+        m = mb_at(d, mx, my);
+        if (!m) return;
+        bx &= 3;
+        by &= 3;
+    }
+    o->avail = 1;
+    if (MB_IS_INTRA(m->type)) return;
+    o->ref = m->ref[(by >> 1) * 2 + (bx >> 1)];
+    o->mv[0] = m->mv[by * 4 + bx][0];
+    o->mv[1] = m->mv[by * 4 + bx][1];
+}
+static int median3(int a, int b, int c) {
+    int mn = a < b ? a : b, mx = a < b ? b : a;
+    return c < mn ? mn : (c > mx ? mx : c);
+}
+/* shape: 0 = median only, 1 = 16x8 top, 2 = 16x8 bottom, 3 = 8x16 left, 4 = 8x16 right */
+static void predict_mv(h264o_decoder *d, int bx, int by, int w, int ref, int shape, int mvp[2]) {
+    nbmv A, B, C;
+    get_nbmv(d, bx - 1, by, &A);
+    get_nbmv(d, bx, by - 1, &B);
+    get_nbmv(d, bx + w, by - 1, &C);
+    if (!C.avail) get_nbmv(d, bx - 1, by - 1, &C);
+    if ((shape == 1 && B.ref == ref) || (shape == 4 && C.ref == ref)) {
+        const nbmv *s = shape == 1 ? &B : &C;
+        mvp[0] = s->mv[0];
+        mvp[1] = s->mv[1];
+        return;
+    }
+    if ((shape == 2 || shape == 3) && A.ref == ref) {
+        mvp[0] = A.mv[0];
+        mvp[1] = A.mv[1];
+        return;
+    }
+    if (!B.avail && !C.avail && A.avail) {
+        B = A;
+        C = A;
+    }
+    int na = A.ref == ref, nb = B.ref == ref, nc = C.ref == ref;
+    if (na + nb + nc == 1) {
+        const nbmv *s = na ? &A : (nb ? &B : &C);
+        mvp[0] = s->mv[0];
+        mvp[1] = s->mv[1];
+        return;
+    }
+    mvp[0] = median3(A.mv[0], B.mv[0], C.mv[0]);
+    mvp[1] = median3(A.mv[1], B.mv[1], C.mv[1]);
+}
+static void set_part(h264o_decoder *d, int bx, int by, int w, int h, const int mv[2], const int mvd[2]) {
+    h264o_mb *m = CUR(d);
+    for (int y = by; y < by + h; y++)
+        for (int x = bx; x < bx + w; x++) {
+            m->mv[y * 4 + x][0] = (int16_t)mv[0];
+            m->mv[y * 4 + x][1] = (int16_t)mv[1];
+            m->mvd[y * 4 + x][0] = (int16_t)abs(mvd[0]);
+            m->mvd[y * 4 + x][1] = (int16_t)abs(mvd[1]);
+            d->cur_done |= (uint16_t)(1 << (y * 4 + x));
+        }
+}
+static void read_mvd(h264o_decoder *d, int bx, int by, int mvd[2]) {
+    if (d->apps->entropy_coding_mode_flag) {
+        mvd[0] = cabac_mvd(d, 0, bx, by);
+        mvd[1] = cabac_mvd(d, 1, bx, by);
+    } else {
+        mvd[0] = h264o_se(&d->br);
+        mvd[1] = h264o_se(&d->br);
+    }
+}
+static void do_part(h264o_decoder *d, int bx, int by, int w, int h, int shape) {
+    h264o_mb *m = CUR(d);
+    int mvd[2], mvp[2], mv[2];
+    read_mvd(d, bx, by, mvd);
+    predict_mv(d, bx, by, w, m->ref[(by >> 1) * 2 + (bx >> 1)], shape, mvp);
+    mv[0] = mvp[0] + mvd[0];
+    mv[1] = mvp[1] + mvd[1];
+    set_part(d, bx, by, w, h, mv, mvd);
+}
+static int read_ref_idx(h264o_decoder *d, int bx, int by) {
+    int nref = d->sh.num_ref_idx_l0_active_minus1;
+    if (nref == 0) return 0;
+    if (d->apps->entropy_coding_mode_flag) return cabac_ref_idx(d, bx, by);
+    return (int)h264o_te(&d->br, nref);
+}
+static void set_refids(h264o_decoder *d, h264o_mb *m) {
+    for (int i = 0; i < 4; i++) {
+        h264o_pic *p = (m->ref[i] >= 0 && m->ref[i] <= 32) ? d->rpl0[m->ref[i]] : NULL;
+        m->refid[i] = p ? p->id : -1;
+    }
+}
+
+/* 8.4.1.1 P_Skip motion */
+static void pskip_motion(h264o_decoder *d) {
+    h264o_mb *m = CUR(d);
+    nbmv A, B;
+    int mv[2] = {0, 0}, zero[2] = {0, 0};
+    memset(m->ref, 0, sizeof(m->ref));
+    get_nbmv(d, -1, 0, &A);
+    get_nbmv(d, 0, -1, &B);
+    if (A.avail && B.avail && !(A.ref == 0 && A.mv[0] == 0 && A.mv[1] == 0) && !(B.ref == 0 && B.mv[0] == 0 && B.mv[1] == 0))
+        predict_mv(d, 0, 0, 4, 0, 0, mv);
+    set_part(d, 0, 0, 4, 4, mv, zero);
+    set_refids(d, m);
+}
+
+/* ------------------------------------------------------------------ macroblock_layer() 7.3.5 */
+static void trace_mb(h264o_decoder *d, h264o_mb *m) {
+    if (!d->trace || d->trace_pos >= d->trace_cap) return;
+    int32_t *t = d->trace + 8 * d->trace_pos++;
+    t[0] = d->c.mb_type_raw;
+    t[1] = m->cbp_luma | (m->cbp_chroma << 4);
+    t[2] = m->qp;
+    t[3] = d->c.type == MBT_I16x16 ? d->c.i16mode : m->chroma_mode;
+    t[4] = m->t8x8;
+    t[5] = m->mv[0][0];
+    t[6] = m->mv[0][1];
+    t[7] = m->ref[0];
+}
+
+static void begin_mb(h264o_decoder *d, int addr) {
+    h264o_curmb *c = &d->c;
+    h264o_mb *m = &d->mb[addr];
+    memset(c, 0, sizeof(*c));
+    c->addr = addr;
+    c->mbx = addr % d->wmb;
+    c->mby = addr / d->wmb;
+    memset(m, 0, sizeof(*m));
+    m->slice_id = (uint16_t)d->slice_id;
+    memset(m->ipm, -1, sizeof(m->ipm));
+    memset(m->ref, -1, sizeof(m->ref));
+    m->refid[0] = m->refid[1] = m->refid[2] = m->refid[3] = -1;
+    m->alpha_off = (int8_t)(d->sh.slice_alpha_c0_offset_div2 * 2);
+    m->beta_off = (int8_t)(d->sh.slice_beta_offset_div2 * 2);
+    m->dbf_idc = (uint8_t)d->sh.disable_deblocking_filter_idc;
+    d->cur_done = 0;
+}
+static void finish_mb(h264o_decoder *d) {
+    h264o_mb *m = CUR(d);
+    m->type = (uint8_t)d->c.type;
+    m->qp = (uint8_t)d->qp;
+    for (int cc = 0; cc < 2; cc++) {
+        int off = cc ? d->apps->second_chroma_qp_index_offset : d->apps->chroma_qp_index_offset;
+        m->qpc[cc] = (uint8_t)h264o_qpc(h264o_clip3(0, 51, d->qp + off));
+    }
+    if (m->type == MBT_IPCM) m->qp = 0, m->qpc[0] = m->qpc[1] = (uint8_t)h264o_qpc(h264o_clip3(0, 51, d->apps->chroma_qp_index_offset));
+    if (m->type == MBT_IPCM) m->qpc[1] = (uint8_t)h264o_qpc(h264o_clip3(0, 51, d->apps->second_chroma_qp_index_offset));
+    h264o_recon_mb(d, m);
+    trace_mb(d, m);
+    d->info.n_mbs++;
+}
+
+static int decode_pskip(h264o_decoder *d, int addr) {
+    begin_mb(d, addr);
+    d->c.type = MBT_PSKIP;
+    d->c.mb_type_raw = -1;
+    CUR(d)->type = MBT_PSKIP; /* so that set_part/refs see an inter MB */
+    pskip_motion(d);
+    d->prev_dqp_nz = 0;
+    finish_mb(d);
+    return 0;
+}
+
+static int decode_mb(h264o_decoder *d, int addr) {
+    h264o_curmb *c;
+    h264o_mb *m;
+    h264o_br *b = &d->br;
+    int cabac = d->apps->entropy_coding_mode_flag;
+    int islice = d->sh.slice_type == 2;
+    begin_mb(d, addr);
+    c = &d->c;
+    m = CUR(d);
+    int raw = cabac ? (islice ? cabac_intra_mb_type(d, 3, 1) : cabac_p_mb_type(d)) : (int)h264o_ue(b);
+    c->mb_type_raw = raw;
+    int it = islice ? raw : raw - 5; /* intra mb_type (Table 7-11) when >= 0 */
+    if (!islice && raw < 5) {
+        static const int pt[5] = {MBT_P16x16, MBT_P16x8, MBT_P8x16, MBT_P8x8, MBT_P8x8};
+        c->type = pt[raw];
+    } else if (it == 0)
+        c->type = MBT_I4x4;
+    else if (it >= 1 && it <= 24) {
+        c->type = MBT_I16x16;
+        c->i16mode = (it - 1) & 3;
+        c->cbp_chroma = ((it - 1) >> 2) % 3;
+        c->cbp_luma = it >= 13 ? 15 : 0;
+    } else if (it == 25)
+        c->type = MBT_IPCM;
+    else
+        return h264o_fail(d, "mb %d: bad mb_type %d", addr, raw);
+    m->type = (uint8_t)c->type; /* provisional: neighbour helpers look at CUR() */
+
+    if (c->type == MBT_IPCM) {
+        /* After the terminate bin (binVal 1) the engine has consumed every bit the encoder's
+         * flush wrote, including its final '1' (9.3.4.5): 9 + #renorm-shifts bits were read for
+         * (#shifts - 1) + 7 + 1 + 2 written.  pcm_alignment_zero_bit(s) follow directly. */
+        while (b->pos & 7) h264o_u(b, 1);
+        for (int i = 0; i < 384; i++) c->pcm[i] = (uint8_t)h264o_u(b, 8);
+        if (cabac) h264o_cabac_init_engine(d);
+        memset(m->nnz, 16, sizeof(m->nnz));
+        m->nzmask = 0xFFFF;
+        m->cbf_dc = 7;
+        m->cbp_luma = 15;
+        m->cbp_chroma = 2;
+        d->prev_dqp_nz = 0;
+        finish_mb(d); /* QP_Y carries over unchanged (mb_qp_delta inferred 0); deblocking uses qP 0 */
+        return b->err ? h264o_fail(d, "mb %d: pcm overrun", addr) : 0;
+    }
+
+    if (c->type == MBT_P8x8) {
+        for (int i = 0; i < 4; i++) {
+            c->sub_type[i] = cabac ? cabac_p_sub_mb_type(d) : (int)h264o_ue(b);
+            if (c->sub_type[i] > 3) return h264o_fail(d, "mb %d: bad sub_mb_type", addr);
+        }
+        for (int i = 0; i < 4; i++) m->ref[i] = (raw == 4) ? 0 : (int8_t)read_ref_idx(d, (i & 1) * 2, (i >> 1) * 2);
+        for (int i = 0; i < 4; i++) {
+            int bx = (i & 1) * 2, by = (i >> 1) * 2;
+            switch (c->sub_type[i]) {
+            case 0: do_part(d, bx, by, 2, 2, 0); break;
+            case 1: do_part(d, bx, by, 2, 1, 0); do_part(d, bx, by + 1, 2, 1, 0); break;
+            case 2: do_part(d, bx, by, 1, 2, 0); do_part(d, bx + 1, by, 1, 2, 0); break;
+            default:
+                do_part(d, bx, by, 1, 1, 0);
+                do_part(d, bx + 1, by, 1, 1, 0);
+                do_part(d, bx, by + 1, 1, 1, 0);
+                do_part(d, bx + 1, by + 1, 1, 1, 0);
+            }
+        }
+    } else if (MB_IS_INTER(c->type)) {
+        if (c->type == MBT_P16x16) {
+            int r = read_ref_idx(d, 0, 0);
+            m->ref[0] = m->ref[1] = m->ref[2] = m->ref[3] = (int8_t)r;
+            do_part(d, 0, 0, 4, 4, 0);
+        } else if (c->type == MBT_P16x8) {
+            int r0 = read_ref_idx(d, 0, 0);
+            m->ref[0] = m->ref[1] = (int8_t)r0;
+            int r1 = read_ref_idx(d, 0, 2);
+            m->ref[2] = m->ref[3] = (int8_t)r1;
+            do_part(d, 0, 0, 4, 2, 1);
+            do_part(d, 0, 2, 4, 2, 2);
+        } else {
+            int r0 = read_ref_idx(d, 0, 0);
+            m->ref[0] = m->ref[2] = (int8_t)r0;
+            int r1 = read_ref_idx(d, 2, 0);
+            m->ref[1] = m->ref[3] = (int8_t)r1;
+            do_part(d, 0, 0, 2, 4, 3);
+            do_part(d, 2, 0, 2, 4, 4);
+        }
+    } else {
+        /* intra: transform_size_8x8_flag, pred modes, chroma mode (7.3.5, 7.3.5.1) */
+        if (c->type == MBT_I4x4 && d->apps->transform_8x8_mode_flag) {
+            c->t8x8 = cabac ? cabac_transform8x8(d) : (int)h264o_u(b, 1);
+            if (c->t8x8) c->type = MBT_I8x8, m->type = MBT_I8x8;
+            m->t8x8 = (uint8_t)c->t8x8;
+        }
+        if (c->type == MBT_I4x4 || c->type == MBT_I8x8) {
+            int n = c->type == MBT_I8x8 ? 4 : 16;
+            for (int i = 0; i < n; i++) {
+                int r = n == 4 ? ((i >> 1) * 8 + (i & 1) * 2) : h264o_blk_raster(i);
+                int bx = r & 3, by = r >> 2;
+                int pred = pred_intra_mode(d, bx, by), mode;
+                int flag = cabac ? h264o_cabac_decision(d, 68) : (int)h264o_u(b, 1);
+                if (flag)
+                    mode = pred;
+                else {
+                    int rem;
+                    if (cabac) {
+                        rem = h264o_cabac_decision(d, 69);
+                        rem |= h264o_cabac_decision(d, 69) << 1;
+                        rem |= h264o_cabac_decision(d, 69) << 2;
+                    } else
+                        rem = (int)h264o_u(b, 3);
+                    mode = rem < pred ? rem : rem + 1;
+                }
+                m->ipm[r] = (int8_t)mode;
+                if (n == 4) m->ipm[r + 1] = m->ipm[r + 4] = m->ipm[r + 5] = (int8_t)mode;
+            }
+        }
+        c->chroma_mode = cabac ? cabac_intra_chroma_mode(d) : (int)h264o_ue(b);
+        if (c->chroma_mode > 3) return h264o_fail(d, "mb %d: bad intra_chroma_pred_mode", addr);
+        m->chroma_mode = (uint8_t)c->chroma_mode;
+    }
+    if (MB_IS_INTER(c->type)) set_refids(d, m);
+
+    if (c->type != MBT_I16x16) {
+        int cbp;
+        if (cabac)
+            cbp = cabac_cbp(d);
+        else {
+            uint32_t k = h264o_ue(b);
+            if (k > 47) return h264o_fail(d, "mb %d: bad coded_block_pattern", addr);
+            cbp = MB_IS_INTRA(c->type) ? h264o_me_intra[k] : h264o_me_inter[k];
+        }
+        c->cbp_luma = cbp & 15;
+        c->cbp_chroma = cbp >> 4;
+        if (c->cbp_luma && d->apps->transform_8x8_mode_flag && MB_IS_INTER(c->type)) {
+            int no_sub8 = 1;
+            if (c->type == MBT_P8x8)
+                for (int i = 0; i < 4; i++)
+                    if (c->sub_type[i] != 0) no_sub8 = 0;
+            if (no_sub8) {
+                c->t8x8 = cabac ? cabac_transform8x8(d) : (int)h264o_u(b, 1);
+                m->t8x8 = (uint8_t)c->t8x8;
+            }
+        }
+    }
+    m->cbp_luma = (uint8_t)c->cbp_luma;
+    m->cbp_chroma = (uint8_t)c->cbp_chroma;
+    if (c->cbp_luma || c->cbp_chroma || c->type == MBT_I16x16) {
+        int dqp = cabac ? cabac_mb_qp_delta(d) : h264o_se(b);
+        if (dqp < -26 || dqp > 25) return h264o_fail(d, "mb %d: mb_qp_delta %d out of range", addr, dqp);
+        d->prev_dqp_nz = dqp != 0;
+        d->qp = (d->qp + dqp + 52) % 52;
+        int r = parse_residual(d);
+        if (r < 0) return r;
+    } else
+        d->prev_dqp_nz = 0;
+    finish_mb(d);
+    return b->err ? h264o_fail(d, "mb %d: bitstream overrun", addr) : 0;
+}
+
+/* ------------------------------------------------------------------ slice_data() 7.3.4 */
+/* h264/slice.go:570-830.  Differences: mb_skip_flag / end_of_slice_flag are ae(v) (A23), mb_type
+ * is tracked per MB (A22), residual() is parsed (A24), next MB address is n+1 (no FMO). */
+int h264o_decode_slice_data(h264o_decoder *d) {
+    h264o_br *b = &d->br;
+    int cabac = d->apps->entropy_coding_mode_flag;
+    int islice = d->sh.slice_type == 2;
+    int total = d->wmb * d->hmb;
+    int addr = d->sh.first_mb_in_slice;
+    int64_t start_bits = b->pos;
+    d->qp = d->sh.slice_qp_y;
+    d->prev_dqp_nz = 0;
+    if (cabac) {
+        while (b->pos & 7)
+            if (!h264o_u(b, 1)) return h264o_fail(d, "cabac_alignment_one_bit is 0");
+        cabac_init_contexts(d);
+        h264o_cabac_init_engine(d);
+    }
+    int more = 1;
+    while (more) {
+        if (addr >= total) return h264o_fail(d, "slice runs past the picture (mb %d)", addr);
+        if (!islice) {
+            if (!cabac) {
+                uint32_t run = h264o_ue(b);
+                if (run > (uint32_t)(total - addr)) return h264o_fail(d, "mb_skip_run %u too long", run);
+                for (uint32_t i = 0; i < run; i++) decode_pskip(d, addr++);
+                if (run > 0) more = h264o_more_rbsp_data(b);
+                if (!more) break;
+                if (addr >= total) return h264o_fail(d, "slice runs past the picture after skip run");
+            } else {
+                begin_mb(d, addr); /* neighbour helpers need c.mbx/mby */
+                if (cabac_mb_skip_flag(d)) {
+                    decode_pskip(d, addr);
+                    goto end_mb;
+                }
+            }
+        }
+        {
+            int r = decode_mb(d, addr);
+            if (r < 0) return r;
+        }
+    end_mb:
+        if (!cabac)
+            more = h264o_more_rbsp_data(b);
+        else
+            more = !cabac_terminate(d);
+        addr++;
+        if (b->err) return h264o_fail(d, "slice data overrun at mb %d", addr);
+    }
+    d->info.n_bits += (uint64_t)(b->pos - start_bits);
+    return addr; /* one past the last MB of the slice */
+}

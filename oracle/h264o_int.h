@@ -1,0 +1,104 @@
+/* oracle/h264o_int.h -- internal structures of the CPU oracle.  TEST INFRASTRUCTURE ONLY. */
+#ifndef H264O_INT_H
+#define H264O_INT_H
+#include "h264o.h"
+
+enum { MBT_NONE = 0, MBT_I4x4, MBT_I8x8, MBT_I16x16, MBT_IPCM, MBT_P16x16, MBT_P16x8, MBT_P8x16, MBT_P8x8, MBT_PSKIP };
+#define MB_IS_INTRA(t) ((t) >= MBT_I4x4 && (t) <= MBT_IPCM)
+#define MB_IS_INTER(t) ((t) >= MBT_P16x16)
+
+typedef struct {
+    uint8_t *plane[3];
+    int stride[3];
+    int frame_num, frame_num_wrap, pic_num, poc;
+    int ref; /* 0 unused, 1 short-term, 2 long-term */
+    int long_term_frame_idx;
+    int id; /* unique, increasing */
+    int in_use;
+} h264o_pic;
+
+typedef struct {
+    uint8_t type; /* MBT_* ; MBT_NONE = not yet decoded in this picture */
+    uint8_t t8x8, qp, qpc[2], cbp_luma, cbp_chroma, chroma_mode;
+    uint16_t slice_id;
+    int8_t ipm[16];   /* Intra4x4/8x8PredMode per 4x4 block, raster (by*4+bx); -1 when not I_NxN */
+    uint8_t nnz[24];  /* TotalCoeff per 4x4 block: luma raster [0..15], Cb [16..19], Cr [20..23] */
+    uint16_t nzmask;  /* luma blocks (raster) holding non-zero coefficients; 8x8 blocks replicated */
+    uint8_t cbf_dc;   /* bit0 Intra16x16 DC, bit1 Cb DC, bit2 Cr DC (CABAC coded_block_flag) */
+    int16_t mv[16][2];
+    int8_t ref[4];    /* ref_idx per 8x8 (raster 2x2); -1 intra */
+    int32_t refid[4]; /* h264o_pic.id referenced, for deblocking */
+    int16_t mvd[16][2]; /* |mvd| per 4x4 block for CABAC ctxIdxInc */
+    int8_t alpha_off, beta_off; /* FilterOffsetA/B of the containing slice */
+    uint8_t dbf_idc;
+    uint8_t dqp_nz; /* mb_qp_delta != 0 (CABAC ctxIdxInc of the next MB) */
+} h264o_mb;
+
+typedef struct {
+    int mb_type_raw, type, mbx, mby, addr;
+    int i16mode, chroma_mode, cbp_luma, cbp_chroma, t8x8;
+    int sub_type[4];
+    int16_t i16dc[16];     /* scan order */
+    int16_t luma[16][16];  /* [luma4x4BlkIdx (z-order)][scan idx]; Intra16x16 AC uses idx 1..15 */
+    int16_t luma8[4][64];  /* [luma8x8BlkIdx][scan idx] */
+    int16_t cdc[2][4];
+    int16_t cac[2][4][16]; /* [iCbCr][blk][scan idx 1..15] */
+    uint8_t pcm[384];
+} h264o_curmb;
+
+struct h264o_decoder {
+    h264o_sps sps[32];
+    h264o_pps pps[256];
+    const h264o_sps *asps;
+    const h264o_pps *apps;
+    int wmb, hmb;
+    h264o_pic pics[20];
+    int n_pics;
+    h264o_pic *cur;
+    int next_pic_id;
+    h264o_mb *mb;
+    /* POC state (8.2.1) */
+    int prev_poc_msb, prev_poc_lsb, prev_frame_num, prev_frame_num_offset, prev_ref_has_mmco5;
+    /* slice state */
+    h264o_slice_header sh;
+    h264o_slice_header first_sh; /* first slice header of the current picture */
+    h264o_br br;
+    int slice_id;
+    h264o_pic *rpl0[33];
+    int qp;
+    int prev_dqp_nz;
+    uint32_t cod_range, cod_offset;
+    uint8_t ctx[H264O_NCTX]; /* (pStateIdx << 1) | valMPS */
+    int level_scale4[6][6][16]; /* [list][qp%6][raster pos] */
+    int level_scale8[2][6][64];
+    h264o_curmb c;
+    uint16_t cur_done; /* 4x4 blocks (raster) of the current MB whose motion is final */
+    /* output */
+    int crop;
+    uint8_t *out;
+    size_t out_cap, out_pos;
+    h264o_stream_info info;
+    int32_t *trace;
+    size_t trace_cap, trace_pos;
+    char err[256];
+    uint8_t *rbsp;
+    size_t rbsp_cap;
+};
+
+/* entropy.c */
+int h264o_decode_slice_data(h264o_decoder *d);
+void h264o_cabac_init_engine(h264o_decoder *d);
+int h264o_cabac_decision(h264o_decoder *d, int ctx_idx);
+/* recon.c */
+void h264o_build_level_scale(h264o_decoder *d);
+void h264o_recon_mb(h264o_decoder *d, h264o_mb *m);
+void h264o_deblock_picture(h264o_decoder *d);
+int h264o_fail(h264o_decoder *d, const char *fmt, ...);
+
+static inline int h264o_clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline int h264o_clip1(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+static inline int h264o_qpc(int qpi) { return qpi < 30 ? qpi : h264o_qpc_tab[qpi - 30]; }
+/* luma4x4BlkIdx (z-order) -> raster index by*4+bx (6.4.3) */
+static inline int h264o_blk_raster(int idx) { return (((idx >> 1) & 1) + 2 * (idx >> 3)) * 4 + ((idx & 1) + 2 * ((idx >> 2) & 1)); }
+
+#endif
