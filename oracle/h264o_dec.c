@@ -67,11 +67,11 @@ static int activate(h264o_decoder *d, const h264o_pps *pps) {
             p->stride[1] = p->stride[2] = wmb * 8;
         }
         d->n_pics = n;
-        d->info.coded_width = wmb * 16;
-        d->info.coded_height = hmb * 16;
-        d->info.width = wmb * 16 - 2 * (s->frame_crop_left_offset + s->frame_crop_right_offset);
-        d->info.height = hmb * 16 - 2 * (s->frame_crop_top_offset + s->frame_crop_bottom_offset);
     }
+    d->info.coded_width = wmb * 16;
+    d->info.coded_height = hmb * 16;
+    d->info.width = wmb * 16 - 2 * (s->frame_crop_left_offset + s->frame_crop_right_offset);
+    d->info.height = hmb * 16 - 2 * (s->frame_crop_top_offset + s->frame_crop_bottom_offset);
     d->asps = s;
     d->apps = pps;
     h264o_build_level_scale(d);

@@ -1,0 +1,61 @@
+/*
+ * streamgen/sg.h -- synthetic H.264 Annex-B stream generator (a small closed-loop encoder).
+ *
+ * Purpose: there is no network, no sample .h264 and no third-party encoder in the build image
+ * (SURVEY.md fact 5), so tests and bench.py synthesise their inputs here.  The generator emits
+ * (a) a conforming Annex-B byte stream and (b) its own reconstruction of every frame, produced by
+ * an implementation of prediction / transform / deblocking written independently of both the
+ * oracle (oracle/) and the product (h264decode_amd/).  Round-trip tests require
+ * decoder output == generator reconstruction, bit for bit.
+ *
+ * This is input synthesis, not part of the decode product and not the oracle.
+ */
+#ifndef SG_H
+#define SG_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int width, height;      /* display size; coded size is rounded up to 16, cropping signalled in the SPS */
+    int frames;
+    int profile_idc;        /* 66 Baseline, 77 Main, 100 High */
+    int cabac;              /* entropy_coding_mode_flag */
+    int qp;                 /* base QP (pic_init_qp); */
+    int qp_jitter;          /* per-MB |mb_qp_delta| up to this value (0 = constant QP) */
+    int idr_period;         /* 1 = all IDR; N = IDR every N frames, P in between; 0 = only the first frame is IDR */
+    int slices;             /* slices per picture (split by MB rows as evenly as possible) */
+    int transform8x8;       /* 0 off; 1 = High 8x8 transform + Intra8x8 enabled (needs profile 100) */
+    int num_ref_frames;     /* 1..4 */
+    int deblock_idc;        /* disable_deblocking_filter_idc: 0 on, 1 off, 2 on except slice edges */
+    int alpha_off_div2, beta_off_div2;
+    int cabac_init_idc;     /* 0..2, or -1: cycle per slice */
+    int constrained_intra;  /* constrained_intra_pred_flag */
+    int chroma_qp_offset;   /* chroma_qp_index_offset (second offset = same unless High: then +1 when transform8x8) */
+    int pcm_permille;       /* probability (1/1000) of an I_PCM macroblock */
+    int intra_in_p_permille;/* probability of an intra MB inside P pictures */
+    int skip_permille;      /* probability of P_Skip */
+    int sub8x8_permille;    /* probability of P_8x8 (with random sub-partitions) / 16x8 / 8x16 */
+    int weighted_pred;      /* explicit weighted prediction in P slices */
+    int scaling_matrix;     /* 0 flat, 1 = send default (non-flat) scaling lists in the SPS (High) */
+    int noise;              /* amplitude of the uniform source noise */
+    uint32_t seed;
+    int long_start_code;    /* 1: 4-byte start codes everywhere; 0: 3-byte for non-parameter-set NALs */
+    int poc_type;           /* 0 or 2 */
+} sg_params;
+
+void sg_default_params(sg_params *p);
+/* Returns stream size in bytes (0 on failure / overflow).  recon (optional) receives every frame
+ * at CODED size, I420 planar, back to back; recon_cap in bytes.  frame_sizes (optional, `frames`
+ * entries) receives the byte size of each access unit. */
+size_t sg_encode(const sg_params *p, uint8_t *stream, size_t stream_cap, uint8_t *recon, size_t recon_cap, uint32_t *frame_sizes);
+/* source picture t of the synthetic sequence (coded size), for reference / PSNR */
+void sg_source_frame(const sg_params *p, int t, uint8_t *dst);
+const char *sg_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

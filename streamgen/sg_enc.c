@@ -1,0 +1,1468 @@
+/*
+ * streamgen/sg_enc.c -- synthetic-stream generator: source pictures, seeded mode decisions,
+ * closed-loop reconstruction (sg_recon.c) and syntax writing (7.3: SPS, PPS, slice header,
+ * slice_data, macroblock_layer, mb_pred, sub_mb_pred, residual) with CAVLC (9.2) or CABAC
+ * (9.3.4) entropy coding.
+ *
+ * Input synthesis for tests/ and bench.py -- not part of the decode product, not the oracle.
+ */
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "sg_int.h"
+
+enum { T_NONE = 0, T_I4, T_I8, T_I16, T_PCM, T_P16, T_P16x8, T_P8x16, T_P8x8, T_SKIP };
+#define IS_INTRA(t) ((t) >= T_I4 && (t) <= T_PCM)
+#define IS_INTER(t) ((t) >= T_P16)
+
+typedef struct {
+    uint8_t type, t8x8, qp, qpc[2], cbp_luma, cbp_chroma, chroma_mode, i16mode, cbf_dc, dqp_nz;
+    uint16_t slice_id, nzmask;
+    int8_t ipm[16], ref[4];
+    uint8_t nnz[24];
+    int16_t mv[16][2], mvd[16][2];
+    int32_t refid[4];
+    uint8_t sub[4];
+} emb;
+
+typedef struct {
+    sg_params p;
+    int wmb, hmb, W, H;
+    sg_pic pics[6];
+    sg_pic *cur, *refs[4];
+    int nrefs, next_id;
+    emb *mb;
+    sg_dbmb *db;
+    uint8_t *src;
+    uint64_t rng;
+    sg_bw bw;
+    int qp, prev_dqp_nz, slice_id, slice_type, skip_run, init_idc, nref_active;
+    int ls4[6][6][16], ls8[2][6][64];
+    uint8_t s4[6][16], s8[2][64]; /* scaling lists, zig-zag */
+    int wp_w[4], wp_o[4], wp_cw[4][2], wp_co[4][2], wp_ld, wp_cd;
+    /* current MB */
+    int mbx, mby, addr, raw_type;
+    uint16_t done;
+    int16_t i16dc[16], luma[16][16], luma8[4][64], cdc[2][4], cac[2][4][16];
+    uint8_t pcm[384];
+} enc;
+
+static char g_err[256];
+const char *sg_last_error(void) { return g_err; }
+
+void sg_default_params(sg_params *p) {
+    memset(p, 0, sizeof(*p));
+    p->width = 176, p->height = 144, p->frames = 2, p->profile_idc = 66, p->qp = 28, p->idr_period = 1, p->slices = 1;
+    p->num_ref_frames = 1, p->cabac_init_idc = 0, p->noise = 8, p->seed = 1, p->long_start_code = 1;
+    p->intra_in_p_permille = 50, p->skip_permille = 250, p->sub8x8_permille = 100;
+}
+
+/* ------------------------------------------------------------------ PRNG + source */
+static uint32_t rnd(enc *e) { /* xorshift64* */
+    e->rng ^= e->rng >> 12;
+    e->rng ^= e->rng << 25;
+    e->rng ^= e->rng >> 27;
+    return (uint32_t)((e->rng * 2685821657736338717ull) >> 32);
+}
+static int rnd_range(enc *e, int lo, int hi) { return lo + (int)(rnd(e) % (uint32_t)(hi - lo + 1)); }
+static uint32_t hash32(uint32_t a) {
+    a ^= a >> 16, a *= 0x7feb352du, a ^= a >> 15, a *= 0x846ca68bu, a ^= a >> 16;
+    return a;
+}
+/* Y(x,y,t) = clip(128 + 64 sin((x+3t)/37) + 48 cos((y-2t)/23) + n), n ~ U[-noise,noise]; chroma analogous.
+ * The noise field moves with the picture (3,-2) px/frame so that motion compensation is meaningful. */
+void sg_source_frame(const sg_params *p, int t, uint8_t *dst) {
+    int W = (p->width + 15) & ~15, H = (p->height + 15) & ~15;
+    uint8_t *y = dst, *cb = dst + W * H, *cr = cb + W * H / 4;
+    for (int j = 0; j < H; j++)
+        for (int i = 0; i < W; i++) {
+            int xs = i + 3 * t, ys = j - 2 * t;
+            double v = 128 + 64 * sin(xs / 37.0) + 48 * cos(ys / 23.0);
+            int n = p->noise ? (int)(hash32((uint32_t)(xs * 7919 + ys * 104729) ^ p->seed) % (uint32_t)(2 * p->noise + 1)) - p->noise : 0;
+            int q = (int)floor(v + 0.5) + n;
+            y[j * W + i] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+        }
+    for (int j = 0; j < H / 2; j++)
+        for (int i = 0; i < W / 2; i++) {
+            int xs = 2 * i + 3 * t, ys = 2 * j - 2 * t;
+            int n = p->noise ? (int)(hash32((uint32_t)(xs * 31337 + ys * 15485863) ^ (p->seed * 3u)) % (uint32_t)(p->noise + 1)) - p->noise / 2 : 0;
+            int a = (int)floor(128 + 40 * sin(xs / 53.0 + 1.0) + 24 * cos(ys / 41.0) + 0.5) + n;
+            int b = (int)floor(128 + 36 * cos(xs / 47.0) + 30 * sin(ys / 29.0 + 2.0) + 0.5) - n;
+            cb[j * (W / 2) + i] = (uint8_t)(a < 0 ? 0 : (a > 255 ? 255 : a));
+            cr[j * (W / 2) + i] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+        }
+}
+
+/* ------------------------------------------------------------------ helpers */
+static int qpc_of(int qpi) {
+    qpi = qpi < 0 ? 0 : (qpi > 51 ? 51 : qpi);
+    return qpi < 30 ? qpi : sg_qpc_tab[qpi - 30];
+}
+static int blk_raster(int idx) { return (((idx >> 1) & 1) + 2 * (idx >> 3)) * 4 + ((idx & 1) + 2 * ((idx >> 2) & 1)); }
+static emb *mb_at(enc *e, int mx, int my) {
+    if (mx < 0 || my < 0 || mx >= e->wmb || my >= e->hmb) return NULL;
+    emb *m = &e->mb[my * e->wmb + mx];
+    if (m->type == T_NONE || m->slice_id != e->slice_id) return NULL;
+    return m;
+}
+#define CURMB(e) (&(e)->mb[(e)->addr])
+#define MBA(e) mb_at(e, (e)->mbx - 1, (e)->mby)
+#define MBB(e) mb_at(e, (e)->mbx, (e)->mby - 1)
+static emb *lnb(enc *e, int bx, int by, int *ri) {
+    emb *m;
+    if (bx < 0)
+        m = MBA(e), bx += 4;
+    else if (by < 0)
+        m = MBB(e), by += 4;
+    else
+        m = CURMB(e);
+    *ri = by * 4 + bx;
+    return m;
+}
+static emb *cnb(enc *e, int cx, int cy, int *ri) {
+    emb *m;
+    if (cx < 0)
+        m = MBA(e), cx += 2;
+    else if (cy < 0)
+        m = MBB(e), cy += 2;
+    else
+        m = CURMB(e);
+    *ri = cy * 2 + cx;
+    return m;
+}
+static int intra_ok(enc *e, int mx, int my) {
+    emb *m = mb_at(e, mx, my);
+    if (!m || my * e->wmb + mx >= e->addr) return 0;
+    if (e->p.constrained_intra && IS_INTER(m->type)) return 0;
+    return 1;
+}
+
+static void build_scale(enc *e) {
+    for (int l = 0; l < 6; l++)
+        for (int q = 0; q < 6; q++)
+            for (int k = 0; k < 16; k++) {
+                int r = sg_zigzag4x4[k], x = r & 3, y = r >> 2;
+                int v = (!(x & 1) && !(y & 1)) ? sg_norm4x4[q][0] : (((x & 1) && (y & 1)) ? sg_norm4x4[q][1] : sg_norm4x4[q][2]);
+                e->ls4[l][q][r] = e->s4[l][k] * v;
+            }
+    for (int l = 0; l < 2; l++)
+        for (int q = 0; q < 6; q++)
+            for (int k = 0; k < 64; k++) {
+                int r = sg_zigzag8x8[k], x = r & 7, y = r >> 3, c;
+                if (!(x & 3) && !(y & 3))
+                    c = 0;
+                else if ((x & 1) && (y & 1))
+                    c = 1;
+                else if ((x & 3) == 2 && (y & 3) == 2)
+                    c = 2;
+                else if ((!(y & 3) && (x & 1)) || ((y & 1) && !(x & 3)))
+                    c = 3;
+                else if ((!(y & 3) && (x & 3) == 2) || ((y & 3) == 2 && !(x & 3)))
+                    c = 4;
+                else
+                    c = 5;
+                e->ls8[l][q][r] = e->s8[l][k] * sg_norm8x8[q][c];
+            }
+}
+
+/* ------------------------------------------------------------------ CAVLC writers (9.2) */
+static void cavlc_block(enc *e, const int16_t *coef, int maxnum, int nC) {
+    sg_bw *w = &e->bw;
+    int level[16], run[16], total = 0, t1s = 0, last = -1;
+    /* collect non-zero coefficients from high to low frequency */
+    for (int i = maxnum - 1; i >= 0; i--)
+        if (coef[i]) {
+            level[total] = coef[i];
+            if (last >= 0) run[total - 1] = last - i - 1;
+            last = i;
+            total++;
+        }
+    if (total) run[total - 1] = last; /* zeros before the lowest coefficient */
+    for (int i = 0; i < total && i < 3; i++) {
+        if (abs(level[i]) != 1) break;
+        t1s++;
+    }
+    if (nC == -1)
+        sg_put(w, sg_chroma_dc_token_bits[4 * total + t1s], sg_chroma_dc_token_len[4 * total + t1s]);
+    else {
+        int tbl = nC < 2 ? 0 : (nC < 4 ? 1 : (nC < 8 ? 2 : 3));
+        sg_put(w, sg_coeff_token_bits[tbl][4 * total + t1s], sg_coeff_token_len[tbl][4 * total + t1s]);
+    }
+    if (!total) return;
+    int suffix_len = (total > 10 && t1s < 3) ? 1 : 0;
+    for (int i = 0; i < total; i++) {
+        if (i < t1s) {
+            sg_put(w, level[i] < 0, 1);
+            continue;
+        }
+        int v = level[i];
+        int code = v > 0 ? 2 * v - 2 : -2 * v - 1; /* levelCode */
+        if (i == t1s && t1s < 3) code -= 2;
+        /* 9.2.2.1 inverse */
+        int prefix, suffix = 0, size = 0;
+        if (suffix_len == 0) {
+            if (code < 14)
+                prefix = code;
+            else if (code < 30)
+                prefix = 14, size = 4, suffix = code - 14;
+            else
+                prefix = 15, size = 12, suffix = code - 30;
+        } else {
+            if (code < (15 << suffix_len))
+                prefix = code >> suffix_len, size = suffix_len, suffix = code & ((1 << suffix_len) - 1);
+            else
+                prefix = 15, size = 12, suffix = code - (15 << suffix_len);
+        }
+        if (prefix == 15 && suffix >= 4096) { /* would need level_prefix >= 16: clamp (never hit at sane QPs) */
+            suffix = 4095;
+        }
+        sg_put(w, 1, prefix + 1);
+        if (size) sg_put(w, (uint32_t)suffix, size);
+        if (suffix_len == 0) suffix_len = 1;
+        if (abs(v) > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+    }
+    int total_zeros = 0;
+    for (int i = 0; i < total; i++) total_zeros += run[i];
+    if (total < maxnum) {
+        if (maxnum == 4)
+            sg_put(w, sg_chroma_dc_total_zeros_bits[total - 1][total_zeros], sg_chroma_dc_total_zeros_len[total - 1][total_zeros]);
+        else
+            sg_put(w, sg_total_zeros_bits[total - 1][total_zeros], sg_total_zeros_len[total - 1][total_zeros]);
+    }
+    int zl = total_zeros;
+    for (int i = 0; i < total - 1 && zl > 0; i++) {
+        int t = (zl > 7 ? 7 : zl) - 1;
+        sg_put(w, sg_run_bits[t][run[i]], sg_run_len[t][run[i]]);
+        zl -= run[i];
+    }
+}
+static int count_nz(const int16_t *c, int n) {
+    int k = 0;
+    for (int i = 0; i < n; i++) k += c[i] != 0;
+    return k;
+}
+static int nc_luma(enc *e, int bx, int by) {
+    int ia, ib;
+    emb *a = lnb(e, bx - 1, by, &ia), *b = lnb(e, bx, by - 1, &ib);
+    if (a && b) return (a->nnz[ia] + b->nnz[ib] + 1) >> 1;
+    return a ? a->nnz[ia] : (b ? b->nnz[ib] : 0);
+}
+static int nc_chroma(enc *e, int c, int cx, int cy) {
+    int ia, ib;
+    emb *a = cnb(e, cx - 1, cy, &ia), *b = cnb(e, cx, cy - 1, &ib);
+    if (a && b) return (a->nnz[16 + 4 * c + ia] + b->nnz[16 + 4 * c + ib] + 1) >> 1;
+    return a ? a->nnz[16 + 4 * c + ia] : (b ? b->nnz[16 + 4 * c + ib] : 0);
+}
+
+/* ------------------------------------------------------------------ CABAC writers (9.3.2 binarisations) */
+static const int sig_off[5] = {0, 15, 29, 44, 47}, abs_off[5] = {0, 10, 20, 30, 39};
+static void cabac_block(enc *e, const int16_t *coef, int cat, int maxnum, int cbf_inc) {
+    sg_bw *w = &e->bw;
+    int n = count_nz(coef, maxnum);
+    if (cbf_inc >= 0) {
+        sg_cabac_bin(w, 85 + cat * 4 + cbf_inc, n != 0);
+        if (!n) return;
+    }
+    int lastpos = maxnum - 1;
+    while (lastpos > 0 && !coef[lastpos]) lastpos--;
+    for (int i = 0; i < maxnum - 1; i++) {
+        int sctx, lctx;
+        if (cat == 5)
+            sctx = 402 + sg_sig8x8_ctx[i], lctx = 417 + sg_last8x8_ctx[i];
+        else {
+            int inc = cat == 3 ? (i < 2 ? i : 2) : i;
+            sctx = 105 + sig_off[cat] + inc, lctx = 166 + sig_off[cat] + inc;
+        }
+        sg_cabac_bin(w, sctx, coef[i] != 0);
+        if (coef[i]) {
+            sg_cabac_bin(w, lctx, i == lastpos);
+            if (i == lastpos) break;
+        }
+    }
+    int eq1 = 0, gt1 = 0, base = cat == 5 ? 426 : 227 + abs_off[cat];
+    for (int i = lastpos; i >= 0; i--) {
+        if (!coef[i]) continue;
+        int a = abs(coef[i]) - 1; /* coeff_abs_level_minus1 */
+        int inc0 = gt1 ? 0 : (1 + eq1 < 4 ? 1 + eq1 : 4);
+        sg_cabac_bin(w, base + inc0, a > 0);
+        if (a == 0)
+            eq1++;
+        else {
+            int lim = 4 - (cat == 3), inc = 5 + (gt1 < lim ? gt1 : lim);
+            int pre = a < 14 ? a : 14;
+            for (int k = 1; k < pre; k++) sg_cabac_bin(w, base + inc, 1);
+            if (a < 14)
+                sg_cabac_bin(w, base + inc, 0);
+            else { /* Exp-Golomb k=0 suffix of a-14 */
+                int s = a - 14, k = 0;
+                while (s >= (1 << k)) {
+                    sg_cabac_bypass(w, 1);
+                    s -= 1 << k;
+                    k++;
+                }
+                sg_cabac_bypass(w, 0);
+                while (k--) sg_cabac_bypass(w, (s >> k) & 1);
+            }
+            gt1++;
+        }
+        sg_cabac_bypass(w, coef[i] < 0);
+    }
+}
+static int cbf_inc2(enc *e, emb *a, int fa, emb *b, int fb) {
+    int ci = IS_INTRA(CURMB(e)->type);
+    return (a ? fa : ci) + 2 * (b ? fb : ci);
+}
+static int cbf_luma(enc *e, int bx, int by) {
+    int ia, ib;
+    emb *a = lnb(e, bx - 1, by, &ia), *b = lnb(e, bx, by - 1, &ib);
+    return cbf_inc2(e, a, a ? a->nnz[ia] != 0 : 0, b, b ? b->nnz[ib] != 0 : 0);
+}
+static int cbf_cac(enc *e, int c, int cx, int cy) {
+    int ia, ib;
+    emb *a = cnb(e, cx - 1, cy, &ia), *b = cnb(e, cx, cy - 1, &ib);
+    return cbf_inc2(e, a, a ? a->nnz[16 + 4 * c + ia] != 0 : 0, b, b ? b->nnz[16 + 4 * c + ib] != 0 : 0);
+}
+static int cbf_dc(enc *e, int bit) {
+    emb *a = MBA(e), *b = MBB(e);
+    return cbf_inc2(e, a, a ? (a->cbf_dc >> bit) & 1 : 0, b, b ? (b->cbf_dc >> bit) & 1 : 0);
+}
+static void cabac_mvd(enc *e, int comp, int bx, int by, int v) {
+    sg_bw *w = &e->bw;
+    int ia, ib;
+    emb *a = lnb(e, bx - 1, by, &ia), *b = lnb(e, bx, by - 1, &ib);
+    int sum = (a ? a->mvd[ia][comp] : 0) + (b ? b->mvd[ib][comp] : 0), base = comp ? 47 : 40, m = abs(v);
+    sg_cabac_bin(w, base + (sum > 2) + (sum > 32), m != 0);
+    if (!m) return;
+    int ctx = base + 3;
+    for (int k = 1; k < (m < 9 ? m : 9); k++) {
+        sg_cabac_bin(w, ctx, 1);
+        if (k < 4) ctx++;
+    }
+    if (m < 9)
+        sg_cabac_bin(w, ctx, 0);
+    else {
+        int s = m - 9, k = 3;
+        while (s >= (1 << k)) {
+            sg_cabac_bypass(w, 1);
+            s -= 1 << k;
+            k++;
+        }
+        sg_cabac_bypass(w, 0);
+        while (k--) sg_cabac_bypass(w, (s >> k) & 1);
+    }
+    sg_cabac_bypass(w, v < 0);
+}
+static void cabac_ref(enc *e, int bx, int by, int ref) {
+    int ia, ib;
+    emb *a = lnb(e, bx - 1, by, &ia), *b = lnb(e, bx, by - 1, &ib);
+    int ra = a ? a->ref[(ia >> 3) * 2 + ((ia & 3) >> 1)] : 0, rb = b ? b->ref[(ib >> 3) * 2 + ((ib & 3) >> 1)] : 0;
+    int ctx = (ra > 0) + 2 * (rb > 0);
+    for (int k = 0; k < ref; k++) {
+        sg_cabac_bin(&e->bw, 54 + ctx, 1);
+        ctx = (ctx >> 2) + 4;
+    }
+    sg_cabac_bin(&e->bw, 54 + ctx, 0);
+}
+static void cabac_intra_type(enc *e, int base, int islice, int it) {
+    sg_bw *w = &e->bw;
+    if (islice) {
+        emb *a = MBA(e), *b = MBB(e);
+        int inc = (a && a->type != T_I4 && a->type != T_I8) + (b && b->type != T_I4 && b->type != T_I8);
+        sg_cabac_bin(w, base + inc, it != 0);
+        base += 2;
+    } else
+        sg_cabac_bin(w, base, it != 0);
+    if (it == 0) return;
+    sg_cabac_terminate(w, it == 25);
+    if (it == 25) return;
+    int t = it - 1, lum = t >= 12, cc = (t >> 2) % 3, pm = t & 3;
+    sg_cabac_bin(w, base + 1, lum);
+    sg_cabac_bin(w, base + 2, cc != 0);
+    if (cc) sg_cabac_bin(w, base + 2 + islice, cc == 2);
+    sg_cabac_bin(w, base + 3 + islice, pm >> 1);
+    sg_cabac_bin(w, base + 3 + 2 * islice, pm & 1);
+}
+static void cabac_cbp(enc *e, int cbp) {
+    sg_bw *w = &e->bw;
+    emb *a = MBA(e), *b = MBB(e);
+    int ca_ = a ? (a->type == T_PCM ? 0x2F : (a->cbp_luma | (a->cbp_chroma << 4))) : 0x0F;
+    int cb_ = b ? (b->type == T_PCM ? 0x2F : (b->cbp_luma | (b->cbp_chroma << 4))) : 0x0F;
+    for (int b8 = 0; b8 < 4; b8++) {
+        int la = (b8 & 1) ? (cbp >> (b8 - 1)) & 1 : (ca_ >> (b8 + 1)) & 1;
+        int lb = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cb_ >> (b8 + 2)) & 1;
+        sg_cabac_bin(w, 73 + (!la) + 2 * (!lb), (cbp >> b8) & 1);
+    }
+    int cc = cbp >> 4;
+    int fa = a && (a->type == T_PCM || a->cbp_chroma), fb = b && (b->type == T_PCM || b->cbp_chroma);
+    sg_cabac_bin(w, 77 + fa + 2 * fb, cc != 0);
+    if (cc) {
+        fa = a && (a->type == T_PCM || a->cbp_chroma == 2), fb = b && (b->type == T_PCM || b->cbp_chroma == 2);
+        sg_cabac_bin(w, 77 + 4 + fa + 2 * fb, cc == 2);
+    }
+}
+static void cabac_dqp(enc *e, int dqp) {
+    int val = dqp > 0 ? 2 * dqp - 1 : -2 * dqp, ctx = e->prev_dqp_nz ? 1 : 0;
+    for (int k = 0; k < val; k++) {
+        sg_cabac_bin(&e->bw, 60 + ctx, 1);
+        ctx = 2 + (ctx >> 1);
+    }
+    sg_cabac_bin(&e->bw, 60 + ctx, 0);
+}
+
+/* ------------------------------------------------------------------ motion vector prediction (8.4.1.3) */
+typedef struct {
+    int ok, ref, x, y;
+} nmv;
+static nmv get_nmv(enc *e, int bx, int by) {
+    nmv r = {0, -1, 0, 0};
+    emb *m;
+    if (by >= 0 && bx > 3) return r;
+    if (bx >= 0 && bx <= 3 && by >= 0) {
+        if (!(e->done >> (by * 4 + bx) & 1)) return r;
+        m = CURMB(e);
+    } else {
+        m = mb_at(e, e->mbx + (bx < 0 ? -1 : (bx > 3 ? 1 : 0)), e->mby + (by < 0 ? -1 : 0));
+        if (!m) return r;
+        bx &= 3, by &= 3;
+    }
+    r.ok = 1;
+    if (IS_INTRA(m->type)) return r;
+    r.ref = m->ref[(by >> 1) * 2 + (bx >> 1)];
+    r.x = m->mv[by * 4 + bx][0];
+    r.y = m->mv[by * 4 + bx][1];
+    return r;
+}
+static int mid3(int a, int b, int c) { return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b)); }
+/* shape: 0 median, 1/2 = 16x8 upper/lower, 3/4 = 8x16 left/right */
+static void mv_pred(enc *e, int bx, int by, int w, int ref, int shape, int out[2]) {
+    nmv A = get_nmv(e, bx - 1, by), B = get_nmv(e, bx, by - 1), C = get_nmv(e, bx + w, by - 1);
+    if (!C.ok) C = get_nmv(e, bx - 1, by - 1);
+    if (shape == 1 && B.ref == ref) { out[0] = B.x, out[1] = B.y; return; }
+    if ((shape == 2 || shape == 3) && A.ref == ref) { out[0] = A.x, out[1] = A.y; return; }
+    if (shape == 4 && C.ref == ref) { out[0] = C.x, out[1] = C.y; return; }
+    if (!B.ok && !C.ok && A.ok) B = A, C = A;
+    int hits = (A.ref == ref) + (B.ref == ref) + (C.ref == ref);
+    if (hits == 1) {
+        nmv s = A.ref == ref ? A : (B.ref == ref ? B : C);
+        out[0] = s.x, out[1] = s.y;
+        return;
+    }
+    out[0] = mid3(A.x, B.x, C.x);
+    out[1] = mid3(A.y, B.y, C.y);
+}
+static void skip_mv(enc *e, int out[2]) {
+    nmv A = get_nmv(e, -1, 0), B = get_nmv(e, 0, -1);
+    out[0] = out[1] = 0;
+    if (!A.ok || !B.ok) return;
+    if ((A.ref == 0 && !A.x && !A.y) || (B.ref == 0 && !B.x && !B.y)) return;
+    mv_pred(e, 0, 0, 4, 0, 0, out);
+}
+static void fill_part(enc *e, int bx, int by, int w, int h, const int mv[2], const int mvd[2]) {
+    emb *m = CURMB(e);
+    for (int y = by; y < by + h; y++)
+        for (int x = bx; x < bx + w; x++) {
+            m->mv[y * 4 + x][0] = (int16_t)mv[0], m->mv[y * 4 + x][1] = (int16_t)mv[1];
+            m->mvd[y * 4 + x][0] = (int16_t)abs(mvd[0]), m->mvd[y * 4 + x][1] = (int16_t)abs(mvd[1]);
+            e->done |= (uint16_t)(1 << (y * 4 + x));
+        }
+}
+
+/* ------------------------------------------------------------------ prediction + residual coding of one MB */
+static int sad(const uint8_t *a, int as, const uint8_t *b, int bs, int w, int h) {
+    int s = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) s += abs(a[y * as + x] - b[y * bs + x]);
+    return s;
+}
+static void put_block(uint8_t *dst, int stride, const uint8_t *pred, int n, const int *res) {
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) {
+            int v = pred[y * n + x] + (res ? res[y * n + x] : 0);
+            dst[y * stride + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+}
+static sg_avail mb_avail(enc *e) {
+    sg_avail a;
+    a.left = intra_ok(e, e->mbx - 1, e->mby);
+    a.top = intra_ok(e, e->mbx, e->mby - 1);
+    a.topleft = intra_ok(e, e->mbx - 1, e->mby - 1);
+    a.topright = intra_ok(e, e->mbx + 1, e->mby - 1);
+    return a;
+}
+static sg_avail blk4_avail(enc *e, int bx, int by) {
+    sg_avail m = mb_avail(e), a;
+    a.left = bx > 0 || m.left;
+    a.top = by > 0 || m.top;
+    a.topleft = (bx > 0 && by > 0) ? 1 : (bx > 0 ? m.top : (by > 0 ? m.left : m.topleft));
+    if (by == 0)
+        a.topright = bx < 3 ? m.top : m.topright;
+    else if (bx == 3)
+        a.topright = 0;
+    else { /* inside the MB: the upper-right neighbour must precede in decoding order */
+        static const uint8_t order[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15}; /* raster -> z index */
+        a.topright = order[(by - 1) * 4 + bx + 1] < order[by * 4 + bx];
+    }
+    return a;
+}
+static sg_avail blk8_avail(enc *e, int b8) {
+    sg_avail m = mb_avail(e), a;
+    int x8 = b8 & 1, y8 = b8 >> 1;
+    a.left = x8 || m.left;
+    a.top = y8 || m.top;
+    a.topleft = b8 == 0 ? m.topleft : (b8 == 1 ? m.top : (b8 == 2 ? m.left : 1));
+    a.topright = b8 == 0 ? m.top : (b8 == 1 ? m.topright : (b8 == 2 ? 1 : 0));
+    return a;
+}
+static int pred_ipm(enc *e, int bx, int by) {
+    int ia, ib;
+    emb *a = lnb(e, bx - 1, by, &ia), *b = lnb(e, bx, by - 1, &ib);
+    if (!a || !b) return 2;
+    if (e->p.constrained_intra && (IS_INTER(a->type) || IS_INTER(b->type))) return 2;
+    int ma = (a->type == T_I4 || a->type == T_I8) ? a->ipm[ia] : 2, mb_ = (b->type == T_I4 || b->type == T_I8) ? b->ipm[ib] : 2;
+    return ma < mb_ ? ma : mb_;
+}
+static double deadzone(int intra) { return intra ? 1.0 / 3 : 1.0 / 6; }
+
+static void code_chroma(enc *e, int intra, const uint8_t pred[2][64]) {
+    emb *m = CURMB(e);
+    int W2 = e->W / 2, any_dc = 0, any_ac = 0;
+    for (int c = 0; c < 2; c++) {
+        const uint8_t *src = e->src + e->W * e->H + c * (e->W * e->H / 4) + e->mby * 8 * W2 + e->mbx * 8;
+        int qp = m->qpc[c], list = (intra ? 1 : 4) + c;
+        const int *ls = e->ls4[list][qp % 6];
+        int sums[4];
+        for (int b = 0; b < 4; b++) {
+            int res[16], xo = (b & 1) * 4, yo = (b >> 1) * 4;
+            sums[b] = 0;
+            for (int y = 0; y < 4; y++)
+                for (int x = 0; x < 4; x++) {
+                    res[y * 4 + x] = src[(yo + y) * W2 + xo + x] - pred[c][(yo + y) * 8 + xo + x];
+                    sums[b] += res[y * 4 + x];
+                }
+            e->cac[c][b][0] = 0;
+            int16_t lev[16];
+            sg_quant4(res, ls, qp, deadzone(intra), 1, lev);
+            memcpy(e->cac[c][b], lev, sizeof(lev));
+            if (count_nz(lev, 16)) any_ac = 1;
+        }
+        sg_quant_chroma_dc(sums, ls[0], qp, deadzone(intra), e->cdc[c]);
+        if (count_nz(e->cdc[c], 4)) any_dc = 1;
+    }
+    m->cbp_chroma = any_ac ? 2 : (any_dc ? 1 : 0);
+    for (int c = 0; c < 2; c++) {
+        uint8_t *dst = e->cur->pl[1 + c] + e->mby * 8 * W2 + e->mbx * 8;
+        int qp = m->qpc[c], list = (intra ? 1 : 4) + c, dc[4];
+        const int *ls = e->ls4[list][qp % 6];
+        if (m->cbp_chroma == 0) memset(e->cdc[c], 0, sizeof(e->cdc[c]));
+        if (m->cbp_chroma != 2) memset(e->cac[c], 0, sizeof(e->cac[c]));
+        sg_chroma_dc(e->cdc[c], ls[0], qp, dc);
+        for (int b = 0; b < 4; b++) {
+            int res[16], xo = (b & 1) * 4, yo = (b >> 1) * 4;
+            uint8_t pb[16];
+            for (int y = 0; y < 4; y++) memcpy(pb + 4 * y, pred[c] + (yo + y) * 8 + xo, 4);
+            if (m->cbp_chroma) {
+                sg_residual4(e->cac[c][b], ls, qp, 1, dc[b], res);
+                put_block(dst + yo * W2 + xo, W2, pb, 4, res);
+            } else
+                put_block(dst + yo * W2 + xo, W2, pb, 4, NULL);
+        }
+    }
+}
+
+/* luma residual for a predicted (non-I4/I8/I16) MB: inter */
+static void code_luma_inter(enc *e, const uint8_t *pred /*16x16*/) {
+    emb *m = CURMB(e);
+    const uint8_t *src = e->src + e->mby * 16 * e->W + e->mbx * 16;
+    uint8_t *dst = e->cur->pl[0] + e->mby * 16 * e->W + e->mbx * 16;
+    int qp = m->qp;
+    m->cbp_luma = 0;
+    for (int b8 = 0; b8 < 4; b8++) {
+        int x8 = (b8 & 1) * 8, y8 = (b8 >> 1) * 8;
+        if (m->t8x8) {
+            int res[64];
+            for (int y = 0; y < 8; y++)
+                for (int x = 0; x < 8; x++) res[y * 8 + x] = src[(y8 + y) * e->W + x8 + x] - pred[(y8 + y) * 16 + x8 + x];
+            sg_quant8(res, e->ls8[1][qp % 6], qp, deadzone(0), e->luma8[b8]);
+            if (count_nz(e->luma8[b8], 64)) m->cbp_luma |= 1 << b8;
+        } else
+            for (int b4 = 0; b4 < 4; b4++) {
+                int idx = b8 * 4 + b4, r = blk_raster(idx), xo = (r & 3) * 4, yo = (r >> 2) * 4, res[16];
+                for (int y = 0; y < 4; y++)
+                    for (int x = 0; x < 4; x++) res[y * 4 + x] = src[(yo + y) * e->W + xo + x] - pred[(yo + y) * 16 + xo + x];
+                sg_quant4(res, e->ls4[3][qp % 6], qp, deadzone(0), 0, e->luma[idx]);
+                if (count_nz(e->luma[idx], 16)) m->cbp_luma |= 1 << b8;
+            }
+    }
+    for (int b8 = 0; b8 < 4; b8++) {
+        int x8 = (b8 & 1) * 8, y8 = (b8 >> 1) * 8, coded = (m->cbp_luma >> b8) & 1;
+        if (m->t8x8) {
+            int res[64];
+            uint8_t pb[64];
+            for (int y = 0; y < 8; y++) memcpy(pb + 8 * y, pred + (y8 + y) * 16 + x8, 8);
+            if (coded) sg_residual8(e->luma8[b8], e->ls8[1][qp % 6], qp, res);
+            put_block(dst + y8 * e->W + x8, e->W, pb, 8, coded ? res : NULL);
+        } else
+            for (int b4 = 0; b4 < 4; b4++) {
+                int idx = b8 * 4 + b4, r = blk_raster(idx), xo = (r & 3) * 4, yo = (r >> 2) * 4, res[16];
+                uint8_t pb[16];
+                for (int y = 0; y < 4; y++) memcpy(pb + 4 * y, pred + (yo + y) * 16 + xo, 4);
+                if (coded) sg_residual4(e->luma[idx], e->ls4[3][qp % 6], qp, 0, 0, res);
+                put_block(dst + yo * e->W + xo, e->W, pb, 4, coded ? res : NULL);
+            }
+    }
+}
+
+/* ------------------------------------------------------------------ syntax: residual() */
+static void write_residual(enc *e) {
+    emb *m = CURMB(e);
+    int cabac = e->p.cabac, i16 = m->type == T_I16;
+    if (i16) {
+        int n = count_nz(e->i16dc, 16);
+        if (cabac)
+            cabac_block(e, e->i16dc, 0, 16, cbf_dc(e, 0));
+        else
+            cavlc_block(e, e->i16dc, 16, nc_luma(e, 0, 0));
+        if (n) m->cbf_dc |= 1;
+    }
+    for (int b8 = 0; b8 < 4; b8++) {
+        if (!(m->cbp_luma >> b8 & 1)) continue;
+        int bx0 = (b8 & 1) * 2, by0 = (b8 >> 1) * 2;
+        if (m->t8x8 && cabac) {
+            int n = count_nz(e->luma8[b8], 64);
+            cabac_block(e, e->luma8[b8], 5, 64, -1);
+            m->nnz[by0 * 4 + bx0] = m->nnz[by0 * 4 + bx0 + 1] = m->nnz[by0 * 4 + 4 + bx0] = m->nnz[by0 * 4 + 5 + bx0] = (uint8_t)n;
+            if (n) m->nzmask |= (uint16_t)(0x33 << (by0 * 4 + bx0));
+            continue;
+        }
+        int any = 0;
+        for (int b4 = 0; b4 < 4; b4++) {
+            int idx = b8 * 4 + b4, r = blk_raster(idx), bx = r & 3, by = r >> 2, n;
+            int16_t tmp[16];
+            const int16_t *c = e->luma[idx];
+            if (m->t8x8) { /* CAVLC 8x8: 4x4 "block" b4 holds coefficients 4*i + b4 of the 8x8 scan */
+                for (int i = 0; i < 16; i++) tmp[i] = e->luma8[b8][4 * i + b4];
+                c = tmp;
+            }
+            if (i16) {
+                n = count_nz(c + 1, 15);
+                if (cabac)
+                    cabac_block(e, c + 1, 1, 15, cbf_luma(e, bx, by));
+                else
+                    cavlc_block(e, c + 1, 15, nc_luma(e, bx, by));
+            } else {
+                n = count_nz(c, 16);
+                if (cabac)
+                    cabac_block(e, c, 2, 16, cbf_luma(e, bx, by));
+                else
+                    cavlc_block(e, c, 16, nc_luma(e, bx, by));
+            }
+            m->nnz[r] = (uint8_t)n;
+            if (n) m->nzmask |= (uint16_t)(1 << r), any = 1;
+        }
+        if (m->t8x8 && any) m->nzmask |= (uint16_t)(0x33 << (by0 * 4 + bx0));
+    }
+    if (m->cbp_chroma) {
+        for (int c = 0; c < 2; c++) {
+            int n = count_nz(e->cdc[c], 4);
+            if (cabac)
+                cabac_block(e, e->cdc[c], 3, 4, cbf_dc(e, 1 + c));
+            else
+                cavlc_block(e, e->cdc[c], 4, -1);
+            if (n) m->cbf_dc |= (uint8_t)(2 << c);
+        }
+    }
+    if (m->cbp_chroma & 2)
+        for (int c = 0; c < 2; c++)
+            for (int b = 0; b < 4; b++) {
+                int n = count_nz(e->cac[c][b] + 1, 15);
+                if (cabac)
+                    cabac_block(e, e->cac[c][b] + 1, 4, 15, cbf_cac(e, c, b & 1, b >> 1));
+                else
+                    cavlc_block(e, e->cac[c][b] + 1, 15, nc_chroma(e, c, b & 1, b >> 1));
+                m->nnz[16 + 4 * c + b] = (uint8_t)n;
+            }
+}
+
+/* ------------------------------------------------------------------ MB begin/end */
+static void begin_mb(enc *e, int addr) {
+    emb *m = &e->mb[addr];
+    e->addr = addr, e->mbx = addr % e->wmb, e->mby = addr / e->wmb, e->done = 0;
+    memset(m, 0, sizeof(*m));
+    m->slice_id = (uint16_t)e->slice_id;
+    memset(m->ipm, -1, sizeof(m->ipm));
+    memset(m->ref, -1, sizeof(m->ref));
+    for (int i = 0; i < 4; i++) m->refid[i] = -1;
+    memset(e->i16dc, 0, sizeof(e->i16dc));
+    memset(e->luma, 0, sizeof(e->luma));
+    memset(e->luma8, 0, sizeof(e->luma8));
+    memset(e->cdc, 0, sizeof(e->cdc));
+    memset(e->cac, 0, sizeof(e->cac));
+}
+static void set_qpc(enc *e, emb *m, int qp) {
+    int second = e->p.chroma_qp_offset + ((e->p.profile_idc == 100 && e->p.transform8x8) ? 1 : 0);
+    m->qp = (uint8_t)qp;
+    m->qpc[0] = (uint8_t)qpc_of(qp + e->p.chroma_qp_offset);
+    m->qpc[1] = (uint8_t)qpc_of(qp + second);
+}
+static void end_mb(enc *e) {
+    emb *m = CURMB(e);
+    sg_dbmb *d = &e->db[e->addr];
+    d->intra = IS_INTRA(m->type);
+    d->t8x8 = m->t8x8;
+    if (m->type == T_PCM) {
+        emb tmp;
+        set_qpc(e, &tmp, 0);
+        d->qp = 0, d->qpc[0] = tmp.qpc[0], d->qpc[1] = tmp.qpc[1];
+    } else
+        d->qp = m->qp, d->qpc[0] = m->qpc[0], d->qpc[1] = m->qpc[1];
+    d->dbf_idc = (uint8_t)e->p.deblock_idc;
+    d->alpha_off = (int8_t)(2 * e->p.alpha_off_div2);
+    d->beta_off = (int8_t)(2 * e->p.beta_off_div2);
+    d->slice_id = m->slice_id;
+    d->nzmask = m->nzmask;
+    memcpy(d->mv, m->mv, sizeof(d->mv));
+    memcpy(d->refid, m->refid, sizeof(d->refid));
+}
+
+/* choose the QP this MB would like to use */
+static int want_qp(enc *e) {
+    if (!e->p.qp_jitter || rnd(e) % 8) return e->qp;
+    int q = e->p.qp + rnd_range(e, -e->p.qp_jitter, e->p.qp_jitter);
+    q = q < 10 ? 10 : (q > 51 ? 51 : q);
+    if (q - e->qp > 25) q = e->qp + 25;
+    if (q - e->qp < -26) q = e->qp - 26;
+    return q;
+}
+
+/* ------------------------------------------------------------------ intra MB */
+static void encode_intra(enc *e, int islice) {
+    emb *m = CURMB(e);
+    sg_bw *w = &e->bw;
+    int cabac = e->p.cabac, W = e->W;
+    const uint8_t *src = e->src + e->mby * 16 * W + e->mbx * 16;
+    uint8_t *dst = e->cur->pl[0] + e->mby * 16 * W + e->mbx * 16;
+    int r = rnd(e) % 1000, kind;
+    if (r < e->p.pcm_permille)
+        kind = T_PCM;
+    else {
+        int k = rnd(e) % 100;
+        kind = e->p.transform8x8 ? (k < 35 ? T_I16 : (k < 70 ? T_I4 : T_I8)) : (k < 50 ? T_I16 : T_I4);
+    }
+    m->type = (uint8_t)kind;
+    int qp = want_qp(e);
+    set_qpc(e, m, qp);
+    if (kind == T_PCM) {
+        /* raw samples */
+        for (int y = 0; y < 16; y++) memcpy(e->pcm + 16 * y, src + y * W, 16);
+        for (int c = 0; c < 2; c++)
+            for (int y = 0; y < 8; y++) memcpy(e->pcm + 256 + 64 * c + 8 * y, e->src + W * e->H + c * (W * e->H / 4) + (e->mby * 8 + y) * (W / 2) + e->mbx * 8, 8);
+        for (int y = 0; y < 16; y++) memcpy(dst + y * W, e->pcm + 16 * y, 16);
+        for (int c = 0; c < 2; c++)
+            for (int y = 0; y < 8; y++) memcpy(e->cur->pl[1 + c] + (e->mby * 8 + y) * (W / 2) + e->mbx * 8, e->pcm + 256 + 64 * c + 8 * y, 8);
+        if (cabac) {
+            if (islice)
+                cabac_intra_type(e, 3, 1, 25);
+            else {
+                sg_cabac_bin(w, 14, 1);
+                cabac_intra_type(e, 17, 0, 25);
+            }
+        } else
+            sg_put_ue(w, islice ? 25 : 30);
+        while (!sg_bw_aligned(w)) sg_put(w, 0, 1);
+        for (int i = 0; i < 384; i++) sg_put(w, e->pcm[i], 8);
+        if (cabac) sg_cabac_start(w);
+        set_qpc(e, m, e->qp); /* QP_Y unchanged across I_PCM */
+        memset(m->nnz, 16, sizeof(m->nnz));
+        m->nzmask = 0xFFFF, m->cbf_dc = 7, m->cbp_luma = 15, m->cbp_chroma = 2;
+        e->prev_dqp_nz = 0;
+        return;
+    }
+    sg_avail ma = mb_avail(e);
+    /* ---- luma ---- */
+    if (kind == T_I16) {
+        uint8_t pred[256], best[256];
+        int bs = 1 << 30, bm = 2;
+        for (int mode = 0; mode < 4; mode++) {
+            if (!sg_intra_mode_allowed(16, mode, &ma)) continue;
+            sg_pred_i16(e->cur, e->mbx * 16, e->mby * 16, mode, &ma, pred);
+            int s = sad(src, W, pred, 16, 16, 16) + (int)(rnd(e) % 64);
+            if (s < bs) bs = s, bm = mode, memcpy(best, pred, 256);
+        }
+        m->i16mode = (uint8_t)bm;
+        int sums[16], any_ac = 0;
+        for (int idx = 0; idx < 16; idx++) {
+            int rr = blk_raster(idx), xo = (rr & 3) * 4, yo = (rr >> 2) * 4, res[16];
+            sums[rr] = 0;
+            for (int y = 0; y < 4; y++)
+                for (int x = 0; x < 4; x++) res[y * 4 + x] = src[(yo + y) * W + xo + x] - best[(yo + y) * 16 + xo + x], sums[rr] += res[y * 4 + x];
+            sg_quant4(res, e->ls4[0][qp % 6], qp, deadzone(1), 1, e->luma[idx]);
+            if (count_nz(e->luma[idx], 16)) any_ac = 1;
+        }
+        sg_quant_luma_dc(sums, e->ls4[0][qp % 6][0], qp, deadzone(1), e->i16dc);
+        m->cbp_luma = any_ac ? 15 : 0;
+        if (!any_ac) memset(e->luma, 0, sizeof(e->luma));
+        int dc[16];
+        sg_luma_dc(e->i16dc, e->ls4[0][qp % 6][0], qp, dc);
+        for (int idx = 0; idx < 16; idx++) {
+            int rr = blk_raster(idx), xo = (rr & 3) * 4, yo = (rr >> 2) * 4, res[16];
+            uint8_t pb[16];
+            for (int y = 0; y < 4; y++) memcpy(pb + 4 * y, best + (yo + y) * 16 + xo, 4);
+            sg_residual4(e->luma[idx], e->ls4[0][qp % 6], qp, 1, dc[rr], res);
+            put_block(dst + yo * W + xo, W, pb, 4, res);
+        }
+    } else if (kind == T_I4) {
+        for (int idx = 0; idx < 16; idx++) {
+            int rr = blk_raster(idx), bx = rr & 3, by = rr >> 2, xo = bx * 4, yo = by * 4, res[16];
+            sg_avail a = blk4_avail(e, bx, by);
+            uint8_t pred[16], best[16];
+            int bs = 1 << 30, bm = 2;
+            for (int mode = 0; mode < 9; mode++) {
+                if (!sg_intra_mode_allowed(4, mode, &a)) continue;
+                sg_pred_i4(e->cur, e->mbx * 16 + xo, e->mby * 16 + yo, mode, &a, pred);
+                int s = sad(src + yo * W + xo, W, pred, 4, 4, 4) + (int)(rnd(e) % 24);
+                if (s < bs) bs = s, bm = mode, memcpy(best, pred, 16);
+            }
+            m->ipm[rr] = (int8_t)bm;
+            for (int y = 0; y < 4; y++)
+                for (int x = 0; x < 4; x++) res[y * 4 + x] = src[(yo + y) * W + xo + x] - best[y * 4 + x];
+            sg_quant4(res, e->ls4[0][qp % 6], qp, deadzone(1), 0, e->luma[idx]);
+            /* cbp is per 8x8: decide after the 4th block of each 8x8; reconstruct assuming "coded" and
+             * fix up below if the whole 8x8 quantised to zero (then residual is zero anyway) */
+            sg_residual4(e->luma[idx], e->ls4[0][qp % 6], qp, 0, 0, res);
+            put_block(dst + yo * W + xo, W, best, 4, res);
+            if (count_nz(e->luma[idx], 16)) m->cbp_luma |= (uint8_t)(1 << (idx >> 2));
+        }
+    } else { /* T_I8 */
+        m->t8x8 = 1;
+        for (int b8 = 0; b8 < 4; b8++) {
+            int xo = (b8 & 1) * 8, yo = (b8 >> 1) * 8, res[64];
+            sg_avail a = blk8_avail(e, b8);
+            uint8_t pred[64], best[64];
+            int bs = 1 << 30, bm = 2;
+            for (int mode = 0; mode < 9; mode++) {
+                if (!sg_intra_mode_allowed(8, mode, &a)) continue;
+                sg_pred_i8(e->cur, e->mbx * 16 + xo, e->mby * 16 + yo, mode, &a, pred);
+                int s = sad(src + yo * W + xo, W, pred, 8, 8, 8) + (int)(rnd(e) % 48);
+                if (s < bs) bs = s, bm = mode, memcpy(best, pred, 64);
+            }
+            int r0 = (b8 >> 1) * 8 + (b8 & 1) * 2;
+            m->ipm[r0] = m->ipm[r0 + 1] = m->ipm[r0 + 4] = m->ipm[r0 + 5] = (int8_t)bm;
+            for (int y = 0; y < 8; y++)
+                for (int x = 0; x < 8; x++) res[y * 8 + x] = src[(yo + y) * W + xo + x] - best[y * 8 + x];
+            sg_quant8(res, e->ls8[0][qp % 6], qp, deadzone(1), e->luma8[b8]);
+            if (count_nz(e->luma8[b8], 64)) {
+                m->cbp_luma |= (uint8_t)(1 << b8);
+                sg_residual8(e->luma8[b8], e->ls8[0][qp % 6], qp, res);
+                put_block(dst + yo * W + xo, W, best, 8, res);
+            } else
+                put_block(dst + yo * W + xo, W, best, 8, NULL);
+        }
+    }
+    /* ---- chroma ---- */
+    {
+        uint8_t pred[2][64], tmp[2][64];
+        int bs = 1 << 30, bm = 0;
+        for (int mode = 0; mode < 4; mode++) {
+            if (!sg_intra_mode_allowed(0, mode, &ma)) continue;
+            int s = (int)(rnd(e) % 32);
+            for (int c = 0; c < 2; c++) {
+                sg_pred_chroma(e->cur, 1 + c, e->mbx * 8, e->mby * 8, mode, &ma, tmp[c]);
+                s += sad(e->src + W * e->H + c * (W * e->H / 4) + e->mby * 8 * (W / 2) + e->mbx * 8, W / 2, tmp[c], 8, 8, 8);
+            }
+            if (s < bs) bs = s, bm = mode, memcpy(pred, tmp, sizeof(pred));
+        }
+        m->chroma_mode = (uint8_t)bm;
+        code_chroma(e, 1, pred);
+    }
+    /* ---- syntax ---- */
+    int it = kind == T_I16 ? 1 + m->i16mode + 4 * m->cbp_chroma + (m->cbp_luma ? 12 : 0) : 0;
+    e->raw_type = islice ? it : it + 5;
+    if (cabac) {
+        if (islice)
+            cabac_intra_type(e, 3, 1, it);
+        else {
+            sg_cabac_bin(w, 14, 1);
+            cabac_intra_type(e, 17, 0, it);
+        }
+    } else
+        sg_put_ue(w, (uint32_t)e->raw_type);
+    if (kind != T_I16 && e->p.transform8x8) {
+        if (cabac) {
+            emb *a = MBA(e), *b = MBB(e);
+            sg_cabac_bin(w, 399 + (a && a->t8x8) + (b && b->t8x8), m->t8x8);
+        } else
+            sg_put(w, m->t8x8, 1);
+    }
+    if (kind != T_I16) {
+        int n = kind == T_I8 ? 4 : 16;
+        for (int i = 0; i < n; i++) {
+            int rr = n == 4 ? (i >> 1) * 8 + (i & 1) * 2 : blk_raster(i), bx = rr & 3, by = rr >> 2;
+            /* pred_ipm must only see modes of blocks that precede this one: ipm of later blocks is still
+             * final here, but the derivation only looks left/up, which always precede. */
+            int pred = pred_ipm(e, bx, by), mode = m->ipm[rr];
+            if (mode == pred) {
+                if (cabac)
+                    sg_cabac_bin(w, 68, 1);
+                else
+                    sg_put(w, 1, 1);
+            } else {
+                int rem = mode < pred ? mode : mode - 1;
+                if (cabac) {
+                    sg_cabac_bin(w, 68, 0);
+                    sg_cabac_bin(w, 69, rem & 1);
+                    sg_cabac_bin(w, 69, (rem >> 1) & 1);
+                    sg_cabac_bin(w, 69, (rem >> 2) & 1);
+                } else {
+                    sg_put(w, 0, 1);
+                    sg_put(w, (uint32_t)rem, 3);
+                }
+            }
+        }
+    }
+    if (cabac) {
+        emb *a = MBA(e), *b = MBB(e);
+        int inc = (a && IS_INTRA(a->type) && a->type != T_PCM && a->chroma_mode) + (b && IS_INTRA(b->type) && b->type != T_PCM && b->chroma_mode);
+        sg_cabac_bin(w, 64 + inc, m->chroma_mode != 0);
+        if (m->chroma_mode) {
+            sg_cabac_bin(w, 67, m->chroma_mode > 1);
+            if (m->chroma_mode > 1) sg_cabac_bin(w, 67, m->chroma_mode > 2);
+        }
+    } else
+        sg_put_ue(w, m->chroma_mode);
+    if (kind != T_I16) {
+        int cbp = m->cbp_luma | (m->cbp_chroma << 4);
+        if (cabac)
+            cabac_cbp(e, cbp);
+        else {
+            int k = 0;
+            while (sg_me_intra[k] != cbp) k++;
+            sg_put_ue(w, (uint32_t)k);
+        }
+    }
+    if (m->cbp_luma || m->cbp_chroma || kind == T_I16) {
+        int dqp = qp - e->qp;
+        if (cabac)
+            cabac_dqp(e, dqp);
+        else
+            sg_put_se(w, dqp);
+        e->prev_dqp_nz = dqp != 0;
+        e->qp = qp;
+        write_residual(e);
+    } else {
+        e->prev_dqp_nz = 0;
+        set_qpc(e, m, e->qp);
+    }
+}
+
+/* ------------------------------------------------------------------ inter MB */
+static void pick_mv(enc *e, int x, int y, int w, int h, sg_pic *ref, const int mvp[2], int out[2]) {
+    const uint8_t *src = e->src + y * e->W + x;
+    int cand[6][2], n = 0, best = 0, bs = 1 << 30;
+    uint8_t tmp[256];
+    cand[n][0] = mvp[0], cand[n++][1] = mvp[1];
+    cand[n][0] = 12, cand[n++][1] = -8; /* true motion of the synthetic scene per frame */
+    cand[n][0] = 12 + rnd_range(e, -6, 6), cand[n++][1] = -8 + rnd_range(e, -6, 6);
+    cand[n][0] = 12 + rnd_range(e, -3, 3), cand[n++][1] = -8 + rnd_range(e, -3, 3);
+    cand[n][0] = rnd_range(e, -64, 64), cand[n++][1] = rnd_range(e, -64, 64);
+    cand[n][0] = 0, cand[n++][1] = 0;
+    if (rnd(e) % 100 < 25)
+        best = (int)(rnd(e) % (uint32_t)n);
+    else
+        for (int i = 0; i < n; i++) {
+            sg_mc_luma(ref, x, y, w, h, cand[i][0], cand[i][1], tmp, 16);
+            int s = sad(src, e->W, tmp, 16, w, h);
+            if (s < bs) bs = s, best = i;
+        }
+    out[0] = cand[best][0], out[1] = cand[best][1];
+    /* keep the displaced block within 32 samples of the picture so that streams stay level-conformant */
+    int minx = -4 * (x + 24), maxx = 4 * (e->W - x - w + 24), miny = -4 * (y + 24), maxy = 4 * (e->H - y - h + 24);
+    out[0] = out[0] < minx ? minx : (out[0] > maxx ? maxx : out[0]);
+    out[1] = out[1] < miny ? miny : (out[1] > maxy ? maxy : out[1]);
+}
+static void mc_part(enc *e, int bx, int by, int w, int h, uint8_t *py, uint8_t pc[2][64]) {
+    emb *m = CURMB(e);
+    int ref = m->ref[(by >> 1) * 2 + (bx >> 1)];
+    sg_pic *rp = e->refs[ref];
+    int mvx = m->mv[by * 4 + bx][0], mvy = m->mv[by * 4 + bx][1];
+    sg_mc_luma(rp, e->mbx * 16 + bx * 4, e->mby * 16 + by * 4, w * 4, h * 4, mvx, mvy, py + by * 4 * 16 + bx * 4, 16);
+    for (int c = 0; c < 2; c++) sg_mc_chroma(rp, 1 + c, e->mbx * 8 + bx * 2, e->mby * 8 + by * 2, w * 2, h * 2, mvx, mvy, pc[c] + by * 2 * 8 + bx * 2, 8);
+    if (e->p.weighted_pred) {
+        int ld = e->wp_ld, w0 = e->wp_w[ref], o0 = e->wp_o[ref];
+        for (int y = by * 4; y < (by + h) * 4; y++)
+            for (int x = bx * 4; x < (bx + w) * 4; x++) {
+                int v = py[y * 16 + x];
+                v = ld >= 1 ? ((v * w0 + (1 << (ld - 1))) >> ld) + o0 : v * w0 + o0;
+                py[y * 16 + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        for (int c = 0; c < 2; c++) {
+            int cd = e->wp_cd, cw = e->wp_cw[ref][c], co = e->wp_co[ref][c];
+            for (int y = by * 2; y < (by + h) * 2; y++)
+                for (int x = bx * 2; x < (bx + w) * 2; x++) {
+                    int v = pc[c][y * 8 + x];
+                    v = cd >= 1 ? ((v * cw + (1 << (cd - 1))) >> cd) + co : v * cw + co;
+                    pc[c][y * 8 + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+                }
+        }
+    }
+}
+typedef struct {
+    int bx, by, w, h, shape, mvd[2];
+} part;
+
+static void set_refids(enc *e, emb *m) {
+    for (int i = 0; i < 4; i++) m->refid[i] = m->ref[i] >= 0 ? e->refs[m->ref[i]]->id : -1;
+}
+
+static void encode_skip(enc *e) {
+    emb *m = CURMB(e);
+    int mv[2], zero[2] = {0, 0};
+    uint8_t py[256], pc[2][64];
+    m->type = T_SKIP;
+    memset(m->ref, 0, sizeof(m->ref));
+    skip_mv(e, mv);
+    fill_part(e, 0, 0, 4, 4, mv, zero);
+    set_refids(e, m);
+    set_qpc(e, m, e->qp);
+    mc_part(e, 0, 0, 4, 4, py, pc);
+    for (int y = 0; y < 16; y++) memcpy(e->cur->pl[0] + (e->mby * 16 + y) * e->W + e->mbx * 16, py + 16 * y, 16);
+    for (int c = 0; c < 2; c++)
+        for (int y = 0; y < 8; y++) memcpy(e->cur->pl[1 + c] + (e->mby * 8 + y) * (e->W / 2) + e->mbx * 8, pc[c] + 8 * y, 8);
+    e->prev_dqp_nz = 0;
+    e->raw_type = -1;
+}
+
+static void encode_inter(enc *e, int kind) {
+    emb *m = CURMB(e);
+    sg_bw *w = &e->bw;
+    int cabac = e->p.cabac, nref = e->nref_active;
+    part parts[16];
+    int np = 0;
+    m->type = (uint8_t)kind;
+    /* reference indices */
+    int refs4[4];
+    for (int i = 0; i < 4; i++) refs4[i] = (nref > 1 && rnd(e) % 100 < 35) ? rnd_range(e, 0, nref - 1) : 0;
+    if (kind == T_P16)
+        refs4[1] = refs4[2] = refs4[3] = refs4[0];
+    else if (kind == T_P16x8)
+        refs4[1] = refs4[0], refs4[3] = refs4[2];
+    else if (kind == T_P8x16)
+        refs4[2] = refs4[0], refs4[3] = refs4[1];
+    for (int i = 0; i < 4; i++) m->ref[i] = (int8_t)refs4[i];
+    set_refids(e, m);
+    if (kind == T_P16)
+        parts[np++] = (part){0, 0, 4, 4, 0, {0, 0}};
+    else if (kind == T_P16x8) {
+        parts[np++] = (part){0, 0, 4, 2, 1, {0, 0}};
+        parts[np++] = (part){0, 2, 4, 2, 2, {0, 0}};
+    } else if (kind == T_P8x16) {
+        parts[np++] = (part){0, 0, 2, 4, 3, {0, 0}};
+        parts[np++] = (part){2, 0, 2, 4, 4, {0, 0}};
+    } else
+        for (int i = 0; i < 4; i++) {
+            int bx = (i & 1) * 2, by = (i >> 1) * 2, st = rnd(e) % 100 < 55 ? 0 : rnd_range(e, 1, 3);
+            m->sub[i] = (uint8_t)st;
+            if (st == 0)
+                parts[np++] = (part){bx, by, 2, 2, 0, {0, 0}};
+            else if (st == 1) {
+                parts[np++] = (part){bx, by, 2, 1, 0, {0, 0}};
+                parts[np++] = (part){bx, by + 1, 2, 1, 0, {0, 0}};
+            } else if (st == 2) {
+                parts[np++] = (part){bx, by, 1, 2, 0, {0, 0}};
+                parts[np++] = (part){bx + 1, by, 1, 2, 0, {0, 0}};
+            } else {
+                parts[np++] = (part){bx, by, 1, 1, 0, {0, 0}};
+                parts[np++] = (part){bx + 1, by, 1, 1, 0, {0, 0}};
+                parts[np++] = (part){bx, by + 1, 1, 1, 0, {0, 0}};
+                parts[np++] = (part){bx + 1, by + 1, 1, 1, 0, {0, 0}};
+            }
+        }
+    /* motion per partition, in decoding order */
+    uint8_t py[256], pc[2][64];
+    for (int i = 0; i < np; i++) {
+        part *p = &parts[i];
+        int mvp[2], mv[2], ref = m->ref[(p->by >> 1) * 2 + (p->bx >> 1)];
+        mv_pred(e, p->bx, p->by, p->w, ref, p->shape, mvp);
+        pick_mv(e, e->mbx * 16 + p->bx * 4, e->mby * 16 + p->by * 4, p->w * 4, p->h * 4, e->refs[ref], mvp, mv);
+        p->mvd[0] = mv[0] - mvp[0], p->mvd[1] = mv[1] - mvp[1];
+        fill_part(e, p->bx, p->by, p->w, p->h, mv, p->mvd);
+        mc_part(e, p->bx, p->by, p->w, p->h, py, pc);
+    }
+    int qp = want_qp(e);
+    set_qpc(e, m, qp);
+    int all8 = 1;
+    if (kind == T_P8x8)
+        for (int i = 0; i < 4; i++)
+            if (m->sub[i]) all8 = 0;
+    m->t8x8 = (e->p.transform8x8 && all8 && rnd(e) % 2) ? 1 : 0;
+    code_luma_inter(e, py);
+    if (!m->cbp_luma) m->t8x8 = 0;
+    code_chroma(e, 0, pc);
+    /* ---- syntax ---- */
+    int raw = kind == T_P16 ? 0 : (kind == T_P16x8 ? 1 : (kind == T_P8x16 ? 2 : 3));
+    e->raw_type = raw;
+    if (cabac) {
+        sg_cabac_bin(w, 14, 0);
+        if (raw == 0 || raw == 3) {
+            sg_cabac_bin(w, 15, 0);
+            sg_cabac_bin(w, 16, raw == 3);
+        } else {
+            sg_cabac_bin(w, 15, 1);
+            sg_cabac_bin(w, 17, raw == 1);
+        }
+    } else
+        sg_put_ue(w, (uint32_t)raw);
+    if (kind == T_P8x8)
+        for (int i = 0; i < 4; i++) {
+            if (cabac) {
+                int st = m->sub[i];
+                sg_cabac_bin(w, 21, st == 0);
+                if (st) {
+                    sg_cabac_bin(w, 22, st != 1);
+                    if (st != 1) sg_cabac_bin(w, 23, st == 2);
+                }
+            } else
+                sg_put_ue(w, m->sub[i]);
+        }
+    if (nref > 1) {
+        /* the CABAC ctxIdxInc for ref_idx looks at refs of neighbouring partitions in *this* MB too: they
+         * are already final in m->ref[], but partitions that come later must read as "not yet known" =
+         * they are never consulted (A/B neighbours always precede). */
+        int nparts_ref = kind == T_P16 ? 1 : (kind == T_P8x8 ? 4 : 2);
+        for (int i = 0; i < nparts_ref; i++) {
+            int bx, by;
+            if (kind == T_P16)
+                bx = by = 0;
+            else if (kind == T_P16x8)
+                bx = 0, by = i * 2;
+            else if (kind == T_P8x16)
+                bx = i * 2, by = 0;
+            else
+                bx = (i & 1) * 2, by = (i >> 1) * 2;
+            int ref = m->ref[(by >> 1) * 2 + (bx >> 1)];
+            if (cabac)
+                cabac_ref(e, bx, by, ref);
+            else
+                sg_put_te(w, nref - 1, (uint32_t)ref);
+        }
+    }
+    for (int i = 0; i < np; i++) {
+        part *p = &parts[i];
+        if (cabac) {
+            cabac_mvd(e, 0, p->bx, p->by, p->mvd[0]);
+            cabac_mvd(e, 1, p->bx, p->by, p->mvd[1]);
+        } else {
+            sg_put_se(w, p->mvd[0]);
+            sg_put_se(w, p->mvd[1]);
+        }
+    }
+    int cbp = m->cbp_luma | (m->cbp_chroma << 4);
+    if (cabac)
+        cabac_cbp(e, cbp);
+    else {
+        int k = 0;
+        while (sg_me_inter[k] != cbp) k++;
+        sg_put_ue(w, (uint32_t)k);
+    }
+    if (m->cbp_luma && e->p.transform8x8 && all8) {
+        if (cabac) {
+            emb *a = MBA(e), *b = MBB(e);
+            sg_cabac_bin(w, 399 + (a && a->t8x8) + (b && b->t8x8), m->t8x8);
+        } else
+            sg_put(w, m->t8x8, 1);
+    }
+    if (cbp) {
+        int dqp = qp - e->qp;
+        if (cabac)
+            cabac_dqp(e, dqp);
+        else
+            sg_put_se(w, dqp);
+        e->prev_dqp_nz = dqp != 0;
+        e->qp = qp;
+        write_residual(e);
+    } else {
+        e->prev_dqp_nz = 0;
+        set_qpc(e, m, e->qp);
+    }
+}
+
+/* The CABAC mvd ctxIdxInc of partition k reads |mvd| of neighbouring partitions that precede k.  In
+ * encode_inter all partitions' mvd are already stored when the syntax is written, which would let
+ * a later partition's values leak into an earlier one's context if the A/B neighbour were a LATER
+ * partition -- impossible, since A (left) and B (above) always precede in decoding order. */
+
+/* ------------------------------------------------------------------ headers */
+static size_t write_sps(enc *e, uint8_t *dst, size_t cap) {
+    uint8_t buf[512];
+    sg_bw w;
+    const sg_params *p = &e->p;
+    sg_bw_init(&w, buf, sizeof(buf));
+    sg_put(&w, (uint32_t)p->profile_idc, 8);
+    sg_put(&w, p->profile_idc == 66 ? 0xC0 : (p->profile_idc == 77 ? 0x40 : 0), 8); /* constraint_set flags */
+    sg_put(&w, e->W * e->H > 1920 * 1088 ? 51 : 40, 8);                            /* level_idc */
+    sg_put_ue(&w, 0);                                                              /* sps id */
+    if (p->profile_idc == 100) {
+        sg_put_ue(&w, 1); /* chroma_format_idc */
+        sg_put_ue(&w, 0);
+        sg_put_ue(&w, 0);
+        sg_put(&w, 0, 1); /* qpprime_y_zero_transform_bypass */
+        sg_put(&w, p->scaling_matrix ? 1 : 0, 1);
+        if (p->scaling_matrix) {
+            /* lists 0 and 3 and 6,7: useDefault (delta_scale -8 at j=0 -> nextScale 0); others fall back */
+            for (int i = 0; i < 8; i++) {
+                int send = (i == 0 || i == 3 || i == 6 || i == 7);
+                sg_put(&w, (uint32_t)send, 1);
+                if (send) sg_put_se(&w, -8);
+            }
+        }
+    }
+    sg_put_ue(&w, 4); /* log2_max_frame_num_minus4 -> 8 bits */
+    sg_put_ue(&w, (uint32_t)p->poc_type);
+    if (p->poc_type == 0) sg_put_ue(&w, 4); /* log2_max_poc_lsb_minus4 -> 8 bits */
+    sg_put_ue(&w, (uint32_t)p->num_ref_frames);
+    sg_put(&w, 0, 1); /* gaps */
+    sg_put_ue(&w, (uint32_t)(e->wmb - 1));
+    sg_put_ue(&w, (uint32_t)(e->hmb - 1));
+    sg_put(&w, 1, 1); /* frame_mbs_only */
+    sg_put(&w, 1, 1); /* direct_8x8_inference */
+    int cr = (e->W - p->width) / 2, cb = (e->H - p->height) / 2;
+    sg_put(&w, cr || cb, 1);
+    if (cr || cb) {
+        sg_put_ue(&w, 0);
+        sg_put_ue(&w, (uint32_t)cr);
+        sg_put_ue(&w, 0);
+        sg_put_ue(&w, (uint32_t)cb);
+    }
+    sg_put(&w, 0, 1); /* vui */
+    sg_trailing(&w);
+    return sg_write_nal(dst, cap, 1, 3, 7, buf, sg_bw_bytes(&w));
+}
+static size_t write_pps(enc *e, uint8_t *dst, size_t cap) {
+    uint8_t buf[64];
+    sg_bw w;
+    const sg_params *p = &e->p;
+    sg_bw_init(&w, buf, sizeof(buf));
+    sg_put_ue(&w, 0);
+    sg_put_ue(&w, 0);
+    sg_put(&w, (uint32_t)p->cabac, 1);
+    sg_put(&w, 0, 1);
+    sg_put_ue(&w, 0); /* slice groups */
+    sg_put_ue(&w, (uint32_t)(p->num_ref_frames - 1));
+    sg_put_ue(&w, 0);
+    sg_put(&w, (uint32_t)p->weighted_pred, 1);
+    sg_put(&w, 0, 2);
+    sg_put_se(&w, p->qp - 26);
+    sg_put_se(&w, 0);
+    sg_put_se(&w, p->chroma_qp_offset);
+    sg_put(&w, 1, 1); /* deblocking_filter_control_present */
+    sg_put(&w, (uint32_t)p->constrained_intra, 1);
+    sg_put(&w, 0, 1);
+    if (p->profile_idc == 100) {
+        sg_put(&w, (uint32_t)p->transform8x8, 1);
+        sg_put(&w, 0, 1); /* pic_scaling_matrix_present */
+        sg_put_se(&w, p->chroma_qp_offset + (p->transform8x8 ? 1 : 0));
+    }
+    sg_trailing(&w);
+    return sg_write_nal(dst, cap, 1, 3, 8, buf, sg_bw_bytes(&w));
+}
+
+static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int idr_id, int poc_lsb) {
+    sg_bw *w = &e->bw;
+    const sg_params *p = &e->p;
+    int is_p = e->slice_type == 0;
+    sg_put_ue(w, (uint32_t)first_mb);
+    sg_put_ue(w, is_p ? 5 : 7); /* slice_type: all slices of the picture alike */
+    sg_put_ue(w, 0);
+    sg_put(w, (uint32_t)frame_num, 8);
+    if (idr) sg_put_ue(w, (uint32_t)idr_id);
+    if (p->poc_type == 0) sg_put(w, (uint32_t)poc_lsb, 8);
+    if (is_p) {
+        int over = e->nref_active != p->num_ref_frames;
+        sg_put(w, (uint32_t)over, 1);
+        if (over) sg_put_ue(w, (uint32_t)(e->nref_active - 1));
+        sg_put(w, 0, 1); /* ref_pic_list_modification_flag_l0 */
+        if (p->weighted_pred) {
+            sg_put_ue(w, (uint32_t)e->wp_ld);
+            sg_put_ue(w, (uint32_t)e->wp_cd);
+            for (int i = 0; i < e->nref_active; i++) {
+                int lf = e->wp_w[i] != (1 << e->wp_ld) || e->wp_o[i];
+                sg_put(w, (uint32_t)lf, 1);
+                if (lf) sg_put_se(w, e->wp_w[i]), sg_put_se(w, e->wp_o[i]);
+                int cf = e->wp_cw[i][0] != (1 << e->wp_cd) || e->wp_co[i][0] || e->wp_cw[i][1] != (1 << e->wp_cd) || e->wp_co[i][1];
+                sg_put(w, (uint32_t)cf, 1);
+                if (cf)
+                    for (int c = 0; c < 2; c++) sg_put_se(w, e->wp_cw[i][c]), sg_put_se(w, e->wp_co[i][c]);
+            }
+        }
+    }
+    /* dec_ref_pic_marking: every picture is a reference (nal_ref_idc 3) */
+    if (idr) {
+        sg_put(w, 0, 1);
+        sg_put(w, 0, 1);
+    } else
+        sg_put(w, 0, 1); /* sliding window */
+    if (p->cabac && is_p) sg_put_ue(w, (uint32_t)e->init_idc);
+    sg_put_se(w, 0); /* slice_qp_delta */
+    sg_put_ue(w, (uint32_t)p->deblock_idc);
+    if (p->deblock_idc != 1) {
+        sg_put_se(w, p->alpha_off_div2);
+        sg_put_se(w, p->beta_off_div2);
+    }
+}
+
+/* ------------------------------------------------------------------ top level */
+size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *recon, size_t recon_cap, uint32_t *frame_sizes) {
+    enc *e = (enc *)calloc(1, sizeof(enc));
+    size_t out = 0;
+    e->p = *pp;
+    sg_params *p = &e->p;
+    g_err[0] = 0;
+    if (p->num_ref_frames < 1) p->num_ref_frames = 1;
+    if (p->num_ref_frames > 4) p->num_ref_frames = 4;
+    if (p->slices < 1) p->slices = 1;
+    if (p->profile_idc != 100) p->transform8x8 = 0, p->scaling_matrix = 0;
+    if (p->profile_idc == 66) p->cabac = 0, p->weighted_pred = 0;
+    e->W = (p->width + 15) & ~15, e->H = (p->height + 15) & ~15;
+    e->wmb = e->W / 16, e->hmb = e->H / 16;
+    if (p->slices > e->hmb) p->slices = e->hmb;
+    e->rng = 0x9E3779B97F4A7C15ull ^ ((uint64_t)p->seed * 0xD1B54A32D192ED03ull);
+    if (!e->rng) e->rng = 1;
+    size_t fsz = (size_t)e->W * e->H * 3 / 2;
+    for (int i = 0; i < 6; i++) {
+        e->pics[i].pl[0] = (uint8_t *)malloc(fsz);
+        e->pics[i].pl[1] = e->pics[i].pl[0] + e->W * e->H;
+        e->pics[i].pl[2] = e->pics[i].pl[1] + e->W * e->H / 4;
+        e->pics[i].w = e->W, e->pics[i].h = e->H;
+    }
+    e->mb = (emb *)calloc((size_t)e->wmb * e->hmb, sizeof(emb));
+    e->db = (sg_dbmb *)calloc((size_t)e->wmb * e->hmb, sizeof(sg_dbmb));
+    e->src = (uint8_t *)malloc(fsz);
+    size_t slice_cap = fsz * 2 + 4096;
+    uint8_t *rbsp = (uint8_t *)malloc(slice_cap);
+    /* scaling lists: flat, or the spec's Default_* lists when scaling_matrix is set */
+    memset(e->s4, 16, sizeof(e->s4));
+    memset(e->s8, 16, sizeof(e->s8));
+    if (p->scaling_matrix) {
+        for (int l = 0; l < 6; l++) memcpy(e->s4[l], l < 3 ? sg_default4x4_intra : sg_default4x4_inter, 16);
+        memcpy(e->s8[0], sg_default8x8_intra, 64);
+        memcpy(e->s8[1], sg_default8x8_inter, 64);
+    }
+    build_scale(e);
+    int frame_num = 0, idr_id = 0, poc = 0;
+    for (int t = 0; t < p->frames; t++) {
+        size_t au_start = out;
+        int idr = t == 0 || (p->idr_period > 0 && t % p->idr_period == 0);
+        sg_source_frame(p, t, e->src);
+        if (idr) {
+            frame_num = 0, poc = 0, e->nrefs = 0;
+            size_t n = write_sps(e, stream + out, cap - out);
+            out += n;
+            n = write_pps(e, stream + out, cap - out);
+            out += n;
+            for (int i = 0; i < 6; i++) e->pics[i].is_ref = 0;
+        }
+        /* current picture buffer */
+        e->cur = NULL;
+        for (int i = 0; i < 6 && !e->cur; i++)
+            if (!e->pics[i].is_ref) e->cur = &e->pics[i];
+        e->cur->id = e->next_id++;
+        e->cur->frame_num = frame_num;
+        e->slice_type = idr ? 2 : 0;
+        e->nref_active = e->nrefs < p->num_ref_frames ? e->nrefs : p->num_ref_frames;
+        if (!idr && p->weighted_pred) {
+            e->wp_ld = 5, e->wp_cd = 4;
+            for (int i = 0; i < 4; i++) {
+                e->wp_w[i] = 32 + rnd_range(e, -3, 3), e->wp_o[i] = rnd_range(e, -2, 2);
+                for (int c = 0; c < 2; c++) e->wp_cw[i][c] = 16 + rnd_range(e, -1, 1), e->wp_co[i][c] = rnd_range(e, -1, 1);
+            }
+            e->wp_w[0] = 32, e->wp_o[0] = 0; /* first entry default: exercises the flag=0 path */
+        }
+        for (int i = 0; i < e->wmb * e->hmb; i++) e->mb[i].type = T_NONE;
+        for (int s = 0; s < p->slices; s++) {
+            int row0 = e->hmb * s / p->slices, row1 = e->hmb * (s + 1) / p->slices;
+            int first = row0 * e->wmb, last = row1 * e->wmb;
+            e->slice_id = s;
+            e->init_idc = p->cabac_init_idc >= 0 ? p->cabac_init_idc : (t + s) % 3;
+            sg_bw_init(&e->bw, rbsp, slice_cap);
+            write_slice_header(e, first, idr, frame_num, idr_id, poc & 255);
+            e->qp = p->qp, e->prev_dqp_nz = 0, e->skip_run = 0;
+            if (p->cabac) {
+                while (!sg_bw_aligned(&e->bw)) sg_put(&e->bw, 1, 1);
+                sg_cabac_init_ctx(&e->bw, idr ? 0 : 1 + e->init_idc, p->qp);
+                sg_cabac_start(&e->bw);
+            }
+            for (int addr = first; addr < last; addr++) {
+                begin_mb(e, addr);
+                if (idr)
+                    encode_intra(e, 1);
+                else {
+                    int r = (int)(rnd(e) % 1000), kind;
+                    if (r < p->skip_permille)
+                        kind = T_SKIP;
+                    else if (r < p->skip_permille + p->intra_in_p_permille)
+                        kind = T_I4; /* any intra */
+                    else if (r < p->skip_permille + p->intra_in_p_permille + p->sub8x8_permille)
+                        kind = T_P16x8 + (int)(rnd(e) % 3);
+                    else
+                        kind = T_P16;
+                    if (p->cabac) {
+                        emb *a = MBA(e), *b = MBB(e);
+                        sg_cabac_bin(&e->bw, 11 + (a && a->type != T_SKIP) + (b && b->type != T_SKIP), kind == T_SKIP);
+                    } else if (kind == T_SKIP)
+                        e->skip_run++;
+                    else {
+                        sg_put_ue(&e->bw, (uint32_t)e->skip_run);
+                        e->skip_run = 0;
+                    }
+                    if (kind == T_SKIP)
+                        encode_skip(e);
+                    else if (kind == T_I4)
+                        encode_intra(e, 0);
+                    else
+                        encode_inter(e, kind);
+                }
+                end_mb(e);
+                if (p->cabac) sg_cabac_terminate(&e->bw, addr == last - 1);
+            }
+            if (p->cabac)
+                while (!sg_bw_aligned(&e->bw)) sg_put(&e->bw, 0, 1);
+            else {
+                if (e->skip_run) sg_put_ue(&e->bw, (uint32_t)e->skip_run);
+                sg_trailing(&e->bw);
+            }
+            if (e->bw.overflow) {
+                snprintf(g_err, sizeof(g_err), "slice buffer overflow");
+                out = 0;
+                goto done;
+            }
+            size_t n = sg_write_nal(stream + out, cap - out, p->long_start_code || s == 0, 3, idr ? 5 : 1, rbsp, sg_bw_bytes(&e->bw));
+            if (!n) {
+                snprintf(g_err, sizeof(g_err), "stream buffer too small");
+                out = 0;
+                goto done;
+            }
+            out += n;
+        }
+        sg_deblock(e->cur, e->db, e->wmb, e->hmb);
+        if (recon && (size_t)(t + 1) * fsz <= recon_cap) memcpy(recon + (size_t)t * fsz, e->cur->pl[0], fsz);
+        /* sliding window: newest first */
+        e->cur->is_ref = 1;
+        if (e->nrefs == p->num_ref_frames) e->refs[e->nrefs - 1]->is_ref = 0, e->nrefs--;
+        for (int i = e->nrefs; i > 0; i--) e->refs[i] = e->refs[i - 1];
+        e->refs[0] = e->cur;
+        e->nrefs++;
+        frame_num = (frame_num + 1) & 255;
+        poc += 2;
+        if (idr) idr_id = (idr_id + 1) & 0xFFFF;
+        if (frame_sizes) frame_sizes[t] = (uint32_t)(out - au_start);
+    }
+done:
+    for (int i = 0; i < 6; i++) free(e->pics[i].pl[0]);
+    free(e->mb);
+    free(e->db);
+    free(e->src);
+    free(rbsp);
+    free(e);
+    return out;
+}
