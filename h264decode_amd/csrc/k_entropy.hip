@@ -1,0 +1,1044 @@
+// h264decode_amd/csrc/k_entropy.hip -- K1/K2: slice_data() entropy decoding on gfx950.
+//
+// One slice per wavefront (one 64-thread workgroup per slice).  The arithmetic decoder is a
+// serial dependency chain, so the syntax-element code is written wave-uniformly: every lane
+// executes the same decision sequence, and the lanes fan out only for the wide work --
+//   * bitstream prefetch: 2 KB chunks of the slice RBSP are pulled into a 4 KB LDS ring with
+//     one 32-byte load per lane (coalesced 128-B requests);
+//   * context initialisation: 460 states copied from the (table-set, QP) row of DevTables;
+//   * neighbour caches: top-row / left-column state (modes, nnz, refs, mvs, |mvd|) lives in LDS;
+//   * write-out: the 128-byte MbRec and the 832-byte coefficient block are assembled in LDS and
+//     stored with one dword / one dwordx4 per lane.
+// CABAC engine state (codIRange, scaled codIOffset, lookahead count) is wave-uniform; context
+// states, rangeTabLPS and transIdxLPS sit in LDS.
+//
+// Replaces: NewSliceData / MbPred (h264/slice.go:570-830, :252-454) and the arithmetic decoding
+// engine (h264/cabac.go:439-553); residual parsing, Intra4x4PredMode derivation and motion vector
+// prediction are absent from the reference and follow ITU-T H.264 7.3.5, 8.3.1.1, 8.4.1, 9.2, 9.3.
+#include <hip/hip_runtime.h>
+#include "mi_kernels.h"
+
+#define RING_WORDS 1024
+#define LANE (static_cast<int>(threadIdx.x))
+
+struct TopInfo { // edge state of a decoded MB as seen by its right / lower neighbours (48 bytes)
+    uint8_t type, t8x8, cbp, chroma_mode, cbf_dc, pad[3];
+    int8_t ipm[4];  // bottom row (top[]) or right column (left)
+    uint8_t nnz[8]; // luma edge [0..3], Cb edge [4..5], Cr edge [6..7]
+    int8_t ref[2];  // the two 8x8 blocks on the edge
+    uint8_t pad2[2];
+    int16_t mv[4][2];
+    uint8_t mvd[4][2];
+};
+static_assert(sizeof(TopInfo) == 48, "TopInfo layout");
+
+struct Shared {
+    uint32_t ring[RING_WORDS];
+    uint8_t ctx[464];
+    uint8_t range_lps[256];
+    uint8_t trans_lps[64];
+    uint8_t zz4[16], zz8[64], sig8[64], last8[64];
+    int16_t coef[MI_COEF_PER_MB];
+    MbRec rec;
+    TopInfo left, tl; // tl = top[] entry of column x-1 as it was for the row above
+    // Neighbour caches of the current MB.  6-wide grids: column 0 = left MB, 1..4 = current MB,
+    // 5 = right / top-right; row 0 = MB row above, rows 1..4 = current MB.
+    int8_t ipm_c[32];     // -2 unavailable, -1 not (yet) an I_NxN block
+    uint8_t nnz_c[32];    // 0x80 = unavailable
+    uint8_t nnzc_c[2][12]; // chroma 3x3 grids
+    int8_t ref_c[32];     // -2 unavailable or not yet decoded, -1 intra, >= 0 ref_idx (motion final)
+    int8_t refi_c[32];    // ref_idx as soon as parsed (CABAC ctxIdxInc of ref_idx)
+    int16_t mv_c[32][2];
+    uint8_t mvd_c[32][2];
+    int16_t lvl[16];      // CAVLC level scratch
+    int16_t tmp16[16];    // CAVLC 8x8 interleave scratch
+    int8_t refs8[4];
+    int8_t sub_type[4];
+    uint8_t cur_cbf_dc, pad[3];
+};
+#define GI(bx, by) (((by) + 1) * 6 + (bx) + 1)
+
+struct Ent {
+    Shared *s;
+    TopInfo *top; // [wmb]
+    const DevTables *tab;
+    const uint8_t *rbsp;
+    const SliceDesc *sd;
+    const PicDesc *pd;
+    MbRec *mbrec;
+    int16_t *coefs;
+    uint32_t rbsp_words, filled, bitpos;
+    uint32_t range, value;
+    int avail;
+    int qp, prev_dqp_nz, mbx, mby, cur_type, err;
+    int cabac, islice, wmb, hmb;
+};
+
+// ------------------------------------------------------------------ bitstream ring
+__device__ __forceinline__ void ring_fill(Ent &e) {
+    // 512 words = 2 KB per call: each lane loads 32 bytes; words are byte-swapped to MSB-first order
+    uint32_t base = e.filled + LANE * 8;
+    const uint4 *src = reinterpret_cast<const uint4 *>(e.rbsp) + (base >> 2);
+    uint4 a = make_uint4(0, 0, 0, 0), b = a;
+    if (base < e.rbsp_words) a = src[0];
+    if (base + 4 < e.rbsp_words) b = src[1];
+    uint32_t *dst = e.s->ring + (base & (RING_WORDS - 1));
+    dst[0] = __builtin_bswap32(a.x), dst[1] = __builtin_bswap32(a.y), dst[2] = __builtin_bswap32(a.z), dst[3] = __builtin_bswap32(a.w);
+    dst[4] = __builtin_bswap32(b.x), dst[5] = __builtin_bswap32(b.y), dst[6] = __builtin_bswap32(b.z), dst[7] = __builtin_bswap32(b.w);
+    e.filled += 512;
+    __syncthreads();
+}
+// keep at least 128 words (4096 bits) resident beyond the cursor
+__device__ __forceinline__ void ensure(Ent &e) {
+    if ((e.bitpos >> 5) + 128 > e.filled) {
+        __syncthreads();
+        ring_fill(e);
+    }
+}
+__device__ __forceinline__ uint32_t peek32(const Ent &e, uint32_t pos) {
+    uint32_t w = pos >> 5, sh = pos & 31;
+    uint64_t v = (static_cast<uint64_t>(e.s->ring[w & (RING_WORDS - 1)]) << 32) | e.s->ring[(w + 1) & (RING_WORDS - 1)];
+    return static_cast<uint32_t>((v << sh) >> 32);
+}
+__device__ __forceinline__ uint32_t get_bits(Ent &e, int n) { // 1..25
+    uint32_t v = peek32(e, e.bitpos) >> (32 - n);
+    e.bitpos += n;
+    return v;
+}
+__device__ __forceinline__ uint32_t get_bit(Ent &e) { return get_bits(e, 1); }
+__device__ __forceinline__ uint32_t get_ue(Ent &e) { // 9.1 with one CLZ
+    uint32_t w = peek32(e, e.bitpos);
+    if (w == 0) {
+        e.err = 1;
+        e.bitpos += 32;
+        return 0;
+    }
+    int lz = __clz(w);
+    if (lz > 15) {
+        e.bitpos += lz + 1;
+        return (1u << lz) - 1 + get_bits(e, lz);
+    }
+    e.bitpos += 2 * lz + 1;
+    return (w >> (31 - 2 * lz)) - 1;
+}
+__device__ __forceinline__ int get_se(Ent &e) {
+    uint32_t k = get_ue(e);
+    int m = static_cast<int>((k + 1) >> 1);
+    return (k & 1) ? m : -m;
+}
+
+// ------------------------------------------------------------------ CABAC engine (9.3.1.2, 9.3.3.2)
+// codIOffset is kept scaled: value = (codIOffset << avail) | next `avail` stream bits.
+__device__ __forceinline__ void cabac_refill(Ent &e) {
+    if (e.avail < 7) {
+        e.value = (e.value << 16) | (peek32(e, e.bitpos) >> 16);
+        e.bitpos += 16;
+        e.avail += 16;
+    }
+}
+__device__ __forceinline__ void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
+    e.range = 510;
+    e.value = get_bits(e, 9);
+    e.avail = 0;
+    cabac_refill(e);
+}
+__device__ __forceinline__ int cabac_bin(Ent &e, int ctx) { // DecodeDecision + state transition + RenormD
+    uint32_t st = e.s->ctx[ctx];
+    uint32_t p = st >> 1, mps = st & 1;
+    uint32_t rlps = e.s->range_lps[p * 4 + ((e.range >> 6) & 3)];
+    e.range -= rlps;
+    uint32_t scaled = e.range << e.avail;
+    int bin;
+    if (e.value >= scaled) {
+        e.value -= scaled;
+        e.range = rlps;
+        bin = static_cast<int>(mps ^ 1);
+        if (p == 0) mps ^= 1;
+        p = e.s->trans_lps[p];
+    } else {
+        bin = static_cast<int>(mps);
+        p = p < 62 ? p + 1 : p;
+    }
+    e.s->ctx[ctx] = static_cast<uint8_t>((p << 1) | mps);
+    int n = __clz(e.range) - 23; // RenormD (h264/cabac.go:503-511) in one step
+    e.range <<= n;
+    e.avail -= n;
+    cabac_refill(e);
+    return bin;
+}
+__device__ __forceinline__ int cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
+    e.avail -= 1;
+    uint32_t scaled = e.range << e.avail;
+    int bin = 0;
+    if (e.value >= scaled) {
+        e.value -= scaled;
+        bin = 1;
+    }
+    cabac_refill(e);
+    return bin;
+}
+__device__ __forceinline__ int cabac_terminate(Ent &e) { // 9.3.3.2.4
+    e.range -= 2;
+    uint32_t scaled = e.range << e.avail;
+    if (e.value >= scaled) return 1;
+    int n = __clz(e.range) - 23;
+    e.range <<= n;
+    e.avail -= n;
+    cabac_refill(e);
+    return 0;
+}
+
+// ------------------------------------------------------------------ neighbour MBs
+__device__ __forceinline__ const TopInfo *mbA(const Ent &e) { return e.s->left.type != MBT_NONE ? &e.s->left : nullptr; }
+__device__ __forceinline__ const TopInfo *mbB(const Ent &e) { return e.top[e.mbx].type != MBT_NONE ? &e.top[e.mbx] : nullptr; }
+
+// ------------------------------------------------------------------ CABAC syntax elements (9.3.2, 9.3.3.1)
+__device__ int cabac_intra_mb_type(Ent &e, int base, int islice) {
+    if (islice) {
+        const TopInfo *a = mbA(e), *b = mbB(e);
+        int inc = (a && a->type != MBT_I4x4 && a->type != MBT_I8x8) + (b && b->type != MBT_I4x4 && b->type != MBT_I8x8);
+        if (!cabac_bin(e, base + inc)) return 0;
+        base += 2;
+    } else if (!cabac_bin(e, base))
+        return 0;
+    if (cabac_terminate(e)) return 25;
+    int t = 1;
+    t += 12 * cabac_bin(e, base + 1);
+    if (cabac_bin(e, base + 2)) t += 4 + 4 * cabac_bin(e, base + 2 + islice);
+    t += 2 * cabac_bin(e, base + 3 + islice);
+    t += cabac_bin(e, base + 3 + 2 * islice);
+    return t;
+}
+__device__ int cabac_p_mb_type(Ent &e) {
+    if (!cabac_bin(e, 14)) {
+        if (!cabac_bin(e, 15)) return 3 * cabac_bin(e, 16);
+        return 2 - cabac_bin(e, 17);
+    }
+    return 5 + cabac_intra_mb_type(e, 17, 0);
+}
+__device__ int cabac_sub_mb_type(Ent &e) {
+    if (cabac_bin(e, 21)) return 0;
+    if (!cabac_bin(e, 22)) return 1;
+    return cabac_bin(e, 23) ? 2 : 3;
+}
+__device__ int cabac_cbp(Ent &e) {
+    const TopInfo *a = mbA(e), *b = mbB(e);
+    int cbp_a = a ? (a->type == MBT_IPCM ? 0x2F : a->cbp) : 0x0F;
+    int cbp_b = b ? (b->type == MBT_IPCM ? 0x2F : b->cbp) : 0x0F;
+    int cbp = 0;
+#pragma unroll
+    for (int b8 = 0; b8 < 4; b8++) {
+        int ca = (b8 & 1) ? (cbp >> (b8 - 1)) & 1 : (cbp_a >> (b8 + 1)) & 1;
+        int cb = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cbp_b >> (b8 + 2)) & 1;
+        cbp |= cabac_bin(e, 73 + (!ca) + 2 * (!cb)) << b8;
+    }
+    int ca = a && (a->type == MBT_IPCM || (a->cbp >> 4) != 0), cb = b && (b->type == MBT_IPCM || (b->cbp >> 4) != 0);
+    if (cabac_bin(e, 77 + ca + 2 * cb)) {
+        ca = a && (a->type == MBT_IPCM || (a->cbp >> 4) == 2);
+        cb = b && (b->type == MBT_IPCM || (b->cbp >> 4) == 2);
+        cbp |= (1 + cabac_bin(e, 77 + 4 + ca + 2 * cb)) << 4;
+    }
+    return cbp;
+}
+__device__ int cabac_dqp(Ent &e) {
+    int ctx = e.prev_dqp_nz ? 1 : 0, val = 0;
+    while (cabac_bin(e, 60 + ctx)) {
+        ctx = 2 + (ctx >> 1);
+        if (++val > 104) {
+            e.err = 2;
+            break;
+        }
+    }
+    return (val & 1) ? (val + 1) >> 1 : -((val + 1) >> 1);
+}
+__device__ int cabac_ref_idx(Ent &e, int bx, int by) {
+    int ra = e.s->refi_c[GI(bx - 1, by)], rb = e.s->refi_c[GI(bx, by - 1)];
+    int ctx = (ra > 0) + 2 * (rb > 0), ref = 0;
+    while (cabac_bin(e, 54 + ctx)) {
+        ctx = (ctx >> 2) + 4;
+        if (++ref > 31) {
+            e.err = 3;
+            break;
+        }
+    }
+    return ref;
+}
+__device__ int cabac_mvd(Ent &e, int comp, int bx, int by) {
+    int sum = e.s->mvd_c[GI(bx - 1, by)][comp] + e.s->mvd_c[GI(bx, by - 1)][comp];
+    int base = comp ? 47 : 40;
+    if (!cabac_bin(e, base + (sum > 2) + (sum > 32))) return 0;
+    int v = 1, ctx = base + 3;
+    while (v < 9 && cabac_bin(e, ctx)) {
+        if (v < 4) ctx++;
+        v++;
+    }
+    if (v >= 9) {
+        int k = 3;
+        while (cabac_bypass(e)) {
+            v += 1 << k;
+            if (++k > 24) {
+                e.err = 4;
+                break;
+            }
+        }
+        while (k--) v += cabac_bypass(e) << k;
+    }
+    return cabac_bypass(e) ? -v : v;
+}
+
+// residual_block_cabac 7.3.5.3.3.  CAT: 0 I16 DC, 1 I16 AC, 2 luma 4x4, 3 chroma DC, 4 chroma AC,
+// 5 luma 8x8.  Coefficients are written de-zig-zagged (raster inside the block).  Returns #non-zero.
+template <int CAT>
+__device__ int cabac_residual(Ent &e, int16_t *dst, int cbf_inc) {
+    constexpr int maxnum = CAT == 5 ? 64 : (CAT == 3 ? 4 : ((CAT == 1 || CAT == 4) ? 15 : 16));
+    constexpr int sig_off = CAT == 0 ? 0 : (CAT == 1 ? 15 : (CAT == 2 ? 29 : (CAT == 3 ? 44 : 47)));
+    constexpr int abs_off = CAT == 0 ? 0 : (CAT == 1 ? 10 : (CAT == 2 ? 20 : (CAT == 3 ? 30 : 39)));
+    constexpr int sbase = CAT == 5 ? 402 : 105 + sig_off, lbase = CAT == 5 ? 417 : 166 + sig_off;
+    constexpr int base = CAT == 5 ? 426 : 227 + abs_off;
+    constexpr int lim = CAT == 3 ? 3 : 4;
+    if (CAT != 5 && !cabac_bin(e, 85 + CAT * 4 + cbf_inc)) return 0;
+    uint64_t sigmask = 0;
+    int n = 0, last = 0;
+    for (int i = 0; i < maxnum - 1; i++) {
+        int inc_s, inc_l;
+        if (CAT == 5)
+            inc_s = e.s->sig8[i], inc_l = e.s->last8[i];
+        else
+            inc_s = inc_l = CAT == 3 ? (i < 2 ? i : 2) : i;
+        if (cabac_bin(e, sbase + inc_s)) {
+            sigmask |= 1ull << i;
+            n++;
+            if (cabac_bin(e, lbase + inc_l)) {
+                last = 1;
+                break;
+            }
+        }
+    }
+    if (!last) sigmask |= 1ull << (maxnum - 1), n++;
+    int eq1 = 0, gt1 = 0;
+    while (sigmask) {
+        int k = 63 - __clzll(static_cast<long long>(sigmask));
+        sigmask &= ~(1ull << k);
+        int inc0 = gt1 ? 0 : (1 + eq1 < 4 ? 1 + eq1 : 4), a;
+        if (!cabac_bin(e, base + inc0)) {
+            a = 1;
+            eq1++;
+        } else {
+            int inc = 5 + (gt1 < lim ? gt1 : lim);
+            a = 2;
+            while (a < 15 && cabac_bin(e, base + inc)) a++;
+            if (a >= 15) {
+                int kk = 0;
+                while (cabac_bypass(e)) {
+                    a += 1 << kk;
+                    if (++kk > 24) {
+                        e.err = 5;
+                        break;
+                    }
+                }
+                while (kk--) a += cabac_bypass(e) << kk;
+            }
+            gt1++;
+        }
+        int v = cabac_bypass(e) ? -a : a;
+        int pos;
+        if (CAT == 5)
+            pos = e.s->zz8[k];
+        else if (CAT == 3)
+            pos = k;
+        else if (CAT == 1 || CAT == 4)
+            pos = e.s->zz4[k + 1];
+        else
+            pos = e.s->zz4[k];
+        dst[pos] = static_cast<int16_t>(v);
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------ CAVLC residual_block_cavlc (9.2)
+// KIND: 0 = 16 coefficients, 1 = 15 (AC, positions 1..15), 2 = chroma DC (4), 3 = 16 coefficients
+// written in scan order (CAVLC + 8x8 transform interleave)
+template <int KIND>
+__device__ int cavlc_residual(Ent &e, int16_t *dst, int nC) {
+    const DevTables *t = e.tab;
+    constexpr int maxnum = KIND == 1 ? 15 : (KIND == 2 ? 4 : 16);
+    uint32_t w = peek32(e, e.bitpos);
+    uint32_t ent;
+    if (KIND == 2)
+        ent = t->vlc_cdc[w >> 24];
+    else if (nC < 2)
+        ent = t->vlc_ct0[w >> (32 - MI_VLC_CT0_BITS)];
+    else if (nC < 4)
+        ent = t->vlc_ct1[w >> (32 - MI_VLC_CT1_BITS)];
+    else if (nC < 8)
+        ent = t->vlc_ct2[w >> (32 - MI_VLC_CT2_BITS)];
+    else
+        ent = t->vlc_ct3[w >> 26];
+    if (!(ent >> 8)) {
+        e.err = 6;
+        return 0;
+    }
+    e.bitpos += ent >> 8;
+    int total = (ent >> 2) & 31, t1s = ent & 3;
+    if (total == 0) return 0;
+    if (total > maxnum) {
+        e.err = 7;
+        return 0;
+    }
+    int suffix_len = (total > 10 && t1s < 3) ? 1 : 0;
+    for (int i = 0; i < total; i++) {
+        if (i < t1s) {
+            e.s->lvl[i] = static_cast<int16_t>(1 - 2 * static_cast<int>(get_bit(e)));
+            continue;
+        }
+        uint32_t ww = peek32(e, e.bitpos);
+        if (ww == 0) {
+            e.err = 8;
+            return 0;
+        }
+        int prefix = __clz(ww);
+        e.bitpos += prefix + 1;
+        int code = (prefix < 15 ? prefix : 15) << suffix_len;
+        if (suffix_len > 0 || prefix >= 14) {
+            int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
+            if (size > 0) code += get_bits(e, size);
+        }
+        if (prefix >= 15 && suffix_len == 0) code += 15;
+        if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+        if (i == t1s && t1s < 3) code += 2;
+        int lv = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
+        e.s->lvl[i] = static_cast<int16_t>(lv);
+        if (suffix_len == 0) suffix_len = 1;
+        int al = lv < 0 ? -lv : lv;
+        if (al > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+    }
+    int zeros_left = 0;
+    if (total < maxnum) {
+        uint32_t ww = peek32(e, e.bitpos);
+        uint32_t en = KIND == 2 ? t->vlc_cdc_tz[total - 1][ww >> 29] : t->vlc_tz[total - 1][ww >> 23];
+        if (!(en >> 8)) {
+            e.err = 9;
+            return 0;
+        }
+        e.bitpos += en >> 8;
+        zeros_left = en & 255;
+    }
+    int pos = zeros_left + total - 1; // scan position of the highest-frequency coefficient
+    if (pos >= maxnum) {
+        e.err = 10;
+        return 0;
+    }
+    for (int i = 0; i < total; i++) {
+        int p = (KIND == 2 || KIND == 3) ? pos : e.s->zz4[pos + (KIND == 1)];
+        dst[p] = e.s->lvl[i];
+        if (i < total - 1) {
+            int run = 0;
+            if (zeros_left > 0) {
+                uint32_t ww = peek32(e, e.bitpos);
+                uint32_t en = t->vlc_run[(zeros_left > 7 ? 7 : zeros_left) - 1][ww >> 21];
+                if (!(en >> 8) || static_cast<int>(en & 255) > zeros_left) {
+                    e.err = 11;
+                    return 0;
+                }
+                e.bitpos += en >> 8;
+                run = en & 255;
+                zeros_left -= run;
+            }
+            pos -= run + 1;
+        }
+    }
+    return total;
+}
+
+// ------------------------------------------------------------------ residual() 7.3.5.3
+__device__ __forceinline__ int nc_of(uint8_t a, uint8_t b) { // 9.2.1
+    int av = !(a & 0x80), bv = !(b & 0x80);
+    if (av && bv) return (a + b + 1) >> 1;
+    return av ? a : (bv ? b : 0);
+}
+__device__ __forceinline__ int cbf_inc_of(const Ent &e, uint8_t a, uint8_t b) { // 9.3.3.1.1.9
+    int ci = MB_IS_INTRA(e.cur_type);
+    int ca = (a & 0x80) ? ci : (a != 0), cb = (b & 0x80) ? ci : (b != 0);
+    return ca + 2 * cb;
+}
+__device__ __forceinline__ int cbf_inc_dc(const Ent &e, int bit) {
+    const TopInfo *a = mbA(e), *b = mbB(e);
+    int ci = MB_IS_INTRA(e.cur_type);
+    return (a ? (a->cbf_dc >> bit) & 1 : ci) + 2 * (b ? (b->cbf_dc >> bit) & 1 : ci);
+}
+
+__device__ void parse_residual(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
+    Shared *s = e.s;
+    const int i16 = e.cur_type == MBT_I16x16;
+    int nzmask = 0;
+    if (i16) {
+        int n = e.cabac ? cabac_residual<0>(e, s->coef + MI_COEF_I16DC, cbf_inc_dc(e, 0))
+                        : cavlc_residual<0>(e, s->coef + MI_COEF_I16DC, nc_of(s->nnz_c[GI(-1, 0)], s->nnz_c[GI(0, -1)]));
+        if (n) s->cur_cbf_dc |= 1;
+    }
+    for (int b8 = 0; b8 < 4; b8++) {
+        if (!((cbp_luma >> b8) & 1)) continue;
+        ensure(e);
+        int bx0 = (b8 & 1) * 2, by0 = (b8 >> 1) * 2;
+        if (t8x8 && e.cabac) {
+            int n = cabac_residual<5>(e, s->coef + b8 * 64, -1);
+            s->nnz_c[GI(bx0, by0)] = s->nnz_c[GI(bx0 + 1, by0)] = s->nnz_c[GI(bx0, by0 + 1)] = s->nnz_c[GI(bx0 + 1, by0 + 1)] = static_cast<uint8_t>(n);
+            if (n) nzmask |= 0x33 << (by0 * 4 + bx0);
+            continue;
+        }
+        int any = 0;
+        for (int b4 = 0; b4 < 4; b4++) {
+            int bx = bx0 + (b4 & 1), by = by0 + (b4 >> 1), r = by * 4 + bx, n;
+            uint8_t na = s->nnz_c[GI(bx - 1, by)], nb = s->nnz_c[GI(bx, by - 1)];
+            if (t8x8) { // CAVLC + 8x8 transform: 4x4 "block" b4 carries coefficients 4*i + b4 of the 8x8 scan (7.3.5.3.2)
+                for (int i = 0; i < 16; i++) s->tmp16[i] = 0;
+                n = cavlc_residual<3>(e, s->tmp16, nc_of(na, nb));
+                for (int i = 0; i < 16; i++) {
+                    int16_t v = s->tmp16[i];
+                    if (v) s->coef[b8 * 64 + s->zz8[4 * i + b4]] = v;
+                }
+            } else if (i16)
+                n = e.cabac ? cabac_residual<1>(e, s->coef + r * 16, cbf_inc_of(e, na, nb)) : cavlc_residual<1>(e, s->coef + r * 16, nc_of(na, nb));
+            else
+                n = e.cabac ? cabac_residual<2>(e, s->coef + r * 16, cbf_inc_of(e, na, nb)) : cavlc_residual<0>(e, s->coef + r * 16, nc_of(na, nb));
+            s->nnz_c[GI(bx, by)] = static_cast<uint8_t>(n);
+            if (n) nzmask |= 1 << r, any = 1;
+        }
+        if (t8x8 && any) nzmask |= 0x33 << (by0 * 4 + bx0);
+    }
+    s->rec.nzmask = static_cast<uint16_t>(nzmask);
+    if (cbp_chroma) {
+        ensure(e);
+        for (int c = 0; c < 2; c++) {
+            int n = e.cabac ? cabac_residual<3>(e, s->coef + MI_COEF_CDC + 4 * c, cbf_inc_dc(e, 1 + c)) : cavlc_residual<2>(e, s->coef + MI_COEF_CDC + 4 * c, -1);
+            if (n) s->cur_cbf_dc |= static_cast<uint8_t>(2 << c);
+        }
+    }
+    if (cbp_chroma & 2)
+        for (int c = 0; c < 2; c++)
+            for (int b4 = 0; b4 < 4; b4++) {
+                int cx = b4 & 1, cy = b4 >> 1;
+                uint8_t na = s->nnzc_c[c][(cy + 1) * 3 + cx], nb = s->nnzc_c[c][cy * 3 + cx + 1];
+                int16_t *dst = s->coef + MI_COEF_CAC + (c * 4 + b4) * 16;
+                int n = e.cabac ? cabac_residual<4>(e, dst, cbf_inc_of(e, na, nb)) : cavlc_residual<1>(e, dst, nc_of(na, nb));
+                s->nnzc_c[c][(cy + 1) * 3 + cx + 1] = static_cast<uint8_t>(n);
+            }
+}
+
+// ------------------------------------------------------------------ motion vector prediction 8.4.1.3
+__device__ __forceinline__ int median3(int a, int b, int c) {
+    int mn = a < b ? a : b, mx = a < b ? b : a;
+    return c < mn ? mn : (c > mx ? mx : c);
+}
+// shape: 0 median, 1/2 = 16x8 upper/lower, 3/4 = 8x16 left/right
+__device__ void predict_mv(const Ent &e, int bx, int by, int w, int ref, int shape, int &px, int &py) {
+    const Shared *s = e.s;
+    int ia = GI(bx - 1, by), ib = GI(bx, by - 1), ic = GI(bx + w, by - 1);
+    int ra = s->ref_c[ia], rb = s->ref_c[ib], rc = s->ref_c[ic];
+    if (rc == -2) {
+        ic = GI(bx - 1, by - 1);
+        rc = s->ref_c[ic];
+    }
+    int ax = s->mv_c[ia][0], ay = s->mv_c[ia][1], bxv = s->mv_c[ib][0], byv = s->mv_c[ib][1], cx = s->mv_c[ic][0], cy = s->mv_c[ic][1];
+    if (shape == 1 && rb == ref) {
+        px = bxv, py = byv;
+        return;
+    }
+    if ((shape == 2 || shape == 3) && ra == ref) {
+        px = ax, py = ay;
+        return;
+    }
+    if (shape == 4 && rc == ref) {
+        px = cx, py = cy;
+        return;
+    }
+    if (rb == -2 && rc == -2 && ra != -2) rb = rc = ra, bxv = cx = ax, byv = cy = ay;
+    int na = ra == ref, nb = rb == ref, nc = rc == ref;
+    if (na + nb + nc == 1) {
+        px = na ? ax : (nb ? bxv : cx);
+        py = na ? ay : (nb ? byv : cy);
+        return;
+    }
+    px = median3(ax, bxv, cx);
+    py = median3(ay, byv, cy);
+}
+__device__ void set_part(Ent &e, int bx, int by, int w, int h, int ref, int mvx, int mvy, int dx, int dy) {
+    Shared *s = e.s;
+    uint8_t ax = static_cast<uint8_t>(min(abs(dx), 255)), ay = static_cast<uint8_t>(min(abs(dy), 255));
+    for (int y = by; y < by + h; y++)
+        for (int x = bx; x < bx + w; x++) {
+            int g = GI(x, y);
+            s->ref_c[g] = static_cast<int8_t>(ref);
+            s->mv_c[g][0] = static_cast<int16_t>(mvx), s->mv_c[g][1] = static_cast<int16_t>(mvy);
+            s->mvd_c[g][0] = ax, s->mvd_c[g][1] = ay;
+        }
+}
+__device__ void do_part(Ent &e, int bx, int by, int w, int h, int ref, int shape) {
+    int dx, dy, px, py;
+    if (e.cabac) {
+        dx = cabac_mvd(e, 0, bx, by);
+        dy = cabac_mvd(e, 1, bx, by);
+    } else {
+        dx = get_se(e);
+        dy = get_se(e);
+    }
+    predict_mv(e, bx, by, w, ref, shape, px, py);
+    set_part(e, bx, by, w, h, ref, px + dx, py + dy, dx, dy);
+}
+// ref_idx_l0 of one partition; also records it for the ctxIdxInc of later partitions and for the MbRec
+__device__ int read_ref_idx(Ent &e, int bx, int by, int w, int h) {
+    int nref = e.sd->num_ref_idx_active, ref;
+    if (nref <= 1)
+        ref = 0;
+    else if (e.cabac)
+        ref = cabac_ref_idx(e, bx, by);
+    else if (nref == 2)
+        ref = !get_bit(e);
+    else
+        ref = static_cast<int>(get_ue(e));
+    if (ref >= nref || ref >= MI_MAX_REFS) e.err = 13, ref = 0;
+    for (int y = by; y < by + h; y++)
+        for (int x = bx; x < bx + w; x++) e.s->refi_c[GI(x, y)] = static_cast<int8_t>(ref);
+    for (int y = by; y < by + h; y += 2)
+        for (int x = bx; x < bx + w; x += 2) e.s->refs8[(y >> 1) * 2 + (x >> 1)] = static_cast<int8_t>(ref);
+    return ref;
+}
+
+// ------------------------------------------------------------------ per-MB neighbour caches
+__device__ void fill_caches(Ent &e) {
+    Shared *s = e.s;
+    const TopInfo *a = mbA(e), *b = mbB(e);
+    const TopInfo *c = (e.mbx + 1 < e.wmb && e.top[e.mbx + 1].type != MBT_NONE) ? &e.top[e.mbx + 1] : nullptr;
+    const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
+    const int cip = e.pd->cip;
+    const int l = LANE;
+    if (l < 30) {
+        int gx = l % 6 - 1, gy = l / 6 - 1; // block coordinates relative to the MB
+        int8_t ipm = -2, ref = -2;
+        uint8_t nnz = 0x80, mvdx = 0, mvdy = 0;
+        int16_t mvx = 0, mvy = 0;
+        const TopInfo *n = nullptr;
+        int k = 0; // index inside the neighbour's edge arrays
+        int edge = 0;
+        if (gy < 0 && gx >= 0 && gx < 4)
+            n = b, k = gx, edge = 1;
+        else if (gx < 0 && gy >= 0)
+            n = a, k = gy, edge = 1;
+        else if (gy < 0 && gx < 0)
+            n = d, k = 3;
+        else if (gy < 0 && gx == 4)
+            n = c, k = 0;
+        if (n) {
+            int inter = MB_IS_INTER(n->type);
+            if (!(cip && inter)) ipm = (n->type == MBT_I4x4 || n->type == MBT_I8x8) ? n->ipm[k] : static_cast<int8_t>(2);
+            if (edge) nnz = n->nnz[k];
+            if (inter) {
+                ref = n->ref[k >> 1];
+                mvx = n->mv[k][0], mvy = n->mv[k][1];
+                mvdx = n->mvd[k][0], mvdy = n->mvd[k][1];
+            } else
+                ref = -1;
+        }
+        if (gx >= 0 && gx < 4 && gy >= 0) { // interior: current MB, nothing decoded yet
+            nnz = 0;
+            ipm = -1;
+        }
+        s->ipm_c[l] = ipm;
+        s->nnz_c[l] = nnz;
+        s->ref_c[l] = ref;
+        s->refi_c[l] = ref;
+        s->mv_c[l][0] = mvx, s->mv_c[l][1] = mvy;
+        s->mvd_c[l][0] = mvdx, s->mvd_c[l][1] = mvdy;
+    } else if (l >= 32 && l < 50) {
+        int i = l - 32, cpl = i / 9, g = i % 9, gx = g % 3 - 1, gy = g / 3 - 1;
+        uint8_t v = 0x80;
+        if (gy < 0 && gx >= 0) {
+            if (b) v = b->nnz[4 + cpl * 2 + gx];
+        } else if (gx < 0 && gy >= 0) {
+            if (a) v = a->nnz[4 + cpl * 2 + gy];
+        } else if (gx >= 0 && gy >= 0)
+            v = 0;
+        s->nnzc_c[cpl][g] = v;
+    } else if (l >= 50 && l < 54) {
+        s->refs8[l - 50] = -1;
+        s->sub_type[l - 50] = 0;
+    } else if (l == 54)
+        s->cur_cbf_dc = 0;
+    { // zero the coefficient staging block: 416 int16 = 208 dwords
+        uint32_t *cz = reinterpret_cast<uint32_t *>(s->coef);
+        for (int i = l; i < MI_COEF_PER_MB / 2; i += 64) cz[i] = 0;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ int pred_intra_mode(const Ent &e, int bx, int by) { // 8.3.1.1 / 8.3.2.1
+    int a = e.s->ipm_c[GI(bx - 1, by)], b = e.s->ipm_c[GI(bx, by - 1)];
+    if (a < -1 || b < -1) return 2; // dcPredModePredictedFlag
+    return a < b ? a : b;
+}
+
+// ------------------------------------------------------------------ macroblock_layer() 7.3.5
+__device__ void decode_mb(Ent &e, int skipped) {
+    Shared *s = e.s;
+    MbRec &r = s->rec;
+    const int cabac = e.cabac, islice = e.islice;
+    int cbp_luma = 0, cbp_chroma = 0, t8x8 = 0, i16mode = 0, chroma_mode = 0, has_coef = 0;
+    int type;
+    const TopInfo *a = mbA(e), *b = mbB(e);
+    r.nzmask = 0;
+    if (skipped) {
+        type = MBT_PSKIP;
+        e.cur_type = type;
+        int mvx = 0, mvy = 0; // 8.4.1.1
+        int ra = s->ref_c[GI(-1, 0)], rb = s->ref_c[GI(0, -1)];
+        bool zero = ra == -2 || rb == -2 || (ra == 0 && s->mv_c[GI(-1, 0)][0] == 0 && s->mv_c[GI(-1, 0)][1] == 0) ||
+                    (rb == 0 && s->mv_c[GI(0, -1)][0] == 0 && s->mv_c[GI(0, -1)][1] == 0);
+        if (!zero) predict_mv(e, 0, 0, 4, 0, 0, mvx, mvy);
+        set_part(e, 0, 0, 4, 4, 0, mvx, mvy, 0, 0);
+        s->refs8[0] = s->refs8[1] = s->refs8[2] = s->refs8[3] = 0;
+        e.prev_dqp_nz = 0;
+    } else {
+        int raw = cabac ? (islice ? cabac_intra_mb_type(e, 3, 1) : cabac_p_mb_type(e)) : static_cast<int>(get_ue(e));
+        int it = islice ? raw : raw - 5;
+        if (!islice && raw < 5)
+            type = raw == 0 ? MBT_P16x16 : (raw == 1 ? MBT_P16x8 : (raw == 2 ? MBT_P8x16 : MBT_P8x8));
+        else if (it == 0)
+            type = MBT_I4x4;
+        else if (it >= 1 && it <= 24) {
+            type = MBT_I16x16;
+            i16mode = (it - 1) & 3;
+            cbp_chroma = ((it - 1) >> 2) % 3;
+            cbp_luma = it >= 13 ? 15 : 0;
+        } else if (it == 25)
+            type = MBT_IPCM;
+        else {
+            e.err = 20;
+            type = MBT_I4x4;
+        }
+        e.cur_type = type;
+        if (type == MBT_IPCM) {
+            // after the terminate bin the arithmetic decoder has consumed exactly what the encoder's
+            // flush wrote (9.3.1.2 / 9.3.4.5): stream position = bits fetched - lookahead
+            if (cabac) e.bitpos -= e.avail;
+            e.bitpos = (e.bitpos + 7) & ~7u;
+            ensure(e);
+            uint8_t *pcm = reinterpret_cast<uint8_t *>(s->coef);
+            for (int i = 0; i < 384; i += 4) {
+                uint32_t w = peek32(e, e.bitpos + i * 8);
+                pcm[i] = static_cast<uint8_t>(w >> 24), pcm[i + 1] = static_cast<uint8_t>(w >> 16);
+                pcm[i + 2] = static_cast<uint8_t>(w >> 8), pcm[i + 3] = static_cast<uint8_t>(w);
+            }
+            e.bitpos += 384 * 8;
+            ensure(e);
+            if (cabac) cabac_start(e);
+            for (int i = 0; i < 16; i++) s->nnz_c[GI(i & 3, i >> 2)] = 16;
+            for (int c = 0; c < 2; c++)
+                for (int i = 0; i < 4; i++) s->nnzc_c[c][((i >> 1) + 1) * 3 + (i & 1) + 1] = 16;
+            for (int i = 0; i < 16; i++) s->ref_c[GI(i & 3, i >> 2)] = -1;
+            s->cur_cbf_dc = 7;
+            r.nzmask = 0xFFFF;
+            cbp_luma = 15, cbp_chroma = 2;
+            has_coef = 1;
+            e.prev_dqp_nz = 0;
+        } else {
+            if (type == MBT_P8x8) {
+                for (int i = 0; i < 4; i++) {
+                    int st = cabac ? cabac_sub_mb_type(e) : static_cast<int>(get_ue(e));
+                    if (st > 3) e.err = 21, st = 0;
+                    s->sub_type[i] = static_cast<int8_t>(st);
+                }
+                for (int i = 0; i < 4; i++) {
+                    if (raw == 4) {
+                        s->refs8[i] = 0;
+                        continue;
+                    }
+                    read_ref_idx(e, (i & 1) * 2, (i >> 1) * 2, 2, 2);
+                }
+                for (int i = 0; i < 4; i++) {
+                    int bx = (i & 1) * 2, by = (i >> 1) * 2, ref = s->refs8[i];
+                    switch (s->sub_type[i]) {
+                    case 0: do_part(e, bx, by, 2, 2, ref, 0); break;
+                    case 1:
+                        do_part(e, bx, by, 2, 1, ref, 0);
+                        do_part(e, bx, by + 1, 2, 1, ref, 0);
+                        break;
+                    case 2:
+                        do_part(e, bx, by, 1, 2, ref, 0);
+                        do_part(e, bx + 1, by, 1, 2, ref, 0);
+                        break;
+                    default:
+                        do_part(e, bx, by, 1, 1, ref, 0);
+                        do_part(e, bx + 1, by, 1, 1, ref, 0);
+                        do_part(e, bx, by + 1, 1, 1, ref, 0);
+                        do_part(e, bx + 1, by + 1, 1, 1, ref, 0);
+                    }
+                }
+            } else if (type == MBT_P16x16) {
+                int ref = read_ref_idx(e, 0, 0, 4, 4);
+                do_part(e, 0, 0, 4, 4, ref, 0);
+            } else if (type == MBT_P16x8) {
+                int r0 = read_ref_idx(e, 0, 0, 4, 2);
+                int r1 = read_ref_idx(e, 0, 2, 4, 2);
+                do_part(e, 0, 0, 4, 2, r0, 1);
+                do_part(e, 0, 2, 4, 2, r1, 2);
+            } else if (type == MBT_P8x16) {
+                int r0 = read_ref_idx(e, 0, 0, 2, 4);
+                int r1 = read_ref_idx(e, 2, 0, 2, 4);
+                do_part(e, 0, 0, 2, 4, r0, 3);
+                do_part(e, 2, 0, 2, 4, r1, 4);
+            } else {
+                // intra: transform_size_8x8_flag, prediction modes, intra_chroma_pred_mode (7.3.5, 7.3.5.1)
+                if (type == MBT_I4x4 && e.pd->t8x8_mode) {
+                    t8x8 = cabac ? cabac_bin(e, 399 + (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
+                    if (t8x8) type = MBT_I8x8, e.cur_type = type;
+                }
+                if (type == MBT_I4x4 || type == MBT_I8x8) {
+                    int n = type == MBT_I8x8 ? 4 : 16;
+                    for (int i = 0; i < n; i++) {
+                        int bx, by;
+                        if (n == 4)
+                            bx = (i & 1) * 2, by = (i >> 1) * 2;
+                        else
+                            bx = (i & 1) + 2 * ((i >> 2) & 1), by = ((i >> 1) & 1) + 2 * (i >> 3);
+                        int pred = pred_intra_mode(e, bx, by), mode;
+                        int flag = cabac ? cabac_bin(e, 68) : static_cast<int>(get_bit(e));
+                        if (flag)
+                            mode = pred;
+                        else {
+                            int rem;
+                            if (cabac) {
+                                rem = cabac_bin(e, 69);
+                                rem |= cabac_bin(e, 69) << 1;
+                                rem |= cabac_bin(e, 69) << 2;
+                            } else
+                                rem = static_cast<int>(get_bits(e, 3));
+                            mode = rem < pred ? rem : rem + 1;
+                        }
+                        s->ipm_c[GI(bx, by)] = static_cast<int8_t>(mode);
+                        if (n == 4) s->ipm_c[GI(bx + 1, by)] = s->ipm_c[GI(bx, by + 1)] = s->ipm_c[GI(bx + 1, by + 1)] = static_cast<int8_t>(mode);
+                    }
+                }
+                if (cabac) {
+                    int inc = (a && MB_IS_INTRA(a->type) && a->type != MBT_IPCM && a->chroma_mode != 0) +
+                              (b && MB_IS_INTRA(b->type) && b->type != MBT_IPCM && b->chroma_mode != 0);
+                    if (!cabac_bin(e, 64 + inc))
+                        chroma_mode = 0;
+                    else if (!cabac_bin(e, 67))
+                        chroma_mode = 1;
+                    else
+                        chroma_mode = cabac_bin(e, 67) ? 3 : 2;
+                } else {
+                    chroma_mode = static_cast<int>(get_ue(e));
+                    if (chroma_mode > 3) e.err = 22, chroma_mode = 0;
+                }
+                for (int i = 0; i < 16; i++) s->ref_c[GI(i & 3, i >> 2)] = -1;
+            }
+            if (type != MBT_I16x16) {
+                int cbp;
+                if (cabac)
+                    cbp = cabac_cbp(e);
+                else {
+                    uint32_t k = get_ue(e);
+                    if (k > 47) e.err = 23, k = 0;
+                    cbp = MB_IS_INTRA(type) ? e.tab->me_intra[k] : e.tab->me_inter[k];
+                }
+                cbp_luma = cbp & 15, cbp_chroma = cbp >> 4;
+                if (cbp_luma && e.pd->t8x8_mode && MB_IS_INTER(type)) {
+                    int all8 = 1;
+                    if (type == MBT_P8x8)
+                        for (int i = 0; i < 4; i++) all8 &= s->sub_type[i] == 0;
+                    if (all8) t8x8 = cabac ? cabac_bin(e, 399 + (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
+                }
+            }
+            if (cbp_luma || cbp_chroma || type == MBT_I16x16) {
+                int dqp = cabac ? cabac_dqp(e) : get_se(e);
+                if (dqp < -26 || dqp > 25) e.err = 24, dqp = 0;
+                e.prev_dqp_nz = dqp != 0;
+                e.qp = (e.qp + dqp + 52) % 52;
+                parse_residual(e, cbp_luma, cbp_chroma, t8x8);
+                has_coef = 1;
+            } else
+                e.prev_dqp_nz = 0;
+        }
+    }
+    // ---- scalar fields of the record ----
+    const int qp_store = type == MBT_IPCM ? 0 : e.qp;
+    r.type = static_cast<uint8_t>(type);
+    r.t8x8 = static_cast<uint8_t>(t8x8);
+    r.qp = static_cast<uint8_t>(qp_store);
+    r.qpc[0] = e.tab->qpc[min(max(qp_store + e.pd->cqp_off[0], 0), 51)];
+    r.qpc[1] = e.tab->qpc[min(max(qp_store + e.pd->cqp_off[1], 0), 51)];
+    r.cbp = static_cast<uint8_t>(cbp_luma | (cbp_chroma << 4));
+    r.chroma_mode = static_cast<uint8_t>(chroma_mode);
+    r.i16mode = static_cast<uint8_t>(i16mode);
+    {
+        // neighbour availability for intra prediction (6.4.x; constrained_intra_pred 8.3.1.2)
+        const int cip = e.pd->cip;
+        int av = 0;
+        const TopInfo *c = (e.mbx + 1 < e.wmb && e.top[e.mbx + 1].type != MBT_NONE) ? &e.top[e.mbx + 1] : nullptr;
+        const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
+        if (a && !(cip && MB_IS_INTER(a->type))) av |= MI_AV_LEFT;
+        if (b && !(cip && MB_IS_INTER(b->type))) av |= MI_AV_TOP;
+        if (d && !(cip && MB_IS_INTER(d->type))) av |= MI_AV_TOPLEFT;
+        if (c && !(cip && MB_IS_INTER(c->type))) av |= MI_AV_TOPRIGHT;
+        r.avail = static_cast<uint8_t>(av);
+    }
+    r.dbf_idc = e.sd->dbf_idc;
+    r.alpha_off = e.sd->alpha_off, r.beta_off = e.sd->beta_off;
+    r.slice_in_pic = e.sd->slice_in_pic;
+    r.slice_idx = blockIdx.x;
+    __syncthreads();
+    // ---- parallel part: per-block arrays of the record, write-out, neighbour state update ----
+    const int l = LANE;
+    const int inter = MB_IS_INTER(type);
+    if (l < 16) {
+        int g = GI(l & 3, l >> 2);
+        r.ipm[l] = s->ipm_c[g];
+        r.mv[l][0] = inter ? s->mv_c[g][0] : static_cast<int16_t>(0);
+        r.mv[l][1] = inter ? s->mv_c[g][1] : static_cast<int16_t>(0);
+    } else if (l < 20) {
+        int i = l - 16, ref = inter ? s->refs8[i] : -1;
+        r.ref[i] = static_cast<int8_t>(ref);
+        r.refslot[i] = ref >= 0 ? e.sd->ref_slot[ref] : static_cast<int16_t>(-1);
+    }
+    // remember the top[] entry of this column for the next MB's top-left neighbour, then replace it
+    TopInfo *tp = &e.top[e.mbx];
+    if (l >= 32 && l < 44) reinterpret_cast<uint32_t *>(&s->tl)[l - 32] = reinterpret_cast<const uint32_t *>(tp)[l - 32];
+    __syncthreads();
+    if (l < 2) {
+        TopInfo *dst = l == 0 ? tp : &s->left;
+        dst->type = static_cast<uint8_t>(type);
+        dst->t8x8 = static_cast<uint8_t>(t8x8);
+        dst->cbp = r.cbp;
+        dst->chroma_mode = static_cast<uint8_t>(chroma_mode);
+        dst->cbf_dc = s->cur_cbf_dc;
+        dst->ref[0] = inter ? s->refs8[l == 0 ? 2 : 1] : static_cast<int8_t>(-1);
+        dst->ref[1] = inter ? s->refs8[3] : static_cast<int8_t>(-1);
+    } else if (l >= 8 && l < 16) {
+        // edge arrays: lanes 8..11 -> top (bottom row), 12..15 -> left (right column)
+        int k = l & 3, is_left = l >= 12;
+        TopInfo *dst = is_left ? &s->left : tp;
+        int g = is_left ? GI(3, k) : GI(k, 3);
+        dst->ipm[k] = s->ipm_c[g];
+        dst->nnz[k] = s->nnz_c[g];
+        dst->mv[k][0] = s->mv_c[g][0], dst->mv[k][1] = s->mv_c[g][1];
+        dst->mvd[k][0] = s->mvd_c[g][0], dst->mvd[k][1] = s->mvd_c[g][1];
+    } else if (l >= 16 && l < 24) {
+        // chroma nnz edges: [plane][k]
+        int i = l - 16, is_left = i >= 4, cpl = (i >> 1) & 1, k = i & 1;
+        TopInfo *dst = is_left ? &s->left : tp;
+        dst->nnz[4 + cpl * 2 + k] = is_left ? s->nnzc_c[cpl][(k + 1) * 3 + 2] : s->nnzc_c[cpl][2 * 3 + k + 1];
+    }
+    const uint64_t mbi = e.pd->mb_base + static_cast<uint64_t>(e.mby) * e.wmb + e.mbx;
+    if (l >= 32) { // MbRec: 128 bytes = 32 dwords, lanes 32..63
+        reinterpret_cast<uint32_t *>(e.mbrec + mbi)[l - 32] = reinterpret_cast<const uint32_t *>(&r)[l - 32];
+    }
+    if (has_coef) { // 832 bytes = 52 x 16 B
+        if (l < MI_COEF_PER_MB * 2 / 16) reinterpret_cast<uint4 *>(e.coefs + mbi * MI_COEF_PER_MB)[l] = reinterpret_cast<const uint4 *>(s->coef)[l];
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ kernel: slice_data() 7.3.4
+extern "C" __global__ void __launch_bounds__(64) k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
+                                                           int16_t *coefs, uint32_t *status, int wmb_max) {
+    __shared__ Shared sh;
+    extern __shared__ uint32_t dyn[];
+    Ent e;
+    e.s = &sh;
+    e.top = reinterpret_cast<TopInfo *>(dyn);
+    e.tab = tab;
+    e.sd = &slices[blockIdx.x];
+    e.pd = &pics[e.sd->pic_idx];
+    e.rbsp = bitstream + e.sd->rbsp_off;
+    e.rbsp_words = (e.sd->rbsp_size + 3) >> 2;
+    e.mbrec = mbrec;
+    e.coefs = coefs;
+    e.filled = 0;
+    e.bitpos = e.sd->data_bit_off;
+    e.err = 0;
+    e.cabac = e.pd->cabac;
+    e.islice = e.sd->slice_type == 2;
+    e.wmb = static_cast<int>(e.pd->wmb), e.hmb = static_cast<int>(e.pd->hmb);
+    e.qp = e.sd->slice_qp;
+    e.prev_dqp_nz = 0;
+    e.range = 510, e.value = 0, e.avail = 0;
+    e.mbx = e.mby = 0, e.cur_type = 0;
+    const int l = LANE;
+    // tables -> LDS
+    for (int i = l; i < 256; i += 64) sh.range_lps[i] = (&tab->range_lps[0][0])[i];
+    sh.trans_lps[l] = tab->trans_lps[l];
+    sh.zz8[l] = tab->zigzag8[l], sh.sig8[l] = tab->sig8x8[l], sh.last8[l] = tab->last8x8[l];
+    if (l < 16) sh.zz4[l] = tab->zigzag4[l];
+    {
+        int set = e.islice ? 0 : 1 + e.sd->cabac_init_idc;
+        const uint8_t *src = tab->ctx_init[set][e.sd->slice_qp];
+        for (int i = l; i < 464; i += 64) sh.ctx[i] = src[i];
+    }
+    for (int i = l; i < e.wmb * 12; i += 64) dyn[i] = 0; // all top[] entries: type NONE
+    if (l < 12) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
+    __syncthreads();
+    // start at the ring chunk containing the first slice_data bit
+    e.filled = (e.bitpos >> 5) & ~511u;
+    ring_fill(e);
+    ring_fill(e);
+    if (e.cabac) {
+        e.bitpos = (e.bitpos + 7) & ~7u; // cabac_alignment_one_bit
+        cabac_start(e);
+    }
+    const int total = e.wmb * e.hmb;
+    const uint32_t stop_bit = e.sd->stop_bit;
+    int addr = static_cast<int>(e.sd->first_mb);
+    int more = 1, skip_state = 0 /* 0: read mb_skip_run, 1: inside a run, 2: coded MB follows a run */, pending = 0;
+    int n_mbs = 0;
+    while (more && !e.err) {
+        if (addr >= total) {
+            e.err = 30;
+            break;
+        }
+        e.mbx = addr % e.wmb, e.mby = addr / e.wmb;
+        if (e.mbx == 0) { // new MB row: no left / top-left neighbour
+            if (l < 12) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
+            __syncthreads();
+        }
+        ensure(e);
+        fill_caches(e);
+        int skipped = 0;
+        if (!e.islice) {
+            if (e.cabac) {
+                const TopInfo *a = mbA(e), *b = mbB(e);
+                skipped = cabac_bin(e, 11 + (a && a->type != MBT_PSKIP) + (b && b->type != MBT_PSKIP));
+            } else {
+                if (skip_state == 0) {
+                    pending = static_cast<int>(get_ue(e));
+                    if (pending > total - addr) e.err = 31, pending = 0;
+                    if (pending > 0) skip_state = 1;
+                }
+                if (skip_state == 1) {
+                    skipped = 1;
+                    pending--;
+                }
+            }
+        }
+        decode_mb(e, skipped);
+        n_mbs++;
+        if (e.cabac)
+            more = !cabac_terminate(e);
+        else {
+            if (skipped) {
+                if (pending == 0) {
+                    more = e.bitpos < stop_bit;
+                    skip_state = 2;
+                }
+            } else {
+                more = e.bitpos < stop_bit;
+                skip_state = 0;
+            }
+        }
+        addr++;
+    }
+    if (l == 0) {
+        status[2 * blockIdx.x] = static_cast<uint32_t>(e.err);
+        status[2 * blockIdx.x + 1] = static_cast<uint32_t>(n_mbs);
+    }
+}

@@ -1,0 +1,652 @@
+// h264decode_amd/csrc/k_recon.hip -- K3 (intra) and K4 (inter) reconstruction kernels, gfx950.
+//
+// Everything here is byte / int16 work bounded by HBM traffic and LDS latency (no MFMA):
+//   residual: scaling (8.5.9, 8.5.12.1) + Intra16x16 / chroma DC transforms (8.5.10, 8.5.11) +
+//             4x4 / 8x8 inverse transforms (8.5.12.2, 8.5.13), two LDS passes (rows, columns);
+//   K4 inter: one macroblock per wavefront.  Reference windows (9x9 luma, 3x3 chroma per 4x4 block,
+//             coordinates clamped to the picture, 8.4.2.2) are staged in LDS, every lane produces
+//             4 luma + 2 chroma samples, adds the residual and stores one dword / one ushort.
+//   K3 intra: macroblocks depend on their left / top / top-right neighbours, so a picture is
+//             decoded by ONE workgroup (no cross-CU visibility problem): wavefront w owns
+//             macroblock rows w, w+16, ..., and waits on an LDS progress counter of the row above
+//             (2-D wavefront order).  Inside a macroblock the 4x4 / 8x8 blocks are reconstructed in
+//             an LDS tile, so the serial block-to-block dependency never touches HBM.
+//
+// The reference has none of this (README.md:10 "Macroblock to YCbCr image decoding" is a TODO);
+// normative source: ITU-T H.264 8.3, 8.4.2, 8.5.
+#include <hip/hip_runtime.h>
+#include "mi_kernels.h"
+
+#define WAVE_SYNC()                                             \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+    } while (0)
+
+__device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
+
+struct ResBuf {
+    int32_t tmp[384];      // row-pass output: luma [0..255], chroma [256..383]
+    int16_t luma[256];     // residual, raster 16x16
+    int16_t chroma[2][64]; // residual, raster 8x8 per plane
+    int32_t dc[24];        // Intra16x16 DC (16, block raster) + chroma DC (2 x 4)
+};
+
+// ------------------------------------------------------------------ 1-D inverse transforms
+__device__ __forceinline__ void inv4(int d0, int d1, int d2, int d3, int &o0, int &o1, int &o2, int &o3) {
+    int e0 = d0 + d2, e1 = d0 - d2, e2 = (d1 >> 1) - d3, e3 = d1 + (d3 >> 1);
+    o0 = e0 + e3, o1 = e1 + e2, o2 = e1 - e2, o3 = e0 - e3;
+}
+__device__ __forceinline__ void inv8(const int *d, int *o) {
+    int e0 = d[0] + d[4], e1 = -d[3] + d[5] - d[7] - (d[7] >> 1), e2 = d[0] - d[4], e3 = d[1] + d[7] - d[3] - (d[3] >> 1);
+    int e4 = (d[2] >> 1) - d[6], e5 = -d[1] + d[7] + d[5] + (d[5] >> 1), e6 = d[2] + (d[6] >> 1), e7 = d[3] + d[5] + d[1] + (d[1] >> 1);
+    int f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2);
+    int f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
+    o[0] = f0 + f7, o[1] = f2 + f5, o[2] = f4 + f3, o[3] = f6 + f1;
+    o[4] = f6 - f1, o[5] = f4 - f3, o[6] = f2 - f5, o[7] = f0 - f7;
+}
+__device__ __forceinline__ int scale4(int c, int ls, int qp) { // 8.5.12.1
+    int per = qp / 6;
+    return per >= 4 ? (c * ls) << (per - 4) : (c * ls + (1 << (3 - per))) >> (4 - per);
+}
+__device__ __forceinline__ int scale8(int c, int ls, int qp) { // 8.5.13 scaling
+    int per = qp / 6;
+    return per >= 6 ? (c * ls) << (per - 6) : (c * ls + (1 << (5 - per))) >> (6 - per);
+}
+
+// Residual of one macroblock, computed by one wavefront (lane = 0..63).  Results in rb->luma / rb->chroma.
+__device__ void mb_residual(int lane, const MbRec *rec, const int16_t *coef, const ScalingSet *sc, ResBuf *rb) {
+    const int type = rec->type, t8x8 = rec->t8x8, cbp = rec->cbp, qp = rec->qp;
+    const int intra = MB_IS_INTRA(type), i16 = type == MBT_I16x16;
+    const int cbp_l = cbp & 15, cbp_c = cbp >> 4;
+    // ---- DC transforms ----
+    if (i16 && lane < 16) { // 8.5.10: f = A c A, A = 4x4 Hadamard
+        const int i = lane >> 2, j = lane & 3;
+        int acc = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // A[i][k]: row i of the Hadamard matrix
+            int aik = (i == 0) ? 1 : (i == 1 ? (k < 2 ? 1 : -1) : (i == 2 ? ((k == 0 || k == 3) ? 1 : -1) : ((k & 1) ? -1 : 1)));
+            int rowsum = 0;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                int amj = (j == 0) ? 1 : (j == 1 ? (m < 2 ? 1 : -1) : (j == 2 ? ((m == 0 || m == 3) ? 1 : -1) : ((m & 1) ? -1 : 1)));
+                rowsum += coef[MI_COEF_I16DC + k * 4 + m] * amj;
+            }
+            acc += aik * rowsum;
+        }
+        int ls00 = sc->ls4[0][qp % 6][0], per = qp / 6;
+        rb->dc[lane] = per >= 6 ? (acc * ls00) << (per - 6) : (acc * ls00 + (1 << (5 - per))) >> (6 - per);
+    }
+    if (cbp_c && lane >= 16 && lane < 24) { // 8.5.11
+        const int c = (lane - 16) >> 2, b = lane & 3;
+        const int16_t *p = coef + MI_COEF_CDC + 4 * c;
+        int c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+        int f = b == 0 ? c0 + c1 + c2 + c3 : (b == 1 ? c0 - c1 + c2 - c3 : (b == 2 ? c0 + c1 - c2 - c3 : c0 - c1 - c2 + c3));
+        int qpc = rec->qpc[c], ls00 = sc->ls4[(intra ? 1 : 4) + c][qpc % 6][0];
+        rb->dc[16 + c * 4 + b] = ((f * ls00) << (qpc / 6)) >> 5;
+    }
+    WAVE_SYNC();
+    // ---- row pass ----
+    if (t8x8) {
+        if (lane < 32) {
+            const int b8 = lane >> 3, row = lane & 7;
+            int o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if ((cbp_l >> b8) & 1) {
+                const uint16_t *ls = sc->ls8[intra ? 0 : 1][qp % 6] + row * 8;
+                const int16_t *c = coef + b8 * 64 + row * 8;
+                int d[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) d[k] = scale8(c[k], ls[k], qp);
+                inv8(d, o);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) rb->tmp[b8 * 64 + row * 8 + k] = o[k];
+        }
+    } else {
+        const int r = lane >> 2, row = lane & 3, b8 = ((r >> 3) << 1) | ((r & 3) >> 1);
+        int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+        const int coded = (cbp_l >> b8) & 1;
+        if (coded || i16) {
+            const uint16_t *ls = sc->ls4[intra ? 0 : 3][qp % 6] + row * 4;
+            const int16_t *c = coef + r * 16 + row * 4;
+            int d0 = coded ? scale4(c[0], ls[0], qp) : 0, d1 = coded ? scale4(c[1], ls[1], qp) : 0;
+            int d2 = coded ? scale4(c[2], ls[2], qp) : 0, d3 = coded ? scale4(c[3], ls[3], qp) : 0;
+            if (i16 && row == 0) d0 = rb->dc[r];
+            inv4(d0, d1, d2, d3, o0, o1, o2, o3);
+        }
+        int32_t *t = rb->tmp + r * 16 + row * 4;
+        t[0] = o0, t[1] = o1, t[2] = o2, t[3] = o3;
+    }
+    if (lane < 32) { // chroma rows: 2 planes x 4 blocks x 4 rows
+        const int c = lane >> 4, b = (lane >> 2) & 3, row = lane & 3;
+        int o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+        if (cbp_c) {
+            const int qpc = rec->qpc[c];
+            const uint16_t *ls = sc->ls4[(intra ? 1 : 4) + c][qpc % 6] + row * 4;
+            const int16_t *p = coef + MI_COEF_CAC + (c * 4 + b) * 16 + row * 4;
+            const int ac = cbp_c & 2;
+            int d0 = ac ? scale4(p[0], ls[0], qpc) : 0, d1 = ac ? scale4(p[1], ls[1], qpc) : 0;
+            int d2 = ac ? scale4(p[2], ls[2], qpc) : 0, d3 = ac ? scale4(p[3], ls[3], qpc) : 0;
+            if (row == 0) d0 = rb->dc[16 + c * 4 + b];
+            inv4(d0, d1, d2, d3, o0, o1, o2, o3);
+        }
+        int32_t *t = rb->tmp + 256 + (c * 4 + b) * 16 + row * 4;
+        t[0] = o0, t[1] = o1, t[2] = o2, t[3] = o3;
+    }
+    WAVE_SYNC();
+    // ---- column pass ----
+    if (t8x8) {
+        if (lane < 32) {
+            const int b8 = lane >> 3, col = lane & 7;
+            int d[8], o[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) d[k] = rb->tmp[b8 * 64 + k * 8 + col];
+            inv8(d, o);
+            const int x0 = (b8 & 1) * 8 + col, y0 = (b8 >> 1) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; k++) rb->luma[(y0 + k) * 16 + x0] = static_cast<int16_t>((o[k] + 32) >> 6);
+        }
+    } else {
+        const int r = lane >> 2, col = lane & 3;
+        const int32_t *t = rb->tmp + r * 16 + col;
+        int o0, o1, o2, o3;
+        inv4(t[0], t[4], t[8], t[12], o0, o1, o2, o3);
+        const int x0 = (r & 3) * 4 + col, y0 = (r >> 2) * 4;
+        rb->luma[(y0 + 0) * 16 + x0] = static_cast<int16_t>((o0 + 32) >> 6);
+        rb->luma[(y0 + 1) * 16 + x0] = static_cast<int16_t>((o1 + 32) >> 6);
+        rb->luma[(y0 + 2) * 16 + x0] = static_cast<int16_t>((o2 + 32) >> 6);
+        rb->luma[(y0 + 3) * 16 + x0] = static_cast<int16_t>((o3 + 32) >> 6);
+    }
+    if (lane < 32) {
+        const int c = lane >> 4, b = (lane >> 2) & 3, col = lane & 3;
+        const int32_t *t = rb->tmp + 256 + (c * 4 + b) * 16 + col;
+        int o0, o1, o2, o3;
+        inv4(t[0], t[4], t[8], t[12], o0, o1, o2, o3);
+        const int x0 = (b & 1) * 4 + col, y0 = (b >> 1) * 4;
+        int16_t *dst = rb->chroma[c];
+        dst[(y0 + 0) * 8 + x0] = static_cast<int16_t>((o0 + 32) >> 6);
+        dst[(y0 + 1) * 8 + x0] = static_cast<int16_t>((o1 + 32) >> 6);
+        dst[(y0 + 2) * 8 + x0] = static_cast<int16_t>((o2 + 32) >> 6);
+        dst[(y0 + 3) * 8 + x0] = static_cast<int16_t>((o3 + 32) >> 6);
+    }
+    WAVE_SYNC();
+}
+
+__device__ __forceinline__ void zero_residual(int lane, ResBuf *rb) {
+    for (int i = lane; i < 128; i += 64) reinterpret_cast<uint32_t *>(rb->luma)[i] = 0;
+    reinterpret_cast<uint32_t *>(rb->chroma)[lane] = 0;
+    WAVE_SYNC();
+}
+
+// ================================================================== K4: inter prediction
+struct InterShared {
+    ResBuf rb;
+    uint8_t win_y[16][9][12];   // 9x9 luma window per 4x4 block, rows padded to 12 bytes
+    uint8_t win_c[2][16][3][4]; // 3x3 chroma window per 2x2 chroma block
+    MbRec rec;
+};
+
+__device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
+
+extern "C" __global__ void __launch_bounds__(64) k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const FramePool *pools,
+                                                         const DevTables *tab, const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max) {
+    __shared__ InterShared sh;
+    const int lane = static_cast<int>(threadIdx.x);
+    const PicDesc *pd = &pics[pic_list[blockIdx.x / mbs_per_pic_max]];
+    const int mb = static_cast<int>(blockIdx.x % mbs_per_pic_max);
+    const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
+    if (mb >= wmb * hmb) return;
+    const uint64_t mbi = pd->mb_base + mb;
+    const MbRec *grec = mbrec + mbi;
+    if (!MB_IS_INTER(grec->type)) return;
+    if (lane < 32) reinterpret_cast<uint32_t *>(&sh.rec)[lane] = reinterpret_cast<const uint32_t *>(grec)[lane];
+    __syncthreads();
+    const MbRec *rec = &sh.rec;
+    const FramePool *pool = &pools[pd->stream];
+    const int W = static_cast<int>(pool->w), H = static_cast<int>(pool->h);
+    const int mbx = mb % wmb, mby = mb / wmb;
+    const uint8_t *pool_base = reinterpret_cast<const uint8_t *>(pool->base);
+    const size_t ysz = static_cast<size_t>(W) * H;
+    // ---- stage reference windows (coordinates clamped: 8.4.2.2.1 / 8.4.2.2.2) ----
+    for (int i = lane; i < 16 * 81; i += 64) {
+        int b = i / 81, rem = i - b * 81, wy = rem / 9, wx = rem - wy * 9;
+        int slot = rec->refslot[((b >> 3) << 1) | ((b & 3) >> 1)];
+        int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
+        int x = mbx * 16 + (b & 3) * 4 + (mvx >> 2) - 2 + wx, y = mby * 16 + (b >> 2) * 4 + (mvy >> 2) - 2 + wy;
+        x = min(max(x, 0), W - 1), y = min(max(y, 0), H - 1);
+        const uint8_t *ref = pool_base + static_cast<size_t>(slot < 0 ? 0 : slot) * pool->slot_bytes;
+        sh.win_y[b][wy][wx] = ref[static_cast<size_t>(y) * W + x];
+    }
+    for (int i = lane; i < 2 * 16 * 9; i += 64) {
+        int c = i / 144, rem = i - c * 144, b = rem / 9, r9 = rem - b * 9, wy = r9 / 3, wx = r9 - wy * 3;
+        int slot = rec->refslot[((b >> 3) << 1) | ((b & 3) >> 1)];
+        int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
+        int x = mbx * 8 + (b & 3) * 2 + (mvx >> 3) + wx, y = mby * 8 + (b >> 2) * 2 + (mvy >> 3) + wy;
+        x = min(max(x, 0), W / 2 - 1), y = min(max(y, 0), H / 2 - 1);
+        const uint8_t *ref = pool_base + static_cast<size_t>(slot < 0 ? 0 : slot) * pool->slot_bytes + ysz + static_cast<size_t>(c) * (ysz / 4);
+        sh.win_c[c][b][wy][wx] = ref[static_cast<size_t>(y) * (W / 2) + x];
+    }
+    // ---- residual (independent of the prediction) ----
+    if (rec->cbp)
+        mb_residual(lane, rec, coefs + mbi * MI_COEF_PER_MB, &tab->scaling[pd->scaling_set], &sh.rb);
+    else
+        zero_residual(lane, &sh.rb);
+    __syncthreads();
+    const SliceDesc *sd = &slices[rec->slice_idx];
+    const int wp = pd->weighted_pred;
+    uint8_t *dst_base = const_cast<uint8_t *>(pool_base) + static_cast<size_t>(pd->slot) * pool->slot_bytes;
+    // ---- luma: lane = (4x4 block, row) -> 4 samples ----
+    {
+        const int b = lane >> 2, r = lane & 3;
+        const int mvx = rec->mv[b][0], mvy = rec->mv[b][1], fx = mvx & 3, fy = mvy & 3;
+        int p[6][9];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(sh.win_y[b][r + j]);
+            uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
+            p[j][0] = w0 & 255, p[j][1] = (w0 >> 8) & 255, p[j][2] = (w0 >> 16) & 255, p[j][3] = w0 >> 24;
+            p[j][4] = w1 & 255, p[j][5] = (w1 >> 8) & 255, p[j][6] = (w1 >> 16) & 255, p[j][7] = w1 >> 24;
+            p[j][8] = w2 & 255;
+        }
+        const int refidx = rec->ref[((b >> 3) << 1) | ((b & 3) >> 1)];
+        uint32_t packed = 0;
+        const int bx = (b & 3) * 4, by = (b >> 2) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int v;
+            const int G = p[2][i + 2];
+            if ((fx | fy) == 0)
+                v = G;
+            else {
+                int hb[6];
+#pragma unroll
+                for (int j = 0; j < 6; j++) hb[j] = tap6(p[j][i], p[j][i + 1], p[j][i + 2], p[j][i + 3], p[j][i + 4], p[j][i + 5]);
+                const int bb = clip255((hb[2] + 16) >> 5), ss = clip255((hb[3] + 16) >> 5);
+                const int hh = clip255((tap6(p[0][i + 2], p[1][i + 2], p[2][i + 2], p[3][i + 2], p[4][i + 2], p[5][i + 2]) + 16) >> 5);
+                const int mm = clip255((tap6(p[0][i + 3], p[1][i + 3], p[2][i + 3], p[3][i + 3], p[4][i + 3], p[5][i + 3]) + 16) >> 5);
+                const int jj = clip255((tap6(hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]) + 512) >> 10);
+                switch (fy * 4 + fx) {
+                case 1: v = (G + bb + 1) >> 1; break;
+                case 2: v = bb; break;
+                case 3: v = (p[2][i + 3] + bb + 1) >> 1; break;
+                case 4: v = (G + hh + 1) >> 1; break;
+                case 5: v = (bb + hh + 1) >> 1; break;
+                case 6: v = (bb + jj + 1) >> 1; break;
+                case 7: v = (bb + mm + 1) >> 1; break;
+                case 8: v = hh; break;
+                case 9: v = (hh + jj + 1) >> 1; break;
+                case 10: v = jj; break;
+                case 11: v = (jj + mm + 1) >> 1; break;
+                case 12: v = (p[3][i + 2] + hh + 1) >> 1; break;
+                case 13: v = (hh + ss + 1) >> 1; break;
+                case 14: v = (jj + ss + 1) >> 1; break;
+                default: v = (mm + ss + 1) >> 1; break;
+                }
+            }
+            if (wp) { // 8.4.2.3 explicit weighted prediction
+                const int ld = sd->luma_log2_denom, w0 = sd->wp_lw[refidx], o0 = sd->wp_lo[refidx];
+                v = ld >= 1 ? clip255(((v * w0 + (1 << (ld - 1))) >> ld) + o0) : clip255(v * w0 + o0);
+            }
+            v = clip255(v + sh.rb.luma[(by + r) * 16 + bx + i]);
+            packed |= static_cast<uint32_t>(v) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t *>(dst_base + static_cast<size_t>(mby * 16 + by + r) * W + mbx * 16 + bx) = packed;
+    }
+    // ---- chroma: lane = (plane, row, column pair) -> 2 samples ----
+    {
+        const int c = lane >> 5, q = lane & 31, cy = q >> 2, cx = (q & 3) * 2;
+        const int b = (cy >> 1) * 4 + (cx >> 1);
+        const int mvx = rec->mv[b][0], mvy = rec->mv[b][1], xf = mvx & 7, yf = mvy & 7;
+        const int refidx = rec->ref[((b >> 3) << 1) | ((b & 3) >> 1)];
+        const uint8_t(*w)[4] = sh.win_c[c][b];
+        const int ry = cy & 1;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            int A = w[ry][i], B = w[ry][i + 1], C = w[ry + 1][i], D = w[ry + 1][i + 1];
+            int v = ((8 - xf) * (8 - yf) * A + xf * (8 - yf) * B + (8 - xf) * yf * C + xf * yf * D + 32) >> 6;
+            if (wp) {
+                const int ld = sd->chroma_log2_denom, w0 = sd->wp_cw[refidx][c], o0 = sd->wp_co[refidx][c];
+                v = ld >= 1 ? clip255(((v * w0 + (1 << (ld - 1))) >> ld) + o0) : clip255(v * w0 + o0);
+            }
+            v = clip255(v + sh.rb.chroma[c][cy * 8 + cx + i]);
+            packed |= static_cast<uint32_t>(v) << (8 * i);
+        }
+        uint8_t *plane = dst_base + ysz + static_cast<size_t>(c) * (ysz / 4);
+        *reinterpret_cast<uint16_t *>(plane + static_cast<size_t>(mby * 8 + cy) * (W / 2) + mbx * 8 + cx) = static_cast<uint16_t>(packed);
+    }
+}
+
+// ================================================================== K3: intra prediction
+struct IntraWave {
+    ResBuf rb;
+    uint8_t tile[17][28];     // luma: row 0 = samples above, column 0 = samples to the left; 24 columns to the right for top-right
+    uint8_t tile_c[2][9][12]; // chroma
+    int16_t fe[2][32];        // Intra8x8 filtered reference samples: [0] top p'[-1..15] at index x+1, [1] left p'[-1..7] at index y+1
+};
+struct IntraShared {
+    IntraWave w[MI_INTRA_WAVES];
+    int prog[320]; // macroblocks finished per row
+};
+
+// directional Intra4x4 / Intra8x8 predictors (8.3.1.2.4-9, 8.3.2.2.5-10).  T(x) = p[x,-1], L(y) = p[-1,y], T(-1)=L(-1)=p[-1,-1]
+template <int N, typename FT, typename FL>
+__device__ __forceinline__ int pred_dir(int mode, int x, int y, FT T, FL L) {
+    switch (mode) {
+    case 3: return (x == N - 1 && y == N - 1) ? (T(2 * N - 2) + 3 * T(2 * N - 1) + 2) >> 2 : (T(x + y) + 2 * T(x + y + 1) + T(x + y + 2) + 2) >> 2;
+    case 4:
+        if (x > y) return (T(x - y - 2) + 2 * T(x - y - 1) + T(x - y) + 2) >> 2;
+        if (x < y) return (L(y - x - 2) + 2 * L(y - x - 1) + L(y - x) + 2) >> 2;
+        return (T(0) + 2 * T(-1) + L(0) + 2) >> 2;
+    case 5: {
+        int z = 2 * x - y, k = x - (y >> 1);
+        if (z < -1) return (L(y - 2 * x - 1) + 2 * L(y - 2 * x - 2) + L(y - 2 * x - 3) + 2) >> 2;
+        if (z == -1) return (L(0) + 2 * T(-1) + T(0) + 2) >> 2;
+        if (!(z & 1)) return (T(k - 1) + T(k) + 1) >> 1;
+        return (T(k - 2) + 2 * T(k - 1) + T(k) + 2) >> 2;
+    }
+    case 6: {
+        int z = 2 * y - x, k = y - (x >> 1);
+        if (z < -1) return (T(x - 2 * y - 1) + 2 * T(x - 2 * y - 2) + T(x - 2 * y - 3) + 2) >> 2;
+        if (z == -1) return (L(0) + 2 * T(-1) + T(0) + 2) >> 2;
+        if (!(z & 1)) return (L(k - 1) + L(k) + 1) >> 1;
+        return (L(k - 2) + 2 * L(k - 1) + L(k) + 2) >> 2;
+    }
+    case 7: {
+        int k = x + (y >> 1);
+        return !(y & 1) ? (T(k) + T(k + 1) + 1) >> 1 : (T(k) + 2 * T(k + 1) + T(k + 2) + 2) >> 2;
+    }
+    default: {
+        int z = x + 2 * y, k = y + (x >> 1);
+        if (z > 2 * N - 3) return L(N - 1);
+        if (z == 2 * N - 3) return (L(N - 2) + 3 * L(N - 1) + 2) >> 2;
+        if (!(z & 1)) return (L(k) + L(k + 1) + 1) >> 1;
+        return (L(k) + 2 * L(k + 1) + L(k + 2) + 2) >> 2;
+    }
+    }
+}
+
+// Intra16x16 (N=16) and chroma (N=8) plane prediction; T/L as above
+template <int N, typename FT, typename FL>
+__device__ __forceinline__ void plane_params(FT T, FL L, int &a, int &b, int &c) {
+    int hh = 0, vv = 0;
+    constexpr int m = N / 2;
+#pragma unroll
+    for (int k = 1; k <= m; k++) {
+        hh += k * (T(m - 1 + k) - T(m - 1 - k));
+        vv += k * (L(m - 1 + k) - L(m - 1 - k));
+    }
+    a = 16 * (L(N - 1) + T(N - 1));
+    b = N == 16 ? (5 * hh + 32) >> 6 : (34 * hh + 32) >> 6;
+    c = N == 16 ? (5 * vv + 32) >> 6 : (34 * vv + 32) >> 6;
+}
+
+__device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_t *coef, const ScalingSet *sc, uint8_t *py, uint8_t *pcb, uint8_t *pcr, int W,
+                         int mbx, int mby) {
+    const int type = rec->type, av = rec->avail;
+    const int a_left = av & MI_AV_LEFT, a_top = (av & MI_AV_TOP) != 0, a_tl = (av & MI_AV_TOPLEFT) != 0, a_tr = (av & MI_AV_TOPRIGHT) != 0;
+    uint8_t *Y = py + static_cast<size_t>(mby * 16) * W + mbx * 16;
+    const int Wc = W / 2;
+    uint8_t *C[2] = {pcb + static_cast<size_t>(mby * 8) * Wc + mbx * 8, pcr + static_cast<size_t>(mby * 8) * Wc + mbx * 8};
+    if (type == MBT_IPCM) { // 8.3.5: samples were stored in the coefficient block
+        const uint8_t *pcm = reinterpret_cast<const uint8_t *>(coef);
+        { // 256 luma bytes: one dword per lane
+            int j = lane >> 2, i = (lane & 3) * 4;
+            *reinterpret_cast<uint32_t *>(Y + static_cast<size_t>(j) * W + i) = *reinterpret_cast<const uint32_t *>(pcm + j * 16 + i);
+        }
+        if (lane < 32) {
+            int c = lane >> 4, j = (lane >> 1) & 7, i = (lane & 1) * 4;
+            *reinterpret_cast<uint32_t *>(C[c] + static_cast<size_t>(j) * Wc + i) = *reinterpret_cast<const uint32_t *>(pcm + 256 + c * 64 + j * 8 + i);
+        }
+        return;
+    }
+    // ---- neighbouring samples into the LDS tiles ----
+    if (lane < 25) { // row above: x = -1 .. 23
+        int x = lane - 1;
+        int ok = x < 0 ? a_tl : (x < 16 ? a_top : a_tr);
+        ws->tile[0][lane] = ok ? Y[-static_cast<ptrdiff_t>(W) + x] : static_cast<uint8_t>(128);
+    } else if (lane >= 32 && lane < 48) {
+        int y = lane - 32;
+        ws->tile[y + 1][0] = a_left ? Y[static_cast<size_t>(y) * W - 1] : static_cast<uint8_t>(128);
+    }
+    if (lane < 18) { // chroma rows above: x = -1..7 for both planes
+        int c = lane / 9, x = lane % 9 - 1;
+        int ok = x < 0 ? a_tl : a_top;
+        ws->tile_c[c][0][x + 1] = ok ? C[c][-static_cast<ptrdiff_t>(Wc) + x] : static_cast<uint8_t>(128);
+    } else if (lane >= 32 && lane < 48) {
+        int c = (lane - 32) >> 3, y = lane & 7;
+        ws->tile_c[c][y + 1][0] = a_left ? C[c][static_cast<size_t>(y) * Wc - 1] : static_cast<uint8_t>(128);
+    }
+    // ---- residual ----
+    if ((rec->cbp & 0x3F) || type == MBT_I16x16)
+        mb_residual(lane, rec, coef, sc, &ws->rb);
+    else
+        zero_residual(lane, &ws->rb);
+    // ---- luma ----
+    if (type == MBT_I16x16) {
+        const int mode = rec->i16mode;
+        auto T = [&](int x) { return static_cast<int>(ws->tile[0][x + 1]); };
+        auto L = [&](int y) { return static_cast<int>(ws->tile[y + 1][0]); };
+        const int j = lane >> 2, i0 = (lane & 3) * 4;
+        int dc = 128, pa = 0, pb = 0, pc = 0;
+        if (mode == 2) {
+            int st = 0, sl = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) st += T(k), sl += L(k);
+            if (a_top && a_left)
+                dc = (st + sl + 16) >> 5;
+            else if (a_top)
+                dc = (st + 8) >> 4;
+            else if (a_left)
+                dc = (sl + 8) >> 4;
+        } else if (mode == 3)
+            plane_params<16>(T, L, pa, pb, pc);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int x = i0 + k, v;
+            if (mode == 0)
+                v = T(x);
+            else if (mode == 1)
+                v = L(j);
+            else if (mode == 2)
+                v = dc;
+            else
+                v = clip255((pa + pb * (x - 7) + pc * (j - 7) + 16) >> 5);
+            v = clip255(v + ws->rb.luma[j * 16 + x]);
+            packed |= static_cast<uint32_t>(v) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(Y + static_cast<size_t>(j) * W + i0) = packed;
+    } else if (type == MBT_I4x4) {
+        for (int idx = 0; idx < 16; idx++) {
+            const int bx = (idx & 1) + 2 * ((idx >> 2) & 1), by = ((idx >> 1) & 1) + 2 * (idx >> 3);
+            const int mode = rec->ipm[by * 4 + bx];
+            const int has_left = bx > 0 || a_left, has_top = by > 0 || a_top;
+            int has_tr;
+            if (by == 0)
+                has_tr = bx < 3 ? a_top : a_tr;
+            else
+                has_tr = bx == 3 ? 0 : !((bx & 1) && (by & 1));
+            if (lane < 16) {
+                const int x = lane & 3, y = lane >> 2;
+                const uint8_t *trow = &ws->tile[by * 4][bx * 4 + 1]; // trow[x] = p[x,-1], trow[-1] = p[-1,-1]
+                auto T = [&](int k) { return static_cast<int>((k >= 4 && !has_tr) ? trow[3] : trow[k]); };
+                auto L = [&](int k) { return k < 0 ? static_cast<int>(trow[-1]) : static_cast<int>(ws->tile[by * 4 + 1 + k][bx * 4]); };
+                int v;
+                if (mode == 0)
+                    v = T(x);
+                else if (mode == 1)
+                    v = L(y);
+                else if (mode == 2) {
+                    int st = T(0) + T(1) + T(2) + T(3), sl = L(0) + L(1) + L(2) + L(3);
+                    v = (has_top && has_left) ? (st + sl + 4) >> 3 : (has_top ? (st + 2) >> 2 : (has_left ? (sl + 2) >> 2 : 128));
+                } else
+                    v = pred_dir<4>(mode, x, y, T, L);
+                v = clip255(v + ws->rb.luma[(by * 4 + y) * 16 + bx * 4 + x]);
+                ws->tile[by * 4 + 1 + y][bx * 4 + 1 + x] = static_cast<uint8_t>(v);
+            }
+            WAVE_SYNC();
+        }
+    } else { // MBT_I8x8
+        for (int b8 = 0; b8 < 4; b8++) {
+            const int x8 = b8 & 1, y8 = b8 >> 1;
+            const int mode = rec->ipm[y8 * 8 + x8 * 2];
+            const int has_left = x8 || a_left, has_top = y8 || a_top;
+            const int has_tl = b8 == 0 ? a_tl : (b8 == 1 ? a_top : (b8 == 2 ? (a_left != 0) : 1));
+            const int has_tr = b8 == 0 ? a_top : (b8 == 1 ? a_tr : (b8 == 2 ? 1 : 0));
+            const uint8_t *trow = &ws->tile[y8 * 8][x8 * 8 + 1];
+            auto Tr = [&](int k) { return k < 0 ? static_cast<int>(trow[-1]) : static_cast<int>((k >= 8 && !has_tr) ? trow[7] : trow[k]); };
+            auto Lr = [&](int k) { return k < 0 ? static_cast<int>(trow[-1]) : static_cast<int>(ws->tile[y8 * 8 + 1 + k][x8 * 8]); };
+            // 8.3.2.2.1 reference sample filtering, one sample per lane
+            if (lane < 17) {
+                int x = lane - 1, v;
+                if (x < 0) {
+                    if (has_top && has_left)
+                        v = (Tr(0) + 2 * Tr(-1) + Lr(0) + 2) >> 2;
+                    else if (has_top)
+                        v = (3 * Tr(-1) + Tr(0) + 2) >> 2;
+                    else if (has_left)
+                        v = (3 * Tr(-1) + Lr(0) + 2) >> 2;
+                    else
+                        v = Tr(-1);
+                } else if (x == 0)
+                    v = has_tl ? (Tr(-1) + 2 * Tr(0) + Tr(1) + 2) >> 2 : (3 * Tr(0) + Tr(1) + 2) >> 2;
+                else if (x < 15)
+                    v = (Tr(x - 1) + 2 * Tr(x) + Tr(x + 1) + 2) >> 2;
+                else
+                    v = (Tr(14) + 3 * Tr(15) + 2) >> 2;
+                ws->fe[0][lane] = static_cast<int16_t>(v);
+            } else if (lane >= 32 && lane < 40) {
+                int y = lane - 32, v;
+                if (y == 0)
+                    v = has_tl ? (Lr(-1) + 2 * Lr(0) + Lr(1) + 2) >> 2 : (3 * Lr(0) + Lr(1) + 2) >> 2;
+                else if (y < 7)
+                    v = (Lr(y - 1) + 2 * Lr(y) + Lr(y + 1) + 2) >> 2;
+                else
+                    v = (Lr(6) + 3 * Lr(7) + 2) >> 2;
+                ws->fe[1][y + 1] = static_cast<int16_t>(v);
+            }
+            WAVE_SYNC();
+            {
+                const int x = lane & 7, y = lane >> 3;
+                auto T = [&](int k) { return static_cast<int>(ws->fe[0][k + 1]); };
+                auto L = [&](int k) { return k < 0 ? static_cast<int>(ws->fe[0][0]) : static_cast<int>(ws->fe[1][k + 1]); };
+                int v;
+                if (mode == 0)
+                    v = T(x);
+                else if (mode == 1)
+                    v = L(y);
+                else if (mode == 2) {
+                    int st = 0, sl = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) st += T(k), sl += L(k);
+                    v = (has_top && has_left) ? (st + sl + 8) >> 4 : (has_top ? (st + 4) >> 3 : (has_left ? (sl + 4) >> 3 : 128));
+                } else
+                    v = pred_dir<8>(mode, x, y, T, L);
+                v = clip255(v + ws->rb.luma[(y8 * 8 + y) * 16 + x8 * 8 + x]);
+                WAVE_SYNC(); // all lanes have read fe[] / tile before the block is written
+                ws->tile[y8 * 8 + 1 + y][x8 * 8 + 1 + x] = static_cast<uint8_t>(v);
+            }
+            WAVE_SYNC();
+        }
+    }
+    if (type != MBT_I16x16) { // tile -> frame: one dword per lane
+        const int j = lane >> 2, i0 = (lane & 3) * 4;
+        const uint8_t *t = &ws->tile[j + 1][i0 + 1];
+        uint32_t packed = t[0] | (t[1] << 8) | (t[2] << 16) | (static_cast<uint32_t>(t[3]) << 24);
+        *reinterpret_cast<uint32_t *>(Y + static_cast<size_t>(j) * W + i0) = packed;
+    }
+    // ---- chroma (8.3.4) ----
+    {
+        const int mode = rec->chroma_mode;
+        const int c = lane >> 5, q = lane & 31, y = q >> 2, x0 = (q & 3) * 2;
+        auto T = [&](int k) { return static_cast<int>(ws->tile_c[c][0][k + 1]); };
+        auto L = [&](int k) { return static_cast<int>(ws->tile_c[c][k + 1][0]); };
+        int pa = 0, pb = 0, pc = 0, dc = 128;
+        if (mode == 3)
+            plane_params<8>(T, L, pa, pb, pc);
+        else if (mode == 0) {
+            const int xo = x0 & 4, yo = y & 4;
+            int st = T(xo) + T(xo + 1) + T(xo + 2) + T(xo + 3), sl = L(yo) + L(yo + 1) + L(yo + 2) + L(yo + 3);
+            int use_t = a_top, use_l = a_left != 0;
+            if (xo && !yo && a_top)
+                use_l = 0;
+            else if (!xo && yo && a_left)
+                use_t = 0;
+            if (use_t && use_l)
+                dc = (st + sl + 4) >> 3;
+            else if (use_t)
+                dc = (st + 2) >> 2;
+            else if (use_l)
+                dc = (sl + 2) >> 2;
+        }
+        uint32_t packed = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            int x = x0 + k, v;
+            if (mode == 0)
+                v = dc;
+            else if (mode == 1)
+                v = L(y);
+            else if (mode == 2)
+                v = T(x);
+            else
+                v = clip255((pa + pb * (x - 3) + pc * (y - 3) + 16) >> 5);
+            v = clip255(v + ws->rb.chroma[c][y * 8 + x]);
+            packed |= static_cast<uint32_t>(v) << (8 * k);
+        }
+        *reinterpret_cast<uint16_t *>(C[c] + static_cast<size_t>(y) * Wc + x0) = static_cast<uint16_t>(packed);
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab,
+                                                                          const MbRec *mbrec, const int16_t *coefs) {
+    __shared__ IntraShared sh;
+    const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6;
+    const PicDesc *pd = &pics[pic_list[blockIdx.x]];
+    const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
+    const FramePool *pool = &pools[pd->stream];
+    const int W = static_cast<int>(pool->w), H = static_cast<int>(pool->h);
+    uint8_t *py = reinterpret_cast<uint8_t *>(pool->base) + static_cast<size_t>(pd->slot) * pool->slot_bytes;
+    uint8_t *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
+    for (int i = tid; i < 320; i += MI_INTRA_WAVES * 64) sh.prog[i] = 0;
+    __syncthreads();
+    IntraWave *ws = &sh.w[wave];
+    const ScalingSet *sc = &tab->scaling[pd->scaling_set];
+    for (int mby = wave; mby < hmb; mby += MI_INTRA_WAVES) {
+        for (int mbx = 0; mbx < wmb; mbx++) {
+            const uint64_t mbi = pd->mb_base + static_cast<uint64_t>(mby) * wmb + mbx;
+            const MbRec *rec = mbrec + mbi;
+            if (MB_IS_INTRA(rec->type)) {
+                if (mby > 0) { // 2-D wavefront: the row above must be past the top-right neighbour
+                    const int need = min(mbx + 2, wmb);
+                    while (__hip_atomic_load(&sh.prog[mby - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+                }
+                intra_mb(lane, ws, rec, coefs + mbi * MI_COEF_PER_MB, sc, py, pcb, pcr, W, mbx, mby);
+            }
+            // publish progress: the release orders this wave's global stores before the counter update
+            if (lane == 0) __hip_atomic_store(&sh.prog[mby], mbx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+// ================================================================== K6: crop + pack to tight I420
+extern "C" __global__ void k_pack(const uint8_t *src_y, const uint8_t *src_cb, const uint8_t *src_cr, int pitch, int x0, int y0, int w, int h, uint8_t *dst) {
+    const int total = w * h * 3 / 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        uint8_t v;
+        if (i < w * h) {
+            int y = i / w, x = i - y * w;
+            v = src_y[static_cast<size_t>(y + y0) * pitch + x + x0];
+        } else {
+            int k = i - w * h, cw = w / 2, ch = h / 2;
+            const uint8_t *src = k < cw * ch ? src_cb : src_cr;
+            if (k >= cw * ch) k -= cw * ch;
+            int y = k / cw, x = k - y * cw;
+            v = src[static_cast<size_t>(y + y0 / 2) * (pitch / 2) + x + x0 / 2];
+        }
+        dst[i] = v;
+    }
+}

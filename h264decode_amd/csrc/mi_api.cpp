@@ -1,0 +1,944 @@
+// h264decode_amd/csrc/mi_api.cpp -- the C ABI of libh264mi.so (include/h264mi.h): host-side
+// front end (NAL dispatch h264/server.go:113-166, picture management 8.2) and GPU launch sequence.
+//
+// There is deliberately NO CPU pixel path in this library: every sample is produced by the HIP
+// kernels in k_entropy.hip / k_recon.hip / k_deblock.hip.  If no device is usable the create call
+// fails (H264MI_ENODEVICE).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../include/h264mi.h"
+#include "mi_kernels.h"
+#include "mi_parse.hpp"
+#include "mi_tables.h"
+
+using namespace mi;
+
+#define HIP_TRY(x)                                                                          \
+    do {                                                                                    \
+        hipError_t _e = (x);                                                                \
+        if (_e != hipSuccess) {                                                             \
+            set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return H264MI_EDEVICE;                                                          \
+        }                                                                                   \
+    } while (0)
+
+// ---------------------------------------------------------------- device tables
+static void put_vlc(uint16_t *lut, int bits, int len, uint32_t code, uint16_t value) {
+    if (!len || len > bits) return;
+    uint32_t base = code << (bits - len), n = 1u << (bits - len);
+    for (uint32_t i = 0; i < n; i++) lut[base + i] = static_cast<uint16_t>((len << 8) | value);
+}
+static void build_tables(DevTables *t) {
+    memset(t, 0, sizeof(*t));
+    memcpy(t->range_lps, mi_range_lps, sizeof(t->range_lps));
+    memcpy(t->trans_lps, mi_trans_lps, sizeof(t->trans_lps));
+    // 9.3.1.1 (9-5): h264/cabac.go:118-121 PreCtxState, :158-164 split into pStateIdx / valMPS
+    for (int set = 0; set < 4; set++)
+        for (int qp = 0; qp < 52; qp++)
+            for (int i = 0; i < MI_NCTX; i++) {
+                int pre = ((mi_cabac_mn[set][i][0] * qp) >> 4) + mi_cabac_mn[set][i][1];
+                pre = std::min(std::max(pre, 1), 126);
+                t->ctx_init[set][qp][i] = pre <= 63 ? static_cast<uint8_t>((63 - pre) << 1) : static_cast<uint8_t>(((pre - 64) << 1) | 1);
+            }
+    memcpy(t->sig8x8, mi_sig8x8_ctx, 63);
+    memcpy(t->last8x8, mi_last8x8_ctx, 63);
+    memcpy(t->zigzag4, mi_zigzag4x4, 16);
+    memcpy(t->zigzag8, mi_zigzag8x8, 64);
+    memcpy(t->me_intra, mi_me_intra, 48);
+    memcpy(t->me_inter, mi_me_inter, 48);
+    memcpy(t->alpha, mi_alpha, 52);
+    memcpy(t->beta, mi_beta, 52);
+    for (int i = 0; i < 52; i++) {
+        for (int b = 0; b < 3; b++) t->tc0[i][b + 1] = mi_tc0[i][b];
+        t->qpc[i] = i < 30 ? static_cast<uint8_t>(i) : mi_qpc_tab[i - 30];
+    }
+    for (int tc = 0; tc <= 16; tc++)
+        for (int t1 = 0; t1 <= std::min(tc, 3); t1++) {
+            uint16_t v = static_cast<uint16_t>((tc << 2) | t1);
+            put_vlc(t->vlc_ct0, MI_VLC_CT0_BITS, mi_coeff_token_len[0][4 * tc + t1], mi_coeff_token_bits[0][4 * tc + t1], v);
+            put_vlc(t->vlc_ct1, MI_VLC_CT1_BITS, mi_coeff_token_len[1][4 * tc + t1], mi_coeff_token_bits[1][4 * tc + t1], v);
+            put_vlc(t->vlc_ct2, MI_VLC_CT2_BITS, mi_coeff_token_len[2][4 * tc + t1], mi_coeff_token_bits[2][4 * tc + t1], v);
+            put_vlc(t->vlc_ct3, 6, mi_coeff_token_len[3][4 * tc + t1], mi_coeff_token_bits[3][4 * tc + t1], v);
+            if (tc <= 4) put_vlc(t->vlc_cdc, 8, mi_chroma_dc_token_len[4 * tc + t1], mi_chroma_dc_token_bits[4 * tc + t1], v);
+        }
+    for (int tc = 1; tc <= 15; tc++)
+        for (int tz = 0; tz <= 16 - tc && tz < 16; tz++) put_vlc(t->vlc_tz[tc - 1], 9, mi_total_zeros_len[tc - 1][tz], mi_total_zeros_bits[tc - 1][tz], static_cast<uint16_t>(tz));
+    for (int tc = 1; tc <= 3; tc++)
+        for (int tz = 0; tz <= 4 - tc; tz++) put_vlc(t->vlc_cdc_tz[tc - 1], 3, mi_chroma_dc_total_zeros_len[tc - 1][tz], mi_chroma_dc_total_zeros_bits[tc - 1][tz], static_cast<uint16_t>(tz));
+    for (int zl = 1; zl <= 7; zl++)
+        for (int r = 0; r < 15; r++) put_vlc(t->vlc_run[zl - 1], 11, mi_run_len[zl - 1][r], mi_run_bits[zl - 1][r], static_cast<uint16_t>(r));
+}
+static void build_scaling(const uint8_t s4[6][16], const uint8_t s8[2][64], ScalingSet *o) { // 8.5.9
+    for (int l = 0; l < 6; l++)
+        for (int q = 0; q < 6; q++)
+            for (int k = 0; k < 16; k++) {
+                int r = mi_zigzag4x4[k], x = r & 3, y = r >> 2;
+                int v = (!(x & 1) && !(y & 1)) ? mi_norm4x4[q][0] : (((x & 1) && (y & 1)) ? mi_norm4x4[q][1] : mi_norm4x4[q][2]);
+                o->ls4[l][q][r] = static_cast<uint16_t>(s4[l][k] * v);
+            }
+    for (int l = 0; l < 2; l++)
+        for (int q = 0; q < 6; q++)
+            for (int k = 0; k < 64; k++) {
+                int r = mi_zigzag8x8[k], x = r & 7, y = r >> 3, c;
+                if (!(x & 3) && !(y & 3))
+                    c = 0;
+                else if ((x & 1) && (y & 1))
+                    c = 1;
+                else if ((x & 3) == 2 && (y & 3) == 2)
+                    c = 2;
+                else if ((!(y & 3) && (x & 1)) || ((y & 1) && !(x & 3)))
+                    c = 3;
+                else if ((!(y & 3) && (x & 3) == 2) || ((y & 3) == 2 && !(x & 3)))
+                    c = 4;
+                else
+                    c = 5;
+                o->ls8[l][q][r] = static_cast<uint16_t>(s8[l][k] * mi_norm8x8[q][c]);
+            }
+}
+
+// ---------------------------------------------------------------- per-stream host state
+struct Slot {
+    int ref = 0; // 0 unused, 1 short-term, 2 long-term
+    int frame_num = 0, frame_num_wrap = 0, pic_num = 0, long_idx = 0, poc = 0;
+    bool held = false; // output of the current batch: keep until the next prepare
+};
+struct StreamState {
+    h264mi_sps sps[32];
+    h264mi_pps pps[256];
+    bool sps_ok[32] = {}, pps_ok[256] = {};
+    int active_sps = -1;
+    int wmb = 0, hmb = 0;
+    std::vector<Slot> slots;
+    int prev_poc_msb = 0, prev_poc_lsb = 0, prev_frame_num = 0, prev_frame_num_offset = 0;
+    // picture under construction
+    int cur_slot = -1, cur_pic = -1, cur_slices = 0;
+    h264mi_slice_header first_sh;
+    std::vector<int> out_slots; // frames of this batch in decoding order
+    int n_pics_in_batch = 0;
+};
+
+struct h264mi_decoder {
+    h264mi_config cfg;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<StreamState> st;
+    int Wmax = 0, Hmax = 0, n_slots = 0;
+    size_t slot_bytes = 0;
+    // device + pinned host mirrors
+    uint8_t *d_bits = nullptr, *h_bits = nullptr;
+    size_t bits_cap = 0, bits_used = 0;
+    SliceDesc *d_slices = nullptr, *h_slices = nullptr;
+    PicDesc *d_pics = nullptr, *h_pics = nullptr;
+    uint32_t *d_status = nullptr, *h_status = nullptr, *d_lists = nullptr, *h_lists = nullptr;
+    int slices_cap = 0, pics_cap = 0;
+    MbRec *d_mbrec = nullptr;
+    int16_t *d_coef = nullptr;
+    uint64_t mb_cap = 0, mb_used = 0;
+    FramePool *d_pools = nullptr;
+    std::vector<FramePool> h_pools;
+    uint8_t *d_frames = nullptr;
+    DevTables *d_tables = nullptr, *h_tables = nullptr;
+    int n_scaling = 0;
+    bool tables_dirty = true;
+    // batch
+    int n_slices = 0, n_pics = 0, wmb_max = 0, mbs_max = 0;
+    std::vector<std::vector<uint32_t>> waves, waves_inter;
+    std::vector<uint32_t> wave_off, wave_inter_off;
+    bool prepared = false;
+    h264mi_batch_info info;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_kind;
+    size_t ev_used = 0;
+    double k_ms[5] = {0, 0, 0, 0, 0};
+};
+
+static int g_device = -1;
+
+extern "C" const char *h264mi_last_error_string(void) { return last_error(); }
+extern "C" const char *h264mi_version(void) { return "h264mi 0.1 (gfx950)"; }
+
+extern "C" int32_t h264mi_annexb_scan(const uint8_t *buf, size_t len, h264mi_nal *out, int32_t cap, int32_t *n) {
+    if (!buf || !out || !n || cap < 0) return H264MI_EINVAL;
+    int cnt = 0;
+    int r = annexb_scan(buf, len, out, cap, &cnt);
+    *n = cnt;
+    return r;
+}
+extern "C" int32_t h264mi_nal_parse(const uint8_t *nal, size_t len, h264mi_nal *hdr, uint8_t *rbsp, size_t *rbsp_len) { return nal_parse(nal, len, hdr, rbsp, rbsp_len); }
+extern "C" int32_t h264mi_sps_parse(const uint8_t *rbsp, size_t len, h264mi_sps *sps) { return parse_sps(rbsp, len, sps); }
+extern "C" int32_t h264mi_pps_parse(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi_pps *pps) { return parse_pps(sps, rbsp, len, pps); }
+extern "C" int32_t h264mi_slice_header_parse(const h264mi_sps *sps, const h264mi_pps *pps, int32_t nal_ref_idc, int32_t nal_unit_type, const uint8_t *rbsp,
+                                             size_t len, h264mi_slice_header *sh) {
+    return parse_slice_header(sps, pps, nal_ref_idc, nal_unit_type, rbsp, len, sh);
+}
+
+extern "C" int32_t h264mi_init(int32_t device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device available: the decode path needs a gfx950 GPU (there is no CPU fallback)");
+        return H264MI_ENODEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (0..%d)", device, n - 1);
+        return H264MI_EINVAL;
+    }
+    HIP_TRY(hipSetDevice(device));
+    g_device = device;
+    return H264MI_OK;
+}
+
+static void free_all(h264mi_decoder *d) {
+    if (d->d_bits) hipFree(d->d_bits);
+    if (d->h_bits) hipHostFree(d->h_bits);
+    if (d->d_slices) hipFree(d->d_slices);
+    if (d->h_slices) hipHostFree(d->h_slices);
+    if (d->d_pics) hipFree(d->d_pics);
+    if (d->h_pics) hipHostFree(d->h_pics);
+    if (d->d_status) hipFree(d->d_status);
+    if (d->h_status) hipHostFree(d->h_status);
+    if (d->d_lists) hipFree(d->d_lists);
+    if (d->h_lists) hipHostFree(d->h_lists);
+    if (d->d_mbrec) hipFree(d->d_mbrec);
+    if (d->d_coef) hipFree(d->d_coef);
+    if (d->d_pools) hipFree(d->d_pools);
+    if (d->d_frames) hipFree(d->d_frames);
+    if (d->d_tables) hipFree(d->d_tables);
+    if (d->h_tables) hipHostFree(d->h_tables);
+    for (auto e : d->ev) hipEventDestroy(e);
+    if (d->own_stream && d->stream) hipStreamDestroy(d->stream);
+}
+
+extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decoder **out) {
+    if (!cfg || !out || cfg->max_streams < 1 || cfg->max_width < 16 || cfg->max_height < 16 || cfg->max_frames_per_batch < 1) return H264MI_EINVAL;
+    int r = h264mi_init(cfg->device);
+    if (r != H264MI_OK) return r;
+    h264mi_decoder *d = new h264mi_decoder();
+    d->cfg = *cfg;
+    if (d->cfg.max_slices_per_frame < 1) d->cfg.max_slices_per_frame = 1;
+    d->Wmax = (cfg->max_width + 15) & ~15;
+    d->Hmax = (cfg->max_height + 15) & ~15;
+    d->n_slots = cfg->max_frames_per_batch + MI_MAX_REFS + 1;
+    d->slot_bytes = (static_cast<size_t>(d->Wmax) * d->Hmax * 3 / 2 + 255) & ~static_cast<size_t>(255);
+    const int S = cfg->max_streams;
+    d->st.resize(S);
+    for (auto &s : d->st) s.slots.resize(d->n_slots);
+    d->pics_cap = S * cfg->max_frames_per_batch;
+    d->slices_cap = d->pics_cap * d->cfg.max_slices_per_frame;
+    d->mb_cap = static_cast<uint64_t>(d->pics_cap) * (d->Wmax / 16) * (d->Hmax / 16);
+    d->bits_cap = cfg->max_bitstream_bytes > 0 ? static_cast<size_t>(cfg->max_bitstream_bytes) : std::max<size_t>(static_cast<size_t>(d->pics_cap) * d->Wmax * d->Hmax / 2, 1 << 20);
+    d->bits_cap = (d->bits_cap + 16 * static_cast<size_t>(d->slices_cap) + 8192 + 15) & ~static_cast<size_t>(15);
+    auto fail = [&](int code) {
+        free_all(d);
+        delete d;
+        return code;
+    };
+#define TRY_ALLOC(x)                                                                 \
+    do {                                                                             \
+        hipError_t _e = (x);                                                         \
+        if (_e != hipSuccess) {                                                      \
+            set_error("%s failed: %s", #x, hipGetErrorString(_e));                   \
+            return fail(_e == hipErrorOutOfMemory ? H264MI_ENOMEM : H264MI_EDEVICE); \
+        }                                                                            \
+    } while (0)
+    if (cfg->hip_stream)
+        d->stream = static_cast<hipStream_t>(cfg->hip_stream);
+    else {
+        TRY_ALLOC(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        d->own_stream = true;
+    }
+    TRY_ALLOC(hipMalloc(&d->d_bits, d->bits_cap));
+    TRY_ALLOC(hipHostMalloc(&d->h_bits, d->bits_cap));
+    TRY_ALLOC(hipMalloc(&d->d_slices, sizeof(SliceDesc) * d->slices_cap));
+    TRY_ALLOC(hipHostMalloc(&d->h_slices, sizeof(SliceDesc) * d->slices_cap));
+    TRY_ALLOC(hipMalloc(&d->d_pics, sizeof(PicDesc) * d->pics_cap));
+    TRY_ALLOC(hipHostMalloc(&d->h_pics, sizeof(PicDesc) * d->pics_cap));
+    TRY_ALLOC(hipMalloc(&d->d_status, sizeof(uint32_t) * 2 * d->slices_cap));
+    TRY_ALLOC(hipHostMalloc(&d->h_status, sizeof(uint32_t) * 2 * d->slices_cap));
+    TRY_ALLOC(hipMalloc(&d->d_lists, sizeof(uint32_t) * 2 * d->pics_cap));
+    TRY_ALLOC(hipHostMalloc(&d->h_lists, sizeof(uint32_t) * 2 * d->pics_cap));
+    TRY_ALLOC(hipMalloc(&d->d_mbrec, sizeof(MbRec) * d->mb_cap));
+    TRY_ALLOC(hipMalloc(&d->d_coef, sizeof(int16_t) * MI_COEF_PER_MB * d->mb_cap));
+    TRY_ALLOC(hipMalloc(&d->d_pools, sizeof(FramePool) * S));
+    TRY_ALLOC(hipMalloc(&d->d_frames, d->slot_bytes * d->n_slots * S));
+    TRY_ALLOC(hipMalloc(&d->d_tables, sizeof(DevTables)));
+    TRY_ALLOC(hipHostMalloc(&d->h_tables, sizeof(DevTables)));
+    build_tables(d->h_tables);
+    d->h_pools.resize(S);
+    // a deterministic background for macroblocks no slice covers
+    TRY_ALLOC(hipMemsetAsync(d->d_frames, 128, d->slot_bytes * d->n_slots * S, d->stream));
+    TRY_ALLOC(hipStreamSynchronize(d->stream));
+#undef TRY_ALLOC
+    *out = d;
+    return H264MI_OK;
+}
+
+extern "C" int32_t h264mi_decoder_destroy(h264mi_decoder *d) {
+    if (!d) return H264MI_EINVAL;
+    hipStreamSynchronize(d->stream);
+    free_all(d);
+    delete d;
+    return H264MI_OK;
+}
+extern "C" int32_t h264mi_decoder_set_stream(h264mi_decoder *d, void *s) {
+    if (!d) return H264MI_EINVAL;
+    hipStreamSynchronize(d->stream);
+    if (d->own_stream) hipStreamDestroy(d->stream);
+    d->own_stream = false;
+    d->stream = static_cast<hipStream_t>(s);
+    return H264MI_OK;
+}
+extern "C" int32_t h264mi_decoder_reset(h264mi_decoder *d) {
+    if (!d) return H264MI_EINVAL;
+    for (auto &s : d->st) {
+        for (auto &sl : s.slots) sl = Slot();
+        s.cur_slot = s.cur_pic = -1;
+        s.out_slots.clear();
+    }
+    d->prepared = false;
+    return H264MI_OK;
+}
+extern "C" int32_t h264mi_decoder_set_profiling(h264mi_decoder *d, int32_t on) {
+    if (!d) return H264MI_EINVAL;
+    d->profiling = on != 0;
+    return H264MI_OK;
+}
+
+// ---------------------------------------------------------------- picture management (8.2)
+static int compute_poc(StreamState &s, const h264mi_sps &sps, const h264mi_slice_header &sh) { // 8.2.1
+    const bool idr = sh.nal_unit_type == 5;
+    const int max_fn = 1 << (sps.log2_max_frame_num_minus4 + 4);
+    int poc = 0;
+    if (sps.pic_order_count_type == 0) {
+        const int max_lsb = 1 << (sps.log2_max_pic_order_cnt_lsb_min4 + 4);
+        int prev_msb = idr ? 0 : s.prev_poc_msb, prev_lsb = idr ? 0 : s.prev_poc_lsb, msb;
+        if (sh.pic_order_cnt_lsb < prev_lsb && prev_lsb - sh.pic_order_cnt_lsb >= max_lsb / 2)
+            msb = prev_msb + max_lsb;
+        else if (sh.pic_order_cnt_lsb > prev_lsb && sh.pic_order_cnt_lsb - prev_lsb > max_lsb / 2)
+            msb = prev_msb - max_lsb;
+        else
+            msb = prev_msb;
+        int top = msb + sh.pic_order_cnt_lsb;
+        poc = std::min(top, top + sh.delta_pic_order_cnt_bottom);
+        if (sh.nal_ref_idc) s.prev_poc_msb = msb, s.prev_poc_lsb = sh.pic_order_cnt_lsb;
+    } else {
+        int fno = idr ? 0 : (s.prev_frame_num > sh.frame_num ? s.prev_frame_num_offset + max_fn : s.prev_frame_num_offset);
+        if (sps.pic_order_count_type == 1) {
+            int n = sps.num_ref_frames_in_pic_order_cnt_cycle;
+            int abs_fn = n ? fno + sh.frame_num : 0;
+            if (!sh.nal_ref_idc && abs_fn > 0) abs_fn--;
+            int expected = 0;
+            if (abs_fn > 0) {
+                int cyc = (abs_fn - 1) / n, in_cyc = (abs_fn - 1) % n, delta = 0;
+                for (int i = 0; i < n; i++) delta += sps.offset_for_ref_frame_list[i];
+                expected = cyc * delta;
+                for (int i = 0; i <= in_cyc; i++) expected += sps.offset_for_ref_frame_list[i];
+            }
+            if (!sh.nal_ref_idc) expected += sps.offset_for_non_ref_pic;
+            int top = expected + sh.delta_pic_order_cnt[0];
+            poc = std::min(top, top + sps.offset_for_top_to_bottom_field + sh.delta_pic_order_cnt[1]);
+        } else
+            poc = idr ? 0 : (sh.nal_ref_idc ? 2 * (fno + sh.frame_num) : 2 * (fno + sh.frame_num) - 1);
+        s.prev_frame_num_offset = fno;
+    }
+    s.prev_frame_num = sh.frame_num;
+    return poc;
+}
+
+// 8.2.4: RefPicList0 of a P slice as frame-pool slots
+static int build_ref_list(StreamState &s, const h264mi_sps &sps, const h264mi_slice_header &sh, int16_t *out /*MI_MAX_REFS*/) {
+    const int max_fn = 1 << (sps.log2_max_frame_num_minus4 + 4);
+    std::vector<int> st, lt;
+    for (int i = 0; i < static_cast<int>(s.slots.size()); i++) {
+        Slot &sl = s.slots[i];
+        if (i == s.cur_slot) continue;
+        if (sl.ref == 1) {
+            sl.frame_num_wrap = sl.frame_num > sh.frame_num ? sl.frame_num - max_fn : sl.frame_num;
+            sl.pic_num = sl.frame_num_wrap;
+            st.push_back(i);
+        } else if (sl.ref == 2) {
+            sl.pic_num = sl.long_idx;
+            lt.push_back(i);
+        }
+    }
+    std::sort(st.begin(), st.end(), [&](int a, int b) { return s.slots[a].pic_num > s.slots[b].pic_num; });
+    std::sort(lt.begin(), lt.end(), [&](int a, int b) { return s.slots[a].long_idx < s.slots[b].long_idx; });
+    std::vector<int> list(st);
+    list.insert(list.end(), lt.begin(), lt.end());
+    if (list.empty()) {
+        set_error("P slice without reference pictures");
+        return H264MI_EBITSTREAM;
+    }
+    const int nact = sh.num_ref_idx_l0_active_minus1 + 1;
+    if (nact > MI_MAX_REFS) {
+        set_error("num_ref_idx_l0_active %d > %d (field refs are out of scope)", nact, MI_MAX_REFS);
+        return H264MI_EUNSUPPORTED;
+    }
+    list.resize(std::max<size_t>(list.size(), nact + 1), -1);
+    if (sh.ref_pic_list_modification_flag_l0) { // 8.2.4.3
+        int pred = sh.frame_num, idx = 0;
+        for (int k = 0; k < sh.n_ref_pic_list_modifications && idx < nact; k++) {
+            int target = -1;
+            if (sh.modification_of_pic_nums[k] < 2) {
+                int diff = sh.modification_value[k] + 1;
+                if (sh.modification_of_pic_nums[k] == 0) {
+                    pred -= diff;
+                    if (pred < 0) pred += max_fn;
+                } else {
+                    pred += diff;
+                    if (pred >= max_fn) pred -= max_fn;
+                }
+                int picnum = pred > sh.frame_num ? pred - max_fn : pred;
+                for (int i : st)
+                    if (s.slots[i].pic_num == picnum) target = i;
+            } else
+                for (int i : lt)
+                    if (s.slots[i].long_idx == sh.modification_value[k]) target = i;
+            if (target < 0) {
+                set_error("ref_pic_list_modification names a missing picture");
+                return H264MI_EBITSTREAM;
+            }
+            for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+            list[idx++] = target;
+            int nidx = idx;
+            for (int c = idx; c <= nact; c++)
+                if (list[c] != target) list[nidx++] = list[c];
+        }
+    }
+    for (int i = 0; i < MI_MAX_REFS; i++) out[i] = static_cast<int16_t>(i < nact ? list[i] : -1);
+    return H264MI_OK;
+}
+
+// 8.2.5: marking after the current picture is complete
+static void mark_reference(StreamState &s, const h264mi_sps &sps) {
+    const h264mi_slice_header &sh = s.first_sh;
+    Slot &cur = s.slots[s.cur_slot];
+    const int max_fn = 1 << (sps.log2_max_frame_num_minus4 + 4);
+    if (!sh.nal_ref_idc) {
+        cur.ref = 0;
+        return;
+    }
+    if (sh.nal_unit_type == 5) {
+        for (auto &sl : s.slots) sl.ref = 0;
+        cur.ref = sh.long_term_reference_flag ? 2 : 1;
+        cur.long_idx = 0;
+        return;
+    }
+    cur.ref = 1;
+    if (sh.adaptive_ref_pic_marking_mode_flag) {
+        for (int k = 0; k < sh.n_memory_management_control_operations; k++) {
+            int op = sh.memory_management_control_operation[k];
+            for (auto &sl : s.slots)
+                if (sl.ref == 1) sl.pic_num = sl.frame_num > sh.frame_num ? sl.frame_num - max_fn : sl.frame_num;
+            if (op == 1 || op == 3) {
+                int picnum = sh.frame_num - (sh.mmco_arg1[k] + 1);
+                for (auto &sl : s.slots)
+                    if (&sl != &cur && sl.ref == 1 && sl.pic_num == picnum) {
+                        if (op == 1)
+                            sl.ref = 0;
+                        else {
+                            for (auto &o : s.slots)
+                                if (o.ref == 2 && o.long_idx == sh.mmco_arg2[k]) o.ref = 0;
+                            sl.ref = 2, sl.long_idx = sh.mmco_arg2[k];
+                        }
+                    }
+            } else if (op == 2) {
+                for (auto &sl : s.slots)
+                    if (sl.ref == 2 && sl.long_idx == sh.mmco_arg1[k]) sl.ref = 0;
+            } else if (op == 4) {
+                for (auto &sl : s.slots)
+                    if (sl.ref == 2 && sl.long_idx >= sh.mmco_arg1[k]) sl.ref = 0;
+            } else if (op == 5) {
+                for (auto &sl : s.slots)
+                    if (&sl != &cur) sl.ref = 0;
+                cur.frame_num = 0;
+                s.prev_frame_num = s.prev_frame_num_offset = s.prev_poc_msb = s.prev_poc_lsb = 0;
+            } else if (op == 6) {
+                for (auto &o : s.slots)
+                    if (o.ref == 2 && o.long_idx == sh.mmco_arg2[k]) o.ref = 0;
+                cur.ref = 2, cur.long_idx = sh.mmco_arg2[k];
+            }
+        }
+    } else { // sliding window 8.2.5.3
+        int nref = 0, maxref = std::max(sps.max_num_ref_frames, 1);
+        Slot *oldest = nullptr;
+        for (auto &sl : s.slots) {
+            if (&sl == &cur || !sl.ref) continue;
+            nref++;
+            if (sl.ref == 1) {
+                sl.frame_num_wrap = sl.frame_num > sh.frame_num ? sl.frame_num - max_fn : sl.frame_num;
+                if (!oldest || sl.frame_num_wrap < oldest->frame_num_wrap) oldest = &sl;
+            }
+        }
+        if (nref >= maxref && oldest) oldest->ref = 0;
+    }
+}
+
+static void finish_picture(h264mi_decoder *d, StreamState &s) {
+    if (s.cur_slot < 0) return;
+    mark_reference(s, s.sps[s.active_sps]);
+    d->h_pics[s.cur_pic].n_slices = static_cast<uint32_t>(s.cur_slices);
+    s.cur_slot = s.cur_pic = -1;
+}
+
+static bool new_picture(const h264mi_sps &sps, const h264mi_slice_header &a, const h264mi_slice_header &b) { // 7.4.1.2.4
+    if (a.frame_num != b.frame_num || a.pps_id != b.pps_id) return true;
+    if ((a.nal_ref_idc == 0) != (b.nal_ref_idc == 0)) return true;
+    if ((a.nal_unit_type == 5) != (b.nal_unit_type == 5)) return true;
+    if (a.nal_unit_type == 5 && a.idr_pic_id != b.idr_pic_id) return true;
+    if (sps.pic_order_count_type == 0 && (a.pic_order_cnt_lsb != b.pic_order_cnt_lsb || a.delta_pic_order_cnt_bottom != b.delta_pic_order_cnt_bottom)) return true;
+    if (sps.pic_order_count_type == 1 && (a.delta_pic_order_cnt[0] != b.delta_pic_order_cnt[0] || a.delta_pic_order_cnt[1] != b.delta_pic_order_cnt[1])) return true;
+    return false;
+}
+
+static int scaling_set_for(h264mi_decoder *d, const h264mi_pps &p) {
+    ScalingSet tmp;
+    build_scaling(p.scaling_list_4x4, p.scaling_list_8x8, &tmp);
+    for (int i = 0; i < d->n_scaling; i++)
+        if (!memcmp(&d->h_tables->scaling[i], &tmp, sizeof(tmp))) return i;
+    if (d->n_scaling >= MI_MAX_SCALING_SETS) return -1;
+    d->h_tables->scaling[d->n_scaling] = tmp;
+    d->tables_dirty = true;
+    return d->n_scaling++;
+}
+
+// one slice NAL of stream `si`
+static int add_slice(h264mi_decoder *d, int si, const uint8_t *nal, size_t len, int ref_idc, int type) {
+    StreamState &s = d->st[si];
+    if (d->n_slices >= d->slices_cap) {
+        set_error("more than %d slices in the batch", d->slices_cap);
+        return H264MI_ECAPACITY;
+    }
+    // unescape straight into the pinned staging buffer, 16-byte aligned
+    size_t off = (d->bits_used + 15) & ~static_cast<size_t>(15);
+    if (off + len + 4096 > d->bits_cap) {
+        set_error("bitstream staging buffer too small (%zu bytes)", d->bits_cap);
+        return H264MI_ECAPACITY;
+    }
+    uint8_t *rbsp = d->h_bits + off;
+    size_t rlen = unescape(nal + 1, len - 1, rbsp);
+    // peek pps id: first_mb_in_slice, slice_type, pic_parameter_set_id
+    BitReader br(rbsp, rlen);
+    br.ue();
+    br.ue();
+    uint32_t pps_id = br.ue();
+    if (pps_id > 255 || !s.pps_ok[pps_id]) {
+        set_error("stream %d: slice refers to missing PPS %u", si, pps_id);
+        return H264MI_EBITSTREAM;
+    }
+    const h264mi_pps &pps = s.pps[pps_id];
+    if (!s.sps_ok[pps.sps_id]) {
+        set_error("stream %d: PPS %u refers to missing SPS %d", si, pps_id, pps.sps_id);
+        return H264MI_EBITSTREAM;
+    }
+    const h264mi_sps &sps = s.sps[pps.sps_id];
+    h264mi_slice_header sh;
+    int r = parse_slice_header(&sps, &pps, ref_idc, type, rbsp, rlen, &sh);
+    if (r != H264MI_OK) return r;
+    if (sh.redundant_pic_cnt > 0) return H264MI_OK; // redundant pictures are dropped
+    const int st = sh.slice_type % 5;
+    if (st != 0 && st != 2) {
+        set_error("stream %d: slice_type %d is out of scope (I and P only)", si, sh.slice_type);
+        return H264MI_EUNSUPPORTED;
+    }
+    if (sps.chroma_format != 1 || sps.bit_depth_luma_minus8 || sps.bit_depth_chroma_minus8 || !sps.frame_mbs_only || sps.qprime_y_zero_transform_bypass) {
+        set_error("stream %d: only 4:2:0 8-bit frame-coded streams are supported (chroma_format_idc %d)", si, sps.chroma_format);
+        return H264MI_EUNSUPPORTED;
+    }
+    const int wmb = sps.pic_width_in_mbs, hmb = sps.pic_height_in_mbs;
+    if (wmb * 16 > d->Wmax || hmb * 16 > d->Hmax || hmb > 320) {
+        set_error("stream %d: %dx%d exceeds the configured maximum %dx%d", si, wmb * 16, hmb * 16, d->Wmax, d->Hmax);
+        return H264MI_ECAPACITY;
+    }
+    if (s.cur_slot >= 0 && (sh.first_mb_in_slice == 0 || new_picture(sps, s.first_sh, sh))) finish_picture(d, s);
+    if (s.active_sps != pps.sps_id || s.wmb != wmb || s.hmb != hmb) { // (re)activate: new sequence geometry
+        if (sh.nal_unit_type != 5 && s.active_sps >= 0 && (s.wmb != wmb || s.hmb != hmb)) {
+            set_error("stream %d: picture size changes without an IDR", si);
+            return H264MI_EBITSTREAM;
+        }
+        s.active_sps = pps.sps_id, s.wmb = wmb, s.hmb = hmb;
+        FramePool &fp = d->h_pools[si];
+        fp.base = reinterpret_cast<uint64_t>(d->d_frames) + static_cast<uint64_t>(si) * d->slot_bytes * d->n_slots;
+        fp.slot_bytes = d->slot_bytes;
+        fp.w = wmb * 16, fp.h = hmb * 16;
+    }
+    if (s.cur_slot < 0) { // first slice of a new picture
+        if (s.n_pics_in_batch >= d->cfg.max_frames_per_batch || d->n_pics >= d->pics_cap) {
+            set_error("stream %d: more than %d frames in one batch", si, d->cfg.max_frames_per_batch);
+            return H264MI_ECAPACITY;
+        }
+        int slot = -1;
+        for (int i = 0; i < static_cast<int>(s.slots.size()) && slot < 0; i++)
+            if (!s.slots[i].ref && !s.slots[i].held) slot = i;
+        if (slot < 0) {
+            set_error("stream %d: frame pool exhausted", si);
+            return H264MI_ECAPACITY;
+        }
+        if (d->mb_used + static_cast<uint64_t>(wmb) * hmb > d->mb_cap) {
+            set_error("macroblock record pool exhausted");
+            return H264MI_ECAPACITY;
+        }
+        s.cur_slot = slot;
+        s.cur_pic = d->n_pics++;
+        s.cur_slices = 0;
+        s.first_sh = sh;
+        Slot &sl = s.slots[slot];
+        sl = Slot();
+        sl.held = true;
+        sl.frame_num = sh.frame_num;
+        sl.poc = compute_poc(s, sps, sh);
+        PicDesc &pd = d->h_pics[s.cur_pic];
+        memset(&pd, 0, sizeof(pd));
+        pd.stream = si, pd.slot = slot, pd.wmb = wmb, pd.hmb = hmb;
+        pd.mb_base = d->mb_used;
+        d->mb_used += static_cast<uint64_t>(wmb) * hmb;
+        pd.first_slice = d->n_slices;
+        pd.cabac = pps.entropy_coding_mode, pd.t8x8_mode = pps.transform_8x8_mode, pd.cip = pps.constrained_intra_pred;
+        pd.weighted_pred = pps.weighted_pred;
+        pd.cqp_off[0] = static_cast<int8_t>(pps.chroma_qp_index_offset), pd.cqp_off[1] = static_cast<int8_t>(pps.second_chroma_qp_index_offset);
+        pd.is_intra_only = 1;
+        int ss = scaling_set_for(d, pps);
+        if (ss < 0) {
+            set_error("more than %d distinct scaling matrices in flight", MI_MAX_SCALING_SETS);
+            return H264MI_ECAPACITY;
+        }
+        pd.scaling_set = static_cast<uint8_t>(ss);
+        pd.order = s.n_pics_in_batch++;
+        s.out_slots.push_back(slot);
+        d->wmb_max = std::max(d->wmb_max, wmb);
+        d->mbs_max = std::max(d->mbs_max, wmb * hmb);
+        d->info.n_macroblocks += static_cast<int64_t>(wmb) * hmb;
+        if (si == 0) d->info.width = sps.width, d->info.height = sps.height, d->info.coded_width = wmb * 16, d->info.coded_height = hmb * 16;
+    }
+    if (s.cur_slices >= d->cfg.max_slices_per_frame) {
+        set_error("stream %d: more than %d slices in a frame", si, d->cfg.max_slices_per_frame);
+        return H264MI_ECAPACITY;
+    }
+    if (sh.first_mb_in_slice >= wmb * hmb) return H264MI_EBITSTREAM;
+    PicDesc &pd = d->h_pics[s.cur_pic];
+    SliceDesc &sd = d->h_slices[d->n_slices];
+    memset(&sd, 0, sizeof(sd));
+    sd.rbsp_off = static_cast<uint32_t>(off), sd.rbsp_size = static_cast<uint32_t>(rlen);
+    sd.data_bit_off = static_cast<uint32_t>(sh.slice_data_bit_offset);
+    {
+        size_t n = rlen;
+        while (n > 0 && rbsp[n - 1] == 0) n--;
+        sd.stop_bit = n ? static_cast<uint32_t>((n - 1) * 8 + 7 - __builtin_ctz(rbsp[n - 1])) : 0;
+    }
+    sd.pic_idx = s.cur_pic, sd.first_mb = sh.first_mb_in_slice;
+    sd.slice_type = static_cast<uint8_t>(st);
+    sd.cabac_init_idc = static_cast<uint8_t>(sh.cabac_init), sd.slice_qp = static_cast<uint8_t>(sh.slice_qp_y);
+    sd.num_ref_idx_active = static_cast<uint8_t>(st == 0 ? sh.num_ref_idx_l0_active_minus1 + 1 : 0);
+    sd.alpha_off = static_cast<int8_t>(2 * sh.slice_alpha_c0_offset_div2), sd.beta_off = static_cast<int8_t>(2 * sh.slice_beta_offset_div2);
+    sd.dbf_idc = static_cast<uint8_t>(sh.disable_deblocking_filter);
+    sd.slice_in_pic = static_cast<uint16_t>(s.cur_slices);
+    for (int i = 0; i < MI_MAX_REFS; i++) sd.ref_slot[i] = -1;
+    if (st == 0) {
+        pd.is_intra_only = 0;
+        r = build_ref_list(s, sps, sh, sd.ref_slot);
+        if (r != H264MI_OK) return r;
+        sd.wp_flag = static_cast<uint8_t>(pps.weighted_pred);
+        sd.luma_log2_denom = static_cast<uint8_t>(sh.luma_log2_weight_denom), sd.chroma_log2_denom = static_cast<uint8_t>(sh.chroma_log2_weight_denom);
+        for (int i = 0; i < MI_MAX_REFS; i++) {
+            sd.wp_lw[i] = static_cast<int16_t>(pps.weighted_pred ? sh.luma_weight_l0[i] : 1), sd.wp_lo[i] = static_cast<int16_t>(sh.luma_offset_l0[i]);
+            for (int j = 0; j < 2; j++)
+                sd.wp_cw[i][j] = static_cast<int16_t>(pps.weighted_pred ? sh.chroma_weight_l0[i][j] : 1), sd.wp_co[i][j] = static_cast<int16_t>(sh.chroma_offset_l0[i][j]);
+        }
+    }
+    d->bits_used = off + rlen;
+    d->n_slices++;
+    s.cur_slices++;
+    return H264MI_OK;
+}
+
+extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, const uint8_t *const *bufs, const size_t *lens, h264mi_batch_info *info) {
+    if (!d || n_streams < 0 || n_streams > static_cast<int>(d->st.size()) || (n_streams && (!bufs || !lens))) return H264MI_EINVAL;
+    auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipStreamSynchronize(d->stream)); // the previous batch must not be reading the staging buffers
+    d->prepared = false;
+    d->n_slices = d->n_pics = 0;
+    d->bits_used = 0, d->mb_used = 0, d->wmb_max = 0, d->mbs_max = 0;
+    memset(&d->info, 0, sizeof(d->info));
+    for (auto &s : d->st) {
+        for (auto &sl : s.slots) sl.held = false;
+        s.out_slots.clear();
+        s.n_pics_in_batch = 0;
+        s.cur_slot = s.cur_pic = -1;
+    }
+    std::vector<h264mi_nal> nals;
+    for (int si = 0; si < n_streams; si++) {
+        if (!bufs[si] || !lens[si]) continue;
+        StreamState &s = d->st[si];
+        nals.resize(1024);
+        int n = 0;
+        while (annexb_scan(bufs[si], lens[si], nals.data(), static_cast<int>(nals.size()), &n) == H264MI_ECAPACITY) nals.resize(nals.size() * 4);
+        std::vector<uint8_t> tmp;
+        for (int i = 0; i < n; i++) {
+            const h264mi_nal &nal = nals[i];
+            const uint8_t *p = bufs[si] + nal.offset;
+            int r = H264MI_OK;
+            switch (nal.type) {
+            case 7: {
+                tmp.resize(nal.num_bytes);
+                size_t rl = unescape(p + 1, nal.num_bytes - 1, tmp.data());
+                h264mi_sps sps;
+                r = parse_sps(tmp.data(), rl, &sps);
+                if (r == H264MI_OK) {
+                    if (s.cur_slot >= 0) finish_picture(d, s);
+                    s.sps[sps.id] = sps, s.sps_ok[sps.id] = true;
+                }
+                break;
+            }
+            case 8: {
+                tmp.resize(nal.num_bytes);
+                size_t rl = unescape(p + 1, nal.num_bytes - 1, tmp.data());
+                BitReader br(tmp.data(), rl);
+                br.ue();
+                uint32_t sid = br.ue();
+                if (sid > 31 || !s.sps_ok[sid]) {
+                    set_error("stream %d: PPS refers to missing SPS %u", si, sid);
+                    r = H264MI_EBITSTREAM;
+                    break;
+                }
+                h264mi_pps pps;
+                r = parse_pps(&s.sps[sid], tmp.data(), rl, &pps);
+                if (r == H264MI_OK) {
+                    if (s.cur_slot >= 0) finish_picture(d, s);
+                    s.pps[pps.id] = pps, s.pps_ok[pps.id] = true;
+                }
+                break;
+            }
+            case 1:
+            case 5: r = add_slice(d, si, p, nal.num_bytes, nal.ref_idc, nal.type); break;
+            case 9:
+            case 10:
+            case 11:
+                if (s.cur_slot >= 0) finish_picture(d, s);
+                break;
+            default: break; // SEI, filler, ... (h264/server.go:147-164 ignores them too)
+            }
+            if (r != H264MI_OK) return r;
+        }
+        if (s.cur_slot >= 0) finish_picture(d, s);
+    }
+    // picture "waves": the k-th picture of every stream can be reconstructed side by side
+    size_t nw = 0;
+    for (auto &s : d->st) nw = std::max<size_t>(nw, s.n_pics_in_batch);
+    d->waves.assign(nw, {});
+    d->waves_inter.assign(nw, {});
+    for (int i = 0; i < d->n_pics; i++) {
+        d->waves[d->h_pics[i].order].push_back(i);
+        if (!d->h_pics[i].is_intra_only) d->waves_inter[d->h_pics[i].order].push_back(i);
+    }
+    d->wave_off.clear();
+    d->wave_inter_off.clear();
+    uint32_t pos = 0;
+    for (size_t w = 0; w < nw; w++) {
+        d->wave_off.push_back(pos);
+        for (uint32_t p : d->waves[w]) d->h_lists[pos++] = p;
+        d->wave_inter_off.push_back(pos);
+        for (uint32_t p : d->waves_inter[w]) d->h_lists[pos++] = p;
+    }
+    // uploads
+    if (d->n_slices) {
+        size_t nbytes = std::min(d->bits_cap, ((d->bits_used + 15) & ~static_cast<size_t>(15)) + 4096);
+        memset(d->h_bits + d->bits_used, 0, nbytes - d->bits_used);
+        HIP_TRY(hipMemcpyAsync(d->d_bits, d->h_bits, nbytes, hipMemcpyHostToDevice, d->stream));
+        HIP_TRY(hipMemcpyAsync(d->d_slices, d->h_slices, sizeof(SliceDesc) * d->n_slices, hipMemcpyHostToDevice, d->stream));
+        HIP_TRY(hipMemcpyAsync(d->d_pics, d->h_pics, sizeof(PicDesc) * d->n_pics, hipMemcpyHostToDevice, d->stream));
+        HIP_TRY(hipMemcpyAsync(d->d_lists, d->h_lists, sizeof(uint32_t) * pos, hipMemcpyHostToDevice, d->stream));
+        HIP_TRY(hipMemcpyAsync(d->d_pools, d->h_pools.data(), sizeof(FramePool) * d->h_pools.size(), hipMemcpyHostToDevice, d->stream));
+    }
+    if (d->tables_dirty) {
+        HIP_TRY(hipMemcpyAsync(d->d_tables, d->h_tables, sizeof(DevTables), hipMemcpyHostToDevice, d->stream));
+        d->tables_dirty = false;
+    }
+    d->info.n_frames = d->n_pics, d->info.n_slices = d->n_slices, d->info.bitstream_bytes = static_cast<int64_t>(d->bits_used);
+    d->info.host_prepare_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (info) *info = d->info;
+    d->prepared = true;
+    return H264MI_OK;
+}
+
+static hipEvent_t next_event(h264mi_decoder *d, size_t &idx, int kind) {
+    if (idx >= d->ev.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        d->ev.push_back(e);
+        d->ev_kind.push_back(kind);
+    }
+    d->ev_kind[idx] = kind;
+    return d->ev[idx++];
+}
+
+extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
+    if (!d || !d->prepared) {
+        set_error("h264mi_batch_execute: no prepared batch");
+        return H264MI_EINVAL;
+    }
+    if (!d->n_slices) return H264MI_OK;
+    size_t ei = 0;
+    const bool prof = d->profiling;
+    auto mark = [&](int kind) {
+        if (prof) hipEventRecord(next_event(d, ei, kind), d->stream);
+    };
+    mark(-1);
+    hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), static_cast<size_t>(d->wmb_max) * 48, d->stream, d->d_slices, d->d_pics, d->d_bits, d->d_tables,
+                       d->d_mbrec, d->d_coef, d->d_status, d->wmb_max);
+    mark(0);
+    for (size_t w = 0; w < d->waves.size(); w++) {
+        const uint32_t n = static_cast<uint32_t>(d->waves[w].size()), ni = static_cast<uint32_t>(d->waves_inter[w].size());
+        if (!n) continue;
+        if (ni) {
+            hipLaunchKernelGGL(k_inter, dim3(ni * d->mbs_max), dim3(64), 0, d->stream, d->d_lists + d->wave_inter_off[w], d->d_pics, d->d_slices, d->d_pools,
+                               d->d_tables, d->d_mbrec, d->d_coef, d->mbs_max);
+            mark(1);
+        }
+        hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, d->stream, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, d->d_mbrec,
+                           d->d_coef);
+        mark(2);
+        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(MI_DEBLOCK_WAVES * 64), 0, d->stream, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables,
+                           d->d_mbrec);
+        mark(3);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(d->h_status, d->d_status, sizeof(uint32_t) * 2 * d->n_slices, hipMemcpyDeviceToHost, d->stream));
+    d->ev_used = prof ? ei : 0;
+    return H264MI_OK;
+}
+
+extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
+    if (!d) return H264MI_EINVAL;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    if (d->profiling && d->ev_used >= 2) {
+        size_t n = d->ev_used;
+        double acc[4] = {0, 0, 0, 0};
+        for (size_t i = 1; i < n && i < d->ev.size(); i++) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, d->ev[i - 1], d->ev[i]);
+            int k = d->ev_kind[i];
+            if (k >= 0 && k < 4) acc[k] += ms;
+        }
+        float tot = 0;
+        hipEventElapsedTime(&tot, d->ev[0], d->ev[n - 1]);
+        for (int k = 0; k < 4; k++) d->k_ms[k] = acc[k];
+        d->k_ms[4] = tot;
+    }
+    for (int i = 0; i < d->n_slices; i++)
+        if (d->h_status[2 * i]) {
+            const SliceDesc &sd = d->h_slices[i];
+            set_error("entropy kernel: slice %d (picture %u, stream %u) failed with code %u after %u macroblocks", i, sd.pic_idx, d->h_pics[sd.pic_idx].stream,
+                      d->h_status[2 * i], d->h_status[2 * i + 1]);
+            return H264MI_EDECODE;
+        }
+    return H264MI_OK;
+}
+
+extern "C" int32_t h264mi_decode_batch(h264mi_decoder *d, int32_t n, const uint8_t *const *bufs, const size_t *lens, h264mi_batch_info *info) {
+    int r = h264mi_batch_prepare(d, n, bufs, lens, info);
+    if (r != H264MI_OK) return r;
+    r = h264mi_batch_execute(d);
+    if (r != H264MI_OK) return r;
+    return h264mi_batch_sync(d);
+}
+
+extern "C" int32_t h264mi_last_kernel_times(h264mi_decoder *d, double ms[5]) {
+    if (!d || !ms) return H264MI_EINVAL;
+    for (int i = 0; i < 5; i++) ms[i] = d->k_ms[i];
+    return H264MI_OK;
+}
+
+extern "C" int32_t h264mi_stream_frame_count(h264mi_decoder *d, int32_t stream, int32_t *n) {
+    if (!d || !n || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
+    *n = static_cast<int32_t>(d->st[stream].out_slots.size());
+    return H264MI_OK;
+}
+
+static int frame_ptrs(h264mi_decoder *d, int stream, int frame, uint8_t **y, int *W, int *H) {
+    if (!d || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
+    StreamState &s = d->st[stream];
+    if (frame < 0 || frame >= static_cast<int>(s.out_slots.size())) return H264MI_EINVAL;
+    *W = s.wmb * 16, *H = s.hmb * 16;
+    *y = d->d_frames + (static_cast<size_t>(stream) * d->n_slots + s.out_slots[frame]) * d->slot_bytes;
+    return H264MI_OK;
+}
+
+extern "C" int32_t h264mi_frame_device_planes(h264mi_decoder *d, int32_t stream, int32_t frame, void **y, void **cb, void **cr, int32_t *pitch_y, int32_t *pitch_c,
+                                              int32_t *cw, int32_t *ch) {
+    uint8_t *p;
+    int W, H;
+    int r = frame_ptrs(d, stream, frame, &p, &W, &H);
+    if (r != H264MI_OK) return r;
+    if (y) *y = p;
+    if (cb) *cb = p + static_cast<size_t>(W) * H;
+    if (cr) *cr = p + static_cast<size_t>(W) * H * 5 / 4;
+    if (pitch_y) *pitch_y = W;
+    if (pitch_c) *pitch_c = W / 2;
+    if (cw) *cw = W;
+    if (ch) *ch = H;
+    return H264MI_OK;
+}
+
+static void crop_rect(const h264mi_sps &sps, int crop, int W, int H, int *x0, int *y0, int *w, int *h) {
+    *x0 = *y0 = 0, *w = W, *h = H;
+    if (crop) {
+        *x0 = 2 * sps.frame_crop_left_offset, *y0 = 2 * sps.frame_crop_top_offset;
+        *w = sps.width, *h = sps.height;
+    }
+}
+
+extern "C" int32_t h264mi_frame_read(h264mi_decoder *d, int32_t stream, int32_t frame, int32_t crop, uint8_t *dst, size_t cap) {
+    uint8_t *p;
+    int W, H, x0, y0, w, h;
+    int r = frame_ptrs(d, stream, frame, &p, &W, &H);
+    if (r != H264MI_OK) return r;
+    if (!dst) return H264MI_EINVAL;
+    StreamState &s = d->st[stream];
+    crop_rect(s.sps[s.active_sps], crop, W, H, &x0, &y0, &w, &h);
+    if (cap < static_cast<size_t>(w) * h * 3 / 2) return H264MI_ECAPACITY;
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    HIP_TRY(hipMemcpy2D(dst, w, p + static_cast<size_t>(y0) * W + x0, W, w, h, hipMemcpyDeviceToHost));
+    const uint8_t *cb = p + static_cast<size_t>(W) * H, *cr = cb + static_cast<size_t>(W) * H / 4;
+    uint8_t *o = dst + static_cast<size_t>(w) * h;
+    HIP_TRY(hipMemcpy2D(o, w / 2, cb + static_cast<size_t>(y0 / 2) * (W / 2) + x0 / 2, W / 2, w / 2, h / 2, hipMemcpyDeviceToHost));
+    o += static_cast<size_t>(w / 2) * (h / 2);
+    HIP_TRY(hipMemcpy2D(o, w / 2, cr + static_cast<size_t>(y0 / 2) * (W / 2) + x0 / 2, W / 2, w / 2, h / 2, hipMemcpyDeviceToHost));
+    return H264MI_OK;
+}
+
+extern "C" int32_t h264mi_frame_pack_device(h264mi_decoder *d, int32_t stream, int32_t frame, void *dst, size_t cap) {
+    uint8_t *p;
+    int W, H, x0, y0, w, h;
+    int r = frame_ptrs(d, stream, frame, &p, &W, &H);
+    if (r != H264MI_OK) return r;
+    if (!dst) return H264MI_EINVAL;
+    StreamState &s = d->st[stream];
+    crop_rect(s.sps[s.active_sps], 1, W, H, &x0, &y0, &w, &h);
+    if (cap < static_cast<size_t>(w) * h * 3 / 2) return H264MI_ECAPACITY;
+    const uint8_t *cb = p + static_cast<size_t>(W) * H, *cr = cb + static_cast<size_t>(W) * H / 4;
+    int total = w * h * 3 / 2;
+    hipLaunchKernelGGL(k_pack, dim3(std::min((total + 255) / 256, 4096)), dim3(256), 0, d->stream, p, cb, cr, W, x0, y0, w, h, static_cast<uint8_t *>(dst));
+    HIP_TRY(hipGetLastError());
+    return H264MI_OK;
+}
+
+extern "C" int32_t h264mi_frame_read_mbrecs(h264mi_decoder *d, int32_t stream, int32_t frame, uint8_t *rec, size_t cap) {
+    if (!d || !rec || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
+    for (int i = 0; i < d->n_pics; i++) {
+        const PicDesc &pd = d->h_pics[i];
+        if (static_cast<int>(pd.stream) == stream && static_cast<int>(pd.order) == frame) {
+            size_t n = static_cast<size_t>(pd.wmb) * pd.hmb * sizeof(MbRec);
+            if (cap < n) return H264MI_ECAPACITY;
+            HIP_TRY(hipStreamSynchronize(d->stream));
+            HIP_TRY(hipMemcpy(rec, d->d_mbrec + pd.mb_base, n, hipMemcpyDeviceToHost));
+            return H264MI_OK;
+        }
+    }
+    return H264MI_EINVAL;
+}

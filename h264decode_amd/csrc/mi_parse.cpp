@@ -1,0 +1,491 @@
+// h264decode_amd/csrc/mi_parse.cpp -- see mi_parse.hpp.
+//
+// Follows the syntax order of the reference where the reference is right and the spec elsewhere;
+// each divergence is tagged with its SURVEY.md Appendix-A number.
+#include "mi_parse.hpp"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "mi_tables.h"
+
+namespace mi {
+
+static thread_local char g_err[512];
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char *last_error() { return g_err; }
+
+// ---------------------------------------------------------------- BitReader
+uint64_t BitReader::window(int64_t bitpos) const {
+    int64_t byte = bitpos >> 3;
+    uint64_t w = 0;
+    int64_t nbytes = nbits_ >> 3;
+    for (int i = 0; i < 9; i++) { // 72 bits gathered, then aligned
+        uint64_t b = (byte + i < nbytes) ? p_[byte + i] : 0;
+        if (i < 8)
+            w = (w << 8) | b;
+        else {
+            int sh = static_cast<int>(bitpos & 7);
+            if (sh) w = (w << sh) | (b >> (8 - sh));
+        }
+    }
+    return w;
+}
+uint32_t BitReader::u(int n) {
+    if (n == 0) return 0;
+    uint64_t w = window(pos_);
+    pos_ += n;
+    return static_cast<uint32_t>(w >> (64 - n));
+}
+// ue(v): count leading zeros with one CLZ instead of a bit loop (h264/bit_reader.go:174-196).
+uint32_t BitReader::ue() {
+    uint64_t w = window(pos_);
+    if (w == 0) { // > 63 leading zeros: malformed
+        pos_ = nbits_ + 1;
+        return 0;
+    }
+    int lz = __builtin_clzll(w);
+    if (lz > 31) {
+        pos_ = nbits_ + 1;
+        return 0;
+    }
+    pos_ += 2 * lz + 1;
+    return static_cast<uint32_t>((w >> (63 - 2 * lz)) - 1);
+}
+// se(v): 9.1.1 (the reference is off by one for odd codeNum, A3)
+int32_t BitReader::se() {
+    uint32_t k = ue();
+    int32_t m = static_cast<int32_t>((k + 1) >> 1);
+    return (k & 1) ? m : -m;
+}
+// more_rbsp_data(): non-destructive look for anything before the final stop bit (A29)
+bool BitReader::more_rbsp_data() const {
+    int64_t n = nbits_ >> 3;
+    while (n > 0 && p_[n - 1] == 0) n--;
+    if (n == 0) return false;
+    int tz = __builtin_ctz(p_[n - 1]);
+    int64_t stop_bit = (n - 1) * 8 + (7 - tz);
+    return pos_ < stop_bit;
+}
+
+// ---------------------------------------------------------------- Annex B / NAL
+// B.1: start code prefix 00 00 01 with optional leading zero bytes; trailing zeros dropped (A31).
+int annexb_scan(const uint8_t *buf, size_t len, h264mi_nal *out, int cap, int *n) {
+    int count = 0;
+    size_t i = 0, nal_start = SIZE_MAX;
+    auto emit = [&](size_t s, size_t e) {
+        while (e > s && buf[e - 1] == 0) e--;
+        if (e <= s) return;
+        if (count < cap) {
+            h264mi_nal &x = out[count];
+            memset(&x, 0, sizeof(x));
+            x.offset = static_cast<int64_t>(s);
+            x.num_bytes = static_cast<int32_t>(e - s);
+            x.forbidden_zero_bit = buf[s] >> 7;
+            x.ref_idc = (buf[s] >> 5) & 3;
+            x.type = buf[s] & 31;
+            x.header_bytes = (x.type == 14 || x.type == 20 || x.type == 21) ? 4 : 1;
+        }
+        count++;
+    };
+    while (i + 2 < len) {
+        // skip quickly: a start code needs buf[i+2] <= 1
+        if (buf[i + 2] > 1) {
+            i += 3;
+            continue;
+        }
+        if (buf[i] == 0 && buf[i + 1] == 0 && buf[i + 2] == 1) {
+            if (nal_start != SIZE_MAX) emit(nal_start, i);
+            nal_start = i + 3;
+            i += 3;
+        } else
+            i++;
+    }
+    if (nal_start != SIZE_MAX && nal_start < len) emit(nal_start, len);
+    *n = count < cap ? count : cap;
+    return count > cap ? H264MI_ECAPACITY : H264MI_OK;
+}
+
+// 7.4.1.1: drop emulation_prevention_three_byte
+size_t unescape(const uint8_t *src, size_t n, uint8_t *dst) {
+    size_t o = 0, i = 0;
+    while (i < n) {
+        // copy up to the next possible 00 00 03
+        if (i + 2 < n && src[i] == 0 && src[i + 1] == 0 && src[i + 2] == 3) {
+            dst[o++] = 0;
+            dst[o++] = 0;
+            i += 3;
+        } else
+            dst[o++] = src[i++];
+    }
+    return o;
+}
+
+// NewNalUnit (h264/nalUnit.go:75-131): header fields + RBSP
+int nal_parse(const uint8_t *nal, size_t len, h264mi_nal *h, uint8_t *rbsp, size_t *rbsp_len) {
+    if (!nal || len < 1 || !h) return H264MI_EINVAL;
+    int64_t keep = h->offset;
+    memset(h, 0, sizeof(*h));
+    h->offset = keep;
+    h->num_bytes = static_cast<int32_t>(len);
+    h->forbidden_zero_bit = nal[0] >> 7;
+    h->ref_idc = (nal[0] >> 5) & 3;
+    h->type = nal[0] & 31;
+    h->header_bytes = 1;
+    if (h->type == 14 || h->type == 20 || h->type == 21) { // 7.3.1: 3 more header bytes (Annex G/H/J)
+        if (len < 4) return H264MI_EBITSTREAM;
+        if (h->type != 21)
+            h->svc_extension_flag = nal[1] >> 7;
+        else
+            h->avc_3d_extension_flag = nal[1] >> 7;
+        h->header_bytes = 4;
+    }
+    if (rbsp && rbsp_len) *rbsp_len = unescape(nal + h->header_bytes, len - h->header_bytes, rbsp);
+    return H264MI_OK;
+}
+
+// ---------------------------------------------------------------- scaling lists
+static bool scaling_list(BitReader &b, uint8_t *list, int size) { // 7.3.2.1.1.1; true = use default
+    int last = 8, next = 8;
+    bool use_default = false;
+    for (int j = 0; j < size; j++) {
+        if (next != 0) {
+            next = (last + b.se() + 256) % 256;
+            use_default = (j == 0 && next == 0);
+        }
+        list[j] = static_cast<uint8_t>(next == 0 ? last : next);
+        last = list[j];
+    }
+    return use_default;
+}
+struct Fallback {
+    const uint8_t *i4, *p4, *i8, *p8;
+};
+static void scaling_matrix(BitReader &b, int n, uint8_t s4[6][16], uint8_t s8[2][64], const Fallback &fb) { // Table 7-2
+    for (int i = 0; i < n; i++) {
+        bool present = b.u(1);
+        if (i < 6) {
+            if (present) {
+                if (scaling_list(b, s4[i], 16)) memcpy(s4[i], i < 3 ? mi_default4x4_intra : mi_default4x4_inter, 16);
+            } else if (i == 0 || i == 3)
+                memcpy(s4[i], i == 0 ? fb.i4 : fb.p4, 16);
+            else
+                memcpy(s4[i], s4[i - 1], 16);
+        } else if (i < 8) {
+            int k = i - 6;
+            if (present) {
+                if (scaling_list(b, s8[k], 64)) memcpy(s8[k], k ? mi_default8x8_inter : mi_default8x8_intra, 64);
+            } else
+                memcpy(s8[k], k ? fb.p8 : fb.i8, 64);
+        } else if (present) { // 4:4:4 chroma 8x8 lists: parsed, unused
+            uint8_t tmp[64];
+            scaling_list(b, tmp, 64);
+        }
+    }
+}
+
+static void hrd(BitReader &b, h264mi_sps *s) { // E.1.2 (A13: lengths after the loop)
+    s->cpb_cnt_minus1 = b.ue();
+    s->bit_rate_scale = b.u(4);
+    s->cpb_size_scale = b.u(4);
+    for (int i = 0; i <= s->cpb_cnt_minus1 && i < 32; i++) {
+        b.ue();
+        b.ue();
+        b.u(1);
+    }
+    s->initial_cpb_removal_delay_length_minus1 = b.u(5);
+    s->cpb_removal_delay_length_minus1 = b.u(5);
+    s->dpb_output_delay_length_minus1 = b.u(5);
+    s->time_offset_length = b.u(5);
+}
+
+// NewSPS (h264/sps.go:192-437)
+int parse_sps(const uint8_t *rbsp, size_t len, h264mi_sps *s) {
+    if (!rbsp || !s) return H264MI_EINVAL;
+    BitReader b(rbsp, len);
+    memset(s, 0, sizeof(*s));
+    s->profile = b.u(8);
+    s->constraint_flags = b.u(8);
+    s->level = b.u(8);
+    s->id = b.ue();
+    s->chroma_format = 1;
+    memset(s->scaling_list_4x4, 16, sizeof(s->scaling_list_4x4));
+    memset(s->scaling_list_8x8, 16, sizeof(s->scaling_list_8x8));
+    switch (s->profile) { // A11: only these profiles carry chroma_format_idc (list as h264/sps.go:230)
+    case 100: case 110: case 122: case 244: case 44: case 83: case 86: case 118: case 128: case 138: case 139: case 134: case 135:
+        s->chroma_format = b.ue();
+        if (s->chroma_format == 3) s->use_separate_color_plane = b.u(1);
+        s->bit_depth_luma_minus8 = b.ue();
+        s->bit_depth_chroma_minus8 = b.ue();
+        s->qprime_y_zero_transform_bypass = b.u(1);
+        s->seq_scaling_matrix_present = b.u(1);
+        if (s->seq_scaling_matrix_present) {
+            Fallback fb{mi_default4x4_intra, mi_default4x4_inter, mi_default8x8_intra, mi_default8x8_inter};
+            scaling_matrix(b, s->chroma_format != 3 ? 8 : 12, s->scaling_list_4x4, s->scaling_list_8x8, fb);
+        }
+        break;
+    default: break;
+    }
+    s->log2_max_frame_num_minus4 = b.ue();
+    s->pic_order_count_type = b.ue();
+    if (s->pic_order_count_type == 0)
+        s->log2_max_pic_order_cnt_lsb_min4 = b.ue();
+    else if (s->pic_order_count_type == 1) {
+        s->delta_pic_order_always_zero = b.u(1);
+        s->offset_for_non_ref_pic = b.se();
+        s->offset_for_top_to_bottom_field = b.se();
+        s->num_ref_frames_in_pic_order_cnt_cycle = b.ue();
+        if (s->num_ref_frames_in_pic_order_cnt_cycle > 255) return H264MI_EBITSTREAM;
+        for (int i = 0; i < s->num_ref_frames_in_pic_order_cnt_cycle; i++) s->offset_for_ref_frame_list[i] = b.se();
+    }
+    s->max_num_ref_frames = b.ue();
+    s->gaps_in_frame_num_value_allowed = b.u(1);
+    s->pic_width_in_mbs_minus1 = b.ue();
+    s->pic_height_in_map_units_minus1 = b.ue();
+    s->frame_mbs_only = b.u(1);
+    if (!s->frame_mbs_only) s->mb_adaptive_frame_field = b.u(1);
+    s->direct_8x8_inference = b.u(1);
+    s->frame_cropping = b.u(1);
+    if (s->frame_cropping) {
+        s->frame_crop_left_offset = b.ue();
+        s->frame_crop_right_offset = b.ue();
+        s->frame_crop_top_offset = b.ue();
+        s->frame_crop_bottom_offset = b.ue();
+    }
+    s->vui_parameters_present = b.u(1);
+    if (s->vui_parameters_present) {
+        s->aspect_ratio_info_present = b.u(1);
+        if (s->aspect_ratio_info_present) {
+            s->aspect_ratio = b.u(8);
+            if (s->aspect_ratio == 255) { // Extended_SAR (A12)
+                s->sar_width = b.u(16);
+                s->sar_height = b.u(16);
+            }
+        }
+        s->overscan_info_present = b.u(1);
+        if (s->overscan_info_present) s->overscan_appropriate = b.u(1);
+        s->video_signal_type_present = b.u(1);
+        if (s->video_signal_type_present) {
+            s->video_format = b.u(3);
+            s->video_full_range = b.u(1);
+            s->color_description_present = b.u(1);
+            if (s->color_description_present) {
+                s->color_primaries = b.u(8);
+                s->transfer_characteristics = b.u(8);
+                s->matrix_coefficients = b.u(8);
+            }
+        }
+        s->chroma_loc_info_present = b.u(1);
+        if (s->chroma_loc_info_present) {
+            s->chroma_sample_loc_type_top_field = b.ue();
+            s->chroma_sample_loc_type_bottom_field = b.ue();
+        }
+        s->timing_info_present = b.u(1);
+        if (s->timing_info_present) {
+            s->num_units_in_tick = b.u(32);
+            s->time_scale = b.u(32);
+            s->fixed_frame_rate = b.u(1);
+        }
+        s->nal_hrd_parameters_present = b.u(1);
+        if (s->nal_hrd_parameters_present) hrd(b, s);
+        s->vcl_hrd_parameters_present = b.u(1);
+        if (s->vcl_hrd_parameters_present) hrd(b, s);
+        if (s->nal_hrd_parameters_present || s->vcl_hrd_parameters_present) s->low_hrd_delay = b.u(1);
+        s->pic_struct_present = b.u(1);
+        s->bitstream_restriction = b.u(1);
+        if (s->bitstream_restriction) {
+            s->motion_vectors_over_pic_boundaries = b.u(1);
+            s->max_bytes_per_pic_denom = b.ue();
+            s->max_bits_per_mb_denom = b.ue();
+            s->log2_max_mv_length_horizontal = b.ue();
+            s->log2_max_mv_length_vertical = b.ue();
+            s->max_num_reorder_frames = b.ue();
+            s->max_dec_frame_buffering = b.ue();
+        }
+    }
+    if (b.overrun() || s->id > 31) {
+        set_error("SPS: truncated or bad id");
+        return H264MI_EBITSTREAM;
+    }
+    // PicWidthInMbs / PicHeightInMbs (h264/slice.go:159-176), cropped size (7-18..7-21, 4:2:0 frame)
+    s->pic_width_in_mbs = s->pic_width_in_mbs_minus1 + 1;
+    s->pic_height_in_mbs = (s->pic_height_in_map_units_minus1 + 1) * (2 - s->frame_mbs_only);
+    s->width = s->pic_width_in_mbs * 16 - 2 * (s->frame_crop_left_offset + s->frame_crop_right_offset);
+    s->height = s->pic_height_in_mbs * 16 - 2 * (2 - s->frame_mbs_only) * (s->frame_crop_top_offset + s->frame_crop_bottom_offset);
+    return H264MI_OK;
+}
+
+// NewPPS (h264/pps.go:40-133)
+int parse_pps(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi_pps *p) {
+    if (!rbsp || !p || !sps) return H264MI_EINVAL;
+    BitReader b(rbsp, len);
+    memset(p, 0, sizeof(*p));
+    p->id = b.ue();
+    p->sps_id = b.ue();
+    p->entropy_coding_mode = b.u(1);
+    p->bottom_field_pic_order_in_frame_present = b.u(1);
+    p->num_slice_groups_minus1 = b.ue();
+    if (p->num_slice_groups_minus1 > 0) {
+        set_error("PPS: FMO (slice groups) is out of scope");
+        return H264MI_EUNSUPPORTED;
+    }
+    p->num_ref_idx_l0_default_active_minus1 = b.ue();
+    p->num_ref_idx_l1_default_active_minus1 = b.ue();
+    p->weighted_pred = b.u(1);
+    p->weighted_bipred = b.u(2);
+    p->pic_init_qp_minus26 = b.se();
+    p->pic_init_qs_minus26 = b.se();
+    p->chroma_qp_index_offset = b.se();
+    p->deblocking_filter_control_present = b.u(1);
+    p->constrained_intra_pred = b.u(1);
+    p->redundant_pic_cnt_present = b.u(1);
+    p->second_chroma_qp_index_offset = p->chroma_qp_index_offset;
+    memcpy(p->scaling_list_4x4, sps->scaling_list_4x4, sizeof(p->scaling_list_4x4));
+    memcpy(p->scaling_list_8x8, sps->scaling_list_8x8, sizeof(p->scaling_list_8x8));
+    if (b.more_rbsp_data()) { // A15/A16
+        p->transform_8x8_mode = b.u(1);
+        p->pic_scaling_matrix_present = b.u(1);
+        if (p->pic_scaling_matrix_present) {
+            int n = 6 + (sps->chroma_format != 3 ? 2 : 6) * p->transform_8x8_mode;
+            Fallback fb = sps->seq_scaling_matrix_present
+                              ? Fallback{sps->scaling_list_4x4[0], sps->scaling_list_4x4[3], sps->scaling_list_8x8[0], sps->scaling_list_8x8[1]}
+                              : Fallback{mi_default4x4_intra, mi_default4x4_inter, mi_default8x8_intra, mi_default8x8_inter};
+            scaling_matrix(b, n, p->scaling_list_4x4, p->scaling_list_8x8, fb);
+        }
+        p->second_chroma_qp_index_offset = b.se();
+    }
+    if (b.overrun() || p->id > 255 || p->sps_id > 31) {
+        set_error("PPS: truncated or bad id");
+        return H264MI_EBITSTREAM;
+    }
+    return H264MI_OK;
+}
+
+// slice_header() 7.3.3 (h264/slice.go:857-1032; A18 frame_num, A19 override flag, A20 MMCO loop)
+int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc, int nal_unit_type, const uint8_t *rbsp, size_t len,
+                       h264mi_slice_header *sh) {
+    if (!s || !p || !rbsp || !sh) return H264MI_EINVAL;
+    BitReader b(rbsp, len);
+    memset(sh, 0, sizeof(*sh));
+    const bool idr = nal_unit_type == 5;
+    sh->nal_ref_idc = nal_ref_idc;
+    sh->nal_unit_type = nal_unit_type;
+    sh->first_mb_in_slice = b.ue();
+    sh->slice_type = b.ue();
+    if (sh->slice_type > 9) return H264MI_EBITSTREAM;
+    const int st = sh->slice_type % 5;
+    sh->pps_id = b.ue();
+    if (s->use_separate_color_plane) sh->color_plane_id = b.u(2);
+    sh->frame_num = b.u(s->log2_max_frame_num_minus4 + 4);
+    if (!s->frame_mbs_only) {
+        sh->field_pic = b.u(1);
+        if (sh->field_pic) sh->bottom_field = b.u(1);
+    }
+    if (idr) sh->idr_pic_id = b.ue();
+    if (s->pic_order_count_type == 0) {
+        sh->pic_order_cnt_lsb = b.u(s->log2_max_pic_order_cnt_lsb_min4 + 4);
+        if (p->bottom_field_pic_order_in_frame_present && !sh->field_pic) sh->delta_pic_order_cnt_bottom = b.se();
+    }
+    if (s->pic_order_count_type == 1 && !s->delta_pic_order_always_zero) {
+        sh->delta_pic_order_cnt[0] = b.se();
+        if (p->bottom_field_pic_order_in_frame_present && !sh->field_pic) sh->delta_pic_order_cnt[1] = b.se();
+    }
+    if (p->redundant_pic_cnt_present) sh->redundant_pic_cnt = b.ue();
+    if (st == 1) sh->direct_spatial_mv_pred = b.u(1);
+    sh->num_ref_idx_l0_active_minus1 = p->num_ref_idx_l0_default_active_minus1;
+    sh->num_ref_idx_l1_active_minus1 = p->num_ref_idx_l1_default_active_minus1;
+    if (st == 0 || st == 3 || st == 1) {
+        sh->num_ref_idx_active_override = b.u(1);
+        if (sh->num_ref_idx_active_override) {
+            sh->num_ref_idx_l0_active_minus1 = b.ue();
+            if (st == 1) sh->num_ref_idx_l1_active_minus1 = b.ue();
+        }
+        if (sh->num_ref_idx_l0_active_minus1 > 31) return H264MI_EBITSTREAM;
+    }
+    if (st == 1) {
+        set_error("B slices are not supported yet (SURVEY 8f rank 1)");
+        return H264MI_EUNSUPPORTED;
+    }
+    if (st != 2 && st != 4) { // ref_pic_list_modification()
+        sh->ref_pic_list_modification_flag_l0 = b.u(1);
+        if (sh->ref_pic_list_modification_flag_l0)
+            for (;;) {
+                uint32_t idc = b.ue();
+                if (idc == 3) break;
+                if (idc > 3 || sh->n_ref_pic_list_modifications >= 66 || b.overrun()) return H264MI_EBITSTREAM;
+                sh->modification_of_pic_nums[sh->n_ref_pic_list_modifications] = idc;
+                sh->modification_value[sh->n_ref_pic_list_modifications++] = b.ue();
+            }
+    }
+    if (p->weighted_pred && (st == 0 || st == 3)) { // pred_weight_table()
+        sh->luma_log2_weight_denom = b.ue();
+        sh->chroma_log2_weight_denom = b.ue();
+        if (sh->luma_log2_weight_denom > 7 || sh->chroma_log2_weight_denom > 7) return H264MI_EBITSTREAM;
+        for (int i = 0; i <= sh->num_ref_idx_l0_active_minus1; i++) {
+            sh->luma_weight_l0[i] = 1 << sh->luma_log2_weight_denom;
+            sh->chroma_weight_l0[i][0] = sh->chroma_weight_l0[i][1] = 1 << sh->chroma_log2_weight_denom;
+            sh->luma_weight_l0_flag[i] = b.u(1);
+            if (sh->luma_weight_l0_flag[i]) {
+                sh->luma_weight_l0[i] = b.se();
+                sh->luma_offset_l0[i] = b.se();
+            }
+            sh->chroma_weight_l0_flag[i] = b.u(1);
+            if (sh->chroma_weight_l0_flag[i])
+                for (int j = 0; j < 2; j++) {
+                    sh->chroma_weight_l0[i][j] = b.se();
+                    sh->chroma_offset_l0[i][j] = b.se();
+                }
+        }
+    }
+    if (nal_ref_idc != 0) { // dec_ref_pic_marking()
+        if (idr) {
+            sh->no_output_of_prior_pics_flag = b.u(1);
+            sh->long_term_reference_flag = b.u(1);
+        } else {
+            sh->adaptive_ref_pic_marking_mode_flag = b.u(1);
+            if (sh->adaptive_ref_pic_marking_mode_flag)
+                for (;;) {
+                    uint32_t op = b.ue();
+                    if (op == 0) break;
+                    int k = sh->n_memory_management_control_operations;
+                    if (op > 6 || k >= 66 || b.overrun()) return H264MI_EBITSTREAM;
+                    sh->memory_management_control_operation[k] = op;
+                    if (op == 1 || op == 3 || op == 2 || op == 4) sh->mmco_arg1[k] = b.ue();
+                    if (op == 3 || op == 6) sh->mmco_arg2[k] = b.ue();
+                    sh->n_memory_management_control_operations++;
+                }
+        }
+    }
+    if (p->entropy_coding_mode && st != 2 && st != 4) {
+        sh->cabac_init = b.ue();
+        if (sh->cabac_init > 2) return H264MI_EBITSTREAM;
+    }
+    sh->slice_qp_delta = b.se();
+    if (st == 3 || st == 4) {
+        if (st == 3) sh->sp_for_switch = b.u(1);
+        sh->slice_qs_delta = b.se();
+    }
+    if (p->deblocking_filter_control_present) {
+        sh->disable_deblocking_filter = b.ue();
+        if (sh->disable_deblocking_filter != 1) {
+            sh->slice_alpha_c0_offset_div2 = b.se();
+            sh->slice_beta_offset_div2 = b.se();
+        }
+        if (sh->disable_deblocking_filter > 2 || sh->slice_alpha_c0_offset_div2 < -6 || sh->slice_alpha_c0_offset_div2 > 6 ||
+            sh->slice_beta_offset_div2 < -6 || sh->slice_beta_offset_div2 > 6)
+            return H264MI_EBITSTREAM;
+    }
+    sh->slice_qp_y = 26 + p->pic_init_qp_minus26 + sh->slice_qp_delta; // (7-30), h264/cabac.go:113
+    sh->slice_data_bit_offset = b.pos();
+    if (b.overrun() || sh->slice_qp_y < 0 || sh->slice_qp_y > 51) {
+        set_error("slice header: truncated or QP out of range");
+        return H264MI_EBITSTREAM;
+    }
+    return H264MI_OK;
+}
+
+} // namespace mi

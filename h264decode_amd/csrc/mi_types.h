@@ -1,0 +1,124 @@
+/*
+ * h264decode_amd/csrc/mi_types.h -- data layout shared by host code and HIP kernels.
+ *
+ * HBM layout per decoder (sized once at create time for 288 GB HBM3E parts; everything stays
+ * resident, nothing is re-allocated per batch):
+ *   bitstream   uint8[]            RBSP bytes of every slice of the batch, 16-byte aligned per slice
+ *   slices      SliceDesc[]        one per slice (host-built)            -> entropy kernels
+ *   pics        PicDesc[]          one per picture (host-built)          -> all kernels
+ *   mbrec       MbRec[]            128 B per macroblock (entropy -> recon/deblock)
+ *   coef        int16[416] per MB  dequantisation input, raster order inside each block
+ *   frames      per stream: `slots` frames of (coded W x H luma + 2 x W/2 x H/2 chroma), pitch = W
+ *   tables      DevTables          CABAC/CAVLC/deblock tables + per-PPS LevelScale sets
+ */
+#ifndef MI_TYPES_H
+#define MI_TYPES_H
+#include <stdint.h>
+
+enum { MBT_NONE = 0, MBT_I4x4, MBT_I8x8, MBT_I16x16, MBT_IPCM, MBT_P16x16, MBT_P16x8, MBT_P8x16, MBT_P8x8, MBT_PSKIP };
+#define MB_IS_INTRA(t) ((t) >= MBT_I4x4 && (t) <= MBT_IPCM)
+#define MB_IS_INTER(t) ((t) >= MBT_P16x16)
+
+#define MI_MAX_REFS 16
+#define MI_COEF_PER_MB 416 /* int16: luma 256 | I16 DC 16 | chroma DC 2x4 | chroma AC 2x4x16 | pad 8 */
+#define MI_COEF_I16DC 256
+#define MI_COEF_CDC 272
+#define MI_COEF_CAC 280
+
+/* intra-prediction neighbour availability of a macroblock (slice + picture bounds +
+ * constrained_intra_pred already applied by the entropy kernel) */
+#define MI_AV_LEFT 1
+#define MI_AV_TOP 2
+#define MI_AV_TOPLEFT 4
+#define MI_AV_TOPRIGHT 8
+
+typedef struct __attribute__((aligned(16))) {
+    uint8_t type;     /* MBT_* */
+    uint8_t t8x8;     /* transform_size_8x8_flag */
+    uint8_t qp;       /* QP_Y (0 for I_PCM, as deblocking wants it) */
+    uint8_t qpc[2];   /* QP_C for Cb, Cr */
+    uint8_t cbp;      /* luma bits 0-3, chroma bits 4-5 */
+    uint8_t chroma_mode;
+    uint8_t i16mode;
+    uint16_t nzmask;  /* 4x4 luma blocks (raster) with non-zero coefficients; 8x8 blocks replicated */
+    uint8_t avail;    /* MI_AV_* */
+    uint8_t dbf_idc;  /* disable_deblocking_filter_idc of the slice */
+    int8_t alpha_off, beta_off; /* FilterOffsetA / FilterOffsetB */
+    uint16_t slice_in_pic;      /* slice ordinal inside the picture (deblock idc 2, intra availability) */
+    int8_t ipm[16];   /* Intra4x4/8x8PredMode per 4x4 block, raster */
+    int8_t ref[4];    /* ref_idx_l0 per 8x8 */
+    int16_t refslot[4]; /* frame-pool slot of the referenced picture per 8x8 (-1 none) */
+    uint32_t slice_idx; /* index into SliceDesc[] (weighted prediction tables) */
+    int16_t mv[16][2];  /* final motion vectors per 4x4 block, raster, quarter-sample units */
+    uint8_t pad[16];
+} MbRec; /* 128 bytes */
+
+typedef struct {
+    uint32_t rbsp_off;     /* byte offset of the slice RBSP in the bitstream buffer */
+    uint32_t rbsp_size;
+    uint32_t data_bit_off; /* slice_data() bit offset inside the RBSP */
+    uint32_t stop_bit;     /* bit position of rbsp_stop_one_bit (more_rbsp_data() for CAVLC) */
+    uint32_t pic_idx;
+    uint32_t first_mb;
+    uint8_t slice_type;    /* 0 P, 2 I */
+    uint8_t cabac_init_idc, slice_qp, num_ref_idx_active;
+    int8_t alpha_off, beta_off;
+    uint8_t dbf_idc, wp_flag;
+    uint16_t slice_in_pic;
+    uint8_t luma_log2_denom, chroma_log2_denom;
+    int16_t ref_slot[MI_MAX_REFS];
+    int16_t wp_lw[MI_MAX_REFS], wp_lo[MI_MAX_REFS];
+    int16_t wp_cw[MI_MAX_REFS][2], wp_co[MI_MAX_REFS][2];
+} SliceDesc;
+
+typedef struct {
+    uint32_t stream;
+    uint32_t slot;        /* frame-pool slot this picture is reconstructed into */
+    uint32_t wmb, hmb;
+    uint64_t mb_base;     /* first MbRec / coefficient block of this picture */
+    uint32_t first_slice, n_slices;
+    uint8_t cabac, t8x8_mode, cip, weighted_pred;
+    int8_t cqp_off[2];
+    uint8_t is_intra_only; /* all slices are I slices */
+    uint8_t scaling_set;   /* index into DevTables.level_scale sets */
+    uint32_t order;        /* ordinal of this picture within its stream in this batch */
+} PicDesc;
+
+typedef struct {
+    uint64_t base;       /* device address of slot 0 */
+    uint64_t slot_bytes; /* bytes per slot (Y + Cb + Cr) */
+    uint32_t w, h;       /* coded luma size; pitch = w, chroma pitch = w/2 */
+    uint32_t pad[2];
+} FramePool;
+
+/* LevelScale(m,i,j) of 8.5.9 for one PPS: [list][qp%6][raster position] */
+typedef struct {
+    uint16_t ls4[6][6][16];
+    uint16_t ls8[2][6][64];
+} ScalingSet;
+
+#define MI_MAX_SCALING_SETS 8
+#define MI_VLC_CT0_BITS 16
+#define MI_VLC_CT1_BITS 14
+#define MI_VLC_CT2_BITS 10
+
+typedef struct {
+    uint8_t range_lps[64][4]; /* Table 9-44 */
+    uint8_t trans_lps[64];    /* Table 9-45 */
+    uint8_t ctx_init[4][52][464]; /* (pStateIdx<<1)|valMPS for every (table set, SliceQPY, ctxIdx): 9.3.1.1 */
+    uint8_t sig8x8[64], last8x8[64];
+    uint8_t zigzag4[16], zigzag8[64];
+    uint8_t me_intra[48], me_inter[48];
+    uint8_t alpha[52], beta[52], tc0[52][4];
+    uint8_t qpc[52];
+    /* CAVLC direct lookup tables: entry = (len<<8) | (total_coeff<<2) | trailing_ones, or for the
+     * other codes (len<<8) | value; indexed by the next N bits of the stream */
+    uint16_t vlc_ct0[1 << MI_VLC_CT0_BITS], vlc_ct1[1 << MI_VLC_CT1_BITS], vlc_ct2[1 << MI_VLC_CT2_BITS], vlc_ct3[64];
+    uint16_t vlc_cdc[256];
+    uint16_t vlc_tz[15][512];
+    uint16_t vlc_cdc_tz[3][8];
+    uint16_t vlc_run[7][2048];
+    ScalingSet scaling[MI_MAX_SCALING_SETS];
+} DevTables;
+
+#endif

@@ -1,0 +1,263 @@
+"""Host-side mirror of the reference's Go package `h264` (same names, argument meaning and -- where
+the reference is right -- values), implemented on the C ABI of libh264mi.so.
+
+Reference            -> here
+  NalUnit            h264/nalUnit.go:3-30      -> NalUnit (fields in CamelCase as in Go)
+  NewNalUnit         h264/nalUnit.go:75        -> NewNalUnit(frame, numBytesInNal)
+  (*NalUnit).RBSP    h264/nalUnit.go:72        -> NalUnit.RBSP()
+  SPS / NewSPS       h264/sps.go:9,192         -> SPS / NewSPS(rbsp, showPacket)
+  PPS / NewPPS       h264/pps.go:10,40         -> PPS / NewPPS(sps, rbsp, showPacket)
+  SliceHeader        h264/slice.go:23          -> SliceHeader
+  SliceContext       h264/slice.go:13          -> SliceContext (NalUnit, SPS, PPS, Slice.Header)
+  NewSliceContext    h264/slice.go:835         -> NewSliceContext(videoStream, nalUnit, rbsp, showPacket)
+  VideoStream        h264/slice.go:8           -> VideoStream(SPS, PPS, Slices)
+  readNalUnit loop   h264/server.go:64-166     -> read_nal_units(bytes)
+New (the reference has no pixel type): Decoder -- batched GPU decode to Y/Cb/Cr planes.
+
+Error behaviour: the reference panics / os.Exit()s on malformed input (h264/server.go:136-143); here
+every failure raises H264MIError carrying the C status code."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import H264MIError, check
+
+NALU_TYPE_NAMES = {  # h264/frame.go:28-60
+    0: "unspecified", 1: "coded slice of non-IDR picture", 2: "coded slice data partition A", 3: "coded slice data partition B",
+    4: "coded slice data partition C", 5: "coded slice of an IDR picture", 6: "SEI", 7: "SPS", 8: "PPS", 9: "AUD",
+    10: "end of sequence", 11: "end of stream", 12: "filler data", 13: "SPS extension", 14: "prefix NAL unit",
+    15: "subset SPS", 19: "auxiliary slice", 20: "slice extension", 21: "slice extension for depth view"}
+
+
+def _camel(name):
+    return "".join(p.capitalize() if not p.isdigit() else p for p in name.split("_"))
+
+
+class _Mirror:
+    """Exposes the fields of a C struct under the reference's CamelCase names (and snake_case)."""
+    _c = None
+
+    def __getattr__(self, name):
+        c = object.__getattribute__(self, "_c")
+        for fname, _ in c._fields_:
+            if name == fname or name == _camel(fname):
+                v = getattr(c, fname)
+                if hasattr(v, "_length_"):
+                    return np.ctypeslib.as_array(v).copy()
+                return v
+        raise AttributeError(name)
+
+    def as_dict(self):
+        out = {}
+        for fname, _ in self._c._fields_:
+            v = getattr(self._c, fname)
+            out[fname] = np.ctypeslib.as_array(v).tolist() if hasattr(v, "_length_") else v
+        return out
+
+
+class NalUnit(_Mirror):
+    def __init__(self, c, rbsp):
+        self._c, self._rbsp = c, rbsp
+
+    def RBSP(self):
+        return self._rbsp
+
+    # Go field names that differ from the C struct's snake_case conversion
+    NumBytes = property(lambda s: s._c.num_bytes)
+    RefIdc = property(lambda s: s._c.ref_idc)
+    Type = property(lambda s: s._c.type)
+
+
+class SPS(_Mirror):
+    def __init__(self, c):
+        self._c = c
+
+
+class PPS(_Mirror):
+    def __init__(self, c):
+        self._c = c
+
+    SPSID = property(lambda s: s._c.sps_id)
+    ID = property(lambda s: s._c.id)
+
+
+class SliceHeader(_Mirror):
+    def __init__(self, c):
+        self._c = c
+
+    PPSID = property(lambda s: s._c.pps_id)
+    SliceQPy = property(lambda s: s._c.slice_qp_y)
+
+
+class Slice:
+    def __init__(self, header):
+        self.Header, self.Data = header, None  # slice_data() is decoded on the GPU (Decoder)
+
+
+class SliceContext:
+    def __init__(self, nal, sps, pps, header):
+        self.NalUnit, self.SPS, self.PPS, self.Slice = nal, sps, pps, Slice(header)
+
+
+class VideoStream:
+    def __init__(self, sps=None, pps=None):
+        self.SPS, self.PPS, self.Slices = sps, pps, []
+
+
+def NewNalUnit(frame: bytes, numBytesInNal: int = None) -> NalUnit:
+    n = len(frame) if numBytesInNal is None else numBytesInNal
+    L = _lib.load()
+    c = _lib.Nal()
+    rbsp = (ctypes.c_uint8 * max(n, 1))()
+    rl = ctypes.c_size_t(0)
+    check(L.h264mi_nal_parse(frame, n, ctypes.byref(c), rbsp, ctypes.byref(rl)))
+    return NalUnit(c, bytes(rbsp[:rl.value]))
+
+
+def NewSPS(rbsp: bytes, showPacket: bool = False) -> SPS:
+    c = _lib.Sps()
+    check(_lib.load().h264mi_sps_parse(rbsp, len(rbsp), ctypes.byref(c)))
+    return SPS(c)
+
+
+def NewPPS(sps: SPS, rbsp: bytes, showPacket: bool = False) -> PPS:
+    c = _lib.Pps()
+    check(_lib.load().h264mi_pps_parse(ctypes.byref(sps._c), rbsp, len(rbsp), ctypes.byref(c)))
+    return PPS(c)
+
+
+def NewSliceContext(videoStream: VideoStream, nalUnit: NalUnit, rbsp: bytes, showPacket: bool = False) -> SliceContext:
+    c = _lib.SliceHdr()
+    check(_lib.load().h264mi_slice_header_parse(ctypes.byref(videoStream.SPS._c), ctypes.byref(videoStream.PPS._c), nalUnit.RefIdc,
+                                                nalUnit.Type, rbsp, len(rbsp), ctypes.byref(c)))
+    return SliceContext(nalUnit, videoStream.SPS, videoStream.PPS, SliceHeader(c))
+
+
+def read_nal_units(stream: bytes):
+    """Annex-B scan: returns [NalUnit] (replaces the readNalUnit loop of h264/server.go:64-111,144-166)."""
+    L = _lib.load()
+    cap = 1024
+    while True:
+        arr = (_lib.Nal * cap)()
+        n = ctypes.c_int32(0)
+        r = L.h264mi_annexb_scan(stream, len(stream), arr, cap, ctypes.byref(n))
+        if r == -7:
+            cap *= 4
+            continue
+        check(r)
+        break
+    out = []
+    for i in range(n.value):
+        off, size = arr[i].offset, arr[i].num_bytes
+        nu = NewNalUnit(stream[off:off + size], size)
+        nu._c.offset = off
+        out.append(nu)
+    return out
+
+
+class Decoder:
+    """Batched GPU decoder: N independent Annex-B streams side by side on one MI355X."""
+
+    def __init__(self, max_streams=1, max_width=1920, max_height=1088, max_frames_per_batch=32, max_slices_per_frame=8, device=0,
+                 max_bitstream_bytes=0, hip_stream=None):
+        L = _lib.load()
+        cfg = _lib.Config()
+        cfg.device, cfg.max_streams, cfg.max_width, cfg.max_height = device, max_streams, max_width, max_height
+        cfg.max_frames_per_batch, cfg.max_slices_per_frame, cfg.max_bitstream_bytes = max_frames_per_batch, max_slices_per_frame, max_bitstream_bytes
+        cfg.hip_stream = hip_stream
+        self._h = ctypes.c_void_p()
+        check(L.h264mi_decoder_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+        self._L = L
+        self.max_streams = max_streams
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            self._L.h264mi_decoder_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        check(self._L.h264mi_decoder_set_stream(self._h, hip_stream))
+
+    def reset(self):
+        check(self._L.h264mi_decoder_reset(self._h))
+
+    def set_profiling(self, on=True):
+        check(self._L.h264mi_decoder_set_profiling(self._h, int(on)))
+
+    def kernel_times_ms(self):
+        a = (ctypes.c_double * 5)()
+        check(self._L.h264mi_last_kernel_times(self._h, a))
+        return dict(zip(("entropy", "inter", "intra", "deblock", "total"), list(a)))
+
+    def _args(self, streams):
+        n = len(streams)
+        bufs = (ctypes.c_void_p * n)()
+        lens = (ctypes.c_size_t * n)()
+        keep = []
+        for i, s in enumerate(streams):
+            if s:
+                b = ctypes.create_string_buffer(bytes(s), len(s))
+                keep.append(b)
+                bufs[i] = ctypes.cast(b, ctypes.c_void_p)
+                lens[i] = len(s)
+        self._keep = keep
+        return n, bufs, lens
+
+    def prepare(self, streams):
+        n, bufs, lens = self._args(streams)
+        info = _lib.BatchInfo()
+        check(self._L.h264mi_batch_prepare(self._h, n, bufs, lens, ctypes.byref(info)))
+        return info
+
+    def execute(self):
+        check(self._L.h264mi_batch_execute(self._h))
+
+    def sync(self):
+        check(self._L.h264mi_batch_sync(self._h))
+
+    def decode(self, streams):
+        """prepare + execute + sync; returns the batch info."""
+        info = self.prepare(streams)
+        self.execute()
+        self.sync()
+        return info
+
+    def frame_count(self, stream=0):
+        n = ctypes.c_int32(0)
+        check(self._L.h264mi_stream_frame_count(self._h, stream, ctypes.byref(n)))
+        return n.value
+
+    def frame_planes(self, stream, frame):
+        y, cb, cr = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+        py, pc, w, h = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        check(self._L.h264mi_frame_device_planes(self._h, stream, frame, ctypes.byref(y), ctypes.byref(cb), ctypes.byref(cr), ctypes.byref(py),
+                                                 ctypes.byref(pc), ctypes.byref(w), ctypes.byref(h)))
+        return dict(y=y.value, cb=cb.value, cr=cr.value, pitch_y=py.value, pitch_c=pc.value, coded_width=w.value, coded_height=h.value)
+
+    def read_frame(self, stream, frame, crop=True):
+        p = self.frame_planes(stream, frame)
+        buf = np.zeros(p["coded_width"] * p["coded_height"] * 3 // 2, dtype=np.uint8)
+        check(self._L.h264mi_frame_read(self._h, stream, frame, int(crop), buf.ctypes.data, buf.nbytes))
+        return buf
+
+    def read_frames(self, stream=0, crop=False, size=None):
+        """All frames of `stream` from the last batch as uint8[n, w*h*3/2] (tight I420)."""
+        n = self.frame_count(stream)
+        out = []
+        for f in range(n):
+            b = self.read_frame(stream, f, crop)
+            out.append(b if size is None else b[:size])
+        return np.stack(out) if out else np.zeros((0, 0), np.uint8)
+
+    def read_mbrecs(self, stream, frame, n_mbs):
+        buf = np.zeros(n_mbs * 128, dtype=np.uint8)
+        check(self._L.h264mi_frame_read_mbrecs(self._h, stream, frame, buf.ctypes.data, buf.nbytes))
+        return buf.reshape(n_mbs, 128)

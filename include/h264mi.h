@@ -1,0 +1,208 @@
+/*
+ * include/h264mi.h -- C ABI of libh264mi.so: MI355X-native H.264 Annex-B decode path.
+ *
+ * This is the drop-in boundary for the hot path of mrmod/h264decode's Go package `h264`
+ * (Annex-B bytes -> NAL -> SPS/PPS/slice header -> macroblocks -> Y/Cb/Cr planes).  The reference
+ * has no FFI of its own ("No interface contracts are implemented right now", README.md:4): the
+ * boundary is the set of exported Go identifiers; each entry point below names the reference
+ * function(s) it replaces.  The cgo / ctypes bindings are shown in INTEGRATION.md.
+ *
+ * Rules:
+ *  - extern "C", plain pointers and sizes only; no C++/torch types.
+ *  - every function returns an int32 status (0 = OK, negative = H264MI_E*); nothing aborts or
+ *    throws across the boundary (the reference panics/os.Exit()s: h264/server.go:136-143).
+ *  - caller owns input buffers for the duration of the call only; the library owns device memory.
+ *  - a decoder handle is single-threaded; distinct handles are independent.
+ *  - the pixel path runs ONLY on the GPU (HIP, gfx950).  There is no CPU fallback: without a
+ *    usable device h264mi_init / h264mi_decoder_create fail with H264MI_ENODEVICE.
+ *
+ * Field names follow the reference structs in snake_case (Go: CamelCase): NalUnit
+ * h264/nalUnit.go:3-30, SPS h264/sps.go:9-103, PPS h264/pps.go:10-38, SliceHeader
+ * h264/slice.go:23-75.  Values are spec-correct where the reference is not.
+ */
+#ifndef H264MI_H
+#define H264MI_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H264MI_OK 0
+#define H264MI_EINVAL (-1)      /* bad argument */
+#define H264MI_EBITSTREAM (-2)  /* malformed / truncated syntax */
+#define H264MI_EUNSUPPORTED (-3)/* valid H.264 outside the implemented scope (B slices, interlace, FMO, 4:4:4 ...) */
+#define H264MI_ENODEVICE (-4)   /* no usable HIP device / kernel image */
+#define H264MI_ENOMEM (-5)
+#define H264MI_EDEVICE (-6)     /* HIP runtime error */
+#define H264MI_ECAPACITY (-7)   /* caller buffer or decoder configuration too small */
+#define H264MI_EDECODE (-8)     /* a GPU entropy kernel reported a slice error */
+
+/* ---- NAL unit: h264/nalUnit.go:3-30 (NalUnit), :75-131 (NewNalUnit) ---- */
+typedef struct {
+    int32_t num_bytes;          /* NumBytes: NAL size incl. header */
+    int32_t forbidden_zero_bit; /* ForbiddenZeroBit */
+    int32_t ref_idc;            /* RefIdc */
+    int32_t type;               /* Type */
+    int32_t header_bytes;       /* HeaderBytes (1; 4 for types 14/20/21) */
+    int32_t svc_extension_flag, avc_3d_extension_flag; /* SvcExtensionFlag, Avc3dExtensionFlag (parsed, Annex G/H/J not decoded) */
+    int64_t offset;             /* byte offset of the NAL header inside the scanned buffer */
+} h264mi_nal;
+
+/* replaces isStartSequence/readNalUnit (h264/server.go:28-39,64-111): finds every NAL of an
+ * Annex-B buffer (3- and 4-byte start codes, trailing zeros stripped).  *n receives the count;
+ * returns H264MI_ECAPACITY if more than `cap` NALs exist (first `cap` are still written). */
+int32_t h264mi_annexb_scan(const uint8_t *buf, size_t len, h264mi_nal *out, int32_t cap, int32_t *n);
+/* replaces NewNalUnit + (*NalUnit).RBSP() (h264/nalUnit.go:72,75-131): parses the header of the
+ * NAL at nal_bytes[0..len) and writes the RBSP (emulation prevention removed) to rbsp_out
+ * (capacity >= len).  *rbsp_len receives its size. */
+int32_t h264mi_nal_parse(const uint8_t *nal_bytes, size_t len, h264mi_nal *nal, uint8_t *rbsp_out, size_t *rbsp_len);
+
+/* ---- SPS: h264/sps.go:9-103, NewSPS :192-437 ---- */
+typedef struct {
+    int32_t profile, constraint_flags, level, id;                      /* Profile, Constraint0..5 (packed), Level, ID */
+    int32_t chroma_format, use_separate_color_plane;                   /* ChromaFormat, UseSeparateColorPlane */
+    int32_t bit_depth_luma_minus8, bit_depth_chroma_minus8;            /* BitDepthLumaMinus8, BitDepthChromaMinus8 */
+    int32_t qprime_y_zero_transform_bypass, seq_scaling_matrix_present;/* QPrimeYZeroTransformBypass, SeqScalingMatrixPresent */
+    int32_t log2_max_frame_num_minus4, pic_order_count_type, log2_max_pic_order_cnt_lsb_min4;
+    int32_t delta_pic_order_always_zero, offset_for_non_ref_pic, offset_for_top_to_bottom_field;
+    int32_t num_ref_frames_in_pic_order_cnt_cycle;
+    int32_t offset_for_ref_frame_list[256];                            /* OffsetForRefFrameList */
+    int32_t max_num_ref_frames, gaps_in_frame_num_value_allowed;
+    int32_t pic_width_in_mbs_minus1, pic_height_in_map_units_minus1;
+    int32_t frame_mbs_only, mb_adaptive_frame_field, direct_8x8_inference;
+    int32_t frame_cropping, frame_crop_left_offset, frame_crop_right_offset, frame_crop_top_offset, frame_crop_bottom_offset;
+    int32_t vui_parameters_present;
+    int32_t aspect_ratio_info_present, aspect_ratio, sar_width, sar_height;
+    int32_t overscan_info_present, overscan_appropriate;
+    int32_t video_signal_type_present, video_format, video_full_range, color_description_present;
+    int32_t color_primaries, transfer_characteristics, matrix_coefficients;
+    int32_t chroma_loc_info_present, chroma_sample_loc_type_top_field, chroma_sample_loc_type_bottom_field;
+    int32_t timing_info_present;
+    uint32_t num_units_in_tick, time_scale;
+    int32_t fixed_frame_rate;
+    int32_t nal_hrd_parameters_present, vcl_hrd_parameters_present, low_hrd_delay, pic_struct_present;
+    int32_t cpb_cnt_minus1, bit_rate_scale, cpb_size_scale;
+    int32_t initial_cpb_removal_delay_length_minus1, cpb_removal_delay_length_minus1, dpb_output_delay_length_minus1, time_offset_length;
+    int32_t bitstream_restriction, motion_vectors_over_pic_boundaries, max_bytes_per_pic_denom, max_bits_per_mb_denom;
+    int32_t log2_max_mv_length_horizontal, log2_max_mv_length_vertical, max_num_reorder_frames, max_dec_frame_buffering;
+    /* resolved scaling lists (Table 7-2 fall-back applied), zig-zag order */
+    uint8_t scaling_list_4x4[6][16];
+    uint8_t scaling_list_8x8[2][64];
+    /* derived (h264/slice.go:159-176 PicWidthInMbs ... PicSizeInMbs) */
+    int32_t pic_width_in_mbs, pic_height_in_mbs, width, height;       /* width/height = cropped display size */
+} h264mi_sps;
+/* replaces NewSPS(rbsp, showPacket) (h264/sps.go:192) */
+int32_t h264mi_sps_parse(const uint8_t *rbsp, size_t len, h264mi_sps *sps);
+
+/* ---- PPS: h264/pps.go:10-38, NewPPS :40-133 ---- */
+typedef struct {
+    int32_t id, sps_id, entropy_coding_mode, bottom_field_pic_order_in_frame_present, num_slice_groups_minus1;
+    int32_t num_ref_idx_l0_default_active_minus1, num_ref_idx_l1_default_active_minus1;
+    int32_t weighted_pred, weighted_bipred, pic_init_qp_minus26, pic_init_qs_minus26, chroma_qp_index_offset;
+    int32_t deblocking_filter_control_present, constrained_intra_pred, redundant_pic_cnt_present;
+    int32_t transform_8x8_mode, pic_scaling_matrix_present, second_chroma_qp_index_offset;
+    uint8_t scaling_list_4x4[6][16];
+    uint8_t scaling_list_8x8[2][64];
+} h264mi_pps;
+/* replaces NewPPS(sps, rbsp, showPacket) (h264/pps.go:40).  `sps` is the SPS the PPS refers to
+ * (the reference passes "the last SPS": h264/server.go:155). */
+int32_t h264mi_pps_parse(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi_pps *pps);
+
+/* ---- slice header: h264/slice.go:23-75, NewSliceContext :835-1048 ---- */
+typedef struct {
+    int32_t first_mb_in_slice, slice_type, pps_id, color_plane_id, frame_num;
+    int32_t field_pic, bottom_field, idr_pic_id, pic_order_cnt_lsb, delta_pic_order_cnt_bottom;
+    int32_t delta_pic_order_cnt[2], redundant_pic_cnt, direct_spatial_mv_pred;
+    int32_t num_ref_idx_active_override, num_ref_idx_l0_active_minus1, num_ref_idx_l1_active_minus1;
+    int32_t ref_pic_list_modification_flag_l0, n_ref_pic_list_modifications;
+    int32_t modification_of_pic_nums[66], modification_value[66]; /* idc / abs_diff_pic_num_minus1 | long_term_pic_num */
+    int32_t luma_log2_weight_denom, chroma_log2_weight_denom;
+    int32_t luma_weight_l0_flag[32], luma_weight_l0[32], luma_offset_l0[32];
+    int32_t chroma_weight_l0_flag[32], chroma_weight_l0[32][2], chroma_offset_l0[32][2];
+    int32_t no_output_of_prior_pics_flag, long_term_reference_flag, adaptive_ref_pic_marking_mode_flag;
+    int32_t n_memory_management_control_operations;
+    int32_t memory_management_control_operation[66], mmco_arg1[66], mmco_arg2[66];
+    int32_t cabac_init, slice_qp_delta, sp_for_switch, slice_qs_delta;
+    int32_t disable_deblocking_filter, slice_alpha_c0_offset_div2, slice_beta_offset_div2;
+    /* derived */
+    int32_t nal_ref_idc, nal_unit_type, slice_qp_y; /* SliceQPy (h264/cabac.go:113) */
+    int64_t slice_data_bit_offset;                  /* where slice_data() starts inside the RBSP */
+} h264mi_slice_header;
+/* replaces NewSliceContext's header part (h264/slice.go:857-1032) */
+int32_t h264mi_slice_header_parse(const h264mi_sps *sps, const h264mi_pps *pps, int32_t nal_ref_idc, int32_t nal_unit_type,
+                                  const uint8_t *rbsp, size_t len, h264mi_slice_header *sh);
+
+/* ---- GPU decode: replaces NewSliceData / MbPred and the absent L7 reconstruction
+ *      (h264/slice.go:570-830, :252-454; README.md:8-10 TODO items) ---- */
+typedef struct h264mi_decoder h264mi_decoder;
+
+typedef struct {
+    int32_t device;                /* HIP device ordinal */
+    int32_t max_streams;           /* independent streams decoded side by side */
+    int32_t max_width, max_height; /* display size upper bound (coded size is rounded up to 16) */
+    int32_t max_frames_per_batch;  /* per stream and per h264mi_decode_batch call */
+    int32_t max_slices_per_frame;
+    int64_t max_bitstream_bytes;   /* per batch, summed over streams */
+    void *hip_stream;              /* hipStream_t to launch on; NULL = a private stream */
+} h264mi_config;
+
+typedef struct {
+    int32_t n_frames;         /* frames decoded in this batch */
+    int32_t n_slices;
+    int64_t n_macroblocks;
+    int64_t bitstream_bytes;  /* RBSP bytes resident on the device */
+    int32_t width, height, coded_width, coded_height; /* of stream 0 */
+    double host_prepare_ms;   /* NAL scan + header parse + DPB bookkeeping + upload enqueue */
+} h264mi_batch_info;
+
+int32_t h264mi_init(int32_t device);
+int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decoder **out);
+int32_t h264mi_decoder_destroy(h264mi_decoder *dec);
+int32_t h264mi_decoder_set_stream(h264mi_decoder *dec, void *hip_stream);
+/* Forget all reference pictures of every stream (seek / new sequence). */
+int32_t h264mi_decoder_reset(h264mi_decoder *dec);
+
+/* Stage 1 (host + H2D): scan and parse each stream's Annex-B chunk (whole access units), run
+ * picture management (POC 8.2.1, reference lists 8.2.4, marking 8.2.5), and make the RBSP bytes
+ * and slice/picture descriptors resident in device memory.  bufs[i]/lens[i] = chunk of stream i
+ * (NULL/0 = nothing for that stream). */
+int32_t h264mi_batch_prepare(h264mi_decoder *dec, int32_t n_streams, const uint8_t *const *bufs, const size_t *lens, h264mi_batch_info *info);
+/* Stage 2 (GPU only): entropy-decode every slice of the prepared batch (one slice per wavefront),
+ * then reconstruct and deblock picture by picture.  Asynchronous on the decoder's stream.  May be
+ * called repeatedly for the same prepared batch (benchmarks); results are identical each time. */
+int32_t h264mi_batch_execute(h264mi_decoder *dec);
+/* Wait for the stream and collect per-slice status written by the entropy kernels. */
+int32_t h264mi_batch_sync(h264mi_decoder *dec);
+/* prepare + execute + sync */
+int32_t h264mi_decode_batch(h264mi_decoder *dec, int32_t n_streams, const uint8_t *const *bufs, const size_t *lens, h264mi_batch_info *info);
+
+/* Frames of the last batch, in decoding order (== output order for the I/P streams in scope). */
+int32_t h264mi_stream_frame_count(h264mi_decoder *dec, int32_t stream, int32_t *n);
+/* Device pointers + pitches of a decoded frame (coded size; planes are resident in HBM until the
+ * next h264mi_batch_prepare). */
+int32_t h264mi_frame_device_planes(h264mi_decoder *dec, int32_t stream, int32_t frame, void **y, void **cb, void **cr, int32_t *pitch_y,
+                                   int32_t *pitch_c, int32_t *coded_width, int32_t *coded_height);
+/* Copy a frame to host memory as tight I420 (crop != 0: display size, else coded size). */
+int32_t h264mi_frame_read(h264mi_decoder *dec, int32_t stream, int32_t frame, int32_t crop, uint8_t *dst, size_t cap);
+/* Cropped, tightly packed I420 copy on the device (K6): dst is a DEVICE pointer. */
+int32_t h264mi_frame_pack_device(h264mi_decoder *dec, int32_t stream, int32_t frame, void *dst_device, size_t cap);
+
+/* Debug / test access to the intermediate macroblock records of a frame (host copy).
+ * rec: 128 bytes per MB (layout: h264decode_amd/csrc/mi_types.h struct MbRec). */
+int32_t h264mi_frame_read_mbrecs(h264mi_decoder *dec, int32_t stream, int32_t frame, uint8_t *rec, size_t cap);
+
+/* Time (ms) spent by the kernels of the last execute, measured with HIP events on the decoder's
+ * stream: [0] entropy, [1] inter recon, [2] intra recon, [3] deblock, [4] total.  Valid after sync
+ * when profiling was enabled with h264mi_decoder_set_profiling(dec, 1). */
+int32_t h264mi_decoder_set_profiling(h264mi_decoder *dec, int32_t on);
+int32_t h264mi_last_kernel_times(h264mi_decoder *dec, double ms[5]);
+
+const char *h264mi_last_error_string(void);
+const char *h264mi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
