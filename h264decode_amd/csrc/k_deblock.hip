@@ -5,36 +5,49 @@
 // MB(x,y)'s horizontal edges were filtered, so a whole-picture "all vertical, then all horizontal"
 // pass is not bit-exact.  The exact dependency is MB(x,y) after MB(x-1,y) and MB(x+1,y-1): a 2-D
 // wavefront.  One workgroup owns a picture (no cross-CU hand-off), wavefront w owns macroblock rows
-// w, w+16, ... and waits on the LDS progress counter of the row above.  Per macroblock the 20x20 luma
-// and two 10x12 chroma neighbourhoods are staged in an LDS tile (dword loads), lanes 0-15 filter
-// luma rows / columns and lanes 16-31 chroma, and the modified samples go back with dword stores.
+// w, w+16, ... and waits on the LDS progress counter of the row above.
+//
+// Per macroblock (one wavefront):
+//   * the MbRec of the current / left / upper macroblock and the alpha/beta/tC0 tables live in LDS,
+//     so no filtering decision ever waits on a dependent global load;
+//   * the macroblock's own 16x16 + 2x 8x8 samples and its MbRecs are PREFETCHED into registers one
+//     macroblock ahead (they are final inputs from K3/K4); only the 4 rows above (written by the
+//     wavefront of the previous row) are loaded after the progress wait, and the 4 columns to the
+//     left are carried over inside LDS from the previous tile;
+//   * lanes 0-15 filter luma rows / columns and lanes 16-31 chroma in a 20x20 / 12x12 LDS tile;
+//     the result goes back with dword stores (rows -3..15, columns -4..15).
 //
 // Absent from the reference (only the slice-header fields are parsed: h264/slice.go:1021-1027).
 #include <hip/hip_runtime.h>
 #include "mi_kernels.h"
 
-#define WAVE_SYNC()                                             \
-    do {                                                        \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
-        __builtin_amdgcn_wave_barrier();                        \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+#define WAVE_SYNC()                                            \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
+struct DbTile {
+    uint8_t y[20][20];    // rows/cols -4..15 of the macroblock
+    uint8_t c[2][12][12]; // rows -4..7 (only -2.. used), cols -4..7
+};
 struct DbWave {
-    uint8_t y[20][20];     // rows/cols -4..15 of the macroblock
-    uint8_t c[2][12][12];  // rows -4..7 (only -2.. used), cols -4..7
-    uint8_t bs[2][4][4];   // [dir][edge][segment]
-    uint8_t any[2];
+    DbTile tile[2];     // double buffer: the left 4 columns of tile[k] come from tile[k^1]
+    MbRec rec[3];       // ring: cur / left share slots (left = previous cur), top
+    uint8_t bs[2][4][4]; // [dir][edge][segment]
+    uint8_t any[2], pad[2];
 };
 struct DbShared {
     DbWave w[MI_DEBLOCK_WAVES];
+    uint8_t alpha[52], beta[52], tc0[52][4];
     int prog[320];
 };
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
 
-// filter one line of samples; p points at q0, `step` = distance between samples across the edge
+// filter one line of samples (8.7.2.3 / 8.7.2.4); q0p points at q0, `step` = distance across the edge
 __device__ __forceinline__ void filter_line(uint8_t *q0p, int step, int bs, int alpha, int beta, int tc0, bool chroma) {
     int p0 = q0p[-step], p1 = q0p[-2 * step], q0 = q0p[0], q1 = q0p[step];
     if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
@@ -76,7 +89,7 @@ __device__ __forceinline__ void filter_line(uint8_t *q0p, int step, int bs, int 
     }
 }
 
-// 8.7.2.1 for P/I frame macroblocks
+// 8.7.2.1 for frame macroblocks of I/P pictures
 __device__ __forceinline__ int edge_bs(const MbRec *mp, int pb, const MbRec *mq, int qb, bool mb_edge) {
     if (MB_IS_INTRA(mp->type) || MB_IS_INTRA(mq->type)) return mb_edge ? 4 : 3;
     if (((mp->nzmask >> pb) & 1) || ((mq->nzmask >> qb) & 1)) return 2;
@@ -86,86 +99,6 @@ __device__ __forceinline__ int edge_bs(const MbRec *mp, int pb, const MbRec *mq,
     return 0;
 }
 
-__device__ void deblock_mb(int lane, DbWave *ws, const MbRec *mq, const MbRec *mleft, const MbRec *mtop, const DevTables *tab, uint8_t *py, uint8_t *pcb,
-                           uint8_t *pcr, int W, int mbx, int mby) {
-    // ---- boundary strengths: lanes 0..31 = (dir, edge, segment) ----
-    if (lane < 2) ws->any[lane] = 0;
-    WAVE_SYNC();
-    if (lane < 32) {
-        const int dir = lane >> 4, e = (lane >> 2) & 3, k = lane & 3;
-        const MbRec *mn = dir == 0 ? mleft : mtop;
-        int bs = 0;
-        if (!(e == 0 && !mn) && !((e & 1) && mq->t8x8)) {
-            const MbRec *mp = e == 0 ? mn : mq;
-            int qb = dir == 0 ? k * 4 + e : e * 4 + k;
-            int pb = dir == 0 ? k * 4 + (e == 0 ? 3 : e - 1) : (e == 0 ? 3 : e - 1) * 4 + k;
-            bs = edge_bs(mp, pb, mq, qb, e == 0);
-        }
-        ws->bs[dir][e][k] = static_cast<uint8_t>(bs);
-        if (bs) ws->any[dir] = 1;
-    }
-    WAVE_SYNC();
-    if (!(ws->any[0] | ws->any[1])) return;
-    const int Wc = W / 2;
-    uint8_t *Y = py + static_cast<size_t>(mby * 16) * W + mbx * 16;
-    uint8_t *C[2] = {pcb + static_cast<size_t>(mby * 8) * Wc + mbx * 8, pcr + static_cast<size_t>(mby * 8) * Wc + mbx * 8};
-    const bool has_left = mbx > 0, has_top = mby > 0;
-    // ---- stage the neighbourhood in LDS: luma 20 rows x 5 dwords, chroma 2 x 12 rows x 3 dwords ----
-    for (int i = lane; i < 100; i += 64) {
-        int r = i / 5, d = i - r * 5;
-        uint32_t v = 0;
-        if ((r >= 4 || has_top) && (d >= 1 || has_left)) v = *reinterpret_cast<const uint32_t *>(Y + static_cast<ptrdiff_t>(r - 4) * W + (d - 1) * 4);
-        *reinterpret_cast<uint32_t *>(&ws->y[r][d * 4]) = v;
-    }
-    for (int i = lane; i < 72; i += 64) {
-        int c = i / 36, rem = i - c * 36, r = rem / 3, d = rem - r * 3;
-        uint32_t v = 0;
-        if ((r >= 4 || has_top) && (d >= 1 || has_left)) v = *reinterpret_cast<const uint32_t *>(C[c] + static_cast<ptrdiff_t>(r - 4) * Wc + (d - 1) * 4);
-        *reinterpret_cast<uint32_t *>(&ws->c[c][r][d * 4]) = v;
-    }
-    WAVE_SYNC();
-    // ---- the two filtering passes ----
-    for (int dir = 0; dir < 2; dir++) {
-        if (ws->any[dir]) {
-            const MbRec *mn = dir == 0 ? mleft : mtop;
-            if (lane < 16) { // luma: one row (dir 0) or column (dir 1) per lane, edges in order
-                for (int e = 0; e < 4; e++) {
-                    int bs = ws->bs[dir][e][lane >> 2];
-                    if (!bs) continue;
-                    const MbRec *mp = e == 0 ? mn : mq;
-                    int qpav = (mp->qp + mq->qp + 1) >> 1;
-                    int ia = clip3(0, 51, qpav + mq->alpha_off), ib = clip3(0, 51, qpav + mq->beta_off);
-                    uint8_t *q0 = dir == 0 ? &ws->y[4 + lane][4 + e * 4] : &ws->y[4 + e * 4][4 + lane];
-                    filter_line(q0, dir == 0 ? 1 : 20, bs, tab->alpha[ia], tab->beta[ib], bs < 4 ? tab->tc0[ia][bs] : 0, false);
-                }
-            } else if (lane < 32) { // chroma: plane = bit 3, row/column = low 3 bits; luma edges 0 and 2
-                const int c = (lane >> 3) & 1, i = lane & 7;
-                for (int e = 0; e < 4; e += 2) {
-                    int bs = ws->bs[dir][e][i >> 1];
-                    if (!bs) continue;
-                    const MbRec *mp = e == 0 ? mn : mq;
-                    int qpav = (mp->qpc[c] + mq->qpc[c] + 1) >> 1;
-                    int ia = clip3(0, 51, qpav + mq->alpha_off), ib = clip3(0, 51, qpav + mq->beta_off);
-                    uint8_t *q0 = dir == 0 ? &ws->c[c][4 + i][4 + e * 2] : &ws->c[c][4 + e * 2][4 + i];
-                    filter_line(q0, dir == 0 ? 1 : 12, bs, tab->alpha[ia], tab->beta[ib], bs < 4 ? tab->tc0[ia][bs] : 0, true);
-                }
-            }
-        }
-        WAVE_SYNC();
-    }
-    // ---- write back rows -3..15 (all 5 dwords) ----
-    for (int i = lane; i < 100; i += 64) {
-        int r = i / 5, d = i - r * 5;
-        if (r >= 1 && (r >= 4 || has_top) && (d >= 1 || has_left) && !(r < 4 && d == 0)) // the top-left corner block is never modified here
-            *reinterpret_cast<uint32_t *>(Y + static_cast<ptrdiff_t>(r - 4) * W + (d - 1) * 4) = *reinterpret_cast<const uint32_t *>(&ws->y[r][d * 4]);
-    }
-    for (int i = lane; i < 72; i += 64) {
-        int c = i / 36, rem = i - c * 36, r = rem / 3, d = rem - r * 3;
-        if (r >= 3 && (r >= 4 || has_top) && (d >= 1 || has_left) && !(r < 4 && d == 0))
-            *reinterpret_cast<uint32_t *>(C[c] + static_cast<ptrdiff_t>(r - 4) * Wc + (d - 1) * 4) = *reinterpret_cast<const uint32_t *>(&ws->c[c][r][d * 4]);
-    }
-}
-
 extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_WAVES * 64) k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
                                                                               const DevTables *tab, const MbRec *mbrec) {
     __shared__ DbShared sh;
@@ -173,27 +106,135 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_WAVES * 64) k_deblock(co
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
     const FramePool *pool = &pools[pd->stream];
-    const int W = static_cast<int>(pool->w), H = static_cast<int>(pool->h);
+    const int W = static_cast<int>(pool->w), H = static_cast<int>(pool->h), Wc = W / 2;
     uint8_t *py = reinterpret_cast<uint8_t *>(pool->base) + static_cast<size_t>(pd->slot) * pool->slot_bytes;
     uint8_t *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
     for (int i = tid; i < 320; i += MI_DEBLOCK_WAVES * 64) sh.prog[i] = 0;
+    for (int i = tid; i < 52; i += MI_DEBLOCK_WAVES * 64) {
+        sh.alpha[i] = tab->alpha[i], sh.beta[i] = tab->beta[i];
+        sh.tc0[i][0] = 0, sh.tc0[i][1] = tab->tc0[i][1], sh.tc0[i][2] = tab->tc0[i][2], sh.tc0[i][3] = tab->tc0[i][3];
+    }
     __syncthreads();
     DbWave *ws = &sh.w[wave];
+    const MbRec *recs = mbrec + pd->mb_base;
     for (int mby = wave; mby < hmb; mby += MI_DEBLOCK_WAVES) {
+        const bool has_top = mby > 0;
+        // ---- prefetch for mbx = 0: MbRecs (cur: lanes 0-31, top: lanes 32-63) and own samples ----
+        const MbRec *row = recs + static_cast<size_t>(mby) * wmb;
+        uint32_t pre_rec = 0, pre_y = 0, pre_c = 0;
+        auto prefetch = [&](int mbx) {
+            const MbRec *src = lane < 32 ? row + mbx : (has_top ? row + mbx - wmb : row + mbx);
+            pre_rec = reinterpret_cast<const uint32_t *>(src)[lane & 31];
+            // own 16x16 luma: 64 dwords (lane -> row lane/4, dword lane%4); own chroma: 2 x 8 rows x 2 dwords on lanes 0-31
+            pre_y = *reinterpret_cast<const uint32_t *>(py + static_cast<size_t>(mby * 16 + (lane >> 2)) * W + mbx * 16 + (lane & 3) * 4);
+            if (lane < 32) {
+                const uint8_t *cp = (lane < 16 ? pcb : pcr) + static_cast<size_t>(mby * 8 + ((lane >> 1) & 7)) * Wc + mbx * 8 + (lane & 1) * 4;
+                pre_c = *reinterpret_cast<const uint32_t *>(cp);
+            }
+        };
+        prefetch(0);
+        int cur_slot = 0; // rec ring: cur = rec[cur_slot], left = rec[cur_slot ^ 1], top = rec[2]
         for (int mbx = 0; mbx < wmb; mbx++) {
-            const MbRec *mq = mbrec + pd->mb_base + static_cast<uint64_t>(mby) * wmb + mbx;
-            if (mq->dbf_idc != 1) {
-                const MbRec *ml = mbx > 0 ? mq - 1 : nullptr, *mt = mby > 0 ? mq - wmb : nullptr;
-                if (mq->dbf_idc == 2) { // no filtering across slice boundaries
+            cur_slot ^= 1;
+            DbTile *tl = &ws->tile[mbx & 1], *prev = &ws->tile[(mbx & 1) ^ 1];
+            MbRec *mq = &ws->rec[cur_slot], *mleft_rec = &ws->rec[cur_slot ^ 1], *mtop_rec = &ws->rec[2];
+            // ---- commit the prefetched data to LDS ----
+            reinterpret_cast<uint32_t *>(lane < 32 ? mq : mtop_rec)[lane & 31] = pre_rec;
+            *reinterpret_cast<uint32_t *>(&tl->y[4 + (lane >> 2)][4 + (lane & 3) * 4]) = pre_y;
+            if (lane < 32) *reinterpret_cast<uint32_t *>(&tl->c[lane >> 4][4 + ((lane >> 1) & 7)][4 + (lane & 1) * 4]) = pre_c;
+            // left 4 columns: carried over from the previous tile (rows 0..15 luma, 0..7 chroma)
+            if (mbx > 0) {
+                if (lane < 16)
+                    *reinterpret_cast<uint32_t *>(&tl->y[4 + lane][0]) = *reinterpret_cast<const uint32_t *>(&prev->y[4 + lane][16]);
+                else if (lane < 32)
+                    *reinterpret_cast<uint32_t *>(&tl->c[(lane >> 3) & 1][4 + (lane & 7)][0]) = *reinterpret_cast<const uint32_t *>(&prev->c[(lane >> 3) & 1][4 + (lane & 7)][8]);
+            }
+            if (lane < 2) ws->any[lane] = 0;
+            WAVE_SYNC();
+            if (mbx + 1 < wmb) prefetch(mbx + 1);
+            const int dbf = mq->dbf_idc;
+            if (dbf != 1) {
+                const MbRec *ml = mbx > 0 ? mleft_rec : nullptr, *mt = has_top ? mtop_rec : nullptr;
+                if (dbf == 2) { // no filtering across slice boundaries
                     if (ml && ml->slice_in_pic != mq->slice_in_pic) ml = nullptr;
                     if (mt && mt->slice_in_pic != mq->slice_in_pic) mt = nullptr;
                 }
-                if (mby > 0) {
-                    const int need = min(mbx + 2, wmb);
-                    while (__hip_atomic_load(&sh.prog[mby - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+                // ---- boundary strengths: lanes 0..31 = (dir, edge, segment) ----
+                if (lane < 32) {
+                    const int dir = lane >> 4, e = (lane >> 2) & 3, k = lane & 3;
+                    const MbRec *mn = dir == 0 ? ml : mt;
+                    int bs = 0;
+                    if (!(e == 0 && !mn) && !((e & 1) && mq->t8x8)) {
+                        const MbRec *mp = e == 0 ? mn : mq;
+                        int qb = dir == 0 ? k * 4 + e : e * 4 + k;
+                        int pb = dir == 0 ? k * 4 + (e == 0 ? 3 : e - 1) : (e == 0 ? 3 : e - 1) * 4 + k;
+                        bs = edge_bs(mp, pb, mq, qb, e == 0);
+                    }
+                    ws->bs[dir][e][k] = static_cast<uint8_t>(bs);
+                    if (bs) ws->any[dir] = 1;
                 }
-                deblock_mb(lane, ws, mq, ml, mt, tab, py, pcb, pcr, W, mbx, mby);
+                WAVE_SYNC();
+                if (ws->any[0] | ws->any[1]) {
+                    uint8_t *Y = py + static_cast<size_t>(mby * 16) * W + mbx * 16;
+                    uint8_t *C0 = pcb + static_cast<size_t>(mby * 8) * Wc + mbx * 8, *C1 = pcr + static_cast<size_t>(mby * 8) * Wc + mbx * 8;
+                    // ---- the 4 rows above come from the wavefront of the previous row ----
+                    if (has_top) {
+                        const int need = min(mbx + 2, wmb);
+                        while (__hip_atomic_load(&sh.prog[mby - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+                        if (lane < 16) // luma rows -4..-1, columns 0..15
+                            *reinterpret_cast<uint32_t *>(&tl->y[lane >> 2][4 + (lane & 3) * 4]) =
+                                *reinterpret_cast<const uint32_t *>(Y + static_cast<ptrdiff_t>((lane >> 2) - 4) * W + (lane & 3) * 4);
+                        else if (lane < 24) { // chroma rows -2..-1
+                            const int c = (lane >> 2) & 1, r = (lane >> 1) & 1, d = lane & 1;
+                            *reinterpret_cast<uint32_t *>(&tl->c[c][2 + r][4 + d * 4]) =
+                                *reinterpret_cast<const uint32_t *>((c ? C1 : C0) + static_cast<ptrdiff_t>(r - 2) * Wc + d * 4);
+                        }
+                        WAVE_SYNC();
+                    }
+                    // ---- the two filtering passes ----
+                    for (int dir = 0; dir < 2; dir++) {
+                        if (ws->any[dir]) {
+                            const MbRec *mn = dir == 0 ? ml : mt;
+                            if (lane < 16) { // luma: one row (dir 0) or column (dir 1) per lane, edges in order
+                                for (int e = 0; e < 4; e++) {
+                                    int bs = ws->bs[dir][e][lane >> 2];
+                                    if (!bs) continue;
+                                    const MbRec *mp = e == 0 ? mn : mq;
+                                    int qpav = (mp->qp + mq->qp + 1) >> 1;
+                                    int ia = clip3(0, 51, qpav + mq->alpha_off), ib = clip3(0, 51, qpav + mq->beta_off);
+                                    uint8_t *q0 = dir == 0 ? &tl->y[4 + lane][4 + e * 4] : &tl->y[4 + e * 4][4 + lane];
+                                    filter_line(q0, dir == 0 ? 1 : 20, bs, sh.alpha[ia], sh.beta[ib], sh.tc0[ia][bs & 3], false);
+                                }
+                            } else if (lane < 32) { // chroma: plane = bit 3, row/column = low 3 bits; luma edges 0 and 2
+                                const int c = (lane >> 3) & 1, i = lane & 7;
+                                for (int e = 0; e < 4; e += 2) {
+                                    int bs = ws->bs[dir][e][i >> 1];
+                                    if (!bs) continue;
+                                    const MbRec *mp = e == 0 ? mn : mq;
+                                    int qpav = (mp->qpc[c] + mq->qpc[c] + 1) >> 1;
+                                    int ia = clip3(0, 51, qpav + mq->alpha_off), ib = clip3(0, 51, qpav + mq->beta_off);
+                                    uint8_t *q0 = dir == 0 ? &tl->c[c][4 + i][4 + e * 2] : &tl->c[c][4 + e * 2][4 + i];
+                                    filter_line(q0, dir == 0 ? 1 : 12, bs, sh.alpha[ia], sh.beta[ib], sh.tc0[ia][bs & 3], true);
+                                }
+                            }
+                        }
+                        WAVE_SYNC();
+                    }
+                    // ---- write back rows -3..15, columns -4..15 (the untouched top-left corner is skipped) ----
+                    const bool has_left = mbx > 0;
+                    for (int i = lane; i < 100; i += 64) {
+                        int r = i / 5, d = i - r * 5;
+                        if (r >= 1 && (r >= 4 || has_top) && (d >= 1 || has_left) && !(r < 4 && d == 0))
+                            *reinterpret_cast<uint32_t *>(Y + static_cast<ptrdiff_t>(r - 4) * W + (d - 1) * 4) = *reinterpret_cast<const uint32_t *>(&tl->y[r][d * 4]);
+                    }
+                    for (int i = lane; i < 72; i += 64) {
+                        int c = i / 36, rem = i - c * 36, r = rem / 3, d = rem - r * 3;
+                        if (r >= 3 && (r >= 4 || has_top) && (d >= 1 || has_left) && !(r < 4 && d == 0))
+                            *reinterpret_cast<uint32_t *>((c ? C1 : C0) + static_cast<ptrdiff_t>(r - 4) * Wc + (d - 1) * 4) = *reinterpret_cast<const uint32_t *>(&tl->c[c][r][d * 4]);
+                    }
+                }
             }
+            // publish progress: the release orders this wave's global stores before the counter update
             if (lane == 0) __hip_atomic_store(&sh.prog[mby], mbx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }

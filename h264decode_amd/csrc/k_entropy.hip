@@ -10,7 +10,12 @@
 //   * write-out: the 128-byte MbRec and the 832-byte coefficient block are assembled in LDS and
 //     stored with one dword / one dwordx4 per lane.
 // CABAC engine state (codIRange, scaled codIOffset, lookahead count) is wave-uniform; context
-// states, rangeTabLPS and transIdxLPS sit in LDS.
+// states and a merged rangeTabLPS/transIdx table (one 8-byte LDS read per decision) sit in LDS.
+//
+// Code-size discipline: the instruction cache is shared, and hundreds of slices run different parts
+// of this kernel at once, so every syntax routine is inlined exactly ONCE: residual blocks, motion
+// partitions and reference indices are decoded by single loops over small schedules instead of
+// per-case call sites, and block categories are run-time parameters (tables below), not templates.
 //
 // Replaces: NewSliceData / MbPred (h264/slice.go:570-830, :252-454) and the arithmetic decoding
 // engine (h264/cabac.go:439-553); residual parsing, Intra4x4PredMode derivation and motion vector
@@ -20,6 +25,7 @@
 
 #define RING_WORDS 1024
 #define LANE (static_cast<int>(threadIdx.x))
+#define FI __device__ __forceinline__
 
 struct TopInfo { // edge state of a decoded MB as seen by its right / lower neighbours (48 bytes)
     uint8_t type, t8x8, cbp, chroma_mode, cbf_dc, pad[3];
@@ -34,24 +40,26 @@ static_assert(sizeof(TopInfo) == 48, "TopInfo layout");
 
 struct Shared {
     uint32_t ring[RING_WORDS];
+    uint2 lps[128];      // per state s=(pStateIdx<<1|valMPS): .x = rangeTabLPS[p][0..3] packed, .y = next(MPS) | next(LPS)<<8
     uint8_t ctx[464];
-    uint8_t range_lps[256];
-    uint8_t trans_lps[64];
-    uint8_t zz4[16], zz8[64], sig8[64], last8[64];
+    uint8_t posmap[4][64]; // scan index -> position: [0] zig-zag 4x4, [1] zig-zag 4x4 of AC index (k+1), [2] zig-zag 8x8, [3] identity
+    uint8_t incmap[3][64]; // ctxIdxInc of significant_coeff_flag: [0] identity, [1] min(i,2) (chroma DC), [2] Table 9-43 8x8
+    uint8_t lastmap[64];   // ctxIdxInc of last_significant_coeff_flag for 8x8 blocks
     int16_t coef[MI_COEF_PER_MB];
     MbRec rec;
     TopInfo left, tl; // tl = top[] entry of column x-1 as it was for the row above
     // Neighbour caches of the current MB.  6-wide grids: column 0 = left MB, 1..4 = current MB,
     // 5 = right / top-right; row 0 = MB row above, rows 1..4 = current MB.
-    int8_t ipm_c[32];     // -2 unavailable, -1 not (yet) an I_NxN block
-    uint8_t nnz_c[32];    // 0x80 = unavailable
+    int8_t ipm_c[32];      // -2 unavailable, -1 not (yet) an I_NxN block
+    uint8_t nnz_c[32];     // 0x80 = unavailable
     uint8_t nnzc_c[2][12]; // chroma 3x3 grids
-    int8_t ref_c[32];     // -2 unavailable or not yet decoded, -1 intra, >= 0 ref_idx (motion final)
-    int8_t refi_c[32];    // ref_idx as soon as parsed (CABAC ctxIdxInc of ref_idx)
+    int8_t ref_c[32];      // -2 unavailable or not yet decoded, -1 intra, >= 0 ref_idx (motion final)
+    int8_t refi_c[32];     // ref_idx as soon as parsed (CABAC ctxIdxInc of ref_idx)
     int16_t mv_c[32][2];
     uint8_t mvd_c[32][2];
-    int16_t lvl[16];      // CAVLC level scratch
-    int16_t tmp16[16];    // CAVLC 8x8 interleave scratch
+    int16_t lvl[16];       // CAVLC level scratch
+    int16_t tmp16[16];     // CAVLC 8x8 interleave scratch
+    uint16_t parts[16];    // motion partition schedule: bx | by<<2 | (w-1)<<4 | (h-1)<<6 | shape<<8
     int8_t refs8[4];
     int8_t sub_type[4];
     uint8_t cur_cbf_dc, pad[3];
@@ -74,8 +82,20 @@ struct Ent {
     int cabac, islice, wmb, hmb;
 };
 
+// per block category (ctxBlockCat 0..5): maxNumCoeff, ctxIdx bases, clamp of numDecodAbsLevelGt1,
+// position map, significance-inc map (Tables 9-34, 9-40, 9-43)
+__constant__ uint16_t c_cat[6][8] = {
+    /* maxnum, cbf base, sig base, last base, abs base, gt1 limit, posmap, incmap */
+    {16, 85 + 0, 105 + 0, 166 + 0, 227 + 0, 4, 0, 0},    // 0 Intra16x16 DC
+    {15, 85 + 4, 105 + 15, 166 + 15, 227 + 10, 4, 1, 0}, // 1 Intra16x16 AC
+    {16, 85 + 8, 105 + 29, 166 + 29, 227 + 20, 4, 0, 0}, // 2 luma 4x4
+    {4, 85 + 12, 105 + 44, 166 + 44, 227 + 30, 3, 3, 1}, // 3 chroma DC
+    {15, 85 + 16, 105 + 47, 166 + 47, 227 + 39, 4, 1, 0},// 4 chroma AC
+    {64, 0, 402, 417, 426, 4, 2, 2},                     // 5 luma 8x8
+};
+
 // ------------------------------------------------------------------ bitstream ring
-__device__ __forceinline__ void ring_fill(Ent &e) {
+FI void ring_fill(Ent &e) {
     // 512 words = 2 KB per call: each lane loads 32 bytes; words are byte-swapped to MSB-first order
     uint32_t base = e.filled + LANE * 8;
     const uint4 *src = reinterpret_cast<const uint4 *>(e.rbsp) + (base >> 2);
@@ -89,24 +109,24 @@ __device__ __forceinline__ void ring_fill(Ent &e) {
     __syncthreads();
 }
 // keep at least 128 words (4096 bits) resident beyond the cursor
-__device__ __forceinline__ void ensure(Ent &e) {
+FI void ensure(Ent &e) {
     if ((e.bitpos >> 5) + 128 > e.filled) {
         __syncthreads();
         ring_fill(e);
     }
 }
-__device__ __forceinline__ uint32_t peek32(const Ent &e, uint32_t pos) {
+FI uint32_t peek32(const Ent &e, uint32_t pos) {
     uint32_t w = pos >> 5, sh = pos & 31;
     uint64_t v = (static_cast<uint64_t>(e.s->ring[w & (RING_WORDS - 1)]) << 32) | e.s->ring[(w + 1) & (RING_WORDS - 1)];
     return static_cast<uint32_t>((v << sh) >> 32);
 }
-__device__ __forceinline__ uint32_t get_bits(Ent &e, int n) { // 1..25
+FI uint32_t get_bits(Ent &e, int n) { // 1..25
     uint32_t v = peek32(e, e.bitpos) >> (32 - n);
     e.bitpos += n;
     return v;
 }
-__device__ __forceinline__ uint32_t get_bit(Ent &e) { return get_bits(e, 1); }
-__device__ __forceinline__ uint32_t get_ue(Ent &e) { // 9.1 with one CLZ
+FI uint32_t get_bit(Ent &e) { return get_bits(e, 1); }
+FI uint32_t get_ue(Ent &e) { // 9.1 with one CLZ
     uint32_t w = peek32(e, e.bitpos);
     if (w == 0) {
         e.err = 1;
@@ -121,7 +141,7 @@ __device__ __forceinline__ uint32_t get_ue(Ent &e) { // 9.1 with one CLZ
     e.bitpos += 2 * lz + 1;
     return (w >> (31 - 2 * lz)) - 1;
 }
-__device__ __forceinline__ int get_se(Ent &e) {
+FI int get_se(Ent &e) {
     uint32_t k = get_ue(e);
     int m = static_cast<int>((k + 1) >> 1);
     return (k & 1) ? m : -m;
@@ -129,242 +149,117 @@ __device__ __forceinline__ int get_se(Ent &e) {
 
 // ------------------------------------------------------------------ CABAC engine (9.3.1.2, 9.3.3.2)
 // codIOffset is kept scaled: value = (codIOffset << avail) | next `avail` stream bits.
-__device__ __forceinline__ void cabac_refill(Ent &e) {
+FI void cabac_refill(Ent &e) {
     if (e.avail < 7) {
         e.value = (e.value << 16) | (peek32(e, e.bitpos) >> 16);
         e.bitpos += 16;
         e.avail += 16;
     }
 }
-__device__ __forceinline__ void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
+FI void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
     e.range = 510;
     e.value = get_bits(e, 9);
     e.avail = 0;
     cabac_refill(e);
 }
-__device__ __forceinline__ int cabac_bin(Ent &e, int ctx) { // DecodeDecision + state transition + RenormD
-    uint32_t st = e.s->ctx[ctx];
-    uint32_t p = st >> 1, mps = st & 1;
-    uint32_t rlps = e.s->range_lps[p * 4 + ((e.range >> 6) & 3)];
-    e.range -= rlps;
-    uint32_t scaled = e.range << e.avail;
-    int bin;
-    if (e.value >= scaled) {
-        e.value -= scaled;
-        e.range = rlps;
-        bin = static_cast<int>(mps ^ 1);
-        if (p == 0) mps ^= 1;
-        p = e.s->trans_lps[p];
-    } else {
-        bin = static_cast<int>(mps);
-        p = p < 62 ? p + 1 : p;
-    }
-    e.s->ctx[ctx] = static_cast<uint8_t>((p << 1) | mps);
-    int n = __clz(e.range) - 23; // RenormD (h264/cabac.go:503-511) in one step
+// DecodeDecision (h264/cabac.go:521-540) + state transition (:544-553) + RenormD (:503-511), branch-free
+FI int cabac_bin(Ent &e, int ctx) {
+    const uint32_t st = e.s->ctx[ctx];
+    const uint2 t = e.s->lps[st];
+    const uint32_t rlps = (t.x >> (((e.range >> 6) & 3) * 8)) & 255;
+    const uint32_t rmps = e.range - rlps;
+    const uint32_t scaled = rmps << e.avail;
+    const bool lps = e.value >= scaled;
+    e.value -= lps ? scaled : 0;
+    e.range = lps ? rlps : rmps;
+    e.s->ctx[ctx] = static_cast<uint8_t>(lps ? (t.y >> 8) : (t.y & 255));
+    const int n = __clz(e.range) - 23;
     e.range <<= n;
     e.avail -= n;
     cabac_refill(e);
-    return bin;
+    return static_cast<int>((st & 1) ^ static_cast<uint32_t>(lps));
 }
-__device__ __forceinline__ int cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
+FI int cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
     e.avail -= 1;
-    uint32_t scaled = e.range << e.avail;
-    int bin = 0;
-    if (e.value >= scaled) {
-        e.value -= scaled;
-        bin = 1;
-    }
+    const uint32_t scaled = e.range << e.avail;
+    const bool one = e.value >= scaled;
+    e.value -= one ? scaled : 0;
     cabac_refill(e);
-    return bin;
+    return one;
 }
-__device__ __forceinline__ int cabac_terminate(Ent &e) { // 9.3.3.2.4
+FI int cabac_terminate(Ent &e) { // 9.3.3.2.4
     e.range -= 2;
-    uint32_t scaled = e.range << e.avail;
-    if (e.value >= scaled) return 1;
-    int n = __clz(e.range) - 23;
+    if (e.value >= (e.range << e.avail)) return 1;
+    const int n = __clz(e.range) - 23;
     e.range <<= n;
     e.avail -= n;
     cabac_refill(e);
     return 0;
 }
+// Exp-Golomb suffix of UEGk binarisations (9.3.2.3), bypass coded
+FI int cabac_egk(Ent &e, int k) {
+    int v = 0;
+    while (cabac_bypass(e)) {
+        v += 1 << k;
+        if (++k > 24) {
+            e.err = 4;
+            break;
+        }
+    }
+    while (k--) v += cabac_bypass(e) << k;
+    return v;
+}
 
 // ------------------------------------------------------------------ neighbour MBs
-__device__ __forceinline__ const TopInfo *mbA(const Ent &e) { return e.s->left.type != MBT_NONE ? &e.s->left : nullptr; }
-__device__ __forceinline__ const TopInfo *mbB(const Ent &e) { return e.top[e.mbx].type != MBT_NONE ? &e.top[e.mbx] : nullptr; }
+FI const TopInfo *mbA(const Ent &e) { return e.s->left.type != MBT_NONE ? &e.s->left : nullptr; }
+FI const TopInfo *mbB(const Ent &e) { return e.top[e.mbx].type != MBT_NONE ? &e.top[e.mbx] : nullptr; }
 
-// ------------------------------------------------------------------ CABAC syntax elements (9.3.2, 9.3.3.1)
-__device__ int cabac_intra_mb_type(Ent &e, int base, int islice) {
-    if (islice) {
-        const TopInfo *a = mbA(e), *b = mbB(e);
-        int inc = (a && a->type != MBT_I4x4 && a->type != MBT_I8x8) + (b && b->type != MBT_I4x4 && b->type != MBT_I8x8);
-        if (!cabac_bin(e, base + inc)) return 0;
-        base += 2;
-    } else if (!cabac_bin(e, base))
-        return 0;
-    if (cabac_terminate(e)) return 25;
-    int t = 1;
-    t += 12 * cabac_bin(e, base + 1);
-    if (cabac_bin(e, base + 2)) t += 4 + 4 * cabac_bin(e, base + 2 + islice);
-    t += 2 * cabac_bin(e, base + 3 + islice);
-    t += cabac_bin(e, base + 3 + 2 * islice);
-    return t;
-}
-__device__ int cabac_p_mb_type(Ent &e) {
-    if (!cabac_bin(e, 14)) {
-        if (!cabac_bin(e, 15)) return 3 * cabac_bin(e, 16);
-        return 2 - cabac_bin(e, 17);
-    }
-    return 5 + cabac_intra_mb_type(e, 17, 0);
-}
-__device__ int cabac_sub_mb_type(Ent &e) {
-    if (cabac_bin(e, 21)) return 0;
-    if (!cabac_bin(e, 22)) return 1;
-    return cabac_bin(e, 23) ? 2 : 3;
-}
-__device__ int cabac_cbp(Ent &e) {
-    const TopInfo *a = mbA(e), *b = mbB(e);
-    int cbp_a = a ? (a->type == MBT_IPCM ? 0x2F : a->cbp) : 0x0F;
-    int cbp_b = b ? (b->type == MBT_IPCM ? 0x2F : b->cbp) : 0x0F;
-    int cbp = 0;
-#pragma unroll
-    for (int b8 = 0; b8 < 4; b8++) {
-        int ca = (b8 & 1) ? (cbp >> (b8 - 1)) & 1 : (cbp_a >> (b8 + 1)) & 1;
-        int cb = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cbp_b >> (b8 + 2)) & 1;
-        cbp |= cabac_bin(e, 73 + (!ca) + 2 * (!cb)) << b8;
-    }
-    int ca = a && (a->type == MBT_IPCM || (a->cbp >> 4) != 0), cb = b && (b->type == MBT_IPCM || (b->cbp >> 4) != 0);
-    if (cabac_bin(e, 77 + ca + 2 * cb)) {
-        ca = a && (a->type == MBT_IPCM || (a->cbp >> 4) == 2);
-        cb = b && (b->type == MBT_IPCM || (b->cbp >> 4) == 2);
-        cbp |= (1 + cabac_bin(e, 77 + 4 + ca + 2 * cb)) << 4;
-    }
-    return cbp;
-}
-__device__ int cabac_dqp(Ent &e) {
-    int ctx = e.prev_dqp_nz ? 1 : 0, val = 0;
-    while (cabac_bin(e, 60 + ctx)) {
-        ctx = 2 + (ctx >> 1);
-        if (++val > 104) {
-            e.err = 2;
-            break;
-        }
-    }
-    return (val & 1) ? (val + 1) >> 1 : -((val + 1) >> 1);
-}
-__device__ int cabac_ref_idx(Ent &e, int bx, int by) {
-    int ra = e.s->refi_c[GI(bx - 1, by)], rb = e.s->refi_c[GI(bx, by - 1)];
-    int ctx = (ra > 0) + 2 * (rb > 0), ref = 0;
-    while (cabac_bin(e, 54 + ctx)) {
-        ctx = (ctx >> 2) + 4;
-        if (++ref > 31) {
-            e.err = 3;
-            break;
-        }
-    }
-    return ref;
-}
-__device__ int cabac_mvd(Ent &e, int comp, int bx, int by) {
-    int sum = e.s->mvd_c[GI(bx - 1, by)][comp] + e.s->mvd_c[GI(bx, by - 1)][comp];
-    int base = comp ? 47 : 40;
-    if (!cabac_bin(e, base + (sum > 2) + (sum > 32))) return 0;
-    int v = 1, ctx = base + 3;
-    while (v < 9 && cabac_bin(e, ctx)) {
-        if (v < 4) ctx++;
-        v++;
-    }
-    if (v >= 9) {
-        int k = 3;
-        while (cabac_bypass(e)) {
-            v += 1 << k;
-            if (++k > 24) {
-                e.err = 4;
-                break;
-            }
-        }
-        while (k--) v += cabac_bypass(e) << k;
-    }
-    return cabac_bypass(e) ? -v : v;
-}
-
-// residual_block_cabac 7.3.5.3.3.  CAT: 0 I16 DC, 1 I16 AC, 2 luma 4x4, 3 chroma DC, 4 chroma AC,
-// 5 luma 8x8.  Coefficients are written de-zig-zagged (raster inside the block).  Returns #non-zero.
-template <int CAT>
-__device__ int cabac_residual(Ent &e, int16_t *dst, int cbf_inc) {
-    constexpr int maxnum = CAT == 5 ? 64 : (CAT == 3 ? 4 : ((CAT == 1 || CAT == 4) ? 15 : 16));
-    constexpr int sig_off = CAT == 0 ? 0 : (CAT == 1 ? 15 : (CAT == 2 ? 29 : (CAT == 3 ? 44 : 47)));
-    constexpr int abs_off = CAT == 0 ? 0 : (CAT == 1 ? 10 : (CAT == 2 ? 20 : (CAT == 3 ? 30 : 39)));
-    constexpr int sbase = CAT == 5 ? 402 : 105 + sig_off, lbase = CAT == 5 ? 417 : 166 + sig_off;
-    constexpr int base = CAT == 5 ? 426 : 227 + abs_off;
-    constexpr int lim = CAT == 3 ? 3 : 4;
-    if (CAT != 5 && !cabac_bin(e, 85 + CAT * 4 + cbf_inc)) return 0;
+// ------------------------------------------------------------------ residual blocks
+// residual_block_cabac 7.3.5.3.3 for ctxBlockCat `cat`; coefficients are written de-zig-zagged.
+FI int cabac_residual(Ent &e, int16_t *dst, int cat, int cbf_inc) {
+    const uint16_t *cc = c_cat[cat];
+    const int maxnum = cc[0];
+    if (cat != 5 && !cabac_bin(e, cc[1] + cbf_inc)) return 0;
+    const int sbase = cc[2], lbase = cc[3], abase = cc[4], lim = cc[5];
+    const uint8_t *pm = e.s->posmap[cc[6]], *im = e.s->incmap[cc[7]];
     uint64_t sigmask = 0;
-    int n = 0, last = 0;
-    for (int i = 0; i < maxnum - 1; i++) {
-        int inc_s, inc_l;
-        if (CAT == 5)
-            inc_s = e.s->sig8[i], inc_l = e.s->last8[i];
-        else
-            inc_s = inc_l = CAT == 3 ? (i < 2 ? i : 2) : i;
+    int n = 0, i = 0;
+    for (; i < maxnum - 1; i++) {
+        const int inc_s = im[i], inc_l = cat == 5 ? e.s->lastmap[i] : inc_s;
         if (cabac_bin(e, sbase + inc_s)) {
             sigmask |= 1ull << i;
             n++;
-            if (cabac_bin(e, lbase + inc_l)) {
-                last = 1;
-                break;
-            }
+            if (cabac_bin(e, lbase + inc_l)) break;
         }
     }
-    if (!last) sigmask |= 1ull << (maxnum - 1), n++;
+    if (i == maxnum - 1) sigmask |= 1ull << i, n++;
     int eq1 = 0, gt1 = 0;
     while (sigmask) {
-        int k = 63 - __clzll(static_cast<long long>(sigmask));
+        const int k = 63 - __clzll(static_cast<long long>(sigmask));
         sigmask &= ~(1ull << k);
-        int inc0 = gt1 ? 0 : (1 + eq1 < 4 ? 1 + eq1 : 4), a;
-        if (!cabac_bin(e, base + inc0)) {
-            a = 1;
-            eq1++;
-        } else {
-            int inc = 5 + (gt1 < lim ? gt1 : lim);
+        const int inc0 = gt1 ? 0 : (eq1 < 3 ? 1 + eq1 : 4);
+        int a = 1;
+        if (cabac_bin(e, abase + inc0)) {
+            const int cx = abase + 5 + (gt1 < lim ? gt1 : lim);
             a = 2;
-            while (a < 15 && cabac_bin(e, base + inc)) a++;
-            if (a >= 15) {
-                int kk = 0;
-                while (cabac_bypass(e)) {
-                    a += 1 << kk;
-                    if (++kk > 24) {
-                        e.err = 5;
-                        break;
-                    }
-                }
-                while (kk--) a += cabac_bypass(e) << kk;
-            }
+            while (a < 15 && cabac_bin(e, cx)) a++;
+            if (a >= 15) a += cabac_egk(e, 0);
             gt1++;
-        }
-        int v = cabac_bypass(e) ? -a : a;
-        int pos;
-        if (CAT == 5)
-            pos = e.s->zz8[k];
-        else if (CAT == 3)
-            pos = k;
-        else if (CAT == 1 || CAT == 4)
-            pos = e.s->zz4[k + 1];
-        else
-            pos = e.s->zz4[k];
-        dst[pos] = static_cast<int16_t>(v);
+        } else
+            eq1++;
+        dst[pm[k]] = static_cast<int16_t>(cabac_bypass(e) ? -a : a);
     }
     return n;
 }
 
-// ------------------------------------------------------------------ CAVLC residual_block_cavlc (9.2)
-// KIND: 0 = 16 coefficients, 1 = 15 (AC, positions 1..15), 2 = chroma DC (4), 3 = 16 coefficients
-// written in scan order (CAVLC + 8x8 transform interleave)
-template <int KIND>
-__device__ int cavlc_residual(Ent &e, int16_t *dst, int nC) {
+// residual_block_cavlc 9.2.  kind: 0 = 16 coefficients, 1 = 15 (AC), 2 = chroma DC (4),
+// 3 = 16 coefficients written in scan order (CAVLC + 8x8 transform interleave)
+FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
     const DevTables *t = e.tab;
-    constexpr int maxnum = KIND == 1 ? 15 : (KIND == 2 ? 4 : 16);
+    const int maxnum = kind == 1 ? 15 : (kind == 2 ? 4 : 16);
     uint32_t w = peek32(e, e.bitpos);
     uint32_t ent;
-    if (KIND == 2)
+    if (kind == 2)
         ent = t->vlc_cdc[w >> 24];
     else if (nC < 2)
         ent = t->vlc_ct0[w >> (32 - MI_VLC_CT0_BITS)];
@@ -379,7 +274,7 @@ __device__ int cavlc_residual(Ent &e, int16_t *dst, int nC) {
         return 0;
     }
     e.bitpos += ent >> 8;
-    int total = (ent >> 2) & 31, t1s = ent & 3;
+    const int total = (ent >> 2) & 31, t1s = ent & 3;
     if (total == 0) return 0;
     if (total > maxnum) {
         e.err = 7;
@@ -387,35 +282,36 @@ __device__ int cavlc_residual(Ent &e, int16_t *dst, int nC) {
     }
     int suffix_len = (total > 10 && t1s < 3) ? 1 : 0;
     for (int i = 0; i < total; i++) {
-        if (i < t1s) {
-            e.s->lvl[i] = static_cast<int16_t>(1 - 2 * static_cast<int>(get_bit(e)));
-            continue;
+        int lv;
+        if (i < t1s)
+            lv = 1 - 2 * static_cast<int>(get_bit(e));
+        else {
+            uint32_t ww = peek32(e, e.bitpos);
+            if (ww == 0) {
+                e.err = 8;
+                return 0;
+            }
+            int prefix = __clz(ww);
+            e.bitpos += prefix + 1;
+            int code = (prefix < 15 ? prefix : 15) << suffix_len;
+            if (suffix_len > 0 || prefix >= 14) {
+                int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
+                if (size > 0) code += get_bits(e, size);
+            }
+            if (prefix >= 15 && suffix_len == 0) code += 15;
+            if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+            if (i == t1s && t1s < 3) code += 2;
+            lv = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
+            if (suffix_len == 0) suffix_len = 1;
+            int al = lv < 0 ? -lv : lv;
+            if (al > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
         }
-        uint32_t ww = peek32(e, e.bitpos);
-        if (ww == 0) {
-            e.err = 8;
-            return 0;
-        }
-        int prefix = __clz(ww);
-        e.bitpos += prefix + 1;
-        int code = (prefix < 15 ? prefix : 15) << suffix_len;
-        if (suffix_len > 0 || prefix >= 14) {
-            int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
-            if (size > 0) code += get_bits(e, size);
-        }
-        if (prefix >= 15 && suffix_len == 0) code += 15;
-        if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
-        if (i == t1s && t1s < 3) code += 2;
-        int lv = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
         e.s->lvl[i] = static_cast<int16_t>(lv);
-        if (suffix_len == 0) suffix_len = 1;
-        int al = lv < 0 ? -lv : lv;
-        if (al > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
     }
     int zeros_left = 0;
     if (total < maxnum) {
         uint32_t ww = peek32(e, e.bitpos);
-        uint32_t en = KIND == 2 ? t->vlc_cdc_tz[total - 1][ww >> 29] : t->vlc_tz[total - 1][ww >> 23];
+        uint32_t en = kind == 2 ? t->vlc_cdc_tz[total - 1][ww >> 29] : t->vlc_tz[total - 1][ww >> 23];
         if (!(en >> 8)) {
             e.err = 9;
             return 0;
@@ -428,9 +324,9 @@ __device__ int cavlc_residual(Ent &e, int16_t *dst, int nC) {
         e.err = 10;
         return 0;
     }
+    const uint8_t *pm = e.s->posmap[kind == 0 ? 0 : (kind == 1 ? 1 : 3)];
     for (int i = 0; i < total; i++) {
-        int p = (KIND == 2 || KIND == 3) ? pos : e.s->zz4[pos + (KIND == 1)];
-        dst[p] = e.s->lvl[i];
+        dst[pm[pos]] = e.s->lvl[i];
         if (i < total - 1) {
             int run = 0;
             if (zeros_left > 0) {
@@ -450,88 +346,111 @@ __device__ int cavlc_residual(Ent &e, int16_t *dst, int nC) {
     return total;
 }
 
-// ------------------------------------------------------------------ residual() 7.3.5.3
-__device__ __forceinline__ int nc_of(uint8_t a, uint8_t b) { // 9.2.1
+FI int nc_of(uint8_t a, uint8_t b) { // 9.2.1
     int av = !(a & 0x80), bv = !(b & 0x80);
     if (av && bv) return (a + b + 1) >> 1;
     return av ? a : (bv ? b : 0);
 }
-__device__ __forceinline__ int cbf_inc_of(const Ent &e, uint8_t a, uint8_t b) { // 9.3.3.1.1.9
+FI int cbf_inc_of(const Ent &e, uint8_t a, uint8_t b) { // 9.3.3.1.1.9
     int ci = MB_IS_INTRA(e.cur_type);
     int ca = (a & 0x80) ? ci : (a != 0), cb = (b & 0x80) ? ci : (b != 0);
     return ca + 2 * cb;
 }
-__device__ __forceinline__ int cbf_inc_dc(const Ent &e, int bit) {
-    const TopInfo *a = mbA(e), *b = mbB(e);
-    int ci = MB_IS_INTRA(e.cur_type);
-    return (a ? (a->cbf_dc >> bit) & 1 : ci) + 2 * (b ? (b->cbf_dc >> bit) & 1 : ci);
-}
 
-__device__ void parse_residual(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
+// residual() 7.3.5.3 as ONE loop over a block schedule:
+//   0: Intra16x16 DC | 1..16: luma blocks (z-order) | 17,18: chroma DC | 19..26: chroma AC
+FI void parse_residual(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
     Shared *s = e.s;
-    const int i16 = e.cur_type == MBT_I16x16;
+    const int i16 = e.cur_type == MBT_I16x16, cabac = e.cabac;
     int nzmask = 0;
-    if (i16) {
-        int n = e.cabac ? cabac_residual<0>(e, s->coef + MI_COEF_I16DC, cbf_inc_dc(e, 0))
-                        : cavlc_residual<0>(e, s->coef + MI_COEF_I16DC, nc_of(s->nnz_c[GI(-1, 0)], s->nnz_c[GI(0, -1)]));
-        if (n) s->cur_cbf_dc |= 1;
-    }
-    for (int b8 = 0; b8 < 4; b8++) {
-        if (!((cbp_luma >> b8) & 1)) continue;
-        ensure(e);
-        int bx0 = (b8 & 1) * 2, by0 = (b8 >> 1) * 2;
-        if (t8x8 && e.cabac) {
-            int n = cabac_residual<5>(e, s->coef + b8 * 64, -1);
-            s->nnz_c[GI(bx0, by0)] = s->nnz_c[GI(bx0 + 1, by0)] = s->nnz_c[GI(bx0, by0 + 1)] = s->nnz_c[GI(bx0 + 1, by0 + 1)] = static_cast<uint8_t>(n);
-            if (n) nzmask |= 0x33 << (by0 * 4 + bx0);
-            continue;
-        }
-        int any = 0;
-        for (int b4 = 0; b4 < 4; b4++) {
-            int bx = bx0 + (b4 & 1), by = by0 + (b4 >> 1), r = by * 4 + bx, n;
-            uint8_t na = s->nnz_c[GI(bx - 1, by)], nb = s->nnz_c[GI(bx, by - 1)];
-            if (t8x8) { // CAVLC + 8x8 transform: 4x4 "block" b4 carries coefficients 4*i + b4 of the 8x8 scan (7.3.5.3.2)
+    const TopInfo *a = mbA(e), *b = mbB(e);
+    const int ci = MB_IS_INTRA(e.cur_type);
+    for (int step = 0; step < 27; step++) {
+        int cat, kind, bx = 0, by = 0;
+        uint8_t na, nb;
+        int16_t *dst;
+        if (step == 0) {
+            if (!i16) continue;
+            cat = 0, kind = 0;
+            dst = s->coef + MI_COEF_I16DC;
+            if (cabac) { // neighbours' Intra16x16 DC coded_block_flag
+                na = a ? (a->cbf_dc & 1) : 0x80, nb = b ? (b->cbf_dc & 1) : 0x80;
+            } else
+                na = s->nnz_c[GI(-1, 0)], nb = s->nnz_c[GI(0, -1)];
+        } else if (step <= 16) {
+            const int idx = step - 1, b8 = idx >> 2;
+            if (!((cbp_luma >> b8) & 1)) {
+                step += 3; // whole 8x8 uncoded
+                continue;
+            }
+            bx = (idx & 1) + 2 * ((idx >> 2) & 1), by = ((idx >> 1) & 1) + 2 * (idx >> 3);
+            if ((idx & 3) == 0) ensure(e);
+            na = s->nnz_c[GI(bx - 1, by)], nb = s->nnz_c[GI(bx, by - 1)];
+            if (t8x8 && cabac) {
+                cat = 5, kind = 0;
+                dst = s->coef + b8 * 64;
+            } else if (t8x8) {
+                cat = 2, kind = 3;
+                dst = s->tmp16;
                 for (int i = 0; i < 16; i++) s->tmp16[i] = 0;
-                n = cavlc_residual<3>(e, s->tmp16, nc_of(na, nb));
-                for (int i = 0; i < 16; i++) {
-                    int16_t v = s->tmp16[i];
-                    if (v) s->coef[b8 * 64 + s->zz8[4 * i + b4]] = v;
-                }
-            } else if (i16)
-                n = e.cabac ? cabac_residual<1>(e, s->coef + r * 16, cbf_inc_of(e, na, nb)) : cavlc_residual<1>(e, s->coef + r * 16, nc_of(na, nb));
-            else
-                n = e.cabac ? cabac_residual<2>(e, s->coef + r * 16, cbf_inc_of(e, na, nb)) : cavlc_residual<0>(e, s->coef + r * 16, nc_of(na, nb));
-            s->nnz_c[GI(bx, by)] = static_cast<uint8_t>(n);
-            if (n) nzmask |= 1 << r, any = 1;
+            } else {
+                cat = i16 ? 1 : 2, kind = i16 ? 1 : 0;
+                dst = s->coef + (by * 4 + bx) * 16;
+            }
+        } else if (step <= 18) {
+            if (!cbp_chroma) break;
+            const int c = step - 17;
+            if (c == 0) ensure(e);
+            cat = 3, kind = 2;
+            dst = s->coef + MI_COEF_CDC + 4 * c;
+            na = a ? ((a->cbf_dc >> (1 + c)) & 1) : 0x80, nb = b ? ((b->cbf_dc >> (1 + c)) & 1) : 0x80;
+        } else {
+            if (!(cbp_chroma & 2)) break;
+            const int j = step - 19, c = j >> 2, b4 = j & 3;
+            bx = b4 & 1, by = b4 >> 1;
+            cat = 4, kind = 1;
+            dst = s->coef + MI_COEF_CAC + j * 16;
+            na = s->nnzc_c[c][(by + 1) * 3 + bx], nb = s->nnzc_c[c][by * 3 + bx + 1];
         }
-        if (t8x8 && any) nzmask |= 0x33 << (by0 * 4 + bx0);
+        int n;
+        if (cabac) {
+            const int ca = (na & 0x80) ? ci : (na != 0), cb = (nb & 0x80) ? ci : (nb != 0);
+            n = cabac_residual(e, dst, cat, ca + 2 * cb);
+        } else
+            n = cavlc_residual(e, dst, kind, kind == 2 ? -1 : nc_of(na, nb));
+        // ---- bookkeeping per block kind ----
+        if (step == 0) {
+            if (n) s->cur_cbf_dc |= 1;
+        } else if (step <= 16) {
+            const int idx = step - 1, b8 = idx >> 2, r = by * 4 + bx;
+            if (cat == 5) {
+                s->nnz_c[GI(bx, by)] = s->nnz_c[GI(bx + 1, by)] = s->nnz_c[GI(bx, by + 1)] = s->nnz_c[GI(bx + 1, by + 1)] = static_cast<uint8_t>(n);
+                if (n) nzmask |= 0x33 << r;
+                step += 3;
+            } else {
+                if (kind == 3) // CAVLC + 8x8 transform: 4x4 "block" b4 carries coefficients 4*i + b4 of the 8x8 scan (7.3.5.3.2)
+                    for (int i = 0; i < 16; i++) {
+                        int16_t v = s->tmp16[i];
+                        if (v) s->coef[b8 * 64 + s->posmap[2][4 * i + (idx & 3)]] = v;
+                    }
+                s->nnz_c[GI(bx, by)] = static_cast<uint8_t>(n);
+                if (n) nzmask |= t8x8 ? (0x33 << ((by & 2) * 4 + (bx & 2))) : (1 << r);
+            }
+        } else if (step <= 18) {
+            if (n) s->cur_cbf_dc |= static_cast<uint8_t>(2 << (step - 17));
+        } else
+            s->nnzc_c[(step - 19) >> 2][(by + 1) * 3 + bx + 1] = static_cast<uint8_t>(n);
     }
     s->rec.nzmask = static_cast<uint16_t>(nzmask);
-    if (cbp_chroma) {
-        ensure(e);
-        for (int c = 0; c < 2; c++) {
-            int n = e.cabac ? cabac_residual<3>(e, s->coef + MI_COEF_CDC + 4 * c, cbf_inc_dc(e, 1 + c)) : cavlc_residual<2>(e, s->coef + MI_COEF_CDC + 4 * c, -1);
-            if (n) s->cur_cbf_dc |= static_cast<uint8_t>(2 << c);
-        }
-    }
-    if (cbp_chroma & 2)
-        for (int c = 0; c < 2; c++)
-            for (int b4 = 0; b4 < 4; b4++) {
-                int cx = b4 & 1, cy = b4 >> 1;
-                uint8_t na = s->nnzc_c[c][(cy + 1) * 3 + cx], nb = s->nnzc_c[c][cy * 3 + cx + 1];
-                int16_t *dst = s->coef + MI_COEF_CAC + (c * 4 + b4) * 16;
-                int n = e.cabac ? cabac_residual<4>(e, dst, cbf_inc_of(e, na, nb)) : cavlc_residual<1>(e, dst, nc_of(na, nb));
-                s->nnzc_c[c][(cy + 1) * 3 + cx + 1] = static_cast<uint8_t>(n);
-            }
 }
 
 // ------------------------------------------------------------------ motion vector prediction 8.4.1.3
-__device__ __forceinline__ int median3(int a, int b, int c) {
+FI int median3(int a, int b, int c) {
     int mn = a < b ? a : b, mx = a < b ? b : a;
     return c < mn ? mn : (c > mx ? mx : c);
 }
 // shape: 0 median, 1/2 = 16x8 upper/lower, 3/4 = 8x16 left/right
-__device__ void predict_mv(const Ent &e, int bx, int by, int w, int ref, int shape, int &px, int &py) {
+FI void predict_mv(const Ent &e, int bx, int by, int w, int ref, int shape, int &px, int &py) {
     const Shared *s = e.s;
     int ia = GI(bx - 1, by), ib = GI(bx, by - 1), ic = GI(bx + w, by - 1);
     int ra = s->ref_c[ia], rb = s->ref_c[ib], rc = s->ref_c[ic];
@@ -562,7 +481,7 @@ __device__ void predict_mv(const Ent &e, int bx, int by, int w, int ref, int sha
     px = median3(ax, bxv, cx);
     py = median3(ay, byv, cy);
 }
-__device__ void set_part(Ent &e, int bx, int by, int w, int h, int ref, int mvx, int mvy, int dx, int dy) {
+FI void set_part(Ent &e, int bx, int by, int w, int h, int ref, int mvx, int mvy, int dx, int dy) {
     Shared *s = e.s;
     uint8_t ax = static_cast<uint8_t>(min(abs(dx), 255)), ay = static_cast<uint8_t>(min(abs(dy), 255));
     for (int y = by; y < by + h; y++)
@@ -573,39 +492,10 @@ __device__ void set_part(Ent &e, int bx, int by, int w, int h, int ref, int mvx,
             s->mvd_c[g][0] = ax, s->mvd_c[g][1] = ay;
         }
 }
-__device__ void do_part(Ent &e, int bx, int by, int w, int h, int ref, int shape) {
-    int dx, dy, px, py;
-    if (e.cabac) {
-        dx = cabac_mvd(e, 0, bx, by);
-        dy = cabac_mvd(e, 1, bx, by);
-    } else {
-        dx = get_se(e);
-        dy = get_se(e);
-    }
-    predict_mv(e, bx, by, w, ref, shape, px, py);
-    set_part(e, bx, by, w, h, ref, px + dx, py + dy, dx, dy);
-}
-// ref_idx_l0 of one partition; also records it for the ctxIdxInc of later partitions and for the MbRec
-__device__ int read_ref_idx(Ent &e, int bx, int by, int w, int h) {
-    int nref = e.sd->num_ref_idx_active, ref;
-    if (nref <= 1)
-        ref = 0;
-    else if (e.cabac)
-        ref = cabac_ref_idx(e, bx, by);
-    else if (nref == 2)
-        ref = !get_bit(e);
-    else
-        ref = static_cast<int>(get_ue(e));
-    if (ref >= nref || ref >= MI_MAX_REFS) e.err = 13, ref = 0;
-    for (int y = by; y < by + h; y++)
-        for (int x = bx; x < bx + w; x++) e.s->refi_c[GI(x, y)] = static_cast<int8_t>(ref);
-    for (int y = by; y < by + h; y += 2)
-        for (int x = bx; x < bx + w; x += 2) e.s->refs8[(y >> 1) * 2 + (x >> 1)] = static_cast<int8_t>(ref);
-    return ref;
-}
+#define PART(bx, by, w, h, shape) static_cast<uint16_t>((bx) | ((by) << 2) | (((w)-1) << 4) | (((h)-1) << 6) | ((shape) << 8))
 
 // ------------------------------------------------------------------ per-MB neighbour caches
-__device__ void fill_caches(Ent &e) {
+FI void fill_caches(Ent &e) {
     Shared *s = e.s;
     const TopInfo *a = mbA(e), *b = mbB(e);
     const TopInfo *c = (e.mbx + 1 < e.wmb && e.top[e.mbx + 1].type != MBT_NONE) ? &e.top[e.mbx + 1] : nullptr;
@@ -671,19 +561,13 @@ __device__ void fill_caches(Ent &e) {
     __syncthreads();
 }
 
-__device__ __forceinline__ int pred_intra_mode(const Ent &e, int bx, int by) { // 8.3.1.1 / 8.3.2.1
-    int a = e.s->ipm_c[GI(bx - 1, by)], b = e.s->ipm_c[GI(bx, by - 1)];
-    if (a < -1 || b < -1) return 2; // dcPredModePredictedFlag
-    return a < b ? a : b;
-}
-
 // ------------------------------------------------------------------ macroblock_layer() 7.3.5
-__device__ void decode_mb(Ent &e, int skipped) {
+FI void decode_mb(Ent &e, int skipped) {
     Shared *s = e.s;
     MbRec &r = s->rec;
     const int cabac = e.cabac, islice = e.islice;
     int cbp_luma = 0, cbp_chroma = 0, t8x8 = 0, i16mode = 0, chroma_mode = 0, has_coef = 0;
-    int type;
+    int type, raw = 0, nparts = 0;
     const TopInfo *a = mbA(e), *b = mbB(e);
     r.nzmask = 0;
     if (skipped) {
@@ -698,8 +582,37 @@ __device__ void decode_mb(Ent &e, int skipped) {
         s->refs8[0] = s->refs8[1] = s->refs8[2] = s->refs8[3] = 0;
         e.prev_dqp_nz = 0;
     } else {
-        int raw = cabac ? (islice ? cabac_intra_mb_type(e, 3, 1) : cabac_p_mb_type(e)) : static_cast<int>(get_ue(e));
-        int it = islice ? raw : raw - 5;
+        // ---- mb_type (Tables 9-36 / 9-37) ----
+        int intra_prefix = 1; // in P slices: bin 0 of mb_type says "intra"
+        if (cabac) {
+            if (!islice) {
+                intra_prefix = cabac_bin(e, 14);
+                if (!intra_prefix) raw = cabac_bin(e, 15) ? 2 - cabac_bin(e, 17) : 3 * cabac_bin(e, 16);
+            }
+            if (intra_prefix) {
+                // I-slice bin string; `base` 3 with neighbour-dependent first bin, or the suffix at 17
+                int base = islice ? 3 : 17, it = 0, first;
+                if (islice) {
+                    int inc = (a && a->type != MBT_I4x4 && a->type != MBT_I8x8) + (b && b->type != MBT_I4x4 && b->type != MBT_I8x8);
+                    first = cabac_bin(e, base + inc);
+                    base += 2;
+                } else
+                    first = cabac_bin(e, base);
+                if (first) {
+                    if (cabac_terminate(e))
+                        it = 25;
+                    else {
+                        it = 1 + 12 * cabac_bin(e, base + 1);
+                        if (cabac_bin(e, base + 2)) it += 4 + 4 * cabac_bin(e, base + 2 + islice);
+                        it += 2 * cabac_bin(e, base + 3 + islice);
+                        it += cabac_bin(e, base + 3 + 2 * islice);
+                    }
+                }
+                raw = islice ? it : it + 5;
+            }
+        } else
+            raw = static_cast<int>(get_ue(e));
+        const int it = islice ? raw : raw - 5;
         if (!islice && raw < 5)
             type = raw == 0 ? MBT_P16x16 : (raw == 1 ? MBT_P16x8 : (raw == 2 ? MBT_P8x16 : MBT_P8x8));
         else if (it == 0)
@@ -731,87 +644,127 @@ __device__ void decode_mb(Ent &e, int skipped) {
             e.bitpos += 384 * 8;
             ensure(e);
             if (cabac) cabac_start(e);
-            for (int i = 0; i < 16; i++) s->nnz_c[GI(i & 3, i >> 2)] = 16;
-            for (int c = 0; c < 2; c++)
-                for (int i = 0; i < 4; i++) s->nnzc_c[c][((i >> 1) + 1) * 3 + (i & 1) + 1] = 16;
-            for (int i = 0; i < 16; i++) s->ref_c[GI(i & 3, i >> 2)] = -1;
+            for (int i = 0; i < 16; i++) s->nnz_c[GI(i & 3, i >> 2)] = 16, s->ref_c[GI(i & 3, i >> 2)] = -1;
+            for (int i = 0; i < 8; i++) s->nnzc_c[i >> 2][(((i >> 1) & 1) + 1) * 3 + (i & 1) + 1] = 16;
             s->cur_cbf_dc = 7;
             r.nzmask = 0xFFFF;
             cbp_luma = 15, cbp_chroma = 2;
             has_coef = 1;
             e.prev_dqp_nz = 0;
         } else {
-            if (type == MBT_P8x8) {
-                for (int i = 0; i < 4; i++) {
-                    int st = cabac ? cabac_sub_mb_type(e) : static_cast<int>(get_ue(e));
-                    if (st > 3) e.err = 21, st = 0;
-                    s->sub_type[i] = static_cast<int8_t>(st);
-                }
-                for (int i = 0; i < 4; i++) {
-                    if (raw == 4) {
-                        s->refs8[i] = 0;
-                        continue;
-                    }
-                    read_ref_idx(e, (i & 1) * 2, (i >> 1) * 2, 2, 2);
-                }
-                for (int i = 0; i < 4; i++) {
-                    int bx = (i & 1) * 2, by = (i >> 1) * 2, ref = s->refs8[i];
-                    switch (s->sub_type[i]) {
-                    case 0: do_part(e, bx, by, 2, 2, ref, 0); break;
-                    case 1:
-                        do_part(e, bx, by, 2, 1, ref, 0);
-                        do_part(e, bx, by + 1, 2, 1, ref, 0);
-                        break;
-                    case 2:
-                        do_part(e, bx, by, 1, 2, ref, 0);
-                        do_part(e, bx + 1, by, 1, 2, ref, 0);
-                        break;
-                    default:
-                        do_part(e, bx, by, 1, 1, ref, 0);
-                        do_part(e, bx + 1, by, 1, 1, ref, 0);
-                        do_part(e, bx, by + 1, 1, 1, ref, 0);
-                        do_part(e, bx + 1, by + 1, 1, 1, ref, 0);
+            if (MB_IS_INTER(type)) {
+                // ---- partition schedule (Tables 7-13, 7-17) ----
+                int nref_parts;
+                if (type == MBT_P16x16) {
+                    s->parts[0] = PART(0, 0, 4, 4, 0);
+                    nparts = nref_parts = 1;
+                } else if (type == MBT_P16x8) {
+                    s->parts[0] = PART(0, 0, 4, 2, 1), s->parts[1] = PART(0, 2, 4, 2, 2);
+                    nparts = nref_parts = 2;
+                } else if (type == MBT_P8x16) {
+                    s->parts[0] = PART(0, 0, 2, 4, 3), s->parts[1] = PART(2, 0, 2, 4, 4);
+                    nparts = nref_parts = 2;
+                } else {
+                    nref_parts = 4;
+                    for (int i = 0; i < 4; i++) {
+                        int st;
+                        if (cabac) // Table 9-38
+                            st = cabac_bin(e, 21) ? 0 : (!cabac_bin(e, 22) ? 1 : (cabac_bin(e, 23) ? 2 : 3));
+                        else
+                            st = static_cast<int>(get_ue(e));
+                        if (st > 3) e.err = 21, st = 0;
+                        s->sub_type[i] = static_cast<int8_t>(st);
+                        const int bx = (i & 1) * 2, by = (i >> 1) * 2;
+                        const int sw = (st == 0 || st == 1) ? 2 : 1, sh = (st == 0 || st == 2) ? 2 : 1;
+                        for (int yy = 0; yy < 2; yy += sh)
+                            for (int xx = 0; xx < 2; xx += sw) s->parts[nparts++] = PART(bx + xx, by + yy, sw, sh, 0);
                     }
                 }
-            } else if (type == MBT_P16x16) {
-                int ref = read_ref_idx(e, 0, 0, 4, 4);
-                do_part(e, 0, 0, 4, 4, ref, 0);
-            } else if (type == MBT_P16x8) {
-                int r0 = read_ref_idx(e, 0, 0, 4, 2);
-                int r1 = read_ref_idx(e, 0, 2, 4, 2);
-                do_part(e, 0, 0, 4, 2, r0, 1);
-                do_part(e, 0, 2, 4, 2, r1, 2);
-            } else if (type == MBT_P8x16) {
-                int r0 = read_ref_idx(e, 0, 0, 2, 4);
-                int r1 = read_ref_idx(e, 2, 0, 2, 4);
-                do_part(e, 0, 0, 2, 4, r0, 3);
-                do_part(e, 2, 0, 2, 4, r1, 4);
+                // ---- ref_idx_l0 per macroblock partition (7.3.5.1 / 7.3.5.2) ----
+                const int nref = e.sd->num_ref_idx_active;
+                for (int i = 0; i < nref_parts; i++) {
+                    int bx, by, w, h;
+                    if (type == MBT_P8x8)
+                        bx = (i & 1) * 2, by = (i >> 1) * 2, w = 2, h = 2;
+                    else {
+                        const int p = s->parts[i];
+                        bx = p & 3, by = (p >> 2) & 3, w = ((p >> 4) & 3) + 1, h = ((p >> 6) & 3) + 1;
+                    }
+                    int ref = 0;
+                    if (nref > 1 && raw != 4) {
+                        if (cabac) { // 9.3.3.1.1.6
+                            int ctx = (s->refi_c[GI(bx - 1, by)] > 0) + 2 * (s->refi_c[GI(bx, by - 1)] > 0);
+                            while (cabac_bin(e, 54 + ctx)) {
+                                ctx = (ctx >> 2) + 4;
+                                if (++ref > 31) {
+                                    e.err = 3;
+                                    break;
+                                }
+                            }
+                        } else
+                            ref = nref == 2 ? !get_bit(e) : static_cast<int>(get_ue(e));
+                        if (ref >= nref || ref >= MI_MAX_REFS) e.err = 13, ref = 0;
+                    }
+                    for (int y = by; y < by + h; y++)
+                        for (int x = bx; x < bx + w; x++) s->refi_c[GI(x, y)] = static_cast<int8_t>(ref);
+                    for (int y = by; y < by + h; y += 2)
+                        for (int x = bx; x < bx + w; x += 2) s->refs8[(y >> 1) * 2 + (x >> 1)] = static_cast<int8_t>(ref);
+                }
+                // ---- mvd_l0 + prediction per (sub-)partition ----
+                for (int i = 0; i < nparts; i++) {
+                    const int p = s->parts[i];
+                    const int bx = p & 3, by = (p >> 2) & 3, w = ((p >> 4) & 3) + 1, h = ((p >> 6) & 3) + 1, shape = p >> 8;
+                    const int ref = s->refs8[(by >> 1) * 2 + (bx >> 1)];
+                    int d[2];
+                    for (int comp = 0; comp < 2; comp++) {
+                        int v;
+                        if (cabac) { // UEG3, uCoff 9, signed (9.3.2.3, 9.3.3.1.1.7)
+                            const int sum = s->mvd_c[GI(bx - 1, by)][comp] + s->mvd_c[GI(bx, by - 1)][comp];
+                            const int base = comp ? 47 : 40;
+                            v = 0;
+                            if (cabac_bin(e, base + (sum > 2) + (sum > 32))) {
+                                int ctx = base + 3;
+                                v = 1;
+                                while (v < 9 && cabac_bin(e, ctx)) {
+                                    if (v < 4) ctx++;
+                                    v++;
+                                }
+                                if (v >= 9) v += cabac_egk(e, 3);
+                                if (cabac_bypass(e)) v = -v;
+                            }
+                        } else
+                            v = get_se(e);
+                        d[comp] = v;
+                    }
+                    int px, py;
+                    predict_mv(e, bx, by, w, ref, shape, px, py);
+                    set_part(e, bx, by, w, h, ref, px + d[0], py + d[1], d[0], d[1]);
+                }
             } else {
-                // intra: transform_size_8x8_flag, prediction modes, intra_chroma_pred_mode (7.3.5, 7.3.5.1)
+                // ---- intra: transform_size_8x8_flag, prediction modes, intra_chroma_pred_mode ----
                 if (type == MBT_I4x4 && e.pd->t8x8_mode) {
                     t8x8 = cabac ? cabac_bin(e, 399 + (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
                     if (t8x8) type = MBT_I8x8, e.cur_type = type;
                 }
                 if (type == MBT_I4x4 || type == MBT_I8x8) {
-                    int n = type == MBT_I8x8 ? 4 : 16;
+                    const int n = type == MBT_I8x8 ? 4 : 16;
                     for (int i = 0; i < n; i++) {
                         int bx, by;
                         if (n == 4)
                             bx = (i & 1) * 2, by = (i >> 1) * 2;
                         else
                             bx = (i & 1) + 2 * ((i >> 2) & 1), by = ((i >> 1) & 1) + 2 * (i >> 3);
-                        int pred = pred_intra_mode(e, bx, by), mode;
-                        int flag = cabac ? cabac_bin(e, 68) : static_cast<int>(get_bit(e));
-                        if (flag)
-                            mode = pred;
-                        else {
-                            int rem;
-                            if (cabac) {
-                                rem = cabac_bin(e, 69);
-                                rem |= cabac_bin(e, 69) << 1;
-                                rem |= cabac_bin(e, 69) << 2;
-                            } else
-                                rem = static_cast<int>(get_bits(e, 3));
+                        const int pa = s->ipm_c[GI(bx - 1, by)], pb = s->ipm_c[GI(bx, by - 1)];
+                        const int pred = (pa < -1 || pb < -1) ? 2 : (pa < pb ? pa : pb); // 8.3.1.1: dcPredModePredictedFlag
+                        int mode = pred;
+                        if (cabac) {
+                            if (!cabac_bin(e, 68)) {
+                                int rem = 0;
+                                for (int k = 0; k < 3; k++) rem |= cabac_bin(e, 69) << k;
+                                mode = rem < pred ? rem : rem + 1;
+                            }
+                        } else if (!get_bit(e)) {
+                            int rem = static_cast<int>(get_bits(e, 3));
                             mode = rem < pred ? rem : rem + 1;
                         }
                         s->ipm_c[GI(bx, by)] = static_cast<int8_t>(mode);
@@ -821,23 +774,36 @@ __device__ void decode_mb(Ent &e, int skipped) {
                 if (cabac) {
                     int inc = (a && MB_IS_INTRA(a->type) && a->type != MBT_IPCM && a->chroma_mode != 0) +
                               (b && MB_IS_INTRA(b->type) && b->type != MBT_IPCM && b->chroma_mode != 0);
-                    if (!cabac_bin(e, 64 + inc))
-                        chroma_mode = 0;
-                    else if (!cabac_bin(e, 67))
+                    chroma_mode = 0;
+                    if (cabac_bin(e, 64 + inc)) {
                         chroma_mode = 1;
-                    else
-                        chroma_mode = cabac_bin(e, 67) ? 3 : 2;
+                        while (chroma_mode < 3 && cabac_bin(e, 67)) chroma_mode++;
+                    }
                 } else {
                     chroma_mode = static_cast<int>(get_ue(e));
                     if (chroma_mode > 3) e.err = 22, chroma_mode = 0;
                 }
                 for (int i = 0; i < 16; i++) s->ref_c[GI(i & 3, i >> 2)] = -1;
             }
+            // ---- coded_block_pattern ----
             if (type != MBT_I16x16) {
                 int cbp;
-                if (cabac)
-                    cbp = cabac_cbp(e);
-                else {
+                if (cabac) { // 9.3.3.1.1.4
+                    const int cbp_a = a ? (a->type == MBT_IPCM ? 0x2F : a->cbp) : 0x0F;
+                    const int cbp_b = b ? (b->type == MBT_IPCM ? 0x2F : b->cbp) : 0x0F;
+                    cbp = 0;
+                    for (int b8 = 0; b8 < 4; b8++) {
+                        int ca = (b8 & 1) ? (cbp >> (b8 - 1)) & 1 : (cbp_a >> (b8 + 1)) & 1;
+                        int cb = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cbp_b >> (b8 + 2)) & 1;
+                        cbp |= cabac_bin(e, 73 + (!ca) + 2 * (!cb)) << b8;
+                    }
+                    int ca = a && (a->type == MBT_IPCM || (a->cbp >> 4) != 0), cb = b && (b->type == MBT_IPCM || (b->cbp >> 4) != 0);
+                    if (cabac_bin(e, 77 + ca + 2 * cb)) {
+                        ca = a && (a->type == MBT_IPCM || (a->cbp >> 4) == 2);
+                        cb = b && (b->type == MBT_IPCM || (b->cbp >> 4) == 2);
+                        cbp |= (1 + cabac_bin(e, 77 + 4 + ca + 2 * cb)) << 4;
+                    }
+                } else {
                     uint32_t k = get_ue(e);
                     if (k > 47) e.err = 23, k = 0;
                     cbp = MB_IS_INTRA(type) ? e.tab->me_intra[k] : e.tab->me_inter[k];
@@ -850,8 +816,21 @@ __device__ void decode_mb(Ent &e, int skipped) {
                     if (all8) t8x8 = cabac ? cabac_bin(e, 399 + (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
                 }
             }
+            // ---- mb_qp_delta + residual ----
             if (cbp_luma || cbp_chroma || type == MBT_I16x16) {
-                int dqp = cabac ? cabac_dqp(e) : get_se(e);
+                int dqp;
+                if (cabac) { // 9.3.2.7 / 9.3.3.1.1.5
+                    int ctx = e.prev_dqp_nz ? 1 : 0, val = 0;
+                    while (cabac_bin(e, 60 + ctx)) {
+                        ctx = 2 + (ctx >> 1);
+                        if (++val > 104) {
+                            e.err = 2;
+                            break;
+                        }
+                    }
+                    dqp = (val & 1) ? (val + 1) >> 1 : -((val + 1) >> 1);
+                } else
+                    dqp = get_se(e);
                 if (dqp < -26 || dqp > 25) e.err = 24, dqp = 0;
                 e.prev_dqp_nz = dqp != 0;
                 e.qp = (e.qp + dqp + 52) % 52;
@@ -930,9 +909,8 @@ __device__ void decode_mb(Ent &e, int skipped) {
         dst->nnz[4 + cpl * 2 + k] = is_left ? s->nnzc_c[cpl][(k + 1) * 3 + 2] : s->nnzc_c[cpl][2 * 3 + k + 1];
     }
     const uint64_t mbi = e.pd->mb_base + static_cast<uint64_t>(e.mby) * e.wmb + e.mbx;
-    if (l >= 32) { // MbRec: 128 bytes = 32 dwords, lanes 32..63
+    if (l >= 32) // MbRec: 128 bytes = 32 dwords, lanes 32..63
         reinterpret_cast<uint32_t *>(e.mbrec + mbi)[l - 32] = reinterpret_cast<const uint32_t *>(&r)[l - 32];
-    }
     if (has_coef) { // 832 bytes = 52 x 16 B
         if (l < MI_COEF_PER_MB * 2 / 16) reinterpret_cast<uint4 *>(e.coefs + mbi * MI_COEF_PER_MB)[l] = reinterpret_cast<const uint4 *>(s->coef)[l];
     }
@@ -965,11 +943,22 @@ extern "C" __global__ void __launch_bounds__(64) k_entropy(const SliceDesc *slic
     e.range = 510, e.value = 0, e.avail = 0;
     e.mbx = e.mby = 0, e.cur_type = 0;
     const int l = LANE;
-    // tables -> LDS
-    for (int i = l; i < 256; i += 64) sh.range_lps[i] = (&tab->range_lps[0][0])[i];
-    sh.trans_lps[l] = tab->trans_lps[l];
-    sh.zz8[l] = tab->zigzag8[l], sh.sig8[l] = tab->sig8x8[l], sh.last8[l] = tab->last8x8[l];
-    if (l < 16) sh.zz4[l] = tab->zigzag4[l];
+    // ---- tables -> LDS ----
+    for (int st = l; st < 128; st += 64) { // merged Table 9-44 / 9-45 entry per (pStateIdx, valMPS)
+        const int p = st >> 1, mps = st & 1;
+        const uint8_t *rl = tab->range_lps[p];
+        const int pl = tab->trans_lps[p], pm = p < 62 ? p + 1 : p;
+        const int next_lps = (pl << 1) | (p == 0 ? mps ^ 1 : mps), next_mps = (pm << 1) | mps;
+        sh.lps[st] = make_uint2(rl[0] | (rl[1] << 8) | (rl[2] << 16) | (static_cast<uint32_t>(rl[3]) << 24), next_mps | (next_lps << 8));
+    }
+    sh.posmap[0][l] = tab->zigzag4[l & 15];
+    sh.posmap[1][l] = tab->zigzag4[(l + 1) & 15];
+    sh.posmap[2][l] = tab->zigzag8[l];
+    sh.posmap[3][l] = static_cast<uint8_t>(l);
+    sh.incmap[0][l] = static_cast<uint8_t>(l);
+    sh.incmap[1][l] = static_cast<uint8_t>(l < 2 ? l : 2);
+    sh.incmap[2][l] = tab->sig8x8[l];
+    sh.lastmap[l] = tab->last8x8[l];
     {
         int set = e.islice ? 0 : 1 + e.sd->cabac_init_idc;
         const uint8_t *src = tab->ctx_init[set][e.sd->slice_qp];
@@ -989,6 +978,7 @@ extern "C" __global__ void __launch_bounds__(64) k_entropy(const SliceDesc *slic
     const int total = e.wmb * e.hmb;
     const uint32_t stop_bit = e.sd->stop_bit;
     int addr = static_cast<int>(e.sd->first_mb);
+    e.mbx = addr % e.wmb, e.mby = addr / e.wmb;
     int more = 1, skip_state = 0 /* 0: read mb_skip_run, 1: inside a run, 2: coded MB follows a run */, pending = 0;
     int n_mbs = 0;
     while (more && !e.err) {
@@ -996,7 +986,6 @@ extern "C" __global__ void __launch_bounds__(64) k_entropy(const SliceDesc *slic
             e.err = 30;
             break;
         }
-        e.mbx = addr % e.wmb, e.mby = addr / e.wmb;
         if (e.mbx == 0) { // new MB row: no left / top-left neighbour
             if (l < 12) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
             __syncthreads();
@@ -1024,18 +1013,17 @@ extern "C" __global__ void __launch_bounds__(64) k_entropy(const SliceDesc *slic
         n_mbs++;
         if (e.cabac)
             more = !cabac_terminate(e);
-        else {
-            if (skipped) {
-                if (pending == 0) {
-                    more = e.bitpos < stop_bit;
-                    skip_state = 2;
-                }
-            } else {
+        else if (skipped) {
+            if (pending == 0) {
                 more = e.bitpos < stop_bit;
-                skip_state = 0;
+                skip_state = 2;
             }
+        } else {
+            more = e.bitpos < stop_bit;
+            skip_state = 0;
         }
         addr++;
+        if (++e.mbx == e.wmb) e.mbx = 0, e.mby++;
     }
     if (l == 0) {
         status[2 * blockIdx.x] = static_cast<uint32_t>(e.err);

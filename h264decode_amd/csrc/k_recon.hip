@@ -325,9 +325,11 @@ struct IntraWave {
     uint8_t tile[17][28];     // luma: row 0 = samples above, column 0 = samples to the left; 24 columns to the right for top-right
     uint8_t tile_c[2][9][12]; // chroma
     int16_t fe[2][32];        // Intra8x8 filtered reference samples: [0] top p'[-1..15] at index x+1, [1] left p'[-1..7] at index y+1
+    MbRec rec;                // LDS copy of the current macroblock record
 };
 struct IntraShared {
     IntraWave w[MI_INTRA_WAVES];
+    ScalingSet sc; // LevelScale tables of the picture
     int prog[320]; // macroblocks finished per row
 };
 
@@ -612,22 +614,37 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
     uint8_t *py = reinterpret_cast<uint8_t *>(pool->base) + static_cast<size_t>(pd->slot) * pool->slot_bytes;
     uint8_t *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
     for (int i = tid; i < 320; i += MI_INTRA_WAVES * 64) sh.prog[i] = 0;
+    { // LevelScale tables of this picture's PPS -> LDS (2688 bytes)
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tab->scaling[pd->scaling_set]);
+        for (int i = tid; i < static_cast<int>(sizeof(ScalingSet) / 4); i += MI_INTRA_WAVES * 64) reinterpret_cast<uint32_t *>(&sh.sc)[i] = src[i];
+    }
     __syncthreads();
     IntraWave *ws = &sh.w[wave];
-    const ScalingSet *sc = &tab->scaling[pd->scaling_set];
     for (int mby = wave; mby < hmb; mby += MI_INTRA_WAVES) {
-        for (int mbx = 0; mbx < wmb; mbx++) {
-            const uint64_t mbi = pd->mb_base + static_cast<uint64_t>(mby) * wmb + mbx;
-            const MbRec *rec = mbrec + mbi;
-            if (MB_IS_INTRA(rec->type)) {
+        const MbRec *row = mbrec + pd->mb_base + static_cast<uint64_t>(mby) * wmb;
+        // scan the row 64 macroblocks at a time: one type byte per lane, ballot -> intra macroblocks
+        for (int x0 = 0; x0 < wmb; x0 += 64) {
+            const int n = min(64, wmb - x0);
+            const int t = lane < n ? row[x0 + lane].type : 0;
+            unsigned long long mask = __ballot(MB_IS_INTRA(t));
+            while (mask) {
+                const int k = __ffsll(static_cast<long long>(mask)) - 1;
+                mask &= mask - 1;
+                const int mbx = x0 + k;
+                // everything left of mbx in this row is final (inter MBs were written by K4)
+                if (lane == 0) __hip_atomic_store(&sh.prog[mby], mbx, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane < 32) reinterpret_cast<uint32_t *>(&ws->rec)[lane] = reinterpret_cast<const uint32_t *>(row + mbx)[lane];
+                WAVE_SYNC();
                 if (mby > 0) { // 2-D wavefront: the row above must be past the top-right neighbour
                     const int need = min(mbx + 2, wmb);
                     while (__hip_atomic_load(&sh.prog[mby - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
                 }
-                intra_mb(lane, ws, rec, coefs + mbi * MI_COEF_PER_MB, sc, py, pcb, pcr, W, mbx, mby);
+                const uint64_t mbi = pd->mb_base + static_cast<uint64_t>(mby) * wmb + mbx;
+                intra_mb(lane, ws, &ws->rec, coefs + mbi * MI_COEF_PER_MB, &sh.sc, py, pcb, pcr, W, mbx, mby);
+                // publish progress: the release orders this wave's global stores before the counter update
+                if (lane == 0) __hip_atomic_store(&sh.prog[mby], mbx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            // publish progress: the release orders this wave's global stores before the counter update
-            if (lane == 0) __hip_atomic_store(&sh.prog[mby], mbx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) __hip_atomic_store(&sh.prog[mby], x0 + n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }
