@@ -47,45 +47,46 @@ struct DbShared {
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
 
-// filter one line of samples (8.7.2.3 / 8.7.2.4); q0p points at q0, `step` = distance across the edge
-__device__ __forceinline__ void filter_line(uint8_t *q0p, int step, int bs, int alpha, int beta, int tc0, bool chroma) {
-    int p0 = q0p[-step], p1 = q0p[-2 * step], q0 = q0p[0], q1 = q0p[step];
-    if (!(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
+// filter one edge of a line of samples held in registers (8.7.2.3 / 8.7.2.4); q0 = px[Q]
+template <int Q, bool CHROMA, int N>
+__device__ __forceinline__ void filter_edge(int (&px)[N], int bs, int alpha, int beta, int tc0) {
+    const int p0 = px[Q - 1], p1 = px[Q - 2], q0 = px[Q], q1 = px[Q + 1];
+    if (!bs || !(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
     if (bs < 4) {
         int tc;
-        if (chroma)
+        if (CHROMA)
             tc = tc0 + 1;
         else {
-            int p2 = q0p[-3 * step], q2 = q0p[2 * step];
-            int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
+            const int p2 = px[Q - 3], q2 = px[Q + 2];
+            const int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
             tc = tc0 + (ap < beta) + (aq < beta);
-            if (ap < beta) q0p[-2 * step] = static_cast<uint8_t>(p1 + clip3(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1));
-            if (aq < beta) q0p[step] = static_cast<uint8_t>(q1 + clip3(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1));
+            if (ap < beta) px[Q - 2] = p1 + clip3(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1);
+            if (aq < beta) px[Q + 1] = q1 + clip3(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1);
         }
-        int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-        q0p[-step] = static_cast<uint8_t>(clip3(0, 255, p0 + delta));
-        q0p[0] = static_cast<uint8_t>(clip3(0, 255, q0 - delta));
-    } else if (chroma) {
-        q0p[-step] = static_cast<uint8_t>((2 * p1 + p0 + q1 + 2) >> 2);
-        q0p[0] = static_cast<uint8_t>((2 * q1 + q0 + p1 + 2) >> 2);
+        const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+        px[Q - 1] = clip3(0, 255, p0 + delta);
+        px[Q] = clip3(0, 255, q0 - delta);
+    } else if (CHROMA) {
+        px[Q - 1] = (2 * p1 + p0 + q1 + 2) >> 2;
+        px[Q] = (2 * q1 + q0 + p1 + 2) >> 2;
     } else {
-        int p2 = q0p[-3 * step], q2 = q0p[2 * step];
-        int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
-        bool small = iabs(p0 - q0) < ((alpha >> 2) + 2);
+        const int p2 = px[Q - 3], q2 = px[Q + 2];
+        const int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
+        const bool small = iabs(p0 - q0) < ((alpha >> 2) + 2);
         if (ap < beta && small) {
-            int p3 = q0p[-4 * step];
-            q0p[-step] = static_cast<uint8_t>((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
-            q0p[-2 * step] = static_cast<uint8_t>((p2 + p1 + p0 + q0 + 2) >> 2);
-            q0p[-3 * step] = static_cast<uint8_t>((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+            const int p3 = px[Q - 4];
+            px[Q - 1] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
+            px[Q - 2] = (p2 + p1 + p0 + q0 + 2) >> 2;
+            px[Q - 3] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
         } else
-            q0p[-step] = static_cast<uint8_t>((2 * p1 + p0 + q1 + 2) >> 2);
+            px[Q - 1] = (2 * p1 + p0 + q1 + 2) >> 2;
         if (aq < beta && small) {
-            int q3 = q0p[3 * step];
-            q0p[0] = static_cast<uint8_t>((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
-            q0p[step] = static_cast<uint8_t>((p0 + q0 + q1 + q2 + 2) >> 2);
-            q0p[2 * step] = static_cast<uint8_t>((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
+            const int q3 = px[Q + 3];
+            px[Q] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
+            px[Q + 1] = (p0 + q0 + q1 + q2 + 2) >> 2;
+            px[Q + 2] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
         } else
-            q0p[0] = static_cast<uint8_t>((2 * q1 + q0 + p1 + 2) >> 2);
+            px[Q] = (2 * q1 + q0 + p1 + 2) >> 2;
     }
 }
 
@@ -191,30 +192,71 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_WAVES * 64) k_deblock(co
                         }
                         WAVE_SYNC();
                     }
-                    // ---- the two filtering passes ----
+                    // ---- the two filtering passes: a whole line of samples in registers per lane ----
                     for (int dir = 0; dir < 2; dir++) {
                         if (ws->any[dir]) {
                             const MbRec *mn = dir == 0 ? ml : mt;
-                            if (lane < 16) { // luma: one row (dir 0) or column (dir 1) per lane, edges in order
-                                for (int e = 0; e < 4; e++) {
-                                    int bs = ws->bs[dir][e][lane >> 2];
-                                    if (!bs) continue;
-                                    const MbRec *mp = e == 0 ? mn : mq;
-                                    int qpav = (mp->qp + mq->qp + 1) >> 1;
-                                    int ia = clip3(0, 51, qpav + mq->alpha_off), ib = clip3(0, 51, qpav + mq->beta_off);
-                                    uint8_t *q0 = dir == 0 ? &tl->y[4 + lane][4 + e * 4] : &tl->y[4 + e * 4][4 + lane];
-                                    filter_line(q0, dir == 0 ? 1 : 20, bs, sh.alpha[ia], sh.beta[ib], sh.tc0[ia][bs & 3], false);
+                            if (lane < 16) { // luma: one row (dir 0) or column (dir 1) per lane
+                                int px[20];
+                                if (dir == 0) {
+#pragma unroll
+                                    for (int d = 0; d < 5; d++) {
+                                        uint32_t w = *reinterpret_cast<const uint32_t *>(&tl->y[4 + lane][d * 4]);
+                                        px[4 * d] = w & 255, px[4 * d + 1] = (w >> 8) & 255, px[4 * d + 2] = (w >> 16) & 255, px[4 * d + 3] = w >> 24;
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int r = 0; r < 20; r++) px[r] = tl->y[r][4 + lane];
+                                }
+                                const uint32_t bsw = *reinterpret_cast<const uint32_t *>(ws->bs[dir][0]) >> (8 * (lane >> 2));
+                                const int bs0 = bsw & 255;
+                                const int bs1 = ws->bs[dir][1][lane >> 2], bs2 = ws->bs[dir][2][lane >> 2], bs3 = ws->bs[dir][3][lane >> 2];
+                                const int qpq = mq->qp, aoff = mq->alpha_off, boff = mq->beta_off;
+                                const int qpe = mn ? (mn->qp + qpq + 1) >> 1 : qpq;
+                                const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
+                                const int ia1 = clip3(0, 51, qpq + aoff), ib1 = clip3(0, 51, qpq + boff);
+                                const int a0 = sh.alpha[ia0], b0 = sh.beta[ib0], a1 = sh.alpha[ia1], b1 = sh.beta[ib1];
+                                filter_edge<4, false>(px, bs0, a0, b0, sh.tc0[ia0][bs0 & 3]);
+                                filter_edge<8, false>(px, bs1, a1, b1, sh.tc0[ia1][bs1 & 3]);
+                                filter_edge<12, false>(px, bs2, a1, b1, sh.tc0[ia1][bs2 & 3]);
+                                filter_edge<16, false>(px, bs3, a1, b1, sh.tc0[ia1][bs3 & 3]);
+                                if (dir == 0) {
+#pragma unroll
+                                    for (int d = 0; d < 5; d++)
+                                        *reinterpret_cast<uint32_t *>(&tl->y[4 + lane][d * 4]) =
+                                            static_cast<uint32_t>(px[4 * d]) | (px[4 * d + 1] << 8) | (px[4 * d + 2] << 16) | (static_cast<uint32_t>(px[4 * d + 3]) << 24);
+                                } else {
+#pragma unroll
+                                    for (int r = 1; r < 19; r++) tl->y[r][4 + lane] = static_cast<uint8_t>(px[r]);
                                 }
                             } else if (lane < 32) { // chroma: plane = bit 3, row/column = low 3 bits; luma edges 0 and 2
                                 const int c = (lane >> 3) & 1, i = lane & 7;
-                                for (int e = 0; e < 4; e += 2) {
-                                    int bs = ws->bs[dir][e][i >> 1];
-                                    if (!bs) continue;
-                                    const MbRec *mp = e == 0 ? mn : mq;
-                                    int qpav = (mp->qpc[c] + mq->qpc[c] + 1) >> 1;
-                                    int ia = clip3(0, 51, qpav + mq->alpha_off), ib = clip3(0, 51, qpav + mq->beta_off);
-                                    uint8_t *q0 = dir == 0 ? &tl->c[c][4 + i][4 + e * 2] : &tl->c[c][4 + e * 2][4 + i];
-                                    filter_line(q0, dir == 0 ? 1 : 12, bs, sh.alpha[ia], sh.beta[ib], sh.tc0[ia][bs & 3], true);
+                                int px[12];
+                                if (dir == 0) {
+#pragma unroll
+                                    for (int d = 0; d < 3; d++) {
+                                        uint32_t w = *reinterpret_cast<const uint32_t *>(&tl->c[c][4 + i][d * 4]);
+                                        px[4 * d] = w & 255, px[4 * d + 1] = (w >> 8) & 255, px[4 * d + 2] = (w >> 16) & 255, px[4 * d + 3] = w >> 24;
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int r = 0; r < 12; r++) px[r] = tl->c[c][r][4 + i];
+                                }
+                                const int bs0 = ws->bs[dir][0][i >> 1], bs2 = ws->bs[dir][2][i >> 1];
+                                const int qpq = mq->qpc[c], aoff = mq->alpha_off, boff = mq->beta_off;
+                                const int qpe = mn ? (mn->qpc[c] + qpq + 1) >> 1 : qpq;
+                                const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
+                                const int ia1 = clip3(0, 51, qpq + aoff), ib1 = clip3(0, 51, qpq + boff);
+                                filter_edge<4, true>(px, bs0, sh.alpha[ia0], sh.beta[ib0], sh.tc0[ia0][bs0 & 3]);
+                                filter_edge<8, true>(px, bs2, sh.alpha[ia1], sh.beta[ib1], sh.tc0[ia1][bs2 & 3]);
+                                if (dir == 0) {
+#pragma unroll
+                                    for (int d = 0; d < 3; d++)
+                                        *reinterpret_cast<uint32_t *>(&tl->c[c][4 + i][d * 4]) =
+                                            static_cast<uint32_t>(px[4 * d]) | (px[4 * d + 1] << 8) | (px[4 * d + 2] << 16) | (static_cast<uint32_t>(px[4 * d + 3]) << 24);
+                                } else {
+#pragma unroll
+                                    for (int r = 2; r < 10; r++) tl->c[c][r][4 + i] = static_cast<uint8_t>(px[r]);
                                 }
                             }
                         }

@@ -391,7 +391,8 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
     const int a_left = av & MI_AV_LEFT, a_top = (av & MI_AV_TOP) != 0, a_tl = (av & MI_AV_TOPLEFT) != 0, a_tr = (av & MI_AV_TOPRIGHT) != 0;
     uint8_t *Y = py + static_cast<size_t>(mby * 16) * W + mbx * 16;
     const int Wc = W / 2;
-    uint8_t *C[2] = {pcb + static_cast<size_t>(mby * 8) * Wc + mbx * 8, pcr + static_cast<size_t>(mby * 8) * Wc + mbx * 8};
+    uint8_t *C0 = pcb + static_cast<size_t>(mby * 8) * Wc + mbx * 8, *C1 = pcr + static_cast<size_t>(mby * 8) * Wc + mbx * 8;
+#define CPL(c) ((c) ? C1 : C0) /* a select, not an indexed pointer array (which would live in scratch) */
     if (type == MBT_IPCM) { // 8.3.5: samples were stored in the coefficient block
         const uint8_t *pcm = reinterpret_cast<const uint8_t *>(coef);
         { // 256 luma bytes: one dword per lane
@@ -400,7 +401,7 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
         }
         if (lane < 32) {
             int c = lane >> 4, j = (lane >> 1) & 7, i = (lane & 1) * 4;
-            *reinterpret_cast<uint32_t *>(C[c] + static_cast<size_t>(j) * Wc + i) = *reinterpret_cast<const uint32_t *>(pcm + 256 + c * 64 + j * 8 + i);
+            *reinterpret_cast<uint32_t *>(CPL(c) + static_cast<size_t>(j) * Wc + i) = *reinterpret_cast<const uint32_t *>(pcm + 256 + c * 64 + j * 8 + i);
         }
         return;
     }
@@ -416,10 +417,10 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
     if (lane < 18) { // chroma rows above: x = -1..7 for both planes
         int c = lane / 9, x = lane % 9 - 1;
         int ok = x < 0 ? a_tl : a_top;
-        ws->tile_c[c][0][x + 1] = ok ? C[c][-static_cast<ptrdiff_t>(Wc) + x] : static_cast<uint8_t>(128);
+        ws->tile_c[c][0][x + 1] = ok ? CPL(c)[-static_cast<ptrdiff_t>(Wc) + x] : static_cast<uint8_t>(128);
     } else if (lane >= 32 && lane < 48) {
         int c = (lane - 32) >> 3, y = lane & 7;
-        ws->tile_c[c][y + 1][0] = a_left ? C[c][static_cast<size_t>(y) * Wc - 1] : static_cast<uint8_t>(128);
+        ws->tile_c[c][y + 1][0] = a_left ? CPL(c)[static_cast<size_t>(y) * Wc - 1] : static_cast<uint8_t>(128);
     }
     // ---- residual ----
     if ((rec->cbp & 0x3F) || type == MBT_I16x16)
@@ -599,7 +600,7 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
             v = clip255(v + ws->rb.chroma[c][y * 8 + x]);
             packed |= static_cast<uint32_t>(v) << (8 * k);
         }
-        *reinterpret_cast<uint16_t *>(C[c] + static_cast<size_t>(y) * Wc + x0) = static_cast<uint16_t>(packed);
+        *reinterpret_cast<uint16_t *>(CPL(c) + static_cast<size_t>(y) * Wc + x0) = static_cast<uint16_t>(packed);
     }
 }
 

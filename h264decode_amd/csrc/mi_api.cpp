@@ -136,8 +136,11 @@ struct h264mi_decoder {
     PicDesc *d_pics = nullptr, *h_pics = nullptr;
     uint32_t *d_status = nullptr, *h_status = nullptr, *d_lists = nullptr, *h_lists = nullptr;
     int slices_cap = 0, pics_cap = 0;
-    MbRec *d_mbrec = nullptr;
-    int16_t *d_coef = nullptr;
+    MbRec *d_mbrec[2] = {nullptr, nullptr}; // double buffered: entropy of pass n+1 overlaps reconstruction of pass n
+    int16_t *d_coef[2] = {nullptr, nullptr};
+    hipStream_t ent_stream = nullptr; // K1/K2 run here; K3-K5 on `stream`
+    hipEvent_t ev_ent[2] = {nullptr, nullptr}, ev_rec[2] = {nullptr, nullptr}, ev_upload = nullptr;
+    uint64_t pass = 0; // execute() counter
     uint64_t mb_cap = 0, mb_used = 0;
     FramePool *d_pools = nullptr;
     std::vector<FramePool> h_pools;
@@ -205,8 +208,14 @@ static void free_all(h264mi_decoder *d) {
     if (d->h_status) hipHostFree(d->h_status);
     if (d->d_lists) hipFree(d->d_lists);
     if (d->h_lists) hipHostFree(d->h_lists);
-    if (d->d_mbrec) hipFree(d->d_mbrec);
-    if (d->d_coef) hipFree(d->d_coef);
+    for (int i = 0; i < 2; i++) {
+        if (d->d_mbrec[i]) hipFree(d->d_mbrec[i]);
+        if (d->d_coef[i]) hipFree(d->d_coef[i]);
+        if (d->ev_ent[i]) hipEventDestroy(d->ev_ent[i]);
+        if (d->ev_rec[i]) hipEventDestroy(d->ev_rec[i]);
+    }
+    if (d->ev_upload) hipEventDestroy(d->ev_upload);
+    if (d->ent_stream) hipStreamDestroy(d->ent_stream);
     if (d->d_pools) hipFree(d->d_pools);
     if (d->d_frames) hipFree(d->d_frames);
     if (d->d_tables) hipFree(d->d_tables);
@@ -263,8 +272,14 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipHostMalloc(&d->h_status, sizeof(uint32_t) * 2 * d->slices_cap));
     TRY_ALLOC(hipMalloc(&d->d_lists, sizeof(uint32_t) * 2 * d->pics_cap));
     TRY_ALLOC(hipHostMalloc(&d->h_lists, sizeof(uint32_t) * 2 * d->pics_cap));
-    TRY_ALLOC(hipMalloc(&d->d_mbrec, sizeof(MbRec) * d->mb_cap));
-    TRY_ALLOC(hipMalloc(&d->d_coef, sizeof(int16_t) * MI_COEF_PER_MB * d->mb_cap));
+    TRY_ALLOC(hipStreamCreateWithFlags(&d->ent_stream, hipStreamNonBlocking));
+    TRY_ALLOC(hipEventCreateWithFlags(&d->ev_upload, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+        TRY_ALLOC(hipMalloc(&d->d_mbrec[i], sizeof(MbRec) * d->mb_cap));
+        TRY_ALLOC(hipMalloc(&d->d_coef[i], sizeof(int16_t) * MI_COEF_PER_MB * d->mb_cap));
+        TRY_ALLOC(hipEventCreateWithFlags(&d->ev_ent[i], hipEventDisableTiming));
+        TRY_ALLOC(hipEventCreateWithFlags(&d->ev_rec[i], hipEventDisableTiming));
+    }
     TRY_ALLOC(hipMalloc(&d->d_pools, sizeof(FramePool) * S));
     TRY_ALLOC(hipMalloc(&d->d_frames, d->slot_bytes * d->n_slots * S));
     TRY_ALLOC(hipMalloc(&d->d_tables, sizeof(DevTables)));
@@ -281,6 +296,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
 
 extern "C" int32_t h264mi_decoder_destroy(h264mi_decoder *d) {
     if (!d) return H264MI_EINVAL;
+    hipStreamSynchronize(d->ent_stream);
     hipStreamSynchronize(d->stream);
     free_all(d);
     delete d;
@@ -660,7 +676,8 @@ static int add_slice(h264mi_decoder *d, int si, const uint8_t *nal, size_t len, 
 extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, const uint8_t *const *bufs, const size_t *lens, h264mi_batch_info *info) {
     if (!d || n_streams < 0 || n_streams > static_cast<int>(d->st.size()) || (n_streams && (!bufs || !lens))) return H264MI_EINVAL;
     auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(hipStreamSynchronize(d->stream)); // the previous batch must not be reading the staging buffers
+    HIP_TRY(hipStreamSynchronize(d->ent_stream)); // the previous batch must not be reading the staging buffers
+    HIP_TRY(hipStreamSynchronize(d->stream));
     d->prepared = false;
     d->n_slices = d->n_pics = 0;
     d->bits_used = 0, d->mb_used = 0, d->wmb_max = 0, d->mbs_max = 0;
@@ -759,6 +776,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
         HIP_TRY(hipMemcpyAsync(d->d_tables, d->h_tables, sizeof(DevTables), hipMemcpyHostToDevice, d->stream));
         d->tables_dirty = false;
     }
+    HIP_TRY(hipEventRecord(d->ev_upload, d->stream));
     d->info.n_frames = d->n_pics, d->info.n_slices = d->n_slices, d->info.bitstream_bytes = static_cast<int64_t>(d->bits_used);
     d->info.host_prepare_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (info) *info = d->info;
@@ -788,25 +806,39 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     auto mark = [&](int kind) {
         if (prof) hipEventRecord(next_event(d, ei, kind), d->stream);
     };
-    mark(-1);
-    hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), static_cast<size_t>(d->wmb_max) * 48, d->stream, d->d_slices, d->d_pics, d->d_bits, d->d_tables,
-                       d->d_mbrec, d->d_coef, d->d_status, d->wmb_max);
-    mark(0);
+    // Pass n uses buffer set n&1.  Entropy runs on its own stream so that the entropy kernels of
+    // pass n+1 overlap the reconstruction kernels of pass n; set reuse is fenced by events.
+    const int set = static_cast<int>(d->pass & 1);
+    MbRec *mbrec = d->d_mbrec[set];
+    int16_t *coef = d->d_coef[set];
+    if (prof) { // profiling serialises the two stages on one stream so that HIP-event intervals are per kernel
+        mark(-1);
+        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), static_cast<size_t>(d->wmb_max) * 48, d->stream, d->d_slices, d->d_pics, d->d_bits, d->d_tables,
+                           mbrec, coef, d->d_status, d->wmb_max);
+        mark(0);
+    } else {
+        HIP_TRY(hipStreamWaitEvent(d->ent_stream, d->ev_upload, 0));
+        if (d->pass >= 2) HIP_TRY(hipStreamWaitEvent(d->ent_stream, d->ev_rec[set], 0)); // pass n-2 finished reading this set
+        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), static_cast<size_t>(d->wmb_max) * 48, d->ent_stream, d->d_slices, d->d_pics, d->d_bits,
+                           d->d_tables, mbrec, coef, d->d_status, d->wmb_max);
+        HIP_TRY(hipEventRecord(d->ev_ent[set], d->ent_stream));
+        HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_ent[set], 0));
+    }
     for (size_t w = 0; w < d->waves.size(); w++) {
         const uint32_t n = static_cast<uint32_t>(d->waves[w].size()), ni = static_cast<uint32_t>(d->waves_inter[w].size());
         if (!n) continue;
         if (ni) {
             hipLaunchKernelGGL(k_inter, dim3(ni * d->mbs_max), dim3(64), 0, d->stream, d->d_lists + d->wave_inter_off[w], d->d_pics, d->d_slices, d->d_pools,
-                               d->d_tables, d->d_mbrec, d->d_coef, d->mbs_max);
+                               d->d_tables, mbrec, coef, d->mbs_max);
             mark(1);
         }
-        hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, d->stream, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, d->d_mbrec,
-                           d->d_coef);
+        hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, d->stream, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec, coef);
         mark(2);
-        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(MI_DEBLOCK_WAVES * 64), 0, d->stream, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables,
-                           d->d_mbrec);
+        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(MI_DEBLOCK_WAVES * 64), 0, d->stream, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec);
         mark(3);
     }
+    HIP_TRY(hipEventRecord(d->ev_rec[set], d->stream));
+    d->pass++;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(d->h_status, d->d_status, sizeof(uint32_t) * 2 * d->n_slices, hipMemcpyDeviceToHost, d->stream));
     d->ev_used = prof ? ei : 0;
@@ -815,6 +847,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
 
 extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
     if (!d) return H264MI_EINVAL;
+    HIP_TRY(hipStreamSynchronize(d->ent_stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     if (d->profiling && d->ev_used >= 2) {
         size_t n = d->ev_used;
@@ -936,7 +969,7 @@ extern "C" int32_t h264mi_frame_read_mbrecs(h264mi_decoder *d, int32_t stream, i
             size_t n = static_cast<size_t>(pd.wmb) * pd.hmb * sizeof(MbRec);
             if (cap < n) return H264MI_ECAPACITY;
             HIP_TRY(hipStreamSynchronize(d->stream));
-            HIP_TRY(hipMemcpy(rec, d->d_mbrec + pd.mb_base, n, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(rec, d->d_mbrec[(d->pass + 1) & 1] + pd.mb_base, n, hipMemcpyDeviceToHost));
             return H264MI_OK;
         }
     }
