@@ -40,7 +40,6 @@ static_assert(sizeof(TopInfo) == 48, "TopInfo layout");
 
 struct Shared {
     uint32_t ring[RING_WORDS];
-    uint2 lps[128];      // per state s=(pStateIdx<<1|valMPS): .x = rangeTabLPS[p][0..3] packed, .y = next(MPS) | next(LPS)<<8
     uint8_t ctx[464];
     uint8_t posmap[4][64]; // scan index -> position: [0] zig-zag 4x4, [1] zig-zag 4x4 of AC index (k+1), [2] zig-zag 8x8, [3] identity
     uint8_t incmap[3][64]; // ctxIdxInc of significant_coeff_flag: [0] identity, [1] min(i,2) (chroma DC), [2] Table 9-43 8x8
@@ -78,6 +77,7 @@ struct Ent {
     uint32_t rbsp_words, filled, bitpos;
     uint32_t range, value;
     int avail;
+    uint32_t v_rlps, v_trans; // per-lane copies of Table 9-44 (4 bytes) / 9-45 for state = lane
     int qp, prev_dqp_nz, mbx, mby, cur_type, err;
     int cabac, islice, wmb, hmb;
 };
@@ -149,35 +149,49 @@ FI int get_se(Ent &e) {
 
 // ------------------------------------------------------------------ CABAC engine (9.3.1.2, 9.3.3.2)
 // codIOffset is kept scaled: value = (codIOffset << avail) | next `avail` stream bits.
+// The engine is scalar: range / value / avail live in SGPRs (every LDS result goes through
+// readfirstlane), and Tables 9-44 / 9-45 are held one state per lane in two VGPRs and looked up
+// with v_readlane, so a decision costs ONE LDS round trip (the context state) instead of three.
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+FI uint32_t speek32(const Ent &e, uint32_t pos) {
+    const uint32_t w = pos >> 5, sh = pos & 31;
+    const uint32_t hi = RFL(e.s->ring[w & (RING_WORDS - 1)]), lo = RFL(e.s->ring[(w + 1) & (RING_WORDS - 1)]);
+    return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32 | lo) << sh) >> 32);
+}
 FI void cabac_refill(Ent &e) {
     if (e.avail < 7) {
-        e.value = (e.value << 16) | (peek32(e, e.bitpos) >> 16);
+        e.value = (e.value << 16) | (speek32(e, e.bitpos) >> 16);
         e.bitpos += 16;
         e.avail += 16;
     }
 }
 FI void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
     e.range = 510;
-    e.value = get_bits(e, 9);
+    e.value = speek32(e, e.bitpos) >> 23;
+    e.bitpos += 9;
     e.avail = 0;
     cabac_refill(e);
 }
-// DecodeDecision (h264/cabac.go:521-540) + state transition (:544-553) + RenormD (:503-511), branch-free
+// DecodeDecision (h264/cabac.go:521-540) + state transition (:544-553) + RenormD (:503-511)
 FI int cabac_bin(Ent &e, int ctx) {
-    const uint32_t st = e.s->ctx[ctx];
-    const uint2 t = e.s->lps[st];
-    const uint32_t rlps = (t.x >> (((e.range >> 6) & 3) * 8)) & 255;
+    const uint32_t st = RFL(static_cast<uint32_t>(e.s->ctx[ctx]));
+    const uint32_t p = st >> 1, mps = st & 1;
+    const uint32_t rl4 = __builtin_amdgcn_readlane(e.v_rlps, p);  // rangeTabLPS[p][0..3]
+    const uint32_t tr = __builtin_amdgcn_readlane(e.v_trans, p);  // transIdxLPS[p]
+    const uint32_t rlps = (rl4 >> (((e.range >> 6) & 3) * 8)) & 255;
     const uint32_t rmps = e.range - rlps;
     const uint32_t scaled = rmps << e.avail;
     const bool lps = e.value >= scaled;
     e.value -= lps ? scaled : 0;
     e.range = lps ? rlps : rmps;
-    e.s->ctx[ctx] = static_cast<uint8_t>(lps ? (t.y >> 8) : (t.y & 255));
-    const int n = __clz(e.range) - 23;
+    const uint32_t nmps = (p == 0 && lps) ? mps ^ 1 : mps;
+    const uint32_t np = lps ? tr : (p < 62 ? p + 1 : p);
+    e.s->ctx[ctx] = static_cast<uint8_t>((np << 1) | nmps);
+    const int n = __builtin_clz(e.range) - 23;
     e.range <<= n;
     e.avail -= n;
     cabac_refill(e);
-    return static_cast<int>((st & 1) ^ static_cast<uint32_t>(lps));
+    return static_cast<int>(mps ^ static_cast<uint32_t>(lps));
 }
 FI int cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
     e.avail -= 1;
@@ -190,7 +204,7 @@ FI int cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
 FI int cabac_terminate(Ent &e) { // 9.3.3.2.4
     e.range -= 2;
     if (e.value >= (e.range << e.avail)) return 1;
-    const int n = __clz(e.range) - 23;
+    const int n = __builtin_clz(e.range) - 23;
     e.range <<= n;
     e.avail -= n;
     cabac_refill(e);
@@ -225,7 +239,8 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat, int cbf_inc) {
     uint64_t sigmask = 0;
     int n = 0, i = 0;
     for (; i < maxnum - 1; i++) {
-        const int inc_s = im[i], inc_l = cat == 5 ? e.s->lastmap[i] : inc_s;
+        const int inc_s = cat == 5 ? RFL(static_cast<int>(im[i])) : (cat == 3 ? (i < 2 ? i : 2) : i);
+        const int inc_l = cat == 5 ? RFL(static_cast<int>(e.s->lastmap[i])) : inc_s;
         if (cabac_bin(e, sbase + inc_s)) {
             sigmask |= 1ull << i;
             n++;
@@ -944,12 +959,10 @@ extern "C" __global__ void __launch_bounds__(64) k_entropy(const SliceDesc *slic
     e.mbx = e.mby = 0, e.cur_type = 0;
     const int l = LANE;
     // ---- tables -> LDS ----
-    for (int st = l; st < 128; st += 64) { // merged Table 9-44 / 9-45 entry per (pStateIdx, valMPS)
-        const int p = st >> 1, mps = st & 1;
-        const uint8_t *rl = tab->range_lps[p];
-        const int pl = tab->trans_lps[p], pm = p < 62 ? p + 1 : p;
-        const int next_lps = (pl << 1) | (p == 0 ? mps ^ 1 : mps), next_mps = (pm << 1) | mps;
-        sh.lps[st] = make_uint2(rl[0] | (rl[1] << 8) | (rl[2] << 16) | (static_cast<uint32_t>(rl[3]) << 24), next_mps | (next_lps << 8));
+    { // Tables 9-44 / 9-45: lane p keeps the entries of pStateIdx p
+        const uint8_t *rl = tab->range_lps[l];
+        e.v_rlps = rl[0] | (rl[1] << 8) | (rl[2] << 16) | (static_cast<uint32_t>(rl[3]) << 24);
+        e.v_trans = tab->trans_lps[l];
     }
     sh.posmap[0][l] = tab->zigzag4[l & 15];
     sh.posmap[1][l] = tab->zigzag4[(l + 1) & 15];

@@ -18,6 +18,8 @@
 
 using namespace mi;
 
+#define MI_SETS 3
+
 #define HIP_TRY(x)                                                                          \
     do {                                                                                    \
         hipError_t _e = (x);                                                                \
@@ -136,10 +138,13 @@ struct h264mi_decoder {
     PicDesc *d_pics = nullptr, *h_pics = nullptr;
     uint32_t *d_status = nullptr, *h_status = nullptr, *d_lists = nullptr, *h_lists = nullptr;
     int slices_cap = 0, pics_cap = 0;
-    MbRec *d_mbrec[2] = {nullptr, nullptr}; // double buffered: entropy of pass n+1 overlaps reconstruction of pass n
-    int16_t *d_coef[2] = {nullptr, nullptr};
-    hipStream_t ent_stream = nullptr; // K1/K2 run here; K3-K5 on `stream`
-    hipEvent_t ev_ent[2] = {nullptr, nullptr}, ev_rec[2] = {nullptr, nullptr}, ev_upload = nullptr;
+    // Passes are pipelined: the entropy kernels of passes n+1 / n+2 (two private streams, alternating)
+    // overlap the reconstruction kernels of pass n (on `stream`); each pass owns one of MI_SETS
+    // MbRec / coefficient buffer sets, fenced by events.
+    MbRec *d_mbrec[MI_SETS] = {};
+    int16_t *d_coef[MI_SETS] = {};
+    hipStream_t ent_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_ent[MI_SETS] = {}, ev_rec[MI_SETS] = {}, ev_upload = nullptr;
     uint64_t pass = 0; // execute() counter
     uint64_t mb_cap = 0, mb_used = 0;
     FramePool *d_pools = nullptr;
@@ -208,14 +213,15 @@ static void free_all(h264mi_decoder *d) {
     if (d->h_status) hipHostFree(d->h_status);
     if (d->d_lists) hipFree(d->d_lists);
     if (d->h_lists) hipHostFree(d->h_lists);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < MI_SETS; i++) {
         if (d->d_mbrec[i]) hipFree(d->d_mbrec[i]);
         if (d->d_coef[i]) hipFree(d->d_coef[i]);
         if (d->ev_ent[i]) hipEventDestroy(d->ev_ent[i]);
         if (d->ev_rec[i]) hipEventDestroy(d->ev_rec[i]);
     }
     if (d->ev_upload) hipEventDestroy(d->ev_upload);
-    if (d->ent_stream) hipStreamDestroy(d->ent_stream);
+    for (int i = 0; i < 2; i++)
+        if (d->ent_stream[i]) hipStreamDestroy(d->ent_stream[i]);
     if (d->d_pools) hipFree(d->d_pools);
     if (d->d_frames) hipFree(d->d_frames);
     if (d->d_tables) hipFree(d->d_tables);
@@ -272,9 +278,9 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipHostMalloc(&d->h_status, sizeof(uint32_t) * 2 * d->slices_cap));
     TRY_ALLOC(hipMalloc(&d->d_lists, sizeof(uint32_t) * 2 * d->pics_cap));
     TRY_ALLOC(hipHostMalloc(&d->h_lists, sizeof(uint32_t) * 2 * d->pics_cap));
-    TRY_ALLOC(hipStreamCreateWithFlags(&d->ent_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) TRY_ALLOC(hipStreamCreateWithFlags(&d->ent_stream[i], hipStreamNonBlocking));
     TRY_ALLOC(hipEventCreateWithFlags(&d->ev_upload, hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < MI_SETS; i++) {
         TRY_ALLOC(hipMalloc(&d->d_mbrec[i], sizeof(MbRec) * d->mb_cap));
         TRY_ALLOC(hipMalloc(&d->d_coef[i], sizeof(int16_t) * MI_COEF_PER_MB * d->mb_cap));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_ent[i], hipEventDisableTiming));
@@ -296,7 +302,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
 
 extern "C" int32_t h264mi_decoder_destroy(h264mi_decoder *d) {
     if (!d) return H264MI_EINVAL;
-    hipStreamSynchronize(d->ent_stream);
+    for (int i = 0; i < 2; i++) hipStreamSynchronize(d->ent_stream[i]);
     hipStreamSynchronize(d->stream);
     free_all(d);
     delete d;
@@ -676,7 +682,7 @@ static int add_slice(h264mi_decoder *d, int si, const uint8_t *nal, size_t len, 
 extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, const uint8_t *const *bufs, const size_t *lens, h264mi_batch_info *info) {
     if (!d || n_streams < 0 || n_streams > static_cast<int>(d->st.size()) || (n_streams && (!bufs || !lens))) return H264MI_EINVAL;
     auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(hipStreamSynchronize(d->ent_stream)); // the previous batch must not be reading the staging buffers
+    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(d->ent_stream[i])); // the previous batch must not be reading the staging buffers
     HIP_TRY(hipStreamSynchronize(d->stream));
     d->prepared = false;
     d->n_slices = d->n_pics = 0;
@@ -744,6 +750,15 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
         }
         if (s.cur_slot >= 0) finish_picture(d, s);
     }
+    // Longest-processing-time-first: the entropy kernel runs one slice per workgroup and workgroups are
+    // dispatched in index order, so the biggest slices (I pictures) must start first.
+    if (d->n_slices > 1) {
+        std::vector<int> order(d->n_slices);
+        for (int i = 0; i < d->n_slices; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return d->h_slices[x].rbsp_size > d->h_slices[y].rbsp_size; });
+        std::vector<SliceDesc> tmp(d->h_slices, d->h_slices + d->n_slices);
+        for (int i = 0; i < d->n_slices; i++) d->h_slices[i] = tmp[order[i]];
+    }
     // picture "waves": the k-th picture of every stream can be reconstructed side by side
     size_t nw = 0;
     for (auto &s : d->st) nw = std::max<size_t>(nw, s.n_pics_in_batch);
@@ -808,7 +823,8 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     };
     // Pass n uses buffer set n&1.  Entropy runs on its own stream so that the entropy kernels of
     // pass n+1 overlap the reconstruction kernels of pass n; set reuse is fenced by events.
-    const int set = static_cast<int>(d->pass & 1);
+    const int set = static_cast<int>(d->pass % MI_SETS);
+    hipStream_t es = d->ent_stream[d->pass & 1];
     MbRec *mbrec = d->d_mbrec[set];
     int16_t *coef = d->d_coef[set];
     if (prof) { // profiling serialises the two stages on one stream so that HIP-event intervals are per kernel
@@ -817,11 +833,11 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
                            mbrec, coef, d->d_status, d->wmb_max);
         mark(0);
     } else {
-        HIP_TRY(hipStreamWaitEvent(d->ent_stream, d->ev_upload, 0));
-        if (d->pass >= 2) HIP_TRY(hipStreamWaitEvent(d->ent_stream, d->ev_rec[set], 0)); // pass n-2 finished reading this set
-        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), static_cast<size_t>(d->wmb_max) * 48, d->ent_stream, d->d_slices, d->d_pics, d->d_bits,
+        HIP_TRY(hipStreamWaitEvent(es, d->ev_upload, 0));
+        if (d->pass >= MI_SETS) HIP_TRY(hipStreamWaitEvent(es, d->ev_rec[set], 0)); // pass n-MI_SETS finished reading this set
+        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), static_cast<size_t>(d->wmb_max) * 48, es, d->d_slices, d->d_pics, d->d_bits,
                            d->d_tables, mbrec, coef, d->d_status, d->wmb_max);
-        HIP_TRY(hipEventRecord(d->ev_ent[set], d->ent_stream));
+        HIP_TRY(hipEventRecord(d->ev_ent[set], es));
         HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_ent[set], 0));
     }
     for (size_t w = 0; w < d->waves.size(); w++) {
@@ -847,7 +863,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
 
 extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
     if (!d) return H264MI_EINVAL;
-    HIP_TRY(hipStreamSynchronize(d->ent_stream));
+    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(d->ent_stream[i]));
     HIP_TRY(hipStreamSynchronize(d->stream));
     if (d->profiling && d->ev_used >= 2) {
         size_t n = d->ev_used;
@@ -969,7 +985,7 @@ extern "C" int32_t h264mi_frame_read_mbrecs(h264mi_decoder *d, int32_t stream, i
             size_t n = static_cast<size_t>(pd.wmb) * pd.hmb * sizeof(MbRec);
             if (cap < n) return H264MI_ECAPACITY;
             HIP_TRY(hipStreamSynchronize(d->stream));
-            HIP_TRY(hipMemcpy(rec, d->d_mbrec[(d->pass + 1) & 1] + pd.mb_base, n, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(rec, d->d_mbrec[(d->pass + MI_SETS - 1) % MI_SETS] + pd.mb_base, n, hipMemcpyDeviceToHost));
             return H264MI_OK;
         }
     }
