@@ -1,0 +1,99 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def sg():
+    import streamgen
+    streamgen.build()
+    return streamgen
+
+
+@pytest.fixture(scope="session")
+def H():
+    """The product package; the shared library must already be built (no build on the GPU box needed:
+    the in-tree .so travels with the snapshot).  Never falls back to anything else."""
+    import h264decode_amd
+    if not os.path.exists(os.path.join(ROOT, "h264decode_amd", "libh264mi.so")):
+        h264decode_amd.build()
+    h264decode_amd.load()
+    return h264decode_amd
+
+
+REAL_MP4 = "/opt/conda/lib/python3.9/site-packages/imageio/resources/images/realshort.mp4"
+
+
+@pytest.fixture(scope="session")
+def real_stream():
+    if not os.path.exists(REAL_MP4):
+        pytest.skip("third-party sample MP4 not present on this machine")
+    from mp4util import mp4_to_annexb
+    return mp4_to_annexb(open(REAL_MP4, "rb").read())
+
+
+# the parity matrix shared by CPU (oracle vs generator) and GPU (product vs oracle + generator) tests
+BASE = dict(width=176, height=144, frames=4, idr_period=0)
+MATRIX = {
+    "cavlc_I": dict(width=64, height=48, frames=2, idr_period=1, profile_idc=66, cabac=0),
+    "cabac_I": dict(width=64, height=48, frames=2, idr_period=1, profile_idc=77, cabac=1),
+    "cavlc_IPP": dict(BASE, profile_idc=66, cabac=0, qp=24),
+    "cabac_IPP": dict(BASE, profile_idc=77, cabac=1, qp=24),
+    "cabac_lowqp": dict(BASE, frames=3, profile_idc=77, cabac=1, qp=8, noise=30),
+    "cavlc_lowqp": dict(BASE, frames=3, profile_idc=66, cabac=0, qp=8, noise=30),
+    "cabac_highqp": dict(BASE, profile_idc=77, cabac=1, qp=45),
+    "cavlc_highqp": dict(BASE, profile_idc=66, cabac=0, qp=40),
+    "high8x8_cabac": dict(BASE, profile_idc=100, cabac=1, transform8x8=1, qp=26),
+    "high8x8_cavlc": dict(BASE, profile_idc=100, cabac=0, transform8x8=1, qp=26),
+    "scaling_matrix": dict(BASE, profile_idc=100, cabac=1, transform8x8=1, qp=26, scaling_matrix=1),
+    "slices_idc_cycle": dict(BASE, profile_idc=77, cabac=1, slices=3, cabac_init_idc=-1),
+    "slices_dbf2": dict(BASE, profile_idc=66, cabac=0, slices=4, deblock_idc=2),
+    "multiref_cabac": dict(BASE, frames=6, profile_idc=77, cabac=1, num_ref_frames=3, qp=30),
+    "multiref_cavlc": dict(BASE, frames=6, profile_idc=66, cabac=0, num_ref_frames=4, qp=30),
+    "pcm_qpjitter_cabac": dict(BASE, profile_idc=77, cabac=1, pcm_permille=60, qp_jitter=6),
+    "pcm_qpjitter_cavlc": dict(BASE, profile_idc=66, cabac=0, pcm_permille=60, qp_jitter=6),
+    "weighted_pred": dict(BASE, frames=5, profile_idc=77, cabac=1, weighted_pred=1, num_ref_frames=2),
+    "constrained_intra": dict(BASE, profile_idc=77, cabac=1, constrained_intra=1, intra_in_p_permille=300),
+    "no_deblock": dict(BASE, profile_idc=77, cabac=1, deblock_idc=1),
+    "dbf_offsets_cqp": dict(BASE, profile_idc=77, cabac=1, alpha_off_div2=3, beta_off_div2=-2, chroma_qp_offset=4),
+    "sub8x8_heavy": dict(BASE, profile_idc=77, cabac=1, sub8x8_permille=600, skip_permille=100, qp=24),
+    "sub8x8_cavlc_poc2": dict(BASE, profile_idc=66, cabac=0, sub8x8_permille=600, skip_permille=100, qp=24, poc_type=2),
+    "crop_3byte_sc": dict(width=180, height=100, frames=3, idr_period=0, profile_idc=100, cabac=1, transform8x8=1, long_start_code=0, slices=2),
+    "idc1": dict(BASE, profile_idc=77, cabac=1, cabac_init_idc=1),
+    "idc2": dict(BASE, profile_idc=77, cabac=1, cabac_init_idc=2),
+    "gop3": dict(BASE, frames=7, idr_period=3, profile_idc=77, cabac=1),
+}

@@ -1,0 +1,120 @@
+"""CPU tests of the product's host layer (libh264mi.so without a GPU): the C ABI loads and exports
+every symbol the header declares, the reference-API mirror parses what the oracle parses, and errors
+are status codes, never crashes.  No decode calls here (they need a GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(H):
+    hdr = open(os.path.join(ROOT, "include", "h264mi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(h264mi_\w+)\s*\(", hdr))
+    assert len(declared) >= 20
+    L = H.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "missing export " + name
+    from h264decode_amd import _lib
+    assert declared == set(_lib.EXPORTS)
+
+
+def test_no_gpu_means_error_not_fallback(H):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(H.H264MIError) as ei:
+        H.Decoder(max_streams=1, max_width=64, max_height=48, max_frames_per_batch=2)
+    assert ei.value.code == -4  # H264MI_ENODEVICE
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "h264decode_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")) or f == "Makefile":
+                src = open(os.path.join(dirpath, f)).read()
+                for needle in ("import oracle", "from oracle", "h264o_", "libh264oracle", "oracle/_build", "oracle/_ref", "import streamgen"):
+                    assert needle not in src, (needle, os.path.join(dirpath, f))
+
+
+def test_annexb_scan_and_nal_parse(H, sg):
+    stream, _, _ = sg.encode(width=64, height=48, frames=3, idr_period=0, profile_idc=77, cabac=1, long_start_code=0)
+    nals = H.read_nal_units(stream)
+    assert [n.Type for n in nals] == [7, 8, 5, 1, 1]
+    assert all(n.ForbiddenZeroBit == 0 and n.RefIdc == 3 for n in nals)
+    # 3- and 4-byte start codes, trailing zeros, leading garbage zeros
+    raw = b"\x00\x00\x00" + b"\x00\x00\x01\x67\x42\x00" + b"\x00\x00\x00\x01\x68\xce\x00\x00" + b"\x00\x00\x01\x65\x88\x80"
+    n2 = H.read_nal_units(raw)
+    assert [(n.Type, n.NumBytes) for n in n2] == [(7, 2), (8, 2), (5, 3)]
+    # emulation prevention: 00 00 03 xx -> 00 00 xx
+    nu = H.NewNalUnit(bytes([0x65, 0x00, 0x00, 0x03, 0x01, 0xAA, 0x00, 0x00, 0x03, 0x00, 0x00, 0x03, 0x02]))
+    assert nu.RBSP() == bytes([0x00, 0x00, 0x01, 0xAA, 0x00, 0x00, 0x00, 0x00, 0x02])
+    assert H.read_nal_units(b"") == [] and H.read_nal_units(b"\x00\x00") == []
+
+
+def test_real_sps_pps_known_fields(H):
+    """The SPS/PPS of the third-party sample analysed by hand in SURVEY.md Appendix C."""
+    sps = H.NewSPS(bytes.fromhex("640028ac2b40a0fd00f1226a"))
+    assert (sps.Profile, sps.Level, sps.ChromaFormat) == (100, 40, 1)
+    assert sps.Log2MaxFrameNumMinus4 == 4 and sps.PicOrderCountType == 2 and sps.MaxNumRefFrames == 1
+    assert (sps.PicWidthInMbsMinus1 + 1, sps.PicHeightInMapUnitsMinus1 + 1) == (20, 15) and sps.FrameMbsOnly == 1
+    assert (sps.width, sps.height) == (320, 240)
+    pps = H.NewPPS(sps, bytes.fromhex("ee025cb0"))
+    assert pps.EntropyCodingMode == 1 and pps.PicInitQpMinus26 == 9 and pps.DeblockingFilterControlPresent == 1 and pps.Transform8x8Mode == 1
+
+
+def test_headers_match_oracle(H, sg, oracle_mod):
+    """Every SPS / PPS / slice header field the product parses equals the oracle's value."""
+    from oracle import lib as olib
+    O = olib()
+
+    class OSH(ctypes.Structure):
+        pass
+    for name, kw in (("hi", dict(width=180, height=100, frames=3, idr_period=0, profile_idc=100, cabac=1, transform8x8=1, slices=2, scaling_matrix=1)),
+                     ("wp", dict(width=64, height=48, frames=4, idr_period=0, profile_idc=77, cabac=1, weighted_pred=1, num_ref_frames=2, poc_type=0))):
+        stream, _, _ = sg.encode(**kw)
+        nals = H.read_nal_units(stream)
+        sps = H.NewSPS(nals[0].RBSP())
+        pps = H.NewPPS(sps, nals[1].RBSP())
+        assert sps.width == kw["width"] and sps.height == kw["height"]
+        assert sps.PicWidthInMbsMinus1 == (kw["width"] + 15) // 16 - 1
+        assert pps.Transform8x8Mode == kw.get("transform8x8", 0) and pps.WeightedPred == kw.get("weighted_pred", 0)
+        if kw.get("scaling_matrix"):
+            assert list(sps.scaling_list_4x4[0]) == [6, 13, 13, 20, 20, 20, 28, 28, 28, 28, 32, 32, 32, 37, 37, 42]
+            assert list(sps.scaling_list_4x4[5]) == [10, 14, 14, 20, 20, 20, 24, 24, 24, 24, 27, 27, 27, 30, 30, 34]
+            assert list(pps.scaling_list_8x8[1][:6]) == [9, 13, 13, 15, 13, 15]
+        vs = H.VideoStream(sps, pps)
+        fn = 0
+        for n in nals[2:]:
+            sc = H.NewSliceContext(vs, n, n.RBSP())
+            h = sc.Slice.Header
+            assert h.SliceType in (5, 7) and h.PPSID == 0
+            assert h.slice_data_bit_offset > 0 and h.SliceQPy == 26 + pps.PicInitQpMinus26 + h.SliceQpDelta
+            if n.Type == 5:
+                fn = 0
+            if h.FirstMbInSlice == 0 and n.Type != 5:
+                fn += 1
+            assert h.FrameNum == fn
+            if kw.get("weighted_pred") and h.SliceType == 5:
+                assert h.LumaLog2WeightDenom == 5 and h.ChromaLog2WeightDenom == 4
+
+
+def test_malformed_inputs_return_status_codes(H):
+    with pytest.raises(H.H264MIError):
+        H.NewSPS(b"")
+    with pytest.raises(H.H264MIError):
+        H.NewSPS(b"\x64")
+    sps = H.NewSPS(bytes.fromhex("640028ac2b40a0fd00f1226a"))
+    with pytest.raises(H.H264MIError):
+        H.NewPPS(sps, b"")
+    # B slice: valid H.264 outside the implemented scope -> H264MI_EUNSUPPORTED (-3)
+    pps = H.NewPPS(sps, bytes.fromhex("ee025cb0"))
+    vs = H.VideoStream(sps, pps)
+    nal = H.NewNalUnit(bytes([0x41]) + bytes([0b10100110, 0x00, 0x00]))  # first_mb 0, slice_type ue=1 (B)
+    with pytest.raises(H.H264MIError) as ei:
+        H.NewSliceContext(vs, nal, nal.RBSP())
+    assert ei.value.code in (-3, -2)

@@ -1,0 +1,98 @@
+"""CPU tests of the oracle: closed-loop round trips against the stream generator's independent
+reconstruction, syntax coverage of the synthetic matrix, and a third-party real stream."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import MATRIX
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "stream_md5.json")
+
+
+@pytest.mark.parametrize("name", sorted(MATRIX))
+def test_roundtrip_oracle_equals_generator(name, sg, oracle_mod):
+    """Bit-exact: oracle decode == generator reconstruction (two independently written recon paths)."""
+    stream, rec, _ = sg.encode(**MATRIX[name])
+    out, info = oracle_mod.decode(stream, crop=False)
+    assert out.shape == rec.shape
+    assert np.array_equal(out, rec)
+    assert info.n_frames == MATRIX[name]["frames"]
+
+
+def test_golden_md5(sg, oracle_mod):
+    """Committed fixtures: MD5 of every synthetic stream and of its decoded frames
+    (tests/golden/make_golden.py regenerates them)."""
+    gold = json.load(open(GOLDEN))
+    for name, g in gold.items():
+        stream, _, _ = sg.encode(**MATRIX[name])
+        assert hashlib.md5(stream).hexdigest() == g["stream_md5"], name
+        out, _ = oracle_mod.decode(stream, crop=False)
+        assert hashlib.md5(out.tobytes()).hexdigest() == g["frames_md5"], name
+
+
+def test_matrix_exercises_the_syntax(sg, oracle_mod):
+    """The matrix must actually contain every macroblock type / feature it claims to test."""
+    seen = set()
+    feats = set()
+    for name, kw in MATRIX.items():
+        stream, _, _ = sg.encode(**kw)
+        _, info, tr = oracle_mod.decode(stream, crop=False, trace=True)
+        cab = kw.get("cabac", 0)
+        for raw, cbp, qp, mode, t8, mvx, mvy, ref in tr:
+            seen.add(("skip" if raw == -1 else int(raw), cab))
+            if t8:
+                feats.add(("t8x8", cab))
+            if ref > 0:
+                feats.add(("ref>0", cab))
+            if mvx & 3 or mvy & 3:
+                feats.add(("qpel", cab))
+    for cab in (0, 1):
+        for raw in ("skip", 0, 1, 2, 3, 25, 30):  # P16x16/I_NxN, 16x8/I16, 8x16, P8x8, I_PCM (I and P slices)
+            assert (raw, cab) in seen, (raw, cab)
+        for f in ("t8x8", "ref>0", "qpel"):
+            assert (f, cab) in feats, (f, cab)
+
+
+def test_crop(sg, oracle_mod):
+    stream, rec, _ = sg.encode(width=180, height=100, frames=2, idr_period=0, profile_idc=77, cabac=1)
+    out, info = oracle_mod.decode(stream, crop=True)
+    assert (info.width, info.height, info.coded_width, info.coded_height) == (180, 100, 192, 112)
+    full = rec[0][:192 * 112].reshape(112, 192)
+    assert np.array_equal(out[0][:180 * 100].reshape(100, 180), full[:100, :180])
+
+
+def test_truncated_stream_is_an_error_not_a_crash(sg, oracle_mod):
+    stream, _, _ = sg.encode(width=64, height=48, frames=2, idr_period=0, profile_idc=77, cabac=1)
+    for cut in (len(stream) // 2, len(stream) - 7, 40):
+        try:
+            oracle_mod.decode(stream[:cut], crop=False)
+        except oracle_mod.OracleError:
+            pass  # an error is fine; a crash is not
+
+
+def test_empty_stream(oracle_mod):
+    out, info = oracle_mod.decode(b"", crop=False)
+    assert info.n_frames == 0
+
+
+def test_real_x264_stream_self_synchronises(real_stream, oracle_mod):
+    """Third-party High-profile CABAC stream (x264, 8x8 transform, deblocking): every slice must decode
+    exactly PicSizeInMbs macroblocks and end on end_of_slice_flag -- any error in the context tables,
+    binarisations or ctxIdxInc rules desynchronises the arithmetic decoder long before that."""
+    out, info = oracle_mod.decode(real_stream, crop=True)
+    assert (info.width, info.height) == (320, 240)
+    assert info.n_frames == 36
+    assert info.n_mbs == 36 * 300
+    # drift check: with a wrong transform / MC / deblock the P-frame chain diverges visibly
+    y = out[:, :320 * 240].astype(np.int32)
+    step = np.abs(y[1:] - y[:-1]).mean(axis=1)
+    assert step.max() < 12.0, step
+    # blockiness: mean |gradient| across 16-pixel MB boundaries must not exceed the interior gradient by much
+    last = y[-1].reshape(240, 320)
+    gx = np.abs(np.diff(last, axis=1))
+    on_edge = gx[:, 15::16].mean()
+    interior = np.delete(gx, np.s_[15::16], axis=1).mean()
+    assert on_edge < 1.5 * interior + 1.0, (on_edge, interior)
