@@ -1,0 +1,234 @@
+// Package h264 -- cgo shim that keeps the exported names of mrmod/h264decode's package h264
+// (h264/nalUnit.go, h264/sps.go, h264/pps.go, h264/slice.go) on top of libh264mi.so.
+//
+// UNVERIFIED: the build image has no Go toolchain; this file was written against the cgo rules and
+// the C header include/h264mi.h but has never been compiled.  The same ABI is exercised from
+// Python ctypes by the test-suite.
+package h264
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../h264decode_amd -lh264mi -Wl,-rpath,${SRCDIR}/../../h264decode_amd
+#include <stdlib.h>
+#include "h264mi.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"log"
+	"os"
+	"unsafe"
+)
+
+var logger = log.New(os.Stderr, "streamer ", log.Lshortfile|log.Lmicroseconds) // h264/server.go:25-27
+
+func status(rc C.int32_t) error {
+	if rc == 0 {
+		return nil
+	}
+	return fmt.Errorf("h264mi %d: %s", int(rc), C.GoString(C.h264mi_last_error_string()))
+}
+
+func bptr(b []byte) *C.uint8_t {
+	if len(b) == 0 {
+		return nil
+	}
+	return (*C.uint8_t)(unsafe.Pointer(&b[0]))
+}
+
+// NalUnit mirrors h264/nalUnit.go:3-30 (fields the C ABI carries).
+type NalUnit struct {
+	NumBytes, ForbiddenZeroBit, RefIdc, Type     int
+	SvcExtensionFlag, Avc3dExtensionFlag         int
+	HeaderBytes                                  int
+	rbsp                                         []byte
+}
+
+func (n *NalUnit) RBSP() []byte { return n.rbsp } // h264/nalUnit.go:72
+
+// NewNalUnit: h264/nalUnit.go:75.
+func NewNalUnit(frame []byte, numBytesInNal int) *NalUnit {
+	var c C.h264mi_nal
+	rbsp := make([]byte, numBytesInNal)
+	var rl C.size_t
+	if err := status(C.h264mi_nal_parse(bptr(frame), C.size_t(numBytesInNal), &c, bptr(rbsp), &rl)); err != nil {
+		logger.Printf("NewNalUnit: %v", err)
+		return &NalUnit{}
+	}
+	return &NalUnit{NumBytes: int(c.num_bytes), ForbiddenZeroBit: int(c.forbidden_zero_bit), RefIdc: int(c.ref_idc), Type: int(c._type),
+		SvcExtensionFlag: int(c.svc_extension_flag), Avc3dExtensionFlag: int(c.avc_3d_extension_flag), HeaderBytes: int(c.header_bytes), rbsp: rbsp[:int(rl)]}
+}
+
+// ReadNalUnits replaces the readNalUnit loop (h264/server.go:64-111).
+func ReadNalUnits(stream []byte) ([]*NalUnit, error) {
+	capN := 1024
+	for {
+		arr := make([]C.h264mi_nal, capN)
+		var n C.int32_t
+		rc := C.h264mi_annexb_scan(bptr(stream), C.size_t(len(stream)), &arr[0], C.int32_t(capN), &n)
+		if rc == C.H264MI_ECAPACITY {
+			capN *= 4
+			continue
+		}
+		if err := status(rc); err != nil {
+			return nil, err
+		}
+		out := make([]*NalUnit, 0, int(n))
+		for i := 0; i < int(n); i++ {
+			off, size := int(arr[i].offset), int(arr[i].num_bytes)
+			out = append(out, NewNalUnit(stream[off:off+size], size))
+		}
+		return out, nil
+	}
+}
+
+// SPS mirrors h264/sps.go:9-103 (subset shown; the remaining fields copy the same way).
+type SPS struct {
+	c                                                C.h264mi_sps
+	Profile, Level, ID, ChromaFormat                 int
+	Log2MaxFrameNumMinus4, PicOrderCountType         int
+	Log2MaxPicOrderCntLSBMin4, MaxNumRefFrames       int
+	PicWidthInMbsMinus1, PicHeightInMapUnitsMinus1   int
+	FrameMbsOnly, Direct8x8Inference, FrameCropping  bool
+	FrameCropLeftOffset, FrameCropRightOffset        int
+	FrameCropTopOffset, FrameCropBottomOffset        int
+	Width, Height                                    int
+}
+
+func NewSPS(rbsp []byte, showPacket bool) *SPS { // h264/sps.go:192
+	s := &SPS{}
+	if err := status(C.h264mi_sps_parse(bptr(rbsp), C.size_t(len(rbsp)), &s.c)); err != nil {
+		logger.Printf("NewSPS: %v", err)
+		return s
+	}
+	c := &s.c
+	s.Profile, s.Level, s.ID, s.ChromaFormat = int(c.profile), int(c.level), int(c.id), int(c.chroma_format)
+	s.Log2MaxFrameNumMinus4, s.PicOrderCountType = int(c.log2_max_frame_num_minus4), int(c.pic_order_count_type)
+	s.Log2MaxPicOrderCntLSBMin4, s.MaxNumRefFrames = int(c.log2_max_pic_order_cnt_lsb_min4), int(c.max_num_ref_frames)
+	s.PicWidthInMbsMinus1, s.PicHeightInMapUnitsMinus1 = int(c.pic_width_in_mbs_minus1), int(c.pic_height_in_map_units_minus1)
+	s.FrameMbsOnly, s.Direct8x8Inference, s.FrameCropping = c.frame_mbs_only != 0, c.direct_8x8_inference != 0, c.frame_cropping != 0
+	s.FrameCropLeftOffset, s.FrameCropRightOffset = int(c.frame_crop_left_offset), int(c.frame_crop_right_offset)
+	s.FrameCropTopOffset, s.FrameCropBottomOffset = int(c.frame_crop_top_offset), int(c.frame_crop_bottom_offset)
+	s.Width, s.Height = int(c.width), int(c.height)
+	return s
+}
+
+// PPS mirrors h264/pps.go:10-38.
+type PPS struct {
+	c                                              C.h264mi_pps
+	ID, SPSID, EntropyCodingMode                   int
+	NumRefIdxL0DefaultActiveMinus1                 int
+	WeightedPred                                   bool
+	PicInitQpMinus26, ChromaQpIndexOffset          int
+	DeblockingFilterControlPresent                 bool
+	ConstrainedIntraPred                           bool
+	Transform8x8Mode, SecondChromaQpIndexOffset    int
+}
+
+func NewPPS(sps *SPS, rbsp []byte, showPacket bool) *PPS { // h264/pps.go:40
+	p := &PPS{}
+	if err := status(C.h264mi_pps_parse(&sps.c, bptr(rbsp), C.size_t(len(rbsp)), &p.c)); err != nil {
+		logger.Printf("NewPPS: %v", err)
+		return p
+	}
+	c := &p.c
+	p.ID, p.SPSID, p.EntropyCodingMode = int(c.id), int(c.sps_id), int(c.entropy_coding_mode)
+	p.NumRefIdxL0DefaultActiveMinus1, p.WeightedPred = int(c.num_ref_idx_l0_default_active_minus1), c.weighted_pred != 0
+	p.PicInitQpMinus26, p.ChromaQpIndexOffset = int(c.pic_init_qp_minus26), int(c.chroma_qp_index_offset)
+	p.DeblockingFilterControlPresent, p.ConstrainedIntraPred = c.deblocking_filter_control_present != 0, c.constrained_intra_pred != 0
+	p.Transform8x8Mode, p.SecondChromaQpIndexOffset = int(c.transform_8x8_mode), int(c.second_chroma_qp_index_offset)
+	return p
+}
+
+// SliceHeader mirrors h264/slice.go:23-75 (subset).
+type SliceHeader struct {
+	FirstMbInSlice, SliceType, PPSID, FrameNum, IDRPicID, PicOrderCntLsb int
+	NumRefIdxL0ActiveMinus1, CabacInit, SliceQpDelta                     int
+	DisableDeblockingFilter, SliceAlphaC0OffsetDiv2, SliceBetaOffsetDiv2 int
+	SliceQPy                                                             int
+}
+type Slice struct{ Header *SliceHeader }
+type VideoStream struct { // h264/slice.go:8-12
+	SPS    *SPS
+	PPS    *PPS
+	Slices []*SliceContext
+}
+type SliceContext struct { // h264/slice.go:13-18
+	*NalUnit
+	*SPS
+	*PPS
+	*Slice
+}
+
+func NewSliceContext(vs *VideoStream, nal *NalUnit, rbsp []byte, showPacket bool) *SliceContext { // h264/slice.go:835
+	var c C.h264mi_slice_header
+	if err := status(C.h264mi_slice_header_parse(&vs.SPS.c, &vs.PPS.c, C.int32_t(nal.RefIdc), C.int32_t(nal.Type), bptr(rbsp), C.size_t(len(rbsp)), &c)); err != nil {
+		logger.Printf("NewSliceContext: %v", err)
+		return &SliceContext{NalUnit: nal, SPS: vs.SPS, PPS: vs.PPS, Slice: &Slice{Header: &SliceHeader{}}}
+	}
+	h := &SliceHeader{FirstMbInSlice: int(c.first_mb_in_slice), SliceType: int(c.slice_type), PPSID: int(c.pps_id), FrameNum: int(c.frame_num),
+		IDRPicID: int(c.idr_pic_id), PicOrderCntLsb: int(c.pic_order_cnt_lsb), NumRefIdxL0ActiveMinus1: int(c.num_ref_idx_l0_active_minus1),
+		CabacInit: int(c.cabac_init), SliceQpDelta: int(c.slice_qp_delta), DisableDeblockingFilter: int(c.disable_deblocking_filter),
+		SliceAlphaC0OffsetDiv2: int(c.slice_alpha_c0_offset_div2), SliceBetaOffsetDiv2: int(c.slice_beta_offset_div2), SliceQPy: int(c.slice_qp_y)}
+	return &SliceContext{NalUnit: nal, SPS: vs.SPS, PPS: vs.PPS, Slice: &Slice{Header: h}}
+}
+
+// ---- additive API: batched GPU decode (the reference has no pixel type) ----
+
+type Config struct {
+	Device, MaxStreams, MaxWidth, MaxHeight, MaxFramesPerBatch, MaxSlicesPerFrame int
+	MaxBitstreamBytes                                                              int64
+}
+type Decoder struct{ h *C.h264mi_decoder }
+type BatchInfo struct {
+	Frames, Slices             int
+	Width, Height              int
+	CodedWidth, CodedHeight    int
+}
+
+func NewDecoder(cfg Config) (*Decoder, error) {
+	c := C.h264mi_config{device: C.int32_t(cfg.Device), max_streams: C.int32_t(cfg.MaxStreams), max_width: C.int32_t(cfg.MaxWidth),
+		max_height: C.int32_t(cfg.MaxHeight), max_frames_per_batch: C.int32_t(cfg.MaxFramesPerBatch),
+		max_slices_per_frame: C.int32_t(cfg.MaxSlicesPerFrame), max_bitstream_bytes: C.int64_t(cfg.MaxBitstreamBytes)}
+	d := &Decoder{}
+	if err := status(C.h264mi_decoder_create(&c, &d.h)); err != nil {
+		return nil, err
+	}
+	return d, nil
+}
+func (d *Decoder) Close() { C.h264mi_decoder_destroy(d.h); d.h = nil }
+
+// DecodeBatch: one Annex-B chunk (whole access units) per stream.  The chunks are copied into C
+// memory for the duration of the call (cgo forbids passing Go memory that holds Go pointers).
+func (d *Decoder) DecodeBatch(chunks [][]byte) (BatchInfo, error) {
+	n := len(chunks)
+	ptrs := (*[1 << 28]*C.uint8_t)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(uintptr(0)))))[:n:n]
+	lens := (*[1 << 28]C.size_t)(C.malloc(C.size_t(n) * C.size_t(unsafe.Sizeof(C.size_t(0)))))[:n:n]
+	defer C.free(unsafe.Pointer(&ptrs[0]))
+	defer C.free(unsafe.Pointer(&lens[0]))
+	for i, b := range chunks {
+		ptrs[i] = (*C.uint8_t)(C.CBytes(b))
+		lens[i] = C.size_t(len(b))
+		defer C.free(unsafe.Pointer(ptrs[i]))
+	}
+	var info C.h264mi_batch_info
+	if err := status(C.h264mi_decode_batch(d.h, C.int32_t(n), &ptrs[0], &lens[0], &info)); err != nil {
+		return BatchInfo{}, err
+	}
+	return BatchInfo{Frames: int(info.n_frames), Slices: int(info.n_slices), Width: int(info.width), Height: int(info.height),
+		CodedWidth: int(info.coded_width), CodedHeight: int(info.coded_height)}, nil
+}
+
+// FrameRead returns tight I420 (Y, Cb, Cr back to back).
+func (d *Decoder) FrameRead(stream, frame int, crop bool, w, h int) ([]byte, error) {
+	buf := make([]byte, w*h*3/2)
+	cr := 0
+	if crop {
+		cr = 1
+	}
+	if err := status(C.h264mi_frame_read(d.h, C.int32_t(stream), C.int32_t(frame), C.int32_t(cr), bptr(buf), C.size_t(len(buf)))); err != nil {
+		return nil, err
+	}
+	return buf, nil
+}
