@@ -23,7 +23,7 @@
 #include <hip/hip_runtime.h>
 #include "mi_kernels.h"
 
-#define RING_WORDS 1024
+#define RING_WORDS 512
 #define LANE (static_cast<int>(threadIdx.x))
 #define FI __device__ __forceinline__
 
@@ -41,12 +41,16 @@ static_assert(sizeof(TopInfo) == 48, "TopInfo layout");
 struct Shared {
     uint32_t ring[RING_WORDS];
     uint8_t ctx[464];
+#if !MI_SCALAR_CABAC
+    uint2 lps[128]; // per state s=(pStateIdx<<1|valMPS): .x = rangeTabLPS[p][0..3] packed, .y = next(MPS) | next(LPS)<<8
+#endif
     uint8_t posmap[4][64]; // scan index -> position: [0] zig-zag 4x4, [1] zig-zag 4x4 of AC index (k+1), [2] zig-zag 8x8, [3] identity
     uint8_t incmap[3][64]; // ctxIdxInc of significant_coeff_flag: [0] identity, [1] min(i,2) (chroma DC), [2] Table 9-43 8x8
     uint8_t lastmap[64];   // ctxIdxInc of last_significant_coeff_flag for 8x8 blocks
     int16_t coef[MI_COEF_PER_MB];
     MbRec rec;
     TopInfo left, tl; // tl = top[] entry of column x-1 as it was for the row above
+    TopInfo topw[2];  // LDS window on the row-above state: [0] = column x, [1] = column x+1 (the row itself lives in HBM)
     // Neighbour caches of the current MB.  6-wide grids: column 0 = left MB, 1..4 = current MB,
     // 5 = right / top-right; row 0 = MB row above, rows 1..4 = current MB.
     int8_t ipm_c[32];      // -2 unavailable, -1 not (yet) an I_NxN block
@@ -67,7 +71,8 @@ struct Shared {
 
 struct Ent {
     Shared *s;
-    TopInfo *top; // [wmb]
+    TopInfo *top; // [wmb] row-above state of this slice, in global memory (read with L1-bypassing loads)
+    uint32_t pre_top; // lanes 0..11: prefetched dwords of top[mbx + 2]
     const DevTables *tab;
     const uint8_t *rbsp;
     const SliceDesc *sd;
@@ -96,16 +101,13 @@ __constant__ uint16_t c_cat[6][8] = {
 
 // ------------------------------------------------------------------ bitstream ring
 FI void ring_fill(Ent &e) {
-    // 512 words = 2 KB per call: each lane loads 32 bytes; words are byte-swapped to MSB-first order
-    uint32_t base = e.filled + LANE * 8;
-    const uint4 *src = reinterpret_cast<const uint4 *>(e.rbsp) + (base >> 2);
-    uint4 a = make_uint4(0, 0, 0, 0), b = a;
-    if (base < e.rbsp_words) a = src[0];
-    if (base + 4 < e.rbsp_words) b = src[1];
+    // 256 words = 1 KB per call: each lane loads 16 bytes; words are byte-swapped to MSB-first order
+    uint32_t base = e.filled + LANE * 4;
+    uint4 a = make_uint4(0, 0, 0, 0);
+    if (base < e.rbsp_words) a = *(reinterpret_cast<const uint4 *>(e.rbsp) + (base >> 2));
     uint32_t *dst = e.s->ring + (base & (RING_WORDS - 1));
     dst[0] = __builtin_bswap32(a.x), dst[1] = __builtin_bswap32(a.y), dst[2] = __builtin_bswap32(a.z), dst[3] = __builtin_bswap32(a.w);
-    dst[4] = __builtin_bswap32(b.x), dst[5] = __builtin_bswap32(b.y), dst[6] = __builtin_bswap32(b.z), dst[7] = __builtin_bswap32(b.w);
-    e.filled += 512;
+    e.filled += 256;
     __syncthreads();
 }
 // keep at least 128 words (4096 bits) resident beyond the cursor
@@ -152,7 +154,14 @@ FI int get_se(Ent &e) {
 // The engine is scalar: range / value / avail live in SGPRs (every LDS result goes through
 // readfirstlane), and Tables 9-44 / 9-45 are held one state per lane in two VGPRs and looked up
 // with v_readlane, so a decision costs ONE LDS round trip (the context state) instead of three.
+#ifndef MI_SCALAR_CABAC
+#define MI_SCALAR_CABAC 1
+#endif
+#if MI_SCALAR_CABAC
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define RFL(x) (x)
+#endif
 FI uint32_t speek32(const Ent &e, uint32_t pos) {
     const uint32_t w = pos >> 5, sh = pos & 31;
     const uint32_t hi = RFL(e.s->ring[w & (RING_WORDS - 1)]), lo = RFL(e.s->ring[(w + 1) & (RING_WORDS - 1)]);
@@ -173,6 +182,7 @@ FI void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
     cabac_refill(e);
 }
 // DecodeDecision (h264/cabac.go:521-540) + state transition (:544-553) + RenormD (:503-511)
+#if MI_SCALAR_CABAC
 FI int cabac_bin(Ent &e, int ctx) {
     const uint32_t st = RFL(static_cast<uint32_t>(e.s->ctx[ctx]));
     const uint32_t p = st >> 1, mps = st & 1;
@@ -193,6 +203,24 @@ FI int cabac_bin(Ent &e, int ctx) {
     cabac_refill(e);
     return static_cast<int>(mps ^ static_cast<uint32_t>(lps));
 }
+#else
+FI int cabac_bin(Ent &e, int ctx) { // vector form: merged Table 9-44/9-45 entry read from LDS
+    const uint32_t st = e.s->ctx[ctx];
+    const uint2 t = e.s->lps[st];
+    const uint32_t rlps = (t.x >> (((e.range >> 6) & 3) * 8)) & 255;
+    const uint32_t rmps = e.range - rlps;
+    const uint32_t scaled = rmps << e.avail;
+    const bool lps = e.value >= scaled;
+    e.value -= lps ? scaled : 0;
+    e.range = lps ? rlps : rmps;
+    e.s->ctx[ctx] = static_cast<uint8_t>(lps ? (t.y >> 8) : (t.y & 255));
+    const int n = __builtin_clz(e.range) - 23;
+    e.range <<= n;
+    e.avail -= n;
+    cabac_refill(e);
+    return static_cast<int>((st & 1) ^ static_cast<uint32_t>(lps));
+}
+#endif
 FI int cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
     e.avail -= 1;
     const uint32_t scaled = e.range << e.avail;
@@ -226,7 +254,12 @@ FI int cabac_egk(Ent &e, int k) {
 
 // ------------------------------------------------------------------ neighbour MBs
 FI const TopInfo *mbA(const Ent &e) { return e.s->left.type != MBT_NONE ? &e.s->left : nullptr; }
-FI const TopInfo *mbB(const Ent &e) { return e.top[e.mbx].type != MBT_NONE ? &e.top[e.mbx] : nullptr; }
+FI const TopInfo *mbB(const Ent &e) { return e.s->topw[0].type != MBT_NONE ? &e.s->topw[0] : nullptr; }
+FI const TopInfo *mbC(const Ent &e) { return (e.mbx + 1 < e.wmb && e.s->topw[1].type != MBT_NONE) ? &e.s->topw[1] : nullptr; }
+// L1-bypassing dword load of the row-above array (it is rewritten by this wave one row later)
+FI uint32_t top_load(const Ent &e, int col, int dw) {
+    return col < e.wmb ? __hip_atomic_load(reinterpret_cast<const uint32_t *>(e.top + col) + dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
 
 // ------------------------------------------------------------------ residual blocks
 // residual_block_cabac 7.3.5.3.3 for ctxBlockCat `cat`; coefficients are written de-zig-zagged.
@@ -513,7 +546,7 @@ FI void set_part(Ent &e, int bx, int by, int w, int h, int ref, int mvx, int mvy
 FI void fill_caches(Ent &e) {
     Shared *s = e.s;
     const TopInfo *a = mbA(e), *b = mbB(e);
-    const TopInfo *c = (e.mbx + 1 < e.wmb && e.top[e.mbx + 1].type != MBT_NONE) ? &e.top[e.mbx + 1] : nullptr;
+    const TopInfo *c = mbC(e);
     const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
     const int cip = e.pd->cip;
     const int l = LANE;
@@ -869,7 +902,7 @@ FI void decode_mb(Ent &e, int skipped) {
         // neighbour availability for intra prediction (6.4.x; constrained_intra_pred 8.3.1.2)
         const int cip = e.pd->cip;
         int av = 0;
-        const TopInfo *c = (e.mbx + 1 < e.wmb && e.top[e.mbx + 1].type != MBT_NONE) ? &e.top[e.mbx + 1] : nullptr;
+        const TopInfo *c = mbC(e);
         const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
         if (a && !(cip && MB_IS_INTER(a->type))) av |= MI_AV_LEFT;
         if (b && !(cip && MB_IS_INTER(b->type))) av |= MI_AV_TOP;
@@ -895,8 +928,8 @@ FI void decode_mb(Ent &e, int skipped) {
         r.ref[i] = static_cast<int8_t>(ref);
         r.refslot[i] = ref >= 0 ? e.sd->ref_slot[ref] : static_cast<int16_t>(-1);
     }
-    // remember the top[] entry of this column for the next MB's top-left neighbour, then replace it
-    TopInfo *tp = &e.top[e.mbx];
+    // remember the row-above entry of this column for the next MB's top-left neighbour, then build the new one
+    TopInfo *tp = &s->topw[0];
     if (l >= 32 && l < 44) reinterpret_cast<uint32_t *>(&s->tl)[l - 32] = reinterpret_cast<const uint32_t *>(tp)[l - 32];
     __syncthreads();
     if (l < 2) {
@@ -923,6 +956,15 @@ FI void decode_mb(Ent &e, int skipped) {
         TopInfo *dst = is_left ? &s->left : tp;
         dst->nnz[4 + cpl * 2 + k] = is_left ? s->nnzc_c[cpl][(k + 1) * 3 + 2] : s->nnzc_c[cpl][2 * 3 + k + 1];
     }
+    __syncthreads();
+    // new entry -> HBM row; slide the LDS window: [0] <- [1], [1] <- prefetched column x+2; prefetch x+3
+    if (l < 12) {
+        const uint32_t nw = reinterpret_cast<const uint32_t *>(tp)[l], w1 = reinterpret_cast<const uint32_t *>(&s->topw[1])[l];
+        reinterpret_cast<uint32_t *>(e.top + e.mbx)[l] = nw;
+        reinterpret_cast<uint32_t *>(&s->topw[0])[l] = w1;
+        reinterpret_cast<uint32_t *>(&s->topw[1])[l] = e.pre_top;
+        e.pre_top = top_load(e, e.mbx + 3, l);
+    }
     const uint64_t mbi = e.pd->mb_base + static_cast<uint64_t>(e.mby) * e.wmb + e.mbx;
     if (l >= 32) // MbRec: 128 bytes = 32 dwords, lanes 32..63
         reinterpret_cast<uint32_t *>(e.mbrec + mbi)[l - 32] = reinterpret_cast<const uint32_t *>(&r)[l - 32];
@@ -933,13 +975,13 @@ FI void decode_mb(Ent &e, int skipped) {
 }
 
 // ------------------------------------------------------------------ kernel: slice_data() 7.3.4
-extern "C" __global__ void __launch_bounds__(64) k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
-                                                           int16_t *coefs, uint32_t *status, int wmb_max) {
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
+                                                           int16_t *coefs, uint32_t *status, uint32_t *toprows, int wmb_max) {
     __shared__ Shared sh;
-    extern __shared__ uint32_t dyn[];
     Ent e;
     e.s = &sh;
-    e.top = reinterpret_cast<TopInfo *>(dyn);
+    e.top = reinterpret_cast<TopInfo *>(toprows + static_cast<size_t>(blockIdx.x) * wmb_max * 12);
+    e.pre_top = 0;
     e.tab = tab;
     e.sd = &slices[blockIdx.x];
     e.pd = &pics[e.sd->pic_idx];
@@ -964,6 +1006,15 @@ extern "C" __global__ void __launch_bounds__(64) k_entropy(const SliceDesc *slic
         e.v_rlps = rl[0] | (rl[1] << 8) | (rl[2] << 16) | (static_cast<uint32_t>(rl[3]) << 24);
         e.v_trans = tab->trans_lps[l];
     }
+#if !MI_SCALAR_CABAC
+    for (int st = l; st < 128; st += 64) {
+        const int p = st >> 1, mps = st & 1;
+        const uint8_t *rl = tab->range_lps[p];
+        const int pl = tab->trans_lps[p], pm = p < 62 ? p + 1 : p;
+        const int next_lps = (pl << 1) | (p == 0 ? mps ^ 1 : mps), next_mps = (pm << 1) | mps;
+        sh.lps[st] = make_uint2(rl[0] | (rl[1] << 8) | (rl[2] << 16) | (static_cast<uint32_t>(rl[3]) << 24), next_mps | (next_lps << 8));
+    }
+#endif
     sh.posmap[0][l] = tab->zigzag4[l & 15];
     sh.posmap[1][l] = tab->zigzag4[(l + 1) & 15];
     sh.posmap[2][l] = tab->zigzag8[l];
@@ -977,11 +1028,12 @@ extern "C" __global__ void __launch_bounds__(64) k_entropy(const SliceDesc *slic
         const uint8_t *src = tab->ctx_init[set][e.sd->slice_qp];
         for (int i = l; i < 464; i += 64) sh.ctx[i] = src[i];
     }
-    for (int i = l; i < e.wmb * 12; i += 64) dyn[i] = 0; // all top[] entries: type NONE
+    for (int i = l; i < e.wmb * 12; i += 64) reinterpret_cast<uint32_t *>(e.top)[i] = 0; // all row-above entries: type NONE
     if (l < 12) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
+    if (l < 24) reinterpret_cast<uint32_t *>(&sh.topw[0])[l] = 0;
     __syncthreads();
     // start at the ring chunk containing the first slice_data bit
-    e.filled = (e.bitpos >> 5) & ~511u;
+    e.filled = (e.bitpos >> 5) & ~255u;
     ring_fill(e);
     ring_fill(e);
     if (e.cabac) {
@@ -999,8 +1051,10 @@ extern "C" __global__ void __launch_bounds__(64) k_entropy(const SliceDesc *slic
             e.err = 30;
             break;
         }
-        if (e.mbx == 0) { // new MB row: no left / top-left neighbour
+        if (e.mbx == 0 || n_mbs == 0) { // new MB row (or slice start): no left / top-left neighbour; (re)load the row-above window
             if (l < 12) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
+            if (l < 24) reinterpret_cast<uint32_t *>(&sh.topw[0])[l] = top_load(e, e.mbx + l / 12, l % 12);
+            if (l < 12) e.pre_top = top_load(e, e.mbx + 2, l);
             __syncthreads();
         }
         ensure(e);

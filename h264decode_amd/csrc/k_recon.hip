@@ -185,7 +185,12 @@ struct InterShared {
     ResBuf rb;
     uint8_t win_y[16][9][12];   // 9x9 luma window per 4x4 block, rows padded to 12 bytes
     uint8_t win_c[2][16][3][4]; // 3x3 chroma window per 2x2 chroma block
+    // uniform-motion fast path (all 16 blocks share one mv + reference, window inside the picture):
+    // one 21x21 luma / 9x9 chroma window for the whole macroblock, loaded as aligned dwords
+    uint8_t win16[21][24];
+    uint8_t winc16[2][9][12];
     MbRec rec;
+    int uniform;
 };
 
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
@@ -209,24 +214,55 @@ extern "C" __global__ void __launch_bounds__(64) k_inter(const uint32_t *pic_lis
     const int mbx = mb % wmb, mby = mb / wmb;
     const uint8_t *pool_base = reinterpret_cast<const uint8_t *>(pool->base);
     const size_t ysz = static_cast<size_t>(W) * H;
-    // ---- stage reference windows (coordinates clamped: 8.4.2.2.1 / 8.4.2.2.2) ----
-    for (int i = lane; i < 16 * 81; i += 64) {
-        int b = i / 81, rem = i - b * 81, wy = rem / 9, wx = rem - wy * 9;
-        int slot = rec->refslot[((b >> 3) << 1) | ((b & 3) >> 1)];
-        int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
-        int x = mbx * 16 + (b & 3) * 4 + (mvx >> 2) - 2 + wx, y = mby * 16 + (b >> 2) * 4 + (mvy >> 2) - 2 + wy;
-        x = min(max(x, 0), W - 1), y = min(max(y, 0), H - 1);
-        const uint8_t *ref = pool_base + static_cast<size_t>(slot < 0 ? 0 : slot) * pool->slot_bytes;
-        sh.win_y[b][wy][wx] = ref[static_cast<size_t>(y) * W + x];
-    }
-    for (int i = lane; i < 2 * 16 * 9; i += 64) {
-        int c = i / 144, rem = i - c * 144, b = rem / 9, r9 = rem - b * 9, wy = r9 / 3, wx = r9 - wy * 3;
-        int slot = rec->refslot[((b >> 3) << 1) | ((b & 3) >> 1)];
-        int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
-        int x = mbx * 8 + (b & 3) * 2 + (mvx >> 3) + wx, y = mby * 8 + (b >> 2) * 2 + (mvy >> 3) + wy;
-        x = min(max(x, 0), W / 2 - 1), y = min(max(y, 0), H / 2 - 1);
-        const uint8_t *ref = pool_base + static_cast<size_t>(slot < 0 ? 0 : slot) * pool->slot_bytes + ysz + static_cast<size_t>(c) * (ysz / 4);
-        sh.win_c[c][b][wy][wx] = ref[static_cast<size_t>(y) * (W / 2) + x];
+    // ---- stage reference windows (8.4.2.2.1 / 8.4.2.2.2) ----
+    // Fast path: P_L0_16x16 / P_Skip (or any MB whose 16 blocks share motion) whose displaced block
+    // lies inside the picture -> 126 + 54 aligned dword loads instead of 1584 clamped byte loads.
+    int ox = 0, ocx = 0;
+    {
+        const int mvx0 = rec->mv[0][0], mvy0 = rec->mv[0][1];
+        bool same = true;
+        if (lane < 16) same = rec->mv[lane][0] == mvx0 && rec->mv[lane][1] == mvy0 && rec->refslot[((lane >> 3) << 1) | ((lane & 3) >> 1)] == rec->refslot[0];
+        const int x0 = mbx * 16 + (mvx0 >> 2) - 2, y0 = mby * 16 + (mvy0 >> 2) - 2;
+        const int cx0 = mbx * 8 + (mvx0 >> 3), cy0 = mby * 8 + (mvy0 >> 3);
+        const bool inside = x0 >= 0 && y0 >= 0 && x0 + 20 <= W - 1 && y0 + 20 <= H - 1 && cx0 >= 0 && cy0 >= 0 && cx0 + 8 <= W / 2 - 1 && cy0 + 8 <= H / 2 - 1 &&
+                            rec->refslot[0] >= 0;
+        const int uniform = inside && __all(same);
+        if (uniform) {
+            const uint8_t *ref = pool_base + static_cast<size_t>(rec->refslot[0]) * pool->slot_bytes;
+            ox = x0 & 3;
+            const int xa = x0 - ox;
+            for (int i = lane; i < 21 * 6; i += 64) {
+                int r = i / 6, d = i - r * 6;
+                *reinterpret_cast<uint32_t *>(&sh.win16[r][d * 4]) = *reinterpret_cast<const uint32_t *>(ref + static_cast<size_t>(y0 + r) * W + xa + d * 4);
+            }
+            ocx = cx0 & 3;
+            const int cxa = cx0 - ocx;
+            if (lane < 54) {
+                int c = lane / 27, rem = lane - c * 27, r = rem / 3, d = rem - r * 3;
+                const uint8_t *cref = ref + ysz + static_cast<size_t>(c) * (ysz / 4);
+                *reinterpret_cast<uint32_t *>(&sh.winc16[c][r][d * 4]) = *reinterpret_cast<const uint32_t *>(cref + static_cast<size_t>(cy0 + r) * (W / 2) + cxa + d * 4);
+            }
+        } else {
+            for (int i = lane; i < 16 * 81; i += 64) {
+                int b = i / 81, rem = i - b * 81, wy = rem / 9, wx = rem - wy * 9;
+                int slot = rec->refslot[((b >> 3) << 1) | ((b & 3) >> 1)];
+                int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
+                int x = mbx * 16 + (b & 3) * 4 + (mvx >> 2) - 2 + wx, y = mby * 16 + (b >> 2) * 4 + (mvy >> 2) - 2 + wy;
+                x = min(max(x, 0), W - 1), y = min(max(y, 0), H - 1);
+                const uint8_t *ref = pool_base + static_cast<size_t>(slot < 0 ? 0 : slot) * pool->slot_bytes;
+                sh.win_y[b][wy][wx] = ref[static_cast<size_t>(y) * W + x];
+            }
+            for (int i = lane; i < 2 * 16 * 9; i += 64) {
+                int c = i / 144, rem = i - c * 144, b = rem / 9, r9 = rem - b * 9, wy = r9 / 3, wx = r9 - wy * 3;
+                int slot = rec->refslot[((b >> 3) << 1) | ((b & 3) >> 1)];
+                int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
+                int x = mbx * 8 + (b & 3) * 2 + (mvx >> 3) + wx, y = mby * 8 + (b >> 2) * 2 + (mvy >> 3) + wy;
+                x = min(max(x, 0), W / 2 - 1), y = min(max(y, 0), H / 2 - 1);
+                const uint8_t *ref = pool_base + static_cast<size_t>(slot < 0 ? 0 : slot) * pool->slot_bytes + ysz + static_cast<size_t>(c) * (ysz / 4);
+                sh.win_c[c][b][wy][wx] = ref[static_cast<size_t>(y) * (W / 2) + x];
+            }
+        }
+        if (lane == 0) sh.uniform = uniform;
     }
     // ---- residual (independent of the prediction) ----
     if (rec->cbp)
@@ -242,10 +278,16 @@ extern "C" __global__ void __launch_bounds__(64) k_inter(const uint32_t *pic_lis
         const int b = lane >> 2, r = lane & 3;
         const int mvx = rec->mv[b][0], mvy = rec->mv[b][1], fx = mvx & 3, fy = mvy & 3;
         int p[6][9];
+        const int uni = sh.uniform;
+        // row j of this lane's 9x9 window: per-block window (stride 12) or the shared 21x21 one (stride 24, byte offset ox + 4*bx)
+        const int boff = uni ? ox + (b & 3) * 4 : 0;
+        const uint8_t *wbase = uni ? &sh.win16[(b >> 2) * 4 + r][(boff >> 2) * 4] : &sh.win_y[b][r][0];
+        const int wstride = uni ? 24 : 12, sh8 = (boff & 3) * 8;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            const uint32_t *row = reinterpret_cast<const uint32_t *>(sh.win_y[b][r + j]);
-            uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
+            const uint32_t *row = reinterpret_cast<const uint32_t *>(wbase + j * wstride);
+            uint64_t lo = row[0] | (static_cast<uint64_t>(row[1]) << 32), hi = row[1] | (static_cast<uint64_t>(row[2]) << 32);
+            uint32_t w0 = static_cast<uint32_t>(lo >> sh8), w1 = static_cast<uint32_t>(hi >> sh8), w2 = row[2] >> sh8;
             p[j][0] = w0 & 255, p[j][1] = (w0 >> 8) & 255, p[j][2] = (w0 >> 16) & 255, p[j][3] = w0 >> 24;
             p[j][4] = w1 & 255, p[j][5] = (w1 >> 8) & 255, p[j][6] = (w1 >> 16) & 255, p[j][7] = w1 >> 24;
             p[j][8] = w2 & 255;
@@ -300,12 +342,15 @@ extern "C" __global__ void __launch_bounds__(64) k_inter(const uint32_t *pic_lis
         const int b = (cy >> 1) * 4 + (cx >> 1);
         const int mvx = rec->mv[b][0], mvy = rec->mv[b][1], xf = mvx & 7, yf = mvy & 7;
         const int refidx = rec->ref[((b >> 3) << 1) | ((b & 3) >> 1)];
-        const uint8_t(*w)[4] = sh.win_c[c][b];
+        const int uni = sh.uniform;
+        // 3x3 window of this 2x2 chroma block: per-block (row stride 4) or inside the shared 9x9 one (row stride 12)
+        const uint8_t *w = uni ? &sh.winc16[c][cy & ~1][ocx + (cx & ~1)] : &sh.win_c[c][b][0][0];
+        const int cstride = uni ? 12 : 4;
         const int ry = cy & 1;
         uint32_t packed = 0;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            int A = w[ry][i], B = w[ry][i + 1], C = w[ry + 1][i], D = w[ry + 1][i + 1];
+            int A = w[ry * cstride + i], B = w[ry * cstride + i + 1], C = w[(ry + 1) * cstride + i], D = w[(ry + 1) * cstride + i + 1];
             int v = ((8 - xf) * (8 - yf) * A + xf * (8 - yf) * B + (8 - xf) * yf * C + xf * yf * D + 32) >> 6;
             if (wp) {
                 const int ld = sd->chroma_log2_denom, w0 = sd->wp_cw[refidx][c], o0 = sd->wp_co[refidx][c];

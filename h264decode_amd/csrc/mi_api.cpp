@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "../../include/h264mi.h"
@@ -137,6 +138,7 @@ struct h264mi_decoder {
     SliceDesc *d_slices = nullptr, *h_slices = nullptr;
     PicDesc *d_pics = nullptr, *h_pics = nullptr;
     uint32_t *d_status = nullptr, *h_status = nullptr, *d_lists = nullptr, *h_lists = nullptr;
+    uint32_t *d_toprows[MI_SETS] = {}; // entropy kernels' row-above neighbour state: 48 B per MB column per slice
     int slices_cap = 0, pics_cap = 0;
     // Passes are pipelined: the entropy kernels of passes n+1 / n+2 (two private streams, alternating)
     // overlap the reconstruction kernels of pass n (on `stream`); each pass owns one of MI_SETS
@@ -144,6 +146,8 @@ struct h264mi_decoder {
     MbRec *d_mbrec[MI_SETS] = {};
     int16_t *d_coef[MI_SETS] = {};
     hipStream_t ent_stream[2] = {nullptr, nullptr};
+    hipStream_t rec_stream = nullptr; // K3-K5; the caller's stream only brackets a pass with events
+    hipEvent_t ev_user = nullptr;
     hipEvent_t ev_ent[MI_SETS] = {}, ev_rec[MI_SETS] = {}, ev_upload = nullptr;
     uint64_t pass = 0; // execute() counter
     uint64_t mb_cap = 0, mb_used = 0;
@@ -216,12 +220,15 @@ static void free_all(h264mi_decoder *d) {
     for (int i = 0; i < MI_SETS; i++) {
         if (d->d_mbrec[i]) hipFree(d->d_mbrec[i]);
         if (d->d_coef[i]) hipFree(d->d_coef[i]);
+        if (d->d_toprows[i]) hipFree(d->d_toprows[i]);
         if (d->ev_ent[i]) hipEventDestroy(d->ev_ent[i]);
         if (d->ev_rec[i]) hipEventDestroy(d->ev_rec[i]);
     }
     if (d->ev_upload) hipEventDestroy(d->ev_upload);
     for (int i = 0; i < 2; i++)
         if (d->ent_stream[i]) hipStreamDestroy(d->ent_stream[i]);
+    if (d->rec_stream) hipStreamDestroy(d->rec_stream);
+    if (d->ev_user) hipEventDestroy(d->ev_user);
     if (d->d_pools) hipFree(d->d_pools);
     if (d->d_frames) hipFree(d->d_frames);
     if (d->d_tables) hipFree(d->d_tables);
@@ -278,11 +285,42 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipHostMalloc(&d->h_status, sizeof(uint32_t) * 2 * d->slices_cap));
     TRY_ALLOC(hipMalloc(&d->d_lists, sizeof(uint32_t) * 2 * d->pics_cap));
     TRY_ALLOC(hipHostMalloc(&d->h_lists, sizeof(uint32_t) * 2 * d->pics_cap));
-    for (int i = 0; i < 2; i++) TRY_ALLOC(hipStreamCreateWithFlags(&d->ent_stream[i], hipStreamNonBlocking));
+    {
+        // Entropy kernels fill every wave slot they can get and would starve the 16-wave workgroups of
+        // K3/K5, so the two stages get disjoint CU partitions (hipExtStreamCreateWithCUMask): the first
+        // H264MI_ENT_CUS compute units (default 128 of 256) decode entropy, the rest reconstruct.
+        hipDeviceProp_t prop;
+        TRY_ALLOC(hipGetDeviceProperties(&prop, cfg->device));
+        const int ncu = prop.multiProcessorCount;
+        int ent_cus = ncu / 2;
+        if (const char *e = getenv("H264MI_ENT_CUS")) ent_cus = atoi(e);
+        const int words = (ncu + 31) / 32;
+        std::vector<uint32_t> me(words, 0), mr(words, 0);
+        bool split = ent_cus > 0 && ent_cus < ncu;
+        for (int i = 0; i < ncu; i++) {
+            // interleave in blocks of 8 so that both partitions span all XCDs / shader engines
+            const int k = i / 8;
+            bool ent = split ? (((k + 1) * ent_cus / ncu) != (k * ent_cus / ncu)) : true;
+            if (ent) me[i / 32] |= 1u << (i % 32);
+            if (!ent || !split) mr[i / 32] |= 1u << (i % 32);
+        }
+        for (int i = 0; i < 2; i++) {
+            if (split)
+                TRY_ALLOC(hipExtStreamCreateWithCUMask(&d->ent_stream[i], words, me.data()));
+            else
+                TRY_ALLOC(hipStreamCreateWithFlags(&d->ent_stream[i], hipStreamNonBlocking));
+        }
+        if (split)
+            TRY_ALLOC(hipExtStreamCreateWithCUMask(&d->rec_stream, words, mr.data()));
+        else
+            TRY_ALLOC(hipStreamCreateWithFlags(&d->rec_stream, hipStreamNonBlocking));
+        TRY_ALLOC(hipEventCreateWithFlags(&d->ev_user, hipEventDisableTiming));
+    }
     TRY_ALLOC(hipEventCreateWithFlags(&d->ev_upload, hipEventDisableTiming));
     for (int i = 0; i < MI_SETS; i++) {
         TRY_ALLOC(hipMalloc(&d->d_mbrec[i], sizeof(MbRec) * d->mb_cap));
         TRY_ALLOC(hipMalloc(&d->d_coef[i], sizeof(int16_t) * MI_COEF_PER_MB * d->mb_cap));
+        TRY_ALLOC(hipMalloc(&d->d_toprows[i], static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * 48));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_ent[i], hipEventDisableTiming));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_rec[i], hipEventDisableTiming));
     }
@@ -303,6 +341,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
 extern "C" int32_t h264mi_decoder_destroy(h264mi_decoder *d) {
     if (!d) return H264MI_EINVAL;
     for (int i = 0; i < 2; i++) hipStreamSynchronize(d->ent_stream[i]);
+    hipStreamSynchronize(d->rec_stream);
     hipStreamSynchronize(d->stream);
     free_all(d);
     delete d;
@@ -683,6 +722,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     if (!d || n_streams < 0 || n_streams > static_cast<int>(d->st.size()) || (n_streams && (!bufs || !lens))) return H264MI_EINVAL;
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(d->ent_stream[i])); // the previous batch must not be reading the staging buffers
+    HIP_TRY(hipStreamSynchronize(d->rec_stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     d->prepared = false;
     d->n_slices = d->n_pics = 0;
@@ -829,31 +869,33 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     int16_t *coef = d->d_coef[set];
     if (prof) { // profiling serialises the two stages on one stream so that HIP-event intervals are per kernel
         mark(-1);
-        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), static_cast<size_t>(d->wmb_max) * 48, d->stream, d->d_slices, d->d_pics, d->d_bits, d->d_tables,
-                           mbrec, coef, d->d_status, d->wmb_max);
+        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), 0, d->stream, d->d_slices, d->d_pics, d->d_bits, d->d_tables, mbrec, coef, d->d_status,
+                           d->d_toprows[set], d->wmb_max);
         mark(0);
     } else {
         HIP_TRY(hipStreamWaitEvent(es, d->ev_upload, 0));
         if (d->pass >= MI_SETS) HIP_TRY(hipStreamWaitEvent(es, d->ev_rec[set], 0)); // pass n-MI_SETS finished reading this set
-        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), static_cast<size_t>(d->wmb_max) * 48, es, d->d_slices, d->d_pics, d->d_bits,
-                           d->d_tables, mbrec, coef, d->d_status, d->wmb_max);
+        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), 0, es, d->d_slices, d->d_pics, d->d_bits, d->d_tables, mbrec, coef, d->d_status,
+                           d->d_toprows[set], d->wmb_max);
         HIP_TRY(hipEventRecord(d->ev_ent[set], es));
-        HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_ent[set], 0));
+        HIP_TRY(hipStreamWaitEvent(d->rec_stream, d->ev_ent[set], 0));
     }
+    hipStream_t rs = prof ? d->stream : d->rec_stream;
     for (size_t w = 0; w < d->waves.size(); w++) {
         const uint32_t n = static_cast<uint32_t>(d->waves[w].size()), ni = static_cast<uint32_t>(d->waves_inter[w].size());
         if (!n) continue;
         if (ni) {
-            hipLaunchKernelGGL(k_inter, dim3(ni * d->mbs_max), dim3(64), 0, d->stream, d->d_lists + d->wave_inter_off[w], d->d_pics, d->d_slices, d->d_pools,
+            hipLaunchKernelGGL(k_inter, dim3(ni * d->mbs_max), dim3(64), 0, rs, d->d_lists + d->wave_inter_off[w], d->d_pics, d->d_slices, d->d_pools,
                                d->d_tables, mbrec, coef, d->mbs_max);
             mark(1);
         }
-        hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, d->stream, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec, coef);
+        hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec, coef);
         mark(2);
-        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(MI_DEBLOCK_WAVES * 64), 0, d->stream, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec);
+        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(MI_DEBLOCK_WAVES * 64), 0, rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec);
         mark(3);
     }
-    HIP_TRY(hipEventRecord(d->ev_rec[set], d->stream));
+    HIP_TRY(hipEventRecord(d->ev_rec[set], rs));
+    if (!prof) HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_rec[set], 0)); // the caller's stream sees the finished pass
     d->pass++;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(d->h_status, d->d_status, sizeof(uint32_t) * 2 * d->n_slices, hipMemcpyDeviceToHost, d->stream));
@@ -864,6 +906,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
 extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
     if (!d) return H264MI_EINVAL;
     for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(d->ent_stream[i]));
+    HIP_TRY(hipStreamSynchronize(d->rec_stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     if (d->profiling && d->ev_used >= 2) {
         size_t n = d->ev_used;
