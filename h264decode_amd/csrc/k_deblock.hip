@@ -4,18 +4,23 @@
 // edges top to bottom), and the left-edge filter of MB(x+1,y) rewrites columns of MB(x,y) AFTER
 // MB(x,y)'s horizontal edges were filtered, so a whole-picture "all vertical, then all horizontal"
 // pass is not bit-exact.  The exact dependency is MB(x,y) after MB(x-1,y) and MB(x+1,y-1): a 2-D
-// wavefront.  One workgroup owns a picture (no cross-CU hand-off), wavefront w owns macroblock rows
-// w, w+16, ... and waits on the LDS progress counter of the row above.
+// wavefront.
 //
-// Per macroblock (one wavefront):
-//   * the MbRec of the current / left / upper macroblock and the alpha/beta/tC0 tables live in LDS,
-//     so no filtering decision ever waits on a dependent global load;
-//   * the macroblock's own 16x16 + 2x 8x8 samples and its MbRecs are PREFETCHED into registers one
-//     macroblock ahead (they are final inputs from K3/K4); only the 4 rows above (written by the
-//     wavefront of the previous row) are loaded after the progress wait, and the 4 columns to the
-//     left are carried over inside LDS from the previous tile;
-//   * lanes 0-15 filter luma rows / columns and lanes 16-31 chroma in a 20x20 / 12x12 LDS tile;
-//     the result goes back with dword stores (rows -3..15, columns -4..15).
+// Mapping.  One workgroup (MI_DEBLOCK_WAVES wavefronts) owns a picture, so no cross-CU hand-off is
+// needed.  A wavefront owns a GROUP of 4 consecutive macroblock rows and filters four macroblocks
+// per step -- 16 lanes each -- staggered along the wavefront diagonal: at step t sub-row k works on
+// MB (t - 2k, 4g + k).  All four are independent by construction, so the 64 lanes are busy and the
+// per-step latency is shared by 4 macroblocks.
+//   * inside a group the 4 sample rows handed from sub-row k-1 to sub-row k travel through a small
+//     LDS ring (4 macroblock columns), never through HBM;
+//   * between groups (different wavefronts of the workgroup) they travel through a second LDS ring that
+//     holds a whole row of macroblock columns per in-flight group, ordered by LDS progress counters;
+//     no HBM access sits on the dependency path: samples are loaded once (prefetch) and stored once,
+//     fire-and-forget -- rows 13..15 of a macroblock are written by the macroblock BELOW it (which
+//     modifies them last), so no address is ever stored twice;
+//   * MbRecs and the macroblock's own samples are prefetched one step ahead (one 16-byte row per
+//     lane); the 4 columns to the left are carried over from the previous tile in LDS;
+//   * a lane filters a whole line of samples in registers (4 luma edges, then 2 chroma edges).
 //
 // Absent from the reference (only the slice-header fields are parsed: h264/slice.go:1021-1027).
 #include <hip/hip_runtime.h>
@@ -32,16 +37,25 @@ struct DbTile {
     uint8_t y[20][20];    // rows/cols -4..15 of the macroblock
     uint8_t c[2][12][12]; // rows -4..7 (only -2.. used), cols -4..7
 };
-struct DbWave {
-    DbTile tile[2];     // double buffer: the left 4 columns of tile[k] come from tile[k^1]
-    MbRec rec[3];       // ring: cur / left share slots (left = previous cur), top
+struct DbSub { // state of one of the 4 macroblock rows a wavefront works on
+    DbTile tile[2];      // double buffer: the left 4 columns of tile[k] come from tile[k^1]
+    MbRec rec[3];        // cur / left alternate in [0],[1]; [2] = macroblock above
     uint8_t bs[2][4][4]; // [dir][edge][segment]
-    uint8_t any[2], pad[2];
+    // bottom rows of this sub-row's macroblocks for the sub-row below: ring over 4 MB columns
+    uint8_t bot_y[4][4][16];    // [column & 3][row 12..15][x]
+    uint8_t bot_c[4][2][2][8];  // [column & 3][plane][row 6..7][x]
+};
+struct DbWave {
+    DbSub sub[4];
+};
+struct GroupSlot { // bottom rows of one macroblock column handed to the group below
+    uint8_t y[4][16];   // rows 12..15
+    uint8_t c[2][2][8]; // [plane][rows 6..7]
 };
 struct DbShared {
     DbWave w[MI_DEBLOCK_WAVES];
     uint8_t alpha[52], beta[52], tc0[52][4];
-    int prog[320];
+    int prog[96]; // per group: macroblocks finished in its LAST row
 };
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
@@ -101,183 +115,271 @@ __device__ __forceinline__ int edge_bs(const MbRec *mp, int pb, const MbRec *mq,
 }
 
 extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_WAVES * 64) k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
-                                                                              const DevTables *tab, const MbRec *mbrec) {
+                                                                              const DevTables *tab, const MbRec *mbrec, int wmb_max) {
     __shared__ DbShared sh;
+    extern __shared__ uint4 dyn_lds[]; // GroupSlot gring[MI_DEBLOCK_WAVES][wmb_max]
+    GroupSlot *gring = reinterpret_cast<GroupSlot *>(dyn_lds);
     const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6;
+    const int sub = lane >> 4, li = lane & 15; // sub-row inside the group, lane inside the macroblock
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
     const FramePool *pool = &pools[pd->stream];
     const int W = static_cast<int>(pool->w), H = static_cast<int>(pool->h), Wc = W / 2;
     uint8_t *py = reinterpret_cast<uint8_t *>(pool->base) + static_cast<size_t>(pd->slot) * pool->slot_bytes;
     uint8_t *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
-    for (int i = tid; i < 320; i += MI_DEBLOCK_WAVES * 64) sh.prog[i] = 0;
+    for (int i = tid; i < 96; i += MI_DEBLOCK_WAVES * 64) sh.prog[i] = 0;
     for (int i = tid; i < 52; i += MI_DEBLOCK_WAVES * 64) {
         sh.alpha[i] = tab->alpha[i], sh.beta[i] = tab->beta[i];
         sh.tc0[i][0] = 0, sh.tc0[i][1] = tab->tc0[i][1], sh.tc0[i][2] = tab->tc0[i][2], sh.tc0[i][3] = tab->tc0[i][3];
     }
     __syncthreads();
-    DbWave *ws = &sh.w[wave];
+    DbSub *ss = &sh.w[wave].sub[sub];
+    const DbSub *sup = sub > 0 ? &sh.w[wave].sub[sub - 1] : nullptr; // the sub-row above (same wavefront)
     const MbRec *recs = mbrec + pd->mb_base;
-    for (int mby = wave; mby < hmb; mby += MI_DEBLOCK_WAVES) {
-        const bool has_top = mby > 0;
-        // ---- prefetch for mbx = 0: MbRecs (cur: lanes 0-31, top: lanes 32-63) and own samples ----
-        const MbRec *row = recs + static_cast<size_t>(mby) * wmb;
-        uint32_t pre_rec = 0, pre_y = 0, pre_c = 0;
+    const int ngroups = (hmb + 3) >> 2;
+    for (int g = wave; g < ngroups; g += MI_DEBLOCK_WAVES) {
+        const int mby = g * 4 + sub;
+        const bool row_ok = mby < hmb, has_top = mby > 0;
+        const MbRec *row = recs + static_cast<size_t>(row_ok ? mby : 0) * wmb;
+        const int last_sub = min(3, hmb - 1 - g * 4); // last valid sub-row of this group
+        // prefetch registers: own 16x16 luma row (16 B), own chroma row (8 B), 2 x 32 dwords of MbRec (cur, top) as 4 dwords per lane
+        uint4 pre_y = make_uint4(0, 0, 0, 0), pre_rec = pre_y;
+        uint2 pre_c = make_uint2(0, 0);
         auto prefetch = [&](int mbx) {
-            const MbRec *src = lane < 32 ? row + mbx : (has_top ? row + mbx - wmb : row + mbx);
-            pre_rec = reinterpret_cast<const uint32_t *>(src)[lane & 31];
-            // own 16x16 luma: 64 dwords (lane -> row lane/4, dword lane%4); own chroma: 2 x 8 rows x 2 dwords on lanes 0-31
-            pre_y = *reinterpret_cast<const uint32_t *>(py + static_cast<size_t>(mby * 16 + (lane >> 2)) * W + mbx * 16 + (lane & 3) * 4);
-            if (lane < 32) {
-                const uint8_t *cp = (lane < 16 ? pcb : pcr) + static_cast<size_t>(mby * 8 + ((lane >> 1) & 7)) * Wc + mbx * 8 + (lane & 1) * 4;
-                pre_c = *reinterpret_cast<const uint32_t *>(cp);
-            }
+            if (!row_ok || mbx < 0 || mbx >= wmb) return;
+            pre_y = *reinterpret_cast<const uint4 *>(py + static_cast<size_t>(mby * 16 + li) * W + mbx * 16);
+            pre_c = *reinterpret_cast<const uint2 *>((li < 8 ? pcb : pcr) + static_cast<size_t>(mby * 8 + (li & 7)) * Wc + mbx * 8);
+            // lanes 0-7: cur record (8 x 16 B), lanes 8-15: record above
+            const MbRec *src = li < 8 ? row + mbx : (has_top ? row + mbx - wmb : row + mbx);
+            pre_rec = reinterpret_cast<const uint4 *>(src)[li & 7];
         };
-        prefetch(0);
-        int cur_slot = 0; // rec ring: cur = rec[cur_slot], left = rec[cur_slot ^ 1], top = rec[2]
-        for (int mbx = 0; mbx < wmb; mbx++) {
-            cur_slot ^= 1;
-            DbTile *tl = &ws->tile[mbx & 1], *prev = &ws->tile[(mbx & 1) ^ 1];
-            MbRec *mq = &ws->rec[cur_slot], *mleft_rec = &ws->rec[cur_slot ^ 1], *mtop_rec = &ws->rec[2];
+        prefetch(-2 * sub); // step 0 (only sub-row 0 is active)
+        const int nsteps = wmb + 6;
+        for (int t = 0; t < nsteps; t++) {
+            const int mbx = t - 2 * sub;
+            const bool active = row_ok && mbx >= 0 && mbx < wmb;
+            DbTile *tl = &ss->tile[t & 1], *prev = &ss->tile[(t & 1) ^ 1];
+            const int cur_slot = t & 1;
+            MbRec *mq = &ss->rec[cur_slot], *mleft_rec = &ss->rec[cur_slot ^ 1], *mtop_rec = &ss->rec[2];
             // ---- commit the prefetched data to LDS ----
-            reinterpret_cast<uint32_t *>(lane < 32 ? mq : mtop_rec)[lane & 31] = pre_rec;
-            *reinterpret_cast<uint32_t *>(&tl->y[4 + (lane >> 2)][4 + (lane & 3) * 4]) = pre_y;
-            if (lane < 32) *reinterpret_cast<uint32_t *>(&tl->c[lane >> 4][4 + ((lane >> 1) & 7)][4 + (lane & 1) * 4]) = pre_c;
-            // left 4 columns: carried over from the previous tile (rows 0..15 luma, 0..7 chroma)
-            if (mbx > 0) {
-                if (lane < 16)
-                    *reinterpret_cast<uint32_t *>(&tl->y[4 + lane][0]) = *reinterpret_cast<const uint32_t *>(&prev->y[4 + lane][16]);
-                else if (lane < 32)
-                    *reinterpret_cast<uint32_t *>(&tl->c[(lane >> 3) & 1][4 + (lane & 7)][0]) = *reinterpret_cast<const uint32_t *>(&prev->c[(lane >> 3) & 1][4 + (lane & 7)][8]);
+            if (active) {
+                reinterpret_cast<uint4 *>(li < 8 ? mq : mtop_rec)[li & 7] = pre_rec;
+                uint32_t *yr = reinterpret_cast<uint32_t *>(&tl->y[4 + li][4]);
+                yr[0] = pre_y.x, yr[1] = pre_y.y, yr[2] = pre_y.z, yr[3] = pre_y.w;
+                uint32_t *cr = reinterpret_cast<uint32_t *>(&tl->c[li >> 3][4 + (li & 7)][4]);
+                cr[0] = pre_c.x, cr[1] = pre_c.y;
+                if (mbx > 0) { // left 4 columns: carried over from the previous tile
+                    *reinterpret_cast<uint32_t *>(&tl->y[4 + li][0]) = *reinterpret_cast<const uint32_t *>(&prev->y[4 + li][16]);
+                    *reinterpret_cast<uint32_t *>(&tl->c[li >> 3][4 + (li & 7)][0]) = *reinterpret_cast<const uint32_t *>(&prev->c[li >> 3][4 + (li & 7)][8]);
+                }
+                // rows above from the sub-row above (same wavefront): LDS ring, final since the previous step
+                if (sub > 0) {
+                    if (li < 4) {
+                        const uint32_t *src = reinterpret_cast<const uint32_t *>(sup->bot_y[mbx & 3][li]);
+                        uint32_t *dst = reinterpret_cast<uint32_t *>(&tl->y[li][4]);
+                        dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+                    } else if (li < 8) {
+                        const uint32_t *src = reinterpret_cast<const uint32_t *>(sup->bot_c[mbx & 3][(li >> 1) & 1][li & 1]);
+                        uint32_t *dst = reinterpret_cast<uint32_t *>(&tl->c[(li >> 1) & 1][2 + (li & 1)][4]);
+                        dst[0] = src[0], dst[1] = src[1];
+                    }
+                }
             }
-            if (lane < 2) ws->any[lane] = 0;
+            // ---- sub-row 0: rows above come from the previous group (another wavefront) through the group ring ----
+            {
+                const int x0 = t; // macroblock of sub-row 0 in this step
+                if (g > 0 && x0 < wmb) {
+                    const int need = min(x0 + 2, wmb);
+                    while (__hip_atomic_load(&sh.prog[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    if (sub == 0) {
+                        const GroupSlot *gs = &gring[((g - 1) % MI_DEBLOCK_WAVES) * wmb_max + x0];
+                        if (li < 4) {
+                            const uint32_t *src = reinterpret_cast<const uint32_t *>(gs->y[li]);
+                            uint32_t *dst = reinterpret_cast<uint32_t *>(&tl->y[li][4]);
+                            dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
+                        } else if (li < 8) {
+                            const uint32_t *src = reinterpret_cast<const uint32_t *>(gs->c[(li >> 1) & 1][li & 1]);
+                            uint32_t *dst = reinterpret_cast<uint32_t *>(&tl->c[(li >> 1) & 1][2 + (li & 1)][4]);
+                            dst[0] = src[0], dst[1] = src[1];
+                        }
+                    }
+                }
+                // the group ring slot this step's last sub-row will overwrite must have been consumed by the
+                // group that read the previous tenant (group g - MI_DEBLOCK_WAVES + 1)
+                const int xl = t - 2 * last_sub;
+                if (g >= MI_DEBLOCK_WAVES && g + 1 < ngroups && xl >= 0 && xl < wmb) {
+                    while (__hip_atomic_load(&sh.prog[g - MI_DEBLOCK_WAVES + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < xl + 1) __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                }
+            }
             WAVE_SYNC();
-            if (mbx + 1 < wmb) prefetch(mbx + 1);
-            const int dbf = mq->dbf_idc;
-            if (dbf != 1) {
-                const MbRec *ml = mbx > 0 ? mleft_rec : nullptr, *mt = has_top ? mtop_rec : nullptr;
+            prefetch(mbx + 1);
+            // ---- boundary strengths: 32 per macroblock, 2 per lane ----
+            const MbRec *ml = nullptr, *mt = nullptr;
+            int dbf = 1;
+            if (active) {
+                dbf = mq->dbf_idc;
+                ml = mbx > 0 ? mleft_rec : nullptr, mt = has_top ? mtop_rec : nullptr;
                 if (dbf == 2) { // no filtering across slice boundaries
                     if (ml && ml->slice_in_pic != mq->slice_in_pic) ml = nullptr;
                     if (mt && mt->slice_in_pic != mq->slice_in_pic) mt = nullptr;
                 }
-                // ---- boundary strengths: lanes 0..31 = (dir, edge, segment) ----
-                if (lane < 32) {
-                    const int dir = lane >> 4, e = (lane >> 2) & 3, k = lane & 3;
-                    const MbRec *mn = dir == 0 ? ml : mt;
-                    int bs = 0;
-                    if (!(e == 0 && !mn) && !((e & 1) && mq->t8x8)) {
-                        const MbRec *mp = e == 0 ? mn : mq;
-                        int qb = dir == 0 ? k * 4 + e : e * 4 + k;
-                        int pb = dir == 0 ? k * 4 + (e == 0 ? 3 : e - 1) : (e == 0 ? 3 : e - 1) * 4 + k;
-                        bs = edge_bs(mp, pb, mq, qb, e == 0);
-                    }
-                    ws->bs[dir][e][k] = static_cast<uint8_t>(bs);
-                    if (bs) ws->any[dir] = 1;
-                }
-                WAVE_SYNC();
-                if (ws->any[0] | ws->any[1]) {
-                    uint8_t *Y = py + static_cast<size_t>(mby * 16) * W + mbx * 16;
-                    uint8_t *C0 = pcb + static_cast<size_t>(mby * 8) * Wc + mbx * 8, *C1 = pcr + static_cast<size_t>(mby * 8) * Wc + mbx * 8;
-                    // ---- the 4 rows above come from the wavefront of the previous row ----
-                    if (has_top) {
-                        const int need = min(mbx + 2, wmb);
-                        while (__hip_atomic_load(&sh.prog[mby - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
-                        if (lane < 16) // luma rows -4..-1, columns 0..15
-                            *reinterpret_cast<uint32_t *>(&tl->y[lane >> 2][4 + (lane & 3) * 4]) =
-                                *reinterpret_cast<const uint32_t *>(Y + static_cast<ptrdiff_t>((lane >> 2) - 4) * W + (lane & 3) * 4);
-                        else if (lane < 24) { // chroma rows -2..-1
-                            const int c = (lane >> 2) & 1, r = (lane >> 1) & 1, d = lane & 1;
-                            *reinterpret_cast<uint32_t *>(&tl->c[c][2 + r][4 + d * 4]) =
-                                *reinterpret_cast<const uint32_t *>((c ? C1 : C0) + static_cast<ptrdiff_t>(r - 2) * Wc + d * 4);
+                if (dbf != 1) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int idx = li + 16 * h, dir = idx >> 4, e = (idx >> 2) & 3, k = idx & 3;
+                        const MbRec *mn = dir == 0 ? ml : mt;
+                        int bs = 0;
+                        if (!(e == 0 && !mn) && !((e & 1) && mq->t8x8)) {
+                            const MbRec *mp = e == 0 ? mn : mq;
+                            int qb = dir == 0 ? k * 4 + e : e * 4 + k;
+                            int pb = dir == 0 ? k * 4 + (e == 0 ? 3 : e - 1) : (e == 0 ? 3 : e - 1) * 4 + k;
+                            bs = edge_bs(mp, pb, mq, qb, e == 0);
                         }
-                        WAVE_SYNC();
-                    }
-                    // ---- the two filtering passes: a whole line of samples in registers per lane ----
-                    for (int dir = 0; dir < 2; dir++) {
-                        if (ws->any[dir]) {
-                            const MbRec *mn = dir == 0 ? ml : mt;
-                            if (lane < 16) { // luma: one row (dir 0) or column (dir 1) per lane
-                                int px[20];
-                                if (dir == 0) {
-#pragma unroll
-                                    for (int d = 0; d < 5; d++) {
-                                        uint32_t w = *reinterpret_cast<const uint32_t *>(&tl->y[4 + lane][d * 4]);
-                                        px[4 * d] = w & 255, px[4 * d + 1] = (w >> 8) & 255, px[4 * d + 2] = (w >> 16) & 255, px[4 * d + 3] = w >> 24;
-                                    }
-                                } else {
-#pragma unroll
-                                    for (int r = 0; r < 20; r++) px[r] = tl->y[r][4 + lane];
-                                }
-                                const uint32_t bsw = *reinterpret_cast<const uint32_t *>(ws->bs[dir][0]) >> (8 * (lane >> 2));
-                                const int bs0 = bsw & 255;
-                                const int bs1 = ws->bs[dir][1][lane >> 2], bs2 = ws->bs[dir][2][lane >> 2], bs3 = ws->bs[dir][3][lane >> 2];
-                                const int qpq = mq->qp, aoff = mq->alpha_off, boff = mq->beta_off;
-                                const int qpe = mn ? (mn->qp + qpq + 1) >> 1 : qpq;
-                                const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
-                                const int ia1 = clip3(0, 51, qpq + aoff), ib1 = clip3(0, 51, qpq + boff);
-                                const int a0 = sh.alpha[ia0], b0 = sh.beta[ib0], a1 = sh.alpha[ia1], b1 = sh.beta[ib1];
-                                filter_edge<4, false>(px, bs0, a0, b0, sh.tc0[ia0][bs0 & 3]);
-                                filter_edge<8, false>(px, bs1, a1, b1, sh.tc0[ia1][bs1 & 3]);
-                                filter_edge<12, false>(px, bs2, a1, b1, sh.tc0[ia1][bs2 & 3]);
-                                filter_edge<16, false>(px, bs3, a1, b1, sh.tc0[ia1][bs3 & 3]);
-                                if (dir == 0) {
-#pragma unroll
-                                    for (int d = 0; d < 5; d++)
-                                        *reinterpret_cast<uint32_t *>(&tl->y[4 + lane][d * 4]) =
-                                            static_cast<uint32_t>(px[4 * d]) | (px[4 * d + 1] << 8) | (px[4 * d + 2] << 16) | (static_cast<uint32_t>(px[4 * d + 3]) << 24);
-                                } else {
-#pragma unroll
-                                    for (int r = 1; r < 19; r++) tl->y[r][4 + lane] = static_cast<uint8_t>(px[r]);
-                                }
-                            } else if (lane < 32) { // chroma: plane = bit 3, row/column = low 3 bits; luma edges 0 and 2
-                                const int c = (lane >> 3) & 1, i = lane & 7;
-                                int px[12];
-                                if (dir == 0) {
-#pragma unroll
-                                    for (int d = 0; d < 3; d++) {
-                                        uint32_t w = *reinterpret_cast<const uint32_t *>(&tl->c[c][4 + i][d * 4]);
-                                        px[4 * d] = w & 255, px[4 * d + 1] = (w >> 8) & 255, px[4 * d + 2] = (w >> 16) & 255, px[4 * d + 3] = w >> 24;
-                                    }
-                                } else {
-#pragma unroll
-                                    for (int r = 0; r < 12; r++) px[r] = tl->c[c][r][4 + i];
-                                }
-                                const int bs0 = ws->bs[dir][0][i >> 1], bs2 = ws->bs[dir][2][i >> 1];
-                                const int qpq = mq->qpc[c], aoff = mq->alpha_off, boff = mq->beta_off;
-                                const int qpe = mn ? (mn->qpc[c] + qpq + 1) >> 1 : qpq;
-                                const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
-                                const int ia1 = clip3(0, 51, qpq + aoff), ib1 = clip3(0, 51, qpq + boff);
-                                filter_edge<4, true>(px, bs0, sh.alpha[ia0], sh.beta[ib0], sh.tc0[ia0][bs0 & 3]);
-                                filter_edge<8, true>(px, bs2, sh.alpha[ia1], sh.beta[ib1], sh.tc0[ia1][bs2 & 3]);
-                                if (dir == 0) {
-#pragma unroll
-                                    for (int d = 0; d < 3; d++)
-                                        *reinterpret_cast<uint32_t *>(&tl->c[c][4 + i][d * 4]) =
-                                            static_cast<uint32_t>(px[4 * d]) | (px[4 * d + 1] << 8) | (px[4 * d + 2] << 16) | (static_cast<uint32_t>(px[4 * d + 3]) << 24);
-                                } else {
-#pragma unroll
-                                    for (int r = 2; r < 10; r++) tl->c[c][r][4 + i] = static_cast<uint8_t>(px[r]);
-                                }
-                            }
-                        }
-                        WAVE_SYNC();
-                    }
-                    // ---- write back rows -3..15, columns -4..15 (the untouched top-left corner is skipped) ----
-                    const bool has_left = mbx > 0;
-                    for (int i = lane; i < 100; i += 64) {
-                        int r = i / 5, d = i - r * 5;
-                        if (r >= 1 && (r >= 4 || has_top) && (d >= 1 || has_left) && !(r < 4 && d == 0))
-                            *reinterpret_cast<uint32_t *>(Y + static_cast<ptrdiff_t>(r - 4) * W + (d - 1) * 4) = *reinterpret_cast<const uint32_t *>(&tl->y[r][d * 4]);
-                    }
-                    for (int i = lane; i < 72; i += 64) {
-                        int c = i / 36, rem = i - c * 36, r = rem / 3, d = rem - r * 3;
-                        if (r >= 3 && (r >= 4 || has_top) && (d >= 1 || has_left) && !(r < 4 && d == 0))
-                            *reinterpret_cast<uint32_t *>((c ? C1 : C0) + static_cast<ptrdiff_t>(r - 4) * Wc + (d - 1) * 4) = *reinterpret_cast<const uint32_t *>(&tl->c[c][r][d * 4]);
+                        ss->bs[dir][e][k] = static_cast<uint8_t>(bs);
                     }
                 }
             }
-            // publish progress: the release orders this wave's global stores before the counter update
-            if (lane == 0) __hip_atomic_store(&sh.prog[mby], mbx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            WAVE_SYNC();
+            // ---- the two filtering passes: a whole line of samples in registers per lane ----
+            const bool filt = active && dbf != 1;
+            for (int dir = 0; dir < 2; dir++) {
+                if (filt) {
+                    const MbRec *mn = dir == 0 ? ml : mt;
+                    const uint32_t b0w = *reinterpret_cast<const uint32_t *>(ss->bs[dir][0]), b1w = *reinterpret_cast<const uint32_t *>(ss->bs[dir][1]);
+                    const uint32_t b2w = *reinterpret_cast<const uint32_t *>(ss->bs[dir][2]), b3w = *reinterpret_cast<const uint32_t *>(ss->bs[dir][3]);
+                    const int aoff = mq->alpha_off, boff = mq->beta_off;
+                    if (b0w | b1w | b2w | b3w) {
+                        { // luma: lane li = row (dir 0) or column (dir 1)
+                            int px[20];
+                            if (dir == 0) {
+#pragma unroll
+                                for (int d = 0; d < 5; d++) {
+                                    uint32_t w = *reinterpret_cast<const uint32_t *>(&tl->y[4 + li][d * 4]);
+                                    px[4 * d] = w & 255, px[4 * d + 1] = (w >> 8) & 255, px[4 * d + 2] = (w >> 16) & 255, px[4 * d + 3] = w >> 24;
+                                }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 20; r++) px[r] = tl->y[r][4 + li];
+                            }
+                            const int sh8 = 8 * (li >> 2);
+                            const int bs0 = (b0w >> sh8) & 255, bs1 = (b1w >> sh8) & 255, bs2 = (b2w >> sh8) & 255, bs3 = (b3w >> sh8) & 255;
+                            const int qpq = mq->qp;
+                            const int qpe = mn ? (mn->qp + qpq + 1) >> 1 : qpq;
+                            const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
+                            const int ia1 = clip3(0, 51, qpq + aoff), ib1 = clip3(0, 51, qpq + boff);
+                            const int a0 = sh.alpha[ia0], be0 = sh.beta[ib0], a1 = sh.alpha[ia1], be1 = sh.beta[ib1];
+                            filter_edge<4, false>(px, bs0, a0, be0, sh.tc0[ia0][bs0 & 3]);
+                            filter_edge<8, false>(px, bs1, a1, be1, sh.tc0[ia1][bs1 & 3]);
+                            filter_edge<12, false>(px, bs2, a1, be1, sh.tc0[ia1][bs2 & 3]);
+                            filter_edge<16, false>(px, bs3, a1, be1, sh.tc0[ia1][bs3 & 3]);
+                            if (dir == 0) {
+#pragma unroll
+                                for (int d = 0; d < 5; d++)
+                                    *reinterpret_cast<uint32_t *>(&tl->y[4 + li][d * 4]) =
+                                        static_cast<uint32_t>(px[4 * d]) | (px[4 * d + 1] << 8) | (px[4 * d + 2] << 16) | (static_cast<uint32_t>(px[4 * d + 3]) << 24);
+                            } else {
+#pragma unroll
+                                for (int r = 1; r < 19; r++) tl->y[r][4 + li] = static_cast<uint8_t>(px[r]);
+                            }
+                        }
+                        { // chroma: plane = li >> 3, row/column = li & 7; luma edges 0 and 2
+                            const int c = li >> 3, i = li & 7;
+                            int px[12];
+                            if (dir == 0) {
+#pragma unroll
+                                for (int d = 0; d < 3; d++) {
+                                    uint32_t w = *reinterpret_cast<const uint32_t *>(&tl->c[c][4 + i][d * 4]);
+                                    px[4 * d] = w & 255, px[4 * d + 1] = (w >> 8) & 255, px[4 * d + 2] = (w >> 16) & 255, px[4 * d + 3] = w >> 24;
+                                }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 12; r++) px[r] = tl->c[c][r][4 + i];
+                            }
+                            const int sh8 = 8 * (i >> 1);
+                            const int bs0 = (b0w >> sh8) & 255, bs2 = (b2w >> sh8) & 255;
+                            const int qpq = mq->qpc[c];
+                            const int qpe = mn ? (mn->qpc[c] + qpq + 1) >> 1 : qpq;
+                            const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
+                            const int ia1 = clip3(0, 51, qpq + aoff), ib1 = clip3(0, 51, qpq + boff);
+                            filter_edge<4, true>(px, bs0, sh.alpha[ia0], sh.beta[ib0], sh.tc0[ia0][bs0 & 3]);
+                            filter_edge<8, true>(px, bs2, sh.alpha[ia1], sh.beta[ib1], sh.tc0[ia1][bs2 & 3]);
+                            if (dir == 0) {
+#pragma unroll
+                                for (int d = 0; d < 3; d++)
+                                    *reinterpret_cast<uint32_t *>(&tl->c[c][4 + i][d * 4]) =
+                                        static_cast<uint32_t>(px[4 * d]) | (px[4 * d + 1] << 8) | (px[4 * d + 2] << 16) | (static_cast<uint32_t>(px[4 * d + 3]) << 24);
+                            } else {
+#pragma unroll
+                                for (int r = 2; r < 10; r++) tl->c[c][r][4 + i] = static_cast<uint8_t>(px[r]);
+                            }
+                        }
+                    }
+                }
+                WAVE_SYNC();
+            }
+            // ---- results.  HBM: own rows 0..12 (0..15 in the last picture row) + the 4 columns to the left, and
+            // rows -3..-1 of the macroblock above (this macroblock modified them last).  LDS rings: bottom rows
+            // for the sub-row / group below ----
+            if (active) {
+                uint8_t *Y = py + static_cast<size_t>(mby * 16) * W + mbx * 16;
+                uint8_t *Cp = (li < 8 ? pcb : pcr) + static_cast<size_t>(mby * 8) * Wc + mbx * 8;
+                const bool has_left = mbx > 0, last_row = mby == hmb - 1;
+                if (filt) {
+                    if (li < 13 || last_row) {
+                        const uint32_t *r = reinterpret_cast<const uint32_t *>(&tl->y[4 + li][0]);
+                        *reinterpret_cast<uint4 *>(Y + static_cast<size_t>(li) * W) = make_uint4(r[1], r[2], r[3], r[4]);
+                        if (has_left) *reinterpret_cast<uint32_t *>(Y + static_cast<size_t>(li) * W - 4) = r[0];
+                    }
+                    if ((li & 7) < 7 || last_row) {
+                        const uint32_t *cr = reinterpret_cast<const uint32_t *>(&tl->c[li >> 3][4 + (li & 7)][0]);
+                        *reinterpret_cast<uint2 *>(Cp + static_cast<size_t>(li & 7) * Wc) = make_uint2(cr[1], cr[2]);
+                        if (has_left) *reinterpret_cast<uint32_t *>(Cp + static_cast<size_t>(li & 7) * Wc - 4) = cr[0];
+                    }
+                }
+                if (has_top) { // rows -3..-1 (luma), -1 (chroma), columns 0..15 / 0..7: always, the macroblock above never stores them
+                    if (li < 3) {
+                        const uint32_t *r = reinterpret_cast<const uint32_t *>(&tl->y[1 + li][4]);
+                        *reinterpret_cast<uint4 *>(Y + static_cast<ptrdiff_t>(li - 3) * W) = make_uint4(r[0], r[1], r[2], r[3]);
+                    } else if (li >= 8 && li < 10) {
+                        const int c = li - 8;
+                        const uint32_t *r = reinterpret_cast<const uint32_t *>(&tl->c[c][3][4]);
+                        *reinterpret_cast<uint2 *>((c ? pcr : pcb) + static_cast<size_t>(mby * 8 - 1) * Wc + mbx * 8) = make_uint2(r[0], r[1]);
+                    }
+                }
+                // rings: own bottom rows (columns 12..15 still provisional) and the now final columns 12..15 of the left MB
+                if (!last_row && li < 8) {
+                    uint32_t *dy, *dyl = nullptr, *dc, *dcl = nullptr;
+                    const int c = (li >> 1) & 1, r = li & 1;
+                    if (sub < last_sub) {
+                        dy = reinterpret_cast<uint32_t *>(ss->bot_y[mbx & 3][li & 3]), dc = reinterpret_cast<uint32_t *>(ss->bot_c[mbx & 3][c][r]);
+                        if (has_left) dyl = reinterpret_cast<uint32_t *>(&ss->bot_y[(mbx - 1) & 3][li & 3][12]), dcl = reinterpret_cast<uint32_t *>(&ss->bot_c[(mbx - 1) & 3][c][r][4]);
+                    } else {
+                        GroupSlot *gs = &gring[(g % MI_DEBLOCK_WAVES) * wmb_max + mbx];
+                        dy = reinterpret_cast<uint32_t *>(gs->y[li & 3]), dc = reinterpret_cast<uint32_t *>(gs->c[c][r]);
+                        if (has_left) dyl = reinterpret_cast<uint32_t *>(&gs[-1].y[li & 3][12]), dcl = reinterpret_cast<uint32_t *>(&gs[-1].c[c][r][4]);
+                    }
+                    if (li < 4) {
+                        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tl->y[16 + li][0]);
+                        dy[0] = src[1], dy[1] = src[2], dy[2] = src[3], dy[3] = src[4];
+                        if (dyl) dyl[0] = src[0];
+                    } else {
+                        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tl->c[c][10 + r][0]);
+                        dc[0] = src[1], dc[1] = src[2];
+                        if (dcl) dcl[0] = src[0];
+                    }
+                }
+            }
+            WAVE_SYNC();
+            // progress of the group's last row (LDS-only hand-off: LDS operations of a wavefront complete in order)
+            {
+                const int xl = t - 2 * last_sub;
+                if (xl >= 0 && xl < wmb) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&sh.prog[g], xl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
     }
 }

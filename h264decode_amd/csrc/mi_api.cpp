@@ -286,13 +286,13 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipMalloc(&d->d_lists, sizeof(uint32_t) * 2 * d->pics_cap));
     TRY_ALLOC(hipHostMalloc(&d->h_lists, sizeof(uint32_t) * 2 * d->pics_cap));
     {
-        // Entropy kernels fill every wave slot they can get and would starve the 16-wave workgroups of
-        // K3/K5, so the two stages get disjoint CU partitions (hipExtStreamCreateWithCUMask): the first
-        // H264MI_ENT_CUS compute units (default 128 of 256) decode entropy, the rest reconstruct.
+        // Optional experiment knob: H264MI_ENT_CUS=n gives the entropy streams the first n compute units
+        // and reconstruction the rest (hipExtStreamCreateWithCUMask).  Measured slower than sharing the
+        // whole chip at every split tried (96..192 of 256), so the default is no partition.
         hipDeviceProp_t prop;
         TRY_ALLOC(hipGetDeviceProperties(&prop, cfg->device));
         const int ncu = prop.multiProcessorCount;
-        int ent_cus = ncu / 2;
+        int ent_cus = 0;
         if (const char *e = getenv("H264MI_ENT_CUS")) ent_cus = atoi(e);
         const int words = (ncu + 31) / 32;
         std::vector<uint32_t> me(words, 0), mr(words, 0);
@@ -328,6 +328,8 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipMalloc(&d->d_frames, d->slot_bytes * d->n_slots * S));
     TRY_ALLOC(hipMalloc(&d->d_tables, sizeof(DevTables)));
     TRY_ALLOC(hipHostMalloc(&d->h_tables, sizeof(DevTables)));
+    // K5 keeps a whole macroblock row per in-flight group in dynamic LDS (up to 320 columns): opt in beyond 64 KB
+    TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
     build_tables(d->h_tables);
     d->h_pools.resize(S);
     // a deterministic background for macroblocks no slice covers
@@ -891,7 +893,8 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         }
         hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec, coef);
         mark(2);
-        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(MI_DEBLOCK_WAVES * 64), 0, rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec);
+        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(MI_DEBLOCK_WAVES * 64), static_cast<size_t>(MI_DEBLOCK_WAVES) * d->wmb_max * MI_DEBLOCK_SLOT_BYTES, rs,
+                           d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec, d->wmb_max);
         mark(3);
     }
     HIP_TRY(hipEventRecord(d->ev_rec[set], rs));

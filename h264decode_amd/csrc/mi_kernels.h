@@ -13,9 +13,11 @@ extern "C" __global__ void k_inter(const uint32_t *pic_list, const PicDesc *pics
 extern "C" __global__ void k_intra(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
                                    const int16_t *coefs);
 // K5: in-loop deblocking, one workgroup per picture, one wavefront per macroblock row.
-extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec);
+extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
+                                     int wmb_max);
+#define MI_DEBLOCK_SLOT_BYTES 96 /* sizeof(GroupSlot): dynamic LDS = MI_DEBLOCK_WAVES * wmb_max * 96 */
 // K6: crop + tight pack of one frame into I420
 extern "C" __global__ void k_pack(const uint8_t *src_y, const uint8_t *src_cb, const uint8_t *src_cr, int pitch, int x0, int y0, int w, int h, uint8_t *dst);
 
 #define MI_INTRA_WAVES 16
-#define MI_DEBLOCK_WAVES 16
+#define MI_DEBLOCK_WAVES 4 /* each wavefront filters 4 macroblock rows at once */
