@@ -23,9 +23,17 @@
 #include <hip/hip_runtime.h>
 #include "mi_kernels.h"
 
-#define RING_WORDS 512
 #define LANE (static_cast<int>(threadIdx.x))
 #define FI __device__ __forceinline__
+// The workgroup is ONE wavefront: cross-lane LDS visibility needs no s_barrier and, above all, no
+// wait for outstanding global stores (what __syncthreads() implies) -- LDS operations of a wavefront
+// are processed in issue order, so ordering the instructions is enough.
+#define LDS_SYNC()                                             \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
 
 struct TopInfo { // edge state of a decoded MB as seen by its right / lower neighbours (48 bytes)
     uint8_t type, t8x8, cbp, chroma_mode, cbf_dc, pad[3];
@@ -39,14 +47,8 @@ struct TopInfo { // edge state of a decoded MB as seen by its right / lower neig
 static_assert(sizeof(TopInfo) == 48, "TopInfo layout");
 
 struct Shared {
-    uint32_t ring[RING_WORDS];
-    uint8_t ctx[464];
-#if !MI_SCALAR_CABAC
-    uint2 lps[128]; // per state s=(pStateIdx<<1|valMPS): .x = rangeTabLPS[p][0..3] packed, .y = next(MPS) | next(LPS)<<8
-#endif
-    uint8_t posmap[4][64]; // scan index -> position: [0] zig-zag 4x4, [1] zig-zag 4x4 of AC index (k+1), [2] zig-zag 8x8, [3] identity
-    uint8_t incmap[3][64]; // ctxIdxInc of significant_coeff_flag: [0] identity, [1] min(i,2) (chroma DC), [2] Table 9-43 8x8
-    uint8_t lastmap[64];   // ctxIdxInc of last_significant_coeff_flag for 8x8 blocks
+    uint8_t ctx[464];      // home of the residual-block context states (ctxIdx >= 105); see Ent::wk
+    uint8_t posmap[4][64]; // CAVLC: scan index -> position: [0] zig-zag 4x4, [1] zig-zag 4x4 of AC index (k+1), [2] zig-zag 8x8, [3] identity
     int16_t coef[MI_COEF_PER_MB];
     MbRec rec;
     TopInfo left, tl; // tl = top[] entry of column x-1 as it was for the row above
@@ -66,81 +68,139 @@ struct Shared {
     int8_t refs8[4];
     int8_t sub_type[4];
     uint8_t cur_cbf_dc, pad[3];
+    int16_t ref_slot[MI_MAX_REFS]; // frame-pool slot per ref_idx of this slice
 };
 #define GI(bx, by) (((by) + 1) * 6 + (bx) + 1)
 
+// Everything the serial syntax code touches per bin lives in registers:
+//   * the bit reader is scalar (64-bit MSB-aligned look-ahead in SGPRs) and is fed from three VGPRs that
+//     hold 3 x 64 consecutive RBSP words, one per lane, read with v_readlane -- no LDS ring;
+//   * the CABAC context states of the macroblock-level syntax elements (ctxIdx 0..104, 399..401) sit
+//     one per lane in two VGPRs (ca, cb); the states of the residual block being decoded are gathered
+//     from their LDS home into a third VGPR (wk) for the duration of the block;
+//   * Tables 9-44 / 9-45, the 8x8 significance maps and the zig-zag scans are per-lane tables too.
+// A decision is then ~35 scalar instructions with no memory access at all.
 struct Ent {
     Shared *s;
     TopInfo *top; // [wmb] row-above state of this slice, in global memory (read with L1-bypassing loads)
     uint32_t pre_top; // lanes 0..11: prefetched dwords of top[mbx + 2]
     const DevTables *tab;
-    const uint8_t *rbsp;
+    const uint32_t *rbsp32;
     const SliceDesc *sd;
     const PicDesc *pd;
     MbRec *mbrec;
     int16_t *coefs;
-    uint32_t rbsp_words, filled, bitpos;
+    // bit reader
+    uint64_t bitbuf;         // next stream bits, MSB first
+    int bcnt;                // valid bits in bitbuf (>= 32 between calls)
+    uint32_t wpos, wbase, rbsp_words; // next word to fetch / first word of `win`
+    uint32_t win, winn, winx; // lane i: RBSP word wbase + i / + 64 + i / + 128 + i, byte-swapped to MSB-first
+    // CABAC engine
     uint32_t range, value;
     int avail;
-    uint32_t v_rlps, v_trans; // per-lane copies of Table 9-44 (4 bytes) / 9-45 for state = lane
+    uint32_t ca, cb, wk;     // context states, see above; cb lanes 61..63 = ctxIdx 399..401
+    uint32_t v_rlps, v_trans; // lane p: rangeTabLPS[p][0..3] / next state after an LPS for valMPS 0 (byte 0) and 1 (byte 1)
+    uint32_t v_maps;         // lane i: sig8x8[i] | last8x8[i] << 8 | zigzag8[i] << 16 | zigzag4[i & 15] << 24
+    uint32_t v_cat0, v_cat1; // lane ctxBlockCat: packed block-category parameters (cat_word0/1)
+    uint32_t v_qpc, v_refslot; // lane i: QPc table entry / frame slot of ref_idx i
     int qp, prev_dqp_nz, mbx, mby, cur_type, err;
     int cabac, islice, wmb, hmb;
+    int cip, t8x8_mode, cqp_off0, cqp_off1, nref;
+    uint64_t mb_base;
+#if MI_ENT_STATS
+    uint32_t bins;
+#endif
 };
+#if MI_ENT_STATS
+#define MI_BINS(e) ((e).bins)
+#define MI_COUNT_BIN(e) ((e).bins++)
+#else
+#define MI_BINS(e) 0u
+#define MI_COUNT_BIN(e) ((void)0)
+#endif
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+#define RDL(v, i) static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(i)))
+// v_writelane_b32: clang has no builtin for it, the LLVM intrinsic is bound by name
+extern "C" __device__ int mi_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
 
-// per block category (ctxBlockCat 0..5): maxNumCoeff, ctxIdx bases, clamp of numDecodAbsLevelGt1,
-// position map, significance-inc map (Tables 9-34, 9-40, 9-43)
-__constant__ uint16_t c_cat[6][8] = {
-    /* maxnum, cbf base, sig base, last base, abs base, gt1 limit, posmap, incmap */
-    {16, 85 + 0, 105 + 0, 166 + 0, 227 + 0, 4, 0, 0},    // 0 Intra16x16 DC
-    {15, 85 + 4, 105 + 15, 166 + 15, 227 + 10, 4, 1, 0}, // 1 Intra16x16 AC
-    {16, 85 + 8, 105 + 29, 166 + 29, 227 + 20, 4, 0, 0}, // 2 luma 4x4
-    {4, 85 + 12, 105 + 44, 166 + 44, 227 + 30, 3, 3, 1}, // 3 chroma DC
-    {15, 85 + 16, 105 + 47, 166 + 47, 227 + 39, 4, 1, 0},// 4 chroma AC
-    {64, 0, 402, 417, 426, 4, 2, 2},                     // 5 luma 8x8
-};
-
-// ------------------------------------------------------------------ bitstream ring
-FI void ring_fill(Ent &e) {
-    // 256 words = 1 KB per call: each lane loads 16 bytes; words are byte-swapped to MSB-first order
-    uint32_t base = e.filled + LANE * 4;
-    uint4 a = make_uint4(0, 0, 0, 0);
-    if (base < e.rbsp_words) a = *(reinterpret_cast<const uint4 *>(e.rbsp) + (base >> 2));
-    uint32_t *dst = e.s->ring + (base & (RING_WORDS - 1));
-    dst[0] = __builtin_bswap32(a.x), dst[1] = __builtin_bswap32(a.y), dst[2] = __builtin_bswap32(a.z), dst[3] = __builtin_bswap32(a.w);
-    e.filled += 256;
-    __syncthreads();
+// per block category (ctxBlockCat 0..5; Tables 9-34, 9-40, 9-43):
+//   word0 = maxNumCoeff | (coded_block_flag base - 64) << 8 | clamp of numDecodAbsLevelGt1 << 16 | position mode << 20
+//           (0 zig-zag 4x4, 1 zig-zag 4x4 of index k+1, 2 zig-zag 8x8, 3 identity) | number of last contexts << 24
+//   word1 = significant_coeff_flag base | last_significant_coeff_flag base << 10 | coeff_abs_level_minus1 base << 20
+FI uint32_t cat_word0(int c) {
+    const uint32_t maxnum[6] = {16, 15, 16, 4, 15, 64}, cbf[6] = {85, 89, 93, 97, 101, 64}, lim[6] = {4, 4, 4, 3, 4, 4}, pm[6] = {0, 1, 0, 3, 1, 2};
+    const uint32_t nlast[6] = {15, 14, 15, 3, 14, 9};
+    c = c < 6 ? c : 0;
+    return maxnum[c] | (cbf[c] - 64) << 8 | lim[c] << 16 | pm[c] << 20 | nlast[c] << 24;
 }
-// keep at least 128 words (4096 bits) resident beyond the cursor
-FI void ensure(Ent &e) {
-    if ((e.bitpos >> 5) + 128 > e.filled) {
-        __syncthreads();
-        ring_fill(e);
+FI uint32_t cat_word1(int c) {
+    const uint32_t sig[6] = {105, 120, 134, 149, 152, 402}, last[6] = {166, 181, 195, 210, 213, 417}, ab[6] = {227, 237, 247, 257, 266, 426};
+    c = c < 6 ? c : 0;
+    return sig[c] | last[c] << 10 | ab[c] << 20;
+}
+
+// ------------------------------------------------------------------ bit reader
+FI uint32_t load_win(const Ent &e, uint32_t base) {
+    const uint32_t i = base + LANE;
+    return i < e.rbsp_words ? __builtin_bswap32(e.rbsp32[i]) : 0u;
+}
+// The three window VGPRs cover 192 consecutive words from wbase.  The window slides at macroblock
+// boundaries only (slide_window): 128 words then remain ahead of the cursor, more than the 3200 bits
+// a macroblock_layer() may occupy (A.3.1); I_PCM samples are reached with seek().
+FI uint32_t fetch_word(Ent &e) {
+    const uint32_t idx = e.wpos - e.wbase;
+    e.wpos++;
+    const uint32_t w0 = RDL(e.win, idx), w1 = RDL(e.winn, idx), w2 = RDL(e.winx, idx); // the lane select is idx & 63
+    return idx < 64 ? w0 : (idx < 128 ? w1 : w2);
+}
+FI void slide_window(Ent &e) {
+    while (e.wpos - e.wbase >= 64) { // twice after a macroblock of more than 2048 bits
+        e.win = e.winn, e.winn = e.winx;
+        e.wbase += 64;
+        e.winx = load_win(e, e.wbase + 128); // consumed 64 words (>= one macroblock) later
     }
 }
-FI uint32_t peek32(const Ent &e, uint32_t pos) {
-    uint32_t w = pos >> 5, sh = pos & 31;
-    uint64_t v = (static_cast<uint64_t>(e.s->ring[w & (RING_WORDS - 1)]) << 32) | e.s->ring[(w + 1) & (RING_WORDS - 1)];
-    return static_cast<uint32_t>((v << sh) >> 32);
+FI uint32_t bitpos(const Ent &e) { return e.wpos * 32 - static_cast<uint32_t>(e.bcnt); }
+FI void seek(Ent &e, uint32_t pos) {
+    const uint32_t w = pos >> 5;
+    if (w - e.wbase >= 64) {
+        e.wbase = w;
+        e.win = load_win(e, w), e.winn = load_win(e, w + 64), e.winx = load_win(e, w + 128);
+    }
+    e.wpos = w;
+    const uint64_t hi = fetch_word(e), lo = fetch_word(e);
+    e.bitbuf = ((hi << 32) | lo) << (pos & 31);
+    e.bcnt = 64 - static_cast<int>(pos & 31);
 }
-FI uint32_t get_bits(Ent &e, int n) { // 1..25
-    uint32_t v = peek32(e, e.bitpos) >> (32 - n);
-    e.bitpos += n;
+FI uint32_t peek32(const Ent &e) { return static_cast<uint32_t>(e.bitbuf >> 32); }
+FI void skip(Ent &e, int n) { // 0..32
+    e.bitbuf <<= n;
+    e.bcnt -= n;
+    if (e.bcnt < 32) {
+        const uint64_t w = fetch_word(e);
+        e.bitbuf |= w << (32 - e.bcnt);
+        e.bcnt += 32;
+    }
+}
+FI uint32_t get_bits(Ent &e, int n) { // 1..32
+    const uint32_t v = peek32(e) >> (32 - n);
+    skip(e, n);
     return v;
 }
 FI uint32_t get_bit(Ent &e) { return get_bits(e, 1); }
 FI uint32_t get_ue(Ent &e) { // 9.1 with one CLZ
-    uint32_t w = peek32(e, e.bitpos);
+    const uint32_t w = peek32(e);
     if (w == 0) {
         e.err = 1;
-        e.bitpos += 32;
+        skip(e, 32);
         return 0;
     }
-    int lz = __clz(w);
+    const int lz = __clz(w);
     if (lz > 15) {
-        e.bitpos += lz + 1;
+        skip(e, lz + 1);
         return (1u << lz) - 1 + get_bits(e, lz);
     }
-    e.bitpos += 2 * lz + 1;
+    skip(e, 2 * lz + 1);
     return (w >> (31 - 2 * lz)) - 1;
 }
 FI int get_se(Ent &e) {
@@ -151,77 +211,48 @@ FI int get_se(Ent &e) {
 
 // ------------------------------------------------------------------ CABAC engine (9.3.1.2, 9.3.3.2)
 // codIOffset is kept scaled: value = (codIOffset << avail) | next `avail` stream bits.
-// The engine is scalar: range / value / avail live in SGPRs (every LDS result goes through
-// readfirstlane), and Tables 9-44 / 9-45 are held one state per lane in two VGPRs and looked up
-// with v_readlane, so a decision costs ONE LDS round trip (the context state) instead of three.
-#ifndef MI_SCALAR_CABAC
-#define MI_SCALAR_CABAC 1
-#endif
-#if MI_SCALAR_CABAC
-#define RFL(x) __builtin_amdgcn_readfirstlane(x)
-#else
-#define RFL(x) (x)
-#endif
-FI uint32_t speek32(const Ent &e, uint32_t pos) {
-    const uint32_t w = pos >> 5, sh = pos & 31;
-    const uint32_t hi = RFL(e.s->ring[w & (RING_WORDS - 1)]), lo = RFL(e.s->ring[(w + 1) & (RING_WORDS - 1)]);
-    return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32 | lo) << sh) >> 32);
-}
 FI void cabac_refill(Ent &e) {
     if (e.avail < 7) {
-        e.value = (e.value << 16) | (speek32(e, e.bitpos) >> 16);
-        e.bitpos += 16;
+        e.value = (e.value << 16) | (peek32(e) >> 16);
+        skip(e, 16);
         e.avail += 16;
     }
 }
 FI void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
     e.range = 510;
-    e.value = speek32(e, e.bitpos) >> 23;
-    e.bitpos += 9;
+    e.value = get_bits(e, 9);
     e.avail = 0;
     cabac_refill(e);
 }
-// DecodeDecision (h264/cabac.go:521-540) + state transition (:544-553) + RenormD (:503-511)
-#if MI_SCALAR_CABAC
-FI int cabac_bin(Ent &e, int ctx) {
-    const uint32_t st = RFL(static_cast<uint32_t>(e.s->ctx[ctx]));
-    const uint32_t p = st >> 1, mps = st & 1;
-    const uint32_t rl4 = __builtin_amdgcn_readlane(e.v_rlps, p);  // rangeTabLPS[p][0..3]
-    const uint32_t tr = __builtin_amdgcn_readlane(e.v_trans, p);  // transIdxLPS[p]
+// DecodeDecision (h264/cabac.go:521-540) + state transition (:544-553) + RenormD (:503-511) on the
+// context state held in lane `idx_` of `reg`
+FI int cabac_decide(Ent &e, uint32_t &reg, int idx_) {
+    MI_COUNT_BIN(e);
+    const int idx = RFL(idx_);
+    const uint32_t st = RDL(reg, idx);
+    const uint32_t p = st >> 1;
+    const uint32_t rl4 = RDL(e.v_rlps, p), tr = RDL(e.v_trans, p);
     const uint32_t rlps = (rl4 >> (((e.range >> 6) & 3) * 8)) & 255;
     const uint32_t rmps = e.range - rlps;
     const uint32_t scaled = rmps << e.avail;
     const bool lps = e.value >= scaled;
     e.value -= lps ? scaled : 0;
     e.range = lps ? rlps : rmps;
-    const uint32_t nmps = (p == 0 && lps) ? mps ^ 1 : mps;
-    const uint32_t np = lps ? tr : (p < 62 ? p + 1 : p);
-    e.s->ctx[ctx] = static_cast<uint8_t>((np << 1) | nmps);
-    const int n = __builtin_clz(e.range) - 23;
-    e.range <<= n;
-    e.avail -= n;
-    cabac_refill(e);
-    return static_cast<int>(mps ^ static_cast<uint32_t>(lps));
-}
-#else
-FI int cabac_bin(Ent &e, int ctx) { // vector form: merged Table 9-44/9-45 entry read from LDS
-    const uint32_t st = e.s->ctx[ctx];
-    const uint2 t = e.s->lps[st];
-    const uint32_t rlps = (t.x >> (((e.range >> 6) & 3) * 8)) & 255;
-    const uint32_t rmps = e.range - rlps;
-    const uint32_t scaled = rmps << e.avail;
-    const bool lps = e.value >= scaled;
-    e.value -= lps ? scaled : 0;
-    e.range = lps ? rlps : rmps;
-    e.s->ctx[ctx] = static_cast<uint8_t>(lps ? (t.y >> 8) : (t.y & 255));
+    const uint32_t next_mps = st < 124 ? st + 2 : st;
+    const uint32_t next_lps = (tr >> ((st & 1) * 8)) & 255;
+    reg = static_cast<uint32_t>(mi_writelane(static_cast<int>(lps ? next_lps : next_mps), idx, static_cast<int>(reg)));
     const int n = __builtin_clz(e.range) - 23;
     e.range <<= n;
     e.avail -= n;
     cabac_refill(e);
     return static_cast<int>((st & 1) ^ static_cast<uint32_t>(lps));
 }
-#endif
+#define BIN_A(e, ctx) cabac_decide(e, (e).ca, (ctx))          /* ctxIdx 0..63 */
+#define BIN_B(e, ctx) cabac_decide(e, (e).cb, (ctx) - 64)     /* ctxIdx 64..124 */
+#define BIN_T8(e, inc) cabac_decide(e, (e).cb, 61 + (inc))    /* ctxIdx 399..401 */
+#define BIN_W(e, lane) cabac_decide(e, (e).wk, (lane))        /* residual working set */
 FI int cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
+    MI_COUNT_BIN(e);
     e.avail -= 1;
     const uint32_t scaled = e.range << e.avail;
     const bool one = e.value >= scaled;
@@ -263,21 +294,30 @@ FI uint32_t top_load(const Ent &e, int col, int dw) {
 
 // ------------------------------------------------------------------ residual blocks
 // residual_block_cabac 7.3.5.3.3 for ctxBlockCat `cat`; coefficients are written de-zig-zagged.
-FI int cabac_residual(Ent &e, int16_t *dst, int cat, int cbf_inc) {
-    const uint16_t *cc = c_cat[cat];
-    const int maxnum = cc[0];
-    if (cat != 5 && !cabac_bin(e, cc[1] + cbf_inc)) return 0;
-    const int sbase = cc[2], lbase = cc[3], abase = cc[4], lim = cc[5];
-    const uint8_t *pm = e.s->posmap[cc[6]], *im = e.s->incmap[cc[7]];
+// The block's context states are gathered into e.wk (lanes 0..15 significant_coeff_flag, 16..31
+// last_significant_coeff_flag, 32..41 coeff_abs_level_minus1) while coded_block_flag is decoded and
+// scattered back to their LDS home afterwards.
+FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
+    const int cat = RFL(cat_);
+    const uint32_t c0 = RDL(e.v_cat0, cat), c1 = RDL(e.v_cat1, cat);
+    const int maxnum = c0 & 255, lim = (c0 >> 16) & 15, pmode = (c0 >> 20) & 15, nlast = (c0 >> 24) & 15;
+    const int l = LANE, grp = l >> 4, li = l & 15;
+    const int home = static_cast<int>((c1 >> (10 * (grp > 2 ? 2 : grp))) & 1023) + (l < 32 ? li : l - 32);
+    const uint32_t pending = e.s->ctx[home < 464 ? home : 463]; // the load overlaps the coded_block_flag decision
+    if (cat != 5 && !BIN_B(e, 64 + ((c0 >> 8) & 255) + cbf_inc)) return 0;
+    e.wk = pending;
+    const bool is8 = cat == 5;
+    const int cap = cat == 3 ? 2 : 15;
     uint64_t sigmask = 0;
     int n = 0, i = 0;
     for (; i < maxnum - 1; i++) {
-        const int inc_s = cat == 5 ? RFL(static_cast<int>(im[i])) : (cat == 3 ? (i < 2 ? i : 2) : i);
-        const int inc_l = cat == 5 ? RFL(static_cast<int>(e.s->lastmap[i])) : inc_s;
-        if (cabac_bin(e, sbase + inc_s)) {
+        const uint32_t m = RDL(e.v_maps, i);
+        const int inc_s = is8 ? static_cast<int>(m & 255) : (i < cap ? i : cap);
+        const int inc_l = is8 ? static_cast<int>((m >> 8) & 255) : inc_s;
+        if (BIN_W(e, inc_s)) {
             sigmask |= 1ull << i;
             n++;
-            if (cabac_bin(e, lbase + inc_l)) break;
+            if (BIN_W(e, 16 + inc_l)) break;
         }
     }
     if (i == maxnum - 1) sigmask |= 1ull << i, n++;
@@ -287,16 +327,21 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat, int cbf_inc) {
         sigmask &= ~(1ull << k);
         const int inc0 = gt1 ? 0 : (eq1 < 3 ? 1 + eq1 : 4);
         int a = 1;
-        if (cabac_bin(e, abase + inc0)) {
-            const int cx = abase + 5 + (gt1 < lim ? gt1 : lim);
+        if (BIN_W(e, 32 + inc0)) {
+            const int cx = 32 + 5 + (gt1 < lim ? gt1 : lim);
             a = 2;
-            while (a < 15 && cabac_bin(e, cx)) a++;
+            while (a < 15 && BIN_W(e, cx)) a++;
             if (a >= 15) a += cabac_egk(e, 0);
             gt1++;
         } else
             eq1++;
-        dst[pm[k]] = static_cast<int16_t>(cabac_bypass(e) ? -a : a);
+        const int pos = pmode == 3 ? k : (pmode == 2 ? static_cast<int>((RDL(e.v_maps, k) >> 16) & 255) : static_cast<int>(RDL(e.v_maps, (k + pmode) & 15) >> 24));
+        dst[pos] = static_cast<int16_t>(cabac_bypass(e) ? -a : a);
     }
+    // scatter the states back; lanes outside the block's own context ranges hold copies of other blocks'
+    // states and must not be written (for 8x8 blocks ctxIdx 417 appears in both the sig and the last group)
+    const int nsig = is8 ? 15 : maxnum - 1;
+    if (grp == 0 ? li < nsig : (grp == 1 ? li < nlast : l < 42)) e.s->ctx[home] = static_cast<uint8_t>(e.wk);
     return n;
 }
 
@@ -305,7 +350,7 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat, int cbf_inc) {
 FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
     const DevTables *t = e.tab;
     const int maxnum = kind == 1 ? 15 : (kind == 2 ? 4 : 16);
-    uint32_t w = peek32(e, e.bitpos);
+    uint32_t w = peek32(e);
     uint32_t ent;
     if (kind == 2)
         ent = t->vlc_cdc[w >> 24];
@@ -317,11 +362,12 @@ FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
         ent = t->vlc_ct2[w >> (32 - MI_VLC_CT2_BITS)];
     else
         ent = t->vlc_ct3[w >> 26];
+    ent = RFL(ent);
     if (!(ent >> 8)) {
         e.err = 6;
         return 0;
     }
-    e.bitpos += ent >> 8;
+    skip(e, ent >> 8);
     const int total = (ent >> 2) & 31, t1s = ent & 3;
     if (total == 0) return 0;
     if (total > maxnum) {
@@ -334,13 +380,13 @@ FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
         if (i < t1s)
             lv = 1 - 2 * static_cast<int>(get_bit(e));
         else {
-            uint32_t ww = peek32(e, e.bitpos);
+            uint32_t ww = peek32(e);
             if (ww == 0) {
                 e.err = 8;
                 return 0;
             }
             int prefix = __clz(ww);
-            e.bitpos += prefix + 1;
+            skip(e, prefix + 1);
             int code = (prefix < 15 ? prefix : 15) << suffix_len;
             if (suffix_len > 0 || prefix >= 14) {
                 int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
@@ -358,13 +404,13 @@ FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
     }
     int zeros_left = 0;
     if (total < maxnum) {
-        uint32_t ww = peek32(e, e.bitpos);
-        uint32_t en = kind == 2 ? t->vlc_cdc_tz[total - 1][ww >> 29] : t->vlc_tz[total - 1][ww >> 23];
+        uint32_t ww = peek32(e);
+        const uint32_t en = RFL(static_cast<uint32_t>(kind == 2 ? t->vlc_cdc_tz[total - 1][ww >> 29] : t->vlc_tz[total - 1][ww >> 23]));
         if (!(en >> 8)) {
             e.err = 9;
             return 0;
         }
-        e.bitpos += en >> 8;
+        skip(e, en >> 8);
         zeros_left = en & 255;
     }
     int pos = zeros_left + total - 1; // scan position of the highest-frequency coefficient
@@ -378,13 +424,13 @@ FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
         if (i < total - 1) {
             int run = 0;
             if (zeros_left > 0) {
-                uint32_t ww = peek32(e, e.bitpos);
-                uint32_t en = t->vlc_run[(zeros_left > 7 ? 7 : zeros_left) - 1][ww >> 21];
+                uint32_t ww = peek32(e);
+                const uint32_t en = RFL(static_cast<uint32_t>(t->vlc_run[(zeros_left > 7 ? 7 : zeros_left) - 1][ww >> 21]));
                 if (!(en >> 8) || static_cast<int>(en & 255) > zeros_left) {
                     e.err = 11;
                     return 0;
                 }
-                e.bitpos += en >> 8;
+                skip(e, en >> 8);
                 run = en & 255;
                 zeros_left -= run;
             }
@@ -432,7 +478,6 @@ FI void parse_residual(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
                 continue;
             }
             bx = (idx & 1) + 2 * ((idx >> 2) & 1), by = ((idx >> 1) & 1) + 2 * (idx >> 3);
-            if ((idx & 3) == 0) ensure(e);
             na = s->nnz_c[GI(bx - 1, by)], nb = s->nnz_c[GI(bx, by - 1)];
             if (t8x8 && cabac) {
                 cat = 5, kind = 0;
@@ -448,7 +493,6 @@ FI void parse_residual(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
         } else if (step <= 18) {
             if (!cbp_chroma) break;
             const int c = step - 17;
-            if (c == 0) ensure(e);
             cat = 3, kind = 2;
             dst = s->coef + MI_COEF_CDC + 4 * c;
             na = a ? ((a->cbf_dc >> (1 + c)) & 1) : 0x80, nb = b ? ((b->cbf_dc >> (1 + c)) & 1) : 0x80;
@@ -548,7 +592,7 @@ FI void fill_caches(Ent &e) {
     const TopInfo *a = mbA(e), *b = mbB(e);
     const TopInfo *c = mbC(e);
     const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
-    const int cip = e.pd->cip;
+    const int cip = e.cip;
     const int l = LANE;
     if (l < 30) {
         int gx = l % 6 - 1, gy = l / 6 - 1; // block coordinates relative to the MB
@@ -606,7 +650,7 @@ FI void fill_caches(Ent &e) {
         uint32_t *cz = reinterpret_cast<uint32_t *>(s->coef);
         for (int i = l; i < MI_COEF_PER_MB / 2; i += 64) cz[i] = 0;
     }
-    __syncthreads();
+    LDS_SYNC();
 }
 
 // ------------------------------------------------------------------ macroblock_layer() 7.3.5
@@ -634,26 +678,26 @@ FI void decode_mb(Ent &e, int skipped) {
         int intra_prefix = 1; // in P slices: bin 0 of mb_type says "intra"
         if (cabac) {
             if (!islice) {
-                intra_prefix = cabac_bin(e, 14);
-                if (!intra_prefix) raw = cabac_bin(e, 15) ? 2 - cabac_bin(e, 17) : 3 * cabac_bin(e, 16);
+                intra_prefix = BIN_A(e, 14);
+                if (!intra_prefix) raw = BIN_A(e, 15) ? 2 - BIN_A(e, 17) : 3 * BIN_A(e, 16);
             }
             if (intra_prefix) {
                 // I-slice bin string; `base` 3 with neighbour-dependent first bin, or the suffix at 17
                 int base = islice ? 3 : 17, it = 0, first;
                 if (islice) {
                     int inc = (a && a->type != MBT_I4x4 && a->type != MBT_I8x8) + (b && b->type != MBT_I4x4 && b->type != MBT_I8x8);
-                    first = cabac_bin(e, base + inc);
+                    first = BIN_A(e, base + inc);
                     base += 2;
                 } else
-                    first = cabac_bin(e, base);
+                    first = BIN_A(e, base);
                 if (first) {
                     if (cabac_terminate(e))
                         it = 25;
                     else {
-                        it = 1 + 12 * cabac_bin(e, base + 1);
-                        if (cabac_bin(e, base + 2)) it += 4 + 4 * cabac_bin(e, base + 2 + islice);
-                        it += 2 * cabac_bin(e, base + 3 + islice);
-                        it += cabac_bin(e, base + 3 + 2 * islice);
+                        it = 1 + 12 * BIN_A(e, base + 1);
+                        if (BIN_A(e, base + 2)) it += 4 + 4 * BIN_A(e, base + 2 + islice);
+                        it += 2 * BIN_A(e, base + 3 + islice);
+                        it += BIN_A(e, base + 3 + 2 * islice);
                     }
                 }
                 raw = islice ? it : it + 5;
@@ -680,17 +724,11 @@ FI void decode_mb(Ent &e, int skipped) {
         if (type == MBT_IPCM) {
             // after the terminate bin the arithmetic decoder has consumed exactly what the encoder's
             // flush wrote (9.3.1.2 / 9.3.4.5): stream position = bits fetched - lookahead
-            if (cabac) e.bitpos -= e.avail;
-            e.bitpos = (e.bitpos + 7) & ~7u;
-            ensure(e);
-            uint8_t *pcm = reinterpret_cast<uint8_t *>(s->coef);
-            for (int i = 0; i < 384; i += 4) {
-                uint32_t w = peek32(e, e.bitpos + i * 8);
-                pcm[i] = static_cast<uint8_t>(w >> 24), pcm[i + 1] = static_cast<uint8_t>(w >> 16);
-                pcm[i + 2] = static_cast<uint8_t>(w >> 8), pcm[i + 3] = static_cast<uint8_t>(w);
-            }
-            e.bitpos += 384 * 8;
-            ensure(e);
+            uint32_t pos = bitpos(e);
+            if (cabac) pos -= static_cast<uint32_t>(e.avail);
+            seek(e, (pos + 7) & ~7u);
+            uint32_t *pcm = reinterpret_cast<uint32_t *>(s->coef);
+            for (int i = 0; i < 96; i++) pcm[i] = __builtin_bswap32(get_bits(e, 32)); // 384 sample bytes in stream order
             if (cabac) cabac_start(e);
             for (int i = 0; i < 16; i++) s->nnz_c[GI(i & 3, i >> 2)] = 16, s->ref_c[GI(i & 3, i >> 2)] = -1;
             for (int i = 0; i < 8; i++) s->nnzc_c[i >> 2][(((i >> 1) & 1) + 1) * 3 + (i & 1) + 1] = 16;
@@ -717,7 +755,7 @@ FI void decode_mb(Ent &e, int skipped) {
                     for (int i = 0; i < 4; i++) {
                         int st;
                         if (cabac) // Table 9-38
-                            st = cabac_bin(e, 21) ? 0 : (!cabac_bin(e, 22) ? 1 : (cabac_bin(e, 23) ? 2 : 3));
+                            st = BIN_A(e, 21) ? 0 : (!BIN_A(e, 22) ? 1 : (BIN_A(e, 23) ? 2 : 3));
                         else
                             st = static_cast<int>(get_ue(e));
                         if (st > 3) e.err = 21, st = 0;
@@ -729,7 +767,7 @@ FI void decode_mb(Ent &e, int skipped) {
                     }
                 }
                 // ---- ref_idx_l0 per macroblock partition (7.3.5.1 / 7.3.5.2) ----
-                const int nref = e.sd->num_ref_idx_active;
+                const int nref = e.nref;
                 for (int i = 0; i < nref_parts; i++) {
                     int bx, by, w, h;
                     if (type == MBT_P8x8)
@@ -742,7 +780,7 @@ FI void decode_mb(Ent &e, int skipped) {
                     if (nref > 1 && raw != 4) {
                         if (cabac) { // 9.3.3.1.1.6
                             int ctx = (s->refi_c[GI(bx - 1, by)] > 0) + 2 * (s->refi_c[GI(bx, by - 1)] > 0);
-                            while (cabac_bin(e, 54 + ctx)) {
+                            while (BIN_A(e, 54 + ctx)) {
                                 ctx = (ctx >> 2) + 4;
                                 if (++ref > 31) {
                                     e.err = 3;
@@ -770,10 +808,10 @@ FI void decode_mb(Ent &e, int skipped) {
                             const int sum = s->mvd_c[GI(bx - 1, by)][comp] + s->mvd_c[GI(bx, by - 1)][comp];
                             const int base = comp ? 47 : 40;
                             v = 0;
-                            if (cabac_bin(e, base + (sum > 2) + (sum > 32))) {
+                            if (BIN_A(e, base + (sum > 2) + (sum > 32))) {
                                 int ctx = base + 3;
                                 v = 1;
-                                while (v < 9 && cabac_bin(e, ctx)) {
+                                while (v < 9 && BIN_A(e, ctx)) {
                                     if (v < 4) ctx++;
                                     v++;
                                 }
@@ -790,8 +828,8 @@ FI void decode_mb(Ent &e, int skipped) {
                 }
             } else {
                 // ---- intra: transform_size_8x8_flag, prediction modes, intra_chroma_pred_mode ----
-                if (type == MBT_I4x4 && e.pd->t8x8_mode) {
-                    t8x8 = cabac ? cabac_bin(e, 399 + (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
+                if (type == MBT_I4x4 && e.t8x8_mode) {
+                    t8x8 = cabac ? BIN_T8(e, (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
                     if (t8x8) type = MBT_I8x8, e.cur_type = type;
                 }
                 if (type == MBT_I4x4 || type == MBT_I8x8) {
@@ -806,9 +844,9 @@ FI void decode_mb(Ent &e, int skipped) {
                         const int pred = (pa < -1 || pb < -1) ? 2 : (pa < pb ? pa : pb); // 8.3.1.1: dcPredModePredictedFlag
                         int mode = pred;
                         if (cabac) {
-                            if (!cabac_bin(e, 68)) {
+                            if (!BIN_B(e, 68)) {
                                 int rem = 0;
-                                for (int k = 0; k < 3; k++) rem |= cabac_bin(e, 69) << k;
+                                for (int k = 0; k < 3; k++) rem |= BIN_B(e, 69) << k;
                                 mode = rem < pred ? rem : rem + 1;
                             }
                         } else if (!get_bit(e)) {
@@ -823,9 +861,9 @@ FI void decode_mb(Ent &e, int skipped) {
                     int inc = (a && MB_IS_INTRA(a->type) && a->type != MBT_IPCM && a->chroma_mode != 0) +
                               (b && MB_IS_INTRA(b->type) && b->type != MBT_IPCM && b->chroma_mode != 0);
                     chroma_mode = 0;
-                    if (cabac_bin(e, 64 + inc)) {
+                    if (BIN_B(e, 64 + inc)) {
                         chroma_mode = 1;
-                        while (chroma_mode < 3 && cabac_bin(e, 67)) chroma_mode++;
+                        while (chroma_mode < 3 && BIN_B(e, 67)) chroma_mode++;
                     }
                 } else {
                     chroma_mode = static_cast<int>(get_ue(e));
@@ -843,25 +881,25 @@ FI void decode_mb(Ent &e, int skipped) {
                     for (int b8 = 0; b8 < 4; b8++) {
                         int ca = (b8 & 1) ? (cbp >> (b8 - 1)) & 1 : (cbp_a >> (b8 + 1)) & 1;
                         int cb = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cbp_b >> (b8 + 2)) & 1;
-                        cbp |= cabac_bin(e, 73 + (!ca) + 2 * (!cb)) << b8;
+                        cbp |= BIN_B(e, 73 + (!ca) + 2 * (!cb)) << b8;
                     }
                     int ca = a && (a->type == MBT_IPCM || (a->cbp >> 4) != 0), cb = b && (b->type == MBT_IPCM || (b->cbp >> 4) != 0);
-                    if (cabac_bin(e, 77 + ca + 2 * cb)) {
+                    if (BIN_B(e, 77 + ca + 2 * cb)) {
                         ca = a && (a->type == MBT_IPCM || (a->cbp >> 4) == 2);
                         cb = b && (b->type == MBT_IPCM || (b->cbp >> 4) == 2);
-                        cbp |= (1 + cabac_bin(e, 77 + 4 + ca + 2 * cb)) << 4;
+                        cbp |= (1 + BIN_B(e, 77 + 4 + ca + 2 * cb)) << 4;
                     }
                 } else {
                     uint32_t k = get_ue(e);
                     if (k > 47) e.err = 23, k = 0;
-                    cbp = MB_IS_INTRA(type) ? e.tab->me_intra[k] : e.tab->me_inter[k];
+                    cbp = RFL(static_cast<int>(MB_IS_INTRA(type) ? e.tab->me_intra[k] : e.tab->me_inter[k]));
                 }
                 cbp_luma = cbp & 15, cbp_chroma = cbp >> 4;
-                if (cbp_luma && e.pd->t8x8_mode && MB_IS_INTER(type)) {
+                if (cbp_luma && e.t8x8_mode && MB_IS_INTER(type)) {
                     int all8 = 1;
                     if (type == MBT_P8x8)
                         for (int i = 0; i < 4; i++) all8 &= s->sub_type[i] == 0;
-                    if (all8) t8x8 = cabac ? cabac_bin(e, 399 + (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
+                    if (all8) t8x8 = cabac ? BIN_T8(e, (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
                 }
             }
             // ---- mb_qp_delta + residual ----
@@ -869,7 +907,7 @@ FI void decode_mb(Ent &e, int skipped) {
                 int dqp;
                 if (cabac) { // 9.3.2.7 / 9.3.3.1.1.5
                     int ctx = e.prev_dqp_nz ? 1 : 0, val = 0;
-                    while (cabac_bin(e, 60 + ctx)) {
+                    while (BIN_A(e, 60 + ctx)) {
                         ctx = 2 + (ctx >> 1);
                         if (++val > 104) {
                             e.err = 2;
@@ -893,14 +931,14 @@ FI void decode_mb(Ent &e, int skipped) {
     r.type = static_cast<uint8_t>(type);
     r.t8x8 = static_cast<uint8_t>(t8x8);
     r.qp = static_cast<uint8_t>(qp_store);
-    r.qpc[0] = e.tab->qpc[min(max(qp_store + e.pd->cqp_off[0], 0), 51)];
-    r.qpc[1] = e.tab->qpc[min(max(qp_store + e.pd->cqp_off[1], 0), 51)];
+    r.qpc[0] = static_cast<uint8_t>(RDL(e.v_qpc, min(max(qp_store + e.cqp_off0, 0), 51)));
+    r.qpc[1] = static_cast<uint8_t>(RDL(e.v_qpc, min(max(qp_store + e.cqp_off1, 0), 51)));
     r.cbp = static_cast<uint8_t>(cbp_luma | (cbp_chroma << 4));
     r.chroma_mode = static_cast<uint8_t>(chroma_mode);
     r.i16mode = static_cast<uint8_t>(i16mode);
     {
         // neighbour availability for intra prediction (6.4.x; constrained_intra_pred 8.3.1.2)
-        const int cip = e.pd->cip;
+        const int cip = e.cip;
         int av = 0;
         const TopInfo *c = mbC(e);
         const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
@@ -910,11 +948,8 @@ FI void decode_mb(Ent &e, int skipped) {
         if (c && !(cip && MB_IS_INTER(c->type))) av |= MI_AV_TOPRIGHT;
         r.avail = static_cast<uint8_t>(av);
     }
-    r.dbf_idc = e.sd->dbf_idc;
-    r.alpha_off = e.sd->alpha_off, r.beta_off = e.sd->beta_off;
-    r.slice_in_pic = e.sd->slice_in_pic;
-    r.slice_idx = blockIdx.x;
-    __syncthreads();
+    // dbf_idc / alpha_off / beta_off / slice_in_pic / slice_idx of the record are slice constants, written once at slice start
+    LDS_SYNC();
     // ---- parallel part: per-block arrays of the record, write-out, neighbour state update ----
     const int l = LANE;
     const int inter = MB_IS_INTER(type);
@@ -926,12 +961,12 @@ FI void decode_mb(Ent &e, int skipped) {
     } else if (l < 20) {
         int i = l - 16, ref = inter ? s->refs8[i] : -1;
         r.ref[i] = static_cast<int8_t>(ref);
-        r.refslot[i] = ref >= 0 ? e.sd->ref_slot[ref] : static_cast<int16_t>(-1);
+        r.refslot[i] = ref >= 0 ? s->ref_slot[ref & (MI_MAX_REFS - 1)] : static_cast<int16_t>(-1);
     }
     // remember the row-above entry of this column for the next MB's top-left neighbour, then build the new one
     TopInfo *tp = &s->topw[0];
     if (l >= 32 && l < 44) reinterpret_cast<uint32_t *>(&s->tl)[l - 32] = reinterpret_cast<const uint32_t *>(tp)[l - 32];
-    __syncthreads();
+    LDS_SYNC();
     if (l < 2) {
         TopInfo *dst = l == 0 ? tp : &s->left;
         dst->type = static_cast<uint8_t>(type);
@@ -956,7 +991,7 @@ FI void decode_mb(Ent &e, int skipped) {
         TopInfo *dst = is_left ? &s->left : tp;
         dst->nnz[4 + cpl * 2 + k] = is_left ? s->nnzc_c[cpl][(k + 1) * 3 + 2] : s->nnzc_c[cpl][2 * 3 + k + 1];
     }
-    __syncthreads();
+    LDS_SYNC();
     // new entry -> HBM row; slide the LDS window: [0] <- [1], [1] <- prefetched column x+2; prefetch x+3
     if (l < 12) {
         const uint32_t nw = reinterpret_cast<const uint32_t *>(tp)[l], w1 = reinterpret_cast<const uint32_t *>(&s->topw[1])[l];
@@ -965,84 +1000,94 @@ FI void decode_mb(Ent &e, int skipped) {
         reinterpret_cast<uint32_t *>(&s->topw[1])[l] = e.pre_top;
         e.pre_top = top_load(e, e.mbx + 3, l);
     }
-    const uint64_t mbi = e.pd->mb_base + static_cast<uint64_t>(e.mby) * e.wmb + e.mbx;
+    const uint64_t mbi = e.mb_base + static_cast<uint64_t>(e.mby) * e.wmb + e.mbx;
     if (l >= 32) // MbRec: 128 bytes = 32 dwords, lanes 32..63
         reinterpret_cast<uint32_t *>(e.mbrec + mbi)[l - 32] = reinterpret_cast<const uint32_t *>(&r)[l - 32];
     if (has_coef) { // 832 bytes = 52 x 16 B
         if (l < MI_COEF_PER_MB * 2 / 16) reinterpret_cast<uint4 *>(e.coefs + mbi * MI_COEF_PER_MB)[l] = reinterpret_cast<const uint4 *>(s->coef)[l];
     }
-    __syncthreads();
+    LDS_SYNC();
 }
 
 // ------------------------------------------------------------------ kernel: slice_data() 7.3.4
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
                                                            int16_t *coefs, uint32_t *status, uint32_t *toprows, int wmb_max) {
     __shared__ Shared sh;
+    const uint64_t t_begin = wall_clock64();
     Ent e;
     e.s = &sh;
+#if MI_ENT_STATS
+    e.bins = 0;
+#endif
     e.top = reinterpret_cast<TopInfo *>(toprows + static_cast<size_t>(blockIdx.x) * wmb_max * 12);
     e.pre_top = 0;
     e.tab = tab;
-    e.sd = &slices[blockIdx.x];
-    e.pd = &pics[e.sd->pic_idx];
-    e.rbsp = bitstream + e.sd->rbsp_off;
-    e.rbsp_words = (e.sd->rbsp_size + 3) >> 2;
+    const SliceDesc *sd = &slices[blockIdx.x];
+    const PicDesc *pd = &pics[sd->pic_idx];
+    e.sd = sd, e.pd = pd;
+    e.rbsp32 = reinterpret_cast<const uint32_t *>(bitstream + sd->rbsp_off); // slices are 16-byte aligned in the staging buffer
+    e.rbsp_words = RFL((sd->rbsp_size + 3) >> 2);
     e.mbrec = mbrec;
     e.coefs = coefs;
-    e.filled = 0;
-    e.bitpos = e.sd->data_bit_off;
     e.err = 0;
-    e.cabac = e.pd->cabac;
-    e.islice = e.sd->slice_type == 2;
-    e.wmb = static_cast<int>(e.pd->wmb), e.hmb = static_cast<int>(e.pd->hmb);
-    e.qp = e.sd->slice_qp;
+    e.cabac = RFL(static_cast<int>(pd->cabac));
+    e.islice = RFL(static_cast<int>(sd->slice_type == 2));
+    e.wmb = RFL(static_cast<int>(pd->wmb)), e.hmb = RFL(static_cast<int>(pd->hmb));
+    e.qp = RFL(static_cast<int>(sd->slice_qp));
+    e.cip = RFL(static_cast<int>(pd->cip)), e.t8x8_mode = RFL(static_cast<int>(pd->t8x8_mode));
+    e.cqp_off0 = RFL(static_cast<int>(pd->cqp_off[0])), e.cqp_off1 = RFL(static_cast<int>(pd->cqp_off[1]));
+    e.nref = RFL(static_cast<int>(sd->num_ref_idx_active));
+    e.mb_base = (static_cast<uint64_t>(RFL(static_cast<uint32_t>(pd->mb_base >> 32))) << 32) | RFL(static_cast<uint32_t>(pd->mb_base));
     e.prev_dqp_nz = 0;
     e.range = 510, e.value = 0, e.avail = 0;
     e.mbx = e.mby = 0, e.cur_type = 0;
     const int l = LANE;
-    // ---- tables -> LDS ----
-    { // Tables 9-44 / 9-45: lane p keeps the entries of pStateIdx p
+    // ---- per-lane tables ----
+    { // Tables 9-44 / 9-45: lane p keeps the entries of pStateIdx p; the transition entry is the complete next
+      // state (pStateIdx << 1 | valMPS) after an LPS, for valMPS 0 in byte 0 and valMPS 1 in byte 1
         const uint8_t *rl = tab->range_lps[l];
         e.v_rlps = rl[0] | (rl[1] << 8) | (rl[2] << 16) | (static_cast<uint32_t>(rl[3]) << 24);
-        e.v_trans = tab->trans_lps[l];
+        const uint32_t pl = tab->trans_lps[l];
+        e.v_trans = ((pl << 1) | (l == 0 ? 1u : 0u)) | (((pl << 1) | (l == 0 ? 0u : 1u)) << 8);
     }
-#if !MI_SCALAR_CABAC
-    for (int st = l; st < 128; st += 64) {
-        const int p = st >> 1, mps = st & 1;
-        const uint8_t *rl = tab->range_lps[p];
-        const int pl = tab->trans_lps[p], pm = p < 62 ? p + 1 : p;
-        const int next_lps = (pl << 1) | (p == 0 ? mps ^ 1 : mps), next_mps = (pm << 1) | mps;
-        sh.lps[st] = make_uint2(rl[0] | (rl[1] << 8) | (rl[2] << 16) | (static_cast<uint32_t>(rl[3]) << 24), next_mps | (next_lps << 8));
-    }
-#endif
+    e.v_maps = tab->sig8x8[l] | (tab->last8x8[l] << 8) | (tab->zigzag8[l] << 16) | (static_cast<uint32_t>(tab->zigzag4[l & 15]) << 24);
+    e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l);
+    e.v_qpc = tab->qpc[l < 52 ? l : 51];
     sh.posmap[0][l] = tab->zigzag4[l & 15];
     sh.posmap[1][l] = tab->zigzag4[(l + 1) & 15];
     sh.posmap[2][l] = tab->zigzag8[l];
     sh.posmap[3][l] = static_cast<uint8_t>(l);
-    sh.incmap[0][l] = static_cast<uint8_t>(l);
-    sh.incmap[1][l] = static_cast<uint8_t>(l < 2 ? l : 2);
-    sh.incmap[2][l] = tab->sig8x8[l];
-    sh.lastmap[l] = tab->last8x8[l];
-    {
-        int set = e.islice ? 0 : 1 + e.sd->cabac_init_idc;
-        const uint8_t *src = tab->ctx_init[set][e.sd->slice_qp];
+    if (l < MI_MAX_REFS) sh.ref_slot[l] = sd->ref_slot[l];
+    { // context variables 9.3.1.1: macroblock-level states into the two VGPRs, residual states into LDS
+        const int set = e.islice ? 0 : 1 + sd->cabac_init_idc;
+        const uint8_t *src = tab->ctx_init[set][sd->slice_qp];
+        e.ca = src[l];
+        e.cb = src[l < 61 ? 64 + l : 399 + (l - 61)];
+        e.wk = 0;
         for (int i = l; i < 464; i += 64) sh.ctx[i] = src[i];
+    }
+    if (l < 32) reinterpret_cast<uint32_t *>(&sh.rec)[l] = 0;
+    LDS_SYNC();
+    if (l == 0) { // slice constants of every MbRec
+        sh.rec.dbf_idc = sd->dbf_idc;
+        sh.rec.alpha_off = sd->alpha_off, sh.rec.beta_off = sd->beta_off;
+        sh.rec.slice_in_pic = sd->slice_in_pic;
+        sh.rec.slice_idx = blockIdx.x;
     }
     for (int i = l; i < e.wmb * 12; i += 64) reinterpret_cast<uint32_t *>(e.top)[i] = 0; // all row-above entries: type NONE
     if (l < 12) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
     if (l < 24) reinterpret_cast<uint32_t *>(&sh.topw[0])[l] = 0;
-    __syncthreads();
-    // start at the ring chunk containing the first slice_data bit
-    e.filled = (e.bitpos >> 5) & ~255u;
-    ring_fill(e);
-    ring_fill(e);
-    if (e.cabac) {
-        e.bitpos = (e.bitpos + 7) & ~7u; // cabac_alignment_one_bit
-        cabac_start(e);
+    LDS_SYNC();
+    {
+        uint32_t pos = RFL(sd->data_bit_off);
+        if (e.cabac) pos = (pos + 7) & ~7u; // cabac_alignment_one_bit
+        e.wbase = 0x80000000u; // force the window load
+        seek(e, pos);
+        if (e.cabac) cabac_start(e);
     }
     const int total = e.wmb * e.hmb;
-    const uint32_t stop_bit = e.sd->stop_bit;
-    int addr = static_cast<int>(e.sd->first_mb);
+    const uint32_t stop_bit = RFL(sd->stop_bit);
+    int addr = RFL(static_cast<int>(sd->first_mb));
     e.mbx = addr % e.wmb, e.mby = addr / e.wmb;
     int more = 1, skip_state = 0 /* 0: read mb_skip_run, 1: inside a run, 2: coded MB follows a run */, pending = 0;
     int n_mbs = 0;
@@ -1053,17 +1098,18 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         }
         if (e.mbx == 0 || n_mbs == 0) { // new MB row (or slice start): no left / top-left neighbour; (re)load the row-above window
             if (l < 12) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stores of the previous row to e.top[] have been issued to L2
             if (l < 24) reinterpret_cast<uint32_t *>(&sh.topw[0])[l] = top_load(e, e.mbx + l / 12, l % 12);
             if (l < 12) e.pre_top = top_load(e, e.mbx + 2, l);
-            __syncthreads();
+            LDS_SYNC();
         }
-        ensure(e);
+        slide_window(e);
         fill_caches(e);
         int skipped = 0;
         if (!e.islice) {
             if (e.cabac) {
                 const TopInfo *a = mbA(e), *b = mbB(e);
-                skipped = cabac_bin(e, 11 + (a && a->type != MBT_PSKIP) + (b && b->type != MBT_PSKIP));
+                skipped = BIN_A(e, 11 + (a && a->type != MBT_PSKIP) + (b && b->type != MBT_PSKIP));
             } else {
                 if (skip_state == 0) {
                     pending = static_cast<int>(get_ue(e));
@@ -1082,18 +1128,20 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
             more = !cabac_terminate(e);
         else if (skipped) {
             if (pending == 0) {
-                more = e.bitpos < stop_bit;
+                more = bitpos(e) < stop_bit;
                 skip_state = 2;
             }
         } else {
-            more = e.bitpos < stop_bit;
+            more = bitpos(e) < stop_bit;
             skip_state = 0;
         }
         addr++;
         if (++e.mbx == e.wmb) e.mbx = 0, e.mby++;
     }
     if (l == 0) {
-        status[2 * blockIdx.x] = static_cast<uint32_t>(e.err);
-        status[2 * blockIdx.x + 1] = static_cast<uint32_t>(n_mbs);
+        status[4 * blockIdx.x] = static_cast<uint32_t>(e.err);
+        status[4 * blockIdx.x + 1] = static_cast<uint32_t>(n_mbs);
+        status[4 * blockIdx.x + 2] = static_cast<uint32_t>(wall_clock64() - t_begin);
+        status[4 * blockIdx.x + 3] = MI_BINS(e);
     }
 }

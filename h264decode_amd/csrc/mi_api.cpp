@@ -281,8 +281,8 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipHostMalloc(&d->h_slices, sizeof(SliceDesc) * d->slices_cap));
     TRY_ALLOC(hipMalloc(&d->d_pics, sizeof(PicDesc) * d->pics_cap));
     TRY_ALLOC(hipHostMalloc(&d->h_pics, sizeof(PicDesc) * d->pics_cap));
-    TRY_ALLOC(hipMalloc(&d->d_status, sizeof(uint32_t) * 2 * d->slices_cap));
-    TRY_ALLOC(hipHostMalloc(&d->h_status, sizeof(uint32_t) * 2 * d->slices_cap));
+    TRY_ALLOC(hipMalloc(&d->d_status, sizeof(uint32_t) * 4 * d->slices_cap));
+    TRY_ALLOC(hipHostMalloc(&d->h_status, sizeof(uint32_t) * 4 * d->slices_cap));
     TRY_ALLOC(hipMalloc(&d->d_lists, sizeof(uint32_t) * 2 * d->pics_cap));
     TRY_ALLOC(hipHostMalloc(&d->h_lists, sizeof(uint32_t) * 2 * d->pics_cap));
     {
@@ -901,7 +901,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     if (!prof) HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_rec[set], 0)); // the caller's stream sees the finished pass
     d->pass++;
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(d->h_status, d->d_status, sizeof(uint32_t) * 2 * d->n_slices, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(d->h_status, d->d_status, sizeof(uint32_t) * 4 * d->n_slices, hipMemcpyDeviceToHost, d->stream));
     d->ev_used = prof ? ei : 0;
     return H264MI_OK;
 }
@@ -925,11 +925,18 @@ extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
         for (int k = 0; k < 4; k++) d->k_ms[k] = acc[k];
         d->k_ms[4] = tot;
     }
+    if (getenv("H264MI_SLICE_STATS")) { // diagnostics: per-slice entropy time (100 MHz ticks) and bin count (MI_ENT_STATS builds)
+        for (int i = 0; i < d->n_slices && i < 64; i++)
+            fprintf(stderr, "slice %d type %d bytes %u mbs %u us %.1f bins %u\n", i, d->h_slices[i].slice_type, d->h_slices[i].rbsp_size, d->h_status[4 * i + 1],
+                    d->h_status[4 * i + 2] * 0.01, d->h_status[4 * i + 3]);
+        fprintf(stderr, "last slice type %d bytes %u mbs %u us %.1f bins %u\n", d->h_slices[d->n_slices - 1].slice_type, d->h_slices[d->n_slices - 1].rbsp_size,
+                d->h_status[4 * (d->n_slices - 1) + 1], d->h_status[4 * (d->n_slices - 1) + 2] * 0.01, d->h_status[4 * (d->n_slices - 1) + 3]);
+    }
     for (int i = 0; i < d->n_slices; i++)
-        if (d->h_status[2 * i]) {
+        if (d->h_status[4 * i]) {
             const SliceDesc &sd = d->h_slices[i];
             set_error("entropy kernel: slice %d (picture %u, stream %u) failed with code %u after %u macroblocks", i, sd.pic_idx, d->h_pics[sd.pic_idx].stream,
-                      d->h_status[2 * i], d->h_status[2 * i + 1]);
+                      d->h_status[4 * i], d->h_status[4 * i + 1]);
             return H264MI_EDECODE;
         }
     return H264MI_OK;
