@@ -23,6 +23,11 @@
 #include <hip/hip_runtime.h>
 #include "mi_kernels.h"
 
+// Register budget: 512 / MI_ENT_MINWAVES VGPRs per wavefront.  The entropy kernel is latency-bound, and the
+// reconstruction kernels of the previous pass must find free registers next to it.
+#ifndef MI_ENT_MINWAVES
+#define MI_ENT_MINWAVES 4
+#endif
 #define LANE (static_cast<int>(threadIdx.x))
 #define FI __device__ __forceinline__
 // The workgroup is ONE wavefront: cross-lane LDS visibility needs no s_barrier and, above all, no
@@ -60,8 +65,8 @@ struct Shared {
     uint8_t nnzc_c[2][12]; // chroma 3x3 grids
     int8_t ref_c[32];      // -2 unavailable or not yet decoded, -1 intra, >= 0 ref_idx (motion final)
     int8_t refi_c[32];     // ref_idx as soon as parsed (CABAC ctxIdxInc of ref_idx)
-    int16_t mv_c[32][2];
-    uint8_t mvd_c[32][2];
+    alignas(4) int16_t mv_c[32][2];
+    alignas(2) uint8_t mvd_c[32][2];
     int16_t lvl[16];       // CAVLC level scratch
     int16_t tmp16[16];     // CAVLC 8x8 interleave scratch
     uint16_t parts[16];    // motion partition schedule: bx | by<<2 | (w-1)<<4 | (h-1)<<6 | shape<<8
@@ -99,7 +104,7 @@ struct Ent {
     uint32_t range, value;
     int avail;
     uint32_t ca, cb, wk;     // context states, see above; cb lanes 61..63 = ctxIdx 399..401
-    uint32_t v_rlps, v_trans; // lane p: rangeTabLPS[p][0..3] / next state after an LPS for valMPS 0 (byte 0) and 1 (byte 1)
+    uint32_t v_rlps, v_trans; // lane p: rangeTabLPS[p][0..3] / next state after an LPS for valMPS 0
     uint32_t v_maps;         // lane i: sig8x8[i] | last8x8[i] << 8 | zigzag8[i] << 16 | zigzag4[i & 15] << 24
     uint32_t v_cat0, v_cat1; // lane ctxBlockCat: packed block-category parameters (cat_word0/1)
     uint32_t v_qpc, v_refslot; // lane i: QPc table entry / frame slot of ref_idx i
@@ -176,7 +181,7 @@ FI uint32_t peek32(const Ent &e) { return static_cast<uint32_t>(e.bitbuf >> 32);
 FI void skip(Ent &e, int n) { // 0..32
     e.bitbuf <<= n;
     e.bcnt -= n;
-    if (e.bcnt < 32) {
+    if (__builtin_expect(e.bcnt < 32, 0)) {
         const uint64_t w = fetch_word(e);
         e.bitbuf |= w << (32 - e.bcnt);
         e.bcnt += 32;
@@ -211,8 +216,18 @@ FI int get_se(Ent &e) {
 
 // ------------------------------------------------------------------ CABAC engine (9.3.1.2, 9.3.3.2)
 // codIOffset is kept scaled: value = (codIOffset << avail) | next `avail` stream bits.
+//
+// Issue balance.  A compute unit has ONE scalar ALU (about one SALU instruction per cycle for all of
+// its wavefronts) next to four vector ALUs, and tens of slices share a CU, so a decoder written purely
+// in scalar instructions is bound by that single unit.  The engine is therefore split: the data path
+// (codIRange / codIOffset arithmetic, renormalisation, state selection) runs on the VALU with the
+// same value in every lane, while table indices, loop control and branches stay scalar.  VGPR() pins
+// a wave-uniform value to the vector side; UNI() turns a vector-side condition into a scalar branch
+// condition (v_cmp writes the lane mask, one s_cmp tests it).
+#define VGPR(x) asm volatile("" : "+v"(x))
+#define UNI(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
 FI void cabac_refill(Ent &e) {
-    if (e.avail < 7) {
+    if (__builtin_expect(UNI(e.avail < 7), 0)) { // about once per 13 decisions: keep the common path fall-through
         e.value = (e.value << 16) | (peek32(e) >> 16);
         skip(e, 16);
         e.avail += 16;
@@ -222,52 +237,58 @@ FI void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
     e.range = 510;
     e.value = get_bits(e, 9);
     e.avail = 0;
+    VGPR(e.range);
+    VGPR(e.value);
+    VGPR(e.avail);
     cabac_refill(e);
 }
 // DecodeDecision (h264/cabac.go:521-540) + state transition (:544-553) + RenormD (:503-511) on the
 // context state held in lane `idx_` of `reg`
-FI int cabac_decide(Ent &e, uint32_t &reg, int idx_) {
+FI bool cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     MI_COUNT_BIN(e);
     const int idx = RFL(idx_);
     const uint32_t st = RDL(reg, idx);
-    const uint32_t p = st >> 1;
+    const uint32_t p = st >> 1, mps = st & 1;
     const uint32_t rl4 = RDL(e.v_rlps, p), tr = RDL(e.v_trans, p);
-    const uint32_t rlps = (rl4 >> (((e.range >> 6) & 3) * 8)) & 255;
+    // scalar side: the two candidate successor states (v_trans holds the LPS successor for valMPS 0; bit 0 flips with valMPS)
+    const uint32_t next_lps = tr ^ mps;
+    const uint32_t next_mps = min(st + 2, 124 + mps);
+    // vector side
+    const uint32_t rlps = __builtin_amdgcn_ubfe(rl4, (e.range >> 3) & 24, 8);
     const uint32_t rmps = e.range - rlps;
     const uint32_t scaled = rmps << e.avail;
     const bool lps = e.value >= scaled;
-    e.value -= lps ? scaled : 0;
+    e.value = min(e.value, e.value - scaled); // value - scaled wraps when value < scaled
     e.range = lps ? rlps : rmps;
-    const uint32_t next_mps = st < 124 ? st + 2 : st;
-    const uint32_t next_lps = (tr >> ((st & 1) * 8)) & 255;
-    reg = static_cast<uint32_t>(mi_writelane(static_cast<int>(lps ? next_lps : next_mps), idx, static_cast<int>(reg)));
+    const uint32_t nst = lps ? next_lps : next_mps;
+    reg = LANE == idx ? nst : reg;
     const int n = __builtin_clz(e.range) - 23;
     e.range <<= n;
     e.avail -= n;
     cabac_refill(e);
-    return static_cast<int>((st & 1) ^ static_cast<uint32_t>(lps));
+    return UNI(lps) != (mps != 0);
 }
 #define BIN_A(e, ctx) cabac_decide(e, (e).ca, (ctx))          /* ctxIdx 0..63 */
 #define BIN_B(e, ctx) cabac_decide(e, (e).cb, (ctx) - 64)     /* ctxIdx 64..124 */
 #define BIN_T8(e, inc) cabac_decide(e, (e).cb, 61 + (inc))    /* ctxIdx 399..401 */
 #define BIN_W(e, lane) cabac_decide(e, (e).wk, (lane))        /* residual working set */
-FI int cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
+FI bool cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
     MI_COUNT_BIN(e);
     e.avail -= 1;
     const uint32_t scaled = e.range << e.avail;
     const bool one = e.value >= scaled;
-    e.value -= one ? scaled : 0;
+    e.value = min(e.value, e.value - scaled);
     cabac_refill(e);
-    return one;
+    return UNI(one);
 }
-FI int cabac_terminate(Ent &e) { // 9.3.3.2.4
+FI bool cabac_terminate(Ent &e) { // 9.3.3.2.4
     e.range -= 2;
-    if (e.value >= (e.range << e.avail)) return 1;
+    if (UNI(e.value >= (e.range << e.avail))) return true;
     const int n = __builtin_clz(e.range) - 23;
     e.range <<= n;
     e.avail -= n;
     cabac_refill(e);
-    return 0;
+    return false;
 }
 // Exp-Golomb suffix of UEGk binarisations (9.3.2.3), bypass coded
 FI int cabac_egk(Ent &e, int k) {
@@ -575,14 +596,15 @@ FI void predict_mv(const Ent &e, int bx, int by, int w, int ref, int shape, int 
 }
 FI void set_part(Ent &e, int bx, int by, int w, int h, int ref, int mvx, int mvy, int dx, int dy) {
     Shared *s = e.s;
-    uint8_t ax = static_cast<uint8_t>(min(abs(dx), 255)), ay = static_cast<uint8_t>(min(abs(dy), 255));
-    for (int y = by; y < by + h; y++)
-        for (int x = bx; x < bx + w; x++) {
-            int g = GI(x, y);
-            s->ref_c[g] = static_cast<int8_t>(ref);
-            s->mv_c[g][0] = static_cast<int16_t>(mvx), s->mv_c[g][1] = static_cast<int16_t>(mvy);
-            s->mvd_c[g][0] = ax, s->mvd_c[g][1] = ay;
-        }
+    const uint8_t ax = static_cast<uint8_t>(min(abs(dx), 255)), ay = static_cast<uint8_t>(min(abs(dy), 255));
+    const int l = LANE, x = l & 3, y = (l >> 2) & 3; // one 4x4 block per lane (lanes 0..15)
+    if (l < 16 && x >= bx && x < bx + w && y >= by && y < by + h) {
+        const int g = GI(x, y);
+        s->ref_c[g] = static_cast<int8_t>(ref);
+        *reinterpret_cast<uint32_t *>(s->mv_c[g]) = (static_cast<uint32_t>(mvx) & 0xffffu) | (static_cast<uint32_t>(mvy) << 16);
+        *reinterpret_cast<uint16_t *>(s->mvd_c[g]) = static_cast<uint16_t>(ax | (ay << 8));
+    }
+    LDS_SYNC();
 }
 #define PART(bx, by, w, h, shape) static_cast<uint16_t>((bx) | ((by) << 2) | (((w)-1) << 4) | (((h)-1) << 6) | ((shape) << 8))
 
@@ -725,7 +747,7 @@ FI void decode_mb(Ent &e, int skipped) {
             // after the terminate bin the arithmetic decoder has consumed exactly what the encoder's
             // flush wrote (9.3.1.2 / 9.3.4.5): stream position = bits fetched - lookahead
             uint32_t pos = bitpos(e);
-            if (cabac) pos -= static_cast<uint32_t>(e.avail);
+            if (cabac) pos -= static_cast<uint32_t>(RFL(e.avail));
             seek(e, (pos + 7) & ~7u);
             uint32_t *pcm = reinterpret_cast<uint32_t *>(s->coef);
             for (int i = 0; i < 96; i++) pcm[i] = __builtin_bswap32(get_bits(e, 32)); // 384 sample bytes in stream order
@@ -791,10 +813,14 @@ FI void decode_mb(Ent &e, int skipped) {
                             ref = nref == 2 ? !get_bit(e) : static_cast<int>(get_ue(e));
                         if (ref >= nref || ref >= MI_MAX_REFS) e.err = 13, ref = 0;
                     }
-                    for (int y = by; y < by + h; y++)
-                        for (int x = bx; x < bx + w; x++) s->refi_c[GI(x, y)] = static_cast<int8_t>(ref);
-                    for (int y = by; y < by + h; y += 2)
-                        for (int x = bx; x < bx + w; x += 2) s->refs8[(y >> 1) * 2 + (x >> 1)] = static_cast<int8_t>(ref);
+                    { // one 4x4 block per lane: ref_idx cache for the ctxIdxInc of later partitions, and the per-8x8 list
+                        const int l = LANE, x = l & 3, y = (l >> 2) & 3;
+                        if (l < 16 && x >= bx && x < bx + w && y >= by && y < by + h) {
+                            s->refi_c[GI(x, y)] = static_cast<int8_t>(ref);
+                            if (!((x | y) & 1)) s->refs8[(y >> 1) * 2 + (x >> 1)] = static_cast<int8_t>(ref);
+                        }
+                        LDS_SYNC();
+                    }
                 }
                 // ---- mvd_l0 + prediction per (sub-)partition ----
                 for (int i = 0; i < nparts; i++) {
@@ -869,7 +895,7 @@ FI void decode_mb(Ent &e, int skipped) {
                     chroma_mode = static_cast<int>(get_ue(e));
                     if (chroma_mode > 3) e.err = 22, chroma_mode = 0;
                 }
-                for (int i = 0; i < 16; i++) s->ref_c[GI(i & 3, i >> 2)] = -1;
+                if (LANE < 16) s->ref_c[GI(LANE & 3, LANE >> 2)] = -1;
             }
             // ---- coded_block_pattern ----
             if (type != MBT_I16x16) {
@@ -1010,7 +1036,7 @@ FI void decode_mb(Ent &e, int skipped) {
 }
 
 // ------------------------------------------------------------------ kernel: slice_data() 7.3.4
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI_ENT_MINWAVES, 8))) k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
                                                            int16_t *coefs, uint32_t *status, uint32_t *toprows, int wmb_max) {
     __shared__ Shared sh;
     const uint64_t t_begin = wall_clock64();
@@ -1043,12 +1069,11 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     e.mbx = e.mby = 0, e.cur_type = 0;
     const int l = LANE;
     // ---- per-lane tables ----
-    { // Tables 9-44 / 9-45: lane p keeps the entries of pStateIdx p; the transition entry is the complete next
-      // state (pStateIdx << 1 | valMPS) after an LPS, for valMPS 0 in byte 0 and valMPS 1 in byte 1
+    { // Tables 9-44 / 9-45: lane p keeps the entries of pStateIdx p; the transition entry is the complete next state
+      // (pStateIdx << 1 | valMPS) after an LPS for valMPS 0 -- XOR with valMPS gives the other one (pStateIdx 0 flips the MPS)
         const uint8_t *rl = tab->range_lps[l];
         e.v_rlps = rl[0] | (rl[1] << 8) | (rl[2] << 16) | (static_cast<uint32_t>(rl[3]) << 24);
-        const uint32_t pl = tab->trans_lps[l];
-        e.v_trans = ((pl << 1) | (l == 0 ? 1u : 0u)) | (((pl << 1) | (l == 0 ? 0u : 1u)) << 8);
+        e.v_trans = (static_cast<uint32_t>(tab->trans_lps[l]) << 1) | (l == 0 ? 1u : 0u);
     }
     e.v_maps = tab->sig8x8[l] | (tab->last8x8[l] << 8) | (tab->zigzag8[l] << 16) | (static_cast<uint32_t>(tab->zigzag4[l & 15]) << 24);
     e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l);
