@@ -172,8 +172,18 @@ def main():
     dom = max(("k_inter", "k_deblock"), key=lambda k: kt["inter" if k == "k_inter" else "deblock"])
     dur_ms, alg_bytes = per_launch[dom]
     achieved = alg_bytes / (dur_ms * 1e-3) / 1e9 if dur_ms > 0 else 0.0
+    # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc pass (counters cannot be
+    # collected from inside this process): profiles/pmc_traffic.json, written by tools/pmc_traffic.sh
+    # for the same workload, holds corrected bytes per launch; null when it does not match this run.
+    traffic = None
+    try:
+        pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pt.get("streams") == S and pt.get("frames") == F and pt.get("width") == args.width and dom in pt.get("bytes_per_launch", {}):
+            traffic = pt["bytes_per_launch"][dom]
+    except (OSError, ValueError):
+        pass
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "launch_ms": round(dur_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
                 "all_kernels_ms_per_step": {k: round(v, 3) for k, v in kt.items()},
                 "per_launch": {k: {"ms": round(v[0], 4), "GB/s": round(v[1] / (v[0] * 1e-3) / 1e9, 2) if v[0] > 0 else 0.0} for k, v in per_launch.items()}}
@@ -182,15 +192,24 @@ def main():
     if not args.no_cpu_baseline:
         import oracle
         sample = streams[0]
+        sinfo = oracle.probe(sample)  # sizing pass outside the timed region: each timed call is exactly one decode
         reps, tcpu = 0, 0.0
         while tcpu < 10.0 and reps < 8:
             t1 = time.perf_counter()
-            oracle.decode(sample, crop=False)
+            oracle.decode(sample, crop=False, info=sinfo)
             tcpu += time.perf_counter() - t1
             reps += 1
         cpu_baseline = {"value": round(reps * F / tcpu, 3), "unit": "frames/s", "cores": 1, "kind": "port",
                         "sample": "%d x stream 0 (%d frames 1080p Main CABAC, %.0f KB) decoded by oracle/ (scalar C restatement; the Go reference "
                                   "cannot be built and produces no pixels)" % (reps, F, len(sample) / 1e3)}
+        # one independent stream per host core (ctypes releases the GIL inside the C decoder)
+        ncore = max(1, min(len(os.sched_getaffinity(0)), 64))
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=ncore) as ex:
+            list(ex.map(lambda i: oracle.decode(streams[i % S], crop=False, info=sinfo)[0].shape, range(ncore)))
+        tmt = time.perf_counter() - t1
+        cpu_baseline["all_cores"] = {"value": round(ncore * F / tmt, 2), "unit": "frames/s", "cores": ncore,
+                                     "sample": "%d streams (one per core) x %d frames" % (ncore, F)}
 
     out = {
         "metric": "1080p Main CABAC frames/sec",
@@ -211,6 +230,8 @@ def main():
         "mpixels_per_s": round(fps * args.width * args.height / 1e6, 1),
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
+        "entropy_stage": {"bits_per_s": round(bytes_per_frame * 8 * S * F / (kt["entropy"] * 1e-3), 0), "slices_in_flight": S * F,
+                          "kernel_ms": round(kt["entropy"], 3), "note": "k_entropy alone, one slice per wavefront; latency of the I slice bounds it"},
         "end_to_end_fps": round(S * F / e2e_s, 2),
         "host_prepare_ms": round(prepare_s * 1e3, 2),
         "parity": parity,

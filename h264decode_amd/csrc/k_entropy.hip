@@ -106,6 +106,7 @@ struct Ent {
     uint32_t ca, cb, wk;     // context states, see above; cb lanes 61..63 = ctxIdx 399..401
     uint32_t v_rlps, v_trans; // lane p: rangeTabLPS[p][0..3] / next state after an LPS for valMPS 0
     uint32_t v_maps;         // lane i: sig8x8[i] | last8x8[i] << 8 | zigzag8[i] << 16 | zigzag4[i & 15] << 24
+    uint32_t v_zzac;         // lane i: zigzag4[(i + 1) & 15] (AC blocks: scan index i is coefficient i + 1)
     uint32_t v_cat0, v_cat1; // lane ctxBlockCat: packed block-category parameters (cat_word0/1)
     uint32_t v_qpc, v_refslot; // lane i: QPc table entry / frame slot of ref_idx i
     int qp, prev_dqp_nz, mbx, mby, cur_type, err;
@@ -266,7 +267,8 @@ FI bool cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     e.range <<= n;
     e.avail -= n;
     cabac_refill(e);
-    return UNI(lps) != (mps != 0);
+    const uint32_t binv = lps ? mps ^ 1 : mps;
+    return UNI(binv != 0);
 }
 #define BIN_A(e, ctx) cabac_decide(e, (e).ca, (ctx))          /* ctxIdx 0..63 */
 #define BIN_B(e, ctx) cabac_decide(e, (e).cb, (ctx) - 64)     /* ctxIdx 64..124 */
@@ -317,51 +319,68 @@ FI uint32_t top_load(const Ent &e, int col, int dw) {
 // residual_block_cabac 7.3.5.3.3 for ctxBlockCat `cat`; coefficients are written de-zig-zagged.
 // The block's context states are gathered into e.wk (lanes 0..15 significant_coeff_flag, 16..31
 // last_significant_coeff_flag, 32..41 coeff_abs_level_minus1) while coded_block_flag is decoded and
-// scattered back to their LDS home afterwards.
+// scattered back to their LDS home afterwards.  Levels are collected in a VGPR (lane = scan index)
+// and stored with one predicated LDS write per block.
 FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
     const int cat = RFL(cat_);
     const uint32_t c0 = RDL(e.v_cat0, cat), c1 = RDL(e.v_cat1, cat);
-    const int maxnum = c0 & 255, lim = (c0 >> 16) & 15, pmode = (c0 >> 20) & 15, nlast = (c0 >> 24) & 15;
     const int l = LANE, grp = l >> 4, li = l & 15;
     const int home = static_cast<int>((c1 >> (10 * (grp > 2 ? 2 : grp))) & 1023) + (l < 32 ? li : l - 32);
     const uint32_t pending = e.s->ctx[home < 464 ? home : 463]; // the load overlaps the coded_block_flag decision
     if (cat != 5 && !BIN_B(e, 64 + ((c0 >> 8) & 255) + cbf_inc)) return 0;
     e.wk = pending;
+    const int last = static_cast<int>(c0 & 255) - 1; // maxNumCoeff - 1
     const bool is8 = cat == 5;
-    const int cap = cat == 3 ? 2 : 15;
-    uint64_t sigmask = 0;
-    int n = 0, i = 0;
-    for (; i < maxnum - 1; i++) {
-        const uint32_t m = RDL(e.v_maps, i);
-        const int inc_s = is8 ? static_cast<int>(m & 255) : (i < cap ? i : cap);
-        const int inc_l = is8 ? static_cast<int>((m >> 8) & 255) : inc_s;
-        if (BIN_W(e, inc_s)) {
-            sigmask |= 1ull << i;
-            n++;
-            if (BIN_W(e, 16 + inc_l)) break;
+    uint64_t sig = 0;
+    int i;
+    // significance map; a set last_significant_coeff_flag ends the loop through the index itself
+    if (is8) {
+        for (i = 0; i < last; i++) {
+            const uint32_t m = RDL(e.v_maps, i);
+            if (BIN_W(e, m & 255)) {
+                sig |= 1ull << i;
+                if (BIN_W(e, 16 + ((m >> 8) & 255))) i = 64;
+            }
+        }
+    } else {
+        const int cap = cat == 3 ? 2 : 15;
+        for (i = 0; i < last; i++) {
+            const int inc = i < cap ? i : cap;
+            if (BIN_W(e, inc)) {
+                sig |= 1ull << i;
+                if (BIN_W(e, 16 + inc)) i = 64;
+            }
         }
     }
-    if (i == maxnum - 1) sigmask |= 1ull << i, n++;
-    int eq1 = 0, gt1 = 0;
-    while (sigmask) {
-        const int k = 63 - __clzll(static_cast<long long>(sigmask));
-        sigmask &= ~(1ull << k);
-        const int inc0 = gt1 ? 0 : (eq1 < 3 ? 1 + eq1 : 4);
+    if (i == last) sig |= 1ull << last; // no last flag seen: the final coefficient is significant by inference
+    const int n = __builtin_popcountll(sig);
+    // levels, highest frequency first (9.3.3.1.3): inc0 / cx are the wk lanes of the two context selections
+    int inc0 = 33, cx = 37;
+    const int cxmax = 37 + static_cast<int>((c0 >> 16) & 15);
+    int lv = 0;
+    while (sig) {
+        const int k = 63 - __clzll(static_cast<long long>(sig));
+        sig &= ~(1ull << k);
         int a = 1;
-        if (BIN_W(e, 32 + inc0)) {
-            const int cx = 32 + 5 + (gt1 < lim ? gt1 : lim);
+        if (BIN_W(e, inc0)) {
             a = 2;
             while (a < 15 && BIN_W(e, cx)) a++;
             if (a >= 15) a += cabac_egk(e, 0);
-            gt1++;
-        } else
-            eq1++;
-        const int pos = pmode == 3 ? k : (pmode == 2 ? static_cast<int>((RDL(e.v_maps, k) >> 16) & 255) : static_cast<int>(RDL(e.v_maps, (k + pmode) & 15) >> 24));
-        dst[pos] = static_cast<int16_t>(cabac_bypass(e) ? -a : a);
+            inc0 = 32;
+            cx = cx < cxmax ? cx + 1 : cxmax;
+        } else if (inc0 != 32)
+            inc0 = inc0 < 36 ? inc0 + 1 : 36;
+        const int v = cabac_bypass(e) ? -a : a;
+        lv = l == k ? v : lv;
+    }
+    {
+        const int pmode = static_cast<int>((c0 >> 20) & 15);
+        const uint32_t pos = pmode == 3 ? static_cast<uint32_t>(l) : (pmode == 2 ? (e.v_maps >> 16) & 255 : (pmode == 1 ? e.v_zzac : e.v_maps >> 24));
+        if (lv != 0) dst[pos] = static_cast<int16_t>(lv);
     }
     // scatter the states back; lanes outside the block's own context ranges hold copies of other blocks'
     // states and must not be written (for 8x8 blocks ctxIdx 417 appears in both the sig and the last group)
-    const int nsig = is8 ? 15 : maxnum - 1;
+    const int nsig = is8 ? 15 : last, nlast = static_cast<int>((c0 >> 24) & 15);
     if (grp == 0 ? li < nsig : (grp == 1 ? li < nlast : l < 42)) e.s->ctx[home] = static_cast<uint8_t>(e.wk);
     return n;
 }
@@ -1076,6 +1095,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         e.v_trans = (static_cast<uint32_t>(tab->trans_lps[l]) << 1) | (l == 0 ? 1u : 0u);
     }
     e.v_maps = tab->sig8x8[l] | (tab->last8x8[l] << 8) | (tab->zigzag8[l] << 16) | (static_cast<uint32_t>(tab->zigzag4[l & 15]) << 24);
+    e.v_zzac = tab->zigzag4[(l + 1) & 15];
     e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l);
     e.v_qpc = tab->qpc[l < 52 ? l : 51];
     sh.posmap[0][l] = tab->zigzag4[l & 15];

@@ -47,15 +47,33 @@ class OracleError(RuntimeError):
     pass
 
 
-def decode(stream: bytes, crop=True, trace=False):
-    """Decode an Annex-B stream.  Returns (frames uint8[n, w*h*3/2], info[, trace int32[nmb,8]])."""
+def probe(stream: bytes) -> "StreamInfo":
+    """Frame count and picture size of a stream (a full decode without output)."""
     L = lib()
     d = L.h264o_decoder_create()
     try:
         info = StreamInfo()
-        r = L.h264o_decode_stream(d, stream, len(stream), int(crop), None, 0, ctypes.byref(info))
+        r = L.h264o_decode_stream(d, stream, len(stream), 1, None, 0, ctypes.byref(info))
         if r < 0:
             raise OracleError(L.h264o_last_error(d).decode())
+        return info
+    finally:
+        L.h264o_decoder_destroy(d)
+
+
+def decode(stream: bytes, crop=True, trace=False, info=None):
+    """Decode an Annex-B stream.  Returns (frames uint8[n, w*h*3/2], info[, trace int32[nmb,8]]).
+    With `info` (from probe()) the sizing pass is skipped: exactly one decode runs (used for timing)."""
+    L = lib()
+    d = L.h264o_decoder_create()
+    try:
+        if info is None:
+            info = StreamInfo()
+            r = L.h264o_decode_stream(d, stream, len(stream), int(crop), None, 0, ctypes.byref(info))
+            if r < 0:
+                raise OracleError(L.h264o_last_error(d).decode())
+            L.h264o_decoder_destroy(d)
+            d = L.h264o_decoder_create()
         w, h = (info.width, info.height) if crop else (info.coded_width, info.coded_height)
         out = np.zeros((info.n_frames, w * h * 3 // 2), dtype=np.uint8)
         tr = None
