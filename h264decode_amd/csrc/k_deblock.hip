@@ -6,15 +6,17 @@
 // pass is not bit-exact.  The exact dependency is MB(x,y) after MB(x-1,y) and MB(x+1,y-1): a 2-D
 // wavefront.
 //
-// Mapping.  One workgroup (MI_DEBLOCK_WAVES wavefronts) owns a picture, so no cross-CU hand-off is
-// needed.  A wavefront owns a GROUP of 4 consecutive macroblock rows and filters four macroblocks
+// Mapping.  One workgroup owns a picture, so no cross-CU hand-off is needed; the host picks the number
+// of wavefronts (blockDim.x / 64, at most MI_DEBLOCK_MAX_WAVES) so that the groups of 4 macroblock rows
+// are covered in as few rounds as possible (1080p: 17 groups -> 9 wavefronts, 2 rounds).  A wavefront owns a GROUP of 4 consecutive macroblock rows and filters four macroblocks
 // per step -- 16 lanes each -- staggered along the wavefront diagonal: at step t sub-row k works on
 // MB (t - 2k, 4g + k).  All four are independent by construction, so the 64 lanes are busy and the
 // per-step latency is shared by 4 macroblocks.
 //   * inside a group the 4 sample rows handed from sub-row k-1 to sub-row k travel through a small
 //     LDS ring (4 macroblock columns), never through HBM;
-//   * between groups (different wavefronts of the workgroup) they travel through a second LDS ring that
-//     holds a whole row of macroblock columns per in-flight group, ordered by LDS progress counters;
+//   * between groups (different wavefronts of the workgroup) they travel through a second LDS ring of
+//     MI_DEBLOCK_RING macroblock columns per in-flight group, ordered by two LDS counters per group
+//     (columns finished by its last row / columns consumed by its first row: back-pressure);
 //     no HBM access sits on the dependency path: samples are loaded once (prefetch) and stored once,
 //     fire-and-forget -- rows 13..15 of a macroblock are written by the macroblock BELOW it (which
 //     modifies them last), so no address is ever stored twice;
@@ -52,11 +54,13 @@ struct GroupSlot { // bottom rows of one macroblock column handed to the group b
     uint8_t y[4][16];   // rows 12..15
     uint8_t c[2][2][8]; // [plane][rows 6..7]
 };
-struct DbShared {
-    DbWave w[MI_DEBLOCK_WAVES];
+struct DbShared { // followed in dynamic LDS by DbWave[nwaves] and GroupSlot[nwaves][MI_DEBLOCK_RING]
     uint8_t alpha[52], beta[52], tc0[52][4];
     int prog[96]; // per group: macroblocks finished in its LAST row
+    int cons[96]; // per group: hand-off slots consumed by its FIRST row
 };
+
+static_assert(sizeof(DbShared) <= MI_DEBLOCK_HDR_BYTES && sizeof(DbWave) == MI_DEBLOCK_WAVE_BYTES && sizeof(GroupSlot) == MI_DEBLOCK_SLOT_BYTES, "LDS layout constants");
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
@@ -114,11 +118,13 @@ __device__ __forceinline__ int edge_bs(const MbRec *mp, int pb, const MbRec *mq,
     return 0;
 }
 
-extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_WAVES * 64) k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
-                                                                              const DevTables *tab, const MbRec *mbrec, int wmb_max) {
-    __shared__ DbShared sh;
-    extern __shared__ uint4 dyn_lds[]; // GroupSlot gring[MI_DEBLOCK_WAVES][wmb_max]
-    GroupSlot *gring = reinterpret_cast<GroupSlot *>(dyn_lds);
+extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
+                                                                                  const DevTables *tab, const MbRec *mbrec) {
+    extern __shared__ uint4 dyn_lds[];
+    const int nthreads = static_cast<int>(blockDim.x), nwaves = nthreads >> 6;
+    DbShared &sh = *reinterpret_cast<DbShared *>(dyn_lds);
+    DbWave *waves = reinterpret_cast<DbWave *>(reinterpret_cast<uint8_t *>(dyn_lds) + MI_DEBLOCK_HDR_BYTES);
+    GroupSlot *gring = reinterpret_cast<GroupSlot *>(waves + nwaves);
     const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6;
     const int sub = lane >> 4, li = lane & 15; // sub-row inside the group, lane inside the macroblock
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
@@ -127,17 +133,17 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_WAVES * 64) k_deblock(co
     const int W = static_cast<int>(pool->w), H = static_cast<int>(pool->h), Wc = W / 2;
     uint8_t *py = reinterpret_cast<uint8_t *>(pool->base) + static_cast<size_t>(pd->slot) * pool->slot_bytes;
     uint8_t *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
-    for (int i = tid; i < 96; i += MI_DEBLOCK_WAVES * 64) sh.prog[i] = 0;
-    for (int i = tid; i < 52; i += MI_DEBLOCK_WAVES * 64) {
+    for (int i = tid; i < 96; i += nthreads) sh.prog[i] = 0, sh.cons[i] = 0;
+    for (int i = tid; i < 52; i += nthreads) {
         sh.alpha[i] = tab->alpha[i], sh.beta[i] = tab->beta[i];
         sh.tc0[i][0] = 0, sh.tc0[i][1] = tab->tc0[i][1], sh.tc0[i][2] = tab->tc0[i][2], sh.tc0[i][3] = tab->tc0[i][3];
     }
     __syncthreads();
-    DbSub *ss = &sh.w[wave].sub[sub];
-    const DbSub *sup = sub > 0 ? &sh.w[wave].sub[sub - 1] : nullptr; // the sub-row above (same wavefront)
+    DbSub *ss = &waves[wave].sub[sub];
+    const DbSub *sup = sub > 0 ? &waves[wave].sub[sub - 1] : nullptr; // the sub-row above (same wavefront)
     const MbRec *recs = mbrec + pd->mb_base;
     const int ngroups = (hmb + 3) >> 2;
-    for (int g = wave; g < ngroups; g += MI_DEBLOCK_WAVES) {
+    for (int g = wave; g < ngroups; g += nwaves) {
         const int mby = g * 4 + sub;
         const bool row_ok = mby < hmb, has_top = mby > 0;
         const MbRec *row = recs + static_cast<size_t>(row_ok ? mby : 0) * wmb;
@@ -154,6 +160,11 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_WAVES * 64) k_deblock(co
             pre_rec = reinterpret_cast<const uint4 *>(src)[li & 7];
         };
         prefetch(-2 * sub); // step 0 (only sub-row 0 is active)
+        // this wavefront's ring row was last used by group g - nwaves: its reader (g - nwaves + 1) must be through with it
+        if (g >= nwaves && g + 1 < ngroups) {
+            while (__hip_atomic_load(&sh.cons[g - nwaves + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < wmb) __builtin_amdgcn_s_sleep(1);
+            asm volatile("" ::: "memory");
+        }
         const int nsteps = wmb + 6;
         for (int t = 0; t < nsteps; t++) {
             const int mbx = t - 2 * sub;
@@ -193,7 +204,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_WAVES * 64) k_deblock(co
                     while (__hip_atomic_load(&sh.prog[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
                     asm volatile("" ::: "memory");
                     if (sub == 0) {
-                        const GroupSlot *gs = &gring[((g - 1) % MI_DEBLOCK_WAVES) * wmb_max + x0];
+                        const GroupSlot *gs = &gring[((g - 1) % nwaves) * MI_DEBLOCK_RING + (x0 & (MI_DEBLOCK_RING - 1))];
                         if (li < 4) {
                             const uint32_t *src = reinterpret_cast<const uint32_t *>(gs->y[li]);
                             uint32_t *dst = reinterpret_cast<uint32_t *>(&tl->y[li][4]);
@@ -205,15 +216,19 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_WAVES * 64) k_deblock(co
                         }
                     }
                 }
-                // the group ring slot this step's last sub-row will overwrite must have been consumed by the
-                // group that read the previous tenant (group g - MI_DEBLOCK_WAVES + 1)
+                // back-pressure: the ring slot this step's last sub-row will overwrite held column xl - RING of this
+                // group; the group below must have consumed it
                 const int xl = t - 2 * last_sub;
-                if (g >= MI_DEBLOCK_WAVES && g + 1 < ngroups && xl >= 0 && xl < wmb) {
-                    while (__hip_atomic_load(&sh.prog[g - MI_DEBLOCK_WAVES + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < xl + 1) __builtin_amdgcn_s_sleep(1);
+                if (g + 1 < ngroups && xl >= MI_DEBLOCK_RING && xl < wmb) {
+                    while (__hip_atomic_load(&sh.cons[g + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < xl - MI_DEBLOCK_RING + 1) __builtin_amdgcn_s_sleep(1);
                     asm volatile("" ::: "memory");
                 }
             }
             WAVE_SYNC();
+            if (g > 0 && t < wmb) { // the hand-off slot of column t has been copied into the tile
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(&sh.cons[g], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             prefetch(mbx + 1);
             // ---- boundary strengths: 32 per macroblock, 2 per lane ----
             const MbRec *ml = nullptr, *mt = nullptr;
@@ -356,9 +371,10 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_WAVES * 64) k_deblock(co
                         dy = reinterpret_cast<uint32_t *>(ss->bot_y[mbx & 3][li & 3]), dc = reinterpret_cast<uint32_t *>(ss->bot_c[mbx & 3][c][r]);
                         if (has_left) dyl = reinterpret_cast<uint32_t *>(&ss->bot_y[(mbx - 1) & 3][li & 3][12]), dcl = reinterpret_cast<uint32_t *>(&ss->bot_c[(mbx - 1) & 3][c][r][4]);
                     } else {
-                        GroupSlot *gs = &gring[(g % MI_DEBLOCK_WAVES) * wmb_max + mbx];
+                        GroupSlot *row = &gring[(g % nwaves) * MI_DEBLOCK_RING];
+                        GroupSlot *gs = &row[mbx & (MI_DEBLOCK_RING - 1)], *gl = &row[(mbx - 1) & (MI_DEBLOCK_RING - 1)];
                         dy = reinterpret_cast<uint32_t *>(gs->y[li & 3]), dc = reinterpret_cast<uint32_t *>(gs->c[c][r]);
-                        if (has_left) dyl = reinterpret_cast<uint32_t *>(&gs[-1].y[li & 3][12]), dcl = reinterpret_cast<uint32_t *>(&gs[-1].c[c][r][4]);
+                        if (has_left) dyl = reinterpret_cast<uint32_t *>(&gl->y[li & 3][12]), dcl = reinterpret_cast<uint32_t *>(&gl->c[c][r][4]);
                     }
                     if (li < 4) {
                         const uint32_t *src = reinterpret_cast<const uint32_t *>(&tl->y[16 + li][0]);

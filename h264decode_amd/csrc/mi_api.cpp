@@ -158,7 +158,7 @@ struct h264mi_decoder {
     int n_scaling = 0;
     bool tables_dirty = true;
     // batch
-    int n_slices = 0, n_pics = 0, wmb_max = 0, mbs_max = 0;
+    int n_slices = 0, n_pics = 0, wmb_max = 0, hmb_max = 0, mbs_max = 0;
     std::vector<std::vector<uint32_t>> waves, waves_inter;
     std::vector<uint32_t> wave_off, wave_inter_off;
     bool prepared = false;
@@ -329,7 +329,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipMalloc(&d->d_tables, sizeof(DevTables)));
     TRY_ALLOC(hipHostMalloc(&d->h_tables, sizeof(DevTables)));
     // K5 keeps a whole macroblock row per in-flight group in dynamic LDS (up to 320 columns): opt in beyond 64 KB
-    TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+    TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(mi_deblock_lds_bytes(MI_DEBLOCK_MAX_WAVES))));
     build_tables(d->h_tables);
     d->h_pools.resize(S);
     // a deterministic background for macroblocks no slice covers
@@ -675,6 +675,7 @@ static int add_slice(h264mi_decoder *d, int si, const uint8_t *nal, size_t len, 
         pd.order = s.n_pics_in_batch++;
         s.out_slots.push_back(slot);
         d->wmb_max = std::max(d->wmb_max, wmb);
+        d->hmb_max = std::max(d->hmb_max, hmb);
         d->mbs_max = std::max(d->mbs_max, wmb * hmb);
         d->info.n_macroblocks += static_cast<int64_t>(wmb) * hmb;
         if (si == 0) d->info.width = sps.width, d->info.height = sps.height, d->info.coded_width = wmb * 16, d->info.coded_height = hmb * 16;
@@ -728,7 +729,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     HIP_TRY(hipStreamSynchronize(d->stream));
     d->prepared = false;
     d->n_slices = d->n_pics = 0;
-    d->bits_used = 0, d->mb_used = 0, d->wmb_max = 0, d->mbs_max = 0;
+    d->bits_used = 0, d->mb_used = 0, d->wmb_max = 0, d->hmb_max = 0, d->mbs_max = 0;
     memset(&d->info, 0, sizeof(d->info));
     for (auto &s : d->st) {
         for (auto &sl : s.slots) sl.held = false;
@@ -893,8 +894,8 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         }
         hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec, coef);
         mark(2);
-        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(MI_DEBLOCK_WAVES * 64), static_cast<size_t>(MI_DEBLOCK_WAVES) * d->wmb_max * MI_DEBLOCK_SLOT_BYTES, rs,
-                           d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec, d->wmb_max);
+        const int dbw = mi_deblock_waves(d->hmb_max);
+        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw), rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec);
         mark(3);
     }
     HIP_TRY(hipEventRecord(d->ev_rec[set], rs));
