@@ -109,20 +109,42 @@ struct Ent {
     uint32_t v_zzac;         // lane i: zigzag4[(i + 1) & 15] (AC blocks: scan index i is coefficient i + 1)
     uint32_t v_cat0, v_cat1; // lane ctxBlockCat: packed block-category parameters (cat_word0/1)
     uint32_t v_qpc, v_refslot; // lane i: QPc table entry / frame slot of ref_idx i
+    uint32_t v_step;         // lane = residual step: step_word()
+    uint64_t nzm, unm;       // coded / unavailable masks of the neighbourhood (parse_residual_cabac)
     int qp, prev_dqp_nz, mbx, mby, cur_type, err;
     int cabac, islice, wmb, hmb;
     int cip, t8x8_mode, cqp_off0, cqp_off1, nref;
     uint64_t mb_base;
 #if MI_ENT_STATS
     uint32_t bins;
+    uint64_t tacc[4], tmark; // diagnostics: shader clocks in [0] fill_caches [1] macroblock syntax before residual() [2] residual() [3] record write-out
 #endif
 };
 #if MI_ENT_STATS
 #define MI_BINS(e) ((e).bins)
 #define MI_COUNT_BIN(e) ((e).bins++)
+#define MI_TT0(e) ((e).tmark = __builtin_readcyclecounter())
+#define MI_TT(e, k) do { const uint64_t now_ = __builtin_readcyclecounter(); (e).tacc[k] += now_ - (e).tmark; (e).tmark = now_; } while (0)
+#if MI_ENT_STATS == 2 /* [0] significance map [1] levels [2] rest of residual_block_cabac [3] rest of residual() */
+#define MI_T0(e) ((void)0)
+#define MI_T(e, k) ((void)0)
+#define MI_R0(e) ((void)0)
+#define MI_R(e, k) ((void)0)
+#define MI_R0(e) MI_TT0(e)
+#define MI_R(e, k) MI_TT(e, k)
+#else
+#define MI_T0(e) MI_TT0(e)
+#define MI_T(e, k) MI_TT(e, k)
+#define MI_R0(e) ((void)0)
+#define MI_R(e, k) ((void)0)
+#endif
 #else
 #define MI_BINS(e) 0u
 #define MI_COUNT_BIN(e) ((void)0)
+#define MI_T0(e) ((void)0)
+#define MI_T(e, k) ((void)0)
+#define MI_R0(e) ((void)0)
+#define MI_R(e, k) ((void)0)
 #endif
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
 #define RDL(v, i) static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(i)))
@@ -244,8 +266,9 @@ FI void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
     cabac_refill(e);
 }
 // DecodeDecision (h264/cabac.go:521-540) + state transition (:544-553) + RenormD (:503-511) on the
-// context state held in lane `idx_` of `reg`
-FI bool cabac_decide(Ent &e, uint32_t &reg, int idx_) {
+// context state held in lane `idx_` of `reg`.  The bin comes back on the vector side (same value in every
+// lane): BIN_x() turns it into a branch condition (v_cmp + s_cbranch_vcc), BINI_x() into a scalar integer.
+FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     MI_COUNT_BIN(e);
     const int idx = RFL(idx_);
     const uint32_t st = RDL(reg, idx);
@@ -254,6 +277,8 @@ FI bool cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     // scalar side: the two candidate successor states (v_trans holds the LPS successor for valMPS 0; bit 0 flips with valMPS)
     const uint32_t next_lps = tr ^ mps;
     const uint32_t next_mps = min(st + 2, 124 + mps);
+    const uint32_t reg_lps = static_cast<uint32_t>(mi_writelane(static_cast<int>(next_lps), idx, static_cast<int>(reg)));
+    const uint32_t reg_mps = static_cast<uint32_t>(mi_writelane(static_cast<int>(next_mps), idx, static_cast<int>(reg)));
     // vector side
     const uint32_t rlps = __builtin_amdgcn_ubfe(rl4, (e.range >> 3) & 24, 8);
     const uint32_t rmps = e.range - rlps;
@@ -261,19 +286,21 @@ FI bool cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     const bool lps = e.value >= scaled;
     e.value = min(e.value, e.value - scaled); // value - scaled wraps when value < scaled
     e.range = lps ? rlps : rmps;
-    const uint32_t nst = lps ? next_lps : next_mps;
-    reg = LANE == idx ? nst : reg;
+    reg = lps ? reg_lps : reg_mps;
+    const uint32_t binv = (lps ? 1u : 0u) ^ mps;
     const int n = __builtin_clz(e.range) - 23;
     e.range <<= n;
     e.avail -= n;
     cabac_refill(e);
-    const uint32_t binv = lps ? mps ^ 1 : mps;
-    return UNI(binv != 0);
+    return binv;
 }
-#define BIN_A(e, ctx) cabac_decide(e, (e).ca, (ctx))          /* ctxIdx 0..63 */
-#define BIN_B(e, ctx) cabac_decide(e, (e).cb, (ctx) - 64)     /* ctxIdx 64..124 */
-#define BIN_T8(e, inc) cabac_decide(e, (e).cb, 61 + (inc))    /* ctxIdx 399..401 */
-#define BIN_W(e, lane) cabac_decide(e, (e).wk, (lane))        /* residual working set */
+#define BIN_A(e, ctx) UNI(cabac_decide(e, (e).ca, (ctx)) != 0)          /* ctxIdx 0..63 */
+#define BIN_B(e, ctx) UNI(cabac_decide(e, (e).cb, (ctx) - 64) != 0)     /* ctxIdx 64..124 */
+#define BIN_T8(e, inc) UNI(cabac_decide(e, (e).cb, 61 + (inc)) != 0)    /* ctxIdx 399..401 */
+#define BIN_W(e, lane) UNI(cabac_decide(e, (e).wk, (lane)) != 0)        /* residual working set */
+#define BINI_A(e, ctx) static_cast<int>(RFL(cabac_decide(e, (e).ca, (ctx))))
+#define BINI_B(e, ctx) static_cast<int>(RFL(cabac_decide(e, (e).cb, (ctx) - 64)))
+#define BINI_T8(e, inc) static_cast<int>(RFL(cabac_decide(e, (e).cb, 61 + (inc))))
 FI bool cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
     MI_COUNT_BIN(e);
     e.avail -= 1;
@@ -322,17 +349,22 @@ FI uint32_t top_load(const Ent &e, int col, int dw) {
 // scattered back to their LDS home afterwards.  Levels are collected in a VGPR (lane = scan index)
 // and stored with one predicated LDS write per block.
 FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
+    MI_R(e, 3);
     const int cat = RFL(cat_);
     const uint32_t c0 = RDL(e.v_cat0, cat), c1 = RDL(e.v_cat1, cat);
     const int l = LANE, grp = l >> 4, li = l & 15;
     const int home = static_cast<int>((c1 >> (10 * (grp > 2 ? 2 : grp))) & 1023) + (l < 32 ? li : l - 32);
     const uint32_t pending = e.s->ctx[home < 464 ? home : 463]; // the load overlaps the coded_block_flag decision
-    if (cat != 5 && !BIN_B(e, 64 + ((c0 >> 8) & 255) + cbf_inc)) return 0;
+    if (cat != 5 && !BIN_B(e, 64 + ((c0 >> 8) & 255) + cbf_inc)) {
+        MI_R(e, 2);
+        return 0;
+    }
     e.wk = pending;
     const int last = static_cast<int>(c0 & 255) - 1; // maxNumCoeff - 1
     const bool is8 = cat == 5;
     uint64_t sig = 0;
     int i;
+    MI_R(e, 2);
     // significance map; a set last_significant_coeff_flag ends the loop through the index itself
     if (is8) {
         for (i = 0; i < last; i++) {
@@ -352,6 +384,7 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
             }
         }
     }
+    MI_R(e, 0);
     if (i == last) sig |= 1ull << last; // no last flag seen: the final coefficient is significant by inference
     const int n = __builtin_popcountll(sig);
     // levels, highest frequency first (9.3.3.1.3): inc0 / cx are the wk lanes of the two context selections
@@ -373,6 +406,7 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
         const int v = cabac_bypass(e) ? -a : a;
         lv = l == k ? v : lv;
     }
+    MI_R(e, 1);
     {
         const int pmode = static_cast<int>((c0 >> 20) & 15);
         const uint32_t pos = pmode == 3 ? static_cast<uint32_t>(l) : (pmode == 2 ? (e.v_maps >> 16) & 255 : (pmode == 1 ? e.v_zzac : e.v_maps >> 24));
@@ -382,6 +416,7 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
     // states and must not be written (for 8x8 blocks ctxIdx 417 appears in both the sig and the last group)
     const int nsig = is8 ? 15 : last, nlast = static_cast<int>((c0 >> 24) & 15);
     if (grp == 0 ? li < nsig : (grp == 1 ? li < nlast : l < 42)) e.s->ctx[home] = static_cast<uint8_t>(e.wk);
+    MI_R(e, 2);
     return n;
 }
 
@@ -493,24 +528,81 @@ FI int cbf_inc_of(const Ent &e, uint8_t a, uint8_t b) { // 9.3.3.1.1.9
 
 // residual() 7.3.5.3 as ONE loop over a block schedule:
 //   0: Intra16x16 DC | 1..16: luma blocks (z-order) | 17,18: chroma DC | 19..26: chroma AC
-FI void parse_residual(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
+// residual() 7.3.5.3 for CABAC.  coded_block_flag contexts (9.3.3.1.1.9) need one bit per neighbouring
+// block, so the neighbourhood is a 64-bit scalar mask instead of LDS arrays:
+//   bits  0..29  luma 4x4 blocks, 6-wide grid GI(bx, by) (column 0 = left MB, row 0 = MB above)
+//   bits 32..49  chroma AC blocks, two 3x3 grids (32 + 9 * plane + 3 * (by + 1) + bx + 1)
+//   bits 50..52 / 53..55  DC flags (Intra16x16 luma, Cb, Cr) of the left / upper macroblock, 56..58 of this one
+// fill_caches() ballots "coded" (e.nzm) and "unavailable" (e.unm); unavailable counts as coded for intra
+// macroblocks.  The schedule is a bit set of steps (0 Intra16x16 DC, 1..16 luma z-order, 17/18 chroma DC,
+// 19..26 chroma AC) and a per-lane descriptor table: A bit | B bit << 6 | own bit << 12 | dst/4 << 18 | kind << 26.
+FI uint32_t step_word(int st) {
+    if (st == 0) return 50u | 53u << 6 | 56u << 12 | (MI_COEF_I16DC / 4) << 18 | 0u << 26;
+    if (st <= 16) {
+        const int idx = st - 1, bx = (idx & 1) + 2 * ((idx >> 2) & 1), by = ((idx >> 1) & 1) + 2 * (idx >> 3);
+        return static_cast<uint32_t>(GI(bx - 1, by)) | static_cast<uint32_t>(GI(bx, by - 1)) << 6 | static_cast<uint32_t>(GI(bx, by)) << 12 |
+               static_cast<uint32_t>((by * 4 + bx) * 4) << 18 | 1u << 26;
+    }
+    if (st <= 18) {
+        const uint32_t c = st - 17;
+        return (51u + c) | (54u + c) << 6 | (57u + c) << 12 | (MI_COEF_CDC / 4 + c) << 18 | 2u << 26;
+    }
+    if (st <= 26) {
+        const int j = st - 19, c = j >> 2, bx = j & 1, by = (j >> 1) & 1, g = 32 + 9 * c;
+        return static_cast<uint32_t>(g + (by + 1) * 3 + bx) | static_cast<uint32_t>(g + by * 3 + bx + 1) << 6 | static_cast<uint32_t>(g + (by + 1) * 3 + bx + 1) << 12 |
+               static_cast<uint32_t>(MI_COEF_CAC / 4 + j * 4) << 18 | 3u << 26;
+    }
+    return 0;
+}
+FI void parse_residual_cabac(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
     Shared *s = e.s;
-    const int i16 = e.cur_type == MBT_I16x16, cabac = e.cabac;
+    const int i16 = e.cur_type == MBT_I16x16;
+    uint64_t nzm = e.nzm | (MB_IS_INTRA(e.cur_type) ? e.unm : 0);
+    // luma steps of the coded 8x8 blocks: all four 4x4 blocks, or the first one standing for the 8x8 block
+    const uint32_t spread = (cbp_luma & 1) | (cbp_luma & 2) << 3 | (cbp_luma & 4) << 6 | (cbp_luma & 8) << 9;
+    uint32_t steps = static_cast<uint32_t>(i16) | (spread * (t8x8 ? 1u : 15u)) << 1;
+    if (cbp_chroma) steps |= 3u << 17;
+    if (cbp_chroma & 2) steps |= 0xFFu << 19;
+    const uint32_t cats = 0u | (t8x8 ? 5u : (i16 ? 1u : 2u)) << 4 | 3u << 8 | 4u << 12; // ctxBlockCat by step kind
+    while (steps) {
+        const int step = __builtin_ctz(steps);
+        steps &= steps - 1;
+        const uint32_t d = RDL(e.v_step, step);
+        const int cat = static_cast<int>((cats >> ((d >> 26) * 4)) & 15);
+        const int own = static_cast<int>((d >> 12) & 63);
+        const int dst = cat == 5 ? (step - 1) * 16 : static_cast<int>((d >> 18) & 255) * 4;
+        const int inc = static_cast<int>((nzm >> (d & 63)) & 1) + 2 * static_cast<int>((nzm >> ((d >> 6) & 63)) & 1);
+        if (cabac_residual(e, s->coef + dst, cat, inc)) nzm |= (cat == 5 ? 0xC3ull : 1ull) << own;
+    }
+    // results: deblocking mask (raster 4x4), DC flags and the 0/1 "coded" grids the neighbours will read
+    const uint32_t lo = static_cast<uint32_t>(nzm);
+    const uint32_t nzmask = ((lo >> GI(0, 0)) & 15) | ((lo >> GI(0, 1)) & 15) << 4 | ((lo >> GI(0, 2)) & 15) << 8 | ((lo >> GI(0, 3)) & 15) << 12;
+    s->rec.nzmask = static_cast<uint16_t>(nzmask);
+    s->cur_cbf_dc = static_cast<uint8_t>((nzm >> 56) & 7);
+    const int l = LANE;
+    const int bit = static_cast<int>((nzm >> l) & 1);
+    if (l < 30) {
+        const int gx = l % 6 - 1, gy = l / 6 - 1;
+        if (gx >= 0 && gx < 4 && gy >= 0) s->nnz_c[l] = static_cast<uint8_t>(bit);
+    } else if (l >= 32 && l < 50) {
+        const int i = l - 32, g = i % 9, gx = g % 3 - 1, gy = g / 3 - 1;
+        if (gx >= 0 && gy >= 0) s->nnzc_c[i / 9][g] = static_cast<uint8_t>(bit);
+    }
+}
+
+FI void parse_residual_cavlc(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
+    Shared *s = e.s;
+    const int i16 = e.cur_type == MBT_I16x16;
     int nzmask = 0;
-    const TopInfo *a = mbA(e), *b = mbB(e);
-    const int ci = MB_IS_INTRA(e.cur_type);
     for (int step = 0; step < 27; step++) {
-        int cat, kind, bx = 0, by = 0;
+        int kind, bx = 0, by = 0;
         uint8_t na, nb;
         int16_t *dst;
         if (step == 0) {
             if (!i16) continue;
-            cat = 0, kind = 0;
+            kind = 0;
             dst = s->coef + MI_COEF_I16DC;
-            if (cabac) { // neighbours' Intra16x16 DC coded_block_flag
-                na = a ? (a->cbf_dc & 1) : 0x80, nb = b ? (b->cbf_dc & 1) : 0x80;
-            } else
-                na = s->nnz_c[GI(-1, 0)], nb = s->nnz_c[GI(0, -1)];
+            na = s->nnz_c[GI(-1, 0)], nb = s->nnz_c[GI(0, -1)];
         } else if (step <= 16) {
             const int idx = step - 1, b8 = idx >> 2;
             if (!((cbp_luma >> b8) & 1)) {
@@ -519,47 +611,35 @@ FI void parse_residual(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
             }
             bx = (idx & 1) + 2 * ((idx >> 2) & 1), by = ((idx >> 1) & 1) + 2 * (idx >> 3);
             na = s->nnz_c[GI(bx - 1, by)], nb = s->nnz_c[GI(bx, by - 1)];
-            if (t8x8 && cabac) {
-                cat = 5, kind = 0;
-                dst = s->coef + b8 * 64;
-            } else if (t8x8) {
-                cat = 2, kind = 3;
+            if (t8x8) {
+                kind = 3;
                 dst = s->tmp16;
                 for (int i = 0; i < 16; i++) s->tmp16[i] = 0;
             } else {
-                cat = i16 ? 1 : 2, kind = i16 ? 1 : 0;
+                kind = i16 ? 1 : 0;
                 dst = s->coef + (by * 4 + bx) * 16;
             }
         } else if (step <= 18) {
             if (!cbp_chroma) break;
             const int c = step - 17;
-            cat = 3, kind = 2;
+            kind = 2;
             dst = s->coef + MI_COEF_CDC + 4 * c;
-            na = a ? ((a->cbf_dc >> (1 + c)) & 1) : 0x80, nb = b ? ((b->cbf_dc >> (1 + c)) & 1) : 0x80;
+            na = nb = 0;
         } else {
             if (!(cbp_chroma & 2)) break;
             const int j = step - 19, c = j >> 2, b4 = j & 3;
             bx = b4 & 1, by = b4 >> 1;
-            cat = 4, kind = 1;
+            kind = 1;
             dst = s->coef + MI_COEF_CAC + j * 16;
             na = s->nnzc_c[c][(by + 1) * 3 + bx], nb = s->nnzc_c[c][by * 3 + bx + 1];
         }
-        int n;
-        if (cabac) {
-            const int ca = (na & 0x80) ? ci : (na != 0), cb = (nb & 0x80) ? ci : (nb != 0);
-            n = cabac_residual(e, dst, cat, ca + 2 * cb);
-        } else
-            n = cavlc_residual(e, dst, kind, kind == 2 ? -1 : nc_of(na, nb));
+        const int n = cavlc_residual(e, dst, kind, kind == 2 ? -1 : nc_of(na, nb));
         // ---- bookkeeping per block kind ----
         if (step == 0) {
             if (n) s->cur_cbf_dc |= 1;
         } else if (step <= 16) {
             const int idx = step - 1, b8 = idx >> 2, r = by * 4 + bx;
-            if (cat == 5) {
-                s->nnz_c[GI(bx, by)] = s->nnz_c[GI(bx + 1, by)] = s->nnz_c[GI(bx, by + 1)] = s->nnz_c[GI(bx + 1, by + 1)] = static_cast<uint8_t>(n);
-                if (n) nzmask |= 0x33 << r;
-                step += 3;
-            } else {
+            {
                 if (kind == 3) // CAVLC + 8x8 transform: 4x4 "block" b4 carries coefficients 4*i + b4 of the 8x8 scan (7.3.5.3.2)
                     for (int i = 0; i < 16; i++) {
                         int16_t v = s->tmp16[i];
@@ -635,6 +715,7 @@ FI void fill_caches(Ent &e) {
     const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
     const int cip = e.cip;
     const int l = LANE;
+    int coded = 0; // this lane's bit of the CABAC neighbourhood masks: 1 coded, 2 unavailable (see parse_residual_cabac)
     if (l < 30) {
         int gx = l % 6 - 1, gy = l / 6 - 1; // block coordinates relative to the MB
         int8_t ipm = -2, ref = -2;
@@ -666,6 +747,7 @@ FI void fill_caches(Ent &e) {
             nnz = 0;
             ipm = -1;
         }
+        coded = (nnz & 0x80) ? 2 : (nnz != 0);
         s->ipm_c[l] = ipm;
         s->nnz_c[l] = nnz;
         s->ref_c[l] = ref;
@@ -681,12 +763,18 @@ FI void fill_caches(Ent &e) {
             if (a) v = a->nnz[4 + cpl * 2 + gy];
         } else if (gx >= 0 && gy >= 0)
             v = 0;
+        coded = (v & 0x80) ? 2 : (v != 0);
         s->nnzc_c[cpl][g] = v;
-    } else if (l >= 50 && l < 54) {
-        s->refs8[l - 50] = -1;
-        s->sub_type[l - 50] = 0;
-    } else if (l == 54)
+    } else if (l >= 50 && l < 56) { // DC coded_block_flags of the left (50..52) / upper (53..55) macroblock: Intra16x16 luma, Cb, Cr
+        const TopInfo *n = l < 53 ? a : b;
+        coded = n ? (n->cbf_dc >> ((l - 50) % 3)) & 1 : 2;
+    } else if (l >= 56 && l < 60) {
+        s->refs8[l - 56] = -1;
+        s->sub_type[l - 56] = 0;
+    } else if (l == 60)
         s->cur_cbf_dc = 0;
+    e.nzm = __builtin_amdgcn_ballot_w64(coded == 1);
+    e.unm = __builtin_amdgcn_ballot_w64(coded == 2);
     { // zero the coefficient staging block: 416 int16 = 208 dwords
         uint32_t *cz = reinterpret_cast<uint32_t *>(s->coef);
         for (int i = l; i < MI_COEF_PER_MB / 2; i += 64) cz[i] = 0;
@@ -719,26 +807,26 @@ FI void decode_mb(Ent &e, int skipped) {
         int intra_prefix = 1; // in P slices: bin 0 of mb_type says "intra"
         if (cabac) {
             if (!islice) {
-                intra_prefix = BIN_A(e, 14);
-                if (!intra_prefix) raw = BIN_A(e, 15) ? 2 - BIN_A(e, 17) : 3 * BIN_A(e, 16);
+                intra_prefix = BINI_A(e, 14);
+                if (!intra_prefix) raw = BIN_A(e, 15) ? 2 - BINI_A(e, 17) : 3 * BINI_A(e, 16);
             }
             if (intra_prefix) {
                 // I-slice bin string; `base` 3 with neighbour-dependent first bin, or the suffix at 17
                 int base = islice ? 3 : 17, it = 0, first;
                 if (islice) {
                     int inc = (a && a->type != MBT_I4x4 && a->type != MBT_I8x8) + (b && b->type != MBT_I4x4 && b->type != MBT_I8x8);
-                    first = BIN_A(e, base + inc);
+                    first = BINI_A(e, base + inc);
                     base += 2;
                 } else
-                    first = BIN_A(e, base);
+                    first = BINI_A(e, base);
                 if (first) {
                     if (cabac_terminate(e))
                         it = 25;
                     else {
-                        it = 1 + 12 * BIN_A(e, base + 1);
-                        if (BIN_A(e, base + 2)) it += 4 + 4 * BIN_A(e, base + 2 + islice);
-                        it += 2 * BIN_A(e, base + 3 + islice);
-                        it += BIN_A(e, base + 3 + 2 * islice);
+                        it = 1 + 12 * BINI_A(e, base + 1);
+                        if (BIN_A(e, base + 2)) it += 4 + 4 * BINI_A(e, base + 2 + islice);
+                        it += 2 * BINI_A(e, base + 3 + islice);
+                        it += BINI_A(e, base + 3 + 2 * islice);
                     }
                 }
                 raw = islice ? it : it + 5;
@@ -874,7 +962,7 @@ FI void decode_mb(Ent &e, int skipped) {
             } else {
                 // ---- intra: transform_size_8x8_flag, prediction modes, intra_chroma_pred_mode ----
                 if (type == MBT_I4x4 && e.t8x8_mode) {
-                    t8x8 = cabac ? BIN_T8(e, (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
+                    t8x8 = cabac ? BINI_T8(e, (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
                     if (t8x8) type = MBT_I8x8, e.cur_type = type;
                 }
                 if (type == MBT_I4x4 || type == MBT_I8x8) {
@@ -891,7 +979,7 @@ FI void decode_mb(Ent &e, int skipped) {
                         if (cabac) {
                             if (!BIN_B(e, 68)) {
                                 int rem = 0;
-                                for (int k = 0; k < 3; k++) rem |= BIN_B(e, 69) << k;
+                                for (int k = 0; k < 3; k++) rem |= BINI_B(e, 69) << k;
                                 mode = rem < pred ? rem : rem + 1;
                             }
                         } else if (!get_bit(e)) {
@@ -926,13 +1014,13 @@ FI void decode_mb(Ent &e, int skipped) {
                     for (int b8 = 0; b8 < 4; b8++) {
                         int ca = (b8 & 1) ? (cbp >> (b8 - 1)) & 1 : (cbp_a >> (b8 + 1)) & 1;
                         int cb = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cbp_b >> (b8 + 2)) & 1;
-                        cbp |= BIN_B(e, 73 + (!ca) + 2 * (!cb)) << b8;
+                        cbp |= BINI_B(e, 73 + (!ca) + 2 * (!cb)) << b8;
                     }
                     int ca = a && (a->type == MBT_IPCM || (a->cbp >> 4) != 0), cb = b && (b->type == MBT_IPCM || (b->cbp >> 4) != 0);
                     if (BIN_B(e, 77 + ca + 2 * cb)) {
                         ca = a && (a->type == MBT_IPCM || (a->cbp >> 4) == 2);
                         cb = b && (b->type == MBT_IPCM || (b->cbp >> 4) == 2);
-                        cbp |= (1 + BIN_B(e, 77 + 4 + ca + 2 * cb)) << 4;
+                        cbp |= (1 + BINI_B(e, 77 + 4 + ca + 2 * cb)) << 4;
                     }
                 } else {
                     uint32_t k = get_ue(e);
@@ -944,7 +1032,7 @@ FI void decode_mb(Ent &e, int skipped) {
                     int all8 = 1;
                     if (type == MBT_P8x8)
                         for (int i = 0; i < 4; i++) all8 &= s->sub_type[i] == 0;
-                    if (all8) t8x8 = cabac ? BIN_T8(e, (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
+                    if (all8) t8x8 = cabac ? BINI_T8(e, (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
                 }
             }
             // ---- mb_qp_delta + residual ----
@@ -965,12 +1053,20 @@ FI void decode_mb(Ent &e, int skipped) {
                 if (dqp < -26 || dqp > 25) e.err = 24, dqp = 0;
                 e.prev_dqp_nz = dqp != 0;
                 e.qp = (e.qp + dqp + 52) % 52;
-                parse_residual(e, cbp_luma, cbp_chroma, t8x8);
+                MI_T(e, 1);
+                MI_R0(e);
+                if (cabac)
+                    parse_residual_cabac(e, cbp_luma, cbp_chroma, t8x8);
+                else
+                    parse_residual_cavlc(e, cbp_luma, cbp_chroma, t8x8);
+                MI_R(e, 3);
+                MI_T(e, 2);
                 has_coef = 1;
             } else
                 e.prev_dqp_nz = 0;
         }
     }
+    MI_T(e, 1);
     // ---- scalar fields of the record ----
     const int qp_store = type == MBT_IPCM ? 0 : e.qp;
     r.type = static_cast<uint8_t>(type);
@@ -1063,6 +1159,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     e.s = &sh;
 #if MI_ENT_STATS
     e.bins = 0;
+    for (int k = 0; k < 4; k++) e.tacc[k] = 0;
 #endif
     e.top = reinterpret_cast<TopInfo *>(toprows + static_cast<size_t>(blockIdx.x) * wmb_max * 12);
     e.pre_top = 0;
@@ -1098,6 +1195,8 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     e.v_zzac = tab->zigzag4[(l + 1) & 15];
     e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l);
     e.v_qpc = tab->qpc[l < 52 ? l : 51];
+    e.v_step = step_word(l);
+    e.nzm = e.unm = 0;
     sh.posmap[0][l] = tab->zigzag4[l & 15];
     sh.posmap[1][l] = tab->zigzag4[(l + 1) & 15];
     sh.posmap[2][l] = tab->zigzag8[l];
@@ -1149,12 +1248,14 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
             LDS_SYNC();
         }
         slide_window(e);
+        MI_T0(e);
         fill_caches(e);
+        MI_T(e, 0);
         int skipped = 0;
         if (!e.islice) {
             if (e.cabac) {
                 const TopInfo *a = mbA(e), *b = mbB(e);
-                skipped = BIN_A(e, 11 + (a && a->type != MBT_PSKIP) + (b && b->type != MBT_PSKIP));
+                skipped = BINI_A(e, 11 + (a && a->type != MBT_PSKIP) + (b && b->type != MBT_PSKIP));
             } else {
                 if (skip_state == 0) {
                     pending = static_cast<int>(get_ue(e));
@@ -1168,6 +1269,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
             }
         }
         decode_mb(e, skipped);
+        MI_T(e, 3);
         n_mbs++;
         if (e.cabac)
             more = !cabac_terminate(e);
@@ -1184,9 +1286,12 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         if (++e.mbx == e.wmb) e.mbx = 0, e.mby++;
     }
     if (l == 0) {
-        status[4 * blockIdx.x] = static_cast<uint32_t>(e.err);
-        status[4 * blockIdx.x + 1] = static_cast<uint32_t>(n_mbs);
-        status[4 * blockIdx.x + 2] = static_cast<uint32_t>(wall_clock64() - t_begin);
-        status[4 * blockIdx.x + 3] = MI_BINS(e);
+        status[8 * blockIdx.x] = static_cast<uint32_t>(e.err);
+        status[8 * blockIdx.x + 1] = static_cast<uint32_t>(n_mbs);
+        status[8 * blockIdx.x + 2] = static_cast<uint32_t>(wall_clock64() - t_begin);
+        status[8 * blockIdx.x + 3] = MI_BINS(e);
+#if MI_ENT_STATS
+        for (int k = 0; k < 4; k++) status[8 * blockIdx.x + 4 + k] = static_cast<uint32_t>(e.tacc[k] >> 4); // shader clocks / 16
+#endif
     }
 }

@@ -159,6 +159,7 @@ struct h264mi_decoder {
     bool tables_dirty = true;
     // batch
     int n_slices = 0, n_pics = 0, wmb_max = 0, hmb_max = 0, mbs_max = 0;
+    size_t ent_lds_pad = 0; // dynamic LDS requested (and not used) by k_entropy: caps its wavefronts per CU, see h264mi_decoder_create
     std::vector<std::vector<uint32_t>> waves, waves_inter;
     std::vector<uint32_t> wave_off, wave_inter_off;
     bool prepared = false;
@@ -281,8 +282,8 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipHostMalloc(&d->h_slices, sizeof(SliceDesc) * d->slices_cap));
     TRY_ALLOC(hipMalloc(&d->d_pics, sizeof(PicDesc) * d->pics_cap));
     TRY_ALLOC(hipHostMalloc(&d->h_pics, sizeof(PicDesc) * d->pics_cap));
-    TRY_ALLOC(hipMalloc(&d->d_status, sizeof(uint32_t) * 4 * d->slices_cap));
-    TRY_ALLOC(hipHostMalloc(&d->h_status, sizeof(uint32_t) * 4 * d->slices_cap));
+    TRY_ALLOC(hipMalloc(&d->d_status, sizeof(uint32_t) * 8 * d->slices_cap));
+    TRY_ALLOC(hipHostMalloc(&d->h_status, sizeof(uint32_t) * 8 * d->slices_cap));
     TRY_ALLOC(hipMalloc(&d->d_lists, sizeof(uint32_t) * 2 * d->pics_cap));
     TRY_ALLOC(hipHostMalloc(&d->h_lists, sizeof(uint32_t) * 2 * d->pics_cap));
     {
@@ -293,6 +294,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
         TRY_ALLOC(hipGetDeviceProperties(&prop, cfg->device));
         const int ncu = prop.multiProcessorCount;
         int ent_cus = 0;
+        if (const char *e = getenv("H264MI_ENT_LDS_PAD")) d->ent_lds_pad = static_cast<size_t>(atoi(e));
         if (const char *e = getenv("H264MI_ENT_CUS")) ent_cus = atoi(e);
         const int words = (ncu + 31) / 32;
         std::vector<uint32_t> me(words, 0), mr(words, 0);
@@ -878,7 +880,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     } else {
         HIP_TRY(hipStreamWaitEvent(es, d->ev_upload, 0));
         if (d->pass >= MI_SETS) HIP_TRY(hipStreamWaitEvent(es, d->ev_rec[set], 0)); // pass n-MI_SETS finished reading this set
-        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), 0, es, d->d_slices, d->d_pics, d->d_bits, d->d_tables, mbrec, coef, d->d_status,
+        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), d->ent_lds_pad, es, d->d_slices, d->d_pics, d->d_bits, d->d_tables, mbrec, coef, d->d_status,
                            d->d_toprows[set], d->wmb_max);
         HIP_TRY(hipEventRecord(d->ev_ent[set], es));
         HIP_TRY(hipStreamWaitEvent(d->rec_stream, d->ev_ent[set], 0));
@@ -902,7 +904,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     if (!prof) HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_rec[set], 0)); // the caller's stream sees the finished pass
     d->pass++;
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(d->h_status, d->d_status, sizeof(uint32_t) * 4 * d->n_slices, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(d->h_status, d->d_status, sizeof(uint32_t) * 8 * d->n_slices, hipMemcpyDeviceToHost, d->stream));
     d->ev_used = prof ? ei : 0;
     return H264MI_OK;
 }
@@ -928,16 +930,17 @@ extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
     }
     if (getenv("H264MI_SLICE_STATS")) { // diagnostics: per-slice entropy time (100 MHz ticks) and bin count (MI_ENT_STATS builds)
         for (int i = 0; i < d->n_slices && i < 64; i++)
-            fprintf(stderr, "slice %d type %d bytes %u mbs %u us %.1f bins %u\n", i, d->h_slices[i].slice_type, d->h_slices[i].rbsp_size, d->h_status[4 * i + 1],
-                    d->h_status[4 * i + 2] * 0.01, d->h_status[4 * i + 3]);
+            fprintf(stderr, "slice %d type %d bytes %u mbs %u us %.1f bins %u | Mclk fill %.1f syntax %.1f residual %.1f writeout %.1f\n", i, d->h_slices[i].slice_type,
+                    d->h_slices[i].rbsp_size, d->h_status[8 * i + 1], d->h_status[8 * i + 2] * 0.01, d->h_status[8 * i + 3], d->h_status[8 * i + 4] * 16e-6,
+                    d->h_status[8 * i + 5] * 16e-6, d->h_status[8 * i + 6] * 16e-6, d->h_status[8 * i + 7] * 16e-6);
         fprintf(stderr, "last slice type %d bytes %u mbs %u us %.1f bins %u\n", d->h_slices[d->n_slices - 1].slice_type, d->h_slices[d->n_slices - 1].rbsp_size,
-                d->h_status[4 * (d->n_slices - 1) + 1], d->h_status[4 * (d->n_slices - 1) + 2] * 0.01, d->h_status[4 * (d->n_slices - 1) + 3]);
+                d->h_status[8 * (d->n_slices - 1) + 1], d->h_status[8 * (d->n_slices - 1) + 2] * 0.01, d->h_status[8 * (d->n_slices - 1) + 3]);
     }
     for (int i = 0; i < d->n_slices; i++)
-        if (d->h_status[4 * i]) {
+        if (d->h_status[8 * i]) {
             const SliceDesc &sd = d->h_slices[i];
             set_error("entropy kernel: slice %d (picture %u, stream %u) failed with code %u after %u macroblocks", i, sd.pic_idx, d->h_pics[sd.pic_idx].stream,
-                      d->h_status[4 * i], d->h_status[4 * i + 1]);
+                      d->h_status[8 * i], d->h_status[8 * i + 1]);
             return H264MI_EDECODE;
         }
     return H264MI_OK;
