@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=128, help="independent streams per GPU")
+    ap.add_argument("--streams", type=int, default=256, help="independent streams per GPU")
     ap.add_argument("--frames", type=int, default=30, help="frames per stream per step (one GOP)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)

@@ -111,6 +111,8 @@ struct Ent {
     uint32_t v_qpc, v_refslot; // lane i: QPc table entry / frame slot of ref_idx i
     uint32_t v_step;         // lane = residual step: step_word()
     uint64_t nzm, unm;       // coded / unavailable masks of the neighbourhood (parse_residual_cabac)
+    uint32_t aw, bw;         // first dword of the left / upper TopInfo (Nb)
+    int v_ipm;               // lanes 0..29: Intra4x4/8x8PredMode grid (same layout and codes as Shared::ipm_c)
     int qp, prev_dqp_nz, mbx, mby, cur_type, err;
     int cabac, islice, wmb, hmb;
     int cip, t8x8_mode, cqp_off0, cqp_off1, nref;
@@ -284,10 +286,11 @@ FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     const uint32_t rmps = e.range - rlps;
     const uint32_t scaled = rmps << e.avail;
     const bool lps = e.value >= scaled;
-    e.value = min(e.value, e.value - scaled); // value - scaled wraps when value < scaled
+    const uint32_t diff = e.value - scaled; // wraps when value < scaled; both are below 2^31
+    e.value = min(e.value, diff);
     e.range = lps ? rlps : rmps;
     reg = lps ? reg_lps : reg_mps;
-    const uint32_t binv = (lps ? 1u : 0u) ^ mps;
+    const uint32_t binv = (diff >> 31) ^ (mps ^ 1); // valMPS on the MPS path (sign bit set), !valMPS otherwise
     const int n = __builtin_clz(e.range) - 23;
     e.range <<= n;
     e.avail -= n;
@@ -337,6 +340,15 @@ FI int cabac_egk(Ent &e, int k) {
 FI const TopInfo *mbA(const Ent &e) { return e.s->left.type != MBT_NONE ? &e.s->left : nullptr; }
 FI const TopInfo *mbB(const Ent &e) { return e.s->topw[0].type != MBT_NONE ? &e.s->topw[0] : nullptr; }
 FI const TopInfo *mbC(const Ent &e) { return (e.mbx + 1 < e.wmb && e.s->topw[1].type != MBT_NONE) ? &e.s->topw[1] : nullptr; }
+// the left / upper macroblock's type, transform flag, cbp and chroma mode as one scalar word (first dword of TopInfo)
+struct Nb {
+    uint32_t w;
+    FI bool ok() const { return (w & 255) != 0; }
+    FI int type() const { return static_cast<int>(w & 255); }
+    FI int t8x8() const { return static_cast<int>((w >> 8) & 255); }
+    FI int cbp() const { return static_cast<int>((w >> 16) & 255); }
+    FI int chroma_mode() const { return static_cast<int>(w >> 24); }
+};
 // L1-bypassing dword load of the row-above array (it is rewritten by this wave one row later)
 FI uint32_t top_load(const Ent &e, int col, int dw) {
     return col < e.wmb ? __hip_atomic_load(reinterpret_cast<const uint32_t *>(e.top + col) + dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
@@ -749,6 +761,7 @@ FI void fill_caches(Ent &e) {
         }
         coded = (nnz & 0x80) ? 2 : (nnz != 0);
         s->ipm_c[l] = ipm;
+        e.v_ipm = ipm;
         s->nnz_c[l] = nnz;
         s->ref_c[l] = ref;
         s->refi_c[l] = ref;
@@ -775,6 +788,7 @@ FI void fill_caches(Ent &e) {
         s->cur_cbf_dc = 0;
     e.nzm = __builtin_amdgcn_ballot_w64(coded == 1);
     e.unm = __builtin_amdgcn_ballot_w64(coded == 2);
+    e.aw = RFL(*reinterpret_cast<const uint32_t *>(&s->left)), e.bw = RFL(*reinterpret_cast<const uint32_t *>(&s->topw[0]));
     { // zero the coefficient staging block: 416 int16 = 208 dwords
         uint32_t *cz = reinterpret_cast<uint32_t *>(s->coef);
         for (int i = l; i < MI_COEF_PER_MB / 2; i += 64) cz[i] = 0;
@@ -789,7 +803,7 @@ FI void decode_mb(Ent &e, int skipped) {
     const int cabac = e.cabac, islice = e.islice;
     int cbp_luma = 0, cbp_chroma = 0, t8x8 = 0, i16mode = 0, chroma_mode = 0, has_coef = 0;
     int type, raw = 0, nparts = 0;
-    const TopInfo *a = mbA(e), *b = mbB(e);
+    const Nb a{e.aw}, b{e.bw};
     r.nzmask = 0;
     if (skipped) {
         type = MBT_PSKIP;
@@ -814,7 +828,7 @@ FI void decode_mb(Ent &e, int skipped) {
                 // I-slice bin string; `base` 3 with neighbour-dependent first bin, or the suffix at 17
                 int base = islice ? 3 : 17, it = 0, first;
                 if (islice) {
-                    int inc = (a && a->type != MBT_I4x4 && a->type != MBT_I8x8) + (b && b->type != MBT_I4x4 && b->type != MBT_I8x8);
+                    int inc = (a.ok() && a.type() != MBT_I4x4 && a.type() != MBT_I8x8) + (b.ok() && b.type() != MBT_I4x4 && b.type() != MBT_I8x8);
                     first = BINI_A(e, base + inc);
                     base += 2;
                 } else
@@ -962,7 +976,7 @@ FI void decode_mb(Ent &e, int skipped) {
             } else {
                 // ---- intra: transform_size_8x8_flag, prediction modes, intra_chroma_pred_mode ----
                 if (type == MBT_I4x4 && e.t8x8_mode) {
-                    t8x8 = cabac ? BINI_T8(e, (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
+                    t8x8 = cabac ? BINI_T8(e, (a.ok() && a.t8x8()) + (b.ok() && b.t8x8())) : static_cast<int>(get_bit(e));
                     if (t8x8) type = MBT_I8x8, e.cur_type = type;
                 }
                 if (type == MBT_I4x4 || type == MBT_I8x8) {
@@ -973,7 +987,7 @@ FI void decode_mb(Ent &e, int skipped) {
                             bx = (i & 1) * 2, by = (i >> 1) * 2;
                         else
                             bx = (i & 1) + 2 * ((i >> 2) & 1), by = ((i >> 1) & 1) + 2 * (i >> 3);
-                        const int pa = s->ipm_c[GI(bx - 1, by)], pb = s->ipm_c[GI(bx, by - 1)];
+                        const int pa = static_cast<int>(RDL(e.v_ipm, GI(bx - 1, by))), pb = static_cast<int>(RDL(e.v_ipm, GI(bx, by - 1)));
                         const int pred = (pa < -1 || pb < -1) ? 2 : (pa < pb ? pa : pb); // 8.3.1.1: dcPredModePredictedFlag
                         int mode = pred;
                         if (cabac) {
@@ -986,13 +1000,14 @@ FI void decode_mb(Ent &e, int skipped) {
                             int rem = static_cast<int>(get_bits(e, 3));
                             mode = rem < pred ? rem : rem + 1;
                         }
-                        s->ipm_c[GI(bx, by)] = static_cast<int8_t>(mode);
-                        if (n == 4) s->ipm_c[GI(bx + 1, by)] = s->ipm_c[GI(bx, by + 1)] = s->ipm_c[GI(bx + 1, by + 1)] = static_cast<int8_t>(mode);
+                        const int g = GI(bx, by), d = LANE - g;
+                        e.v_ipm = (d == 0 || (n == 4 && (d == 1 || d == 6 || d == 7))) ? mode : e.v_ipm;
                     }
+                    if (LANE < 30) s->ipm_c[LANE] = static_cast<int8_t>(e.v_ipm); // for the record / neighbour write-out
                 }
                 if (cabac) {
-                    int inc = (a && MB_IS_INTRA(a->type) && a->type != MBT_IPCM && a->chroma_mode != 0) +
-                              (b && MB_IS_INTRA(b->type) && b->type != MBT_IPCM && b->chroma_mode != 0);
+                    int inc = (a.ok() && MB_IS_INTRA(a.type()) && a.type() != MBT_IPCM && a.chroma_mode() != 0) +
+                              (b.ok() && MB_IS_INTRA(b.type()) && b.type() != MBT_IPCM && b.chroma_mode() != 0);
                     chroma_mode = 0;
                     if (BIN_B(e, 64 + inc)) {
                         chroma_mode = 1;
@@ -1008,18 +1023,18 @@ FI void decode_mb(Ent &e, int skipped) {
             if (type != MBT_I16x16) {
                 int cbp;
                 if (cabac) { // 9.3.3.1.1.4
-                    const int cbp_a = a ? (a->type == MBT_IPCM ? 0x2F : a->cbp) : 0x0F;
-                    const int cbp_b = b ? (b->type == MBT_IPCM ? 0x2F : b->cbp) : 0x0F;
+                    const int cbp_a = a.ok() ? (a.type() == MBT_IPCM ? 0x2F : a.cbp()) : 0x0F;
+                    const int cbp_b = b.ok() ? (b.type() == MBT_IPCM ? 0x2F : b.cbp()) : 0x0F;
                     cbp = 0;
                     for (int b8 = 0; b8 < 4; b8++) {
                         int ca = (b8 & 1) ? (cbp >> (b8 - 1)) & 1 : (cbp_a >> (b8 + 1)) & 1;
                         int cb = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cbp_b >> (b8 + 2)) & 1;
                         cbp |= BINI_B(e, 73 + (!ca) + 2 * (!cb)) << b8;
                     }
-                    int ca = a && (a->type == MBT_IPCM || (a->cbp >> 4) != 0), cb = b && (b->type == MBT_IPCM || (b->cbp >> 4) != 0);
+                    int ca = a.ok() && (a.type() == MBT_IPCM || (a.cbp() >> 4) != 0), cb = b.ok() && (b.type() == MBT_IPCM || (b.cbp() >> 4) != 0);
                     if (BIN_B(e, 77 + ca + 2 * cb)) {
-                        ca = a && (a->type == MBT_IPCM || (a->cbp >> 4) == 2);
-                        cb = b && (b->type == MBT_IPCM || (b->cbp >> 4) == 2);
+                        ca = a.ok() && (a.type() == MBT_IPCM || (a.cbp() >> 4) == 2);
+                        cb = b.ok() && (b.type() == MBT_IPCM || (b.cbp() >> 4) == 2);
                         cbp |= (1 + BINI_B(e, 77 + 4 + ca + 2 * cb)) << 4;
                     }
                 } else {
@@ -1032,7 +1047,7 @@ FI void decode_mb(Ent &e, int skipped) {
                     int all8 = 1;
                     if (type == MBT_P8x8)
                         for (int i = 0; i < 4; i++) all8 &= s->sub_type[i] == 0;
-                    if (all8) t8x8 = cabac ? BINI_T8(e, (a && a->t8x8) + (b && b->t8x8)) : static_cast<int>(get_bit(e));
+                    if (all8) t8x8 = cabac ? BINI_T8(e, (a.ok() && a.t8x8()) + (b.ok() && b.t8x8())) : static_cast<int>(get_bit(e));
                 }
             }
             // ---- mb_qp_delta + residual ----
@@ -1083,8 +1098,8 @@ FI void decode_mb(Ent &e, int skipped) {
         int av = 0;
         const TopInfo *c = mbC(e);
         const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
-        if (a && !(cip && MB_IS_INTER(a->type))) av |= MI_AV_LEFT;
-        if (b && !(cip && MB_IS_INTER(b->type))) av |= MI_AV_TOP;
+        if (a.ok() && !(cip && MB_IS_INTER(a.type()))) av |= MI_AV_LEFT;
+        if (b.ok() && !(cip && MB_IS_INTER(b.type()))) av |= MI_AV_TOP;
         if (d && !(cip && MB_IS_INTER(d->type))) av |= MI_AV_TOPLEFT;
         if (c && !(cip && MB_IS_INTER(c->type))) av |= MI_AV_TOPRIGHT;
         r.avail = static_cast<uint8_t>(av);
@@ -1197,6 +1212,8 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     e.v_qpc = tab->qpc[l < 52 ? l : 51];
     e.v_step = step_word(l);
     e.nzm = e.unm = 0;
+    e.aw = e.bw = 0;
+    e.v_ipm = 0;
     sh.posmap[0][l] = tab->zigzag4[l & 15];
     sh.posmap[1][l] = tab->zigzag4[(l + 1) & 15];
     sh.posmap[2][l] = tab->zigzag8[l];
@@ -1254,8 +1271,8 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         int skipped = 0;
         if (!e.islice) {
             if (e.cabac) {
-                const TopInfo *a = mbA(e), *b = mbB(e);
-                skipped = BINI_A(e, 11 + (a && a->type != MBT_PSKIP) + (b && b->type != MBT_PSKIP));
+                const Nb a{e.aw}, b{e.bw};
+                skipped = BINI_A(e, 11 + (a.ok() && a.type() != MBT_PSKIP) + (b.ok() && b.type() != MBT_PSKIP));
             } else {
                 if (skip_state == 0) {
                     pending = static_cast<int>(get_ue(e));

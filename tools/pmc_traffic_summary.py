@@ -3,7 +3,7 @@
 import argparse, collections, csv, glob, json, os, sys
 out = sys.argv[1]
 ap = argparse.ArgumentParser()
-ap.add_argument("--streams", type=int, default=128)
+ap.add_argument("--streams", type=int, default=256)
 ap.add_argument("--frames", type=int, default=30)
 ap.add_argument("--width", type=int, default=1920)
 args, _ = ap.parse_known_args(sys.argv[2:])
