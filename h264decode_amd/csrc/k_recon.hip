@@ -56,7 +56,7 @@ __device__ __forceinline__ int scale8(int c, int ls, int qp) { // 8.5.13 scaling
 }
 
 // Residual of one macroblock, computed by one wavefront (lane = 0..63).  Results in rb->luma / rb->chroma.
-__device__ void mb_residual(int lane, const MbRec *rec, const int16_t *coef, const ScalingSet *sc, ResBuf *rb) {
+__device__ __forceinline__ void mb_residual(int lane, const MbRec *rec, const int16_t *coef, const ScalingSet *sc, ResBuf *rb) {
     const int type = rec->type, t8x8 = rec->t8x8, cbp = rec->cbp, qp = rec->qp;
     const int intra = MB_IS_INTRA(type), i16 = type == MBT_I16x16;
     const int cbp_l = cbp & 15, cbp_c = cbp >> 4;
@@ -191,6 +191,7 @@ struct InterShared {
     uint8_t winc16[2][9][12];
     MbRec rec;
     int uniform;
+    alignas(16) int16_t coef[MI_COEF_PER_MB]; // coefficient block, fetched while the reference windows are in flight
 };
 
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
@@ -214,6 +215,10 @@ extern "C" __global__ void __launch_bounds__(64) k_inter(const uint32_t *pic_lis
     const int mbx = mb % wmb, mby = mb / wmb;
     const uint8_t *pool_base = reinterpret_cast<const uint8_t *>(pool->base);
     const size_t ysz = static_cast<size_t>(W) * H;
+    // coefficient block: issue the loads now, park them in LDS after the window loads have been issued
+    const int has_res = rec->cbp != 0;
+    uint4 cv = make_uint4(0, 0, 0, 0);
+    if (has_res && lane < MI_COEF_PER_MB * 2 / 16) cv = reinterpret_cast<const uint4 *>(coefs + mbi * MI_COEF_PER_MB)[lane];
     // ---- stage reference windows (8.4.2.2.1 / 8.4.2.2.2) ----
     // Fast path: P_L0_16x16 / P_Skip (or any MB whose 16 blocks share motion) whose displaced block
     // lies inside the picture -> 126 + 54 aligned dword loads instead of 1584 clamped byte loads.
@@ -265,9 +270,11 @@ extern "C" __global__ void __launch_bounds__(64) k_inter(const uint32_t *pic_lis
         if (lane == 0) sh.uniform = uniform;
     }
     // ---- residual (independent of the prediction) ----
-    if (rec->cbp)
-        mb_residual(lane, rec, coefs + mbi * MI_COEF_PER_MB, &tab->scaling[pd->scaling_set], &sh.rb);
-    else
+    if (has_res) {
+        if (lane < MI_COEF_PER_MB * 2 / 16) reinterpret_cast<uint4 *>(sh.coef)[lane] = cv;
+        __syncthreads();
+        mb_residual(lane, rec, sh.coef, &tab->scaling[pd->scaling_set], &sh.rb);
+    } else
         zero_residual(lane, &sh.rb);
     __syncthreads();
     const SliceDesc *sd = &slices[rec->slice_idx];
@@ -277,56 +284,85 @@ extern "C" __global__ void __launch_bounds__(64) k_inter(const uint32_t *pic_lis
     {
         const int b = lane >> 2, r = lane & 3;
         const int mvx = rec->mv[b][0], mvy = rec->mv[b][1], fx = mvx & 3, fy = mvy & 3;
-        int p[6][9];
         const int uni = sh.uniform;
         // row j of this lane's 9x9 window: per-block window (stride 12) or the shared 21x21 one (stride 24, byte offset ox + 4*bx)
         const int boff = uni ? ox + (b & 3) * 4 : 0;
         const uint8_t *wbase = uni ? &sh.win16[(b >> 2) * 4 + r][(boff >> 2) * 4] : &sh.win_y[b][r][0];
         const int wstride = uni ? 24 : 12, sh8 = (boff & 3) * 8;
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
+        auto load_row = [&](int j, int (&q)[9]) {
             const uint32_t *row = reinterpret_cast<const uint32_t *>(wbase + j * wstride);
             uint64_t lo = row[0] | (static_cast<uint64_t>(row[1]) << 32), hi = row[1] | (static_cast<uint64_t>(row[2]) << 32);
             uint32_t w0 = static_cast<uint32_t>(lo >> sh8), w1 = static_cast<uint32_t>(hi >> sh8), w2 = row[2] >> sh8;
-            p[j][0] = w0 & 255, p[j][1] = (w0 >> 8) & 255, p[j][2] = (w0 >> 16) & 255, p[j][3] = w0 >> 24;
-            p[j][4] = w1 & 255, p[j][5] = (w1 >> 8) & 255, p[j][6] = (w1 >> 16) & 255, p[j][7] = w1 >> 24;
-            p[j][8] = w2 & 255;
+            q[0] = w0 & 255, q[1] = (w0 >> 8) & 255, q[2] = (w0 >> 16) & 255, q[3] = w0 >> 24;
+            q[4] = w1 & 255, q[5] = (w1 >> 8) & 255, q[6] = (w1 >> 16) & 255, q[7] = w1 >> 24;
+            q[8] = w2 & 255;
+        };
+        // 8.4.2.2.1 by class of fractional position, so that a lane computes only the intermediates its position
+        // needs (motion-uniform macroblocks take one branch for the whole wavefront):
+        //   0 integer | 1 horizontal only (b) | 2 vertical only (h) | 3 diagonal quarter (b|s with h|m) | 4 around the centre (j)
+        const int cls = (fx | fy) == 0 ? 0 : (fy == 0 ? 1 : (fx == 0 ? 2 : ((fx & fy & 1) ? 3 : 4)));
+        int pv[4];
+        if (cls == 0) {
+            int q[9];
+            load_row(2, q);
+#pragma unroll
+            for (int i = 0; i < 4; i++) pv[i] = q[i + 2];
+        } else if (cls == 1) {
+            int q[9];
+            load_row(2, q);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int bb = clip255((tap6(q[i], q[i + 1], q[i + 2], q[i + 3], q[i + 4], q[i + 5]) + 16) >> 5);
+                pv[i] = fx == 2 ? bb : ((fx == 1 ? q[i + 2] : q[i + 3]) + bb + 1) >> 1;
+            }
+        } else {
+            int p[6][9];
+#pragma unroll
+            for (int j = 0; j < 6; j++) load_row(j, p[j]);
+            if (cls == 2) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int hh = clip255((tap6(p[0][i + 2], p[1][i + 2], p[2][i + 2], p[3][i + 2], p[4][i + 2], p[5][i + 2]) + 16) >> 5);
+                    pv[i] = fy == 2 ? hh : ((fy == 1 ? p[2][i + 2] : p[3][i + 2]) + hh + 1) >> 1;
+                }
+            } else if (cls == 3) {
+                const int rsel = fy == 3, csel = fx == 3; // row 2 (b) or 3 (s); column i+2 (h) or i+3 (m)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    int hrow[6], vcol[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) hrow[k] = rsel ? p[3][i + k] : p[2][i + k], vcol[k] = csel ? p[k][i + 3] : p[k][i + 2];
+                    const int hv = clip255((tap6(hrow[0], hrow[1], hrow[2], hrow[3], hrow[4], hrow[5]) + 16) >> 5);
+                    const int vv = clip255((tap6(vcol[0], vcol[1], vcol[2], vcol[3], vcol[4], vcol[5]) + 16) >> 5);
+                    pv[i] = (hv + vv + 1) >> 1;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    int hb[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) hb[j] = tap6(p[j][i], p[j][i + 1], p[j][i + 2], p[j][i + 3], p[j][i + 4], p[j][i + 5]);
+                    const int jj = clip255((tap6(hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]) + 512) >> 10);
+                    int v = jj;
+                    if (fy != 2) // (2,1): b + j, (2,3): s + j
+                        v = (clip255(((fy == 1 ? hb[2] : hb[3]) + 16) >> 5) + jj + 1) >> 1;
+                    else if (fx != 2) { // (1,2): h + j, (3,2): m + j
+                        int vc[6];
+#pragma unroll
+                        for (int k = 0; k < 6; k++) vc[k] = fx == 1 ? p[k][i + 2] : p[k][i + 3];
+                        const int hm = clip255((tap6(vc[0], vc[1], vc[2], vc[3], vc[4], vc[5]) + 16) >> 5);
+                        v = (hm + jj + 1) >> 1;
+                    }
+                    pv[i] = v;
+                }
+            }
         }
         const int refidx = rec->ref[((b >> 3) << 1) | ((b & 3) >> 1)];
         uint32_t packed = 0;
         const int bx = (b & 3) * 4, by = (b >> 2) * 4;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            int v;
-            const int G = p[2][i + 2];
-            if ((fx | fy) == 0)
-                v = G;
-            else {
-                int hb[6];
-#pragma unroll
-                for (int j = 0; j < 6; j++) hb[j] = tap6(p[j][i], p[j][i + 1], p[j][i + 2], p[j][i + 3], p[j][i + 4], p[j][i + 5]);
-                const int bb = clip255((hb[2] + 16) >> 5), ss = clip255((hb[3] + 16) >> 5);
-                const int hh = clip255((tap6(p[0][i + 2], p[1][i + 2], p[2][i + 2], p[3][i + 2], p[4][i + 2], p[5][i + 2]) + 16) >> 5);
-                const int mm = clip255((tap6(p[0][i + 3], p[1][i + 3], p[2][i + 3], p[3][i + 3], p[4][i + 3], p[5][i + 3]) + 16) >> 5);
-                const int jj = clip255((tap6(hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]) + 512) >> 10);
-                switch (fy * 4 + fx) {
-                case 1: v = (G + bb + 1) >> 1; break;
-                case 2: v = bb; break;
-                case 3: v = (p[2][i + 3] + bb + 1) >> 1; break;
-                case 4: v = (G + hh + 1) >> 1; break;
-                case 5: v = (bb + hh + 1) >> 1; break;
-                case 6: v = (bb + jj + 1) >> 1; break;
-                case 7: v = (bb + mm + 1) >> 1; break;
-                case 8: v = hh; break;
-                case 9: v = (hh + jj + 1) >> 1; break;
-                case 10: v = jj; break;
-                case 11: v = (jj + mm + 1) >> 1; break;
-                case 12: v = (p[3][i + 2] + hh + 1) >> 1; break;
-                case 13: v = (hh + ss + 1) >> 1; break;
-                case 14: v = (jj + ss + 1) >> 1; break;
-                default: v = (mm + ss + 1) >> 1; break;
-                }
-            }
+            int v = pv[i];
             if (wp) { // 8.4.2.3 explicit weighted prediction
                 const int ld = sd->luma_log2_denom, w0 = sd->wp_lw[refidx], o0 = sd->wp_lo[refidx];
                 v = ld >= 1 ? clip255(((v * w0 + (1 << (ld - 1))) >> ld) + o0) : clip255(v * w0 + o0);
