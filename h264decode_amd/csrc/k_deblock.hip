@@ -65,46 +65,52 @@ static_assert(sizeof(DbShared) <= MI_DEBLOCK_HDR_BYTES && sizeof(DbWave) == MI_D
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
 
-// filter one edge of a line of samples held in registers (8.7.2.3 / 8.7.2.4); q0 = px[Q]
+// filter one edge of a line of samples held in registers (8.7.2.3 / 8.7.2.4); q0 = px[Q].
+// Written without per-lane branches: both filters are evaluated with selects, and the only branches are
+// wave-uniform (ballot) skips -- "no lane filters this edge" and "no lane needs the bS 4 filter".
 template <int Q, bool CHROMA, int N>
 __device__ __forceinline__ void filter_edge(int (&px)[N], int bs, int alpha, int beta, int tc0) {
     const int p0 = px[Q - 1], p1 = px[Q - 2], q0 = px[Q], q1 = px[Q + 1];
-    if (!bs || !(iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta)) return;
-    if (bs < 4) {
-        int tc;
-        if (CHROMA)
-            tc = tc0 + 1;
-        else {
-            const int p2 = px[Q - 3], q2 = px[Q + 2];
-            const int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
-            tc = tc0 + (ap < beta) + (aq < beta);
-            if (ap < beta) px[Q - 2] = p1 + clip3(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1);
-            if (aq < beta) px[Q + 1] = q1 + clip3(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1);
-        }
+    const bool on = bs != 0 && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
+    if (__builtin_amdgcn_ballot_w64(on) == 0) return;
+    const bool strong = on && bs == 4;
+    int np0, nq0;
+    if (CHROMA) {
+        const int tc = tc0 + 1;
         const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-        px[Q - 1] = clip3(0, 255, p0 + delta);
-        px[Q] = clip3(0, 255, q0 - delta);
-    } else if (CHROMA) {
-        px[Q - 1] = (2 * p1 + p0 + q1 + 2) >> 2;
-        px[Q] = (2 * q1 + q0 + p1 + 2) >> 2;
+        np0 = clip3(0, 255, p0 + delta), nq0 = clip3(0, 255, q0 - delta);
+        if (__builtin_amdgcn_ballot_w64(strong) != 0) {
+            np0 = strong ? (2 * p1 + p0 + q1 + 2) >> 2 : np0;
+            nq0 = strong ? (2 * q1 + q0 + p1 + 2) >> 2 : nq0;
+        }
+        px[Q - 1] = on ? np0 : p0, px[Q] = on ? nq0 : q0;
+        return;
     } else {
         const int p2 = px[Q - 3], q2 = px[Q + 2];
-        const int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
-        const bool small = iabs(p0 - q0) < ((alpha >> 2) + 2);
-        if (ap < beta && small) {
-            const int p3 = px[Q - 4];
-            px[Q - 1] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
-            px[Q - 2] = (p2 + p1 + p0 + q0 + 2) >> 2;
-            px[Q - 3] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
-        } else
-            px[Q - 1] = (2 * p1 + p0 + q1 + 2) >> 2;
-        if (aq < beta && small) {
-            const int q3 = px[Q + 3];
-            px[Q] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
-            px[Q + 1] = (p0 + q0 + q1 + q2 + 2) >> 2;
-            px[Q + 2] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-        } else
-            px[Q] = (2 * q1 + q0 + p1 + 2) >> 2;
+        const bool ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
+        const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
+        const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+        const int avg = (p0 + q0 + 1) >> 1;
+        np0 = clip3(0, 255, p0 + delta), nq0 = clip3(0, 255, q0 - delta);
+        int np1 = ap ? p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1) : p1;
+        int nq1 = aq ? q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1) : q1;
+        int np2 = p2, nq2 = q2;
+        if (__builtin_amdgcn_ballot_w64(strong) != 0) {
+            const int p3 = px[Q - 4], q3 = px[Q + 3];
+            const bool small = iabs(p0 - q0) < ((alpha >> 2) + 2);
+            const bool sp = strong && ap && small, sq = strong && aq && small;
+            const int s3 = p0 + q0 + p1 + 2; // shared partial sums of the 4- and 5-tap filters
+            np0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (strong ? (2 * p1 + p0 + q1 + 2) >> 2 : np0);
+            np1 = sp ? (p2 + s3) >> 2 : (strong ? p1 : np1);
+            np2 = sp ? (2 * p3 + 3 * p2 + s3 + 2) >> 3 : p2;
+            const int t3 = p0 + q0 + q1 + 2;
+            nq0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (strong ? (2 * q1 + q0 + p1 + 2) >> 2 : nq0);
+            nq1 = sq ? (q2 + t3) >> 2 : (strong ? q1 : nq1);
+            nq2 = sq ? (2 * q3 + 3 * q2 + t3 + 2) >> 3 : q2;
+        }
+        px[Q - 1] = on ? np0 : p0, px[Q] = on ? nq0 : q0;
+        px[Q - 2] = on ? np1 : p1, px[Q + 1] = on ? nq1 : q1;
+        px[Q - 3] = on ? np2 : p2, px[Q + 2] = on ? nq2 : q2;
     }
 }
 
