@@ -146,3 +146,13 @@ def test_gpu_720p_cavlc_intra(H, sg, oracle_mod):
     stream, rec, _ = sg.encode(**kw)
     out, _ = _decode_gpu(H, [stream], 1280, 720, 2)
     assert np.array_equal(out[0], rec)
+
+
+def test_gpu_4k_high_8_slices(H, sg):
+    """BASELINE configs[3]: 3840x2160 High CABAC, 8x8 transform, 8 slices per picture (240 x 135 macroblocks: widest row
+    state, 34 deblocking row groups in 3 rounds, slice boundaries inside and across macroblock rows)."""
+    kw = sg.recipe("C4", frames=3, idr_period=3)
+    stream, rec, _ = sg.encode(**kw)
+    out, info = _decode_gpu(H, [stream], 3840, 2160, 3, slices=8)
+    assert (info.coded_width, info.coded_height) == (3840, 2160)
+    assert np.array_equal(out[0], rec)

@@ -1,0 +1,1316 @@
+// h264decode_amd/csrc/k_entropy.hip -- K1/K2: slice_data() entropy decoding on gfx950.
+//
+// One slice per wavefront (one 64-thread workgroup per slice).  The arithmetic decoder is a
+// serial dependency chain, so the syntax-element code is written wave-uniformly: every lane
+// executes the same decision sequence, and the lanes fan out only for the wide work --
+//   * bitstream prefetch: 2 KB chunks of the slice RBSP are pulled into a 4 KB LDS ring with
+//     one 32-byte load per lane (coalesced 128-B requests);
+//   * context initialisation: 460 states copied from the (table-set, QP) row of DevTables;
+//   * neighbour caches: top-row / left-column state (modes, nnz, refs, mvs, |mvd|) lives in LDS;
+//   * write-out: the 128-byte MbRec and the 832-byte coefficient block are assembled in LDS and
+//     stored with one dword / one dwordx4 per lane.
+// CABAC engine state (codIRange, scaled codIOffset, lookahead count) is wave-uniform; context
+// states and a merged rangeTabLPS/transIdx table (one 8-byte LDS read per decision) sit in LDS.
+//
+// Code-size discipline: the instruction cache is shared, and hundreds of slices run different parts
+// of this kernel at once, so every syntax routine is inlined exactly ONCE: residual blocks, motion
+// partitions and reference indices are decoded by single loops over small schedules instead of
+// per-case call sites, and block categories are run-time parameters (tables below), not templates.
+//
+// Replaces: NewSliceData / MbPred (h264/slice.go:570-830, :252-454) and the arithmetic decoding
+// engine (h264/cabac.go:439-553); residual parsing, Intra4x4PredMode derivation and motion vector
+// prediction are absent from the reference and follow ITU-T H.264 7.3.5, 8.3.1.1, 8.4.1, 9.2, 9.3.
+#include <hip/hip_runtime.h>
+#include "mi_kernels.h"
+
+// Register budget: 512 / MI_ENT_MINWAVES VGPRs per wavefront.  The reconstruction kernels of the previous pass
+// must find free registers next to the long-lived entropy wavefronts: measured at 256 streams, 6 (80 VGPRs, a few
+// spills) gives 19.1k frames/s against 18.2k for 4 and 18.4k for 8.
+#ifndef MI_ENT_MINWAVES
+#define MI_ENT_MINWAVES 6
+#endif
+#define LANE (static_cast<int>(threadIdx.x))
+#define FI __device__ __forceinline__
+// The workgroup is ONE wavefront: cross-lane LDS visibility needs no s_barrier and, above all, no
+// wait for outstanding global stores (what __syncthreads() implies) -- LDS operations of a wavefront
+// are processed in issue order, so ordering the instructions is enough.
+#define LDS_SYNC()                                             \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+struct TopInfo { // edge state of a decoded MB as seen by its right / lower neighbours (48 bytes)
+    uint8_t type, t8x8, cbp, chroma_mode, cbf_dc, pad[3];
+    int8_t ipm[4];  // bottom row (top[]) or right column (left)
+    uint8_t nnz[8]; // luma edge [0..3], Cb edge [4..5], Cr edge [6..7]
+    int8_t ref[2];  // the two 8x8 blocks on the edge
+    uint8_t pad2[2];
+    int16_t mv[4][2];
+    uint8_t mvd[4][2];
+};
+static_assert(sizeof(TopInfo) == 48, "TopInfo layout");
+
+struct Shared {
+    uint8_t ctx[464];      // home of the residual-block context states (ctxIdx >= 105); see Ent::wk
+    uint8_t posmap[4][64]; // CAVLC: scan index -> position: [0] zig-zag 4x4, [1] zig-zag 4x4 of AC index (k+1), [2] zig-zag 8x8, [3] identity
+    int16_t coef[MI_COEF_PER_MB];
+    MbRec rec;
+    TopInfo left, tl; // tl = top[] entry of column x-1 as it was for the row above
+    TopInfo topw[2];  // LDS window on the row-above state: [0] = column x, [1] = column x+1 (the row itself lives in HBM)
+    // Neighbour caches of the current MB.  6-wide grids: column 0 = left MB, 1..4 = current MB,
+    // 5 = right / top-right; row 0 = MB row above, rows 1..4 = current MB.
+    int8_t ipm_c[32];      // -2 unavailable, -1 not (yet) an I_NxN block
+    uint8_t nnz_c[32];     // 0x80 = unavailable
+    uint8_t nnzc_c[2][12]; // chroma 3x3 grids
+    int8_t ref_c[32];      // -2 unavailable or not yet decoded, -1 intra, >= 0 ref_idx (motion final)
+    int8_t refi_c[32];     // ref_idx as soon as parsed (CABAC ctxIdxInc of ref_idx)
+    alignas(4) int16_t mv_c[32][2];
+    alignas(2) uint8_t mvd_c[32][2];
+    int16_t lvl[16];       // CAVLC level scratch
+    int16_t tmp16[16];     // CAVLC 8x8 interleave scratch
+    uint16_t parts[16];    // motion partition schedule: bx | by<<2 | (w-1)<<4 | (h-1)<<6 | shape<<8
+    int8_t refs8[4];
+    int8_t sub_type[4];
+    uint8_t cur_cbf_dc, pad[3];
+    int16_t ref_slot[MI_MAX_REFS]; // frame-pool slot per ref_idx of this slice
+};
+#define GI(bx, by) (((by) + 1) * 6 + (bx) + 1)
+
+// Everything the serial syntax code touches per bin lives in registers:
+//   * the bit reader is scalar (64-bit MSB-aligned look-ahead in SGPRs) and is fed from three VGPRs that
+//     hold 3 x 64 consecutive RBSP words, one per lane, read with v_readlane -- no LDS ring;
+//   * the CABAC context states of the macroblock-level syntax elements (ctxIdx 0..104, 399..401) sit
+//     one per lane in two VGPRs (ca, cb); the states of the residual block being decoded are gathered
+//     from their LDS home into a third VGPR (wk) for the duration of the block;
+//   * Tables 9-44 / 9-45, the 8x8 significance maps and the zig-zag scans are per-lane tables too.
+// A decision is then ~35 scalar instructions with no memory access at all.
+struct Ent {
+    Shared *s;
+    TopInfo *top; // [wmb] row-above state of this slice, in global memory (read with L1-bypassing loads)
+    uint32_t pre_top; // lanes 0..11: prefetched dwords of top[mbx + 2]
+    const DevTables *tab;
+    const uint32_t *rbsp32;
+    const SliceDesc *sd;
+    const PicDesc *pd;
+    MbRec *mbrec;
+    int16_t *coefs;
+    // bit reader
+    uint64_t bitbuf;         // next stream bits, MSB first
+    int bcnt;                // valid bits in bitbuf (>= 32 between calls)
+    uint32_t wpos, wbase, rbsp_words; // next word to fetch / first word of `win`
+    uint32_t win, winn, winx; // lane i: RBSP word wbase + i / + 64 + i / + 128 + i, byte-swapped to MSB-first
+    // CABAC engine
+    uint32_t range, value;
+    int avail;
+    uint32_t ca, cb, wk;     // context states, see above; cb lanes 61..63 = ctxIdx 399..401
+    uint32_t v_rlps, v_trans; // lane p: rangeTabLPS[p][0..3] / next state after an LPS for valMPS 0
+    uint32_t v_maps;         // lane i: sig8x8[i] | last8x8[i] << 8 | zigzag8[i] << 16 | zigzag4[i & 15] << 24
+    uint32_t v_zzac;         // lane i: zigzag4[(i + 1) & 15] (AC blocks: scan index i is coefficient i + 1)
+    uint32_t v_cat0, v_cat1; // lane ctxBlockCat: packed block-category parameters (cat_word0/1)
+    uint32_t v_qpc, v_refslot; // lane i: QPc table entry / frame slot of ref_idx i
+    uint32_t v_step;         // lane = residual step: step_word()
+    uint64_t nzm, unm;       // coded / unavailable masks of the neighbourhood (parse_residual_cabac)
+    uint32_t aw, bw;         // first dword of the left / upper TopInfo (Nb)
+    int v_ipm;               // lanes 0..29: Intra4x4/8x8PredMode grid (same layout and codes as Shared::ipm_c)
+    int qp, prev_dqp_nz, mbx, mby, cur_type, err;
+    int cabac, islice, wmb, hmb;
+    int cip, t8x8_mode, cqp_off0, cqp_off1, nref;
+    uint64_t mb_base;
+#if MI_ENT_STATS
+    uint32_t bins;
+    uint64_t tacc[4], tmark; // diagnostics: shader clocks in [0] fill_caches [1] macroblock syntax before residual() [2] residual() [3] record write-out
+#endif
+};
+#if MI_ENT_STATS
+#define MI_BINS(e) ((e).bins)
+#define MI_COUNT_BIN(e) ((e).bins++)
+#define MI_TT0(e) ((e).tmark = __builtin_readcyclecounter())
+#define MI_TT(e, k) do { const uint64_t now_ = __builtin_readcyclecounter(); (e).tacc[k] += now_ - (e).tmark; (e).tmark = now_; } while (0)
+#if MI_ENT_STATS == 2 /* [0] significance map [1] levels [2] rest of residual_block_cabac [3] rest of residual() */
+#define MI_T0(e) ((void)0)
+#define MI_T(e, k) ((void)0)
+#define MI_R0(e) ((void)0)
+#define MI_R(e, k) ((void)0)
+#define MI_R0(e) MI_TT0(e)
+#define MI_R(e, k) MI_TT(e, k)
+#else
+#define MI_T0(e) MI_TT0(e)
+#define MI_T(e, k) MI_TT(e, k)
+#define MI_R0(e) ((void)0)
+#define MI_R(e, k) ((void)0)
+#endif
+#else
+#define MI_BINS(e) 0u
+#define MI_COUNT_BIN(e) ((void)0)
+#define MI_T0(e) ((void)0)
+#define MI_T(e, k) ((void)0)
+#define MI_R0(e) ((void)0)
+#define MI_R(e, k) ((void)0)
+#endif
+#define RFL(x) __builtin_amdgcn_readfirstlane(x)
+#define RDL(v, i) static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(i)))
+// v_writelane_b32: clang has no builtin for it, the LLVM intrinsic is bound by name
+extern "C" __device__ int mi_writelane(int val, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+
+// per block category (ctxBlockCat 0..5; Tables 9-34, 9-40, 9-43):
+//   word0 = maxNumCoeff | (coded_block_flag base - 64) << 8 | clamp of numDecodAbsLevelGt1 << 16 | position mode << 20
+//           (0 zig-zag 4x4, 1 zig-zag 4x4 of index k+1, 2 zig-zag 8x8, 3 identity) | number of last contexts << 24
+//   word1 = significant_coeff_flag base | last_significant_coeff_flag base << 10 | coeff_abs_level_minus1 base << 20
+FI uint32_t cat_word0(int c) {
+    const uint32_t maxnum[6] = {16, 15, 16, 4, 15, 64}, cbf[6] = {85, 89, 93, 97, 101, 64}, lim[6] = {4, 4, 4, 3, 4, 4}, pm[6] = {0, 1, 0, 3, 1, 2};
+    const uint32_t nlast[6] = {15, 14, 15, 3, 14, 9};
+    c = c < 6 ? c : 0;
+    return maxnum[c] | (cbf[c] - 64) << 8 | lim[c] << 16 | pm[c] << 20 | nlast[c] << 24;
+}
+FI uint32_t cat_word1(int c) {
+    const uint32_t sig[6] = {105, 120, 134, 149, 152, 402}, last[6] = {166, 181, 195, 210, 213, 417}, ab[6] = {227, 237, 247, 257, 266, 426};
+    c = c < 6 ? c : 0;
+    return sig[c] | last[c] << 10 | ab[c] << 20;
+}
+
+// ------------------------------------------------------------------ bit reader
+FI uint32_t load_win(const Ent &e, uint32_t base) {
+    const uint32_t i = base + LANE;
+    return i < e.rbsp_words ? __builtin_bswap32(e.rbsp32[i]) : 0u;
+}
+// The three window VGPRs cover 192 consecutive words from wbase.  The window slides at macroblock
+// boundaries only (slide_window): 128 words then remain ahead of the cursor, more than the 3200 bits
+// a macroblock_layer() may occupy (A.3.1); I_PCM samples are reached with seek().
+FI uint32_t fetch_word(Ent &e) {
+    const uint32_t idx = e.wpos - e.wbase;
+    e.wpos++;
+    const uint32_t w0 = RDL(e.win, idx), w1 = RDL(e.winn, idx), w2 = RDL(e.winx, idx); // the lane select is idx & 63
+    return idx < 64 ? w0 : (idx < 128 ? w1 : w2);
+}
+FI void slide_window(Ent &e) {
+    while (e.wpos - e.wbase >= 64) { // twice after a macroblock of more than 2048 bits
+        e.win = e.winn, e.winn = e.winx;
+        e.wbase += 64;
+        e.winx = load_win(e, e.wbase + 128); // consumed 64 words (>= one macroblock) later
+    }
+}
+FI uint32_t bitpos(const Ent &e) { return e.wpos * 32 - static_cast<uint32_t>(e.bcnt); }
+FI void seek(Ent &e, uint32_t pos) {
+    const uint32_t w = pos >> 5;
+    if (w - e.wbase >= 64) {
+        e.wbase = w;
+        e.win = load_win(e, w), e.winn = load_win(e, w + 64), e.winx = load_win(e, w + 128);
+    }
+    e.wpos = w;
+    const uint64_t hi = fetch_word(e), lo = fetch_word(e);
+    e.bitbuf = ((hi << 32) | lo) << (pos & 31);
+    e.bcnt = 64 - static_cast<int>(pos & 31);
+}
+FI uint32_t peek32(const Ent &e) { return static_cast<uint32_t>(e.bitbuf >> 32); }
+FI void skip(Ent &e, int n) { // 0..32
+    e.bitbuf <<= n;
+    e.bcnt -= n;
+    if (__builtin_expect(e.bcnt < 32, 0)) {
+        const uint64_t w = fetch_word(e);
+        e.bitbuf |= w << (32 - e.bcnt);
+        e.bcnt += 32;
+    }
+}
+FI uint32_t get_bits(Ent &e, int n) { // 1..32
+    const uint32_t v = peek32(e) >> (32 - n);
+    skip(e, n);
+    return v;
+}
+FI uint32_t get_bit(Ent &e) { return get_bits(e, 1); }
+FI uint32_t get_ue(Ent &e) { // 9.1 with one CLZ
+    const uint32_t w = peek32(e);
+    if (w == 0) {
+        e.err = 1;
+        skip(e, 32);
+        return 0;
+    }
+    const int lz = __clz(w);
+    if (lz > 15) {
+        skip(e, lz + 1);
+        return (1u << lz) - 1 + get_bits(e, lz);
+    }
+    skip(e, 2 * lz + 1);
+    return (w >> (31 - 2 * lz)) - 1;
+}
+FI int get_se(Ent &e) {
+    uint32_t k = get_ue(e);
+    int m = static_cast<int>((k + 1) >> 1);
+    return (k & 1) ? m : -m;
+}
+
+// ------------------------------------------------------------------ CABAC engine (9.3.1.2, 9.3.3.2)
+// codIOffset is kept scaled: value = (codIOffset << avail) | next `avail` stream bits.
+//
+// Issue balance.  A compute unit has ONE scalar ALU (about one SALU instruction per cycle for all of
+// its wavefronts) next to four vector ALUs, and tens of slices share a CU, so a decoder written purely
+// in scalar instructions is bound by that single unit.  The engine is therefore split: the data path
+// (codIRange / codIOffset arithmetic, renormalisation, state selection) runs on the VALU with the
+// same value in every lane, while table indices, loop control and branches stay scalar.  VGPR() pins
+// a wave-uniform value to the vector side; UNI() turns a vector-side condition into a scalar branch
+// condition (v_cmp writes the lane mask, one s_cmp tests it).
+#define VGPR(x) asm volatile("" : "+v"(x))
+#define UNI(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
+FI void cabac_refill(Ent &e) {
+    if (__builtin_expect(UNI(e.avail < 7), 0)) { // about once per 13 decisions: keep the common path fall-through
+        e.value = (e.value << 16) | (peek32(e) >> 16);
+        skip(e, 16);
+        e.avail += 16;
+    }
+}
+FI void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
+    e.range = 510;
+    e.value = get_bits(e, 9);
+    e.avail = 0;
+    VGPR(e.range);
+    VGPR(e.value);
+    VGPR(e.avail);
+    cabac_refill(e);
+}
+// DecodeDecision (h264/cabac.go:521-540) + state transition (:544-553) + RenormD (:503-511) on the
+// context state held in lane `idx_` of `reg`.  The bin comes back on the vector side (same value in every
+// lane): BIN_x() turns it into a branch condition (v_cmp + s_cbranch_vcc), BINI_x() into a scalar integer.
+FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
+    MI_COUNT_BIN(e);
+    const int idx = RFL(idx_);
+    const uint32_t st = RDL(reg, idx);
+    const uint32_t p = st >> 1;
+    const uint32_t rl4 = RDL(e.v_rlps, p), tr = RDL(e.v_trans, p);
+    // everything else runs on the vector side (the CU's single scalar ALU is the scarce unit): st is pinned there
+    uint32_t vst = st;
+    VGPR(vst);
+    const uint32_t mps = vst & 1;
+    // the two candidate successor states (v_trans holds the LPS successor for valMPS 0; bit 0 flips with valMPS)
+    const uint32_t next_lps = tr ^ mps;
+    const uint32_t next_mps = min(vst + 2, 124 | mps);
+    const uint32_t rlps = __builtin_amdgcn_ubfe(rl4, (e.range >> 3) & 24, 8);
+    const uint32_t rmps = e.range - rlps;
+    const uint32_t scaled = rmps << e.avail;
+    const bool lps = e.value >= scaled;
+    const uint32_t diff = e.value - scaled; // wraps when value < scaled; both are below 2^31
+    e.value = min(e.value, diff);
+    e.range = lps ? rlps : rmps;
+    reg = LANE == idx ? (lps ? next_lps : next_mps) : reg;
+    const uint32_t binv = (diff >> 31) ^ (mps ^ 1); // valMPS on the MPS path (sign bit set), !valMPS otherwise
+    const int n = __builtin_clz(e.range) - 23;
+    e.range <<= n;
+    e.avail -= n;
+    cabac_refill(e);
+    return binv;
+}
+#define BIN_A(e, ctx) UNI(cabac_decide(e, (e).ca, (ctx)) != 0)          /* ctxIdx 0..63 */
+#define BIN_B(e, ctx) UNI(cabac_decide(e, (e).cb, (ctx) - 64) != 0)     /* ctxIdx 64..124 */
+#define BIN_T8(e, inc) UNI(cabac_decide(e, (e).cb, 61 + (inc)) != 0)    /* ctxIdx 399..401 */
+#define BIN_W(e, lane) UNI(cabac_decide(e, (e).wk, (lane)) != 0)        /* residual working set */
+#define BINI_A(e, ctx) static_cast<int>(RFL(cabac_decide(e, (e).ca, (ctx))))
+#define BINI_B(e, ctx) static_cast<int>(RFL(cabac_decide(e, (e).cb, (ctx) - 64)))
+#define BINI_T8(e, inc) static_cast<int>(RFL(cabac_decide(e, (e).cb, 61 + (inc))))
+FI bool cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
+    MI_COUNT_BIN(e);
+    e.avail -= 1;
+    const uint32_t scaled = e.range << e.avail;
+    const bool one = e.value >= scaled;
+    e.value = min(e.value, e.value - scaled);
+    cabac_refill(e);
+    return UNI(one);
+}
+FI bool cabac_terminate(Ent &e) { // 9.3.3.2.4
+    e.range -= 2;
+    if (UNI(e.value >= (e.range << e.avail))) return true;
+    const int n = __builtin_clz(e.range) - 23;
+    e.range <<= n;
+    e.avail -= n;
+    cabac_refill(e);
+    return false;
+}
+// Exp-Golomb suffix of UEGk binarisations (9.3.2.3), bypass coded
+FI int cabac_egk(Ent &e, int k) {
+    int v = 0;
+    while (cabac_bypass(e)) {
+        v += 1 << k;
+        if (++k > 24) {
+            e.err = 4;
+            break;
+        }
+    }
+    while (k--) v += cabac_bypass(e) << k;
+    return v;
+}
+
+// ------------------------------------------------------------------ neighbour MBs
+FI const TopInfo *mbA(const Ent &e) { return e.s->left.type != MBT_NONE ? &e.s->left : nullptr; }
+FI const TopInfo *mbB(const Ent &e) { return e.s->topw[0].type != MBT_NONE ? &e.s->topw[0] : nullptr; }
+FI const TopInfo *mbC(const Ent &e) { return (e.mbx + 1 < e.wmb && e.s->topw[1].type != MBT_NONE) ? &e.s->topw[1] : nullptr; }
+// the left / upper macroblock's type, transform flag, cbp and chroma mode as one scalar word (first dword of TopInfo)
+struct Nb {
+    uint32_t w;
+    FI bool ok() const { return (w & 255) != 0; }
+    FI int type() const { return static_cast<int>(w & 255); }
+    FI int t8x8() const { return static_cast<int>((w >> 8) & 255); }
+    FI int cbp() const { return static_cast<int>((w >> 16) & 255); }
+    FI int chroma_mode() const { return static_cast<int>(w >> 24); }
+};
+// L1-bypassing dword load of the row-above array (it is rewritten by this wave one row later)
+FI uint32_t top_load(const Ent &e, int col, int dw) {
+    return col < e.wmb ? __hip_atomic_load(reinterpret_cast<const uint32_t *>(e.top + col) + dw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
+
+// ------------------------------------------------------------------ residual blocks
+// residual_block_cabac 7.3.5.3.3 for ctxBlockCat `cat`; coefficients are written de-zig-zagged.
+// The block's context states are gathered into e.wk (lanes 0..15 significant_coeff_flag, 16..31
+// last_significant_coeff_flag, 32..41 coeff_abs_level_minus1) while coded_block_flag is decoded and
+// scattered back to their LDS home afterwards.  Levels are collected in a VGPR (lane = scan index)
+// and stored with one predicated LDS write per block.
+FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
+    MI_R(e, 3);
+    const int cat = RFL(cat_);
+    const uint32_t c0 = RDL(e.v_cat0, cat), c1 = RDL(e.v_cat1, cat);
+    const int l = LANE, grp = l >> 4, li = l & 15;
+    const int home = static_cast<int>((c1 >> (10 * (grp > 2 ? 2 : grp))) & 1023) + (l < 32 ? li : l - 32);
+    const uint32_t pending = e.s->ctx[home < 464 ? home : 463]; // the load overlaps the coded_block_flag decision
+    if (cat != 5 && !BIN_B(e, 64 + ((c0 >> 8) & 255) + cbf_inc)) {
+        MI_R(e, 2);
+        return 0;
+    }
+    e.wk = pending;
+    const int last = static_cast<int>(c0 & 255) - 1; // maxNumCoeff - 1
+    const bool is8 = cat == 5;
+    uint64_t sig = 0;
+    int i;
+    MI_R(e, 2);
+    // significance map; a set last_significant_coeff_flag ends the loop through the index itself
+    if (is8) {
+        for (i = 0; i < last; i++) {
+            const uint32_t m = RDL(e.v_maps, i);
+            if (BIN_W(e, m & 255)) {
+                sig |= 1ull << i;
+                if (BIN_W(e, 16 + ((m >> 8) & 255))) i = 64;
+            }
+        }
+    } else {
+        const int cap = cat == 3 ? 2 : 15;
+        for (i = 0; i < last; i++) {
+            const int inc = i < cap ? i : cap;
+            if (BIN_W(e, inc)) {
+                sig |= 1ull << i;
+                if (BIN_W(e, 16 + inc)) i = 64;
+            }
+        }
+    }
+    MI_R(e, 0);
+    if (i == last) sig |= 1ull << last; // no last flag seen: the final coefficient is significant by inference
+    const int n = __builtin_popcountll(sig);
+    // levels, highest frequency first (9.3.3.1.3): inc0 / cx are the wk lanes of the two context selections
+    int inc0 = 33, cx = 37;
+    const int cxmax = 37 + static_cast<int>((c0 >> 16) & 15);
+    int lv = 0;
+    while (sig) {
+        const int k = 63 - __clzll(static_cast<long long>(sig));
+        sig &= ~(1ull << k);
+        int a = 1;
+        if (BIN_W(e, inc0)) {
+            a = 2;
+            while (a < 15 && BIN_W(e, cx)) a++;
+            if (a >= 15) a += cabac_egk(e, 0);
+            inc0 = 32;
+            cx = cx < cxmax ? cx + 1 : cxmax;
+        } else if (inc0 != 32)
+            inc0 = inc0 < 36 ? inc0 + 1 : 36;
+        const int v = cabac_bypass(e) ? -a : a;
+        lv = l == k ? v : lv;
+    }
+    MI_R(e, 1);
+    {
+        const int pmode = static_cast<int>((c0 >> 20) & 15);
+        const uint32_t pos = pmode == 3 ? static_cast<uint32_t>(l) : (pmode == 2 ? (e.v_maps >> 16) & 255 : (pmode == 1 ? e.v_zzac : e.v_maps >> 24));
+        if (lv != 0) dst[pos] = static_cast<int16_t>(lv);
+    }
+    // scatter the states back; lanes outside the block's own context ranges hold copies of other blocks'
+    // states and must not be written (for 8x8 blocks ctxIdx 417 appears in both the sig and the last group)
+    const int nsig = is8 ? 15 : last, nlast = static_cast<int>((c0 >> 24) & 15);
+    if (grp == 0 ? li < nsig : (grp == 1 ? li < nlast : l < 42)) e.s->ctx[home] = static_cast<uint8_t>(e.wk);
+    MI_R(e, 2);
+    return n;
+}
+
+// residual_block_cavlc 9.2.  kind: 0 = 16 coefficients, 1 = 15 (AC), 2 = chroma DC (4),
+// 3 = 16 coefficients written in scan order (CAVLC + 8x8 transform interleave)
+FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
+    const DevTables *t = e.tab;
+    const int maxnum = kind == 1 ? 15 : (kind == 2 ? 4 : 16);
+    uint32_t w = peek32(e);
+    uint32_t ent;
+    if (kind == 2)
+        ent = t->vlc_cdc[w >> 24];
+    else if (nC < 2)
+        ent = t->vlc_ct0[w >> (32 - MI_VLC_CT0_BITS)];
+    else if (nC < 4)
+        ent = t->vlc_ct1[w >> (32 - MI_VLC_CT1_BITS)];
+    else if (nC < 8)
+        ent = t->vlc_ct2[w >> (32 - MI_VLC_CT2_BITS)];
+    else
+        ent = t->vlc_ct3[w >> 26];
+    ent = RFL(ent);
+    if (!(ent >> 8)) {
+        e.err = 6;
+        return 0;
+    }
+    skip(e, ent >> 8);
+    const int total = (ent >> 2) & 31, t1s = ent & 3;
+    if (total == 0) return 0;
+    if (total > maxnum) {
+        e.err = 7;
+        return 0;
+    }
+    int suffix_len = (total > 10 && t1s < 3) ? 1 : 0;
+    for (int i = 0; i < total; i++) {
+        int lv;
+        if (i < t1s)
+            lv = 1 - 2 * static_cast<int>(get_bit(e));
+        else {
+            uint32_t ww = peek32(e);
+            if (ww == 0) {
+                e.err = 8;
+                return 0;
+            }
+            int prefix = __clz(ww);
+            skip(e, prefix + 1);
+            int code = (prefix < 15 ? prefix : 15) << suffix_len;
+            if (suffix_len > 0 || prefix >= 14) {
+                int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
+                if (size > 0) code += get_bits(e, size);
+            }
+            if (prefix >= 15 && suffix_len == 0) code += 15;
+            if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+            if (i == t1s && t1s < 3) code += 2;
+            lv = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
+            if (suffix_len == 0) suffix_len = 1;
+            int al = lv < 0 ? -lv : lv;
+            if (al > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
+        }
+        e.s->lvl[i] = static_cast<int16_t>(lv);
+    }
+    int zeros_left = 0;
+    if (total < maxnum) {
+        uint32_t ww = peek32(e);
+        const uint32_t en = RFL(static_cast<uint32_t>(kind == 2 ? t->vlc_cdc_tz[total - 1][ww >> 29] : t->vlc_tz[total - 1][ww >> 23]));
+        if (!(en >> 8)) {
+            e.err = 9;
+            return 0;
+        }
+        skip(e, en >> 8);
+        zeros_left = en & 255;
+    }
+    int pos = zeros_left + total - 1; // scan position of the highest-frequency coefficient
+    if (pos >= maxnum) {
+        e.err = 10;
+        return 0;
+    }
+    const uint8_t *pm = e.s->posmap[kind == 0 ? 0 : (kind == 1 ? 1 : 3)];
+    for (int i = 0; i < total; i++) {
+        dst[pm[pos]] = e.s->lvl[i];
+        if (i < total - 1) {
+            int run = 0;
+            if (zeros_left > 0) {
+                uint32_t ww = peek32(e);
+                const uint32_t en = RFL(static_cast<uint32_t>(t->vlc_run[(zeros_left > 7 ? 7 : zeros_left) - 1][ww >> 21]));
+                if (!(en >> 8) || static_cast<int>(en & 255) > zeros_left) {
+                    e.err = 11;
+                    return 0;
+                }
+                skip(e, en >> 8);
+                run = en & 255;
+                zeros_left -= run;
+            }
+            pos -= run + 1;
+        }
+    }
+    return total;
+}
+
+FI int nc_of(uint8_t a, uint8_t b) { // 9.2.1
+    int av = !(a & 0x80), bv = !(b & 0x80);
+    if (av && bv) return (a + b + 1) >> 1;
+    return av ? a : (bv ? b : 0);
+}
+FI int cbf_inc_of(const Ent &e, uint8_t a, uint8_t b) { // 9.3.3.1.1.9
+    int ci = MB_IS_INTRA(e.cur_type);
+    int ca = (a & 0x80) ? ci : (a != 0), cb = (b & 0x80) ? ci : (b != 0);
+    return ca + 2 * cb;
+}
+
+// residual() 7.3.5.3 as ONE loop over a block schedule:
+//   0: Intra16x16 DC | 1..16: luma blocks (z-order) | 17,18: chroma DC | 19..26: chroma AC
+// residual() 7.3.5.3 for CABAC.  coded_block_flag contexts (9.3.3.1.1.9) need one bit per neighbouring
+// block, so the neighbourhood is a 64-bit scalar mask instead of LDS arrays:
+//   bits  0..29  luma 4x4 blocks, 6-wide grid GI(bx, by) (column 0 = left MB, row 0 = MB above)
+//   bits 32..49  chroma AC blocks, two 3x3 grids (32 + 9 * plane + 3 * (by + 1) + bx + 1)
+//   bits 50..52 / 53..55  DC flags (Intra16x16 luma, Cb, Cr) of the left / upper macroblock, 56..58 of this one
+// fill_caches() ballots "coded" (e.nzm) and "unavailable" (e.unm); unavailable counts as coded for intra
+// macroblocks.  The schedule is a bit set of steps (0 Intra16x16 DC, 1..16 luma z-order, 17/18 chroma DC,
+// 19..26 chroma AC) and a per-lane descriptor table: A bit | B bit << 6 | own bit << 12 | dst/4 << 18 | kind << 26.
+FI uint32_t step_word(int st) {
+    if (st == 0) return 50u | 53u << 6 | 56u << 12 | (MI_COEF_I16DC / 4) << 18 | 0u << 26;
+    if (st <= 16) {
+        const int idx = st - 1, bx = (idx & 1) + 2 * ((idx >> 2) & 1), by = ((idx >> 1) & 1) + 2 * (idx >> 3);
+        return static_cast<uint32_t>(GI(bx - 1, by)) | static_cast<uint32_t>(GI(bx, by - 1)) << 6 | static_cast<uint32_t>(GI(bx, by)) << 12 |
+               static_cast<uint32_t>((by * 4 + bx) * 4) << 18 | 1u << 26;
+    }
+    if (st <= 18) {
+        const uint32_t c = st - 17;
+        return (51u + c) | (54u + c) << 6 | (57u + c) << 12 | (MI_COEF_CDC / 4 + c) << 18 | 2u << 26;
+    }
+    if (st <= 26) {
+        const int j = st - 19, c = j >> 2, bx = j & 1, by = (j >> 1) & 1, g = 32 + 9 * c;
+        return static_cast<uint32_t>(g + (by + 1) * 3 + bx) | static_cast<uint32_t>(g + by * 3 + bx + 1) << 6 | static_cast<uint32_t>(g + (by + 1) * 3 + bx + 1) << 12 |
+               static_cast<uint32_t>(MI_COEF_CAC / 4 + j * 4) << 18 | 3u << 26;
+    }
+    return 0;
+}
+FI void parse_residual_cabac(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
+    Shared *s = e.s;
+    const int i16 = e.cur_type == MBT_I16x16;
+    uint64_t nzm = e.nzm | (MB_IS_INTRA(e.cur_type) ? e.unm : 0);
+    // luma steps of the coded 8x8 blocks: all four 4x4 blocks, or the first one standing for the 8x8 block
+    const uint32_t spread = (cbp_luma & 1) | (cbp_luma & 2) << 3 | (cbp_luma & 4) << 6 | (cbp_luma & 8) << 9;
+    uint32_t steps = static_cast<uint32_t>(i16) | (spread * (t8x8 ? 1u : 15u)) << 1;
+    if (cbp_chroma) steps |= 3u << 17;
+    if (cbp_chroma & 2) steps |= 0xFFu << 19;
+    const uint32_t cats = 0u | (t8x8 ? 5u : (i16 ? 1u : 2u)) << 4 | 3u << 8 | 4u << 12; // ctxBlockCat by step kind
+    while (steps) {
+        const int step = __builtin_ctz(steps);
+        steps &= steps - 1;
+        const uint32_t d = RDL(e.v_step, step);
+        const int cat = static_cast<int>((cats >> ((d >> 26) * 4)) & 15);
+        const int own = static_cast<int>((d >> 12) & 63);
+        const int dst = cat == 5 ? (step - 1) * 16 : static_cast<int>((d >> 18) & 255) * 4;
+        const int inc = static_cast<int>((nzm >> (d & 63)) & 1) + 2 * static_cast<int>((nzm >> ((d >> 6) & 63)) & 1);
+        if (cabac_residual(e, s->coef + dst, cat, inc)) nzm |= (cat == 5 ? 0xC3ull : 1ull) << own;
+    }
+    // results: deblocking mask (raster 4x4), DC flags and the 0/1 "coded" grids the neighbours will read
+    const uint32_t lo = static_cast<uint32_t>(nzm);
+    const uint32_t nzmask = ((lo >> GI(0, 0)) & 15) | ((lo >> GI(0, 1)) & 15) << 4 | ((lo >> GI(0, 2)) & 15) << 8 | ((lo >> GI(0, 3)) & 15) << 12;
+    s->rec.nzmask = static_cast<uint16_t>(nzmask);
+    s->cur_cbf_dc = static_cast<uint8_t>((nzm >> 56) & 7);
+    const int l = LANE;
+    const int bit = static_cast<int>((nzm >> l) & 1);
+    if (l < 30) {
+        const int gx = l % 6 - 1, gy = l / 6 - 1;
+        if (gx >= 0 && gx < 4 && gy >= 0) s->nnz_c[l] = static_cast<uint8_t>(bit);
+    } else if (l >= 32 && l < 50) {
+        const int i = l - 32, g = i % 9, gx = g % 3 - 1, gy = g / 3 - 1;
+        if (gx >= 0 && gy >= 0) s->nnzc_c[i / 9][g] = static_cast<uint8_t>(bit);
+    }
+}
+
+FI void parse_residual_cavlc(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
+    Shared *s = e.s;
+    const int i16 = e.cur_type == MBT_I16x16;
+    int nzmask = 0;
+    for (int step = 0; step < 27; step++) {
+        int kind, bx = 0, by = 0;
+        uint8_t na, nb;
+        int16_t *dst;
+        if (step == 0) {
+            if (!i16) continue;
+            kind = 0;
+            dst = s->coef + MI_COEF_I16DC;
+            na = s->nnz_c[GI(-1, 0)], nb = s->nnz_c[GI(0, -1)];
+        } else if (step <= 16) {
+            const int idx = step - 1, b8 = idx >> 2;
+            if (!((cbp_luma >> b8) & 1)) {
+                step += 3; // whole 8x8 uncoded
+                continue;
+            }
+            bx = (idx & 1) + 2 * ((idx >> 2) & 1), by = ((idx >> 1) & 1) + 2 * (idx >> 3);
+            na = s->nnz_c[GI(bx - 1, by)], nb = s->nnz_c[GI(bx, by - 1)];
+            if (t8x8) {
+                kind = 3;
+                dst = s->tmp16;
+                for (int i = 0; i < 16; i++) s->tmp16[i] = 0;
+            } else {
+                kind = i16 ? 1 : 0;
+                dst = s->coef + (by * 4 + bx) * 16;
+            }
+        } else if (step <= 18) {
+            if (!cbp_chroma) break;
+            const int c = step - 17;
+            kind = 2;
+            dst = s->coef + MI_COEF_CDC + 4 * c;
+            na = nb = 0;
+        } else {
+            if (!(cbp_chroma & 2)) break;
+            const int j = step - 19, c = j >> 2, b4 = j & 3;
+            bx = b4 & 1, by = b4 >> 1;
+            kind = 1;
+            dst = s->coef + MI_COEF_CAC + j * 16;
+            na = s->nnzc_c[c][(by + 1) * 3 + bx], nb = s->nnzc_c[c][by * 3 + bx + 1];
+        }
+        const int n = cavlc_residual(e, dst, kind, kind == 2 ? -1 : nc_of(na, nb));
+        // ---- bookkeeping per block kind ----
+        if (step == 0) {
+            if (n) s->cur_cbf_dc |= 1;
+        } else if (step <= 16) {
+            const int idx = step - 1, b8 = idx >> 2, r = by * 4 + bx;
+            {
+                if (kind == 3) // CAVLC + 8x8 transform: 4x4 "block" b4 carries coefficients 4*i + b4 of the 8x8 scan (7.3.5.3.2)
+                    for (int i = 0; i < 16; i++) {
+                        int16_t v = s->tmp16[i];
+                        if (v) s->coef[b8 * 64 + s->posmap[2][4 * i + (idx & 3)]] = v;
+                    }
+                s->nnz_c[GI(bx, by)] = static_cast<uint8_t>(n);
+                if (n) nzmask |= t8x8 ? (0x33 << ((by & 2) * 4 + (bx & 2))) : (1 << r);
+            }
+        } else if (step <= 18) {
+            if (n) s->cur_cbf_dc |= static_cast<uint8_t>(2 << (step - 17));
+        } else
+            s->nnzc_c[(step - 19) >> 2][(by + 1) * 3 + bx + 1] = static_cast<uint8_t>(n);
+    }
+    s->rec.nzmask = static_cast<uint16_t>(nzmask);
+}
+
+// ------------------------------------------------------------------ motion vector prediction 8.4.1.3
+FI int median3(int a, int b, int c) {
+    int mn = a < b ? a : b, mx = a < b ? b : a;
+    return c < mn ? mn : (c > mx ? mx : c);
+}
+// shape: 0 median, 1/2 = 16x8 upper/lower, 3/4 = 8x16 left/right
+FI void predict_mv(const Ent &e, int bx, int by, int w, int ref, int shape, int &px, int &py) {
+    const Shared *s = e.s;
+    int ia = GI(bx - 1, by), ib = GI(bx, by - 1), ic = GI(bx + w, by - 1);
+    int ra = s->ref_c[ia], rb = s->ref_c[ib], rc = s->ref_c[ic];
+    if (rc == -2) {
+        ic = GI(bx - 1, by - 1);
+        rc = s->ref_c[ic];
+    }
+    int ax = s->mv_c[ia][0], ay = s->mv_c[ia][1], bxv = s->mv_c[ib][0], byv = s->mv_c[ib][1], cx = s->mv_c[ic][0], cy = s->mv_c[ic][1];
+    if (shape == 1 && rb == ref) {
+        px = bxv, py = byv;
+        return;
+    }
+    if ((shape == 2 || shape == 3) && ra == ref) {
+        px = ax, py = ay;
+        return;
+    }
+    if (shape == 4 && rc == ref) {
+        px = cx, py = cy;
+        return;
+    }
+    if (rb == -2 && rc == -2 && ra != -2) rb = rc = ra, bxv = cx = ax, byv = cy = ay;
+    int na = ra == ref, nb = rb == ref, nc = rc == ref;
+    if (na + nb + nc == 1) {
+        px = na ? ax : (nb ? bxv : cx);
+        py = na ? ay : (nb ? byv : cy);
+        return;
+    }
+    px = median3(ax, bxv, cx);
+    py = median3(ay, byv, cy);
+}
+FI void set_part(Ent &e, int bx, int by, int w, int h, int ref, int mvx, int mvy, int dx, int dy) {
+    Shared *s = e.s;
+    const uint8_t ax = static_cast<uint8_t>(min(abs(dx), 255)), ay = static_cast<uint8_t>(min(abs(dy), 255));
+    const int l = LANE, x = l & 3, y = (l >> 2) & 3; // one 4x4 block per lane (lanes 0..15)
+    if (l < 16 && x >= bx && x < bx + w && y >= by && y < by + h) {
+        const int g = GI(x, y);
+        s->ref_c[g] = static_cast<int8_t>(ref);
+        *reinterpret_cast<uint32_t *>(s->mv_c[g]) = (static_cast<uint32_t>(mvx) & 0xffffu) | (static_cast<uint32_t>(mvy) << 16);
+        *reinterpret_cast<uint16_t *>(s->mvd_c[g]) = static_cast<uint16_t>(ax | (ay << 8));
+    }
+    LDS_SYNC();
+}
+#define PART(bx, by, w, h, shape) static_cast<uint16_t>((bx) | ((by) << 2) | (((w)-1) << 4) | (((h)-1) << 6) | ((shape) << 8))
+
+// ------------------------------------------------------------------ per-MB neighbour caches
+FI void fill_caches(Ent &e) {
+    Shared *s = e.s;
+    const TopInfo *a = mbA(e), *b = mbB(e);
+    const TopInfo *c = mbC(e);
+    const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
+    const int cip = e.cip;
+    const int l = LANE;
+    int coded = 0; // this lane's bit of the CABAC neighbourhood masks: 1 coded, 2 unavailable (see parse_residual_cabac)
+    if (l < 30) {
+        int gx = l % 6 - 1, gy = l / 6 - 1; // block coordinates relative to the MB
+        int8_t ipm = -2, ref = -2;
+        uint8_t nnz = 0x80, mvdx = 0, mvdy = 0;
+        int16_t mvx = 0, mvy = 0;
+        const TopInfo *n = nullptr;
+        int k = 0; // index inside the neighbour's edge arrays
+        int edge = 0;
+        if (gy < 0 && gx >= 0 && gx < 4)
+            n = b, k = gx, edge = 1;
+        else if (gx < 0 && gy >= 0)
+            n = a, k = gy, edge = 1;
+        else if (gy < 0 && gx < 0)
+            n = d, k = 3;
+        else if (gy < 0 && gx == 4)
+            n = c, k = 0;
+        if (n) {
+            int inter = MB_IS_INTER(n->type);
+            if (!(cip && inter)) ipm = (n->type == MBT_I4x4 || n->type == MBT_I8x8) ? n->ipm[k] : static_cast<int8_t>(2);
+            if (edge) nnz = n->nnz[k];
+            if (inter) {
+                ref = n->ref[k >> 1];
+                mvx = n->mv[k][0], mvy = n->mv[k][1];
+                mvdx = n->mvd[k][0], mvdy = n->mvd[k][1];
+            } else
+                ref = -1;
+        }
+        if (gx >= 0 && gx < 4 && gy >= 0) { // interior: current MB, nothing decoded yet
+            nnz = 0;
+            ipm = -1;
+        }
+        coded = (nnz & 0x80) ? 2 : (nnz != 0);
+        s->ipm_c[l] = ipm;
+        e.v_ipm = ipm;
+        s->nnz_c[l] = nnz;
+        s->ref_c[l] = ref;
+        s->refi_c[l] = ref;
+        s->mv_c[l][0] = mvx, s->mv_c[l][1] = mvy;
+        s->mvd_c[l][0] = mvdx, s->mvd_c[l][1] = mvdy;
+    } else if (l >= 32 && l < 50) {
+        int i = l - 32, cpl = i / 9, g = i % 9, gx = g % 3 - 1, gy = g / 3 - 1;
+        uint8_t v = 0x80;
+        if (gy < 0 && gx >= 0) {
+            if (b) v = b->nnz[4 + cpl * 2 + gx];
+        } else if (gx < 0 && gy >= 0) {
+            if (a) v = a->nnz[4 + cpl * 2 + gy];
+        } else if (gx >= 0 && gy >= 0)
+            v = 0;
+        coded = (v & 0x80) ? 2 : (v != 0);
+        s->nnzc_c[cpl][g] = v;
+    } else if (l >= 50 && l < 56) { // DC coded_block_flags of the left (50..52) / upper (53..55) macroblock: Intra16x16 luma, Cb, Cr
+        const TopInfo *n = l < 53 ? a : b;
+        coded = n ? (n->cbf_dc >> ((l - 50) % 3)) & 1 : 2;
+    } else if (l >= 56 && l < 60) {
+        s->refs8[l - 56] = -1;
+        s->sub_type[l - 56] = 0;
+    } else if (l == 60)
+        s->cur_cbf_dc = 0;
+    e.nzm = __builtin_amdgcn_ballot_w64(coded == 1);
+    e.unm = __builtin_amdgcn_ballot_w64(coded == 2);
+    e.aw = RFL(*reinterpret_cast<const uint32_t *>(&s->left)), e.bw = RFL(*reinterpret_cast<const uint32_t *>(&s->topw[0]));
+    { // zero the coefficient staging block: 416 int16 = 208 dwords
+        uint32_t *cz = reinterpret_cast<uint32_t *>(s->coef);
+        for (int i = l; i < MI_COEF_PER_MB / 2; i += 64) cz[i] = 0;
+    }
+    LDS_SYNC();
+}
+
+// ------------------------------------------------------------------ macroblock_layer() 7.3.5
+FI void decode_mb(Ent &e, int skipped) {
+    Shared *s = e.s;
+    MbRec &r = s->rec;
+    const int cabac = e.cabac, islice = e.islice;
+    int cbp_luma = 0, cbp_chroma = 0, t8x8 = 0, i16mode = 0, chroma_mode = 0, has_coef = 0;
+    int type, raw = 0, nparts = 0;
+    const Nb a{e.aw}, b{e.bw};
+    r.nzmask = 0;
+    if (skipped) {
+        type = MBT_PSKIP;
+        e.cur_type = type;
+        int mvx = 0, mvy = 0; // 8.4.1.1
+        int ra = s->ref_c[GI(-1, 0)], rb = s->ref_c[GI(0, -1)];
+        bool zero = ra == -2 || rb == -2 || (ra == 0 && s->mv_c[GI(-1, 0)][0] == 0 && s->mv_c[GI(-1, 0)][1] == 0) ||
+                    (rb == 0 && s->mv_c[GI(0, -1)][0] == 0 && s->mv_c[GI(0, -1)][1] == 0);
+        if (!zero) predict_mv(e, 0, 0, 4, 0, 0, mvx, mvy);
+        set_part(e, 0, 0, 4, 4, 0, mvx, mvy, 0, 0);
+        s->refs8[0] = s->refs8[1] = s->refs8[2] = s->refs8[3] = 0;
+        e.prev_dqp_nz = 0;
+    } else {
+        // ---- mb_type (Tables 9-36 / 9-37) ----
+        int intra_prefix = 1; // in P slices: bin 0 of mb_type says "intra"
+        if (cabac) {
+            if (!islice) {
+                intra_prefix = BINI_A(e, 14);
+                if (!intra_prefix) raw = BIN_A(e, 15) ? 2 - BINI_A(e, 17) : 3 * BINI_A(e, 16);
+            }
+            if (intra_prefix) {
+                // I-slice bin string; `base` 3 with neighbour-dependent first bin, or the suffix at 17
+                int base = islice ? 3 : 17, it = 0, first;
+                if (islice) {
+                    int inc = (a.ok() && a.type() != MBT_I4x4 && a.type() != MBT_I8x8) + (b.ok() && b.type() != MBT_I4x4 && b.type() != MBT_I8x8);
+                    first = BINI_A(e, base + inc);
+                    base += 2;
+                } else
+                    first = BINI_A(e, base);
+                if (first) {
+                    if (cabac_terminate(e))
+                        it = 25;
+                    else {
+                        it = 1 + 12 * BINI_A(e, base + 1);
+                        if (BIN_A(e, base + 2)) it += 4 + 4 * BINI_A(e, base + 2 + islice);
+                        it += 2 * BINI_A(e, base + 3 + islice);
+                        it += BINI_A(e, base + 3 + 2 * islice);
+                    }
+                }
+                raw = islice ? it : it + 5;
+            }
+        } else
+            raw = static_cast<int>(get_ue(e));
+        const int it = islice ? raw : raw - 5;
+        if (!islice && raw < 5)
+            type = raw == 0 ? MBT_P16x16 : (raw == 1 ? MBT_P16x8 : (raw == 2 ? MBT_P8x16 : MBT_P8x8));
+        else if (it == 0)
+            type = MBT_I4x4;
+        else if (it >= 1 && it <= 24) {
+            type = MBT_I16x16;
+            i16mode = (it - 1) & 3;
+            cbp_chroma = ((it - 1) >> 2) % 3;
+            cbp_luma = it >= 13 ? 15 : 0;
+        } else if (it == 25)
+            type = MBT_IPCM;
+        else {
+            e.err = 20;
+            type = MBT_I4x4;
+        }
+        e.cur_type = type;
+        if (type == MBT_IPCM) {
+            // after the terminate bin the arithmetic decoder has consumed exactly what the encoder's
+            // flush wrote (9.3.1.2 / 9.3.4.5): stream position = bits fetched - lookahead
+            uint32_t pos = bitpos(e);
+            if (cabac) pos -= static_cast<uint32_t>(RFL(e.avail));
+            seek(e, (pos + 7) & ~7u);
+            uint32_t *pcm = reinterpret_cast<uint32_t *>(s->coef);
+            for (int i = 0; i < 96; i++) pcm[i] = __builtin_bswap32(get_bits(e, 32)); // 384 sample bytes in stream order
+            if (cabac) cabac_start(e);
+            for (int i = 0; i < 16; i++) s->nnz_c[GI(i & 3, i >> 2)] = 16, s->ref_c[GI(i & 3, i >> 2)] = -1;
+            for (int i = 0; i < 8; i++) s->nnzc_c[i >> 2][(((i >> 1) & 1) + 1) * 3 + (i & 1) + 1] = 16;
+            s->cur_cbf_dc = 7;
+            r.nzmask = 0xFFFF;
+            cbp_luma = 15, cbp_chroma = 2;
+            has_coef = 1;
+            e.prev_dqp_nz = 0;
+        } else {
+            if (MB_IS_INTER(type)) {
+                // ---- partition schedule (Tables 7-13, 7-17) ----
+                int nref_parts;
+                if (type == MBT_P16x16) {
+                    s->parts[0] = PART(0, 0, 4, 4, 0);
+                    nparts = nref_parts = 1;
+                } else if (type == MBT_P16x8) {
+                    s->parts[0] = PART(0, 0, 4, 2, 1), s->parts[1] = PART(0, 2, 4, 2, 2);
+                    nparts = nref_parts = 2;
+                } else if (type == MBT_P8x16) {
+                    s->parts[0] = PART(0, 0, 2, 4, 3), s->parts[1] = PART(2, 0, 2, 4, 4);
+                    nparts = nref_parts = 2;
+                } else {
+                    nref_parts = 4;
+                    for (int i = 0; i < 4; i++) {
+                        int st;
+                        if (cabac) // Table 9-38
+                            st = BIN_A(e, 21) ? 0 : (!BIN_A(e, 22) ? 1 : (BIN_A(e, 23) ? 2 : 3));
+                        else
+                            st = static_cast<int>(get_ue(e));
+                        if (st > 3) e.err = 21, st = 0;
+                        s->sub_type[i] = static_cast<int8_t>(st);
+                        const int bx = (i & 1) * 2, by = (i >> 1) * 2;
+                        const int sw = (st == 0 || st == 1) ? 2 : 1, sh = (st == 0 || st == 2) ? 2 : 1;
+                        for (int yy = 0; yy < 2; yy += sh)
+                            for (int xx = 0; xx < 2; xx += sw) s->parts[nparts++] = PART(bx + xx, by + yy, sw, sh, 0);
+                    }
+                }
+                // ---- ref_idx_l0 per macroblock partition (7.3.5.1 / 7.3.5.2) ----
+                const int nref = e.nref;
+                for (int i = 0; i < nref_parts; i++) {
+                    int bx, by, w, h;
+                    if (type == MBT_P8x8)
+                        bx = (i & 1) * 2, by = (i >> 1) * 2, w = 2, h = 2;
+                    else {
+                        const int p = s->parts[i];
+                        bx = p & 3, by = (p >> 2) & 3, w = ((p >> 4) & 3) + 1, h = ((p >> 6) & 3) + 1;
+                    }
+                    int ref = 0;
+                    if (nref > 1 && raw != 4) {
+                        if (cabac) { // 9.3.3.1.1.6
+                            int ctx = (s->refi_c[GI(bx - 1, by)] > 0) + 2 * (s->refi_c[GI(bx, by - 1)] > 0);
+                            while (BIN_A(e, 54 + ctx)) {
+                                ctx = (ctx >> 2) + 4;
+                                if (++ref > 31) {
+                                    e.err = 3;
+                                    break;
+                                }
+                            }
+                        } else
+                            ref = nref == 2 ? !get_bit(e) : static_cast<int>(get_ue(e));
+                        if (ref >= nref || ref >= MI_MAX_REFS) e.err = 13, ref = 0;
+                    }
+                    { // one 4x4 block per lane: ref_idx cache for the ctxIdxInc of later partitions, and the per-8x8 list
+                        const int l = LANE, x = l & 3, y = (l >> 2) & 3;
+                        if (l < 16 && x >= bx && x < bx + w && y >= by && y < by + h) {
+                            s->refi_c[GI(x, y)] = static_cast<int8_t>(ref);
+                            if (!((x | y) & 1)) s->refs8[(y >> 1) * 2 + (x >> 1)] = static_cast<int8_t>(ref);
+                        }
+                        LDS_SYNC();
+                    }
+                }
+                // ---- mvd_l0 + prediction per (sub-)partition ----
+                for (int i = 0; i < nparts; i++) {
+                    const int p = s->parts[i];
+                    const int bx = p & 3, by = (p >> 2) & 3, w = ((p >> 4) & 3) + 1, h = ((p >> 6) & 3) + 1, shape = p >> 8;
+                    const int ref = s->refs8[(by >> 1) * 2 + (bx >> 1)];
+                    int d[2];
+                    for (int comp = 0; comp < 2; comp++) {
+                        int v;
+                        if (cabac) { // UEG3, uCoff 9, signed (9.3.2.3, 9.3.3.1.1.7)
+                            const int sum = s->mvd_c[GI(bx - 1, by)][comp] + s->mvd_c[GI(bx, by - 1)][comp];
+                            const int base = comp ? 47 : 40;
+                            v = 0;
+                            if (BIN_A(e, base + (sum > 2) + (sum > 32))) {
+                                int ctx = base + 3;
+                                v = 1;
+                                while (v < 9 && BIN_A(e, ctx)) {
+                                    if (v < 4) ctx++;
+                                    v++;
+                                }
+                                if (v >= 9) v += cabac_egk(e, 3);
+                                if (cabac_bypass(e)) v = -v;
+                            }
+                        } else
+                            v = get_se(e);
+                        d[comp] = v;
+                    }
+                    int px, py;
+                    predict_mv(e, bx, by, w, ref, shape, px, py);
+                    set_part(e, bx, by, w, h, ref, px + d[0], py + d[1], d[0], d[1]);
+                }
+            } else {
+                // ---- intra: transform_size_8x8_flag, prediction modes, intra_chroma_pred_mode ----
+                if (type == MBT_I4x4 && e.t8x8_mode) {
+                    t8x8 = cabac ? BINI_T8(e, (a.ok() && a.t8x8()) + (b.ok() && b.t8x8())) : static_cast<int>(get_bit(e));
+                    if (t8x8) type = MBT_I8x8, e.cur_type = type;
+                }
+                if (type == MBT_I4x4 || type == MBT_I8x8) {
+                    const int n = type == MBT_I8x8 ? 4 : 16;
+                    for (int i = 0; i < n; i++) {
+                        int bx, by;
+                        if (n == 4)
+                            bx = (i & 1) * 2, by = (i >> 1) * 2;
+                        else
+                            bx = (i & 1) + 2 * ((i >> 2) & 1), by = ((i >> 1) & 1) + 2 * (i >> 3);
+                        const int pa = static_cast<int>(RDL(e.v_ipm, GI(bx - 1, by))), pb = static_cast<int>(RDL(e.v_ipm, GI(bx, by - 1)));
+                        const int pred = (pa < -1 || pb < -1) ? 2 : (pa < pb ? pa : pb); // 8.3.1.1: dcPredModePredictedFlag
+                        int mode = pred;
+                        if (cabac) {
+                            if (!BIN_B(e, 68)) {
+                                int rem = 0;
+                                for (int k = 0; k < 3; k++) rem |= BINI_B(e, 69) << k;
+                                mode = rem < pred ? rem : rem + 1;
+                            }
+                        } else if (!get_bit(e)) {
+                            int rem = static_cast<int>(get_bits(e, 3));
+                            mode = rem < pred ? rem : rem + 1;
+                        }
+                        const int g = GI(bx, by), d = LANE - g;
+                        e.v_ipm = (d == 0 || (n == 4 && (d == 1 || d == 6 || d == 7))) ? mode : e.v_ipm;
+                    }
+                    if (LANE < 30) s->ipm_c[LANE] = static_cast<int8_t>(e.v_ipm); // for the record / neighbour write-out
+                }
+                if (cabac) {
+                    int inc = (a.ok() && MB_IS_INTRA(a.type()) && a.type() != MBT_IPCM && a.chroma_mode() != 0) +
+                              (b.ok() && MB_IS_INTRA(b.type()) && b.type() != MBT_IPCM && b.chroma_mode() != 0);
+                    chroma_mode = 0;
+                    if (BIN_B(e, 64 + inc)) {
+                        chroma_mode = 1;
+                        while (chroma_mode < 3 && BIN_B(e, 67)) chroma_mode++;
+                    }
+                } else {
+                    chroma_mode = static_cast<int>(get_ue(e));
+                    if (chroma_mode > 3) e.err = 22, chroma_mode = 0;
+                }
+                if (LANE < 16) s->ref_c[GI(LANE & 3, LANE >> 2)] = -1;
+            }
+            // ---- coded_block_pattern ----
+            if (type != MBT_I16x16) {
+                int cbp;
+                if (cabac) { // 9.3.3.1.1.4
+                    const int cbp_a = a.ok() ? (a.type() == MBT_IPCM ? 0x2F : a.cbp()) : 0x0F;
+                    const int cbp_b = b.ok() ? (b.type() == MBT_IPCM ? 0x2F : b.cbp()) : 0x0F;
+                    cbp = 0;
+                    for (int b8 = 0; b8 < 4; b8++) {
+                        int ca = (b8 & 1) ? (cbp >> (b8 - 1)) & 1 : (cbp_a >> (b8 + 1)) & 1;
+                        int cb = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cbp_b >> (b8 + 2)) & 1;
+                        cbp |= BINI_B(e, 73 + (!ca) + 2 * (!cb)) << b8;
+                    }
+                    int ca = a.ok() && (a.type() == MBT_IPCM || (a.cbp() >> 4) != 0), cb = b.ok() && (b.type() == MBT_IPCM || (b.cbp() >> 4) != 0);
+                    if (BIN_B(e, 77 + ca + 2 * cb)) {
+                        ca = a.ok() && (a.type() == MBT_IPCM || (a.cbp() >> 4) == 2);
+                        cb = b.ok() && (b.type() == MBT_IPCM || (b.cbp() >> 4) == 2);
+                        cbp |= (1 + BINI_B(e, 77 + 4 + ca + 2 * cb)) << 4;
+                    }
+                } else {
+                    uint32_t k = get_ue(e);
+                    if (k > 47) e.err = 23, k = 0;
+                    cbp = RFL(static_cast<int>(MB_IS_INTRA(type) ? e.tab->me_intra[k] : e.tab->me_inter[k]));
+                }
+                cbp_luma = cbp & 15, cbp_chroma = cbp >> 4;
+                if (cbp_luma && e.t8x8_mode && MB_IS_INTER(type)) {
+                    int all8 = 1;
+                    if (type == MBT_P8x8)
+                        for (int i = 0; i < 4; i++) all8 &= s->sub_type[i] == 0;
+                    if (all8) t8x8 = cabac ? BINI_T8(e, (a.ok() && a.t8x8()) + (b.ok() && b.t8x8())) : static_cast<int>(get_bit(e));
+                }
+            }
+            // ---- mb_qp_delta + residual ----
+            if (cbp_luma || cbp_chroma || type == MBT_I16x16) {
+                int dqp;
+                if (cabac) { // 9.3.2.7 / 9.3.3.1.1.5
+                    int ctx = e.prev_dqp_nz ? 1 : 0, val = 0;
+                    while (BIN_A(e, 60 + ctx)) {
+                        ctx = 2 + (ctx >> 1);
+                        if (++val > 104) {
+                            e.err = 2;
+                            break;
+                        }
+                    }
+                    dqp = (val & 1) ? (val + 1) >> 1 : -((val + 1) >> 1);
+                } else
+                    dqp = get_se(e);
+                if (dqp < -26 || dqp > 25) e.err = 24, dqp = 0;
+                e.prev_dqp_nz = dqp != 0;
+                e.qp = (e.qp + dqp + 52) % 52;
+                MI_T(e, 1);
+                MI_R0(e);
+                if (cabac)
+                    parse_residual_cabac(e, cbp_luma, cbp_chroma, t8x8);
+                else
+                    parse_residual_cavlc(e, cbp_luma, cbp_chroma, t8x8);
+                MI_R(e, 3);
+                MI_T(e, 2);
+                has_coef = 1;
+            } else
+                e.prev_dqp_nz = 0;
+        }
+    }
+    MI_T(e, 1);
+    // ---- scalar fields of the record ----
+    const int qp_store = type == MBT_IPCM ? 0 : e.qp;
+    r.type = static_cast<uint8_t>(type);
+    r.t8x8 = static_cast<uint8_t>(t8x8);
+    r.qp = static_cast<uint8_t>(qp_store);
+    r.qpc[0] = static_cast<uint8_t>(RDL(e.v_qpc, min(max(qp_store + e.cqp_off0, 0), 51)));
+    r.qpc[1] = static_cast<uint8_t>(RDL(e.v_qpc, min(max(qp_store + e.cqp_off1, 0), 51)));
+    r.cbp = static_cast<uint8_t>(cbp_luma | (cbp_chroma << 4));
+    r.chroma_mode = static_cast<uint8_t>(chroma_mode);
+    r.i16mode = static_cast<uint8_t>(i16mode);
+    {
+        // neighbour availability for intra prediction (6.4.x; constrained_intra_pred 8.3.1.2)
+        const int cip = e.cip;
+        int av = 0;
+        const TopInfo *c = mbC(e);
+        const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
+        if (a.ok() && !(cip && MB_IS_INTER(a.type()))) av |= MI_AV_LEFT;
+        if (b.ok() && !(cip && MB_IS_INTER(b.type()))) av |= MI_AV_TOP;
+        if (d && !(cip && MB_IS_INTER(d->type))) av |= MI_AV_TOPLEFT;
+        if (c && !(cip && MB_IS_INTER(c->type))) av |= MI_AV_TOPRIGHT;
+        r.avail = static_cast<uint8_t>(av);
+    }
+    // dbf_idc / alpha_off / beta_off / slice_in_pic / slice_idx of the record are slice constants, written once at slice start
+    LDS_SYNC();
+    // ---- parallel part: per-block arrays of the record, write-out, neighbour state update ----
+    const int l = LANE;
+    const int inter = MB_IS_INTER(type);
+    if (l < 16) {
+        int g = GI(l & 3, l >> 2);
+        r.ipm[l] = s->ipm_c[g];
+        r.mv[l][0] = inter ? s->mv_c[g][0] : static_cast<int16_t>(0);
+        r.mv[l][1] = inter ? s->mv_c[g][1] : static_cast<int16_t>(0);
+    } else if (l < 20) {
+        int i = l - 16, ref = inter ? s->refs8[i] : -1;
+        r.ref[i] = static_cast<int8_t>(ref);
+        r.refslot[i] = ref >= 0 ? s->ref_slot[ref & (MI_MAX_REFS - 1)] : static_cast<int16_t>(-1);
+    }
+    // remember the row-above entry of this column for the next MB's top-left neighbour, then build the new one
+    TopInfo *tp = &s->topw[0];
+    if (l >= 32 && l < 44) reinterpret_cast<uint32_t *>(&s->tl)[l - 32] = reinterpret_cast<const uint32_t *>(tp)[l - 32];
+    LDS_SYNC();
+    if (l < 2) {
+        TopInfo *dst = l == 0 ? tp : &s->left;
+        dst->type = static_cast<uint8_t>(type);
+        dst->t8x8 = static_cast<uint8_t>(t8x8);
+        dst->cbp = r.cbp;
+        dst->chroma_mode = static_cast<uint8_t>(chroma_mode);
+        dst->cbf_dc = s->cur_cbf_dc;
+        dst->ref[0] = inter ? s->refs8[l == 0 ? 2 : 1] : static_cast<int8_t>(-1);
+        dst->ref[1] = inter ? s->refs8[3] : static_cast<int8_t>(-1);
+    } else if (l >= 8 && l < 16) {
+        // edge arrays: lanes 8..11 -> top (bottom row), 12..15 -> left (right column)
+        int k = l & 3, is_left = l >= 12;
+        TopInfo *dst = is_left ? &s->left : tp;
+        int g = is_left ? GI(3, k) : GI(k, 3);
+        dst->ipm[k] = s->ipm_c[g];
+        dst->nnz[k] = s->nnz_c[g];
+        dst->mv[k][0] = s->mv_c[g][0], dst->mv[k][1] = s->mv_c[g][1];
+        dst->mvd[k][0] = s->mvd_c[g][0], dst->mvd[k][1] = s->mvd_c[g][1];
+    } else if (l >= 16 && l < 24) {
+        // chroma nnz edges: [plane][k]
+        int i = l - 16, is_left = i >= 4, cpl = (i >> 1) & 1, k = i & 1;
+        TopInfo *dst = is_left ? &s->left : tp;
+        dst->nnz[4 + cpl * 2 + k] = is_left ? s->nnzc_c[cpl][(k + 1) * 3 + 2] : s->nnzc_c[cpl][2 * 3 + k + 1];
+    }
+    LDS_SYNC();
+    // new entry -> HBM row; slide the LDS window: [0] <- [1], [1] <- prefetched column x+2; prefetch x+3
+    if (l < 12) {
+        const uint32_t nw = reinterpret_cast<const uint32_t *>(tp)[l], w1 = reinterpret_cast<const uint32_t *>(&s->topw[1])[l];
+        reinterpret_cast<uint32_t *>(e.top + e.mbx)[l] = nw;
+        reinterpret_cast<uint32_t *>(&s->topw[0])[l] = w1;
+        reinterpret_cast<uint32_t *>(&s->topw[1])[l] = e.pre_top;
+        e.pre_top = top_load(e, e.mbx + 3, l);
+    }
+    const uint64_t mbi = e.mb_base + static_cast<uint64_t>(e.mby) * e.wmb + e.mbx;
+    if (l >= 32) // MbRec: 128 bytes = 32 dwords, lanes 32..63
+        reinterpret_cast<uint32_t *>(e.mbrec + mbi)[l - 32] = reinterpret_cast<const uint32_t *>(&r)[l - 32];
+    if (has_coef) { // 832 bytes = 52 x 16 B
+        if (l < MI_COEF_PER_MB * 2 / 16) reinterpret_cast<uint4 *>(e.coefs + mbi * MI_COEF_PER_MB)[l] = reinterpret_cast<const uint4 *>(s->coef)[l];
+    }
+    LDS_SYNC();
+}
+
+// ------------------------------------------------------------------ kernel: slice_data() 7.3.4
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI_ENT_MINWAVES, 8))) k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
+                                                           int16_t *coefs, uint32_t *status, uint32_t *toprows, int wmb_max) {
+    __shared__ Shared sh;
+    const uint64_t t_begin = wall_clock64();
+    Ent e;
+    e.s = &sh;
+#if MI_ENT_STATS
+    e.bins = 0;
+    for (int k = 0; k < 4; k++) e.tacc[k] = 0;
+#endif
+    e.top = reinterpret_cast<TopInfo *>(toprows + static_cast<size_t>(blockIdx.x) * wmb_max * 12);
+    e.pre_top = 0;
+    e.tab = tab;
+    const SliceDesc *sd = &slices[blockIdx.x];
+    const PicDesc *pd = &pics[sd->pic_idx];
+    e.sd = sd, e.pd = pd;
+    e.rbsp32 = reinterpret_cast<const uint32_t *>(bitstream + sd->rbsp_off); // slices are 16-byte aligned in the staging buffer
+    e.rbsp_words = RFL((sd->rbsp_size + 3) >> 2);
+    e.mbrec = mbrec;
+    e.coefs = coefs;
+    e.err = 0;
+    e.cabac = RFL(static_cast<int>(pd->cabac));
+    e.islice = RFL(static_cast<int>(sd->slice_type == 2));
+    e.wmb = RFL(static_cast<int>(pd->wmb)), e.hmb = RFL(static_cast<int>(pd->hmb));
+    e.qp = RFL(static_cast<int>(sd->slice_qp));
+    e.cip = RFL(static_cast<int>(pd->cip)), e.t8x8_mode = RFL(static_cast<int>(pd->t8x8_mode));
+    e.cqp_off0 = RFL(static_cast<int>(pd->cqp_off[0])), e.cqp_off1 = RFL(static_cast<int>(pd->cqp_off[1]));
+    e.nref = RFL(static_cast<int>(sd->num_ref_idx_active));
+    e.mb_base = (static_cast<uint64_t>(RFL(static_cast<uint32_t>(pd->mb_base >> 32))) << 32) | RFL(static_cast<uint32_t>(pd->mb_base));
+    e.prev_dqp_nz = 0;
+    e.range = 510, e.value = 0, e.avail = 0;
+    e.mbx = e.mby = 0, e.cur_type = 0;
+    const int l = LANE;
+    // ---- per-lane tables ----
+    { // Tables 9-44 / 9-45: lane p keeps the entries of pStateIdx p; the transition entry is the complete next state
+      // (pStateIdx << 1 | valMPS) after an LPS for valMPS 0 -- XOR with valMPS gives the other one (pStateIdx 0 flips the MPS)
+        const uint8_t *rl = tab->range_lps[l];
+        e.v_rlps = rl[0] | (rl[1] << 8) | (rl[2] << 16) | (static_cast<uint32_t>(rl[3]) << 24);
+        e.v_trans = (static_cast<uint32_t>(tab->trans_lps[l]) << 1) | (l == 0 ? 1u : 0u);
+    }
+    e.v_maps = tab->sig8x8[l] | (tab->last8x8[l] << 8) | (tab->zigzag8[l] << 16) | (static_cast<uint32_t>(tab->zigzag4[l & 15]) << 24);
+    e.v_zzac = tab->zigzag4[(l + 1) & 15];
+    e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l);
+    e.v_qpc = tab->qpc[l < 52 ? l : 51];
+    e.v_step = step_word(l);
+    e.nzm = e.unm = 0;
+    e.aw = e.bw = 0;
+    e.v_ipm = 0;
+    sh.posmap[0][l] = tab->zigzag4[l & 15];
+    sh.posmap[1][l] = tab->zigzag4[(l + 1) & 15];
+    sh.posmap[2][l] = tab->zigzag8[l];
+    sh.posmap[3][l] = static_cast<uint8_t>(l);
+    if (l < MI_MAX_REFS) sh.ref_slot[l] = sd->ref_slot[l];
+    { // context variables 9.3.1.1: macroblock-level states into the two VGPRs, residual states into LDS
+        const int set = e.islice ? 0 : 1 + sd->cabac_init_idc;
+        const uint8_t *src = tab->ctx_init[set][sd->slice_qp];
+        e.ca = src[l];
+        e.cb = src[l < 61 ? 64 + l : 399 + (l - 61)];
+        e.wk = 0;
+        for (int i = l; i < 464; i += 64) sh.ctx[i] = src[i];
+    }
+    if (l < 32) reinterpret_cast<uint32_t *>(&sh.rec)[l] = 0;
+    LDS_SYNC();
+    if (l == 0) { // slice constants of every MbRec
+        sh.rec.dbf_idc = sd->dbf_idc;
+        sh.rec.alpha_off = sd->alpha_off, sh.rec.beta_off = sd->beta_off;
+        sh.rec.slice_in_pic = sd->slice_in_pic;
+        sh.rec.slice_idx = blockIdx.x;
+    }
+    for (int i = l; i < e.wmb * 12; i += 64) reinterpret_cast<uint32_t *>(e.top)[i] = 0; // all row-above entries: type NONE
+    if (l < 12) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
+    if (l < 24) reinterpret_cast<uint32_t *>(&sh.topw[0])[l] = 0;
+    LDS_SYNC();
+    {
+        uint32_t pos = RFL(sd->data_bit_off);
+        if (e.cabac) pos = (pos + 7) & ~7u; // cabac_alignment_one_bit
+        e.wbase = 0x80000000u; // force the window load
+        seek(e, pos);
+        if (e.cabac) cabac_start(e);
+    }
+    const int total = e.wmb * e.hmb;
+    const uint32_t stop_bit = RFL(sd->stop_bit);
+    int addr = RFL(static_cast<int>(sd->first_mb));
+    e.mbx = addr % e.wmb, e.mby = addr / e.wmb;
+    int more = 1, skip_state = 0 /* 0: read mb_skip_run, 1: inside a run, 2: coded MB follows a run */, pending = 0;
+    int n_mbs = 0;
+    while (more && !e.err) {
+        if (addr >= total) {
+            e.err = 30;
+            break;
+        }
+        if (e.mbx == 0 || n_mbs == 0) { // new MB row (or slice start): no left / top-left neighbour; (re)load the row-above window
+            if (l < 12) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stores of the previous row to e.top[] have been issued to L2
+            if (l < 24) reinterpret_cast<uint32_t *>(&sh.topw[0])[l] = top_load(e, e.mbx + l / 12, l % 12);
+            if (l < 12) e.pre_top = top_load(e, e.mbx + 2, l);
+            LDS_SYNC();
+        }
+        slide_window(e);
+        MI_T0(e);
+        fill_caches(e);
+        MI_T(e, 0);
+        int skipped = 0;
+        if (!e.islice) {
+            if (e.cabac) {
+                const Nb a{e.aw}, b{e.bw};
+                skipped = BINI_A(e, 11 + (a.ok() && a.type() != MBT_PSKIP) + (b.ok() && b.type() != MBT_PSKIP));
+            } else {
+                if (skip_state == 0) {
+                    pending = static_cast<int>(get_ue(e));
+                    if (pending > total - addr) e.err = 31, pending = 0;
+                    if (pending > 0) skip_state = 1;
+                }
+                if (skip_state == 1) {
+                    skipped = 1;
+                    pending--;
+                }
+            }
+        }
+        decode_mb(e, skipped);
+        MI_T(e, 3);
+        n_mbs++;
+        if (e.cabac)
+            more = !cabac_terminate(e);
+        else if (skipped) {
+            if (pending == 0) {
+                more = bitpos(e) < stop_bit;
+                skip_state = 2;
+            }
+        } else {
+            more = bitpos(e) < stop_bit;
+            skip_state = 0;
+        }
+        addr++;
+        if (++e.mbx == e.wmb) e.mbx = 0, e.mby++;
+    }
+    if (l == 0) {
+        status[8 * blockIdx.x] = static_cast<uint32_t>(e.err);
+        status[8 * blockIdx.x + 1] = static_cast<uint32_t>(n_mbs);
+        status[8 * blockIdx.x + 2] = static_cast<uint32_t>(wall_clock64() - t_begin);
+        status[8 * blockIdx.x + 3] = MI_BINS(e);
+#if MI_ENT_STATS
+        for (int k = 0; k < 4; k++) status[8 * blockIdx.x + 4 + k] = static_cast<uint32_t>(e.tacc[k] >> 4); // shader clocks / 16
+#endif
+    }
+}
