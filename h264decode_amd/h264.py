@@ -215,6 +215,7 @@ class Decoder:
         n, bufs, lens = self._args(streams)
         info = _lib.BatchInfo()
         check(self._L.h264mi_batch_prepare(self._h, n, bufs, lens, ctypes.byref(info)))
+        self.info = info
         return info
 
     def execute(self):
@@ -261,3 +262,147 @@ class Decoder:
         buf = np.zeros(n_mbs * 128, dtype=np.uint8)
         check(self._L.h264mi_frame_read_mbrecs(self._h, stream, frame, buf.ctypes.data, buf.nbytes))
         return buf.reshape(n_mbs, 128)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Stream front-end: the reference's ByteStreamReader / handleConnection / readNalUnit
+# (h264/server.go:64-172) read an endless Annex-B byte stream from a connection one byte at a time.
+# Here the bytes are cut at access-unit boundaries and handed to the batched GPU decoder.
+
+class AccessUnitSplitter:
+    """Incremental Annex-B splitter: feed() arbitrary byte chunks, get back byte strings that end on an
+    access-unit boundary (7.4.1.2.3/4, simplified: a new access unit starts at an access unit delimiter, at an
+    SPS / PPS / SEI that follows a slice, or at a slice with first_mb_in_slice == 0).  3- and 4-byte start
+    codes are accepted (Annex B.1); the tail that may still grow is held back until flush()."""
+
+    def __init__(self, max_units_per_chunk=30):
+        self._buf = bytearray()
+        self._max = max(1, int(max_units_per_chunk))
+
+    @staticmethod
+    def _nal_starts(buf):
+        """offsets of the first start-code byte of every NAL unit"""
+        out, i, n = [], 0, len(buf)
+        while True:
+            j = buf.find(b"\x00\x00\x01", i)
+            if j < 0:
+                return out
+            out.append(j - 1 if j > 0 and buf[j - 1] == 0 else j)
+            i = j + 3
+
+    def _boundaries(self, final):
+        """offsets at which a new access unit starts (excluding 0), in order"""
+        buf = self._buf
+        starts = self._nal_starts(buf)
+        cuts, seen_vcl = [], False
+        for k, off in enumerate(starts):
+            j = buf.find(b"\x00\x00\x01", off) + 3
+            if j >= len(buf):
+                break  # header byte not here yet
+            t = buf[j] & 31
+            if t in (1, 5):
+                if j + 1 >= len(buf) and not final:
+                    break
+                first_mb_zero = j + 1 < len(buf) and (buf[j + 1] & 0x80) != 0  # ue(v) == 0 <=> leading 1 bit
+                if first_mb_zero and seen_vcl:
+                    cuts.append(off)
+                seen_vcl = True
+            elif t in (6, 7, 8, 9) and seen_vcl:
+                cuts.append(off)
+                seen_vcl = False
+            elif t in (10, 11) and seen_vcl:  # end of sequence / stream belong to the access unit they follow
+                nxt = starts[k + 1] if k + 1 < len(starts) else None
+                if nxt is not None:
+                    cuts.append(nxt)
+                    seen_vcl = False
+        # de-duplicate while keeping order
+        out = []
+        for c in cuts:
+            if c > 0 and (not out or c > out[-1]):
+                out.append(c)
+        return out
+
+    def feed(self, data: bytes):
+        """Append bytes; returns a list of chunks, each holding whole access units (at most max_units_per_chunk)."""
+        self._buf += data
+        return self._emit(False)
+
+    def flush(self):
+        """End of stream: everything that is left is the last access unit(s)."""
+        return self._emit(True)
+
+    def _emit(self, final):
+        cuts = self._boundaries(final)
+        if final:
+            cuts = cuts + [len(self._buf)]
+        chunks, prev, k = [], 0, 0
+        while k < len(cuts):
+            take = min(self._max, len(cuts) - k)
+            end = cuts[k + take - 1]
+            if end > prev:
+                chunks.append(bytes(self._buf[prev:end]))
+            prev, k = end, k + take
+        del self._buf[:prev]
+        return chunks
+
+
+class H264Reader:
+    """Mirror of the reference's H264Reader + handleConnection loop (h264/server.go:113-166): reads a connection
+    (anything with recv() or read()), cuts the byte stream at access units and decodes them on the GPU.
+    `on_frames(frames)` receives uint8[n, width*height*3/2] arrays (cropped I420) in decoding order."""
+
+    def __init__(self, connection, decoder=None, on_frames=None, max_width=1920, max_height=1088, frames_per_batch=30, read_size=1 << 16):
+        self.Stream = connection
+        self.frames_per_batch = frames_per_batch
+        self.decoder = decoder or Decoder(max_streams=1, max_width=(max_width + 15) // 16 * 16, max_height=(max_height + 15) // 16 * 16,
+                                          max_frames_per_batch=frames_per_batch, max_slices_per_frame=16)
+        self.on_frames = on_frames
+        self.read_size = read_size
+        self.splitter = AccessUnitSplitter(frames_per_batch)
+        self.n_frames = 0
+        self._dims = (0, 0)
+
+    def _read(self):
+        s = self.Stream
+        return s.recv(self.read_size) if hasattr(s, "recv") else s.read(self.read_size)
+
+    def _decode(self, chunks):
+        for c in chunks:
+            self.decoder.decode([c])
+            n = self.decoder.frame_count(0)
+            if n:
+                frames = np.stack([self.decoder.read_frame(0, f, crop=True)[:self._size()] for f in range(n)])
+                self.n_frames += n
+                if self.on_frames:
+                    self.on_frames(frames)
+
+    def _size(self):
+        info = self.decoder.info
+        if info.width and info.height:
+            self._dims = (info.width, info.height)
+        return self._dims[0] * self._dims[1] * 3 // 2
+
+    def run(self):
+        """Read until the peer closes the connection; returns the number of decoded frames."""
+        while True:
+            data = self._read()
+            if not data:
+                break
+            self._decode(self.splitter.feed(data))
+        self._decode(self.splitter.flush())
+        return self.n_frames
+
+
+def handleConnection(connection, **kw):
+    """h264/server.go:113 -- decode everything arriving on `connection`; returns the frame count."""
+    return H264Reader(connection, **kw).run()
+
+
+def ByteStreamReader(connection, **kw):
+    """h264/server.go:168 -- same, and closes the connection afterwards."""
+    try:
+        return handleConnection(connection, **kw)
+    finally:
+        if hasattr(connection, "close"):
+            connection.close()
+

@@ -1,0 +1,105 @@
+"""Stream front-end: access-unit splitting of an Annex-B byte stream fed in arbitrary pieces, and the
+connection handler that mirrors the reference's ByteStreamReader / handleConnection (h264/server.go:113-172)."""
+import io
+import random
+import socket
+import threading
+
+import numpy as np
+import pytest
+
+
+def _streams(sg):
+    a = sg.encode(width=64, height=48, frames=7, idr_period=3, profile_idc=77, cabac=1, slices=2, seed=5)[0]
+    b = sg.encode(width=64, height=48, frames=4, idr_period=0, profile_idc=66, cabac=0, long_start_code=0, seed=6)[0]
+    return a, b
+
+
+def _count_units(H, chunk):
+    """pictures in a chunk = slices with first_mb_in_slice == 0"""
+    n = 0
+    for nu in H.read_nal_units(chunk):
+        if nu.Type in (1, 5) and nu.RBSP()[0] & 0x80:
+            n += 1
+    return n
+
+
+@pytest.mark.parametrize("piece", [1, 7, 64, 1000, 1 << 20])
+def test_splitter_is_independent_of_the_feeding_pattern(H, sg, piece):
+    for stream in _streams(sg):
+        sp = H.AccessUnitSplitter(max_units_per_chunk=3)
+        chunks = []
+        for i in range(0, len(stream), piece):
+            chunks += sp.feed(stream[i:i + piece])
+        chunks += sp.flush()
+        assert b"".join(chunks) == stream  # nothing lost, nothing duplicated
+        total = _count_units(H, stream)
+        per_chunk = [_count_units(H, c) for c in chunks]
+        assert sum(per_chunk) == total and max(per_chunk) <= 3 and min(per_chunk) >= 1
+        for c in chunks:  # every chunk starts on a start code
+            assert c[:3] == b"\x00\x00\x01" or c[:4] == b"\x00\x00\x00\x01"
+
+
+def test_splitter_random_pieces_and_delimiters(H, sg):
+    a, _ = _streams(sg)
+    aud = b"\x00\x00\x00\x01\x09\xf0"
+    sei = b"\x00\x00\x01\x06\x05\x01\xaa\x80"
+    # re-assemble with an access unit delimiter and an SEI in front of every picture
+    nals = H.read_nal_units(a)
+    parts = []
+    for nu in nals:
+        raw = a[nu._c.offset - 0:nu._c.offset + nu._c.num_bytes]
+        if nu.Type in (1, 5) and nu.RBSP()[0] & 0x80:
+            parts += [aud, sei]
+        parts.append(b"\x00\x00\x01" + raw)
+    stream = b"".join(parts)
+    rng = random.Random(1)
+    sp = H.AccessUnitSplitter(max_units_per_chunk=1)
+    chunks, i = [], 0
+    while i < len(stream):
+        k = rng.randint(1, 300)
+        chunks += sp.feed(stream[i:i + k])
+        i += k
+    chunks += sp.flush()
+    assert b"".join(chunks) == stream
+    assert all(_count_units(H, c) == 1 for c in chunks)
+    # every access unit opens with its delimiter, or with the parameter sets that precede the delimiter of an IDR picture
+    assert all(c.startswith(aud) or (H.read_nal_units(c)[0].Type == 7) for c in chunks)
+
+
+@pytest.mark.gpu
+def test_gpu_connection_handler_over_a_socket(H, sg, oracle_mod):
+    stream = sg.encode(width=176, height=144, frames=9, idr_period=4, profile_idc=77, cabac=1, slices=2, seed=21)[0]
+    ref, info = oracle_mod.decode(stream, crop=True)
+    srv = socket.socket()
+    srv.bind(("127.0.0.1", 0))
+    srv.listen(1)
+
+    def sender():
+        c = socket.create_connection(srv.getsockname())
+        rng = random.Random(2)
+        i = 0
+        while i < len(stream):
+            k = rng.randint(1, 4000)
+            c.sendall(stream[i:i + k])
+            i += k
+        c.close()
+
+    t = threading.Thread(target=sender)
+    t.start()
+    conn, _ = srv.accept()
+    got = []
+    n = H.ByteStreamReader(conn, on_frames=got.append, max_width=176, max_height=144, frames_per_batch=4)
+    t.join()
+    srv.close()
+    assert n == 9
+    assert np.array_equal(np.concatenate(got), ref)
+
+
+@pytest.mark.gpu
+def test_gpu_handle_connection_reads_file_objects(H, sg, oracle_mod):
+    stream = sg.encode(width=64, height=48, frames=5, idr_period=0, profile_idc=66, cabac=0, long_start_code=0, seed=22)[0]
+    ref, _ = oracle_mod.decode(stream, crop=True)
+    got = []
+    assert H.handleConnection(io.BytesIO(stream), on_frames=got.append, max_width=64, max_height=48, frames_per_batch=2, read_size=333) == 5
+    assert np.array_equal(np.concatenate(got), ref)

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""TCP front-end mirroring the reference program (main.go:7-22: "Listens for a stream of H264 bytes on port 8000"):
+accepts connections, decodes the Annex-B byte stream of each on the GPU and prints one line per batch of frames
+(count + MD5 of the cropped I420 data); --out writes the raw frames.
+
+    python tools/serve.py --port 8000 [--out frames.yuv]      # then e.g.:  nc 127.0.0.1 8000 < clip.h264
+"""
+import argparse
+import hashlib
+import os
+import socket
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import h264decode_amd as H  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--host", default="0.0.0.0")
+    ap.add_argument("--port", type=int, default=8000)
+    ap.add_argument("--max-width", type=int, default=1920)
+    ap.add_argument("--max-height", type=int, default=1088)
+    ap.add_argument("--frames-per-batch", type=int, default=30)
+    ap.add_argument("--out", default=None, help="append decoded frames (tight I420) to this file")
+    ap.add_argument("--once", action="store_true", help="serve one connection and exit")
+    args = ap.parse_args()
+    srv = socket.socket()
+    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    srv.bind((args.host, args.port))
+    srv.listen(4)
+    print("listening on %s:%d" % (args.host, args.port), flush=True)
+    out = open(args.out, "ab") if args.out else None
+    while True:
+        conn, peer = srv.accept()
+        total = [0]
+
+        def on_frames(frames):
+            total[0] += len(frames)
+            print("%s: %d frames (%d so far) md5 %s" % (peer[0], len(frames), total[0], hashlib.md5(frames.tobytes()).hexdigest()), flush=True)
+            if out:
+                out.write(frames.tobytes())
+
+        try:
+            H.ByteStreamReader(conn, on_frames=on_frames, max_width=args.max_width, max_height=args.max_height, frames_per_batch=args.frames_per_batch)
+        except H.H264MIError as e:
+            print("%s: decode error: %s" % (peer[0], e), flush=True)
+        if args.once:
+            break
+
+
+if __name__ == "__main__":
+    main()
