@@ -39,6 +39,8 @@ def gen_stream(args):
     kw = streamgen.recipe("C3", frames=frames, idr_period=frames, seed=seed, width=width, height=height)
     if os.environ.get("H264MI_BENCH_DBF"):  # experiments only: disable_deblocking_filter_idc of the synthetic streams
         kw["deblock_idc"] = int(os.environ["H264MI_BENCH_DBF"])
+    if os.environ.get("H264MI_BENCH_INTRAP"):  # experiments only: share of intra macroblocks in P pictures (per mille)
+        kw["intra_in_p_permille"] = int(os.environ["H264MI_BENCH_INTRAP"])
     s, rec, sizes = streamgen.encode(want_recon=True, **kw)
     # keep only what the parity gate needs: full recon for the first stream, last frame otherwise
     return s, rec, sizes

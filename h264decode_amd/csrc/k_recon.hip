@@ -408,10 +408,15 @@ struct IntraWave {
     int16_t fe[2][32];        // Intra8x8 filtered reference samples: [0] top p'[-1..15] at index x+1, [1] left p'[-1..7] at index y+1
     MbRec rec;                // LDS copy of the current macroblock record
 };
+#define MI_INTRA_MAX_ROWS 320  /* macroblock rows (5120 luma lines) */
+#define MI_INTRA_MAX_CHUNKS 8 /* 64-macroblock chunks per row (8192 luma columns) */
 struct IntraShared {
     IntraWave w[MI_INTRA_WAVES];
     ScalingSet sc; // LevelScale tables of the picture
-    int prog[320]; // macroblocks finished per row
+    // intra macroblocks still to be reconstructed, one bit each: an intra macroblock waits for exactly the intra
+    // macroblocks among its upper-left / upper / upper-right neighbours (inter ones were finished by K4), so the
+    // isolated intra macroblocks of P pictures do not serialise behind each other row after row
+    unsigned long long pend[MI_INTRA_MAX_ROWS][MI_INTRA_MAX_CHUNKS];
 };
 
 // directional Intra4x4 / Intra8x8 predictors (8.3.1.2.4-9, 8.3.2.2.5-10).  T(x) = p[x,-1], L(y) = p[-1,y], T(-1)=L(-1)=p[-1,-1]
@@ -695,38 +700,47 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
     const int W = static_cast<int>(pool->w), H = static_cast<int>(pool->h);
     uint8_t *py = reinterpret_cast<uint8_t *>(pool->base) + static_cast<size_t>(pd->slot) * pool->slot_bytes;
     uint8_t *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
-    for (int i = tid; i < 320; i += MI_INTRA_WAVES * 64) sh.prog[i] = 0;
     { // LevelScale tables of this picture's PPS -> LDS (2688 bytes)
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&tab->scaling[pd->scaling_set]);
         for (int i = tid; i < static_cast<int>(sizeof(ScalingSet) / 4); i += MI_INTRA_WAVES * 64) reinterpret_cast<uint32_t *>(&sh.sc)[i] = src[i];
     }
+    const int nchunks = (wmb + 63) >> 6;
+    const MbRec *recs = mbrec + pd->mb_base;
+    // ---- pass 1: intra masks of every row (one type byte per lane, ballot) ----
+    for (int mby = wave; mby < hmb; mby += MI_INTRA_WAVES)
+        for (int c = 0; c < nchunks; c++) {
+            const int x = c * 64 + lane;
+            const int t = x < wmb ? recs[static_cast<size_t>(mby) * wmb + x].type : 0;
+            const unsigned long long m = __ballot(MB_IS_INTRA(t));
+            if (lane == 0) sh.pend[mby][c] = m;
+        }
     __syncthreads();
+    // ---- pass 2: wavefront w owns rows w, w+16, ...; left-to-right inside a row ----
     IntraWave *ws = &sh.w[wave];
     for (int mby = wave; mby < hmb; mby += MI_INTRA_WAVES) {
-        const MbRec *row = mbrec + pd->mb_base + static_cast<uint64_t>(mby) * wmb;
-        // scan the row 64 macroblocks at a time: one type byte per lane, ballot -> intra macroblocks
-        for (int x0 = 0; x0 < wmb; x0 += 64) {
-            const int n = min(64, wmb - x0);
-            const int t = lane < n ? row[x0 + lane].type : 0;
-            unsigned long long mask = __ballot(MB_IS_INTRA(t));
+        const MbRec *row = recs + static_cast<uint64_t>(mby) * wmb;
+        for (int c = 0; c < nchunks; c++) {
+            unsigned long long mask = sh.pend[mby][c]; // only this wavefront clears bits of this row
             while (mask) {
                 const int k = __ffsll(static_cast<long long>(mask)) - 1;
                 mask &= mask - 1;
-                const int mbx = x0 + k;
-                // everything left of mbx in this row is final (inter MBs were written by K4)
-                if (lane == 0) __hip_atomic_store(&sh.prog[mby], mbx, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int mbx = c * 64 + k;
                 if (lane < 32) reinterpret_cast<uint32_t *>(&ws->rec)[lane] = reinterpret_cast<const uint32_t *>(row + mbx)[lane];
                 WAVE_SYNC();
-                if (mby > 0) { // 2-D wavefront: the row above must be past the top-right neighbour
-                    const int need = min(mbx + 2, wmb);
-                    while (__hip_atomic_load(&sh.prog[mby - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+                if (mby > 0) { // the intra macroblocks among (mbx-1 .. mbx+1, mby-1) must be done
+                    const int xl = max(mbx - 1, 0), xr = min(mbx + 1, wmb - 1);
+                    const int c0 = xl >> 6, c1 = xr >> 6;
+                    const unsigned long long span = ((xr - xl + 1) >= 64 ? ~0ull : ((1ull << (xr - xl + 1)) - 1));
+                    const unsigned long long m0 = span << (xl & 63), m1 = c1 != c0 ? span >> (64 - (xl & 63)) : 0ull;
+                    while ((__hip_atomic_load(&sh.pend[mby - 1][c0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & m0) ||
+                           (m1 && (__hip_atomic_load(&sh.pend[mby - 1][c1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & m1)))
+                        __builtin_amdgcn_s_sleep(1);
                 }
                 const uint64_t mbi = pd->mb_base + static_cast<uint64_t>(mby) * wmb + mbx;
                 intra_mb(lane, ws, &ws->rec, coefs + mbi * MI_COEF_PER_MB, &sh.sc, py, pcb, pcr, W, mbx, mby);
-                // publish progress: the release orders this wave's global stores before the counter update
-                if (lane == 0) __hip_atomic_store(&sh.prog[mby], mbx + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // done: the release orders this wavefront's sample stores before the bit is cleared
+                if (lane == 0) __hip_atomic_fetch_and(&sh.pend[mby][c], ~(1ull << k), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            if (lane == 0) __hip_atomic_store(&sh.prog[mby], x0 + n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
 }

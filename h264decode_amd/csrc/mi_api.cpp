@@ -247,6 +247,11 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     if (d->cfg.max_slices_per_frame < 1) d->cfg.max_slices_per_frame = 1;
     d->Wmax = (cfg->max_width + 15) & ~15;
     d->Hmax = (cfg->max_height + 15) & ~15;
+    if (d->Wmax > 8192 || d->Hmax > 5120) { // LDS row-state of K3 (320 rows x 512 columns of macroblocks) and K5 (96 row groups)
+        set_error("h264mi_decoder_create: pictures larger than 8192x5120 are not supported");
+        delete d;
+        return H264MI_EUNSUPPORTED;
+    }
     d->n_slots = cfg->max_frames_per_batch + MI_MAX_REFS + 1;
     d->slot_bytes = (static_cast<size_t>(d->Wmax) * d->Hmax * 3 / 2 + 255) & ~static_cast<size_t>(255);
     const int S = cfg->max_streams;
