@@ -191,7 +191,7 @@ def main():
                 "per_launch": {k: {"ms": round(v[0], 4), "GB/s": round(v[1] / (v[0] * 1e-3) / 1e9, 2) if v[0] > 0 else 0.0} for k, v in per_launch.items()}}
 
     cpu_baseline = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
         import oracle
         sample = streams[0]
         sinfo = oracle.probe(sample)  # sizing pass outside the timed region: each timed call is exactly one decode
