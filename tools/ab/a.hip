@@ -275,14 +275,15 @@ FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     MI_COUNT_BIN(e);
     const int idx = RFL(idx_);
     const uint32_t st = RDL(reg, idx);
-    const uint32_t p = st >> 1, mps = st & 1;
+    const uint32_t p = st >> 1;
     const uint32_t rl4 = RDL(e.v_rlps, p), tr = RDL(e.v_trans, p);
-    // scalar side: the two candidate successor states (v_trans holds the LPS successor for valMPS 0; bit 0 flips with valMPS)
+    // everything else runs on the vector side (the CU's single scalar ALU is the scarce unit): st is pinned there
+    uint32_t vst = st;
+    VGPR(vst);
+    const uint32_t mps = vst & 1;
+    // the two candidate successor states (v_trans holds the LPS successor for valMPS 0; bit 0 flips with valMPS)
     const uint32_t next_lps = tr ^ mps;
-    const uint32_t next_mps = min(st + 2, 124 + mps);
-    const uint32_t reg_lps = static_cast<uint32_t>(mi_writelane(static_cast<int>(next_lps), idx, static_cast<int>(reg)));
-    const uint32_t reg_mps = static_cast<uint32_t>(mi_writelane(static_cast<int>(next_mps), idx, static_cast<int>(reg)));
-    // vector side
+    const uint32_t next_mps = min(vst + 2, 124 | mps);
     const uint32_t rlps = __builtin_amdgcn_ubfe(rl4, (e.range >> 3) & 24, 8);
     const uint32_t rmps = e.range - rlps;
     const uint32_t scaled = rmps << e.avail;
@@ -290,7 +291,7 @@ FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     const uint32_t diff = e.value - scaled; // wraps when value < scaled; both are below 2^31
     e.value = min(e.value, diff);
     e.range = lps ? rlps : rmps;
-    reg = lps ? reg_lps : reg_mps;
+    reg = LANE == idx ? (lps ? next_lps : next_mps) : reg;
     const uint32_t binv = (diff >> 31) ^ (mps ^ 1); // valMPS on the MPS path (sign bit set), !valMPS otherwise
     const int n = __builtin_clz(e.range) - 23;
     e.range <<= n;
