@@ -255,6 +255,7 @@ FI int get_se(Ent &e) {
 // a wave-uniform value to the vector side; UNI() turns a vector-side condition into a scalar branch
 // condition (v_cmp writes the lane mask, one s_cmp tests it).
 #define VGPR(x) asm volatile("" : "+v"(x))
+#define OPAQUE(x) asm volatile("" : "+v"(x))
 #define UNI(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
 FI void cabac_refill(Ent &e) {
     if (__builtin_expect(UNI(e.avail < 7), 0)) { // about once per 13 decisions: keep the common path fall-through
@@ -369,7 +370,8 @@ FI uint32_t top_load(const Ent &e, int col, int dw) {
 FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
     MI_R(e, 3);
     const int cat = RFL(cat_);
-    const int l = LANE;
+    int l = LANE;
+    OPAQUE(l); // keeps lane-dependent addresses from being hoisted out of the macroblock loop and spilled
     // The working set stays in e.wk from block to block (and macroblock to macroblock) as long as the category does
     // not change -- a macroblock has at most four category runs -- so states move between LDS and the VGPR only then.
     if (cat != e.wk_cat) {
@@ -606,7 +608,8 @@ FI void parse_residual_cabac(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
     const uint32_t nzmask = ((lo >> GI(0, 0)) & 15) | ((lo >> GI(0, 1)) & 15) << 4 | ((lo >> GI(0, 2)) & 15) << 8 | ((lo >> GI(0, 3)) & 15) << 12;
     s->rec.nzmask = static_cast<uint16_t>(nzmask);
     s->cur_cbf_dc = static_cast<uint8_t>((nzm >> 56) & 7);
-    const int l = LANE;
+    int l = LANE;
+    OPAQUE(l); // keeps lane-dependent addresses from being hoisted out of the macroblock loop and spilled
     const int bit = static_cast<int>((nzm >> l) & 1);
     if (l < 30) {
         const int gx = l % 6 - 1, gy = l / 6 - 1;
@@ -741,7 +744,8 @@ FI void fill_caches(Ent &e) {
     const TopInfo *c = mbC(e);
     const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
     const int cip = e.cip;
-    const int l = LANE;
+    int l = LANE;
+    OPAQUE(l); // keeps lane-dependent addresses from being hoisted out of the macroblock loop and spilled
     int coded = 0; // this lane's bit of the CABAC neighbourhood masks: 1 coded, 2 unavailable (see parse_residual_cabac)
     if (l < 30) {
         int gx = l % 6 - 1, gy = l / 6 - 1; // block coordinates relative to the MB
@@ -1122,7 +1126,8 @@ FI void decode_mb(Ent &e, int skipped) {
     // dbf_idc / alpha_off / beta_off / slice_in_pic / slice_idx of the record are slice constants, written once at slice start
     LDS_SYNC();
     // ---- parallel part: per-block arrays of the record, write-out, neighbour state update ----
-    const int l = LANE;
+    int l = LANE;
+    OPAQUE(l); // keeps lane-dependent addresses from being hoisted out of the macroblock loop and spilled
     const int inter = MB_IS_INTER(type);
     if (l < 16) {
         int g = GI(l & 3, l >> 2);

@@ -105,6 +105,10 @@ struct Ent {
     uint32_t range, value;
     int avail;
     uint32_t ca, cb, wk;     // context states, see above; cb lanes 61..63 = ctxIdx 399..401
+    int wk_cat;              // ctxBlockCat whose states are in wk (-1: none)
+    uint32_t wk_c0;          // cat_word0 of that category
+    int wk_home;             // per lane: ctxIdx this lane of wk mirrors
+    bool wk_valid;           // per lane: the lane belongs to the category's own contexts
     uint32_t v_rlps, v_trans; // lane p: rangeTabLPS[p][0..3] / next state after an LPS for valMPS 0
     uint32_t v_maps;         // lane i: sig8x8[i] | last8x8[i] << 8 | zigzag8[i] << 16 | zigzag4[i & 15] << 24
     uint32_t v_zzac;         // lane i: zigzag4[(i + 1) & 15] (AC blocks: scan index i is coefficient i + 1)
@@ -365,15 +369,28 @@ FI uint32_t top_load(const Ent &e, int col, int dw) {
 FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
     MI_R(e, 3);
     const int cat = RFL(cat_);
-    const uint32_t c0 = RDL(e.v_cat0, cat), c1 = RDL(e.v_cat1, cat);
-    const int l = LANE, grp = l >> 4, li = l & 15;
-    const int home = static_cast<int>((c1 >> (10 * (grp > 2 ? 2 : grp))) & 1023) + (l < 32 ? li : l - 32);
-    const uint32_t pending = e.s->ctx[home < 464 ? home : 463]; // the load overlaps the coded_block_flag decision
+    const int l = LANE;
+    // The working set stays in e.wk from block to block (and macroblock to macroblock) as long as the category does
+    // not change -- a macroblock has at most four category runs -- so states move between LDS and the VGPR only then.
+    if (cat != e.wk_cat) {
+        if (e.wk_valid) e.s->ctx[e.wk_home] = static_cast<uint8_t>(e.wk); // masked scatter of the previous category
+        const uint32_t c0n = RDL(e.v_cat0, cat), c1n = RDL(e.v_cat1, cat);
+        const int grp = l >> 4, li = l & 15;
+        const int home = static_cast<int>((c1n >> (10 * (grp > 2 ? 2 : grp))) & 1023) + (l < 32 ? li : l - 32);
+        // lanes outside the category's own context ranges would hold copies of other categories' states and must never
+        // be written back (for 8x8 blocks ctxIdx 417 appears in both the sig and the last group)
+        const int nsig = cat == 5 ? 15 : static_cast<int>(c0n & 255) - 1, nlast = static_cast<int>((c0n >> 24) & 15);
+        e.wk_valid = grp == 0 ? li < nsig : (grp == 1 ? li < nlast : l < 42);
+        e.wk_home = home < 464 ? home : 463;
+        LDS_SYNC(); // the scatter above may alias the gather below
+        e.wk = e.s->ctx[e.wk_home];
+        e.wk_cat = cat, e.wk_c0 = c0n;
+    }
+    const uint32_t c0 = e.wk_c0;
     if (cat != 5 && !BIN_B(e, 64 + ((c0 >> 8) & 255) + cbf_inc)) {
         MI_R(e, 2);
         return 0;
     }
-    e.wk = pending;
     const int last = static_cast<int>(c0 & 255) - 1; // maxNumCoeff - 1
     const bool is8 = cat == 5;
     uint64_t sig = 0;
@@ -426,10 +443,6 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
         const uint32_t pos = pmode == 3 ? static_cast<uint32_t>(l) : (pmode == 2 ? (e.v_maps >> 16) & 255 : (pmode == 1 ? e.v_zzac : e.v_maps >> 24));
         if (lv != 0) dst[pos] = static_cast<int16_t>(lv);
     }
-    // scatter the states back; lanes outside the block's own context ranges hold copies of other blocks'
-    // states and must not be written (for 8x8 blocks ctxIdx 417 appears in both the sig and the last group)
-    const int nsig = is8 ? 15 : last, nlast = static_cast<int>((c0 >> 24) & 15);
-    if (grp == 0 ? li < nsig : (grp == 1 ? li < nlast : l < 42)) e.s->ctx[home] = static_cast<uint8_t>(e.wk);
     MI_R(e, 2);
     return n;
 }
@@ -1227,6 +1240,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         e.ca = src[l];
         e.cb = src[l < 61 ? 64 + l : 399 + (l - 61)];
         e.wk = 0;
+        e.wk_cat = -1, e.wk_c0 = 0, e.wk_home = 0, e.wk_valid = false;
         for (int i = l; i < 464; i += 64) sh.ctx[i] = src[i];
     }
     if (l < 32) reinterpret_cast<uint32_t *>(&sh.rec)[l] = 0;
