@@ -15,6 +15,7 @@
 // The reference has none of this (README.md:10 "Macroblock to YCbCr image decoding" is a TODO);
 // normative source: ITU-T H.264 8.3, 8.4.2, 8.5.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include "mi_kernels.h"
 
 #define WAVE_SYNC()                                             \
@@ -182,21 +183,30 @@ __device__ __forceinline__ void zero_residual(int lane, ResBuf *rb) {
 
 // ================================================================== K4: inter prediction
 struct InterShared {
+    // The coefficient block (832 bytes, fetched while the reference windows are in flight) is parked on top of
+    // rb.luma | rb.chroma | rb.dc[0..15]: it is dead once the row pass has run, those are written by the column
+    // pass (dc[0..15] is the Intra16x16 DC, never used here).  LDS per wavefront decides the occupancy of this kernel.
     ResBuf rb;
-    uint8_t win_y[16][9][12];   // 9x9 luma window per 4x4 block, rows padded to 12 bytes
-    uint8_t win_c[2][16][3][4]; // 3x3 chroma window per 2x2 chroma block
-    // uniform-motion fast path (all 16 blocks share one mv + reference, window inside the picture):
-    // one 21x21 luma / 9x9 chroma window for the whole macroblock, loaded as aligned dwords
-    uint8_t win16[21][24];
-    uint8_t winc16[2][9][12];
+    union {
+        struct {
+            uint8_t win_y[16][9][12];   // 9x9 luma window per 4x4 block, rows padded to 12 bytes
+            uint8_t win_c[2][16][3][4]; // 3x3 chroma window per 2x2 chroma block
+        };
+        struct { // uniform-motion fast path (all 16 blocks share one mv + reference, window inside the picture):
+                 // one 21x21 luma / 9x9 chroma window for the whole macroblock, loaded as aligned dwords
+            uint8_t win16[21][24];
+            uint8_t winc16[2][9][12];
+        };
+    };
     MbRec rec;
     int uniform;
-    alignas(16) int16_t coef[MI_COEF_PER_MB]; // coefficient block, fetched while the reference windows are in flight
 };
+static_assert(offsetof(ResBuf, chroma) == offsetof(ResBuf, luma) + 512 && offsetof(ResBuf, dc) == offsetof(ResBuf, luma) + 768 && offsetof(ResBuf, luma) % 16 == 0,
+              "coefficient overlay needs luma | chroma | dc back to back");
 
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
 
-extern "C" __global__ void __launch_bounds__(64) k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const FramePool *pools,
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const FramePool *pools,
                                                          const DevTables *tab, const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max) {
     __shared__ InterShared sh;
     const int lane = static_cast<int>(threadIdx.x);
@@ -271,9 +281,10 @@ extern "C" __global__ void __launch_bounds__(64) k_inter(const uint32_t *pic_lis
     }
     // ---- residual (independent of the prediction) ----
     if (has_res) {
-        if (lane < MI_COEF_PER_MB * 2 / 16) reinterpret_cast<uint4 *>(sh.coef)[lane] = cv;
+        int16_t *coef_lds = sh.rb.luma; // overlay, see InterShared
+        if (lane < MI_COEF_PER_MB * 2 / 16) reinterpret_cast<uint4 *>(coef_lds)[lane] = cv;
         __syncthreads();
-        mb_residual(lane, rec, sh.coef, &tab->scaling[pd->scaling_set], &sh.rb);
+        mb_residual(lane, rec, coef_lds, &tab->scaling[pd->scaling_set], &sh.rb);
     } else
         zero_residual(lane, &sh.rb);
     __syncthreads();
