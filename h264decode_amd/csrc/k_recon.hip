@@ -207,17 +207,26 @@ static_assert(offsetof(ResBuf, chroma) == offsetof(ResBuf, luma) + 512 && offset
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
 
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const FramePool *pools,
-                                                         const DevTables *tab, const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max) {
+                                                         const DevTables *tab, const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max, int n_blocks) {
     __shared__ InterShared sh;
     const int lane = static_cast<int>(threadIdx.x);
-    const PicDesc *pd = &pics[pic_list[blockIdx.x / mbs_per_pic_max]];
-    const int mb = static_cast<int>(blockIdx.x % mbs_per_pic_max);
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Give every XCD a
+    // contiguous run of macroblocks (whole pictures) so that the reference rows shared by neighbouring macroblocks
+    // are re-read from the same L2.
+    // (the grid is the block count rounded up to a multiple of 8, so this is a bijection; surplus blocks leave)
+    const uint32_t per_xcd = gridDim.x >> 3;
+    const uint32_t lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lb >= static_cast<uint32_t>(n_blocks)) return;
+    const PicDesc *pd = &pics[pic_list[lb / mbs_per_pic_max]];
+    const int mb = static_cast<int>(lb % mbs_per_pic_max);
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
     if (mb >= wmb * hmb) return;
     const uint64_t mbi = pd->mb_base + mb;
     const MbRec *grec = mbrec + mbi;
-    if (!MB_IS_INTER(grec->type)) return;
-    if (lane < 32) reinterpret_cast<uint32_t *>(&sh.rec)[lane] = reinterpret_cast<const uint32_t *>(grec)[lane];
+    // one round trip: fetch the whole record, then look at its type (first byte of dword 0)
+    const uint32_t rv = lane < 32 ? reinterpret_cast<const uint32_t *>(grec)[lane] : 0u;
+    if (!MB_IS_INTER(static_cast<int>(__builtin_amdgcn_readfirstlane(rv) & 255u))) return;
+    if (lane < 32) reinterpret_cast<uint32_t *>(&sh.rec)[lane] = rv;
     __syncthreads();
     const MbRec *rec = &sh.rec;
     const FramePool *pool = &pools[pd->stream];

@@ -895,8 +895,9 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         const uint32_t n = static_cast<uint32_t>(d->waves[w].size()), ni = static_cast<uint32_t>(d->waves_inter[w].size());
         if (!n) continue;
         if (ni) {
-            hipLaunchKernelGGL(k_inter, dim3(ni * d->mbs_max), dim3(64), 0, rs, d->d_lists + d->wave_inter_off[w], d->d_pics, d->d_slices, d->d_pools,
-                               d->d_tables, mbrec, coef, d->mbs_max);
+            const uint32_t nb = ni * d->mbs_max;
+            hipLaunchKernelGGL(k_inter, dim3((nb + 7) & ~7u), dim3(64), 0, rs, d->d_lists + d->wave_inter_off[w], d->d_pics, d->d_slices, d->d_pools,
+                               d->d_tables, mbrec, coef, d->mbs_max, static_cast<int>(nb));
             mark(1);
         }
         hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec, coef);

@@ -7,8 +7,9 @@
 extern "C" __global__ void k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec, int16_t *coefs,
                                      uint32_t *status, uint32_t *toprows, int wmb_max);
 // K4: inter macroblocks of a set of pictures (one per stream), one macroblock per wavefront.
+// n_blocks = #pictures * mbs_per_pic_max; grid = n_blocks rounded up to a multiple of 8 (XCD-aware block order)
 extern "C" __global__ void k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const FramePool *pools, const DevTables *tab,
-                                   const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max);
+                                   const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max, int n_blocks);
 // K3: intra macroblocks, one workgroup per picture, one wavefront per macroblock row (2-D wavefront order).
 extern "C" __global__ void k_intra(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
                                    const int16_t *coefs);
