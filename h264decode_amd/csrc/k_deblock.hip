@@ -46,6 +46,7 @@ struct DbSub { // state of one of the 4 macroblock rows a wavefront works on
     // bottom rows of this sub-row's macroblocks for the sub-row below: ring over 4 MB columns
     uint8_t bot_y[4][4][16];    // [column & 3][row 12..15][x]
     uint8_t bot_c[4][2][2][8];  // [column & 3][plane][row 6..7][x]
+    uint8_t pad[32];            // sub-row stride = 552 dwords = 8 (mod 32 banks): the 4 sub-rows of a wavefront no longer hit the same banks
 };
 struct DbWave {
     DbSub sub[4];

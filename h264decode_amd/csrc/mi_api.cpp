@@ -902,7 +902,8 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         }
         hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec, coef);
         mark(2);
-        const int dbw = mi_deblock_waves(d->hmb_max);
+        int dbw = mi_deblock_waves(d->hmb_max);
+        if (const char *e = getenv("H264MI_DEBLOCK_WAVES")) dbw = std::min(MI_DEBLOCK_MAX_WAVES, std::max(2, atoi(e))); // experiments
         hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw), rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec);
         mark(3);
     }

@@ -19,7 +19,7 @@ extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pi
 #define MI_DEBLOCK_MAX_WAVES 12   /* 170 VGPRs -> 3 wavefronts per SIMD */
 #define MI_DEBLOCK_RING 32        /* macroblock columns of the hand-off ring between row groups (power of two) */
 #define MI_DEBLOCK_HDR_BYTES 1088 /* sizeof(DbShared) rounded up to 16 */
-#define MI_DEBLOCK_WAVE_BYTES 8704
+#define MI_DEBLOCK_WAVE_BYTES 8832
 #define MI_DEBLOCK_SLOT_BYTES 96
 static inline size_t mi_deblock_lds_bytes(int nwaves) {
     return MI_DEBLOCK_HDR_BYTES + static_cast<size_t>(nwaves) * (MI_DEBLOCK_WAVE_BYTES + MI_DEBLOCK_RING * MI_DEBLOCK_SLOT_BYTES);
