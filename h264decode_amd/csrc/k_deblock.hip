@@ -61,6 +61,13 @@ struct DbShared { // followed in dynamic LDS by DbWave[nwaves] and GroupSlot[nwa
     int cons[96]; // per group: hand-off slots consumed by its FIRST row
 };
 
+#if MI_DB_STATS /* diagnostics: shader clocks per phase of wavefront `wave`, written into the pad bytes of MbRec[wave] of the picture */
+#define DB_T0() uint64_t db_mark = __builtin_readcyclecounter(); uint32_t db_acc[4] = {0, 0, 0, 0}
+#define DB_T(k) do { const uint64_t now_ = __builtin_readcyclecounter(); db_acc[k] += static_cast<uint32_t>((now_ - db_mark) >> 4); db_mark = now_; } while (0)
+#else
+#define DB_T0() ((void)0)
+#define DB_T(k) ((void)0)
+#endif
 static_assert(sizeof(DbShared) <= MI_DEBLOCK_HDR_BYTES && sizeof(DbWave) == MI_DEBLOCK_WAVE_BYTES && sizeof(GroupSlot) == MI_DEBLOCK_SLOT_BYTES, "LDS layout constants");
 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
@@ -150,6 +157,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
     const DbSub *sup = sub > 0 ? &waves[wave].sub[sub - 1] : nullptr; // the sub-row above (same wavefront)
     const MbRec *recs = mbrec + pd->mb_base;
     const int ngroups = (hmb + 3) >> 2;
+    DB_T0();
     for (int g = wave; g < ngroups; g += nwaves) {
         const int mby = g * 4 + sub;
         const bool row_ok = mby < hmb, has_top = mby > 0;
@@ -179,6 +187,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
             DbTile *tl = &ss->tile[t & 1], *prev = &ss->tile[(t & 1) ^ 1];
             const int cur_slot = t & 1;
             MbRec *mq = &ss->rec[cur_slot], *mleft_rec = &ss->rec[cur_slot ^ 1], *mtop_rec = &ss->rec[2];
+            DB_T(3);
             // ---- commit the prefetched data to LDS ----
             if (active) {
                 reinterpret_cast<uint4 *>(li < 8 ? mq : mtop_rec)[li & 7] = pre_rec;
@@ -231,6 +240,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
                     asm volatile("" ::: "memory");
                 }
             }
+            DB_T(0);
             WAVE_SYNC();
             if (g > 0 && t < wmb) { // the hand-off slot of column t has been copied into the tile
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -264,6 +274,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
                 }
             }
             WAVE_SYNC();
+            DB_T(1);
             // ---- the two filtering passes: a whole line of samples in registers per lane ----
             const bool filt = active && dbf != 1;
             for (int dir = 0; dir < 2; dir++) {
@@ -341,6 +352,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
                 }
                 WAVE_SYNC();
             }
+            DB_T(2);
             // ---- results.  HBM: own rows 0..12 (0..15 in the last picture row) + the 4 columns to the left, and
             // rows -3..-1 of the macroblock above (this macroblock modified them last).  LDS rings: bottom rows
             // for the sub-row / group below ----
@@ -405,4 +417,10 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
             }
         }
     }
+#if MI_DB_STATS
+    if (lane == 0) {
+        uint32_t *dst = reinterpret_cast<uint32_t *>(const_cast<MbRec *>(recs + wave)->pad);
+        dst[0] = db_acc[0], dst[1] = db_acc[1], dst[2] = db_acc[2], dst[3] = db_acc[3];
+    }
+#endif
 }
