@@ -20,8 +20,8 @@
 //     no HBM access sits on the dependency path: samples are loaded once (prefetch) and stored once,
 //     fire-and-forget -- rows 13..15 of a macroblock are written by the macroblock BELOW it (which
 //     modifies them last), so no address is ever stored twice;
-//   * MbRecs and the macroblock's own samples are prefetched one step ahead (one 16-byte row per
-//     lane); the 4 columns to the left are carried over from the previous tile in LDS;
+//   * MbRecs are prefetched one step ahead, the macroblock's own samples four macroblocks (one 64-byte line
+//     per lane) at a time; the 4 columns to the left are carried over from the previous tile in LDS;
 //   * a lane filters a whole line of samples in registers (4 luma edges, then 2 chroma edges).
 //
 // Absent from the reference (only the slice-header fields are parsed: h264/slice.go:1021-1027).
@@ -163,18 +163,42 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
         const bool row_ok = mby < hmb, has_top = mby > 0;
         const MbRec *row = recs + static_cast<size_t>(row_ok ? mby : 0) * wmb;
         const int last_sub = min(3, hmb - 1 - g * 4); // last valid sub-row of this group
-        // prefetch registers: own 16x16 luma row (16 B), own chroma row (8 B), 2 x 32 dwords of MbRec (cur, top) as 4 dwords per lane
-        uint4 pre_y = make_uint4(0, 0, 0, 0), pre_rec = pre_y;
-        uint2 pre_c = make_uint2(0, 0);
-        auto prefetch = [&](int mbx) {
+        // Prefetch registers.  Samples are fetched one aligned group of 4 macroblocks at a time -- the whole 64-byte
+        // line of a luma row (32 bytes of a chroma row) by one lane with back-to-back loads -- so that every line
+        // leaves HBM once; fetching 16 bytes per step let the line be evicted between its four uses (4x read traffic).
+        // MbRecs (cur, top: 2 x 128 bytes as 4 dwords per lane) are whole lines already and stay per step.
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+        uint4 gy0 = z4, gy1 = z4, gy2 = z4, gy3 = z4, gc0 = z4, gc1 = z4, pre_rec = z4;
+        auto prefetch_samples = [&](int gb) { // gb = first macroblock of the aligned group
+            if (!row_ok || gb < 0 || gb >= wmb) return;
+            const uint8_t *yrow = py + static_cast<size_t>(mby * 16 + li) * W + gb * 16;
+            const uint8_t *crow = (li < 8 ? pcb : pcr) + static_cast<size_t>(mby * 8 + (li & 7)) * Wc + gb * 8;
+            const int left = wmb - gb; // macroblocks from gb to the end of the row (>= 1)
+            gy0 = *reinterpret_cast<const uint4 *>(yrow);
+            if (left > 1) gy1 = *reinterpret_cast<const uint4 *>(yrow + 16);
+            if (left > 2) gy2 = *reinterpret_cast<const uint4 *>(yrow + 32);
+            if (left > 3) gy3 = *reinterpret_cast<const uint4 *>(yrow + 48);
+            if (left > 1)
+                gc0 = *reinterpret_cast<const uint4 *>(crow);
+            else {
+                const uint2 h = *reinterpret_cast<const uint2 *>(crow);
+                gc0 = make_uint4(h.x, h.y, 0, 0);
+            }
+            if (left > 3)
+                gc1 = *reinterpret_cast<const uint4 *>(crow + 16);
+            else if (left > 2) {
+                const uint2 h = *reinterpret_cast<const uint2 *>(crow + 16);
+                gc1 = make_uint4(h.x, h.y, 0, 0);
+            }
+        };
+        auto prefetch_rec = [&](int mbx) {
             if (!row_ok || mbx < 0 || mbx >= wmb) return;
-            pre_y = *reinterpret_cast<const uint4 *>(py + static_cast<size_t>(mby * 16 + li) * W + mbx * 16);
-            pre_c = *reinterpret_cast<const uint2 *>((li < 8 ? pcb : pcr) + static_cast<size_t>(mby * 8 + (li & 7)) * Wc + mbx * 8);
             // lanes 0-7: cur record (8 x 16 B), lanes 8-15: record above
             const MbRec *src = li < 8 ? row + mbx : (has_top ? row + mbx - wmb : row + mbx);
             pre_rec = reinterpret_cast<const uint4 *>(src)[li & 7];
         };
-        prefetch(-2 * sub); // step 0 (only sub-row 0 is active)
+        prefetch_samples(0);
+        prefetch_rec(-2 * sub); // step 0 (only sub-row 0 is active)
         // this wavefront's ring row was last used by group g - nwaves: its reader (g - nwaves + 1) must be through with it
         if (g >= nwaves && g + 1 < ngroups) {
             while (__hip_atomic_load(&sh.cons[g - nwaves + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < wmb) __builtin_amdgcn_s_sleep(1);
@@ -191,6 +215,10 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
             // ---- commit the prefetched data to LDS ----
             if (active) {
                 reinterpret_cast<uint4 *>(li < 8 ? mq : mtop_rec)[li & 7] = pre_rec;
+                const int k4 = mbx & 3;
+                const uint4 pre_y = k4 == 0 ? gy0 : (k4 == 1 ? gy1 : (k4 == 2 ? gy2 : gy3));
+                const uint4 pc4 = k4 < 2 ? gc0 : gc1;
+                const uint2 pre_c = (k4 & 1) ? make_uint2(pc4.z, pc4.w) : make_uint2(pc4.x, pc4.y);
                 uint32_t *yr = reinterpret_cast<uint32_t *>(&tl->y[4 + li][4]);
                 yr[0] = pre_y.x, yr[1] = pre_y.y, yr[2] = pre_y.z, yr[3] = pre_y.w;
                 uint32_t *cr = reinterpret_cast<uint32_t *>(&tl->c[li >> 3][4 + (li & 7)][4]);
@@ -246,7 +274,8 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(&sh.cons[g], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-            prefetch(mbx + 1);
+            if ((mbx & 3) == 3) prefetch_samples(mbx + 1); // the group's registers are free: fetch the next one (used from the next step on)
+            prefetch_rec(mbx + 1);
             // ---- boundary strengths: 32 per macroblock, 2 per lane ----
             const MbRec *ml = nullptr, *mt = nullptr;
             int dbf = 1;
