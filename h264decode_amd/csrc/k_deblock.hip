@@ -15,7 +15,7 @@
 //   * inside a group the 4 sample rows handed from sub-row k-1 to sub-row k travel through a small
 //     LDS ring (4 macroblock columns), never through HBM;
 //   * between groups (different wavefronts of the workgroup) they travel through a second LDS ring of
-//     MI_DEBLOCK_RING macroblock columns per in-flight group, ordered by two LDS counters per group
+//     `ring` macroblock columns per in-flight group (chosen by the host, see mi_deblock_plan), ordered by two LDS counters per group
 //     (columns finished by its last row / columns consumed by its first row: back-pressure);
 //     no HBM access sits on the dependency path: samples are loaded once (prefetch) and stored once,
 //     fire-and-forget -- rows 13..15 of a macroblock are written by the macroblock BELOW it (which
@@ -46,7 +46,11 @@ struct DbSub { // state of one of the 4 macroblock rows a wavefront works on
     // bottom rows of this sub-row's macroblocks for the sub-row below: ring over 4 MB columns
     uint8_t bot_y[4][4][16];    // [column & 3][row 12..15][x]
     uint8_t bot_c[4][2][2][8];  // [column & 3][plane][row 6..7][x]
-    uint8_t pad[32];            // sub-row stride = 552 dwords = 8 (mod 32 banks): the 4 sub-rows of a wavefront no longer hit the same banks
+    uint8_t pad[32];            // sub-row stride = 8 dwords (mod 32 banks): the 4 sub-rows of a wavefront do not hit the same banks
+    // output staging: finished samples of an aligned group of 4 macroblocks, flushed as whole 64-byte (luma) / 32-byte
+    // (chroma) lines -- storing 16 bytes per step left every line in HBM as four partial writes (4x write traffic)
+    alignas(16) uint8_t ost_y[16][64];
+    alignas(16) uint8_t ost_c[2][8][32];
 };
 struct DbWave {
     DbSub sub[4];
@@ -55,7 +59,7 @@ struct GroupSlot { // bottom rows of one macroblock column handed to the group b
     uint8_t y[4][16];   // rows 12..15
     uint8_t c[2][2][8]; // [plane][rows 6..7]
 };
-struct DbShared { // followed in dynamic LDS by DbWave[nwaves] and GroupSlot[nwaves][MI_DEBLOCK_RING]
+struct DbShared { // followed in dynamic LDS by DbWave[nwaves] and GroupSlot[nwaves][ring]
     uint8_t alpha[52], beta[52], tc0[52][4];
     int prog[96]; // per group: macroblocks finished in its LAST row
     int cons[96]; // per group: hand-off slots consumed by its FIRST row
@@ -133,7 +137,7 @@ __device__ __forceinline__ int edge_bs(const MbRec *mp, int pb, const MbRec *mq,
 }
 
 extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
-                                                                                  const DevTables *tab, const MbRec *mbrec) {
+                                                                                  const DevTables *tab, const MbRec *mbrec, int ring) {
     extern __shared__ uint4 dyn_lds[];
     const int nthreads = static_cast<int>(blockDim.x), nwaves = nthreads >> 6;
     DbShared &sh = *reinterpret_cast<DbShared *>(dyn_lds);
@@ -248,7 +252,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
                     while (__hip_atomic_load(&sh.prog[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
                     asm volatile("" ::: "memory");
                     if (sub == 0) {
-                        const GroupSlot *gs = &gring[((g - 1) % nwaves) * MI_DEBLOCK_RING + (x0 & (MI_DEBLOCK_RING - 1))];
+                        const GroupSlot *gs = &gring[((g - 1) % nwaves) * ring + x0 % ring];
                         if (li < 4) {
                             const uint32_t *src = reinterpret_cast<const uint32_t *>(gs->y[li]);
                             uint32_t *dst = reinterpret_cast<uint32_t *>(&tl->y[li][4]);
@@ -263,8 +267,8 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
                 // back-pressure: the ring slot this step's last sub-row will overwrite held column xl - RING of this
                 // group; the group below must have consumed it
                 const int xl = t - 2 * last_sub;
-                if (g + 1 < ngroups && xl >= MI_DEBLOCK_RING && xl < wmb) {
-                    while (__hip_atomic_load(&sh.cons[g + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < xl - MI_DEBLOCK_RING + 1) __builtin_amdgcn_s_sleep(1);
+                if (g + 1 < ngroups && xl >= ring && xl < wmb) {
+                    while (__hip_atomic_load(&sh.cons[g + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < xl - ring + 1) __builtin_amdgcn_s_sleep(1);
                     asm volatile("" ::: "memory");
                 }
             }
@@ -382,24 +386,55 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
                 WAVE_SYNC();
             }
             DB_T(2);
-            // ---- results.  HBM: own rows 0..12 (0..15 in the last picture row) + the 4 columns to the left, and
-            // rows -3..-1 of the macroblock above (this macroblock modified them last).  LDS rings: bottom rows
-            // for the sub-row / group below ----
+            // ---- results.  Own rows 0..12 (0..15 in the last picture row) go to the staging group and reach HBM as whole
+            // lines once the group is complete; rows -3..-1 of the macroblock above (this macroblock modified them last) are
+            // stored directly.  LDS rings: bottom rows for the sub-row / group below ----
             if (active) {
                 uint8_t *Y = py + static_cast<size_t>(mby * 16) * W + mbx * 16;
-                uint8_t *Cp = (li < 8 ? pcb : pcr) + static_cast<size_t>(mby * 8) * Wc + mbx * 8;
-                const bool has_left = mbx > 0, last_row = mby == hmb - 1;
-                if (filt) {
-                    if (li < 13 || last_row) {
-                        const uint32_t *r = reinterpret_cast<const uint32_t *>(&tl->y[4 + li][0]);
-                        *reinterpret_cast<uint4 *>(Y + static_cast<size_t>(li) * W) = make_uint4(r[1], r[2], r[3], r[4]);
-                        if (has_left) *reinterpret_cast<uint32_t *>(Y + static_cast<size_t>(li) * W - 4) = r[0];
+                const bool has_left = mbx > 0, last_row = mby == hmb - 1, row_end = mbx == wmb - 1;
+                const int k4 = mbx & 3;
+                const uint32_t *r = reinterpret_cast<const uint32_t *>(&tl->y[4 + li][0]);
+                const uint32_t *cr = reinterpret_cast<const uint32_t *>(&tl->c[li >> 3][4 + (li & 7)][0]);
+                uint32_t *oy = reinterpret_cast<uint32_t *>(ss->ost_y[li]);
+                uint32_t *oc = reinterpret_cast<uint32_t *>(ss->ost_c[li >> 3][li & 7]);
+                const bool store_y = li < 13 || last_row, store_c = (li & 7) < 7 || last_row;
+                // a lane stages and flushes only its own rows, and LDS operations of a wavefront complete in order: no sync needed
+                auto flush = [&](int first_mb, int n_mb) { // macroblocks first_mb .. first_mb + n_mb - 1 of this row, n_mb = 1..4
+                    WAVE_SYNC(); // order the dword stores into the staging rows before the wide reads below
+                    uint8_t *Yd = py + static_cast<size_t>(mby * 16 + li) * W + first_mb * 16;
+                    uint8_t *Cd = (li < 8 ? pcb : pcr) + static_cast<size_t>(mby * 8 + (li & 7)) * Wc + first_mb * 8;
+                    const uint4 *sy = reinterpret_cast<const uint4 *>(oy);
+                    const uint2 *sc = reinterpret_cast<const uint2 *>(oc);
+                    if (store_y) {
+                        if (n_mb == 4) {
+                            const uint4 a = sy[0], b = sy[1], c = sy[2], d = sy[3];
+                            uint4 *dst = reinterpret_cast<uint4 *>(Yd);
+                            dst[0] = a, dst[1] = b, dst[2] = c, dst[3] = d;
+                        } else
+                            for (int k = 0; k < n_mb; k++) reinterpret_cast<uint4 *>(Yd)[k] = sy[k];
                     }
-                    if ((li & 7) < 7 || last_row) {
-                        const uint32_t *cr = reinterpret_cast<const uint32_t *>(&tl->c[li >> 3][4 + (li & 7)][0]);
-                        *reinterpret_cast<uint2 *>(Cp + static_cast<size_t>(li & 7) * Wc) = make_uint2(cr[1], cr[2]);
-                        if (has_left) *reinterpret_cast<uint32_t *>(Cp + static_cast<size_t>(li & 7) * Wc - 4) = cr[0];
+                    if (store_c) {
+                        if (n_mb == 4) {
+                            const uint4 a = reinterpret_cast<const uint4 *>(oc)[0], b = reinterpret_cast<const uint4 *>(oc)[1];
+                            reinterpret_cast<uint4 *>(Cd)[0] = a, reinterpret_cast<uint4 *>(Cd)[1] = b;
+                        } else
+                            for (int k = 0; k < n_mb; k++) reinterpret_cast<uint2 *>(Cd)[k] = sc[k];
                     }
+                    WAVE_SYNC(); // ... and the reads before the next group's stores
+                };
+                // columns 12..15 (chroma 4..7) of the macroblock to the left are final now
+                if (has_left) {
+                    const int kl = (k4 + 3) & 3; // its slot in the staging group
+                    oy[kl * 4 + 3] = r[0];
+                    oc[kl * 2 + 1] = cr[0];
+                    if (k4 == 0) flush(mbx - 4, 4); // that completed the previous group
+                }
+                oy[k4 * 4 + 0] = r[1], oy[k4 * 4 + 1] = r[2], oy[k4 * 4 + 2] = r[3];
+                oc[k4 * 2] = cr[1];
+                if (row_end) { // no macroblock to the right: the last columns are final too
+                    oy[k4 * 4 + 3] = r[4];
+                    oc[k4 * 2 + 1] = cr[2];
+                    flush(mbx - k4, k4 + 1);
                 }
                 if (has_top) { // rows -3..-1 (luma), -1 (chroma), columns 0..15 / 0..7: always, the macroblock above never stores them
                     if (li < 3) {
@@ -419,8 +454,8 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
                         dy = reinterpret_cast<uint32_t *>(ss->bot_y[mbx & 3][li & 3]), dc = reinterpret_cast<uint32_t *>(ss->bot_c[mbx & 3][c][r]);
                         if (has_left) dyl = reinterpret_cast<uint32_t *>(&ss->bot_y[(mbx - 1) & 3][li & 3][12]), dcl = reinterpret_cast<uint32_t *>(&ss->bot_c[(mbx - 1) & 3][c][r][4]);
                     } else {
-                        GroupSlot *row = &gring[(g % nwaves) * MI_DEBLOCK_RING];
-                        GroupSlot *gs = &row[mbx & (MI_DEBLOCK_RING - 1)], *gl = &row[(mbx - 1) & (MI_DEBLOCK_RING - 1)];
+                        GroupSlot *row = &gring[(g % nwaves) * ring];
+                        GroupSlot *gs = &row[mbx % ring], *gl = &row[(mbx + ring - 1) % ring];
                         dy = reinterpret_cast<uint32_t *>(gs->y[li & 3]), dc = reinterpret_cast<uint32_t *>(gs->c[c][r]);
                         if (has_left) dyl = reinterpret_cast<uint32_t *>(&gl->y[li & 3][12]), dcl = reinterpret_cast<uint32_t *>(&gl->c[c][r][4]);
                     }

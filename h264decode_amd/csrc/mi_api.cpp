@@ -336,7 +336,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipMalloc(&d->d_tables, sizeof(DevTables)));
     TRY_ALLOC(hipHostMalloc(&d->h_tables, sizeof(DevTables)));
     // K5 keeps a whole macroblock row per in-flight group in dynamic LDS (up to 320 columns): opt in beyond 64 KB
-    TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(mi_deblock_lds_bytes(MI_DEBLOCK_MAX_WAVES))));
+    TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
     build_tables(d->h_tables);
     d->h_pools.resize(S);
     // a deterministic background for macroblocks no slice covers
@@ -902,9 +902,10 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         }
         hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec, coef);
         mark(2);
-        int dbw = mi_deblock_waves(d->hmb_max);
-        if (const char *e = getenv("H264MI_DEBLOCK_WAVES")) dbw = std::min(MI_DEBLOCK_MAX_WAVES, std::max(2, atoi(e))); // experiments
-        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw), rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec);
+        int dbw = 1, dbring = 16;
+        mi_deblock_plan(d->wmb_max, d->hmb_max, &dbw, &dbring);
+        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring), rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec,
+                           dbring);
         mark(3);
     }
     HIP_TRY(hipEventRecord(d->ev_rec[set], rs));
@@ -1055,3 +1056,14 @@ extern "C" int32_t h264mi_frame_read_mbrecs(h264mi_decoder *d, int32_t stream, i
     }
     return H264MI_EINVAL;
 }
+
+// Not part of the public ABI: lets the CPU test-suite check the K5 launch plan (wavefronts, hand-off ring depth,
+// dynamic LDS) without a GPU -- a wrong plan would deadlock the kernel, see mi_deblock_plan().
+extern "C" int32_t h264mi_internal_deblock_plan(int32_t wmb, int32_t hmb, int32_t *nwaves, int32_t *ring, int64_t *lds_bytes) {
+    if (!nwaves || !ring || !lds_bytes || wmb < 1 || hmb < 1) return H264MI_EINVAL;
+    int w = 1, r = 1;
+    mi_deblock_plan(wmb, hmb, &w, &r);
+    *nwaves = w, *ring = r, *lds_bytes = static_cast<int64_t>(mi_deblock_lds_bytes(w, r));
+    return H264MI_OK;
+}
+

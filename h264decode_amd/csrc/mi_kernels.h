@@ -14,21 +14,35 @@ extern "C" __global__ void k_inter(const uint32_t *pic_list, const PicDesc *pics
 extern "C" __global__ void k_intra(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
                                    const int16_t *coefs);
 // K5: in-loop deblocking, one workgroup per picture, one wavefront per group of 4 macroblock rows.
-// block = 64 * nwaves (2..MI_DEBLOCK_MAX_WAVES, or 1 for a single group), dynamic LDS = mi_deblock_lds_bytes(nwaves)
-extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec);
-#define MI_DEBLOCK_MAX_WAVES 12   /* 170 VGPRs -> 3 wavefronts per SIMD */
-#define MI_DEBLOCK_RING 32        /* macroblock columns of the hand-off ring between row groups (power of two) */
-#define MI_DEBLOCK_HDR_BYTES 1088 /* sizeof(DbShared) rounded up to 16 */
-#define MI_DEBLOCK_WAVE_BYTES 8832
+// block = 64 * nwaves, dynamic LDS = mi_deblock_lds_bytes(nwaves, ring); (nwaves, ring) from mi_deblock_plan()
+extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring);
+#define MI_DEBLOCK_MAX_WAVES 9     /* LDS: 14.6 KB of row state per wavefront + its hand-off ring */
+#define MI_DEBLOCK_HDR_BYTES 1088  /* sizeof(DbShared) rounded up to 16 */
+#define MI_DEBLOCK_WAVE_BYTES 14976
 #define MI_DEBLOCK_SLOT_BYTES 96
-static inline size_t mi_deblock_lds_bytes(int nwaves) {
-    return MI_DEBLOCK_HDR_BYTES + static_cast<size_t>(nwaves) * (MI_DEBLOCK_WAVE_BYTES + MI_DEBLOCK_RING * MI_DEBLOCK_SLOT_BYTES);
+#define MI_DEBLOCK_LDS_MAX (160 * 1024)
+static inline size_t mi_deblock_lds_bytes(int nwaves, int ring) {
+    return MI_DEBLOCK_HDR_BYTES + static_cast<size_t>(nwaves) * (MI_DEBLOCK_WAVE_BYTES + static_cast<size_t>(ring) * MI_DEBLOCK_SLOT_BYTES);
 }
-// number of wavefronts for a picture of hmb macroblock rows: fewest rounds over the row groups, then fewest wavefronts
-static inline int mi_deblock_waves(int hmb) {
+// Wavefront count and hand-off ring depth for pictures of wmb x hmb macroblocks.  Fewest rounds over the 4-row groups,
+// then fewest wavefronts.  A group may run at most `ring` columns ahead of the group below it, and the group below
+// the last wavefront's group only starts when wavefront 0 has finished its first group, so nwaves * ring must cover a
+// whole row (otherwise the chain of back-pressure stops wavefront 0 before the end of its row: deadlock).
+static inline void mi_deblock_plan(int wmb, int hmb, int *nwaves, int *ring) {
     const int ngroups = (hmb + 3) / 4;
-    const int rounds = (ngroups + MI_DEBLOCK_MAX_WAVES - 1) / MI_DEBLOCK_MAX_WAVES;
-    return (ngroups + rounds - 1) / rounds;
+    for (int nw = ngroups < MI_DEBLOCK_MAX_WAVES ? ngroups : MI_DEBLOCK_MAX_WAVES; nw >= 1; nw--) {
+        const int rounds = (ngroups + nw - 1) / nw;
+        int w = (ngroups + rounds - 1) / rounds; // fewest wavefronts for that many rounds
+        if (w < 1) w = 1;
+        int r = rounds == 1 ? 16 : (wmb + 16 + w - 1) / w + 8;
+        if (r < 16) r = 16;
+        if (r > wmb) r = wmb > 0 ? wmb : 1; // a whole row never needs back-pressure
+        if (mi_deblock_lds_bytes(w, r) <= MI_DEBLOCK_LDS_MAX) {
+            *nwaves = w, *ring = r;
+            return;
+        }
+    }
+    *nwaves = 1, *ring = wmb > 0 ? wmb : 1;
 }
 // K6: crop + tight pack of one frame into I420
 extern "C" __global__ void k_pack(const uint8_t *src_y, const uint8_t *src_cb, const uint8_t *src_cr, int pitch, int x0, int y0, int w, int h, uint8_t *dst);

@@ -118,3 +118,26 @@ def test_malformed_inputs_return_status_codes(H):
     with pytest.raises(H.H264MIError) as ei:
         H.NewSliceContext(vs, nal, nal.RBSP())
     assert ei.value.code in (-3, -2)
+
+
+def test_deblock_launch_plan_cannot_deadlock(H):
+    """K5 hands rows from one wavefront to the next through a bounded LDS ring with back-pressure.  With several rounds of
+    row groups, the consumer of the last wavefront's group only starts when wavefront 0 has finished its first group, so
+    the rings of all wavefronts together must span a whole macroblock row; and the plan must fit the 160 KB of LDS."""
+    import ctypes
+    L = H.load()
+    f = L.h264mi_internal_deblock_plan
+    f.restype = ctypes.c_int32
+    f.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]
+    for wmb in list(range(1, 40)) + [45, 80, 120, 128, 240, 256, 300, 512]:
+        for hmb in list(range(1, 80)) + [135, 136, 160, 320]:
+            nw, ring, lds = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+            assert f(wmb, hmb, ctypes.byref(nw), ctypes.byref(ring), ctypes.byref(lds)) == 0
+            groups = (hmb + 3) // 4
+            rounds = (groups + nw.value - 1) // nw.value
+            assert 1 <= nw.value <= 9 and 1 <= ring.value and lds.value <= 160 * 1024, (wmb, hmb, nw.value, ring.value, lds.value)
+            if rounds > 1:  # each group runs at most `ring` columns (+6 of stagger) ahead of the next one
+                assert ring.value >= wmb or nw.value * ring.value >= wmb + 6 * nw.value, (wmb, hmb, nw.value, ring.value)
+            else:
+                assert ring.value >= min(wmb, 16)
+
