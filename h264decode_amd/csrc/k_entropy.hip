@@ -26,6 +26,9 @@
 // Register budget: 512 / MI_ENT_MINWAVES VGPRs per wavefront.  The reconstruction kernels of the previous pass
 // must find free registers next to the long-lived entropy wavefronts: measured at 256 streams, 6 (80 VGPRs, a few
 // spills) gives 19.1k frames/s against 18.2k for 4 and 18.4k for 8.
+#ifndef MI_ENT_ISLICE_PRIO
+#define MI_ENT_ISLICE_PRIO 0
+#endif
 #ifndef MI_ENT_MINWAVES
 #define MI_ENT_MINWAVES 6
 #endif
@@ -1209,6 +1212,11 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     e.err = 0;
     e.cabac = RFL(static_cast<int>(pd->cabac));
     e.islice = RFL(static_cast<int>(sd->slice_type == 2));
+#if MI_ENT_ISLICE_PRIO
+    // the I slice of a GOP is the longest wavefront of the launch by far: let it win the instruction arbitration
+    // against the P-slice wavefronts that share its SIMD
+    if (e.islice) __builtin_amdgcn_s_setprio(MI_ENT_ISLICE_PRIO);
+#endif
     e.wmb = RFL(static_cast<int>(pd->wmb)), e.hmb = RFL(static_cast<int>(pd->hmb));
     e.qp = RFL(static_cast<int>(sd->slice_qp));
     e.cip = RFL(static_cast<int>(pd->cip)), e.t8x8_mode = RFL(static_cast<int>(pd->t8x8_mode));

@@ -19,7 +19,9 @@
 
 using namespace mi;
 
+#ifndef MI_SETS
 #define MI_SETS 3
+#endif
 
 #define HIP_TRY(x)                                                                          \
     do {                                                                                    \

@@ -47,4 +47,6 @@ static inline void mi_deblock_plan(int wmb, int hmb, int *nwaves, int *ring) {
 // K6: crop + tight pack of one frame into I420
 extern "C" __global__ void k_pack(const uint8_t *src_y, const uint8_t *src_cb, const uint8_t *src_cr, int pitch, int x0, int y0, int w, int h, uint8_t *dst);
 
+#ifndef MI_INTRA_WAVES
 #define MI_INTRA_WAVES 16
+#endif
