@@ -48,5 +48,5 @@ static inline void mi_deblock_plan(int wmb, int hmb, int *nwaves, int *ring) {
 extern "C" __global__ void k_pack(const uint8_t *src_y, const uint8_t *src_cb, const uint8_t *src_cr, int pitch, int x0, int y0, int w, int h, uint8_t *dst);
 
 #ifndef MI_INTRA_WAVES
-#define MI_INTRA_WAVES 16
+#define MI_INTRA_WAVES 12 /* 768 threads: 170 VGPRs per wavefront (16 wavefronts would cap them at 128 and spill) */
 #endif
