@@ -6,6 +6,9 @@
 // fails (H264MI_ENODEVICE).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <thread>
+#include <functional>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -581,20 +584,14 @@ static int scaling_set_for(h264mi_decoder *d, const h264mi_pps &p) {
 }
 
 // one slice NAL of stream `si`
-static int add_slice(h264mi_decoder *d, int si, const uint8_t *nal, size_t len, int ref_idc, int type) {
+// `off` / `rlen`: where batch_prepare's parallel pass put the slice's RBSP in the pinned staging buffer (16-byte aligned)
+static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref_idc, int type) {
     StreamState &s = d->st[si];
     if (d->n_slices >= d->slices_cap) {
         set_error("more than %d slices in the batch", d->slices_cap);
         return H264MI_ECAPACITY;
     }
-    // unescape straight into the pinned staging buffer, 16-byte aligned
-    size_t off = (d->bits_used + 15) & ~static_cast<size_t>(15);
-    if (off + len + 4096 > d->bits_cap) {
-        set_error("bitstream staging buffer too small (%zu bytes)", d->bits_cap);
-        return H264MI_ECAPACITY;
-    }
     uint8_t *rbsp = d->h_bits + off;
-    size_t rlen = unescape(nal + 1, len - 1, rbsp);
     // peek pps id: first_mb_in_slice, slice_type, pic_parameter_set_id
     BitReader br(rbsp, rlen);
     br.ue();
@@ -724,7 +721,7 @@ static int add_slice(h264mi_decoder *d, int si, const uint8_t *nal, size_t len, 
                 sd.wp_cw[i][j] = static_cast<int16_t>(pps.weighted_pred ? sh.chroma_weight_l0[i][j] : 1), sd.wp_co[i][j] = static_cast<int16_t>(sh.chroma_offset_l0[i][j]);
         }
     }
-    d->bits_used = off + rlen;
+    d->bits_used = std::max(d->bits_used, off + rlen);
     d->n_slices++;
     s.cur_slices++;
     return H264MI_OK;
@@ -746,13 +743,68 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
         s.n_pics_in_batch = 0;
         s.cur_slot = s.cur_pic = -1;
     }
-    std::vector<h264mi_nal> nals;
+    // ---- pass 1 (parallel over streams): Annex-B scan ----
+    const int n_threads = std::max(1, std::min<int>({static_cast<int>(std::thread::hardware_concurrency()), 16, n_streams}));
+    std::vector<std::vector<h264mi_nal>> all_nals(n_streams);
+    std::vector<int> n_nals(n_streams, 0);
+    auto parallel_for = [&](int count, const std::function<void(int)> &fn) {
+        if (n_threads <= 1 || count <= 1) {
+            for (int i = 0; i < count; i++) fn(i);
+            return;
+        }
+        std::atomic<int> next(0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < std::min(n_threads, count); t++)
+            pool.emplace_back([&] {
+                for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i);
+            });
+        for (auto &t : pool) t.join();
+    };
+    parallel_for(n_streams, [&](int si) {
+        if (!bufs[si] || !lens[si]) return;
+        std::vector<h264mi_nal> &v = all_nals[si];
+        v.resize(1024);
+        int n = 0;
+        while (annexb_scan(bufs[si], lens[si], v.data(), static_cast<int>(v.size()), &n) == H264MI_ECAPACITY) v.resize(v.size() * 4);
+        n_nals[si] = n;
+    });
+    // ---- pass 2 (serial, trivial): staging offsets of the slice NALs; the escaped length bounds the RBSP length ----
+    struct Staged {
+        int si, nal;
+        size_t off, rlen;
+    };
+    std::vector<Staged> staged;
+    std::vector<std::vector<int>> staged_of(n_streams); // [stream][nal] -> index into staged or -1
+    {
+        size_t cursor = 0;
+        for (int si = 0; si < n_streams; si++) {
+            staged_of[si].assign(n_nals[si], -1);
+            for (int i = 0; i < n_nals[si]; i++) {
+                const h264mi_nal &nal = all_nals[si][i];
+                if (nal.type != 1 && nal.type != 5) continue;
+                const size_t off = (cursor + 15) & ~static_cast<size_t>(15);
+                if (off + nal.num_bytes + 4096 > d->bits_cap) {
+                    set_error("bitstream staging buffer too small (%zu bytes)", d->bits_cap);
+                    return H264MI_ECAPACITY;
+                }
+                staged_of[si][i] = static_cast<int>(staged.size());
+                staged.push_back({si, i, off, 0});
+                cursor = off + nal.num_bytes;
+            }
+        }
+    }
+    // ---- pass 3 (parallel over slices): remove emulation prevention straight into the pinned staging buffer ----
+    parallel_for(static_cast<int>(staged.size()), [&](int k) {
+        Staged &g = staged[k];
+        const h264mi_nal &nal = all_nals[g.si][g.nal];
+        g.rlen = unescape(bufs[g.si] + nal.offset + 1, nal.num_bytes - 1, d->h_bits + g.off);
+    });
+    // ---- pass 4 (serial): parameter sets, slice headers, DPB / POC / reference lists, descriptors ----
     for (int si = 0; si < n_streams; si++) {
         if (!bufs[si] || !lens[si]) continue;
         StreamState &s = d->st[si];
-        nals.resize(1024);
-        int n = 0;
-        while (annexb_scan(bufs[si], lens[si], nals.data(), static_cast<int>(nals.size()), &n) == H264MI_ECAPACITY) nals.resize(nals.size() * 4);
+        const std::vector<h264mi_nal> &nals = all_nals[si];
+        const int n = n_nals[si];
         std::vector<uint8_t> tmp;
         for (int i = 0; i < n; i++) {
             const h264mi_nal &nal = nals[i];
@@ -790,7 +842,11 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
                 break;
             }
             case 1:
-            case 5: r = add_slice(d, si, p, nal.num_bytes, nal.ref_idc, nal.type); break;
+            case 5: {
+                const Staged &g = staged[staged_of[si][i]];
+                r = add_slice(d, si, g.off, g.rlen, nal.ref_idc, nal.type);
+                break;
+            }
             case 9:
             case 10:
             case 11:
