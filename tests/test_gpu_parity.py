@@ -156,3 +156,19 @@ def test_gpu_4k_high_8_slices(H, sg):
     out, info = _decode_gpu(H, [stream], 3840, 2160, 3, slices=8)
     assert (info.coded_width, info.coded_height) == (3840, 2160)
     assert np.array_equal(out[0], rec)
+
+
+def test_gpu_rejects_out_of_scope_profile(H):
+    """A third-party High 4:4:4 Predictive stream (chroma_format_idc 3) must be refused with a clear status, not mis-decoded."""
+    import os
+    from mp4util import mp4_to_annexb
+    path = "/opt/conda/lib/python3.9/site-packages/imageio/resources/images/cockatoo.mp4"
+    if not os.path.exists(path):
+        pytest.skip("third-party sample MP4 not present on this machine")
+    stream = mp4_to_annexb(open(path, "rb").read())
+    dec = H.Decoder(max_streams=1, max_width=1280, max_height=720, max_frames_per_batch=8, max_slices_per_frame=4)
+    with pytest.raises(H.H264MIError) as ei:
+        dec.decode([stream[:400000]])
+    assert ei.value.code == -3 and "4:2:0" in str(ei.value)  # H264MI_EUNSUPPORTED
+    dec.close()
+
