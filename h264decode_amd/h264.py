@@ -406,3 +406,102 @@ def ByteStreamReader(connection, **kw):
         if hasattr(connection, "close"):
             connection.close()
 
+
+class BatchServer:
+    """Several connections decoded side by side: every connection owns one stream slot of ONE batched Decoder, and each
+    tick hands one chunk (whole access units) per connection that has one to a single h264mi_decode_batch call -- the
+    batch scheduler the reference's per-connection goroutine (main.go:12-21) lacks.  `on_frames(slot, frames)` receives
+    the cropped I420 frames of a connection in decoding order; `on_close(slot, n_frames)` when its peer is done."""
+
+    def __init__(self, max_connections=8, max_width=1920, max_height=1088, frames_per_batch=30, on_frames=None, on_close=None, read_size=1 << 16):
+        self.decoder = Decoder(max_streams=max_connections, max_width=(max_width + 15) // 16 * 16, max_height=(max_height + 15) // 16 * 16,
+                               max_frames_per_batch=frames_per_batch, max_slices_per_frame=16)
+        self.n = max_connections
+        self.frames_per_batch = frames_per_batch
+        self.on_frames, self.on_close, self.read_size = on_frames, on_close, read_size
+        self.conn = [None] * self.n       # socket-like object per slot
+        self.split = [None] * self.n
+        self.queue = [[] for _ in range(self.n)]  # chunks waiting to be decoded
+        self.eof = [False] * self.n
+        self.count = [0] * self.n
+        self.dims = [(0, 0)] * self.n
+
+    def add(self, connection):
+        """Attach a connection to a free slot; returns the slot or -1 when the server is full."""
+        for i in range(self.n):
+            if self.conn[i] is None:
+                self.conn[i], self.split[i], self.queue[i], self.eof[i], self.count[i] = connection, AccessUnitSplitter(self.frames_per_batch), [], False, 0
+                if hasattr(connection, "setblocking"):
+                    connection.setblocking(False)
+                return i
+        return -1
+
+    def _pump(self, i):
+        """Read what the connection has; returns True if anything arrived or it closed."""
+        c = self.conn[i]
+        try:
+            data = c.recv(self.read_size) if hasattr(c, "recv") else c.read(self.read_size)
+        except (BlockingIOError, InterruptedError):
+            return False
+        if data:
+            self.queue[i] += self.split[i].feed(data)
+        else:
+            self.queue[i] += self.split[i].flush()
+            self.eof[i] = True
+        return True
+
+    def tick(self):
+        """One scheduling step: read every connection, decode one chunk per connection in one batch.  Returns the number
+        of frames decoded."""
+        for i in range(self.n):
+            if self.conn[i] is not None and not self.eof[i]:
+                self._pump(i)
+        batch = [self.queue[i].pop(0) if (self.conn[i] is not None and self.queue[i]) else b"" for i in range(self.n)]
+        total = 0
+        if any(batch):
+            self.decoder.decode(batch)
+            for i in range(self.n):
+                if not batch[i]:
+                    continue
+                k = self.decoder.frame_count(i)
+                if not k:
+                    continue
+                p = self.decoder.frame_planes(i, 0)
+                # display size of this stream: parse it from the frames themselves (cropped read fills w*h*3/2 bytes)
+                frames = [self.decoder.read_frame(i, f, crop=True) for f in range(k)]
+                w, h = self._display_size(i, batch[i], p)
+                out = np.stack([fr[:w * h * 3 // 2] for fr in frames])
+                self.count[i] += k
+                total += k
+                if self.on_frames:
+                    self.on_frames(i, out)
+        for i in range(self.n):
+            if self.conn[i] is not None and self.eof[i] and not self.queue[i]:
+                c, n = self.conn[i], self.count[i]
+                self.conn[i] = None
+                if hasattr(c, "close"):
+                    c.close()
+                if self.on_close:
+                    self.on_close(i, n)
+        return total
+
+    def _display_size(self, i, chunk, planes):
+        for nu in read_nal_units(chunk):
+            if nu.Type == 7:
+                sps = NewSPS(nu.RBSP())
+                self.dims[i] = (sps.Width, sps.Height)
+        if self.dims[i] == (0, 0):
+            self.dims[i] = (planes["coded_width"], planes["coded_height"])
+        return self.dims[i]
+
+    def active(self):
+        return sum(c is not None for c in self.conn)
+
+    def run(self, idle_sleep=0.001):
+        """Serve until every attached connection has closed."""
+        import time
+        while self.active():
+            if not self.tick():
+                time.sleep(idle_sleep)
+        return list(self.count)
+

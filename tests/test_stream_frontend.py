@@ -103,3 +103,39 @@ def test_gpu_handle_connection_reads_file_objects(H, sg, oracle_mod):
     got = []
     assert H.handleConnection(io.BytesIO(stream), on_frames=got.append, max_width=64, max_height=48, frames_per_batch=2, read_size=333) == 5
     assert np.array_equal(np.concatenate(got), ref)
+
+
+@pytest.mark.gpu
+def test_gpu_batch_server_decodes_several_connections_side_by_side(H, sg, oracle_mod):
+    cfgs = [dict(width=176, height=144, frames=7, idr_period=3, profile_idc=77, cabac=1, seed=31),
+            dict(width=64, height=48, frames=5, idr_period=0, profile_idc=66, cabac=0, long_start_code=0, seed=32),
+            dict(width=180, height=100, frames=4, idr_period=0, profile_idc=100, cabac=1, transform8x8=1, slices=2, seed=33)]
+    streams = [sg.encode(**c)[0] for c in cfgs]
+    refs = [oracle_mod.decode(s, crop=True)[0] for s in streams]
+    got = {i: [] for i in range(3)}
+    closed = {}
+    srv = H.BatchServer(max_connections=4, max_width=192, max_height=144, frames_per_batch=3,
+                        on_frames=lambda i, f: got[i].append(f), on_close=lambda i, n: closed.__setitem__(i, n))
+    pairs = [socket.socketpair() for _ in streams]
+    slots = [srv.add(b) for _, b in pairs]
+    assert slots == [0, 1, 2]
+
+    def sender(sock, data, seed):
+        rng = random.Random(seed)
+        i = 0
+        while i < len(data):
+            k = rng.randint(1, 3000)
+            sock.sendall(data[i:i + k])
+            i += k
+        sock.close()
+
+    threads = [threading.Thread(target=sender, args=(a, s, 40 + i)) for i, ((a, _), s) in enumerate(zip(pairs, streams))]
+    for t in threads:
+        t.start()
+    counts = srv.run()
+    for t in threads:
+        t.join()
+    assert counts[:3] == [7, 5, 4] and closed == {0: 7, 1: 5, 2: 4}
+    for i in range(3):
+        assert np.array_equal(np.concatenate(got[i]), refs[i]), i
+

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--frames-per-batch", type=int, default=30)
     ap.add_argument("--out", default=None, help="append decoded frames (tight I420) to this file")
     ap.add_argument("--once", action="store_true", help="serve one connection and exit")
+    ap.add_argument("--batch", type=int, default=0, help="decode up to N concurrent connections side by side in one batched decoder (H.BatchServer)")
     args = ap.parse_args()
     srv = socket.socket()
     srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
@@ -31,6 +32,18 @@ def main():
     srv.listen(4)
     print("listening on %s:%d" % (args.host, args.port), flush=True)
     out = open(args.out, "ab") if args.out else None
+    if args.batch > 0:  # several connections, one batched GPU decoder
+        import select
+        bs = H.BatchServer(max_connections=args.batch, max_width=args.max_width, max_height=args.max_height, frames_per_batch=args.frames_per_batch,
+                           on_frames=lambda i, f: print("slot %d: %d frames md5 %s" % (i, len(f), hashlib.md5(f.tobytes()).hexdigest()), flush=True),
+                           on_close=lambda i, n: print("slot %d closed after %d frames" % (i, n), flush=True))
+        srv.setblocking(False)
+        while True:
+            if bs.active() < args.batch and select.select([srv], [], [], 0 if bs.active() else 0.5)[0]:
+                conn, peer = srv.accept()
+                print("%s -> slot %d" % (peer[0], bs.add(conn)), flush=True)
+            if bs.active() and not bs.tick():
+                select.select([c for c in bs.conn if c is not None], [], [], 0.01)
     while True:
         conn, peer = srv.accept()
         total = [0]
