@@ -172,3 +172,17 @@ def test_gpu_rejects_out_of_scope_profile(H):
     assert ei.value.code == -3 and "4:2:0" in str(ei.value)  # H264MI_EUNSUPPORTED
     dec.close()
 
+
+def test_gpu_c_program_through_the_abi(H, sg, oracle_mod, tmp_path):
+    """examples/h264mi_decode.c (plain C, only include/h264mi.h): file in, raw I420 out, several batches."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
+    stream = sg.encode(width=180, height=100, frames=8, idr_period=3, profile_idc=100, cabac=1, transform8x8=1, slices=2, long_start_code=0, seed=77)[0]
+    ref, info = oracle_mod.decode(stream, crop=True)
+    src, dst = tmp_path / "in.h264", tmp_path / "out.yuv"
+    src.write_bytes(stream)
+    subprocess.check_call([os.path.join(root, "examples", "h264mi_decode"), str(src), str(dst), "3"])
+    got = np.frombuffer(dst.read_bytes(), dtype=np.uint8).reshape(-1, info.width * info.height * 3 // 2)
+    assert np.array_equal(got, ref)
+
