@@ -68,11 +68,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
+    # rehearsal hooks (one-GPU box): H264MI_BENCH_DEVICE pins every rank to one device, H264MI_BENCH_BACKEND=gloo replaces RCCL
+    if os.environ.get("H264MI_BENCH_DEVICE"):
+        local_rank = int(os.environ["H264MI_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("H264MI_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     S, F = args.streams, args.frames
     nd = max(1, min(args.distinct, S))

@@ -88,3 +88,23 @@ def test_world_size_2_gloo():
         out, _ = oracle.decode(stream, crop=True)
         want ^= int.from_bytes(hashlib.md5(out.tobytes()).digest()[:7], "big")
     assert tot["checksum"] == want
+
+
+@pytest.mark.gpu
+def test_gpu_bench_two_ranks_rehearsal():
+    """bench.py's multi-rank path (barriers, max-over-ranks time, summed frames, rank-0 JSON) with two ranks sharing the one GPU
+    of the test box over gloo; on the 8-GPU node the same code runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, H264MI_BENCH_DEVICE="0", H264MI_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--streams", "8", "--frames", "4", "--width", "320", "--height", "240"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_step_per_gpu"] == 32 and d["cpu_baseline"] is None
+    assert abs(d["value"] - 2 * 32 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.02  # all ranks' frames over the slowest rank's time
