@@ -16,7 +16,9 @@ extern "C" __global__ void k_intra(const uint32_t *pic_list, const PicDesc *pics
 // K5: in-loop deblocking, one workgroup per picture, one wavefront per group of 4 macroblock rows.
 // block = 64 * nwaves, dynamic LDS = mi_deblock_lds_bytes(nwaves, ring); (nwaves, ring) from mi_deblock_plan()
 extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring);
+#ifndef MI_DEBLOCK_MAX_WAVES
 #define MI_DEBLOCK_MAX_WAVES 9     /* LDS: 14.6 KB of row state per wavefront + its hand-off ring */
+#endif
 #define MI_DEBLOCK_HDR_BYTES 1088  /* sizeof(DbShared) rounded up to 16 */
 #define MI_DEBLOCK_WAVE_BYTES 14976
 #define MI_DEBLOCK_SLOT_BYTES 96
