@@ -46,8 +46,8 @@ def _parse_structs():
 
 
 _S = _parse_structs()
-Nal, Sps, Pps, SliceHdr, Config, BatchInfo = (_S["h264mi_nal"], _S["h264mi_sps"], _S["h264mi_pps"], _S["h264mi_slice_header"],
-                                              _S["h264mi_config"], _S["h264mi_batch_info"])
+Nal, Sps, Pps, SliceHdr, Config, BatchInfo, FrameInfo = (_S["h264mi_nal"], _S["h264mi_sps"], _S["h264mi_pps"], _S["h264mi_slice_header"],
+                                                         _S["h264mi_config"], _S["h264mi_batch_info"], _S["h264mi_frame_info"])
 
 
 def build(force=False):
@@ -83,6 +83,10 @@ def load():
         "h264mi_decoder_destroy": [vp],
         "h264mi_decoder_set_stream": [vp, vp],
         "h264mi_decoder_reset": [vp],
+        "h264mi_stream_reset": [vp, I32],
+        "h264mi_stream_status": [vp, I32, P(I32)],
+        "h264mi_decoder_set_isolation": [vp, I32],
+        "h264mi_frame_get_info": [vp, I32, I32, P(FrameInfo)],
         "h264mi_batch_prepare": [vp, I32, P(vp), P(SZ), P(BatchInfo)],
         "h264mi_batch_execute": [vp],
         "h264mi_batch_sync": [vp],
@@ -118,4 +122,5 @@ EXPORTS = ["h264mi_annexb_scan", "h264mi_nal_parse", "h264mi_sps_parse", "h264mi
            "h264mi_init", "h264mi_decoder_create", "h264mi_decoder_destroy", "h264mi_decoder_set_stream", "h264mi_decoder_reset",
            "h264mi_batch_prepare", "h264mi_batch_execute", "h264mi_batch_sync", "h264mi_decode_batch", "h264mi_stream_frame_count",
            "h264mi_frame_device_planes", "h264mi_frame_read", "h264mi_frame_pack_device", "h264mi_frame_read_mbrecs",
-           "h264mi_decoder_set_profiling", "h264mi_last_kernel_times", "h264mi_last_error_string", "h264mi_version"]
+           "h264mi_decoder_set_profiling", "h264mi_last_kernel_times", "h264mi_last_error_string", "h264mi_version",
+           "h264mi_stream_reset", "h264mi_stream_status", "h264mi_decoder_set_isolation", "h264mi_frame_get_info"]

@@ -148,7 +148,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
     const FramePool *pool = &pools[pd->stream];
-    const int W = static_cast<int>(pool->w), H = static_cast<int>(pool->h), Wc = W / 2;
+    const int W = wmb * 16, H = hmb * 16, Wc = W / 2; // the picture's own geometry
     uint8_t *py = reinterpret_cast<uint8_t *>(pool->base) + static_cast<size_t>(pd->slot) * pool->slot_bytes;
     uint8_t *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
     for (int i = tid; i < 96; i += nthreads) sh.prog[i] = 0, sh.cons[i] = 0;

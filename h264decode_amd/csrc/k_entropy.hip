@@ -1188,6 +1188,13 @@ FI void decode_mb(Ent &e, int skipped) {
     LDS_SYNC();
 }
 
+// All-zero records (type MBT_NONE) for macroblocks [from, to) of the picture: what this slice is responsible for but did
+// not decode.  The reconstruction kernels skip them (K3 paints them mid-grey), K5 finds no edge to filter.
+FI void fill_none(const Ent &e, int from, int to) {
+    const int l = LANE;
+    for (int a = from + (l >> 5); a < to; a += 2) reinterpret_cast<uint32_t *>(e.mbrec + e.mb_base + static_cast<uint64_t>(a))[l & 31] = 0u;
+}
+
 // ------------------------------------------------------------------ kernel: slice_data() 7.3.4
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI_ENT_MINWAVES, 8))) k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
                                                            int16_t *coefs, uint32_t *status, uint32_t *toprows, int wmb_max) {
@@ -1275,9 +1282,10 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         seek(e, pos);
         if (e.cabac) cabac_start(e);
     }
-    const int total = e.wmb * e.hmb;
+    const int total = min(e.wmb * e.hmb, RFL(static_cast<int>(sd->end_mb))); // the next slice's territory is out of bounds
     const uint32_t stop_bit = RFL(sd->stop_bit);
     int addr = RFL(static_cast<int>(sd->first_mb));
+    fill_none(e, RFL(static_cast<int>(sd->fill_from)), min(addr, total)); // a gap in front of the first slice of the picture
     e.mbx = addr % e.wmb, e.mby = addr / e.wmb;
     int more = 1, skip_state = 0 /* 0: read mb_skip_run, 1: inside a run, 2: coded MB follows a run */, pending = 0;
     int n_mbs = 0;
@@ -1316,6 +1324,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         }
         decode_mb(e, skipped);
         MI_T(e, 3);
+        if (e.err) break; // the record of this macroblock cannot be trusted: it is blanked with the rest of the range
         n_mbs++;
         if (e.cabac)
             more = !cabac_terminate(e);
@@ -1331,6 +1340,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         addr++;
         if (++e.mbx == e.wmb) e.mbx = 0, e.mby++;
     }
+    fill_none(e, addr, total); // after an error or an early end of the slice
     if (l == 0) {
         status[8 * blockIdx.x] = static_cast<uint32_t>(e.err);
         status[8 * blockIdx.x + 1] = static_cast<uint32_t>(n_mbs);

@@ -230,7 +230,8 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     __syncthreads();
     const MbRec *rec = &sh.rec;
     const FramePool *pool = &pools[pd->stream];
-    const int W = static_cast<int>(pool->w), H = static_cast<int>(pool->h);
+    const int W = wmb * 16, H = hmb * 16; // the picture's own geometry (the pool's follows the latest SPS of the stream)
+    const int max_slot = static_cast<int>(pool->n_slots) - 1;
     const int mbx = mb % wmb, mby = mb / wmb;
     const uint8_t *pool_base = reinterpret_cast<const uint8_t *>(pool->base);
     const size_t ysz = static_cast<size_t>(W) * H;
@@ -252,7 +253,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
                             rec->refslot[0] >= 0;
         const int uniform = inside && __all(same);
         if (uniform) {
-            const uint8_t *ref = pool_base + static_cast<size_t>(rec->refslot[0]) * pool->slot_bytes;
+            const uint8_t *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rec->refslot[0]), max_slot)) * pool->slot_bytes;
             ox = x0 & 3;
             const int xa = x0 - ox;
             for (int i = lane; i < 21 * 6; i += 64) {
@@ -273,7 +274,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
                 int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
                 int x = mbx * 16 + (b & 3) * 4 + (mvx >> 2) - 2 + wx, y = mby * 16 + (b >> 2) * 4 + (mvy >> 2) - 2 + wy;
                 x = min(max(x, 0), W - 1), y = min(max(y, 0), H - 1);
-                const uint8_t *ref = pool_base + static_cast<size_t>(slot < 0 ? 0 : slot) * pool->slot_bytes;
+                const uint8_t *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool->slot_bytes;
                 sh.win_y[b][wy][wx] = ref[static_cast<size_t>(y) * W + x];
             }
             for (int i = lane; i < 2 * 16 * 9; i += 64) {
@@ -282,7 +283,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
                 int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
                 int x = mbx * 8 + (b & 3) * 2 + (mvx >> 3) + wx, y = mby * 8 + (b >> 2) * 2 + (mvy >> 3) + wy;
                 x = min(max(x, 0), W / 2 - 1), y = min(max(y, 0), H / 2 - 1);
-                const uint8_t *ref = pool_base + static_cast<size_t>(slot < 0 ? 0 : slot) * pool->slot_bytes + ysz + static_cast<size_t>(c) * (ysz / 4);
+                const uint8_t *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool->slot_bytes + ysz + static_cast<size_t>(c) * (ysz / 4);
                 sh.win_c[c][b][wy][wx] = ref[static_cast<size_t>(y) * (W / 2) + x];
             }
         }
@@ -499,6 +500,11 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
     const int Wc = W / 2;
     uint8_t *C0 = pcb + static_cast<size_t>(mby * 8) * Wc + mbx * 8, *C1 = pcr + static_cast<size_t>(mby * 8) * Wc + mbx * 8;
 #define CPL(c) ((c) ? C1 : C0) /* a select, not an indexed pointer array (which would live in scratch) */
+    if (type == MBT_NONE) { // lost macroblock: a defined background instead of whatever the slot held before
+        *reinterpret_cast<uint32_t *>(Y + static_cast<size_t>(lane >> 2) * W + (lane & 3) * 4) = 0x80808080u;
+        if (lane < 32) *reinterpret_cast<uint32_t *>(CPL(lane >> 4) + static_cast<size_t>((lane >> 1) & 7) * Wc + (lane & 1) * 4) = 0x80808080u;
+        return;
+    }
     if (type == MBT_IPCM) { // 8.3.5: samples were stored in the coefficient block
         const uint8_t *pcm = reinterpret_cast<const uint8_t *>(coef);
         { // 256 luma bytes: one dword per lane
@@ -717,7 +723,7 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
     const FramePool *pool = &pools[pd->stream];
-    const int W = static_cast<int>(pool->w), H = static_cast<int>(pool->h);
+    const int W = wmb * 16, H = hmb * 16; // the picture's own geometry
     uint8_t *py = reinterpret_cast<uint8_t *>(pool->base) + static_cast<size_t>(pd->slot) * pool->slot_bytes;
     uint8_t *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
     { // LevelScale tables of this picture's PPS -> LDS (2688 bytes)
@@ -730,8 +736,9 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
     for (int mby = wave; mby < hmb; mby += MI_INTRA_WAVES)
         for (int c = 0; c < nchunks; c++) {
             const int x = c * 64 + lane;
-            const int t = x < wmb ? recs[static_cast<size_t>(mby) * wmb + x].type : 0;
-            const unsigned long long m = __ballot(MB_IS_INTRA(t));
+            const int t = x < wmb ? recs[static_cast<size_t>(mby) * wmb + x].type : -1;
+            // macroblocks no slice delivered (type MBT_NONE) take the intra path too: it paints them mid-grey
+            const unsigned long long m = __ballot(MB_IS_INTRA(t) || t == MBT_NONE);
             if (lane == 0) sh.pend[mby][c] = m;
         }
     __syncthreads();

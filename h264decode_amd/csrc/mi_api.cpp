@@ -113,7 +113,14 @@ static void build_scaling(const uint8_t s4[6][16], const uint8_t s8[2][64], Scal
 struct Slot {
     int ref = 0; // 0 unused, 1 short-term, 2 long-term
     int frame_num = 0, frame_num_wrap = 0, pic_num = 0, long_idx = 0, poc = 0;
-    bool held = false; // output of the current batch: keep until the next prepare
+    // Output of the current batch, or a reference picture at the start of the batch: not reused before the next prepare.
+    // (The second half keeps h264mi_batch_execute repeatable: a slot freed by a marking operation in the middle of the
+    // batch still holds the samples earlier pictures of the batch predict from.)
+    bool held = false;
+};
+struct OutFrame { // a decoded picture of the current batch, with the geometry it was coded with
+    int slot, wmb, hmb, crop_x, crop_y, width, height;
+    int poc, frame_num, nal_ref_idc, idr, pic;
 };
 struct StreamState {
     h264mi_sps sps[32];
@@ -126,8 +133,10 @@ struct StreamState {
     // picture under construction
     int cur_slot = -1, cur_pic = -1, cur_slices = 0;
     h264mi_slice_header first_sh;
-    std::vector<int> out_slots; // frames of this batch in decoding order
+    std::vector<OutFrame> out; // frames of this batch in decoding order
     int n_pics_in_batch = 0;
+    int status = H264MI_OK; // of this stream in the current batch (h264mi_stream_status)
+    bool need_idr = false;  // after an error: nothing is decodable before the next IDR picture
 };
 
 struct h264mi_decoder {
@@ -168,6 +177,7 @@ struct h264mi_decoder {
     std::vector<std::vector<uint32_t>> waves, waves_inter;
     std::vector<uint32_t> wave_off, wave_inter_off;
     bool prepared = false;
+    bool isolate = false; // h264mi_decoder_set_isolation: a broken stream does not fail the batch
     h264mi_batch_info info;
     // profiling
     bool profiling = false;
@@ -178,6 +188,27 @@ struct h264mi_decoder {
 };
 
 static int g_device = -1;
+
+// hipSetDevice is per-thread state: every entry point that takes a decoder selects the decoder's device for the
+// duration of the call and restores the caller's afterwards (callers may be pool threads or migrating goroutines).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(const h264mi_decoder *d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != d->cfg.device) ok = hipSetDevice(d->cfg.device) == hipSuccess;
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define GUARD(d)                                                        \
+    DeviceGuard guard_(d);                                              \
+    if (!guard_.ok) {                                                   \
+        set_error("hipSetDevice(%d) failed", (d)->cfg.device);          \
+        return H264MI_EDEVICE;                                          \
+    }
 
 extern "C" const char *h264mi_last_error_string(void) { return last_error(); }
 extern "C" const char *h264mi_version(void) { return "h264mi 0.1 (gfx950)"; }
@@ -354,6 +385,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
 
 extern "C" int32_t h264mi_decoder_destroy(h264mi_decoder *d) {
     if (!d) return H264MI_EINVAL;
+    GUARD(d);
     for (int i = 0; i < 2; i++) hipStreamSynchronize(d->ent_stream[i]);
     hipStreamSynchronize(d->rec_stream);
     hipStreamSynchronize(d->stream);
@@ -363,20 +395,46 @@ extern "C" int32_t h264mi_decoder_destroy(h264mi_decoder *d) {
 }
 extern "C" int32_t h264mi_decoder_set_stream(h264mi_decoder *d, void *s) {
     if (!d) return H264MI_EINVAL;
+    GUARD(d);
     hipStreamSynchronize(d->stream);
     if (d->own_stream) hipStreamDestroy(d->stream);
     d->own_stream = false;
     d->stream = static_cast<hipStream_t>(s);
     return H264MI_OK;
 }
+// Forget everything about a stream: parameter sets, reference pictures, POC / frame_num history, outputs.
+static void reset_stream(StreamState &s, bool keep_parameter_sets) {
+    for (auto &sl : s.slots) sl = Slot();
+    s.cur_slot = s.cur_pic = -1, s.cur_slices = 0;
+    s.out.clear();
+    s.n_pics_in_batch = 0;
+    s.prev_poc_msb = s.prev_poc_lsb = s.prev_frame_num = s.prev_frame_num_offset = 0;
+    if (!keep_parameter_sets) {
+        memset(s.sps_ok, 0, sizeof(s.sps_ok));
+        memset(s.pps_ok, 0, sizeof(s.pps_ok));
+        s.active_sps = -1, s.wmb = s.hmb = 0;
+        s.need_idr = false, s.status = H264MI_OK;
+    }
+}
 extern "C" int32_t h264mi_decoder_reset(h264mi_decoder *d) {
     if (!d) return H264MI_EINVAL;
-    for (auto &s : d->st) {
-        for (auto &sl : s.slots) sl = Slot();
-        s.cur_slot = s.cur_pic = -1;
-        s.out_slots.clear();
-    }
+    for (auto &s : d->st) reset_stream(s, true);
     d->prepared = false;
+    return H264MI_OK;
+}
+extern "C" int32_t h264mi_stream_reset(h264mi_decoder *d, int32_t stream) {
+    if (!d || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
+    reset_stream(d->st[stream], false);
+    return H264MI_OK;
+}
+extern "C" int32_t h264mi_stream_status(h264mi_decoder *d, int32_t stream, int32_t *status) {
+    if (!d || !status || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
+    *status = d->st[stream].status;
+    return H264MI_OK;
+}
+extern "C" int32_t h264mi_decoder_set_isolation(h264mi_decoder *d, int32_t on) {
+    if (!d) return H264MI_EINVAL;
+    d->isolate = on != 0;
     return H264MI_OK;
 }
 extern "C" int32_t h264mi_decoder_set_profiling(h264mi_decoder *d, int32_t on) {
@@ -532,7 +590,7 @@ static void mark_reference(StreamState &s, const h264mi_sps &sps) {
             } else if (op == 5) {
                 for (auto &sl : s.slots)
                     if (&sl != &cur) sl.ref = 0;
-                cur.frame_num = 0;
+                cur.frame_num = 0, cur.poc = 0; // 8.2.1: tempPicOrderCnt is subtracted, the picture ends up at PicOrderCnt 0
                 s.prev_frame_num = s.prev_frame_num_offset = s.prev_poc_msb = s.prev_poc_lsb = 0;
             } else if (op == 6) {
                 for (auto &o : s.slots)
@@ -558,7 +616,20 @@ static void mark_reference(StreamState &s, const h264mi_sps &sps) {
 static void finish_picture(h264mi_decoder *d, StreamState &s) {
     if (s.cur_slot < 0) return;
     mark_reference(s, s.sps[s.active_sps]);
-    d->h_pics[s.cur_pic].n_slices = static_cast<uint32_t>(s.cur_slices);
+    PicDesc &pd = d->h_pics[s.cur_pic];
+    pd.n_slices = static_cast<uint32_t>(s.cur_slices);
+    if (!s.out.empty()) s.out.back().poc = s.slots[s.cur_slot].poc; // operation 5 rewrites it
+    // Every macroblock of the picture belongs to exactly one slice wavefront (SliceDesc::fill_from / end_mb): order the
+    // slices by first_mb (arbitrary slice order is legal in Baseline); a slice's range ends where the next one starts.
+    std::vector<uint32_t> idx(pd.n_slices);
+    for (uint32_t i = 0; i < pd.n_slices; i++) idx[i] = pd.first_slice + i;
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return d->h_slices[a].first_mb < d->h_slices[b].first_mb; });
+    const uint32_t total = pd.wmb * pd.hmb;
+    for (uint32_t i = 0; i < pd.n_slices; i++) {
+        SliceDesc &sd = d->h_slices[idx[i]];
+        sd.fill_from = i == 0 ? 0 : sd.first_mb;
+        sd.end_mb = i + 1 < pd.n_slices ? std::max(d->h_slices[idx[i + 1]].first_mb, sd.first_mb) : total;
+    }
     s.cur_slot = s.cur_pic = -1;
 }
 
@@ -611,6 +682,10 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
     int r = parse_slice_header(&sps, &pps, ref_idc, type, rbsp, rlen, &sh);
     if (r != H264MI_OK) return r;
     if (sh.redundant_pic_cnt > 0) return H264MI_OK; // redundant pictures are dropped
+    if (s.need_idr) { // after an error nothing can be trusted before the next IDR picture
+        if (type != 5) return H264MI_OK;
+        s.need_idr = false;
+    }
     const int st = sh.slice_type % 5;
     if (st != 0 && st != 2) {
         set_error("stream %d: slice_type %d is out of scope (I and P only)", si, sh.slice_type);
@@ -636,6 +711,7 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         fp.base = reinterpret_cast<uint64_t>(d->d_frames) + static_cast<uint64_t>(si) * d->slot_bytes * d->n_slots;
         fp.slot_bytes = d->slot_bytes;
         fp.w = wmb * 16, fp.h = hmb * 16;
+        fp.n_slots = static_cast<uint32_t>(d->n_slots);
     }
     if (s.cur_slot < 0) { // first slice of a new picture
         if (s.n_pics_in_batch >= d->cfg.max_frames_per_batch || d->n_pics >= d->pics_cap) {
@@ -679,7 +755,8 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         }
         pd.scaling_set = static_cast<uint8_t>(ss);
         pd.order = s.n_pics_in_batch++;
-        s.out_slots.push_back(slot);
+        s.out.push_back({slot, wmb, hmb, 2 * sps.frame_crop_left_offset, 2 * sps.frame_crop_top_offset, sps.width, sps.height, sl.poc, sh.frame_num,
+                         sh.nal_ref_idc, sh.nal_unit_type == 5, s.cur_pic});
         d->wmb_max = std::max(d->wmb_max, wmb);
         d->hmb_max = std::max(d->hmb_max, hmb);
         d->mbs_max = std::max(d->mbs_max, wmb * hmb);
@@ -729,6 +806,7 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
 
 extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, const uint8_t *const *bufs, const size_t *lens, h264mi_batch_info *info) {
     if (!d || n_streams < 0 || n_streams > static_cast<int>(d->st.size()) || (n_streams && (!bufs || !lens))) return H264MI_EINVAL;
+    GUARD(d);
     auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(d->ent_stream[i])); // the previous batch must not be reading the staging buffers
     HIP_TRY(hipStreamSynchronize(d->rec_stream));
@@ -738,10 +816,11 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     d->bits_used = 0, d->mb_used = 0, d->wmb_max = 0, d->hmb_max = 0, d->mbs_max = 0;
     memset(&d->info, 0, sizeof(d->info));
     for (auto &s : d->st) {
-        for (auto &sl : s.slots) sl.held = false;
-        s.out_slots.clear();
+        for (auto &sl : s.slots) sl.held = sl.ref != 0; // reference pictures at batch start stay put for the whole batch
+        s.out.clear();
         s.n_pics_in_batch = 0;
         s.cur_slot = s.cur_pic = -1;
+        s.status = H264MI_OK;
     }
     // ---- pass 1 (parallel over streams): Annex-B scan ----
     const int n_threads = std::max(1, std::min<int>({static_cast<int>(std::thread::hardware_concurrency()), 16, n_streams}));
@@ -800,16 +879,21 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
         g.rlen = unescape(bufs[g.si] + nal.offset + 1, nal.num_bytes - 1, d->h_bits + g.off);
     });
     // ---- pass 4 (serial): parameter sets, slice headers, DPB / POC / reference lists, descriptors ----
+    int first_error = H264MI_OK;
     for (int si = 0; si < n_streams; si++) {
         if (!bufs[si] || !lens[si]) continue;
         StreamState &s = d->st[si];
         const std::vector<h264mi_nal> &nals = all_nals[si];
         const int n = n_nals[si];
         std::vector<uint8_t> tmp;
-        for (int i = 0; i < n; i++) {
+        // what this stream adds to the batch sits at the tail of every table: a failing stream is taken out again
+        const int pics0 = d->n_pics, slices0 = d->n_slices;
+        const uint64_t mb0 = d->mb_used;
+        const int64_t info_mb0 = d->info.n_macroblocks;
+        int r = H264MI_OK;
+        for (int i = 0; i < n && r == H264MI_OK; i++) {
             const h264mi_nal &nal = nals[i];
             const uint8_t *p = bufs[si] + nal.offset;
-            int r = H264MI_OK;
             switch (nal.type) {
             case 7: {
                 tmp.resize(nal.num_bytes);
@@ -854,7 +938,17 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
                 break;
             default: break; // SEI, filler, ... (h264/server.go:147-164 ignores them too)
             }
-            if (r != H264MI_OK) return r;
+        }
+        if (r != H264MI_OK) {
+            // The stream leaves the batch: its pictures, slices and records are dropped, its references are forgotten
+            // (nothing is decodable before its next IDR picture); the other streams are not affected.
+            d->n_pics = pics0, d->n_slices = slices0, d->mb_used = mb0, d->info.n_macroblocks = info_mb0;
+            reset_stream(s, true);
+            s.need_idr = true;
+            s.status = r;
+            if (first_error == H264MI_OK) first_error = r;
+            if (!d->isolate) return r;
+            continue;
         }
         if (s.cur_slot >= 0) finish_picture(d, s);
     }
@@ -924,6 +1018,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         return H264MI_EINVAL;
     }
     if (!d->n_slices) return H264MI_OK;
+    GUARD(d);
     size_t ei = 0;
     const bool prof = d->profiling;
     auto mark = [&](int kind) {
@@ -977,6 +1072,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
 
 extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
     if (!d) return H264MI_EINVAL;
+    GUARD(d);
     for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(d->ent_stream[i]));
     HIP_TRY(hipStreamSynchronize(d->rec_stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
@@ -1002,14 +1098,22 @@ extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
         fprintf(stderr, "last slice type %d bytes %u mbs %u us %.1f bins %u\n", d->h_slices[d->n_slices - 1].slice_type, d->h_slices[d->n_slices - 1].rbsp_size,
                 d->h_status[8 * (d->n_slices - 1) + 1], d->h_status[8 * (d->n_slices - 1) + 2] * 0.01, d->h_status[8 * (d->n_slices - 1) + 3]);
     }
+    int result = H264MI_OK;
     for (int i = 0; i < d->n_slices; i++)
         if (d->h_status[8 * i]) {
             const SliceDesc &sd = d->h_slices[i];
-            set_error("entropy kernel: slice %d (picture %u, stream %u) failed with code %u after %u macroblocks", i, sd.pic_idx, d->h_pics[sd.pic_idx].stream,
-                      d->h_status[8 * i], d->h_status[8 * i + 1]);
-            return H264MI_EDECODE;
+            StreamState &s = d->st[d->h_pics[sd.pic_idx].stream];
+            if (result == H264MI_OK)
+                set_error("entropy kernel: slice %d (picture %u, stream %u) failed with code %u after %u macroblocks", i, sd.pic_idx, d->h_pics[sd.pic_idx].stream,
+                          d->h_status[8 * i], d->h_status[8 * i + 1]);
+            if (s.status == H264MI_OK) { // the stream's pictures from here on are damaged: nothing is decodable before its next IDR
+                s.status = H264MI_EDECODE;
+                for (auto &sl : s.slots) sl.ref = 0;
+                s.need_idr = true;
+            }
+            result = H264MI_EDECODE;
         }
-    return H264MI_OK;
+    return d->isolate ? H264MI_OK : result;
 }
 
 extern "C" int32_t h264mi_decode_batch(h264mi_decoder *d, int32_t n, const uint8_t *const *bufs, const size_t *lens, h264mi_batch_info *info) {
@@ -1028,25 +1132,26 @@ extern "C" int32_t h264mi_last_kernel_times(h264mi_decoder *d, double ms[5]) {
 
 extern "C" int32_t h264mi_stream_frame_count(h264mi_decoder *d, int32_t stream, int32_t *n) {
     if (!d || !n || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
-    *n = static_cast<int32_t>(d->st[stream].out_slots.size());
+    *n = static_cast<int32_t>(d->st[stream].out.size());
     return H264MI_OK;
 }
 
-static int frame_ptrs(h264mi_decoder *d, int stream, int frame, uint8_t **y, int *W, int *H) {
+static int frame_ptrs(h264mi_decoder *d, int stream, int frame, uint8_t **y, const OutFrame **of) {
     if (!d || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
     StreamState &s = d->st[stream];
-    if (frame < 0 || frame >= static_cast<int>(s.out_slots.size())) return H264MI_EINVAL;
-    *W = s.wmb * 16, *H = s.hmb * 16;
-    *y = d->d_frames + (static_cast<size_t>(stream) * d->n_slots + s.out_slots[frame]) * d->slot_bytes;
+    if (frame < 0 || frame >= static_cast<int>(s.out.size())) return H264MI_EINVAL;
+    *of = &s.out[frame];
+    *y = d->d_frames + (static_cast<size_t>(stream) * d->n_slots + s.out[frame].slot) * d->slot_bytes;
     return H264MI_OK;
 }
 
 extern "C" int32_t h264mi_frame_device_planes(h264mi_decoder *d, int32_t stream, int32_t frame, void **y, void **cb, void **cr, int32_t *pitch_y, int32_t *pitch_c,
                                               int32_t *cw, int32_t *ch) {
     uint8_t *p;
-    int W, H;
-    int r = frame_ptrs(d, stream, frame, &p, &W, &H);
+    const OutFrame *of;
+    int r = frame_ptrs(d, stream, frame, &p, &of);
     if (r != H264MI_OK) return r;
+    const int W = of->wmb * 16, H = of->hmb * 16;
     if (y) *y = p;
     if (cb) *cb = p + static_cast<size_t>(W) * H;
     if (cr) *cr = p + static_cast<size_t>(W) * H * 5 / 4;
@@ -1057,22 +1162,34 @@ extern "C" int32_t h264mi_frame_device_planes(h264mi_decoder *d, int32_t stream,
     return H264MI_OK;
 }
 
-static void crop_rect(const h264mi_sps &sps, int crop, int W, int H, int *x0, int *y0, int *w, int *h) {
-    *x0 = *y0 = 0, *w = W, *h = H;
-    if (crop) {
-        *x0 = 2 * sps.frame_crop_left_offset, *y0 = 2 * sps.frame_crop_top_offset;
-        *w = sps.width, *h = sps.height;
-    }
+extern "C" int32_t h264mi_frame_get_info(h264mi_decoder *d, int32_t stream, int32_t frame, h264mi_frame_info *fi) {
+    uint8_t *p;
+    const OutFrame *of;
+    int r = frame_ptrs(d, stream, frame, &p, &of);
+    if (r != H264MI_OK) return r;
+    if (!fi) return H264MI_EINVAL;
+    fi->width = of->width, fi->height = of->height, fi->coded_width = of->wmb * 16, fi->coded_height = of->hmb * 16;
+    fi->crop_x = of->crop_x, fi->crop_y = of->crop_y;
+    fi->pic_order_cnt = of->poc, fi->frame_num = of->frame_num, fi->nal_ref_idc = of->nal_ref_idc, fi->idr = of->idr;
+    return H264MI_OK;
+}
+
+// the picture's own geometry (a new SPS may have activated later in the same batch)
+static void crop_rect(const OutFrame *of, int crop, int *x0, int *y0, int *w, int *h) {
+    *x0 = *y0 = 0, *w = of->wmb * 16, *h = of->hmb * 16;
+    if (crop) *x0 = of->crop_x, *y0 = of->crop_y, *w = of->width, *h = of->height;
 }
 
 extern "C" int32_t h264mi_frame_read(h264mi_decoder *d, int32_t stream, int32_t frame, int32_t crop, uint8_t *dst, size_t cap) {
     uint8_t *p;
-    int W, H, x0, y0, w, h;
-    int r = frame_ptrs(d, stream, frame, &p, &W, &H);
+    const OutFrame *of;
+    int x0, y0, w, h;
+    int r = frame_ptrs(d, stream, frame, &p, &of);
     if (r != H264MI_OK) return r;
     if (!dst) return H264MI_EINVAL;
-    StreamState &s = d->st[stream];
-    crop_rect(s.sps[s.active_sps], crop, W, H, &x0, &y0, &w, &h);
+    GUARD(d);
+    const int W = of->wmb * 16, H = of->hmb * 16;
+    crop_rect(of, crop, &x0, &y0, &w, &h);
     if (cap < static_cast<size_t>(w) * h * 3 / 2) return H264MI_ECAPACITY;
     HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(hipMemcpy2D(dst, w, p + static_cast<size_t>(y0) * W + x0, W, w, h, hipMemcpyDeviceToHost));
@@ -1086,12 +1203,14 @@ extern "C" int32_t h264mi_frame_read(h264mi_decoder *d, int32_t stream, int32_t 
 
 extern "C" int32_t h264mi_frame_pack_device(h264mi_decoder *d, int32_t stream, int32_t frame, void *dst, size_t cap) {
     uint8_t *p;
-    int W, H, x0, y0, w, h;
-    int r = frame_ptrs(d, stream, frame, &p, &W, &H);
+    const OutFrame *of;
+    int x0, y0, w, h;
+    int r = frame_ptrs(d, stream, frame, &p, &of);
     if (r != H264MI_OK) return r;
     if (!dst) return H264MI_EINVAL;
-    StreamState &s = d->st[stream];
-    crop_rect(s.sps[s.active_sps], 1, W, H, &x0, &y0, &w, &h);
+    GUARD(d);
+    const int W = of->wmb * 16, H = of->hmb * 16;
+    crop_rect(of, 1, &x0, &y0, &w, &h);
     if (cap < static_cast<size_t>(w) * h * 3 / 2) return H264MI_ECAPACITY;
     const uint8_t *cb = p + static_cast<size_t>(W) * H, *cr = cb + static_cast<size_t>(W) * H / 4;
     int total = w * h * 3 / 2;
@@ -1102,6 +1221,7 @@ extern "C" int32_t h264mi_frame_pack_device(h264mi_decoder *d, int32_t stream, i
 
 extern "C" int32_t h264mi_frame_read_mbrecs(h264mi_decoder *d, int32_t stream, int32_t frame, uint8_t *rec, size_t cap) {
     if (!d || !rec || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
+    GUARD(d);
     for (int i = 0; i < d->n_pics; i++) {
         const PicDesc &pd = d->h_pics[i];
         if (static_cast<int>(pd.stream) == stream && static_cast<int>(pd.order) == frame) {
@@ -1113,6 +1233,23 @@ extern "C" int32_t h264mi_frame_read_mbrecs(h264mi_decoder *d, int32_t stream, i
         }
     }
     return H264MI_EINVAL;
+}
+
+// Not part of the public ABI: fills every intermediate buffer (macroblock records, coefficient blocks, row state) with
+// 0xFF so that a test can prove that no kernel depends on what an earlier batch -- or the allocator -- left there.
+extern "C" int32_t h264mi_internal_poison(h264mi_decoder *d) {
+    if (!d) return H264MI_EINVAL;
+    GUARD(d);
+    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(d->ent_stream[i]));
+    HIP_TRY(hipStreamSynchronize(d->rec_stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    for (int i = 0; i < MI_SETS; i++) {
+        HIP_TRY(hipMemset(d->d_mbrec[i], 0xFF, sizeof(MbRec) * d->mb_cap));
+        HIP_TRY(hipMemset(d->d_coef[i], 0xFF, sizeof(int16_t) * MI_COEF_PER_MB * d->mb_cap));
+        HIP_TRY(hipMemset(d->d_toprows[i], 0xFF, static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * 48));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return H264MI_OK;
 }
 
 // Not part of the public ABI: lets the CPU test-suite check the K5 launch plan (wavefronts, hand-off ring depth,

@@ -311,6 +311,32 @@ int parse_sps(const uint8_t *rbsp, size_t len, h264mi_sps *s) {
         set_error("SPS: truncated or bad id");
         return H264MI_EBITSTREAM;
     }
+    // Range checks (7.4.2.1.1, Annex A): these fields later size buffers, shift counts and addresses, and the input may
+    // come straight from a socket -- ue(v) can carry anything up to 2^32 - 2.
+    {
+        const uint32_t wmb1 = static_cast<uint32_t>(s->pic_width_in_mbs_minus1), hmu1 = static_cast<uint32_t>(s->pic_height_in_map_units_minus1);
+        const char *bad = nullptr;
+        if (static_cast<uint32_t>(s->log2_max_frame_num_minus4) > 12) bad = "log2_max_frame_num_minus4 > 12";
+        else if (static_cast<uint32_t>(s->pic_order_count_type) > 2) bad = "pic_order_cnt_type > 2";
+        else if (static_cast<uint32_t>(s->log2_max_pic_order_cnt_lsb_min4) > 12) bad = "log2_max_pic_order_cnt_lsb_minus4 > 12";
+        else if (static_cast<uint32_t>(s->max_num_ref_frames) > 16) bad = "max_num_ref_frames > 16";
+        else if (wmb1 >= 512) bad = "pic_width_in_mbs > 512";
+        else if (hmu1 >= 320 || (hmu1 + 1) * (2 - s->frame_mbs_only) > 320) bad = "pic_height_in_mbs > 320";
+        else if (static_cast<uint32_t>(s->chroma_format) > 3) bad = "chroma_format_idc > 3";
+        else if (static_cast<uint32_t>(s->bit_depth_luma_minus8) > 6 || static_cast<uint32_t>(s->bit_depth_chroma_minus8) > 6) bad = "bit depth > 14";
+        else {
+            // cropping (7-18 .. 7-21) in 4:2:0 frame units of 2 luma samples: what remains must be a non-empty part of the coded picture
+            const uint32_t cl = static_cast<uint32_t>(s->frame_crop_left_offset), cr = static_cast<uint32_t>(s->frame_crop_right_offset);
+            const uint32_t ct = static_cast<uint32_t>(s->frame_crop_top_offset), cb = static_cast<uint32_t>(s->frame_crop_bottom_offset);
+            const uint32_t W = (wmb1 + 1) * 16, H = (hmu1 + 1) * (2 - s->frame_mbs_only) * 16, vy = 2 * (2 - s->frame_mbs_only);
+            if (cl > W || cr > W || 2 * (static_cast<uint64_t>(cl) + cr) >= W) bad = "horizontal cropping leaves no picture";
+            else if (ct > H || cb > H || vy * (static_cast<uint64_t>(ct) + cb) >= H) bad = "vertical cropping leaves no picture";
+        }
+        if (bad) {
+            set_error("SPS: %s", bad);
+            return H264MI_EBITSTREAM;
+        }
+    }
     // PicWidthInMbs / PicHeightInMbs (h264/slice.go:159-176), cropped size (7-18..7-21, 4:2:0 frame)
     s->pic_width_in_mbs = s->pic_width_in_mbs_minus1 + 1;
     s->pic_height_in_mbs = (s->pic_height_in_map_units_minus1 + 1) * (2 - s->frame_mbs_only);

@@ -60,6 +60,11 @@ typedef struct {
     uint32_t stop_bit;     /* bit position of rbsp_stop_one_bit (more_rbsp_data() for CAVLC) */
     uint32_t pic_idx;
     uint32_t first_mb;
+    /* Macroblock range this slice's wavefront is responsible for: [fill_from, end_mb).  It decodes from first_mb and may
+     * not pass end_mb (the next slice of the picture, or the picture size); whatever it does not decode inside the range
+     * -- a gap in front of the slice, the rest after an error or an early end -- gets all-zero records (type MBT_NONE),
+     * so that the reconstruction kernels never see stale or uninitialised records. */
+    uint32_t fill_from, end_mb;
     uint8_t slice_type;    /* 0 P, 2 I */
     uint8_t cabac_init_idc, slice_qp, num_ref_idx_active;
     int8_t alpha_off, beta_off;
@@ -87,8 +92,9 @@ typedef struct {
 typedef struct {
     uint64_t base;       /* device address of slot 0 */
     uint64_t slot_bytes; /* bytes per slot (Y + Cb + Cr) */
-    uint32_t w, h;       /* coded luma size; pitch = w, chroma pitch = w/2 */
-    uint32_t pad[2];
+    uint32_t w, h;       /* coded luma size of the active sequence (kernels take the geometry of a picture from its PicDesc) */
+    uint32_t n_slots;    /* slots in this pool: reference slots in MbRecs are clamped to it */
+    uint32_t pad;
 } FramePool;
 
 /* LevelScale(m,i,j) of 8.5.9 for one PPS: [list][qp%6][raster position] */

@@ -189,6 +189,25 @@ class Decoder:
     def reset(self):
         check(self._L.h264mi_decoder_reset(self._h))
 
+    def reset_stream(self, stream):
+        """Forget parameter sets, reference pictures and POC history of one stream slot (a new connection takes it over)."""
+        check(self._L.h264mi_stream_reset(self._h, stream))
+
+    def set_isolation(self, on=True):
+        """With isolation a broken stream is dropped from the batch and marked instead of failing prepare() / sync()."""
+        check(self._L.h264mi_decoder_set_isolation(self._h, int(on)))
+
+    def stream_status(self, stream):
+        st = ctypes.c_int32(0)
+        check(self._L.h264mi_stream_status(self._h, stream, ctypes.byref(st)))
+        return st.value
+
+    def frame_info(self, stream, frame):
+        """h264mi_frame_info of a decoded frame: display / coded size, crop origin, PicOrderCnt, frame_num, nal_ref_idc, idr."""
+        fi = _lib.FrameInfo()
+        check(self._L.h264mi_frame_get_info(self._h, stream, frame, ctypes.byref(fi)))
+        return fi
+
     def set_profiling(self, on=True):
         check(self._L.h264mi_decoder_set_profiling(self._h, int(on)))
 
@@ -248,6 +267,12 @@ class Decoder:
         buf = np.zeros(p["coded_width"] * p["coded_height"] * 3 // 2, dtype=np.uint8)
         check(self._L.h264mi_frame_read(self._h, stream, frame, int(crop), buf.ctypes.data, buf.nbytes))
         return buf
+
+    def read_frame_tight(self, stream, frame, crop=True):
+        """The frame as exactly w*h*3/2 bytes of its own geometry (display size when cropped)."""
+        fi = self.frame_info(stream, frame)
+        w, h = (fi.width, fi.height) if crop else (fi.coded_width, fi.coded_height)
+        return self.read_frame(stream, frame, crop)[:w * h * 3 // 2]
 
     def read_frames(self, stream=0, crop=False, size=None):
         """All frames of `stream` from the last batch as uint8[n, w*h*3/2] (tight I420)."""
@@ -416,6 +441,8 @@ class BatchServer:
     def __init__(self, max_connections=8, max_width=1920, max_height=1088, frames_per_batch=30, on_frames=None, on_close=None, read_size=1 << 16):
         self.decoder = Decoder(max_streams=max_connections, max_width=(max_width + 15) // 16 * 16, max_height=(max_height + 15) // 16 * 16,
                                max_frames_per_batch=frames_per_batch, max_slices_per_frame=16)
+        self.decoder.set_isolation(True)  # one bad client must not take the other connections' chunks down with it
+        self.errors = [0] * max_connections
         self.n = max_connections
         self.frames_per_batch = frames_per_batch
         self.on_frames, self.on_close, self.read_size = on_frames, on_close, read_size
@@ -431,6 +458,8 @@ class BatchServer:
         for i in range(self.n):
             if self.conn[i] is None:
                 self.conn[i], self.split[i], self.queue[i], self.eof[i], self.count[i] = connection, AccessUnitSplitter(self.frames_per_batch), [], False, 0
+                self.dims[i], self.errors[i] = (0, 0), 0
+                self.decoder.reset_stream(i)  # nothing of the slot's previous client (parameter sets, reference pictures) survives
                 if hasattr(connection, "setblocking"):
                     connection.setblocking(False)
                 return i
@@ -463,18 +492,27 @@ class BatchServer:
             for i in range(self.n):
                 if not batch[i]:
                     continue
+                st = self.decoder.stream_status(i)
+                if st != 0:  # this connection's chunk was malformed / out of scope: close it, the others go on
+                    self.errors[i] = st
+                    self.queue[i] = []
+                    self.eof[i] = True
+                    continue
                 k = self.decoder.frame_count(i)
                 if not k:
                     continue
-                p = self.decoder.frame_planes(i, 0)
-                # display size of this stream: parse it from the frames themselves (cropped read fills w*h*3/2 bytes)
-                frames = [self.decoder.read_frame(i, f, crop=True) for f in range(k)]
-                w, h = self._display_size(i, batch[i], p)
-                out = np.stack([fr[:w * h * 3 // 2] for fr in frames])
+                frames = [self.decoder.read_frame_tight(i, f, crop=True) for f in range(k)]
+                fi = self.decoder.frame_info(i, k - 1)
+                self.dims[i] = (fi.width, fi.height)
+                # frames of one geometry go out together (a chunk may span a resolution change)
+                start = 0
+                for f in range(1, k + 1):
+                    if f == k or len(frames[f]) != len(frames[start]):
+                        if self.on_frames:
+                            self.on_frames(i, np.stack(frames[start:f]))
+                        start = f
                 self.count[i] += k
                 total += k
-                if self.on_frames:
-                    self.on_frames(i, out)
         for i in range(self.n):
             if self.conn[i] is not None and self.eof[i] and not self.queue[i]:
                 c, n = self.conn[i], self.count[i]
@@ -484,15 +522,6 @@ class BatchServer:
                 if self.on_close:
                     self.on_close(i, n)
         return total
-
-    def _display_size(self, i, chunk, planes):
-        for nu in read_nal_units(chunk):
-            if nu.Type == 7:
-                sps = NewSPS(nu.RBSP())
-                self.dims[i] = (sps.Width, sps.Height)
-        if self.dims[i] == (0, 0):
-            self.dims[i] = (planes["coded_width"], planes["coded_height"])
-        return self.dims[i]
 
     def active(self):
         return sum(c is not None for c in self.conn)

@@ -12,7 +12,10 @@
  *  - every function returns an int32 status (0 = OK, negative = H264MI_E*); nothing aborts or
  *    throws across the boundary (the reference panics/os.Exit()s: h264/server.go:136-143).
  *  - caller owns input buffers for the duration of the call only; the library owns device memory.
- *  - a decoder handle is single-threaded; distinct handles are independent.
+ *  - threading: a decoder handle is used by one thread at a time (any thread: every entry point selects the decoder's
+ *    HIP device for the duration of the call and restores the caller's); distinct handles are independent.  The error
+ *    text of h264mi_last_error_string() is thread-local: fetch it on the thread that received the status (a Go caller
+ *    wraps call + fetch in runtime.LockOSThread).
  *  - the pixel path runs ONLY on the GPU (HIP, gfx950).  There is no CPU fallback: without a
  *    usable device h264mi_init / h264mi_decoder_create fail with H264MI_ENODEVICE.
  *
@@ -163,6 +166,17 @@ int32_t h264mi_decoder_destroy(h264mi_decoder *dec);
 int32_t h264mi_decoder_set_stream(h264mi_decoder *dec, void *hip_stream);
 /* Forget all reference pictures of every stream (seek / new sequence). */
 int32_t h264mi_decoder_reset(h264mi_decoder *dec);
+/* Forget everything about ONE stream slot -- parameter sets, reference pictures, POC / frame_num history -- before the
+ * slot is given to a new connection (the reference starts every connection from scratch: h264/server.go:113-125). */
+int32_t h264mi_stream_reset(h264mi_decoder *dec, int32_t stream);
+/* Error isolation for batches of unrelated streams (one connection each).  Off (default): the first stream error fails
+ * h264mi_batch_prepare / h264mi_batch_sync.  On: a stream whose chunk cannot be parsed, or whose slices fail in the
+ * entropy kernel, is dropped from the batch and marked; the calls return H264MI_OK and the other streams decode
+ * normally.  A marked stream resumes at its next IDR picture. */
+int32_t h264mi_decoder_set_isolation(h264mi_decoder *dec, int32_t on);
+/* Status of a stream in the current batch: H264MI_OK or the H264MI_E* that took it out (valid after prepare; entropy
+ * kernel failures appear after sync). */
+int32_t h264mi_stream_status(h264mi_decoder *dec, int32_t stream, int32_t *status);
 
 /* Stage 1 (host + H2D): scan and parse each stream's Annex-B chunk (whole access units), run
  * picture management (POC 8.2.1, reference lists 8.2.4, marking 8.2.5), and make the RBSP bytes
@@ -184,6 +198,13 @@ int32_t h264mi_stream_frame_count(h264mi_decoder *dec, int32_t stream, int32_t *
  * next h264mi_batch_prepare). */
 int32_t h264mi_frame_device_planes(h264mi_decoder *dec, int32_t stream, int32_t frame, void **y, void **cb, void **cr, int32_t *pitch_y,
                                    int32_t *pitch_c, int32_t *coded_width, int32_t *coded_height);
+/* Geometry and picture-order data of a decoded frame (the picture's own SPS: a batch may span a resolution change). */
+typedef struct {
+    int32_t width, height, coded_width, coded_height, crop_x, crop_y; /* display size, coded size, crop origin (luma samples) */
+    int32_t pic_order_cnt;                                            /* PicOrderCnt(CurrPic) 8.2.1, after a possible MMCO 5 */
+    int32_t frame_num, nal_ref_idc, idr;
+} h264mi_frame_info;
+int32_t h264mi_frame_get_info(h264mi_decoder *dec, int32_t stream, int32_t frame, h264mi_frame_info *info);
 /* Copy a frame to host memory as tight I420 (crop != 0: display size, else coded size). */
 int32_t h264mi_frame_read(h264mi_decoder *dec, int32_t stream, int32_t frame, int32_t crop, uint8_t *dst, size_t cap);
 /* Cropped, tightly packed I420 copy on the device (K6): dst is a DEVICE pointer. */

@@ -39,8 +39,15 @@ def lib():
         L.h264o_decode_stream.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(StreamInfo)]
         L.h264o_set_mb_trace.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        L.h264o_last_features.argtypes = [ctypes.c_void_p]
+        L.h264o_last_features.restype = ctypes.c_uint32
+        L.h264o_last_pocs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         _lib = L
     return _lib
+
+
+last_features = 0   # picture-management operations the last decode() executed (bit set, see h264o.h)
+last_pocs = np.zeros(0, dtype=np.int32)  # PicOrderCnt of every picture the last decode() produced
 
 
 class OracleError(RuntimeError):
@@ -83,6 +90,11 @@ def decode(stream: bytes, crop=True, trace=False, info=None):
         r = L.h264o_decode_stream(d, stream, len(stream), int(crop), out.ctypes.data, out.nbytes, ctypes.byref(info))
         if r < 0:
             raise OracleError(L.h264o_last_error(d).decode())
+        global last_features, last_pocs
+        last_features = int(L.h264o_last_features(d))
+        n = L.h264o_last_pocs(d, None, 0)
+        last_pocs = np.zeros(n, dtype=np.int32)
+        L.h264o_last_pocs(d, last_pocs.ctypes.data, n)
         return (out, info, tr) if trace else (out, info)
     finally:
         L.h264o_decoder_destroy(d)

@@ -154,6 +154,13 @@ int h264o_decode_stream(h264o_decoder *d, const uint8_t *buf, size_t len, int cr
  * Pass NULL to disable. cap in MBs across all frames. */
 void h264o_set_mb_trace(h264o_decoder *d, int32_t *trace, size_t cap_mbs);
 const char *h264o_last_error(h264o_decoder *d);
+/* Test instrumentation of the last h264o_decode_stream() call.
+ * features: bit k = memory_management_control_operation k executed (1..6), bit 8/9/10 = modification_of_pic_nums_idc
+ * 0/1/2 applied, bit 11 = a long-term picture in a final RefPicList0, bit 12 = non-reference picture decoded, bit 13 =
+ * slice_qp_delta != 0, bit 14 = pic_order_cnt_type 1 with delta_pic_order_cnt[0] != 0.
+ * pocs: PicOrderCnt(CurrPic) (8.2.1; 0 after an operation 5) of every output picture, in output order. */
+uint32_t h264o_last_features(h264o_decoder *d);
+int h264o_last_pocs(h264o_decoder *d, int32_t *dst, int cap);
 
 /* KAT helpers exported for tests */
 int h264o_kat_ue(const uint8_t *bytes, size_t n, int count, uint32_t *out);

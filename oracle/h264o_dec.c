@@ -179,6 +179,7 @@ static int build_ref_list(h264o_decoder *d) {
                     if (lt[i]->pic_num == sh->rplm_val[k]) target = lt[i];
             }
             if (!target) return h264o_fail(d, "ref_pic_list_modification names a missing picture");
+            d->feat |= 1u << (8 + sh->rplm_idc[k]);
             /* shift up, insert, remove the duplicate further down (8-37/8-38) */
             for (int c = nact; c > idx; c--) d->rpl0[c] = d->rpl0[c - 1];
             d->rpl0[idx++] = target;
@@ -188,6 +189,8 @@ static int build_ref_list(h264o_decoder *d) {
         }
     }
     for (int i = nact; i < 33; i++) d->rpl0[i] = NULL;
+    for (int i = 0; i < nact; i++)
+        if (d->rpl0[i] && d->rpl0[i]->ref == 2) d->feat |= 1u << 11;
     /* entries beyond the initial list that were never filled stay NULL; prediction from them is an error */
     return 0;
 }
@@ -199,6 +202,7 @@ static void mark_reference(h264o_decoder *d) {
     int max_fn = 1 << (d->asps->log2_max_frame_num_minus4 + 4);
     if (!sh->nal_ref_idc) {
         cur->ref = 0;
+        d->feat |= 1u << 12;
         return;
     }
     if (sh->idr_flag) {
@@ -212,6 +216,7 @@ static void mark_reference(h264o_decoder *d) {
     if (sh->adaptive_ref_pic_marking_mode_flag) {
         for (int k = 0; k < sh->n_mmco; k++) {
             int op = sh->mmco_op[k];
+            d->feat |= 1u << op;
             for (int i = 0; i < d->n_pics; i++) { /* refresh PicNum */
                 h264o_pic *p = &d->pics[i];
                 if (p->ref == 1) p->pic_num = p->frame_num > sh->frame_num ? p->frame_num - max_fn : p->frame_num;
@@ -241,6 +246,7 @@ static void mark_reference(h264o_decoder *d) {
                 for (int i = 0; i < d->n_pics; i++)
                     if (&d->pics[i] != cur) d->pics[i].ref = 0;
                 cur->frame_num = 0;
+                cur->poc = 0; /* 8.2.1: tempPicOrderCnt is subtracted after decoding */
                 d->prev_frame_num = 0;
                 d->prev_frame_num_offset = 0;
                 d->prev_poc_msb = 0;
@@ -290,6 +296,7 @@ static void emit_frame(h264o_decoder *d) {
         }
     }
     d->out_pos += need;
+    if (d->n_pocs < 8192) d->pocs[d->n_pocs++] = p->poc;
     d->info.n_frames++;
 }
 
@@ -331,6 +338,8 @@ static int start_picture(h264o_decoder *d) {
     p->id = d->next_pic_id++;
     p->frame_num = d->sh.frame_num;
     p->poc = compute_poc(d, &d->sh);
+    if (d->sh.slice_qp_delta) d->feat |= 1u << 13;
+    if (d->asps->pic_order_cnt_type == 1 && d->sh.delta_pic_order_cnt[0]) d->feat |= 1u << 14;
     for (int i = 0; i < d->wmb * d->hmb; i++) d->mb[i].type = MBT_NONE;
     /* deterministic content for MBs that no slice covers */
     memset(p->plane[0], 128, (size_t)d->wmb * 16 * d->hmb * 16 * 3 / 2);
@@ -351,6 +360,7 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
     if (d->cur && (sh.first_mb_in_slice == 0 || is_new_picture(d, &d->first_sh, &sh))) finish_picture(d);
     if (activate(d, pps) < 0) return -1;
     d->sh = sh;
+    if (sh.slice_qp_delta) d->feat |= 1u << 13;
     if (!d->cur) {
         if (start_picture(d) < 0) return -1;
     } else
@@ -373,6 +383,7 @@ int h264o_decode_stream(h264o_decoder *d, const uint8_t *buf, size_t len, int cr
     d->out_cap = out_cap;
     d->out_pos = 0;
     d->trace_pos = 0;
+    d->feat = 0, d->n_pocs = 0;
     for (int i = 0; i < d->n_pics; i++) d->pics[i].ref = 0, d->pics[i].in_use = 0;
     d->cur = NULL;
     for (int i = 0; i < n && !d->info.error; i++) {
@@ -421,4 +432,10 @@ int h264o_decode_stream(h264o_decoder *d, const uint8_t *buf, size_t len, int cr
     if (d->info.error) return -1;
     if (out && d->out_pos > out_cap) return -2;
     return 0;
+}
+
+uint32_t h264o_last_features(h264o_decoder *d) { return d->feat; }
+int h264o_last_pocs(h264o_decoder *d, int32_t *dst, int cap) {
+    for (int i = 0; i < d->n_pocs && i < cap && dst; i++) dst[i] = d->pocs[i];
+    return d->n_pocs;
 }

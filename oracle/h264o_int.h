@@ -83,6 +83,11 @@ struct h264o_decoder {
     char err[256];
     uint8_t *rbsp;
     size_t rbsp_cap;
+    /* test instrumentation: what the picture-management code actually executed (see h264o_last_features) and the
+     * PicOrderCnt of every output picture */
+    uint32_t feat;
+    int32_t pocs[8192];
+    int n_pocs;
 };
 
 /* entropy.c */

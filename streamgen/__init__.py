@@ -17,7 +17,8 @@ class Params(ctypes.Structure):
         "transform8x8", "num_ref_frames", "deblock_idc", "alpha_off_div2", "beta_off_div2", "cabac_init_idc",
         "constrained_intra", "chroma_qp_offset", "pcm_permille", "intra_in_p_permille", "skip_permille",
         "sub8x8_permille", "weighted_pred", "scaling_matrix", "noise")] + [("seed", ctypes.c_uint32),
-        ("long_start_code", ctypes.c_int), ("poc_type", ctypes.c_int)]
+        ("long_start_code", ctypes.c_int), ("poc_type", ctypes.c_int), ("rplm", ctypes.c_int), ("mmco", ctypes.c_int),
+        ("idr_long_term", ctypes.c_int), ("nonref_period", ctypes.c_int), ("slice_qp_delta", ctypes.c_int)]
 
 
 def build(force=False):
@@ -41,6 +42,8 @@ def lib():
         _lib.sg_default_params.argtypes = [ctypes.POINTER(Params)]
         _lib.sg_last_error.restype = ctypes.c_char_p
         _lib.sg_source_frame.argtypes = [ctypes.POINTER(Params), ctypes.c_int, ctypes.c_void_p]
+        _lib.sg_last_pocs.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        _lib.sg_last_features.restype = ctypes.c_uint32
     return _lib
 
 
@@ -68,6 +71,19 @@ def encode(want_recon=True, **kw):
     if n == 0:
         raise RuntimeError("streamgen failed: %s" % lib().sg_last_error().decode())
     return stream[:n].tobytes(), recon, sizes
+
+
+def last_pocs():
+    """PicOrderCnt the generator intended for every picture of the last encode() call."""
+    n = lib().sg_last_pocs(None, 0)
+    out = np.zeros(n, dtype=np.int32)
+    lib().sg_last_pocs(out.ctypes.data, n)
+    return out
+
+
+def last_features():
+    """Bit set of the picture-management syntax the last encode() call emitted (see sg.h)."""
+    return int(lib().sg_last_features())
 
 
 # Named recipes (SURVEY.md 8d).  Sizes may be overridden for small test cases.

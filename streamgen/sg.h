@@ -43,7 +43,13 @@ typedef struct {
     int noise;              /* amplitude of the uniform source noise */
     uint32_t seed;
     int long_start_code;    /* 1: 4-byte start codes everywhere; 0: 3-byte for non-parameter-set NALs */
-    int poc_type;           /* 0 or 2 */
+    int poc_type;           /* 0, 1 or 2 */
+    /* picture management stimulus (8.2.1, 8.2.4.3, 8.2.5.4); all 0 = sliding window, default lists, every picture a reference */
+    int rplm;               /* 1: P slices carry random ref_pic_list_modification() commands (idc 0, 1 and, with long-term pictures, 2) */
+    int mmco;               /* 1: reference P pictures carry random memory_management_control_operation scripts (1..6) */
+    int idr_long_term;      /* 1: IDR pictures set long_term_reference_flag */
+    int nonref_period;      /* N > 1: every N-th P picture is a non-reference picture (nal_ref_idc 0) */
+    int slice_qp_delta;     /* d != 0: slice_qp_delta cycles through -d, 0, +d per slice */
 } sg_params;
 
 void sg_default_params(sg_params *p);
@@ -54,6 +60,13 @@ size_t sg_encode(const sg_params *p, uint8_t *stream, size_t stream_cap, uint8_t
 /* source picture t of the synthetic sequence (coded size), for reference / PSNR */
 void sg_source_frame(const sg_params *p, int t, uint8_t *dst);
 const char *sg_last_error(void);
+/* PicOrderCnt the generator intended for every picture of the last sg_encode() call (display order == coding order:
+ * 2 * pictures since the last IDR / memory_management_control_operation 5).  Returns the number of pictures. */
+int sg_last_pocs(int32_t *dst, int cap);
+/* what the last sg_encode() call actually emitted: bit k = memory_management_control_operation k (1..6), bit 8/9/10 =
+ * modification_of_pic_nums_idc 0/1/2, bit 11 = a long-term picture in an active reference list, bit 12 = non-reference
+ * picture, bit 13 = slice_qp_delta != 0, bit 14 = pic_order_cnt_type 1 with delta_pic_order_cnt[0] != 0 */
+uint32_t sg_last_features(void);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,10 @@ typedef struct {
     int ls4[6][6][16], ls8[2][6][64];
     uint8_t s4[6][16], s8[2][64]; /* scaling lists, zig-zag */
     int wp_w[4], wp_o[4], wp_cw[4][2], wp_co[4][2], wp_ld, wp_cd;
+    /* picture management of the current picture (8.2.4.3 / 8.2.5.4), planned before its slice headers are written */
+    int nal_ref_idc, cur_frame_num, n_rplm, n_mmco, max_lt, idr_lt, slice_qp, delta_poc0;
+    struct { int idc, val; } rplm[8];
+    struct { int op, a1, a2; } mmco[12];
     /* current MB */
     int mbx, mby, addr, raw_type;
     uint16_t done;
@@ -1220,6 +1224,14 @@ static size_t write_sps(enc *e, uint8_t *dst, size_t cap) {
     sg_put_ue(&w, 4); /* log2_max_frame_num_minus4 -> 8 bits */
     sg_put_ue(&w, (uint32_t)p->poc_type);
     if (p->poc_type == 0) sg_put_ue(&w, 4); /* log2_max_poc_lsb_minus4 -> 8 bits */
+    if (p->poc_type == 1) {
+        sg_put(&w, 0, 1);   /* delta_pic_order_always_zero_flag */
+        sg_put_se(&w, -1);  /* offset_for_non_ref_pic */
+        sg_put_se(&w, 1);   /* offset_for_top_to_bottom_field: PicOrderCnt = min(top, top + 1) = top */
+        sg_put_ue(&w, 2);   /* num_ref_frames_in_pic_order_cnt_cycle */
+        sg_put_se(&w, 2);   /* offset_for_ref_frame[0] */
+        sg_put_se(&w, 6);   /* offset_for_ref_frame[1] */
+    }
     sg_put_ue(&w, (uint32_t)p->num_ref_frames);
     sg_put(&w, 0, 1); /* gaps */
     sg_put_ue(&w, (uint32_t)(e->wmb - 1));
@@ -1277,11 +1289,19 @@ static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int
     sg_put(w, (uint32_t)frame_num, 8);
     if (idr) sg_put_ue(w, (uint32_t)idr_id);
     if (p->poc_type == 0) sg_put(w, (uint32_t)poc_lsb, 8);
+    if (p->poc_type == 1) sg_put_se(w, e->delta_poc0); /* delta_pic_order_cnt[0] (delta_pic_order_always_zero_flag = 0) */
     if (is_p) {
         int over = e->nref_active != p->num_ref_frames;
         sg_put(w, (uint32_t)over, 1);
         if (over) sg_put_ue(w, (uint32_t)(e->nref_active - 1));
-        sg_put(w, 0, 1); /* ref_pic_list_modification_flag_l0 */
+        sg_put(w, e->n_rplm > 0, 1); /* ref_pic_list_modification_flag_l0 */
+        if (e->n_rplm > 0) {
+            for (int i = 0; i < e->n_rplm; i++) {
+                sg_put_ue(w, (uint32_t)e->rplm[i].idc);
+                sg_put_ue(w, (uint32_t)e->rplm[i].val);
+            }
+            sg_put_ue(w, 3);
+        }
         if (p->weighted_pred) {
             sg_put_ue(w, (uint32_t)e->wp_ld);
             sg_put_ue(w, (uint32_t)e->wp_cd);
@@ -1296,19 +1316,238 @@ static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int
             }
         }
     }
-    /* dec_ref_pic_marking: every picture is a reference (nal_ref_idc 3) */
-    if (idr) {
-        sg_put(w, 0, 1);
-        sg_put(w, 0, 1);
-    } else
-        sg_put(w, 0, 1); /* sliding window */
+    /* dec_ref_pic_marking() 7.3.3.3 */
+    if (e->nal_ref_idc) {
+        if (idr) {
+            sg_put(w, 0, 1);                    /* no_output_of_prior_pics_flag */
+            sg_put(w, (uint32_t)e->idr_lt, 1);  /* long_term_reference_flag */
+        } else {
+            sg_put(w, e->n_mmco > 0, 1); /* adaptive_ref_pic_marking_mode_flag (0: sliding window) */
+            if (e->n_mmco > 0) {
+                for (int i = 0; i < e->n_mmco; i++) {
+                    int op = e->mmco[i].op;
+                    sg_put_ue(w, (uint32_t)op);
+                    if (op == 1 || op == 3) sg_put_ue(w, (uint32_t)e->mmco[i].a1); /* difference_of_pic_nums_minus1 */
+                    if (op == 2) sg_put_ue(w, (uint32_t)e->mmco[i].a1);            /* long_term_pic_num */
+                    if (op == 3 || op == 6) sg_put_ue(w, (uint32_t)e->mmco[i].a2); /* long_term_frame_idx */
+                    if (op == 4) sg_put_ue(w, (uint32_t)e->mmco[i].a1);            /* max_long_term_frame_idx_plus1 */
+                }
+                sg_put_ue(w, 0);
+            }
+        }
+    }
     if (p->cabac && is_p) sg_put_ue(w, (uint32_t)e->init_idc);
-    sg_put_se(w, 0); /* slice_qp_delta */
+    sg_put_se(w, e->slice_qp - p->qp); /* slice_qp_delta (pic_init_qp = p->qp) */
     sg_put_ue(w, (uint32_t)p->deblock_idc);
     if (p->deblock_idc != 1) {
         sg_put_se(w, p->alpha_off_div2);
         sg_put_se(w, p->beta_off_div2);
     }
+}
+
+/* ------------------------------------------------------------------ picture management (generator side)
+ * The generator decides WHAT happens to its pictures (which ones a P picture predicts from and in which order,
+ * which ones stop being references or become long-term) and derives the syntax element values from that;
+ * a decoder has to get back to the same pictures from the syntax (8.2.4, 8.2.5). */
+#define SG_MAX_FN 256 /* log2_max_frame_num_minus4 = 4 */
+static uint32_t g_feat;
+static int32_t g_pocs[8192];
+static int g_npocs;
+uint32_t sg_last_features(void) { return g_feat; }
+int sg_last_pocs(int32_t *dst, int cap) {
+    for (int i = 0; i < g_npocs && i < cap && dst; i++) dst[i] = g_pocs[i];
+    return g_npocs;
+}
+static int picnum(const sg_pic *p, int cur_fn) { return p->frame_num > cur_fn ? p->frame_num - SG_MAX_FN : p->frame_num; }
+
+/* RefPicList0 of the coming P picture into e->refs[] / e->nref_active; with p->rplm a random re-ordering. */
+static void plan_ref_list(enc *e) {
+    sg_pic *st[6], *lt[6], *init[12];
+    int nst = 0, nlt = 0, n = 0, cur_fn = e->cur_frame_num;
+    for (int i = 0; i < 6; i++) {
+        sg_pic *q = &e->pics[i];
+        if (q == e->cur) continue;
+        if (q->is_ref == 1) st[nst++] = q;
+        if (q->is_ref == 2) lt[nlt++] = q;
+    }
+    for (int i = 0; i < nst; i++) /* short-term: most recent (largest PicNum) first */
+        for (int j = i + 1; j < nst; j++)
+            if (picnum(st[j], cur_fn) > picnum(st[i], cur_fn)) {
+                sg_pic *t = st[i];
+                st[i] = st[j], st[j] = t;
+            }
+    for (int i = 0; i < nlt; i++) /* long-term: ascending LongTermPicNum */
+        for (int j = i + 1; j < nlt; j++)
+            if (lt[j]->long_idx < lt[i]->long_idx) {
+                sg_pic *t = lt[i];
+                lt[i] = lt[j], lt[j] = t;
+            }
+    for (int i = 0; i < nst; i++) init[n++] = st[i];
+    for (int i = 0; i < nlt; i++) init[n++] = lt[i];
+    e->nrefs = n;
+    e->nref_active = n < e->p.num_ref_frames ? n : e->p.num_ref_frames;
+    e->n_rplm = 0;
+    sg_pic *final[12];
+    int nf = 0;
+    if (e->p.rplm && n >= 2 && rnd(e) % 100 < 75) {
+        /* the first k entries become k distinct pictures picked from the WHOLE set of reference pictures */
+        int k = 1 + (int)(rnd(e) % (uint32_t)(e->nref_active < 3 ? e->nref_active : 3));
+        int pred = cur_fn; /* picNumL0Pred */
+        for (int c = 0; c < k; c++) {
+            sg_pic *t;
+            int dup;
+            do {
+                t = init[rnd(e) % (uint32_t)n];
+                dup = 0;
+                for (int j = 0; j < nf; j++) dup |= final[j] == t;
+            } while (dup);
+            final[nf++] = t;
+            if (t->is_ref == 2) {
+                e->rplm[e->n_rplm].idc = 2, e->rplm[e->n_rplm++].val = t->long_idx;
+                g_feat |= 1u << 10;
+            } else {
+                /* go down or up from the predictor, modulo MaxPicNum; both directions reach every picture */
+                int fn = t->frame_num, down = (pred - fn + SG_MAX_FN) % SG_MAX_FN, up = (fn - pred + SG_MAX_FN) % SG_MAX_FN;
+                int use_up = down == 0 || (up != 0 && rnd(e) % 100 < 30);
+                e->rplm[e->n_rplm].idc = use_up ? 1 : 0;
+                e->rplm[e->n_rplm++].val = (use_up ? up : down) - 1;
+                g_feat |= 1u << (use_up ? 9 : 8);
+                pred = fn;
+            }
+        }
+    }
+    for (int i = 0; i < n; i++) { /* the rest follows in initial order */
+        int used = 0;
+        for (int j = 0; j < e->n_rplm; j++) used |= final[j] == init[i];
+        if (!used) final[nf++] = init[i];
+    }
+    for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? final[i] : NULL;
+    for (int i = 0; i < e->nref_active; i++)
+        if (e->refs[i]->is_ref == 2) g_feat |= 1u << 11;
+}
+
+/* Marking of the current (reference, non-IDR) picture.  plan_marking() draws a random script of memory management
+ * control operations against a copy of the reference state and records the syntax; apply_marking() then performs the
+ * same decisions on the pictures themselves once the picture is complete. */
+typedef struct {
+    int ref[6], lidx[6], cur_ref, cur_lidx, max_lt, clear_all;
+} mark_state;
+static int ms_count(const mark_state *m, int kind) {
+    int n = 0;
+    for (int i = 0; i < 6; i++) n += m->ref[i] == kind;
+    return n;
+}
+static int ms_pick(enc *e, const mark_state *m, int kind) { /* a random picture of that kind */
+    int k = (int)(rnd(e) % (uint32_t)ms_count(m, kind));
+    for (int i = 0; i < 6; i++)
+        if (m->ref[i] == kind && k-- == 0) return i;
+    return -1;
+}
+static void ms_free_lidx(mark_state *m, int idx) {
+    for (int i = 0; i < 6; i++)
+        if (m->ref[i] == 2 && m->lidx[i] == idx) m->ref[i] = 0;
+}
+static void add_mmco(enc *e, int op, int a1, int a2) {
+    e->mmco[e->n_mmco].op = op, e->mmco[e->n_mmco].a1 = a1, e->mmco[e->n_mmco].a2 = a2;
+    e->n_mmco++;
+    g_feat |= 1u << op;
+}
+static void plan_marking(enc *e, mark_state *m) {
+    const int maxref = e->p.num_ref_frames, cur_fn = e->cur_frame_num;
+    memset(m, 0, sizeof(*m));
+    for (int i = 0; i < 6; i++) m->ref[i] = &e->pics[i] == e->cur ? 0 : e->pics[i].is_ref, m->lidx[i] = e->pics[i].long_idx;
+    m->cur_ref = 1, m->max_lt = e->max_lt;
+    e->n_mmco = 0;
+    if (!e->p.mmco || maxref < 2 || rnd(e) % 100 < 35) return; /* sliding window */
+    if (rnd(e) % 100 < 6) { /* operation 5 stands alone: everything before this picture is dropped */
+        add_mmco(e, 5, 0, 0);
+        for (int i = 0; i < 6; i++) m->ref[i] = 0;
+        m->clear_all = 1, m->max_lt = 0;
+        return;
+    }
+    int nops = 1 + (int)(rnd(e) % 3);
+    for (int k = 0; k < nops; k++) {
+        int r = (int)(rnd(e) % 100);
+        if (m->max_lt == 0) { /* long-term indices must be enabled before they are used */
+            add_mmco(e, 4, 2, 0);
+            m->max_lt = 2;
+        } else if (r < 25 && ms_count(m, 1) > 0) { /* 3: short-term -> long-term */
+            int i = ms_pick(e, m, 1), idx = (int)(rnd(e) % (uint32_t)m->max_lt);
+            if (m->cur_ref == 2 && idx == m->cur_lidx) { /* never take the index operation 6 has just given to this picture */
+                if (m->max_lt < 2) continue;
+                idx = (idx + 1) % m->max_lt;
+            }
+            add_mmco(e, 3, cur_fn - picnum(&e->pics[i], cur_fn) - 1, idx);
+            ms_free_lidx(m, idx);
+            m->ref[i] = 2, m->lidx[i] = idx;
+        } else if (r < 45 && ms_count(m, 1) > 1) { /* 1: short-term -> unused */
+            int i = ms_pick(e, m, 1);
+            add_mmco(e, 1, cur_fn - picnum(&e->pics[i], cur_fn) - 1, 0);
+            m->ref[i] = 0;
+        } else if (r < 60 && ms_count(m, 2) > 0) { /* 2: long-term -> unused */
+            int i = ms_pick(e, m, 2);
+            add_mmco(e, 2, m->lidx[i], 0);
+            m->ref[i] = 0;
+        } else if (r < 75 && m->cur_ref == 1) { /* 6: the current picture becomes a long-term picture */
+            int idx = (int)(rnd(e) % (uint32_t)m->max_lt);
+            add_mmco(e, 6, 0, idx);
+            ms_free_lidx(m, idx);
+            m->cur_ref = 2, m->cur_lidx = idx;
+        } else if (r < 85) { /* 4: shrink (or re-state) the range of long-term indices */
+            int plus1 = 1 + (int)(rnd(e) % 2);
+            if (m->cur_ref == 2 && plus1 <= m->cur_lidx) plus1 = m->cur_lidx + 1; /* the index just given to this picture survives */
+            add_mmco(e, 4, plus1, 0);
+            for (int i = 0; i < 6; i++)
+                if (m->ref[i] == 2 && m->lidx[i] >= plus1) m->ref[i] = 0;
+            m->max_lt = plus1;
+        }
+    }
+    /* no sliding window in adaptive mode: the script itself has to make room, and it must leave at least one
+     * short-term slot so that a later sliding-window picture finds something to drop */
+    while (ms_count(m, 1) + ms_count(m, 2) + 1 > maxref || ms_count(m, 2) + (m->cur_ref == 2) > maxref - 1) {
+        if (ms_count(m, 2) + (m->cur_ref == 2) > maxref - 1 && ms_count(m, 2) > 0) {
+            int i = ms_pick(e, m, 2);
+            add_mmco(e, 2, m->lidx[i], 0);
+            m->ref[i] = 0;
+        } else if (ms_count(m, 1) > 0) { /* the oldest short-term picture */
+            int best = -1;
+            for (int i = 0; i < 6; i++)
+                if (m->ref[i] == 1 && (best < 0 || picnum(&e->pics[i], cur_fn) < picnum(&e->pics[best], cur_fn))) best = i;
+            add_mmco(e, 1, cur_fn - picnum(&e->pics[best], cur_fn) - 1, 0);
+            m->ref[best] = 0;
+        } else {
+            int i = ms_pick(e, m, 2);
+            add_mmco(e, 2, m->lidx[i], 0);
+            m->ref[i] = 0;
+        }
+    }
+    if (e->n_mmco == 0) add_mmco(e, 4, m->max_lt, 0); /* adaptive mode was chosen: say something harmless */
+}
+static void apply_marking(enc *e, const mark_state *m, int idr) {
+    if (!e->nal_ref_idc) return; /* non-reference picture: nothing changes */
+    if (idr) {
+        for (int i = 0; i < 6; i++) e->pics[i].is_ref = 0;
+        e->cur->is_ref = e->idr_lt ? 2 : 1, e->cur->long_idx = 0;
+        e->max_lt = e->idr_lt ? 1 : 0;
+        return;
+    }
+    if (e->n_mmco > 0) {
+        for (int i = 0; i < 6; i++)
+            if (&e->pics[i] != e->cur) e->pics[i].is_ref = m->ref[i], e->pics[i].long_idx = m->lidx[i];
+        e->cur->is_ref = m->cur_ref, e->cur->long_idx = m->cur_lidx;
+        e->max_lt = m->max_lt;
+        return;
+    }
+    /* sliding window: with all slots taken the oldest short-term picture goes */
+    int n = 0, oldest = -1;
+    for (int i = 0; i < 6; i++) {
+        sg_pic *q = &e->pics[i];
+        if (q == e->cur || !q->is_ref) continue;
+        n++;
+        if (q->is_ref == 1 && (oldest < 0 || picnum(q, e->cur_frame_num) < picnum(&e->pics[oldest], e->cur_frame_num))) oldest = i;
+    }
+    if (n >= e->p.num_ref_frames && oldest >= 0) e->pics[oldest].is_ref = 0;
+    e->cur->is_ref = 1;
 }
 
 /* ------------------------------------------------------------------ top level */
@@ -1349,13 +1588,15 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         memcpy(e->s8[1], sg_default8x8_inter, 64);
     }
     build_scale(e);
-    int frame_num = 0, idr_id = 0, poc = 0;
+    int frame_num = 0, idr_id = 0, poc = 0, refs_since_reset = 0, since_idr = 0;
+    static const int poc1_offsets[2] = {2, 6}; /* offset_for_ref_frame[] of write_sps() */
+    g_feat = 0, g_npocs = 0;
     for (int t = 0; t < p->frames; t++) {
         size_t au_start = out;
         int idr = t == 0 || (p->idr_period > 0 && t % p->idr_period == 0);
         sg_source_frame(p, t, e->src);
         if (idr) {
-            frame_num = 0, poc = 0, e->nrefs = 0;
+            frame_num = 0, poc = 0, e->nrefs = 0, refs_since_reset = 0, since_idr = 0;
             size_t n = write_sps(e, stream + out, cap - out);
             out += n;
             n = write_pps(e, stream + out, cap - out);
@@ -1368,8 +1609,40 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             if (!e->pics[i].is_ref) e->cur = &e->pics[i];
         e->cur->id = e->next_id++;
         e->cur->frame_num = frame_num;
+        e->cur_frame_num = frame_num;
         e->slice_type = idr ? 2 : 0;
-        e->nref_active = e->nrefs < p->num_ref_frames ? e->nrefs : p->num_ref_frames;
+        e->nal_ref_idc = (!idr && p->nonref_period > 1 && since_idr % p->nonref_period == p->nonref_period - 1) ? 0 : 3;
+        if (!e->nal_ref_idc) g_feat |= 1u << 12;
+        e->idr_lt = idr && p->idr_long_term;
+        e->n_rplm = e->n_mmco = 0;
+        mark_state ms;
+        memset(&ms, 0, sizeof(ms));
+        if (!idr) {
+            plan_ref_list(e);
+            if (e->nal_ref_idc) plan_marking(e, &ms);
+        }
+        if (getenv("SG_DEBUG")) {
+            fprintf(stderr, "t=%d fn=%d ref_idc=%d list:", t, frame_num, e->nal_ref_idc);
+            for (int i = 0; i < e->nref_active && !idr; i++) fprintf(stderr, " id%d(fn%d,%s%d)", e->refs[i]->id, e->refs[i]->frame_num, e->refs[i]->is_ref == 2 ? "L" : "s", e->refs[i]->long_idx);
+            fprintf(stderr, " rplm:");
+            for (int i = 0; i < e->n_rplm; i++) fprintf(stderr, " (%d,%d)", e->rplm[i].idc, e->rplm[i].val);
+            fprintf(stderr, " mmco:");
+            for (int i = 0; i < e->n_mmco; i++) fprintf(stderr, " (%d,%d,%d)", e->mmco[i].op, e->mmco[i].a1, e->mmco[i].a2);
+            fprintf(stderr, "\n");
+        }
+        /* pic_order_cnt_type 1 (8.2.1.2): the picture shall come out at POC `poc`; what the offsets of the SPS do not
+         * give is sent as delta_pic_order_cnt[0] */
+        e->delta_poc0 = 0;
+        if (p->poc_type == 1) {
+            int abs_fn = e->nal_ref_idc ? refs_since_reset : refs_since_reset - 1, expected = 0;
+            if (idr) abs_fn = 0;
+            for (int i = 0; i < abs_fn; i++) expected += poc1_offsets[i % 2];
+            if (!e->nal_ref_idc) expected += -1; /* offset_for_non_ref_pic */
+            e->delta_poc0 = poc - expected;
+            if (e->delta_poc0) g_feat |= 1u << 14;
+        }
+        if (g_npocs < 8192) /* pic_order_cnt_type 2 leaves no choice: 2 * FrameNum, minus 1 for non-reference pictures (8.2.1.3) */
+            g_pocs[g_npocs++] = p->poc_type == 2 ? (idr ? 0 : 2 * refs_since_reset - (e->nal_ref_idc ? 0 : 1)) : poc;
         if (!idr && p->weighted_pred) {
             e->wp_ld = 5, e->wp_cd = 4;
             for (int i = 0; i < 4; i++) {
@@ -1384,12 +1657,15 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             int first = row0 * e->wmb, last = row1 * e->wmb;
             e->slice_id = s;
             e->init_idc = p->cabac_init_idc >= 0 ? p->cabac_init_idc : (t + s) % 3;
+            e->slice_qp = p->qp + p->slice_qp_delta * ((t + s) % 3 - 1);
+            e->slice_qp = e->slice_qp < 0 ? 0 : (e->slice_qp > 51 ? 51 : e->slice_qp);
+            if (e->slice_qp != p->qp) g_feat |= 1u << 13;
             sg_bw_init(&e->bw, rbsp, slice_cap);
             write_slice_header(e, first, idr, frame_num, idr_id, poc & 255);
-            e->qp = p->qp, e->prev_dqp_nz = 0, e->skip_run = 0;
+            e->qp = e->slice_qp, e->prev_dqp_nz = 0, e->skip_run = 0;
             if (p->cabac) {
                 while (!sg_bw_aligned(&e->bw)) sg_put(&e->bw, 1, 1);
-                sg_cabac_init_ctx(&e->bw, idr ? 0 : 1 + e->init_idc, p->qp);
+                sg_cabac_init_ctx(&e->bw, idr ? 0 : 1 + e->init_idc, e->slice_qp);
                 sg_cabac_start(&e->bw);
             }
             for (int addr = first; addr < last; addr++) {
@@ -1436,7 +1712,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
                 out = 0;
                 goto done;
             }
-            size_t n = sg_write_nal(stream + out, cap - out, p->long_start_code || s == 0, 3, idr ? 5 : 1, rbsp, sg_bw_bytes(&e->bw));
+            size_t n = sg_write_nal(stream + out, cap - out, p->long_start_code || s == 0, e->nal_ref_idc, idr ? 5 : 1, rbsp, sg_bw_bytes(&e->bw));
             if (!n) {
                 snprintf(g_err, sizeof(g_err), "stream buffer too small");
                 out = 0;
@@ -1446,14 +1722,18 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         }
         sg_deblock(e->cur, e->db, e->wmb, e->hmb);
         if (recon && (size_t)(t + 1) * fsz <= recon_cap) memcpy(recon + (size_t)t * fsz, e->cur->pl[0], fsz);
-        /* sliding window: newest first */
-        e->cur->is_ref = 1;
-        if (e->nrefs == p->num_ref_frames) e->refs[e->nrefs - 1]->is_ref = 0, e->nrefs--;
-        for (int i = e->nrefs; i > 0; i--) e->refs[i] = e->refs[i - 1];
-        e->refs[0] = e->cur;
-        e->nrefs++;
-        frame_num = (frame_num + 1) & 255;
+        apply_marking(e, &ms, idr);
+        since_idr++;
         poc += 2;
+        if (e->nal_ref_idc) {
+            frame_num = (frame_num + 1) & (SG_MAX_FN - 1);
+            refs_since_reset++;
+        }
+        if (ms.clear_all) { /* after operation 5 the picture counts as frame_num 0 / POC 0 (7.4.3, 8.2.1) */
+            e->cur->frame_num = 0;
+            frame_num = 1, refs_since_reset = 1, poc = 2;
+            g_pocs[g_npocs - 1] = 0;
+        }
         if (idr) idr_id = (idr_id + 1) & 0xFFFF;
         if (frame_sizes) frame_sizes[t] = (uint32_t)(out - au_start);
     }

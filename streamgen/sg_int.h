@@ -38,7 +38,9 @@ void sg_cabac_terminate(sg_bw *w, int bin); /* bin=1 also flushes */
 typedef struct {
     uint8_t *pl[3];
     int w, h; /* coded luma size */
-    int id, frame_num, is_ref;
+    int id, frame_num;
+    int is_ref;   /* 0 unused for reference, 1 short-term, 2 long-term */
+    int long_idx; /* LongTermFrameIdx when is_ref == 2 */
 } sg_pic;
 
 typedef struct {

@@ -96,4 +96,16 @@ MATRIX = {
     "idc1": dict(BASE, profile_idc=77, cabac=1, cabac_init_idc=1),
     "idc2": dict(BASE, profile_idc=77, cabac=1, cabac_init_idc=2),
     "gop3": dict(BASE, frames=7, idr_period=3, profile_idc=77, cabac=1),
+    # picture management (8.2.1, 8.2.4.3, 8.2.5.4): list modification, MMCO 1..6, long-term pictures, POC type 1,
+    # non-reference pictures, slice_qp_delta != 0
+    "rplm_cabac": dict(BASE, frames=8, profile_idc=77, cabac=1, num_ref_frames=4, rplm=1, qp=30, seed=31),
+    "rplm_cavlc": dict(BASE, frames=8, profile_idc=66, cabac=0, num_ref_frames=3, rplm=1, qp=30, seed=32),
+    "mmco_cabac": dict(BASE, frames=24, profile_idc=77, cabac=1, num_ref_frames=4, rplm=1, mmco=1, qp=32, seed=33),
+    "mmco_cavlc": dict(BASE, frames=24, profile_idc=66, cabac=0, num_ref_frames=3, rplm=1, mmco=1, qp=32, seed=34),
+    "mmco_idr_lt": dict(BASE, frames=20, idr_period=10, profile_idc=77, cabac=1, num_ref_frames=3, rplm=1, mmco=1, idr_long_term=1, qp=32, seed=35),
+    "poc1_nonref": dict(BASE, frames=9, profile_idc=77, cabac=1, num_ref_frames=2, poc_type=1, nonref_period=3, qp=30, seed=36),
+    "poc2_nonref_cavlc": dict(BASE, frames=9, profile_idc=66, cabac=0, num_ref_frames=2, poc_type=2, nonref_period=2, qp=30, seed=37),
+    "poc1_mmco": dict(BASE, frames=20, profile_idc=77, cabac=1, num_ref_frames=4, poc_type=1, mmco=1, rplm=1, nonref_period=4, qp=32, seed=38),
+    "slice_qp_delta": dict(BASE, frames=5, profile_idc=77, cabac=1, slices=3, slice_qp_delta=5, qp=27, seed=39),
+    "slice_qp_delta_cavlc": dict(BASE, frames=5, profile_idc=66, cabac=0, slices=2, slice_qp_delta=7, qp_jitter=3, qp=30, seed=40),
 }

@@ -20,6 +20,7 @@ def _decode_gpu(H, streams, w, h, frames, slices=1, crop=False):
     info = dec.decode(streams)
     size = (w * h if crop else W * Hc) * 3 // 2
     out = [dec.read_frames(i, crop=crop, size=size) for i in range(len(streams))]
+    info.pocs = [[dec.frame_info(i, f).pic_order_cnt for f in range(dec.frame_count(i))] for i in range(len(streams))]
     dec.close()
     return out, info
 
@@ -34,6 +35,8 @@ def test_gpu_matches_oracle_and_generator(name, H, sg, oracle_mod):
     assert out[0].shape == ref.shape
     assert np.array_equal(out[0], ref), "GPU != oracle"
     assert np.array_equal(out[0], rec), "GPU != generator reconstruction"
+    # picture order counts (8.2.1, incl. type 1 / type 2, non-reference pictures and the reset after MMCO 5)
+    assert info.pocs[0] == list(oracle_mod.last_pocs) == list(sg.last_pocs()), "PicOrderCnt"
 
 
 def test_gpu_golden_md5(H, sg):
@@ -186,3 +189,135 @@ def test_gpu_c_program_through_the_abi(H, sg, oracle_mod, tmp_path):
     got = np.frombuffer(dst.read_bytes(), dtype=np.uint8).reshape(-1, info.width * info.height * 3 // 2)
     assert np.array_equal(got, ref)
 
+
+
+def test_gpu_c5_share_32_distinct_1080p_streams(H, sg):
+    """BASELINE configs[4], one GPU's share: 32 DISTINCT 1080p Main CABAC streams (seeds 1000..1031), one
+    IPPP GOP of 30 frames each, decoded as one batch; every frame of every stream must equal the generator's own
+    reconstruction (an implementation independent of the product and of the oracle)."""
+    from concurrent.futures import ThreadPoolExecutor
+    S, F = 32, 30
+    kws = [sg.recipe("C3", frames=F, idr_period=F, seed=1000 + i) for i in range(S)]
+    with ThreadPoolExecutor(max_workers=min(S, max(1, (os.cpu_count() or 8) - 2))) as ex:  # ctypes releases the GIL
+        gen = list(ex.map(lambda kw: sg.encode(**kw), kws))
+    streams = [g[0] for g in gen]
+    assert len(set(hashlib.md5(s).hexdigest() for s in streams)) == S, "streams are not distinct"
+    dec = H.Decoder(max_streams=S, max_width=1920, max_height=1088, max_frames_per_batch=F, max_slices_per_frame=1,
+                    max_bitstream_bytes=int(sum(len(s) for s in streams) * 1.1) + (1 << 20))
+    info = dec.decode(streams)
+    assert info.n_frames == S * F
+    fsz = 1920 * 1088 * 3 // 2
+    for si in range(S):
+        assert dec.frame_count(si) == F
+        for f in range(F):
+            got = dec.read_frame(si, f, crop=False)[:fsz]
+            assert np.array_equal(got, gen[si][1][f]), "stream %d frame %d differs from the generator's reconstruction" % (si, f)
+    dec.close()
+
+
+def _poison(H, dec):
+    import ctypes
+    f = H.load().h264mi_internal_poison
+    f.restype, f.argtypes = ctypes.c_int32, [ctypes.c_void_p]
+    assert f(dec._h) == 0
+
+
+def test_gpu_lost_and_broken_slices_leave_defined_pictures(H, sg, oracle_mod):
+    """Macroblock records no slice delivered must not be whatever an earlier batch (or the allocator) left in memory: every
+    intermediate buffer is filled with 0xFF first, then a stream with a dropped slice NAL, one with a slice cut short, and
+    corrupted ones are decoded -- in a decoder that held a differently sized batch before.  The undamaged slices must
+    still decode exactly, lost macroblocks come out mid-grey, and two runs give identical pictures."""
+    kw = dict(width=176, height=144, frames=2, idr_period=1, profile_idc=77, cabac=1, slices=3, seed=9, deblock_idc=2)
+    stream, rec, _ = sg.encode(**kw)
+    nals = H.read_nal_units(stream)
+    # split at the NALs (the generator writes 4-byte start codes) to rebuild the stream without the 2nd slice of picture 0
+    offs = [n.Offset - 4 for n in nals] + [len(stream)]
+
+    def piece(i):
+        return stream[offs[i]:offs[i + 1]]
+    pieces = [piece(i) for i in range(len(nals))]
+    assert b"".join(pieces) == stream
+    assert [n.Type for n in nals] == [7, 8, 5, 5, 5, 7, 8, 5, 5, 5]
+    lost = b"".join(p for i, p in enumerate(pieces) if i != 3)
+    cut = b"".join(p[:len(p) // 2] if i == 4 else p for i, p in enumerate(pieces))
+    outs = []
+    for rep_ in range(2):
+        dec = H.Decoder(max_streams=2, max_width=352, max_height=288, max_frames_per_batch=4, max_slices_per_frame=4)
+        big = sg.encode(width=352, height=288, frames=3, idr_period=0, profile_idc=77, cabac=1, seed=3)[0]
+        dec.decode([big, big])  # leaves records of another geometry behind
+        _poison(H, dec)
+        dec.set_isolation(True)
+        dec.reset()
+        dec.decode([lost, cut])
+        assert dec.stream_status(0) == 0           # a missing slice is not an error of the slices that are there
+        assert dec.stream_status(1) in (0, -8)     # the truncated slice may or may not trip the entropy decoder
+        a = dec.read_frames(0, crop=False)
+        b = dec.read_frames(1, crop=False)
+        outs.append((a.copy(), b.copy()))
+        dec.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]), "pictures differ between runs"
+    W, Hc = 176, 144
+    y0 = outs[0][0][0][:W * Hc].reshape(Hc, W)
+    ry = rec[0][:W * Hc].reshape(Hc, W)
+    # 9 macroblock rows in 3 slices of 3 rows; deblocking does not cross slice edges (idc 2): rows of slices 0 and 2 are exact
+    assert np.array_equal(y0[:48], ry[:48]) and np.array_equal(y0[96:], ry[96:])
+    assert (y0[48:96] == 128).all(), "lost macroblocks are not mid-grey"
+    assert np.array_equal(outs[0][0][1], rec[1])   # the next IDR picture is complete again
+    yb = outs[0][1][0][:W * Hc].reshape(Hc, W)
+    assert np.array_equal(yb[:48], ry[:48])        # stream 1: slice 0 intact, the cut slice 1 ends early somewhere
+
+
+def test_gpu_isolation_keeps_other_streams_alive(H, sg, oracle_mod):
+    """One malformed stream in a batch (P pictures whose IDR picture is missing) is dropped and marked; the others decode."""
+    good = sg.encode(width=176, height=144, frames=3, idr_period=0, profile_idc=77, cabac=1, seed=41)
+    other = sg.encode(width=176, height=144, frames=3, idr_period=0, profile_idc=77, cabac=1, seed=42)[0]
+    offs = [n.Offset - 4 for n in H.read_nal_units(other)]
+    bad = other[:offs[2]] + other[offs[3]:]  # SPS, PPS, then P pictures without their IDR picture: H264MI_EBITSTREAM
+    dec = H.Decoder(max_streams=3, max_width=176, max_height=144, max_frames_per_batch=3)
+    with pytest.raises(H.H264MIError):
+        dec.decode([good[0], bad, good[0]])  # without isolation the batch fails as before
+    dec.reset()
+    dec.set_isolation(True)
+    dec.decode([good[0], bad, good[0]])
+    assert dec.stream_status(0) == 0 and dec.stream_status(2) == 0 and dec.stream_status(1) == -2
+    assert dec.frame_count(1) == 0
+    assert np.array_equal(dec.read_frames(0, crop=False), good[1]) and np.array_equal(dec.read_frames(2, crop=False), good[1])
+    # the slot is given to a new client: nothing of the old one survives, a P picture without an IDR is not decodable
+    dec.reset_stream(1)
+    dec.decode([b"", good[0], b""])
+    assert dec.stream_status(1) == 0 and np.array_equal(dec.read_frames(1, crop=False), good[1])
+    dec.close()
+
+
+def test_gpu_resolution_change_inside_one_batch(H, sg):
+    """Two sequences of different size back to back in ONE chunk of one stream: every picture keeps its own geometry."""
+    a = sg.encode(width=176, height=144, frames=3, idr_period=0, profile_idc=77, cabac=1, seed=51)
+    b = sg.encode(width=320, height=200, frames=2, idr_period=0, profile_idc=66, cabac=0, seed=52)
+    dec = H.Decoder(max_streams=1, max_width=320, max_height=208, max_frames_per_batch=5)
+    dec.decode([a[0] + b[0]])
+    assert dec.frame_count(0) == 5
+    for f in range(3):
+        fi = dec.frame_info(0, f)
+        assert (fi.width, fi.height, fi.coded_width, fi.coded_height) == (176, 144, 176, 144)
+        assert np.array_equal(dec.read_frame_tight(0, f, crop=False), a[1][f])
+    for f in range(2):
+        fi = dec.frame_info(0, 3 + f)
+        assert (fi.width, fi.height, fi.coded_width, fi.coded_height) == (320, 200, 320, 208)
+        assert np.array_equal(dec.read_frame_tight(0, 3 + f, crop=False), b[1][f])
+    dec.close()
+
+
+def test_gpu_repeated_execute_with_marking_inside_the_batch(H, sg):
+    """h264mi_batch_execute may be repeated for a batch that does NOT start with an IDR picture and whose marking
+    operations free reference pictures half-way: those slots must not be recycled inside the batch."""
+    kw = dict(MATRIX["mmco_cabac"])
+    stream, rec, sizes = sg.encode(**kw)
+    cut = int(sizes[:7].sum())
+    dec = H.Decoder(max_streams=1, max_width=176, max_height=144, max_frames_per_batch=kw["frames"])
+    dec.decode([stream[:cut]])
+    dec.prepare([stream[cut:]])
+    for _ in range(3):
+        dec.execute()
+    dec.sync()
+    assert np.array_equal(dec.read_frames(0, crop=False), rec[7:])
+    dec.close()

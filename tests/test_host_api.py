@@ -141,3 +141,61 @@ def test_deblock_launch_plan_cannot_deadlock(H):
             else:
                 assert ring.value >= min(wmb, 16)
 
+
+
+class _Bits:
+    """MSB-first bit writer for hand-assembled parameter sets."""
+
+    def __init__(self):
+        self.b = []
+
+    def u(self, v, n):
+        self.b += [(v >> (n - 1 - i)) & 1 for i in range(n)]
+        return self
+
+    def ue(self, v):
+        v += 1
+        n = v.bit_length()
+        return self.u(0, n - 1).u(v, n) if n > 1 else self.u(1, 1)
+
+    def se(self, v):
+        return self.ue(2 * v - 1 if v > 0 else -2 * v)
+
+    def bytes(self):
+        bits = self.b + [1]
+        bits += [0] * (-len(bits) % 8)
+        return bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
+
+
+def _sps(log2_fn=4, poc_type=0, log2_poc=4, refs=1, wmb1=10, hmu1=8, crop=None, frame_mbs_only=1):
+    w = _Bits().u(66, 8).u(0xC0, 8).u(30, 8).ue(0).ue(log2_fn).ue(poc_type)
+    if poc_type == 0:
+        w.ue(log2_poc)
+    w.ue(refs).u(0, 1).ue(wmb1).ue(hmu1).u(frame_mbs_only, 1)
+    if not frame_mbs_only:
+        w.u(0, 1)
+    w.u(1, 1)
+    if crop:
+        w.u(1, 1)
+        for c in crop:
+            w.ue(c)
+    else:
+        w.u(0, 1)
+    return w.u(0, 1).bytes()
+
+
+def test_sps_range_checks(H):
+    """Fields that later size buffers, shift counts and addresses are range-checked at parse time (network-facing input):
+    every violation is H264MI_EBITSTREAM (-2), every boundary value is accepted."""
+    ok = H.NewSPS(_sps())
+    assert (ok.width, ok.height) == (176, 144)
+    assert H.NewSPS(_sps(log2_fn=12, log2_poc=12, refs=16, wmb1=511, hmu1=319)).PicWidthInMbsMinus1 == 511
+    assert H.NewSPS(_sps(crop=(0, 87, 0, 71))).width == 2  # 176 - 2*87
+    bad = [dict(log2_fn=13), dict(log2_poc=13), dict(poc_type=3), dict(refs=17), dict(wmb1=512), dict(hmu1=320),
+           dict(wmb1=(1 << 31) - 2), dict(hmu1=(1 << 32) - 2), dict(wmb1=(1 << 32) - 2),
+           dict(hmu1=160, frame_mbs_only=0),           # 2 * 161 macroblock rows
+           dict(crop=(44, 44, 0, 0)), dict(crop=(0, 0, 36, 36)), dict(crop=((1 << 31), 0, 0, 0)), dict(crop=(0, 0, 0, (1 << 32) - 2))]
+    for kw in bad:
+        with pytest.raises(H.H264MIError) as ei:
+            H.NewSPS(_sps(**kw))
+        assert ei.value.code == -2, kw

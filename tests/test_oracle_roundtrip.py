@@ -49,6 +49,22 @@ def test_matrix_exercises_the_syntax(sg, oracle_mod):
                 feats.add(("ref>0", cab))
             if mvx & 3 or mvy & 3:
                 feats.add(("qpel", cab))
+    # picture management: the generator must have emitted, and the oracle executed, every operation the matrix claims
+    dpb = {0: 0, 1: 0}
+    for name, kw in MATRIX.items():
+        if not any(kw.get(k) for k in ("rplm", "mmco", "idr_long_term", "nonref_period", "slice_qp_delta")) and kw.get("poc_type", 0) != 1:
+            continue
+        stream, _, _ = sg.encode(**kw)
+        emitted = sg.last_features()
+        oracle_mod.decode(stream, crop=False)
+        assert oracle_mod.last_features == emitted, (name, hex(emitted), hex(oracle_mod.last_features))
+        assert np.array_equal(oracle_mod.last_pocs, sg.last_pocs()), name
+        dpb[kw.get("cabac", 0)] |= emitted
+    for cab in (0, 1):
+        for bit, what in [(1, "mmco1"), (2, "mmco2"), (3, "mmco3"), (4, "mmco4"), (6, "mmco6"), (8, "rplm idc0"), (9, "rplm idc1"),
+                          (10, "rplm idc2"), (11, "long-term ref in list"), (12, "non-ref picture"), (13, "slice_qp_delta")]:
+            assert dpb[cab] >> bit & 1, (what, cab)
+    assert dpb[1] >> 5 & 1 and dpb[1] >> 14 & 1  # mmco5 and POC type 1 with a non-zero delta (CABAC cases)
     for cab in (0, 1):
         for raw in ("skip", 0, 1, 2, 3, 25, 30):  # P16x16/I_NxN, 16x8/I16, 8x16, P8x8, I_PCM (I and P slices)
             assert (raw, cab) in seen, (raw, cab)
