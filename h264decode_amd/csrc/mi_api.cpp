@@ -185,6 +185,7 @@ struct h264mi_decoder {
     std::vector<int> ev_kind;
     size_t ev_used = 0;
     double k_ms[5] = {0, 0, 0, 0, 0};
+    std::vector<float> launch_ms[4]; // duration of every launch of the last profiled pass, per kernel
 };
 
 static int g_device = -1;
@@ -1079,11 +1080,12 @@ extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
     if (d->profiling && d->ev_used >= 2) {
         size_t n = d->ev_used;
         double acc[4] = {0, 0, 0, 0};
+        for (auto &v : d->launch_ms) v.clear();
         for (size_t i = 1; i < n && i < d->ev.size(); i++) {
             float ms = 0;
             hipEventElapsedTime(&ms, d->ev[i - 1], d->ev[i]);
             int k = d->ev_kind[i];
-            if (k >= 0 && k < 4) acc[k] += ms;
+            if (k >= 0 && k < 4) acc[k] += ms, d->launch_ms[k].push_back(ms);
         }
         float tot = 0;
         hipEventElapsedTime(&tot, d->ev[0], d->ev[n - 1]);
@@ -1127,6 +1129,14 @@ extern "C" int32_t h264mi_decode_batch(h264mi_decoder *d, int32_t n, const uint8
 extern "C" int32_t h264mi_last_kernel_times(h264mi_decoder *d, double ms[5]) {
     if (!d || !ms) return H264MI_EINVAL;
     for (int i = 0; i < 5; i++) ms[i] = d->k_ms[i];
+    return H264MI_OK;
+}
+
+extern "C" int32_t h264mi_last_launch_times(h264mi_decoder *d, int32_t kernel, float *ms, int32_t cap, int32_t *n) {
+    if (!d || !n || kernel < 0 || kernel > 3 || cap < 0 || (cap && !ms)) return H264MI_EINVAL;
+    const std::vector<float> &v = d->launch_ms[kernel];
+    for (int i = 0; i < cap && i < static_cast<int>(v.size()); i++) ms[i] = v[i];
+    *n = static_cast<int32_t>(v.size());
     return H264MI_OK;
 }
 

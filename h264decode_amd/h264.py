@@ -216,6 +216,15 @@ class Decoder:
         check(self._L.h264mi_last_kernel_times(self._h, a))
         return dict(zip(("entropy", "inter", "intra", "deblock", "total"), list(a)))
 
+    def launch_times_ms(self, kernel):
+        """Duration of every launch of `kernel` ("entropy", "inter", "intra", "deblock") in the last profiled pass."""
+        k = ("entropy", "inter", "intra", "deblock").index(kernel)
+        n = ctypes.c_int32(0)
+        check(self._L.h264mi_last_launch_times(self._h, k, None, 0, ctypes.byref(n)))
+        a = (ctypes.c_float * max(n.value, 1))()
+        check(self._L.h264mi_last_launch_times(self._h, k, a, n.value, ctypes.byref(n)))
+        return list(a)[:n.value]
+
     def _args(self, streams):
         n = len(streams)
         bufs = (ctypes.c_void_p * n)()

@@ -219,6 +219,10 @@ int32_t h264mi_frame_read_mbrecs(h264mi_decoder *dec, int32_t stream, int32_t fr
  * when profiling was enabled with h264mi_decoder_set_profiling(dec, 1). */
 int32_t h264mi_decoder_set_profiling(h264mi_decoder *dec, int32_t on);
 int32_t h264mi_last_kernel_times(h264mi_decoder *dec, double ms[5]);
+/* Duration (ms) of every single launch of one kernel in that pass, in launch order (kernel: 0 entropy, 1 inter, 2 intra,
+ * 3 deblock; launch k of the pixel kernels handles picture k of every stream, so launch 0 of a GOP is the IDR picture).
+ * *n receives the number of launches; at most cap values are written. */
+int32_t h264mi_last_launch_times(h264mi_decoder *dec, int32_t kernel, float *ms, int32_t cap, int32_t *n);
 
 const char *h264mi_last_error_string(void);
 const char *h264mi_version(void);

@@ -276,11 +276,14 @@ def test_gpu_isolation_keeps_other_streams_alive(H, sg, oracle_mod):
     dec = H.Decoder(max_streams=3, max_width=176, max_height=144, max_frames_per_batch=3)
     with pytest.raises(H.H264MIError):
         dec.decode([good[0], bad, good[0]])  # without isolation the batch fails as before
-    dec.reset()
+    dec.close()
+    dec = H.Decoder(max_streams=3, max_width=176, max_height=144, max_frames_per_batch=3)
     dec.set_isolation(True)
     dec.decode([good[0], bad, good[0]])
     assert dec.stream_status(0) == 0 and dec.stream_status(2) == 0 and dec.stream_status(1) == -2
     assert dec.frame_count(1) == 0
+    dec.decode([good[0], bad, good[0]])  # the marked stream now waits for an IDR picture: its P pictures are skipped, not errors
+    assert dec.stream_status(1) == 0 and dec.frame_count(1) == 0 and dec.frame_count(0) == 3
     assert np.array_equal(dec.read_frames(0, crop=False), good[1]) and np.array_equal(dec.read_frames(2, crop=False), good[1])
     # the slot is given to a new client: nothing of the old one survives, a P picture without an IDR is not decodable
     dec.reset_stream(1)
