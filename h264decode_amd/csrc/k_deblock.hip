@@ -1,28 +1,31 @@
 // h264decode_amd/csrc/k_deblock.hip -- K5: in-loop deblocking filter (ITU-T H.264 8.7), gfx950.
 //
 // 8.7 is specified per macroblock in raster order (vertical edges left to right, then horizontal
-// edges top to bottom), and the left-edge filter of MB(x+1,y) rewrites columns of MB(x,y) AFTER
+// edges top to bottom), and the left-edge filter of MB(x+1,y) rewrites columns 13..15 of MB(x,y) AFTER
 // MB(x,y)'s horizontal edges were filtered, so a whole-picture "all vertical, then all horizontal"
-// pass is not bit-exact.  The exact dependency is MB(x,y) after MB(x-1,y) and MB(x+1,y-1): a 2-D
-// wavefront.
+// pass is not bit-exact.  Per 4x4 block the order is: left edge, right edge, top edge, bottom edge --
+// except in the last block column of a macroblock, whose right edge belongs to the next macroblock.
+// That exception makes every macroblock row one serial chain (V0..V3 of MB x, its horizontal edges in
+// columns 12..15, V0 of MB x+1, ...), and the top edge of MB(x,y) needs rows 13..15 of MB(x,y-1) after
+// V0 of MB(x+1,y-1).  So a picture is a 2-D wavefront in which row y can trail row y-1 by ONE macroblock,
+// provided the vertical-edge pass of a step runs before the horizontal-edge pass of the same step.
 //
-// Mapping.  One workgroup owns a picture, so no cross-CU hand-off is needed; the host picks the number
-// of wavefronts (blockDim.x / 64, at most MI_DEBLOCK_MAX_WAVES) so that the groups of 4 macroblock rows
-// are covered in as few rounds as possible (1080p: 17 groups -> 9 wavefronts, 2 rounds).  A wavefront owns a GROUP of 4 consecutive macroblock rows and filters four macroblocks
-// per step -- 16 lanes each -- staggered along the wavefront diagonal: at step t sub-row k works on
-// MB (t - 2k, 4g + k).  All four are independent by construction, so the 64 lanes are busy and the
-// per-step latency is shared by 4 macroblocks.
-//   * inside a group the 4 sample rows handed from sub-row k-1 to sub-row k travel through a small
-//     LDS ring (4 macroblock columns), never through HBM;
-//   * between groups (different wavefronts of the workgroup) they travel through a second LDS ring of
-//     `ring` macroblock columns per in-flight group (chosen by the host, see mi_deblock_plan), ordered by two LDS counters per group
-//     (columns finished by its last row / columns consumed by its first row: back-pressure);
-//     no HBM access sits on the dependency path: samples are loaded once (prefetch) and stored once,
-//     fire-and-forget -- rows 13..15 of a macroblock are written by the macroblock BELOW it (which
-//     modifies them last), so no address is ever stored twice;
-//   * MbRecs are prefetched one step ahead, the macroblock's own samples four macroblocks (one 64-byte line
-//     per lane) at a time; the 4 columns to the left are carried over from the previous tile in LDS;
-//   * a lane filters a whole line of samples in registers (4 luma edges, then 2 chroma edges).
+// Mapping.  One workgroup owns a picture (no cross-CU hand-off); it has up to 16 wavefronts, and a
+// wavefront owns a GROUP of 4 consecutive macroblock rows ("sub-rows", 16 lanes each).  At step t sub-row k of a
+// group works on macroblock column t - k, so a group trails the one above it by 4 steps and 16 groups (64 of the
+// 68 macroblock rows of a 1080p picture) run side by side.  A step is:
+//   1. commit the prefetched MbRecs, compute the 32 boundary strengths of the macroblock (2 per lane);
+//   2. vertical edges: a lane filters one whole line of 20 samples in registers -- 16 fresh from the
+//      prefetch registers, 4 (columns 12..15 of the macroblock to the left) from the LDS tile;
+//   3. hand-off: those 4 columns are final now, which completes rows 12..15 of the macroblock to the left for the
+//      sub-row below (same wavefront: an LDS buffer; next group: an LDS ring ordered by two counters with
+//      workgroup-scope release / acquire); then every sub-row picks up the rows above its own macroblock;
+//   4. horizontal edges: a lane filters one column of 20 samples;
+//   5. finished samples go to HBM.  Loads and stores move whole 64-byte lines: a lane prefetches the line of its row
+//      for 4 macroblocks at once, and collects its 16 finished bytes per step in registers until the aligned group of
+//      4 macroblocks is complete (rows 13..15 of a macroblock are finished -- and stored -- by the sub-row below).
+//      Fetching / storing 16 bytes per step instead costs 4x the HBM traffic (every line moves four times).
+// No HBM access sits on the dependency path, and nothing is stored twice.
 //
 // Absent from the reference (only the slice-header fields are parsed: h264/slice.go:1021-1027).
 #include <hip/hip_runtime.h>
@@ -35,46 +38,50 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
-struct DbTile {
-    uint8_t y[20][20];    // rows/cols -4..15 of the macroblock
-    uint8_t c[2][12][12]; // rows -4..7 (only -2.. used), cols -4..7
-};
 struct DbSub { // state of one of the 4 macroblock rows a wavefront works on
-    DbTile tile[2];      // double buffer: the left 4 columns of tile[k] come from tile[k^1]
+    // luma tile, rows -4..15 of the macroblock: bytes 12..15 of a row = columns -4..-1, bytes 16..31 = columns 0..15
+    alignas(16) uint8_t y[20][32];
+    // chroma tiles, rows -4..7 (-2.. used): bytes 4..7 = columns -4..-1, bytes 8..15 = columns 0..7
+    alignas(16) uint8_t c[2][12][16];
     MbRec rec[3];        // cur / left alternate in [0],[1]; [2] = macroblock above
     uint8_t bs[2][4][4]; // [dir][edge][segment]
-    // bottom rows of this sub-row's macroblocks for the sub-row below: ring over 4 MB columns
-    uint8_t bot_y[4][4][16];    // [column & 3][row 12..15][x]
-    uint8_t bot_c[4][2][2][8];  // [column & 3][plane][row 6..7][x]
-    uint8_t pad[32];            // sub-row stride = 8 dwords (mod 32 banks): the 4 sub-rows of a wavefront do not hit the same banks
-    // output staging: finished samples of an aligned group of 4 macroblocks, flushed as whole 64-byte (luma) / 32-byte
-    // (chroma) lines -- storing 16 bytes per step left every line in HBM as four partial writes (4x write traffic)
-    alignas(16) uint8_t ost_y[16][64];
-    alignas(16) uint8_t ost_c[2][8][32];
+    // rows 12..15 (chroma 6..7) of the macroblock this sub-row finished in the previous step, for the sub-row below
+    alignas(16) uint8_t bot_y[4][16];
+    alignas(8) uint8_t bot_c[2][2][8];
 };
 struct DbWave {
     DbSub sub[4];
 };
-struct GroupSlot { // bottom rows of one macroblock column handed to the group below
-    uint8_t y[4][16];   // rows 12..15
-    uint8_t c[2][2][8]; // [plane][rows 6..7]
+struct GroupSlot { // rows 12..15 of one macroblock column handed to the group below
+    alignas(16) uint8_t y[4][16];
+    alignas(8) uint8_t c[2][2][8];
 };
-struct DbShared { // followed in dynamic LDS by DbWave[nwaves] and GroupSlot[nwaves][ring]
+struct DbShared { // followed in dynamic LDS by DbWave[nwaves] and the hand-off rings
     uint8_t alpha[52], beta[52], tc0[52][4];
-    int prog[96]; // per group: macroblocks finished in its LAST row
+    int prog[96]; // per group: macroblock columns of its LAST row that are final (rows 12..15 complete)
     int cons[96]; // per group: hand-off slots consumed by its FIRST row
 };
-
-#if MI_DB_STATS /* diagnostics: shader clocks per phase of wavefront `wave`, written into the pad bytes of MbRec[wave] of the picture */
-#define DB_T0() uint64_t db_mark = __builtin_readcyclecounter(); uint32_t db_acc[4] = {0, 0, 0, 0}
-#define DB_T(k) do { const uint64_t now_ = __builtin_readcyclecounter(); db_acc[k] += static_cast<uint32_t>((now_ - db_mark) >> 4); db_mark = now_; } while (0)
-#else
-#define DB_T0() ((void)0)
-#define DB_T(k) ((void)0)
-#endif
 static_assert(sizeof(DbShared) <= MI_DEBLOCK_HDR_BYTES && sizeof(DbWave) == MI_DEBLOCK_WAVE_BYTES && sizeof(GroupSlot) == MI_DEBLOCK_SLOT_BYTES, "LDS layout constants");
 
-__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+// Global memory through an explicit address-space-1 pointer with a wave-uniform base and a 32-bit per-lane offset: the
+// frame pointers are built from integers (FramePool::base), which the compiler would otherwise treat as generic (flat_*
+// instructions, two wait counters) and keep as 64-bit per-lane pointers in registers for the whole kernel.
+typedef __attribute__((address_space(1))) uint8_t g8;
+typedef uint32_t v4u __attribute__((ext_vector_type(4))); // native vectors: assignable across address spaces (HIP's uint4 is a struct)
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) v4u g_uint4;
+typedef __attribute__((address_space(1))) v2u g_uint2;
+#define GLD16(base, off) (*reinterpret_cast<const g_uint4 *>((base) + (off)))
+#define GLD8(base, off) (*reinterpret_cast<const g_uint2 *>((base) + (off)))
+#define GST16(base, off, v) (*reinterpret_cast<g_uint4 *>((base) + (off)) = (v))
+#define GST8(base, off, v) (*reinterpret_cast<g_uint2 *>((base) + (off)) = (v))
+// keeps lane-dependent values from being hoisted out of the step loop (dozens of loop-invariant addresses would otherwise
+// live in registers for the whole kernel)
+#define OPAQUE(x) asm volatile("" : "+v"(x))
+
+__device__ __forceinline__ int adiff(int a, int b) { // |a - b| for operands in 0..65535 (one v_sad_u16)
+    return static_cast<int>(__builtin_amdgcn_sad_u16(static_cast<uint32_t>(a), static_cast<uint32_t>(b), 0u));
+}
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
 
 // filter one edge of a line of samples held in registers (8.7.2.3 / 8.7.2.4); q0 = px[Q].
@@ -83,7 +90,7 @@ __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, 
 template <int Q, bool CHROMA, int N>
 __device__ __forceinline__ void filter_edge(int (&px)[N], int bs, int alpha, int beta, int tc0) {
     const int p0 = px[Q - 1], p1 = px[Q - 2], q0 = px[Q], q1 = px[Q + 1];
-    const bool on = bs != 0 && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
+    const bool on = bs != 0 && adiff(p0, q0) < alpha && adiff(p1, p0) < beta && adiff(q1, q0) < beta;
     if (__builtin_amdgcn_ballot_w64(on) == 0) return;
     const bool strong = on && bs == 4;
     int np0, nq0;
@@ -99,7 +106,7 @@ __device__ __forceinline__ void filter_edge(int (&px)[N], int bs, int alpha, int
         return;
     } else {
         const int p2 = px[Q - 3], q2 = px[Q + 2];
-        const bool ap = iabs(p2 - p0) < beta, aq = iabs(q2 - q0) < beta;
+        const bool ap = adiff(p2, p0) < beta, aq = adiff(q2, q0) < beta;
         const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
         const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
         const int avg = (p0 + q0 + 1) >> 1;
@@ -109,7 +116,7 @@ __device__ __forceinline__ void filter_edge(int (&px)[N], int bs, int alpha, int
         int np2 = p2, nq2 = q2;
         if (__builtin_amdgcn_ballot_w64(strong) != 0) {
             const int p3 = px[Q - 4], q3 = px[Q + 3];
-            const bool small = iabs(p0 - q0) < ((alpha >> 2) + 2);
+            const bool small = adiff(p0, q0) < ((alpha >> 2) + 2);
             const bool sp = strong && ap && small, sq = strong && aq && small;
             const int s3 = p0 + q0 + p1 + 2; // shared partial sums of the 4- and 5-tap filters
             np0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (strong ? (2 * p1 + p0 + q1 + 2) >> 2 : np0);
@@ -132,155 +139,140 @@ __device__ __forceinline__ int edge_bs(const MbRec *mp, int pb, const MbRec *mq,
     if (((mp->nzmask >> pb) & 1) || ((mq->nzmask >> qb) & 1)) return 2;
     int rp = mp->refslot[((pb >> 3) << 1) | ((pb & 3) >> 1)], rq = mq->refslot[((qb >> 3) << 1) | ((qb & 3) >> 1)];
     if (rp != rq) return 1;
-    if (iabs(mp->mv[pb][0] - mq->mv[qb][0]) >= 4 || iabs(mp->mv[pb][1] - mq->mv[qb][1]) >= 4) return 1;
+    if (abs(mp->mv[pb][0] - mq->mv[qb][0]) >= 4 || abs(mp->mv[pb][1] - mq->mv[qb][1]) >= 4) return 1;
     return 0;
 }
 
+__device__ __forceinline__ void unpack4(uint32_t w, int &a, int &b, int &c, int &d) {
+    a = static_cast<int>(w & 255u), b = static_cast<int>(__builtin_amdgcn_ubfe(w, 8, 8)), c = static_cast<int>(__builtin_amdgcn_ubfe(w, 16, 8)), d = static_cast<int>(w >> 24);
+}
+__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
+    return static_cast<uint32_t>(a) | (static_cast<uint32_t>(b) << 8) | (static_cast<uint32_t>(c) << 16) | (static_cast<uint32_t>(d) << 24);
+}
+
 extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
-                                                                                  const DevTables *tab, const MbRec *mbrec, int ring) {
+                                                                                  const DevTables *tab, const MbRec *mbrec, int ring, int ring_last, int last_bufs) {
     extern __shared__ uint4 dyn_lds[];
     const int nthreads = static_cast<int>(blockDim.x), nwaves = nthreads >> 6;
     DbShared &sh = *reinterpret_cast<DbShared *>(dyn_lds);
     DbWave *waves = reinterpret_cast<DbWave *>(reinterpret_cast<uint8_t *>(dyn_lds) + MI_DEBLOCK_HDR_BYTES);
-    GroupSlot *gring = reinterpret_cast<GroupSlot *>(waves + nwaves);
-    const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6;
-    const int sub = lane >> 4, li = lane & 15; // sub-row inside the group, lane inside the macroblock
+    GroupSlot *rings = reinterpret_cast<GroupSlot *>(waves + nwaves); // region r (written by the groups of wavefront r) starts at r * ring
+    const int tid = static_cast<int>(threadIdx.x), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane_v = tid & 63;
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
     const FramePool *pool = &pools[pd->stream];
     const int W = wmb * 16, H = hmb * 16, Wc = W / 2; // the picture's own geometry
-    uint8_t *py = reinterpret_cast<uint8_t *>(pool->base) + static_cast<size_t>(pd->slot) * pool->slot_bytes;
-    uint8_t *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
+    g8 *const py = (g8 *)(pool->base + static_cast<uint64_t>(pd->slot) * pool->slot_bytes); // luma plane; Cb at +W*H, Cr at +W*H*5/4
+    const uint32_t cb_off = static_cast<uint32_t>(W) * H, cr_off = cb_off + cb_off / 4;
     for (int i = tid; i < 96; i += nthreads) sh.prog[i] = 0, sh.cons[i] = 0;
     for (int i = tid; i < 52; i += nthreads) {
         sh.alpha[i] = tab->alpha[i], sh.beta[i] = tab->beta[i];
         sh.tc0[i][0] = 0, sh.tc0[i][1] = tab->tc0[i][1], sh.tc0[i][2] = tab->tc0[i][2], sh.tc0[i][3] = tab->tc0[i][3];
     }
     __syncthreads();
-    DbSub *ss = &waves[wave].sub[sub];
-    const DbSub *sup = sub > 0 ? &waves[wave].sub[sub - 1] : nullptr; // the sub-row above (same wavefront)
     const MbRec *recs = mbrec + pd->mb_base;
     const int ngroups = (hmb + 3) >> 2;
-    DB_T0();
+    const v4u z4 = v4u{0u, 0u, 0u, 0u};
+    const v2u z2 = v2u{0u, 0u};
     for (int g = wave; g < ngroups; g += nwaves) {
+        int lane = lane_v;
+        OPAQUE(lane);
+        const int sub = lane >> 4, li = lane & 15; // sub-row inside the group, lane inside the macroblock
         const int mby = g * 4 + sub;
-        const bool row_ok = mby < hmb, has_top = mby > 0;
-        const MbRec *row = recs + static_cast<size_t>(row_ok ? mby : 0) * wmb;
+        const bool row_ok = mby < hmb, has_top = mby > 0, last_row = mby == hmb - 1;
         const int last_sub = min(3, hmb - 1 - g * 4); // last valid sub-row of this group
-        // Prefetch registers.  Samples are fetched one aligned group of 4 macroblocks at a time -- the whole 64-byte
-        // line of a luma row (32 bytes of a chroma row) by one lane with back-to-back loads -- so that every line
-        // leaves HBM once; fetching 16 bytes per step let the line be evicted between its four uses (4x read traffic).
-        // MbRecs (cur, top: 2 x 128 bytes as 4 dwords per lane) are whole lines already and stay per step.
-        const uint4 z4 = make_uint4(0, 0, 0, 0);
-        uint4 gy0 = z4, gy1 = z4, gy2 = z4, gy3 = z4, gc0 = z4, gc1 = z4, pre_rec = z4;
-        auto prefetch_samples = [&](int gb) { // gb = first macroblock of the aligned group
-            if (!row_ok || gb < 0 || gb >= wmb) return;
-            const uint8_t *yrow = py + static_cast<size_t>(mby * 16 + li) * W + gb * 16;
-            const uint8_t *crow = (li < 8 ? pcb : pcr) + static_cast<size_t>(mby * 8 + (li & 7)) * Wc + gb * 8;
-            const int left = wmb - gb; // macroblocks from gb to the end of the row (>= 1)
-            gy0 = *reinterpret_cast<const uint4 *>(yrow);
-            if (left > 1) gy1 = *reinterpret_cast<const uint4 *>(yrow + 16);
-            if (left > 2) gy2 = *reinterpret_cast<const uint4 *>(yrow + 32);
-            if (left > 3) gy3 = *reinterpret_cast<const uint4 *>(yrow + 48);
-            if (left > 1)
-                gc0 = *reinterpret_cast<const uint4 *>(crow);
-            else {
-                const uint2 h = *reinterpret_cast<const uint2 *>(crow);
-                gc0 = make_uint4(h.x, h.y, 0, 0);
-            }
-            if (left > 3)
-                gc1 = *reinterpret_cast<const uint4 *>(crow + 16);
-            else if (left > 2) {
-                const uint2 h = *reinterpret_cast<const uint2 *>(crow + 16);
-                gc1 = make_uint4(h.x, h.y, 0, 0);
-            }
+        const bool feeds_group = g + 1 < ngroups;     // this group's last row hands its bottom rows to group g + 1
+        // hand-off rings: the one this group writes (region `wave`) and the one it reads (written by group g - 1)
+        // (the last wavefront's region holds whole rows and, from three rounds on, one buffer per round parity: see mi_deblock_plan)
+        const bool out_last = wave == nwaves - 1;
+        const int out_depth = out_last ? ring_last : ring;
+        GroupSlot *out_ring = rings + wave * ring + (out_last ? ((g / nwaves) % last_bufs) * ring_last : 0);
+        const int in_wave = (g + nwaves - 1) % nwaves;
+        const bool in_last = in_wave == nwaves - 1;
+        const int in_depth = in_last ? ring_last : ring;
+        const GroupSlot *in_ring = rings + in_wave * ring + (in_last && g > 0 ? (((g - 1) / nwaves) % last_bufs) * ring_last : 0);
+        const uint32_t yrow0 = static_cast<uint32_t>((row_ok ? mby : 0) * 16 + li) * W;                                   // this lane's luma row
+        const uint32_t crow0 = (li < 8 ? cb_off : cr_off) + static_cast<uint32_t>((row_ok ? mby : 0) * 8 + (li & 7)) * Wc; // and chroma row
+        // Input registers.  Slot s of P / Pc holds macroblock column c with (c + sub) % 4 == s, so that at step t every
+        // sub-row consumes slot t % 4 (a wave-uniform register index) although the sub-rows are one column apart.
+        v4u P0 = z4, P1 = z4, P2 = z4, P3 = z4;
+        v2u Q0 = z2, Q1 = z2, Q2 = z2, Q3 = z2;
+        v4u pre_rec = z4;
+        auto prefetch_group = [&](int gb) { // gb = first macroblock of an aligned group of four
+            if (!row_ok || gb >= wmb) return;
+            const uint32_t yb = yrow0 + gb * 16, cb = crow0 + gb * 8;
+            const int left = wmb - gb;
+            const int j0 = (0 - sub) & 3, j1 = (1 - sub) & 3, j2 = (2 - sub) & 3, j3 = (3 - sub) & 3; // position inside the group of slot s
+            if (j0 < left) P0 = GLD16(py, yb + j0 * 16), Q0 = GLD8(py, cb + j0 * 8);
+            if (j1 < left) P1 = GLD16(py, yb + j1 * 16), Q1 = GLD8(py, cb + j1 * 8);
+            if (j2 < left) P2 = GLD16(py, yb + j2 * 16), Q2 = GLD8(py, cb + j2 * 8);
+            if (j3 < left) P3 = GLD16(py, yb + j3 * 16), Q3 = GLD8(py, cb + j3 * 8);
         };
         auto prefetch_rec = [&](int mbx) {
             if (!row_ok || mbx < 0 || mbx >= wmb) return;
             // lanes 0-7: cur record (8 x 16 B), lanes 8-15: record above
-            const MbRec *src = li < 8 ? row + mbx : (has_top ? row + mbx - wmb : row + mbx);
-            pre_rec = reinterpret_cast<const uint4 *>(src)[li & 7];
+            const uint32_t mbi = static_cast<uint32_t>((li >= 8 && has_top ? mby - 1 : mby) * wmb + mbx);
+            pre_rec = reinterpret_cast<const v4u *>(recs + mbi)[li & 7];
         };
-        prefetch_samples(0);
-        prefetch_rec(-2 * sub); // step 0 (only sub-row 0 is active)
-        // this wavefront's ring row was last used by group g - nwaves: its reader (g - nwaves + 1) must be through with it
-        if (g >= nwaves && g + 1 < ngroups) {
-            while (__hip_atomic_load(&sh.cons[g - nwaves + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < wmb) __builtin_amdgcn_s_sleep(1);
-            asm volatile("" ::: "memory");
-        }
-        const int nsteps = wmb + 6;
+        // Output registers: slot s collects the finished bytes of the column with (c + sub) % 4 == s; a group of four
+        // columns leaves as one 64-byte line (32 bytes of chroma).  Lanes 13..15 do not own finished rows (rows 13..15
+        // of a macroblock are completed by the macroblock below): they collect rows -3..-1 of the macroblock ABOVE
+        // instead, which this sub-row completes -- except in the last picture row, where they own rows 13..15 after all
+        // and the three rows above are stored directly.
+        v4u R0 = z4, R1 = z4, R2 = z4, R3 = z4;
+        v2u S0 = z2, S1 = z2, S2 = z2, S3 = z2;
+        const bool up_lane = li >= 13 && !last_row;        // luma: this lane collects a row of the macroblock above
+        const bool upc_lane = (li & 7) == 7 && !last_row;  // chroma: rows 7 collect row -1 of the macroblock above
+        const bool y_stores = !up_lane || has_top, c_stores = !upc_lane || has_top; // up lanes of the first picture row have nothing above
+        const uint32_t yout = up_lane && has_top ? yrow0 - 16u * W : yrow0; // row li of the MB above = row li - 16
+        const uint32_t cout = upc_lane && has_top ? crow0 - 8u * Wc : crow0;
+        auto flush = [&](int first_mb, int n_mb) { // columns first_mb .. first_mb + n_mb - 1 (an aligned group, or its start)
+            const int j0 = (0 - sub) & 3, j1 = (1 - sub) & 3, j2 = (2 - sub) & 3, j3 = (3 - sub) & 3;
+            if (y_stores) {
+                const uint32_t yb = yout + first_mb * 16;
+                if (j0 < n_mb) GST16(py, yb + j0 * 16, R0);
+                if (j1 < n_mb) GST16(py, yb + j1 * 16, R1);
+                if (j2 < n_mb) GST16(py, yb + j2 * 16, R2);
+                if (j3 < n_mb) GST16(py, yb + j3 * 16, R3);
+            }
+            if (c_stores) {
+                const uint32_t cb = cout + first_mb * 8;
+                if (j0 < n_mb) GST8(py, cb + j0 * 8, S0);
+                if (j1 < n_mb) GST8(py, cb + j1 * 8, S1);
+                if (j2 < n_mb) GST8(py, cb + j2 * 8, S2);
+                if (j3 < n_mb) GST8(py, cb + j3 * 8, S3);
+            }
+        };
+        prefetch_group(0);
+        prefetch_rec(-sub); // step 0 (only sub-row 0 is active)
+        // the ring this group writes was last used by the group `reuse` groups earlier: that group's reader must be through with it
+        const int reuse = out_last ? nwaves * last_bufs : nwaves;
+        if (g >= reuse && feeds_group)
+            while (__hip_atomic_load(&sh.cons[g - reuse + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < wmb) __builtin_amdgcn_s_sleep(1);
+        const int nsteps = wmb + 3;
         for (int t = 0; t < nsteps; t++) {
-            const int mbx = t - 2 * sub;
+            int lane = lane_v;
+            OPAQUE(lane);
+            const int sub = lane >> 4, li = lane & 15;
+            DbSub *ss = &waves[wave].sub[sub];
+            const DbSub *sup = &waves[wave].sub[sub > 0 ? sub - 1 : 0]; // the sub-row above (same wavefront)
+            const int mby = g * 4 + sub;
+            const bool row_ok = mby < hmb, has_top = mby > 0, last_row = mby == hmb - 1;
+            const bool up_lane = li >= 13 && !last_row, upc_lane = (li & 7) == 7 && !last_row;
+            const int mbx = t - sub;
             const bool active = row_ok && mbx >= 0 && mbx < wmb;
-            DbTile *tl = &ss->tile[t & 1], *prev = &ss->tile[(t & 1) ^ 1];
             const int cur_slot = t & 1;
             MbRec *mq = &ss->rec[cur_slot], *mleft_rec = &ss->rec[cur_slot ^ 1], *mtop_rec = &ss->rec[2];
-            DB_T(3);
-            // ---- commit the prefetched data to LDS ----
-            if (active) {
-                reinterpret_cast<uint4 *>(li < 8 ? mq : mtop_rec)[li & 7] = pre_rec;
-                const int k4 = mbx & 3;
-                const uint4 pre_y = k4 == 0 ? gy0 : (k4 == 1 ? gy1 : (k4 == 2 ? gy2 : gy3));
-                const uint4 pc4 = k4 < 2 ? gc0 : gc1;
-                const uint2 pre_c = (k4 & 1) ? make_uint2(pc4.z, pc4.w) : make_uint2(pc4.x, pc4.y);
-                uint32_t *yr = reinterpret_cast<uint32_t *>(&tl->y[4 + li][4]);
-                yr[0] = pre_y.x, yr[1] = pre_y.y, yr[2] = pre_y.z, yr[3] = pre_y.w;
-                uint32_t *cr = reinterpret_cast<uint32_t *>(&tl->c[li >> 3][4 + (li & 7)][4]);
-                cr[0] = pre_c.x, cr[1] = pre_c.y;
-                if (mbx > 0) { // left 4 columns: carried over from the previous tile
-                    *reinterpret_cast<uint32_t *>(&tl->y[4 + li][0]) = *reinterpret_cast<const uint32_t *>(&prev->y[4 + li][16]);
-                    *reinterpret_cast<uint32_t *>(&tl->c[li >> 3][4 + (li & 7)][0]) = *reinterpret_cast<const uint32_t *>(&prev->c[li >> 3][4 + (li & 7)][8]);
-                }
-                // rows above from the sub-row above (same wavefront): LDS ring, final since the previous step
-                if (sub > 0) {
-                    if (li < 4) {
-                        const uint32_t *src = reinterpret_cast<const uint32_t *>(sup->bot_y[mbx & 3][li]);
-                        uint32_t *dst = reinterpret_cast<uint32_t *>(&tl->y[li][4]);
-                        dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
-                    } else if (li < 8) {
-                        const uint32_t *src = reinterpret_cast<const uint32_t *>(sup->bot_c[mbx & 3][(li >> 1) & 1][li & 1]);
-                        uint32_t *dst = reinterpret_cast<uint32_t *>(&tl->c[(li >> 1) & 1][2 + (li & 1)][4]);
-                        dst[0] = src[0], dst[1] = src[1];
-                    }
-                }
-            }
-            // ---- sub-row 0: rows above come from the previous group (another wavefront) through the group ring ----
-            {
-                const int x0 = t; // macroblock of sub-row 0 in this step
-                if (g > 0 && x0 < wmb) {
-                    const int need = min(x0 + 2, wmb);
-                    while (__hip_atomic_load(&sh.prog[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
-                    asm volatile("" ::: "memory");
-                    if (sub == 0) {
-                        const GroupSlot *gs = &gring[((g - 1) % nwaves) * ring + x0 % ring];
-                        if (li < 4) {
-                            const uint32_t *src = reinterpret_cast<const uint32_t *>(gs->y[li]);
-                            uint32_t *dst = reinterpret_cast<uint32_t *>(&tl->y[li][4]);
-                            dst[0] = src[0], dst[1] = src[1], dst[2] = src[2], dst[3] = src[3];
-                        } else if (li < 8) {
-                            const uint32_t *src = reinterpret_cast<const uint32_t *>(gs->c[(li >> 1) & 1][li & 1]);
-                            uint32_t *dst = reinterpret_cast<uint32_t *>(&tl->c[(li >> 1) & 1][2 + (li & 1)][4]);
-                            dst[0] = src[0], dst[1] = src[1];
-                        }
-                    }
-                }
-                // back-pressure: the ring slot this step's last sub-row will overwrite held column xl - RING of this
-                // group; the group below must have consumed it
-                const int xl = t - 2 * last_sub;
-                if (g + 1 < ngroups && xl >= ring && xl < wmb) {
-                    while (__hip_atomic_load(&sh.cons[g + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < xl - ring + 1) __builtin_amdgcn_s_sleep(1);
-                    asm volatile("" ::: "memory");
-                }
-            }
-            DB_T(0);
+            // this step's input registers (wave-uniform slot)
+            const int ts = t & 3;
+            const v4u in_y = ts == 0 ? P0 : (ts == 1 ? P1 : (ts == 2 ? P2 : P3));
+            const v2u in_c = ts == 0 ? Q0 : (ts == 1 ? Q1 : (ts == 2 ? Q2 : Q3));
+            // ---- 1. records -> LDS; boundary strengths: 32 per macroblock, 2 per lane ----
+            if (active) reinterpret_cast<v4u *>(li < 8 ? mq : mtop_rec)[li & 7] = pre_rec;
             WAVE_SYNC();
-            if (g > 0 && t < wmb) { // the hand-off slot of column t has been copied into the tile
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store(&sh.cons[g], t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if ((mbx & 3) == 3) prefetch_samples(mbx + 1); // the group's registers are free: fetch the next one (used from the next step on)
+            if (active && (mbx & 3) == 3) prefetch_group(mbx + 1); // the input registers of this sub-row are free again
             prefetch_rec(mbx + 1);
-            // ---- boundary strengths: 32 per macroblock, 2 per lane ----
             const MbRec *ml = nullptr, *mt = nullptr;
             int dbf = 1;
             if (active) {
@@ -290,201 +282,210 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
                     if (ml && ml->slice_in_pic != mq->slice_in_pic) ml = nullptr;
                     if (mt && mt->slice_in_pic != mq->slice_in_pic) mt = nullptr;
                 }
-                if (dbf != 1) {
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int idx = li + 16 * h, dir = idx >> 4, e = (idx >> 2) & 3, k = idx & 3;
-                        const MbRec *mn = dir == 0 ? ml : mt;
-                        int bs = 0;
-                        if (!(e == 0 && !mn) && !((e & 1) && mq->t8x8)) {
-                            const MbRec *mp = e == 0 ? mn : mq;
-                            int qb = dir == 0 ? k * 4 + e : e * 4 + k;
-                            int pb = dir == 0 ? k * 4 + (e == 0 ? 3 : e - 1) : (e == 0 ? 3 : e - 1) * 4 + k;
-                            bs = edge_bs(mp, pb, mq, qb, e == 0);
-                        }
-                        ss->bs[dir][e][k] = static_cast<uint8_t>(bs);
+                for (int h = 0; h < 2; h++) {
+                    const int idx = li + 16 * h, dir = idx >> 4, e = (idx >> 2) & 3, k = idx & 3;
+                    const MbRec *mn = dir == 0 ? ml : mt;
+                    int bs = 0;
+                    if (dbf != 1 && !(e == 0 && !mn) && !((e & 1) && mq->t8x8)) {
+                        const MbRec *mp = e == 0 ? mn : mq;
+                        int qb = dir == 0 ? k * 4 + e : e * 4 + k;
+                        int pb = dir == 0 ? k * 4 + (e == 0 ? 3 : e - 1) : (e == 0 ? 3 : e - 1) * 4 + k;
+                        bs = edge_bs(mp, pb, mq, qb, e == 0);
                     }
+                    ss->bs[dir][e][k] = static_cast<uint8_t>(bs);
                 }
             }
             WAVE_SYNC();
-            DB_T(1);
-            // ---- the two filtering passes: a whole line of samples in registers per lane ----
-            const bool filt = active && dbf != 1;
-            for (int dir = 0; dir < 2; dir++) {
-                if (filt) {
-                    const MbRec *mn = dir == 0 ? ml : mt;
-                    const uint32_t b0w = *reinterpret_cast<const uint32_t *>(ss->bs[dir][0]), b1w = *reinterpret_cast<const uint32_t *>(ss->bs[dir][1]);
-                    const uint32_t b2w = *reinterpret_cast<const uint32_t *>(ss->bs[dir][2]), b3w = *reinterpret_cast<const uint32_t *>(ss->bs[dir][3]);
-                    const int aoff = mq->alpha_off, boff = mq->beta_off;
-                    if (b0w | b1w | b2w | b3w) {
-                        { // luma: lane li = row (dir 0) or column (dir 1)
+            // filter parameters of this macroblock (8.7.2.2)
+            int aoff = 0, boff = 0, qpq = 0, qpc_q = 0;
+            if (active) aoff = mq->alpha_off, boff = mq->beta_off, qpq = mq->qp, qpc_q = mq->qpc[li >> 3];
+            // ---- 2. vertical edges: lane li = luma row li, then chroma (plane li >> 3, row li & 7) ----
+            {
+                const uint32_t b0w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[0][0]) : 0u, b1w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[0][1]) : 0u;
+                const uint32_t b2w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[0][2]) : 0u, b3w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[0][3]) : 0u;
+                const bool any = (b0w | b1w | b2w | b3w) != 0;
+                uint32_t w0 = 0, w1 = in_y.x, w2 = in_y.y, w3 = in_y.z, w4 = in_y.w; // w0 = columns -4..-1
+                uint32_t c0 = 0, c1 = in_c.x, c2 = in_c.y;
+                if (active && mbx > 0) {
+                    w0 = *reinterpret_cast<const uint32_t *>(&ss->y[4 + li][28]); // columns 12..15 of the previous macroblock, after its horizontal pass
+                    c0 = *reinterpret_cast<const uint32_t *>(&ss->c[li >> 3][4 + (li & 7)][12]);
+                }
+                if (__builtin_amdgcn_ballot_w64(any) != 0) {
+                    {
+                        int px[20];
+                        unpack4(w0, px[0], px[1], px[2], px[3]);
+                        unpack4(w1, px[4], px[5], px[6], px[7]);
+                        unpack4(w2, px[8], px[9], px[10], px[11]);
+                        unpack4(w3, px[12], px[13], px[14], px[15]);
+                        unpack4(w4, px[16], px[17], px[18], px[19]);
+                        const int sh8 = 8 * (li >> 2);
+                        const int bs0 = (b0w >> sh8) & 255, bs1 = (b1w >> sh8) & 255, bs2 = (b2w >> sh8) & 255, bs3 = (b3w >> sh8) & 255;
+                        const int qpe = ml ? (ml->qp + qpq + 1) >> 1 : qpq;
+                        const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
+                        const int ia1 = clip3(0, 51, qpq + aoff), ib1 = clip3(0, 51, qpq + boff);
+                        const int a1 = sh.alpha[ia1], be1 = sh.beta[ib1];
+                        filter_edge<4, false>(px, bs0, sh.alpha[ia0], sh.beta[ib0], sh.tc0[ia0][bs0 & 3]);
+                        filter_edge<8, false>(px, bs1, a1, be1, sh.tc0[ia1][bs1 & 3]);
+                        filter_edge<12, false>(px, bs2, a1, be1, sh.tc0[ia1][bs2 & 3]);
+                        filter_edge<16, false>(px, bs3, a1, be1, sh.tc0[ia1][bs3 & 3]);
+                        w0 = pack4(px[0], px[1], px[2], px[3]), w1 = pack4(px[4], px[5], px[6], px[7]), w2 = pack4(px[8], px[9], px[10], px[11]);
+                        w3 = pack4(px[12], px[13], px[14], px[15]), w4 = pack4(px[16], px[17], px[18], px[19]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    { // chroma: luma edges 0 and 2
+                        int px[12];
+                        unpack4(c0, px[0], px[1], px[2], px[3]);
+                        unpack4(c1, px[4], px[5], px[6], px[7]);
+                        unpack4(c2, px[8], px[9], px[10], px[11]);
+                        const int sh8 = 8 * ((li & 7) >> 1);
+                        const int bs0 = (b0w >> sh8) & 255, bs2 = (b2w >> sh8) & 255;
+                        const int qpe = ml ? (ml->qpc[li >> 3] + qpc_q + 1) >> 1 : qpc_q;
+                        const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
+                        const int ia1 = clip3(0, 51, qpc_q + aoff), ib1 = clip3(0, 51, qpc_q + boff);
+                        filter_edge<4, true>(px, bs0, sh.alpha[ia0], sh.beta[ib0], sh.tc0[ia0][bs0 & 3]);
+                        filter_edge<8, true>(px, bs2, sh.alpha[ia1], sh.beta[ib1], sh.tc0[ia1][bs2 & 3]);
+                        c0 = pack4(px[0], px[1], px[2], px[3]), c1 = pack4(px[4], px[5], px[6], px[7]), c2 = pack4(px[8], px[9], px[10], px[11]);
+                    }
+                }
+                if (active) { // the line goes into the tile for the horizontal pass
+                    *reinterpret_cast<uint32_t *>(&ss->y[4 + li][12]) = w0;
+                    *reinterpret_cast<v4u *>(&ss->y[4 + li][16]) = v4u{w1, w2, w3, w4};
+                    uint8_t *cr = &ss->c[li >> 3][4 + (li & 7)][4];
+                    *reinterpret_cast<uint32_t *>(cr) = c0;
+                    *reinterpret_cast<v2u *>(cr + 4) = v2u{c1, c2};
+                }
+            }
+            WAVE_SYNC();
+            // ---- 3. hand-off of the rows above ----
+            // 3a. columns 12..15 of the previous macroblock are final now: complete its bottom rows where they wait
+            //     (the buffer for the sub-row below, or the ring slot for the group below), then publish the column
+            const bool to_ring = sub == last_sub; // the group's last row feeds the next group, the others the sub-row below
+            if (active && mbx > 0 && !last_row && li < 8) {
+                const int cpl = (li >> 1) & 1, r = li & 1;
+                GroupSlot *gl = &out_ring[(mbx - 1) % out_depth];
+                uint32_t *dst;
+                uint32_t v;
+                if (li < 4)
+                    dst = reinterpret_cast<uint32_t *>(to_ring ? &gl->y[li][12] : &ss->bot_y[li][12]), v = *reinterpret_cast<const uint32_t *>(&ss->y[16 + li][12]);
+                else
+                    dst = reinterpret_cast<uint32_t *>(to_ring ? &gl->c[cpl][r][4] : &ss->bot_c[cpl][r][4]), v = *reinterpret_cast<const uint32_t *>(&ss->c[cpl][10 + r][4]);
+                *dst = v;
+            }
+            WAVE_SYNC();
+            if (feeds_group) {
+                const int xl = t - last_sub; // column of the group's last row in this step: columns 0 .. xl - 1 are final now
+                if (xl >= 1 && xl < wmb && lane == 0) __hip_atomic_store(&sh.prog[g], xl, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // 3b. rows above this macroblock: from the sub-row above (same wavefront, written in the previous step and just
+            //     completed), or -- sub-row 0 -- from the group above through its ring, once it says the column is final
+            if (g > 0 && t < wmb)
+                while (__hip_atomic_load(&sh.prog[g - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
+            WAVE_SYNC();
+            if (active && has_top && li < 8) {
+                const int cpl = (li >> 1) & 1, r = li & 1;
+                const GroupSlot *gs = &in_ring[(mbx > 0 ? mbx : 0) % in_depth];
+                if (li < 4)
+                    *reinterpret_cast<v4u *>(&ss->y[li][16]) = *reinterpret_cast<const v4u *>(sub > 0 ? sup->bot_y[li] : gs->y[li]);
+                else
+                    *reinterpret_cast<v2u *>(&ss->c[cpl][2 + r][8]) = *reinterpret_cast<const v2u *>(sub > 0 ? sup->bot_c[cpl][r] : gs->c[cpl][r]);
+            }
+            WAVE_SYNC();
+            if (g > 0 && t < wmb && lane == 0) // the hand-off slot of column t has been copied: the group above may reuse it
+                __hip_atomic_store(&sh.cons[g], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // ---- 4. horizontal edges: lane li = luma column li, then chroma (plane li >> 3, column li & 7) ----
+            {
+                const uint32_t b0w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[1][0]) : 0u, b1w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[1][1]) : 0u;
+                const uint32_t b2w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[1][2]) : 0u, b3w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[1][3]) : 0u;
+                const bool any = (b0w | b1w | b2w | b3w) != 0;
+                if (__builtin_amdgcn_ballot_w64(any) != 0) {
+                    if (any) {
+                        {
                             int px[20];
-                            if (dir == 0) {
 #pragma unroll
-                                for (int d = 0; d < 5; d++) {
-                                    uint32_t w = *reinterpret_cast<const uint32_t *>(&tl->y[4 + li][d * 4]);
-                                    px[4 * d] = w & 255, px[4 * d + 1] = (w >> 8) & 255, px[4 * d + 2] = (w >> 16) & 255, px[4 * d + 3] = w >> 24;
-                                }
-                            } else {
-#pragma unroll
-                                for (int r = 0; r < 20; r++) px[r] = tl->y[r][4 + li];
-                            }
+                            for (int r = 0; r < 20; r++) px[r] = ss->y[r][16 + li];
                             const int sh8 = 8 * (li >> 2);
                             const int bs0 = (b0w >> sh8) & 255, bs1 = (b1w >> sh8) & 255, bs2 = (b2w >> sh8) & 255, bs3 = (b3w >> sh8) & 255;
-                            const int qpq = mq->qp;
-                            const int qpe = mn ? (mn->qp + qpq + 1) >> 1 : qpq;
+                            const int qpe = mt ? (mt->qp + qpq + 1) >> 1 : qpq;
                             const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
                             const int ia1 = clip3(0, 51, qpq + aoff), ib1 = clip3(0, 51, qpq + boff);
-                            const int a0 = sh.alpha[ia0], be0 = sh.beta[ib0], a1 = sh.alpha[ia1], be1 = sh.beta[ib1];
-                            filter_edge<4, false>(px, bs0, a0, be0, sh.tc0[ia0][bs0 & 3]);
+                            const int a1 = sh.alpha[ia1], be1 = sh.beta[ib1];
+                            filter_edge<4, false>(px, bs0, sh.alpha[ia0], sh.beta[ib0], sh.tc0[ia0][bs0 & 3]);
                             filter_edge<8, false>(px, bs1, a1, be1, sh.tc0[ia1][bs1 & 3]);
                             filter_edge<12, false>(px, bs2, a1, be1, sh.tc0[ia1][bs2 & 3]);
                             filter_edge<16, false>(px, bs3, a1, be1, sh.tc0[ia1][bs3 & 3]);
-                            if (dir == 0) {
 #pragma unroll
-                                for (int d = 0; d < 5; d++)
-                                    *reinterpret_cast<uint32_t *>(&tl->y[4 + li][d * 4]) =
-                                        static_cast<uint32_t>(px[4 * d]) | (px[4 * d + 1] << 8) | (px[4 * d + 2] << 16) | (static_cast<uint32_t>(px[4 * d + 3]) << 24);
-                            } else {
-#pragma unroll
-                                for (int r = 1; r < 19; r++) tl->y[r][4 + li] = static_cast<uint8_t>(px[r]);
-                            }
+                            for (int r = 1; r < 19; r++) ss->y[r][16 + li] = static_cast<uint8_t>(px[r]);
                         }
-                        { // chroma: plane = li >> 3, row/column = li & 7; luma edges 0 and 2
-                            const int c = li >> 3, i = li & 7;
+                        __builtin_amdgcn_sched_barrier(0);
+                        {
+                            const int cpl = li >> 3, i = li & 7;
                             int px[12];
-                            if (dir == 0) {
+                            px[0] = px[1] = 0;
 #pragma unroll
-                                for (int d = 0; d < 3; d++) {
-                                    uint32_t w = *reinterpret_cast<const uint32_t *>(&tl->c[c][4 + i][d * 4]);
-                                    px[4 * d] = w & 255, px[4 * d + 1] = (w >> 8) & 255, px[4 * d + 2] = (w >> 16) & 255, px[4 * d + 3] = w >> 24;
-                                }
-                            } else {
-#pragma unroll
-                                for (int r = 0; r < 12; r++) px[r] = tl->c[c][r][4 + i];
-                            }
+                            for (int r = 2; r < 12; r++) px[r] = ss->c[cpl][r][8 + i];
                             const int sh8 = 8 * (i >> 1);
                             const int bs0 = (b0w >> sh8) & 255, bs2 = (b2w >> sh8) & 255;
-                            const int qpq = mq->qpc[c];
-                            const int qpe = mn ? (mn->qpc[c] + qpq + 1) >> 1 : qpq;
+                            const int qpe = mt ? (mt->qpc[cpl] + qpc_q + 1) >> 1 : qpc_q;
                             const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
-                            const int ia1 = clip3(0, 51, qpq + aoff), ib1 = clip3(0, 51, qpq + boff);
+                            const int ia1 = clip3(0, 51, qpc_q + aoff), ib1 = clip3(0, 51, qpc_q + boff);
                             filter_edge<4, true>(px, bs0, sh.alpha[ia0], sh.beta[ib0], sh.tc0[ia0][bs0 & 3]);
                             filter_edge<8, true>(px, bs2, sh.alpha[ia1], sh.beta[ib1], sh.tc0[ia1][bs2 & 3]);
-                            if (dir == 0) {
 #pragma unroll
-                                for (int d = 0; d < 3; d++)
-                                    *reinterpret_cast<uint32_t *>(&tl->c[c][4 + i][d * 4]) =
-                                        static_cast<uint32_t>(px[4 * d]) | (px[4 * d + 1] << 8) | (px[4 * d + 2] << 16) | (static_cast<uint32_t>(px[4 * d + 3]) << 24);
-                            } else {
-#pragma unroll
-                                for (int r = 2; r < 10; r++) tl->c[c][r][4 + i] = static_cast<uint8_t>(px[r]);
-                            }
+                            for (int r = 3; r < 9; r++) ss->c[cpl][r][8 + i] = static_cast<uint8_t>(px[r]);
                         }
-                    }
-                }
-                WAVE_SYNC();
-            }
-            DB_T(2);
-            // ---- results.  Own rows 0..12 (0..15 in the last picture row) go to the staging group and reach HBM as whole
-            // lines once the group is complete; rows -3..-1 of the macroblock above (this macroblock modified them last) are
-            // stored directly.  LDS rings: bottom rows for the sub-row / group below ----
-            if (active) {
-                uint8_t *Y = py + static_cast<size_t>(mby * 16) * W + mbx * 16;
-                const bool has_left = mbx > 0, last_row = mby == hmb - 1, row_end = mbx == wmb - 1;
-                const int k4 = mbx & 3;
-                const uint32_t *r = reinterpret_cast<const uint32_t *>(&tl->y[4 + li][0]);
-                const uint32_t *cr = reinterpret_cast<const uint32_t *>(&tl->c[li >> 3][4 + (li & 7)][0]);
-                uint32_t *oy = reinterpret_cast<uint32_t *>(ss->ost_y[li]);
-                uint32_t *oc = reinterpret_cast<uint32_t *>(ss->ost_c[li >> 3][li & 7]);
-                const bool store_y = li < 13 || last_row, store_c = (li & 7) < 7 || last_row;
-                // a lane stages and flushes only its own rows, and LDS operations of a wavefront complete in order: no sync needed
-                auto flush = [&](int first_mb, int n_mb) { // macroblocks first_mb .. first_mb + n_mb - 1 of this row, n_mb = 1..4
-                    WAVE_SYNC(); // order the dword stores into the staging rows before the wide reads below
-                    uint8_t *Yd = py + static_cast<size_t>(mby * 16 + li) * W + first_mb * 16;
-                    uint8_t *Cd = (li < 8 ? pcb : pcr) + static_cast<size_t>(mby * 8 + (li & 7)) * Wc + first_mb * 8;
-                    const uint4 *sy = reinterpret_cast<const uint4 *>(oy);
-                    const uint2 *sc = reinterpret_cast<const uint2 *>(oc);
-                    if (store_y) {
-                        if (n_mb == 4) {
-                            const uint4 a = sy[0], b = sy[1], c = sy[2], d = sy[3];
-                            uint4 *dst = reinterpret_cast<uint4 *>(Yd);
-                            dst[0] = a, dst[1] = b, dst[2] = c, dst[3] = d;
-                        } else
-                            for (int k = 0; k < n_mb; k++) reinterpret_cast<uint4 *>(Yd)[k] = sy[k];
-                    }
-                    if (store_c) {
-                        if (n_mb == 4) {
-                            const uint4 a = reinterpret_cast<const uint4 *>(oc)[0], b = reinterpret_cast<const uint4 *>(oc)[1];
-                            reinterpret_cast<uint4 *>(Cd)[0] = a, reinterpret_cast<uint4 *>(Cd)[1] = b;
-                        } else
-                            for (int k = 0; k < n_mb; k++) reinterpret_cast<uint2 *>(Cd)[k] = sc[k];
-                    }
-                    WAVE_SYNC(); // ... and the reads before the next group's stores
-                };
-                // columns 12..15 (chroma 4..7) of the macroblock to the left are final now
-                if (has_left) {
-                    const int kl = (k4 + 3) & 3; // its slot in the staging group
-                    oy[kl * 4 + 3] = r[0];
-                    oc[kl * 2 + 1] = cr[0];
-                    if (k4 == 0) flush(mbx - 4, 4); // that completed the previous group
-                }
-                oy[k4 * 4 + 0] = r[1], oy[k4 * 4 + 1] = r[2], oy[k4 * 4 + 2] = r[3];
-                oc[k4 * 2] = cr[1];
-                if (row_end) { // no macroblock to the right: the last columns are final too
-                    oy[k4 * 4 + 3] = r[4];
-                    oc[k4 * 2 + 1] = cr[2];
-                    flush(mbx - k4, k4 + 1);
-                }
-                if (has_top) { // rows -3..-1 (luma), -1 (chroma), columns 0..15 / 0..7: always, the macroblock above never stores them
-                    if (li < 3) {
-                        const uint32_t *r = reinterpret_cast<const uint32_t *>(&tl->y[1 + li][4]);
-                        *reinterpret_cast<uint4 *>(Y + static_cast<ptrdiff_t>(li - 3) * W) = make_uint4(r[0], r[1], r[2], r[3]);
-                    } else if (li >= 8 && li < 10) {
-                        const int c = li - 8;
-                        const uint32_t *r = reinterpret_cast<const uint32_t *>(&tl->c[c][3][4]);
-                        *reinterpret_cast<uint2 *>((c ? pcr : pcb) + static_cast<size_t>(mby * 8 - 1) * Wc + mbx * 8) = make_uint2(r[0], r[1]);
-                    }
-                }
-                // rings: own bottom rows (columns 12..15 still provisional) and the now final columns 12..15 of the left MB
-                if (!last_row && li < 8) {
-                    uint32_t *dy, *dyl = nullptr, *dc, *dcl = nullptr;
-                    const int c = (li >> 1) & 1, r = li & 1;
-                    if (sub < last_sub) {
-                        dy = reinterpret_cast<uint32_t *>(ss->bot_y[mbx & 3][li & 3]), dc = reinterpret_cast<uint32_t *>(ss->bot_c[mbx & 3][c][r]);
-                        if (has_left) dyl = reinterpret_cast<uint32_t *>(&ss->bot_y[(mbx - 1) & 3][li & 3][12]), dcl = reinterpret_cast<uint32_t *>(&ss->bot_c[(mbx - 1) & 3][c][r][4]);
-                    } else {
-                        GroupSlot *row = &gring[(g % nwaves) * ring];
-                        GroupSlot *gs = &row[mbx % ring], *gl = &row[(mbx + ring - 1) % ring];
-                        dy = reinterpret_cast<uint32_t *>(gs->y[li & 3]), dc = reinterpret_cast<uint32_t *>(gs->c[c][r]);
-                        if (has_left) dyl = reinterpret_cast<uint32_t *>(&gl->y[li & 3][12]), dcl = reinterpret_cast<uint32_t *>(&gl->c[c][r][4]);
-                    }
-                    if (li < 4) {
-                        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tl->y[16 + li][0]);
-                        dy[0] = src[1], dy[1] = src[2], dy[2] = src[3], dy[3] = src[4];
-                        if (dyl) dyl[0] = src[0];
-                    } else {
-                        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tl->c[c][10 + r][0]);
-                        dc[0] = src[1], dc[1] = src[2];
-                        if (dcl) dcl[0] = src[0];
                     }
                 }
             }
             WAVE_SYNC();
-            // progress of the group's last row (LDS-only hand-off: LDS operations of a wavefront complete in order)
-            {
-                const int xl = t - 2 * last_sub;
-                if (xl >= 0 && xl < wmb) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(&sh.prog[g], xl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // ---- 5. results ----
+            // Back-pressure first: the ring slot the group's last row is about to overwrite held column xl - depth of this
+            // group; the group below must have consumed it.
+            if (feeds_group) {
+                const int xl = t - last_sub;
+                if (xl >= out_depth && xl < wmb)
+                    while (__hip_atomic_load(&sh.cons[g + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < xl - out_depth + 1) __builtin_amdgcn_s_sleep(1);
+            }
+            if (active) {
+                const bool row_end = mbx == wmb - 1;
+                // finished bytes of this step.  Own rows: columns 12..15 of the macroblock to the left complete ITS register
+                // slot, columns 0..11 of this one open a new slot.  Rows of the macroblock above (up lanes): all 16 columns.
+                const uint32_t l4 = *reinterpret_cast<const uint32_t *>(&ss->y[4 + li][12]);
+                const v4u own = *reinterpret_cast<const v4u *>(&ss->y[up_lane ? li - 12 : 4 + li][16]); // up lanes: tile rows 1..3 = rows -3..-1
+                const uint8_t *crp = &ss->c[li >> 3][upc_lane ? 3 : 4 + (li & 7)][4];                     // chroma up lanes: row -1
+                const uint32_t cl4 = *reinterpret_cast<const uint32_t *>(crp);
+                const v2u cown = *reinterpret_cast<const v2u *>(crp + 4);
+                const int ps = (t + 3) & 3; // slot of the previous column
+                if (mbx > 0) {
+                    if (!up_lane) {
+                        if (ps == 0) R0.w = l4; else if (ps == 1) R1.w = l4; else if (ps == 2) R2.w = l4; else R3.w = l4;
+                    }
+                    if (!upc_lane) {
+                        if (ps == 0) S0.y = cl4; else if (ps == 1) S1.y = cl4; else if (ps == 2) S2.y = cl4; else S3.y = cl4;
+                    }
+                    if ((mbx & 3) == 0) flush(mbx - 4, 4); // that completed the previous aligned group
+                }
+                if (ts == 0) R0 = own, S0 = cown; else if (ts == 1) R1 = own, S1 = cown; else if (ts == 2) R2 = own, S2 = cown; else R3 = own, S3 = cown;
+                if (row_end) flush(mbx & ~3, (mbx & 3) + 1); // no macroblock to the right: the last columns are final too
+                if (last_row && has_top) { // the up lanes own rows 13..15 here: rows -3..-1 of the macroblock above go out directly
+                    if (li < 3)
+                        GST16(py, static_cast<uint32_t>(mby * 16 - 3 + li) * W + mbx * 16, *reinterpret_cast<const v4u *>(&ss->y[1 + li][16]));
+                    else if (li >= 8 && li < 10)
+                        GST8(py, (li == 8 ? cb_off : cr_off) + static_cast<uint32_t>(mby * 8 - 1) * Wc + mbx * 8, *reinterpret_cast<const v2u *>(&ss->c[li - 8][3][8]));
+                }
+                // bottom rows of this macroblock (columns 12..15 still provisional unless the row ends here) for whoever is below
+                if (!last_row && li < 8) {
+                    const int cpl = (li >> 1) & 1, r = li & 1;
+                    GroupSlot *gs = &out_ring[mbx % out_depth];
+                    if (li < 4)
+                        *reinterpret_cast<v4u *>(to_ring ? gs->y[li] : ss->bot_y[li]) = *reinterpret_cast<const v4u *>(&ss->y[16 + li][16]);
+                    else
+                        *reinterpret_cast<v2u *>(to_ring ? gs->c[cpl][r] : ss->bot_c[cpl][r]) = *reinterpret_cast<const v2u *>(&ss->c[cpl][10 + r][8]);
                 }
             }
+            WAVE_SYNC();
+            if (feeds_group && t - last_sub == wmb - 1 && lane == 0) // the last column of the group's last row is final without a right neighbour
+                __hip_atomic_store(&sh.prog[g], wmb, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
-#if MI_DB_STATS
-    if (lane == 0) {
-        uint32_t *dst = reinterpret_cast<uint32_t *>(const_cast<MbRec *>(recs + wave)->pad);
-        dst[0] = db_acc[0], dst[1] = db_acc[1], dst[2] = db_acc[2], dst[3] = db_acc[3];
-    }
-#endif
 }

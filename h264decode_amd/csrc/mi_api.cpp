@@ -1056,10 +1056,10 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         }
         hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec, coef);
         mark(2);
-        int dbw = 1, dbring = 16;
-        mi_deblock_plan(d->wmb_max, d->hmb_max, &dbw, &dbring);
-        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring), rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec,
-                           dbring);
+        int dbw = 1, dbring = 16, dbring_last = 16, dbbufs = 1;
+        mi_deblock_plan(d->wmb_max, d->hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
+        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, d->d_lists + d->wave_off[w], d->d_pics,
+                           d->d_pools, d->d_tables, mbrec, dbring, dbring_last, dbbufs);
         mark(3);
     }
     HIP_TRY(hipEventRecord(d->ev_rec[set], rs));
@@ -1264,11 +1264,11 @@ extern "C" int32_t h264mi_internal_poison(h264mi_decoder *d) {
 
 // Not part of the public ABI: lets the CPU test-suite check the K5 launch plan (wavefronts, hand-off ring depth,
 // dynamic LDS) without a GPU -- a wrong plan would deadlock the kernel, see mi_deblock_plan().
-extern "C" int32_t h264mi_internal_deblock_plan(int32_t wmb, int32_t hmb, int32_t *nwaves, int32_t *ring, int64_t *lds_bytes) {
-    if (!nwaves || !ring || !lds_bytes || wmb < 1 || hmb < 1) return H264MI_EINVAL;
-    int w = 1, r = 1;
-    mi_deblock_plan(wmb, hmb, &w, &r);
-    *nwaves = w, *ring = r, *lds_bytes = static_cast<int64_t>(mi_deblock_lds_bytes(w, r));
+extern "C" int32_t h264mi_internal_deblock_plan(int32_t wmb, int32_t hmb, int32_t *nwaves, int32_t *ring, int32_t *ring_last, int32_t *last_bufs, int64_t *lds_bytes) {
+    if (!nwaves || !ring || !ring_last || !last_bufs || !lds_bytes || wmb < 1 || hmb < 1) return H264MI_EINVAL;
+    int w = 1, r = 1, rl = 1, nb = 1;
+    mi_deblock_plan(wmb, hmb, &w, &r, &rl, &nb);
+    *nwaves = w, *ring = r, *ring_last = rl, *last_bufs = nb, *lds_bytes = static_cast<int64_t>(mi_deblock_lds_bytes(w, r, rl, nb));
     return H264MI_OK;
 }
 

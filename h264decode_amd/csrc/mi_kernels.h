@@ -13,38 +13,44 @@ extern "C" __global__ void k_inter(const uint32_t *pic_list, const PicDesc *pics
 // K3: intra macroblocks, one workgroup per picture, one wavefront per macroblock row (2-D wavefront order).
 extern "C" __global__ void k_intra(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
                                    const int16_t *coefs);
-// K5: in-loop deblocking, one workgroup per picture, one wavefront per group of 4 macroblock rows.
-// block = 64 * nwaves, dynamic LDS = mi_deblock_lds_bytes(nwaves, ring); (nwaves, ring) from mi_deblock_plan()
-extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring);
+// K5: in-loop deblocking, one workgroup per picture, one wavefront per group of 4 macroblock rows (up to 16 groups side by side).
+// block = 64 * nwaves, dynamic LDS = mi_deblock_lds_bytes(nwaves, ring, ring_last); (nwaves, ring, ring_last) from mi_deblock_plan()
+extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring,
+                                     int ring_last, int last_bufs);
 #ifndef MI_DEBLOCK_MAX_WAVES
-#define MI_DEBLOCK_MAX_WAVES 9     /* LDS: 14.6 KB of row state per wavefront + its hand-off ring */
+#define MI_DEBLOCK_MAX_WAVES 12    /* 1024 threads; LDS: 6 KB of row state per wavefront + its hand-off ring */
 #endif
 #define MI_DEBLOCK_HDR_BYTES 1088  /* sizeof(DbShared) rounded up to 16 */
-#define MI_DEBLOCK_WAVE_BYTES 14976
+#define MI_DEBLOCK_WAVE_BYTES 6144
 #define MI_DEBLOCK_SLOT_BYTES 96
 #define MI_DEBLOCK_LDS_MAX (160 * 1024)
-static inline size_t mi_deblock_lds_bytes(int nwaves, int ring) {
-    return MI_DEBLOCK_HDR_BYTES + static_cast<size_t>(nwaves) * (MI_DEBLOCK_WAVE_BYTES + static_cast<size_t>(ring) * MI_DEBLOCK_SLOT_BYTES);
+static inline size_t mi_deblock_lds_bytes(int nwaves, int ring, int ring_last, int last_bufs) {
+    return MI_DEBLOCK_HDR_BYTES + static_cast<size_t>(nwaves) * MI_DEBLOCK_WAVE_BYTES +
+           (static_cast<size_t>(nwaves - 1) * ring + static_cast<size_t>(ring_last) * last_bufs) * MI_DEBLOCK_SLOT_BYTES;
 }
-// Wavefront count and hand-off ring depth for pictures of wmb x hmb macroblocks.  Fewest rounds over the 4-row groups,
-// then fewest wavefronts.  A group may run at most `ring` columns ahead of the group below it, and the group below
-// the last wavefront's group only starts when wavefront 0 has finished its first group, so nwaves * ring must cover a
-// whole row (otherwise the chain of back-pressure stops wavefront 0 before the end of its row: deadlock).
-static inline void mi_deblock_plan(int wmb, int hmb, int *nwaves, int *ring) {
+// Wavefront count and hand-off ring depths for pictures of wmb x hmb macroblocks.  Wavefront w runs the 4-row groups
+// w, w + nwaves, ...; group g hands its bottom rows to group g + 1 through the ring region of its wavefront.  A group may
+// run at most `depth` columns ahead of the group below it.  Groups of one round run side by side, 4 steps apart, so a
+// short ring is enough between them; but the reader of the LAST wavefront's groups is wavefront 0 in the NEXT round, which
+// only starts when it has finished a whole row -- that ring (ring_last) holds a whole row, otherwise the last wavefront
+// (and through back-pressure every wavefront above it) would wait for wavefront 0.  From three rounds on that ring is
+// double-buffered by round: the last wavefront's group of round r must not wait until wavefront 0 has read ALL of round
+// r - 1's ring, because wavefront 0's group of round r can only finish when the groups below it -- up to the last
+// wavefront's, through the short rings -- make progress: with a single buffer wide pictures deadlock.  As many wavefronts as fit.
+static inline void mi_deblock_plan(int wmb, int hmb, int *nwaves, int *ring, int *ring_last, int *last_bufs) {
     const int ngroups = (hmb + 3) / 4;
+    const int w1 = wmb > 0 ? wmb : 1;
     for (int nw = ngroups < MI_DEBLOCK_MAX_WAVES ? ngroups : MI_DEBLOCK_MAX_WAVES; nw >= 1; nw--) {
         const int rounds = (ngroups + nw - 1) / nw;
-        int w = (ngroups + rounds - 1) / rounds; // fewest wavefronts for that many rounds
-        if (w < 1) w = 1;
-        int r = rounds == 1 ? 16 : (wmb + 16 + w - 1) / w + 8;
-        if (r < 16) r = 16;
-        if (r > wmb) r = wmb > 0 ? wmb : 1; // a whole row never needs back-pressure
-        if (mi_deblock_lds_bytes(w, r) <= MI_DEBLOCK_LDS_MAX) {
-            *nwaves = w, *ring = r;
+        const int r = w1 < 16 ? w1 : 16;
+        const int rl = rounds > 1 ? w1 : r;
+        const int nb = rounds > 2 ? 2 : 1;
+        if (mi_deblock_lds_bytes(nw, r, rl, nb) <= MI_DEBLOCK_LDS_MAX) {
+            *nwaves = nw, *ring = r, *ring_last = rl, *last_bufs = nb;
             return;
         }
     }
-    *nwaves = 1, *ring = wmb > 0 ? wmb : 1;
+    *nwaves = 1, *ring = 1, *ring_last = w1, *last_bufs = 2; // 2 x 512 columns x 96 bytes + one wavefront always fit
 }
 // K6: crop + tight pack of one frame into I420
 extern "C" __global__ void k_pack(const uint8_t *src_y, const uint8_t *src_cb, const uint8_t *src_cr, int pitch, int x0, int y0, int w, int h, uint8_t *dst);

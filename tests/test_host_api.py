@@ -121,27 +121,33 @@ def test_malformed_inputs_return_status_codes(H):
 
 
 def test_deblock_launch_plan_cannot_deadlock(H):
-    """K5 hands rows from one wavefront to the next through a bounded LDS ring with back-pressure.  With several rounds of
-    row groups, the consumer of the last wavefront's group only starts when wavefront 0 has finished its first group, so
-    the rings of all wavefronts together must span a whole macroblock row; and the plan must fit the 160 KB of LDS."""
+    """K5 hands rows from one group of 4 macroblock rows to the next through bounded LDS rings with back-pressure.  The
+    groups of one round run side by side; the ring written by the LAST wavefront is read by wavefront 0 one round later, so
+    it must hold a whole macroblock row (otherwise every wavefront would end up waiting for wavefront 0's previous group).
+    The plan must fit the 160 KB of LDS and use as many wavefronts as there are groups, up to the kernel's limit."""
     import ctypes
     L = H.load()
     f = L.h264mi_internal_deblock_plan
     f.restype = ctypes.c_int32
-    f.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int64)]
+    I32 = ctypes.c_int32
+    f.argtypes = [I32, I32, ctypes.POINTER(I32), ctypes.POINTER(I32), ctypes.POINTER(I32), ctypes.POINTER(I32), ctypes.POINTER(ctypes.c_int64)]
+    nw, ring, ring_last, nb, lds = I32(), I32(), I32(), I32(), ctypes.c_int64()
+    assert f(8, 320, ctypes.byref(nw), ctypes.byref(ring), ctypes.byref(ring_last), ctypes.byref(nb), ctypes.byref(lds)) == 0
+    maxw = nw.value  # the kernel's wavefront limit (register budget): 80 groups of a narrow picture use all of them
+    assert 8 <= maxw <= 16
     for wmb in list(range(1, 40)) + [45, 80, 120, 128, 240, 256, 300, 512]:
         for hmb in list(range(1, 80)) + [135, 136, 160, 320]:
-            nw, ring, lds = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
-            assert f(wmb, hmb, ctypes.byref(nw), ctypes.byref(ring), ctypes.byref(lds)) == 0
+            nw, ring, ring_last, nb, lds = I32(), I32(), I32(), I32(), ctypes.c_int64()
+            assert f(wmb, hmb, ctypes.byref(nw), ctypes.byref(ring), ctypes.byref(ring_last), ctypes.byref(nb), ctypes.byref(lds)) == 0
             groups = (hmb + 3) // 4
             rounds = (groups + nw.value - 1) // nw.value
-            assert 1 <= nw.value <= 9 and 1 <= ring.value and lds.value <= 160 * 1024, (wmb, hmb, nw.value, ring.value, lds.value)
-            if rounds > 1:  # each group runs at most `ring` columns (+6 of stagger) ahead of the next one
-                assert ring.value >= wmb or nw.value * ring.value >= wmb + 6 * nw.value, (wmb, hmb, nw.value, ring.value)
-            else:
-                assert ring.value >= min(wmb, 16)
-
-
+            assert 1 <= nw.value <= min(maxw, groups) and lds.value <= 160 * 1024, (wmb, hmb, nw.value, lds.value)
+            assert lds.value == 1088 + nw.value * 6144 + ((nw.value - 1) * ring.value + ring_last.value * nb.value) * 96
+            assert nb.value == (2 if rounds > 2 else 1)  # a single whole-row buffer deadlocks from three rounds on (test_deblock_schedule_model)
+            assert 1 <= ring.value <= wmb and ring.value >= min(wmb, 16)
+            assert ring_last.value == (wmb if rounds > 1 else ring.value), (wmb, hmb, nw.value, ring.value, ring_last.value)
+            if wmb <= 240:
+                assert nw.value == min(maxw, groups), (wmb, hmb, nw.value)
 
 class _Bits:
     """MSB-first bit writer for hand-assembled parameter sets."""
