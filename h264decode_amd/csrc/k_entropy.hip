@@ -7,8 +7,8 @@
 //     one 32-byte load per lane (coalesced 128-B requests);
 //   * context initialisation: 460 states copied from the (table-set, QP) row of DevTables;
 //   * neighbour caches: top-row / left-column state (modes, nnz, refs, mvs, |mvd|) lives in LDS;
-//   * write-out: the 128-byte MbRec and the 832-byte coefficient block are assembled in LDS and
-//     stored with one dword / one dwordx4 per lane.
+//   * write-out: the 128-byte MbRec and the coefficient blocks are assembled in LDS; the record leaves with
+//     one dword per lane, and only the 16-coefficient blocks that carry anything go to a packed per-pass pool.
 // CABAC engine state (codIRange, scaled codIOffset, lookahead count) is wave-uniform; context
 // states and a merged rangeTabLPS/transIdx table (one 8-byte LDS read per decision) sit in LDS.
 //
@@ -98,7 +98,10 @@ struct Ent {
     const SliceDesc *sd;
     const PicDesc *pd;
     MbRec *mbrec;
-    int16_t *coefs;
+    int16_t *coefs;          // coefficient pool of this pass (32-byte blocks)
+    uint32_t *pool_head;     // next free block of the pool (device counter, reset per pass)
+    uint32_t pool_blocks;    // pool size
+    uint32_t coef_cur, coef_end; // this wavefront's chunk of the pool: [coef_cur, coef_end)
     // bit reader
     uint64_t bitbuf;         // next stream bits, MSB first
     int bcnt;                // valid bits in bitbuf (>= 32 between calls)
@@ -1132,6 +1135,31 @@ FI void decode_mb(Ent &e, int skipped) {
     int l = LANE;
     OPAQUE(l); // keeps lane-dependent addresses from being hoisted out of the macroblock loop and spilled
     const int inter = MB_IS_INTER(type);
+    // ---- coefficient blocks: which of the 26 staging blocks carry anything, and where they go in the pool ----
+    uint32_t cmask = 0, coff = 0;
+    if (has_coef) {
+        bool nz = false;
+        if (l < MI_COEF_BLOCKS) {
+            const uint4 a = reinterpret_cast<const uint4 *>(s->coef)[2 * l], b = reinterpret_cast<const uint4 *>(s->coef)[2 * l + 1];
+            nz = (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) != 0;
+        }
+        cmask = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(nz));
+        if (type == MBT_IPCM) cmask = 0xFFFu; // all 384 sample bytes, zero or not
+        const uint32_t n = static_cast<uint32_t>(__builtin_popcount(cmask));
+        if (n && e.coef_cur + n > e.coef_end) { // next chunk of the pool (a macroblock never straddles chunks)
+            uint32_t base = 0;
+            if (l == 0) base = atomicAdd(e.pool_head, static_cast<uint32_t>(MI_COEF_CHUNK));
+            base = RFL(base);
+            if (base + MI_COEF_CHUNK > e.pool_blocks) {
+                e.err = 40; // coefficient pool exhausted (H264MI_EDECODE; raise the pool size)
+                cmask = 0;
+            } else
+                e.coef_cur = base, e.coef_end = base + MI_COEF_CHUNK;
+        }
+        coff = e.coef_cur;
+        e.coef_cur += static_cast<uint32_t>(__builtin_popcount(cmask));
+    }
+    if (l == 0) r.coef_off = coff, r.coef_mask = cmask;
     if (l < 16) {
         int g = GI(l & 3, l >> 2);
         r.ipm[l] = s->ipm_c[g];
@@ -1182,8 +1210,9 @@ FI void decode_mb(Ent &e, int skipped) {
     const uint64_t mbi = e.mb_base + static_cast<uint64_t>(e.mby) * e.wmb + e.mbx;
     if (l >= 32) // MbRec: 128 bytes = 32 dwords, lanes 32..63
         reinterpret_cast<uint32_t *>(e.mbrec + mbi)[l - 32] = reinterpret_cast<const uint32_t *>(&r)[l - 32];
-    if (has_coef) { // 832 bytes = 52 x 16 B
-        if (l < MI_COEF_PER_MB * 2 / 16) reinterpret_cast<uint4 *>(e.coefs + mbi * MI_COEF_PER_MB)[l] = reinterpret_cast<const uint4 *>(s->coef)[l];
+    if (l < MI_COEF_BLOCKS && ((cmask >> l) & 1)) { // present blocks, packed in ascending order: 2 x 16 bytes per lane
+        uint4 *dst = reinterpret_cast<uint4 *>(e.coefs) + 2 * (static_cast<size_t>(coff) + __builtin_popcount(cmask & ((1u << l) - 1u)));
+        dst[0] = reinterpret_cast<const uint4 *>(s->coef)[2 * l], dst[1] = reinterpret_cast<const uint4 *>(s->coef)[2 * l + 1];
     }
     LDS_SYNC();
 }
@@ -1197,7 +1226,7 @@ FI void fill_none(const Ent &e, int from, int to) {
 
 // ------------------------------------------------------------------ kernel: slice_data() 7.3.4
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI_ENT_MINWAVES, 8))) k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
-                                                           int16_t *coefs, uint32_t *status, uint32_t *toprows, int wmb_max) {
+                                                           int16_t *coefs, uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status, uint32_t *toprows, int wmb_max) {
     __shared__ Shared sh;
     const uint64_t t_begin = wall_clock64();
     Ent e;
@@ -1216,6 +1245,8 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     e.rbsp_words = RFL((sd->rbsp_size + 3) >> 2);
     e.mbrec = mbrec;
     e.coefs = coefs;
+    e.pool_head = pool_head, e.pool_blocks = pool_blocks;
+    e.coef_cur = e.coef_end = 0;
     e.err = 0;
     e.cabac = RFL(static_cast<int>(pd->cabac));
     e.islice = RFL(static_cast<int>(sd->slice_type == 2));

@@ -183,7 +183,7 @@ __device__ __forceinline__ void zero_residual(int lane, ResBuf *rb) {
 
 // ================================================================== K4: inter prediction
 struct InterShared {
-    // The coefficient block (832 bytes, fetched while the reference windows are in flight) is parked on top of
+    // The dense coefficient layout (832 bytes; its blocks are fetched from the pool while the reference windows are in flight) is parked on top of
     // rb.luma | rb.chroma | rb.dc[0..15]: it is dead once the row pass has run, those are written by the column
     // pass (dc[0..15] is the Intra16x16 DC, never used here).  LDS per wavefront decides the occupancy of this kernel.
     ResBuf rb;
@@ -235,10 +235,15 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     const int mbx = mb % wmb, mby = mb / wmb;
     const uint8_t *pool_base = reinterpret_cast<const uint8_t *>(pool->base);
     const size_t ysz = static_cast<size_t>(W) * H;
-    // coefficient block: issue the loads now, park them in LDS after the window loads have been issued
-    const int has_res = rec->cbp != 0;
-    uint4 cv = make_uint4(0, 0, 0, 0);
-    if (has_res && lane < MI_COEF_PER_MB * 2 / 16) cv = reinterpret_cast<const uint4 *>(coefs + mbi * MI_COEF_PER_MB)[lane];
+    // coefficient blocks (packed in the pool, MbRec::coef_off / coef_mask): issue the loads now, scatter them into the dense LDS
+    // layout after the window loads have been issued
+    const uint32_t cmask = rec->coef_mask;
+    const int has_res = cmask != 0;
+    uint4 cv0 = make_uint4(0, 0, 0, 0), cv1 = cv0; // absent blocks are zero
+    if (lane < MI_COEF_BLOCKS && ((cmask >> lane) & 1)) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(coefs) + 2 * (static_cast<size_t>(rec->coef_off) + __builtin_popcount(cmask & ((1u << lane) - 1u)));
+        cv0 = src[0], cv1 = src[1];
+    }
     // ---- stage reference windows (8.4.2.2.1 / 8.4.2.2.2) ----
     // Fast path: P_L0_16x16 / P_Skip (or any MB whose 16 blocks share motion) whose displaced block
     // lies inside the picture -> 126 + 54 aligned dword loads instead of 1584 clamped byte loads.
@@ -292,7 +297,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     // ---- residual (independent of the prediction) ----
     if (has_res) {
         int16_t *coef_lds = sh.rb.luma; // overlay, see InterShared
-        if (lane < MI_COEF_PER_MB * 2 / 16) reinterpret_cast<uint4 *>(coef_lds)[lane] = cv;
+        if (lane < MI_COEF_BLOCKS) reinterpret_cast<uint4 *>(coef_lds)[2 * lane] = cv0, reinterpret_cast<uint4 *>(coef_lds)[2 * lane + 1] = cv1;
         __syncthreads();
         mb_residual(lane, rec, coef_lds, &tab->scaling[pd->scaling_set], &sh.rb);
     } else
@@ -428,6 +433,7 @@ struct IntraWave {
     uint8_t tile_c[2][9][12]; // chroma
     int16_t fe[2][32];        // Intra8x8 filtered reference samples: [0] top p'[-1..15] at index x+1, [1] left p'[-1..7] at index y+1
     MbRec rec;                // LDS copy of the current macroblock record
+    alignas(16) int16_t coef[MI_COEF_PER_MB]; // dense coefficient layout of the macroblock, scattered from the packed pool
 };
 #define MI_INTRA_MAX_ROWS 320  /* macroblock rows (5120 luma lines) */
 #define MI_INTRA_MAX_CHUNKS 8 /* 64-macroblock chunks per row (8192 luma columns) */
@@ -763,8 +769,17 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
                            (m1 && (__hip_atomic_load(&sh.pend[mby - 1][c1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & m1)))
                         __builtin_amdgcn_s_sleep(1);
                 }
-                const uint64_t mbi = pd->mb_base + static_cast<uint64_t>(mby) * wmb + mbx;
-                intra_mb(lane, ws, &ws->rec, coefs + mbi * MI_COEF_PER_MB, &sh.sc, py, pcb, pcr, W, mbx, mby);
+                { // coefficient blocks of this macroblock: pool -> dense LDS layout (absent blocks are zero)
+                    const uint32_t cmask = ws->rec.coef_mask;
+                    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+                    if (lane < MI_COEF_BLOCKS && ((cmask >> lane) & 1)) {
+                        const uint4 *src = reinterpret_cast<const uint4 *>(coefs) + 2 * (static_cast<size_t>(ws->rec.coef_off) + __builtin_popcount(cmask & ((1u << lane) - 1u)));
+                        c0 = src[0], c1 = src[1];
+                    }
+                    if (lane < MI_COEF_BLOCKS) reinterpret_cast<uint4 *>(ws->coef)[2 * lane] = c0, reinterpret_cast<uint4 *>(ws->coef)[2 * lane + 1] = c1;
+                    WAVE_SYNC();
+                }
+                intra_mb(lane, ws, &ws->rec, ws->coef, &sh.sc, py, pcb, pcr, W, mbx, mby);
                 // done: the release orders this wavefront's sample stores before the bit is cleared
                 if (lane == 0) __hip_atomic_fetch_and(&sh.pend[mby][c], ~(1ull << k), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }

@@ -158,7 +158,9 @@ struct h264mi_decoder {
     // overlap the reconstruction kernels of pass n (on `stream`); each pass owns one of MI_SETS
     // MbRec / coefficient buffer sets, fenced by events.
     MbRec *d_mbrec[MI_SETS] = {};
-    int16_t *d_coef[MI_SETS] = {};
+    int16_t *d_coef[MI_SETS] = {};       // coefficient pools: 32-byte blocks, only the blocks that carry anything (MbRec::coef_off / coef_mask)
+    uint32_t *d_pool_head = nullptr;     // MI_SETS counters: next free block of each pool, reset before every entropy launch
+    uint64_t pool_blocks = 0;            // blocks per pool
     hipStream_t ent_stream[2] = {nullptr, nullptr};
     hipStream_t rec_stream = nullptr; // K3-K5; the caller's stream only brackets a pass with events
     hipEvent_t ev_user = nullptr;
@@ -258,6 +260,7 @@ static void free_all(h264mi_decoder *d) {
     for (int i = 0; i < MI_SETS; i++) {
         if (d->d_mbrec[i]) hipFree(d->d_mbrec[i]);
         if (d->d_coef[i]) hipFree(d->d_coef[i]);
+        if (i == 0 && d->d_pool_head) hipFree(d->d_pool_head);
         if (d->d_toprows[i]) hipFree(d->d_toprows[i]);
         if (d->ev_ent[i]) hipEventDestroy(d->ev_ent[i]);
         if (d->ev_rec[i]) hipEventDestroy(d->ev_rec[i]);
@@ -363,7 +366,19 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipEventCreateWithFlags(&d->ev_upload, hipEventDisableTiming));
     for (int i = 0; i < MI_SETS; i++) {
         TRY_ALLOC(hipMalloc(&d->d_mbrec[i], sizeof(MbRec) * d->mb_cap));
-        TRY_ALLOC(hipMalloc(&d->d_coef[i], sizeof(int16_t) * MI_COEF_PER_MB * d->mb_cap));
+        if (i == 0) {
+            // Pool size.  The worst case is 26 blocks (832 bytes) per macroblock; real streams code a fraction of that (the
+            // 1080p QP 28 bench streams: ~5 blocks per macroblock).  Small decoders get the worst case; large ones 10 blocks
+            // per macroblock, at least 1 GiB -- a batch that needs more fails with H264MI_EDECODE ("coefficient pool
+            // exhausted", code 40) instead of reserving 3 x 52 GB for a case that does not occur.  H264MI_COEF_BLOCKS_PER_MB overrides.
+            const uint64_t worst = d->mb_cap * MI_COEF_BLOCKS + static_cast<uint64_t>(d->slices_cap + 1) * MI_COEF_CHUNK;
+            uint64_t per_mb = 10;
+            if (const char *e = getenv("H264MI_COEF_BLOCKS_PER_MB")) per_mb = static_cast<uint64_t>(std::min(std::max(atoi(e), 1), MI_COEF_BLOCKS));
+            const uint64_t typical = std::max<uint64_t>(d->mb_cap * per_mb, (1ull << 30) / 32) + static_cast<uint64_t>(d->slices_cap + 1) * MI_COEF_CHUNK;
+            d->pool_blocks = std::min<uint64_t>(std::min<uint64_t>(worst, typical), 0xFFFF0000ull);
+            TRY_ALLOC(hipMalloc(&d->d_pool_head, sizeof(uint32_t) * MI_SETS));
+        }
+        TRY_ALLOC(hipMalloc(&d->d_coef[i], d->pool_blocks * 32));
         TRY_ALLOC(hipMalloc(&d->d_toprows[i], static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * 48));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_ent[i], hipEventDisableTiming));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_rec[i], hipEventDisableTiming));
@@ -1033,14 +1048,16 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     int16_t *coef = d->d_coef[set];
     if (prof) { // profiling serialises the two stages on one stream so that HIP-event intervals are per kernel
         mark(-1);
-        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), 0, d->stream, d->d_slices, d->d_pics, d->d_bits, d->d_tables, mbrec, coef, d->d_status,
-                           d->d_toprows[set], d->wmb_max);
+        HIP_TRY(hipMemsetAsync(d->d_pool_head + set, 0, sizeof(uint32_t), d->stream));
+        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), 0, d->stream, d->d_slices, d->d_pics, d->d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
+                           static_cast<uint32_t>(d->pool_blocks), d->d_status, d->d_toprows[set], d->wmb_max);
         mark(0);
     } else {
         HIP_TRY(hipStreamWaitEvent(es, d->ev_upload, 0));
         if (d->pass >= MI_SETS) HIP_TRY(hipStreamWaitEvent(es, d->ev_rec[set], 0)); // pass n-MI_SETS finished reading this set
-        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), d->ent_lds_pad, es, d->d_slices, d->d_pics, d->d_bits, d->d_tables, mbrec, coef, d->d_status,
-                           d->d_toprows[set], d->wmb_max);
+        HIP_TRY(hipMemsetAsync(d->d_pool_head + set, 0, sizeof(uint32_t), es));
+        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), d->ent_lds_pad, es, d->d_slices, d->d_pics, d->d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
+                           static_cast<uint32_t>(d->pool_blocks), d->d_status, d->d_toprows[set], d->wmb_max);
         HIP_TRY(hipEventRecord(d->ev_ent[set], es));
         HIP_TRY(hipStreamWaitEvent(d->rec_stream, d->ev_ent[set], 0));
     }
@@ -1255,7 +1272,7 @@ extern "C" int32_t h264mi_internal_poison(h264mi_decoder *d) {
     HIP_TRY(hipStreamSynchronize(d->stream));
     for (int i = 0; i < MI_SETS; i++) {
         HIP_TRY(hipMemset(d->d_mbrec[i], 0xFF, sizeof(MbRec) * d->mb_cap));
-        HIP_TRY(hipMemset(d->d_coef[i], 0xFF, sizeof(int16_t) * MI_COEF_PER_MB * d->mb_cap));
+        HIP_TRY(hipMemset(d->d_coef[i], 0xFF, d->pool_blocks * 32));
         HIP_TRY(hipMemset(d->d_toprows[i], 0xFF, static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * 48));
     }
     HIP_TRY(hipDeviceSynchronize());

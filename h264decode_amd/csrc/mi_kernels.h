@@ -5,7 +5,7 @@
 
 // K1/K2: one slice per wavefront.  grid = #slices, block = 64; toprows = 12 dwords per MB column per slice.
 extern "C" __global__ void k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec, int16_t *coefs,
-                                     uint32_t *status, uint32_t *toprows, int wmb_max);
+                                     uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status, uint32_t *toprows, int wmb_max);
 // K4: inter macroblocks of a set of pictures (one per stream), one macroblock per wavefront.
 // n_blocks = #pictures * mbs_per_pic_max; grid = n_blocks rounded up to a multiple of 8 (XCD-aware block order)
 extern "C" __global__ void k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const FramePool *pools, const DevTables *tab,

@@ -20,10 +20,16 @@ enum { MBT_NONE = 0, MBT_I4x4, MBT_I8x8, MBT_I16x16, MBT_IPCM, MBT_P16x16, MBT_P
 #define MB_IS_INTER(t) ((t) >= MBT_P16x16)
 
 #define MI_MAX_REFS 16
-#define MI_COEF_PER_MB 416 /* int16: luma 256 | I16 DC 16 | chroma DC 2x4 | chroma AC 2x4x16 | pad 8 */
+/* Coefficient staging layout of a macroblock: 26 blocks of 16 int16 --
+ * luma 16 blocks (raster 4x4 blocks, or 4 x 64 for the 8x8 transform) | I16 DC | chroma DC 2x4 + pad 8 | chroma AC 2x4 blocks.
+ * The entropy kernels assemble it in LDS; only the blocks with a non-zero coefficient go to HBM, packed back to back in a
+ * per-pass pool (MbRec::coef_off / coef_mask), and K3 / K4 scatter them into the same layout in LDS again. */
+#define MI_COEF_PER_MB 416
 #define MI_COEF_I16DC 256
 #define MI_COEF_CDC 272
-#define MI_COEF_CAC 280
+#define MI_COEF_CAC 288
+#define MI_COEF_BLOCKS 26
+#define MI_COEF_CHUNK 2048 /* blocks a slice wavefront takes from the pool at a time (64 KB) */
 
 /* intra-prediction neighbour availability of a macroblock (slice + picture bounds +
  * constrained_intra_pred already applied by the entropy kernel) */
@@ -50,7 +56,9 @@ typedef struct __attribute__((aligned(16))) {
     int16_t refslot[4]; /* frame-pool slot of the referenced picture per 8x8 (-1 none) */
     uint32_t slice_idx; /* index into SliceDesc[] (weighted prediction tables) */
     int16_t mv[16][2];  /* final motion vectors per 4x4 block, raster, quarter-sample units */
-    uint8_t pad[16];
+    uint32_t coef_off;  /* first 32-byte block of this macroblock in the coefficient pool */
+    uint32_t coef_mask; /* bit j: staging block j is present (packed in ascending order); I_PCM: 0xFFF = 384 sample bytes */
+    uint8_t pad[8];
 } MbRec; /* 128 bytes */
 
 typedef struct {
