@@ -133,10 +133,32 @@ struct StreamState {
     // picture under construction
     int cur_slot = -1, cur_pic = -1, cur_slices = 0;
     h264mi_slice_header first_sh;
-    std::vector<OutFrame> out; // frames of this batch in decoding order
     int n_pics_in_batch = 0;
     int status = H264MI_OK; // of this stream in the current batch (h264mi_stream_status)
     bool need_idr = false;  // after an error: nothing is decodable before the next IDR picture
+};
+
+// Everything one prepared batch owns: the pinned staging buffers and their device mirrors, the descriptors, the launch
+// lists and the output frame lists.  There are MI_STAGES of them, so that h264mi_batch_prepare(n + 1) -- host parsing and
+// the H2D copies -- runs while batch n is still executing (h264/server.go:144-145 reads its connection in an endless loop).
+#ifndef MI_STAGES
+#define MI_STAGES 2
+#endif
+struct Stage {
+    uint8_t *d_bits = nullptr, *h_bits = nullptr;
+    size_t bits_used = 0;
+    SliceDesc *d_slices = nullptr, *h_slices = nullptr;
+    PicDesc *d_pics = nullptr, *h_pics = nullptr;
+    uint32_t *d_status = nullptr, *h_status = nullptr, *d_lists = nullptr, *h_lists = nullptr;
+    int n_slices = 0, n_pics = 0, wmb_max = 0, hmb_max = 0, mbs_max = 0;
+    uint64_t mb_used = 0;
+    std::vector<std::vector<uint32_t>> waves, waves_inter;
+    std::vector<uint32_t> wave_off, wave_inter_off;
+    std::vector<std::vector<OutFrame>> out; // per stream: frames of this batch in decoding order
+    bool prepared = false, executed = false;
+    h264mi_batch_info info;
+    hipEvent_t ev_upload = nullptr; // H2D copies of this batch are complete
+    hipEvent_t ev_done = nullptr;   // the last pass over this batch has finished (nothing reads or writes its buffers any more)
 };
 
 struct h264mi_decoder {
@@ -146,12 +168,11 @@ struct h264mi_decoder {
     std::vector<StreamState> st;
     int Wmax = 0, Hmax = 0, n_slots = 0;
     size_t slot_bytes = 0;
-    // device + pinned host mirrors
-    uint8_t *d_bits = nullptr, *h_bits = nullptr;
-    size_t bits_cap = 0, bits_used = 0;
-    SliceDesc *d_slices = nullptr, *h_slices = nullptr;
-    PicDesc *d_pics = nullptr, *h_pics = nullptr;
-    uint32_t *d_status = nullptr, *h_status = nullptr, *d_lists = nullptr, *h_lists = nullptr;
+    Stage stage[MI_STAGES];
+    int prep = 0;  // stage of the most recent h264mi_batch_prepare
+    int exec = 0;  // stage of the most recent h264mi_batch_execute: what sync and the frame accessors refer to
+    hipStream_t up_stream = nullptr; // H2D copies (a stream of their own: the caller's stream is busy with the previous batch)
+    size_t bits_cap = 0;
     uint32_t *d_toprows[MI_SETS] = {}; // entropy kernels' row-above neighbour state: 48 B per MB column per slice
     int slices_cap = 0, pics_cap = 0;
     // Passes are pipelined: the entropy kernels of passes n+1 / n+2 (two private streams, alternating)
@@ -164,23 +185,17 @@ struct h264mi_decoder {
     hipStream_t ent_stream[2] = {nullptr, nullptr};
     hipStream_t rec_stream = nullptr; // K3-K5; the caller's stream only brackets a pass with events
     hipEvent_t ev_user = nullptr;
-    hipEvent_t ev_ent[MI_SETS] = {}, ev_rec[MI_SETS] = {}, ev_upload = nullptr;
+    hipEvent_t ev_ent[MI_SETS] = {}, ev_rec[MI_SETS] = {};
     uint64_t pass = 0; // execute() counter
-    uint64_t mb_cap = 0, mb_used = 0;
+    uint64_t mb_cap = 0;
     FramePool *d_pools = nullptr;
     std::vector<FramePool> h_pools;
     uint8_t *d_frames = nullptr;
     DevTables *d_tables = nullptr, *h_tables = nullptr;
     int n_scaling = 0;
     bool tables_dirty = true;
-    // batch
-    int n_slices = 0, n_pics = 0, wmb_max = 0, hmb_max = 0, mbs_max = 0;
     size_t ent_lds_pad = 0; // dynamic LDS requested (and not used) by k_entropy: caps its wavefronts per CU, see h264mi_decoder_create
-    std::vector<std::vector<uint32_t>> waves, waves_inter;
-    std::vector<uint32_t> wave_off, wave_inter_off;
-    bool prepared = false;
     bool isolate = false; // h264mi_decoder_set_isolation: a broken stream does not fail the batch
-    h264mi_batch_info info;
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> ev;
@@ -247,16 +262,21 @@ extern "C" int32_t h264mi_init(int32_t device) {
 }
 
 static void free_all(h264mi_decoder *d) {
-    if (d->d_bits) hipFree(d->d_bits);
-    if (d->h_bits) hipHostFree(d->h_bits);
-    if (d->d_slices) hipFree(d->d_slices);
-    if (d->h_slices) hipHostFree(d->h_slices);
-    if (d->d_pics) hipFree(d->d_pics);
-    if (d->h_pics) hipHostFree(d->h_pics);
-    if (d->d_status) hipFree(d->d_status);
-    if (d->h_status) hipHostFree(d->h_status);
-    if (d->d_lists) hipFree(d->d_lists);
-    if (d->h_lists) hipHostFree(d->h_lists);
+    for (Stage &g : d->stage) {
+        if (g.d_bits) hipFree(g.d_bits);
+        if (g.h_bits) hipHostFree(g.h_bits);
+        if (g.d_slices) hipFree(g.d_slices);
+        if (g.h_slices) hipHostFree(g.h_slices);
+        if (g.d_pics) hipFree(g.d_pics);
+        if (g.h_pics) hipHostFree(g.h_pics);
+        if (g.d_status) hipFree(g.d_status);
+        if (g.h_status) hipHostFree(g.h_status);
+        if (g.d_lists) hipFree(g.d_lists);
+        if (g.h_lists) hipHostFree(g.h_lists);
+        if (g.ev_upload) hipEventDestroy(g.ev_upload);
+        if (g.ev_done) hipEventDestroy(g.ev_done);
+    }
+    if (d->up_stream) hipStreamDestroy(d->up_stream);
     for (int i = 0; i < MI_SETS; i++) {
         if (d->d_mbrec[i]) hipFree(d->d_mbrec[i]);
         if (d->d_coef[i]) hipFree(d->d_coef[i]);
@@ -265,7 +285,6 @@ static void free_all(h264mi_decoder *d) {
         if (d->ev_ent[i]) hipEventDestroy(d->ev_ent[i]);
         if (d->ev_rec[i]) hipEventDestroy(d->ev_rec[i]);
     }
-    if (d->ev_upload) hipEventDestroy(d->ev_upload);
     for (int i = 0; i < 2; i++)
         if (d->ent_stream[i]) hipStreamDestroy(d->ent_stream[i]);
     if (d->rec_stream) hipStreamDestroy(d->rec_stream);
@@ -292,7 +311,9 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
         delete d;
         return H264MI_EUNSUPPORTED;
     }
-    d->n_slots = cfg->max_frames_per_batch + MI_MAX_REFS + 1;
+    // frame slots per stream: the outputs of the batch being prepared and of the one before it (still being read or executed:
+    // MI_STAGES batches are in flight), up to 16 reference pictures, and the picture under construction
+    d->n_slots = MI_STAGES * cfg->max_frames_per_batch + MI_MAX_REFS + 1;
     d->slot_bytes = (static_cast<size_t>(d->Wmax) * d->Hmax * 3 / 2 + 255) & ~static_cast<size_t>(255);
     const int S = cfg->max_streams;
     d->st.resize(S);
@@ -321,16 +342,23 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
         TRY_ALLOC(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         d->own_stream = true;
     }
-    TRY_ALLOC(hipMalloc(&d->d_bits, d->bits_cap));
-    TRY_ALLOC(hipHostMalloc(&d->h_bits, d->bits_cap));
-    TRY_ALLOC(hipMalloc(&d->d_slices, sizeof(SliceDesc) * d->slices_cap));
-    TRY_ALLOC(hipHostMalloc(&d->h_slices, sizeof(SliceDesc) * d->slices_cap));
-    TRY_ALLOC(hipMalloc(&d->d_pics, sizeof(PicDesc) * d->pics_cap));
-    TRY_ALLOC(hipHostMalloc(&d->h_pics, sizeof(PicDesc) * d->pics_cap));
-    TRY_ALLOC(hipMalloc(&d->d_status, sizeof(uint32_t) * 8 * d->slices_cap));
-    TRY_ALLOC(hipHostMalloc(&d->h_status, sizeof(uint32_t) * 8 * d->slices_cap));
-    TRY_ALLOC(hipMalloc(&d->d_lists, sizeof(uint32_t) * 2 * d->pics_cap));
-    TRY_ALLOC(hipHostMalloc(&d->h_lists, sizeof(uint32_t) * 2 * d->pics_cap));
+    TRY_ALLOC(hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking));
+    for (Stage &g : d->stage) {
+        TRY_ALLOC(hipMalloc(&g.d_bits, d->bits_cap));
+        TRY_ALLOC(hipHostMalloc(&g.h_bits, d->bits_cap));
+        TRY_ALLOC(hipMalloc(&g.d_slices, sizeof(SliceDesc) * d->slices_cap));
+        TRY_ALLOC(hipHostMalloc(&g.h_slices, sizeof(SliceDesc) * d->slices_cap));
+        TRY_ALLOC(hipMalloc(&g.d_pics, sizeof(PicDesc) * d->pics_cap));
+        TRY_ALLOC(hipHostMalloc(&g.h_pics, sizeof(PicDesc) * d->pics_cap));
+        TRY_ALLOC(hipMalloc(&g.d_status, sizeof(uint32_t) * 8 * d->slices_cap));
+        TRY_ALLOC(hipHostMalloc(&g.h_status, sizeof(uint32_t) * 8 * d->slices_cap));
+        TRY_ALLOC(hipMalloc(&g.d_lists, sizeof(uint32_t) * 2 * d->pics_cap));
+        TRY_ALLOC(hipHostMalloc(&g.h_lists, sizeof(uint32_t) * 2 * d->pics_cap));
+        TRY_ALLOC(hipEventCreateWithFlags(&g.ev_upload, hipEventDisableTiming));
+        TRY_ALLOC(hipEventCreateWithFlags(&g.ev_done, hipEventDisableTiming));
+        g.out.resize(S);
+        memset(&g.info, 0, sizeof(g.info));
+    }
     {
         // Optional experiment knob: H264MI_ENT_CUS=n gives the entropy streams the first n compute units
         // and reconstruction the rest (hipExtStreamCreateWithCUMask).  Measured slower than sharing the
@@ -363,7 +391,6 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
             TRY_ALLOC(hipStreamCreateWithFlags(&d->rec_stream, hipStreamNonBlocking));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_user, hipEventDisableTiming));
     }
-    TRY_ALLOC(hipEventCreateWithFlags(&d->ev_upload, hipEventDisableTiming));
     for (int i = 0; i < MI_SETS; i++) {
         TRY_ALLOC(hipMalloc(&d->d_mbrec[i], sizeof(MbRec) * d->mb_cap));
         if (i == 0) {
@@ -391,6 +418,15 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
     build_tables(d->h_tables);
     d->h_pools.resize(S);
+    for (int si = 0; si < S; si++) { // static per stream (kernels take the geometry of a picture from its PicDesc)
+        FramePool &fp = d->h_pools[si];
+        fp.base = reinterpret_cast<uint64_t>(d->d_frames) + static_cast<uint64_t>(si) * d->slot_bytes * d->n_slots;
+        fp.slot_bytes = d->slot_bytes;
+        fp.w = fp.h = 0;
+        fp.n_slots = static_cast<uint32_t>(d->n_slots);
+        fp.pad = 0;
+    }
+    TRY_ALLOC(hipMemcpy(d->d_pools, d->h_pools.data(), sizeof(FramePool) * S, hipMemcpyHostToDevice));
     // a deterministic background for macroblocks no slice covers
     TRY_ALLOC(hipMemsetAsync(d->d_frames, 128, d->slot_bytes * d->n_slots * S, d->stream));
     TRY_ALLOC(hipStreamSynchronize(d->stream));
@@ -404,6 +440,7 @@ extern "C" int32_t h264mi_decoder_destroy(h264mi_decoder *d) {
     GUARD(d);
     for (int i = 0; i < 2; i++) hipStreamSynchronize(d->ent_stream[i]);
     hipStreamSynchronize(d->rec_stream);
+    hipStreamSynchronize(d->up_stream);
     hipStreamSynchronize(d->stream);
     free_all(d);
     delete d;
@@ -422,7 +459,6 @@ extern "C" int32_t h264mi_decoder_set_stream(h264mi_decoder *d, void *s) {
 static void reset_stream(StreamState &s, bool keep_parameter_sets) {
     for (auto &sl : s.slots) sl = Slot();
     s.cur_slot = s.cur_pic = -1, s.cur_slices = 0;
-    s.out.clear();
     s.n_pics_in_batch = 0;
     s.prev_poc_msb = s.prev_poc_lsb = s.prev_frame_num = s.prev_frame_num_offset = 0;
     if (!keep_parameter_sets) {
@@ -435,12 +471,16 @@ static void reset_stream(StreamState &s, bool keep_parameter_sets) {
 extern "C" int32_t h264mi_decoder_reset(h264mi_decoder *d) {
     if (!d) return H264MI_EINVAL;
     for (auto &s : d->st) reset_stream(s, true);
-    d->prepared = false;
+    for (Stage &g : d->stage) {
+        g.prepared = false;
+        for (auto &o : g.out) o.clear();
+    }
     return H264MI_OK;
 }
 extern "C" int32_t h264mi_stream_reset(h264mi_decoder *d, int32_t stream) {
     if (!d || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
     reset_stream(d->st[stream], false);
+    for (Stage &g : d->stage) g.out[stream].clear();
     return H264MI_OK;
 }
 extern "C" int32_t h264mi_stream_status(h264mi_decoder *d, int32_t stream, int32_t *status) {
@@ -629,22 +669,24 @@ static void mark_reference(StreamState &s, const h264mi_sps &sps) {
     }
 }
 
-static void finish_picture(h264mi_decoder *d, StreamState &s) {
+static void finish_picture(h264mi_decoder *d, int si) {
+    StreamState &s = d->st[si];
+    Stage &g = d->stage[d->prep];
     if (s.cur_slot < 0) return;
     mark_reference(s, s.sps[s.active_sps]);
-    PicDesc &pd = d->h_pics[s.cur_pic];
+    PicDesc &pd = g.h_pics[s.cur_pic];
     pd.n_slices = static_cast<uint32_t>(s.cur_slices);
-    if (!s.out.empty()) s.out.back().poc = s.slots[s.cur_slot].poc; // operation 5 rewrites it
+    if (!g.out[si].empty()) g.out[si].back().poc = s.slots[s.cur_slot].poc; // operation 5 rewrites it
     // Every macroblock of the picture belongs to exactly one slice wavefront (SliceDesc::fill_from / end_mb): order the
     // slices by first_mb (arbitrary slice order is legal in Baseline); a slice's range ends where the next one starts.
     std::vector<uint32_t> idx(pd.n_slices);
     for (uint32_t i = 0; i < pd.n_slices; i++) idx[i] = pd.first_slice + i;
-    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return d->h_slices[a].first_mb < d->h_slices[b].first_mb; });
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return g.h_slices[a].first_mb < g.h_slices[b].first_mb; });
     const uint32_t total = pd.wmb * pd.hmb;
     for (uint32_t i = 0; i < pd.n_slices; i++) {
-        SliceDesc &sd = d->h_slices[idx[i]];
+        SliceDesc &sd = g.h_slices[idx[i]];
         sd.fill_from = i == 0 ? 0 : sd.first_mb;
-        sd.end_mb = i + 1 < pd.n_slices ? std::max(d->h_slices[idx[i + 1]].first_mb, sd.first_mb) : total;
+        sd.end_mb = i + 1 < pd.n_slices ? std::max(g.h_slices[idx[i + 1]].first_mb, sd.first_mb) : total;
     }
     s.cur_slot = s.cur_pic = -1;
 }
@@ -674,11 +716,12 @@ static int scaling_set_for(h264mi_decoder *d, const h264mi_pps &p) {
 // `off` / `rlen`: where batch_prepare's parallel pass put the slice's RBSP in the pinned staging buffer (16-byte aligned)
 static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref_idc, int type) {
     StreamState &s = d->st[si];
-    if (d->n_slices >= d->slices_cap) {
+    Stage &g = d->stage[d->prep];
+    if (g.n_slices >= d->slices_cap) {
         set_error("more than %d slices in the batch", d->slices_cap);
         return H264MI_ECAPACITY;
     }
-    uint8_t *rbsp = d->h_bits + off;
+    uint8_t *rbsp = g.h_bits + off;
     // peek pps id: first_mb_in_slice, slice_type, pic_parameter_set_id
     BitReader br(rbsp, rlen);
     br.ue();
@@ -716,21 +759,16 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         set_error("stream %d: %dx%d exceeds the configured maximum %dx%d", si, wmb * 16, hmb * 16, d->Wmax, d->Hmax);
         return H264MI_ECAPACITY;
     }
-    if (s.cur_slot >= 0 && (sh.first_mb_in_slice == 0 || new_picture(sps, s.first_sh, sh))) finish_picture(d, s);
+    if (s.cur_slot >= 0 && (sh.first_mb_in_slice == 0 || new_picture(sps, s.first_sh, sh))) finish_picture(d, si);
     if (s.active_sps != pps.sps_id || s.wmb != wmb || s.hmb != hmb) { // (re)activate: new sequence geometry
         if (sh.nal_unit_type != 5 && s.active_sps >= 0 && (s.wmb != wmb || s.hmb != hmb)) {
             set_error("stream %d: picture size changes without an IDR", si);
             return H264MI_EBITSTREAM;
         }
         s.active_sps = pps.sps_id, s.wmb = wmb, s.hmb = hmb;
-        FramePool &fp = d->h_pools[si];
-        fp.base = reinterpret_cast<uint64_t>(d->d_frames) + static_cast<uint64_t>(si) * d->slot_bytes * d->n_slots;
-        fp.slot_bytes = d->slot_bytes;
-        fp.w = wmb * 16, fp.h = hmb * 16;
-        fp.n_slots = static_cast<uint32_t>(d->n_slots);
     }
     if (s.cur_slot < 0) { // first slice of a new picture
-        if (s.n_pics_in_batch >= d->cfg.max_frames_per_batch || d->n_pics >= d->pics_cap) {
+        if (s.n_pics_in_batch >= d->cfg.max_frames_per_batch || g.n_pics >= d->pics_cap) {
             set_error("stream %d: more than %d frames in one batch", si, d->cfg.max_frames_per_batch);
             return H264MI_ECAPACITY;
         }
@@ -741,12 +779,12 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
             set_error("stream %d: frame pool exhausted", si);
             return H264MI_ECAPACITY;
         }
-        if (d->mb_used + static_cast<uint64_t>(wmb) * hmb > d->mb_cap) {
+        if (g.mb_used + static_cast<uint64_t>(wmb) * hmb > d->mb_cap) {
             set_error("macroblock record pool exhausted");
             return H264MI_ECAPACITY;
         }
         s.cur_slot = slot;
-        s.cur_pic = d->n_pics++;
+        s.cur_pic = g.n_pics++;
         s.cur_slices = 0;
         s.first_sh = sh;
         Slot &sl = s.slots[slot];
@@ -754,12 +792,12 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         sl.held = true;
         sl.frame_num = sh.frame_num;
         sl.poc = compute_poc(s, sps, sh);
-        PicDesc &pd = d->h_pics[s.cur_pic];
+        PicDesc &pd = g.h_pics[s.cur_pic];
         memset(&pd, 0, sizeof(pd));
         pd.stream = si, pd.slot = slot, pd.wmb = wmb, pd.hmb = hmb;
-        pd.mb_base = d->mb_used;
-        d->mb_used += static_cast<uint64_t>(wmb) * hmb;
-        pd.first_slice = d->n_slices;
+        pd.mb_base = g.mb_used;
+        g.mb_used += static_cast<uint64_t>(wmb) * hmb;
+        pd.first_slice = g.n_slices;
         pd.cabac = pps.entropy_coding_mode, pd.t8x8_mode = pps.transform_8x8_mode, pd.cip = pps.constrained_intra_pred;
         pd.weighted_pred = pps.weighted_pred;
         pd.cqp_off[0] = static_cast<int8_t>(pps.chroma_qp_index_offset), pd.cqp_off[1] = static_cast<int8_t>(pps.second_chroma_qp_index_offset);
@@ -771,21 +809,21 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         }
         pd.scaling_set = static_cast<uint8_t>(ss);
         pd.order = s.n_pics_in_batch++;
-        s.out.push_back({slot, wmb, hmb, 2 * sps.frame_crop_left_offset, 2 * sps.frame_crop_top_offset, sps.width, sps.height, sl.poc, sh.frame_num,
+        g.out[si].push_back({slot, wmb, hmb, 2 * sps.frame_crop_left_offset, 2 * sps.frame_crop_top_offset, sps.width, sps.height, sl.poc, sh.frame_num,
                          sh.nal_ref_idc, sh.nal_unit_type == 5, s.cur_pic});
-        d->wmb_max = std::max(d->wmb_max, wmb);
-        d->hmb_max = std::max(d->hmb_max, hmb);
-        d->mbs_max = std::max(d->mbs_max, wmb * hmb);
-        d->info.n_macroblocks += static_cast<int64_t>(wmb) * hmb;
-        if (si == 0) d->info.width = sps.width, d->info.height = sps.height, d->info.coded_width = wmb * 16, d->info.coded_height = hmb * 16;
+        g.wmb_max = std::max(g.wmb_max, wmb);
+        g.hmb_max = std::max(g.hmb_max, hmb);
+        g.mbs_max = std::max(g.mbs_max, wmb * hmb);
+        g.info.n_macroblocks += static_cast<int64_t>(wmb) * hmb;
+        if (si == 0) g.info.width = sps.width, g.info.height = sps.height, g.info.coded_width = wmb * 16, g.info.coded_height = hmb * 16;
     }
     if (s.cur_slices >= d->cfg.max_slices_per_frame) {
         set_error("stream %d: more than %d slices in a frame", si, d->cfg.max_slices_per_frame);
         return H264MI_ECAPACITY;
     }
     if (sh.first_mb_in_slice >= wmb * hmb) return H264MI_EBITSTREAM;
-    PicDesc &pd = d->h_pics[s.cur_pic];
-    SliceDesc &sd = d->h_slices[d->n_slices];
+    PicDesc &pd = g.h_pics[s.cur_pic];
+    SliceDesc &sd = g.h_slices[g.n_slices];
     memset(&sd, 0, sizeof(sd));
     sd.rbsp_off = static_cast<uint32_t>(off), sd.rbsp_size = static_cast<uint32_t>(rlen);
     sd.data_bit_off = static_cast<uint32_t>(sh.slice_data_bit_offset);
@@ -814,8 +852,8 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
                 sd.wp_cw[i][j] = static_cast<int16_t>(pps.weighted_pred ? sh.chroma_weight_l0[i][j] : 1), sd.wp_co[i][j] = static_cast<int16_t>(sh.chroma_offset_l0[i][j]);
         }
     }
-    d->bits_used = std::max(d->bits_used, off + rlen);
-    d->n_slices++;
+    g.bits_used = std::max(g.bits_used, off + rlen);
+    g.n_slices++;
     s.cur_slices++;
     return H264MI_OK;
 }
@@ -824,16 +862,23 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     if (!d || n_streams < 0 || n_streams > static_cast<int>(d->st.size()) || (n_streams && (!bufs || !lens))) return H264MI_EINVAL;
     GUARD(d);
     auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(d->ent_stream[i])); // the previous batch must not be reading the staging buffers
-    HIP_TRY(hipStreamSynchronize(d->rec_stream));
-    HIP_TRY(hipStreamSynchronize(d->stream));
-    d->prepared = false;
-    d->n_slices = d->n_pics = 0;
-    d->bits_used = 0, d->mb_used = 0, d->wmb_max = 0, d->hmb_max = 0, d->mbs_max = 0;
-    memset(&d->info, 0, sizeof(d->info));
-    for (auto &s : d->st) {
+    // The next staging set; the batch that used it last (MI_STAGES batches ago) must have finished executing.  The batch
+    // prepared before this one may still be executing: nothing it uses is touched here.
+    const int prev_stage = d->prep;
+    d->prep = (d->prep + 1) % MI_STAGES;
+    Stage &g = d->stage[d->prep];
+    if (g.executed) HIP_TRY(hipEventSynchronize(g.ev_done));
+    g.prepared = false, g.executed = false;
+    g.n_slices = g.n_pics = 0;
+    g.bits_used = 0, g.mb_used = 0, g.wmb_max = 0, g.hmb_max = 0, g.mbs_max = 0;
+    memset(&g.info, 0, sizeof(g.info));
+    for (size_t si = 0; si < d->st.size(); si++) {
+        StreamState &s = d->st[si];
         for (auto &sl : s.slots) sl.held = sl.ref != 0; // reference pictures at batch start stay put for the whole batch
-        s.out.clear();
+        // the frames of the batch prepared before this one stay readable (and, if it is still executing, writable)
+        if (MI_STAGES > 1)
+            for (const OutFrame &o : d->stage[prev_stage].out[si]) s.slots[o.slot].held = true;
+        g.out[si].clear();
         s.n_pics_in_batch = 0;
         s.cur_slot = s.cur_pic = -1;
         s.status = H264MI_OK;
@@ -890,9 +935,9 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     }
     // ---- pass 3 (parallel over slices): remove emulation prevention straight into the pinned staging buffer ----
     parallel_for(static_cast<int>(staged.size()), [&](int k) {
-        Staged &g = staged[k];
-        const h264mi_nal &nal = all_nals[g.si][g.nal];
-        g.rlen = unescape(bufs[g.si] + nal.offset + 1, nal.num_bytes - 1, d->h_bits + g.off);
+        Staged &sg = staged[k];
+        const h264mi_nal &nal = all_nals[sg.si][sg.nal];
+        sg.rlen = unescape(bufs[sg.si] + nal.offset + 1, nal.num_bytes - 1, g.h_bits + sg.off);
     });
     // ---- pass 4 (serial): parameter sets, slice headers, DPB / POC / reference lists, descriptors ----
     int first_error = H264MI_OK;
@@ -903,9 +948,9 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
         const int n = n_nals[si];
         std::vector<uint8_t> tmp;
         // what this stream adds to the batch sits at the tail of every table: a failing stream is taken out again
-        const int pics0 = d->n_pics, slices0 = d->n_slices;
-        const uint64_t mb0 = d->mb_used;
-        const int64_t info_mb0 = d->info.n_macroblocks;
+        const int pics0 = g.n_pics, slices0 = g.n_slices;
+        const uint64_t mb0 = g.mb_used;
+        const int64_t info_mb0 = g.info.n_macroblocks;
         int r = H264MI_OK;
         for (int i = 0; i < n && r == H264MI_OK; i++) {
             const h264mi_nal &nal = nals[i];
@@ -917,7 +962,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
                 h264mi_sps sps;
                 r = parse_sps(tmp.data(), rl, &sps);
                 if (r == H264MI_OK) {
-                    if (s.cur_slot >= 0) finish_picture(d, s);
+                    if (s.cur_slot >= 0) finish_picture(d, si);
                     s.sps[sps.id] = sps, s.sps_ok[sps.id] = true;
                 }
                 break;
@@ -936,21 +981,21 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
                 h264mi_pps pps;
                 r = parse_pps(&s.sps[sid], tmp.data(), rl, &pps);
                 if (r == H264MI_OK) {
-                    if (s.cur_slot >= 0) finish_picture(d, s);
+                    if (s.cur_slot >= 0) finish_picture(d, si);
                     s.pps[pps.id] = pps, s.pps_ok[pps.id] = true;
                 }
                 break;
             }
             case 1:
             case 5: {
-                const Staged &g = staged[staged_of[si][i]];
-                r = add_slice(d, si, g.off, g.rlen, nal.ref_idc, nal.type);
+                const Staged &sg = staged[staged_of[si][i]];
+                r = add_slice(d, si, sg.off, sg.rlen, nal.ref_idc, nal.type);
                 break;
             }
             case 9:
             case 10:
             case 11:
-                if (s.cur_slot >= 0) finish_picture(d, s);
+                if (s.cur_slot >= 0) finish_picture(d, si);
                 break;
             default: break; // SEI, filler, ... (h264/server.go:147-164 ignores them too)
             }
@@ -958,62 +1003,65 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
         if (r != H264MI_OK) {
             // The stream leaves the batch: its pictures, slices and records are dropped, its references are forgotten
             // (nothing is decodable before its next IDR picture); the other streams are not affected.
-            d->n_pics = pics0, d->n_slices = slices0, d->mb_used = mb0, d->info.n_macroblocks = info_mb0;
+            g.n_pics = pics0, g.n_slices = slices0, g.mb_used = mb0, g.info.n_macroblocks = info_mb0;
             reset_stream(s, true);
+            g.out[si].clear();
             s.need_idr = true;
             s.status = r;
             if (first_error == H264MI_OK) first_error = r;
             if (!d->isolate) return r;
             continue;
         }
-        if (s.cur_slot >= 0) finish_picture(d, s);
+        if (s.cur_slot >= 0) finish_picture(d, si);
     }
     // Longest-processing-time-first: the entropy kernel runs one slice per workgroup and workgroups are
     // dispatched in index order, so the biggest slices (I pictures) must start first.
-    if (d->n_slices > 1) {
-        std::vector<int> order(d->n_slices);
-        for (int i = 0; i < d->n_slices; i++) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return d->h_slices[x].rbsp_size > d->h_slices[y].rbsp_size; });
-        std::vector<SliceDesc> tmp(d->h_slices, d->h_slices + d->n_slices);
-        for (int i = 0; i < d->n_slices; i++) d->h_slices[i] = tmp[order[i]];
+    if (g.n_slices > 1) {
+        std::vector<int> order(g.n_slices);
+        for (int i = 0; i < g.n_slices; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return g.h_slices[x].rbsp_size > g.h_slices[y].rbsp_size; });
+        std::vector<SliceDesc> tmp(g.h_slices, g.h_slices + g.n_slices);
+        for (int i = 0; i < g.n_slices; i++) g.h_slices[i] = tmp[order[i]];
     }
     // picture "waves": the k-th picture of every stream can be reconstructed side by side
     size_t nw = 0;
     for (auto &s : d->st) nw = std::max<size_t>(nw, s.n_pics_in_batch);
-    d->waves.assign(nw, {});
-    d->waves_inter.assign(nw, {});
-    for (int i = 0; i < d->n_pics; i++) {
-        d->waves[d->h_pics[i].order].push_back(i);
-        if (!d->h_pics[i].is_intra_only) d->waves_inter[d->h_pics[i].order].push_back(i);
+    g.waves.assign(nw, {});
+    g.waves_inter.assign(nw, {});
+    for (int i = 0; i < g.n_pics; i++) {
+        g.waves[g.h_pics[i].order].push_back(i);
+        if (!g.h_pics[i].is_intra_only) g.waves_inter[g.h_pics[i].order].push_back(i);
     }
-    d->wave_off.clear();
-    d->wave_inter_off.clear();
+    g.wave_off.clear();
+    g.wave_inter_off.clear();
     uint32_t pos = 0;
     for (size_t w = 0; w < nw; w++) {
-        d->wave_off.push_back(pos);
-        for (uint32_t p : d->waves[w]) d->h_lists[pos++] = p;
-        d->wave_inter_off.push_back(pos);
-        for (uint32_t p : d->waves_inter[w]) d->h_lists[pos++] = p;
+        g.wave_off.push_back(pos);
+        for (uint32_t p : g.waves[w]) g.h_lists[pos++] = p;
+        g.wave_inter_off.push_back(pos);
+        for (uint32_t p : g.waves_inter[w]) g.h_lists[pos++] = p;
     }
     // uploads
-    if (d->n_slices) {
-        size_t nbytes = std::min(d->bits_cap, ((d->bits_used + 15) & ~static_cast<size_t>(15)) + 4096);
-        memset(d->h_bits + d->bits_used, 0, nbytes - d->bits_used);
-        HIP_TRY(hipMemcpyAsync(d->d_bits, d->h_bits, nbytes, hipMemcpyHostToDevice, d->stream));
-        HIP_TRY(hipMemcpyAsync(d->d_slices, d->h_slices, sizeof(SliceDesc) * d->n_slices, hipMemcpyHostToDevice, d->stream));
-        HIP_TRY(hipMemcpyAsync(d->d_pics, d->h_pics, sizeof(PicDesc) * d->n_pics, hipMemcpyHostToDevice, d->stream));
-        HIP_TRY(hipMemcpyAsync(d->d_lists, d->h_lists, sizeof(uint32_t) * pos, hipMemcpyHostToDevice, d->stream));
-        HIP_TRY(hipMemcpyAsync(d->d_pools, d->h_pools.data(), sizeof(FramePool) * d->h_pools.size(), hipMemcpyHostToDevice, d->stream));
+    if (g.n_slices) {
+        size_t nbytes = std::min(d->bits_cap, ((g.bits_used + 15) & ~static_cast<size_t>(15)) + 4096);
+        memset(g.h_bits + g.bits_used, 0, nbytes - g.bits_used);
+        HIP_TRY(hipMemcpyAsync(g.d_bits, g.h_bits, nbytes, hipMemcpyHostToDevice, d->up_stream));
+        HIP_TRY(hipMemcpyAsync(g.d_slices, g.h_slices, sizeof(SliceDesc) * g.n_slices, hipMemcpyHostToDevice, d->up_stream));
+        HIP_TRY(hipMemcpyAsync(g.d_pics, g.h_pics, sizeof(PicDesc) * g.n_pics, hipMemcpyHostToDevice, d->up_stream));
+        HIP_TRY(hipMemcpyAsync(g.d_lists, g.h_lists, sizeof(uint32_t) * pos, hipMemcpyHostToDevice, d->up_stream));
     }
     if (d->tables_dirty) {
-        HIP_TRY(hipMemcpyAsync(d->d_tables, d->h_tables, sizeof(DevTables), hipMemcpyHostToDevice, d->stream));
+        // a new PPS added a LevelScale set: the table only grows, so the batch still executing keeps seeing its own sets.
+        // (h_tables is pinned and rewritten only by the next prepare, which cannot start its copy before this one is done:
+        // same stream.)
+        HIP_TRY(hipMemcpyAsync(d->d_tables, d->h_tables, sizeof(DevTables), hipMemcpyHostToDevice, d->up_stream));
         d->tables_dirty = false;
     }
-    HIP_TRY(hipEventRecord(d->ev_upload, d->stream));
-    d->info.n_frames = d->n_pics, d->info.n_slices = d->n_slices, d->info.bitstream_bytes = static_cast<int64_t>(d->bits_used);
-    d->info.host_prepare_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (info) *info = d->info;
-    d->prepared = true;
+    HIP_TRY(hipEventRecord(g.ev_upload, d->up_stream));
+    g.info.n_frames = g.n_pics, g.info.n_slices = g.n_slices, g.info.bitstream_bytes = static_cast<int64_t>(g.bits_used);
+    g.info.host_prepare_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (info) *info = g.info;
+    g.prepared = true;
     return H264MI_OK;
 }
 
@@ -1029,11 +1077,13 @@ static hipEvent_t next_event(h264mi_decoder *d, size_t &idx, int kind) {
 }
 
 extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
-    if (!d || !d->prepared) {
+    if (!d || !d->stage[d->prep].prepared) {
         set_error("h264mi_batch_execute: no prepared batch");
         return H264MI_EINVAL;
     }
-    if (!d->n_slices) return H264MI_OK;
+    d->exec = d->prep; // sync and the frame accessors refer to this batch from now on
+    Stage &g = d->stage[d->exec];
+    if (!g.n_slices) return H264MI_OK;
     GUARD(d);
     size_t ei = 0;
     const bool prof = d->profiling;
@@ -1047,35 +1097,36 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     MbRec *mbrec = d->d_mbrec[set];
     int16_t *coef = d->d_coef[set];
     if (prof) { // profiling serialises the two stages on one stream so that HIP-event intervals are per kernel
+        HIP_TRY(hipStreamWaitEvent(d->stream, g.ev_upload, 0));
         mark(-1);
         HIP_TRY(hipMemsetAsync(d->d_pool_head + set, 0, sizeof(uint32_t), d->stream));
-        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), 0, d->stream, d->d_slices, d->d_pics, d->d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
-                           static_cast<uint32_t>(d->pool_blocks), d->d_status, d->d_toprows[set], d->wmb_max);
+        hipLaunchKernelGGL(k_entropy, dim3(g.n_slices), dim3(64), 0, d->stream, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
+                           static_cast<uint32_t>(d->pool_blocks), g.d_status, d->d_toprows[set], g.wmb_max);
         mark(0);
     } else {
-        HIP_TRY(hipStreamWaitEvent(es, d->ev_upload, 0));
+        HIP_TRY(hipStreamWaitEvent(es, g.ev_upload, 0));
         if (d->pass >= MI_SETS) HIP_TRY(hipStreamWaitEvent(es, d->ev_rec[set], 0)); // pass n-MI_SETS finished reading this set
         HIP_TRY(hipMemsetAsync(d->d_pool_head + set, 0, sizeof(uint32_t), es));
-        hipLaunchKernelGGL(k_entropy, dim3(d->n_slices), dim3(64), d->ent_lds_pad, es, d->d_slices, d->d_pics, d->d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
-                           static_cast<uint32_t>(d->pool_blocks), d->d_status, d->d_toprows[set], d->wmb_max);
+        hipLaunchKernelGGL(k_entropy, dim3(g.n_slices), dim3(64), d->ent_lds_pad, es, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
+                           static_cast<uint32_t>(d->pool_blocks), g.d_status, d->d_toprows[set], g.wmb_max);
         HIP_TRY(hipEventRecord(d->ev_ent[set], es));
         HIP_TRY(hipStreamWaitEvent(d->rec_stream, d->ev_ent[set], 0));
     }
     hipStream_t rs = prof ? d->stream : d->rec_stream;
-    for (size_t w = 0; w < d->waves.size(); w++) {
-        const uint32_t n = static_cast<uint32_t>(d->waves[w].size()), ni = static_cast<uint32_t>(d->waves_inter[w].size());
+    for (size_t w = 0; w < g.waves.size(); w++) {
+        const uint32_t n = static_cast<uint32_t>(g.waves[w].size()), ni = static_cast<uint32_t>(g.waves_inter[w].size());
         if (!n) continue;
         if (ni) {
-            const uint32_t nb = ni * d->mbs_max;
-            hipLaunchKernelGGL(k_inter, dim3((nb + 7) & ~7u), dim3(64), 0, rs, d->d_lists + d->wave_inter_off[w], d->d_pics, d->d_slices, d->d_pools,
-                               d->d_tables, mbrec, coef, d->mbs_max, static_cast<int>(nb));
+            const uint32_t nb = ni * g.mbs_max;
+            hipLaunchKernelGGL(k_inter, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_inter_off[w], g.d_pics, g.d_slices, d->d_pools,
+                               d->d_tables, mbrec, coef, g.mbs_max, static_cast<int>(nb));
             mark(1);
         }
-        hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, d->d_lists + d->wave_off[w], d->d_pics, d->d_pools, d->d_tables, mbrec, coef);
+        hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, g.d_lists + g.wave_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, coef);
         mark(2);
         int dbw = 1, dbring = 16, dbring_last = 16, dbbufs = 1;
-        mi_deblock_plan(d->wmb_max, d->hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
-        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, d->d_lists + d->wave_off[w], d->d_pics,
+        mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
+        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_off[w], g.d_pics,
                            d->d_pools, d->d_tables, mbrec, dbring, dbring_last, dbbufs);
         mark(3);
     }
@@ -1083,7 +1134,9 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     if (!prof) HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_rec[set], 0)); // the caller's stream sees the finished pass
     d->pass++;
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(d->h_status, d->d_status, sizeof(uint32_t) * 8 * d->n_slices, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(g.h_status, g.d_status, sizeof(uint32_t) * 8 * g.n_slices, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipEventRecord(g.ev_done, d->stream)); // d->stream has waited for the reconstruction kernels: the batch's buffers are idle after this
+    g.executed = true;
     d->ev_used = prof ? ei : 0;
     return H264MI_OK;
 }
@@ -1091,6 +1144,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
 extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
     if (!d) return H264MI_EINVAL;
     GUARD(d);
+    Stage &g = d->stage[d->exec];
     for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(d->ent_stream[i]));
     HIP_TRY(hipStreamSynchronize(d->rec_stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
@@ -1110,21 +1164,21 @@ extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
         d->k_ms[4] = tot;
     }
     if (getenv("H264MI_SLICE_STATS")) { // diagnostics: per-slice entropy time (100 MHz ticks) and bin count (MI_ENT_STATS builds)
-        for (int i = 0; i < d->n_slices && i < 64; i++)
-            fprintf(stderr, "slice %d type %d bytes %u mbs %u us %.1f bins %u | Mclk fill %.1f syntax %.1f residual %.1f writeout %.1f\n", i, d->h_slices[i].slice_type,
-                    d->h_slices[i].rbsp_size, d->h_status[8 * i + 1], d->h_status[8 * i + 2] * 0.01, d->h_status[8 * i + 3], d->h_status[8 * i + 4] * 16e-6,
-                    d->h_status[8 * i + 5] * 16e-6, d->h_status[8 * i + 6] * 16e-6, d->h_status[8 * i + 7] * 16e-6);
-        fprintf(stderr, "last slice type %d bytes %u mbs %u us %.1f bins %u\n", d->h_slices[d->n_slices - 1].slice_type, d->h_slices[d->n_slices - 1].rbsp_size,
-                d->h_status[8 * (d->n_slices - 1) + 1], d->h_status[8 * (d->n_slices - 1) + 2] * 0.01, d->h_status[8 * (d->n_slices - 1) + 3]);
+        for (int i = 0; i < g.n_slices && i < 64; i++)
+            fprintf(stderr, "slice %d type %d bytes %u mbs %u us %.1f bins %u | Mclk fill %.1f syntax %.1f residual %.1f writeout %.1f\n", i, g.h_slices[i].slice_type,
+                    g.h_slices[i].rbsp_size, g.h_status[8 * i + 1], g.h_status[8 * i + 2] * 0.01, g.h_status[8 * i + 3], g.h_status[8 * i + 4] * 16e-6,
+                    g.h_status[8 * i + 5] * 16e-6, g.h_status[8 * i + 6] * 16e-6, g.h_status[8 * i + 7] * 16e-6);
+        fprintf(stderr, "last slice type %d bytes %u mbs %u us %.1f bins %u\n", g.h_slices[g.n_slices - 1].slice_type, g.h_slices[g.n_slices - 1].rbsp_size,
+                g.h_status[8 * (g.n_slices - 1) + 1], g.h_status[8 * (g.n_slices - 1) + 2] * 0.01, g.h_status[8 * (g.n_slices - 1) + 3]);
     }
     int result = H264MI_OK;
-    for (int i = 0; i < d->n_slices; i++)
-        if (d->h_status[8 * i]) {
-            const SliceDesc &sd = d->h_slices[i];
-            StreamState &s = d->st[d->h_pics[sd.pic_idx].stream];
+    for (int i = 0; i < g.n_slices; i++)
+        if (g.h_status[8 * i]) {
+            const SliceDesc &sd = g.h_slices[i];
+            StreamState &s = d->st[g.h_pics[sd.pic_idx].stream];
             if (result == H264MI_OK)
-                set_error("entropy kernel: slice %d (picture %u, stream %u) failed with code %u after %u macroblocks", i, sd.pic_idx, d->h_pics[sd.pic_idx].stream,
-                          d->h_status[8 * i], d->h_status[8 * i + 1]);
+                set_error("entropy kernel: slice %d (picture %u, stream %u) failed with code %u after %u macroblocks", i, sd.pic_idx, g.h_pics[sd.pic_idx].stream,
+                          g.h_status[8 * i], g.h_status[8 * i + 1]);
             if (s.status == H264MI_OK) { // the stream's pictures from here on are damaged: nothing is decodable before its next IDR
                 s.status = H264MI_EDECODE;
                 for (auto &sl : s.slots) sl.ref = 0;
@@ -1159,16 +1213,16 @@ extern "C" int32_t h264mi_last_launch_times(h264mi_decoder *d, int32_t kernel, f
 
 extern "C" int32_t h264mi_stream_frame_count(h264mi_decoder *d, int32_t stream, int32_t *n) {
     if (!d || !n || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
-    *n = static_cast<int32_t>(d->st[stream].out.size());
+    *n = static_cast<int32_t>(d->stage[d->exec].out[stream].size());
     return H264MI_OK;
 }
 
 static int frame_ptrs(h264mi_decoder *d, int stream, int frame, uint8_t **y, const OutFrame **of) {
     if (!d || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
-    StreamState &s = d->st[stream];
-    if (frame < 0 || frame >= static_cast<int>(s.out.size())) return H264MI_EINVAL;
-    *of = &s.out[frame];
-    *y = d->d_frames + (static_cast<size_t>(stream) * d->n_slots + s.out[frame].slot) * d->slot_bytes;
+    const std::vector<OutFrame> &out = d->stage[d->exec].out[stream];
+    if (frame < 0 || frame >= static_cast<int>(out.size())) return H264MI_EINVAL;
+    *of = &out[frame];
+    *y = d->d_frames + (static_cast<size_t>(stream) * d->n_slots + out[frame].slot) * d->slot_bytes;
     return H264MI_OK;
 }
 
@@ -1249,8 +1303,9 @@ extern "C" int32_t h264mi_frame_pack_device(h264mi_decoder *d, int32_t stream, i
 extern "C" int32_t h264mi_frame_read_mbrecs(h264mi_decoder *d, int32_t stream, int32_t frame, uint8_t *rec, size_t cap) {
     if (!d || !rec || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
     GUARD(d);
-    for (int i = 0; i < d->n_pics; i++) {
-        const PicDesc &pd = d->h_pics[i];
+    Stage &g = d->stage[d->exec];
+    for (int i = 0; i < g.n_pics; i++) {
+        const PicDesc &pd = g.h_pics[i];
         if (static_cast<int>(pd.stream) == stream && static_cast<int>(pd.order) == frame) {
             size_t n = static_cast<size_t>(pd.wmb) * pd.hmb * sizeof(MbRec);
             if (cap < n) return H264MI_ECAPACITY;

@@ -324,3 +324,25 @@ def test_gpu_repeated_execute_with_marking_inside_the_batch(H, sg):
     dec.sync()
     assert np.array_equal(dec.read_frames(0, crop=False), rec[7:])
     dec.close()
+
+
+def test_gpu_prepare_overlaps_execute(H, sg):
+    """Two staging sets: h264mi_batch_prepare(n + 1) may run while batch n executes; sync and the frame accessors keep
+    referring to the batch executed last, and its frames stay intact until the prepare after next."""
+    a = sg.encode(width=176, height=144, frames=4, idr_period=0, profile_idc=77, cabac=1, seed=61)
+    b = sg.encode(width=176, height=144, frames=3, idr_period=0, profile_idc=66, cabac=0, seed=62)
+    c = sg.encode(width=176, height=144, frames=4, idr_period=0, profile_idc=100, cabac=1, transform8x8=1, seed=63)
+    dec = H.Decoder(max_streams=1, max_width=176, max_height=144, max_frames_per_batch=4)
+    dec.prepare([a[0]])
+    dec.execute()            # batch A in flight
+    dec.prepare([b[0]])      # host parse + H2D of batch B meanwhile
+    dec.sync()
+    assert dec.frame_count(0) == 4 and np.array_equal(dec.read_frames(0, crop=False), a[1])  # still batch A
+    dec.execute()            # batch B
+    dec.prepare([c[0]])      # reuses A's staging set; A's frames may go, B's must stay
+    dec.sync()
+    assert dec.frame_count(0) == 3 and np.array_equal(dec.read_frames(0, crop=False), b[1])
+    dec.execute()
+    dec.sync()
+    assert np.array_equal(dec.read_frames(0, crop=False), c[1])
+    dec.close()
