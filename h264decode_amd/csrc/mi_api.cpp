@@ -171,7 +171,6 @@ struct h264mi_decoder {
     Stage stage[MI_STAGES];
     int prep = 0;  // stage of the most recent h264mi_batch_prepare
     int exec = 0;  // stage of the most recent h264mi_batch_execute: what sync and the frame accessors refer to
-    hipStream_t up_stream = nullptr; // H2D copies (a stream of their own: the caller's stream is busy with the previous batch)
     size_t bits_cap = 0;
     uint32_t *d_toprows[MI_SETS] = {}; // entropy kernels' row-above neighbour state: 48 B per MB column per slice
     int slices_cap = 0, pics_cap = 0;
@@ -276,7 +275,6 @@ static void free_all(h264mi_decoder *d) {
         if (g.ev_upload) hipEventDestroy(g.ev_upload);
         if (g.ev_done) hipEventDestroy(g.ev_done);
     }
-    if (d->up_stream) hipStreamDestroy(d->up_stream);
     for (int i = 0; i < MI_SETS; i++) {
         if (d->d_mbrec[i]) hipFree(d->d_mbrec[i]);
         if (d->d_coef[i]) hipFree(d->d_coef[i]);
@@ -342,7 +340,6 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
         TRY_ALLOC(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         d->own_stream = true;
     }
-    TRY_ALLOC(hipStreamCreateWithFlags(&d->up_stream, hipStreamNonBlocking));
     for (Stage &g : d->stage) {
         TRY_ALLOC(hipMalloc(&g.d_bits, d->bits_cap));
         TRY_ALLOC(hipHostMalloc(&g.h_bits, d->bits_cap));
@@ -440,7 +437,6 @@ extern "C" int32_t h264mi_decoder_destroy(h264mi_decoder *d) {
     GUARD(d);
     for (int i = 0; i < 2; i++) hipStreamSynchronize(d->ent_stream[i]);
     hipStreamSynchronize(d->rec_stream);
-    hipStreamSynchronize(d->up_stream);
     hipStreamSynchronize(d->stream);
     free_all(d);
     delete d;
@@ -1041,23 +1037,27 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
         g.wave_inter_off.push_back(pos);
         for (uint32_t p : g.waves_inter[w]) g.h_lists[pos++] = p;
     }
-    // uploads
+    // Uploads go to the entropy stream the next execute will use: in order with that pass's entropy kernel, and not behind
+    // the batch that is still executing (the caller's stream waits for its reconstruction).  No stream of their own: the
+    // runtime multiplexes streams onto 4 hardware queues by default, and a fifth stream ended up sharing a queue with one of
+    // the kernel streams, which serialised entropy decoding and reconstruction of consecutive passes.
+    hipStream_t up = d->ent_stream[d->pass & 1];
     if (g.n_slices) {
         size_t nbytes = std::min(d->bits_cap, ((g.bits_used + 15) & ~static_cast<size_t>(15)) + 4096);
         memset(g.h_bits + g.bits_used, 0, nbytes - g.bits_used);
-        HIP_TRY(hipMemcpyAsync(g.d_bits, g.h_bits, nbytes, hipMemcpyHostToDevice, d->up_stream));
-        HIP_TRY(hipMemcpyAsync(g.d_slices, g.h_slices, sizeof(SliceDesc) * g.n_slices, hipMemcpyHostToDevice, d->up_stream));
-        HIP_TRY(hipMemcpyAsync(g.d_pics, g.h_pics, sizeof(PicDesc) * g.n_pics, hipMemcpyHostToDevice, d->up_stream));
-        HIP_TRY(hipMemcpyAsync(g.d_lists, g.h_lists, sizeof(uint32_t) * pos, hipMemcpyHostToDevice, d->up_stream));
+        HIP_TRY(hipMemcpyAsync(g.d_bits, g.h_bits, nbytes, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemcpyAsync(g.d_slices, g.h_slices, sizeof(SliceDesc) * g.n_slices, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemcpyAsync(g.d_pics, g.h_pics, sizeof(PicDesc) * g.n_pics, hipMemcpyHostToDevice, up));
+        HIP_TRY(hipMemcpyAsync(g.d_lists, g.h_lists, sizeof(uint32_t) * pos, hipMemcpyHostToDevice, up));
     }
     if (d->tables_dirty) {
         // a new PPS added a LevelScale set: the table only grows, so the batch still executing keeps seeing its own sets.
         // (h_tables is pinned and rewritten only by the next prepare, which cannot start its copy before this one is done:
         // same stream.)
-        HIP_TRY(hipMemcpyAsync(d->d_tables, d->h_tables, sizeof(DevTables), hipMemcpyHostToDevice, d->up_stream));
+        HIP_TRY(hipMemcpyAsync(d->d_tables, d->h_tables, sizeof(DevTables), hipMemcpyHostToDevice, up));
         d->tables_dirty = false;
     }
-    HIP_TRY(hipEventRecord(g.ev_upload, d->up_stream));
+    HIP_TRY(hipEventRecord(g.ev_upload, up));
     g.info.n_frames = g.n_pics, g.info.n_slices = g.n_slices, g.info.bitstream_bytes = static_cast<int64_t>(g.bits_used);
     g.info.host_prepare_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (info) *info = g.info;
