@@ -7,3 +7,7 @@ from ._lib import H264MIError, build, lib, load  # noqa: F401
 from .h264 import (  # noqa: F401
     NALU_TYPE_NAMES, PPS, SPS, Decoder, NalUnit, NewNalUnit, NewPPS, NewSPS, NewSliceContext, SliceContext, SliceHeader,
     VideoStream, read_nal_units, AccessUnitSplitter, H264Reader, handleConnection, ByteStreamReader, BatchServer)
+from .mbtype import (  # noqa: F401
+    MB_TYPE_INFERRED, ISliceMbType, SISliceMbType, PSliceMbType, BSliceMbType, MbTypeName, MbPartPredMode, NumMbPart, PicWidthInMbs,
+    PicHeightInMapUnits, PicSizeInMapUnits, FrameHeightInMbs, PicHeightInMbs, PicSizeInMbs, SubWidthC, SubHeightC, MbWidthC, MbHeightC,
+    MbaffFrameFlag, CodedBlockPatternLuma, CodedBlockPatternChroma, Clip3, Clip1y, Clipc, SliceQPy, PreCtxState, SliceData, NewSliceData, MbPred)

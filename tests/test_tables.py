@@ -147,3 +147,48 @@ def test_idct_properties(oracle_mod):
         fn(b.ctypes.data, rb.ctypes.data)
         fn((a + b).astype(np.int16).ctypes.data, rab.ctypes.data)
         assert np.abs(rab.astype(int) - ra - rb).max() <= 1
+
+
+def test_mb_type_names_against_the_reference(H):
+    """Tables 7-11 / 7-13 / 7-14 as exported by h264decode_amd (MbTypeName, MbPartPredMode, size helpers) against the
+    reference's own name maps (h264/mbType.go:8-72, read as text in the build container only).  Known reference slips:
+    P mb_type 1 is spelled "P_L0_16x8" there (Table 7-13: P_L0_L0_16x8) and B mb_type 18 "B_Bi_l1_16x8"."""
+    if not os.path.isdir(REF):
+        pytest.skip("reference tree not present (GPU box)")
+    src = open(os.path.join(REF, "mbType.go")).read()
+
+    def table(name):
+        body = src[src.index(name + " = map[int]string{"):]
+        body = body[:body.index("}")]
+        out = {}
+        for k, v in re.findall(r'(\w+):\s*"([^"]+)"', body):
+            out[H.MB_TYPE_INFERRED if k == "MB_TYPE_INFERRED" else int(k)] = v
+        return out
+    assert table("ISliceMbType") == H.ISliceMbType
+    ref_p, ref_b = table("PSliceMbType"), table("BSliceMbType")
+    assert {k: v for k, v in ref_p.items() if k != 1} == {k: v for k, v in H.PSliceMbType.items() if k != 1}
+    assert ref_p[1] == "P_L0_16x8" and H.PSliceMbType[1] == "P_L0_L0_16x8"
+    assert {k: v for k, v in ref_b.items() if k != 18} == {k: v for k, v in H.BSliceMbType.items() if k != 18}
+    assert ref_b[18].lower() == H.BSliceMbType[18].lower()
+    # MbTypeName / MbPartPredMode (h264/mbType.go:75-163; spec-correct where the reference is not: App. A32)
+    assert H.MbTypeName("I", 0) == "I_NxN" and H.MbTypeName("I", 25) == "I_PCM" and H.MbTypeName("P", 5) == "I_NxN"
+    assert H.MbTypeName("P", H.MB_TYPE_INFERRED) == "P_Skip" and H.MbTypeName("B", 23 + 25) == "I_PCM" and H.MbTypeName("X", 0) == "NaSliceType"
+    class D:  # noqa: E306
+        TransformSize8x8Flag = True
+        CodedBlockPattern = 0x2F
+    assert H.MbPartPredMode(D, "I", 0, 0) == "Intra_8x8" and H.MbPartPredMode(None, "I", 0, 0) == "Intra_4x4"
+    assert H.MbPartPredMode(None, "I", 7, 0) == "Intra_16x16" and H.MbPartPredMode(None, "P", 1, 1) == "Pred_L0"
+    assert H.MbPartPredMode(None, "P", 3, 0) == "NaPSliceMode" and H.MbPartPredMode(None, "B", 0, 0) == "Direct"
+    assert [H.MbPartPredMode(None, "B", t, 0) for t in (1, 2, 3)] == ["Pred_L0", "Pred_L1", "BiPred"]
+    assert (H.MbPartPredMode(None, "B", 12, 0), H.MbPartPredMode(None, "B", 12, 1)) == ("Pred_L0", "BiPred")   # B_L0_Bi_16x8
+    assert (H.MbPartPredMode(None, "B", 19, 0), H.MbPartPredMode(None, "B", 19, 1)) == ("BiPred", "Pred_L1")   # B_Bi_L1_8x16
+    assert H.NumMbPart("B_L0_Bi_16x8") == 2 and H.NumMbPart("P_8x8") == 4 and H.NumMbPart("P_L0_16x16") == 1
+    assert (H.CodedBlockPatternLuma(D), H.CodedBlockPatternChroma(D)) == (15, 2)
+    # size helpers (h264/slice.go:159-176) on the hand-analysed third-party SPS of SURVEY App. C
+    sps = H.NewSPS(bytes.fromhex("640028ac2b40a0fd00f1226a"))
+    class Hdr:  # noqa: E306
+        FieldPic = 0
+    assert (H.PicWidthInMbs(sps), H.PicHeightInMapUnits(sps), H.PicSizeInMapUnits(sps), H.FrameHeightInMbs(sps)) == (20, 15, 300, 15)
+    assert (H.PicHeightInMbs(sps, Hdr), H.PicSizeInMbs(sps, Hdr), H.SubWidthC(sps), H.SubHeightC(sps), H.MbWidthC(sps), H.MbHeightC(sps)) == (15, 300, 2, 2, 8, 8)
+    assert H.MbaffFrameFlag(sps, Hdr) == 0 and H.Clip3(0, 51, 77) == 51 and H.Clip1y(300) == 255 and H.Clipc(-4) == 0
+    assert H.PreCtxState(-46, 127, 28) == max(1, min(126, ((-46 * 28) >> 4) + 127))
