@@ -161,9 +161,8 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
     int lane_v = tid & 63;
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
-    const FramePool *pool = &pools[pd->stream];
     const int W = wmb * 16, H = hmb * 16, Wc = W / 2; // the picture's own geometry
-    g8 *const py = (g8 *)(pool->base + static_cast<uint64_t>(pd->slot) * pool->slot_bytes); // luma plane; Cb at +W*H, Cr at +W*H*5/4
+    g8 *const py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes); // luma plane; Cb at +W*H, Cr at +W*H*5/4
     const uint32_t cb_off = static_cast<uint32_t>(W) * H, cr_off = cb_off + cb_off / 4;
     for (int i = tid; i < 96; i += nthreads) sh.prog[i] = 0, sh.cons[i] = 0;
     for (int i = tid; i < 52; i += nthreads) {

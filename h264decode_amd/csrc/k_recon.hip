@@ -229,11 +229,11 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     if (lane < 32) reinterpret_cast<uint32_t *>(&sh.rec)[lane] = rv;
     __syncthreads();
     const MbRec *rec = &sh.rec;
-    const FramePool *pool = &pools[pd->stream];
-    const int W = wmb * 16, H = hmb * 16; // the picture's own geometry (the pool's follows the latest SPS of the stream)
-    const int max_slot = static_cast<int>(pool->n_slots) - 1;
+    const int W = wmb * 16, H = hmb * 16; // the picture's own geometry
+    const int max_slot = static_cast<int>(pd->n_slots) - 1;
+    const uint64_t pool_slot_bytes = pd->slot_bytes;
     const int mbx = mb % wmb, mby = mb / wmb;
-    const uint8_t *pool_base = reinterpret_cast<const uint8_t *>(pool->base);
+    const uint8_t *pool_base = reinterpret_cast<const uint8_t *>(pd->pool_base);
     const size_t ysz = static_cast<size_t>(W) * H;
     // coefficient blocks (packed in the pool, MbRec::coef_off / coef_mask): issue the loads now, scatter them into the dense LDS
     // layout after the window loads have been issued
@@ -258,7 +258,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
                             rec->refslot[0] >= 0;
         const int uniform = inside && __all(same);
         if (uniform) {
-            const uint8_t *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rec->refslot[0]), max_slot)) * pool->slot_bytes;
+            const uint8_t *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rec->refslot[0]), max_slot)) * pool_slot_bytes;
             ox = x0 & 3;
             const int xa = x0 - ox;
             for (int i = lane; i < 21 * 6; i += 64) {
@@ -279,7 +279,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
                 int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
                 int x = mbx * 16 + (b & 3) * 4 + (mvx >> 2) - 2 + wx, y = mby * 16 + (b >> 2) * 4 + (mvy >> 2) - 2 + wy;
                 x = min(max(x, 0), W - 1), y = min(max(y, 0), H - 1);
-                const uint8_t *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool->slot_bytes;
+                const uint8_t *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool_slot_bytes;
                 sh.win_y[b][wy][wx] = ref[static_cast<size_t>(y) * W + x];
             }
             for (int i = lane; i < 2 * 16 * 9; i += 64) {
@@ -288,7 +288,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
                 int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
                 int x = mbx * 8 + (b & 3) * 2 + (mvx >> 3) + wx, y = mby * 8 + (b >> 2) * 2 + (mvy >> 3) + wy;
                 x = min(max(x, 0), W / 2 - 1), y = min(max(y, 0), H / 2 - 1);
-                const uint8_t *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool->slot_bytes + ysz + static_cast<size_t>(c) * (ysz / 4);
+                const uint8_t *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool_slot_bytes + ysz + static_cast<size_t>(c) * (ysz / 4);
                 sh.win_c[c][b][wy][wx] = ref[static_cast<size_t>(y) * (W / 2) + x];
             }
         }
@@ -305,16 +305,20 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     __syncthreads();
     const SliceDesc *sd = &slices[rec->slice_idx];
     const int wp = pd->weighted_pred;
-    uint8_t *dst_base = const_cast<uint8_t *>(pool_base) + static_cast<size_t>(pd->slot) * pool->slot_bytes;
+    uint8_t *dst_base = const_cast<uint8_t *>(pool_base) + static_cast<size_t>(pd->slot) * pool_slot_bytes;
     // ---- luma: lane = (4x4 block, row) -> 4 samples ----
     {
         const int b = lane >> 2, r = lane & 3;
-        const int mvx = rec->mv[b][0], mvy = rec->mv[b][1], fx = mvx & 3, fy = mvy & 3;
         const int uni = sh.uniform;
+        int pv[4];
+        // The interpolation is written once and instantiated twice: for motion-uniform macroblocks (85 % of them) the
+        // fractional position is a SCALAR (readfirstlane), so the class switch below compiles to scalar branches instead of
+        // five exec-masked regions; the general instance keeps per-lane positions.
+        auto interpolate = [&](const int fx, const int fy, const bool U) {
         // row j of this lane's 9x9 window: per-block window (stride 12) or the shared 21x21 one (stride 24, byte offset ox + 4*bx)
-        const int boff = uni ? ox + (b & 3) * 4 : 0;
-        const uint8_t *wbase = uni ? &sh.win16[(b >> 2) * 4 + r][(boff >> 2) * 4] : &sh.win_y[b][r][0];
-        const int wstride = uni ? 24 : 12, sh8 = (boff & 3) * 8;
+        const int boff = U ? ox + (b & 3) * 4 : 0;
+        const uint8_t *wbase = U ? &sh.win16[(b >> 2) * 4 + r][(boff >> 2) * 4] : &sh.win_y[b][r][0];
+        const int wstride = U ? 24 : 12, sh8 = (boff & 3) * 8;
         auto load_row = [&](int j, int (&q)[9]) {
             const uint32_t *row = reinterpret_cast<const uint32_t *>(wbase + j * wstride);
             uint64_t lo = row[0] | (static_cast<uint64_t>(row[1]) << 32), hi = row[1] | (static_cast<uint64_t>(row[2]) << 32);
@@ -327,7 +331,6 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         // needs (motion-uniform macroblocks take one branch for the whole wavefront):
         //   0 integer | 1 horizontal only (b) | 2 vertical only (h) | 3 diagonal quarter (b|s with h|m) | 4 around the centre (j)
         const int cls = (fx | fy) == 0 ? 0 : (fy == 0 ? 1 : (fx == 0 ? 2 : ((fx & fy & 1) ? 3 : 4)));
-        int pv[4];
         if (cls == 0) {
             int q[9];
             load_row(2, q);
@@ -382,6 +385,14 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
                     pv[i] = v;
                 }
             }
+        }
+        };
+        {
+            const int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
+            if (uni)
+                interpolate(__builtin_amdgcn_readfirstlane(mvx & 3), __builtin_amdgcn_readfirstlane(mvy & 3), true);
+            else
+                interpolate(mvx & 3, mvy & 3, false);
         }
         const int refidx = rec->ref[((b >> 3) << 1) | ((b & 3) >> 1)];
         uint32_t packed = 0;
@@ -728,9 +739,8 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
     const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6;
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
-    const FramePool *pool = &pools[pd->stream];
     const int W = wmb * 16, H = hmb * 16; // the picture's own geometry
-    uint8_t *py = reinterpret_cast<uint8_t *>(pool->base) + static_cast<size_t>(pd->slot) * pool->slot_bytes;
+    uint8_t *py = reinterpret_cast<uint8_t *>(pd->pool_base) + static_cast<size_t>(pd->slot) * pd->slot_bytes;
     uint8_t *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
     { // LevelScale tables of this picture's PPS -> LDS (2688 bytes)
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&tab->scaling[pd->scaling_set]);

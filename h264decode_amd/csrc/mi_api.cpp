@@ -791,6 +791,7 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         PicDesc &pd = g.h_pics[s.cur_pic];
         memset(&pd, 0, sizeof(pd));
         pd.stream = si, pd.slot = slot, pd.wmb = wmb, pd.hmb = hmb;
+        pd.pool_base = d->h_pools[si].base, pd.slot_bytes = d->slot_bytes, pd.n_slots = static_cast<uint32_t>(d->n_slots);
         pd.mb_base = g.mb_used;
         g.mb_used += static_cast<uint64_t>(wmb) * hmb;
         pd.first_slice = g.n_slices;

@@ -95,6 +95,11 @@ typedef struct {
     uint8_t is_intra_only; /* all slices are I slices */
     uint8_t scaling_set;   /* index into DevTables.level_scale sets */
     uint32_t order;        /* ordinal of this picture within its stream in this batch */
+    /* the stream's frame pool, copied here so that a kernel needs ONE descriptor load per picture (a workgroup of K4 lives
+     * for one macroblock: three dependent scalar loads -- list, picture, pool -- were 8 % of its lifetime) */
+    uint32_t n_slots;
+    uint64_t pool_base;    /* device address of slot 0 */
+    uint64_t slot_bytes;
 } PicDesc;
 
 typedef struct {
