@@ -798,20 +798,31 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
 }
 
 // ================================================================== K6: crop + pack to tight I420
-extern "C" __global__ void k_pack(const uint8_t *src_y, const uint8_t *src_cb, const uint8_t *src_cr, int pitch, int x0, int y0, int w, int h, uint8_t *dst) {
-    const int total = w * h * 3 / 2;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        uint8_t v;
-        if (i < w * h) {
-            int y = i / w, x = i - y * w;
-            v = src_y[static_cast<size_t>(y + y0) * pitch + x + x0];
+// One launch packs any number of frames (a whole batch): blockIdx.x = frame, blockIdx.y = a chunk of its rows (luma rows,
+// then the Cb rows, then the Cr rows).  A thread moves 16 bytes when source and destination rows are 16-byte aligned
+// (1080p: always), single bytes otherwise.
+extern "C" __global__ void __launch_bounds__(256) k_pack(const PackDesc *descs, uint8_t *dst, int rows_per_block) {
+    const PackDesc pd = descs[blockIdx.x];
+    const int w = static_cast<int>(pd.w), h = static_cast<int>(pd.h), W = static_cast<int>(pd.W), H = static_cast<int>(pd.H);
+    const int nrows = 2 * h; // h luma rows + h/2 + h/2 chroma rows
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(pd.src);
+    uint8_t *out = dst + pd.dst_off;
+    const int r0 = static_cast<int>(blockIdx.y) * rows_per_block, r1 = min(r0 + rows_per_block, nrows);
+    for (int r = r0; r < r1; r++) {
+        const uint8_t *s;
+        uint8_t *d;
+        int n;
+        if (r < h) {
+            s = src + static_cast<size_t>(r + pd.y0) * W + pd.x0, d = out + static_cast<size_t>(r) * w, n = w;
         } else {
-            int k = i - w * h, cw = w / 2, ch = h / 2;
-            const uint8_t *src = k < cw * ch ? src_cb : src_cr;
-            if (k >= cw * ch) k -= cw * ch;
-            int y = k / cw, x = k - y * cw;
-            v = src[static_cast<size_t>(y + y0 / 2) * (pitch / 2) + x + x0 / 2];
+            const int c = r - h >= h / 2, rc = r - h - c * (h / 2);
+            s = src + static_cast<size_t>(W) * H + static_cast<size_t>(c) * (W / 2) * (H / 2) + static_cast<size_t>(rc + pd.y0 / 2) * (W / 2) + pd.x0 / 2;
+            d = out + static_cast<size_t>(w) * h + static_cast<size_t>(c) * (w / 2) * (h / 2) + static_cast<size_t>(rc) * (w / 2), n = w / 2;
         }
-        dst[i] = v;
+        if ((((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) && (n & 15) == 0) {
+            for (int i = static_cast<int>(threadIdx.x) * 16; i < n; i += 256 * 16) *reinterpret_cast<uint4 *>(d + i) = *reinterpret_cast<const uint4 *>(s + i);
+        } else {
+            for (int i = static_cast<int>(threadIdx.x); i < n; i += 256) d[i] = s[i];
+        }
     }
 }

@@ -201,6 +201,8 @@ struct h264mi_decoder {
     std::vector<int> ev_kind;
     size_t ev_used = 0;
     double k_ms[5] = {0, 0, 0, 0, 0};
+    PackDesc *h_pack = nullptr, *d_pack = nullptr; // K6 descriptor table
+    size_t pack_cap = 0;
     std::vector<float> launch_ms[4]; // duration of every launch of the last profiled pass, per kernel
 };
 
@@ -288,6 +290,8 @@ static void free_all(h264mi_decoder *d) {
     if (d->rec_stream) hipStreamDestroy(d->rec_stream);
     if (d->ev_user) hipEventDestroy(d->ev_user);
     if (d->d_pools) hipFree(d->d_pools);
+    if (d->h_pack) hipHostFree(d->h_pack);
+    if (d->d_pack) hipFree(d->d_pack);
     if (d->d_frames) hipFree(d->d_frames);
     if (d->d_tables) hipFree(d->d_tables);
     if (d->h_tables) hipHostFree(d->h_tables);
@@ -1283,22 +1287,57 @@ extern "C" int32_t h264mi_frame_read(h264mi_decoder *d, int32_t stream, int32_t 
     return H264MI_OK;
 }
 
-extern "C" int32_t h264mi_frame_pack_device(h264mi_decoder *d, int32_t stream, int32_t frame, void *dst, size_t cap) {
-    uint8_t *p;
-    const OutFrame *of;
-    int x0, y0, w, h;
-    int r = frame_ptrs(d, stream, frame, &p, &of);
-    if (r != H264MI_OK) return r;
-    if (!dst) return H264MI_EINVAL;
+// K6 over a list of frames: descriptors go through a small pinned table, one launch packs them all.
+static int pack_frames(h264mi_decoder *d, const std::vector<std::pair<int, int>> &frames /* (stream, frame) */, void *dst, size_t cap, size_t *bytes) {
     GUARD(d);
-    const int W = of->wmb * 16, H = of->hmb * 16;
-    crop_rect(of, 1, &x0, &y0, &w, &h);
-    if (cap < static_cast<size_t>(w) * h * 3 / 2) return H264MI_ECAPACITY;
-    const uint8_t *cb = p + static_cast<size_t>(W) * H, *cr = cb + static_cast<size_t>(W) * H / 4;
-    int total = w * h * 3 / 2;
-    hipLaunchKernelGGL(k_pack, dim3(std::min((total + 255) / 256, 4096)), dim3(256), 0, d->stream, p, cb, cr, W, x0, y0, w, h, static_cast<uint8_t *>(dst));
+    if (frames.size() > d->pack_cap) {
+        if (d->h_pack) hipHostFree(d->h_pack);
+        if (d->d_pack) hipFree(d->d_pack);
+        d->h_pack = nullptr, d->d_pack = nullptr;
+        d->pack_cap = std::max<size_t>(frames.size(), 64);
+        HIP_TRY(hipHostMalloc(&d->h_pack, sizeof(PackDesc) * d->pack_cap));
+        HIP_TRY(hipMalloc(&d->d_pack, sizeof(PackDesc) * d->pack_cap));
+    }
+    HIP_TRY(hipStreamSynchronize(d->stream)); // the table of the previous call is no longer in flight
+    size_t off = 0;
+    int hmax = 0;
+    for (size_t i = 0; i < frames.size(); i++) {
+        uint8_t *p;
+        const OutFrame *of;
+        int x0, y0, w, h;
+        int r = frame_ptrs(d, frames[i].first, frames[i].second, &p, &of);
+        if (r != H264MI_OK) return r;
+        crop_rect(of, 1, &x0, &y0, &w, &h);
+        PackDesc &pk = d->h_pack[i];
+        pk.src = reinterpret_cast<uint64_t>(p), pk.dst_off = off;
+        pk.W = of->wmb * 16, pk.H = of->hmb * 16, pk.x0 = x0, pk.y0 = y0, pk.w = w, pk.h = h;
+        off += static_cast<size_t>(w) * h * 3 / 2;
+        hmax = std::max(hmax, h);
+    }
+    if (bytes) *bytes = off;
+    if (off > cap) return H264MI_ECAPACITY;
+    if (frames.empty()) return H264MI_OK;
+    HIP_TRY(hipMemcpyAsync(d->d_pack, d->h_pack, sizeof(PackDesc) * frames.size(), hipMemcpyHostToDevice, d->stream));
+    const int rows_per_block = 32;
+    hipLaunchKernelGGL(k_pack, dim3(static_cast<uint32_t>(frames.size()), (2 * hmax + rows_per_block - 1) / rows_per_block), dim3(256), 0, d->stream, d->d_pack,
+                       static_cast<uint8_t *>(dst), rows_per_block);
     HIP_TRY(hipGetLastError());
     return H264MI_OK;
+}
+
+extern "C" int32_t h264mi_frame_pack_device(h264mi_decoder *d, int32_t stream, int32_t frame, void *dst, size_t cap) {
+    if (!d || !dst) return H264MI_EINVAL;
+    return pack_frames(d, {{stream, frame}}, dst, cap, nullptr);
+}
+
+extern "C" int32_t h264mi_batch_pack_device(h264mi_decoder *d, int32_t stream, void *dst, size_t cap, size_t *bytes) {
+    if (!d || !dst || stream < -1 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
+    std::vector<std::pair<int, int>> frames;
+    const Stage &g = d->stage[d->exec];
+    for (int si = 0; si < static_cast<int>(g.out.size()); si++)
+        if (stream < 0 || stream == si)
+            for (int f = 0; f < static_cast<int>(g.out[si].size()); f++) frames.push_back({si, f});
+    return pack_frames(d, frames, dst, cap, bytes);
 }
 
 extern "C" int32_t h264mi_frame_read_mbrecs(h264mi_decoder *d, int32_t stream, int32_t frame, uint8_t *rec, size_t cap) {

@@ -52,8 +52,13 @@ static inline void mi_deblock_plan(int wmb, int hmb, int *nwaves, int *ring, int
     }
     *nwaves = 1, *ring = 1, *ring_last = w1, *last_bufs = 2; // 2 x 512 columns x 96 bytes + one wavefront always fit
 }
-// K6: crop + tight pack of one frame into I420
-extern "C" __global__ void k_pack(const uint8_t *src_y, const uint8_t *src_cb, const uint8_t *src_cr, int pitch, int x0, int y0, int w, int h, uint8_t *dst);
+// K6: crop + tight pack of a list of frames into I420; grid = (frames, ceil(2 * h_max / rows_per_block)), block = 256
+typedef struct {
+    uint64_t src;     // Y plane of the frame (coded size W x H; Cb at + W*H, Cr at + W*H*5/4)
+    uint64_t dst_off; // byte offset of the packed frame in the destination buffer
+    uint32_t W, H, x0, y0, w, h;
+} PackDesc;
+extern "C" __global__ void k_pack(const PackDesc *descs, uint8_t *dst, int rows_per_block);
 
 #ifndef MI_INTRA_WAVES
 #define MI_INTRA_WAVES 12 /* 768 threads: 170 VGPRs per wavefront (16 wavefronts would cap them at 128 and spill) */

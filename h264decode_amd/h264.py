@@ -292,6 +292,13 @@ class Decoder:
             out.append(b if size is None else b[:size])
         return np.stack(out) if out else np.zeros((0, 0), np.uint8)
 
+    def pack_batch(self, dst_ptr, cap, stream=-1):
+        """K6 in one launch: every frame of the last executed batch (of one stream, or of all streams) cropped and packed
+        back to back as tight I420 into the DEVICE buffer at dst_ptr.  Returns the number of bytes."""
+        n = ctypes.c_size_t(0)
+        check(self._L.h264mi_batch_pack_device(self._h, stream, dst_ptr, cap, ctypes.byref(n)))
+        return n.value
+
     def read_mbrecs(self, stream, frame, n_mbs):
         buf = np.zeros(n_mbs * 128, dtype=np.uint8)
         check(self._L.h264mi_frame_read_mbrecs(self._h, stream, frame, buf.ctypes.data, buf.nbytes))

@@ -209,6 +209,9 @@ int32_t h264mi_frame_get_info(h264mi_decoder *dec, int32_t stream, int32_t frame
 int32_t h264mi_frame_read(h264mi_decoder *dec, int32_t stream, int32_t frame, int32_t crop, uint8_t *dst, size_t cap);
 /* Cropped, tightly packed I420 copy on the device (K6): dst is a DEVICE pointer. */
 int32_t h264mi_frame_pack_device(h264mi_decoder *dec, int32_t stream, int32_t frame, void *dst_device, size_t cap);
+/* The same for every frame of the last executed batch in ONE launch: frames of stream `stream` (or of all streams when
+ * stream = -1, stream-major) in decoding order, back to back.  *bytes receives the total size (also on H264MI_ECAPACITY). */
+int32_t h264mi_batch_pack_device(h264mi_decoder *dec, int32_t stream, void *dst_device, size_t cap, size_t *bytes);
 
 /* Debug / test access to the intermediate macroblock records of a frame (host copy).
  * rec: 128 bytes per MB (layout: h264decode_amd/csrc/mi_types.h struct MbRec). */

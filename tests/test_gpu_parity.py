@@ -63,6 +63,13 @@ def test_gpu_batch_of_unequal_streams(H, sg, oracle_mod):
         got = dec.read_frames(i, crop=True, size=info.width * info.height * 3 // 2)
         assert np.array_equal(got, ref), i
     assert dec.frame_count(4) == 0
+    # K6 over the whole batch (odd sizes: 180x100 takes the byte path, 176x144 the 16-byte path)
+    import torch
+    want = np.concatenate([oracle_mod.decode(streams[i], crop=True)[0].reshape(-1) for i in range(4)])
+    buf = torch.empty(want.size, dtype=torch.uint8, device="cuda")
+    assert dec.pack_batch(buf.data_ptr(), buf.numel()) == want.size
+    dec.sync()
+    assert np.array_equal(buf.cpu().numpy(), want)
     dec.close()
 
 
@@ -140,6 +147,11 @@ def test_gpu_1080p_full_size_properties(H, sg, oracle_mod):
     check(dec._L.h264mi_frame_pack_device(dec._h, 0, 3, buf.data_ptr(), buf.numel()))
     dec.sync()
     assert np.array_equal(buf.cpu().numpy(), out[0][3])
+    # ... and the batched form: all 4 frames of the stream in one launch
+    allbuf = torch.empty(4 * 1920 * 1080 * 3 // 2, dtype=torch.uint8, device="cuda")
+    assert dec.pack_batch(allbuf.data_ptr(), allbuf.numel()) == allbuf.numel()
+    dec.sync()
+    assert np.array_equal(allbuf.cpu().numpy().reshape(4, -1), out[0])
     dec.close()
 
 
