@@ -1,6 +1,6 @@
 /*
  * oracle/h264o.h -- CPU oracle: scalar C restatement of the H.264 Annex-B -> NAL -> slice ->
- * macroblock -> YCbCr path (ITU-T H.264 04/2017), frame-coded 4:2:0 8-bit, I and P slices,
+ * macroblock -> YCbCr path (ITU-T H.264 04/2017), frame-coded 4:2:0 8-bit, I, P and B slices,
  * CAVLC and CABAC, 4x4 and 8x8 transforms, in-loop deblocking.
  *
  * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
@@ -123,6 +123,12 @@ typedef struct {
     int mmco_op[66], mmco_arg1[66], mmco_arg2[66];
     int cabac_init_idc, slice_qp_delta, sp_for_switch_flag, slice_qs_delta;
     int disable_deblocking_filter_idc, slice_alpha_c0_offset_div2, slice_beta_offset_div2;
+    /* B slices: list 1 (h264/slice.go:924-936 modification, :940-984 weights) */
+    int ref_pic_list_modification_flag_l1, n_rplm1;
+    int rplm1_idc[66];
+    int rplm1_val[66];
+    int luma_weight_l1_flag[32], luma_weight_l1[32], luma_offset_l1[32];
+    int chroma_weight_l1_flag[32], chroma_weight_l1[32][2], chroma_offset_l1[32][2];
     /* derived */
     int nal_ref_idc, nal_unit_type, idr_flag, slice_qp_y;
     int64_t slice_data_bit_offset; /* bit position of slice_data() in the RBSP */
@@ -145,7 +151,7 @@ h264o_decoder *h264o_decoder_create(void);
 void h264o_decoder_destroy(h264o_decoder *d);
 /* crop != 0: frames are written at display size (I420: Y, Cb, Cr planes back to back);
  * crop == 0: at coded size.  out may be NULL to count frames only.  Frames are emitted in
- * decoding order (== output order for the I/P-only streams in scope).
+ * DECODING order (with B pictures that is not the output order: h264o_last_pocs() gives the PicOrderCnt of each).
  * Returns 0 on success, negative on error. */
 int h264o_decode_stream(h264o_decoder *d, const uint8_t *buf, size_t len, int crop, uint8_t *out, size_t out_cap,
                         h264o_stream_info *info);

@@ -25,7 +25,7 @@ const char *h264o_last_error(h264o_decoder *d) { return d->err; }
 
 h264o_decoder *h264o_decoder_create(void) { return (h264o_decoder *)calloc(1, sizeof(h264o_decoder)); }
 static void free_pics(h264o_decoder *d) {
-    for (int i = 0; i < d->n_pics; i++) free(d->pics[i].plane[0]);
+    for (int i = 0; i < d->n_pics; i++) free(d->pics[i].plane[0]), free(d->pics[i].mbs);
     d->n_pics = 0;
     free(d->mb);
     d->mb = NULL;
@@ -128,11 +128,49 @@ static int compute_poc(h264o_decoder *d, const h264o_slice_header *sh) {
     return poc;
 }
 
-/* ------------------------------------------------------------------ 8.2.4 reference picture lists (P) */
+/* ------------------------------------------------------------------ 8.2.4 reference picture lists */
 static int cmp_picnum_desc(const void *a, const void *b) { return (*(h264o_pic *const *)b)->pic_num - (*(h264o_pic *const *)a)->pic_num; }
 static int cmp_ltidx_asc(const void *a, const void *b) {
     return (*(h264o_pic *const *)a)->long_term_frame_idx - (*(h264o_pic *const *)b)->long_term_frame_idx;
 }
+static int cmp_poc_desc(const void *a, const void *b) { return (*(h264o_pic *const *)b)->poc - (*(h264o_pic *const *)a)->poc; }
+static int cmp_poc_asc(const void *a, const void *b) { return (*(h264o_pic *const *)a)->poc - (*(h264o_pic *const *)b)->poc; }
+
+/* 8.2.4.3 modification of one list (h264/slice.go:909-936 parses the commands) */
+static int modify_list(h264o_decoder *d, h264o_pic **list, int nact, h264o_pic **st, int nst, h264o_pic **lt, int nlt, int ncmd, const int *idc, const int *val) {
+    const h264o_slice_header *sh = &d->sh;
+    int max_fn = 1 << (d->asps->log2_max_frame_num_minus4 + 4);
+    int pred = sh->frame_num, idx = 0; /* picNumLXPred = CurrPicNum */
+    for (int k = 0; k < ncmd && idx < nact; k++) {
+        h264o_pic *target = NULL;
+        if (idc[k] < 2) {
+            int diff = val[k] + 1;
+            if (idc[k] == 0) {
+                pred -= diff;
+                if (pred < 0) pred += max_fn;
+            } else {
+                pred += diff;
+                if (pred >= max_fn) pred -= max_fn;
+            }
+            int picnum = pred > sh->frame_num ? pred - max_fn : pred;
+            for (int i = 0; i < nst; i++)
+                if (st[i]->pic_num == picnum) target = st[i];
+        } else {
+            for (int i = 0; i < nlt; i++)
+                if (lt[i]->long_term_frame_idx == val[k]) target = lt[i];
+        }
+        if (!target) return h264o_fail(d, "ref_pic_list_modification names a missing picture");
+        d->feat |= 1u << (8 + idc[k]);
+        /* shift up, insert, remove the duplicate further down (8-37/8-38) */
+        for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+        list[idx++] = target;
+        int nidx = idx;
+        for (int c = idx; c <= nact; c++)
+            if (list[c] != target) list[nidx++] = list[c];
+    }
+    return 0;
+}
+
 static int build_ref_list(h264o_decoder *d) {
     const h264o_slice_header *sh = &d->sh;
     int max_fn = 1 << (d->asps->log2_max_frame_num_minus4 + 4);
@@ -145,51 +183,51 @@ static int build_ref_list(h264o_decoder *d) {
             p->frame_num_wrap = p->frame_num > sh->frame_num ? p->frame_num - max_fn : p->frame_num;
             p->pic_num = p->frame_num_wrap;
             st[nst++] = p;
-        } else if (p->ref == 2) {
-            p->pic_num = p->long_term_frame_idx; /* LongTermPicNum */
+        } else if (p->ref == 2)
             lt[nlt++] = p;
-        }
     }
-    qsort(st, nst, sizeof(st[0]), cmp_picnum_desc);
     qsort(lt, nlt, sizeof(lt[0]), cmp_ltidx_asc);
-    int n = 0, nact = sh->num_ref_idx_l0_active_minus1 + 1;
+    int nact0 = sh->num_ref_idx_l0_active_minus1 + 1, nact1 = sh->num_ref_idx_l1_active_minus1 + 1;
     memset(d->rpl0, 0, sizeof(d->rpl0));
-    for (int i = 0; i < nst && n < 32; i++) d->rpl0[n++] = st[i];
-    for (int i = 0; i < nlt && n < 32; i++) d->rpl0[n++] = lt[i];
-    if (n == 0) return h264o_fail(d, "P slice without reference pictures");
-    /* 8.2.4.3 modification */
-    if (sh->ref_pic_list_modification_flag_l0) {
-        int pred = sh->frame_num, idx = 0; /* picNumL0Pred = CurrPicNum */
-        for (int k = 0; k < sh->n_rplm && idx < nact; k++) {
-            h264o_pic *target = NULL;
-            if (sh->rplm_idc[k] < 2) {
-                int diff = sh->rplm_val[k] + 1;
-                if (sh->rplm_idc[k] == 0) {
-                    pred -= diff;
-                    if (pred < 0) pred += max_fn;
-                } else {
-                    pred += diff;
-                    if (pred >= max_fn) pred -= max_fn;
-                }
-                int picnum = pred > sh->frame_num ? pred - max_fn : pred;
-                for (int i = 0; i < nst; i++)
-                    if (st[i]->pic_num == picnum) target = st[i];
-            } else {
-                for (int i = 0; i < nlt; i++)
-                    if (lt[i]->pic_num == sh->rplm_val[k]) target = lt[i];
-            }
-            if (!target) return h264o_fail(d, "ref_pic_list_modification names a missing picture");
-            d->feat |= 1u << (8 + sh->rplm_idc[k]);
-            /* shift up, insert, remove the duplicate further down (8-37/8-38) */
-            for (int c = nact; c > idx; c--) d->rpl0[c] = d->rpl0[c - 1];
-            d->rpl0[idx++] = target;
-            int nidx = idx;
-            for (int c = idx; c <= nact; c++)
-                if (d->rpl0[c] != target) d->rpl0[nidx++] = d->rpl0[c];
+    memset(d->rpl1, 0, sizeof(d->rpl1));
+    if (nst + nlt == 0) return h264o_fail(d, "P/B slice without reference pictures");
+    int n0 = 0, n1 = 0;
+    if (sh->slice_type != 1) { /* 8.2.4.2.1: P / SP -- PicNum descending, then LongTermPicNum ascending */
+        qsort(st, nst, sizeof(st[0]), cmp_picnum_desc);
+        for (int i = 0; i < nst && n0 < 32; i++) d->rpl0[n0++] = st[i];
+    } else { /* 8.2.4.2.3: B -- by PicOrderCnt relative to the current picture */
+        h264o_pic *before[20], *after[20];
+        int nb = 0, na = 0, cur_poc = d->cur->poc;
+        for (int i = 0; i < nst; i++) {
+            if (st[i]->poc < cur_poc)
+                before[nb++] = st[i];
+            else
+                after[na++] = st[i];
         }
+        qsort(before, nb, sizeof(before[0]), cmp_poc_desc);
+        qsort(after, na, sizeof(after[0]), cmp_poc_asc);
+        for (int i = 0; i < nb; i++) d->rpl0[n0++] = before[i];
+        for (int i = 0; i < na; i++) d->rpl0[n0++] = after[i];
+        for (int i = 0; i < na; i++) d->rpl1[n1++] = after[i];
+        for (int i = 0; i < nb; i++) d->rpl1[n1++] = before[i];
+        for (int i = 0; i < nlt && n1 < 32; i++) d->rpl1[n1++] = lt[i];
     }
-    for (int i = nact; i < 33; i++) d->rpl0[i] = NULL;
-    for (int i = 0; i < nact; i++)
+    for (int i = 0; i < nlt && n0 < 32; i++) d->rpl0[n0++] = lt[i];
+    if (sh->slice_type == 1 && n1 > 1 && n0 == n1 && memcmp(d->rpl0, d->rpl1, sizeof(d->rpl0[0]) * n1) == 0) { /* identical lists: swap the first two of list 1 */
+        h264o_pic *t = d->rpl1[0];
+        d->rpl1[0] = d->rpl1[1], d->rpl1[1] = t;
+    }
+    /* the initial lists are cut to the active size before modification (8.2.4.2) */
+    for (int i = nact0; i < 33; i++) d->rpl0[i] = NULL;
+    for (int i = nact1; i < 33; i++) d->rpl1[i] = NULL;
+    /* PicNum of short-term pictures for the modification commands; long-term: LongTermPicNum == LongTermFrameIdx for frames */
+    if (sh->ref_pic_list_modification_flag_l0 && modify_list(d, d->rpl0, nact0, st, nst, lt, nlt, sh->n_rplm, sh->rplm_idc, sh->rplm_val) < 0) return -1;
+    if (sh->slice_type == 1 && sh->ref_pic_list_modification_flag_l1 &&
+        modify_list(d, d->rpl1, nact1, st, nst, lt, nlt, sh->n_rplm1, sh->rplm1_idc, sh->rplm1_val) < 0)
+        return -1;
+    for (int i = nact0; i < 33; i++) d->rpl0[i] = NULL;
+    for (int i = nact1; i < 33; i++) d->rpl1[i] = NULL;
+    for (int i = 0; i < nact0; i++)
         if (d->rpl0[i] && d->rpl0[i]->ref == 2) d->feat |= 1u << 11;
     /* entries beyond the initial list that were never filled stay NULL; prediction from them is an error */
     return 0;
@@ -305,6 +343,14 @@ static void finish_picture(h264o_decoder *d) {
     /* conceal MBs never covered by a slice (not expected in scope): copy nothing, leave as is */
     h264o_deblock_picture(d);
     mark_reference(d);
+    if (d->cur->ref) { /* a later B picture may use this one as its co-located picture (RefPicList1[0]) */
+        if (d->cur->n_mbs != d->wmb * d->hmb) {
+            free(d->cur->mbs);
+            d->cur->mbs = (h264o_mb *)malloc(sizeof(h264o_mb) * (size_t)d->wmb * d->hmb);
+            d->cur->n_mbs = d->wmb * d->hmb;
+        }
+        memcpy(d->cur->mbs, d->mb, sizeof(h264o_mb) * (size_t)d->wmb * d->hmb);
+    }
     emit_frame(d);
     d->cur->in_use = 0;
     d->cur = NULL;
@@ -354,7 +400,7 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
     int r = h264o_parse_slice_header(&d->br, nal->nal_ref_idc, nal->nal_unit_type, d->sps, d->pps, &sh);
     if (r < 0) return h264o_fail(d, "slice header parse error %d", r);
     if (sh.field_pic_flag) return h264o_fail(d, "field pictures are out of scope");
-    if (sh.slice_type != 0 && sh.slice_type != 2) return h264o_fail(d, "slice_type %d out of scope (I and P only)", sh.slice_type);
+    if (sh.slice_type > 2) return h264o_fail(d, "slice_type %d out of scope (I, P and B only)", sh.slice_type);
     if (sh.redundant_pic_cnt > 0) return 0; /* redundant coded pictures are ignored */
     const h264o_pps *pps = &d->pps[sh.pic_parameter_set_id];
     if (d->cur && (sh.first_mb_in_slice == 0 || is_new_picture(d, &d->first_sh, &sh))) finish_picture(d);
@@ -365,7 +411,7 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
         if (start_picture(d) < 0) return -1;
     } else
         d->slice_id++;
-    if (sh.slice_type == 0 && build_ref_list(d) < 0) return -1;
+    if (sh.slice_type != 2 && build_ref_list(d) < 0) return -1;
     if (sh.first_mb_in_slice >= d->wmb * d->hmb) return h264o_fail(d, "first_mb_in_slice out of range");
     return h264o_decode_slice_data(d) < 0 ? -1 : 0;
 }

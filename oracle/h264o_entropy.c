@@ -27,6 +27,12 @@ static h264o_mb *mb_at(h264o_decoder *d, int mbx, int mby) {
 #define MB_A(d) mb_at(d, (d)->c.mbx - 1, (d)->c.mby)
 #define MB_B(d) mb_at(d, (d)->c.mbx, (d)->c.mby - 1)
 #define CUR(d) (&(d)->mb[(d)->c.addr])
+/* per-list views of a macroblock's motion (list 0: mv/ref/refid/mvd, list 1: mv1/ref1/refid1/mvd1) */
+#define L_MV(m, l) ((l) ? (m)->mv1 : (m)->mv)
+#define L_REF(m, l) ((l) ? (m)->ref1 : (m)->ref)
+#define L_REFID(m, l) ((l) ? (m)->refid1 : (m)->refid)
+#define L_MVD(m, l) ((l) ? (m)->mvd1 : (m)->mvd)
+#define IS_SKIP(t) ((t) == MBT_PSKIP || (t) == MBT_BSKIP)
 
 /* luma 4x4 block neighbour at (bx,by) relative to the current MB (bx,by in -1..3):
  * returns the owning MB (NULL if unavailable) and the raster block index inside it. */
@@ -277,10 +283,10 @@ int h264o_kat_cabac_bins(const uint8_t *bytes, size_t n, int pstate, int mps, in
 }
 
 /* ------------------------------------------------------------------ CABAC syntax elements 9.3.2 / 9.3.3.1 */
-static int cabac_mb_skip_flag(h264o_decoder *d) {
+static int cabac_mb_skip_flag(h264o_decoder *d) { /* ctxIdxOffset 11 in P / SP slices, 24 in B slices (Table 9-34) */
     h264o_mb *a = MB_A(d), *b = MB_B(d);
-    int inc = (a && a->type != MBT_PSKIP) + (b && b->type != MBT_PSKIP);
-    return h264o_cabac_decision(d, 11 + inc);
+    int inc = (a && !IS_SKIP(a->type)) + (b && !IS_SKIP(b->type));
+    return h264o_cabac_decision(d, (d->sh.slice_type == 1 ? 24 : 11) + inc);
 }
 
 /* Table 9-36 I-slice mb_type bin string; `base` = 3 for I slices (bin 0 neighbour-dependent),
@@ -308,6 +314,37 @@ static int cabac_p_mb_type(h264o_decoder *d) {
         return 2 - h264o_cabac_decision(d, 17);
     }
     return 5 + cabac_intra_mb_type(d, 17, 0);
+}
+/* Table 9-37 (b) B mb_type, ctxIdxOffset 27 (prefix) / 32 (intra suffix); returns raw mb_type 0..22, 23.. intra.
+ * h264/cabac.go:278 leaves these bin strings as a TODO. */
+static int cabac_b_mb_type(h264o_decoder *d) {
+    h264o_mb *a = MB_A(d), *b = MB_B(d);
+    int inc = (a && a->type != MBT_BSKIP && a->type != MBT_BDIRECT) + (b && b->type != MBT_BSKIP && b->type != MBT_BDIRECT);
+    if (!h264o_cabac_decision(d, 27 + inc)) return 0; /* B_Direct_16x16 */
+    if (!h264o_cabac_decision(d, 27 + 3)) return 1 + h264o_cabac_decision(d, 27 + 5); /* B_L0_16x16, B_L1_16x16 */
+    int bits = h264o_cabac_decision(d, 27 + 4) << 3;
+    bits |= h264o_cabac_decision(d, 27 + 5) << 2;
+    bits |= h264o_cabac_decision(d, 27 + 5) << 1;
+    bits |= h264o_cabac_decision(d, 27 + 5);
+    if (bits < 8) return bits + 3; /* B_Bi_16x16 .. B_L1_L0_16x8 */
+    if (bits == 13) return 23 + cabac_intra_mb_type(d, 32, 0);
+    if (bits == 14) return 11; /* B_L1_L0_8x16 */
+    if (bits == 15) return 22; /* B_8x8 */
+    bits = (bits << 1) | h264o_cabac_decision(d, 27 + 5);
+    return bits - 4; /* B_L0_Bi_16x8 .. B_Bi_Bi_8x16 */
+}
+/* Table 9-38 (b) B sub_mb_type, ctxIdxOffset 36 (h264/cabac.go:295 TODO) */
+static int cabac_b_sub_mb_type(h264o_decoder *d) {
+    if (!h264o_cabac_decision(d, 36)) return 0; /* B_Direct_8x8 */
+    if (!h264o_cabac_decision(d, 37)) return 1 + h264o_cabac_decision(d, 39);
+    int type = 3;
+    if (h264o_cabac_decision(d, 38)) {
+        if (h264o_cabac_decision(d, 39)) return 11 + h264o_cabac_decision(d, 39); /* B_L1_4x4, B_Bi_4x4 */
+        type += 4;
+    }
+    type += 2 * h264o_cabac_decision(d, 39);
+    type += h264o_cabac_decision(d, 39);
+    return type;
 }
 static int cabac_p_sub_mb_type(h264o_decoder *d) {
     if (h264o_cabac_decision(d, 21)) return 0;
@@ -366,12 +403,13 @@ static int cabac_mb_qp_delta(h264o_decoder *d) {
     }
     return (val & 1) ? (val + 1) >> 1 : -((val + 1) >> 1);
 }
-static int cabac_ref_idx(h264o_decoder *d, int bx, int by) {
-    /* 9.3.3.1.1.6: A/B partition refIdx > 0 */
+static int cabac_ref_idx(h264o_decoder *d, int list, int bx, int by) {
+    /* 9.3.3.1.1.6: A/B partition refIdx > 0; partitions predicted in direct mode (B_Skip, B_Direct_16x16, B_Direct_8x8) count as 0 */
     int ia, ib;
     h264o_mb *a = luma_nb(d, bx - 1, by, &ia), *b = luma_nb(d, bx, by - 1, &ib);
-    int ra = a ? a->ref[(ia >> 3) * 2 + ((ia & 3) >> 1)] : 0;
-    int rb = b ? b->ref[(ib >> 3) * 2 + ((ib & 3) >> 1)] : 0;
+    int a8 = (ia >> 3) * 2 + ((ia & 3) >> 1), b8 = (ib >> 3) * 2 + ((ib & 3) >> 1);
+    int ra = (a && !((a->direct8 >> a8) & 1)) ? L_REF(a, list)[a8] : 0;
+    int rb = (b && !((b->direct8 >> b8) & 1)) ? L_REF(b, list)[b8] : 0;
     int ctx = (ra > 0) + 2 * (rb > 0), ref = 0;
     while (h264o_cabac_decision(d, 54 + ctx)) {
         ref++;
@@ -381,10 +419,10 @@ static int cabac_ref_idx(h264o_decoder *d, int bx, int by) {
     return ref;
 }
 /* 9.3.2.3 UEG3, signedValFlag=1, uCoff=9; ctxIdxInc per 9.3.3.1.1.7 */
-static int cabac_mvd(h264o_decoder *d, int comp, int bx, int by) {
+static int cabac_mvd(h264o_decoder *d, int list, int comp, int bx, int by) {
     int ia, ib;
     h264o_mb *a = luma_nb(d, bx - 1, by, &ia), *b = luma_nb(d, bx, by - 1, &ib);
-    int sum = (a ? a->mvd[ia][comp] : 0) + (b ? b->mvd[ib][comp] : 0);
+    int sum = (a ? L_MVD(a, list)[ia][comp] : 0) + (b ? L_MVD(b, list)[ib][comp] : 0);
     int base = comp ? 47 : 40;
     if (!h264o_cabac_decision(d, base + (sum > 2) + (sum > 32))) return 0;
     int v = 1, ctx = base + 3;
@@ -574,11 +612,14 @@ static int pred_intra_mode(h264o_decoder *d, int bx, int by) {
 /* ------------------------------------------------------------------ motion vector prediction 8.4.1.3 */
 typedef struct {
     int avail; /* partition available (8.4.1.3.2) */
-    int ref;   /* -1: intra / not available */
+    int ref;   /* -1: intra / not available / list not used */
     int mv[2];
 } nbmv;
 
-static void get_nbmv(h264o_decoder *d, int bx, int by, nbmv *o) {
+/* neighbouring partition covering block (bx, by) (relative to the current MB, -1 / 4 = outside) as seen by list `list`.
+ * Inside the current macroblock a block is available once its motion for that list is final (cur_done[list]) and -- direct
+ * sub-macroblocks are derived up front -- only if it lies in a sub-macroblock not later than the one being decoded (6.4.11.7). */
+static void get_nbmv(h264o_decoder *d, int list, int bx, int by, nbmv *o) {
     h264o_curmb *c = &d->c;
     h264o_mb *m = NULL;
     o->avail = 0;
@@ -586,7 +627,8 @@ static void get_nbmv(h264o_decoder *d, int bx, int by, nbmv *o) {
     o->mv[0] = o->mv[1] = 0;
     if (by >= 0 && bx >= 4) return; /* right MB: never available */
     if (bx >= 0 && bx < 4 && by >= 0) {
-        if (!((d->cur_done >> (by * 4 + bx)) & 1)) return;
+        if (!((d->cur_done[list] >> (by * 4 + bx)) & 1)) return;
+        if ((by >> 1) * 2 + (bx >> 1) > d->cur_sub) return;
         m = CUR(d);
     } else {
         int mx = c->mbx + (bx < 0 ? -1 : (bx >= 4 ? 1 : 0)), my = c->mby + (by < 0 ? -1 : 0);
@@ -597,21 +639,22 @@ static void get_nbmv(h264o_decoder *d, int bx, int by, nbmv *o) {
     }
     o->avail = 1;
     if (MB_IS_INTRA(m->type)) return;
-    o->ref = m->ref[(by >> 1) * 2 + (bx >> 1)];
-    o->mv[0] = m->mv[by * 4 + bx][0];
-    o->mv[1] = m->mv[by * 4 + bx][1];
+    o->ref = L_REF(m, list)[(by >> 1) * 2 + (bx >> 1)];
+    if (o->ref < 0) return; /* the partition does not use this list: refIdx -1, mv 0 */
+    o->mv[0] = L_MV(m, list)[by * 4 + bx][0];
+    o->mv[1] = L_MV(m, list)[by * 4 + bx][1];
 }
 static int median3(int a, int b, int c) {
     int mn = a < b ? a : b, mx = a < b ? b : a;
     return c < mn ? mn : (c > mx ? mx : c);
 }
 /* shape: 0 = median only, 1 = 16x8 top, 2 = 16x8 bottom, 3 = 8x16 left, 4 = 8x16 right */
-static void predict_mv(h264o_decoder *d, int bx, int by, int w, int ref, int shape, int mvp[2]) {
+static void predict_mv(h264o_decoder *d, int list, int bx, int by, int w, int ref, int shape, int mvp[2]) {
     nbmv A, B, C;
-    get_nbmv(d, bx - 1, by, &A);
-    get_nbmv(d, bx, by - 1, &B);
-    get_nbmv(d, bx + w, by - 1, &C);
-    if (!C.avail) get_nbmv(d, bx - 1, by - 1, &C);
+    get_nbmv(d, list, bx - 1, by, &A);
+    get_nbmv(d, list, bx, by - 1, &B);
+    get_nbmv(d, list, bx + w, by - 1, &C);
+    if (!C.avail) get_nbmv(d, list, bx - 1, by - 1, &C);
     if ((shape == 1 && B.ref == ref) || (shape == 4 && C.ref == ref)) {
         const nbmv *s = shape == 1 ? &B : &C;
         mvp[0] = s->mv[0];
@@ -637,46 +680,48 @@ static void predict_mv(h264o_decoder *d, int bx, int by, int w, int ref, int sha
     mvp[0] = median3(A.mv[0], B.mv[0], C.mv[0]);
     mvp[1] = median3(A.mv[1], B.mv[1], C.mv[1]);
 }
-static void set_part(h264o_decoder *d, int bx, int by, int w, int h, const int mv[2], const int mvd[2]) {
+static void set_part(h264o_decoder *d, int list, int bx, int by, int w, int h, const int mv[2], const int mvd[2]) {
     h264o_mb *m = CUR(d);
     for (int y = by; y < by + h; y++)
         for (int x = bx; x < bx + w; x++) {
-            m->mv[y * 4 + x][0] = (int16_t)mv[0];
-            m->mv[y * 4 + x][1] = (int16_t)mv[1];
-            m->mvd[y * 4 + x][0] = (int16_t)abs(mvd[0]);
-            m->mvd[y * 4 + x][1] = (int16_t)abs(mvd[1]);
-            d->cur_done |= (uint16_t)(1 << (y * 4 + x));
+            L_MV(m, list)[y * 4 + x][0] = (int16_t)mv[0];
+            L_MV(m, list)[y * 4 + x][1] = (int16_t)mv[1];
+            L_MVD(m, list)[y * 4 + x][0] = (int16_t)abs(mvd[0]);
+            L_MVD(m, list)[y * 4 + x][1] = (int16_t)abs(mvd[1]);
+            d->cur_done[list] |= (uint16_t)(1 << (y * 4 + x));
         }
 }
-static void read_mvd(h264o_decoder *d, int bx, int by, int mvd[2]) {
+static void read_mvd(h264o_decoder *d, int list, int bx, int by, int mvd[2]) {
     if (d->apps->entropy_coding_mode_flag) {
-        mvd[0] = cabac_mvd(d, 0, bx, by);
-        mvd[1] = cabac_mvd(d, 1, bx, by);
+        mvd[0] = cabac_mvd(d, list, 0, bx, by);
+        mvd[1] = cabac_mvd(d, list, 1, bx, by);
     } else {
         mvd[0] = h264o_se(&d->br);
         mvd[1] = h264o_se(&d->br);
     }
 }
-static void do_part(h264o_decoder *d, int bx, int by, int w, int h, int shape) {
+static void do_part(h264o_decoder *d, int list, int bx, int by, int w, int h, int shape) {
     h264o_mb *m = CUR(d);
     int mvd[2], mvp[2], mv[2];
-    read_mvd(d, bx, by, mvd);
-    predict_mv(d, bx, by, w, m->ref[(by >> 1) * 2 + (bx >> 1)], shape, mvp);
+    read_mvd(d, list, bx, by, mvd);
+    predict_mv(d, list, bx, by, w, L_REF(m, list)[(by >> 1) * 2 + (bx >> 1)], shape, mvp);
     mv[0] = mvp[0] + mvd[0];
     mv[1] = mvp[1] + mvd[1];
-    set_part(d, bx, by, w, h, mv, mvd);
+    set_part(d, list, bx, by, w, h, mv, mvd);
 }
-static int read_ref_idx(h264o_decoder *d, int bx, int by) {
-    int nref = d->sh.num_ref_idx_l0_active_minus1;
+static int read_ref_idx(h264o_decoder *d, int list, int bx, int by) {
+    int nref = list ? d->sh.num_ref_idx_l1_active_minus1 : d->sh.num_ref_idx_l0_active_minus1;
     if (nref == 0) return 0;
-    if (d->apps->entropy_coding_mode_flag) return cabac_ref_idx(d, bx, by);
+    if (d->apps->entropy_coding_mode_flag) return cabac_ref_idx(d, list, bx, by);
     return (int)h264o_te(&d->br, nref);
 }
 static void set_refids(h264o_decoder *d, h264o_mb *m) {
-    for (int i = 0; i < 4; i++) {
-        h264o_pic *p = (m->ref[i] >= 0 && m->ref[i] <= 32) ? d->rpl0[m->ref[i]] : NULL;
-        m->refid[i] = p ? p->id : -1;
-    }
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < 4; i++) {
+            int r = L_REF(m, l)[i];
+            h264o_pic *p = (r >= 0 && r <= 32) ? (l ? d->rpl1[r] : d->rpl0[r]) : NULL;
+            L_REFID(m, l)[i] = p ? p->id : -1;
+        }
 }
 
 /* 8.4.1.1 P_Skip motion */
@@ -685,12 +730,107 @@ static void pskip_motion(h264o_decoder *d) {
     nbmv A, B;
     int mv[2] = {0, 0}, zero[2] = {0, 0};
     memset(m->ref, 0, sizeof(m->ref));
-    get_nbmv(d, -1, 0, &A);
-    get_nbmv(d, 0, -1, &B);
+    get_nbmv(d, 0, -1, 0, &A);
+    get_nbmv(d, 0, 0, -1, &B);
     if (A.avail && B.avail && !(A.ref == 0 && A.mv[0] == 0 && A.mv[1] == 0) && !(B.ref == 0 && B.mv[0] == 0 && B.mv[1] == 0))
-        predict_mv(d, 0, 0, 4, 0, 0, mv);
-    set_part(d, 0, 0, 4, 4, mv, zero);
+        predict_mv(d, 0, 0, 0, 4, 0, 0, mv);
+    set_part(d, 0, 0, 0, 4, 4, mv, zero);
     set_refids(d, m);
+}
+
+/* ------------------------------------------------------------------ direct prediction 8.4.1.2 (B_Skip, B_Direct_16x16, B_Direct_8x8) */
+/* co-located 4x4 block of block (bx, by): 8.4.1.2.1 for frame pictures.  With direct_8x8_inference_flag the corner block
+ * of the 8x8 quadrant stands for the whole quadrant.  Returns refIdxCol (-1: intra), the vector and the picture it points to. */
+static int colocated(h264o_decoder *d, int bx, int by, int mvcol[2], int *refid_col) {
+    const h264o_pic *col = d->rpl1[0];
+    mvcol[0] = mvcol[1] = 0;
+    *refid_col = -1;
+    if (!col || !col->mbs || col->n_mbs != d->wmb * d->hmb) return -1;
+    const h264o_mb *cm = &col->mbs[d->c.addr];
+    if (d->asps->direct_8x8_inference_flag) bx = (bx >> 1) * 3, by = (by >> 1) * 3;
+    if (!MB_IS_INTER(cm->type)) return -1;
+    int i8 = (by >> 1) * 2 + (bx >> 1), l = cm->ref[i8] >= 0 ? 0 : 1;
+    if (L_REF(cm, l)[i8] < 0) return -1;
+    mvcol[0] = L_MV(cm, l)[by * 4 + bx][0];
+    mvcol[1] = L_MV(cm, l)[by * 4 + bx][1];
+    *refid_col = L_REFID(cm, l)[i8];
+    return L_REF(cm, l)[i8];
+}
+static int min_positive(int a, int b) { return (a >= 0 && b >= 0) ? (a < b ? a : b) : (a > b ? a : b); }
+
+/* derive the motion of the 8x8 quadrants in `mask8` (bit i = quadrant i) */
+static int direct_pred(h264o_decoder *d, int mask8) {
+    h264o_mb *m = CUR(d);
+    const int zero[2] = {0, 0};
+    if (d->sh.direct_spatial_mv_pred_flag) { /* 8.4.1.2.2 */
+        int ref[2], mvp[2][2] = {{0, 0}, {0, 0}};
+        int save_sub = d->cur_sub;
+        d->cur_sub = -1; /* the neighbours A, B, C of the MACROBLOCK: nothing inside it counts */
+        for (int l = 0; l < 2; l++) {
+            nbmv A, B, C;
+            get_nbmv(d, l, -1, 0, &A);
+            get_nbmv(d, l, 0, -1, &B);
+            get_nbmv(d, l, 4, -1, &C);
+            if (!C.avail) get_nbmv(d, l, -1, -1, &C);
+            ref[l] = min_positive(A.ref, min_positive(B.ref, C.ref));
+        }
+        if (ref[0] < 0 && ref[1] < 0)
+            ref[0] = ref[1] = 0; /* directZeroPredictionFlag: both vectors stay zero */
+        else
+            for (int l = 0; l < 2; l++)
+                if (ref[l] >= 0) predict_mv(d, l, 0, 0, 4, ref[l], 0, mvp[l]);
+        d->cur_sub = save_sub;
+        const int col_short = d->rpl1[0] && d->rpl1[0]->ref == 1;
+        for (int i8 = 0; i8 < 4; i8++) {
+            if (!((mask8 >> i8) & 1)) continue;
+            for (int k = 0; k < 4; k++) {
+                int bx = (i8 & 1) * 2 + (k & 1), by = (i8 >> 1) * 2 + (k >> 1), mvcol[2], rid;
+                int refcol = colocated(d, bx, by, mvcol, &rid);
+                int colzero = col_short && refcol == 0 && mvcol[0] >= -1 && mvcol[0] <= 1 && mvcol[1] >= -1 && mvcol[1] <= 1;
+                for (int l = 0; l < 2; l++) {
+                    L_REF(m, l)[i8] = (int8_t)ref[l];
+                    const int *mv = (ref[l] < 0 || (ref[l] == 0 && colzero)) ? zero : mvp[l];
+                    set_part(d, l, bx, by, 1, 1, mv, zero);
+                }
+            }
+        }
+        return 0;
+    }
+    /* 8.4.1.2.3 temporal direct */
+    for (int i8 = 0; i8 < 4; i8++) {
+        if (!((mask8 >> i8) & 1)) continue;
+        for (int k = 0; k < 4; k++) {
+            int bx = (i8 & 1) * 2 + (k & 1), by = (i8 >> 1) * 2 + (k >> 1), mvcol[2], rid;
+            int refcol = colocated(d, bx, by, mvcol, &rid);
+            int ref0 = 0;
+            if (refcol >= 0) { /* the picture the co-located block refers to, as an index of the current RefPicList0 */
+                ref0 = -1;
+                for (int i = 0; i <= d->sh.num_ref_idx_l0_active_minus1 && ref0 < 0; i++)
+                    if (d->rpl0[i] && d->rpl0[i]->id == rid) ref0 = i;
+                if (ref0 < 0) return h264o_fail(d, "temporal direct: the co-located reference is not in RefPicList0");
+            }
+            const h264o_pic *p0 = d->rpl0[ref0], *p1 = d->rpl1[0];
+            if (!p0 || !p1) return h264o_fail(d, "temporal direct without reference pictures");
+            int mv0[2], mv1[2];
+            int tb = h264o_clip3(-128, 127, d->cur->poc - p0->poc), td = h264o_clip3(-128, 127, p1->poc - p0->poc);
+            if (p0->ref == 2 || td == 0) {
+                mv0[0] = mvcol[0], mv0[1] = mvcol[1];
+                mv1[0] = mv1[1] = 0;
+            } else {
+                int tx = (16384 + abs(td / 2)) / td;
+                int dsf = h264o_clip3(-1024, 1023, (tb * tx + 32) >> 6);
+                for (int c = 0; c < 2; c++) {
+                    mv0[c] = (dsf * mvcol[c] + 128) >> 8;
+                    mv1[c] = mv0[c] - mvcol[c];
+                }
+            }
+            m->ref[i8] = (int8_t)ref0;
+            m->ref1[i8] = 0;
+            set_part(d, 0, bx, by, 1, 1, mv0, zero);
+            set_part(d, 1, bx, by, 1, 1, mv1, zero);
+        }
+    }
+    return 0;
 }
 
 /* ------------------------------------------------------------------ macroblock_layer() 7.3.5 */
@@ -705,6 +845,7 @@ static void trace_mb(h264o_decoder *d, h264o_mb *m) {
     t[5] = m->mv[0][0];
     t[6] = m->mv[0][1];
     t[7] = m->ref[0];
+    if (d->sh.slice_type == 1) t[7] -= 100; /* marks macroblocks of B slices (raw mb_type is per slice type) */
 }
 
 static void begin_mb(h264o_decoder *d, int addr) {
@@ -718,11 +859,13 @@ static void begin_mb(h264o_decoder *d, int addr) {
     m->slice_id = (uint16_t)d->slice_id;
     memset(m->ipm, -1, sizeof(m->ipm));
     memset(m->ref, -1, sizeof(m->ref));
-    m->refid[0] = m->refid[1] = m->refid[2] = m->refid[3] = -1;
+    memset(m->ref1, -1, sizeof(m->ref1));
+    for (int i = 0; i < 4; i++) m->refid[i] = m->refid1[i] = -1;
     m->alpha_off = (int8_t)(d->sh.slice_alpha_c0_offset_div2 * 2);
     m->beta_off = (int8_t)(d->sh.slice_beta_offset_div2 * 2);
     m->dbf_idc = (uint8_t)d->sh.disable_deblocking_filter_idc;
-    d->cur_done = 0;
+    d->cur_done[0] = d->cur_done[1] = 0;
+    d->cur_sub = 3;
 }
 static void finish_mb(h264o_decoder *d) {
     h264o_mb *m = CUR(d);
@@ -750,6 +893,46 @@ static int decode_pskip(h264o_decoder *d, int addr) {
     return 0;
 }
 
+/* B_Skip: direct prediction of the whole macroblock, no residual (7.3.4, 8.4.1.2) */
+static int decode_bskip(h264o_decoder *d, int addr) {
+    begin_mb(d, addr);
+    d->c.type = MBT_BSKIP;
+    d->c.mb_type_raw = -1;
+    CUR(d)->type = MBT_BSKIP;
+    CUR(d)->direct8 = 15;
+    if (direct_pred(d, 15) < 0) return -1;
+    set_refids(d, CUR(d));
+    d->prev_dqp_nz = 0;
+    finish_mb(d);
+    return 0;
+}
+
+/* Table 7-14: prediction modes of the two partitions of mb_type 4..21 (1 = Pred_L0, 2 = Pred_L1, 3 = BiPred) */
+static const uint8_t b_part_modes[9][2] = {{1, 1}, {2, 2}, {1, 2}, {2, 1}, {1, 3}, {2, 3}, {3, 1}, {3, 2}, {3, 3}};
+/* Table 7-18: sub_mb_type of B macroblocks -> prediction mode (0 = direct) and sub-partition shape (0 8x8, 1 8x4, 2 4x8, 3 4x4) */
+static const uint8_t b_sub_mode[13] = {0, 1, 2, 3, 1, 1, 2, 2, 3, 3, 1, 2, 3};
+static const uint8_t b_sub_shape[13] = {0, 0, 0, 0, 1, 2, 1, 2, 1, 2, 3, 3, 3};
+
+typedef struct {
+    int bx, by, w, h, shape, mode;
+} ipart;
+
+/* mb_pred() for the unsplit / two-partition inter types of P and B slices: every ref_idx_l0, every ref_idx_l1, every
+ * mvd_l0, every mvd_l1 (7.3.5.1) */
+static void decode_parts(h264o_decoder *d, const ipart *pt, int n) {
+    h264o_mb *m = CUR(d);
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < n; i++) {
+            if (!((pt[i].mode >> l) & 1)) continue;
+            int r = read_ref_idx(d, l, pt[i].bx, pt[i].by);
+            for (int y = pt[i].by; y < pt[i].by + pt[i].h; y += 2)
+                for (int x = pt[i].bx; x < pt[i].bx + pt[i].w; x += 2) L_REF(m, l)[(y >> 1) * 2 + (x >> 1)] = (int8_t)r;
+        }
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < n; i++)
+            if ((pt[i].mode >> l) & 1) do_part(d, l, pt[i].bx, pt[i].by, pt[i].w, pt[i].h, pt[i].shape);
+}
+
 static int decode_mb(h264o_decoder *d, int addr) {
     h264o_curmb *c;
     h264o_mb *m;
@@ -759,10 +942,13 @@ static int decode_mb(h264o_decoder *d, int addr) {
     begin_mb(d, addr);
     c = &d->c;
     m = CUR(d);
-    int raw = cabac ? (islice ? cabac_intra_mb_type(d, 3, 1) : cabac_p_mb_type(d)) : (int)h264o_ue(b);
+    const int bslice = d->sh.slice_type == 1;
+    int raw = cabac ? (islice ? cabac_intra_mb_type(d, 3, 1) : (bslice ? cabac_b_mb_type(d) : cabac_p_mb_type(d))) : (int)h264o_ue(b);
     c->mb_type_raw = raw;
-    int it = islice ? raw : raw - 5; /* intra mb_type (Table 7-11) when >= 0 */
-    if (!islice && raw < 5) {
+    int it = islice ? raw : raw - (bslice ? 23 : 5); /* intra mb_type (Table 7-11) when >= 0 */
+    if (bslice && raw < 23) { /* Table 7-14 */
+        c->type = raw == 0 ? MBT_BDIRECT : (raw <= 3 ? MBT_P16x16 : (raw == 22 ? MBT_P8x8 : ((raw & 1) ? MBT_P8x16 : MBT_P16x8)));
+    } else if (!islice && !bslice && raw < 5) {
         static const int pt[5] = {MBT_P16x16, MBT_P16x8, MBT_P8x16, MBT_P8x8, MBT_P8x8};
         c->type = pt[raw];
     } else if (it == 0)
@@ -795,45 +981,68 @@ static int decode_mb(h264o_decoder *d, int addr) {
         return b->err ? h264o_fail(d, "mb %d: pcm overrun", addr) : 0;
     }
 
-    if (c->type == MBT_P8x8) {
+    int no_sub8 = 1; /* NoSubMbPartSizeLessThan8x8Flag (7.3.5) */
+    if (c->type == MBT_BDIRECT) {
+        m->direct8 = 15;
+        if (direct_pred(d, 15) < 0) return -1;
+        if (!d->asps->direct_8x8_inference_flag) no_sub8 = 0;
+    } else if (c->type == MBT_P8x8) {
+        int mode[4], shape[4];
         for (int i = 0; i < 4; i++) {
-            c->sub_type[i] = cabac ? cabac_p_sub_mb_type(d) : (int)h264o_ue(b);
-            if (c->sub_type[i] > 3) return h264o_fail(d, "mb %d: bad sub_mb_type", addr);
+            int st = cabac ? (bslice ? cabac_b_sub_mb_type(d) : cabac_p_sub_mb_type(d)) : (int)h264o_ue(b);
+            if (st > (bslice ? 12 : 3)) return h264o_fail(d, "mb %d: bad sub_mb_type", addr);
+            c->sub_type[i] = st;
+            mode[i] = bslice ? b_sub_mode[st] : 1;
+            shape[i] = bslice ? b_sub_shape[st] : st;
+            if (mode[i] == 0) {
+                m->direct8 |= (uint8_t)(1 << i);
+                if (!d->asps->direct_8x8_inference_flag) no_sub8 = 0;
+            } else if (shape[i] != 0)
+                no_sub8 = 0;
         }
-        for (int i = 0; i < 4; i++) m->ref[i] = (raw == 4) ? 0 : (int8_t)read_ref_idx(d, (i & 1) * 2, (i >> 1) * 2);
-        for (int i = 0; i < 4; i++) {
-            int bx = (i & 1) * 2, by = (i >> 1) * 2;
-            switch (c->sub_type[i]) {
-            case 0: do_part(d, bx, by, 2, 2, 0); break;
-            case 1: do_part(d, bx, by, 2, 1, 0); do_part(d, bx, by + 1, 2, 1, 0); break;
-            case 2: do_part(d, bx, by, 1, 2, 0); do_part(d, bx + 1, by, 1, 2, 0); break;
-            default:
-                do_part(d, bx, by, 1, 1, 0);
-                do_part(d, bx + 1, by, 1, 1, 0);
-                do_part(d, bx, by + 1, 1, 1, 0);
-                do_part(d, bx + 1, by + 1, 1, 1, 0);
+        if (m->direct8) { /* direct sub-macroblocks are derived first: later sub-macroblocks predict from them */
+            d->cur_sub = -1;
+            if (direct_pred(d, m->direct8) < 0) return -1;
+        }
+        for (int l = 0; l < 2; l++)
+            for (int i = 0; i < 4; i++) {
+                if (!((mode[i] >> l) & 1)) continue;
+                d->cur_sub = i;
+                L_REF(m, l)[i] = (!bslice && raw == 4) ? 0 : (int8_t)read_ref_idx(d, l, (i & 1) * 2, (i >> 1) * 2);
             }
-        }
+        for (int l = 0; l < 2; l++)
+            for (int i = 0; i < 4; i++) {
+                if (!((mode[i] >> l) & 1)) continue;
+                int bx = (i & 1) * 2, by = (i >> 1) * 2;
+                d->cur_sub = i;
+                switch (shape[i]) {
+                case 0: do_part(d, l, bx, by, 2, 2, 0); break;
+                case 1: do_part(d, l, bx, by, 2, 1, 0); do_part(d, l, bx, by + 1, 2, 1, 0); break;
+                case 2: do_part(d, l, bx, by, 1, 2, 0); do_part(d, l, bx + 1, by, 1, 2, 0); break;
+                default:
+                    do_part(d, l, bx, by, 1, 1, 0);
+                    do_part(d, l, bx + 1, by, 1, 1, 0);
+                    do_part(d, l, bx, by + 1, 1, 1, 0);
+                    do_part(d, l, bx + 1, by + 1, 1, 1, 0);
+                }
+            }
+        d->cur_sub = 3;
     } else if (MB_IS_INTER(c->type)) {
-        if (c->type == MBT_P16x16) {
-            int r = read_ref_idx(d, 0, 0);
-            m->ref[0] = m->ref[1] = m->ref[2] = m->ref[3] = (int8_t)r;
-            do_part(d, 0, 0, 4, 4, 0);
-        } else if (c->type == MBT_P16x8) {
-            int r0 = read_ref_idx(d, 0, 0);
-            m->ref[0] = m->ref[1] = (int8_t)r0;
-            int r1 = read_ref_idx(d, 0, 2);
-            m->ref[2] = m->ref[3] = (int8_t)r1;
-            do_part(d, 0, 0, 4, 2, 1);
-            do_part(d, 0, 2, 4, 2, 2);
-        } else {
-            int r0 = read_ref_idx(d, 0, 0);
-            m->ref[0] = m->ref[2] = (int8_t)r0;
-            int r1 = read_ref_idx(d, 2, 0);
-            m->ref[1] = m->ref[3] = (int8_t)r1;
-            do_part(d, 0, 0, 2, 4, 3);
-            do_part(d, 2, 0, 2, 4, 4);
+        ipart pt[2];
+        int n, m0 = 1, m1 = 1;
+        if (bslice) {
+            if (raw <= 3)
+                m0 = raw;
+            else
+                m0 = b_part_modes[(raw - 4) >> 1][0], m1 = b_part_modes[(raw - 4) >> 1][1];
         }
+        if (c->type == MBT_P16x16)
+            pt[0] = (ipart){0, 0, 4, 4, 0, m0}, n = 1;
+        else if (c->type == MBT_P16x8)
+            pt[0] = (ipart){0, 0, 4, 2, 1, m0}, pt[1] = (ipart){0, 2, 4, 2, 2, m1}, n = 2;
+        else
+            pt[0] = (ipart){0, 0, 2, 4, 3, m0}, pt[1] = (ipart){2, 0, 2, 4, 4, m1}, n = 2;
+        decode_parts(d, pt, n);
     } else {
         /* intra: transform_size_8x8_flag, pred modes, chroma mode (7.3.5, 7.3.5.1) */
         if (c->type == MBT_I4x4 && d->apps->transform_8x8_mode_flag) {
@@ -882,10 +1091,6 @@ static int decode_mb(h264o_decoder *d, int addr) {
         c->cbp_luma = cbp & 15;
         c->cbp_chroma = cbp >> 4;
         if (c->cbp_luma && d->apps->transform_8x8_mode_flag && MB_IS_INTER(c->type)) {
-            int no_sub8 = 1;
-            if (c->type == MBT_P8x8)
-                for (int i = 0; i < 4; i++)
-                    if (c->sub_type[i] != 0) no_sub8 = 0;
             if (no_sub8) {
                 c->t8x8 = cabac ? cabac_transform8x8(d) : (int)h264o_u(b, 1);
                 m->t8x8 = (uint8_t)c->t8x8;
@@ -914,6 +1119,7 @@ int h264o_decode_slice_data(h264o_decoder *d) {
     h264o_br *b = &d->br;
     int cabac = d->apps->entropy_coding_mode_flag;
     int islice = d->sh.slice_type == 2;
+    int bslice = d->sh.slice_type == 1;
     int total = d->wmb * d->hmb;
     int addr = d->sh.first_mb_in_slice;
     int64_t start_bits = b->pos;
@@ -932,14 +1138,15 @@ int h264o_decode_slice_data(h264o_decoder *d) {
             if (!cabac) {
                 uint32_t run = h264o_ue(b);
                 if (run > (uint32_t)(total - addr)) return h264o_fail(d, "mb_skip_run %u too long", run);
-                for (uint32_t i = 0; i < run; i++) decode_pskip(d, addr++);
+                for (uint32_t i = 0; i < run; i++)
+                    if ((bslice ? decode_bskip(d, addr++) : decode_pskip(d, addr++)) < 0) return -1;
                 if (run > 0) more = h264o_more_rbsp_data(b);
                 if (!more) break;
                 if (addr >= total) return h264o_fail(d, "slice runs past the picture after skip run");
             } else {
                 begin_mb(d, addr); /* neighbour helpers need c.mbx/mby */
                 if (cabac_mb_skip_flag(d)) {
-                    decode_pskip(d, addr);
+                    if ((bslice ? decode_bskip(d, addr) : decode_pskip(d, addr)) < 0) return -1;
                     goto end_mb;
                 }
             }

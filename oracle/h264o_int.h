@@ -3,7 +3,9 @@
 #define H264O_INT_H
 #include "h264o.h"
 
-enum { MBT_NONE = 0, MBT_I4x4, MBT_I8x8, MBT_I16x16, MBT_IPCM, MBT_P16x16, MBT_P16x8, MBT_P8x16, MBT_P8x8, MBT_PSKIP };
+/* Inter types name the partition shape; which lists a partition predicts from is in ref[] / ref1[] (>= 0: used), so the
+ * shapes serve P and B macroblocks alike.  MBT_BDIRECT = B_Direct_16x16 (with residual), MBT_BSKIP = B_Skip. */
+enum { MBT_NONE = 0, MBT_I4x4, MBT_I8x8, MBT_I16x16, MBT_IPCM, MBT_P16x16, MBT_P16x8, MBT_P8x16, MBT_P8x8, MBT_PSKIP, MBT_BDIRECT, MBT_BSKIP };
 #define MB_IS_INTRA(t) ((t) >= MBT_I4x4 && (t) <= MBT_IPCM)
 #define MB_IS_INTER(t) ((t) >= MBT_P16x16)
 
@@ -15,9 +17,11 @@ typedef struct {
     int long_term_frame_idx;
     int id; /* unique, increasing */
     int in_use;
+    struct h264o_mb_s *mbs; /* motion of the decoded picture (co-located data for direct prediction, 8.4.1.2) */
+    int n_mbs;
 } h264o_pic;
 
-typedef struct {
+typedef struct h264o_mb_s {
     uint8_t type; /* MBT_* ; MBT_NONE = not yet decoded in this picture */
     uint8_t t8x8, qp, qpc[2], cbp_luma, cbp_chroma, chroma_mode;
     uint16_t slice_id;
@@ -32,6 +36,12 @@ typedef struct {
     int8_t alpha_off, beta_off; /* FilterOffsetA/B of the containing slice */
     uint8_t dbf_idc;
     uint8_t dqp_nz; /* mb_qp_delta != 0 (CABAC ctxIdxInc of the next MB) */
+    /* list 1 (B macroblocks); ref[] / ref1[] = -1 where the list is not used */
+    int16_t mv1[16][2];
+    int8_t ref1[4];
+    int32_t refid1[4];
+    int16_t mvd1[16][2];
+    uint8_t direct8; /* bit i: 8x8 block i is direct-predicted (B_Skip / B_Direct_16x16 / B_Direct_8x8): ref_idx contexts read it as 0 */
 } h264o_mb;
 
 typedef struct {
@@ -65,6 +75,7 @@ struct h264o_decoder {
     h264o_br br;
     int slice_id;
     h264o_pic *rpl0[33];
+    h264o_pic *rpl1[33];
     int qp;
     int prev_dqp_nz;
     uint32_t cod_range, cod_offset;
@@ -72,7 +83,8 @@ struct h264o_decoder {
     int level_scale4[6][6][16]; /* [list][qp%6][raster pos] */
     int level_scale8[2][6][64];
     h264o_curmb c;
-    uint16_t cur_done; /* 4x4 blocks (raster) of the current MB whose motion is final */
+    uint16_t cur_done[2]; /* per list: 4x4 blocks (raster) of the current MB whose motion is final */
+    int cur_sub;          /* sub-macroblock being decoded (3 when the macroblock is not split): later ones are not available (6.4.11.7) */
     /* output */
     int crop;
     uint8_t *out;

@@ -293,9 +293,22 @@ int h264o_parse_slice_header(h264o_br *b, int nal_ref_idc, int nal_unit_type, co
             }
         }
     }
-    if (sh->slice_type == 1) return -4; /* B slices: SURVEY 8f rank 1, not in this round */
+    if (sh->slice_type == 1) { /* list 1 of B slices (h264/slice.go:924-936) */
+        if (sh->num_ref_idx_l1_active_minus1 > 31) return -1;
+        sh->ref_pic_list_modification_flag_l1 = h264o_u(b, 1);
+        if (sh->ref_pic_list_modification_flag_l1) {
+            for (;;) {
+                int idc = h264o_ue(b);
+                if (idc == 3) break;
+                if (idc > 3 || sh->n_rplm1 >= 66 || b->err) return -1;
+                sh->rplm1_idc[sh->n_rplm1] = idc;
+                sh->rplm1_val[sh->n_rplm1] = h264o_ue(b);
+                sh->n_rplm1++;
+            }
+        }
+    }
     /* pred_weight_table() 7.3.3.2 */
-    if (p->weighted_pred_flag && (sh->slice_type == 0 || sh->slice_type == 3)) {
+    if ((p->weighted_pred_flag && (sh->slice_type == 0 || sh->slice_type == 3)) || (p->weighted_bipred_idc == 1 && sh->slice_type == 1)) {
         sh->luma_log2_weight_denom = h264o_ue(b);
         sh->chroma_log2_weight_denom = h264o_ue(b); /* ChromaArrayType != 0 */
         for (int i = 0; i <= sh->num_ref_idx_l0_active_minus1; i++) {
@@ -313,6 +326,22 @@ int h264o_parse_slice_header(h264o_br *b, int nal_ref_idc, int nal_unit_type, co
                     sh->chroma_offset_l0[i][j] = h264o_se(b);
                 }
         }
+        if (sh->slice_type == 1)
+            for (int i = 0; i <= sh->num_ref_idx_l1_active_minus1; i++) {
+                sh->luma_weight_l1[i] = 1 << sh->luma_log2_weight_denom;
+                sh->chroma_weight_l1[i][0] = sh->chroma_weight_l1[i][1] = 1 << sh->chroma_log2_weight_denom;
+                sh->luma_weight_l1_flag[i] = h264o_u(b, 1);
+                if (sh->luma_weight_l1_flag[i]) {
+                    sh->luma_weight_l1[i] = h264o_se(b);
+                    sh->luma_offset_l1[i] = h264o_se(b);
+                }
+                sh->chroma_weight_l1_flag[i] = h264o_u(b, 1);
+                if (sh->chroma_weight_l1_flag[i])
+                    for (int j = 0; j < 2; j++) {
+                        sh->chroma_weight_l1[i][j] = h264o_se(b);
+                        sh->chroma_offset_l1[i][j] = h264o_se(b);
+                    }
+            }
     }
     /* dec_ref_pic_marking() 7.3.3.3 */
     if (nal_ref_idc != 0) {

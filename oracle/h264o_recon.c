@@ -430,46 +430,95 @@ static int luma_sample(const uint8_t *p, int stride, int w, int h, int xi, int y
 #undef H1
 }
 
+/* 8.4.2.3: combine the predictions of one sample.  n = 1: a = the single prediction (list `l`), explicit weights when
+ * `explicit_`; n = 2: a from list 0, b from list 1 -- default average, explicit or implicit weights (logWD = 5, offsets 0). */
+static int weight1(int a, int logwd, int w, int o) { return logwd >= 1 ? h264o_clip1(((a * w + (1 << (logwd - 1))) >> logwd) + o) : h264o_clip1(a * w + o); }
+static int weight2(int a, int b, int logwd, int w0, int w1, int o0, int o1) {
+    return h264o_clip1(((a * w0 + b * w1 + (1 << logwd)) >> (logwd + 1)) + ((o0 + o1 + 1) >> 1));
+}
+/* 8.4.2.3.1 implicit bi-prediction weights from the picture order counts */
+static void implicit_weights(const h264o_decoder *d, const h264o_pic *p0, const h264o_pic *p1, int *w0, int *w1) {
+    int tb = h264o_clip3(-128, 127, d->cur->poc - p0->poc), td = h264o_clip3(-128, 127, p1->poc - p0->poc);
+    *w0 = *w1 = 32;
+    if (td == 0 || p0->ref == 2 || p1->ref == 2) return;
+    int tx = (16384 + abs(td / 2)) / td;
+    int dsf = h264o_clip3(-1024, 1023, (tb * tx + 32) >> 6);
+    if ((dsf >> 2) < -64 || (dsf >> 2) > 128) return;
+    *w0 = 64 - (dsf >> 2), *w1 = dsf >> 2;
+}
 static void inter_pred_mb(h264o_decoder *d, h264o_mb *m) {
     h264o_curmb *c = &d->c;
     int W = d->wmb * 16, H = d->hmb * 16;
     const h264o_slice_header *sh = &d->sh;
-    int wp = d->apps->weighted_pred_flag;
+    const int bslice = sh->slice_type == 1;
+    /* weighted prediction mode: 0 default, 1 explicit, 2 implicit (B only) */
+    const int wmode = bslice ? d->apps->weighted_bipred_idc : (d->apps->weighted_pred_flag ? 1 : 0);
     for (int blk = 0; blk < 16; blk++) {
-        int bx = blk & 3, by = blk >> 2;
-        int refidx = m->ref[(by >> 1) * 2 + (bx >> 1)];
-        h264o_pic *rp = (refidx >= 0 && refidx <= 32) ? d->rpl0[refidx] : NULL;
-        if (!rp) rp = d->cur; /* missing reference: conceal with the current picture (never hit on valid streams) */
-        int mvx = m->mv[blk][0], mvy = m->mv[blk][1];
+        int bx = blk & 3, by = blk >> 2, i8 = (by >> 1) * 2 + (bx >> 1);
         int x0 = c->mbx * 16 + bx * 4, y0 = c->mby * 16 + by * 4;
-        uint8_t *dy = d->cur->plane[0] + y0 * d->cur->stride[0] + x0;
-        for (int y = 0; y < 4; y++)
-            for (int x = 0; x < 4; x++) {
-                int v = luma_sample(rp->plane[0], rp->stride[0], W, H, x0 + x + (mvx >> 2), y0 + y + (mvy >> 2), mvx & 3, mvy & 3);
-                if (wp) {
-                    int lw = sh->luma_log2_weight_denom, w0 = sh->luma_weight_l0[refidx], o0 = sh->luma_offset_l0[refidx];
-                    v = lw >= 1 ? h264o_clip1(((v * w0 + (1 << (lw - 1))) >> lw) + o0) : h264o_clip1(v * w0 + o0);
-                }
-                dy[y * d->cur->stride[0] + x] = (uint8_t)v;
-            }
-        /* chroma 8.4.2.2.2: 2x2 samples per 4x4 luma block, mv in 1/8 chroma sample units */
-        int cx0 = x0 >> 1, cy0 = y0 >> 1, xf = mvx & 7, yf = mvy & 7;
-        for (int pl = 1; pl < 3; pl++) {
-            uint8_t *dc = d->cur->plane[pl] + cy0 * d->cur->stride[pl] + cx0;
-            const uint8_t *rc = rp->plane[pl];
-            int rs = rp->stride[pl];
-            for (int y = 0; y < 2; y++)
-                for (int x = 0; x < 2; x++) {
-                    int xi = cx0 + x + (mvx >> 3), yi = cy0 + y + (mvy >> 3);
-                    int A = refpix(rc, rs, W / 2, H / 2, xi, yi), B = refpix(rc, rs, W / 2, H / 2, xi + 1, yi);
-                    int C = refpix(rc, rs, W / 2, H / 2, xi, yi + 1), D = refpix(rc, rs, W / 2, H / 2, xi + 1, yi + 1);
-                    int v = ((8 - xf) * (8 - yf) * A + xf * (8 - yf) * B + (8 - xf) * yf * C + xf * yf * D + 32) >> 6;
-                    if (wp) {
-                        int lw = sh->chroma_log2_weight_denom, w0 = sh->chroma_weight_l0[refidx][pl - 1], o0 = sh->chroma_offset_l0[refidx][pl - 1];
-                        v = lw >= 1 ? h264o_clip1(((v * w0 + (1 << (lw - 1))) >> lw) + o0) : h264o_clip1(v * w0 + o0);
+        int cx0 = x0 >> 1, cy0 = y0 >> 1;
+        int py[2][16], pc[2][2][4], used[2], refidx[2];
+        h264o_pic *rp[2];
+        for (int l = 0; l < 2; l++) {
+            refidx[l] = l ? m->ref1[i8] : m->ref[i8];
+            used[l] = refidx[l] >= 0;
+            rp[l] = NULL;
+            if (!used[l]) continue;
+            rp[l] = refidx[l] <= 32 ? (l ? d->rpl1[refidx[l]] : d->rpl0[refidx[l]]) : NULL;
+            if (!rp[l]) rp[l] = d->cur; /* missing reference: conceal with the current picture (never hit on valid streams) */
+            int mvx = l ? m->mv1[blk][0] : m->mv[blk][0], mvy = l ? m->mv1[blk][1] : m->mv[blk][1];
+            for (int y = 0; y < 4; y++)
+                for (int x = 0; x < 4; x++)
+                    py[l][y * 4 + x] = luma_sample(rp[l]->plane[0], rp[l]->stride[0], W, H, x0 + x + (mvx >> 2), y0 + y + (mvy >> 2), mvx & 3, mvy & 3);
+            /* chroma 8.4.2.2.2: 2x2 samples per 4x4 luma block, mv in 1/8 chroma sample units */
+            int xf = mvx & 7, yf = mvy & 7;
+            for (int pl = 1; pl < 3; pl++) {
+                const uint8_t *rc = rp[l]->plane[pl];
+                int rs = rp[l]->stride[pl];
+                for (int y = 0; y < 2; y++)
+                    for (int x = 0; x < 2; x++) {
+                        int xi = cx0 + x + (mvx >> 3), yi = cy0 + y + (mvy >> 3);
+                        int A = refpix(rc, rs, W / 2, H / 2, xi, yi), B = refpix(rc, rs, W / 2, H / 2, xi + 1, yi);
+                        int C = refpix(rc, rs, W / 2, H / 2, xi, yi + 1), D = refpix(rc, rs, W / 2, H / 2, xi + 1, yi + 1);
+                        pc[l][pl - 1][y * 2 + x] = ((8 - xf) * (8 - yf) * A + xf * (8 - yf) * B + (8 - xf) * yf * C + xf * yf * D + 32) >> 6;
                     }
-                    dc[y * d->cur->stride[pl] + x] = (uint8_t)v;
+            }
+        }
+        if (!used[0] && !used[1]) used[0] = 1, refidx[0] = 0, memset(py[0], 128, sizeof(py[0])), memset(pc[0], 128, sizeof(pc[0])); /* cannot happen */
+        /* weights of this block: luma and the two chroma planes */
+        int lw = sh->luma_log2_weight_denom, cw = sh->chroma_log2_weight_denom;
+        int iw0 = 32, iw1 = 32;
+        if (wmode == 2 && used[0] && used[1]) implicit_weights(d, rp[0], rp[1], &iw0, &iw1);
+        for (int comp = 0; comp < 3; comp++) {
+            int n = comp == 0 ? 16 : 4;
+            uint8_t *dst = comp == 0 ? d->cur->plane[0] + y0 * d->cur->stride[0] + x0 : d->cur->plane[comp] + cy0 * d->cur->stride[comp] + cx0;
+            int stride = d->cur->stride[comp], wdt = comp == 0 ? 4 : 2;
+            for (int i = 0; i < n; i++) {
+                int a = comp == 0 ? py[0][i] : pc[0][comp - 1][i], bb = comp == 0 ? py[1][i] : pc[1][comp - 1][i], v;
+                if (used[0] && used[1]) {
+                    if (wmode == 1) {
+                        int w0 = comp ? sh->chroma_weight_l0[refidx[0]][comp - 1] : sh->luma_weight_l0[refidx[0]];
+                        int w1 = comp ? sh->chroma_weight_l1[refidx[1]][comp - 1] : sh->luma_weight_l1[refidx[1]];
+                        int o0 = comp ? sh->chroma_offset_l0[refidx[0]][comp - 1] : sh->luma_offset_l0[refidx[0]];
+                        int o1 = comp ? sh->chroma_offset_l1[refidx[1]][comp - 1] : sh->luma_offset_l1[refidx[1]];
+                        v = weight2(a, bb, comp ? cw : lw, w0, w1, o0, o1);
+                    } else if (wmode == 2)
+                        v = weight2(a, bb, 5, iw0, iw1, 0, 0);
+                    else
+                        v = (a + bb + 1) >> 1;
+                } else {
+                    int l = used[0] ? 0 : 1;
+                    v = l ? bb : a;
+                    if (wmode == 1) {
+                        int w = l ? (comp ? sh->chroma_weight_l1[refidx[1]][comp - 1] : sh->luma_weight_l1[refidx[1]])
+                                  : (comp ? sh->chroma_weight_l0[refidx[0]][comp - 1] : sh->luma_weight_l0[refidx[0]]);
+                        int o = l ? (comp ? sh->chroma_offset_l1[refidx[1]][comp - 1] : sh->luma_offset_l1[refidx[1]])
+                                  : (comp ? sh->chroma_offset_l0[refidx[0]][comp - 1] : sh->luma_offset_l0[refidx[0]]);
+                        v = weight1(v, comp ? cw : lw, w, o);
+                    }
                 }
+                dst[(i / wdt) * stride + (i % wdt)] = (uint8_t)v;
+            }
         }
     }
 }
@@ -656,13 +705,27 @@ static void filter_line(uint8_t *pix, int xs, int bS, int alpha, int beta, int t
 }
 
 /* 8.7.2.1 bS for the 4-sample segment between 4x4 blocks pb (in MB mp) and qb (in MB mq) */
+static int mv_far(const int16_t *a, const int16_t *b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
 static int edge_bs(const h264o_mb *mp, int pb, const h264o_mb *mq, int qb, int mb_edge) {
     if (MB_IS_INTRA(mp->type) || MB_IS_INTRA(mq->type)) return mb_edge ? 4 : 3;
     if (((mp->nzmask >> pb) & 1) || ((mq->nzmask >> qb) & 1)) return 2;
-    int rp = mp->refid[(pb >> 3) * 2 + ((pb & 3) >> 1)], rq = mq->refid[(qb >> 3) * 2 + ((qb & 3) >> 1)];
-    if (rp != rq) return 1;
-    if (abs(mp->mv[pb][0] - mq->mv[qb][0]) >= 4 || abs(mp->mv[pb][1] - mq->mv[qb][1]) >= 4) return 1;
-    return 0;
+    /* different reference pictures or a different number of motion vectors; which list a picture is referenced through does not matter */
+    int p8 = (pb >> 3) * 2 + ((pb & 3) >> 1), q8 = (qb >> 3) * 2 + ((qb & 3) >> 1);
+    int pr0 = mp->ref[p8] >= 0 ? mp->refid[p8] : -1, pr1 = mp->ref1[p8] >= 0 ? mp->refid1[p8] : -1;
+    int qr0 = mq->ref[q8] >= 0 ? mq->refid[q8] : -1, qr1 = mq->ref1[q8] >= 0 ? mq->refid1[q8] : -1;
+    const int16_t *pm0 = mp->mv[pb], *pm1 = mp->mv1[pb], *qm0 = mq->mv[qb], *qm1 = mq->mv1[qb];
+    int np = (pr0 >= 0) + (pr1 >= 0), nq = (qr0 >= 0) + (qr1 >= 0);
+    if (np != nq) return 1;
+    if (np == 1) {
+        int rp = pr0 >= 0 ? pr0 : pr1, rq = qr0 >= 0 ? qr0 : qr1;
+        if (rp != rq) return 1;
+        return mv_far(pr0 >= 0 ? pm0 : pm1, qr0 >= 0 ? qm0 : qm1);
+    }
+    if (!((pr0 == qr0 && pr1 == qr1) || (pr0 == qr1 && pr1 == qr0))) return 1;
+    if (pr0 != pr1) /* two different pictures: compare the vectors that point into the same picture */
+        return pr0 == qr0 ? (mv_far(pm0, qm0) || mv_far(pm1, qm1)) : (mv_far(pm0, qm1) || mv_far(pm1, qm0));
+    /* both vectors into the same picture: filtered unless one of the two pairings matches */
+    return (mv_far(pm0, qm0) || mv_far(pm1, qm1)) && (mv_far(pm0, qm1) || mv_far(pm1, qm0));
 }
 
 static void deblock_mb(h264o_decoder *d, int mbx, int mby) {

@@ -50,6 +50,12 @@ typedef struct {
     int idr_long_term;      /* 1: IDR pictures set long_term_reference_flag */
     int nonref_period;      /* N > 1: every N-th P picture is a non-reference picture (nal_ref_idc 0) */
     int slice_qp_delta;     /* d != 0: slice_qp_delta cycles through -d, 0, +d per slice */
+    /* B pictures (Main / High): `bframes` non-reference B pictures between two anchors (display order I B B P -> coding
+     * order I P B B); needs num_ref_frames >= 2 and forces pic_order_cnt_type 0 */
+    int bframes;
+    int direct_temporal;    /* 0: direct_spatial_mv_pred_flag = 1; 1: temporal direct */
+    int weighted_bipred;    /* weighted_bipred_idc: 0 default average, 1 explicit, 2 implicit */
+    int bskip_permille;     /* probability of B_Skip; B_Direct_16x16 gets half of it on top */
 } sg_params;
 
 void sg_default_params(sg_params *p);

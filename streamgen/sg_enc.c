@@ -13,7 +13,8 @@
 #include <string.h>
 #include "sg_int.h"
 
-enum { T_NONE = 0, T_I4, T_I8, T_I16, T_PCM, T_P16, T_P16x8, T_P8x16, T_P8x8, T_SKIP };
+enum { T_NONE = 0, T_I4, T_I8, T_I16, T_PCM, T_P16, T_P16x8, T_P8x16, T_P8x8, T_SKIP, T_BDIRECT, T_BSKIP };
+#define IS_SKIPPED(t) ((t) == T_SKIP || (t) == T_BSKIP)
 #define IS_INTRA(t) ((t) >= T_I4 && (t) <= T_PCM)
 #define IS_INTER(t) ((t) >= T_P16)
 
@@ -25,6 +26,11 @@ typedef struct {
     int16_t mv[16][2], mvd[16][2];
     int32_t refid[4];
     uint8_t sub[4];
+    /* list 1 of B macroblocks (ref / ref1 = -1: list not used by that 8x8 quadrant) */
+    int8_t ref1[4];
+    int16_t mv1[16][2], mvd1[16][2];
+    int32_t refid1[4];
+    uint8_t direct8; /* quadrants predicted in direct mode */
 } emb;
 
 typedef struct {
@@ -32,6 +38,11 @@ typedef struct {
     int wmb, hmb, W, H;
     sg_pic pics[6];
     sg_pic *cur, *refs[4];
+    sg_pic *refs1[4];             /* RefPicList1 of a B picture */
+    int nref1_active, cur_poc;
+    uint16_t done_l[2];           /* B macroblocks: per list, 4x4 blocks whose motion is final */
+    int cur_sub;                  /* sub-macroblock being coded: later ones are not available as neighbours (6.4.11.7) */
+    int wb_w1[4], wb_o1[4], wb_cw1[4][2], wb_co1[4][2]; /* explicit weights of list 1 */
     int nrefs, next_id;
     emb *mb;
     sg_dbmb *db;
@@ -388,6 +399,71 @@ static void cabac_intra_type(enc *e, int base, int islice, int it) {
     sg_cabac_bin(w, base + 3 + islice, pm >> 1);
     sg_cabac_bin(w, base + 3 + 2 * islice, pm & 1);
 }
+/* B slices: first bin of mb_type (ctxIdx 27 + neighbours that are neither B_Skip nor B_Direct_16x16), Table 9-37 (b) */
+static void cabac_b_type_bin0(enc *e, int bin) {
+    emb *a = MBA(e), *b = MBB(e);
+    int inc = (a && a->type != T_BSKIP && a->type != T_BDIRECT) + (b && b->type != T_BSKIP && b->type != T_BDIRECT);
+    sg_cabac_bin(&e->bw, 27 + inc, bin);
+}
+static void cabac_b_intra_prefix(enc *e) { /* "111101", then the intra suffix at ctxIdxOffset 32 */
+    sg_bw *w = &e->bw;
+    cabac_b_type_bin0(e, 1);
+    sg_cabac_bin(w, 27 + 3, 1);
+    sg_cabac_bin(w, 27 + 4, 1);
+    sg_cabac_bin(w, 27 + 5, 1);
+    sg_cabac_bin(w, 27 + 5, 0);
+    sg_cabac_bin(w, 27 + 5, 1);
+}
+static void cabac_b_mb_type(enc *e, int t) { /* mb_type 0..22 of Table 7-14 */
+    sg_bw *w = &e->bw;
+    cabac_b_type_bin0(e, t != 0);
+    if (t == 0) return;
+    if (t <= 2) {
+        sg_cabac_bin(w, 27 + 3, 0);
+        sg_cabac_bin(w, 27 + 5, t - 1);
+        return;
+    }
+    sg_cabac_bin(w, 27 + 3, 1);
+    int bits, extra = -1;
+    if (t <= 10)
+        bits = t - 3;
+    else if (t == 11)
+        bits = 14;
+    else if (t == 22)
+        bits = 15;
+    else
+        bits = (t + 4) >> 1, extra = (t + 4) & 1; /* 12..21 -> 8..12 + one more bin */
+    sg_cabac_bin(w, 27 + 4, (bits >> 3) & 1);
+    sg_cabac_bin(w, 27 + 5, (bits >> 2) & 1);
+    sg_cabac_bin(w, 27 + 5, (bits >> 1) & 1);
+    sg_cabac_bin(w, 27 + 5, bits & 1);
+    if (extra >= 0) sg_cabac_bin(w, 27 + 5, extra);
+}
+static void cabac_b_sub_type(enc *e, int st) { /* sub_mb_type 0..12 of Table 7-18, Table 9-38 (b) */
+    sg_bw *w = &e->bw;
+    sg_cabac_bin(w, 36, st != 0);
+    if (st == 0) return;
+    if (st <= 2) {
+        sg_cabac_bin(w, 37, 0);
+        sg_cabac_bin(w, 39, st - 1);
+        return;
+    }
+    sg_cabac_bin(w, 37, 1);
+    if (st <= 6) {
+        sg_cabac_bin(w, 38, 0);
+        sg_cabac_bin(w, 39, ((st - 3) >> 1) & 1);
+        sg_cabac_bin(w, 39, (st - 3) & 1);
+    } else if (st <= 10) {
+        sg_cabac_bin(w, 38, 1);
+        sg_cabac_bin(w, 39, 0);
+        sg_cabac_bin(w, 39, ((st - 7) >> 1) & 1);
+        sg_cabac_bin(w, 39, (st - 7) & 1);
+    } else {
+        sg_cabac_bin(w, 38, 1);
+        sg_cabac_bin(w, 39, 1);
+        sg_cabac_bin(w, 39, st - 11);
+    }
+}
 static void cabac_cbp(enc *e, int cbp) {
     sg_bw *w = &e->bw;
     emb *a = MBA(e), *b = MBB(e);
@@ -697,7 +773,9 @@ static void begin_mb(enc *e, int addr) {
     m->slice_id = (uint16_t)e->slice_id;
     memset(m->ipm, -1, sizeof(m->ipm));
     memset(m->ref, -1, sizeof(m->ref));
-    for (int i = 0; i < 4; i++) m->refid[i] = -1;
+    memset(m->ref1, -1, sizeof(m->ref1));
+    for (int i = 0; i < 4; i++) m->refid[i] = m->refid1[i] = -1;
+    e->done_l[0] = e->done_l[1] = 0, e->cur_sub = 3;
     memset(e->i16dc, 0, sizeof(e->i16dc));
     memset(e->luma, 0, sizeof(e->luma));
     memset(e->luma8, 0, sizeof(e->luma8));
@@ -728,6 +806,12 @@ static void end_mb(enc *e) {
     d->nzmask = m->nzmask;
     memcpy(d->mv, m->mv, sizeof(d->mv));
     memcpy(d->refid, m->refid, sizeof(d->refid));
+    memcpy(d->mv1, m->mv1, sizeof(d->mv1));
+    memcpy(d->refid1, m->refid1, sizeof(d->refid1));
+    for (int i = 0; i < 4; i++) { /* a list that is not used carries no picture */
+        if (m->ref[i] < 0) d->refid[i] = -1;
+        if (m->ref1[i] < 0) d->refid1[i] = -1;
+    }
 }
 
 /* choose the QP this MB would like to use */
@@ -768,12 +852,15 @@ static void encode_intra(enc *e, int islice) {
         if (cabac) {
             if (islice)
                 cabac_intra_type(e, 3, 1, 25);
-            else {
+            else if (e->slice_type == 1) {
+                cabac_b_intra_prefix(e);
+                cabac_intra_type(e, 32, 0, 25);
+            } else {
                 sg_cabac_bin(w, 14, 1);
                 cabac_intra_type(e, 17, 0, 25);
             }
         } else
-            sg_put_ue(w, islice ? 25 : 30);
+            sg_put_ue(w, islice ? 25 : (e->slice_type == 1 ? 48 : 30));
         while (!sg_bw_aligned(w)) sg_put(w, 0, 1);
         for (int i = 0; i < 384; i++) sg_put(w, e->pcm[i], 8);
         if (cabac) sg_cabac_start(w);
@@ -882,11 +969,14 @@ static void encode_intra(enc *e, int islice) {
     }
     /* ---- syntax ---- */
     int it = kind == T_I16 ? 1 + m->i16mode + 4 * m->cbp_chroma + (m->cbp_luma ? 12 : 0) : 0;
-    e->raw_type = islice ? it : it + 5;
+    e->raw_type = islice ? it : it + (e->slice_type == 1 ? 23 : 5);
     if (cabac) {
         if (islice)
             cabac_intra_type(e, 3, 1, it);
-        else {
+        else if (e->slice_type == 1) {
+            cabac_b_intra_prefix(e);
+            cabac_intra_type(e, 32, 0, it);
+        } else {
             sg_cabac_bin(w, 14, 1);
             cabac_intra_type(e, 17, 0, it);
         }
@@ -1191,6 +1281,408 @@ static void encode_inter(enc *e, int kind) {
     }
 }
 
+
+/* ------------------------------------------------------------------ B macroblocks (7.3.5 with Table 7-14 / 7-18, 8.4.1.2)
+ * Written next to the P path, not into it: P streams stay bit-identical.  Motion is kept per list; a quadrant uses a
+ * list when its ref / ref1 entry is >= 0. */
+#define EMV(m, l) ((l) ? (m)->mv1 : (m)->mv)
+#define EMVD(m, l) ((l) ? (m)->mvd1 : (m)->mvd)
+#define EREF(m, l) ((l) ? (m)->ref1 : (m)->ref)
+#define EREFID(m, l) ((l) ? (m)->refid1 : (m)->refid)
+
+static nmv get_nmv_l(enc *e, int l, int bx, int by) {
+    nmv r = {0, -1, 0, 0};
+    emb *m;
+    if (by >= 0 && bx > 3) return r;
+    if (bx >= 0 && bx <= 3 && by >= 0) {
+        if (!(e->done_l[l] >> (by * 4 + bx) & 1)) return r;
+        if ((by >> 1) * 2 + (bx >> 1) > e->cur_sub) return r; /* a later sub-macroblock (possible for direct ones, derived up front) */
+        m = CURMB(e);
+    } else {
+        m = mb_at(e, e->mbx + (bx < 0 ? -1 : (bx > 3 ? 1 : 0)), e->mby + (by < 0 ? -1 : 0));
+        if (!m) return r;
+        bx &= 3, by &= 3;
+    }
+    r.ok = 1;
+    if (IS_INTRA(m->type)) return r;
+    r.ref = EREF(m, l)[(by >> 1) * 2 + (bx >> 1)];
+    if (r.ref < 0) return r;
+    r.x = EMV(m, l)[by * 4 + bx][0];
+    r.y = EMV(m, l)[by * 4 + bx][1];
+    return r;
+}
+static void mv_pred_l(enc *e, int l, int bx, int by, int w, int ref, int shape, int out[2]) {
+    nmv A = get_nmv_l(e, l, bx - 1, by), B = get_nmv_l(e, l, bx, by - 1), C = get_nmv_l(e, l, bx + w, by - 1);
+    if (!C.ok) C = get_nmv_l(e, l, bx - 1, by - 1);
+    if (shape == 1 && B.ref == ref) { out[0] = B.x, out[1] = B.y; return; }
+    if ((shape == 2 || shape == 3) && A.ref == ref) { out[0] = A.x, out[1] = A.y; return; }
+    if (shape == 4 && C.ref == ref) { out[0] = C.x, out[1] = C.y; return; }
+    if (!B.ok && !C.ok && A.ok) B = A, C = A;
+    int hits = (A.ref == ref) + (B.ref == ref) + (C.ref == ref);
+    if (hits == 1) {
+        nmv s = A.ref == ref ? A : (B.ref == ref ? B : C);
+        out[0] = s.x, out[1] = s.y;
+        return;
+    }
+    out[0] = mid3(A.x, B.x, C.x);
+    out[1] = mid3(A.y, B.y, C.y);
+}
+static void fill_part_l(enc *e, int l, int bx, int by, int w, int h, const int mv[2], const int mvd[2]) {
+    emb *m = CURMB(e);
+    for (int y = by; y < by + h; y++)
+        for (int x = bx; x < bx + w; x++) {
+            EMV(m, l)[y * 4 + x][0] = (int16_t)mv[0], EMV(m, l)[y * 4 + x][1] = (int16_t)mv[1];
+            EMVD(m, l)[y * 4 + x][0] = (int16_t)abs(mvd[0]), EMVD(m, l)[y * 4 + x][1] = (int16_t)abs(mvd[1]);
+            e->done_l[l] |= (uint16_t)(1 << (y * 4 + x));
+        }
+}
+static void cabac_mvd_l(enc *e, int l, int comp, int bx, int by, int v) {
+    sg_bw *w = &e->bw;
+    int ia, ib;
+    emb *a = lnb(e, bx - 1, by, &ia), *b = lnb(e, bx, by - 1, &ib);
+    int sum = (a ? EMVD(a, l)[ia][comp] : 0) + (b ? EMVD(b, l)[ib][comp] : 0), base = comp ? 47 : 40, m = abs(v);
+    sg_cabac_bin(w, base + (sum > 2) + (sum > 32), m != 0);
+    if (!m) return;
+    int ctx = base + 3;
+    for (int k = 1; k < (m < 9 ? m : 9); k++) {
+        sg_cabac_bin(w, ctx, 1);
+        if (k < 4) ctx++;
+    }
+    if (m < 9)
+        sg_cabac_bin(w, ctx, 0);
+    else {
+        int s = m - 9, k = 3;
+        while (s >= (1 << k)) {
+            sg_cabac_bypass(w, 1);
+            s -= 1 << k;
+            k++;
+        }
+        sg_cabac_bypass(w, 0);
+        while (k--) sg_cabac_bypass(w, (s >> k) & 1);
+    }
+    sg_cabac_bypass(w, v < 0);
+}
+static void cabac_ref_l(enc *e, int l, int bx, int by, int ref) {
+    int ia, ib;
+    emb *a = lnb(e, bx - 1, by, &ia), *b = lnb(e, bx, by - 1, &ib);
+    int qa = (ia >> 3) * 2 + ((ia & 3) >> 1), qb = (ib >> 3) * 2 + ((ib & 3) >> 1);
+    /* quadrants predicted in direct mode count as refIdx 0 here (9.3.3.1.1.6) */
+    int ra = (a && !(a->direct8 >> qa & 1)) ? EREF(a, l)[qa] : 0, rb = (b && !(b->direct8 >> qb & 1)) ? EREF(b, l)[qb] : 0;
+    int ctx = (ra > 0) + 2 * (rb > 0);
+    for (int k = 0; k < ref; k++) {
+        sg_cabac_bin(&e->bw, 54 + ctx, 1);
+        ctx = (ctx >> 2) + 4;
+    }
+    sg_cabac_bin(&e->bw, 54 + ctx, 0);
+}
+
+/* co-located block of (bx, by) in RefPicList1[0] (direct_8x8_inference_flag = 1: the corner block of the quadrant) */
+static int col_block(enc *e, int bx, int by, int mv[2], int *pic_id) {
+    const sg_pic *col = e->refs1[0];
+    const emb *cm = col && col->motion ? &((const emb *)col->motion)[e->addr] : NULL;
+    mv[0] = mv[1] = 0, *pic_id = -1;
+    if (!cm || !IS_INTER(cm->type)) return -1;
+    int cx = (bx >> 1) * 3, cy = (by >> 1) * 3, q = (cy >> 1) * 2 + (cx >> 1), l = cm->ref[q] >= 0 ? 0 : 1;
+    if (EREF(cm, l)[q] < 0) return -1;
+    mv[0] = EMV(cm, l)[cy * 4 + cx][0], mv[1] = EMV(cm, l)[cy * 4 + cx][1];
+    *pic_id = EREFID(cm, l)[q];
+    return EREF(cm, l)[q];
+}
+static int poc_clip(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }
+/* DistScaleFactor of 8.4.1.2.3 / 8.4.2.3.1; returns 0 when no scaling applies (long-term or equal POCs) */
+static int dist_scale(int cur, int p0, int p1, int lt, int *dsf) {
+    int tb = poc_clip(cur - p0), td = poc_clip(p1 - p0);
+    if (lt || td == 0) return 0;
+    int tx = (16384 + abs(td / 2)) / td, v = (tb * tx + 32) >> 6;
+    *dsf = v < -1024 ? -1024 : (v > 1023 ? 1023 : v);
+    return 1;
+}
+/* motion of the quadrants in mask8, predicted in direct mode */
+static void b_direct(enc *e, int mask8) {
+    emb *m = CURMB(e);
+    const int zero[2] = {0, 0};
+    if (!e->p.direct_temporal) { /* spatial: reference indices and vectors from the neighbours A, B, C of the macroblock */
+        int ref[2], mvp[2][2] = {{0, 0}, {0, 0}};
+        for (int l = 0; l < 2; l++) {
+            nmv A = get_nmv_l(e, l, -1, 0), B = get_nmv_l(e, l, 0, -1), C = get_nmv_l(e, l, 4, -1);
+            if (!C.ok) C = get_nmv_l(e, l, -1, -1);
+            int r = -1; /* the smallest non-negative one */
+            if (A.ref >= 0) r = A.ref;
+            if (B.ref >= 0 && (r < 0 || B.ref < r)) r = B.ref;
+            if (C.ref >= 0 && (r < 0 || C.ref < r)) r = C.ref;
+            ref[l] = r;
+        }
+        if (ref[0] < 0 && ref[1] < 0)
+            ref[0] = ref[1] = 0;
+        else
+            for (int l = 0; l < 2; l++)
+                if (ref[l] >= 0) mv_pred_l(e, l, 0, 0, 4, ref[l], 0, mvp[l]);
+        int col_is_short = e->refs1[0] && e->refs1[0]->is_ref == 1;
+        for (int q = 0; q < 4; q++) {
+            if (!(mask8 >> q & 1)) continue;
+            int cmv[2], cid, cref = col_block(e, (q & 1) * 2, (q >> 1) * 2, cmv, &cid);
+            int still = col_is_short && cref == 0 && abs(cmv[0]) <= 1 && abs(cmv[1]) <= 1; /* colZeroFlag */
+            for (int l = 0; l < 2; l++) {
+                EREF(m, l)[q] = (int8_t)ref[l];
+                fill_part_l(e, l, (q & 1) * 2, (q >> 1) * 2, 2, 2, (ref[l] < 0 || (ref[l] == 0 && still)) ? zero : mvp[l], zero);
+            }
+        }
+        return;
+    }
+    for (int q = 0; q < 4; q++) { /* temporal: the co-located vector scaled by the POC distances */
+        if (!(mask8 >> q & 1)) continue;
+        int cmv[2], cid, cref = col_block(e, (q & 1) * 2, (q >> 1) * 2, cmv, &cid), r0 = 0;
+        if (cref >= 0) {
+            r0 = -1;
+            for (int i = 0; i < e->nref_active && r0 < 0; i++)
+                if (e->refs[i]->id == cid) r0 = i;
+            if (r0 < 0) r0 = 0, cmv[0] = cmv[1] = 0; /* cannot happen: the anchors' references stay in the DPB */
+        }
+        int dsf = 0, mv0[2], mv1[2];
+        if (dist_scale(e->cur_poc, e->refs[r0]->poc, e->refs1[0]->poc, e->refs[r0]->is_ref == 2, &dsf)) {
+            for (int c = 0; c < 2; c++) mv0[c] = (dsf * cmv[c] + 128) >> 8, mv1[c] = mv0[c] - cmv[c];
+        } else
+            mv0[0] = cmv[0], mv0[1] = cmv[1], mv1[0] = mv1[1] = 0;
+        m->ref[q] = (int8_t)r0, m->ref1[q] = 0;
+        fill_part_l(e, 0, (q & 1) * 2, (q >> 1) * 2, 2, 2, mv0, zero);
+        fill_part_l(e, 1, (q & 1) * 2, (q >> 1) * 2, 2, 2, mv1, zero);
+    }
+}
+
+/* prediction samples of the whole macroblock from its per-list motion (8.4.2.2, 8.4.2.3) */
+static void b_predict(enc *e, uint8_t *py, uint8_t pc[2][64]) {
+    emb *m = CURMB(e);
+    const int idc = e->p.weighted_bipred;
+    for (int blk = 0; blk < 16; blk++) {
+        int bx = blk & 3, by = blk >> 2, q = (by >> 1) * 2 + (bx >> 1);
+        uint8_t ty[2][16], tc[2][2][4];
+        int use[2] = {m->ref[q] >= 0, m->ref1[q] >= 0};
+        sg_pic *rp[2] = {use[0] ? e->refs[m->ref[q]] : NULL, use[1] ? e->refs1[m->ref1[q]] : NULL};
+        for (int l = 0; l < 2; l++) {
+            if (!use[l]) continue;
+            int mvx = EMV(m, l)[blk][0], mvy = EMV(m, l)[blk][1];
+            sg_mc_luma(rp[l], e->mbx * 16 + bx * 4, e->mby * 16 + by * 4, 4, 4, mvx, mvy, ty[l], 4);
+            for (int c = 0; c < 2; c++) sg_mc_chroma(rp[l], 1 + c, e->mbx * 8 + bx * 2, e->mby * 8 + by * 2, 2, 2, mvx, mvy, tc[l][c], 2);
+        }
+        int iw[2] = {32, 32};
+        if (idc == 2 && use[0] && use[1]) {
+            int dsf = 0;
+            if (rp[1]->is_ref != 2 && dist_scale(e->cur_poc, rp[0]->poc, rp[1]->poc, rp[0]->is_ref == 2, &dsf) && (dsf >> 2) >= -64 && (dsf >> 2) <= 128)
+                iw[0] = 64 - (dsf >> 2), iw[1] = dsf >> 2;
+        }
+        for (int comp = 0; comp < 3; comp++) {
+            int n = comp ? 4 : 16, wd = comp ? 2 : 4;
+            int ld = comp ? e->wp_cd : e->wp_ld;
+            int w0 = use[0] ? (comp ? e->wp_cw[m->ref[q]][comp - 1] : e->wp_w[m->ref[q]]) : 0, o0 = use[0] ? (comp ? e->wp_co[m->ref[q]][comp - 1] : e->wp_o[m->ref[q]]) : 0;
+            int w1 = use[1] ? (comp ? e->wb_cw1[m->ref1[q]][comp - 1] : e->wb_w1[m->ref1[q]]) : 0, o1 = use[1] ? (comp ? e->wb_co1[m->ref1[q]][comp - 1] : e->wb_o1[m->ref1[q]]) : 0;
+            for (int i = 0; i < n; i++) {
+                int a = comp ? tc[0][comp - 1][i] : ty[0][i], b = comp ? tc[1][comp - 1][i] : ty[1][i], v;
+                if (use[0] && use[1]) {
+                    if (idc == 1)
+                        v = ((a * w0 + b * w1 + (1 << ld)) >> (ld + 1)) + ((o0 + o1 + 1) >> 1);
+                    else if (idc == 2)
+                        v = (a * iw[0] + b * iw[1] + 32) >> 6;
+                    else
+                        v = (a + b + 1) >> 1;
+                } else {
+                    v = use[0] ? a : b;
+                    if (idc == 1) {
+                        int ww = use[0] ? w0 : w1, oo = use[0] ? o0 : o1;
+                        v = ld >= 1 ? ((v * ww + (1 << (ld - 1))) >> ld) + oo : v * ww + oo;
+                    }
+                }
+                v = v < 0 ? 0 : (v > 255 ? 255 : v);
+                if (comp == 0)
+                    py[(by * 4 + i / wd) * 16 + bx * 4 + i % wd] = (uint8_t)v;
+                else
+                    pc[comp - 1][(by * 2 + i / wd) * 8 + bx * 2 + i % wd] = (uint8_t)v;
+            }
+        }
+    }
+}
+
+static const uint8_t b_pair_modes[9][2] = {{1, 1}, {2, 2}, {1, 2}, {2, 1}, {1, 3}, {2, 3}, {3, 1}, {3, 2}, {3, 3}}; /* Table 7-14, mb_type 4..21 */
+static const uint8_t b_sub_mode[13] = {0, 1, 2, 3, 1, 1, 2, 2, 3, 3, 1, 2, 3};                                      /* Table 7-18: 0 = direct */
+static const uint8_t b_sub_shape[13] = {0, 0, 0, 0, 1, 2, 1, 2, 1, 2, 3, 3, 3};                                     /* 0 8x8, 1 8x4, 2 4x8, 3 4x4 */
+typedef struct {
+    int bx, by, w, h, shape, mode, sub, mvd[2][2];
+} bpart;
+
+/* kind: T_BSKIP, T_BDIRECT, T_P16 (16x16), T_P16x8, T_P8x16, T_P8x8 */
+static void encode_b(enc *e, int kind) {
+    emb *m = CURMB(e);
+    sg_bw *w = &e->bw;
+    const int cabac = e->p.cabac;
+    bpart pt[16];
+    int np = 0, raw = 0;
+    m->type = (uint8_t)kind;
+    if (kind == T_BSKIP || kind == T_BDIRECT) {
+        m->direct8 = 15;
+        b_direct(e, 15);
+    } else if (kind == T_P8x8) {
+        raw = 22;
+        for (int i = 0; i < 4; i++) {
+            int st = (int)(rnd(e) % 13);
+            m->sub[i] = (uint8_t)st;
+            if (b_sub_mode[st] == 0) m->direct8 |= (uint8_t)(1 << i);
+        }
+        if (m->direct8) {
+            e->cur_sub = -1;
+            b_direct(e, m->direct8);
+        }
+        for (int i = 0; i < 4; i++) {
+            int st = m->sub[i], bx = (i & 1) * 2, by = (i >> 1) * 2, md = b_sub_mode[st];
+            if (!md) continue;
+            switch (b_sub_shape[st]) {
+            case 0: pt[np++] = (bpart){bx, by, 2, 2, 0, md, i, {{0, 0}, {0, 0}}}; break;
+            case 1: pt[np++] = (bpart){bx, by, 2, 1, 0, md, i, {{0, 0}, {0, 0}}}, pt[np++] = (bpart){bx, by + 1, 2, 1, 0, md, i, {{0, 0}, {0, 0}}}; break;
+            case 2: pt[np++] = (bpart){bx, by, 1, 2, 0, md, i, {{0, 0}, {0, 0}}}, pt[np++] = (bpart){bx + 1, by, 1, 2, 0, md, i, {{0, 0}, {0, 0}}}; break;
+            default:
+                for (int k = 0; k < 4; k++) pt[np++] = (bpart){bx + (k & 1), by + (k >> 1), 1, 1, 0, md, i, {{0, 0}, {0, 0}}};
+            }
+        }
+    } else {
+        int m0 = 1 + (int)(rnd(e) % 3), m1 = 1 + (int)(rnd(e) % 3);
+        if (kind == T_P16) {
+            raw = m0;
+            pt[np++] = (bpart){0, 0, 4, 4, 0, m0, 3, {{0, 0}, {0, 0}}};
+        } else {
+            int k = 0;
+            while (b_pair_modes[k][0] != m0 || b_pair_modes[k][1] != m1) k++;
+            raw = 4 + 2 * k + (kind == T_P8x16);
+            if (kind == T_P16x8)
+                pt[np++] = (bpart){0, 0, 4, 2, 1, m0, 3, {{0, 0}, {0, 0}}}, pt[np++] = (bpart){0, 2, 4, 2, 2, m1, 3, {{0, 0}, {0, 0}}};
+            else
+                pt[np++] = (bpart){0, 0, 2, 4, 3, m0, 3, {{0, 0}, {0, 0}}}, pt[np++] = (bpart){2, 0, 2, 4, 4, m1, 3, {{0, 0}, {0, 0}}};
+        }
+    }
+    /* reference indices: one per (quadrant-aligned partition, list); then the vectors, list by list in decoding order */
+    const int nref[2] = {e->nref_active, e->nref1_active};
+    for (int l = 0; l < 2; l++) {
+        if (kind == T_P8x8) { /* one index per non-direct quadrant that uses the list */
+            for (int i = 0; i < 4; i++)
+                if (b_sub_mode[m->sub[i]] >> l & 1) EREF(m, l)[i] = (int8_t)((nref[l] > 1 && rnd(e) % 100 < 35) ? rnd_range(e, 0, nref[l] - 1) : 0);
+            continue;
+        }
+        for (int i = 0; i < np; i++) {
+            if (!(pt[i].mode >> l & 1)) continue;
+            int r = (nref[l] > 1 && rnd(e) % 100 < 35) ? rnd_range(e, 0, nref[l] - 1) : 0;
+            for (int y = pt[i].by >> 1; y < (pt[i].by + pt[i].h + 1) >> 1; y++)
+                for (int x = pt[i].bx >> 1; x < (pt[i].bx + pt[i].w + 1) >> 1; x++) EREF(m, l)[y * 2 + x] = (int8_t)r;
+        }
+    }
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < np; i++) {
+            bpart *p = &pt[i];
+            if (!(p->mode >> l & 1)) continue;
+            int mvp[2], mv[2], ref = EREF(m, l)[(p->by >> 1) * 2 + (p->bx >> 1)];
+            e->cur_sub = p->sub;
+            mv_pred_l(e, l, p->bx, p->by, p->w, ref, p->shape, mvp);
+            pick_mv(e, e->mbx * 16 + p->bx * 4, e->mby * 16 + p->by * 4, p->w * 4, p->h * 4, l ? e->refs1[ref] : e->refs[ref], mvp, mv);
+            p->mvd[l][0] = mv[0] - mvp[0], p->mvd[l][1] = mv[1] - mvp[1];
+            fill_part_l(e, l, p->bx, p->by, p->w, p->h, mv, p->mvd[l]);
+        }
+    e->cur_sub = 3;
+    for (int i = 0; i < 4; i++) {
+        m->refid[i] = m->ref[i] >= 0 ? e->refs[m->ref[i]]->id : -1;
+        m->refid1[i] = m->ref1[i] >= 0 ? e->refs1[m->ref1[i]]->id : -1;
+    }
+    uint8_t py[256], pc[2][64];
+    b_predict(e, py, pc);
+    if (kind == T_BSKIP) {
+        set_qpc(e, m, e->qp);
+        for (int y = 0; y < 16; y++) memcpy(e->cur->pl[0] + (e->mby * 16 + y) * e->W + e->mbx * 16, py + 16 * y, 16);
+        for (int c = 0; c < 2; c++)
+            for (int y = 0; y < 8; y++) memcpy(e->cur->pl[1 + c] + (e->mby * 8 + y) * (e->W / 2) + e->mbx * 8, pc[c] + 8 * y, 8);
+        e->prev_dqp_nz = 0;
+        e->raw_type = -1;
+        return;
+    }
+    int qp = want_qp(e);
+    set_qpc(e, m, qp);
+    int all8 = 1; /* no sub-partition smaller than 8x8 (direct quadrants count as 8x8: direct_8x8_inference_flag = 1) */
+    if (kind == T_P8x8)
+        for (int i = 0; i < 4; i++)
+            if (b_sub_shape[m->sub[i]]) all8 = 0;
+    m->t8x8 = (e->p.transform8x8 && all8 && rnd(e) % 2) ? 1 : 0;
+    code_luma_inter(e, py);
+    if (!m->cbp_luma) m->t8x8 = 0;
+    code_chroma(e, 0, pc);
+    /* ---- syntax ---- */
+    e->raw_type = raw;
+    if (cabac)
+        cabac_b_mb_type(e, raw);
+    else
+        sg_put_ue(w, (uint32_t)raw);
+    if (kind == T_P8x8)
+        for (int i = 0; i < 4; i++) {
+            if (cabac)
+                cabac_b_sub_type(e, m->sub[i]);
+            else
+                sg_put_ue(w, m->sub[i]);
+        }
+    for (int l = 0; l < 2; l++) {
+        if (nref[l] <= 1) continue;
+        if (kind == T_P8x8) {
+            for (int i = 0; i < 4; i++) {
+                if (!(b_sub_mode[m->sub[i]] >> l & 1)) continue;
+                if (cabac)
+                    cabac_ref_l(e, l, (i & 1) * 2, (i >> 1) * 2, EREF(m, l)[i]);
+                else
+                    sg_put_te(w, nref[l] - 1, (uint32_t)EREF(m, l)[i]);
+            }
+            continue;
+        }
+        for (int i = 0; i < np; i++) {
+            if (!(pt[i].mode >> l & 1)) continue;
+            int ref = EREF(m, l)[(pt[i].by >> 1) * 2 + (pt[i].bx >> 1)];
+            if (cabac)
+                cabac_ref_l(e, l, pt[i].bx, pt[i].by, ref);
+            else
+                sg_put_te(w, nref[l] - 1, (uint32_t)ref);
+        }
+    }
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < np; i++) {
+            if (!(pt[i].mode >> l & 1)) continue;
+            if (cabac) {
+                cabac_mvd_l(e, l, 0, pt[i].bx, pt[i].by, pt[i].mvd[l][0]);
+                cabac_mvd_l(e, l, 1, pt[i].bx, pt[i].by, pt[i].mvd[l][1]);
+            } else {
+                sg_put_se(w, pt[i].mvd[l][0]);
+                sg_put_se(w, pt[i].mvd[l][1]);
+            }
+        }
+    int cbp = m->cbp_luma | (m->cbp_chroma << 4);
+    if (cabac)
+        cabac_cbp(e, cbp);
+    else {
+        int k = 0;
+        while (sg_me_inter[k] != cbp) k++;
+        sg_put_ue(w, (uint32_t)k);
+    }
+    if (m->cbp_luma && e->p.transform8x8 && all8) {
+        if (cabac) {
+            emb *a = MBA(e), *b = MBB(e);
+            sg_cabac_bin(w, 399 + (a && a->t8x8) + (b && b->t8x8), m->t8x8);
+        } else
+            sg_put(w, m->t8x8, 1);
+    }
+    if (cbp) {
+        int dqp = qp - e->qp;
+        if (cabac)
+            cabac_dqp(e, dqp);
+        else
+            sg_put_se(w, dqp);
+        e->prev_dqp_nz = dqp != 0;
+        e->qp = qp;
+        write_residual(e);
+    } else {
+        e->prev_dqp_nz = 0;
+        set_qpc(e, m, e->qp);
+    }
+}
+
 /* The CABAC mvd ctxIdxInc of partition k reads |mvd| of neighbouring partitions that precede k.  In
  * encode_inter all partitions' mvd are already stored when the syntax is written, which would let
  * a later partition's values leak into an earlier one's context if the A/B neighbour were a LATER
@@ -1263,7 +1755,7 @@ static size_t write_pps(enc *e, uint8_t *dst, size_t cap) {
     sg_put_ue(&w, (uint32_t)(p->num_ref_frames - 1));
     sg_put_ue(&w, 0);
     sg_put(&w, (uint32_t)p->weighted_pred, 1);
-    sg_put(&w, 0, 2);
+    sg_put(&w, (uint32_t)p->weighted_bipred, 2); /* weighted_bipred_idc */
     sg_put_se(&w, p->qp - 26);
     sg_put_se(&w, 0);
     sg_put_se(&w, p->chroma_qp_offset);
@@ -1282,18 +1774,22 @@ static size_t write_pps(enc *e, uint8_t *dst, size_t cap) {
 static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int idr_id, int poc_lsb) {
     sg_bw *w = &e->bw;
     const sg_params *p = &e->p;
-    int is_p = e->slice_type == 0;
+    int is_b = e->slice_type == 1, is_p = e->slice_type == 0 || is_b; /* is_p: a slice with reference lists */
     sg_put_ue(w, (uint32_t)first_mb);
-    sg_put_ue(w, is_p ? 5 : 7); /* slice_type: all slices of the picture alike */
+    sg_put_ue(w, is_b ? 6 : (is_p ? 5 : 7)); /* slice_type: all slices of the picture alike */
     sg_put_ue(w, 0);
     sg_put(w, (uint32_t)frame_num, 8);
     if (idr) sg_put_ue(w, (uint32_t)idr_id);
     if (p->poc_type == 0) sg_put(w, (uint32_t)poc_lsb, 8);
     if (p->poc_type == 1) sg_put_se(w, e->delta_poc0); /* delta_pic_order_cnt[0] (delta_pic_order_always_zero_flag = 0) */
+    if (is_b) sg_put(w, e->p.direct_temporal ? 0 : 1, 1); /* direct_spatial_mv_pred_flag */
     if (is_p) {
-        int over = e->nref_active != p->num_ref_frames;
+        int over = e->nref_active != p->num_ref_frames || (is_b && e->nref1_active != 1);
         sg_put(w, (uint32_t)over, 1);
-        if (over) sg_put_ue(w, (uint32_t)(e->nref_active - 1));
+        if (over) {
+            sg_put_ue(w, (uint32_t)(e->nref_active - 1));
+            if (is_b) sg_put_ue(w, (uint32_t)(e->nref1_active - 1));
+        }
         sg_put(w, e->n_rplm > 0, 1); /* ref_pic_list_modification_flag_l0 */
         if (e->n_rplm > 0) {
             for (int i = 0; i < e->n_rplm; i++) {
@@ -1302,7 +1798,8 @@ static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int
             }
             sg_put_ue(w, 3);
         }
-        if (p->weighted_pred) {
+        if (is_b) sg_put(w, 0, 1); /* ref_pic_list_modification_flag_l1 */
+        if ((p->weighted_pred && !is_b) || (is_b && p->weighted_bipred == 1)) {
             sg_put_ue(w, (uint32_t)e->wp_ld);
             sg_put_ue(w, (uint32_t)e->wp_cd);
             for (int i = 0; i < e->nref_active; i++) {
@@ -1313,6 +1810,15 @@ static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int
                 sg_put(w, (uint32_t)cf, 1);
                 if (cf)
                     for (int c = 0; c < 2; c++) sg_put_se(w, e->wp_cw[i][c]), sg_put_se(w, e->wp_co[i][c]);
+            }
+            for (int i = 0; is_b && i < e->nref1_active; i++) { /* list 1 */
+                int lf = e->wb_w1[i] != (1 << e->wp_ld) || e->wb_o1[i];
+                sg_put(w, (uint32_t)lf, 1);
+                if (lf) sg_put_se(w, e->wb_w1[i]), sg_put_se(w, e->wb_o1[i]);
+                int cf = e->wb_cw1[i][0] != (1 << e->wp_cd) || e->wb_co1[i][0] || e->wb_cw1[i][1] != (1 << e->wp_cd) || e->wb_co1[i][1];
+                sg_put(w, (uint32_t)cf, 1);
+                if (cf)
+                    for (int c = 0; c < 2; c++) sg_put_se(w, e->wb_cw1[i][c]), sg_put_se(w, e->wb_co1[i][c]);
             }
         }
     }
@@ -1386,10 +1892,13 @@ static void plan_ref_list(enc *e) {
     for (int i = 0; i < nlt; i++) init[n++] = lt[i];
     e->nrefs = n;
     e->nref_active = n < e->p.num_ref_frames ? n : e->p.num_ref_frames;
+    /* temporal direct maps the co-located block's reference picture into RefPicList0 of the B picture: an anchor must not
+     * predict from the one picture that its own arrival pushes out of the sliding window */
+    if (e->p.bframes > 0 && e->p.direct_temporal && e->nref_active > 1 && e->nref_active == e->p.num_ref_frames) e->nref_active--;
     e->n_rplm = 0;
     sg_pic *final[12];
     int nf = 0;
-    if (e->p.rplm && n >= 2 && rnd(e) % 100 < 75) {
+    if (e->p.rplm && !(e->p.bframes > 0 && e->p.direct_temporal) && n >= 2 && rnd(e) % 100 < 75) { /* (temporal direct: see above) */
         /* the first k entries become k distinct pictures picked from the WHOLE set of reference pictures */
         int k = 1 + (int)(rnd(e) % (uint32_t)(e->nref_active < 3 ? e->nref_active : 3));
         int pred = cur_fn; /* picNumL0Pred */
@@ -1424,6 +1933,53 @@ static void plan_ref_list(enc *e) {
     for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? final[i] : NULL;
     for (int i = 0; i < e->nref_active; i++)
         if (e->refs[i]->is_ref == 2) g_feat |= 1u << 11;
+}
+
+/* RefPicList0 / RefPicList1 of a B picture (8.2.4.2.3): by PicOrderCnt around the current picture */
+static void plan_b_lists(enc *e) {
+    sg_pic *past[6], *future[6];
+    int np = 0, nf = 0;
+    for (int i = 0; i < 6; i++) {
+        sg_pic *q = &e->pics[i];
+        if (q == e->cur || q->is_ref != 1) continue;
+        if (q->poc < e->cur_poc)
+            past[np++] = q;
+        else
+            future[nf++] = q;
+    }
+    for (int i = 0; i < np; i++) /* nearest past first */
+        for (int j = i + 1; j < np; j++)
+            if (past[j]->poc > past[i]->poc) {
+                sg_pic *t = past[i];
+                past[i] = past[j], past[j] = t;
+            }
+    for (int i = 0; i < nf; i++) /* nearest future first */
+        for (int j = i + 1; j < nf; j++)
+            if (future[j]->poc < future[i]->poc) {
+                sg_pic *t = future[i];
+                future[i] = future[j], future[j] = t;
+            }
+    sg_pic *l0[12], *l1[12];
+    int n = 0;
+    for (int i = 0; i < np; i++) l0[n++] = past[i];
+    for (int i = 0; i < nf; i++) l0[n++] = future[i];
+    n = 0;
+    for (int i = 0; i < nf; i++) l1[n++] = future[i];
+    for (int i = 0; i < np; i++) l1[n++] = past[i];
+    if (n > 1) { /* identical lists: the first two entries of list 1 trade places */
+        int same = 1;
+        for (int i = 0; i < n; i++) same &= l0[i] == l1[i];
+        if (same) {
+            sg_pic *t = l1[0];
+            l1[0] = l1[1], l1[1] = t;
+        }
+    }
+    e->nrefs = n;
+    e->nref_active = n < e->p.num_ref_frames ? n : e->p.num_ref_frames;
+    e->nref1_active = n < 2 ? n : 1 + (int)(rnd(e) % 2); /* one or two list-1 entries */
+    if (e->nref1_active > e->p.num_ref_frames) e->nref1_active = e->p.num_ref_frames;
+    for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? l0[i] : NULL, e->refs1[i] = i < e->nref1_active ? l1[i] : NULL;
+    e->n_rplm = 0;
 }
 
 /* Marking of the current (reference, non-IDR) picture.  plan_marking() draws a random script of memory management
@@ -1561,7 +2117,12 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
     if (p->num_ref_frames > 4) p->num_ref_frames = 4;
     if (p->slices < 1) p->slices = 1;
     if (p->profile_idc != 100) p->transform8x8 = 0, p->scaling_matrix = 0;
-    if (p->profile_idc == 66) p->cabac = 0, p->weighted_pred = 0;
+    if (p->profile_idc == 66) p->cabac = 0, p->weighted_pred = 0, p->bframes = 0;
+    if (p->bframes > 0) { /* B pictures: two anchors must be referable, and the output order differs from the coding order */
+        if (p->num_ref_frames < 2) p->num_ref_frames = 2;
+        p->poc_type = 0, p->nonref_period = 0, p->mmco = 0, p->idr_long_term = 0;
+        if (p->bframes > 3) p->bframes = 3;
+    }
     e->W = (p->width + 15) & ~15, e->H = (p->height + 15) & ~15;
     e->wmb = e->W / 16, e->hmb = e->H / 16;
     if (p->slices > e->hmb) p->slices = e->hmb;
@@ -1591,10 +2152,36 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
     int frame_num = 0, idr_id = 0, poc = 0, refs_since_reset = 0, since_idr = 0;
     static const int poc1_offsets[2] = {2, 6}; /* offset_for_ref_frame[] of write_sps() */
     g_feat = 0, g_npocs = 0;
+    /* coding order.  Without B pictures it is the display order.  With them every (bframes + 1)-th picture is an anchor
+     * (I or P) and the pictures between two anchors are B pictures coded right after the later anchor -- unless that anchor
+     * is an IDR picture or does not exist any more: then they are P pictures in display order (a closed group). */
+    int *disp = (int *)malloc(sizeof(int) * (size_t)p->frames), *is_b = (int *)calloc((size_t)p->frames, sizeof(int));
+    {
+        int n = 0, g = p->bframes + 1, a = 0;
+        while (a < p->frames) {
+            disp[n++] = a; /* an anchor that starts a chain of groups */
+            for (;;) {
+                int nx = a + g, nidr = p->idr_period > 0 && nx % p->idr_period == 0;
+                if (p->bframes > 0 && nx < p->frames && !nidr) {
+                    disp[n++] = nx; /* the later anchor first, then the B pictures between the two */
+                    for (int d = a + 1; d < nx; d++) is_b[n] = 1, disp[n++] = d;
+                    a = nx;
+                } else {
+                    for (int d = a + 1; d < nx && d < p->frames; d++) disp[n++] = d; /* closed group: P pictures in display order */
+                    a = nx;
+                    break;
+                }
+            }
+        }
+    }
+    int idr_disp = 0;
     for (int t = 0; t < p->frames; t++) {
         size_t au_start = out;
-        int idr = t == 0 || (p->idr_period > 0 && t % p->idr_period == 0);
-        sg_source_frame(p, t, e->src);
+        const int dsp = disp[t], bpic = is_b[t];
+        int idr = dsp == 0 || (p->idr_period > 0 && dsp % p->idr_period == 0);
+        sg_source_frame(p, dsp, e->src);
+        if (idr) idr_disp = dsp;
+        if (p->bframes > 0) poc = 2 * (dsp - idr_disp);
         if (idr) {
             frame_num = 0, poc = 0, e->nrefs = 0, refs_since_reset = 0, since_idr = 0;
             size_t n = write_sps(e, stream + out, cap - out);
@@ -1610,14 +2197,17 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         e->cur->id = e->next_id++;
         e->cur->frame_num = frame_num;
         e->cur_frame_num = frame_num;
-        e->slice_type = idr ? 2 : 0;
-        e->nal_ref_idc = (!idr && p->nonref_period > 1 && since_idr % p->nonref_period == p->nonref_period - 1) ? 0 : 3;
+        e->slice_type = idr ? 2 : (bpic ? 1 : 0);
+        e->cur->poc = e->cur_poc = poc;
+        e->nal_ref_idc = bpic ? 0 : ((!idr && p->nonref_period > 1 && since_idr % p->nonref_period == p->nonref_period - 1) ? 0 : 3);
         if (!e->nal_ref_idc) g_feat |= 1u << 12;
         e->idr_lt = idr && p->idr_long_term;
         e->n_rplm = e->n_mmco = 0;
         mark_state ms;
         memset(&ms, 0, sizeof(ms));
-        if (!idr) {
+        if (bpic)
+            plan_b_lists(e);
+        else if (!idr) {
             plan_ref_list(e);
             if (e->nal_ref_idc) plan_marking(e, &ms);
         }
@@ -1651,6 +2241,19 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             }
             e->wp_w[0] = 32, e->wp_o[0] = 0; /* first entry default: exercises the flag=0 path */
         }
+        if (bpic) { /* explicit weights of both lists (weighted_bipred_idc 1); unit weights otherwise, so that b_predict can index them blindly */
+            e->wp_ld = 5, e->wp_cd = 4;
+            for (int i = 0; i < 4; i++) {
+                int ex = p->weighted_bipred == 1;
+                e->wp_w[i] = 32 + (ex ? rnd_range(e, -3, 3) : 0), e->wp_o[i] = ex ? rnd_range(e, -2, 2) : 0;
+                e->wb_w1[i] = 32 + (ex ? rnd_range(e, -3, 3) : 0), e->wb_o1[i] = ex ? rnd_range(e, -2, 2) : 0;
+                for (int c = 0; c < 2; c++) {
+                    e->wp_cw[i][c] = 16 + (ex ? rnd_range(e, -1, 1) : 0), e->wp_co[i][c] = ex ? rnd_range(e, -1, 1) : 0;
+                    e->wb_cw1[i][c] = 16 + (ex ? rnd_range(e, -1, 1) : 0), e->wb_co1[i][c] = ex ? rnd_range(e, -1, 1) : 0;
+                }
+            }
+            e->wb_w1[0] = 32, e->wb_o1[0] = 0;
+        }
         for (int i = 0; i < e->wmb * e->hmb; i++) e->mb[i].type = T_NONE;
         for (int s = 0; s < p->slices; s++) {
             int row0 = e->hmb * s / p->slices, row1 = e->hmb * (s + 1) / p->slices;
@@ -1672,7 +2275,32 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
                 begin_mb(e, addr);
                 if (idr)
                     encode_intra(e, 1);
-                else {
+                else if (bpic) {
+                    int r = (int)(rnd(e) % 1000), kind, sk = p->bskip_permille;
+                    if (r < sk)
+                        kind = T_BSKIP;
+                    else if (r < sk + sk / 2)
+                        kind = T_BDIRECT;
+                    else if (r < sk + sk / 2 + p->intra_in_p_permille)
+                        kind = T_I4; /* any intra */
+                    else if (r < sk + sk / 2 + p->intra_in_p_permille + p->sub8x8_permille)
+                        kind = T_P16x8 + (int)(rnd(e) % 3);
+                    else
+                        kind = T_P16;
+                    if (p->cabac) {
+                        emb *a = MBA(e), *b = MBB(e);
+                        sg_cabac_bin(&e->bw, 24 + (a && !IS_SKIPPED(a->type)) + (b && !IS_SKIPPED(b->type)), kind == T_BSKIP);
+                    } else if (kind == T_BSKIP)
+                        e->skip_run++;
+                    else {
+                        sg_put_ue(&e->bw, (uint32_t)e->skip_run);
+                        e->skip_run = 0;
+                    }
+                    if (kind == T_I4)
+                        encode_intra(e, 0);
+                    else
+                        encode_b(e, kind);
+                } else {
                     int r = (int)(rnd(e) % 1000), kind;
                     if (r < p->skip_permille)
                         kind = T_SKIP;
@@ -1723,6 +2351,10 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         sg_deblock(e->cur, e->db, e->wmb, e->hmb);
         if (recon && (size_t)(t + 1) * fsz <= recon_cap) memcpy(recon + (size_t)t * fsz, e->cur->pl[0], fsz);
         apply_marking(e, &ms, idr);
+        if (e->cur->is_ref && p->bframes > 0) { /* a later B picture may take this one as its co-located picture */
+            if (!e->cur->motion) e->cur->motion = malloc(sizeof(emb) * (size_t)e->wmb * e->hmb);
+            memcpy(e->cur->motion, e->mb, sizeof(emb) * (size_t)e->wmb * e->hmb);
+        }
         since_idr++;
         poc += 2;
         if (e->nal_ref_idc) {
@@ -1738,7 +2370,9 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         if (frame_sizes) frame_sizes[t] = (uint32_t)(out - au_start);
     }
 done:
-    for (int i = 0; i < 6; i++) free(e->pics[i].pl[0]);
+    free(disp);
+    free(is_b);
+    for (int i = 0; i < 6; i++) free(e->pics[i].pl[0]), free(e->pics[i].motion);
     free(e->mb);
     free(e->db);
     free(e->src);

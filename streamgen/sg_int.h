@@ -41,6 +41,8 @@ typedef struct {
     int id, frame_num;
     int is_ref;   /* 0 unused for reference, 1 short-term, 2 long-term */
     int long_idx; /* LongTermFrameIdx when is_ref == 2 */
+    int poc;
+    void *motion; /* the picture's macroblock motion (an emb array of sg_enc.c): co-located data of later B pictures */
 } sg_pic;
 
 typedef struct {
@@ -72,6 +74,8 @@ typedef struct {
     uint16_t slice_id, nzmask;
     int16_t mv[16][2];
     int32_t refid[4];
+    int16_t mv1[16][2]; /* list 1 of B macroblocks; refid / refid1 = -1 where a list is not used */
+    int32_t refid1[4];
 } sg_dbmb;
 void sg_deblock(sg_pic *p, const sg_dbmb *mbs, int wmb, int hmb);
 

@@ -509,13 +509,31 @@ static void edge_line(uint8_t *q0p, int step, int bs, int alpha, int beta, int t
         q0p[i * step] = (uint8_t)nq[i];
     }
 }
+/* motion of one 4x4 block as a sorted set of (picture, vector) pairs: which list a picture came through is irrelevant (8.7.2.1) */
+typedef struct {
+    int n, pic[2], mvx[2], mvy[2];
+} blkmotion;
+static blkmotion motion_of(const sg_dbmb *m, int b) {
+    blkmotion r;
+    int q = (b / 8) * 2 + (b % 4) / 2;
+    r.n = 0;
+    if (m->refid[q] >= 0) r.pic[r.n] = m->refid[q], r.mvx[r.n] = m->mv[b][0], r.mvy[r.n] = m->mv[b][1], r.n++;
+    if (m->refid1[q] >= 0) r.pic[r.n] = m->refid1[q], r.mvx[r.n] = m->mv1[b][0], r.mvy[r.n] = m->mv1[b][1], r.n++;
+    return r;
+}
+static int close_mv(const blkmotion *a, int i, const blkmotion *b, int j) { return abs(a->mvx[i] - b->mvx[j]) < 4 && abs(a->mvy[i] - b->mvy[j]) < 4; }
 static int strength(const sg_dbmb *mp, int bp, const sg_dbmb *mq, int bq, int on_mb_edge) {
     if (mp->intra || mq->intra) return on_mb_edge ? 4 : 3;
     if ((mp->nzmask >> bp & 1) || (mq->nzmask >> bq & 1)) return 2;
-    int rp = mp->refid[(bp / 8) * 2 + (bp % 4) / 2], rq = mq->refid[(bq / 8) * 2 + (bq % 4) / 2];
-    if (rp != rq) return 1;
-    if (abs(mp->mv[bp][0] - mq->mv[bq][0]) >= 4 || abs(mp->mv[bp][1] - mq->mv[bq][1]) >= 4) return 1;
-    return 0;
+    blkmotion P = motion_of(mp, bp), Q = motion_of(mq, bq);
+    if (P.n != Q.n) return 1;
+    if (P.n == 1) return !(P.pic[0] == Q.pic[0] && close_mv(&P, 0, &Q, 0));
+    /* two vectors each: the same two pictures, and some pairing of vectors into the same picture that is close */
+    int straight = P.pic[0] == Q.pic[0] && P.pic[1] == Q.pic[1], crossed = P.pic[0] == Q.pic[1] && P.pic[1] == Q.pic[0];
+    if (!straight && !crossed) return 1;
+    if (straight && close_mv(&P, 0, &Q, 0) && close_mv(&P, 1, &Q, 1)) return 0;
+    if (crossed && close_mv(&P, 0, &Q, 1) && close_mv(&P, 1, &Q, 0)) return 0;
+    return 1;
 }
 void sg_deblock(sg_pic *pic, const sg_dbmb *mbs, int wmb, int hmb) {
     for (int my = 0; my < hmb; my++)

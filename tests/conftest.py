@@ -68,6 +68,9 @@ def real_stream():
 
 # the parity matrix shared by CPU (oracle vs generator) and GPU (product vs oracle + generator) tests
 BASE = dict(width=176, height=144, frames=4, idr_period=0)
+# Set when libh264mi decodes B slices; until then the GPU tests assert the documented refusal (H264MI_EUNSUPPORTED = -3).
+PRODUCT_DECODES_B = False
+
 MATRIX = {
     "cavlc_I": dict(width=64, height=48, frames=2, idr_period=1, profile_idc=66, cabac=0),
     "cabac_I": dict(width=64, height=48, frames=2, idr_period=1, profile_idc=77, cabac=1),
@@ -108,4 +111,18 @@ MATRIX = {
     "poc1_mmco": dict(BASE, frames=20, profile_idc=77, cabac=1, num_ref_frames=4, poc_type=1, mmco=1, rplm=1, nonref_period=4, qp=32, seed=38),
     "slice_qp_delta": dict(BASE, frames=5, profile_idc=77, cabac=1, slices=3, slice_qp_delta=5, qp=27, seed=39),
     "slice_qp_delta_cavlc": dict(BASE, frames=5, profile_idc=66, cabac=0, slices=2, slice_qp_delta=7, qp_jitter=3, qp=30, seed=40),
+    # B pictures: IBP / IBBP / IBBBP coding orders, spatial and temporal direct, B_Skip / B_Direct / all 22
+    # inter mb_types and 13 sub_mb_types, default / explicit / implicit bi-prediction weights, list 1
+    "b_ibp_cabac": dict(BASE, frames=9, profile_idc=77, cabac=1, bframes=1, num_ref_frames=2, bskip_permille=200, seed=41),
+    "b_ibp_cavlc": dict(BASE, frames=9, profile_idc=77, cabac=0, bframes=1, num_ref_frames=2, bskip_permille=200, seed=42),
+    "b_ibbp_cabac": dict(BASE, frames=10, profile_idc=77, cabac=1, bframes=2, num_ref_frames=3, bskip_permille=200, sub8x8_permille=300, seed=43),
+    "b_ibbp_cavlc": dict(BASE, frames=10, profile_idc=77, cabac=0, bframes=2, num_ref_frames=3, bskip_permille=200, sub8x8_permille=300, seed=44),
+    "b_temporal_cabac": dict(BASE, frames=13, profile_idc=77, cabac=1, bframes=2, num_ref_frames=2, direct_temporal=1, bskip_permille=300, seed=45),
+    "b_temporal_cavlc": dict(BASE, frames=13, profile_idc=77, cabac=0, bframes=3, num_ref_frames=3, direct_temporal=1, bskip_permille=300, seed=46),
+    "b_wp_explicit": dict(BASE, frames=10, profile_idc=77, cabac=1, bframes=2, num_ref_frames=3, weighted_bipred=1, weighted_pred=1, seed=47),
+    "b_wp_implicit": dict(BASE, frames=10, profile_idc=77, cabac=0, bframes=2, num_ref_frames=4, weighted_bipred=2, direct_temporal=1, seed=48),
+    "b_high8x8_slices": dict(BASE, frames=10, profile_idc=100, cabac=1, transform8x8=1, bframes=2, num_ref_frames=2, slices=3, sub8x8_permille=400,
+                             cabac_init_idc=-1, seed=49),
+    "b_gop_intra_pcm": dict(BASE, frames=16, idr_period=8, profile_idc=77, cabac=1, bframes=3, num_ref_frames=3, intra_in_p_permille=200,
+                            pcm_permille=100, qp_jitter=5, rplm=1, seed=50),
 }

@@ -42,6 +42,8 @@ def test_matrix_exercises_the_syntax(sg, oracle_mod):
         _, info, tr = oracle_mod.decode(stream, crop=False, trace=True)
         cab = kw.get("cabac", 0)
         for raw, cbp, qp, mode, t8, mvx, mvy, ref in tr:
+            if ref <= -100:
+                continue  # macroblock of a B slice: checked below
             seen.add(("skip" if raw == -1 else int(raw), cab))
             if t8:
                 feats.add(("t8x8", cab))
@@ -70,6 +72,17 @@ def test_matrix_exercises_the_syntax(sg, oracle_mod):
             assert (raw, cab) in seen, (raw, cab)
         for f in ("t8x8", "ref>0", "qpel"):
             assert (f, cab) in feats, (f, cab)
+    # B pictures: every inter mb_type of Table 7-14 (0..22), intra types inside B slices (23.., incl. I_PCM = 48), B_Skip
+    bseen = {0: set(), 1: set()}
+    for name, kw in MATRIX.items():
+        if not kw.get("bframes"):
+            continue
+        stream, _, _ = sg.encode(**kw)
+        _, info, tr = oracle_mod.decode(stream, crop=False, trace=True)
+        bseen[kw.get("cabac", 0)] |= {int(r[0]) for r in tr[tr[:, 7] <= -100]}
+    for cab in (0, 1):
+        assert set(range(23)) <= bseen[cab] and -1 in bseen[cab] and any(t >= 23 for t in bseen[cab]), (cab, sorted(bseen[cab]))
+    assert 48 in bseen[1]
 
 
 def test_crop(sg, oracle_mod):
