@@ -917,6 +917,12 @@ typedef struct {
     int bx, by, w, h, shape, mode;
 } ipart;
 
+/* A partition that does not use list `list`: for the partitions decoded after it, it is an AVAILABLE neighbour with
+ * refIdxLX = -1 and a zero vector (8.4.1.3.2); availability is a matter of decoding order only (6.4.11.7). */
+static void mark_unused(h264o_decoder *d, int list, int bx, int by, int w, int h) {
+    for (int y = by; y < by + h; y++)
+        for (int x = bx; x < bx + w; x++) d->cur_done[list] |= (uint16_t)(1 << (y * 4 + x));
+}
 /* mb_pred() for the unsplit / two-partition inter types of P and B slices: every ref_idx_l0, every ref_idx_l1, every
  * mvd_l0, every mvd_l1 (7.3.5.1) */
 static void decode_parts(h264o_decoder *d, const ipart *pt, int n) {
@@ -929,8 +935,12 @@ static void decode_parts(h264o_decoder *d, const ipart *pt, int n) {
                 for (int x = pt[i].bx; x < pt[i].bx + pt[i].w; x += 2) L_REF(m, l)[(y >> 1) * 2 + (x >> 1)] = (int8_t)r;
         }
     for (int l = 0; l < 2; l++)
-        for (int i = 0; i < n; i++)
-            if ((pt[i].mode >> l) & 1) do_part(d, l, pt[i].bx, pt[i].by, pt[i].w, pt[i].h, pt[i].shape);
+        for (int i = 0; i < n; i++) {
+            if ((pt[i].mode >> l) & 1)
+                do_part(d, l, pt[i].bx, pt[i].by, pt[i].w, pt[i].h, pt[i].shape);
+            else
+                mark_unused(d, l, pt[i].bx, pt[i].by, pt[i].w, pt[i].h);
+        }
 }
 
 static int decode_mb(h264o_decoder *d, int addr) {
@@ -1012,8 +1022,11 @@ static int decode_mb(h264o_decoder *d, int addr) {
             }
         for (int l = 0; l < 2; l++)
             for (int i = 0; i < 4; i++) {
-                if (!((mode[i] >> l) & 1)) continue;
                 int bx = (i & 1) * 2, by = (i >> 1) * 2;
+                if (!((mode[i] >> l) & 1)) {
+                    if (mode[i]) mark_unused(d, l, bx, by, 2, 2); /* (direct sub-macroblocks are final already) */
+                    continue;
+                }
                 d->cur_sub = i;
                 switch (shape[i]) {
                 case 0: do_part(d, l, bx, by, 2, 2, 0); break;

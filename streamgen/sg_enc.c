@@ -1574,7 +1574,13 @@ static void encode_b(enc *e, int kind) {
     for (int l = 0; l < 2; l++)
         for (int i = 0; i < np; i++) {
             bpart *p = &pt[i];
-            if (!(p->mode >> l & 1)) continue;
+            if (!(p->mode >> l & 1)) {
+                /* the partition does not use this list: for the partitions after it, it is an AVAILABLE neighbour with
+                 * refIdxLX = -1 and a zero vector (8.4.1.3.2) -- availability is a matter of decoding order (6.4.11.7) */
+                for (int y = p->by; y < p->by + p->h; y++)
+                    for (int x = p->bx; x < p->bx + p->w; x++) e->done_l[l] |= (uint16_t)(1 << (y * 4 + x));
+                continue;
+            }
             int mvp[2], mv[2], ref = EREF(m, l)[(p->by >> 1) * 2 + (p->bx >> 1)];
             e->cur_sub = p->sub;
             mv_pred_l(e, l, p->bx, p->by, p->w, ref, p->shape, mvp);
