@@ -31,6 +31,13 @@
 #include <hip/hip_runtime.h>
 #include "mi_kernels.h"
 
+// Compiled twice: as k_deblock, and from k_deblock_b.hip (MI_DB_B = 1) as k_deblock_b for pictures with B slices, whose
+// boundary strengths compare two vectors and two reference pictures per block (8.7.2.1): that build also stages the
+// list-1 vectors (MbMv1) of the current / left / upper macroblock.
+#ifndef MI_DB_B
+#define MI_DB_B 0
+#endif
+
 #define WAVE_SYNC()                                            \
     do {                                                       \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -44,6 +51,9 @@ struct DbSub { // state of one of the 4 macroblock rows a wavefront works on
     // chroma tiles, rows -4..7 (-2.. used): bytes 4..7 = columns -4..-1, bytes 8..15 = columns 0..7
     alignas(16) uint8_t c[2][12][16];
     MbRec rec[3];        // cur / left alternate in [0],[1]; [2] = macroblock above
+#if MI_DB_B
+    MbMv1 mv1[3];        // their list-1 vectors
+#endif
     uint8_t bs[2][4][4]; // [dir][edge][segment]
     // rows 12..15 (chroma 6..7) of the macroblock this sub-row finished in the previous step, for the sub-row below
     alignas(16) uint8_t bot_y[4][16];
@@ -61,7 +71,8 @@ struct DbShared { // followed in dynamic LDS by DbWave[nwaves] and the hand-off 
     int prog[96]; // per group: macroblock columns of its LAST row that are final (rows 12..15 complete)
     int cons[96]; // per group: hand-off slots consumed by its FIRST row
 };
-static_assert(sizeof(DbShared) <= MI_DEBLOCK_HDR_BYTES && sizeof(DbWave) == MI_DEBLOCK_WAVE_BYTES && sizeof(GroupSlot) == MI_DEBLOCK_SLOT_BYTES, "LDS layout constants");
+static_assert(sizeof(DbShared) <= MI_DEBLOCK_HDR_BYTES && sizeof(DbWave) == (MI_DB_B ? MI_DEBLOCK_WAVE_BYTES_B : MI_DEBLOCK_WAVE_BYTES) && sizeof(GroupSlot) == MI_DEBLOCK_SLOT_BYTES,
+              "LDS layout constants");
 
 // Global memory through an explicit address-space-1 pointer with a wave-uniform base and a 32-bit per-lane offset: the
 // frame pointers are built from integers (FramePool::base), which the compiler would otherwise treat as generic (flat_*
@@ -143,6 +154,30 @@ __device__ __forceinline__ int edge_bs(const MbRec *mp, int pb, const MbRec *mq,
     return 0;
 }
 
+#if MI_DB_B
+// 8.7.2.1 with two lists: the blocks differ if they use different reference PICTURES (frame slots; the list a picture
+// comes from does not matter) or a different number of vectors, or if the vectors that belong together differ by >= 4
+__device__ __forceinline__ bool mv_far(const int16_t *a, const int16_t *b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
+__device__ __forceinline__ int edge_bs_b(const MbRec *mp, const MbMv1 *vp, int pb, const MbRec *mq, const MbMv1 *vq, int qb, bool mb_edge) {
+    if (MB_IS_INTRA(mp->type) || MB_IS_INTRA(mq->type)) return mb_edge ? 4 : 3;
+    if (((mp->nzmask >> pb) & 1) || ((mq->nzmask >> qb) & 1)) return 2;
+    const int p8 = ((pb >> 3) << 1) | ((pb & 3) >> 1), q8 = ((qb >> 3) << 1) | ((qb & 3) >> 1);
+    const int p0 = mp->refslot[p8], p1 = mp->refslot1[p8], q0 = mq->refslot[q8], q1 = mq->refslot1[q8];
+    const int np = (p0 >= 0) + (p1 >= 0), nq = (q0 >= 0) + (q1 >= 0);
+    if (np != nq) return 1;
+    const int16_t *pv0 = mp->mv[pb], *pv1 = vp->mv[pb], *qv0 = mq->mv[qb], *qv1 = vq->mv[qb];
+    if (np < 2) { // one vector each (or none: corrupt records)
+        const int rp = p0 >= 0 ? p0 : p1, rq = q0 >= 0 ? q0 : q1;
+        if (rp != rq) return 1;
+        return mv_far(p0 >= 0 ? pv0 : pv1, q0 >= 0 ? qv0 : qv1) ? 1 : 0;
+    }
+    if (!((p0 == q0 && p1 == q1) || (p0 == q1 && p1 == q0))) return 1;
+    if (p0 != p1) // two different pictures: each vector against the one that points to the same picture
+        return (p0 == q0 ? (mv_far(pv0, qv0) || mv_far(pv1, qv1)) : (mv_far(pv0, qv1) || mv_far(pv1, qv0))) ? 1 : 0;
+    return ((mv_far(pv0, qv0) || mv_far(pv1, qv1)) && (mv_far(pv0, qv1) || mv_far(pv1, qv0))) ? 1 : 0; // both vectors into one picture
+}
+#endif
+
 __device__ __forceinline__ void unpack4(uint32_t w, int &a, int &b, int &c, int &d) {
     a = static_cast<int>(w & 255u), b = static_cast<int>(__builtin_amdgcn_ubfe(w, 8, 8)), c = static_cast<int>(__builtin_amdgcn_ubfe(w, 16, 8)), d = static_cast<int>(w >> 24);
 }
@@ -150,8 +185,14 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
     return static_cast<uint32_t>(a) | (static_cast<uint32_t>(b) << 8) | (static_cast<uint32_t>(c) << 16) | (static_cast<uint32_t>(d) << 24);
 }
 
+#if MI_DB_B
+extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_deblock_b(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
+                                                                                    const DevTables *tab, const MbRec *mbrec, int ring, int ring_last, int last_bufs,
+                                                                                    const MbMv1 *mbmv1) {
+#else
 extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
                                                                                   const DevTables *tab, const MbRec *mbrec, int ring, int ring_last, int last_bufs) {
+#endif
     extern __shared__ uint4 dyn_lds[];
     const int nthreads = static_cast<int>(blockDim.x), nwaves = nthreads >> 6;
     DbShared &sh = *reinterpret_cast<DbShared *>(dyn_lds);
@@ -171,6 +212,9 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
     }
     __syncthreads();
     const MbRec *recs = mbrec + pd->mb_base;
+#if MI_DB_B
+    const MbMv1 *recs1 = mbmv1 + pd->mb_base;
+#endif
     const int ngroups = (hmb + 3) >> 2;
     const v4u z4 = v4u{0u, 0u, 0u, 0u};
     const v2u z2 = v2u{0u, 0u};
@@ -198,6 +242,9 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
         v4u P0 = z4, P1 = z4, P2 = z4, P3 = z4;
         v2u Q0 = z2, Q1 = z2, Q2 = z2, Q3 = z2;
         v4u pre_rec = z4;
+#if MI_DB_B
+        v4u pre_mv1 = z4;
+#endif
         auto prefetch_group = [&](int gb) { // gb = first macroblock of an aligned group of four
             if (!row_ok || gb >= wmb) return;
             const uint32_t yb = yrow0 + gb * 16, cb = crow0 + gb * 8;
@@ -213,6 +260,9 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
             // lanes 0-7: cur record (8 x 16 B), lanes 8-15: record above
             const uint32_t mbi = static_cast<uint32_t>((li >= 8 && has_top ? mby - 1 : mby) * wmb + mbx);
             pre_rec = reinterpret_cast<const v4u *>(recs + mbi)[li & 7];
+#if MI_DB_B
+            pre_mv1 = reinterpret_cast<const v4u *>(recs1 + mbi)[li & 3]; // lanes 0-3: cur, lanes 8-11: above (4 x 16 B each)
+#endif
         };
         // Output registers: slot s collects the finished bytes of the column with (c + sub) % 4 == s; a group of four
         // columns leaves as one 64-byte line (32 bytes of chroma).  Lanes 13..15 do not own finished rows (rows 13..15
@@ -269,6 +319,10 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
             const v2u in_c = ts == 0 ? Q0 : (ts == 1 ? Q1 : (ts == 2 ? Q2 : Q3));
             // ---- 1. records -> LDS; boundary strengths: 32 per macroblock, 2 per lane ----
             if (active) reinterpret_cast<v4u *>(li < 8 ? mq : mtop_rec)[li & 7] = pre_rec;
+#if MI_DB_B
+            MbMv1 *vq = &ss->mv1[cur_slot], *vleft = &ss->mv1[cur_slot ^ 1], *vtop = &ss->mv1[2];
+            if (active && (li & 7) < 4) reinterpret_cast<v4u *>(li < 8 ? vq : vtop)[li & 3] = pre_mv1;
+#endif
             WAVE_SYNC();
             if (active && (mbx & 3) == 3) prefetch_group(mbx + 1); // the input registers of this sub-row are free again
             prefetch_rec(mbx + 1);
@@ -290,7 +344,11 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
                         const MbRec *mp = e == 0 ? mn : mq;
                         int qb = dir == 0 ? k * 4 + e : e * 4 + k;
                         int pb = dir == 0 ? k * 4 + (e == 0 ? 3 : e - 1) : (e == 0 ? 3 : e - 1) * 4 + k;
+#if MI_DB_B
+                        bs = edge_bs_b(mp, e == 0 ? (dir == 0 ? vleft : vtop) : vq, pb, mq, vq, qb, e == 0);
+#else
                         bs = edge_bs(mp, pb, mq, qb, e == 0);
+#endif
                     }
                     ss->bs[dir][e][k] = static_cast<uint8_t>(bs);
                 }

@@ -32,6 +32,19 @@
 #ifndef MI_ENT_MINWAVES
 #define MI_ENT_MINWAVES 6
 #endif
+// The file is compiled twice: as k_entropy (I and P slices) and, from k_entropy_b.hip with MI_ENT_B = 1, as k_entropy_b (B
+// slices only: two reference lists, direct prediction, Tables 7-14 / 7-18).  Everything list-dependent is indexed by a list
+// number that is the constant 0 in the first build, so the I/P kernel carries none of the B machinery.
+#ifndef MI_ENT_B
+#define MI_ENT_B 0
+#endif
+#if MI_ENT_B
+#define NL 2
+#define MI_ENT_KERNEL k_entropy_b
+#else
+#define NL 1
+#define MI_ENT_KERNEL k_entropy
+#endif
 #define LANE (static_cast<int>(threadIdx.x))
 #define FI __device__ __forceinline__
 // The workgroup is ONE wavefront: cross-lane LDS visibility needs no s_barrier and, above all, no
@@ -44,16 +57,18 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
-struct TopInfo { // edge state of a decoded MB as seen by its right / lower neighbours (48 bytes)
-    uint8_t type, t8x8, cbp, chroma_mode, cbf_dc, pad[3];
+struct TopInfo { // edge state of a decoded MB as seen by its right / lower neighbours (48 bytes; 72 in the B build)
+    uint8_t type, t8x8, cbp, chroma_mode, cbf_dc;
+    uint8_t dmask;  // B: bit k = the k-th 8x8 block on the edge is predicted in direct mode (ref_idx contexts, 9.3.3.1.1.6)
+    uint8_t pad[2];
     int8_t ipm[4];  // bottom row (top[]) or right column (left)
     uint8_t nnz[8]; // luma edge [0..3], Cb edge [4..5], Cr edge [6..7]
-    int8_t ref[2];  // the two 8x8 blocks on the edge
-    uint8_t pad2[2];
-    int16_t mv[4][2];
-    uint8_t mvd[4][2];
+    int8_t ref[2][2]; // [list][the two 8x8 blocks on the edge] (the I/P build uses list 0 only; [1] is padding there)
+    int16_t mv[NL][4][2];
+    uint8_t mvd[NL][4][2];
 };
-static_assert(sizeof(TopInfo) == 48, "TopInfo layout");
+#define TOP_DW (static_cast<int>(sizeof(TopInfo) / 4))
+static_assert(sizeof(TopInfo) == (MI_ENT_B ? 72 : 48), "TopInfo layout");
 
 struct Shared {
     uint8_t ctx[464];      // home of the residual-block context states (ctxIdx >= 105); see Ent::wk
@@ -67,17 +82,23 @@ struct Shared {
     int8_t ipm_c[32];      // -2 unavailable, -1 not (yet) an I_NxN block
     uint8_t nnz_c[32];     // 0x80 = unavailable
     uint8_t nnzc_c[2][12]; // chroma 3x3 grids
-    int8_t ref_c[32];      // -2 unavailable or not yet decoded, -1 intra, >= 0 ref_idx (motion final)
-    int8_t refi_c[32];     // ref_idx as soon as parsed (CABAC ctxIdxInc of ref_idx)
-    alignas(4) int16_t mv_c[32][2];
-    alignas(2) uint8_t mvd_c[32][2];
+    int8_t ref_c[NL][32];  // -2 unavailable or not yet decoded, -1 intra / list not used, >= 0 ref_idx (motion final)
+    int8_t refi_c[NL][32]; // ref_idx as soon as parsed (CABAC ctxIdxInc of ref_idx; 0 for direct-predicted blocks)
+    alignas(4) int16_t mv_c[NL][32][2];
+    alignas(2) uint8_t mvd_c[NL][32][2];
     int16_t lvl[16];       // CAVLC level scratch
     int16_t tmp16[16];     // CAVLC 8x8 interleave scratch
-    uint16_t parts[16];    // motion partition schedule: bx | by<<2 | (w-1)<<4 | (h-1)<<6 | shape<<8
-    int8_t refs8[4];
+    uint16_t parts[16];    // motion partition schedule: bx | by<<2 | (w-1)<<4 | (h-1)<<6 | shape<<8 | B: Pred_L0 / Pred_L1 bits << 11 (0 = direct)
+    int8_t refs8[2][4];    // [list][8x8]
     int8_t sub_type[4];
     uint8_t cur_cbf_dc, pad[3];
-    int16_t ref_slot[MI_MAX_REFS]; // frame-pool slot per ref_idx of this slice
+    int16_t ref_slot[NL][MI_MAX_REFS]; // frame-pool slot per ref_idx of this slice
+#if MI_ENT_B
+    uint32_t col[20];          // ColRec of the co-located macroblock (8.4.1.2.1)
+    alignas(4) int16_t dmv[2][16][2]; // direct-predicted sub-macroblocks of a B_8x8 macroblock, until their turn comes (6.4.11.7)
+    int8_t dref[2][4];
+    int16_t dsf[MI_MAX_REFS];  // temporal direct: DistScaleFactor per refIdxL0
+#endif
 };
 #define GI(bx, by) (((by) + 1) * 6 + (bx) + 1)
 
@@ -128,6 +149,12 @@ struct Ent {
     int cabac, islice, wmb, hmb;
     int cip, t8x8_mode, cqp_off0, cqp_off1, nref;
     uint64_t mb_base;
+#if MI_ENT_B
+    int nref1, direct_spatial, d8inf, col_short, direct8; // direct8: 8x8 blocks of the current macroblock predicted in direct mode
+    const uint32_t *col;     // ColRec array of RefPicList1[0] (nullptr: none)
+    uint32_t v_col;          // lanes 0..19: the co-located macroblock's ColRec, fetched at the start of the macroblock
+    MbMv1 *mbmv1;            // list-1 vectors of the pass
+#endif
 #if MI_ENT_STATS
     uint32_t bins;
     uint64_t tacc[4], tmark; // diagnostics: shader clocks in [0] fill_caches [1] macroblock syntax before residual() [2] residual() [3] record write-out
@@ -698,15 +725,15 @@ FI int median3(int a, int b, int c) {
     return c < mn ? mn : (c > mx ? mx : c);
 }
 // shape: 0 median, 1/2 = 16x8 upper/lower, 3/4 = 8x16 left/right
-FI void predict_mv(const Ent &e, int bx, int by, int w, int ref, int shape, int &px, int &py) {
+FI void predict_mv(const Ent &e, const int L, int bx, int by, int w, int ref, int shape, int &px, int &py) {
     const Shared *s = e.s;
     int ia = GI(bx - 1, by), ib = GI(bx, by - 1), ic = GI(bx + w, by - 1);
-    int ra = s->ref_c[ia], rb = s->ref_c[ib], rc = s->ref_c[ic];
+    int ra = s->ref_c[L][ia], rb = s->ref_c[L][ib], rc = s->ref_c[L][ic];
     if (rc == -2) {
         ic = GI(bx - 1, by - 1);
-        rc = s->ref_c[ic];
+        rc = s->ref_c[L][ic];
     }
-    int ax = s->mv_c[ia][0], ay = s->mv_c[ia][1], bxv = s->mv_c[ib][0], byv = s->mv_c[ib][1], cx = s->mv_c[ic][0], cy = s->mv_c[ic][1];
+    int ax = s->mv_c[L][ia][0], ay = s->mv_c[L][ia][1], bxv = s->mv_c[L][ib][0], byv = s->mv_c[L][ib][1], cx = s->mv_c[L][ic][0], cy = s->mv_c[L][ic][1];
     if (shape == 1 && rb == ref) {
         px = bxv, py = byv;
         return;
@@ -729,15 +756,15 @@ FI void predict_mv(const Ent &e, int bx, int by, int w, int ref, int shape, int 
     px = median3(ax, bxv, cx);
     py = median3(ay, byv, cy);
 }
-FI void set_part(Ent &e, int bx, int by, int w, int h, int ref, int mvx, int mvy, int dx, int dy) {
+FI void set_part(Ent &e, const int L, int bx, int by, int w, int h, int ref, int mvx, int mvy, int dx, int dy) {
     Shared *s = e.s;
     const uint8_t ax = static_cast<uint8_t>(min(abs(dx), 255)), ay = static_cast<uint8_t>(min(abs(dy), 255));
     const int l = LANE, x = l & 3, y = (l >> 2) & 3; // one 4x4 block per lane (lanes 0..15)
     if (l < 16 && x >= bx && x < bx + w && y >= by && y < by + h) {
         const int g = GI(x, y);
-        s->ref_c[g] = static_cast<int8_t>(ref);
-        *reinterpret_cast<uint32_t *>(s->mv_c[g]) = (static_cast<uint32_t>(mvx) & 0xffffu) | (static_cast<uint32_t>(mvy) << 16);
-        *reinterpret_cast<uint16_t *>(s->mvd_c[g]) = static_cast<uint16_t>(ax | (ay << 8));
+        s->ref_c[L][g] = static_cast<int8_t>(ref);
+        *reinterpret_cast<uint32_t *>(s->mv_c[L][g]) = (static_cast<uint32_t>(mvx) & 0xffffu) | (static_cast<uint32_t>(mvy) << 16);
+        *reinterpret_cast<uint16_t *>(s->mvd_c[L][g]) = static_cast<uint16_t>(ax | (ay << 8));
     }
     LDS_SYNC();
 }
@@ -755,9 +782,8 @@ FI void fill_caches(Ent &e) {
     int coded = 0; // this lane's bit of the CABAC neighbourhood masks: 1 coded, 2 unavailable (see parse_residual_cabac)
     if (l < 30) {
         int gx = l % 6 - 1, gy = l / 6 - 1; // block coordinates relative to the MB
-        int8_t ipm = -2, ref = -2;
-        uint8_t nnz = 0x80, mvdx = 0, mvdy = 0;
-        int16_t mvx = 0, mvy = 0;
+        int8_t ipm = -2;
+        uint8_t nnz = 0x80;
         const TopInfo *n = nullptr;
         int k = 0; // index inside the neighbour's edge arrays
         int edge = 0;
@@ -770,15 +796,28 @@ FI void fill_caches(Ent &e) {
         else if (gy < 0 && gx == 4)
             n = c, k = 0;
         if (n) {
-            int inter = MB_IS_INTER(n->type);
+            const int inter = MB_IS_INTER(n->type);
             if (!(cip && inter)) ipm = (n->type == MBT_I4x4 || n->type == MBT_I8x8) ? n->ipm[k] : static_cast<int8_t>(2);
             if (edge) nnz = n->nnz[k];
-            if (inter) {
-                ref = n->ref[k >> 1];
-                mvx = n->mv[k][0], mvy = n->mv[k][1];
-                mvdx = n->mvd[k][0], mvdy = n->mvd[k][1];
-            } else
-                ref = -1;
+        }
+#pragma unroll
+        for (int L = 0; L < NL; L++) {
+            int8_t ref = -2, refi = -2;
+            uint8_t mvdx = 0, mvdy = 0;
+            int16_t mvx = 0, mvy = 0;
+            if (n) {
+                if (MB_IS_INTER(n->type)) {
+                    ref = refi = n->ref[L][k >> 1];
+                    mvx = n->mv[L][k][0], mvy = n->mv[L][k][1];
+                    mvdx = n->mvd[L][k][0], mvdy = n->mvd[L][k][1];
+                    if (MI_ENT_B && ((n->dmask >> (k >> 1)) & 1)) refi = 0;
+                } else
+                    ref = refi = -1;
+            }
+            s->ref_c[L][l] = ref;
+            s->refi_c[L][l] = refi;
+            s->mv_c[L][l][0] = mvx, s->mv_c[L][l][1] = mvy;
+            s->mvd_c[L][l][0] = mvdx, s->mvd_c[L][l][1] = mvdy;
         }
         if (gx >= 0 && gx < 4 && gy >= 0) { // interior: current MB, nothing decoded yet
             nnz = 0;
@@ -788,10 +827,6 @@ FI void fill_caches(Ent &e) {
         s->ipm_c[l] = ipm;
         e.v_ipm = ipm;
         s->nnz_c[l] = nnz;
-        s->ref_c[l] = ref;
-        s->refi_c[l] = ref;
-        s->mv_c[l][0] = mvx, s->mv_c[l][1] = mvy;
-        s->mvd_c[l][0] = mvdx, s->mvd_c[l][1] = mvdy;
     } else if (l >= 32 && l < 50) {
         int i = l - 32, cpl = i / 9, g = i % 9, gx = g % 3 - 1, gy = g / 3 - 1;
         uint8_t v = 0x80;
@@ -806,11 +841,11 @@ FI void fill_caches(Ent &e) {
     } else if (l >= 50 && l < 56) { // DC coded_block_flags of the left (50..52) / upper (53..55) macroblock: Intra16x16 luma, Cb, Cr
         const TopInfo *n = l < 53 ? a : b;
         coded = n ? (n->cbf_dc >> ((l - 50) % 3)) & 1 : 2;
-    } else if (l >= 56 && l < 60) {
-        s->refs8[l - 56] = -1;
-        s->sub_type[l - 56] = 0;
-    } else if (l == 60)
-        s->cur_cbf_dc = 0;
+    } else if (l >= 56) {
+        s->refs8[(l - 56) >> 2][l & 3] = -1;
+        if (l < 60) s->sub_type[l - 56] = 0;
+        if (l == 60) s->cur_cbf_dc = 0;
+    }
     e.nzm = __builtin_amdgcn_ballot_w64(coded == 1);
     e.unm = __builtin_amdgcn_ballot_w64(coded == 2);
     e.aw = RFL(*reinterpret_cast<const uint32_t *>(&s->left)), e.bw = RFL(*reinterpret_cast<const uint32_t *>(&s->topw[0]));
@@ -819,6 +854,158 @@ FI void fill_caches(Ent &e) {
         for (int i = l; i < MI_COEF_PER_MB / 2; i += 64) cz[i] = 0;
     }
     LDS_SYNC();
+}
+
+#if MI_ENT_B
+// ------------------------------------------------------------------ direct prediction 8.4.1.2 (B_Skip, B_Direct_16x16, B_Direct_8x8)
+FI int min_positive(int a, int b) { return (a >= 0 && b >= 0) ? min(a, b) : max(a, b); }
+// Tables 7-14 / 7-18 as packed constants: prediction modes (bit 0 Pred_L0, bit 1 Pred_L1) of the two partitions of
+// mb_type 4..21, and mode / shape (0 8x8, 1 8x4, 2 4x8, 3 4x4) of the 13 sub_mb_types (mode 0 = direct)
+FI int b_pair_modes(int k) { return static_cast<int>((0xFB7ED69A5ull >> (4 * k)) & 15); } // m0 | m1 << 2 of {1,1},{2,2},{1,2},{2,1},{1,3},{2,3},{3,1},{3,2},{3,3}
+FI int b_sub_mode(int st) { return static_cast<int>((0x39FA5E4u >> (2 * st)) & 3); }     // {0,1,2,3,1,1,2,2,3,3,1,2,3}
+FI int b_sub_shape(int st) { return static_cast<int>((0x3F99900u >> (2 * st)) & 3); }    // {0,0,0,0,1,2,1,2,1,2,3,3,3}
+static_assert(((0x39FA5E4u >> 8) & 3) == 1 && ((0x39FA5E4u >> 24) & 3) == 3 && ((0x39FA5E4u >> 12) & 3) == 2 && ((0x3F99900u >> 8) & 3) == 1 && ((0x3F99900u >> 10) & 3) == 2,
+              "Table 7-18 constants");
+
+// Motion of the 8x8 quadrants in `mask8`, one 4x4 block per lane.  commit: straight into the neighbour caches (the whole
+// macroblock is direct); otherwise into the staging arrays, from where commit_direct() takes each quadrant when its turn in
+// the partition order comes -- until then it must stay "not yet decoded" for the quadrants before it (6.4.11.7).
+FI void direct_pred(Ent &e, int mask8, bool commit) {
+    Shared *s = e.s;
+    int l = LANE;
+    OPAQUE(l);
+    if (l < 20) s->col[l] = e.v_col;
+    LDS_SYNC();
+    const int bx = l & 3, by = (l >> 2) & 3, q = (by >> 1) * 2 + (bx >> 1);
+    const int cb = e.d8inf ? (by >> 1) * 12 + (bx >> 1) * 3 : (l & 15); // the corner block stands for the quadrant
+    const uint32_t mvw = s->col[cb];
+    const int mcx = static_cast<int16_t>(mvw & 0xffffu), mcy = static_cast<int32_t>(mvw) >> 16;
+    const int refcol = static_cast<int8_t>((s->col[18] >> (8 * q)) & 255u);
+    const int slotcol = static_cast<int16_t>((s->col[16 + (q >> 1)] >> (16 * (q & 1))) & 0xffffu);
+    int ref0, ref1, m0x, m0y, m1x, m1y;
+    if (e.direct_spatial) { // 8.4.1.2.2: reference indices and predictors are those of the MACROBLOCK (neighbours A, B, C outside it)
+        int rf[2], px[2] = {0, 0}, py[2] = {0, 0};
+#pragma unroll
+        for (int L = 0; L < 2; L++) {
+            const int ra = s->ref_c[L][GI(-1, 0)], rb = s->ref_c[L][GI(0, -1)];
+            int rc = s->ref_c[L][GI(4, -1)];
+            if (rc == -2) rc = s->ref_c[L][GI(-1, -1)];
+            rf[L] = RFL(min_positive(ra, min_positive(rb, rc)));
+        }
+        if (rf[0] < 0 && rf[1] < 0)
+            rf[0] = rf[1] = 0; // directZeroPredictionFlag
+        else {
+            if (rf[0] >= 0) predict_mv(e, 0, 0, 0, 4, rf[0], 0, px[0], py[0]);
+            if (rf[1] >= 0) predict_mv(e, 1, 0, 0, 4, rf[1], 0, px[1], py[1]);
+        }
+        const bool colzero = e.col_short && refcol == 0 && mcx >= -1 && mcx <= 1 && mcy >= -1 && mcy <= 1;
+        ref0 = rf[0], ref1 = rf[1];
+        const bool z0 = rf[0] < 0 || (rf[0] == 0 && colzero), z1 = rf[1] < 0 || (rf[1] == 0 && colzero);
+        m0x = z0 ? 0 : px[0], m0y = z0 ? 0 : py[0];
+        m1x = z1 ? 0 : px[1], m1y = z1 ? 0 : py[1];
+    } else { // 8.4.1.2.3: the picture the co-located block refers to, as the lowest index of this slice's RefPicList0
+        ref0 = 0;
+        if (refcol >= 0) {
+            ref0 = -1;
+            for (int i = e.nref - 1; i >= 0; i--)
+                if (s->ref_slot[0][i] == slotcol) ref0 = i;
+        }
+        if (UNI(l < 16 && ((mask8 >> q) & 1) && ref0 < 0)) e.err = 41; // the co-located reference is not in RefPicList0
+        ref0 = max(ref0, 0);
+        const int dsf = s->dsf[ref0];
+        m0x = (dsf * mcx + 128) >> 8, m0y = (dsf * mcy + 128) >> 8;
+        m1x = m0x - mcx, m1y = m0y - mcy;
+        ref1 = 0;
+    }
+    if (l < 16 && ((mask8 >> q) & 1)) {
+        const uint32_t w0 = (static_cast<uint32_t>(m0x) & 0xffffu) | (static_cast<uint32_t>(m0y) << 16);
+        const uint32_t w1 = (static_cast<uint32_t>(m1x) & 0xffffu) | (static_cast<uint32_t>(m1y) << 16);
+        if (commit) {
+            const int g = GI(bx, by);
+            s->ref_c[0][g] = static_cast<int8_t>(ref0), s->ref_c[1][g] = static_cast<int8_t>(ref1);
+            *reinterpret_cast<uint32_t *>(s->mv_c[0][g]) = w0, *reinterpret_cast<uint32_t *>(s->mv_c[1][g]) = w1;
+        } else {
+            *reinterpret_cast<uint32_t *>(s->dmv[0][l]) = w0, *reinterpret_cast<uint32_t *>(s->dmv[1][l]) = w1;
+        }
+        if (!((bx | by) & 1)) {
+            if (commit)
+                s->refs8[0][q] = static_cast<int8_t>(ref0), s->refs8[1][q] = static_cast<int8_t>(ref1);
+            else
+                s->dref[0][q] = static_cast<int8_t>(ref0), s->dref[1][q] = static_cast<int8_t>(ref1);
+        }
+    }
+    LDS_SYNC();
+}
+// list L of the direct-predicted quadrant q becomes visible to the partitions after it
+FI void commit_direct(Ent &e, const int L, int q) {
+    Shared *s = e.s;
+    const int l = LANE, bx = l & 3, by = (l >> 2) & 3;
+    if (l < 16 && (by >> 1) * 2 + (bx >> 1) == q) {
+        const int g = GI(bx, by);
+        s->ref_c[L][g] = s->dref[L][q];
+        *reinterpret_cast<uint32_t *>(s->mv_c[L][g]) = *reinterpret_cast<const uint32_t *>(s->dmv[L][l]);
+        if (!((bx | by) & 1)) s->refs8[L][q] = s->dref[L][q];
+    }
+    LDS_SYNC();
+}
+#endif
+
+// ref_idx_lX of a partition (7.3.5.1 / 7.3.5.2; te(v) or 9.3.3.1.1.6), entered into the context cache and the per-8x8 list
+FI void read_ref_idx(Ent &e, const int L, int bx, int by, int w, int h, int nref) {
+    Shared *s = e.s;
+    int ref = 0;
+    if (nref > 1) {
+        if (e.cabac) {
+            int ctx = (s->refi_c[L][GI(bx - 1, by)] > 0) + 2 * (s->refi_c[L][GI(bx, by - 1)] > 0);
+            while (BIN_A(e, 54 + ctx)) {
+                ctx = (ctx >> 2) + 4;
+                if (++ref > 31) {
+                    e.err = 3;
+                    break;
+                }
+            }
+        } else
+            ref = nref == 2 ? !get_bit(e) : static_cast<int>(get_ue(e));
+        if (ref >= nref || ref >= MI_MAX_REFS) e.err = 13, ref = 0;
+    }
+    { // one 4x4 block per lane: ref_idx cache for the ctxIdxInc of later partitions, and the per-8x8 list
+        const int l = LANE, x = l & 3, y = (l >> 2) & 3;
+        if (l < 16 && x >= bx && x < bx + w && y >= by && y < by + h) {
+            s->refi_c[L][GI(x, y)] = static_cast<int8_t>(ref);
+            if (!((x | y) & 1)) s->refs8[L][(y >> 1) * 2 + (x >> 1)] = static_cast<int8_t>(ref);
+        }
+        LDS_SYNC();
+    }
+}
+// mvd_lX of a partition (se(v) or UEG3 9.3.2.3 / 9.3.3.1.1.7), prediction 8.4.1.3, result into the caches
+FI void read_mv(Ent &e, const int L, int p) {
+    Shared *s = e.s;
+    const int bx = p & 3, by = (p >> 2) & 3, w = ((p >> 4) & 3) + 1, h = ((p >> 6) & 3) + 1, shape = (p >> 8) & 7;
+    const int ref = s->refs8[L][(by >> 1) * 2 + (bx >> 1)];
+    int d[2];
+    for (int comp = 0; comp < 2; comp++) {
+        int v;
+        if (e.cabac) { // UEG3, uCoff 9, signed (9.3.2.3, 9.3.3.1.1.7)
+            const int sum = s->mvd_c[L][GI(bx - 1, by)][comp] + s->mvd_c[L][GI(bx, by - 1)][comp];
+            const int base = comp ? 47 : 40;
+            v = 0;
+            if (BIN_A(e, base + (sum > 2) + (sum > 32))) {
+                int ctx = base + 3;
+                v = 1;
+                while (v < 9 && BIN_A(e, ctx)) {
+                    if (v < 4) ctx++;
+                    v++;
+                }
+                if (v >= 9) v += cabac_egk(e, 3);
+                if (cabac_bypass(e)) v = -v;
+            }
+        } else
+            v = get_se(e);
+        d[comp] = v;
+    }
+    int px, py;
+    predict_mv(e, L, bx, by, w, ref, shape, px, py);
+    set_part(e, L, bx, by, w, h, ref, px + d[0], py + d[1], d[0], d[1]);
 }
 
 // ------------------------------------------------------------------ macroblock_layer() 7.3.5
@@ -830,28 +1017,66 @@ FI void decode_mb(Ent &e, int skipped) {
     int type, raw = 0, nparts = 0;
     const Nb a{e.aw}, b{e.bw};
     r.nzmask = 0;
+#if MI_ENT_B
+    int no_sub8 = 1; // NoSubMbPartSizeLessThan8x8Flag (7.3.5)
+    e.direct8 = 0;
+#endif
     if (skipped) {
+#if MI_ENT_B
+        type = MBT_BSKIP; // the whole macroblock is predicted in direct mode, no residual (7.3.4, 8.4.1.2)
+        e.cur_type = type;
+        e.direct8 = 15;
+        direct_pred(e, 15, true);
+#else
         type = MBT_PSKIP;
         e.cur_type = type;
         int mvx = 0, mvy = 0; // 8.4.1.1
-        int ra = s->ref_c[GI(-1, 0)], rb = s->ref_c[GI(0, -1)];
-        bool zero = ra == -2 || rb == -2 || (ra == 0 && s->mv_c[GI(-1, 0)][0] == 0 && s->mv_c[GI(-1, 0)][1] == 0) ||
-                    (rb == 0 && s->mv_c[GI(0, -1)][0] == 0 && s->mv_c[GI(0, -1)][1] == 0);
-        if (!zero) predict_mv(e, 0, 0, 4, 0, 0, mvx, mvy);
-        set_part(e, 0, 0, 4, 4, 0, mvx, mvy, 0, 0);
-        s->refs8[0] = s->refs8[1] = s->refs8[2] = s->refs8[3] = 0;
+        int ra = s->ref_c[0][GI(-1, 0)], rb = s->ref_c[0][GI(0, -1)];
+        bool zero = ra == -2 || rb == -2 || (ra == 0 && s->mv_c[0][GI(-1, 0)][0] == 0 && s->mv_c[0][GI(-1, 0)][1] == 0) ||
+                    (rb == 0 && s->mv_c[0][GI(0, -1)][0] == 0 && s->mv_c[0][GI(0, -1)][1] == 0);
+        if (!zero) predict_mv(e, 0, 0, 0, 4, 0, 0, mvx, mvy);
+        set_part(e, 0, 0, 0, 4, 4, 0, mvx, mvy, 0, 0);
+        s->refs8[0][0] = s->refs8[0][1] = s->refs8[0][2] = s->refs8[0][3] = 0;
+#endif
         e.prev_dqp_nz = 0;
     } else {
         // ---- mb_type (Tables 9-36 / 9-37) ----
         int intra_prefix = 1; // in P slices: bin 0 of mb_type says "intra"
         if (cabac) {
+#if MI_ENT_B
+            { // Table 9-37 (b): B slices, ctxIdxOffset 27; the intra types hang off the prefix 111101 with their suffix at 32
+                intra_prefix = 0;
+                const int inc = (a.ok() && a.type() != MBT_BSKIP && a.type() != MBT_BDIRECT) + (b.ok() && b.type() != MBT_BSKIP && b.type() != MBT_BDIRECT);
+                if (!BIN_A(e, 27 + inc))
+                    raw = 0; // B_Direct_16x16
+                else if (!BIN_A(e, 27 + 3))
+                    raw = 1 + BINI_A(e, 27 + 5); // B_L0_16x16, B_L1_16x16
+                else {
+                    int bits = BINI_A(e, 27 + 4) << 3;
+                    bits |= BINI_A(e, 27 + 5) << 2;
+                    bits |= BINI_A(e, 27 + 5) << 1;
+                    bits |= BINI_A(e, 27 + 5);
+                    if (bits < 8)
+                        raw = bits + 3; // B_Bi_16x16 .. B_L1_L0_16x8
+                    else if (bits == 13)
+                        intra_prefix = 1;
+                    else if (bits == 14)
+                        raw = 11; // B_L1_L0_8x16
+                    else if (bits == 15)
+                        raw = 22; // B_8x8
+                    else
+                        raw = ((bits << 1) | BINI_A(e, 27 + 5)) - 4; // B_L0_Bi_16x8 .. B_Bi_Bi_8x16
+                }
+            }
+#else
             if (!islice) {
                 intra_prefix = BINI_A(e, 14);
                 if (!intra_prefix) raw = BIN_A(e, 15) ? 2 - BINI_A(e, 17) : 3 * BINI_A(e, 16);
             }
+#endif
             if (intra_prefix) {
-                // I-slice bin string; `base` 3 with neighbour-dependent first bin, or the suffix at 17
-                int base = islice ? 3 : 17, it = 0, first;
+                // I-slice bin string; `base` 3 with neighbour-dependent first bin, or the suffix at 17 (P) / 32 (B)
+                int base = islice ? 3 : (MI_ENT_B ? 32 : 17), it = 0, first;
                 if (islice) {
                     int inc = (a.ok() && a.type() != MBT_I4x4 && a.type() != MBT_I8x8) + (b.ok() && b.type() != MBT_I4x4 && b.type() != MBT_I8x8);
                     first = BINI_A(e, base + inc);
@@ -868,13 +1093,18 @@ FI void decode_mb(Ent &e, int skipped) {
                         it += BINI_A(e, base + 3 + 2 * islice);
                     }
                 }
-                raw = islice ? it : it + 5;
+                raw = islice ? it : it + (MI_ENT_B ? 23 : 5);
             }
         } else
             raw = static_cast<int>(get_ue(e));
-        const int it = islice ? raw : raw - 5;
+        const int it = islice ? raw : raw - (MI_ENT_B ? 23 : 5);
+#if MI_ENT_B
+        if (raw < 23)
+            type = raw == 0 ? MBT_BDIRECT : MBT_B;
+#else
         if (!islice && raw < 5)
             type = raw == 0 ? MBT_P16x16 : (raw == 1 ? MBT_P16x8 : (raw == 2 ? MBT_P8x16 : MBT_P8x8));
+#endif
         else if (it == 0)
             type = MBT_I4x4;
         else if (it >= 1 && it <= 24) {
@@ -898,7 +1128,10 @@ FI void decode_mb(Ent &e, int skipped) {
             uint32_t *pcm = reinterpret_cast<uint32_t *>(s->coef);
             for (int i = 0; i < 96; i++) pcm[i] = __builtin_bswap32(get_bits(e, 32)); // 384 sample bytes in stream order
             if (cabac) cabac_start(e);
-            for (int i = 0; i < 16; i++) s->nnz_c[GI(i & 3, i >> 2)] = 16, s->ref_c[GI(i & 3, i >> 2)] = -1;
+            for (int i = 0; i < 16; i++) {
+                s->nnz_c[GI(i & 3, i >> 2)] = 16, s->ref_c[0][GI(i & 3, i >> 2)] = -1;
+                if (MI_ENT_B) s->ref_c[NL - 1][GI(i & 3, i >> 2)] = -1;
+            }
             for (int i = 0; i < 8; i++) s->nnzc_c[i >> 2][(((i >> 1) & 1) + 1) * 3 + (i & 1) + 1] = 16;
             s->cur_cbf_dc = 7;
             r.nzmask = 0xFFFF;
@@ -907,6 +1140,93 @@ FI void decode_mb(Ent &e, int skipped) {
             e.prev_dqp_nz = 0;
         } else {
             if (MB_IS_INTER(type)) {
+#if MI_ENT_B
+                if (type == MBT_BDIRECT) {
+                    e.direct8 = 15;
+                    direct_pred(e, 15, true);
+                    no_sub8 = e.d8inf;
+                } else {
+                    // ---- partition schedule (Tables 7-14, 7-18): geometry | prediction modes << 11 ----
+                    int nref_parts;
+                    if (raw <= 3) {
+                        s->parts[0] = static_cast<uint16_t>(PART(0, 0, 4, 4, 0) | (raw << 11));
+                        nparts = nref_parts = 1;
+                    } else if (raw < 22) {
+                        const int mm = b_pair_modes((raw - 4) >> 1), m0 = mm & 3, m1 = mm >> 2;
+                        if (raw & 1)
+                            s->parts[0] = static_cast<uint16_t>(PART(0, 0, 2, 4, 3) | (m0 << 11)), s->parts[1] = static_cast<uint16_t>(PART(2, 0, 2, 4, 4) | (m1 << 11));
+                        else
+                            s->parts[0] = static_cast<uint16_t>(PART(0, 0, 4, 2, 1) | (m0 << 11)), s->parts[1] = static_cast<uint16_t>(PART(0, 2, 4, 2, 2) | (m1 << 11));
+                        nparts = nref_parts = 2;
+                    } else {
+                        nref_parts = 4;
+                        for (int i = 0; i < 4; i++) {
+                            int st;
+                            if (cabac) { // Table 9-38 (b), ctxIdxOffset 36
+                                if (!BIN_A(e, 36))
+                                    st = 0; // B_Direct_8x8
+                                else if (!BIN_A(e, 37))
+                                    st = 1 + BINI_A(e, 39);
+                                else {
+                                    st = 3;
+                                    int done = 0;
+                                    if (BIN_A(e, 38)) {
+                                        if (BIN_A(e, 39))
+                                            st = 11 + BINI_A(e, 39), done = 1; // B_L1_4x4, B_Bi_4x4
+                                        else
+                                            st += 4;
+                                    }
+                                    if (!done) {
+                                        st += 2 * BINI_A(e, 39);
+                                        st += BINI_A(e, 39);
+                                    }
+                                }
+                            } else
+                                st = static_cast<int>(get_ue(e));
+                            if (st > 12) e.err = 21, st = 1;
+                            s->sub_type[i] = static_cast<int8_t>(st);
+                            const int md = b_sub_mode(st), shp = b_sub_shape(st);
+                            const int bx = (i & 1) * 2, by = (i >> 1) * 2;
+                            if (md == 0) {
+                                e.direct8 |= 1 << i;
+                                if (!e.d8inf) no_sub8 = 0;
+                                s->parts[nparts++] = PART(bx, by, 2, 2, 0); // modes 0: marks the quadrant's turn in the vector loops
+                            } else {
+                                if (shp) no_sub8 = 0;
+                                const int sw = (shp == 0 || shp == 1) ? 2 : 1, sh = (shp == 0 || shp == 2) ? 2 : 1;
+                                for (int yy = 0; yy < 2; yy += sh)
+                                    for (int xx = 0; xx < 2; xx += sw) s->parts[nparts++] = static_cast<uint16_t>(PART(bx + xx, by + yy, sw, sh, 0) | (md << 11));
+                            }
+                        }
+                        if (e.direct8) direct_pred(e, e.direct8, false); // derived first, visible to the others in partition order
+                    }
+                    // ---- every ref_idx_l0, every ref_idx_l1, every mvd_l0, every mvd_l1 (7.3.5.1 / 7.3.5.2) ----
+#pragma unroll
+                    for (int L = 0; L < 2; L++)
+                        for (int i = 0; i < nref_parts; i++) {
+                            int bx, by, w, h, md;
+                            if (raw == 22)
+                                bx = (i & 1) * 2, by = (i >> 1) * 2, w = 2, h = 2, md = b_sub_mode(s->sub_type[i]);
+                            else {
+                                const int p = s->parts[i];
+                                bx = p & 3, by = (p >> 2) & 3, w = ((p >> 4) & 3) + 1, h = ((p >> 6) & 3) + 1, md = p >> 11;
+                            }
+                            if ((md >> L) & 1) read_ref_idx(e, L, bx, by, w, h, L ? e.nref1 : e.nref);
+                        }
+#pragma unroll
+                    for (int L = 0; L < 2; L++)
+                        for (int i = 0; i < nparts; i++) {
+                            const int p = s->parts[i], md = p >> 11;
+                            const int bx = p & 3, by = (p >> 2) & 3;
+                            if (md == 0)
+                                commit_direct(e, L, (by >> 1) * 2 + (bx >> 1));
+                            else if ((md >> L) & 1)
+                                read_mv(e, L, p);
+                            else // the partition does not use this list: an available neighbour with refIdxLX = -1 and a zero vector (8.4.1.3.2)
+                                set_part(e, L, bx, by, ((p >> 4) & 3) + 1, ((p >> 6) & 3) + 1, -1, 0, 0, 0, 0);
+                        }
+                }
+#else
                 // ---- partition schedule (Tables 7-13, 7-17) ----
                 int nref_parts;
                 if (type == MBT_P16x16) {
@@ -935,7 +1255,6 @@ FI void decode_mb(Ent &e, int skipped) {
                     }
                 }
                 // ---- ref_idx_l0 per macroblock partition (7.3.5.1 / 7.3.5.2) ----
-                const int nref = e.nref;
                 for (int i = 0; i < nref_parts; i++) {
                     int bx, by, w, h;
                     if (type == MBT_P8x8)
@@ -944,60 +1263,11 @@ FI void decode_mb(Ent &e, int skipped) {
                         const int p = s->parts[i];
                         bx = p & 3, by = (p >> 2) & 3, w = ((p >> 4) & 3) + 1, h = ((p >> 6) & 3) + 1;
                     }
-                    int ref = 0;
-                    if (nref > 1 && raw != 4) {
-                        if (cabac) { // 9.3.3.1.1.6
-                            int ctx = (s->refi_c[GI(bx - 1, by)] > 0) + 2 * (s->refi_c[GI(bx, by - 1)] > 0);
-                            while (BIN_A(e, 54 + ctx)) {
-                                ctx = (ctx >> 2) + 4;
-                                if (++ref > 31) {
-                                    e.err = 3;
-                                    break;
-                                }
-                            }
-                        } else
-                            ref = nref == 2 ? !get_bit(e) : static_cast<int>(get_ue(e));
-                        if (ref >= nref || ref >= MI_MAX_REFS) e.err = 13, ref = 0;
-                    }
-                    { // one 4x4 block per lane: ref_idx cache for the ctxIdxInc of later partitions, and the per-8x8 list
-                        const int l = LANE, x = l & 3, y = (l >> 2) & 3;
-                        if (l < 16 && x >= bx && x < bx + w && y >= by && y < by + h) {
-                            s->refi_c[GI(x, y)] = static_cast<int8_t>(ref);
-                            if (!((x | y) & 1)) s->refs8[(y >> 1) * 2 + (x >> 1)] = static_cast<int8_t>(ref);
-                        }
-                        LDS_SYNC();
-                    }
+                    read_ref_idx(e, 0, bx, by, w, h, raw != 4 ? e.nref : 1);
                 }
                 // ---- mvd_l0 + prediction per (sub-)partition ----
-                for (int i = 0; i < nparts; i++) {
-                    const int p = s->parts[i];
-                    const int bx = p & 3, by = (p >> 2) & 3, w = ((p >> 4) & 3) + 1, h = ((p >> 6) & 3) + 1, shape = p >> 8;
-                    const int ref = s->refs8[(by >> 1) * 2 + (bx >> 1)];
-                    int d[2];
-                    for (int comp = 0; comp < 2; comp++) {
-                        int v;
-                        if (cabac) { // UEG3, uCoff 9, signed (9.3.2.3, 9.3.3.1.1.7)
-                            const int sum = s->mvd_c[GI(bx - 1, by)][comp] + s->mvd_c[GI(bx, by - 1)][comp];
-                            const int base = comp ? 47 : 40;
-                            v = 0;
-                            if (BIN_A(e, base + (sum > 2) + (sum > 32))) {
-                                int ctx = base + 3;
-                                v = 1;
-                                while (v < 9 && BIN_A(e, ctx)) {
-                                    if (v < 4) ctx++;
-                                    v++;
-                                }
-                                if (v >= 9) v += cabac_egk(e, 3);
-                                if (cabac_bypass(e)) v = -v;
-                            }
-                        } else
-                            v = get_se(e);
-                        d[comp] = v;
-                    }
-                    int px, py;
-                    predict_mv(e, bx, by, w, ref, shape, px, py);
-                    set_part(e, bx, by, w, h, ref, px + d[0], py + d[1], d[0], d[1]);
-                }
+                for (int i = 0; i < nparts; i++) read_mv(e, 0, s->parts[i]);
+#endif
             } else {
                 // ---- intra: transform_size_8x8_flag, prediction modes, intra_chroma_pred_mode ----
                 if (type == MBT_I4x4 && e.t8x8_mode) {
@@ -1042,7 +1312,10 @@ FI void decode_mb(Ent &e, int skipped) {
                     chroma_mode = static_cast<int>(get_ue(e));
                     if (chroma_mode > 3) e.err = 22, chroma_mode = 0;
                 }
-                if (LANE < 16) s->ref_c[GI(LANE & 3, LANE >> 2)] = -1;
+                if (LANE < 16) {
+                    s->ref_c[0][GI(LANE & 3, LANE >> 2)] = -1;
+                    if (MI_ENT_B) s->ref_c[NL - 1][GI(LANE & 3, LANE >> 2)] = -1;
+                }
             }
             // ---- coded_block_pattern ----
             if (type != MBT_I16x16) {
@@ -1069,9 +1342,13 @@ FI void decode_mb(Ent &e, int skipped) {
                 }
                 cbp_luma = cbp & 15, cbp_chroma = cbp >> 4;
                 if (cbp_luma && e.t8x8_mode && MB_IS_INTER(type)) {
+#if MI_ENT_B
+                    const int all8 = no_sub8;
+#else
                     int all8 = 1;
                     if (type == MBT_P8x8)
                         for (int i = 0; i < 4; i++) all8 &= s->sub_type[i] == 0;
+#endif
                     if (all8) t8x8 = cabac ? BINI_T8(e, (a.ok() && a.t8x8()) + (b.ok() && b.t8x8())) : static_cast<int>(get_bit(e));
                 }
             }
@@ -1162,17 +1439,23 @@ FI void decode_mb(Ent &e, int skipped) {
     if (l == 0) r.coef_off = coff, r.coef_mask = cmask;
     if (l < 16) {
         int g = GI(l & 3, l >> 2);
-        r.ipm[l] = s->ipm_c[g];
-        r.mv[l][0] = inter ? s->mv_c[g][0] : static_cast<int16_t>(0);
-        r.mv[l][1] = inter ? s->mv_c[g][1] : static_cast<int16_t>(0);
+        r.ipm[l] = (MI_ENT_B && inter && l < 4) ? s->refs8[NL - 1][l] : s->ipm_c[g]; // B: MBREC_REF1 shares the bytes
+        r.mv[l][0] = inter ? s->mv_c[0][g][0] : static_cast<int16_t>(0);
+        r.mv[l][1] = inter ? s->mv_c[0][g][1] : static_cast<int16_t>(0);
     } else if (l < 20) {
-        int i = l - 16, ref = inter ? s->refs8[i] : -1;
+        int i = l - 16, ref = inter ? s->refs8[0][i] : -1;
         r.ref[i] = static_cast<int8_t>(ref);
-        r.refslot[i] = ref >= 0 ? s->ref_slot[ref & (MI_MAX_REFS - 1)] : static_cast<int16_t>(-1);
+        r.refslot[i] = ref >= 0 ? s->ref_slot[0][ref & (MI_MAX_REFS - 1)] : static_cast<int16_t>(-1);
     }
+#if MI_ENT_B
+    else if (l < 24) {
+        const int i = l - 20, ref = inter ? s->refs8[1][i] : -1;
+        r.refslot1[i] = ref >= 0 ? s->ref_slot[1][ref & (MI_MAX_REFS - 1)] : static_cast<int16_t>(-1);
+    }
+#endif
     // remember the row-above entry of this column for the next MB's top-left neighbour, then build the new one
     TopInfo *tp = &s->topw[0];
-    if (l >= 32 && l < 44) reinterpret_cast<uint32_t *>(&s->tl)[l - 32] = reinterpret_cast<const uint32_t *>(tp)[l - 32];
+    if (l >= 32 && l < 32 + TOP_DW) reinterpret_cast<uint32_t *>(&s->tl)[l - 32] = reinterpret_cast<const uint32_t *>(tp)[l - 32];
     LDS_SYNC();
     if (l < 2) {
         TopInfo *dst = l == 0 ? tp : &s->left;
@@ -1181,8 +1464,15 @@ FI void decode_mb(Ent &e, int skipped) {
         dst->cbp = r.cbp;
         dst->chroma_mode = static_cast<uint8_t>(chroma_mode);
         dst->cbf_dc = s->cur_cbf_dc;
-        dst->ref[0] = inter ? s->refs8[l == 0 ? 2 : 1] : static_cast<int8_t>(-1);
-        dst->ref[1] = inter ? s->refs8[3] : static_cast<int8_t>(-1);
+#pragma unroll
+        for (int L = 0; L < NL; L++) {
+            dst->ref[L][0] = inter ? s->refs8[L][l == 0 ? 2 : 1] : static_cast<int8_t>(-1);
+            dst->ref[L][1] = inter ? s->refs8[L][3] : static_cast<int8_t>(-1);
+        }
+#if MI_ENT_B
+        // direct-predicted 8x8 blocks on the edge: bottom row = quadrants 2, 3; right column = quadrants 1, 3
+        dst->dmask = static_cast<uint8_t>(l == 0 ? (e.direct8 >> 2) & 3 : ((e.direct8 >> 1) & 1) | ((e.direct8 >> 2) & 2));
+#endif
     } else if (l >= 8 && l < 16) {
         // edge arrays: lanes 8..11 -> top (bottom row), 12..15 -> left (right column)
         int k = l & 3, is_left = l >= 12;
@@ -1190,8 +1480,11 @@ FI void decode_mb(Ent &e, int skipped) {
         int g = is_left ? GI(3, k) : GI(k, 3);
         dst->ipm[k] = s->ipm_c[g];
         dst->nnz[k] = s->nnz_c[g];
-        dst->mv[k][0] = s->mv_c[g][0], dst->mv[k][1] = s->mv_c[g][1];
-        dst->mvd[k][0] = s->mvd_c[g][0], dst->mvd[k][1] = s->mvd_c[g][1];
+#pragma unroll
+        for (int L = 0; L < NL; L++) {
+            dst->mv[L][k][0] = s->mv_c[L][g][0], dst->mv[L][k][1] = s->mv_c[L][g][1];
+            dst->mvd[L][k][0] = s->mvd_c[L][g][0], dst->mvd[L][k][1] = s->mvd_c[L][g][1];
+        }
     } else if (l >= 16 && l < 24) {
         // chroma nnz edges: [plane][k]
         int i = l - 16, is_left = i >= 4, cpl = (i >> 1) & 1, k = i & 1;
@@ -1200,7 +1493,7 @@ FI void decode_mb(Ent &e, int skipped) {
     }
     LDS_SYNC();
     // new entry -> HBM row; slide the LDS window: [0] <- [1], [1] <- prefetched column x+2; prefetch x+3
-    if (l < 12) {
+    if (l < TOP_DW) {
         const uint32_t nw = reinterpret_cast<const uint32_t *>(tp)[l], w1 = reinterpret_cast<const uint32_t *>(&s->topw[1])[l];
         reinterpret_cast<uint32_t *>(e.top + e.mbx)[l] = nw;
         reinterpret_cast<uint32_t *>(&s->topw[0])[l] = w1;
@@ -1210,6 +1503,9 @@ FI void decode_mb(Ent &e, int skipped) {
     const uint64_t mbi = e.mb_base + static_cast<uint64_t>(e.mby) * e.wmb + e.mbx;
     if (l >= 32) // MbRec: 128 bytes = 32 dwords, lanes 32..63
         reinterpret_cast<uint32_t *>(e.mbrec + mbi)[l - 32] = reinterpret_cast<const uint32_t *>(&r)[l - 32];
+#if MI_ENT_B
+    if (l < 16) reinterpret_cast<uint32_t *>(e.mbmv1 + mbi)[l] = inter ? *reinterpret_cast<const uint32_t *>(s->mv_c[1][GI(l & 3, l >> 2)]) : 0u; // MbMv1
+#endif
     if (l < MI_COEF_BLOCKS && ((cmask >> l) & 1)) { // present blocks, packed in ascending order: 2 x 16 bytes per lane
         uint4 *dst = reinterpret_cast<uint4 *>(e.coefs) + 2 * (static_cast<size_t>(coff) + __builtin_popcount(cmask & ((1u << l) - 1u)));
         dst[0] = reinterpret_cast<const uint4 *>(s->coef)[2 * l], dst[1] = reinterpret_cast<const uint4 *>(s->coef)[2 * l + 1];
@@ -1225,9 +1521,20 @@ FI void fill_none(const Ent &e, int from, int to) {
 }
 
 // ------------------------------------------------------------------ kernel: slice_data() 7.3.4
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI_ENT_MINWAVES, 8))) k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
-                                                           int16_t *coefs, uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status, uint32_t *toprows, int wmb_max) {
+// grid = number of slices of the launch; `slice_base` = index of its first slice (the host orders the slices by launch)
+#if MI_ENT_B
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_entropy_b(const SliceDesc *slices_, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
+                                                           int16_t *coefs, uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status_, uint32_t *toprows_, int wmb_max, uint32_t slice_base,
+                                                           const BSliceExt *bexts, MbMv1 *mbmv1) {
+#else
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI_ENT_MINWAVES, 8))) k_entropy(const SliceDesc *slices_, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
+                                                           int16_t *coefs, uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status_, uint32_t *toprows_, int wmb_max, uint32_t slice_base) {
+#endif
     __shared__ Shared sh;
+    const uint32_t slice_no = slice_base + blockIdx.x;
+    const SliceDesc *slices = slices_ + slice_base;
+    uint32_t *status = status_ + 8 * static_cast<size_t>(slice_base);
+    uint32_t *toprows = toprows_ + static_cast<size_t>(slice_base) * wmb_max * TOP_DW;
     const uint64_t t_begin = wall_clock64();
     Ent e;
     e.s = &sh;
@@ -1235,7 +1542,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     e.bins = 0;
     for (int k = 0; k < 4; k++) e.tacc[k] = 0;
 #endif
-    e.top = reinterpret_cast<TopInfo *>(toprows + static_cast<size_t>(blockIdx.x) * wmb_max * 12);
+    e.top = reinterpret_cast<TopInfo *>(toprows + static_cast<size_t>(blockIdx.x) * wmb_max * TOP_DW);
     e.pre_top = 0;
     e.tab = tab;
     const SliceDesc *sd = &slices[blockIdx.x];
@@ -1284,7 +1591,19 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     sh.posmap[1][l] = tab->zigzag4[(l + 1) & 15];
     sh.posmap[2][l] = tab->zigzag8[l];
     sh.posmap[3][l] = static_cast<uint8_t>(l);
-    if (l < MI_MAX_REFS) sh.ref_slot[l] = sd->ref_slot[l];
+    if (l < MI_MAX_REFS) sh.ref_slot[0][l] = sd->ref_slot[l];
+#if MI_ENT_B
+    {
+        const BSliceExt *bx = &bexts[sd->bext];
+        if (l < MI_MAX_REFS) sh.ref_slot[1][l] = bx->ref_slot1[l], sh.dsf[l] = bx->dist_scale[l];
+        e.nref1 = RFL(static_cast<int>(bx->num_ref_idx_l1_active));
+        e.direct_spatial = RFL(static_cast<int>(bx->direct_spatial)), e.d8inf = RFL(static_cast<int>(bx->direct_8x8_inference));
+        e.col_short = RFL(static_cast<int>(bx->col_short));
+        e.col = reinterpret_cast<const uint32_t *>(bx->col);
+        e.direct8 = 0, e.v_col = 0;
+        e.mbmv1 = mbmv1;
+    }
+#endif
     { // context variables 9.3.1.1: macroblock-level states into the two VGPRs, residual states into LDS
         const int set = e.islice ? 0 : 1 + sd->cabac_init_idc;
         const uint8_t *src = tab->ctx_init[set][sd->slice_qp];
@@ -1300,11 +1619,12 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         sh.rec.dbf_idc = sd->dbf_idc;
         sh.rec.alpha_off = sd->alpha_off, sh.rec.beta_off = sd->beta_off;
         sh.rec.slice_in_pic = sd->slice_in_pic;
-        sh.rec.slice_idx = blockIdx.x;
+        sh.rec.slice_idx = slice_no;
+        sh.rec.refslot1[0] = sh.rec.refslot1[1] = sh.rec.refslot1[2] = sh.rec.refslot1[3] = -1; // (the B build rewrites them per macroblock)
     }
-    for (int i = l; i < e.wmb * 12; i += 64) reinterpret_cast<uint32_t *>(e.top)[i] = 0; // all row-above entries: type NONE
-    if (l < 12) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
-    if (l < 24) reinterpret_cast<uint32_t *>(&sh.topw[0])[l] = 0;
+    for (int i = l; i < e.wmb * TOP_DW; i += 64) reinterpret_cast<uint32_t *>(e.top)[i] = 0; // all row-above entries: type NONE
+    if (l < TOP_DW) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
+    if (l < 2 * TOP_DW) reinterpret_cast<uint32_t *>(&sh.topw[0])[l] = 0;
     LDS_SYNC();
     {
         uint32_t pos = RFL(sd->data_bit_off);
@@ -1326,21 +1646,26 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
             break;
         }
         if (e.mbx == 0 || n_mbs == 0) { // new MB row (or slice start): no left / top-left neighbour; (re)load the row-above window
-            if (l < 12) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
+            if (l < TOP_DW) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stores of the previous row to e.top[] have been issued to L2
-            if (l < 24) reinterpret_cast<uint32_t *>(&sh.topw[0])[l] = top_load(e, e.mbx + l / 12, l % 12);
-            if (l < 12) e.pre_top = top_load(e, e.mbx + 2, l);
+            if (l < 2 * TOP_DW) reinterpret_cast<uint32_t *>(&sh.topw[0])[l] = top_load(e, e.mbx + l / TOP_DW, l % TOP_DW);
+            if (l < TOP_DW) e.pre_top = top_load(e, e.mbx + 2, l);
             LDS_SYNC();
         }
         slide_window(e);
         MI_T0(e);
+#if MI_ENT_B
+        // the co-located macroblock's record (80 bytes), consumed by direct_pred(); "intra" when there is no such picture
+        e.v_col = (e.col && l < 20) ? e.col[static_cast<size_t>(addr) * 20 + l] : ((l >= 16 && l < 19) ? 0xFFFFFFFFu : 0u);
+#endif
         fill_caches(e);
         MI_T(e, 0);
         int skipped = 0;
         if (!e.islice) {
             if (e.cabac) {
                 const Nb a{e.aw}, b{e.bw};
-                skipped = BINI_A(e, 11 + (a.ok() && a.type() != MBT_PSKIP) + (b.ok() && b.type() != MBT_PSKIP));
+                const int skip_type = MI_ENT_B ? MBT_BSKIP : MBT_PSKIP; // ctxIdxOffset 11 in P slices, 24 in B slices (Table 9-34)
+                skipped = BINI_A(e, (MI_ENT_B ? 24 : 11) + (a.ok() && a.type() != skip_type) + (b.ok() && b.type() != skip_type));
             } else {
                 if (skip_state == 0) {
                     pending = static_cast<int>(get_ue(e));

@@ -206,9 +206,13 @@ static_assert(offsetof(ResBuf, chroma) == offsetof(ResBuf, luma) + 512 && offset
 
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
 
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const FramePool *pools,
-                                                         const DevTables *tab, const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max, int n_blocks) {
-    __shared__ InterShared sh;
+// One macroblock per wavefront.  B = false: macroblocks of I/P pictures (one list).  B = true: pictures with B slices -- every
+// 8x8 quadrant is predicted from list 0, list 1 or both (MbRec::refslot / refslot1; list-1 vectors in MbMv1), the two
+// predictions are staged and interpolated one after the other through the same LDS windows and combined by the default,
+// explicit or implicit weighting of 8.4.2.3.
+template <bool B>
+__device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab,
+                                         const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max, int n_blocks, const BSliceExt *bexts, const MbMv1 *mbmv1) {
     const int lane = static_cast<int>(threadIdx.x);
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Give every XCD a
     // contiguous run of macroblocks (whole pictures) so that the reference rows shared by neighbouring macroblocks
@@ -227,6 +231,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     const uint32_t rv = lane < 32 ? reinterpret_cast<const uint32_t *>(grec)[lane] : 0u;
     if (!MB_IS_INTER(static_cast<int>(__builtin_amdgcn_readfirstlane(rv) & 255u))) return;
     if (lane < 32) reinterpret_cast<uint32_t *>(&sh.rec)[lane] = rv;
+    if (B && lane >= 32 && lane < 48) reinterpret_cast<uint32_t *>(sh_mv1)[lane - 32] = reinterpret_cast<const uint32_t *>(mbmv1 + mbi)[lane - 32];
     __syncthreads();
     const MbRec *rec = &sh.rec;
     const int W = wmb * 16, H = hmb * 16; // the picture's own geometry
@@ -248,17 +253,19 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     // Fast path: P_L0_16x16 / P_Skip (or any MB whose 16 blocks share motion) whose displaced block
     // lies inside the picture -> 126 + 54 aligned dword loads instead of 1584 clamped byte loads.
     int ox = 0, ocx = 0;
-    {
-        const int mvx0 = rec->mv[0][0], mvy0 = rec->mv[0][1];
+    const int16_t(*mvs)[2] = rec->mv; // vectors / frame slots of the list being predicted from
+    const int16_t *rslots = rec->refslot;
+    auto stage = [&]() {
+        const int mvx0 = mvs[0][0], mvy0 = mvs[0][1];
         bool same = true;
-        if (lane < 16) same = rec->mv[lane][0] == mvx0 && rec->mv[lane][1] == mvy0 && rec->refslot[((lane >> 3) << 1) | ((lane & 3) >> 1)] == rec->refslot[0];
+        if (lane < 16) same = mvs[lane][0] == mvx0 && mvs[lane][1] == mvy0 && rslots[((lane >> 3) << 1) | ((lane & 3) >> 1)] == rslots[0];
         const int x0 = mbx * 16 + (mvx0 >> 2) - 2, y0 = mby * 16 + (mvy0 >> 2) - 2;
         const int cx0 = mbx * 8 + (mvx0 >> 3), cy0 = mby * 8 + (mvy0 >> 3);
         const bool inside = x0 >= 0 && y0 >= 0 && x0 + 20 <= W - 1 && y0 + 20 <= H - 1 && cx0 >= 0 && cy0 >= 0 && cx0 + 8 <= W / 2 - 1 && cy0 + 8 <= H / 2 - 1 &&
-                            rec->refslot[0] >= 0;
+                            rslots[0] >= 0;
         const int uniform = inside && __all(same);
         if (uniform) {
-            const uint8_t *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rec->refslot[0]), max_slot)) * pool_slot_bytes;
+            const uint8_t *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rslots[0]), max_slot)) * pool_slot_bytes;
             ox = x0 & 3;
             const int xa = x0 - ox;
             for (int i = lane; i < 21 * 6; i += 64) {
@@ -275,8 +282,8 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         } else {
             for (int i = lane; i < 16 * 81; i += 64) {
                 int b = i / 81, rem = i - b * 81, wy = rem / 9, wx = rem - wy * 9;
-                int slot = rec->refslot[((b >> 3) << 1) | ((b & 3) >> 1)];
-                int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
+                int slot = rslots[((b >> 3) << 1) | ((b & 3) >> 1)];
+                int mvx = mvs[b][0], mvy = mvs[b][1];
                 int x = mbx * 16 + (b & 3) * 4 + (mvx >> 2) - 2 + wx, y = mby * 16 + (b >> 2) * 4 + (mvy >> 2) - 2 + wy;
                 x = min(max(x, 0), W - 1), y = min(max(y, 0), H - 1);
                 const uint8_t *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool_slot_bytes;
@@ -284,8 +291,8 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
             }
             for (int i = lane; i < 2 * 16 * 9; i += 64) {
                 int c = i / 144, rem = i - c * 144, b = rem / 9, r9 = rem - b * 9, wy = r9 / 3, wx = r9 - wy * 3;
-                int slot = rec->refslot[((b >> 3) << 1) | ((b & 3) >> 1)];
-                int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
+                int slot = rslots[((b >> 3) << 1) | ((b & 3) >> 1)];
+                int mvx = mvs[b][0], mvy = mvs[b][1];
                 int x = mbx * 8 + (b & 3) * 2 + (mvx >> 3) + wx, y = mby * 8 + (b >> 2) * 2 + (mvy >> 3) + wy;
                 x = min(max(x, 0), W / 2 - 1), y = min(max(y, 0), H / 2 - 1);
                 const uint8_t *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool_slot_bytes + ysz + static_cast<size_t>(c) * (ysz / 4);
@@ -293,7 +300,15 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
             }
         }
         if (lane == 0) sh.uniform = uniform;
+    };
+    // which lists the macroblock predicts from (wave-uniform); a record without any usable reference is concealed from list 0
+    bool use_l0 = true, use_l1 = false;
+    if (B) {
+        use_l1 = rec->refslot1[0] >= 0 || rec->refslot1[1] >= 0 || rec->refslot1[2] >= 0 || rec->refslot1[3] >= 0;
+        use_l0 = rec->refslot[0] >= 0 || rec->refslot[1] >= 0 || rec->refslot[2] >= 0 || rec->refslot[3] >= 0 || !use_l1;
+        if (!use_l0) mvs = sh_mv1->mv, rslots = rec->refslot1;
     }
+    stage();
     // ---- residual (independent of the prediction) ----
     if (has_res) {
         int16_t *coef_lds = sh.rb.luma; // overlay, see InterShared
@@ -304,13 +319,14 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         zero_residual(lane, &sh.rb);
     __syncthreads();
     const SliceDesc *sd = &slices[rec->slice_idx];
-    const int wp = pd->weighted_pred;
+    const int wp = B ? sd->wp_flag : pd->weighted_pred;
     uint8_t *dst_base = const_cast<uint8_t *>(pool_base) + static_cast<size_t>(pd->slot) * pool_slot_bytes;
+    int pv[4], pc[2];          // prediction of the list being processed: luma row of 4, chroma pair
+    int pv0[4] = {0, 0, 0, 0}, pc0[2] = {0, 0}; // B: list-0 prediction while list 1 is computed
     // ---- luma: lane = (4x4 block, row) -> 4 samples ----
-    {
+    auto predict_luma = [&]() {
         const int b = lane >> 2, r = lane & 3;
         const int uni = sh.uniform;
-        int pv[4];
         // The interpolation is written once and instantiated twice: for motion-uniform macroblocks (85 % of them) the
         // fractional position is a SCALAR (readfirstlane), so the class switch below compiles to scalar branches instead of
         // five exec-masked regions; the general instance keeps per-lane positions.
@@ -388,53 +404,145 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         }
         };
         {
-            const int mvx = rec->mv[b][0], mvy = rec->mv[b][1];
+            const int mvx = mvs[b][0], mvy = mvs[b][1];
             if (uni)
                 interpolate(__builtin_amdgcn_readfirstlane(mvx & 3), __builtin_amdgcn_readfirstlane(mvy & 3), true);
             else
                 interpolate(mvx & 3, mvy & 3, false);
         }
-        const int refidx = rec->ref[((b >> 3) << 1) | ((b & 3) >> 1)];
-        uint32_t packed = 0;
-        const int bx = (b & 3) * 4, by = (b >> 2) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int v = pv[i];
-            if (wp) { // 8.4.2.3 explicit weighted prediction
-                const int ld = sd->luma_log2_denom, w0 = sd->wp_lw[refidx], o0 = sd->wp_lo[refidx];
-                v = ld >= 1 ? clip255(((v * w0 + (1 << (ld - 1))) >> ld) + o0) : clip255(v * w0 + o0);
-            }
-            v = clip255(v + sh.rb.luma[(by + r) * 16 + bx + i]);
-            packed |= static_cast<uint32_t>(v) << (8 * i);
-        }
-        *reinterpret_cast<uint32_t *>(dst_base + static_cast<size_t>(mby * 16 + by + r) * W + mbx * 16 + bx) = packed;
-    }
+    };
     // ---- chroma: lane = (plane, row, column pair) -> 2 samples ----
-    {
+    auto predict_chroma = [&]() {
         const int c = lane >> 5, q = lane & 31, cy = q >> 2, cx = (q & 3) * 2;
         const int b = (cy >> 1) * 4 + (cx >> 1);
-        const int mvx = rec->mv[b][0], mvy = rec->mv[b][1], xf = mvx & 7, yf = mvy & 7;
-        const int refidx = rec->ref[((b >> 3) << 1) | ((b & 3) >> 1)];
+        const int mvx = mvs[b][0], mvy = mvs[b][1], xf = mvx & 7, yf = mvy & 7;
         const int uni = sh.uniform;
         // 3x3 window of this 2x2 chroma block: per-block (row stride 4) or inside the shared 9x9 one (row stride 12)
         const uint8_t *w = uni ? &sh.winc16[c][cy & ~1][ocx + (cx & ~1)] : &sh.win_c[c][b][0][0];
         const int cstride = uni ? 12 : 4;
         const int ry = cy & 1;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            int pa = w[ry * cstride + i], pb = w[ry * cstride + i + 1], pcc = w[(ry + 1) * cstride + i], pd_ = w[(ry + 1) * cstride + i + 1];
+            pc[i] = ((8 - xf) * (8 - yf) * pa + xf * (8 - yf) * pb + (8 - xf) * yf * pcc + xf * yf * pd_ + 32) >> 6;
+        }
+    };
+    predict_luma();
+    predict_chroma();
+    if (B && use_l0 && use_l1) { // second list through the same windows
+#pragma unroll
+        for (int i = 0; i < 4; i++) pv0[i] = pv[i];
+        pc0[0] = pc[0], pc0[1] = pc[1];
+        __syncthreads();
+        mvs = sh_mv1->mv, rslots = rec->refslot1;
+        stage();
+        __syncthreads();
+        predict_luma();
+        predict_chroma();
+    }
+    // ---- weighting (8.4.2.3), residual, store ----
+    // one sample: a = list-0 prediction, b = list-1 prediction, u0 / u1 = which lists the 8x8 quadrant uses
+    const BSliceExt *bx = (B && sd->slice_type == 1) ? &bexts[sd->bext] : nullptr;
+    const int wmode = B ? (bx ? bx->wp_mode : (sd->wp_flag ? 1 : 0)) : (wp ? 1 : 0); // 0 default, 1 explicit, 2 implicit
+    auto weigh = [&](int a, int b, bool u0, bool u1, int ld, int w0, int o0, int w1, int o1, int iw1) {
+        if (!B || !(u0 && u1)) {
+            int v = (!B || u0) ? a : b;
+            const int w = (!B || u0) ? w0 : w1, o = (!B || u0) ? o0 : o1;
+            if (wmode == 1) v = ld >= 1 ? clip255(((v * w + (1 << (ld - 1))) >> ld) + o) : clip255(v * w + o);
+            return v;
+        }
+        if (wmode == 1) return clip255(((a * w0 + b * w1 + (1 << ld)) >> (ld + 1)) + ((o0 + o1 + 1) >> 1));
+        if (wmode == 2) return clip255((a * (64 - iw1) + b * iw1 + 32) >> 6);
+        return (a + b + 1) >> 1;
+    };
+    {
+        const int b = lane >> 2, r = lane & 3, q8 = ((b >> 3) << 1) | ((b & 3) >> 1);
+        bool u0 = true, u1 = false;
+        int ref0 = rec->ref[q8], ref1 = 0;
+        if (B) {
+            u1 = rec->refslot1[q8] >= 0, u0 = rec->refslot[q8] >= 0 || !u1;
+            ref1 = MBREC_REF1(rec)[q8];
+        }
+        ref0 = max(ref0, 0) & (MI_MAX_REFS - 1), ref1 = max(ref1, 0) & (MI_MAX_REFS - 1);
+        const int ld = sd->luma_log2_denom, w0 = sd->wp_lw[ref0], o0 = sd->wp_lo[ref0];
+        const int w1 = bx ? bx->wp_lw1[ref1] : 1, o1 = bx ? bx->wp_lo1[ref1] : 0, iw1 = bx ? bx->implicit_w1[ref0][ref1] : 32;
+        const bool both = B && use_l0 && use_l1; // pv0 holds list 0 and pv list 1; otherwise pv is the only prediction there is
+        uint32_t packed = 0;
+        const int bxs = (b & 3) * 4, by = (b >> 2) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int v = both ? weigh(pv0[i], pv[i], u0, u1, ld, w0, o0, w1, o1, iw1) : weigh(pv[i], pv[i], u0, u1 && !u0, ld, w0, o0, w1, o1, iw1);
+            v = clip255(v + sh.rb.luma[(by + r) * 16 + bxs + i]);
+            packed |= static_cast<uint32_t>(v) << (8 * i);
+        }
+        *reinterpret_cast<uint32_t *>(dst_base + static_cast<size_t>(mby * 16 + by + r) * W + mbx * 16 + bxs) = packed;
+    }
+    {
+        const int c = lane >> 5, q = lane & 31, cy = q >> 2, cx = (q & 3) * 2;
+        const int b = (cy >> 1) * 4 + (cx >> 1), q8 = ((b >> 3) << 1) | ((b & 3) >> 1);
+        bool u0 = true, u1 = false;
+        int ref0 = rec->ref[q8], ref1 = 0;
+        if (B) {
+            u1 = rec->refslot1[q8] >= 0, u0 = rec->refslot[q8] >= 0 || !u1;
+            ref1 = MBREC_REF1(rec)[q8];
+        }
+        ref0 = max(ref0, 0) & (MI_MAX_REFS - 1), ref1 = max(ref1, 0) & (MI_MAX_REFS - 1);
+        const int ld = sd->chroma_log2_denom, w0 = sd->wp_cw[ref0][c], o0 = sd->wp_co[ref0][c];
+        const int w1 = bx ? bx->wp_cw1[ref1][c] : 1, o1 = bx ? bx->wp_co1[ref1][c] : 0, iw1 = bx ? bx->implicit_w1[ref0][ref1] : 32;
+        const bool both = B && use_l0 && use_l1;
         uint32_t packed = 0;
 #pragma unroll
         for (int i = 0; i < 2; i++) {
-            int A = w[ry * cstride + i], B = w[ry * cstride + i + 1], C = w[(ry + 1) * cstride + i], D = w[(ry + 1) * cstride + i + 1];
-            int v = ((8 - xf) * (8 - yf) * A + xf * (8 - yf) * B + (8 - xf) * yf * C + xf * yf * D + 32) >> 6;
-            if (wp) {
-                const int ld = sd->chroma_log2_denom, w0 = sd->wp_cw[refidx][c], o0 = sd->wp_co[refidx][c];
-                v = ld >= 1 ? clip255(((v * w0 + (1 << (ld - 1))) >> ld) + o0) : clip255(v * w0 + o0);
-            }
+            int v = both ? weigh(pc0[i], pc[i], u0, u1, ld, w0, o0, w1, o1, iw1) : weigh(pc[i], pc[i], u0, u1 && !u0, ld, w0, o0, w1, o1, iw1);
             v = clip255(v + sh.rb.chroma[c][cy * 8 + cx + i]);
             packed |= static_cast<uint32_t>(v) << (8 * i);
         }
         uint8_t *plane = dst_base + ysz + static_cast<size_t>(c) * (ysz / 4);
         *reinterpret_cast<uint16_t *>(plane + static_cast<size_t>(mby * 8 + cy) * (W / 2) + mbx * 8 + cx) = static_cast<uint16_t>(packed);
     }
+}
+
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const FramePool *pools,
+                                                         const DevTables *tab, const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max, int n_blocks) {
+    __shared__ InterShared sh;
+    inter_mb<false>(sh, nullptr, pic_list, pics, slices, tab, mbrec, coefs, mbs_per_pic_max, n_blocks, nullptr, nullptr);
+}
+// K4 for the pictures that have B slices
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_inter_b(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab,
+                                                           const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max, int n_blocks, const BSliceExt *bexts,
+                                                           const MbMv1 *mbmv1) {
+    __shared__ InterShared sh;
+    __shared__ MbMv1 sh_mv1;
+    inter_mb<true>(sh, &sh_mv1, pic_list, pics, slices, tab, mbrec, coefs, mbs_per_pic_max, n_blocks, bexts, mbmv1);
+}
+
+// Motion a picture leaves for the direct prediction of later B pictures (ColRec, 8.4.1.2.1): one thread per macroblock.
+// grid = (ceil(mbs_per_pic_max / 64), pictures)
+extern "C" __global__ void __launch_bounds__(64) k_colsave(const uint32_t *pic_list, const PicDesc *pics, const MbRec *mbrec, const MbMv1 *mbmv1) {
+    const PicDesc *pd = &pics[pic_list[blockIdx.y]];
+    const uint32_t mb = blockIdx.x * 64 + threadIdx.x;
+    if (mb >= pd->wmb * pd->hmb) return;
+    const MbRec *r = mbrec + pd->mb_base + mb;
+    ColRec out;
+    const bool inter = MB_IS_INTER(r->type);
+    const bool need1 = inter && pd->has_b && (r->ref[0] < 0 || r->ref[1] < 0 || r->ref[2] < 0 || r->ref[3] < 0);
+    MbMv1 v1;
+    if (need1)
+        v1 = mbmv1[pd->mb_base + mb];
+    else
+        for (int i = 0; i < 16; i++) v1.mv[i][0] = v1.mv[i][1] = 0;
+    for (int q = 0; q < 4; q++) {
+        const bool l0 = inter && r->ref[q] >= 0, l1 = inter && !l0 && pd->has_b && r->refslot1[q] >= 0;
+        out.refslot[q] = l0 ? r->refslot[q] : (l1 ? r->refslot1[q] : static_cast<int16_t>(-1));
+        out.ref[q] = l0 ? r->ref[q] : (l1 ? MBREC_REF1(r)[q] : static_cast<int8_t>(-1));
+        for (int k = 0; k < 4; k++) {
+            const int b = (q >> 1) * 8 + (q & 1) * 2 + (k >> 1) * 4 + (k & 1);
+            out.mv[b][0] = l0 ? r->mv[b][0] : (l1 ? v1.mv[b][0] : static_cast<int16_t>(0));
+            out.mv[b][1] = l0 ? r->mv[b][1] : (l1 ? v1.mv[b][1] : static_cast<int16_t>(0));
+        }
+    }
+    out.pad[0] = out.pad[1] = out.pad[2] = out.pad[3] = 0;
+    reinterpret_cast<ColRec *>(pd->col_out)[mb] = out;
 }
 
 // ================================================================== K3: intra prediction

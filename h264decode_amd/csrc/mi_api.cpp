@@ -117,6 +117,7 @@ struct Slot {
     // (The second half keeps h264mi_batch_execute repeatable: a slot freed by a marking operation in the middle of the
     // batch still holds the samples earlier pictures of the batch predict from.)
     bool held = false;
+    int pic = -1; // index into the PicDesc table of the batch being prepared, -1: decoded by an earlier batch
 };
 struct OutFrame { // a decoded picture of the current batch, with the geometry it was coded with
     int slot, wmb, hmb, crop_x, crop_y, width, height;
@@ -150,6 +151,16 @@ struct Stage {
     SliceDesc *d_slices = nullptr, *h_slices = nullptr;
     PicDesc *d_pics = nullptr, *h_pics = nullptr;
     uint32_t *d_status = nullptr, *h_status = nullptr, *d_lists = nullptr, *h_lists = nullptr;
+    BSliceExt *d_bext = nullptr, *h_bext = nullptr; // one per B slice
+    int n_bext = 0;
+    // B pictures take their direct-mode motion from RefPicList1[0], so that picture's slices must have been entropy-decoded
+    // first: slices are launched by level -- 0: I and P slices (k_entropy), n: B slices whose co-located picture is of level
+    // n - 1 or older than the batch (k_entropy_b) -- and the slice table is ordered by level.
+    std::vector<int> pic_level, slice_level; // per picture / per slice of the batch (slice_level in parse order, until the table is sorted)
+    std::vector<uint8_t> pic_save_col;       // the picture's motion is kept for later direct prediction (k_colsave)
+    std::vector<int> level_first;            // first slice of each level in the sorted table (+ end marker)
+    std::vector<uint32_t> colsave_off, colsave_n; // per level: pictures to run k_colsave on, as a range of d_lists
+    std::vector<uint32_t> wave_b_off, wave_b_n, wave_p_off, wave_p_n, wave_nb_off, wave_nb_n; // per wave: B pictures / inter non-B / non-B
     int n_slices = 0, n_pics = 0, wmb_max = 0, hmb_max = 0, mbs_max = 0;
     uint64_t mb_used = 0;
     std::vector<std::vector<uint32_t>> waves, waves_inter;
@@ -178,6 +189,9 @@ struct h264mi_decoder {
     // overlap the reconstruction kernels of pass n (on `stream`); each pass owns one of MI_SETS
     // MbRec / coefficient buffer sets, fenced by events.
     MbRec *d_mbrec[MI_SETS] = {};
+    MbMv1 *d_mv1[MI_SETS] = {};          // list-1 vectors, same indexing as d_mbrec; allocated when the first B slice arrives
+    ColRec *d_colrec = nullptr;          // per stream and frame slot: the motion a picture leaves for later direct prediction
+    size_t colrec_per_slot = 0;          // ColRecs per frame slot
     int16_t *d_coef[MI_SETS] = {};       // coefficient pools: 32-byte blocks, only the blocks that carry anything (MbRec::coef_off / coef_mask)
     uint32_t *d_pool_head = nullptr;     // MI_SETS counters: next free block of each pool, reset before every entropy launch
     uint64_t pool_blocks = 0;            // blocks per pool
@@ -274,11 +288,14 @@ static void free_all(h264mi_decoder *d) {
         if (g.h_status) hipHostFree(g.h_status);
         if (g.d_lists) hipFree(g.d_lists);
         if (g.h_lists) hipHostFree(g.h_lists);
+        if (g.d_bext) hipFree(g.d_bext);
+        if (g.h_bext) hipHostFree(g.h_bext);
         if (g.ev_upload) hipEventDestroy(g.ev_upload);
         if (g.ev_done) hipEventDestroy(g.ev_done);
     }
     for (int i = 0; i < MI_SETS; i++) {
         if (d->d_mbrec[i]) hipFree(d->d_mbrec[i]);
+        if (d->d_mv1[i]) hipFree(d->d_mv1[i]);
         if (d->d_coef[i]) hipFree(d->d_coef[i]);
         if (i == 0 && d->d_pool_head) hipFree(d->d_pool_head);
         if (d->d_toprows[i]) hipFree(d->d_toprows[i]);
@@ -289,6 +306,7 @@ static void free_all(h264mi_decoder *d) {
         if (d->ent_stream[i]) hipStreamDestroy(d->ent_stream[i]);
     if (d->rec_stream) hipStreamDestroy(d->rec_stream);
     if (d->ev_user) hipEventDestroy(d->ev_user);
+    if (d->d_colrec) hipFree(d->d_colrec);
     if (d->d_pools) hipFree(d->d_pools);
     if (d->h_pack) hipHostFree(d->h_pack);
     if (d->d_pack) hipFree(d->d_pack);
@@ -353,8 +371,10 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
         TRY_ALLOC(hipHostMalloc(&g.h_pics, sizeof(PicDesc) * d->pics_cap));
         TRY_ALLOC(hipMalloc(&g.d_status, sizeof(uint32_t) * 8 * d->slices_cap));
         TRY_ALLOC(hipHostMalloc(&g.h_status, sizeof(uint32_t) * 8 * d->slices_cap));
-        TRY_ALLOC(hipMalloc(&g.d_lists, sizeof(uint32_t) * 2 * d->pics_cap));
-        TRY_ALLOC(hipHostMalloc(&g.h_lists, sizeof(uint32_t) * 2 * d->pics_cap));
+        TRY_ALLOC(hipMalloc(&g.d_lists, sizeof(uint32_t) * 5 * d->pics_cap));
+        TRY_ALLOC(hipHostMalloc(&g.h_lists, sizeof(uint32_t) * 5 * d->pics_cap));
+        TRY_ALLOC(hipMalloc(&g.d_bext, sizeof(BSliceExt) * d->slices_cap));
+        TRY_ALLOC(hipHostMalloc(&g.h_bext, sizeof(BSliceExt) * d->slices_cap));
         TRY_ALLOC(hipEventCreateWithFlags(&g.ev_upload, hipEventDisableTiming));
         TRY_ALLOC(hipEventCreateWithFlags(&g.ev_done, hipEventDisableTiming));
         g.out.resize(S);
@@ -407,16 +427,20 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
             TRY_ALLOC(hipMalloc(&d->d_pool_head, sizeof(uint32_t) * MI_SETS));
         }
         TRY_ALLOC(hipMalloc(&d->d_coef[i], d->pool_blocks * 32));
-        TRY_ALLOC(hipMalloc(&d->d_toprows[i], static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * 48));
+        TRY_ALLOC(hipMalloc(&d->d_toprows[i], static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * MI_TOPROW_BYTES));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_ent[i], hipEventDisableTiming));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_rec[i], hipEventDisableTiming));
     }
     TRY_ALLOC(hipMalloc(&d->d_pools, sizeof(FramePool) * S));
     TRY_ALLOC(hipMalloc(&d->d_frames, d->slot_bytes * d->n_slots * S));
+    // 80 bytes per macroblock and frame slot: whatever a later B picture may need of a reference picture's motion (8.4.1.2.1)
+    d->colrec_per_slot = static_cast<size_t>(d->Wmax / 16) * (d->Hmax / 16);
+    TRY_ALLOC(hipMalloc(&d->d_colrec, sizeof(ColRec) * d->colrec_per_slot * d->n_slots * S));
     TRY_ALLOC(hipMalloc(&d->d_tables, sizeof(DevTables)));
     TRY_ALLOC(hipHostMalloc(&d->h_tables, sizeof(DevTables)));
     // K5 keeps a whole macroblock row per in-flight group in dynamic LDS (up to 320 columns): opt in beyond 64 KB
     TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
+    TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock_b), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
     build_tables(d->h_tables);
     d->h_pools.resize(S);
     for (int si = 0; si < S; si++) { // static per stream (kernels take the geometry of a picture from its PicDesc)
@@ -540,8 +564,8 @@ static int compute_poc(StreamState &s, const h264mi_sps &sps, const h264mi_slice
     return poc;
 }
 
-// 8.2.4: RefPicList0 of a P slice as frame-pool slots
-static int build_ref_list(StreamState &s, const h264mi_sps &sps, const h264mi_slice_header &sh, int16_t *out /*MI_MAX_REFS*/) {
+// 8.2.4: RefPicList0 (P and B slices) and RefPicList1 (B slices) as frame-pool slots
+static int build_ref_lists(StreamState &s, const h264mi_sps &sps, const h264mi_slice_header &sh, bool bslice, int16_t *out0 /*MI_MAX_REFS*/, int16_t *out1) {
     const int max_fn = 1 << (sps.log2_max_frame_num_minus4 + 4);
     std::vector<int> st, lt;
     for (int i = 0; i < static_cast<int>(s.slots.size()); i++) {
@@ -556,51 +580,73 @@ static int build_ref_list(StreamState &s, const h264mi_sps &sps, const h264mi_sl
             lt.push_back(i);
         }
     }
-    std::sort(st.begin(), st.end(), [&](int a, int b) { return s.slots[a].pic_num > s.slots[b].pic_num; });
     std::sort(lt.begin(), lt.end(), [&](int a, int b) { return s.slots[a].long_idx < s.slots[b].long_idx; });
-    std::vector<int> list(st);
-    list.insert(list.end(), lt.begin(), lt.end());
-    if (list.empty()) {
-        set_error("P slice without reference pictures");
+    if (st.empty() && lt.empty()) {
+        set_error("P/B slice without reference pictures");
         return H264MI_EBITSTREAM;
     }
-    const int nact = sh.num_ref_idx_l0_active_minus1 + 1;
-    if (nact > MI_MAX_REFS) {
-        set_error("num_ref_idx_l0_active %d > %d (field refs are out of scope)", nact, MI_MAX_REFS);
-        return H264MI_EUNSUPPORTED;
+    std::vector<int> lists[2];
+    if (!bslice) { // 8.2.4.2.1: PicNum descending, then LongTermPicNum ascending
+        std::sort(st.begin(), st.end(), [&](int a, int b) { return s.slots[a].pic_num > s.slots[b].pic_num; });
+        lists[0] = st;
+    } else { // 8.2.4.2.3: by PicOrderCnt relative to the current picture
+        const int cur_poc = s.slots[s.cur_slot].poc;
+        std::vector<int> before, after;
+        for (int i : st) (s.slots[i].poc < cur_poc ? before : after).push_back(i);
+        std::sort(before.begin(), before.end(), [&](int a, int b) { return s.slots[a].poc > s.slots[b].poc; });
+        std::sort(after.begin(), after.end(), [&](int a, int b) { return s.slots[a].poc < s.slots[b].poc; });
+        lists[0] = before;
+        lists[0].insert(lists[0].end(), after.begin(), after.end());
+        lists[1] = after;
+        lists[1].insert(lists[1].end(), before.begin(), before.end());
+        lists[1].insert(lists[1].end(), lt.begin(), lt.end());
     }
-    list.resize(std::max<size_t>(list.size(), nact + 1), -1);
-    if (sh.ref_pic_list_modification_flag_l0) { // 8.2.4.3
-        int pred = sh.frame_num, idx = 0;
-        for (int k = 0; k < sh.n_ref_pic_list_modifications && idx < nact; k++) {
-            int target = -1;
-            if (sh.modification_of_pic_nums[k] < 2) {
-                int diff = sh.modification_value[k] + 1;
-                if (sh.modification_of_pic_nums[k] == 0) {
-                    pred -= diff;
-                    if (pred < 0) pred += max_fn;
-                } else {
-                    pred += diff;
-                    if (pred >= max_fn) pred -= max_fn;
-                }
-                int picnum = pred > sh.frame_num ? pred - max_fn : pred;
-                for (int i : st)
-                    if (s.slots[i].pic_num == picnum) target = i;
-            } else
-                for (int i : lt)
-                    if (s.slots[i].long_idx == sh.modification_value[k]) target = i;
-            if (target < 0) {
-                set_error("ref_pic_list_modification names a missing picture");
-                return H264MI_EBITSTREAM;
-            }
-            for (int c = nact; c > idx; c--) list[c] = list[c - 1];
-            list[idx++] = target;
-            int nidx = idx;
-            for (int c = idx; c <= nact; c++)
-                if (list[c] != target) list[nidx++] = list[c];
+    lists[0].insert(lists[0].end(), lt.begin(), lt.end());
+    if (bslice && lists[1].size() > 1 && lists[1] == lists[0]) std::swap(lists[1][0], lists[1][1]);
+    for (int l = 0; l < (bslice ? 2 : 1); l++) {
+        std::vector<int> &list = lists[l];
+        const int nact = (l ? sh.num_ref_idx_l1_active_minus1 : sh.num_ref_idx_l0_active_minus1) + 1;
+        if (nact > MI_MAX_REFS) {
+            set_error("num_ref_idx_l%d_active %d > %d (field refs are out of scope)", l, nact, MI_MAX_REFS);
+            return H264MI_EUNSUPPORTED;
         }
+        list.resize(nact, -1); // the initial list is cut (or padded with "no reference picture") to the active size
+        list.resize(nact + 1, -1);
+        const int32_t *idcs = l ? sh.modification_of_pic_nums_l1 : sh.modification_of_pic_nums, *vals = l ? sh.modification_value_l1 : sh.modification_value;
+        const int nmod = l ? sh.n_ref_pic_list_modifications_l1 : sh.n_ref_pic_list_modifications;
+        if (l ? sh.ref_pic_list_modification_flag_l1 : sh.ref_pic_list_modification_flag_l0) { // 8.2.4.3
+            int pred = sh.frame_num, idx = 0;
+            for (int k = 0; k < nmod && idx < nact; k++) {
+                int target = -1;
+                if (idcs[k] < 2) {
+                    int diff = vals[k] + 1;
+                    if (idcs[k] == 0) {
+                        pred -= diff;
+                        if (pred < 0) pred += max_fn;
+                    } else {
+                        pred += diff;
+                        if (pred >= max_fn) pred -= max_fn;
+                    }
+                    int picnum = pred > sh.frame_num ? pred - max_fn : pred;
+                    for (int i : st)
+                        if (s.slots[i].pic_num == picnum) target = i;
+                } else
+                    for (int i : lt)
+                        if (s.slots[i].long_idx == vals[k]) target = i;
+                if (target < 0) {
+                    set_error("ref_pic_list_modification names a missing picture");
+                    return H264MI_EBITSTREAM;
+                }
+                for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+                list[idx++] = target;
+                int nidx = idx;
+                for (int c = idx; c <= nact; c++)
+                    if (list[c] != target) list[nidx++] = list[c];
+            }
+        }
+        int16_t *out = l ? out1 : out0;
+        for (int i = 0; i < MI_MAX_REFS; i++) out[i] = static_cast<int16_t>(i < nact ? list[i] : -1);
     }
-    for (int i = 0; i < MI_MAX_REFS; i++) out[i] = static_cast<int16_t>(i < nact ? list[i] : -1);
     return H264MI_OK;
 }
 
@@ -712,6 +758,19 @@ static int scaling_set_for(h264mi_decoder *d, const h264mi_pps &p) {
     return d->n_scaling++;
 }
 
+// The list-1 vector arrays exist only once a B slice has been seen (64 bytes per macroblock and buffer set).
+static int ensure_b_buffers(h264mi_decoder *d) {
+    for (int i = 0; i < MI_SETS; i++)
+        if (!d->d_mv1[i]) {
+            hipError_t e = hipMalloc(&d->d_mv1[i], sizeof(MbMv1) * d->mb_cap);
+            if (e != hipSuccess) {
+                set_error("hipMalloc of the list-1 vector array failed: %s", hipGetErrorString(e));
+                return e == hipErrorOutOfMemory ? H264MI_ENOMEM : H264MI_EDEVICE;
+            }
+        }
+    return H264MI_OK;
+}
+
 // one slice NAL of stream `si`
 // `off` / `rlen`: where batch_prepare's parallel pass put the slice's RBSP in the pinned staging buffer (16-byte aligned)
 static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref_idc, int type) {
@@ -746,8 +805,8 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         s.need_idr = false;
     }
     const int st = sh.slice_type % 5;
-    if (st != 0 && st != 2) {
-        set_error("stream %d: slice_type %d is out of scope (I and P only)", si, sh.slice_type);
+    if (st > 2) {
+        set_error("stream %d: slice_type %d is out of scope (SP / SI slices)", si, sh.slice_type);
         return H264MI_EUNSUPPORTED;
     }
     if (sps.chroma_format != 1 || sps.bit_depth_luma_minus8 || sps.bit_depth_chroma_minus8 || !sps.frame_mbs_only || sps.qprime_y_zero_transform_bypass) {
@@ -792,10 +851,14 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         sl.held = true;
         sl.frame_num = sh.frame_num;
         sl.poc = compute_poc(s, sps, sh);
+        sl.pic = s.cur_pic;
         PicDesc &pd = g.h_pics[s.cur_pic];
         memset(&pd, 0, sizeof(pd));
         pd.stream = si, pd.slot = slot, pd.wmb = wmb, pd.hmb = hmb;
         pd.pool_base = d->h_pools[si].base, pd.slot_bytes = d->slot_bytes, pd.n_slots = static_cast<uint32_t>(d->n_slots);
+        pd.col_out = reinterpret_cast<uint64_t>(d->d_colrec + (static_cast<size_t>(si) * d->n_slots + slot) * d->colrec_per_slot);
+        g.pic_level.resize(g.n_pics, 0), g.pic_save_col.resize(g.n_pics, 0);
+        g.pic_level[s.cur_pic] = 0, g.pic_save_col[s.cur_pic] = 0;
         pd.mb_base = g.mb_used;
         g.mb_used += static_cast<uint64_t>(wmb) * hmb;
         pd.first_slice = g.n_slices;
@@ -836,23 +899,86 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
     sd.pic_idx = s.cur_pic, sd.first_mb = sh.first_mb_in_slice;
     sd.slice_type = static_cast<uint8_t>(st);
     sd.cabac_init_idc = static_cast<uint8_t>(sh.cabac_init), sd.slice_qp = static_cast<uint8_t>(sh.slice_qp_y);
-    sd.num_ref_idx_active = static_cast<uint8_t>(st == 0 ? sh.num_ref_idx_l0_active_minus1 + 1 : 0);
+    sd.num_ref_idx_active = static_cast<uint8_t>(st != 2 ? sh.num_ref_idx_l0_active_minus1 + 1 : 0);
     sd.alpha_off = static_cast<int8_t>(2 * sh.slice_alpha_c0_offset_div2), sd.beta_off = static_cast<int8_t>(2 * sh.slice_beta_offset_div2);
     sd.dbf_idc = static_cast<uint8_t>(sh.disable_deblocking_filter);
     sd.slice_in_pic = static_cast<uint16_t>(s.cur_slices);
     for (int i = 0; i < MI_MAX_REFS; i++) sd.ref_slot[i] = -1;
-    if (st == 0) {
+    int level = 0;
+    if (st != 2) {
         pd.is_intra_only = 0;
-        r = build_ref_list(s, sps, sh, sd.ref_slot);
+        const bool bslice = st == 1;
+        const bool explicit_wp = bslice ? pps.weighted_bipred == 1 : pps.weighted_pred != 0;
+        BSliceExt bx;
+        memset(&bx, 0, sizeof(bx));
+        r = build_ref_lists(s, sps, sh, bslice, sd.ref_slot, bx.ref_slot1);
         if (r != H264MI_OK) return r;
-        sd.wp_flag = static_cast<uint8_t>(pps.weighted_pred);
+        sd.wp_flag = static_cast<uint8_t>(explicit_wp);
         sd.luma_log2_denom = static_cast<uint8_t>(sh.luma_log2_weight_denom), sd.chroma_log2_denom = static_cast<uint8_t>(sh.chroma_log2_weight_denom);
         for (int i = 0; i < MI_MAX_REFS; i++) {
-            sd.wp_lw[i] = static_cast<int16_t>(pps.weighted_pred ? sh.luma_weight_l0[i] : 1), sd.wp_lo[i] = static_cast<int16_t>(sh.luma_offset_l0[i]);
+            sd.wp_lw[i] = static_cast<int16_t>(explicit_wp ? sh.luma_weight_l0[i] : 1), sd.wp_lo[i] = static_cast<int16_t>(sh.luma_offset_l0[i]);
             for (int j = 0; j < 2; j++)
-                sd.wp_cw[i][j] = static_cast<int16_t>(pps.weighted_pred ? sh.chroma_weight_l0[i][j] : 1), sd.wp_co[i][j] = static_cast<int16_t>(sh.chroma_offset_l0[i][j]);
+                sd.wp_cw[i][j] = static_cast<int16_t>(explicit_wp ? sh.chroma_weight_l0[i][j] : 1), sd.wp_co[i][j] = static_cast<int16_t>(sh.chroma_offset_l0[i][j]);
+        }
+        if (bslice) {
+            r = ensure_b_buffers(d);
+            if (r != H264MI_OK) return r;
+            pd.has_b = 1;
+            const int cur_poc = s.slots[s.cur_slot].poc;
+            const int n0 = sh.num_ref_idx_l0_active_minus1 + 1, n1 = sh.num_ref_idx_l1_active_minus1 + 1;
+            bx.num_ref_idx_l1_active = static_cast<uint8_t>(n1);
+            bx.direct_spatial = static_cast<uint8_t>(sh.direct_spatial_mv_pred), bx.direct_8x8_inference = static_cast<uint8_t>(sps.direct_8x8_inference);
+            bx.wp_mode = static_cast<uint8_t>(pps.weighted_bipred);
+            for (int i = 0; i < MI_MAX_REFS; i++) {
+                bx.wp_lw1[i] = static_cast<int16_t>(explicit_wp ? sh.luma_weight_l1[i] : 1), bx.wp_lo1[i] = static_cast<int16_t>(sh.luma_offset_l1[i]);
+                for (int j = 0; j < 2; j++)
+                    bx.wp_cw1[i][j] = static_cast<int16_t>(explicit_wp ? sh.chroma_weight_l1[i][j] : 1), bx.wp_co1[i][j] = static_cast<int16_t>(sh.chroma_offset_l1[i][j]);
+            }
+            // POC distances: DistScaleFactor of temporal direct prediction (8.4.1.2.3) per refIdxL0 against RefPicList1[0], and the
+            // implicit bi-prediction weights (8.4.2.3.1) per (refIdxL0, refIdxL1)
+            auto dist_scale = [&](int slot0, int slot1, bool *copy) {
+                const Slot &p0 = s.slots[slot0], &p1 = s.slots[slot1];
+                const int tb = std::min(std::max(cur_poc - p0.poc, -128), 127), td = std::min(std::max(p1.poc - p0.poc, -128), 127);
+                *copy = td == 0 || p0.ref == 2;
+                if (td == 0) return 256;
+                const int tx = (16384 + std::abs(td / 2)) / td;
+                return std::min(std::max((tb * tx + 32) >> 6, -1024), 1023);
+            };
+            const int col_slot = bx.ref_slot1[0];
+            for (int i = 0; i < MI_MAX_REFS; i++) {
+                bool copy = true;
+                int dsf = 256;
+                if (i < n0 && sd.ref_slot[i] >= 0 && col_slot >= 0) dsf = dist_scale(sd.ref_slot[i], col_slot, &copy);
+                bx.dist_scale[i] = static_cast<int16_t>(copy ? 256 : dsf);
+                for (int j = 0; j < MI_MAX_REFS; j++) {
+                    int w1 = 32;
+                    if (i < n0 && j < n1 && sd.ref_slot[i] >= 0 && bx.ref_slot1[j] >= 0) {
+                        bool cp;
+                        const int f = dist_scale(sd.ref_slot[i], bx.ref_slot1[j], &cp) >> 2;
+                        const int td = s.slots[bx.ref_slot1[j]].poc - s.slots[sd.ref_slot[i]].poc;
+                        if (td != 0 && s.slots[sd.ref_slot[i]].ref != 2 && s.slots[bx.ref_slot1[j]].ref != 2 && f >= -64 && f <= 128) w1 = f;
+                    }
+                    bx.implicit_w1[i][j] = static_cast<int16_t>(w1);
+                }
+            }
+            // the co-located picture: its motion record array, and when its slices are entropy-decoded relative to this one
+            level = 1;
+            if (col_slot >= 0) {
+                const Slot &cs = s.slots[col_slot];
+                bx.col = reinterpret_cast<uint64_t>(d->d_colrec + (static_cast<size_t>(si) * d->n_slots + col_slot) * d->colrec_per_slot);
+                bx.col_short = cs.ref == 1;
+                if (cs.pic >= 0) {
+                    level = g.pic_level[cs.pic] + 1;
+                    g.pic_save_col[cs.pic] = 1;
+                }
+            }
+            sd.bext = static_cast<uint32_t>(g.n_bext);
+            g.h_bext[g.n_bext++] = bx;
         }
     }
+    g.pic_level[s.cur_pic] = std::max(g.pic_level[s.cur_pic], level);
+    g.slice_level.resize(g.n_slices + 1);
+    g.slice_level[g.n_slices] = level;
     g.bits_used = std::max(g.bits_used, off + rlen);
     g.n_slices++;
     s.cur_slices++;
@@ -872,10 +998,12 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     g.prepared = false, g.executed = false;
     g.n_slices = g.n_pics = 0;
     g.bits_used = 0, g.mb_used = 0, g.wmb_max = 0, g.hmb_max = 0, g.mbs_max = 0;
+    g.n_bext = 0;
+    g.pic_level.clear(), g.slice_level.clear(), g.pic_save_col.clear();
     memset(&g.info, 0, sizeof(g.info));
     for (size_t si = 0; si < d->st.size(); si++) {
         StreamState &s = d->st[si];
-        for (auto &sl : s.slots) sl.held = sl.ref != 0; // reference pictures at batch start stay put for the whole batch
+        for (auto &sl : s.slots) sl.held = sl.ref != 0, sl.pic = -1; // reference pictures at batch start stay put for the whole batch
         // the frames of the batch prepared before this one stay readable (and, if it is still executing, writable)
         if (MI_STAGES > 1)
             for (const OutFrame &o : d->stage[prev_stage].out[si]) s.slots[o.slot].held = true;
@@ -949,7 +1077,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
         const int n = n_nals[si];
         std::vector<uint8_t> tmp;
         // what this stream adds to the batch sits at the tail of every table: a failing stream is taken out again
-        const int pics0 = g.n_pics, slices0 = g.n_slices;
+        const int pics0 = g.n_pics, slices0 = g.n_slices, bext0 = g.n_bext;
         const uint64_t mb0 = g.mb_used;
         const int64_t info_mb0 = g.info.n_macroblocks;
         int r = H264MI_OK;
@@ -1005,6 +1133,8 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
             // The stream leaves the batch: its pictures, slices and records are dropped, its references are forgotten
             // (nothing is decodable before its next IDR picture); the other streams are not affected.
             g.n_pics = pics0, g.n_slices = slices0, g.mb_used = mb0, g.info.n_macroblocks = info_mb0;
+            g.n_bext = bext0;
+            g.pic_level.resize(pics0), g.pic_save_col.resize(pics0), g.slice_level.resize(slices0);
             reset_stream(s, true);
             g.out[si].clear();
             s.need_idr = true;
@@ -1015,16 +1145,32 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
         }
         if (s.cur_slot >= 0) finish_picture(d, si);
     }
-    // Longest-processing-time-first: the entropy kernel runs one slice per workgroup and workgroups are
-    // dispatched in index order, so the biggest slices (I pictures) must start first.
-    if (g.n_slices > 1) {
+    // A reference picture that outlives the batch may become the co-located picture of a B picture of a later batch: its
+    // motion is kept too (8.4.1.2.1).
+    g.pic_level.resize(g.n_pics, 0), g.pic_save_col.resize(g.n_pics, 0), g.slice_level.resize(g.n_slices, 0);
+    for (int si = 0; si < n_streams; si++)
+        for (const Slot &sl : d->st[si].slots)
+            if (sl.ref && sl.pic >= 0 && sl.pic < g.n_pics) g.pic_save_col[sl.pic] = 1;
+    // Slice order = launch order: by level (see Stage), and inside a level longest-processing-time-first -- the entropy
+    // kernels run one slice per workgroup and workgroups are dispatched in index order, so the biggest slices (I pictures)
+    // must start first.
+    int n_levels = 1;
+    {
         std::vector<int> order(g.n_slices);
-        for (int i = 0; i < g.n_slices; i++) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return g.h_slices[x].rbsp_size > g.h_slices[y].rbsp_size; });
+        for (int i = 0; i < g.n_slices; i++) order[i] = i, n_levels = std::max(n_levels, g.slice_level[i] + 1);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+            if (g.slice_level[x] != g.slice_level[y]) return g.slice_level[x] < g.slice_level[y];
+            return g.h_slices[x].rbsp_size > g.h_slices[y].rbsp_size;
+        });
         std::vector<SliceDesc> tmp(g.h_slices, g.h_slices + g.n_slices);
-        for (int i = 0; i < g.n_slices; i++) g.h_slices[i] = tmp[order[i]];
+        std::vector<int> lv(g.slice_level);
+        for (int i = 0; i < g.n_slices; i++) g.h_slices[i] = tmp[order[i]], g.slice_level[i] = lv[order[i]];
+        g.level_first.assign(n_levels + 1, g.n_slices);
+        for (int i = g.n_slices - 1; i >= 0; i--) g.level_first[g.slice_level[i]] = i;
+        for (int l = n_levels - 1; l >= 0; l--) g.level_first[l] = std::min(g.level_first[l], g.level_first[l + 1]);
     }
-    // picture "waves": the k-th picture of every stream can be reconstructed side by side
+    // picture "waves": the k-th picture of every stream can be reconstructed side by side.  Per wave: all pictures (K3), the
+    // inter pictures without / the pictures with B slices (K4 / K4 two-list), the pictures without B slices (K5; with: K5 two-list)
     size_t nw = 0;
     for (auto &s : d->st) nw = std::max<size_t>(nw, s.n_pics_in_batch);
     g.waves.assign(nw, {});
@@ -1035,12 +1181,31 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     }
     g.wave_off.clear();
     g.wave_inter_off.clear();
+    g.wave_b_off.assign(nw, 0), g.wave_b_n.assign(nw, 0), g.wave_p_off.assign(nw, 0), g.wave_p_n.assign(nw, 0), g.wave_nb_off.assign(nw, 0), g.wave_nb_n.assign(nw, 0);
     uint32_t pos = 0;
     for (size_t w = 0; w < nw; w++) {
         g.wave_off.push_back(pos);
         for (uint32_t p : g.waves[w]) g.h_lists[pos++] = p;
         g.wave_inter_off.push_back(pos);
-        for (uint32_t p : g.waves_inter[w]) g.h_lists[pos++] = p;
+        g.wave_p_off[w] = pos;
+        for (uint32_t p : g.waves_inter[w])
+            if (!g.h_pics[p].has_b) g.h_lists[pos++] = p;
+        g.wave_p_n[w] = pos - g.wave_p_off[w];
+        g.wave_b_off[w] = pos;
+        for (uint32_t p : g.waves[w])
+            if (g.h_pics[p].has_b) g.h_lists[pos++] = p;
+        g.wave_b_n[w] = pos - g.wave_b_off[w];
+        g.wave_nb_off[w] = pos;
+        for (uint32_t p : g.waves[w])
+            if (!g.h_pics[p].has_b) g.h_lists[pos++] = p;
+        g.wave_nb_n[w] = pos - g.wave_nb_off[w];
+    }
+    g.colsave_off.assign(n_levels, 0), g.colsave_n.assign(n_levels, 0);
+    for (int l = 0; l < n_levels; l++) {
+        g.colsave_off[l] = pos;
+        for (int i = 0; i < g.n_pics; i++)
+            if (g.pic_save_col[i] && g.pic_level[i] == l) g.h_lists[pos++] = i;
+        g.colsave_n[l] = pos - g.colsave_off[l];
     }
     // Uploads go to the entropy stream the next execute will use: in order with that pass's entropy kernel, and not behind
     // the batch that is still executing (the caller's stream waits for its reconstruction).  No stream of their own: the
@@ -1054,6 +1219,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
         HIP_TRY(hipMemcpyAsync(g.d_slices, g.h_slices, sizeof(SliceDesc) * g.n_slices, hipMemcpyHostToDevice, up));
         HIP_TRY(hipMemcpyAsync(g.d_pics, g.h_pics, sizeof(PicDesc) * g.n_pics, hipMemcpyHostToDevice, up));
         HIP_TRY(hipMemcpyAsync(g.d_lists, g.h_lists, sizeof(uint32_t) * pos, hipMemcpyHostToDevice, up));
+        if (g.n_bext) HIP_TRY(hipMemcpyAsync(g.d_bext, g.h_bext, sizeof(BSliceExt) * g.n_bext, hipMemcpyHostToDevice, up));
     }
     if (d->tables_dirty) {
         // a new PPS added a LevelScale set: the table only grows, so the batch still executing keeps seeing its own sets.
@@ -1101,39 +1267,71 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     hipStream_t es = d->ent_stream[d->pass & 1];
     MbRec *mbrec = d->d_mbrec[set];
     int16_t *coef = d->d_coef[set];
+    // Entropy decoding, level by level (Stage::level_first): k_entropy for the I / P slices, k_entropy_b for each level of B
+    // slices, and after each level k_colsave for the pictures whose motion a later B picture (or batch) will ask for.
+    auto launch_entropy = [&](hipStream_t st, size_t lds_pad) {
+        const int n_levels = static_cast<int>(g.level_first.size()) - 1;
+        for (int lv = 0; lv < n_levels; lv++) {
+            const int first = g.level_first[lv], n = g.level_first[lv + 1] - first;
+            if (n > 0) {
+                if (lv == 0)
+                    hipLaunchKernelGGL(k_entropy, dim3(n), dim3(64), lds_pad, st, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
+                                       static_cast<uint32_t>(d->pool_blocks), g.d_status, d->d_toprows[set], g.wmb_max, static_cast<uint32_t>(first));
+                else
+                    hipLaunchKernelGGL(k_entropy_b, dim3(n), dim3(64), 0, st, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
+                                       static_cast<uint32_t>(d->pool_blocks), g.d_status, d->d_toprows[set], g.wmb_max, static_cast<uint32_t>(first), g.d_bext, d->d_mv1[set]);
+            }
+            if (g.colsave_n[lv])
+                hipLaunchKernelGGL(k_colsave, dim3((g.mbs_max + 63) / 64, g.colsave_n[lv]), dim3(64), 0, st, g.d_lists + g.colsave_off[lv], g.d_pics, mbrec, d->d_mv1[set]);
+        }
+    };
     if (prof) { // profiling serialises the two stages on one stream so that HIP-event intervals are per kernel
         HIP_TRY(hipStreamWaitEvent(d->stream, g.ev_upload, 0));
         mark(-1);
         HIP_TRY(hipMemsetAsync(d->d_pool_head + set, 0, sizeof(uint32_t), d->stream));
-        hipLaunchKernelGGL(k_entropy, dim3(g.n_slices), dim3(64), 0, d->stream, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
-                           static_cast<uint32_t>(d->pool_blocks), g.d_status, d->d_toprows[set], g.wmb_max);
+        launch_entropy(d->stream, 0);
         mark(0);
     } else {
         HIP_TRY(hipStreamWaitEvent(es, g.ev_upload, 0));
         if (d->pass >= MI_SETS) HIP_TRY(hipStreamWaitEvent(es, d->ev_rec[set], 0)); // pass n-MI_SETS finished reading this set
+        // B slices may read the motion records (ColRec) the previous pass left: its entropy stream must be through with them
+        if (g.n_bext && d->pass > 0) HIP_TRY(hipStreamWaitEvent(es, d->ev_ent[(d->pass - 1) % MI_SETS], 0));
         HIP_TRY(hipMemsetAsync(d->d_pool_head + set, 0, sizeof(uint32_t), es));
-        hipLaunchKernelGGL(k_entropy, dim3(g.n_slices), dim3(64), d->ent_lds_pad, es, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
-                           static_cast<uint32_t>(d->pool_blocks), g.d_status, d->d_toprows[set], g.wmb_max);
+        launch_entropy(es, d->ent_lds_pad);
         HIP_TRY(hipEventRecord(d->ev_ent[set], es));
         HIP_TRY(hipStreamWaitEvent(d->rec_stream, d->ev_ent[set], 0));
     }
     hipStream_t rs = prof ? d->stream : d->rec_stream;
     for (size_t w = 0; w < g.waves.size(); w++) {
-        const uint32_t n = static_cast<uint32_t>(g.waves[w].size()), ni = static_cast<uint32_t>(g.waves_inter[w].size());
+        const uint32_t n = static_cast<uint32_t>(g.waves[w].size()), ni = g.wave_p_n[w], nbp = g.wave_b_n[w], nnb = g.wave_nb_n[w];
         if (!n) continue;
         if (ni) {
             const uint32_t nb = ni * g.mbs_max;
-            hipLaunchKernelGGL(k_inter, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_inter_off[w], g.d_pics, g.d_slices, d->d_pools,
+            hipLaunchKernelGGL(k_inter, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_p_off[w], g.d_pics, g.d_slices, d->d_pools,
                                d->d_tables, mbrec, coef, g.mbs_max, static_cast<int>(nb));
+            mark(1);
+        }
+        if (nbp) {
+            const uint32_t nb = nbp * g.mbs_max;
+            hipLaunchKernelGGL(k_inter_b, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_b_off[w], g.d_pics, g.d_slices, d->d_tables, mbrec, coef, g.mbs_max,
+                               static_cast<int>(nb), g.d_bext, d->d_mv1[set]);
             mark(1);
         }
         hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, g.d_lists + g.wave_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, coef);
         mark(2);
         int dbw = 1, dbring = 16, dbring_last = 16, dbbufs = 1;
-        mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
-        hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_off[w], g.d_pics,
-                           d->d_pools, d->d_tables, mbrec, dbring, dbring_last, dbbufs);
-        mark(3);
+        if (nnb) {
+            mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
+            hipLaunchKernelGGL(k_deblock, dim3(nnb), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_nb_off[w], g.d_pics,
+                               d->d_pools, d->d_tables, mbrec, dbring, dbring_last, dbbufs);
+            mark(3);
+        }
+        if (nbp) {
+            mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs, MI_DEBLOCK_WAVE_BYTES_B);
+            hipLaunchKernelGGL(k_deblock_b, dim3(nbp), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs, MI_DEBLOCK_WAVE_BYTES_B), rs,
+                               g.d_lists + g.wave_b_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, dbring, dbring_last, dbbufs, d->d_mv1[set]);
+            mark(3);
+        }
     }
     HIP_TRY(hipEventRecord(d->ev_rec[set], rs));
     if (!prof) HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_rec[set], 0)); // the caller's stream sees the finished pass
@@ -1368,7 +1566,8 @@ extern "C" int32_t h264mi_internal_poison(h264mi_decoder *d) {
     for (int i = 0; i < MI_SETS; i++) {
         HIP_TRY(hipMemset(d->d_mbrec[i], 0xFF, sizeof(MbRec) * d->mb_cap));
         HIP_TRY(hipMemset(d->d_coef[i], 0xFF, d->pool_blocks * 32));
-        HIP_TRY(hipMemset(d->d_toprows[i], 0xFF, static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * 48));
+        HIP_TRY(hipMemset(d->d_toprows[i], 0xFF, static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * MI_TOPROW_BYTES));
+        if (d->d_mv1[i]) HIP_TRY(hipMemset(d->d_mv1[i], 0xFF, sizeof(MbMv1) * d->mb_cap));
     }
     HIP_TRY(hipDeviceSynchronize());
     return H264MI_OK;

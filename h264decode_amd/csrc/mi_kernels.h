@@ -5,11 +5,21 @@
 
 // K1/K2: one slice per wavefront.  grid = #slices, block = 64; toprows = 12 dwords per MB column per slice.
 extern "C" __global__ void k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec, int16_t *coefs,
-                                     uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status, uint32_t *toprows, int wmb_max);
+                                     uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status, uint32_t *toprows, int wmb_max, uint32_t slice_base);
+// the same for B slices (k_entropy_b.hip): two reference lists, direct prediction from the ColRec array of RefPicList1[0]; toprows = 18 dwords per column
+extern "C" __global__ void k_entropy_b(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec, int16_t *coefs,
+                                       uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status, uint32_t *toprows, int wmb_max, uint32_t slice_base,
+                                       const BSliceExt *bexts, MbMv1 *mbmv1);
+#define MI_TOPROW_BYTES 72 /* per macroblock column per slice (the B kernel's TopInfo; the I/P kernel uses 48 of them) */
 // K4: inter macroblocks of a set of pictures (one per stream), one macroblock per wavefront.
 // n_blocks = #pictures * mbs_per_pic_max; grid = n_blocks rounded up to a multiple of 8 (XCD-aware block order)
 extern "C" __global__ void k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const FramePool *pools, const DevTables *tab,
                                    const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max, int n_blocks);
+// K4 for pictures with B slices: two lists per 8x8 quadrant (MbRec::refslot1, MbMv1), default / explicit / implicit weighting
+extern "C" __global__ void k_inter_b(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
+                                     const int16_t *coefs, int mbs_per_pic_max, int n_blocks, const BSliceExt *bexts, const MbMv1 *mbmv1);
+// ColRec of a list of pictures (their motion, for the direct prediction of later B pictures); grid = (ceil(mbs_per_pic_max / 64), pictures), block = 64
+extern "C" __global__ void k_colsave(const uint32_t *pic_list, const PicDesc *pics, const MbRec *mbrec, const MbMv1 *mbmv1);
 // K3: intra macroblocks, one workgroup per picture, one wavefront per macroblock row (2-D wavefront order).
 extern "C" __global__ void k_intra(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
                                    const int16_t *coefs);
@@ -17,15 +27,19 @@ extern "C" __global__ void k_intra(const uint32_t *pic_list, const PicDesc *pics
 // block = 64 * nwaves, dynamic LDS = mi_deblock_lds_bytes(nwaves, ring, ring_last); (nwaves, ring, ring_last) from mi_deblock_plan()
 extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring,
                                      int ring_last, int last_bufs);
+// the same for pictures with B slices (k_deblock_b.hip): boundary strengths over two lists; plan with MI_DEBLOCK_WAVE_BYTES_B
+extern "C" __global__ void k_deblock_b(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring,
+                                       int ring_last, int last_bufs, const MbMv1 *mbmv1);
 #ifndef MI_DEBLOCK_MAX_WAVES
 #define MI_DEBLOCK_MAX_WAVES 12    /* 1024 threads; LDS: 6 KB of row state per wavefront + its hand-off ring */
 #endif
 #define MI_DEBLOCK_HDR_BYTES 1088  /* sizeof(DbShared) rounded up to 16 */
 #define MI_DEBLOCK_WAVE_BYTES 6144
+#define MI_DEBLOCK_WAVE_BYTES_B 6912 /* k_deblock_b: + the list-1 vectors of the current / left / upper macroblock per sub-row */
 #define MI_DEBLOCK_SLOT_BYTES 96
 #define MI_DEBLOCK_LDS_MAX (160 * 1024)
-static inline size_t mi_deblock_lds_bytes(int nwaves, int ring, int ring_last, int last_bufs) {
-    return MI_DEBLOCK_HDR_BYTES + static_cast<size_t>(nwaves) * MI_DEBLOCK_WAVE_BYTES +
+static inline size_t mi_deblock_lds_bytes(int nwaves, int ring, int ring_last, int last_bufs, int wave_bytes = MI_DEBLOCK_WAVE_BYTES) {
+    return MI_DEBLOCK_HDR_BYTES + static_cast<size_t>(nwaves) * wave_bytes +
            (static_cast<size_t>(nwaves - 1) * ring + static_cast<size_t>(ring_last) * last_bufs) * MI_DEBLOCK_SLOT_BYTES;
 }
 // Wavefront count and hand-off ring depths for pictures of wmb x hmb macroblocks.  Wavefront w runs the 4-row groups
@@ -37,7 +51,7 @@ static inline size_t mi_deblock_lds_bytes(int nwaves, int ring, int ring_last, i
 // double-buffered by round: the last wavefront's group of round r must not wait until wavefront 0 has read ALL of round
 // r - 1's ring, because wavefront 0's group of round r can only finish when the groups below it -- up to the last
 // wavefront's, through the short rings -- make progress: with a single buffer wide pictures deadlock.  As many wavefronts as fit.
-static inline void mi_deblock_plan(int wmb, int hmb, int *nwaves, int *ring, int *ring_last, int *last_bufs) {
+static inline void mi_deblock_plan(int wmb, int hmb, int *nwaves, int *ring, int *ring_last, int *last_bufs, int wave_bytes = MI_DEBLOCK_WAVE_BYTES) {
     const int ngroups = (hmb + 3) / 4;
     const int w1 = wmb > 0 ? wmb : 1;
     for (int nw = ngroups < MI_DEBLOCK_MAX_WAVES ? ngroups : MI_DEBLOCK_MAX_WAVES; nw >= 1; nw--) {
@@ -45,7 +59,7 @@ static inline void mi_deblock_plan(int wmb, int hmb, int *nwaves, int *ring, int
         const int r = w1 < 16 ? w1 : 16;
         const int rl = rounds > 1 ? w1 : r;
         const int nb = rounds > 2 ? 2 : 1;
-        if (mi_deblock_lds_bytes(nw, r, rl, nb) <= MI_DEBLOCK_LDS_MAX) {
+        if (mi_deblock_lds_bytes(nw, r, rl, nb, wave_bytes) <= MI_DEBLOCK_LDS_MAX) {
             *nwaves = nw, *ring = r, *ring_last = rl, *last_bufs = nb;
             return;
         }

@@ -430,41 +430,49 @@ int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc
             sh->num_ref_idx_l0_active_minus1 = b.ue();
             if (st == 1) sh->num_ref_idx_l1_active_minus1 = b.ue();
         }
-        if (sh->num_ref_idx_l0_active_minus1 > 31) return H264MI_EBITSTREAM;
+        if (sh->num_ref_idx_l0_active_minus1 > 31 || sh->num_ref_idx_l1_active_minus1 > 31) return H264MI_EBITSTREAM;
     }
-    if (st == 1) {
-        set_error("B slices are not supported yet (SURVEY 8f rank 1)");
-        return H264MI_EUNSUPPORTED;
+    if (st != 2 && st != 4) { // ref_pic_list_modification(): list 0, then list 1 of B slices
+        for (int l = 0; l < (st == 1 ? 2 : 1); l++) {
+            int32_t &flag = l ? sh->ref_pic_list_modification_flag_l1 : sh->ref_pic_list_modification_flag_l0;
+            int32_t &n = l ? sh->n_ref_pic_list_modifications_l1 : sh->n_ref_pic_list_modifications;
+            int32_t *idcs = l ? sh->modification_of_pic_nums_l1 : sh->modification_of_pic_nums, *vals = l ? sh->modification_value_l1 : sh->modification_value;
+            flag = b.u(1);
+            if (flag)
+                for (;;) {
+                    uint32_t idc = b.ue();
+                    if (idc == 3) break;
+                    if (idc > 3 || n >= 66 || b.overrun()) return H264MI_EBITSTREAM;
+                    idcs[n] = idc;
+                    vals[n++] = b.ue();
+                }
+        }
     }
-    if (st != 2 && st != 4) { // ref_pic_list_modification()
-        sh->ref_pic_list_modification_flag_l0 = b.u(1);
-        if (sh->ref_pic_list_modification_flag_l0)
-            for (;;) {
-                uint32_t idc = b.ue();
-                if (idc == 3) break;
-                if (idc > 3 || sh->n_ref_pic_list_modifications >= 66 || b.overrun()) return H264MI_EBITSTREAM;
-                sh->modification_of_pic_nums[sh->n_ref_pic_list_modifications] = idc;
-                sh->modification_value[sh->n_ref_pic_list_modifications++] = b.ue();
-            }
-    }
-    if (p->weighted_pred && (st == 0 || st == 3)) { // pred_weight_table()
+    if ((p->weighted_pred && (st == 0 || st == 3)) || (p->weighted_bipred == 1 && st == 1)) { // pred_weight_table()
         sh->luma_log2_weight_denom = b.ue();
         sh->chroma_log2_weight_denom = b.ue();
         if (sh->luma_log2_weight_denom > 7 || sh->chroma_log2_weight_denom > 7) return H264MI_EBITSTREAM;
-        for (int i = 0; i <= sh->num_ref_idx_l0_active_minus1; i++) {
-            sh->luma_weight_l0[i] = 1 << sh->luma_log2_weight_denom;
-            sh->chroma_weight_l0[i][0] = sh->chroma_weight_l0[i][1] = 1 << sh->chroma_log2_weight_denom;
-            sh->luma_weight_l0_flag[i] = b.u(1);
-            if (sh->luma_weight_l0_flag[i]) {
-                sh->luma_weight_l0[i] = b.se();
-                sh->luma_offset_l0[i] = b.se();
-            }
-            sh->chroma_weight_l0_flag[i] = b.u(1);
-            if (sh->chroma_weight_l0_flag[i])
-                for (int j = 0; j < 2; j++) {
-                    sh->chroma_weight_l0[i][j] = b.se();
-                    sh->chroma_offset_l0[i][j] = b.se();
+        for (int l = 0; l < (st == 1 ? 2 : 1); l++) {
+            const int n = l ? sh->num_ref_idx_l1_active_minus1 : sh->num_ref_idx_l0_active_minus1;
+            int32_t *lf = l ? sh->luma_weight_l1_flag : sh->luma_weight_l0_flag, *lw = l ? sh->luma_weight_l1 : sh->luma_weight_l0;
+            int32_t *lo = l ? sh->luma_offset_l1 : sh->luma_offset_l0, *cf = l ? sh->chroma_weight_l1_flag : sh->chroma_weight_l0_flag;
+            int32_t(*cw)[2] = l ? sh->chroma_weight_l1 : sh->chroma_weight_l0, (*co)[2] = l ? sh->chroma_offset_l1 : sh->chroma_offset_l0;
+            for (int i = 0; i <= n; i++) {
+                lw[i] = 1 << sh->luma_log2_weight_denom;
+                cw[i][0] = cw[i][1] = 1 << sh->chroma_log2_weight_denom;
+                lf[i] = b.u(1);
+                if (lf[i]) {
+                    lw[i] = b.se();
+                    lo[i] = b.se();
                 }
+                cf[i] = b.u(1);
+                if (cf[i])
+                    for (int j = 0; j < 2; j++) {
+                        cw[i][j] = b.se();
+                        co[i][j] = b.se();
+                    }
+                if (lw[i] < -128 || lw[i] > 127 || lo[i] < -128 || lo[i] > 127 || b.overrun()) return H264MI_EBITSTREAM;
+            }
         }
     }
     if (nal_ref_idc != 0) { // dec_ref_pic_marking()

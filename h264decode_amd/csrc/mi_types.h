@@ -15,7 +15,9 @@
 #define MI_TYPES_H
 #include <stdint.h>
 
-enum { MBT_NONE = 0, MBT_I4x4, MBT_I8x8, MBT_I16x16, MBT_IPCM, MBT_P16x16, MBT_P16x8, MBT_P8x16, MBT_P8x8, MBT_PSKIP };
+/* B macroblocks: MBT_B stands for every coded inter type of Table 7-14 (the partition geometry only matters while the
+ * macroblock is parsed); B_Direct_16x16 and B_Skip are kept apart because neighbours' CABAC contexts ask for them. */
+enum { MBT_NONE = 0, MBT_I4x4, MBT_I8x8, MBT_I16x16, MBT_IPCM, MBT_P16x16, MBT_P16x8, MBT_P8x16, MBT_P8x8, MBT_PSKIP, MBT_B, MBT_BDIRECT, MBT_BSKIP };
 #define MB_IS_INTRA(t) ((t) >= MBT_I4x4 && (t) <= MBT_IPCM)
 #define MB_IS_INTER(t) ((t) >= MBT_P16x16)
 
@@ -51,15 +53,31 @@ typedef struct __attribute__((aligned(16))) {
     uint8_t dbf_idc;  /* disable_deblocking_filter_idc of the slice */
     int8_t alpha_off, beta_off; /* FilterOffsetA / FilterOffsetB */
     uint16_t slice_in_pic;      /* slice ordinal inside the picture (deblock idc 2, intra availability) */
-    int8_t ipm[16];   /* Intra4x4/8x8PredMode per 4x4 block, raster */
+    int8_t ipm[16];   /* Intra4x4/8x8PredMode per 4x4 block, raster; inter macroblocks of B slices: [0..3] = ref_idx_l1 per 8x8 */
     int8_t ref[4];    /* ref_idx_l0 per 8x8 */
     int16_t refslot[4]; /* frame-pool slot of the referenced picture per 8x8 (-1 none) */
     uint32_t slice_idx; /* index into SliceDesc[] (weighted prediction tables) */
     int16_t mv[16][2];  /* final motion vectors per 4x4 block, raster, quarter-sample units */
     uint32_t coef_off;  /* first 32-byte block of this macroblock in the coefficient pool */
     uint32_t coef_mask; /* bit j: staging block j is present (packed in ascending order); I_PCM: 0xFFF = 384 sample bytes */
-    uint8_t pad[8];
+    int16_t refslot1[4]; /* list 1: frame-pool slot per 8x8, -1 = the quadrant does not use list 1 (always -1 outside B slices);
+                          * the list-1 vectors of the pictures that have B slices live in a second array, MbMv1 */
 } MbRec; /* 128 bytes */
+#define MBREC_REF1(r) ((r)->ipm) /* ref_idx_l1 per 8x8 of an inter macroblock */
+
+typedef struct __attribute__((aligned(16))) {
+    int16_t mv[16][2];
+} MbMv1; /* list-1 motion vectors per 4x4 block: one per MbRec, same index */
+
+/* Motion a picture leaves behind for the direct prediction of later B pictures (8.4.1.2.1): per 4x4 block the vector of
+ * the list the co-located block uses (list 0 if it uses it, otherwise list 1), per 8x8 the reference index and the frame
+ * slot of the picture it points to (-1: intra).  One array per frame slot, written by k_colsave. */
+typedef struct __attribute__((aligned(16))) {
+    int16_t mv[16][2];
+    int16_t refslot[4];
+    int8_t ref[4];
+    uint8_t pad[4];
+} ColRec; /* 80 bytes */
 
 typedef struct {
     uint32_t rbsp_off;     /* byte offset of the slice RBSP in the bitstream buffer */
@@ -73,7 +91,7 @@ typedef struct {
      * -- a gap in front of the slice, the rest after an error or an early end -- gets all-zero records (type MBT_NONE),
      * so that the reconstruction kernels never see stale or uninitialised records. */
     uint32_t fill_from, end_mb;
-    uint8_t slice_type;    /* 0 P, 2 I */
+    uint8_t slice_type;    /* 0 P, 1 B, 2 I */
     uint8_t cabac_init_idc, slice_qp, num_ref_idx_active;
     int8_t alpha_off, beta_off;
     uint8_t dbf_idc, wp_flag;
@@ -82,7 +100,23 @@ typedef struct {
     int16_t ref_slot[MI_MAX_REFS];
     int16_t wp_lw[MI_MAX_REFS], wp_lo[MI_MAX_REFS];
     int16_t wp_cw[MI_MAX_REFS][2], wp_co[MI_MAX_REFS][2];
+    uint32_t bext;         /* B slices: index of the slice's BSliceExt */
 } SliceDesc;
+
+/* What a B slice needs on top of its SliceDesc (host-built, 8.2.4.2.3 / 8.4.1.2 / 8.4.2.3) */
+typedef struct {
+    int16_t ref_slot1[MI_MAX_REFS];  /* RefPicList1 as frame-pool slots */
+    int16_t wp_lw1[MI_MAX_REFS], wp_lo1[MI_MAX_REFS];
+    int16_t wp_cw1[MI_MAX_REFS][2], wp_co1[MI_MAX_REFS][2];
+    int16_t implicit_w1[MI_MAX_REFS][MI_MAX_REFS]; /* [refIdxL0][refIdxL1] -> w1 of 8.4.2.3.1 (w0 = 64 - w1), -64..128 */
+    int16_t dist_scale[MI_MAX_REFS]; /* temporal direct: DistScaleFactor per refIdxL0; 256 where the vector is copied (long-term / equal POC) */
+    uint64_t col;                    /* ColRec array of RefPicList1[0] (device address; 0: no such picture) */
+    uint8_t col_short;               /* RefPicList1[0] is a short-term reference picture (colZeroFlag) */
+    uint8_t direct_spatial, direct_8x8_inference;
+    uint8_t wp_mode;                 /* weighted_bipred_idc: 0 default, 1 explicit, 2 implicit */
+    uint8_t num_ref_idx_l1_active;
+    uint8_t pad[3];
+} BSliceExt;
 
 typedef struct {
     uint32_t stream;
@@ -100,6 +134,9 @@ typedef struct {
     uint32_t n_slots;
     uint64_t pool_base;    /* device address of slot 0 */
     uint64_t slot_bytes;
+    uint64_t col_out;      /* ColRec array of this picture's frame slot */
+    uint8_t has_b;         /* the picture has B slices: MbMv1 records exist, K4 / K5 run their two-list variants */
+    uint8_t pad[7];
 } PicDesc;
 
 typedef struct {

@@ -124,6 +124,11 @@ typedef struct {
     int32_t luma_log2_weight_denom, chroma_log2_weight_denom;
     int32_t luma_weight_l0_flag[32], luma_weight_l0[32], luma_offset_l0[32];
     int32_t chroma_weight_l0_flag[32], chroma_weight_l0[32][2], chroma_offset_l0[32][2];
+    /* list 1 of B slices (7.3.3.1, 7.3.3.2) */
+    int32_t ref_pic_list_modification_flag_l1, n_ref_pic_list_modifications_l1;
+    int32_t modification_of_pic_nums_l1[66], modification_value_l1[66];
+    int32_t luma_weight_l1_flag[32], luma_weight_l1[32], luma_offset_l1[32];
+    int32_t chroma_weight_l1_flag[32], chroma_weight_l1[32][2], chroma_offset_l1[32][2];
     int32_t no_output_of_prior_pics_flag, long_term_reference_flag, adaptive_ref_pic_marking_mode_flag;
     int32_t n_memory_management_control_operations;
     int32_t memory_management_control_operation[66], mmco_arg1[66], mmco_arg2[66];

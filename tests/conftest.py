@@ -69,7 +69,7 @@ def real_stream():
 # the parity matrix shared by CPU (oracle vs generator) and GPU (product vs oracle + generator) tests
 BASE = dict(width=176, height=144, frames=4, idr_period=0)
 # Set when libh264mi decodes B slices; until then the GPU tests assert the documented refusal (H264MI_EUNSUPPORTED = -3).
-PRODUCT_DECODES_B = False
+PRODUCT_DECODES_B = True
 
 MATRIX = {
     "cavlc_I": dict(width=64, height=48, frames=2, idr_period=1, profile_idc=66, cabac=0),

@@ -10,7 +10,7 @@ import streamgen  # noqa: E402
 import oracle  # noqa: E402
 import h264decode_amd as H  # noqa: E402
 
-MBT = ["NONE", "I4x4", "I8x8", "I16x16", "IPCM", "P16x16", "P16x8", "P8x16", "P8x8", "PSKIP"]
+MBT = ["NONE", "I4x4", "I8x8", "I16x16", "IPCM", "P16x16", "P16x8", "P8x16", "P8x8", "PSKIP", "B", "BDIRECT", "BSKIP"]
 
 
 def gpu_type_from_trace(raw, islice_guess):
@@ -61,14 +61,15 @@ def compare(name, kw, dec_cache={}):
                 bad.append(f"qp {o[2]}!={qp[m]}")
             if o[4] != t8[m]:
                 bad.append(f"t8x8 {o[4]}!={t8[m]}")
-            if not is_i and (o[5] != mv0[m, 0] or o[6] != mv0[m, 1]):
+            if not is_i and ref0[m] >= 0 and (o[5] != mv0[m, 0] or o[6] != mv0[m, 1]):
                 bad.append(f"mv0 ({o[5]},{o[6]})!=({mv0[m,0]},{mv0[m,1]})")
-            if not is_i and o[7] != ref0[m]:
-                bad.append(f"ref0 {o[7]}!={ref0[m]}")
-            if raw == -1 and typ[m] != 9:
-                bad.append(f"type skip!={MBT[typ[m]] if typ[m] < 10 else typ[m]}")
+            oref = o[7] + 100 if o[7] <= -100 else o[7]  # the oracle marks macroblocks of B slices by ref - 100
+            if not is_i and oref != ref0[m]:
+                bad.append(f"ref0 {oref}!={ref0[m]}")
+            if raw == -1 and typ[m] not in (9, 12):
+                bad.append(f"type skip!={MBT[typ[m]] if typ[m] < 13 else typ[m]}")
             if bad and shown < 6:
-                print(f"   frame {f} mb {m} ({m % (W//16)},{m // (W//16)}) raw={raw} gpu_type={MBT[typ[m]] if typ[m] < 10 else typ[m]}: " + "; ".join(bad))
+                print(f"   frame {f} mb {m} ({m % (W//16)},{m // (W//16)}) raw={raw} gpu_type={MBT[typ[m]] if typ[m] < 13 else typ[m]}: " + "; ".join(bad))
                 shown += 1
         if f < out.shape[0] and not np.array_equal(out[f], rec[f]):
             d = np.nonzero(out[f] != rec[f])[0]
@@ -84,12 +85,12 @@ def compare(name, kw, dec_cache={}):
                 pl = "Cb" if i < W * H_ * 5 // 4 else "Cr"
             ymis = int((out[f][:W * H_] != rec[f][:W * H_]).sum())
             cmis = len(d) - ymis
-            print(f"   frame {f}: first sample mismatch {pl}({x},{y}) mb {m} type {MBT[typ[m]] if typ[m] < 10 else typ[m]} gpu={out[f][i]} ref={rec[f][i]}; "
-                  f"mismatching luma={ymis} chroma={cmis}; mb types in frame: { {MBT[t]: int((typ==t).sum()) for t in np.unique(typ) if t < 10} }")
+            print(f"   frame {f}: first sample mismatch {pl}({x},{y}) mb {m} type {MBT[typ[m]] if typ[m] < 13 else typ[m]} gpu={out[f][i]} ref={rec[f][i]}; "
+                  f"mismatching luma={ymis} chroma={cmis}; mb types in frame: { {MBT[t]: int((typ==t).sum()) for t in np.unique(typ) if t < 13} }")
             # which MBs mismatch (luma)
             dy = (out[f][:W * H_] != rec[f][:W * H_]).reshape(H_ // 16, 16, W // 16, 16).any(axis=(1, 3))
             bad_mbs = np.nonzero(dy.reshape(-1))[0]
-            print(f"   luma-mismatching MBs ({len(bad_mbs)}): {[(int(b), MBT[typ[b]] if typ[b] < 10 else int(typ[b])) for b in bad_mbs[:12]]}")
+            print(f"   luma-mismatching MBs ({len(bad_mbs)}): {[(int(b), MBT[typ[b]] if typ[b] < 13 else int(typ[b])) for b in bad_mbs[:12]]}")
             break
     dec.close()
     return False
@@ -116,6 +117,9 @@ def main():
         ("lowqp_cavlc", dict(width=176, height=144, frames=3, idr_period=0, profile_idc=66, cabac=0, qp=8, noise=30)),
         ("crop_dbf2", dict(width=180, height=100, frames=3, idr_period=0, profile_idc=77, cabac=1, slices=2, deblock_idc=2, alpha_off_div2=2, beta_off_div2=-1, chroma_qp_offset=3)),
     ]
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+    from conftest import MATRIX
+    cases += [(k, v) for k, v in sorted(MATRIX.items()) if v.get("bframes")]
     sel = sys.argv[1:]
     nok = 0
     for name, kw in cases:
