@@ -87,6 +87,7 @@ def load():
         "h264mi_stream_status": [vp, I32, P(I32)],
         "h264mi_decoder_set_isolation": [vp, I32],
         "h264mi_frame_get_info": [vp, I32, I32, P(FrameInfo)],
+        "h264mi_stream_output_order": [vp, I32, P(I32), I32, P(I32)],
         "h264mi_batch_prepare": [vp, I32, P(vp), P(SZ), P(BatchInfo)],
         "h264mi_batch_execute": [vp],
         "h264mi_batch_sync": [vp],
@@ -125,4 +126,4 @@ EXPORTS = ["h264mi_annexb_scan", "h264mi_nal_parse", "h264mi_sps_parse", "h264mi
            "h264mi_batch_prepare", "h264mi_batch_execute", "h264mi_batch_sync", "h264mi_decode_batch", "h264mi_stream_frame_count",
            "h264mi_frame_device_planes", "h264mi_frame_read", "h264mi_frame_pack_device", "h264mi_frame_read_mbrecs",
            "h264mi_decoder_set_profiling", "h264mi_last_kernel_times", "h264mi_last_error_string", "h264mi_version",
-           "h264mi_last_launch_times", "h264mi_batch_pack_device", "h264mi_stream_reset", "h264mi_stream_status", "h264mi_decoder_set_isolation", "h264mi_frame_get_info"]
+           "h264mi_last_launch_times", "h264mi_batch_pack_device", "h264mi_stream_reset", "h264mi_stream_status", "h264mi_decoder_set_isolation", "h264mi_frame_get_info", "h264mi_stream_output_order"]

@@ -122,6 +122,7 @@ struct Slot {
 struct OutFrame { // a decoded picture of the current batch, with the geometry it was coded with
     int slot, wmb, hmb, crop_x, crop_y, width, height;
     int poc, frame_num, nal_ref_idc, idr, pic;
+    int new_sequence; // IDR picture or memory_management_control_operation 5: picture order counts start over
 };
 struct StreamState {
     h264mi_sps sps[32];
@@ -874,7 +875,10 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         pd.scaling_set = static_cast<uint8_t>(ss);
         pd.order = s.n_pics_in_batch++;
         g.out[si].push_back({slot, wmb, hmb, 2 * sps.frame_crop_left_offset, 2 * sps.frame_crop_top_offset, sps.width, sps.height, sl.poc, sh.frame_num,
-                         sh.nal_ref_idc, sh.nal_unit_type == 5, s.cur_pic});
+                         sh.nal_ref_idc, sh.nal_unit_type == 5, s.cur_pic, sh.nal_unit_type == 5});
+        if (sh.nal_ref_idc && sh.adaptive_ref_pic_marking_mode_flag)
+            for (int k = 0; k < sh.n_memory_management_control_operations; k++)
+                if (sh.memory_management_control_operation[k] == 5) g.out[si].back().new_sequence = 1;
         g.wmb_max = std::max(g.wmb_max, wmb);
         g.hmb_max = std::max(g.hmb_max, hmb);
         g.mbs_max = std::max(g.mbs_max, wmb * hmb);
@@ -1455,6 +1459,21 @@ extern "C" int32_t h264mi_frame_get_info(h264mi_decoder *d, int32_t stream, int3
     fi->width = of->width, fi->height = of->height, fi->coded_width = of->wmb * 16, fi->coded_height = of->hmb * 16;
     fi->crop_x = of->crop_x, fi->crop_y = of->crop_y;
     fi->pic_order_cnt = of->poc, fi->frame_num = of->frame_num, fi->nal_ref_idc = of->nal_ref_idc, fi->idr = of->idr;
+    return H264MI_OK;
+}
+
+extern "C" int32_t h264mi_stream_output_order(h264mi_decoder *d, int32_t stream, int32_t *order, int32_t cap, int32_t *n) {
+    if (!d || !n || stream < 0 || stream >= static_cast<int>(d->st.size()) || cap < 0 || (cap && !order)) return H264MI_EINVAL;
+    const std::vector<OutFrame> &out = d->stage[d->exec].out[stream];
+    std::vector<int> idx(out.size()), seq(out.size());
+    int cur = 0;
+    for (size_t i = 0; i < out.size(); i++) {
+        if (i && out[i].new_sequence) cur++;
+        idx[i] = static_cast<int>(i), seq[i] = cur;
+    }
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return seq[a] != seq[b] ? seq[a] < seq[b] : out[a].poc < out[b].poc; });
+    *n = static_cast<int32_t>(out.size());
+    for (int i = 0; i < cap && i < static_cast<int>(idx.size()); i++) order[i] = idx[i];
     return H264MI_OK;
 }
 

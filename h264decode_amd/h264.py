@@ -299,6 +299,15 @@ class Decoder:
         check(self._L.h264mi_batch_pack_device(self._h, stream, dst_ptr, cap, ctypes.byref(n)))
         return n.value
 
+    def output_order(self, stream=0):
+        """Indices (decoding order) of the stream's frames of the last batch in display order: ascending PicOrderCnt per
+        coded video sequence.  Only differs from range(n) for streams with B pictures."""
+        n = self.frame_count(stream)
+        order = (ctypes.c_int32 * max(n, 1))()
+        got = ctypes.c_int32(0)
+        check(self._L.h264mi_stream_output_order(self._h, stream, order, n, ctypes.byref(got)))
+        return [order[i] for i in range(min(n, got.value))]
+
     def read_mbrecs(self, stream, frame, n_mbs):
         buf = np.zeros(n_mbs * 128, dtype=np.uint8)
         check(self._L.h264mi_frame_read_mbrecs(self._h, stream, frame, buf.ctypes.data, buf.nbytes))

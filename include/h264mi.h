@@ -197,7 +197,7 @@ int32_t h264mi_batch_sync(h264mi_decoder *dec);
 /* prepare + execute + sync */
 int32_t h264mi_decode_batch(h264mi_decoder *dec, int32_t n_streams, const uint8_t *const *bufs, const size_t *lens, h264mi_batch_info *info);
 
-/* Frames of the last batch, in decoding order (== output order for the I/P streams in scope). */
+/* Frames of the last batch, in decoding order (== output order unless the stream has B pictures: h264mi_stream_output_order). */
 int32_t h264mi_stream_frame_count(h264mi_decoder *dec, int32_t stream, int32_t *n);
 /* Device pointers + pitches of a decoded frame (coded size; planes are resident in HBM until the
  * next h264mi_batch_prepare). */
@@ -210,6 +210,12 @@ typedef struct {
     int32_t frame_num, nal_ref_idc, idr;
 } h264mi_frame_info;
 int32_t h264mi_frame_get_info(h264mi_decoder *dec, int32_t stream, int32_t frame, h264mi_frame_info *info);
+/* Output (display) order of the frames of the last batch of one stream: order[k] = index (decoding order) of the k-th frame
+ * to show -- ascending PicOrderCnt inside each coded video sequence (a new one starts at an IDR picture or at a picture
+ * with memory_management_control_operation 5).  The batch is ordered on its own: a caller that cuts batches in the middle
+ * of a group of B pictures merges the tail of one batch with the head of the next by pic_order_cnt.  (The reference has no
+ * output process at all: h264/server.go:113-166 stops at the parsed slice.) */
+int32_t h264mi_stream_output_order(h264mi_decoder *dec, int32_t stream, int32_t *order, int32_t cap, int32_t *n);
 /* Copy a frame to host memory as tight I420 (crop != 0: display size, else coded size). */
 int32_t h264mi_frame_read(h264mi_decoder *dec, int32_t stream, int32_t frame, int32_t crop, uint8_t *dst, size_t cap);
 /* Cropped, tightly packed I420 copy on the device (K6): dst is a DEVICE pointer. */

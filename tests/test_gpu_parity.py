@@ -365,3 +365,61 @@ def test_gpu_prepare_overlaps_execute(H, sg):
     dec.sync()
     assert np.array_equal(dec.read_frames(0, crop=False), c[1])
     dec.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# B pictures
+
+@pytest.mark.parametrize("name,chunk", [("b_temporal_cabac", 1), ("b_ibbp_cavlc", 2), ("b_wp_implicit", 1), ("b_gop_intra_pcm", 3)])
+def test_gpu_b_stream_split_across_batches(name, chunk, H, sg):
+    """Reference lists, picture order counts and the co-located motion (ColRec) survive batch boundaries: a B stream fed
+    `chunk` pictures per call -- every B picture's co-located picture then comes from an earlier batch -- decodes like one piece."""
+    kw = MATRIX[name]
+    stream, rec, sizes = sg.encode(**kw)
+    dec = H.Decoder(max_streams=1, max_width=kw["width"], max_height=kw["height"], max_frames_per_batch=chunk, max_slices_per_frame=kw.get("slices", 1))
+    got, pos = [], 0
+    for k in range(0, len(sizes), chunk):
+        n = int(sizes[k:k + chunk].sum())
+        dec.decode([stream[pos:pos + n]])
+        pos += n
+        got.append(dec.read_frames(0, crop=False))
+    dec.close()
+    assert np.array_equal(np.concatenate(got), rec)
+
+
+def test_gpu_b_and_p_streams_side_by_side_1080p(H, sg):
+    """Full-size pictures through the two-list kernels (K4/K5 variants run next to the I/P ones in the same waves): four
+    1080p streams -- temporal direct + implicit weights (CABAC), spatial direct (CAVLC), P only, High 8x8 with 4 slices."""
+    base = dict(width=1920, height=1080, frames=7, idr_period=0, qp=30)
+    cfgs = [dict(base, profile_idc=77, cabac=1, bframes=2, num_ref_frames=3, direct_temporal=1, weighted_bipred=2, bskip_permille=400, seed=61),
+            dict(base, profile_idc=77, cabac=0, bframes=1, num_ref_frames=2, bskip_permille=400, seed=62),
+            dict(base, profile_idc=77, cabac=1, num_ref_frames=2, seed=63),
+            dict(base, profile_idc=100, cabac=1, transform8x8=1, bframes=3, num_ref_frames=2, slices=4, weighted_bipred=1, sub8x8_permille=300, seed=64)]
+    enc = [sg.encode(**c) for c in cfgs]
+    dec = H.Decoder(max_streams=4, max_width=1920, max_height=1088, max_frames_per_batch=7, max_slices_per_frame=4)
+    dec.decode([e[0] for e in enc])
+    for i, e in enumerate(enc):
+        got = dec.read_frames(i, crop=False)
+        assert got.shape == e[1].shape
+        bad = [f for f in range(got.shape[0]) if not np.array_equal(got[f], e[1][f])]
+        assert not bad, (i, bad)
+    dec.close()
+
+
+def test_gpu_output_order_of_b_streams(H, sg):
+    kw = MATRIX["b_gop_intra_pcm"]  # two IDR periods, three B pictures between the anchors
+    stream, _, _ = sg.encode(**kw)
+    dec = H.Decoder(max_streams=2, max_width=kw["width"], max_height=kw["height"], max_frames_per_batch=kw["frames"])
+    pstream, _, _ = sg.encode(**MATRIX["cabac_IPP"])
+    dec.decode([stream, pstream])
+    order = dec.output_order(0)
+    info = [dec.frame_info(0, f) for f in range(dec.frame_count(0))]
+    assert sorted(order) == list(range(kw["frames"])) and order != list(range(kw["frames"]))
+    seq, cur = [], -1
+    for fi in info:
+        cur += fi.idr
+        seq.append(cur)
+    keys = [(seq[i], info[i].pic_order_cnt) for i in order]
+    assert keys == sorted(keys) and len(set(keys)) == len(keys)
+    assert dec.output_order(1) == list(range(dec.frame_count(1)))  # no B pictures: decoding order
+    dec.close()
