@@ -99,6 +99,23 @@ def extra_configs(H, streams, F, W, Hc, device, args):
     r["workload"] = "C3: 1 stream x %d frames (%d GOPs)" % (F * g1, g1)
     out["single_stream"] = r
     dec.close()
+    del dec
+    # B pictures: the same recipe coded I B B P ... (two B pictures between the anchors, three reference
+    # frames, spatial direct), through k_entropy_b / k_inter_b / k_deblock_b.  16 distinct streams, each used twice.
+    import streamgen
+    nb = 16
+    with ThreadPoolExecutor(max_workers=max(1, min(nb, (os.cpu_count() or 8) - 1))) as ex:
+        gen = list(ex.map(lambda sd: streamgen.encode(want_recon=True, **dict(streamgen.recipe("C3", frames=F, idr_period=F, seed=sd, width=W, height=args.height),
+                                                                                  bframes=2, num_ref_frames=3, bskip_permille=300)), range(3000, 3000 + nb)))
+    bstreams = [g[0] for g in gen] * 2
+    dec = H.Decoder(max_streams=len(bstreams), max_width=W, max_height=Hc, max_frames_per_batch=F, max_slices_per_frame=1, device=device,
+                    max_bitstream_bytes=int(sum(len(s) for s in bstreams) * 1.1) + (1 << 20))
+    r = timed_fps(dec, bstreams, len(bstreams) * F, steps=max(2, args.steps))
+    got = dec.read_frames(nb + 1, crop=False)
+    r["parity"] = "bit-exact vs streamgen recon (stream %d, all frames)" % (nb + 1) if np.array_equal(got, gen[1][1]) else "MISMATCH"
+    r["workload"] = "%d streams (%d distinct) x %d frames, I B B P coding order, 3 reference frames" % (len(bstreams), nb, F)
+    out["b_pictures"] = r
+    dec.close()
     return out
 
 

@@ -232,3 +232,81 @@ func (d *Decoder) FrameRead(stream, frame int, crop bool, w, h int) ([]byte, err
 	}
 	return buf, nil
 }
+
+// ---- round-2 API: per-stream control, per-frame geometry / picture order, display order, pipelined ingest ----
+//
+// Threading (include/h264mi.h "Threading"): a decoder handle is used by one goroutine at a time; the library selects the
+// decoder's device per call, but hipSetDevice and the last-error string are per OS thread, so a goroutine that reads
+// LastError after a failing call must not have migrated: wrap call + error fetch in runtime.LockOSThread /
+// UnlockOSThread (status() above does both inside one cgo call sequence and is safe as long as the goroutine is locked).
+
+type FrameInfo struct {
+	Width, Height, CodedWidth, CodedHeight, CropX, CropY int
+	PicOrderCnt, FrameNum, NalRefIdc                     int
+	IDR                                                  bool
+}
+
+// SetIsolation: a stream with a bitstream error leaves the batch (its status is reported by StreamStatus, it decodes again
+// from its next IDR picture); the other streams of the batch are not affected.
+func (d *Decoder) SetIsolation(on bool) error {
+	v := 0
+	if on {
+		v = 1
+	}
+	return status(C.h264mi_decoder_set_isolation(d.h, C.int32_t(v)))
+}
+func (d *Decoder) StreamStatus(stream int) (int, error) {
+	var st C.int32_t
+	err := status(C.h264mi_stream_status(d.h, C.int32_t(stream), &st))
+	return int(st), err
+}
+
+// StreamReset forgets parameter sets, reference pictures and POC history of one stream slot (a new connection takes it over).
+func (d *Decoder) StreamReset(stream int) error { return status(C.h264mi_stream_reset(d.h, C.int32_t(stream))) }
+
+func (d *Decoder) FrameCount(stream int) (int, error) {
+	var n C.int32_t
+	err := status(C.h264mi_stream_frame_count(d.h, C.int32_t(stream), &n))
+	return int(n), err
+}
+func (d *Decoder) FrameInfo(stream, frame int) (FrameInfo, error) {
+	var c C.h264mi_frame_info
+	if err := status(C.h264mi_frame_get_info(d.h, C.int32_t(stream), C.int32_t(frame), &c)); err != nil {
+		return FrameInfo{}, err
+	}
+	return FrameInfo{Width: int(c.width), Height: int(c.height), CodedWidth: int(c.coded_width), CodedHeight: int(c.coded_height), CropX: int(c.crop_x),
+		CropY: int(c.crop_y), PicOrderCnt: int(c.pic_order_cnt), FrameNum: int(c.frame_num), NalRefIdc: int(c.nal_ref_idc), IDR: c.idr != 0}, nil
+}
+
+// OutputOrder: indices (decoding order) of the stream's frames of the last batch in display order -- ascending PicOrderCnt
+// per coded video sequence.  Differs from 0..n-1 only for streams with B pictures.
+func (d *Decoder) OutputOrder(stream int) ([]int, error) {
+	n, err := d.FrameCount(stream)
+	if err != nil || n == 0 {
+		return nil, err
+	}
+	buf := make([]C.int32_t, n)
+	var got C.int32_t
+	if err := status(C.h264mi_stream_output_order(d.h, C.int32_t(stream), &buf[0], C.int32_t(n), &got)); err != nil {
+		return nil, err
+	}
+	out := make([]int, int(got))
+	for i := range out {
+		out[i] = int(buf[i])
+	}
+	return out, nil
+}
+
+// Prepare / Execute / Sync: the three phases of DecodeBatch.  Prepare(n+1) may be called while batch n is still executing
+// (two staging sets): host parsing and the H2D copies then overlap the kernels of batch n.  The frames of batch n stay
+// readable until the batch after n+1 is prepared.
+func (d *Decoder) Execute() error { return status(C.h264mi_batch_execute(d.h)) }
+func (d *Decoder) Sync() error    { return status(C.h264mi_batch_sync(d.h)) }
+
+// PackBatch writes tight cropped I420 copies of every frame of the last batch (stream < 0: all streams, stream-major) into
+// device memory `dst` with one kernel launch and returns the byte count.
+func (d *Decoder) PackBatch(stream int, dst unsafe.Pointer, capBytes int) (int, error) {
+	var n C.size_t
+	err := status(C.h264mi_batch_pack_device(d.h, C.int32_t(stream), dst, C.size_t(capBytes), &n))
+	return int(n), err
+}

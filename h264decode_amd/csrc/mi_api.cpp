@@ -201,6 +201,7 @@ struct h264mi_decoder {
     hipEvent_t ev_user = nullptr;
     hipEvent_t ev_ent[MI_SETS] = {}, ev_rec[MI_SETS] = {};
     uint64_t pass = 0; // execute() counter
+    bool last_pass_had_b = false;
     uint64_t mb_cap = 0;
     FramePool *d_pools = nullptr;
     std::vector<FramePool> h_pools;
@@ -1298,8 +1299,11 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     } else {
         HIP_TRY(hipStreamWaitEvent(es, g.ev_upload, 0));
         if (d->pass >= MI_SETS) HIP_TRY(hipStreamWaitEvent(es, d->ev_rec[set], 0)); // pass n-MI_SETS finished reading this set
-        // B slices may read the motion records (ColRec) the previous pass left: its entropy stream must be through with them
-        if (g.n_bext && d->pass > 0) HIP_TRY(hipStreamWaitEvent(es, d->ev_ent[(d->pass - 1) % MI_SETS], 0));
+        // B slices read the motion records (ColRec) the previous pass wrote, and this pass's k_colsave may rewrite a record
+        // (of a frame slot released meanwhile) that the previous pass's B slices still read: either way the previous pass's
+        // entropy stream must be through first.  Batches without B slices on both sides keep overlapping freely.
+        if ((g.n_bext || d->last_pass_had_b) && d->pass > 0) HIP_TRY(hipStreamWaitEvent(es, d->ev_ent[(d->pass - 1) % MI_SETS], 0));
+        d->last_pass_had_b = g.n_bext > 0;
         HIP_TRY(hipMemsetAsync(d->d_pool_head + set, 0, sizeof(uint32_t), es));
         launch_entropy(es, d->ent_lds_pad);
         HIP_TRY(hipEventRecord(d->ev_ent[set], es));

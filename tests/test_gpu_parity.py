@@ -106,8 +106,10 @@ def test_gpu_repeated_execute_is_idempotent(H, sg):
     dec.close()
 
 
-def test_gpu_corrupt_streams_do_not_hang_or_crash(H, sg):
-    kw = dict(width=176, height=144, frames=3, idr_period=0, profile_idc=77, cabac=1, seed=5)
+@pytest.mark.parametrize("extra", [dict(frames=3), dict(frames=7, bframes=2, num_ref_frames=2, direct_temporal=1, weighted_bipred=2),
+                                   dict(frames=7, bframes=2, num_ref_frames=3, cabac=0, sub8x8_permille=400)])
+def test_gpu_corrupt_streams_do_not_hang_or_crash(extra, H, sg):
+    kw = dict(dict(width=176, height=144, frames=3, idr_period=0, profile_idc=77, cabac=1, seed=5), **extra)
     stream, _, _ = sg.encode(**kw)
     rng = np.random.default_rng(0)
     for trial in range(6):
@@ -115,14 +117,14 @@ def test_gpu_corrupt_streams_do_not_hang_or_crash(H, sg):
         for _ in range(8):
             i = int(rng.integers(60, len(b)))
             b[i] ^= 1 << int(rng.integers(0, 8))
-        dec = H.Decoder(max_streams=1, max_width=176, max_height=144, max_frames_per_batch=3)
+        dec = H.Decoder(max_streams=1, max_width=176, max_height=144, max_frames_per_batch=kw["frames"])
         try:
             dec.decode([bytes(b)])
         except H.H264MIError as e:
-            assert e.code in (-2, -3, -8)
+            assert e.code in (-2, -3, -7, -8), e
         dec.close()
     # truncated
-    dec = H.Decoder(max_streams=1, max_width=176, max_height=144, max_frames_per_batch=3)
+    dec = H.Decoder(max_streams=1, max_width=176, max_height=144, max_frames_per_batch=kw["frames"])
     try:
         dec.decode([stream[:len(stream) // 2]])
     except H.H264MIError as e:
