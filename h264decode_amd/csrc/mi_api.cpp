@@ -434,7 +434,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_rec[i], hipEventDisableTiming));
     }
     TRY_ALLOC(hipMalloc(&d->d_pools, sizeof(FramePool) * S));
-    TRY_ALLOC(hipMalloc(&d->d_frames, d->slot_bytes * d->n_slots * S));
+    TRY_ALLOC(hipMalloc(&d->d_frames, d->slot_bytes * d->n_slots * S + 256)); // (K4's unaligned dword loads may read 3 bytes past a plane)
     // 80 bytes per macroblock and frame slot: whatever a later B picture may need of a reference picture's motion (8.4.1.2.1)
     d->colrec_per_slot = static_cast<size_t>(d->Wmax / 16) * (d->Hmax / 16);
     TRY_ALLOC(hipMalloc(&d->d_colrec, sizeof(ColRec) * d->colrec_per_slot * d->n_slots * S));
@@ -1274,10 +1274,18 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     int16_t *coef = d->d_coef[set];
     // Entropy decoding, level by level (Stage::level_first): k_entropy for the I / P slices, k_entropy_b for each level of B
     // slices, and after each level k_colsave for the pictures whose motion a later B picture (or batch) will ask for.
-    auto launch_entropy = [&](hipStream_t st, size_t lds_pad) {
+    auto launch_entropy = [&](hipStream_t st, size_t lds_pad, bool fence_prev_pass) {
         const int n_levels = static_cast<int>(g.level_first.size()) - 1;
         for (int lv = 0; lv < n_levels; lv++) {
             const int first = g.level_first[lv], n = g.level_first[lv + 1] - first;
+            // ColRec arrays cross passes: B slices read what the previous pass's k_colsave wrote, and this pass's k_colsave may
+            // rewrite the record array of a frame slot (released meanwhile) that the previous pass's B slices still read.  So
+            // everything after the I/P launch waits for the previous pass's entropy stream -- the I/P launch itself does not,
+            // it overlaps the previous pass's B launches; batches without B slices on both sides never wait.
+            if (fence_prev_pass && (lv > 0 || g.colsave_n[lv])) {
+                hipStreamWaitEvent(st, d->ev_ent[(d->pass - 1) % MI_SETS], 0);
+                fence_prev_pass = false;
+            }
             if (n > 0) {
                 if (lv == 0)
                     hipLaunchKernelGGL(k_entropy, dim3(n), dim3(64), lds_pad, st, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
@@ -1294,18 +1302,14 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         HIP_TRY(hipStreamWaitEvent(d->stream, g.ev_upload, 0));
         mark(-1);
         HIP_TRY(hipMemsetAsync(d->d_pool_head + set, 0, sizeof(uint32_t), d->stream));
-        launch_entropy(d->stream, 0);
+        launch_entropy(d->stream, 0, false);
         mark(0);
     } else {
         HIP_TRY(hipStreamWaitEvent(es, g.ev_upload, 0));
         if (d->pass >= MI_SETS) HIP_TRY(hipStreamWaitEvent(es, d->ev_rec[set], 0)); // pass n-MI_SETS finished reading this set
-        // B slices read the motion records (ColRec) the previous pass wrote, and this pass's k_colsave may rewrite a record
-        // (of a frame slot released meanwhile) that the previous pass's B slices still read: either way the previous pass's
-        // entropy stream must be through first.  Batches without B slices on both sides keep overlapping freely.
-        if ((g.n_bext || d->last_pass_had_b) && d->pass > 0) HIP_TRY(hipStreamWaitEvent(es, d->ev_ent[(d->pass - 1) % MI_SETS], 0));
-        d->last_pass_had_b = g.n_bext > 0;
         HIP_TRY(hipMemsetAsync(d->d_pool_head + set, 0, sizeof(uint32_t), es));
-        launch_entropy(es, d->ent_lds_pad);
+        launch_entropy(es, d->ent_lds_pad, (g.n_bext || d->last_pass_had_b) && d->pass > 0);
+        d->last_pass_had_b = g.n_bext > 0;
         HIP_TRY(hipEventRecord(d->ev_ent[set], es));
         HIP_TRY(hipStreamWaitEvent(d->rec_stream, d->ev_ent[set], 0));
     }

@@ -3,7 +3,7 @@
 extra=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-rm -f h264decode_amd/csrc/_build/k_*.o
+rm -f h264decode_amd/csrc/_build/*.o
 make -s -j16 -C h264decode_amd/csrc EXTRA="$extra" 2>&1 | grep -E "error" 
 echo "== $extra"
 timeout -k 10 200 python tools/slice_stats.py 1 4 2>&1 | grep "^slice [01] "
