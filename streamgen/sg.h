@@ -56,6 +56,8 @@ typedef struct {
     int direct_temporal;    /* 0: direct_spatial_mv_pred_flag = 1; 1: temporal direct */
     int weighted_bipred;    /* weighted_bipred_idc: 0 default average, 1 explicit, 2 implicit */
     int bskip_permille;     /* probability of B_Skip; B_Direct_16x16 gets half of it on top */
+    int b_pyramid;          /* with bframes >= 2: the middle B picture of a group is coded first, as a REFERENCE picture (nal_ref_idc 2);
+                             * the other B pictures of the group may predict from it and take it as their co-located picture */
 } sg_params;
 
 void sg_default_params(sg_params *p);

@@ -1901,6 +1901,8 @@ static void plan_ref_list(enc *e) {
     /* temporal direct maps the co-located block's reference picture into RefPicList0 of the B picture: an anchor must not
      * predict from the one picture that its own arrival pushes out of the sliding window */
     if (e->p.bframes > 0 && e->p.direct_temporal && e->nref_active > 1 && e->nref_active == e->p.num_ref_frames) e->nref_active--;
+    /* ... and with reference B pictures two pictures leave the window before the last B picture of the next group is decoded */
+    if (e->p.b_pyramid && e->p.direct_temporal && e->nref_active > 2) e->nref_active = 2;
     e->n_rplm = 0;
     sg_pic *final[12];
     int nf = 0;
@@ -1984,6 +1986,10 @@ static void plan_b_lists(enc *e) {
     e->nref_active = n < e->p.num_ref_frames ? n : e->p.num_ref_frames;
     e->nref1_active = n < 2 ? n : 1 + (int)(rnd(e) % 2); /* one or two list-1 entries */
     if (e->nref1_active > e->p.num_ref_frames) e->nref1_active = e->p.num_ref_frames;
+    if (e->nal_ref_idc && e->p.direct_temporal) { /* a reference B picture (b_pyramid) may become a co-located picture: see plan_ref_list() */
+        if (e->nref_active > 2) e->nref_active = 2;
+        e->nref1_active = 1;
+    }
     for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? l0[i] : NULL, e->refs1[i] = i < e->nref1_active ? l1[i] : NULL;
     e->n_rplm = 0;
 }
@@ -2128,7 +2134,10 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         if (p->num_ref_frames < 2) p->num_ref_frames = 2;
         p->poc_type = 0, p->nonref_period = 0, p->mmco = 0, p->idr_long_term = 0;
         if (p->bframes > 3) p->bframes = 3;
-    }
+        if (p->bframes < 2) p->b_pyramid = 0;
+        if (p->b_pyramid) p->num_ref_frames = 4; /* two anchors, the reference B picture of this group and the one of the group before */
+    } else
+        p->b_pyramid = 0;
     e->W = (p->width + 15) & ~15, e->H = (p->height + 15) & ~15;
     e->wmb = e->W / 16, e->hmb = e->H / 16;
     if (p->slices > e->hmb) p->slices = e->hmb;
@@ -2162,6 +2171,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
      * (I or P) and the pictures between two anchors are B pictures coded right after the later anchor -- unless that anchor
      * is an IDR picture or does not exist any more: then they are P pictures in display order (a closed group). */
     int *disp = (int *)malloc(sizeof(int) * (size_t)p->frames), *is_b = (int *)calloc((size_t)p->frames, sizeof(int));
+    int *b_ref = (int *)calloc((size_t)p->frames, sizeof(int));
     {
         int n = 0, g = p->bframes + 1, a = 0;
         while (a < p->frames) {
@@ -2170,7 +2180,10 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
                 int nx = a + g, nidr = p->idr_period > 0 && nx % p->idr_period == 0;
                 if (p->bframes > 0 && nx < p->frames && !nidr) {
                     disp[n++] = nx; /* the later anchor first, then the B pictures between the two */
-                    for (int d = a + 1; d < nx; d++) is_b[n] = 1, disp[n++] = d;
+                    const int mid = p->b_pyramid ? a + g / 2 : -1; /* b_pyramid: the middle one first, as a reference picture */
+                    if (mid > 0) is_b[n] = 1, b_ref[n] = 1, disp[n++] = mid;
+                    for (int d = a + 1; d < nx; d++)
+                        if (d != mid) is_b[n] = 1, disp[n++] = d;
                     a = nx;
                 } else {
                     for (int d = a + 1; d < nx && d < p->frames; d++) disp[n++] = d; /* closed group: P pictures in display order */
@@ -2205,7 +2218,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         e->cur_frame_num = frame_num;
         e->slice_type = idr ? 2 : (bpic ? 1 : 0);
         e->cur->poc = e->cur_poc = poc;
-        e->nal_ref_idc = bpic ? 0 : ((!idr && p->nonref_period > 1 && since_idr % p->nonref_period == p->nonref_period - 1) ? 0 : 3);
+        e->nal_ref_idc = bpic ? (b_ref[t] ? 2 : 0) : ((!idr && p->nonref_period > 1 && since_idr % p->nonref_period == p->nonref_period - 1) ? 0 : 3);
         if (!e->nal_ref_idc) g_feat |= 1u << 12;
         e->idr_lt = idr && p->idr_long_term;
         e->n_rplm = e->n_mmco = 0;
@@ -2378,6 +2391,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
 done:
     free(disp);
     free(is_b);
+    free(b_ref);
     for (int i = 0; i < 6; i++) free(e->pics[i].pl[0]), free(e->pics[i].motion);
     free(e->mb);
     free(e->db);

@@ -123,6 +123,12 @@ MATRIX = {
     "b_wp_implicit": dict(BASE, frames=10, profile_idc=77, cabac=0, bframes=2, num_ref_frames=4, weighted_bipred=2, direct_temporal=1, seed=48),
     "b_high8x8_slices": dict(BASE, frames=10, profile_idc=100, cabac=1, transform8x8=1, bframes=2, num_ref_frames=2, slices=3, sub8x8_permille=400,
                              cabac_init_idc=-1, seed=49),
+    # B pyramids: the middle B picture of a group is a reference picture (nal_ref_idc 2) -- B pictures in both lists and as
+    # the co-located picture (its blocks may use list 1 only), three levels of entropy launches on the GPU
+    "b_pyramid_cabac": dict(BASE, frames=13, profile_idc=77, cabac=1, bframes=3, b_pyramid=1, direct_temporal=1, bskip_permille=300, sub8x8_permille=200, seed=51),
+    "b_pyramid_cavlc": dict(BASE, frames=13, profile_idc=77, cabac=0, bframes=3, b_pyramid=1, bskip_permille=300, sub8x8_permille=200, seed=52),
+    "b_pyramid_implicit": dict(BASE, frames=14, profile_idc=100, cabac=1, transform8x8=1, bframes=2, b_pyramid=1, direct_temporal=1, weighted_bipred=2, slices=2,
+                               idr_period=7, seed=53),
     "b_gop_intra_pcm": dict(BASE, frames=16, idr_period=8, profile_idc=77, cabac=1, bframes=3, num_ref_frames=3, intra_in_p_permille=200,
                             pcm_permille=100, qp_jitter=5, rplm=1, seed=50),
 }

@@ -372,7 +372,8 @@ def test_gpu_prepare_overlaps_execute(H, sg):
 # ---------------------------------------------------------------------------------------------------
 # B pictures
 
-@pytest.mark.parametrize("name,chunk", [("b_temporal_cabac", 1), ("b_ibbp_cavlc", 2), ("b_wp_implicit", 1), ("b_gop_intra_pcm", 3)])
+@pytest.mark.parametrize("name,chunk", [("b_temporal_cabac", 1), ("b_ibbp_cavlc", 2), ("b_wp_implicit", 1), ("b_gop_intra_pcm", 3), ("b_pyramid_cabac", 1),
+                                        ("b_pyramid_cavlc", 2), ("b_pyramid_implicit", 3)])
 def test_gpu_b_stream_split_across_batches(name, chunk, H, sg):
     """Reference lists, picture order counts and the co-located motion (ColRec) survive batch boundaries: a B stream fed
     `chunk` pictures per call -- every B picture's co-located picture then comes from an earlier batch -- decodes like one piece."""
