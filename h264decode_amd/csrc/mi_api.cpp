@@ -199,7 +199,7 @@ struct h264mi_decoder {
     hipStream_t ent_stream[2] = {nullptr, nullptr};
     hipStream_t rec_stream = nullptr; // K3-K5; the caller's stream only brackets a pass with events
     hipEvent_t ev_user = nullptr;
-    hipEvent_t ev_ent[MI_SETS] = {}, ev_rec[MI_SETS] = {};
+    hipEvent_t ev_ent[MI_SETS] = {}, ev_rec[MI_SETS] = {}, ev_col[MI_SETS] = {};
     uint64_t pass = 0; // execute() counter
     bool last_pass_had_b = false;
     uint64_t mb_cap = 0;
@@ -302,6 +302,7 @@ static void free_all(h264mi_decoder *d) {
         if (i == 0 && d->d_pool_head) hipFree(d->d_pool_head);
         if (d->d_toprows[i]) hipFree(d->d_toprows[i]);
         if (d->ev_ent[i]) hipEventDestroy(d->ev_ent[i]);
+        if (d->ev_col[i]) hipEventDestroy(d->ev_col[i]);
         if (d->ev_rec[i]) hipEventDestroy(d->ev_rec[i]);
     }
     for (int i = 0; i < 2; i++)
@@ -431,6 +432,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
         TRY_ALLOC(hipMalloc(&d->d_coef[i], d->pool_blocks * 32));
         TRY_ALLOC(hipMalloc(&d->d_toprows[i], static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * MI_TOPROW_BYTES));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_ent[i], hipEventDisableTiming));
+        TRY_ALLOC(hipEventCreateWithFlags(&d->ev_col[i], hipEventDisableTiming));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_rec[i], hipEventDisableTiming));
     }
     TRY_ALLOC(hipMalloc(&d->d_pools, sizeof(FramePool) * S));
@@ -1274,7 +1276,10 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     int16_t *coef = d->d_coef[set];
     // Entropy decoding, level by level (Stage::level_first): k_entropy for the I / P slices, k_entropy_b for each level of B
     // slices, and after each level k_colsave for the pictures whose motion a later B picture (or batch) will ask for.
-    auto launch_entropy = [&](hipStream_t st, size_t lds_pad, bool fence_prev_pass) {
+    // `done`: recorded after the LAST entropy launch -- what the reconstruction kernels wait for; the k_colsave behind it only
+    // matters to later B slices (ev_col), so it does not delay them (its workgroups trickle in between the next pass's
+    // entropy wavefronts and can take tens of milliseconds to drain).
+    auto launch_entropy = [&](hipStream_t st, size_t lds_pad, bool fence_prev_pass, hipEvent_t done) {
         const int n_levels = static_cast<int>(g.level_first.size()) - 1;
         for (int lv = 0; lv < n_levels; lv++) {
             const int first = g.level_first[lv], n = g.level_first[lv + 1] - first;
@@ -1283,7 +1288,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
             // everything after the I/P launch waits for the previous pass's entropy stream -- the I/P launch itself does not,
             // it overlaps the previous pass's B launches; batches without B slices on both sides never wait.
             if (fence_prev_pass && (lv > 0 || g.colsave_n[lv])) {
-                hipStreamWaitEvent(st, d->ev_ent[(d->pass - 1) % MI_SETS], 0);
+                hipStreamWaitEvent(st, d->ev_col[(d->pass - 1) % MI_SETS], 0);
                 fence_prev_pass = false;
             }
             if (n > 0) {
@@ -1294,6 +1299,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
                     hipLaunchKernelGGL(k_entropy_b, dim3(n), dim3(64), 0, st, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
                                        static_cast<uint32_t>(d->pool_blocks), g.d_status, d->d_toprows[set], g.wmb_max, static_cast<uint32_t>(first), g.d_bext, d->d_mv1[set]);
             }
+            if (lv == n_levels - 1 && done) hipEventRecord(done, st);
             if (g.colsave_n[lv])
                 hipLaunchKernelGGL(k_colsave, dim3((g.mbs_max + 63) / 64, g.colsave_n[lv]), dim3(64), 0, st, g.d_lists + g.colsave_off[lv], g.d_pics, mbrec, d->d_mv1[set]);
         }
@@ -1302,15 +1308,18 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         HIP_TRY(hipStreamWaitEvent(d->stream, g.ev_upload, 0));
         mark(-1);
         HIP_TRY(hipMemsetAsync(d->d_pool_head + set, 0, sizeof(uint32_t), d->stream));
-        launch_entropy(d->stream, 0, false);
+        launch_entropy(d->stream, 0, false, nullptr);
         mark(0);
     } else {
         HIP_TRY(hipStreamWaitEvent(es, g.ev_upload, 0));
-        if (d->pass >= MI_SETS) HIP_TRY(hipStreamWaitEvent(es, d->ev_rec[set], 0)); // pass n-MI_SETS finished reading this set
+        if (d->pass >= MI_SETS) { // pass n-MI_SETS finished reading this set: its reconstruction kernels and its k_colsave
+            HIP_TRY(hipStreamWaitEvent(es, d->ev_rec[set], 0));
+            HIP_TRY(hipStreamWaitEvent(es, d->ev_col[set], 0));
+        }
         HIP_TRY(hipMemsetAsync(d->d_pool_head + set, 0, sizeof(uint32_t), es));
-        launch_entropy(es, d->ent_lds_pad, (g.n_bext || d->last_pass_had_b) && d->pass > 0);
+        launch_entropy(es, d->ent_lds_pad, (g.n_bext || d->last_pass_had_b) && d->pass > 0, d->ev_ent[set]);
         d->last_pass_had_b = g.n_bext > 0;
-        HIP_TRY(hipEventRecord(d->ev_ent[set], es));
+        HIP_TRY(hipEventRecord(d->ev_col[set], es)); // entropy stream through with this pass, k_colsave included
         HIP_TRY(hipStreamWaitEvent(d->rec_stream, d->ev_ent[set], 0));
     }
     hipStream_t rs = prof ? d->stream : d->rec_stream;
