@@ -103,6 +103,43 @@ def test_headers_match_oracle(H, sg, oracle_mod):
                 assert h.LumaLog2WeightDenom == 5 and h.ChromaLog2WeightDenom == 4
 
 
+def test_b_slice_headers(H, sg, oracle_mod):
+    """slice_header() of B slices (7.3.3): direct_spatial_mv_pred_flag, both num_ref_idx overrides, both list-modification
+    flags, the list-1 half of pred_weight_table() -- the header must end exactly where the oracle starts slice_data()
+    (checked through the picture count and PicOrderCnt list of a full oracle decode of the same stream)."""
+    for kw in (dict(width=64, height=48, frames=8, idr_period=0, profile_idc=77, cabac=1, bframes=2, num_ref_frames=3, weighted_bipred=1, direct_temporal=1),
+               dict(width=64, height=48, frames=8, idr_period=0, profile_idc=77, cabac=0, bframes=3, b_pyramid=1, weighted_bipred=2)):
+        stream, _, _ = sg.encode(**kw)
+        _, info = oracle_mod.decode(stream, crop=False)
+        assert info.n_frames == kw["frames"]
+        nals = H.read_nal_units(stream)
+        sps = H.NewSPS(nals[0].RBSP())
+        pps = H.NewPPS(sps, nals[1].RBSP())
+        assert pps.WeightedBipred == kw["weighted_bipred"]
+        vs = H.VideoStream(sps, pps)
+        n_b = n_ref_b = 0
+        pocs = []
+        for n in nals[2:]:
+            h = H.NewSliceContext(vs, n, n.RBSP()).Slice.Header
+            pocs.append(h.PicOrderCntLsb)
+            if h.SliceType % 5 != 1:
+                continue
+            n_b += 1
+            n_ref_b += n.RefIdc != 0
+            assert h.DirectSpatialMvPred == (0 if kw.get("direct_temporal") else 1)
+            assert 0 <= h.NumRefIdxL1ActiveMinus1 <= 1 and 0 <= h.NumRefIdxL0ActiveMinus1 < sps.MaxNumRefFrames
+            assert h.RefPicListModificationFlagL1 == 0 and h.slice_data_bit_offset > 0
+            if kw["weighted_bipred"] == 1:
+                assert h.LumaLog2WeightDenom == 5 and h.ChromaLog2WeightDenom == 4
+                assert h.LumaWeightL1[0] == 32 and h.LumaOffsetL1[0] == 0  # the generator leaves entry 0 at its default
+                assert all(-128 <= int(w) <= 127 for w in h.LumaWeightL1[:2])
+            else:
+                assert h.LumaLog2WeightDenom == 0  # no pred_weight_table() in the header
+        assert n_b >= 4
+        assert (n_ref_b > 0) == bool(kw.get("b_pyramid"))
+        assert [p // 2 for p in pocs][:4] == ([0, 3, 1, 2] if kw["bframes"] == 2 else [0, 4, 2, 1])  # coding order: anchor first, then its B pictures
+
+
 def test_malformed_inputs_return_status_codes(H):
     with pytest.raises(H.H264MIError):
         H.NewSPS(b"")
