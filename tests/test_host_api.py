@@ -135,7 +135,7 @@ def test_b_slice_headers(H, sg, oracle_mod):
                 assert all(-128 <= int(w) <= 127 for w in h.LumaWeightL1[:2])
             else:
                 assert h.LumaLog2WeightDenom == 0  # no pred_weight_table() in the header
-        assert n_b >= 4
+        assert n_b >= 3
         assert (n_ref_b > 0) == bool(kw.get("b_pyramid"))
         assert [p // 2 for p in pocs][:4] == ([0, 3, 1, 2] if kw["bframes"] == 2 else [0, 4, 2, 1])  # coding order: anchor first, then its B pictures
 
