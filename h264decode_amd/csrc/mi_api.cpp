@@ -23,7 +23,7 @@
 using namespace mi;
 
 #ifndef MI_SETS
-#define MI_SETS 3
+#define MI_SETS 4
 #endif
 
 #define HIP_TRY(x)                                                                          \
@@ -1605,6 +1605,7 @@ extern "C" int32_t h264mi_internal_poison(h264mi_decoder *d) {
         HIP_TRY(hipMemset(d->d_toprows[i], 0xFF, static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * MI_TOPROW_BYTES));
         if (d->d_mv1[i]) HIP_TRY(hipMemset(d->d_mv1[i], 0xFF, sizeof(MbMv1) * d->mb_cap));
     }
+    HIP_TRY(hipMemset(d->d_colrec, 0xFF, sizeof(ColRec) * d->colrec_per_slot * d->n_slots * d->st.size()));
     HIP_TRY(hipDeviceSynchronize());
     return H264MI_OK;
 }
