@@ -12,7 +12,7 @@
  * (its only test, h264/server_test.go:8-16, does not compile and its fixture is git-ignored).
  * It also stops before residual decoding (h264/slice.go:599-828) and never produces a pixel.
  * Hence: "parity unpinned" against the reference itself.  What pins this oracle instead:
- *   - spec-table KATs (tests/test_oracle_tables.py), cross-checked against the reference's own
+ *   - spec-table KATs (tests/test_tables.py), cross-checked against the reference's own
  *     table files where those are right (h264/rangeTabLPS.go, h264/stateTransxTab.go,
  *     h264/bit_reader.go:67-134) -- fixtures in tests/golden/;
  *   - an independent second implementation of reconstruction inside the stream generator
