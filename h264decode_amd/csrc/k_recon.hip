@@ -214,7 +214,7 @@ __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { 
 // explicit or implicit weighting of 8.4.2.3.
 template <bool B>
 __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab,
-                                         const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max, int n_blocks, const BSliceExt *bexts, const MbMv1 *mbmv1) {
+                                         const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_log2, int n_blocks, const BSliceExt *bexts, const MbMv1 *mbmv1) {
     const int lane = static_cast<int>(threadIdx.x);
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Give every XCD a
     // contiguous run of macroblocks (whole pictures) so that the reference rows shared by neighbouring macroblocks
@@ -223,8 +223,12 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
     const uint32_t per_xcd = gridDim.x >> 3;
     const uint32_t lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (lb >= static_cast<uint32_t>(n_blocks)) return;
-    const PicDesc *pd = &pics[pic_list[lb / mbs_per_pic_max]];
-    const int mb = static_cast<int>(lb % mbs_per_pic_max);
+    // (no integer divisions in this prologue: a wavefront lives for ONE macroblock, and the three divisions that used to
+    // be here -- block / macroblocks per picture, macroblock / picture width, and its remainder -- were a quarter of the
+    // scalar instructions of a skipped macroblock.  The per-picture block count is a power of two, the picture width comes
+    // with a precomputed reciprocal.)
+    const PicDesc *pd = &pics[pic_list[lb >> mbs_per_pic_log2]];
+    const int mb = static_cast<int>(lb & ((1u << mbs_per_pic_log2) - 1u));
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
     if (mb >= wmb * hmb) return;
     const uint64_t mbi = pd->mb_base + mb;
@@ -239,7 +243,7 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
     const int W = wmb * 16, H = hmb * 16; // the picture's own geometry
     const int max_slot = static_cast<int>(pd->n_slots) - 1;
     const uint64_t pool_slot_bytes = pd->slot_bytes;
-    const int mbx = mb % wmb, mby = mb / wmb;
+    const int mby = static_cast<int>(__umulhi(static_cast<uint32_t>(mb), pd->inv_wmb)), mbx = mb - mby * wmb; // PicDesc::inv_wmb: exact for every macroblock address
     const uint8_t *pool_base = reinterpret_cast<const uint8_t *>(pd->pool_base);
     const size_t ysz = static_cast<size_t>(W) * H;
     // coefficient blocks (packed in the pool, MbRec::coef_off / coef_mask): issue the loads now, scatter them into the dense LDS
@@ -260,19 +264,21 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
     const int16_t *rslots = rec->refslot;
     auto stage = [&]() {
         const int mvx0 = mvs[0][0], mvy0 = mvs[0][1];
-        bool same = true;
-        if (lane < 16) same = mvs[lane][0] == mvx0 && mvs[lane][1] == mvy0 && rslots[((lane >> 3) << 1) | ((lane & 3) >> 1)] == rslots[0];
+        bool same = true; // P_L0_16x16 and P_Skip have one vector and one reference by construction
+        if (rec->type != MBT_P16x16 && rec->type != MBT_PSKIP && lane < 16)
+            same = mvs[lane][0] == mvx0 && mvs[lane][1] == mvy0 && rslots[((lane >> 3) << 1) | ((lane & 3) >> 1)] == rslots[0];
         const int x0 = mbx * 16 + (mvx0 >> 2) - 2, y0 = mby * 16 + (mvy0 >> 2) - 2;
         const int cx0 = mbx * 8 + (mvx0 >> 3), cy0 = mby * 8 + (mvy0 >> 3);
-        const bool inside = x0 >= 0 && y0 >= 0 && x0 + 20 <= W - 1 && y0 + 20 <= H - 1 && cx0 >= 0 && cy0 >= 0 && cx0 + 8 <= W / 2 - 1 && cy0 + 8 <= H / 2 - 1 &&
-                            rslots[0] >= 0;
+        // 0 <= v <= limit as one unsigned comparison (a negative limit -- pictures one macroblock wide -- admits nothing)
+        auto in_range = [](int v, int limit) { return limit >= 0 && static_cast<uint32_t>(v) <= static_cast<uint32_t>(limit); };
+        const bool inside = in_range(x0, W - 21) && in_range(y0, H - 21) && in_range(cx0, W / 2 - 9) && in_range(cy0, H / 2 - 9) && rslots[0] >= 0;
         int uniform = inside && __all(same);
         // Integer luma vectors (78 % of the inter macroblocks of the bench streams; with "all 16 blocks alike": 71 %) need no
         // interpolation window at all: every lane fetches its own 4 luma samples and the 3 x 2 chroma samples of its pair
         // (chroma vectors have 1/8 precision: half-sample positions remain) with unaligned dword loads, no LDS, no barrier.
         const int X0 = x0 + 2, Y0 = y0 + 2, cxf = mvx0 & 7, cyf = mvy0 & 7;
-        const bool direct = ((mvx0 | mvy0) & 3) == 0 && rslots[0] >= 0 && X0 >= 0 && Y0 >= 0 && X0 + 16 <= W && Y0 + 16 <= H && cx0 >= 0 && cy0 >= 0 &&
-                            cx0 + 8 + (cxf ? 1 : 0) <= W / 2 && cy0 + 8 + (cyf ? 1 : 0) <= H / 2;
+        const bool direct = ((mvx0 | mvy0) & 3) == 0 && rslots[0] >= 0 && in_range(X0, W - 16) && in_range(Y0, H - 16) && in_range(cx0, W / 2 - 8 - (cxf ? 1 : 0)) &&
+                            in_range(cy0, H / 2 - 8 - (cyf ? 1 : 0));
         if (direct && __all(same)) {
             uniform = 2;
             const uint8_t *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rslots[0]), max_slot)) * pool_slot_bytes;
@@ -494,8 +500,12 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
             ref1 = MBREC_REF1(rec)[q8];
         }
         ref0 = max(ref0, 0) & (MI_MAX_REFS - 1), ref1 = max(ref1, 0) & (MI_MAX_REFS - 1);
-        const int ld = sd->luma_log2_denom, w0 = sd->wp_lw[ref0], o0 = sd->wp_lo[ref0];
-        const int w1 = bx ? bx->wp_lw1[ref1] : 1, o1 = bx ? bx->wp_lo1[ref1] : 0, iw1 = bx ? bx->implicit_w1[ref0][ref1] : 32;
+        int ld = 0, w0 = 1, o0 = 0, w1 = 1, o1 = 0, iw1 = 32; // the tables are only looked up (per lane: vector loads) when they are used
+        if (wmode == 1) {
+            ld = sd->luma_log2_denom, w0 = sd->wp_lw[ref0], o0 = sd->wp_lo[ref0];
+            if (bx) w1 = bx->wp_lw1[ref1], o1 = bx->wp_lo1[ref1];
+        } else if (B && wmode == 2)
+            iw1 = bx->implicit_w1[ref0][ref1];
         const bool both = B && use_l0 && use_l1; // pv0 holds list 0 and pv list 1; otherwise pv is the only prediction there is
         uint32_t packed = 0;
         const int bxs = (b & 3) * 4, by = (b >> 2) * 4;
@@ -517,8 +527,12 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
             ref1 = MBREC_REF1(rec)[q8];
         }
         ref0 = max(ref0, 0) & (MI_MAX_REFS - 1), ref1 = max(ref1, 0) & (MI_MAX_REFS - 1);
-        const int ld = sd->chroma_log2_denom, w0 = sd->wp_cw[ref0][c], o0 = sd->wp_co[ref0][c];
-        const int w1 = bx ? bx->wp_cw1[ref1][c] : 1, o1 = bx ? bx->wp_co1[ref1][c] : 0, iw1 = bx ? bx->implicit_w1[ref0][ref1] : 32;
+        int ld = 0, w0 = 1, o0 = 0, w1 = 1, o1 = 0, iw1 = 32;
+        if (wmode == 1) {
+            ld = sd->chroma_log2_denom, w0 = sd->wp_cw[ref0][c], o0 = sd->wp_co[ref0][c];
+            if (bx) w1 = bx->wp_cw1[ref1][c], o1 = bx->wp_co1[ref1][c];
+        } else if (B && wmode == 2)
+            iw1 = bx->implicit_w1[ref0][ref1];
         const bool both = B && use_l0 && use_l1;
         uint32_t packed = 0;
 #pragma unroll
@@ -533,17 +547,17 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
 }
 
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const FramePool *pools,
-                                                         const DevTables *tab, const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max, int n_blocks) {
+                                                         const DevTables *tab, const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_log2, int n_blocks) {
     __shared__ InterShared sh;
-    inter_mb<false>(sh, nullptr, pic_list, pics, slices, tab, mbrec, coefs, mbs_per_pic_max, n_blocks, nullptr, nullptr);
+    inter_mb<false>(sh, nullptr, pic_list, pics, slices, tab, mbrec, coefs, mbs_per_pic_log2, n_blocks, nullptr, nullptr);
 }
 // K4 for the pictures that have B slices
 extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_inter_b(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab,
-                                                           const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_max, int n_blocks, const BSliceExt *bexts,
+                                                           const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_log2, int n_blocks, const BSliceExt *bexts,
                                                            const MbMv1 *mbmv1) {
     __shared__ InterShared sh;
     __shared__ MbMv1 sh_mv1;
-    inter_mb<true>(sh, &sh_mv1, pic_list, pics, slices, tab, mbrec, coefs, mbs_per_pic_max, n_blocks, bexts, mbmv1);
+    inter_mb<true>(sh, &sh_mv1, pic_list, pics, slices, tab, mbrec, coefs, mbs_per_pic_log2, n_blocks, bexts, mbmv1);
 }
 
 // Motion a picture leaves for the direct prediction of later B pictures (ColRec, 8.4.1.2.1): one thread per macroblock.

@@ -859,6 +859,7 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         PicDesc &pd = g.h_pics[s.cur_pic];
         memset(&pd, 0, sizeof(pd));
         pd.stream = si, pd.slot = slot, pd.wmb = wmb, pd.hmb = hmb;
+        pd.inv_wmb = static_cast<uint32_t>((1ull << 32) / static_cast<uint32_t>(wmb)) + 1u;
         pd.pool_base = d->h_pools[si].base, pd.slot_bytes = d->slot_bytes, pd.n_slots = static_cast<uint32_t>(d->n_slots);
         pd.col_out = reinterpret_cast<uint64_t>(d->d_colrec + (static_cast<size_t>(si) * d->n_slots + slot) * d->colrec_per_slot);
         g.pic_level.resize(g.n_pics, 0), g.pic_save_col.resize(g.n_pics, 0);
@@ -1326,15 +1327,17 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     for (size_t w = 0; w < g.waves.size(); w++) {
         const uint32_t n = static_cast<uint32_t>(g.waves[w].size()), ni = g.wave_p_n[w], nbp = g.wave_b_n[w], nnb = g.wave_nb_n[w];
         if (!n) continue;
+        int mbs_log2 = 0; // K4 workgroups per picture: the largest picture's macroblock count rounded up to a power of two
+        while ((1 << mbs_log2) < g.mbs_max) mbs_log2++;
         if (ni) {
-            const uint32_t nb = ni * g.mbs_max;
+            const uint32_t nb = ni << mbs_log2;
             hipLaunchKernelGGL(k_inter, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_p_off[w], g.d_pics, g.d_slices, d->d_pools,
-                               d->d_tables, mbrec, coef, g.mbs_max, static_cast<int>(nb));
+                               d->d_tables, mbrec, coef, mbs_log2, static_cast<int>(nb));
             mark(1);
         }
         if (nbp) {
-            const uint32_t nb = nbp * g.mbs_max;
-            hipLaunchKernelGGL(k_inter_b, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_b_off[w], g.d_pics, g.d_slices, d->d_tables, mbrec, coef, g.mbs_max,
+            const uint32_t nb = nbp << mbs_log2;
+            hipLaunchKernelGGL(k_inter_b, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_b_off[w], g.d_pics, g.d_slices, d->d_tables, mbrec, coef, mbs_log2,
                                static_cast<int>(nb), g.d_bext, d->d_mv1[set]);
             mark(1);
         }

@@ -136,7 +136,8 @@ typedef struct {
     uint64_t slot_bytes;
     uint64_t col_out;      /* ColRec array of this picture's frame slot */
     uint8_t has_b;         /* the picture has B slices: MbMv1 records exist, K4 / K5 run their two-list variants */
-    uint8_t pad[7];
+    uint8_t pad[3];
+    uint32_t inv_wmb;      /* floor(2^32 / wmb) + 1: mby = mulhi(mb, inv_wmb) is exact for mb < 2^32 / wmb / wmb (wmb <= 512, hmb <= 320) */
 } PicDesc;
 
 typedef struct {
