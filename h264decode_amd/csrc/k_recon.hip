@@ -251,7 +251,7 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
     const uint32_t cmask = rec->coef_mask;
     const int has_res = cmask != 0;
     uint4 cv0 = make_uint4(0, 0, 0, 0), cv1 = cv0; // absent blocks are zero
-    if (lane < MI_COEF_BLOCKS && ((cmask >> lane) & 1)) {
+    if (has_res && lane < MI_COEF_BLOCKS && ((cmask >> lane) & 1)) {
         const uint4 *src = reinterpret_cast<const uint4 *>(coefs) + 2 * (static_cast<size_t>(rec->coef_off) + __builtin_popcount(cmask & ((1u << lane) - 1u)));
         cv0 = src[0], cv1 = src[1];
     }
@@ -262,33 +262,36 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
     uint32_t dl = 0, dc0 = 0, dc1 = 0; // direct path: this lane's 4 luma samples / its chroma pair's 3x2 neighbourhood, straight from the reference picture
     const int16_t(*mvs)[2] = rec->mv; // vectors / frame slots of the list being predicted from
     const int16_t *rslots = rec->refslot;
+    int stage_mode = 0; // how the list's samples were staged: 0 per-block windows, 1 one window for the macroblock, 2 direct (wave-uniform)
     auto stage = [&]() {
         const int mvx0 = mvs[0][0], mvy0 = mvs[0][1];
-        bool same = true; // P_L0_16x16 and P_Skip have one vector and one reference by construction
-        if (rec->type != MBT_P16x16 && rec->type != MBT_PSKIP && lane < 16)
-            same = mvs[lane][0] == mvx0 && mvs[lane][1] == mvy0 && rslots[((lane >> 3) << 1) | ((lane & 3) >> 1)] == rslots[0];
-        const int x0 = mbx * 16 + (mvx0 >> 2) - 2, y0 = mby * 16 + (mvy0 >> 2) - 2;
-        const int cx0 = mbx * 8 + (mvx0 >> 3), cy0 = mby * 8 + (mvy0 >> 3);
-        // 0 <= v <= limit as one unsigned comparison (a negative limit -- pictures one macroblock wide -- admits nothing)
-        auto in_range = [](int v, int limit) { return limit >= 0 && static_cast<uint32_t>(v) <= static_cast<uint32_t>(limit); };
-        const bool inside = in_range(x0, W - 21) && in_range(y0, H - 21) && in_range(cx0, W / 2 - 9) && in_range(cy0, H / 2 - 9) && rslots[0] >= 0;
-        int uniform = inside && __all(same);
+        // all 16 blocks share one vector and one reference?  P_L0_16x16 and P_Skip do by construction
+        bool same_v = true;
+        if (rec->type != MBT_P16x16 && rec->type != MBT_PSKIP) {
+            bool same = true;
+            if (lane < 16) same = mvs[lane][0] == mvx0 && mvs[lane][1] == mvy0 && rslots[((lane >> 3) << 1) | ((lane & 3) >> 1)] == rslots[0];
+            same_v = __all(same);
+        }
+        const int X0 = mbx * 16 + (mvx0 >> 2), Y0 = mby * 16 + (mvy0 >> 2), cx0 = mbx * 8 + (mvx0 >> 3), cy0 = mby * 8 + (mvy0 >> 3);
+        const int x0 = X0 - 2, y0 = Y0 - 2;
+        // The range checks are sign tests of one OR: every term must be non-negative (scalar arithmetic instead of a
+        // branch per comparison -- this prologue runs once per macroblock and was most of a skipped macroblock's cost).
         // Integer luma vectors (78 % of the inter macroblocks of the bench streams; with "all 16 blocks alike": 71 %) need no
         // interpolation window at all: every lane fetches its own 4 luma samples and the 3 x 2 chroma samples of its pair
         // (chroma vectors have 1/8 precision: half-sample positions remain) with unaligned dword loads, no LDS, no barrier.
-        const int X0 = x0 + 2, Y0 = y0 + 2, cxf = mvx0 & 7, cyf = mvy0 & 7;
-        const bool direct = ((mvx0 | mvy0) & 3) == 0 && rslots[0] >= 0 && in_range(X0, W - 16) && in_range(Y0, H - 16) && in_range(cx0, W / 2 - 8 - (cxf ? 1 : 0)) &&
-                            in_range(cy0, H / 2 - 8 - (cyf ? 1 : 0));
-        if (direct && __all(same)) {
+        const int cxh = (mvx0 >> 2) & 1, cyh = (mvy0 >> 2) & 1; // integer luma vector: the chroma vector sits on a half sample iff this bit is set
+        const int dneg = X0 | Y0 | (W - 16 - X0) | (H - 16 - Y0) | cx0 | cy0 | (W / 2 - 8 - cxh - cx0) | (H / 2 - 8 - cyh - cy0) | rslots[0] | -((mvx0 | mvy0) & 3);
+        int uniform = 0;
+        if (dneg >= 0 && same_v) {
             uniform = 2;
             const uint8_t *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rslots[0]), max_slot)) * pool_slot_bytes;
             const int b = lane >> 2, r = lane & 3;
-            dl = *reinterpret_cast<const uint32_t *>(ref + static_cast<size_t>(Y0 + (b >> 2) * 4 + r) * W + X0 + (b & 3) * 4);
+            dl = *reinterpret_cast<const uint32_t *>(ref + static_cast<uint32_t>((Y0 + (b >> 2) * 4 + r) * W + X0 + (b & 3) * 4));
             const int c = lane >> 5, q = lane & 31, cy = q >> 2, cx = (q & 3) * 2;
-            const uint8_t *cp = ref + ysz + static_cast<size_t>(c) * (ysz / 4) + static_cast<size_t>(cy0 + cy) * (W / 2) + cx0 + cx;
+            const uint8_t *cp = ref + static_cast<uint32_t>(static_cast<int>(ysz) + c * static_cast<int>(ysz / 4) + (cy0 + cy) * (W / 2) + cx0 + cx);
             dc0 = *reinterpret_cast<const uint32_t *>(cp);
-            dc1 = cyf ? *reinterpret_cast<const uint32_t *>(cp + W / 2) : dc0;
-        } else if (uniform) {
+            dc1 = cyh ? *reinterpret_cast<const uint32_t *>(cp + W / 2) : dc0;
+        } else if ((uniform = same_v && (x0 | y0 | (W - 21 - x0) | (H - 21 - y0) | cx0 | cy0 | (W / 2 - 9 - cx0) | (H / 2 - 9 - cy0) | rslots[0]) >= 0) != 0) {
             const uint8_t *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rslots[0]), max_slot)) * pool_slot_bytes;
             ox = x0 & 3;
             const int xa = x0 - ox;
@@ -323,7 +326,7 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
                 sh.win_c[c][b][wy][wx] = ref[static_cast<size_t>(y) * (W / 2) + x];
             }
         }
-        if (lane == 0) sh.uniform = uniform;
+        stage_mode = uniform;
     };
     // which lists the macroblock predicts from (wave-uniform); a record without any usable reference is concealed from list 0
     bool use_l0 = true, use_l1 = false;
@@ -349,7 +352,7 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
     // ---- luma: lane = (4x4 block, row) -> 4 samples ----
     auto predict_luma = [&]() {
         const int b = lane >> 2, r = lane & 3;
-        const int uni = sh.uniform;
+        const int uni = stage_mode;
         if (uni == 2) { // direct path: integer sample positions
 #pragma unroll
             for (int i = 0; i < 4; i++) pv[i] = static_cast<int>((dl >> (8 * i)) & 255u);
@@ -444,8 +447,12 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
         const int c = lane >> 5, q = lane & 31, cy = q >> 2, cx = (q & 3) * 2;
         const int b = (cy >> 1) * 4 + (cx >> 1);
         const int mvx = mvs[b][0], mvy = mvs[b][1], xf = mvx & 7, yf = mvy & 7;
-        const int uni = sh.uniform;
+        const int uni = stage_mode;
         if (uni == 2) { // direct path: bytes 0..2 of dc0 / dc1 are rows cy, cy + 1 of this pair's neighbourhood
+            if (__builtin_amdgcn_readfirstlane(xf | yf) == 0) { // (the macroblock has ONE vector on this path)
+                pc[0] = dc0 & 255, pc[1] = (dc0 >> 8) & 255;
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 const int pa = (dc0 >> (8 * i)) & 255, pb = (dc0 >> (8 * i + 8)) & 255, pcc = (dc1 >> (8 * i)) & 255, pd_ = (dc1 >> (8 * i + 8)) & 255;
@@ -515,7 +522,7 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
             if (has_res) v = clip255(v + sh.rb.luma[(by + r) * 16 + bxs + i]);
             packed |= static_cast<uint32_t>(v) << (8 * i);
         }
-        *reinterpret_cast<uint32_t *>(dst_base + static_cast<size_t>(mby * 16 + by + r) * W + mbx * 16 + bxs) = packed;
+        *reinterpret_cast<uint32_t *>(dst_base + static_cast<uint32_t>((mby * 16 + by + r) * W + mbx * 16 + bxs)) = packed;
     }
     {
         const int c = lane >> 5, q = lane & 31, cy = q >> 2, cx = (q & 3) * 2;
@@ -541,8 +548,8 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
             if (has_res) v = clip255(v + sh.rb.chroma[c][cy * 8 + cx + i]);
             packed |= static_cast<uint32_t>(v) << (8 * i);
         }
-        uint8_t *plane = dst_base + ysz + static_cast<size_t>(c) * (ysz / 4);
-        *reinterpret_cast<uint16_t *>(plane + static_cast<size_t>(mby * 8 + cy) * (W / 2) + mbx * 8 + cx) = static_cast<uint16_t>(packed);
+        *reinterpret_cast<uint16_t *>(dst_base + static_cast<uint32_t>(static_cast<int>(ysz) + c * static_cast<int>(ysz / 4) + (mby * 8 + cy) * (W / 2) + mbx * 8 + cx)) =
+            static_cast<uint16_t>(packed);
     }
 }
 
