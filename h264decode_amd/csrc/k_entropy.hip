@@ -75,8 +75,11 @@ struct Shared {
     uint8_t posmap[4][64]; // CAVLC: scan index -> position: [0] zig-zag 4x4, [1] zig-zag 4x4 of AC index (k+1), [2] zig-zag 8x8, [3] identity
     int16_t coef[MI_COEF_PER_MB];
     MbRec rec;
-    TopInfo left, tl; // tl = top[] entry of column x-1 as it was for the row above
-    TopInfo topw[2];  // LDS window on the row-above state: [0] = column x, [1] = column x+1 (the row itself lives in HBM)
+    // The neighbour entries as ONE array, so that a lane picks its neighbour by index (an LDS offset) and not by a select of
+    // pointers (which the compiler turns into generic pointers with null checks): [NB_LEFT] the macroblock to the left,
+    // [NB_TL] the top[] entry of column x-1 as it was for the row above, [NB_TOP], [NB_TOP + 1] the LDS window on the
+    // row-above state: columns x and x+1 (the row itself lives in HBM)
+    TopInfo nb[4];
     // Neighbour caches of the current MB.  6-wide grids: column 0 = left MB, 1..4 = current MB,
     // 5 = right / top-right; row 0 = MB row above, rows 1..4 = current MB.
     int8_t ipm_c[32];      // -2 unavailable, -1 not (yet) an I_NxN block
@@ -101,6 +104,7 @@ struct Shared {
 #endif
 };
 #define GI(bx, by) (((by) + 1) * 6 + (bx) + 1)
+enum { NB_LEFT = 0, NB_TL = 1, NB_TOP = 2 };
 
 // Everything the serial syntax code touches per bin lives in registers:
 //   * the bit reader is scalar (64-bit MSB-aligned look-ahead in SGPRs) and is fed from three VGPRs that
@@ -377,9 +381,7 @@ FI int cabac_egk(Ent &e, int k) {
 }
 
 // ------------------------------------------------------------------ neighbour MBs
-FI const TopInfo *mbA(const Ent &e) { return e.s->left.type != MBT_NONE ? &e.s->left : nullptr; }
-FI const TopInfo *mbB(const Ent &e) { return e.s->topw[0].type != MBT_NONE ? &e.s->topw[0] : nullptr; }
-FI const TopInfo *mbC(const Ent &e) { return (e.mbx + 1 < e.wmb && e.s->topw[1].type != MBT_NONE) ? &e.s->topw[1] : nullptr; }
+FI bool nb_ok(const Ent &e, int i) { return e.s->nb[i].type != MBT_NONE && (i != NB_TOP + 1 || e.mbx + 1 < e.wmb); } // macroblock D, A, B, C available
 // the left / upper macroblock's type, transform flag, cbp and chroma mode as one scalar word (first dword of TopInfo)
 struct Nb {
     uint32_t w;
@@ -773,9 +775,8 @@ FI void set_part(Ent &e, const int L, int bx, int by, int w, int h, int ref, int
 // ------------------------------------------------------------------ per-MB neighbour caches
 FI void fill_caches(Ent &e) {
     Shared *s = e.s;
-    const TopInfo *a = mbA(e), *b = mbB(e);
-    const TopInfo *c = mbC(e);
-    const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
+    e.aw = RFL(*reinterpret_cast<const uint32_t *>(&s->nb[NB_LEFT])), e.bw = RFL(*reinterpret_cast<const uint32_t *>(&s->nb[NB_TOP]));
+    const bool a_ok = (e.aw & 255) != 0, b_ok = (e.bw & 255) != 0;
     const int cip = e.cip;
     int l = LANE;
     OPAQUE(l); // keeps lane-dependent addresses from being hoisted out of the macroblock loop and spilled
@@ -784,18 +785,20 @@ FI void fill_caches(Ent &e) {
         int gx = l % 6 - 1, gy = l / 6 - 1; // block coordinates relative to the MB
         int8_t ipm = -2;
         uint8_t nnz = 0x80;
-        const TopInfo *n = nullptr;
+        int ni = -1;
         int k = 0; // index inside the neighbour's edge arrays
         int edge = 0;
         if (gy < 0 && gx >= 0 && gx < 4)
-            n = b, k = gx, edge = 1;
+            ni = NB_TOP, k = gx, edge = 1;
         else if (gx < 0 && gy >= 0)
-            n = a, k = gy, edge = 1;
+            ni = NB_LEFT, k = gy, edge = 1;
         else if (gy < 0 && gx < 0)
-            n = d, k = 3;
-        else if (gy < 0 && gx == 4)
-            n = c, k = 0;
-        if (n) {
+            ni = NB_TL, k = 3;
+        else if (gy < 0 && gx == 4 && e.mbx + 1 < e.wmb)
+            ni = NB_TOP + 1, k = 0;
+        const TopInfo *n = &s->nb[ni < 0 ? 0 : ni];
+        const bool n_ok = ni >= 0 && n->type != MBT_NONE;
+        if (n_ok) {
             const int inter = MB_IS_INTER(n->type);
             if (!(cip && inter)) ipm = (n->type == MBT_I4x4 || n->type == MBT_I8x8) ? n->ipm[k] : static_cast<int8_t>(2);
             if (edge) nnz = n->nnz[k];
@@ -805,7 +808,7 @@ FI void fill_caches(Ent &e) {
             int8_t ref = -2, refi = -2;
             uint8_t mvdx = 0, mvdy = 0;
             int16_t mvx = 0, mvy = 0;
-            if (n) {
+            if (n_ok) {
                 if (MB_IS_INTER(n->type)) {
                     ref = refi = n->ref[L][k >> 1];
                     mvx = n->mv[L][k][0], mvy = n->mv[L][k][1];
@@ -831,16 +834,16 @@ FI void fill_caches(Ent &e) {
         int i = l - 32, cpl = i / 9, g = i % 9, gx = g % 3 - 1, gy = g / 3 - 1;
         uint8_t v = 0x80;
         if (gy < 0 && gx >= 0) {
-            if (b) v = b->nnz[4 + cpl * 2 + gx];
+            if (b_ok) v = s->nb[NB_TOP].nnz[4 + cpl * 2 + gx];
         } else if (gx < 0 && gy >= 0) {
-            if (a) v = a->nnz[4 + cpl * 2 + gy];
+            if (a_ok) v = s->nb[NB_LEFT].nnz[4 + cpl * 2 + gy];
         } else if (gx >= 0 && gy >= 0)
             v = 0;
         coded = (v & 0x80) ? 2 : (v != 0);
         s->nnzc_c[cpl][g] = v;
     } else if (l >= 50 && l < 56) { // DC coded_block_flags of the left (50..52) / upper (53..55) macroblock: Intra16x16 luma, Cb, Cr
-        const TopInfo *n = l < 53 ? a : b;
-        coded = n ? (n->cbf_dc >> ((l - 50) % 3)) & 1 : 2;
+        const bool ok = l < 53 ? a_ok : b_ok;
+        coded = ok ? (s->nb[l < 53 ? NB_LEFT : NB_TOP].cbf_dc >> ((l - 50) % 3)) & 1 : 2;
     } else if (l >= 56) {
         s->refs8[(l - 56) >> 2][l & 3] = -1;
         if (l < 60) s->sub_type[l - 56] = 0;
@@ -848,7 +851,6 @@ FI void fill_caches(Ent &e) {
     }
     e.nzm = __builtin_amdgcn_ballot_w64(coded == 1);
     e.unm = __builtin_amdgcn_ballot_w64(coded == 2);
-    e.aw = RFL(*reinterpret_cast<const uint32_t *>(&s->left)), e.bw = RFL(*reinterpret_cast<const uint32_t *>(&s->topw[0]));
     { // zero the coefficient staging block: 416 int16 = 208 dwords
         uint32_t *cz = reinterpret_cast<uint32_t *>(s->coef);
         for (int i = l; i < MI_COEF_PER_MB / 2; i += 64) cz[i] = 0;
@@ -1398,12 +1400,11 @@ FI void decode_mb(Ent &e, int skipped) {
         // neighbour availability for intra prediction (6.4.x; constrained_intra_pred 8.3.1.2)
         const int cip = e.cip;
         int av = 0;
-        const TopInfo *c = mbC(e);
-        const TopInfo *d = s->tl.type != MBT_NONE ? &s->tl : nullptr;
+        const int td = s->nb[NB_TL].type, tc = nb_ok(e, NB_TOP + 1) ? s->nb[NB_TOP + 1].type : MBT_NONE;
         if (a.ok() && !(cip && MB_IS_INTER(a.type()))) av |= MI_AV_LEFT;
         if (b.ok() && !(cip && MB_IS_INTER(b.type()))) av |= MI_AV_TOP;
-        if (d && !(cip && MB_IS_INTER(d->type))) av |= MI_AV_TOPLEFT;
-        if (c && !(cip && MB_IS_INTER(c->type))) av |= MI_AV_TOPRIGHT;
+        if (td != MBT_NONE && !(cip && MB_IS_INTER(td))) av |= MI_AV_TOPLEFT;
+        if (tc != MBT_NONE && !(cip && MB_IS_INTER(tc))) av |= MI_AV_TOPRIGHT;
         r.avail = static_cast<uint8_t>(av);
     }
     // dbf_idc / alpha_off / beta_off / slice_in_pic / slice_idx of the record are slice constants, written once at slice start
@@ -1454,11 +1455,11 @@ FI void decode_mb(Ent &e, int skipped) {
     }
 #endif
     // remember the row-above entry of this column for the next MB's top-left neighbour, then build the new one
-    TopInfo *tp = &s->topw[0];
-    if (l >= 32 && l < 32 + TOP_DW) reinterpret_cast<uint32_t *>(&s->tl)[l - 32] = reinterpret_cast<const uint32_t *>(tp)[l - 32];
+    TopInfo *tp = &s->nb[NB_TOP];
+    if (l >= 32 && l < 32 + TOP_DW) reinterpret_cast<uint32_t *>(&s->nb[NB_TL])[l - 32] = reinterpret_cast<const uint32_t *>(tp)[l - 32];
     LDS_SYNC();
     if (l < 2) {
-        TopInfo *dst = l == 0 ? tp : &s->left;
+        TopInfo *dst = &s->nb[l == 0 ? NB_TOP : NB_LEFT];
         dst->type = static_cast<uint8_t>(type);
         dst->t8x8 = static_cast<uint8_t>(t8x8);
         dst->cbp = r.cbp;
@@ -1476,7 +1477,7 @@ FI void decode_mb(Ent &e, int skipped) {
     } else if (l >= 8 && l < 16) {
         // edge arrays: lanes 8..11 -> top (bottom row), 12..15 -> left (right column)
         int k = l & 3, is_left = l >= 12;
-        TopInfo *dst = is_left ? &s->left : tp;
+        TopInfo *dst = &s->nb[is_left ? NB_LEFT : NB_TOP];
         int g = is_left ? GI(3, k) : GI(k, 3);
         dst->ipm[k] = s->ipm_c[g];
         dst->nnz[k] = s->nnz_c[g];
@@ -1488,16 +1489,16 @@ FI void decode_mb(Ent &e, int skipped) {
     } else if (l >= 16 && l < 24) {
         // chroma nnz edges: [plane][k]
         int i = l - 16, is_left = i >= 4, cpl = (i >> 1) & 1, k = i & 1;
-        TopInfo *dst = is_left ? &s->left : tp;
+        TopInfo *dst = &s->nb[is_left ? NB_LEFT : NB_TOP];
         dst->nnz[4 + cpl * 2 + k] = is_left ? s->nnzc_c[cpl][(k + 1) * 3 + 2] : s->nnzc_c[cpl][2 * 3 + k + 1];
     }
     LDS_SYNC();
     // new entry -> HBM row; slide the LDS window: [0] <- [1], [1] <- prefetched column x+2; prefetch x+3
     if (l < TOP_DW) {
-        const uint32_t nw = reinterpret_cast<const uint32_t *>(tp)[l], w1 = reinterpret_cast<const uint32_t *>(&s->topw[1])[l];
+        const uint32_t nw = reinterpret_cast<const uint32_t *>(tp)[l], w1 = reinterpret_cast<const uint32_t *>(&s->nb[NB_TOP + 1])[l];
         reinterpret_cast<uint32_t *>(e.top + e.mbx)[l] = nw;
-        reinterpret_cast<uint32_t *>(&s->topw[0])[l] = w1;
-        reinterpret_cast<uint32_t *>(&s->topw[1])[l] = e.pre_top;
+        reinterpret_cast<uint32_t *>(&s->nb[NB_TOP])[l] = w1;
+        reinterpret_cast<uint32_t *>(&s->nb[NB_TOP + 1])[l] = e.pre_top;
         e.pre_top = top_load(e, e.mbx + 3, l);
     }
     const uint64_t mbi = e.mb_base + static_cast<uint64_t>(e.mby) * e.wmb + e.mbx;
@@ -1623,8 +1624,8 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         sh.rec.refslot1[0] = sh.rec.refslot1[1] = sh.rec.refslot1[2] = sh.rec.refslot1[3] = -1; // (the B build rewrites them per macroblock)
     }
     for (int i = l; i < e.wmb * TOP_DW; i += 64) reinterpret_cast<uint32_t *>(e.top)[i] = 0; // all row-above entries: type NONE
-    if (l < TOP_DW) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
-    if (l < 2 * TOP_DW) reinterpret_cast<uint32_t *>(&sh.topw[0])[l] = 0;
+    if (l < TOP_DW) reinterpret_cast<uint32_t *>(&sh.nb[NB_LEFT])[l] = 0, reinterpret_cast<uint32_t *>(&sh.nb[NB_TL])[l] = 0;
+    if (l < 2 * TOP_DW) reinterpret_cast<uint32_t *>(&sh.nb[NB_TOP])[l] = 0;
     LDS_SYNC();
     {
         uint32_t pos = RFL(sd->data_bit_off);
@@ -1646,9 +1647,9 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
             break;
         }
         if (e.mbx == 0 || n_mbs == 0) { // new MB row (or slice start): no left / top-left neighbour; (re)load the row-above window
-            if (l < TOP_DW) reinterpret_cast<uint32_t *>(&sh.left)[l] = 0, reinterpret_cast<uint32_t *>(&sh.tl)[l] = 0;
+            if (l < TOP_DW) reinterpret_cast<uint32_t *>(&sh.nb[NB_LEFT])[l] = 0, reinterpret_cast<uint32_t *>(&sh.nb[NB_TL])[l] = 0;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stores of the previous row to e.top[] have been issued to L2
-            if (l < 2 * TOP_DW) reinterpret_cast<uint32_t *>(&sh.topw[0])[l] = top_load(e, e.mbx + l / TOP_DW, l % TOP_DW);
+            if (l < 2 * TOP_DW) reinterpret_cast<uint32_t *>(&sh.nb[NB_TOP])[l] = top_load(e, e.mbx + l / TOP_DW, l % TOP_DW);
             if (l < TOP_DW) e.pre_top = top_load(e, e.mbx + 2, l);
             LDS_SYNC();
         }
