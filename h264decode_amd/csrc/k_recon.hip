@@ -668,28 +668,33 @@ __device__ __forceinline__ void plane_params(FT T, FL L, int &a, int &b, int &c)
     c = N == 16 ? (5 * vv + 32) >> 6 : (34 * vv + 32) >> 6;
 }
 
-__device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_t *coef, const ScalingSet *sc, uint8_t *py, uint8_t *pcb, uint8_t *pcr, int W,
+typedef __attribute__((address_space(1))) uint8_t g8;
+typedef __attribute__((address_space(1))) uint16_t g16;
+typedef __attribute__((address_space(1))) uint32_t g32;
+__device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_t *coef, const ScalingSet *sc, g8 *py, g8 *pcb, g8 *pcr, int W,
                          int mbx, int mby) {
     const int type = rec->type, av = rec->avail;
     const int a_left = av & MI_AV_LEFT, a_top = (av & MI_AV_TOP) != 0, a_tl = (av & MI_AV_TOPLEFT) != 0, a_tr = (av & MI_AV_TOPRIGHT) != 0;
-    uint8_t *Y = py + static_cast<size_t>(mby * 16) * W + mbx * 16;
+    // (frame pointers carry address space 1: built from an integer they would otherwise be generic -- flat_load / flat_store,
+    // which count against the LDS wait counter too, so that every LDS fence below would wait for the sample stores)
+    g8 *Y = py + static_cast<size_t>(mby * 16) * W + mbx * 16;
     const int Wc = W / 2;
-    uint8_t *C0 = pcb + static_cast<size_t>(mby * 8) * Wc + mbx * 8, *C1 = pcr + static_cast<size_t>(mby * 8) * Wc + mbx * 8;
+    g8 *C0 = pcb + static_cast<size_t>(mby * 8) * Wc + mbx * 8, *C1 = pcr + static_cast<size_t>(mby * 8) * Wc + mbx * 8;
 #define CPL(c) ((c) ? C1 : C0) /* a select, not an indexed pointer array (which would live in scratch) */
     if (type == MBT_NONE) { // lost macroblock: a defined background instead of whatever the slot held before
-        *reinterpret_cast<uint32_t *>(Y + static_cast<size_t>(lane >> 2) * W + (lane & 3) * 4) = 0x80808080u;
-        if (lane < 32) *reinterpret_cast<uint32_t *>(CPL(lane >> 4) + static_cast<size_t>((lane >> 1) & 7) * Wc + (lane & 1) * 4) = 0x80808080u;
+        *reinterpret_cast<g32 *>(Y + static_cast<size_t>(lane >> 2) * W + (lane & 3) * 4) = 0x80808080u;
+        if (lane < 32) *reinterpret_cast<g32 *>(CPL(lane >> 4) + static_cast<size_t>((lane >> 1) & 7) * Wc + (lane & 1) * 4) = 0x80808080u;
         return;
     }
     if (type == MBT_IPCM) { // 8.3.5: samples were stored in the coefficient block
         const uint8_t *pcm = reinterpret_cast<const uint8_t *>(coef);
         { // 256 luma bytes: one dword per lane
             int j = lane >> 2, i = (lane & 3) * 4;
-            *reinterpret_cast<uint32_t *>(Y + static_cast<size_t>(j) * W + i) = *reinterpret_cast<const uint32_t *>(pcm + j * 16 + i);
+            *reinterpret_cast<g32 *>(Y + static_cast<size_t>(j) * W + i) = *reinterpret_cast<const uint32_t *>(pcm + j * 16 + i);
         }
         if (lane < 32) {
             int c = lane >> 4, j = (lane >> 1) & 7, i = (lane & 1) * 4;
-            *reinterpret_cast<uint32_t *>(CPL(c) + static_cast<size_t>(j) * Wc + i) = *reinterpret_cast<const uint32_t *>(pcm + 256 + c * 64 + j * 8 + i);
+            *reinterpret_cast<g32 *>(CPL(c) + static_cast<size_t>(j) * Wc + i) = *reinterpret_cast<const uint32_t *>(pcm + 256 + c * 64 + j * 8 + i);
         }
         return;
     }
@@ -749,7 +754,7 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
             v = clip255(v + ws->rb.luma[j * 16 + x]);
             packed |= static_cast<uint32_t>(v) << (8 * k);
         }
-        *reinterpret_cast<uint32_t *>(Y + static_cast<size_t>(j) * W + i0) = packed;
+        *reinterpret_cast<g32 *>(Y + static_cast<size_t>(j) * W + i0) = packed;
     } else if (type == MBT_I4x4) {
         for (int idx = 0; idx < 16; idx++) {
             const int bx = (idx & 1) + 2 * ((idx >> 2) & 1), by = ((idx >> 1) & 1) + 2 * (idx >> 3);
@@ -847,7 +852,7 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
         const int j = lane >> 2, i0 = (lane & 3) * 4;
         const uint8_t *t = &ws->tile[j + 1][i0 + 1];
         uint32_t packed = t[0] | (t[1] << 8) | (t[2] << 16) | (static_cast<uint32_t>(t[3]) << 24);
-        *reinterpret_cast<uint32_t *>(Y + static_cast<size_t>(j) * W + i0) = packed;
+        *reinterpret_cast<g32 *>(Y + static_cast<size_t>(j) * W + i0) = packed;
     }
     // ---- chroma (8.3.4) ----
     {
@@ -888,7 +893,7 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
             v = clip255(v + ws->rb.chroma[c][y * 8 + x]);
             packed |= static_cast<uint32_t>(v) << (8 * k);
         }
-        *reinterpret_cast<uint16_t *>(CPL(c) + static_cast<size_t>(y) * Wc + x0) = static_cast<uint16_t>(packed);
+        *reinterpret_cast<g16 *>(CPL(c) + static_cast<size_t>(y) * Wc + x0) = static_cast<uint16_t>(packed);
     }
 }
 
@@ -899,8 +904,8 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
     const int W = wmb * 16, H = hmb * 16; // the picture's own geometry
-    uint8_t *py = reinterpret_cast<uint8_t *>(pd->pool_base) + static_cast<size_t>(pd->slot) * pd->slot_bytes;
-    uint8_t *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
+    g8 *py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes);
+    g8 *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
     { // LevelScale tables of this picture's PPS -> LDS (2688 bytes)
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&tab->scaling[pd->scaling_set]);
         for (int i = tid; i < static_cast<int>(sizeof(ScalingSet) / 4); i += MI_INTRA_WAVES * 64) reinterpret_cast<uint32_t *>(&sh.sc)[i] = src[i];
