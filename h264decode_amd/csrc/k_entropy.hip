@@ -45,7 +45,11 @@
 #define NL 1
 #define MI_ENT_KERNEL k_entropy
 #endif
-#define LANE (static_cast<int>(threadIdx.x))
+// The lane number as the slice loop sees it: refreshed through an opaque move at the top of every macroblock (Ent::lane), so
+// that the compiler recomputes lane predicates (one v_cmp) where they are used instead of hoisting dozens of them out of
+// the macroblock loop into scalar register pairs -- which it then spills into VGPR lanes and reloads with two v_readlane
+// each.  Every user has an `e` in scope.
+#define LANE (e.lane)
 #define FI __device__ __forceinline__
 // The workgroup is ONE wavefront: cross-lane LDS visibility needs no s_barrier and, above all, no
 // wait for outstanding global stores (what __syncthreads() implies) -- LDS operations of a wavefront
@@ -115,6 +119,7 @@ enum { NB_LEFT = 0, NB_TL = 1, NB_TOP = 2 };
 //   * Tables 9-44 / 9-45, the 8x8 significance maps and the zig-zag scans are per-lane tables too.
 // A decision is then ~35 scalar instructions with no memory access at all.
 struct Ent {
+    int lane;                // see LANE
     Shared *s;
     TopInfo *top; // [wmb] row-above state of this slice, in global memory (read with L1-bypassing loads)
     uint32_t pre_top; // lanes 0..11: prefetched dwords of top[mbx + 2]
@@ -1538,6 +1543,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     uint32_t *toprows = toprows_ + static_cast<size_t>(slice_base) * wmb_max * TOP_DW;
     const uint64_t t_begin = wall_clock64();
     Ent e;
+    e.lane = static_cast<int>(threadIdx.x);
     e.s = &sh;
 #if MI_ENT_STATS
     e.bins = 0;
@@ -1653,6 +1659,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
             if (l < TOP_DW) e.pre_top = top_load(e, e.mbx + 2, l);
             LDS_SYNC();
         }
+        OPAQUE(e.lane);
         slide_window(e);
         MI_T0(e);
 #if MI_ENT_B

@@ -25,6 +25,13 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
     } while (0)
 
+// Frame memory through explicit address-space-1 pointers: the frame pool's address arrives as an integer (PicDesc::pool_base),
+// and a pointer made from an integer is generic -- flat_load / flat_store, which are slower and count against the LDS wait
+// counter as well.
+typedef __attribute__((address_space(1))) uint8_t g8;
+typedef __attribute__((address_space(1))) uint16_t g16;
+typedef __attribute__((address_space(1))) uint32_t g32;
+
 __device__ __forceinline__ int clip255(int v) { return min(max(v, 0), 255); }
 
 struct ResBuf {
@@ -244,7 +251,7 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
     const int max_slot = static_cast<int>(pd->n_slots) - 1;
     const uint64_t pool_slot_bytes = pd->slot_bytes;
     const int mby = static_cast<int>(__umulhi(static_cast<uint32_t>(mb), pd->inv_wmb)), mbx = mb - mby * wmb; // PicDesc::inv_wmb: exact for every macroblock address
-    const uint8_t *pool_base = reinterpret_cast<const uint8_t *>(pd->pool_base);
+    const g8 *pool_base = (const g8 *)pd->pool_base;
     const size_t ysz = static_cast<size_t>(W) * H;
     // coefficient blocks (packed in the pool, MbRec::coef_off / coef_mask): issue the loads now, scatter them into the dense LDS
     // layout after the window loads have been issued
@@ -284,27 +291,27 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
         int uniform = 0;
         if (dneg >= 0 && same_v) {
             uniform = 2;
-            const uint8_t *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rslots[0]), max_slot)) * pool_slot_bytes;
+            const g8 *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rslots[0]), max_slot)) * pool_slot_bytes;
             const int b = lane >> 2, r = lane & 3;
-            dl = *reinterpret_cast<const uint32_t *>(ref + static_cast<uint32_t>((Y0 + (b >> 2) * 4 + r) * W + X0 + (b & 3) * 4));
+            dl = *reinterpret_cast<const g32 *>(ref + static_cast<uint32_t>((Y0 + (b >> 2) * 4 + r) * W + X0 + (b & 3) * 4));
             const int c = lane >> 5, q = lane & 31, cy = q >> 2, cx = (q & 3) * 2;
-            const uint8_t *cp = ref + static_cast<uint32_t>(static_cast<int>(ysz) + c * static_cast<int>(ysz / 4) + (cy0 + cy) * (W / 2) + cx0 + cx);
-            dc0 = *reinterpret_cast<const uint32_t *>(cp);
-            dc1 = cyh ? *reinterpret_cast<const uint32_t *>(cp + W / 2) : dc0;
+            const g8 *cp = ref + static_cast<uint32_t>(static_cast<int>(ysz) + c * static_cast<int>(ysz / 4) + (cy0 + cy) * (W / 2) + cx0 + cx);
+            dc0 = *reinterpret_cast<const g32 *>(cp);
+            dc1 = cyh ? *reinterpret_cast<const g32 *>(cp + W / 2) : dc0;
         } else if ((uniform = same_v && (x0 | y0 | (W - 21 - x0) | (H - 21 - y0) | cx0 | cy0 | (W / 2 - 9 - cx0) | (H / 2 - 9 - cy0) | rslots[0]) >= 0) != 0) {
-            const uint8_t *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rslots[0]), max_slot)) * pool_slot_bytes;
+            const g8 *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rslots[0]), max_slot)) * pool_slot_bytes;
             ox = x0 & 3;
             const int xa = x0 - ox;
             for (int i = lane; i < 21 * 6; i += 64) {
                 int r = i / 6, d = i - r * 6;
-                *reinterpret_cast<uint32_t *>(&sh.win16[r][d * 4]) = *reinterpret_cast<const uint32_t *>(ref + static_cast<size_t>(y0 + r) * W + xa + d * 4);
+                *reinterpret_cast<uint32_t *>(&sh.win16[r][d * 4]) = *reinterpret_cast<const g32 *>(ref + static_cast<size_t>(y0 + r) * W + xa + d * 4);
             }
             ocx = cx0 & 3;
             const int cxa = cx0 - ocx;
             if (lane < 54) {
                 int c = lane / 27, rem = lane - c * 27, r = rem / 3, d = rem - r * 3;
-                const uint8_t *cref = ref + ysz + static_cast<size_t>(c) * (ysz / 4);
-                *reinterpret_cast<uint32_t *>(&sh.winc16[c][r][d * 4]) = *reinterpret_cast<const uint32_t *>(cref + static_cast<size_t>(cy0 + r) * (W / 2) + cxa + d * 4);
+                const g8 *cref = ref + ysz + static_cast<size_t>(c) * (ysz / 4);
+                *reinterpret_cast<uint32_t *>(&sh.winc16[c][r][d * 4]) = *reinterpret_cast<const g32 *>(cref + static_cast<size_t>(cy0 + r) * (W / 2) + cxa + d * 4);
             }
         } else {
             for (int i = lane; i < 16 * 81; i += 64) {
@@ -313,7 +320,7 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
                 int mvx = mvs[b][0], mvy = mvs[b][1];
                 int x = mbx * 16 + (b & 3) * 4 + (mvx >> 2) - 2 + wx, y = mby * 16 + (b >> 2) * 4 + (mvy >> 2) - 2 + wy;
                 x = min(max(x, 0), W - 1), y = min(max(y, 0), H - 1);
-                const uint8_t *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool_slot_bytes;
+                const g8 *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool_slot_bytes;
                 sh.win_y[b][wy][wx] = ref[static_cast<size_t>(y) * W + x];
             }
             for (int i = lane; i < 2 * 16 * 9; i += 64) {
@@ -322,7 +329,7 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
                 int mvx = mvs[b][0], mvy = mvs[b][1];
                 int x = mbx * 8 + (b & 3) * 2 + (mvx >> 3) + wx, y = mby * 8 + (b >> 2) * 2 + (mvy >> 3) + wy;
                 x = min(max(x, 0), W / 2 - 1), y = min(max(y, 0), H / 2 - 1);
-                const uint8_t *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool_slot_bytes + ysz + static_cast<size_t>(c) * (ysz / 4);
+                const g8 *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool_slot_bytes + ysz + static_cast<size_t>(c) * (ysz / 4);
                 sh.win_c[c][b][wy][wx] = ref[static_cast<size_t>(y) * (W / 2) + x];
             }
         }
@@ -346,7 +353,7 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
     __syncthreads();
     const SliceDesc *sd = &slices[rec->slice_idx];
     const int wp = B ? sd->wp_flag : pd->weighted_pred;
-    uint8_t *dst_base = const_cast<uint8_t *>(pool_base) + static_cast<size_t>(pd->slot) * pool_slot_bytes;
+    g8 *dst_base = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pool_slot_bytes);
     int pv[4], pc[2];          // prediction of the list being processed: luma row of 4, chroma pair
     int pv0[4] = {0, 0, 0, 0}, pc0[2] = {0, 0}; // B: list-0 prediction while list 1 is computed
     // ---- luma: lane = (4x4 block, row) -> 4 samples ----
@@ -522,7 +529,7 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
             if (has_res) v = clip255(v + sh.rb.luma[(by + r) * 16 + bxs + i]);
             packed |= static_cast<uint32_t>(v) << (8 * i);
         }
-        *reinterpret_cast<uint32_t *>(dst_base + static_cast<uint32_t>((mby * 16 + by + r) * W + mbx * 16 + bxs)) = packed;
+        *reinterpret_cast<g32 *>(dst_base + static_cast<uint32_t>((mby * 16 + by + r) * W + mbx * 16 + bxs)) = packed;
     }
     {
         const int c = lane >> 5, q = lane & 31, cy = q >> 2, cx = (q & 3) * 2;
@@ -548,7 +555,7 @@ __device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const u
             if (has_res) v = clip255(v + sh.rb.chroma[c][cy * 8 + cx + i]);
             packed |= static_cast<uint32_t>(v) << (8 * i);
         }
-        *reinterpret_cast<uint16_t *>(dst_base + static_cast<uint32_t>(static_cast<int>(ysz) + c * static_cast<int>(ysz / 4) + (mby * 8 + cy) * (W / 2) + mbx * 8 + cx)) =
+        *reinterpret_cast<g16 *>(dst_base + static_cast<uint32_t>(static_cast<int>(ysz) + c * static_cast<int>(ysz / 4) + (mby * 8 + cy) * (W / 2) + mbx * 8 + cx)) =
             static_cast<uint16_t>(packed);
     }
 }
@@ -668,9 +675,6 @@ __device__ __forceinline__ void plane_params(FT T, FL L, int &a, int &b, int &c)
     c = N == 16 ? (5 * vv + 32) >> 6 : (34 * vv + 32) >> 6;
 }
 
-typedef __attribute__((address_space(1))) uint8_t g8;
-typedef __attribute__((address_space(1))) uint16_t g16;
-typedef __attribute__((address_space(1))) uint32_t g32;
 __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_t *coef, const ScalingSet *sc, g8 *py, g8 *pcb, g8 *pcr, int W,
                          int mbx, int mby) {
     const int type = rec->type, av = rec->avail;
