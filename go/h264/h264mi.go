@@ -243,7 +243,7 @@ func (d *Decoder) FrameRead(stream, frame int, crop bool, w, h int) ([]byte, err
 type FrameInfo struct {
 	Width, Height, CodedWidth, CodedHeight, CropX, CropY int
 	PicOrderCnt, FrameNum, NalRefIdc                     int
-	IDR                                                  bool
+	IDR, NewSequence                                     bool // NewSequence: picture order counts start over (IDR or MMCO 5)
 }
 
 // SetIsolation: a stream with a bitstream error leaves the batch (its status is reported by StreamStatus, it decodes again
@@ -275,7 +275,7 @@ func (d *Decoder) FrameInfo(stream, frame int) (FrameInfo, error) {
 		return FrameInfo{}, err
 	}
 	return FrameInfo{Width: int(c.width), Height: int(c.height), CodedWidth: int(c.coded_width), CodedHeight: int(c.coded_height), CropX: int(c.crop_x),
-		CropY: int(c.crop_y), PicOrderCnt: int(c.pic_order_cnt), FrameNum: int(c.frame_num), NalRefIdc: int(c.nal_ref_idc), IDR: c.idr != 0}, nil
+		CropY: int(c.crop_y), PicOrderCnt: int(c.pic_order_cnt), FrameNum: int(c.frame_num), NalRefIdc: int(c.nal_ref_idc), IDR: c.idr != 0, NewSequence: c.new_sequence != 0}, nil
 }
 
 // OutputOrder: indices (decoding order) of the stream's frames of the last batch in display order -- ascending PicOrderCnt

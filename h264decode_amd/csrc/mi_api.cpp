@@ -1479,6 +1479,7 @@ extern "C" int32_t h264mi_frame_get_info(h264mi_decoder *d, int32_t stream, int3
     fi->width = of->width, fi->height = of->height, fi->coded_width = of->wmb * 16, fi->coded_height = of->hmb * 16;
     fi->crop_x = of->crop_x, fi->crop_y = of->crop_y;
     fi->pic_order_cnt = of->poc, fi->frame_num = of->frame_num, fi->nal_ref_idc = of->nal_ref_idc, fi->idr = of->idr;
+    fi->new_sequence = of->new_sequence;
     return H264MI_OK;
 }
 

@@ -319,6 +319,37 @@ class Decoder:
 # (h264/server.go:64-172) read an endless Annex-B byte stream from a connection one byte at a time.
 # Here the bytes are cut at access-unit boundaries and handed to the batched GPU decoder.
 
+class DisplayOrder:
+    """Output process for streams with B pictures: frames go in in decoding order, come out in display order.  A simplified
+    C.4.5.3 "bumping": frames wait in a buffer ordered by PicOrderCnt; when more than `depth` frames wait the one with the
+    smallest PicOrderCnt is released, and an IDR picture (or a picture with memory_management_control_operation 5: its
+    PicOrderCnt is 0 again) releases everything before it.  `depth` must be at least the stream's number of reorder
+    frames (consecutive B pictures + 1 for a B pyramid level); the SPS's max_num_ref_frames is always enough.
+    (The reference has no output process: h264/server.go:113-166 stops at the parsed slice.)"""
+
+    def __init__(self, depth=4):
+        self.depth = depth
+        self._wait = []  # (PicOrderCnt, arrival number, frame)
+        self._n = 0
+
+    def push(self, frame, pic_order_cnt, new_sequence=False):
+        """Returns the frames that can be shown now, in display order."""
+        out = []
+        if new_sequence:
+            out = self.flush()
+        self._wait.append((pic_order_cnt, self._n, frame))
+        self._n += 1
+        self._wait.sort(key=lambda t: t[:2])
+        while len(self._wait) > self.depth:
+            out.append(self._wait.pop(0)[2])
+        return out
+
+    def flush(self):
+        out = [t[2] for t in self._wait]
+        self._wait = []
+        return out
+
+
 class AccessUnitSplitter:
     """Incremental Annex-B splitter: feed() arbitrary byte chunks, get back byte strings that end on an
     access-unit boundary (7.4.1.2.3/4, simplified: a new access unit starts at an access unit delimiter, at an
@@ -399,9 +430,10 @@ class AccessUnitSplitter:
 class H264Reader:
     """Mirror of the reference's H264Reader + handleConnection loop (h264/server.go:113-166): reads a connection
     (anything with recv() or read()), cuts the byte stream at access units and decodes them on the GPU.
-    `on_frames(frames)` receives uint8[n, width*height*3/2] arrays (cropped I420) in decoding order."""
+    `on_frames(frames)` receives uint8[n, width*height*3/2] arrays (cropped I420) in decoding order, or -- with
+    display_order=N -- in display order through a DisplayOrder buffer of depth N (streams with B pictures)."""
 
-    def __init__(self, connection, decoder=None, on_frames=None, max_width=1920, max_height=1088, frames_per_batch=30, read_size=1 << 16):
+    def __init__(self, connection, decoder=None, on_frames=None, max_width=1920, max_height=1088, frames_per_batch=30, read_size=1 << 16, display_order=0):
         self.Stream = connection
         self.frames_per_batch = frames_per_batch
         self.decoder = decoder or Decoder(max_streams=1, max_width=(max_width + 15) // 16 * 16, max_height=(max_height + 15) // 16 * 16,
@@ -411,6 +443,7 @@ class H264Reader:
         self.splitter = AccessUnitSplitter(frames_per_batch)
         self.n_frames = 0
         self._dims = (0, 0)
+        self._reorder = DisplayOrder(display_order) if display_order else None
 
     def _read(self):
         s = self.Stream
@@ -421,10 +454,16 @@ class H264Reader:
             self.decoder.decode([c])
             n = self.decoder.frame_count(0)
             if n:
-                frames = np.stack([self.decoder.read_frame(0, f, crop=True)[:self._size()] for f in range(n)])
+                frames = [self.decoder.read_frame(0, f, crop=True)[:self._size()] for f in range(n)]
                 self.n_frames += n
-                if self.on_frames:
-                    self.on_frames(frames)
+                if self._reorder:
+                    shown = []
+                    for f in range(n):
+                        fi = self.decoder.frame_info(0, f)
+                        shown += self._reorder.push(frames[f], fi.pic_order_cnt, bool(fi.new_sequence))
+                    frames = shown
+                if self.on_frames and len(frames):
+                    self.on_frames(np.stack(frames))
 
     def _size(self):
         info = self.decoder.info
@@ -440,6 +479,10 @@ class H264Reader:
                 break
             self._decode(self.splitter.feed(data))
         self._decode(self.splitter.flush())
+        if self._reorder:
+            rest = self._reorder.flush()
+            if self.on_frames and rest:
+                self.on_frames(np.stack(rest))
         return self.n_frames
 
 

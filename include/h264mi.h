@@ -208,6 +208,7 @@ typedef struct {
     int32_t width, height, coded_width, coded_height, crop_x, crop_y; /* display size, coded size, crop origin (luma samples) */
     int32_t pic_order_cnt;                                            /* PicOrderCnt(CurrPic) 8.2.1, after a possible MMCO 5 */
     int32_t frame_num, nal_ref_idc, idr;
+    int32_t new_sequence; /* picture order counts start over here: IDR picture, or memory_management_control_operation 5 */
 } h264mi_frame_info;
 int32_t h264mi_frame_get_info(h264mi_decoder *dec, int32_t stream, int32_t frame, h264mi_frame_info *info);
 /* Output (display) order of the frames of the last batch of one stream: order[k] = index (decoding order) of the k-th frame

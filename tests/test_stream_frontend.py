@@ -139,3 +139,42 @@ def test_gpu_batch_server_decodes_several_connections_side_by_side(H, sg, oracle
     for i in range(3):
         assert np.array_equal(np.concatenate(got[i]), refs[i]), i
 
+
+
+def test_display_order_buffer(H, sg):
+    """DisplayOrder turns the coding order of B streams (incl. pyramids and several IDR periods) back into display order."""
+    from conftest import MATRIX
+    for name in ("b_ibp_cabac", "b_ibbp_cavlc", "b_pyramid_cabac", "b_pyramid_implicit", "b_gop_intra_pcm", "cabac_IPP"):
+        kw = MATRIX[name]
+        sg.encode(**kw)
+        pocs = [int(p) for p in sg.last_pocs()]
+        buf = H.DisplayOrder(depth=4)
+        shown, seq = [], -1
+        for k, poc in enumerate(pocs):
+            new_seq = poc == 0 and (k == 0 or kw.get("idr_period", 0) > 0)
+            seq += new_seq
+            shown += buf.push((seq, poc), poc, new_seq)
+        shown += buf.flush()
+        assert len(shown) == len(pocs) and shown == sorted(shown), (name, shown)
+
+
+@pytest.mark.gpu
+def test_gpu_reader_delivers_b_streams_in_display_order(H, sg):
+    from conftest import MATRIX
+    kw = MATRIX["b_gop_intra_pcm"]  # I B B B P ..., two IDR periods
+    stream, rec, _ = sg.encode(**kw)
+    pocs = [int(p) for p in sg.last_pocs()]
+    got = []
+    r = H.H264Reader(io.BytesIO(stream), on_frames=lambda f: got.append(f), max_width=kw["width"], max_height=kw["height"], frames_per_batch=5, display_order=4)
+    assert r.run() == kw["frames"]
+    got = np.concatenate(got)
+    seq, cur = [], -1
+    for p in pocs:
+        cur += p == 0
+        seq.append(cur)
+    order = sorted(range(len(pocs)), key=lambda i: (seq[i], pocs[i]))
+    W, Hc = (kw["width"] + 15) // 16 * 16, (kw["height"] + 15) // 16 * 16
+    want = rec[order]
+    if (W, Hc) != (kw["width"], kw["height"]):  # the reader delivers cropped frames
+        pytest.skip("cropped geometry")
+    assert np.array_equal(got, want)
