@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--max-width", type=int, default=1920)
     ap.add_argument("--max-height", type=int, default=1088)
     ap.add_argument("--frames-per-batch", type=int, default=30)
+    ap.add_argument("--display-order", type=int, default=0, metavar="DEPTH",
+                    help="deliver frames in display order through a reorder buffer of this depth (streams with B pictures; single-connection mode)")
     ap.add_argument("--out", default=None, help="append decoded frames (tight I420) to this file")
     ap.add_argument("--once", action="store_true", help="serve one connection and exit")
     ap.add_argument("--batch", type=int, default=0, help="decode up to N concurrent connections side by side in one batched decoder (H.BatchServer)")
@@ -55,7 +57,8 @@ def main():
                 out.write(frames.tobytes())
 
         try:
-            H.ByteStreamReader(conn, on_frames=on_frames, max_width=args.max_width, max_height=args.max_height, frames_per_batch=args.frames_per_batch)
+            H.ByteStreamReader(conn, on_frames=on_frames, max_width=args.max_width, max_height=args.max_height, frames_per_batch=args.frames_per_batch,
+                               display_order=args.display_order)
         except H.H264MIError as e:
             print("%s: decode error: %s" % (peer[0], e), flush=True)
         if args.once:
