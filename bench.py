@@ -119,6 +119,47 @@ def extra_configs(H, streams, F, W, Hc, device, args):
     return out
 
 
+def strong_share(H, torch, dist, streams, F, W, Hc, device, args, rank, world, total=256, gops=8, steps=2):
+    """C5 as ONE fixed job on the N > 1 line (SURVEY 8e "256 streams total"): `total` streams of `gops` GOPs each, stream s on
+    rank s mod N, built from the GOP streams the rank has already generated; deep batches (several GOPs of every stream per
+    batch) and pipelined ingest as in run_strong.  Returns rank 0's dict (None elsewhere)."""
+    from h264decode_amd.dist import allreduce_stats
+    S = len([s for s in range(total) if s % world == rank])
+    nd = len(streams)
+    D = max(1, min(gops, 256 // max(S, 1)))
+    while gops % D:
+        D -= 1
+    nbatch = gops // D
+    batches = [[b"".join(streams[(k + S * (b * D + j)) % nd] for j in range(D)) for k in range(S)] for b in range(nbatch)]
+    dec = H.Decoder(max_streams=max(S, 1), max_width=W, max_height=Hc, max_frames_per_batch=F * D, max_slices_per_frame=1, device=device,
+                    max_bitstream_bytes=int(max(sum(len(x) for x in bt) for bt in batches) * 1.1) + (1 << 20))
+    seq = [b for _ in range(1 + steps) for b in batches]
+    dec.prepare(seq[0])
+    for k in range(nbatch):  # one warm-up step through the same pipeline
+        dec.execute()
+        dec.prepare(seq[k + 1])
+    dec.sync()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(nbatch, len(seq)):
+        dec.execute()
+        if k + 1 < len(seq):
+            dec.prepare(seq[k + 1])
+    dec.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    red = allreduce_stats({"ranks": 1, "frames": S * gops * F * steps, "seconds": time.perf_counter() - t0}, device="cuda" if (dist and dist.get_backend() == "nccl") else None)
+    dec.close()
+    if rank != 0:
+        return None
+    return {"fps": round(red["frames"] / red["seconds"], 2), "ms_per_step": round(red["seconds"] / steps * 1e3, 3), "scaling": "strong", "ranks_seen": int(red.get("ranks", 1)),
+            "workload": "%d streams x %d GOPs in total, stream s on rank s mod %d; rank 0: %d streams, %d batch(es) of %d GOP(s); ingest pipelined inside the timed region"
+                        % (total, gops, world, S, nbatch, D)}
+
+
 def run_strong(args, H, torch, dist, rank, world, local_rank):
     """STRONG scaling: a fixed job -- `--total-streams` streams of `--gops` GOPs each -- sharded over the GPUs
     by longest-processing-time-first on the streams' byte counts (dist.shard_streams_lpt).  A GPU with few streams gets
@@ -184,13 +225,13 @@ def run_strong(args, H, torch, dist, rank, world, local_rank):
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    red = allreduce_stats({"frames": S * G * F * args.steps, "pixels": S * G * F * args.steps * args.width * args.height,
+    red = allreduce_stats({"ranks": 1, "frames": S * G * F * args.steps, "pixels": S * G * F * args.steps * args.width * args.height,
                            "bytes_in": sum(len(x) for bt in batches for x in bt) * args.steps, "seconds": elapsed}, device="cuda" if (dist and dist.get_backend() == "nccl") else None)
     dec.close()
     if rank == 0:
         fps = red["frames"] / red["seconds"]
         print(json.dumps({
-            "metric": "1080p Main CABAC frames/sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "1080p Main CABAC frames/sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "ranks_seen": int(red.get("ranks", 1)), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(red["seconds"] / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "%dx%d Main CABAC IPPP GOP-%d: %d streams x %d GOPs in total, sharded over %d GPU(s) by LPT on stream bytes; rank 0: %d streams, "
@@ -219,7 +260,22 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the c5_share (32 streams per GPU) and single_stream (C3: 1 stream x 300 frames) measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous check only: every rank joins the process group, the closing all-reduce runs and rank 0 "
+                                                           "prints n_gpus / ranks_seen; nothing is decoded (works without a GPU over gloo)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` starts its own N ranks (one process per GPU).  This process has not imported torch or touched
+    # HIP yet and never will: the ranks run as a CHILD process (torch.distributed.run), whose single JSON line and exit code
+    # are relayed.  Under a launcher (WORLD_SIZE set) this branch is skipped and --gpus is checked against the world size.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        return subprocess.call(cmd)
 
     import torch
     import h264decode_amd as H
@@ -227,6 +283,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if args.dry_run:
+        import torch.distributed as dist
+        from h264decode_amd.dist import allreduce_stats
+        if world > 1:
+            dist.init_process_group(os.environ.get("H264MI_BENCH_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
+        red = allreduce_stats({"frames": 1.0, "ranks": 1.0, "seconds": float(rank)})
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(red["ranks"]), "slowest_rank_seconds": red["seconds"]}))
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the decode path has no CPU fallback")
     # rehearsal hooks (one-GPU box): H264MI_BENCH_DEVICE pins every rank to one device, H264MI_BENCH_BACKEND=gloo replaces RCCL
@@ -302,9 +371,10 @@ def main():
     elapsed = time.perf_counter() - t_start
     # closing reduction over the ranks (no collective anywhere in the decode path): frames summed, time = the slowest rank
     from h264decode_amd.dist import allreduce_stats
-    red = allreduce_stats({"frames": S * F * args.steps, "pixels": S * F * args.steps * args.width * args.height,
+    red = allreduce_stats({"ranks": 1, "frames": S * F * args.steps, "pixels": S * F * args.steps * args.width * args.height,
                            "bytes_in": sum(len(x) for x in streams) * args.steps, "seconds": elapsed}, device="cuda" if (dist and dist.get_backend() == "nccl") else None)
     elapsed, total_frames = red["seconds"], red["frames"]
+    ranks_seen = int(red.get("ranks", 1))
     fps = total_frames / elapsed
     ms_per_step = elapsed / args.steps * 1e3
 
@@ -365,6 +435,10 @@ def main():
     extra = {}
     if not args.no_extra and world == 1:
         extra = extra_configs(H, streams, F, W, Hc, local_rank, args)
+    elif not args.no_extra and S >= 256 // world:  # N > 1: C5 as a fixed 256-stream job next to the weak-scaling `value`
+        c5 = strong_share(H, torch, dist, streams, F, W, Hc, local_rank, args, rank, world)
+        if c5:
+            extra = {"c5_strong": c5}
 
     if rank != 0:
         if dist:
@@ -433,6 +507,7 @@ def main():
         "value": round(fps, 2),
         "unit": "frames/s",
         "n_gpus": world,
+        "ranks_seen": ranks_seen,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3),
@@ -464,4 +539,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -26,12 +26,13 @@ def shard_streams_lpt(costs: Sequence[int], world_size: int, rank: int) -> List[
 
 
 def allreduce_stats(stats: Dict[str, float], device=None) -> Dict[str, float]:
-    """Sum `frames`, `pixels`, `bytes_in`; max `seconds`; xor-fold `checksum` across ranks."""
+    """Sum `frames`, `pixels`, `bytes_in`, `ranks` (1 per rank: how many ranks the collective saw); max `seconds`; xor-fold
+    `checksum` across ranks."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return dict(stats)
-    keys_sum = [k for k in ("frames", "pixels", "bytes_in") if k in stats]
+    keys_sum = [k for k in ("frames", "pixels", "bytes_in", "ranks") if k in stats]
     t = torch.tensor([float(stats[k]) for k in keys_sum], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     out = dict(zip(keys_sum, t.tolist()))

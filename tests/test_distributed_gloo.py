@@ -90,6 +90,27 @@ def test_world_size_2_gloo():
     assert tot["checksum"] == want
 
 
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver uses) must start two ranks as a child
+    process, relay rank 0's single JSON line and exit code, and the closing all-reduce must have seen both ranks.
+    --dry-run: rendezvous + all-reduce only, so this runs without a GPU (gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["H264MI_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["slowest_rank_seconds"] == 1.0
+    # a launcher whose world size contradicts --gpus is an error, not a silent one-rank run
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "--gpus 4" in (bad.stderr + bad.stdout)
+
+
 @pytest.mark.gpu
 def test_gpu_bench_two_ranks_rehearsal():
     """bench.py's multi-rank path (barriers, max-over-ranks time, summed frames, rank-0 JSON) with two ranks sharing the one GPU
@@ -98,13 +119,13 @@ def test_gpu_bench_two_ranks_rehearsal():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, H264MI_BENCH_DEVICE="0", H264MI_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--streams", "8", "--frames", "4", "--width", "320", "--height", "240"]
+    env = dict({k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}, H264MI_BENCH_DEVICE="0", H264MI_BENCH_BACKEND="gloo")
+    # no launcher: bench.py --gpus 2 starts its two ranks itself
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--streams", "8", "--frames", "4", "--width", "320", "--height", "240"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1  # rank 0 only
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_step_per_gpu"] == 32 and d["cpu_baseline"] is None
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and d["config"]["frames_per_step_per_gpu"] == 32 and d["cpu_baseline"] is None
     assert abs(d["value"] - 2 * 32 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.02  # all ranks' frames over the slowest rank's time
