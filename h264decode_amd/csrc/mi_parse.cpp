@@ -461,17 +461,20 @@ int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc
                 lw[i] = 1 << sh->luma_log2_weight_denom;
                 cw[i][0] = cw[i][1] = 1 << sh->chroma_log2_weight_denom;
                 lf[i] = b.u(1);
+                // 7.4.3.2: CODED weights and offsets are in -128..127; the inferred default 2^denom (128 for denom 7) is not coded
                 if (lf[i]) {
                     lw[i] = b.se();
                     lo[i] = b.se();
+                    if (lw[i] < -128 || lw[i] > 127 || lo[i] < -128 || lo[i] > 127) return H264MI_EBITSTREAM;
                 }
                 cf[i] = b.u(1);
                 if (cf[i])
                     for (int j = 0; j < 2; j++) {
                         cw[i][j] = b.se();
                         co[i][j] = b.se();
+                        if (cw[i][j] < -128 || cw[i][j] > 127 || co[i][j] < -128 || co[i][j] > 127) return H264MI_EBITSTREAM;
                     }
-                if (lw[i] < -128 || lw[i] > 127 || lo[i] < -128 || lo[i] > 127 || b.overrun()) return H264MI_EBITSTREAM;
+                if (b.overrun()) return H264MI_EBITSTREAM;
             }
         }
     }

@@ -1760,7 +1760,7 @@ static size_t write_pps(enc *e, uint8_t *dst, size_t cap) {
     sg_put_ue(&w, 0); /* slice groups */
     sg_put_ue(&w, (uint32_t)(p->num_ref_frames - 1));
     sg_put_ue(&w, 0);
-    sg_put(&w, (uint32_t)p->weighted_pred, 1);
+    sg_put(&w, p->weighted_pred != 0, 1);
     sg_put(&w, (uint32_t)p->weighted_bipred, 2); /* weighted_bipred_idc */
     sg_put_se(&w, p->qp - 26);
     sg_put_se(&w, 0);
@@ -2252,26 +2252,29 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         }
         if (g_npocs < 8192) /* pic_order_cnt_type 2 leaves no choice: 2 * FrameNum, minus 1 for non-reference pictures (8.2.1.3) */
             g_pocs[g_npocs++] = p->poc_type == 2 ? (idr ? 0 : 2 * refs_since_reset - (e->nal_ref_idc ? 0 : 1)) : poc;
+        /* weighted_pred 2: both denominators 7, so that the DEFAULT weight of an entry without a flag is 128 -- outside the
+         * range of a coded weight (-128..127); coded weights stay below it */
+        const int wld = p->weighted_pred == 2 ? 7 : 5, wcd = p->weighted_pred == 2 ? 7 : 4;
         if (!idr && p->weighted_pred) {
-            e->wp_ld = 5, e->wp_cd = 4;
+            e->wp_ld = wld, e->wp_cd = wcd;
             for (int i = 0; i < 4; i++) {
-                e->wp_w[i] = 32 + rnd_range(e, -3, 3), e->wp_o[i] = rnd_range(e, -2, 2);
-                for (int c = 0; c < 2; c++) e->wp_cw[i][c] = 16 + rnd_range(e, -1, 1), e->wp_co[i][c] = rnd_range(e, -1, 1);
+                e->wp_w[i] = (1 << wld) + (wld == 7 ? rnd_range(e, -9, -1) : rnd_range(e, -3, 3)), e->wp_o[i] = rnd_range(e, -2, 2);
+                for (int c = 0; c < 2; c++) e->wp_cw[i][c] = (1 << wcd) + (wcd == 7 ? rnd_range(e, -5, -1) : rnd_range(e, -1, 1)), e->wp_co[i][c] = rnd_range(e, -1, 1);
             }
-            e->wp_w[0] = 32, e->wp_o[0] = 0; /* first entry default: exercises the flag=0 path */
+            e->wp_w[0] = 1 << wld, e->wp_o[0] = 0; /* first entry default: exercises the flag=0 path */
         }
         if (bpic) { /* explicit weights of both lists (weighted_bipred_idc 1); unit weights otherwise, so that b_predict can index them blindly */
-            e->wp_ld = 5, e->wp_cd = 4;
+            e->wp_ld = wld, e->wp_cd = wcd;
             for (int i = 0; i < 4; i++) {
                 int ex = p->weighted_bipred == 1;
-                e->wp_w[i] = 32 + (ex ? rnd_range(e, -3, 3) : 0), e->wp_o[i] = ex ? rnd_range(e, -2, 2) : 0;
-                e->wb_w1[i] = 32 + (ex ? rnd_range(e, -3, 3) : 0), e->wb_o1[i] = ex ? rnd_range(e, -2, 2) : 0;
+                e->wp_w[i] = (1 << wld) + (ex ? (wld == 7 ? rnd_range(e, -9, -1) : rnd_range(e, -3, 3)) : 0), e->wp_o[i] = ex ? rnd_range(e, -2, 2) : 0;
+                e->wb_w1[i] = (1 << wld) + (ex ? (wld == 7 ? rnd_range(e, -9, -1) : rnd_range(e, -3, 3)) : 0), e->wb_o1[i] = ex ? rnd_range(e, -2, 2) : 0;
                 for (int c = 0; c < 2; c++) {
-                    e->wp_cw[i][c] = 16 + (ex ? rnd_range(e, -1, 1) : 0), e->wp_co[i][c] = ex ? rnd_range(e, -1, 1) : 0;
-                    e->wb_cw1[i][c] = 16 + (ex ? rnd_range(e, -1, 1) : 0), e->wb_co1[i][c] = ex ? rnd_range(e, -1, 1) : 0;
+                    e->wp_cw[i][c] = (1 << wcd) + (ex ? (wcd == 7 ? rnd_range(e, -5, -1) : rnd_range(e, -1, 1)) : 0), e->wp_co[i][c] = ex ? rnd_range(e, -1, 1) : 0;
+                    e->wb_cw1[i][c] = (1 << wcd) + (ex ? (wcd == 7 ? rnd_range(e, -5, -1) : rnd_range(e, -1, 1)) : 0), e->wb_co1[i][c] = ex ? rnd_range(e, -1, 1) : 0;
                 }
             }
-            e->wb_w1[0] = 32, e->wb_o1[0] = 0;
+            e->wb_w1[0] = 1 << wld, e->wb_o1[0] = 0;
         }
         for (int i = 0; i < e->wmb * e->hmb; i++) e->mb[i].type = T_NONE;
         for (int s = 0; s < p->slices; s++) {

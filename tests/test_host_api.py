@@ -140,6 +140,68 @@ def test_b_slice_headers(H, sg, oracle_mod):
         assert [p // 2 for p in pocs][:4] == ([0, 3, 1, 2] if kw["bframes"] == 2 else [0, 4, 2, 1])  # coding order: anchor first, then its B pictures
 
 
+def test_pred_weight_table_default_weight_128_is_accepted(H, sg):
+    """7.4.3.2: only CODED weights are limited to -128..127.  With luma_log2_weight_denom = 7 an entry whose flag is 0 infers
+    the weight 2^7 = 128, which the range check must not refuse (P slices, and list 1 of B slices)."""
+    for kw, is_b in ((dict(width=64, height=48, frames=5, idr_period=0, profile_idc=77, cabac=0, weighted_pred=2, num_ref_frames=3), False),
+                     (dict(width=64, height=48, frames=8, idr_period=0, profile_idc=77, cabac=1, bframes=2, num_ref_frames=3, weighted_bipred=1, weighted_pred=2), True)):
+        stream, _, _ = sg.encode(**kw)
+        nals = H.read_nal_units(stream)
+        sps = H.NewSPS(nals[0].RBSP())
+        pps = H.NewPPS(sps, nals[1].RBSP())
+        assert pps.WeightedPred == 1
+        vs = H.VideoStream(sps, pps)
+        seen = 0
+        for n in nals[2:]:
+            h = H.NewSliceContext(vs, n, n.RBSP()).Slice.Header  # raises H264MIError if the header is refused
+            st = h.SliceType % 5
+            if st == 2:
+                continue
+            if st == 0 or (st == 1 and is_b):
+                assert h.LumaLog2WeightDenom == 7 and h.ChromaLog2WeightDenom == 7
+                if st == 0:  # the generator leaves entry 0 of list 0 (P slices) / of list 1 (B slices) at the inferred default
+                    assert h.LumaWeightL0[0] == 128 and h.LumaOffsetL0[0] == 0
+                    if h.NumRefIdxL0ActiveMinus1 >= 1:
+                        assert 119 <= h.LumaWeightL0[1] <= 127
+                else:
+                    assert h.LumaWeightL1[0] == 128 and 119 <= h.LumaWeightL0[0] <= 127
+                seen += 1
+        assert seen >= 2
+    # a CODED weight of 128 stays an error, 127 is fine: hand-built P slice header with both denominators 7
+    sps, pps = H.NewSPS(sg_sps_for_kat(H, sg)), None
+    pps = H.NewPPS(sps, sg_pps_for_kat(H, sg))
+    assert sps.Log2MaxFrameNumMinus4 == 4 and sps.PicOrderCountType == 0 and pps.DeblockingFilterControlPresent == 1
+
+    def se(v):
+        b = bin((2 * v - 1 if v > 0 else -2 * v) + 1)[2:]
+        return "0" * (len(b) - 1) + b
+    vs = H.VideoStream(sps, pps)
+    for weight in (127, 128):
+        bits = "1" + "00110" + "1" + "00000001" + "00000010"  # first_mb 0, slice_type 5 (P), pps 0, frame_num u(8) = 1, pic_order_cnt_lsb u(8) = 2
+        bits += "0" + "0"                                      # num_ref_idx_active_override_flag, ref_pic_list_modification_flag_l0
+        bits += "0001000" + "0001000"                          # luma / chroma log2_weight_denom = ue(7)
+        bits += "1" + se(weight) + se(0) + "0"                 # luma_weight_l0_flag 1, weight, offset 0; chroma_weight_l0_flag 0
+        bits += "0" + se(0) + "1"                              # adaptive_ref_pic_marking_mode_flag 0, slice_qp_delta 0, disable_deblocking_filter_idc ue(0)
+        bits += se(0) + se(0) + "1"                            # alpha / beta offsets, then slice data
+        raw = int(bits.ljust((len(bits) + 7) // 8 * 8, "0"), 2).to_bytes((len(bits) + 7) // 8, "big")
+        if weight == 127:
+            h = H.NewSliceContext(vs, H.NewNalUnit(bytes([0x41]) + raw), raw).Slice.Header
+            assert h.LumaWeightL0[0] == 127 and h.LumaLog2WeightDenom == 7 and h.FrameNum == 1
+        else:
+            with pytest.raises(H.H264MIError):
+                H.NewSliceContext(vs, H.NewNalUnit(bytes([0x41]) + raw), raw)
+
+
+def sg_sps_for_kat(H, sg):
+    stream, _, _ = sg.encode(width=64, height=48, frames=2, idr_period=0, profile_idc=77, cabac=0, weighted_pred=2, num_ref_frames=1)
+    return H.read_nal_units(stream)[0].RBSP()
+
+
+def sg_pps_for_kat(H, sg):
+    stream, _, _ = sg.encode(width=64, height=48, frames=2, idr_period=0, profile_idc=77, cabac=0, weighted_pred=2, num_ref_frames=1)
+    return H.read_nal_units(stream)[1].RBSP()
+
+
 def test_malformed_inputs_return_status_codes(H):
     with pytest.raises(H.H264MIError):
         H.NewSPS(b"")
