@@ -37,6 +37,16 @@
 #ifndef MI_DB_B
 #define MI_DB_B 0
 #endif
+// Third / fourth build (k_deblock_x.hip, k_deblock_b_x.hip: MI_DB_BANDS = 1): a picture is spread over several workgroups
+// ("bands" of consecutive row groups, one wavefront per group, one round) for launches with fewer pictures than the chip
+// has CUs.  Inside a band nothing changes (LDS rings, workgroup-scope counters).  Between bands the bottom rows travel
+// through a ring in global memory as 8-byte {epoch, data} granules written by ONE agent-scope (sc1) store each and read
+// by agent-scope loads until every tag shows this launch's epoch: the data is its own flag, so no fence, no separate
+// flag and no assumption about which CU or XCD a band runs on.  A band only ever waits for the band above it, and bands
+// take their (picture, band) from a ticket counter in that order, so whoever a workgroup waits for is already running.
+#ifndef MI_DB_BANDS
+#define MI_DB_BANDS 0
+#endif
 
 #define WAVE_SYNC()                                            \
     do {                                                       \
@@ -70,6 +80,7 @@ struct DbShared { // followed in dynamic LDS by DbWave[nwaves] and the hand-off 
     uint8_t alpha[52], beta[52], tc0[52][4];
     int prog[96]; // per group: macroblock columns of its LAST row that are final (rows 12..15 complete)
     int cons[96]; // per group: hand-off slots consumed by its FIRST row
+    uint32_t ticket; // banded builds: which (picture, band) this workgroup drew
 };
 static_assert(sizeof(DbShared) <= MI_DEBLOCK_HDR_BYTES && sizeof(DbWave) == (MI_DB_B ? MI_DEBLOCK_WAVE_BYTES_B : MI_DEBLOCK_WAVE_BYTES) && sizeof(GroupSlot) == MI_DEBLOCK_SLOT_BYTES,
               "LDS layout constants");
@@ -185,13 +196,29 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
     return static_cast<uint32_t>(a) | (static_cast<uint32_t>(b) << 8) | (static_cast<uint32_t>(c) << 16) | (static_cast<uint32_t>(d) << 24);
 }
 
+#if MI_DB_BANDS
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+#define XARGS , unsigned long long *xring_, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus
 #if MI_DB_B
-extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_deblock_b(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
-                                                                                    const DevTables *tab, const MbRec *mbrec, int ring, int ring_last, int last_bufs,
-                                                                                    const MbMv1 *mbmv1) {
+#define KNAME k_deblock_b_x
 #else
-extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
-                                                                                  const DevTables *tab, const MbRec *mbrec, int ring, int ring_last, int last_bufs) {
+#define KNAME k_deblock_x
+#endif
+#else
+#define XARGS
+#if MI_DB_B
+#define KNAME k_deblock_b
+#else
+#define KNAME k_deblock
+#endif
+#endif
+#if MI_DB_B
+extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
+                                                                              const DevTables *tab, const MbRec *mbrec, int ring, int ring_last, int last_bufs,
+                                                                              const MbMv1 *mbmv1 XARGS) {
+#else
+extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
+                                                                              const DevTables *tab, const MbRec *mbrec, int ring, int ring_last, int last_bufs XARGS) {
 #endif
     extern __shared__ uint4 dyn_lds[];
     const int nthreads = static_cast<int>(blockDim.x), nwaves = nthreads >> 6;
@@ -200,7 +227,16 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
     GroupSlot *rings = reinterpret_cast<GroupSlot *>(waves + nwaves); // region r (written by the groups of wavefront r) starts at r * ring
     const int tid = static_cast<int>(threadIdx.x), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane_v = tid & 63;
+#if MI_DB_BANDS
+    if (tid == 0) sh.ticket = atomicAdd(ticket, 1u) - ticket_base; // tickets go out in (picture, band) order: see the header
+    __syncthreads();
+    const uint32_t tk = sh.ticket;
+    const uint32_t pic_i = tk / static_cast<uint32_t>(nbands);
+    const int band = static_cast<int>(tk - pic_i * static_cast<uint32_t>(nbands));
+    const PicDesc *pd = &pics[pic_list[pic_i]];
+#else
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
+#endif
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
     const int W = wmb * 16, H = hmb * 16, Wc = W / 2; // the picture's own geometry
     g8 *const py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes); // luma plane; Cb at +W*H, Cr at +W*H*5/4
@@ -218,7 +254,19 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
     const int ngroups = (hmb + 3) >> 2;
     const v4u z4 = v4u{0u, 0u, 0u, 0u};
     const v2u z2 = v2u{0u, 0u};
+#if MI_DB_BANDS
+    // band b owns the groups [b * ngroups / nbands, (b + 1) * ngroups / nbands), one wavefront each (the host launches
+    // enough wavefronts for the largest band); rings: region w of LDS is written by wavefront w, also by the band's last one
+    const int g0 = band * ngroups / nbands, g1 = (band + 1) * ngroups / nbands;
+    GroupSlot *const in_stage = rings + nwaves * ring; // the slot of the band above, copied from the global ring
+    int pband = band - 1;                               // the band that owns group g0 - 1 (bands of small pictures can be empty)
+    while (pband > 0 && pband * ngroups / nbands == (pband + 1) * ngroups / nbands) pband--;
+    gu64 *const xin = (gu64 *)xring_ + (static_cast<size_t>(pic_i) * nbands + (pband > 0 ? pband : 0)) * static_cast<size_t>(wmb_max) * 24;
+    gu64 *const xout = (gu64 *)xring_ + (static_cast<size_t>(pic_i) * nbands + band) * static_cast<size_t>(wmb_max) * 24;
+    for (int g = g0 + wave; g < g1; g += ngroups) { // at most one iteration
+#else
     for (int g = wave; g < ngroups; g += nwaves) {
+#endif
         int lane = lane_v;
         OPAQUE(lane);
         const int sub = lane >> 4, li = lane & 15; // sub-row inside the group, lane inside the macroblock
@@ -228,6 +276,17 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
         const bool feeds_group = g + 1 < ngroups;     // this group's last row hands its bottom rows to group g + 1
         // hand-off rings: the one this group writes (region `wave`) and the one it reads (written by group g - 1)
         // (the last wavefront's region holds whole rows and, from three rounds on, one buffer per round parity: see mi_deblock_plan)
+#if MI_DB_BANDS
+        const bool band_first = wave == 0 && g > 0;            // the rows above come from another workgroup
+        const bool to_global = feeds_group && g == g1 - 1;     // the bottom rows go to another workgroup
+        const int out_depth = ring;
+        GroupSlot *out_ring = rings + wave * ring;
+        const int in_depth = band_first ? 1 : ring;
+        const GroupSlot *in_ring = band_first ? in_stage : rings + (wave > 0 ? wave - 1 : 0) * ring;
+        // this lane's granule of the slot of column 0 (lanes 0..23: the 24 dwords of a GroupSlot), re-read until its tag matches
+        unsigned long long pf = 0;
+        if (band_first && lane < 24) pf = __hip_atomic_load(xin + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         const bool out_last = wave == nwaves - 1;
         const int out_depth = out_last ? ring_last : ring;
         GroupSlot *out_ring = rings + wave * ring + (out_last ? ((g / nwaves) % last_bufs) * ring_last : 0);
@@ -235,6 +294,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
         const bool in_last = in_wave == nwaves - 1;
         const int in_depth = in_last ? ring_last : ring;
         const GroupSlot *in_ring = rings + in_wave * ring + (in_last && g > 0 ? (((g - 1) / nwaves) % last_bufs) * ring_last : 0);
+#endif
         const uint32_t yrow0 = static_cast<uint32_t>((row_ok ? mby : 0) * 16 + li) * W;                                   // this lane's luma row
         const uint32_t crow0 = (li < 8 ? cb_off : cr_off) + static_cast<uint32_t>((row_ok ? mby : 0) * 8 + (li & 7)) * Wc; // and chroma row
         // Input registers.  Slot s of P / Pc holds macroblock column c with (c + sub) % 4 == s, so that at step t every
@@ -296,9 +356,11 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
         prefetch_group(0);
         prefetch_rec(-sub); // step 0 (only sub-row 0 is active)
         // the ring this group writes was last used by the group `reuse` groups earlier: that group's reader must be through with it
+#if !MI_DB_BANDS
         const int reuse = out_last ? nwaves * last_bufs : nwaves;
         if (g >= reuse && feeds_group)
             while (__hip_atomic_load(&sh.cons[g - reuse + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < wmb) __builtin_amdgcn_s_sleep(1);
+#endif
         const int nsteps = wmb + 3;
         for (int t = 0; t < nsteps; t++) {
             int lane = lane_v;
@@ -432,10 +494,38 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
             WAVE_SYNC();
             if (feeds_group) {
                 const int xl = t - last_sub; // column of the group's last row in this step: columns 0 .. xl - 1 are final now
+#if MI_DB_BANDS
+                if (to_global) { // the finished slot of column xl - 1 leaves as 24 granules
+                    if (xl >= 1 && xl < wmb && lane < 24)
+                        __hip_atomic_store(xout + (xl - 1) * 24 + lane,
+                                           (static_cast<unsigned long long>(epoch) << 32) | reinterpret_cast<const uint32_t *>(&out_ring[(xl - 1) % out_depth])[lane],
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else
+#endif
                 if (xl >= 1 && xl < wmb && lane == 0) __hip_atomic_store(&sh.prog[g], xl, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // 3b. rows above this macroblock: from the sub-row above (same wavefront, written in the previous step and just
             //     completed), or -- sub-row 0 -- from the group above through its ring, once it says the column is final
+#if MI_DB_BANDS
+            if (band_first) {
+                if (t < wmb) {
+                    // every granule of column t must carry this launch's epoch (the data is the flag); stragglers are re-read
+                    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        const bool ok = lane >= 24 || static_cast<uint32_t>(pf >> 32) == epoch;
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if (lane < 24) pf = __hip_atomic_load(xin + t * 24 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__builtin_amdgcn_s_memrealtime() - t_start > 400000000ull) { // 4 s at 100 MHz: report instead of hanging the GPU
+                            if (lane == 0) atomicExch(xstatus, 0x5D000000u | static_cast<uint32_t>(g));
+                            break;
+                        }
+                    }
+                    if (lane < 24) reinterpret_cast<uint32_t *>(in_stage)[lane] = static_cast<uint32_t>(pf);
+                    if (t + 1 < wmb && lane < 24) pf = __hip_atomic_load(xin + (t + 1) * 24 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // next step's slot
+                }
+            } else
+#endif
             if (g > 0 && t < wmb)
                 while (__hip_atomic_load(&sh.prog[g - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
             WAVE_SYNC();
@@ -498,7 +588,11 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
             // ---- 5. results ----
             // Back-pressure first: the ring slot the group's last row is about to overwrite held column xl - depth of this
             // group; the group below must have consumed it.
+#if MI_DB_BANDS
+            if (feeds_group && !to_global) { // (a slot that went to the global ring has been copied out: nothing to wait for)
+#else
             if (feeds_group) {
+#endif
                 const int xl = t - last_sub;
                 if (xl >= out_depth && xl < wmb)
                     while (__hip_atomic_load(&sh.cons[g + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < xl - out_depth + 1) __builtin_amdgcn_s_sleep(1);
@@ -541,6 +635,14 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) k_debloc
                 }
             }
             WAVE_SYNC();
+#if MI_DB_BANDS
+            if (to_global) {
+                if (t - last_sub == wmb - 1 && lane < 24)
+                    __hip_atomic_store(xout + (wmb - 1) * 24 + lane,
+                                       (static_cast<unsigned long long>(epoch) << 32) | reinterpret_cast<const uint32_t *>(&out_ring[(wmb - 1) % out_depth])[lane],
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else
+#endif
             if (feeds_group && t - last_sub == wmb - 1 && lane == 0) // the last column of the group's last row is final without a right neighbour
                 __hip_atomic_store(&sh.prog[g], wmb, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }

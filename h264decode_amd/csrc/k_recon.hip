@@ -675,6 +675,30 @@ __device__ __forceinline__ void plane_params(FT T, FL L, int &a, int &b, int &c)
     c = N == 16 ? (5 * vv + 32) >> 6 : (34 * vv + 32) >> 6;
 }
 
+// Frame accesses of K3.  X = true (k_intra_x: a picture spread over several workgroups): the samples a macroblock leaves are
+// read by macroblocks of OTHER CUs in the same launch, so every store is an agent-scope (sc1, write-through) store and every
+// neighbour sample is read by an agent-scope load (past this CU's L1, which other CUs' stores never refresh).
+template <bool X>
+__device__ __forceinline__ int ld_px(const g8 *p) {
+    if (X) return static_cast<int>(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return static_cast<int>(*p);
+}
+template <bool X>
+__device__ __forceinline__ void st_px32(g8 *p, uint32_t v) {
+    if (X)
+        __hip_atomic_store(reinterpret_cast<g32 *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *reinterpret_cast<g32 *>(p) = v;
+}
+template <bool X>
+__device__ __forceinline__ void st_px16(g8 *p, uint16_t v) {
+    if (X)
+        __hip_atomic_store(reinterpret_cast<g16 *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *reinterpret_cast<g16 *>(p) = v;
+}
+
+template <bool X>
 __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_t *coef, const ScalingSet *sc, g8 *py, g8 *pcb, g8 *pcr, int W,
                          int mbx, int mby) {
     const int type = rec->type, av = rec->avail;
@@ -686,19 +710,19 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
     g8 *C0 = pcb + static_cast<size_t>(mby * 8) * Wc + mbx * 8, *C1 = pcr + static_cast<size_t>(mby * 8) * Wc + mbx * 8;
 #define CPL(c) ((c) ? C1 : C0) /* a select, not an indexed pointer array (which would live in scratch) */
     if (type == MBT_NONE) { // lost macroblock: a defined background instead of whatever the slot held before
-        *reinterpret_cast<g32 *>(Y + static_cast<size_t>(lane >> 2) * W + (lane & 3) * 4) = 0x80808080u;
-        if (lane < 32) *reinterpret_cast<g32 *>(CPL(lane >> 4) + static_cast<size_t>((lane >> 1) & 7) * Wc + (lane & 1) * 4) = 0x80808080u;
+        st_px32<X>(Y + static_cast<size_t>(lane >> 2) * W + (lane & 3) * 4, 0x80808080u);
+        if (lane < 32) st_px32<X>(CPL(lane >> 4) + static_cast<size_t>((lane >> 1) & 7) * Wc + (lane & 1) * 4, 0x80808080u);
         return;
     }
     if (type == MBT_IPCM) { // 8.3.5: samples were stored in the coefficient block
         const uint8_t *pcm = reinterpret_cast<const uint8_t *>(coef);
         { // 256 luma bytes: one dword per lane
             int j = lane >> 2, i = (lane & 3) * 4;
-            *reinterpret_cast<g32 *>(Y + static_cast<size_t>(j) * W + i) = *reinterpret_cast<const uint32_t *>(pcm + j * 16 + i);
+            st_px32<X>(Y + static_cast<size_t>(j) * W + i, *reinterpret_cast<const uint32_t *>(pcm + j * 16 + i));
         }
         if (lane < 32) {
             int c = lane >> 4, j = (lane >> 1) & 7, i = (lane & 1) * 4;
-            *reinterpret_cast<g32 *>(CPL(c) + static_cast<size_t>(j) * Wc + i) = *reinterpret_cast<const uint32_t *>(pcm + 256 + c * 64 + j * 8 + i);
+            st_px32<X>(CPL(c) + static_cast<size_t>(j) * Wc + i, *reinterpret_cast<const uint32_t *>(pcm + 256 + c * 64 + j * 8 + i));
         }
         return;
     }
@@ -706,18 +730,18 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
     if (lane < 25) { // row above: x = -1 .. 23
         int x = lane - 1;
         int ok = x < 0 ? a_tl : (x < 16 ? a_top : a_tr);
-        ws->tile[0][lane] = ok ? Y[-static_cast<ptrdiff_t>(W) + x] : static_cast<uint8_t>(128);
+        ws->tile[0][lane] = ok ? static_cast<uint8_t>(ld_px<X>(Y - static_cast<ptrdiff_t>(W) + x)) : static_cast<uint8_t>(128);
     } else if (lane >= 32 && lane < 48) {
         int y = lane - 32;
-        ws->tile[y + 1][0] = a_left ? Y[static_cast<size_t>(y) * W - 1] : static_cast<uint8_t>(128);
+        ws->tile[y + 1][0] = a_left ? static_cast<uint8_t>(ld_px<X>(Y + static_cast<size_t>(y) * W - 1)) : static_cast<uint8_t>(128);
     }
     if (lane < 18) { // chroma rows above: x = -1..7 for both planes
         int c = lane / 9, x = lane % 9 - 1;
         int ok = x < 0 ? a_tl : a_top;
-        ws->tile_c[c][0][x + 1] = ok ? CPL(c)[-static_cast<ptrdiff_t>(Wc) + x] : static_cast<uint8_t>(128);
+        ws->tile_c[c][0][x + 1] = ok ? static_cast<uint8_t>(ld_px<X>(CPL(c) - static_cast<ptrdiff_t>(Wc) + x)) : static_cast<uint8_t>(128);
     } else if (lane >= 32 && lane < 48) {
         int c = (lane - 32) >> 3, y = lane & 7;
-        ws->tile_c[c][y + 1][0] = a_left ? CPL(c)[static_cast<size_t>(y) * Wc - 1] : static_cast<uint8_t>(128);
+        ws->tile_c[c][y + 1][0] = a_left ? static_cast<uint8_t>(ld_px<X>(CPL(c) + static_cast<size_t>(y) * Wc - 1)) : static_cast<uint8_t>(128);
     }
     // ---- residual ----
     if ((rec->cbp & 0x3F) || type == MBT_I16x16)
@@ -758,7 +782,7 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
             v = clip255(v + ws->rb.luma[j * 16 + x]);
             packed |= static_cast<uint32_t>(v) << (8 * k);
         }
-        *reinterpret_cast<g32 *>(Y + static_cast<size_t>(j) * W + i0) = packed;
+        st_px32<X>(Y + static_cast<size_t>(j) * W + i0, packed);
     } else if (type == MBT_I4x4) {
         for (int idx = 0; idx < 16; idx++) {
             const int bx = (idx & 1) + 2 * ((idx >> 2) & 1), by = ((idx >> 1) & 1) + 2 * (idx >> 3);
@@ -856,7 +880,7 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
         const int j = lane >> 2, i0 = (lane & 3) * 4;
         const uint8_t *t = &ws->tile[j + 1][i0 + 1];
         uint32_t packed = t[0] | (t[1] << 8) | (t[2] << 16) | (static_cast<uint32_t>(t[3]) << 24);
-        *reinterpret_cast<g32 *>(Y + static_cast<size_t>(j) * W + i0) = packed;
+        st_px32<X>(Y + static_cast<size_t>(j) * W + i0, packed);
     }
     // ---- chroma (8.3.4) ----
     {
@@ -897,7 +921,7 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
             v = clip255(v + ws->rb.chroma[c][y * 8 + x]);
             packed |= static_cast<uint32_t>(v) << (8 * k);
         }
-        *reinterpret_cast<g16 *>(CPL(c) + static_cast<size_t>(y) * Wc + x0) = static_cast<uint16_t>(packed);
+        st_px16<X>(CPL(c) + static_cast<size_t>(y) * Wc + x0, static_cast<uint16_t>(packed));
     }
 }
 
@@ -957,8 +981,109 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
                     if (lane < MI_COEF_BLOCKS) reinterpret_cast<uint4 *>(ws->coef)[2 * lane] = c0, reinterpret_cast<uint4 *>(ws->coef)[2 * lane + 1] = c1;
                     WAVE_SYNC();
                 }
-                intra_mb(lane, ws, &ws->rec, ws->coef, &sh.sc, py, pcb, pcr, W, mbx, mby);
+                intra_mb<false>(lane, ws, &ws->rec, ws->coef, &sh.sc, py, pcb, pcr, W, mbx, mby);
                 // done: the release orders this wavefront's sample stores before the bit is cleared
+                if (lane == 0) __hip_atomic_fetch_and(&sh.pend[mby][c], ~(1ull << k), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+}
+
+// K3 spread over several workgroups per picture, for launches with fewer pictures than the chip has CUs: workgroup = a band of
+// consecutive macroblock rows, wavefront w of it owns rows r0 + w, r0 + w + nwaves, ...  Inside a band the LDS bit masks order
+// the rows as in k_intra.  The first row of a band waits for the intra macroblocks of the row above -- another workgroup's --
+// through one agent-scope flag word per macroblock column (tag = this launch's epoch), which the band above sets after it has
+// drained the macroblock's write-through sample stores.  A band waits only for the band above it and bands draw their
+// (picture, band) from a ticket counter in that order, so the workgroup being waited for is always running.
+extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab,
+                                                                            const MbRec *mbrec, const int16_t *coefs, uint32_t *xdone_, uint32_t epoch, int nbands,
+                                                                            uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus) {
+    __shared__ IntraShared sh;
+    __shared__ uint32_t s_ticket;
+    const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6, nthreads = static_cast<int>(blockDim.x), nwaves = nthreads >> 6;
+    if (tid == 0) s_ticket = atomicAdd(ticket, 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t tk = s_ticket, pic_i = tk / static_cast<uint32_t>(nbands);
+    const int band = static_cast<int>(tk - pic_i * static_cast<uint32_t>(nbands));
+    const PicDesc *pd = &pics[pic_list[pic_i]];
+    const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
+    const int r0 = band * hmb / nbands, r1 = (band + 1) * hmb / nbands;
+    if (r0 >= r1) return; // (pictures smaller than the launch's largest can leave bands empty)
+    const int W = wmb * 16, H = hmb * 16;
+    g8 *py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes);
+    g8 *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tab->scaling[pd->scaling_set]);
+        for (int i = tid; i < static_cast<int>(sizeof(ScalingSet) / 4); i += nthreads) reinterpret_cast<uint32_t *>(&sh.sc)[i] = src[i];
+    }
+    const int nchunks = (wmb + 63) >> 6;
+    const MbRec *recs = mbrec + pd->mb_base;
+    typedef __attribute__((address_space(1))) uint32_t gflag;
+    int pband = band - 1; // the band that owns row r0 - 1
+    while (pband > 0 && pband * hmb / nbands == (pband + 1) * hmb / nbands) pband--;
+    gflag *const xin = (gflag *)xdone_ + (static_cast<size_t>(pic_i) * nbands + (pband > 0 ? pband : 0)) * static_cast<size_t>(wmb_max);
+    gflag *const xout = (gflag *)xdone_ + (static_cast<size_t>(pic_i) * nbands + band) * static_cast<size_t>(wmb_max);
+    // ---- pass 1: intra masks of the band's rows and of the row above it (that one is never cleared here: it says which flags to wait for) ----
+    for (int mby = (r0 > 0 ? r0 - 1 : 0) + wave; mby < r1; mby += nwaves)
+        for (int c = 0; c < nchunks; c++) {
+            const int x = c * 64 + lane;
+            const int t = x < wmb ? recs[static_cast<size_t>(mby) * wmb + x].type : -1;
+            const unsigned long long m = __ballot(MB_IS_INTRA(t) || t == MBT_NONE);
+            if (lane == 0) sh.pend[mby][c] = m;
+        }
+    __syncthreads();
+    IntraWave *ws = &sh.w[wave];
+    for (int mby = r0 + wave; mby < r1; mby += nwaves) {
+        const MbRec *row = recs + static_cast<uint64_t>(mby) * wmb;
+        const bool publish = mby == r1 - 1 && r1 < hmb; // the band below waits for this row
+        for (int c = 0; c < nchunks; c++) {
+            unsigned long long mask = sh.pend[mby][c];
+            while (mask) {
+                const int k = __ffsll(static_cast<long long>(mask)) - 1;
+                mask &= mask - 1;
+                const int mbx = c * 64 + k;
+                if (lane < 32) reinterpret_cast<uint32_t *>(&ws->rec)[lane] = reinterpret_cast<const uint32_t *>(row + mbx)[lane];
+                WAVE_SYNC();
+                if (mby > 0) {
+                    const int xl = max(mbx - 1, 0), xr = min(mbx + 1, wmb - 1);
+                    const int c0 = xl >> 6, c1 = xr >> 6;
+                    const unsigned long long span = ((xr - xl + 1) >= 64 ? ~0ull : ((1ull << (xr - xl + 1)) - 1));
+                    const unsigned long long m0 = span << (xl & 63), m1 = c1 != c0 ? span >> (64 - (xl & 63)) : 0ull;
+                    if (mby > r0) {
+                        while ((__hip_atomic_load(&sh.pend[mby - 1][c0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & m0) ||
+                               (m1 && (__hip_atomic_load(&sh.pend[mby - 1][c1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & m1)))
+                            __builtin_amdgcn_s_sleep(1);
+                    } else { // another workgroup's row: lane i watches the flag of column xl + i if that macroblock is an intra one
+                        const int col = xl + lane;
+                        const bool need = lane < 3 && col <= xr && ((sh.pend[mby - 1][col >> 6] >> (col & 63)) & 1ull);
+                        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                        for (;;) {
+                            const uint32_t v = need ? __hip_atomic_load(xin + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
+                            if (__builtin_amdgcn_ballot_w64(v != epoch) == 0) break;
+                            __builtin_amdgcn_s_sleep(2);
+                            if (__builtin_amdgcn_s_memrealtime() - t_start > 400000000ull) { // 4 s: report instead of hanging the GPU
+                                if (lane == 0) atomicExch(xstatus, 0x3D000000u | static_cast<uint32_t>(mby));
+                                break;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (no instruction: the sample loads below stay below the poll)
+                    }
+                }
+                {
+                    const uint32_t cmask = ws->rec.coef_mask;
+                    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+                    if (lane < MI_COEF_BLOCKS && ((cmask >> lane) & 1)) {
+                        const uint4 *src = reinterpret_cast<const uint4 *>(coefs) + 2 * (static_cast<size_t>(ws->rec.coef_off) + __builtin_popcount(cmask & ((1u << lane) - 1u)));
+                        c0 = src[0], c1 = src[1];
+                    }
+                    if (lane < MI_COEF_BLOCKS) reinterpret_cast<uint4 *>(ws->coef)[2 * lane] = c0, reinterpret_cast<uint4 *>(ws->coef)[2 * lane + 1] = c1;
+                    WAVE_SYNC();
+                }
+                intra_mb<true>(lane, ws, &ws->rec, ws->coef, &sh.sc, py, pcb, pcr, W, mbx, mby);
+                if (publish) { // every sample store of this wavefront has left the CU before the flag does
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(xout + mbx, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 if (lane == 0) __hip_atomic_fetch_and(&sh.pend[mby][c], ~(1ull << k), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }

@@ -217,6 +217,13 @@ struct h264mi_decoder {
     std::vector<int> ev_kind;
     size_t ev_used = 0;
     double k_ms[5] = {0, 0, 0, 0, 0};
+    // Launches with fewer pictures than the chip has CUs spread a picture over several workgroups (k_intra_x, k_deblock_x,
+    // k_deblock_b_x): hand-off rings / flags in global memory, a ticket counter per kernel family, a give-up word
+    unsigned long long *d_xring = nullptr; // K5: x_cap * (Wmax / 16) * 24 granules
+    uint32_t *d_xdone = nullptr;           // K3: x_cap * (Wmax / 16) flag words
+    uint32_t *d_xctl = nullptr, *h_xstatus = nullptr; // [0] K5 tickets, [32] K3 tickets, [64] give-up code (128-byte lines of their own)
+    uint32_t x_epoch = 0, x_tk5 = 0, x_tk3 = 0;
+    int x_max_wgs = 256, x_cap = 512;
     PackDesc *h_pack = nullptr, *d_pack = nullptr; // K6 descriptor table
     size_t pack_cap = 0;
     std::vector<float> launch_ms[4]; // duration of every launch of the last profiled pass, per kernel
@@ -310,6 +317,10 @@ static void free_all(h264mi_decoder *d) {
     if (d->rec_stream) hipStreamDestroy(d->rec_stream);
     if (d->ev_user) hipEventDestroy(d->ev_user);
     if (d->d_colrec) hipFree(d->d_colrec);
+    if (d->d_xring) hipFree(d->d_xring);
+    if (d->d_xdone) hipFree(d->d_xdone);
+    if (d->d_xctl) hipFree(d->d_xctl);
+    if (d->h_xstatus) hipHostFree(d->h_xstatus);
     if (d->d_pools) hipFree(d->d_pools);
     if (d->h_pack) hipHostFree(d->h_pack);
     if (d->d_pack) hipFree(d->d_pack);
@@ -445,6 +456,18 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     // K5 keeps a whole macroblock row per in-flight group in dynamic LDS (up to 320 columns): opt in beyond 64 KB
     TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
     TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock_b), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
+    TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock_x), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
+    TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock_b_x), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
+    // cross-workgroup hand-off state of the banded kernels; H264MI_X_WGS = 0 switches them off, n: up to n workgroups per launch
+    if (const char *e = getenv("H264MI_X_WGS")) d->x_max_wgs = std::min(std::max(atoi(e), 0), d->x_cap);
+    TRY_ALLOC(hipMalloc(&d->d_xring, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long)));
+    TRY_ALLOC(hipMalloc(&d->d_xdone, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * sizeof(uint32_t)));
+    TRY_ALLOC(hipMalloc(&d->d_xctl, 3 * 128));
+    TRY_ALLOC(hipHostMalloc(&d->h_xstatus, sizeof(uint32_t)));
+    *d->h_xstatus = 0;
+    TRY_ALLOC(hipMemset(d->d_xring, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long)));
+    TRY_ALLOC(hipMemset(d->d_xdone, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * sizeof(uint32_t)));
+    TRY_ALLOC(hipMemset(d->d_xctl, 0, 3 * 128));
     build_tables(d->h_tables);
     d->h_pools.resize(S);
     for (int si = 0; si < S; si++) { // static per stream (kernels take the geometry of a picture from its PicDesc)
@@ -1324,6 +1347,16 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         HIP_TRY(hipStreamWaitEvent(d->rec_stream, d->ev_ent[set], 0));
     }
     hipStream_t rs = prof ? d->stream : d->rec_stream;
+    // tag of a banded launch's hand-off words: no earlier launch on the same rings has used it (the rings start out zero, and
+    // are zeroed again should the counter ever wrap)
+    auto next_epoch = [&]() {
+        if (++d->x_epoch == 0) {
+            hipMemsetAsync(d->d_xring, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long), rs);
+            hipMemsetAsync(d->d_xdone, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * sizeof(uint32_t), rs);
+            d->x_epoch = 1;
+        }
+        return d->x_epoch;
+    };
     for (size_t w = 0; w < g.waves.size(); w++) {
         const uint32_t n = static_cast<uint32_t>(g.waves[w].size()), ni = g.wave_p_n[w], nbp = g.wave_b_n[w], nnb = g.wave_nb_n[w];
         if (!n) continue;
@@ -1341,19 +1374,43 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
                                static_cast<int>(nb), g.d_bext, d->d_mv1[set]);
             mark(1);
         }
-        hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, g.d_lists + g.wave_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, coef);
+        // K3 / K5 keep a picture inside one workgroup when the launch has pictures enough to fill the chip; otherwise the
+        // banded kernels spread each picture over up to x_max_wgs / pictures workgroups (mi_intra_bands / mi_deblock_bands)
+        int nb3 = 1, nw3 = MI_INTRA_WAVES;
+        mi_intra_bands(static_cast<int>(n), g.hmb_max, d->x_max_wgs, &nb3, &nw3);
+        if (nb3 > 1) {
+            hipLaunchKernelGGL(k_intra_x, dim3(n * nb3), dim3(nw3 * 64), 0, rs, g.d_lists + g.wave_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, coef, d->d_xdone,
+                               next_epoch(), nb3, d->d_xctl + 32, d->x_tk3, g.wmb_max, d->d_xctl + 64);
+            d->x_tk3 += n * nb3;
+        } else
+            hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, g.d_lists + g.wave_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, coef);
         mark(2);
-        int dbw = 1, dbring = 16, dbring_last = 16, dbbufs = 1;
+        int dbw = 1, dbring = 16, dbring_last = 16, dbbufs = 1, nb5 = 1;
         if (nnb) {
-            mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
-            hipLaunchKernelGGL(k_deblock, dim3(nnb), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_nb_off[w], g.d_pics,
-                               d->d_pools, d->d_tables, mbrec, dbring, dbring_last, dbbufs);
+            mi_deblock_bands(static_cast<int>(nnb), g.wmb_max, g.hmb_max, d->x_max_wgs, &nb5, &dbw, &dbring);
+            if (nb5 > 1) {
+                hipLaunchKernelGGL(k_deblock_x, dim3(nnb * nb5), dim3(dbw * 64), mi_deblock_lds_bytes_banded(dbw, dbring), rs, g.d_lists + g.wave_nb_off[w], g.d_pics,
+                                   d->d_pools, d->d_tables, mbrec, dbring, 0, 1, d->d_xring, next_epoch(), nb5, d->d_xctl, d->x_tk5, g.wmb_max, d->d_xctl + 64);
+                d->x_tk5 += nnb * nb5;
+            } else {
+                mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
+                hipLaunchKernelGGL(k_deblock, dim3(nnb), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_nb_off[w], g.d_pics,
+                                   d->d_pools, d->d_tables, mbrec, dbring, dbring_last, dbbufs);
+            }
             mark(3);
         }
         if (nbp) {
-            mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs, MI_DEBLOCK_WAVE_BYTES_B);
-            hipLaunchKernelGGL(k_deblock_b, dim3(nbp), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs, MI_DEBLOCK_WAVE_BYTES_B), rs,
-                               g.d_lists + g.wave_b_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, dbring, dbring_last, dbbufs, d->d_mv1[set]);
+            mi_deblock_bands(static_cast<int>(nbp), g.wmb_max, g.hmb_max, d->x_max_wgs, &nb5, &dbw, &dbring);
+            if (nb5 > 1) {
+                hipLaunchKernelGGL(k_deblock_b_x, dim3(nbp * nb5), dim3(dbw * 64), mi_deblock_lds_bytes_banded(dbw, dbring, MI_DEBLOCK_WAVE_BYTES_B), rs,
+                                   g.d_lists + g.wave_b_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, dbring, 0, 1, d->d_mv1[set], d->d_xring, next_epoch(), nb5,
+                                   d->d_xctl, d->x_tk5, g.wmb_max, d->d_xctl + 64);
+                d->x_tk5 += nbp * nb5;
+            } else {
+                mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs, MI_DEBLOCK_WAVE_BYTES_B);
+                hipLaunchKernelGGL(k_deblock_b, dim3(nbp), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs, MI_DEBLOCK_WAVE_BYTES_B), rs,
+                                   g.d_lists + g.wave_b_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, dbring, dbring_last, dbbufs, d->d_mv1[set]);
+            }
             mark(3);
         }
     }
@@ -1362,6 +1419,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     d->pass++;
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(g.h_status, g.d_status, sizeof(uint32_t) * 8 * g.n_slices, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(d->h_xstatus, d->d_xctl + 64, sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipEventRecord(g.ev_done, d->stream)); // d->stream has waited for the reconstruction kernels: the batch's buffers are idle after this
     g.executed = true;
     d->ev_used = prof ? ei : 0;
@@ -1397,6 +1455,12 @@ extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
                     g.h_status[8 * i + 5] * 16e-6, g.h_status[8 * i + 6] * 16e-6, g.h_status[8 * i + 7] * 16e-6);
         fprintf(stderr, "last slice type %d bytes %u mbs %u us %.1f bins %u\n", g.h_slices[g.n_slices - 1].slice_type, g.h_slices[g.n_slices - 1].rbsp_size,
                 g.h_status[8 * (g.n_slices - 1) + 1], g.h_status[8 * (g.n_slices - 1) + 2] * 0.01, g.h_status[8 * (g.n_slices - 1) + 3]);
+    }
+    if (*d->h_xstatus) { // a banded kernel gave up waiting for its neighbour workgroup: the pictures of that launch are wrong
+        set_error("reconstruction hand-off timed out (code 0x%08x)", *d->h_xstatus);
+        *d->h_xstatus = 0;
+        HIP_TRY(hipMemset(d->d_xctl + 64, 0, sizeof(uint32_t)));
+        return H264MI_EDEVICE;
     }
     int result = H264MI_OK;
     for (int i = 0; i < g.n_slices; i++)
@@ -1624,3 +1688,15 @@ extern "C" int32_t h264mi_internal_deblock_plan(int32_t wmb, int32_t hmb, int32_
     return H264MI_OK;
 }
 
+
+// Not part of the public ABI: the banded launch plan of K5 / K3 (mi_deblock_bands, mi_intra_bands) for the CPU model test.
+extern "C" int32_t h264mi_internal_band_plan(int32_t n_pics, int32_t wmb, int32_t hmb, int32_t max_wgs, int32_t *k5_bands, int32_t *k5_waves, int32_t *k5_ring,
+                                             int64_t *k5_lds, int32_t *k3_bands, int32_t *k3_waves) {
+    if (!k5_bands || !k5_waves || !k5_ring || !k5_lds || !k3_bands || !k3_waves || n_pics < 1 || wmb < 1 || hmb < 1) return H264MI_EINVAL;
+    int nb = 1, nw = 1, ring = 1, b3 = 1, w3 = 1;
+    mi_deblock_bands(n_pics, wmb, hmb, max_wgs, &nb, &nw, &ring);
+    mi_intra_bands(n_pics, hmb, max_wgs, &b3, &w3);
+    *k5_bands = nb, *k5_waves = nw, *k5_ring = ring, *k5_lds = static_cast<int64_t>(mi_deblock_lds_bytes_banded(nw, ring, MI_DEBLOCK_WAVE_BYTES_B));
+    *k3_bands = b3, *k3_waves = w3;
+    return H264MI_OK;
+}

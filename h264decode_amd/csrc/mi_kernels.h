@@ -24,6 +24,11 @@ extern "C" __global__ void k_colsave(const uint32_t *pic_list, const PicDesc *pi
 // K3: intra macroblocks, one workgroup per picture, one wavefront per macroblock row (2-D wavefront order).
 extern "C" __global__ void k_intra(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
                                    const int16_t *coefs);
+// K3 spread over `nbands` workgroups per picture: grid = pictures * nbands, block = 64 * wavefronts per band (<= MI_INTRA_WAVES);
+// xdone: pictures * nbands * wmb_max flag words; epoch / ticket as for k_deblock_x
+extern "C" __global__ void k_intra_x(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
+                                     const int16_t *coefs, uint32_t *xdone, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max,
+                                     uint32_t *xstatus);
 // K5: in-loop deblocking, one workgroup per picture, one wavefront per group of 4 macroblock rows (up to 16 groups side by side).
 // block = 64 * nwaves, dynamic LDS = mi_deblock_lds_bytes(nwaves, ring, ring_last); (nwaves, ring, ring_last) from mi_deblock_plan()
 extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring,
@@ -31,6 +36,15 @@ extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pi
 // the same for pictures with B slices (k_deblock_b.hip): boundary strengths over two lists; plan with MI_DEBLOCK_WAVE_BYTES_B
 extern "C" __global__ void k_deblock_b(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring,
                                        int ring_last, int last_bufs, const MbMv1 *mbmv1);
+// K5 spread over `nbands` workgroups per picture (k_deblock_x.hip / k_deblock_b_x.hip): grid = pictures * nbands, block = 64 * (largest band's
+// group count), dynamic LDS = mi_deblock_lds_bytes_banded().  xring: pictures * nbands * wmb_max * 24 granules of 8 bytes; epoch: a value no
+// earlier launch on this ring has used (never 0); ticket / ticket_base: a counter that only ever grows and its value before this launch.
+extern "C" __global__ void k_deblock_x(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring,
+                                       int ring_last, int last_bufs, unsigned long long *xring, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base,
+                                       int wmb_max, uint32_t *xstatus);
+extern "C" __global__ void k_deblock_b_x(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring,
+                                         int ring_last, int last_bufs, const MbMv1 *mbmv1, unsigned long long *xring, uint32_t epoch, int nbands, uint32_t *ticket,
+                                         uint32_t ticket_base, int wmb_max, uint32_t *xstatus);
 #ifndef MI_DEBLOCK_MAX_WAVES
 #define MI_DEBLOCK_MAX_WAVES 12    /* 1024 threads; LDS: 6 KB of row state per wavefront + its hand-off ring */
 #endif
@@ -42,6 +56,22 @@ extern "C" __global__ void k_deblock_b(const uint32_t *pic_list, const PicDesc *
 static inline size_t mi_deblock_lds_bytes(int nwaves, int ring, int ring_last, int last_bufs, int wave_bytes = MI_DEBLOCK_WAVE_BYTES) {
     return MI_DEBLOCK_HDR_BYTES + static_cast<size_t>(nwaves) * wave_bytes +
            (static_cast<size_t>(nwaves - 1) * ring + static_cast<size_t>(ring_last) * last_bufs) * MI_DEBLOCK_SLOT_BYTES;
+}
+// banded builds: one ring region per wavefront (the last one stages what goes to the global ring) + the staging slot of the band above
+static inline size_t mi_deblock_lds_bytes_banded(int nwaves, int ring, int wave_bytes = MI_DEBLOCK_WAVE_BYTES) {
+    return MI_DEBLOCK_HDR_BYTES + static_cast<size_t>(nwaves) * wave_bytes + (static_cast<size_t>(nwaves) * ring + 1) * MI_DEBLOCK_SLOT_BYTES;
+}
+// How a launch of n_pics pictures of up to wmb x hmb macroblocks is spread over the chip.  nbands = 1: the one-workgroup kernels.
+// Otherwise every band is one round of at most MI_DEBLOCK_MAX_WAVES groups, and pictures * bands stays within `max_wgs`
+// workgroups (all of them can be resident at once; the ticket order makes the hand-off safe even if they are not).
+static inline void mi_deblock_bands(int n_pics, int wmb, int hmb, int max_wgs, int *nbands, int *nwaves, int *ring) {
+    const int ngroups = (hmb + 3) / 4;
+    int nb = n_pics > 0 ? max_wgs / n_pics : 1;
+    if (nb > ngroups) nb = ngroups;
+    if (nb < 2 || (ngroups + nb - 1) / nb > MI_DEBLOCK_MAX_WAVES) nb = 1;
+    *nbands = nb;
+    *nwaves = (ngroups + nb - 1) / nb;
+    *ring = wmb < 16 ? (wmb > 0 ? wmb : 1) : 16;
 }
 // Wavefront count and hand-off ring depths for pictures of wmb x hmb macroblocks.  Wavefront w runs the 4-row groups
 // w, w + nwaves, ...; group g hands its bottom rows to group g + 1 through the ring region of its wavefront.  A group may
@@ -78,3 +108,15 @@ extern "C" __global__ void k_pack(const PackDesc *descs, uint8_t *dst, int rows_
 #ifndef MI_INTRA_WAVES
 #define MI_INTRA_WAVES 12 /* 768 threads: 170 VGPRs per wavefront (16 wavefronts would cap them at 128 and spill) */
 #endif
+
+// K3 over several workgroups per picture: bands of about 4 macroblock rows, as many as keep pictures * bands within max_wgs;
+// nbands = 1: the one-workgroup kernel
+static inline void mi_intra_bands(int n_pics, int hmb, int max_wgs, int *nbands, int *nwaves) {
+    int nb = n_pics > 0 ? max_wgs / n_pics : 1;
+    const int want = (hmb + 3) / 4;
+    if (nb > want) nb = want;
+    if (nb < 2) nb = 1;
+    const int rows = (hmb + nb - 1) / nb;
+    *nbands = nb;
+    *nwaves = nb > 1 ? (rows < MI_INTRA_WAVES ? rows : MI_INTRA_WAVES) : MI_INTRA_WAVES;
+}

@@ -13,7 +13,31 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "stream_md5.json")
 
 
-def _decode_gpu(H, streams, w, h, frames, slices=1, crop=False):
+class _x_wgs:
+    """H264MI_X_WGS for the decoders created inside: 0 = a picture never leaves one workgroup in K3 / K5 (the kernels made
+    for launches that fill the chip), n = spread over up to n workgroups per launch (default 256)."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        self.old = os.environ.get("H264MI_X_WGS")
+        if self.n is not None:
+            os.environ["H264MI_X_WGS"] = str(self.n)
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("H264MI_X_WGS", None)
+        else:
+            os.environ["H264MI_X_WGS"] = self.old
+
+
+def _decode_gpu(H, streams, w, h, frames, slices=1, crop=False, x_wgs=None):
+    with _x_wgs(x_wgs):
+        return _decode_gpu_(H, streams, w, h, frames, slices, crop)
+
+
+def _decode_gpu_(H, streams, w, h, frames, slices=1, crop=False):
     W, Hc = (w + 15) // 16 * 16, (h + 15) // 16 * 16
     dec = H.Decoder(max_streams=len(streams), max_width=W, max_height=Hc, max_frames_per_batch=frames, max_slices_per_frame=max(1, slices),
                     max_bitstream_bytes=sum(len(s) for s in streams) * 2 + (1 << 20))
@@ -42,6 +66,17 @@ def test_gpu_matches_oracle_and_generator(name, H, sg, oracle_mod):
     assert np.array_equal(out[0], rec), "GPU != generator reconstruction"
     # picture order counts (8.2.1, incl. type 1 / type 2, non-reference pictures and the reset after MMCO 5)
     assert info.pocs[0] == list(oracle_mod.last_pocs) == list(sg.last_pocs()), "PicOrderCnt"
+
+
+def test_gpu_matrix_with_one_workgroup_per_picture(H, sg):
+    """The same matrix through k_intra / k_deblock / k_deblock_b (a picture inside ONE workgroup: what a launch that fills the
+    chip uses); the default for these one-stream batches is the banded kernels.  Also 512 workgroups per launch."""
+    for name in sorted(MATRIX):
+        kw = MATRIX[name]
+        stream, rec, _ = sg.encode(**kw)
+        for x in (0, 512):
+            out, _ = _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], kw.get("slices", 1), x_wgs=x)
+            assert np.array_equal(out[0], rec), (name, x)
 
 
 def test_gpu_golden_md5(H, sg):
@@ -144,9 +179,13 @@ def test_gpu_1080p_full_size_properties(H, sg, oracle_mod):
     streams = [sg.encode(**dict(kw, seed=3 + i))[0] for i in range(2)]
     out, info = _decode_gpu(H, streams, 1920, 1080, 4, crop=True)
     assert (info.width, info.height, info.coded_width, info.coded_height) == (1920, 1080, 1920, 1088)
+    refs = [oracle_mod.decode(streams[i], crop=True)[0] for i in range(2)]
     for i in range(2):
-        ref, _ = oracle_mod.decode(streams[i], crop=True)
-        assert np.array_equal(out[i], ref)
+        assert np.array_equal(out[i], refs[i])
+    for x in (0, 7, 64):  # one workgroup per picture; 3 bands of 6 row groups; 32 bands
+        out2, _ = _decode_gpu(H, streams, 1920, 1080, 4, crop=True, x_wgs=x)
+        for i in range(2):
+            assert np.array_equal(out2[i], refs[i]), x
     # device-side crop/pack kernel (K6) == host-side cropped read
     import torch
     dec = H.Decoder(max_streams=1, max_width=1920, max_height=1088, max_frames_per_batch=4)
@@ -168,8 +207,9 @@ def test_gpu_720p_cavlc_intra(H, sg, oracle_mod):
     """BASELINE configs[1]: 720p Baseline CAVLC I-frames."""
     kw = sg.recipe("C2", frames=2)
     stream, rec, _ = sg.encode(**kw)
-    out, _ = _decode_gpu(H, [stream], 1280, 720, 2)
-    assert np.array_equal(out[0], rec)
+    for x in (None, 0):
+        out, _ = _decode_gpu(H, [stream], 1280, 720, 2, x_wgs=x)
+        assert np.array_equal(out[0], rec), x
 
 
 def test_gpu_4k_high_8_slices(H, sg):
@@ -177,9 +217,10 @@ def test_gpu_4k_high_8_slices(H, sg):
     state, 34 deblocking row groups in 3 rounds, slice boundaries inside and across macroblock rows)."""
     kw = sg.recipe("C4", frames=3, idr_period=3)
     stream, rec, _ = sg.encode(**kw)
-    out, info = _decode_gpu(H, [stream], 3840, 2160, 3, slices=8)
-    assert (info.coded_width, info.coded_height) == (3840, 2160)
-    assert np.array_equal(out[0], rec)
+    for x in (None, 0, 3):  # 34 bands; one workgroup (3 rounds of 12 wavefronts); 3 bands of 12 wavefronts
+        out, info = _decode_gpu(H, [stream], 3840, 2160, 3, slices=8, x_wgs=x)
+        assert (info.coded_width, info.coded_height) == (3840, 2160)
+        assert np.array_equal(out[0], rec), x
 
 
 def test_gpu_rejects_out_of_scope_profile(H):
@@ -223,17 +264,21 @@ def test_gpu_c5_share_32_distinct_1080p_streams(H, sg):
         gen = list(ex.map(lambda kw: sg.encode(**kw), kws))
     streams = [g[0] for g in gen]
     assert len(set(hashlib.md5(s).hexdigest() for s in streams)) == S, "streams are not distinct"
-    dec = H.Decoder(max_streams=S, max_width=1920, max_height=1088, max_frames_per_batch=F, max_slices_per_frame=1,
-                    max_bitstream_bytes=int(sum(len(s) for s in streams) * 1.1) + (1 << 20))
-    info = dec.decode(streams)
-    assert info.n_frames == S * F
-    fsz = 1920 * 1088 * 3 // 2
-    for si in range(S):
-        assert dec.frame_count(si) == F
-        for f in range(F):
-            got = dec.read_frame(si, f, crop=False)[:fsz]
-            assert np.array_equal(got, gen[si][1][f]), "stream %d frame %d differs from the generator's reconstruction" % (si, f)
-    dec.close()
+    for x in (None, 0):  # 8 bands per picture (the default for 32 pictures per launch), then one workgroup per picture
+        with _x_wgs(x):
+            dec = H.Decoder(max_streams=S, max_width=1920, max_height=1088, max_frames_per_batch=F, max_slices_per_frame=1,
+                            max_bitstream_bytes=int(sum(len(s) for s in streams) * 1.1) + (1 << 20))
+        dec.prepare(streams)
+        for _ in range(3 if x is None else 1):  # pipelined passes: the entropy kernels of the next pass run beside the banded kernels (uneven load)
+            dec.execute()
+        dec.sync()
+        fsz = 1920 * 1088 * 3 // 2
+        for si in range(S):
+            assert dec.frame_count(si) == F
+            for f in range(F):
+                got = dec.read_frame(si, f, crop=False)[:fsz]
+                assert np.array_equal(got, gen[si][1][f]), "stream %d frame %d differs from the generator's reconstruction (x_wgs %s)" % (si, f, x)
+        dec.close()
 
 
 def _poison(H, dec):
