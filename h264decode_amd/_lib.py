@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _HEADER = os.path.join(_HERE, "..", "include", "h264mi.h")
-_LIBPATH = os.path.join(_HERE, "libh264mi.so")
+_LIBPATH = os.environ.get("H264MI_LIB") or os.path.join(_HERE, "libh264mi.so")  # H264MI_LIB: a diagnostic build of the same library (csrc/Makefile)
 
 _CT = {"int32_t": ctypes.c_int32, "uint32_t": ctypes.c_uint32, "int64_t": ctypes.c_int64, "uint8_t": ctypes.c_uint8,
        "double": ctypes.c_double, "void": None}

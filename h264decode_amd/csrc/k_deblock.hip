@@ -100,6 +100,13 @@ typedef __attribute__((address_space(1))) v2u g_uint2;
 // keeps lane-dependent values from being hoisted out of the step loop (dozens of loop-invariant addresses would otherwise
 // live in registers for the whole kernel)
 #define OPAQUE(x) asm volatile("" : "+v"(x))
+// diagnostic build (-DMI_DB_STATS, banded kernels only): shader clocks per phase of the step loop, summed over one wavefront's
+// steps, added to xstatus[8 + phase] by the wavefront of group 0 (tools/deblock_phase_probe.py)
+#if defined(MI_DB_STATS) && MI_DB_BANDS
+#define STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += static_cast<uint32_t>(now_ - st_last); st_last = now_; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 __device__ __forceinline__ int adiff(int a, int b) { // |a - b| for operands in 0..65535 (one v_sad_u16)
     return static_cast<int>(__builtin_amdgcn_sad_u16(static_cast<uint32_t>(a), static_cast<uint32_t>(b), 0u));
@@ -362,7 +369,12 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             while (__hip_atomic_load(&sh.cons[g - reuse + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < wmb) __builtin_amdgcn_s_sleep(1);
 #endif
         const int nsteps = wmb + 3;
+#if defined(MI_DB_STATS) && MI_DB_BANDS
+        uint32_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
         for (int t = 0; t < nsteps; t++) {
+            STAMP(5); // loop control + whatever the compiler moved across the step boundary
             int lane = lane_v;
             OPAQUE(lane);
             const int sub = lane >> 4, li = lane & 15;
@@ -386,8 +398,10 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             if (active && (li & 7) < 4) reinterpret_cast<v4u *>(li < 8 ? vq : vtop)[li & 3] = pre_mv1;
 #endif
             WAVE_SYNC();
+            STAMP(6);
             if (active && (mbx & 3) == 3) prefetch_group(mbx + 1); // the input registers of this sub-row are free again
             prefetch_rec(mbx + 1);
+            STAMP(7);
             const MbRec *ml = nullptr, *mt = nullptr;
             int dbf = 1;
             if (active) {
@@ -397,6 +411,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                     if (ml && ml->slice_in_pic != mq->slice_in_pic) ml = nullptr;
                     if (mt && mt->slice_in_pic != mq->slice_in_pic) mt = nullptr;
                 }
+#if MI_DB_B
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int idx = li + 16 * h, dir = idx >> 4, e = (idx >> 2) & 3, k = idx & 3;
@@ -406,24 +421,75 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                         const MbRec *mp = e == 0 ? mn : mq;
                         int qb = dir == 0 ? k * 4 + e : e * 4 + k;
                         int pb = dir == 0 ? k * 4 + (e == 0 ? 3 : e - 1) : (e == 0 ? 3 : e - 1) * 4 + k;
-#if MI_DB_B
                         bs = edge_bs_b(mp, e == 0 ? (dir == 0 ? vleft : vtop) : vq, pb, mq, vq, qb, e == 0);
-#else
-                        bs = edge_bs(mp, pb, mq, qb, e == 0);
-#endif
                     }
                     ss->bs[dir][e][k] = static_cast<uint8_t>(bs);
                 }
+#else
+                // Branch-free (8.7.2.1, one list): every operand of both strengths of this lane is fetched from the LDS records up
+                // front -- independent reads, one wait -- and the decision is a chain of selects.  (With early returns the reads
+                // of types, nzmasks, frame slots and vectors were five dependent LDS round trips per strength.)
+                const int e = li >> 2, k = li & 3;
+                const bool mb_edge = e == 0;
+                const int qb0 = k * 4 + e, qb1 = li;                          // q block of the vertical / horizontal edge segment
+                const int pb0 = mb_edge ? k * 4 + 3 : qb0 - 1, pb1 = mb_edge ? 12 + k : qb1 - 4;
+                const MbRec *mp0 = mb_edge && ml ? ml : mq, *mp1 = mb_edge && mt ? mt : mq; // (no neighbour: any record, the result is masked)
+                const int tq = mq->type, t8 = mq->t8x8, nzq = mq->nzmask;
+                const int tp0 = mp0->type, tp1 = mp1->type, nzp0 = mp0->nzmask, nzp1 = mp1->nzmask;
+#define Q8(b) ((((b) >> 3) << 1) | (((b) & 3) >> 1))
+                const int rq0 = mq->refslot[Q8(qb0)], rq1 = mq->refslot[Q8(qb1)], rp0 = mp0->refslot[Q8(pb0)], rp1 = mp1->refslot[Q8(pb1)];
+#undef Q8
+                const int vq0x = mq->mv[qb0][0], vq0y = mq->mv[qb0][1], vq1x = mq->mv[qb1][0], vq1y = mq->mv[qb1][1];
+                const int vp0x = mp0->mv[pb0][0], vp0y = mp0->mv[pb0][1], vp1x = mp1->mv[pb1][0], vp1y = mp1->mv[pb1][1];
+                const bool ok = dbf != 1 && !((e & 1) && t8);
+                const bool ok0 = ok && !(mb_edge && !ml), ok1 = ok && !(mb_edge && !mt);
+                const bool iq = MB_IS_INTRA(tq);
+                const int bs_i = mb_edge ? 4 : 3;
+                const bool far0 = rp0 != rq0 || abs(vp0x - vq0x) >= 4 || abs(vp0y - vq0y) >= 4;
+                const bool far1 = rp1 != rq1 || abs(vp1x - vq1x) >= 4 || abs(vp1y - vq1y) >= 4;
+                int bs0 = (iq || MB_IS_INTRA(tp0)) ? bs_i : ((((nzp0 >> pb0) | (nzq >> qb0)) & 1) ? 2 : (far0 ? 1 : 0));
+                int bs1 = (iq || MB_IS_INTRA(tp1)) ? bs_i : ((((nzp1 >> pb1) | (nzq >> qb1)) & 1) ? 2 : (far1 ? 1 : 0));
+                ss->bs[0][e][k] = static_cast<uint8_t>(ok0 ? bs0 : 0);
+                ss->bs[1][e][k] = static_cast<uint8_t>(ok1 ? bs1 : 0);
+#endif
             }
+            STAMP(8);
             WAVE_SYNC();
-            // filter parameters of this macroblock (8.7.2.2)
-            int aoff = 0, boff = 0, qpq = 0, qpc_q = 0;
-            if (active) aoff = mq->alpha_off, boff = mq->beta_off, qpq = mq->qp, qpc_q = mq->qpc[li >> 3];
+            STAMP(9);
+            // Filter parameters of this macroblock (8.7.2.2), ALL of them here: the strengths of this lane's four edges in both
+            // directions, and alpha / beta / tC0 of the luma and the chroma edges, packed into bytes.  The table reads are
+            // independent of each other -- one LDS round trip for the whole step instead of one per edge in the passes below.
+            // P*[0] luma, [1] chroma: bs = four strengths (edge e in byte e), ab = alpha(e0) | beta(e0) << 8 | alpha(inner) << 16 |
+            // beta(inner) << 24, tc = tC0 per edge.  V: vertical edges, H: horizontal edges.
+            uint32_t Vbs[2] = {0, 0}, Vab[2] = {0, 0}, Vtc[2] = {0, 0}, Hbs[2] = {0, 0}, Hab[2] = {0, 0}, Htc[2] = {0, 0};
+            if (active) {
+                const int aoff = mq->alpha_off, boff = mq->beta_off, cpl_ = li >> 3;
+                const int qpq = mq->qp, qpc_q = mq->qpc[cpl_];
+                const MbRec *mlq = ml ? ml : mq, *mtq = mt ? mt : mq; // no neighbour: the edge's strength is 0 anyway
+                const int qpl = mlq->qp, qpt = mtq->qp, qpcl = mlq->qpc[cpl_], qpct = mtq->qpc[cpl_];
+                const v4u bv = *reinterpret_cast<const v4u *>(ss->bs[0][0]), bh = *reinterpret_cast<const v4u *>(ss->bs[1][0]);
+                auto pick = [](v4u w, int sh8, bool chroma) { // this lane's segment of edges 0..3 (chroma: luma edges 0 and 2 only)
+                    const uint32_t b0 = (w.x >> sh8) & 255u, b1 = (w.y >> sh8) & 255u, b2 = (w.z >> sh8) & 255u, b3 = (w.w >> sh8) & 255u;
+                    return chroma ? (b0 | (b2 << 16)) : (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
+                };
+                auto tables = [&](uint32_t bsp, int qpn, int qp, uint32_t &ab, uint32_t &tc) {
+                    const int qpe = (qpn + qp + 1) >> 1;
+                    const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff), ia1 = clip3(0, 51, qp + aoff), ib1 = clip3(0, 51, qp + boff);
+                    ab = sh.alpha[ia0] | (static_cast<uint32_t>(sh.beta[ib0]) << 8) | (static_cast<uint32_t>(sh.alpha[ia1]) << 16) | (static_cast<uint32_t>(sh.beta[ib1]) << 24);
+                    tc = sh.tc0[ia0][bsp & 3u] | (static_cast<uint32_t>(sh.tc0[ia1][(bsp >> 8) & 3u]) << 8) | (static_cast<uint32_t>(sh.tc0[ia1][(bsp >> 16) & 3u]) << 16) |
+                         (static_cast<uint32_t>(sh.tc0[ia1][(bsp >> 24) & 3u]) << 24);
+                };
+                Vbs[0] = pick(bv, 8 * (li >> 2), false), Vbs[1] = pick(bv, 8 * ((li & 7) >> 1), true);
+                Hbs[0] = pick(bh, 8 * (li >> 2), false), Hbs[1] = pick(bh, 8 * ((li & 7) >> 1), true);
+                tables(Vbs[0], qpl, qpq, Vab[0], Vtc[0]);
+                tables(Vbs[1], qpcl, qpc_q, Vab[1], Vtc[1]);
+                tables(Hbs[0], qpt, qpq, Hab[0], Htc[0]);
+                tables(Hbs[1], qpct, qpc_q, Hab[1], Htc[1]);
+            }
+            STAMP(0);
             // ---- 2. vertical edges: lane li = luma row li, then chroma (plane li >> 3, row li & 7) ----
             {
-                const uint32_t b0w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[0][0]) : 0u, b1w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[0][1]) : 0u;
-                const uint32_t b2w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[0][2]) : 0u, b3w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[0][3]) : 0u;
-                const bool any = (b0w | b1w | b2w | b3w) != 0;
+                const bool any = (Vbs[0] | Vbs[1]) != 0;
                 uint32_t w0 = 0, w1 = in_y.x, w2 = in_y.y, w3 = in_y.z, w4 = in_y.w; // w0 = columns -4..-1
                 uint32_t c0 = 0, c1 = in_c.x, c2 = in_c.y;
                 if (active && mbx > 0) {
@@ -438,16 +504,12 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                         unpack4(w2, px[8], px[9], px[10], px[11]);
                         unpack4(w3, px[12], px[13], px[14], px[15]);
                         unpack4(w4, px[16], px[17], px[18], px[19]);
-                        const int sh8 = 8 * (li >> 2);
-                        const int bs0 = (b0w >> sh8) & 255, bs1 = (b1w >> sh8) & 255, bs2 = (b2w >> sh8) & 255, bs3 = (b3w >> sh8) & 255;
-                        const int qpe = ml ? (ml->qp + qpq + 1) >> 1 : qpq;
-                        const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
-                        const int ia1 = clip3(0, 51, qpq + aoff), ib1 = clip3(0, 51, qpq + boff);
-                        const int a1 = sh.alpha[ia1], be1 = sh.beta[ib1];
-                        filter_edge<4, false>(px, bs0, sh.alpha[ia0], sh.beta[ib0], sh.tc0[ia0][bs0 & 3]);
-                        filter_edge<8, false>(px, bs1, a1, be1, sh.tc0[ia1][bs1 & 3]);
-                        filter_edge<12, false>(px, bs2, a1, be1, sh.tc0[ia1][bs2 & 3]);
-                        filter_edge<16, false>(px, bs3, a1, be1, sh.tc0[ia1][bs3 & 3]);
+                        const uint32_t bsp = Vbs[0], ab = Vab[0], tc = Vtc[0];
+                        const int a1 = static_cast<int>((ab >> 16) & 255u), be1 = static_cast<int>(ab >> 24);
+                        filter_edge<4, false>(px, static_cast<int>(bsp & 255u), static_cast<int>(ab & 255u), static_cast<int>((ab >> 8) & 255u), static_cast<int>(tc & 255u));
+                        filter_edge<8, false>(px, static_cast<int>((bsp >> 8) & 255u), a1, be1, static_cast<int>((tc >> 8) & 255u));
+                        filter_edge<12, false>(px, static_cast<int>((bsp >> 16) & 255u), a1, be1, static_cast<int>((tc >> 16) & 255u));
+                        filter_edge<16, false>(px, static_cast<int>(bsp >> 24), a1, be1, static_cast<int>(tc >> 24));
                         w0 = pack4(px[0], px[1], px[2], px[3]), w1 = pack4(px[4], px[5], px[6], px[7]), w2 = pack4(px[8], px[9], px[10], px[11]);
                         w3 = pack4(px[12], px[13], px[14], px[15]), w4 = pack4(px[16], px[17], px[18], px[19]);
                     }
@@ -457,13 +519,9 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                         unpack4(c0, px[0], px[1], px[2], px[3]);
                         unpack4(c1, px[4], px[5], px[6], px[7]);
                         unpack4(c2, px[8], px[9], px[10], px[11]);
-                        const int sh8 = 8 * ((li & 7) >> 1);
-                        const int bs0 = (b0w >> sh8) & 255, bs2 = (b2w >> sh8) & 255;
-                        const int qpe = ml ? (ml->qpc[li >> 3] + qpc_q + 1) >> 1 : qpc_q;
-                        const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
-                        const int ia1 = clip3(0, 51, qpc_q + aoff), ib1 = clip3(0, 51, qpc_q + boff);
-                        filter_edge<4, true>(px, bs0, sh.alpha[ia0], sh.beta[ib0], sh.tc0[ia0][bs0 & 3]);
-                        filter_edge<8, true>(px, bs2, sh.alpha[ia1], sh.beta[ib1], sh.tc0[ia1][bs2 & 3]);
+                        const uint32_t bsp = Vbs[1], ab = Vab[1], tc = Vtc[1];
+                        filter_edge<4, true>(px, static_cast<int>(bsp & 255u), static_cast<int>(ab & 255u), static_cast<int>((ab >> 8) & 255u), static_cast<int>(tc & 255u));
+                        filter_edge<8, true>(px, static_cast<int>((bsp >> 16) & 255u), static_cast<int>((ab >> 16) & 255u), static_cast<int>(ab >> 24), static_cast<int>((tc >> 16) & 255u));
                         c0 = pack4(px[0], px[1], px[2], px[3]), c1 = pack4(px[4], px[5], px[6], px[7]), c2 = pack4(px[8], px[9], px[10], px[11]);
                     }
                 }
@@ -476,6 +534,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                 }
             }
             WAVE_SYNC();
+            STAMP(1);
             // ---- 3. hand-off of the rows above ----
             // 3a. columns 12..15 of the previous macroblock are final now: complete its bottom rows where they wait
             //     (the buffer for the sub-row below, or the ring slot for the group below), then publish the column
@@ -540,27 +599,22 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             WAVE_SYNC();
             if (g > 0 && t < wmb && lane == 0) // the hand-off slot of column t has been copied: the group above may reuse it
                 __hip_atomic_store(&sh.cons[g], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            STAMP(2);
             // ---- 4. horizontal edges: lane li = luma column li, then chroma (plane li >> 3, column li & 7) ----
             {
-                const uint32_t b0w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[1][0]) : 0u, b1w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[1][1]) : 0u;
-                const uint32_t b2w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[1][2]) : 0u, b3w = active ? *reinterpret_cast<const uint32_t *>(ss->bs[1][3]) : 0u;
-                const bool any = (b0w | b1w | b2w | b3w) != 0;
+                const bool any = (Hbs[0] | Hbs[1]) != 0;
                 if (__builtin_amdgcn_ballot_w64(any) != 0) {
                     if (any) {
                         {
                             int px[20];
 #pragma unroll
                             for (int r = 0; r < 20; r++) px[r] = ss->y[r][16 + li];
-                            const int sh8 = 8 * (li >> 2);
-                            const int bs0 = (b0w >> sh8) & 255, bs1 = (b1w >> sh8) & 255, bs2 = (b2w >> sh8) & 255, bs3 = (b3w >> sh8) & 255;
-                            const int qpe = mt ? (mt->qp + qpq + 1) >> 1 : qpq;
-                            const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
-                            const int ia1 = clip3(0, 51, qpq + aoff), ib1 = clip3(0, 51, qpq + boff);
-                            const int a1 = sh.alpha[ia1], be1 = sh.beta[ib1];
-                            filter_edge<4, false>(px, bs0, sh.alpha[ia0], sh.beta[ib0], sh.tc0[ia0][bs0 & 3]);
-                            filter_edge<8, false>(px, bs1, a1, be1, sh.tc0[ia1][bs1 & 3]);
-                            filter_edge<12, false>(px, bs2, a1, be1, sh.tc0[ia1][bs2 & 3]);
-                            filter_edge<16, false>(px, bs3, a1, be1, sh.tc0[ia1][bs3 & 3]);
+                            const uint32_t bsp = Hbs[0], ab = Hab[0], tc = Htc[0];
+                            const int a1 = static_cast<int>((ab >> 16) & 255u), be1 = static_cast<int>(ab >> 24);
+                            filter_edge<4, false>(px, static_cast<int>(bsp & 255u), static_cast<int>(ab & 255u), static_cast<int>((ab >> 8) & 255u), static_cast<int>(tc & 255u));
+                            filter_edge<8, false>(px, static_cast<int>((bsp >> 8) & 255u), a1, be1, static_cast<int>((tc >> 8) & 255u));
+                            filter_edge<12, false>(px, static_cast<int>((bsp >> 16) & 255u), a1, be1, static_cast<int>((tc >> 16) & 255u));
+                            filter_edge<16, false>(px, static_cast<int>(bsp >> 24), a1, be1, static_cast<int>(tc >> 24));
 #pragma unroll
                             for (int r = 1; r < 19; r++) ss->y[r][16 + li] = static_cast<uint8_t>(px[r]);
                         }
@@ -571,13 +625,9 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                             px[0] = px[1] = 0;
 #pragma unroll
                             for (int r = 2; r < 12; r++) px[r] = ss->c[cpl][r][8 + i];
-                            const int sh8 = 8 * (i >> 1);
-                            const int bs0 = (b0w >> sh8) & 255, bs2 = (b2w >> sh8) & 255;
-                            const int qpe = mt ? (mt->qpc[cpl] + qpc_q + 1) >> 1 : qpc_q;
-                            const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff);
-                            const int ia1 = clip3(0, 51, qpc_q + aoff), ib1 = clip3(0, 51, qpc_q + boff);
-                            filter_edge<4, true>(px, bs0, sh.alpha[ia0], sh.beta[ib0], sh.tc0[ia0][bs0 & 3]);
-                            filter_edge<8, true>(px, bs2, sh.alpha[ia1], sh.beta[ib1], sh.tc0[ia1][bs2 & 3]);
+                            const uint32_t bsp = Hbs[1], ab = Hab[1], tc = Htc[1];
+                            filter_edge<4, true>(px, static_cast<int>(bsp & 255u), static_cast<int>(ab & 255u), static_cast<int>((ab >> 8) & 255u), static_cast<int>(tc & 255u));
+                            filter_edge<8, true>(px, static_cast<int>((bsp >> 16) & 255u), static_cast<int>((ab >> 16) & 255u), static_cast<int>(ab >> 24), static_cast<int>((tc >> 16) & 255u));
 #pragma unroll
                             for (int r = 3; r < 9; r++) ss->c[cpl][r][8 + i] = static_cast<uint8_t>(px[r]);
                         }
@@ -585,6 +635,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                 }
             }
             WAVE_SYNC();
+            STAMP(3);
             // ---- 5. results ----
             // Back-pressure first: the ring slot the group's last row is about to overwrite held column xl - depth of this
             // group; the group below must have consumed it.
@@ -645,6 +696,11 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
 #endif
             if (feeds_group && t - last_sub == wmb - 1 && lane == 0) // the last column of the group's last row is final without a right neighbour
                 __hip_atomic_store(&sh.prog[g], wmb, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            STAMP(4);
         }
+#if defined(MI_DB_STATS) && MI_DB_BANDS
+        if (g == 0 && lane_v == 0)
+            for (int k = 0; k < 12; k++) atomicAdd(xstatus + 8 + k, st_acc[k]);
+#endif
     }
 }

@@ -1689,6 +1689,16 @@ extern "C" int32_t h264mi_internal_deblock_plan(int32_t wmb, int32_t hmb, int32_
 }
 
 
+// Not part of the public ABI: the phase clocks a -DMI_DB_STATS build of the banded deblocking kernels leaves (zero otherwise); reading clears them
+extern "C" int32_t h264mi_internal_deblock_phase_clocks(h264mi_decoder *d, uint32_t out[12]) {
+    if (!d || !out) return H264MI_EINVAL;
+    GUARD(d);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d->d_xctl + 64 + 8, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(d->d_xctl + 64 + 8, 0, 12 * sizeof(uint32_t)));
+    return H264MI_OK;
+}
+
 // Not part of the public ABI: the banded launch plan of K5 / K3 (mi_deblock_bands, mi_intra_bands) for the CPU model test.
 extern "C" int32_t h264mi_internal_band_plan(int32_t n_pics, int32_t wmb, int32_t hmb, int32_t max_wgs, int32_t *k5_bands, int32_t *k5_waves, int32_t *k5_ring,
                                              int64_t *k5_lds, int32_t *k3_bands, int32_t *k3_waves) {
