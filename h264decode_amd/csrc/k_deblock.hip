@@ -31,13 +31,11 @@
 #include <hip/hip_runtime.h>
 #include "mi_kernels.h"
 
-// Compiled twice: as k_deblock, and from k_deblock_b.hip (MI_DB_B = 1) as k_deblock_b for pictures with B slices, whose
-// boundary strengths compare two vectors and two reference pictures per block (8.7.2.1): that build also stages the
-// list-1 vectors (MbMv1) of the current / left / upper macroblock.
-#ifndef MI_DB_B
-#define MI_DB_B 0
-#endif
-// Third / fourth build (k_deblock_x.hip, k_deblock_b_x.hip: MI_DB_BANDS = 1): a picture is spread over several workgroups
+// Boundary strengths and alpha / beta / tC0 do not depend on samples: k_dbprep (bottom of this file) works them out for every
+// macroblock of a batch in one fully parallel launch and leaves an 80-byte DbPrm per macroblock; the kernels below -- a serial
+// dependency chain per picture -- only pick their bytes out of it.  (Pictures with B slices differ in the strengths only, so
+// they need no kernel of their own any more.)
+// Second build (k_deblock_x.hip: MI_DB_BANDS = 1): a picture is spread over several workgroups
 // ("bands" of consecutive row groups, one wavefront per group, one round) for launches with fewer pictures than the chip
 // has CUs.  Inside a band nothing changes (LDS rings, workgroup-scope counters).  Between bands the bottom rows travel
 // through a ring in global memory as 8-byte {epoch, data} granules written by ONE agent-scope (sc1) store each and read
@@ -60,11 +58,7 @@ struct DbSub { // state of one of the 4 macroblock rows a wavefront works on
     alignas(16) uint8_t y[20][32];
     // chroma tiles, rows -4..7 (-2.. used): bytes 4..7 = columns -4..-1, bytes 8..15 = columns 0..7
     alignas(16) uint8_t c[2][12][16];
-    MbRec rec[3];        // cur / left alternate in [0],[1]; [2] = macroblock above
-#if MI_DB_B
-    MbMv1 mv1[3];        // their list-1 vectors
-#endif
-    uint8_t bs[2][4][4]; // [dir][edge][segment]
+    DbPrm prm;           // the current macroblock's strengths and filter parameters (k_dbprep)
     // rows 12..15 (chroma 6..7) of the macroblock this sub-row finished in the previous step, for the sub-row below
     alignas(16) uint8_t bot_y[4][16];
     alignas(8) uint8_t bot_c[2][2][8];
@@ -77,12 +71,11 @@ struct GroupSlot { // rows 12..15 of one macroblock column handed to the group b
     alignas(8) uint8_t c[2][2][8];
 };
 struct DbShared { // followed in dynamic LDS by DbWave[nwaves] and the hand-off rings
-    uint8_t alpha[52], beta[52], tc0[52][4];
     int prog[96]; // per group: macroblock columns of its LAST row that are final (rows 12..15 complete)
     int cons[96]; // per group: hand-off slots consumed by its FIRST row
     uint32_t ticket; // banded builds: which (picture, band) this workgroup drew
 };
-static_assert(sizeof(DbShared) <= MI_DEBLOCK_HDR_BYTES && sizeof(DbWave) == (MI_DB_B ? MI_DEBLOCK_WAVE_BYTES_B : MI_DEBLOCK_WAVE_BYTES) && sizeof(GroupSlot) == MI_DEBLOCK_SLOT_BYTES,
+static_assert(sizeof(DbShared) <= MI_DEBLOCK_HDR_BYTES && sizeof(DbWave) == MI_DEBLOCK_WAVE_BYTES && sizeof(GroupSlot) == MI_DEBLOCK_SLOT_BYTES,
               "LDS layout constants");
 
 // Global memory through an explicit address-space-1 pointer with a wave-uniform base and a 32-bit per-lane offset: the
@@ -162,40 +155,6 @@ __device__ __forceinline__ void filter_edge(int (&px)[N], int bs, int alpha, int
     }
 }
 
-// 8.7.2.1 for frame macroblocks of I/P pictures
-__device__ __forceinline__ int edge_bs(const MbRec *mp, int pb, const MbRec *mq, int qb, bool mb_edge) {
-    if (MB_IS_INTRA(mp->type) || MB_IS_INTRA(mq->type)) return mb_edge ? 4 : 3;
-    if (((mp->nzmask >> pb) & 1) || ((mq->nzmask >> qb) & 1)) return 2;
-    int rp = mp->refslot[((pb >> 3) << 1) | ((pb & 3) >> 1)], rq = mq->refslot[((qb >> 3) << 1) | ((qb & 3) >> 1)];
-    if (rp != rq) return 1;
-    if (abs(mp->mv[pb][0] - mq->mv[qb][0]) >= 4 || abs(mp->mv[pb][1] - mq->mv[qb][1]) >= 4) return 1;
-    return 0;
-}
-
-#if MI_DB_B
-// 8.7.2.1 with two lists: the blocks differ if they use different reference PICTURES (frame slots; the list a picture
-// comes from does not matter) or a different number of vectors, or if the vectors that belong together differ by >= 4
-__device__ __forceinline__ bool mv_far(const int16_t *a, const int16_t *b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
-__device__ __forceinline__ int edge_bs_b(const MbRec *mp, const MbMv1 *vp, int pb, const MbRec *mq, const MbMv1 *vq, int qb, bool mb_edge) {
-    if (MB_IS_INTRA(mp->type) || MB_IS_INTRA(mq->type)) return mb_edge ? 4 : 3;
-    if (((mp->nzmask >> pb) & 1) || ((mq->nzmask >> qb) & 1)) return 2;
-    const int p8 = ((pb >> 3) << 1) | ((pb & 3) >> 1), q8 = ((qb >> 3) << 1) | ((qb & 3) >> 1);
-    const int p0 = mp->refslot[p8], p1 = mp->refslot1[p8], q0 = mq->refslot[q8], q1 = mq->refslot1[q8];
-    const int np = (p0 >= 0) + (p1 >= 0), nq = (q0 >= 0) + (q1 >= 0);
-    if (np != nq) return 1;
-    const int16_t *pv0 = mp->mv[pb], *pv1 = vp->mv[pb], *qv0 = mq->mv[qb], *qv1 = vq->mv[qb];
-    if (np < 2) { // one vector each (or none: corrupt records)
-        const int rp = p0 >= 0 ? p0 : p1, rq = q0 >= 0 ? q0 : q1;
-        if (rp != rq) return 1;
-        return mv_far(p0 >= 0 ? pv0 : pv1, q0 >= 0 ? qv0 : qv1) ? 1 : 0;
-    }
-    if (!((p0 == q0 && p1 == q1) || (p0 == q1 && p1 == q0))) return 1;
-    if (p0 != p1) // two different pictures: each vector against the one that points to the same picture
-        return (p0 == q0 ? (mv_far(pv0, qv0) || mv_far(pv1, qv1)) : (mv_far(pv0, qv1) || mv_far(pv1, qv0))) ? 1 : 0;
-    return ((mv_far(pv0, qv0) || mv_far(pv1, qv1)) && (mv_far(pv0, qv1) || mv_far(pv1, qv0))) ? 1 : 0; // both vectors into one picture
-}
-#endif
-
 __device__ __forceinline__ void unpack4(uint32_t w, int &a, int &b, int &c, int &d) {
     a = static_cast<int>(w & 255u), b = static_cast<int>(__builtin_amdgcn_ubfe(w, 8, 8)), c = static_cast<int>(__builtin_amdgcn_ubfe(w, 16, 8)), d = static_cast<int>(w >> 24);
 }
@@ -206,27 +165,13 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
 #if MI_DB_BANDS
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 #define XARGS , unsigned long long *xring_, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus
-#if MI_DB_B
-#define KNAME k_deblock_b_x
-#else
 #define KNAME k_deblock_x
-#endif
 #else
 #define XARGS
-#if MI_DB_B
-#define KNAME k_deblock_b
-#else
 #define KNAME k_deblock
 #endif
-#endif
-#if MI_DB_B
-extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
-                                                                              const DevTables *tab, const MbRec *mbrec, int ring, int ring_last, int last_bufs,
-                                                                              const MbMv1 *mbmv1 XARGS) {
-#else
-extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools,
-                                                                              const DevTables *tab, const MbRec *mbrec, int ring, int ring_last, int last_bufs XARGS) {
-#endif
+extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring,
+                                                                              int ring_last, int last_bufs XARGS) {
     extern __shared__ uint4 dyn_lds[];
     const int nthreads = static_cast<int>(blockDim.x), nwaves = nthreads >> 6;
     DbShared &sh = *reinterpret_cast<DbShared *>(dyn_lds);
@@ -249,15 +194,8 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
     g8 *const py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes); // luma plane; Cb at +W*H, Cr at +W*H*5/4
     const uint32_t cb_off = static_cast<uint32_t>(W) * H, cr_off = cb_off + cb_off / 4;
     for (int i = tid; i < 96; i += nthreads) sh.prog[i] = 0, sh.cons[i] = 0;
-    for (int i = tid; i < 52; i += nthreads) {
-        sh.alpha[i] = tab->alpha[i], sh.beta[i] = tab->beta[i];
-        sh.tc0[i][0] = 0, sh.tc0[i][1] = tab->tc0[i][1], sh.tc0[i][2] = tab->tc0[i][2], sh.tc0[i][3] = tab->tc0[i][3];
-    }
     __syncthreads();
-    const MbRec *recs = mbrec + pd->mb_base;
-#if MI_DB_B
-    const MbMv1 *recs1 = mbmv1 + pd->mb_base;
-#endif
+    const DbPrm *prms = dbprm + pd->mb_base;
     const int ngroups = (hmb + 3) >> 2;
     const v4u z4 = v4u{0u, 0u, 0u, 0u};
     const v2u z2 = v2u{0u, 0u};
@@ -309,9 +247,6 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
         v4u P0 = z4, P1 = z4, P2 = z4, P3 = z4;
         v2u Q0 = z2, Q1 = z2, Q2 = z2, Q3 = z2;
         v4u pre_rec = z4;
-#if MI_DB_B
-        v4u pre_mv1 = z4;
-#endif
         auto prefetch_group = [&](int gb) { // gb = first macroblock of an aligned group of four
             if (!row_ok || gb >= wmb) return;
             const uint32_t yb = yrow0 + gb * 16, cb = crow0 + gb * 8;
@@ -322,14 +257,9 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             if (j2 < left) P2 = GLD16(py, yb + j2 * 16), Q2 = GLD8(py, cb + j2 * 8);
             if (j3 < left) P3 = GLD16(py, yb + j3 * 16), Q3 = GLD8(py, cb + j3 * 8);
         };
-        auto prefetch_rec = [&](int mbx) {
-            if (!row_ok || mbx < 0 || mbx >= wmb) return;
-            // lanes 0-7: cur record (8 x 16 B), lanes 8-15: record above
-            const uint32_t mbi = static_cast<uint32_t>((li >= 8 && has_top ? mby - 1 : mby) * wmb + mbx);
-            pre_rec = reinterpret_cast<const v4u *>(recs + mbi)[li & 7];
-#if MI_DB_B
-            pre_mv1 = reinterpret_cast<const v4u *>(recs1 + mbi)[li & 3]; // lanes 0-3: cur, lanes 8-11: above (4 x 16 B each)
-#endif
+        auto prefetch_rec = [&](int mbx) { // lanes 0..4 of a sub-row: the five 16-byte pieces of the macroblock's DbPrm
+            if (!row_ok || mbx < 0 || mbx >= wmb || li >= 5) return;
+            pre_rec = reinterpret_cast<const v4u *>(prms + static_cast<uint32_t>(mby * wmb + mbx))[li];
         };
         // Output registers: slot s collects the finished bytes of the column with (c + sub) % 4 == s; a group of four
         // columns leaves as one 64-byte line (32 bytes of chroma).  Lanes 13..15 do not own finished rows (rows 13..15
@@ -385,106 +315,42 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             const bool up_lane = li >= 13 && !last_row, upc_lane = (li & 7) == 7 && !last_row;
             const int mbx = t - sub;
             const bool active = row_ok && mbx >= 0 && mbx < wmb;
-            const int cur_slot = t & 1;
-            MbRec *mq = &ss->rec[cur_slot], *mleft_rec = &ss->rec[cur_slot ^ 1], *mtop_rec = &ss->rec[2];
             // this step's input registers (wave-uniform slot)
             const int ts = t & 3;
             const v4u in_y = ts == 0 ? P0 : (ts == 1 ? P1 : (ts == 2 ? P2 : P3));
             const v2u in_c = ts == 0 ? Q0 : (ts == 1 ? Q1 : (ts == 2 ? Q2 : Q3));
-            // ---- 1. records -> LDS; boundary strengths: 32 per macroblock, 2 per lane ----
-            if (active) reinterpret_cast<v4u *>(li < 8 ? mq : mtop_rec)[li & 7] = pre_rec;
-#if MI_DB_B
-            MbMv1 *vq = &ss->mv1[cur_slot], *vleft = &ss->mv1[cur_slot ^ 1], *vtop = &ss->mv1[2];
-            if (active && (li & 7) < 4) reinterpret_cast<v4u *>(li < 8 ? vq : vtop)[li & 3] = pre_mv1;
-#endif
+            // ---- 1. the macroblock's DbPrm -> LDS -> this lane's strengths and filter parameters ----
+            if (active && li < 5) reinterpret_cast<v4u *>(&ss->prm)[li] = pre_rec;
             WAVE_SYNC();
             STAMP(6);
             if (active && (mbx & 3) == 3) prefetch_group(mbx + 1); // the input registers of this sub-row are free again
             prefetch_rec(mbx + 1);
             STAMP(7);
-            const MbRec *ml = nullptr, *mt = nullptr;
-            int dbf = 1;
-            if (active) {
-                dbf = mq->dbf_idc;
-                ml = mbx > 0 ? mleft_rec : nullptr, mt = has_top ? mtop_rec : nullptr;
-                if (dbf == 2) { // no filtering across slice boundaries
-                    if (ml && ml->slice_in_pic != mq->slice_in_pic) ml = nullptr;
-                    if (mt && mt->slice_in_pic != mq->slice_in_pic) mt = nullptr;
-                }
-#if MI_DB_B
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const int idx = li + 16 * h, dir = idx >> 4, e = (idx >> 2) & 3, k = idx & 3;
-                    const MbRec *mn = dir == 0 ? ml : mt;
-                    int bs = 0;
-                    if (dbf != 1 && !(e == 0 && !mn) && !((e & 1) && mq->t8x8)) {
-                        const MbRec *mp = e == 0 ? mn : mq;
-                        int qb = dir == 0 ? k * 4 + e : e * 4 + k;
-                        int pb = dir == 0 ? k * 4 + (e == 0 ? 3 : e - 1) : (e == 0 ? 3 : e - 1) * 4 + k;
-                        bs = edge_bs_b(mp, e == 0 ? (dir == 0 ? vleft : vtop) : vq, pb, mq, vq, qb, e == 0);
-                    }
-                    ss->bs[dir][e][k] = static_cast<uint8_t>(bs);
-                }
-#else
-                // Branch-free (8.7.2.1, one list): every operand of both strengths of this lane is fetched from the LDS records up
-                // front -- independent reads, one wait -- and the decision is a chain of selects.  (With early returns the reads
-                // of types, nzmasks, frame slots and vectors were five dependent LDS round trips per strength.)
-                const int e = li >> 2, k = li & 3;
-                const bool mb_edge = e == 0;
-                const int qb0 = k * 4 + e, qb1 = li;                          // q block of the vertical / horizontal edge segment
-                const int pb0 = mb_edge ? k * 4 + 3 : qb0 - 1, pb1 = mb_edge ? 12 + k : qb1 - 4;
-                const MbRec *mp0 = mb_edge && ml ? ml : mq, *mp1 = mb_edge && mt ? mt : mq; // (no neighbour: any record, the result is masked)
-                const int tq = mq->type, t8 = mq->t8x8, nzq = mq->nzmask;
-                const int tp0 = mp0->type, tp1 = mp1->type, nzp0 = mp0->nzmask, nzp1 = mp1->nzmask;
-#define Q8(b) ((((b) >> 3) << 1) | (((b) & 3) >> 1))
-                const int rq0 = mq->refslot[Q8(qb0)], rq1 = mq->refslot[Q8(qb1)], rp0 = mp0->refslot[Q8(pb0)], rp1 = mp1->refslot[Q8(pb1)];
-#undef Q8
-                const int vq0x = mq->mv[qb0][0], vq0y = mq->mv[qb0][1], vq1x = mq->mv[qb1][0], vq1y = mq->mv[qb1][1];
-                const int vp0x = mp0->mv[pb0][0], vp0y = mp0->mv[pb0][1], vp1x = mp1->mv[pb1][0], vp1y = mp1->mv[pb1][1];
-                const bool ok = dbf != 1 && !((e & 1) && t8);
-                const bool ok0 = ok && !(mb_edge && !ml), ok1 = ok && !(mb_edge && !mt);
-                const bool iq = MB_IS_INTRA(tq);
-                const int bs_i = mb_edge ? 4 : 3;
-                const bool far0 = rp0 != rq0 || abs(vp0x - vq0x) >= 4 || abs(vp0y - vq0y) >= 4;
-                const bool far1 = rp1 != rq1 || abs(vp1x - vq1x) >= 4 || abs(vp1y - vq1y) >= 4;
-                int bs0 = (iq || MB_IS_INTRA(tp0)) ? bs_i : ((((nzp0 >> pb0) | (nzq >> qb0)) & 1) ? 2 : (far0 ? 1 : 0));
-                int bs1 = (iq || MB_IS_INTRA(tp1)) ? bs_i : ((((nzp1 >> pb1) | (nzq >> qb1)) & 1) ? 2 : (far1 ? 1 : 0));
-                ss->bs[0][e][k] = static_cast<uint8_t>(ok0 ? bs0 : 0);
-                ss->bs[1][e][k] = static_cast<uint8_t>(ok1 ? bs1 : 0);
-#endif
-            }
-            STAMP(8);
-            WAVE_SYNC();
-            STAMP(9);
-            // Filter parameters of this macroblock (8.7.2.2), ALL of them here: the strengths of this lane's four edges in both
-            // directions, and alpha / beta / tC0 of the luma and the chroma edges, packed into bytes.  The table reads are
-            // independent of each other -- one LDS round trip for the whole step instead of one per edge in the passes below.
-            // P*[0] luma, [1] chroma: bs = four strengths (edge e in byte e), ab = alpha(e0) | beta(e0) << 8 | alpha(inner) << 16 |
-            // beta(inner) << 24, tc = tC0 per edge.  V: vertical edges, H: horizontal edges.
+            // P*[0] luma, [1] chroma (plane li >> 3): bs = the strengths of this lane's segment of edges 0..3 (edge e in byte e; chroma:
+            // luma edges 0 and 2), ab = alpha(e0) | beta(e0) << 8 | alpha(inner) << 16 | beta(inner) << 24, tc = tC0 per edge.
+            // V: vertical edges, H: horizontal edges.  No table, no record, no division of labour: four 16-byte LDS reads.
             uint32_t Vbs[2] = {0, 0}, Vab[2] = {0, 0}, Vtc[2] = {0, 0}, Hbs[2] = {0, 0}, Hab[2] = {0, 0}, Htc[2] = {0, 0};
             if (active) {
-                const int aoff = mq->alpha_off, boff = mq->beta_off, cpl_ = li >> 3;
-                const int qpq = mq->qp, qpc_q = mq->qpc[cpl_];
-                const MbRec *mlq = ml ? ml : mq, *mtq = mt ? mt : mq; // no neighbour: the edge's strength is 0 anyway
-                const int qpl = mlq->qp, qpt = mtq->qp, qpcl = mlq->qpc[cpl_], qpct = mtq->qpc[cpl_];
-                const v4u bv = *reinterpret_cast<const v4u *>(ss->bs[0][0]), bh = *reinterpret_cast<const v4u *>(ss->bs[1][0]);
-                auto pick = [](v4u w, int sh8, bool chroma) { // this lane's segment of edges 0..3 (chroma: luma edges 0 and 2 only)
+                const v4u bv = *reinterpret_cast<const v4u *>(ss->prm.bs[0][0]), bh = *reinterpret_cast<const v4u *>(ss->prm.bs[1][0]);
+                const v4u blk_l = *reinterpret_cast<const v4u *>(&ss->prm.pl[0]), blk_c = *reinterpret_cast<const v4u *>(&ss->prm.pl[1 + (li >> 3)]);
+                auto pick = [](v4u w, int sh8, bool chroma) {
                     const uint32_t b0 = (w.x >> sh8) & 255u, b1 = (w.y >> sh8) & 255u, b2 = (w.z >> sh8) & 255u, b3 = (w.w >> sh8) & 255u;
                     return chroma ? (b0 | (b2 << 16)) : (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
                 };
-                auto tables = [&](uint32_t bsp, int qpn, int qp, uint32_t &ab, uint32_t &tc) {
-                    const int qpe = (qpn + qp + 1) >> 1;
-                    const int ia0 = clip3(0, 51, qpe + aoff), ib0 = clip3(0, 51, qpe + boff), ia1 = clip3(0, 51, qp + aoff), ib1 = clip3(0, 51, qp + boff);
-                    ab = sh.alpha[ia0] | (static_cast<uint32_t>(sh.beta[ib0]) << 8) | (static_cast<uint32_t>(sh.alpha[ia1]) << 16) | (static_cast<uint32_t>(sh.beta[ib1]) << 24);
-                    tc = sh.tc0[ia0][bsp & 3u] | (static_cast<uint32_t>(sh.tc0[ia1][(bsp >> 8) & 3u]) << 8) | (static_cast<uint32_t>(sh.tc0[ia1][(bsp >> 16) & 3u]) << 16) |
-                         (static_cast<uint32_t>(sh.tc0[ia1][(bsp >> 24) & 3u]) << 24);
+                // a plane's block: a0V b0V a1 b1 | a0H b0H t00 t01 | t02 t10 t11 t12 | t20 t21 t22 pad  (tKb: tC0 of edge kind K -- left /
+                // inner / top -- for bS b + 1).  Rows shifted up by one byte, so that bS 0 (and 4: & 3) selects a zero byte.
+                auto params = [](v4u blk, uint32_t vbs, uint32_t hbs, uint32_t &vab, uint32_t &vtc, uint32_t &hab, uint32_t &htc) {
+                    vab = blk.x;
+                    hab = (blk.y & 0xFFFFu) | (blk.x & 0xFFFF0000u);
+                    const uint32_t tw0 = ((blk.y >> 16) | ((blk.z & 255u) << 16)) << 8, tw1 = blk.z & 0xFFFFFF00u, tw2 = blk.w << 8;
+                    auto sel = [](uint32_t tw, uint32_t bs) { return (tw >> (8u * (bs & 3u))) & 255u; };
+                    vtc = sel(tw0, vbs) | (sel(tw1, vbs >> 8) << 8) | (sel(tw1, vbs >> 16) << 16) | (sel(tw1, vbs >> 24) << 24);
+                    htc = sel(tw2, hbs) | (sel(tw1, hbs >> 8) << 8) | (sel(tw1, hbs >> 16) << 16) | (sel(tw1, hbs >> 24) << 24);
                 };
                 Vbs[0] = pick(bv, 8 * (li >> 2), false), Vbs[1] = pick(bv, 8 * ((li & 7) >> 1), true);
                 Hbs[0] = pick(bh, 8 * (li >> 2), false), Hbs[1] = pick(bh, 8 * ((li & 7) >> 1), true);
-                tables(Vbs[0], qpl, qpq, Vab[0], Vtc[0]);
-                tables(Vbs[1], qpcl, qpc_q, Vab[1], Vtc[1]);
-                tables(Hbs[0], qpt, qpq, Hab[0], Htc[0]);
-                tables(Hbs[1], qpct, qpc_q, Hab[1], Htc[1]);
+                params(blk_l, Vbs[0], Hbs[0], Vab[0], Vtc[0], Hab[0], Htc[0]);
+                params(blk_c, Vbs[1], Hbs[1], Vab[1], Vtc[1], Hab[1], Htc[1]);
             }
             STAMP(0);
             // ---- 2. vertical edges: lane li = luma row li, then chroma (plane li >> 3, row li & 7) ----
@@ -704,3 +570,127 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
 #endif
     }
 }
+
+#if !MI_DB_BANDS
+// ================================================================== k_dbprep: DbPrm of every macroblock of a batch
+// 8.7.2.1 with one list (I / P pictures)
+__device__ __forceinline__ int prep_bs(const MbRec *mp, int pb, const MbRec *mq, int qb, bool mb_edge) {
+    // branch-free: every operand is fetched up front (independent LDS reads), the decision is a chain of selects
+    const int q8p = ((pb >> 3) << 1) | ((pb & 3) >> 1), q8q = ((qb >> 3) << 1) | ((qb & 3) >> 1);
+    const int tp = mp->type, tq = mq->type, nzp = mp->nzmask, nzq = mq->nzmask, rp = mp->refslot[q8p], rq = mq->refslot[q8q];
+    const int vpx = mp->mv[pb][0], vpy = mp->mv[pb][1], vqx = mq->mv[qb][0], vqy = mq->mv[qb][1];
+    const bool far = rp != rq || abs(vpx - vqx) >= 4 || abs(vpy - vqy) >= 4;
+    return (MB_IS_INTRA(tp) || MB_IS_INTRA(tq)) ? (mb_edge ? 4 : 3) : ((((nzp >> pb) | (nzq >> qb)) & 1) ? 2 : (far ? 1 : 0));
+}
+// 8.7.2.1 with two lists (pictures with B slices): the blocks differ if they use different reference PICTURES (frame slots; the
+// list a picture comes from does not matter) or a different number of vectors, or if the vectors that belong together differ by >= 4
+__device__ __forceinline__ bool mv_far(const int16_t *a, const int16_t *b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
+__device__ __forceinline__ int prep_bs_b(const MbRec *mp, const MbMv1 *vp, int pb, const MbRec *mq, const MbMv1 *vq, int qb, bool mb_edge) {
+    if (MB_IS_INTRA(mp->type) || MB_IS_INTRA(mq->type)) return mb_edge ? 4 : 3;
+    if (((mp->nzmask >> pb) & 1) || ((mq->nzmask >> qb) & 1)) return 2;
+    const int p8 = ((pb >> 3) << 1) | ((pb & 3) >> 1), q8 = ((qb >> 3) << 1) | ((qb & 3) >> 1);
+    const int p0 = mp->refslot[p8], p1 = mp->refslot1[p8], q0 = mq->refslot[q8], q1 = mq->refslot1[q8];
+    const int np = (p0 >= 0) + (p1 >= 0), nq = (q0 >= 0) + (q1 >= 0);
+    if (np != nq) return 1;
+    const int16_t *pv0 = mp->mv[pb], *pv1 = vp->mv[pb], *qv0 = mq->mv[qb], *qv1 = vq->mv[qb];
+    if (np < 2) { // one vector each (or none: corrupt records)
+        const int rp = p0 >= 0 ? p0 : p1, rq = q0 >= 0 ? q0 : q1;
+        if (rp != rq) return 1;
+        return mv_far(p0 >= 0 ? pv0 : pv1, q0 >= 0 ? qv0 : qv1) ? 1 : 0;
+    }
+    if (!((p0 == q0 && p1 == q1) || (p0 == q1 && p1 == q0))) return 1;
+    if (p0 != p1) // two different pictures: each vector against the one that points to the same picture
+        return (p0 == q0 ? (mv_far(pv0, qv0) || mv_far(pv1, qv1)) : (mv_far(pv0, qv1) || mv_far(pv1, qv0))) ? 1 : 0;
+    return ((mv_far(pv0, qv0) || mv_far(pv1, qv1)) && (mv_far(pv0, qv1) || mv_far(pv1, qv0))) ? 1 : 0; // both vectors into one picture
+}
+
+struct PrepSub {
+    MbRec rec[3]; // current, left, upper macroblock
+    MbMv1 mv1[3]; // their list-1 vectors (pictures with B slices)
+    DbPrm out;
+};
+// grid = (ceil(macroblocks of the largest picture / MI_DBPREP_MBS), pictures), block = 256: a wavefront works on 4 macroblocks at a
+// time, 16 lanes each -- lane li computes the strength of segment li & 3 of vertical edge li >> 2 and of horizontal edge li >> 2
+// (the same division of labour K5 had when it did this itself), lanes 0..8 the parameters of (plane, edge kind) li / 3, li % 3.
+extern "C" __global__ void __launch_bounds__(256) k_dbprep(const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1, DbPrm *out) {
+    __shared__ PrepSub subs[4][4];
+    __shared__ uint8_t s_alpha[52], s_beta[52], s_tc0[52][4];
+    const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63, sub = lane >> 4, li = lane & 15;
+    const PicDesc *pd = &pics[blockIdx.y];
+    const int wmb = static_cast<int>(pd->wmb), nmb = wmb * static_cast<int>(pd->hmb);
+    const int mb_first = static_cast<int>(blockIdx.x) * MI_DBPREP_MBS;
+    if (mb_first >= nmb) return;
+    for (int i = tid; i < 52; i += 256) {
+        s_alpha[i] = tab->alpha[i], s_beta[i] = tab->beta[i];
+        s_tc0[i][0] = 0, s_tc0[i][1] = tab->tc0[i][1], s_tc0[i][2] = tab->tc0[i][2], s_tc0[i][3] = tab->tc0[i][3];
+    }
+    __syncthreads();
+    const bool two = pd->has_b != 0;
+    const MbRec *recs = mbrec + pd->mb_base;
+    const MbMv1 *recs1 = two ? mbmv1 + pd->mb_base : nullptr;
+    DbPrm *outs = out + pd->mb_base;
+    PrepSub *ss = &subs[wave][sub];
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    for (int it = wave; it < MI_DBPREP_MBS / 4; it += 4) {
+        const int mb = mb_first + it * 4 + sub;
+        const bool valid = mb < nmb;
+        const int mby = static_cast<int>(__umulhi(static_cast<uint32_t>(valid ? mb : 0), pd->inv_wmb)), mbx = (valid ? mb : 0) - mby * wmb;
+        const bool has_left = valid && mbx > 0, has_top = valid && mby > 0;
+        if (valid) { // lanes 0-7: the record, lanes 8-15: the record above; then lanes 0-7: the record to the left
+            const v4u z = v4u{0u, 0u, 0u, 0u};
+            const bool up = li >= 8;
+            v4u a = z, b = z;
+            if (!up || has_top) a = reinterpret_cast<const v4u *>(recs + (up ? mb - wmb : mb))[li & 7];
+            if (!up && has_left) b = reinterpret_cast<const v4u *>(recs + mb - 1)[li];
+            reinterpret_cast<v4u *>(&ss->rec[up ? 2 : 0])[li & 7] = a;
+            if (!up) reinterpret_cast<v4u *>(&ss->rec[1])[li] = b;
+            if (two) { // list-1 vectors: lanes 0-3 current, 4-7 left, 8-11 above
+                const int which = li >> 2;
+                if (which < 3) {
+                    const bool ok = which == 0 || (which == 1 ? has_left : has_top);
+                    reinterpret_cast<v4u *>(&ss->mv1[which == 0 ? 0 : (which == 1 ? 1 : 2)])[li & 3] =
+                        ok ? reinterpret_cast<const v4u *>(recs1 + (which == 0 ? mb : (which == 1 ? mb - 1 : mb - wmb)))[li & 3] : z;
+                }
+            }
+        }
+        WAVE_SYNC();
+        if (valid) {
+            const MbRec *mq = &ss->rec[0], *ml = has_left ? &ss->rec[1] : nullptr, *mt = has_top ? &ss->rec[2] : nullptr;
+            const int dbf = mq->dbf_idc;
+            if (dbf == 2) { // no filtering across slice boundaries
+                if (ml && ml->slice_in_pic != mq->slice_in_pic) ml = nullptr;
+                if (mt && mt->slice_in_pic != mq->slice_in_pic) mt = nullptr;
+            }
+            const int e = li >> 2, k = li & 3;
+            const bool mb_edge = e == 0;
+            const int qb0 = k * 4 + e, qb1 = li; // q block of the vertical / horizontal edge segment
+            const int pb0 = mb_edge ? k * 4 + 3 : qb0 - 1, pb1 = mb_edge ? 12 + k : qb1 - 4;
+            const bool ok = dbf != 1 && !((e & 1) && mq->t8x8);
+            const bool ok0 = ok && !(mb_edge && !ml), ok1 = ok && !(mb_edge && !mt);
+            const MbRec *mp0 = mb_edge && ml ? ml : mq, *mp1 = mb_edge && mt ? mt : mq; // (no neighbour: any record, the result is masked)
+            int bs0, bs1;
+            if (two) {
+                bs0 = prep_bs_b(mp0, mb_edge && ml ? &ss->mv1[1] : &ss->mv1[0], pb0, mq, &ss->mv1[0], qb0, mb_edge);
+                bs1 = prep_bs_b(mp1, mb_edge && mt ? &ss->mv1[2] : &ss->mv1[0], pb1, mq, &ss->mv1[0], qb1, mb_edge);
+            } else
+                bs0 = prep_bs(mp0, pb0, mq, qb0, mb_edge), bs1 = prep_bs(mp1, pb1, mq, qb1, mb_edge);
+            ss->out.bs[0][e][k] = static_cast<uint8_t>(ok0 ? bs0 : 0);
+            ss->out.bs[1][e][k] = static_cast<uint8_t>(ok1 ? bs1 : 0);
+            if (li < 9) { // 8.7.2.2: (plane, edge kind): qPav of the left / no / the upper neighbour, indexA / indexB, the table rows
+                const int plane = li / 3, kind = li - plane * 3;
+                const MbRec *mn = kind == 0 ? ml : (kind == 2 ? mt : nullptr);
+                const int qpq = plane == 0 ? mq->qp : mq->qpc[plane - 1];
+                const int qpn = mn ? (plane == 0 ? mn->qp : mn->qpc[plane - 1]) : qpq;
+                const int qpav = (qpn + qpq + 1) >> 1;
+                const int ia = min(max(qpav + mq->alpha_off, 0), 51), ib = min(max(qpav + mq->beta_off, 0), 51);
+                ss->out.pl[plane].ab[2 * kind] = s_alpha[ia], ss->out.pl[plane].ab[2 * kind + 1] = s_beta[ib];
+                ss->out.pl[plane].tc[kind][0] = s_tc0[ia][1], ss->out.pl[plane].tc[kind][1] = s_tc0[ia][2], ss->out.pl[plane].tc[kind][2] = s_tc0[ia][3];
+                if (kind == 0) ss->out.pl[plane].pad = 0;
+            }
+        }
+        WAVE_SYNC();
+        if (valid && li < 5) reinterpret_cast<v4u *>(outs + mb)[li] = reinterpret_cast<const v4u *>(&ss->out)[li];
+        WAVE_SYNC();
+    }
+}
+#endif

@@ -190,6 +190,7 @@ struct h264mi_decoder {
     // overlap the reconstruction kernels of pass n (on `stream`); each pass owns one of MI_SETS
     // MbRec / coefficient buffer sets, fenced by events.
     MbRec *d_mbrec[MI_SETS] = {};
+    DbPrm *d_dbprm[MI_SETS] = {};        // k_dbprep -> K5: boundary strengths and filter parameters, same indexing as d_mbrec
     MbMv1 *d_mv1[MI_SETS] = {};          // list-1 vectors, same indexing as d_mbrec; allocated when the first B slice arrives
     ColRec *d_colrec = nullptr;          // per stream and frame slot: the motion a picture leaves for later direct prediction
     size_t colrec_per_slot = 0;          // ColRecs per frame slot
@@ -218,7 +219,7 @@ struct h264mi_decoder {
     size_t ev_used = 0;
     double k_ms[5] = {0, 0, 0, 0, 0};
     // Launches with fewer pictures than the chip has CUs spread a picture over several workgroups (k_intra_x, k_deblock_x,
-    // k_deblock_b_x): hand-off rings / flags in global memory, a ticket counter per kernel family, a give-up word
+    // k_deblock_x): hand-off rings / flags in global memory, a ticket counter per kernel family, a give-up word
     unsigned long long *d_xring = nullptr; // K5: x_cap * (Wmax / 16) * 24 granules
     uint32_t *d_xdone = nullptr;           // K3: x_cap * (Wmax / 16) flag words
     uint32_t *d_xctl = nullptr, *h_xstatus = nullptr; // [0] K5 tickets, [32] K3 tickets, [64] give-up code (128-byte lines of their own)
@@ -305,6 +306,7 @@ static void free_all(h264mi_decoder *d) {
     for (int i = 0; i < MI_SETS; i++) {
         if (d->d_mbrec[i]) hipFree(d->d_mbrec[i]);
         if (d->d_mv1[i]) hipFree(d->d_mv1[i]);
+        if (d->d_dbprm[i]) hipFree(d->d_dbprm[i]);
         if (d->d_coef[i]) hipFree(d->d_coef[i]);
         if (i == 0 && d->d_pool_head) hipFree(d->d_pool_head);
         if (d->d_toprows[i]) hipFree(d->d_toprows[i]);
@@ -428,6 +430,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     }
     for (int i = 0; i < MI_SETS; i++) {
         TRY_ALLOC(hipMalloc(&d->d_mbrec[i], sizeof(MbRec) * d->mb_cap));
+        TRY_ALLOC(hipMalloc(&d->d_dbprm[i], sizeof(DbPrm) * d->mb_cap));
         if (i == 0) {
             // Pool size.  The worst case is 26 blocks (832 bytes) per macroblock; real streams code a fraction of that (the
             // 1080p QP 28 bench streams: ~5 blocks per macroblock).  Small decoders get the worst case; large ones 10 blocks
@@ -455,9 +458,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipHostMalloc(&d->h_tables, sizeof(DevTables)));
     // K5 keeps a whole macroblock row per in-flight group in dynamic LDS (up to 320 columns): opt in beyond 64 KB
     TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
-    TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock_b), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
     TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock_x), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
-    TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock_b_x), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
     // cross-workgroup hand-off state of the banded kernels; H264MI_X_WGS = 0 switches them off, n: up to n workgroups per launch
     if (const char *e = getenv("H264MI_X_WGS")) d->x_max_wgs = std::min(std::max(atoi(e), 0), d->x_cap);
     TRY_ALLOC(hipMalloc(&d->d_xring, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long)));
@@ -1323,7 +1324,11 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
                     hipLaunchKernelGGL(k_entropy_b, dim3(n), dim3(64), 0, st, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
                                        static_cast<uint32_t>(d->pool_blocks), g.d_status, d->d_toprows[set], g.wmb_max, static_cast<uint32_t>(first), g.d_bext, d->d_mv1[set]);
             }
-            if (lv == n_levels - 1 && done) hipEventRecord(done, st);
+            if (lv == n_levels - 1) { // every record of the batch exists now: K5's strengths and filter parameters, all pictures at once
+                hipLaunchKernelGGL(k_dbprep, dim3((g.mbs_max + MI_DBPREP_MBS - 1) / MI_DBPREP_MBS, g.n_pics), dim3(256), 0, st, g.d_pics, d->d_tables, mbrec, d->d_mv1[set],
+                                   d->d_dbprm[set]);
+                if (done) hipEventRecord(done, st);
+            }
             if (g.colsave_n[lv])
                 hipLaunchKernelGGL(k_colsave, dim3((g.mbs_max + 63) / 64, g.colsave_n[lv]), dim3(64), 0, st, g.d_lists + g.colsave_off[lv], g.d_pics, mbrec, d->d_mv1[set]);
         }
@@ -1358,7 +1363,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         return d->x_epoch;
     };
     for (size_t w = 0; w < g.waves.size(); w++) {
-        const uint32_t n = static_cast<uint32_t>(g.waves[w].size()), ni = g.wave_p_n[w], nbp = g.wave_b_n[w], nnb = g.wave_nb_n[w];
+        const uint32_t n = static_cast<uint32_t>(g.waves[w].size()), ni = g.wave_p_n[w], nbp = g.wave_b_n[w];
         if (!n) continue;
         int mbs_log2 = 0; // K4 workgroups per picture: the largest picture's macroblock count rounded up to a power of two
         while ((1 << mbs_log2) < g.mbs_max) mbs_log2++;
@@ -1386,33 +1391,17 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
             hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, g.d_lists + g.wave_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, coef);
         mark(2);
         int dbw = 1, dbring = 16, dbring_last = 16, dbbufs = 1, nb5 = 1;
-        if (nnb) {
-            mi_deblock_bands(static_cast<int>(nnb), g.wmb_max, g.hmb_max, d->x_max_wgs, &nb5, &dbw, &dbring);
-            if (nb5 > 1) {
-                hipLaunchKernelGGL(k_deblock_x, dim3(nnb * nb5), dim3(dbw * 64), mi_deblock_lds_bytes_banded(dbw, dbring), rs, g.d_lists + g.wave_nb_off[w], g.d_pics,
-                                   d->d_pools, d->d_tables, mbrec, dbring, 0, 1, d->d_xring, next_epoch(), nb5, d->d_xctl, d->x_tk5, g.wmb_max, d->d_xctl + 64);
-                d->x_tk5 += nnb * nb5;
-            } else {
-                mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
-                hipLaunchKernelGGL(k_deblock, dim3(nnb), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_nb_off[w], g.d_pics,
-                                   d->d_pools, d->d_tables, mbrec, dbring, dbring_last, dbbufs);
-            }
-            mark(3);
+        mi_deblock_bands(static_cast<int>(n), g.wmb_max, g.hmb_max, d->x_max_wgs, &nb5, &dbw, &dbring);
+        if (nb5 > 1) {
+            hipLaunchKernelGGL(k_deblock_x, dim3(n * nb5), dim3(dbw * 64), mi_deblock_lds_bytes_banded(dbw, dbring), rs, g.d_lists + g.wave_off[w], g.d_pics,
+                               d->d_dbprm[set], dbring, 0, 1, d->d_xring, next_epoch(), nb5, d->d_xctl, d->x_tk5, g.wmb_max, d->d_xctl + 64);
+            d->x_tk5 += n * nb5;
+        } else {
+            mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
+            hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_off[w], g.d_pics,
+                               d->d_dbprm[set], dbring, dbring_last, dbbufs);
         }
-        if (nbp) {
-            mi_deblock_bands(static_cast<int>(nbp), g.wmb_max, g.hmb_max, d->x_max_wgs, &nb5, &dbw, &dbring);
-            if (nb5 > 1) {
-                hipLaunchKernelGGL(k_deblock_b_x, dim3(nbp * nb5), dim3(dbw * 64), mi_deblock_lds_bytes_banded(dbw, dbring, MI_DEBLOCK_WAVE_BYTES_B), rs,
-                                   g.d_lists + g.wave_b_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, dbring, 0, 1, d->d_mv1[set], d->d_xring, next_epoch(), nb5,
-                                   d->d_xctl, d->x_tk5, g.wmb_max, d->d_xctl + 64);
-                d->x_tk5 += nbp * nb5;
-            } else {
-                mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs, MI_DEBLOCK_WAVE_BYTES_B);
-                hipLaunchKernelGGL(k_deblock_b, dim3(nbp), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs, MI_DEBLOCK_WAVE_BYTES_B), rs,
-                                   g.d_lists + g.wave_b_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, dbring, dbring_last, dbbufs, d->d_mv1[set]);
-            }
-            mark(3);
-        }
+        mark(3);
     }
     HIP_TRY(hipEventRecord(d->ev_rec[set], rs));
     if (!prof) HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_rec[set], 0)); // the caller's stream sees the finished pass
@@ -1706,7 +1695,7 @@ extern "C" int32_t h264mi_internal_band_plan(int32_t n_pics, int32_t wmb, int32_
     int nb = 1, nw = 1, ring = 1, b3 = 1, w3 = 1;
     mi_deblock_bands(n_pics, wmb, hmb, max_wgs, &nb, &nw, &ring);
     mi_intra_bands(n_pics, hmb, max_wgs, &b3, &w3);
-    *k5_bands = nb, *k5_waves = nw, *k5_ring = ring, *k5_lds = static_cast<int64_t>(mi_deblock_lds_bytes_banded(nw, ring, MI_DEBLOCK_WAVE_BYTES_B));
+    *k5_bands = nb, *k5_waves = nw, *k5_ring = ring, *k5_lds = static_cast<int64_t>(mi_deblock_lds_bytes_banded(nw, ring));
     *k3_bands = b3, *k3_waves = w3;
     return H264MI_OK;
 }

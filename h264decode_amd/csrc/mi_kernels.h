@@ -29,28 +29,23 @@ extern "C" __global__ void k_intra(const uint32_t *pic_list, const PicDesc *pics
 extern "C" __global__ void k_intra_x(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
                                      const int16_t *coefs, uint32_t *xdone, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max,
                                      uint32_t *xstatus);
+// k_dbprep: boundary strengths + alpha / beta / tC0 of every macroblock of a batch (DbPrm), so that K5 -- one serial dependency chain per
+// picture -- has none of that work in its steps.  grid = (ceil(mbs_max / MI_DBPREP_MBS), pictures), block = 256; pictures in PicDesc order.
+#define MI_DBPREP_MBS 64
+extern "C" __global__ void k_dbprep(const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1, DbPrm *out);
 // K5: in-loop deblocking, one workgroup per picture, one wavefront per group of 4 macroblock rows (up to 16 groups side by side).
 // block = 64 * nwaves, dynamic LDS = mi_deblock_lds_bytes(nwaves, ring, ring_last); (nwaves, ring, ring_last) from mi_deblock_plan()
-extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring,
-                                     int ring_last, int last_bufs);
-// the same for pictures with B slices (k_deblock_b.hip): boundary strengths over two lists; plan with MI_DEBLOCK_WAVE_BYTES_B
-extern "C" __global__ void k_deblock_b(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring,
-                                       int ring_last, int last_bufs, const MbMv1 *mbmv1);
-// K5 spread over `nbands` workgroups per picture (k_deblock_x.hip / k_deblock_b_x.hip): grid = pictures * nbands, block = 64 * (largest band's
-// group count), dynamic LDS = mi_deblock_lds_bytes_banded().  xring: pictures * nbands * wmb_max * 24 granules of 8 bytes; epoch: a value no
-// earlier launch on this ring has used (never 0); ticket / ticket_base: a counter that only ever grows and its value before this launch.
-extern "C" __global__ void k_deblock_x(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring,
-                                       int ring_last, int last_bufs, unsigned long long *xring, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base,
-                                       int wmb_max, uint32_t *xstatus);
-extern "C" __global__ void k_deblock_b_x(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec, int ring,
-                                         int ring_last, int last_bufs, const MbMv1 *mbmv1, unsigned long long *xring, uint32_t epoch, int nbands, uint32_t *ticket,
-                                         uint32_t ticket_base, int wmb_max, uint32_t *xstatus);
+extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring, int ring_last, int last_bufs);
+// K5 spread over `nbands` workgroups per picture (k_deblock_x.hip): grid = pictures * nbands, block = 64 * (largest band's group count),
+// dynamic LDS = mi_deblock_lds_bytes_banded().  xring: pictures * nbands * wmb_max * 24 granules of 8 bytes; epoch: a value no earlier
+// launch on this ring has used (never 0); ticket / ticket_base: a counter that only ever grows and its value before this launch.
+extern "C" __global__ void k_deblock_x(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring, int ring_last, int last_bufs,
+                                       unsigned long long *xring, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus);
 #ifndef MI_DEBLOCK_MAX_WAVES
 #define MI_DEBLOCK_MAX_WAVES 12    /* 1024 threads; LDS: 6 KB of row state per wavefront + its hand-off ring */
 #endif
-#define MI_DEBLOCK_HDR_BYTES 1088  /* sizeof(DbShared) rounded up to 16 */
-#define MI_DEBLOCK_WAVE_BYTES 6144
-#define MI_DEBLOCK_WAVE_BYTES_B 6912 /* k_deblock_b: + the list-1 vectors of the current / left / upper macroblock per sub-row */
+#define MI_DEBLOCK_HDR_BYTES 784   /* sizeof(DbShared) rounded up to 16 */
+#define MI_DEBLOCK_WAVE_BYTES 4800 /* 4 sub-rows: sample tiles, the macroblock's DbPrm, the bottom rows for the sub-row below */
 #define MI_DEBLOCK_SLOT_BYTES 96
 #define MI_DEBLOCK_LDS_MAX (160 * 1024)
 static inline size_t mi_deblock_lds_bytes(int nwaves, int ring, int ring_last, int last_bufs, int wave_bytes = MI_DEBLOCK_WAVE_BYTES) {

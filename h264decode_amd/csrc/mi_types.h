@@ -79,6 +79,19 @@ typedef struct __attribute__((aligned(16))) {
     uint8_t pad[4];
 } ColRec; /* 80 bytes */
 
+/* What K5 needs of a macroblock, worked out by k_dbprep for every macroblock of a batch at once (no dependencies, fully
+ * parallel) so that the deblocking kernels -- a serial dependency chain per picture -- carry none of it: the 32 boundary
+ * strengths (8.7.2.1) and, per colour plane, alpha / beta and the tC0 rows (8.7.2.2, Tables 8-16 / 8-17) of the three QP
+ * averages a macroblock's edges use: its left edge, its inner edges, its top edge. */
+typedef struct __attribute__((aligned(16))) {
+    uint8_t bs[2][4][4];      /* [direction: 0 vertical edges, 1 horizontal][edge][segment] */
+    struct {
+        uint8_t ab[6];        /* alpha, beta of the left edge | of the inner edges | of the top edge */
+        uint8_t tc[3][3];     /* tC0 for bS 1..3 of the left edge | inner edges | top edge */
+        uint8_t pad;
+    } pl[3];                  /* Y, Cb, Cr */
+} DbPrm; /* 80 bytes */
+
 typedef struct {
     uint32_t rbsp_off;     /* byte offset of the slice RBSP in the bitstream buffer */
     uint32_t rbsp_size;

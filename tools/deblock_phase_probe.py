@@ -20,7 +20,7 @@ assert np.array_equal(dec.read_frames(0, crop=False), rec)
 f(dec._h, buf)
 dec.decode([s])
 f(dec._h, buf)
-names = ["1d tables (rest of 1)", "2 vertical edges", "3 hand-off", "4 horizontal edges", "5 results", "loop", "1a records -> LDS", "1b prefetch issue", "1c strengths", "1c sync", "-", "-"]
+names = ["1c parameters (rest of 1)", "2 vertical edges", "3 hand-off", "4 horizontal edges", "5 results", "loop", "1a DbPrm -> LDS", "1b prefetch issue", "-", "-", "-", "-"]
 steps = F * 123.0
 tot = sum(buf)
 print("clocks per step of the wavefront of group 0 (1080p, %d pictures, %d steps each):" % (F, 123))
