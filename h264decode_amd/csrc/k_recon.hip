@@ -1,11 +1,8 @@
-// h264decode_amd/csrc/k_recon.hip -- K3 (intra) and K4 (inter) reconstruction kernels, gfx950.
+// h264decode_amd/csrc/k_recon.hip -- K3 (intra reconstruction), k_colsave and K6 (crop + pack), gfx950.  (K4 is k_inter.hip.)
 //
 // Everything here is byte / int16 work bounded by HBM traffic and LDS latency (no MFMA):
 //   residual: scaling (8.5.9, 8.5.12.1) + Intra16x16 / chroma DC transforms (8.5.10, 8.5.11) +
 //             4x4 / 8x8 inverse transforms (8.5.12.2, 8.5.13), two LDS passes (rows, columns);
-//   K4 inter: one macroblock per wavefront.  Reference windows (9x9 luma, 3x3 chroma per 4x4 block,
-//             coordinates clamped to the picture, 8.4.2.2) are staged in LDS, every lane produces
-//             4 luma + 2 chroma samples, adds the residual and stores one dword / one ushort.
 //   K3 intra: macroblocks depend on their left / top / top-right neighbours, so a picture is
 //             decoded by ONE workgroup (no cross-CU visibility problem): wavefront w owns
 //             macroblock rows w, w+16, ..., and waits on an LDS progress counter of the row above
@@ -188,390 +185,6 @@ __device__ __forceinline__ void zero_residual(int lane, ResBuf *rb) {
     for (int i = lane; i < 128; i += 64) reinterpret_cast<uint32_t *>(rb->luma)[i] = 0;
     reinterpret_cast<uint32_t *>(rb->chroma)[lane] = 0;
     WAVE_SYNC();
-}
-
-// ================================================================== K4: inter prediction
-struct InterShared {
-    // The dense coefficient layout (832 bytes; its blocks are fetched from the pool while the reference windows are in flight) is parked on top of
-    // rb.luma | rb.chroma | rb.dc[0..15]: it is dead once the row pass has run, those are written by the column
-    // pass (dc[0..15] is the Intra16x16 DC, never used here).  LDS per wavefront decides the occupancy of this kernel.
-    ResBuf rb;
-    union {
-        struct {
-            uint8_t win_y[16][9][12];   // 9x9 luma window per 4x4 block, rows padded to 12 bytes
-            uint8_t win_c[2][16][3][4]; // 3x3 chroma window per 2x2 chroma block
-        };
-        struct { // uniform-motion fast path (all 16 blocks share one mv + reference, window inside the picture):
-                 // one 21x21 luma / 9x9 chroma window for the whole macroblock, loaded as aligned dwords
-            uint8_t win16[21][24];
-            uint8_t winc16[2][9][12];
-        };
-    };
-    MbRec rec;
-    int uniform;
-};
-static_assert(offsetof(ResBuf, chroma) == offsetof(ResBuf, luma) + 512 && offsetof(ResBuf, dc) == offsetof(ResBuf, luma) + 768 && offsetof(ResBuf, luma) % 16 == 0,
-              "coefficient overlay needs luma | chroma | dc back to back");
-
-__device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
-
-// One macroblock per wavefront.  B = false: macroblocks of I/P pictures (one list).  B = true: pictures with B slices -- every
-// 8x8 quadrant is predicted from list 0, list 1 or both (MbRec::refslot / refslot1; list-1 vectors in MbMv1), the two
-// predictions are staged and interpolated one after the other through the same LDS windows and combined by the default,
-// explicit or implicit weighting of 8.4.2.3.
-template <bool B>
-__device__ __forceinline__ void inter_mb(InterShared &sh, MbMv1 *sh_mv1, const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab,
-                                         const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_log2, int n_blocks, const BSliceExt *bexts, const MbMv1 *mbmv1) {
-    const int lane = static_cast<int>(threadIdx.x);
-    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  Give every XCD a
-    // contiguous run of macroblocks (whole pictures) so that the reference rows shared by neighbouring macroblocks
-    // are re-read from the same L2.
-    // (the grid is the block count rounded up to a multiple of 8, so this is a bijection; surplus blocks leave)
-    const uint32_t per_xcd = gridDim.x >> 3;
-    const uint32_t lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (lb >= static_cast<uint32_t>(n_blocks)) return;
-    // (no integer divisions in this prologue: a wavefront lives for ONE macroblock, and the three divisions that used to
-    // be here -- block / macroblocks per picture, macroblock / picture width, and its remainder -- were a quarter of the
-    // scalar instructions of a skipped macroblock.  The per-picture block count is a power of two, the picture width comes
-    // with a precomputed reciprocal.)
-    const PicDesc *pd = &pics[pic_list[lb >> mbs_per_pic_log2]];
-    const int mb = static_cast<int>(lb & ((1u << mbs_per_pic_log2) - 1u));
-    const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
-    if (mb >= wmb * hmb) return;
-    const uint64_t mbi = pd->mb_base + mb;
-    const MbRec *grec = mbrec + mbi;
-    // one round trip: fetch the whole record, then look at its type (first byte of dword 0)
-    const uint32_t rv = lane < 32 ? reinterpret_cast<const uint32_t *>(grec)[lane] : 0u;
-    if (!MB_IS_INTER(static_cast<int>(__builtin_amdgcn_readfirstlane(rv) & 255u))) return;
-    if (lane < 32) reinterpret_cast<uint32_t *>(&sh.rec)[lane] = rv;
-    if (B && lane >= 32 && lane < 48) reinterpret_cast<uint32_t *>(sh_mv1)[lane - 32] = reinterpret_cast<const uint32_t *>(mbmv1 + mbi)[lane - 32];
-    __syncthreads();
-    const MbRec *rec = &sh.rec;
-    const int W = wmb * 16, H = hmb * 16; // the picture's own geometry
-    const int max_slot = static_cast<int>(pd->n_slots) - 1;
-    const uint64_t pool_slot_bytes = pd->slot_bytes;
-    const int mby = static_cast<int>(__umulhi(static_cast<uint32_t>(mb), pd->inv_wmb)), mbx = mb - mby * wmb; // PicDesc::inv_wmb: exact for every macroblock address
-    const g8 *pool_base = (const g8 *)pd->pool_base;
-    const size_t ysz = static_cast<size_t>(W) * H;
-    // coefficient blocks (packed in the pool, MbRec::coef_off / coef_mask): issue the loads now, scatter them into the dense LDS
-    // layout after the window loads have been issued
-    const uint32_t cmask = rec->coef_mask;
-    const int has_res = cmask != 0;
-    uint4 cv0 = make_uint4(0, 0, 0, 0), cv1 = cv0; // absent blocks are zero
-    if (has_res && lane < MI_COEF_BLOCKS && ((cmask >> lane) & 1)) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(coefs) + 2 * (static_cast<size_t>(rec->coef_off) + __builtin_popcount(cmask & ((1u << lane) - 1u)));
-        cv0 = src[0], cv1 = src[1];
-    }
-    // ---- stage reference windows (8.4.2.2.1 / 8.4.2.2.2) ----
-    // Fast path: P_L0_16x16 / P_Skip (or any MB whose 16 blocks share motion) whose displaced block
-    // lies inside the picture -> 126 + 54 aligned dword loads instead of 1584 clamped byte loads.
-    int ox = 0, ocx = 0;
-    uint32_t dl = 0, dc0 = 0, dc1 = 0; // direct path: this lane's 4 luma samples / its chroma pair's 3x2 neighbourhood, straight from the reference picture
-    const int16_t(*mvs)[2] = rec->mv; // vectors / frame slots of the list being predicted from
-    const int16_t *rslots = rec->refslot;
-    int stage_mode = 0; // how the list's samples were staged: 0 per-block windows, 1 one window for the macroblock, 2 direct (wave-uniform)
-    auto stage = [&]() {
-        const int mvx0 = mvs[0][0], mvy0 = mvs[0][1];
-        // all 16 blocks share one vector and one reference?  P_L0_16x16 and P_Skip do by construction
-        bool same_v = true;
-        if (rec->type != MBT_P16x16 && rec->type != MBT_PSKIP) {
-            bool same = true;
-            if (lane < 16) same = mvs[lane][0] == mvx0 && mvs[lane][1] == mvy0 && rslots[((lane >> 3) << 1) | ((lane & 3) >> 1)] == rslots[0];
-            same_v = __all(same);
-        }
-        const int X0 = mbx * 16 + (mvx0 >> 2), Y0 = mby * 16 + (mvy0 >> 2), cx0 = mbx * 8 + (mvx0 >> 3), cy0 = mby * 8 + (mvy0 >> 3);
-        const int x0 = X0 - 2, y0 = Y0 - 2;
-        // The range checks are sign tests of one OR: every term must be non-negative (scalar arithmetic instead of a
-        // branch per comparison -- this prologue runs once per macroblock and was most of a skipped macroblock's cost).
-        // Integer luma vectors (78 % of the inter macroblocks of the bench streams; with "all 16 blocks alike": 71 %) need no
-        // interpolation window at all: every lane fetches its own 4 luma samples and the 3 x 2 chroma samples of its pair
-        // (chroma vectors have 1/8 precision: half-sample positions remain) with unaligned dword loads, no LDS, no barrier.
-        const int cxh = (mvx0 >> 2) & 1, cyh = (mvy0 >> 2) & 1; // integer luma vector: the chroma vector sits on a half sample iff this bit is set
-        const int dneg = X0 | Y0 | (W - 16 - X0) | (H - 16 - Y0) | cx0 | cy0 | (W / 2 - 8 - cxh - cx0) | (H / 2 - 8 - cyh - cy0) | rslots[0] | -((mvx0 | mvy0) & 3);
-        int uniform = 0;
-        if (dneg >= 0 && same_v) {
-            uniform = 2;
-            const g8 *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rslots[0]), max_slot)) * pool_slot_bytes;
-            const int b = lane >> 2, r = lane & 3;
-            dl = *reinterpret_cast<const g32 *>(ref + static_cast<uint32_t>((Y0 + (b >> 2) * 4 + r) * W + X0 + (b & 3) * 4));
-            const int c = lane >> 5, q = lane & 31, cy = q >> 2, cx = (q & 3) * 2;
-            const g8 *cp = ref + static_cast<uint32_t>(static_cast<int>(ysz) + c * static_cast<int>(ysz / 4) + (cy0 + cy) * (W / 2) + cx0 + cx);
-            dc0 = *reinterpret_cast<const g32 *>(cp);
-            dc1 = cyh ? *reinterpret_cast<const g32 *>(cp + W / 2) : dc0;
-        } else if ((uniform = same_v && (x0 | y0 | (W - 21 - x0) | (H - 21 - y0) | cx0 | cy0 | (W / 2 - 9 - cx0) | (H / 2 - 9 - cy0) | rslots[0]) >= 0) != 0) {
-            const g8 *ref = pool_base + static_cast<size_t>(min(static_cast<int>(rslots[0]), max_slot)) * pool_slot_bytes;
-            ox = x0 & 3;
-            const int xa = x0 - ox;
-            for (int i = lane; i < 21 * 6; i += 64) {
-                int r = i / 6, d = i - r * 6;
-                *reinterpret_cast<uint32_t *>(&sh.win16[r][d * 4]) = *reinterpret_cast<const g32 *>(ref + static_cast<size_t>(y0 + r) * W + xa + d * 4);
-            }
-            ocx = cx0 & 3;
-            const int cxa = cx0 - ocx;
-            if (lane < 54) {
-                int c = lane / 27, rem = lane - c * 27, r = rem / 3, d = rem - r * 3;
-                const g8 *cref = ref + ysz + static_cast<size_t>(c) * (ysz / 4);
-                *reinterpret_cast<uint32_t *>(&sh.winc16[c][r][d * 4]) = *reinterpret_cast<const g32 *>(cref + static_cast<size_t>(cy0 + r) * (W / 2) + cxa + d * 4);
-            }
-        } else {
-            for (int i = lane; i < 16 * 81; i += 64) {
-                int b = i / 81, rem = i - b * 81, wy = rem / 9, wx = rem - wy * 9;
-                int slot = rslots[((b >> 3) << 1) | ((b & 3) >> 1)];
-                int mvx = mvs[b][0], mvy = mvs[b][1];
-                int x = mbx * 16 + (b & 3) * 4 + (mvx >> 2) - 2 + wx, y = mby * 16 + (b >> 2) * 4 + (mvy >> 2) - 2 + wy;
-                x = min(max(x, 0), W - 1), y = min(max(y, 0), H - 1);
-                const g8 *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool_slot_bytes;
-                sh.win_y[b][wy][wx] = ref[static_cast<size_t>(y) * W + x];
-            }
-            for (int i = lane; i < 2 * 16 * 9; i += 64) {
-                int c = i / 144, rem = i - c * 144, b = rem / 9, r9 = rem - b * 9, wy = r9 / 3, wx = r9 - wy * 3;
-                int slot = rslots[((b >> 3) << 1) | ((b & 3) >> 1)];
-                int mvx = mvs[b][0], mvy = mvs[b][1];
-                int x = mbx * 8 + (b & 3) * 2 + (mvx >> 3) + wx, y = mby * 8 + (b >> 2) * 2 + (mvy >> 3) + wy;
-                x = min(max(x, 0), W / 2 - 1), y = min(max(y, 0), H / 2 - 1);
-                const g8 *ref = pool_base + static_cast<size_t>(min(max(slot, 0), max_slot)) * pool_slot_bytes + ysz + static_cast<size_t>(c) * (ysz / 4);
-                sh.win_c[c][b][wy][wx] = ref[static_cast<size_t>(y) * (W / 2) + x];
-            }
-        }
-        stage_mode = uniform;
-    };
-    // which lists the macroblock predicts from (wave-uniform); a record without any usable reference is concealed from list 0
-    bool use_l0 = true, use_l1 = false;
-    if (B) {
-        use_l1 = rec->refslot1[0] >= 0 || rec->refslot1[1] >= 0 || rec->refslot1[2] >= 0 || rec->refslot1[3] >= 0;
-        use_l0 = rec->refslot[0] >= 0 || rec->refslot[1] >= 0 || rec->refslot[2] >= 0 || rec->refslot[3] >= 0 || !use_l1;
-        if (!use_l0) mvs = sh_mv1->mv, rslots = rec->refslot1;
-    }
-    stage();
-    // ---- residual (independent of the prediction) ----
-    if (has_res) {
-        int16_t *coef_lds = sh.rb.luma; // overlay, see InterShared
-        if (lane < MI_COEF_BLOCKS) reinterpret_cast<uint4 *>(coef_lds)[2 * lane] = cv0, reinterpret_cast<uint4 *>(coef_lds)[2 * lane + 1] = cv1;
-        __syncthreads();
-        mb_residual(lane, rec, coef_lds, &tab->scaling[pd->scaling_set], &sh.rb);
-    }
-    __syncthreads();
-    const SliceDesc *sd = &slices[rec->slice_idx];
-    const int wp = B ? sd->wp_flag : pd->weighted_pred;
-    g8 *dst_base = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pool_slot_bytes);
-    int pv[4], pc[2];          // prediction of the list being processed: luma row of 4, chroma pair
-    int pv0[4] = {0, 0, 0, 0}, pc0[2] = {0, 0}; // B: list-0 prediction while list 1 is computed
-    // ---- luma: lane = (4x4 block, row) -> 4 samples ----
-    auto predict_luma = [&]() {
-        const int b = lane >> 2, r = lane & 3;
-        const int uni = stage_mode;
-        if (uni == 2) { // direct path: integer sample positions
-#pragma unroll
-            for (int i = 0; i < 4; i++) pv[i] = static_cast<int>((dl >> (8 * i)) & 255u);
-            return;
-        }
-        // The interpolation is written once and instantiated twice: for motion-uniform macroblocks (85 % of them) the
-        // fractional position is a SCALAR (readfirstlane), so the class switch below compiles to scalar branches instead of
-        // five exec-masked regions; the general instance keeps per-lane positions.
-        auto interpolate = [&](const int fx, const int fy, const bool U) {
-        // row j of this lane's 9x9 window: per-block window (stride 12) or the shared 21x21 one (stride 24, byte offset ox + 4*bx)
-        const int boff = U ? ox + (b & 3) * 4 : 0;
-        const uint8_t *wbase = U ? &sh.win16[(b >> 2) * 4 + r][(boff >> 2) * 4] : &sh.win_y[b][r][0];
-        const int wstride = U ? 24 : 12, sh8 = (boff & 3) * 8;
-        auto load_row = [&](int j, int (&q)[9]) {
-            const uint32_t *row = reinterpret_cast<const uint32_t *>(wbase + j * wstride);
-            uint64_t lo = row[0] | (static_cast<uint64_t>(row[1]) << 32), hi = row[1] | (static_cast<uint64_t>(row[2]) << 32);
-            uint32_t w0 = static_cast<uint32_t>(lo >> sh8), w1 = static_cast<uint32_t>(hi >> sh8), w2 = row[2] >> sh8;
-            q[0] = w0 & 255, q[1] = (w0 >> 8) & 255, q[2] = (w0 >> 16) & 255, q[3] = w0 >> 24;
-            q[4] = w1 & 255, q[5] = (w1 >> 8) & 255, q[6] = (w1 >> 16) & 255, q[7] = w1 >> 24;
-            q[8] = w2 & 255;
-        };
-        // 8.4.2.2.1 by class of fractional position, so that a lane computes only the intermediates its position
-        // needs (motion-uniform macroblocks take one branch for the whole wavefront):
-        //   0 integer | 1 horizontal only (b) | 2 vertical only (h) | 3 diagonal quarter (b|s with h|m) | 4 around the centre (j)
-        const int cls = (fx | fy) == 0 ? 0 : (fy == 0 ? 1 : (fx == 0 ? 2 : ((fx & fy & 1) ? 3 : 4)));
-        if (cls == 0) {
-            int q[9];
-            load_row(2, q);
-#pragma unroll
-            for (int i = 0; i < 4; i++) pv[i] = q[i + 2];
-        } else if (cls == 1) {
-            int q[9];
-            load_row(2, q);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int bb = clip255((tap6(q[i], q[i + 1], q[i + 2], q[i + 3], q[i + 4], q[i + 5]) + 16) >> 5);
-                pv[i] = fx == 2 ? bb : ((fx == 1 ? q[i + 2] : q[i + 3]) + bb + 1) >> 1;
-            }
-        } else {
-            int p[6][9];
-#pragma unroll
-            for (int j = 0; j < 6; j++) load_row(j, p[j]);
-            if (cls == 2) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int hh = clip255((tap6(p[0][i + 2], p[1][i + 2], p[2][i + 2], p[3][i + 2], p[4][i + 2], p[5][i + 2]) + 16) >> 5);
-                    pv[i] = fy == 2 ? hh : ((fy == 1 ? p[2][i + 2] : p[3][i + 2]) + hh + 1) >> 1;
-                }
-            } else if (cls == 3) {
-                const int rsel = fy == 3, csel = fx == 3; // row 2 (b) or 3 (s); column i+2 (h) or i+3 (m)
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    int hrow[6], vcol[6];
-#pragma unroll
-                    for (int k = 0; k < 6; k++) hrow[k] = rsel ? p[3][i + k] : p[2][i + k], vcol[k] = csel ? p[k][i + 3] : p[k][i + 2];
-                    const int hv = clip255((tap6(hrow[0], hrow[1], hrow[2], hrow[3], hrow[4], hrow[5]) + 16) >> 5);
-                    const int vv = clip255((tap6(vcol[0], vcol[1], vcol[2], vcol[3], vcol[4], vcol[5]) + 16) >> 5);
-                    pv[i] = (hv + vv + 1) >> 1;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    int hb[6];
-#pragma unroll
-                    for (int j = 0; j < 6; j++) hb[j] = tap6(p[j][i], p[j][i + 1], p[j][i + 2], p[j][i + 3], p[j][i + 4], p[j][i + 5]);
-                    const int jj = clip255((tap6(hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]) + 512) >> 10);
-                    int v = jj;
-                    if (fy != 2) // (2,1): b + j, (2,3): s + j
-                        v = (clip255(((fy == 1 ? hb[2] : hb[3]) + 16) >> 5) + jj + 1) >> 1;
-                    else if (fx != 2) { // (1,2): h + j, (3,2): m + j
-                        int vc[6];
-#pragma unroll
-                        for (int k = 0; k < 6; k++) vc[k] = fx == 1 ? p[k][i + 2] : p[k][i + 3];
-                        const int hm = clip255((tap6(vc[0], vc[1], vc[2], vc[3], vc[4], vc[5]) + 16) >> 5);
-                        v = (hm + jj + 1) >> 1;
-                    }
-                    pv[i] = v;
-                }
-            }
-        }
-        };
-        {
-            const int mvx = mvs[b][0], mvy = mvs[b][1];
-            if (uni)
-                interpolate(__builtin_amdgcn_readfirstlane(mvx & 3), __builtin_amdgcn_readfirstlane(mvy & 3), true);
-            else
-                interpolate(mvx & 3, mvy & 3, false);
-        }
-    };
-    // ---- chroma: lane = (plane, row, column pair) -> 2 samples ----
-    auto predict_chroma = [&]() {
-        const int c = lane >> 5, q = lane & 31, cy = q >> 2, cx = (q & 3) * 2;
-        const int b = (cy >> 1) * 4 + (cx >> 1);
-        const int mvx = mvs[b][0], mvy = mvs[b][1], xf = mvx & 7, yf = mvy & 7;
-        const int uni = stage_mode;
-        if (uni == 2) { // direct path: bytes 0..2 of dc0 / dc1 are rows cy, cy + 1 of this pair's neighbourhood
-            if (__builtin_amdgcn_readfirstlane(xf | yf) == 0) { // (the macroblock has ONE vector on this path)
-                pc[0] = dc0 & 255, pc[1] = (dc0 >> 8) & 255;
-                return;
-            }
-#pragma unroll
-            for (int i = 0; i < 2; i++) {
-                const int pa = (dc0 >> (8 * i)) & 255, pb = (dc0 >> (8 * i + 8)) & 255, pcc = (dc1 >> (8 * i)) & 255, pd_ = (dc1 >> (8 * i + 8)) & 255;
-                pc[i] = ((8 - xf) * (8 - yf) * pa + xf * (8 - yf) * pb + (8 - xf) * yf * pcc + xf * yf * pd_ + 32) >> 6;
-            }
-            return;
-        }
-        // 3x3 window of this 2x2 chroma block: per-block (row stride 4) or inside the shared 9x9 one (row stride 12)
-        const uint8_t *w = uni ? &sh.winc16[c][cy & ~1][ocx + (cx & ~1)] : &sh.win_c[c][b][0][0];
-        const int cstride = uni ? 12 : 4;
-        const int ry = cy & 1;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            int pa = w[ry * cstride + i], pb = w[ry * cstride + i + 1], pcc = w[(ry + 1) * cstride + i], pd_ = w[(ry + 1) * cstride + i + 1];
-            pc[i] = ((8 - xf) * (8 - yf) * pa + xf * (8 - yf) * pb + (8 - xf) * yf * pcc + xf * yf * pd_ + 32) >> 6;
-        }
-    };
-    predict_luma();
-    predict_chroma();
-    if (B && use_l0 && use_l1) { // second list through the same windows
-#pragma unroll
-        for (int i = 0; i < 4; i++) pv0[i] = pv[i];
-        pc0[0] = pc[0], pc0[1] = pc[1];
-        __syncthreads();
-        mvs = sh_mv1->mv, rslots = rec->refslot1;
-        stage();
-        __syncthreads();
-        predict_luma();
-        predict_chroma();
-    }
-    // ---- weighting (8.4.2.3), residual, store ----
-    // one sample: a = list-0 prediction, b = list-1 prediction, u0 / u1 = which lists the 8x8 quadrant uses
-    const BSliceExt *bx = (B && sd->slice_type == 1) ? &bexts[sd->bext] : nullptr;
-    const int wmode = B ? (bx ? bx->wp_mode : (sd->wp_flag ? 1 : 0)) : (wp ? 1 : 0); // 0 default, 1 explicit, 2 implicit
-    auto weigh = [&](int a, int b, bool u0, bool u1, int ld, int w0, int o0, int w1, int o1, int iw1) {
-        if (!B || !(u0 && u1)) {
-            int v = (!B || u0) ? a : b;
-            const int w = (!B || u0) ? w0 : w1, o = (!B || u0) ? o0 : o1;
-            if (wmode == 1) v = ld >= 1 ? clip255(((v * w + (1 << (ld - 1))) >> ld) + o) : clip255(v * w + o);
-            return v;
-        }
-        if (wmode == 1) return clip255(((a * w0 + b * w1 + (1 << ld)) >> (ld + 1)) + ((o0 + o1 + 1) >> 1));
-        if (wmode == 2) return clip255((a * (64 - iw1) + b * iw1 + 32) >> 6);
-        return (a + b + 1) >> 1;
-    };
-    {
-        const int b = lane >> 2, r = lane & 3, q8 = ((b >> 3) << 1) | ((b & 3) >> 1);
-        bool u0 = true, u1 = false;
-        int ref0 = rec->ref[q8], ref1 = 0;
-        if (B) {
-            u1 = rec->refslot1[q8] >= 0, u0 = rec->refslot[q8] >= 0 || !u1;
-            ref1 = MBREC_REF1(rec)[q8];
-        }
-        ref0 = max(ref0, 0) & (MI_MAX_REFS - 1), ref1 = max(ref1, 0) & (MI_MAX_REFS - 1);
-        int ld = 0, w0 = 1, o0 = 0, w1 = 1, o1 = 0, iw1 = 32; // the tables are only looked up (per lane: vector loads) when they are used
-        if (wmode == 1) {
-            ld = sd->luma_log2_denom, w0 = sd->wp_lw[ref0], o0 = sd->wp_lo[ref0];
-            if (bx) w1 = bx->wp_lw1[ref1], o1 = bx->wp_lo1[ref1];
-        } else if (B && wmode == 2)
-            iw1 = bx->implicit_w1[ref0][ref1];
-        const bool both = B && use_l0 && use_l1; // pv0 holds list 0 and pv list 1; otherwise pv is the only prediction there is
-        uint32_t packed = 0;
-        const int bxs = (b & 3) * 4, by = (b >> 2) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            int v = both ? weigh(pv0[i], pv[i], u0, u1, ld, w0, o0, w1, o1, iw1) : weigh(pv[i], pv[i], u0, u1 && !u0, ld, w0, o0, w1, o1, iw1);
-            if (has_res) v = clip255(v + sh.rb.luma[(by + r) * 16 + bxs + i]);
-            packed |= static_cast<uint32_t>(v) << (8 * i);
-        }
-        *reinterpret_cast<g32 *>(dst_base + static_cast<uint32_t>((mby * 16 + by + r) * W + mbx * 16 + bxs)) = packed;
-    }
-    {
-        const int c = lane >> 5, q = lane & 31, cy = q >> 2, cx = (q & 3) * 2;
-        const int b = (cy >> 1) * 4 + (cx >> 1), q8 = ((b >> 3) << 1) | ((b & 3) >> 1);
-        bool u0 = true, u1 = false;
-        int ref0 = rec->ref[q8], ref1 = 0;
-        if (B) {
-            u1 = rec->refslot1[q8] >= 0, u0 = rec->refslot[q8] >= 0 || !u1;
-            ref1 = MBREC_REF1(rec)[q8];
-        }
-        ref0 = max(ref0, 0) & (MI_MAX_REFS - 1), ref1 = max(ref1, 0) & (MI_MAX_REFS - 1);
-        int ld = 0, w0 = 1, o0 = 0, w1 = 1, o1 = 0, iw1 = 32;
-        if (wmode == 1) {
-            ld = sd->chroma_log2_denom, w0 = sd->wp_cw[ref0][c], o0 = sd->wp_co[ref0][c];
-            if (bx) w1 = bx->wp_cw1[ref1][c], o1 = bx->wp_co1[ref1][c];
-        } else if (B && wmode == 2)
-            iw1 = bx->implicit_w1[ref0][ref1];
-        const bool both = B && use_l0 && use_l1;
-        uint32_t packed = 0;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            int v = both ? weigh(pc0[i], pc[i], u0, u1, ld, w0, o0, w1, o1, iw1) : weigh(pc[i], pc[i], u0, u1 && !u0, ld, w0, o0, w1, o1, iw1);
-            if (has_res) v = clip255(v + sh.rb.chroma[c][cy * 8 + cx + i]);
-            packed |= static_cast<uint32_t>(v) << (8 * i);
-        }
-        *reinterpret_cast<g16 *>(dst_base + static_cast<uint32_t>(static_cast<int>(ysz) + c * static_cast<int>(ysz / 4) + (mby * 8 + cy) * (W / 2) + mbx * 8 + cx)) =
-            static_cast<uint16_t>(packed);
-    }
-}
-
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const FramePool *pools,
-                                                         const DevTables *tab, const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_log2, int n_blocks) {
-    __shared__ InterShared sh;
-    inter_mb<false>(sh, nullptr, pic_list, pics, slices, tab, mbrec, coefs, mbs_per_pic_log2, n_blocks, nullptr, nullptr);
-}
-// K4 for the pictures that have B slices
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) k_inter_b(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab,
-                                                           const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_log2, int n_blocks, const BSliceExt *bexts,
-                                                           const MbMv1 *mbmv1) {
-    __shared__ InterShared sh;
-    __shared__ MbMv1 sh_mv1;
-    inter_mb<true>(sh, &sh_mv1, pic_list, pics, slices, tab, mbrec, coefs, mbs_per_pic_log2, n_blocks, bexts, mbmv1);
 }
 
 // Motion a picture leaves for the direct prediction of later B pictures (ColRec, 8.4.1.2.1): one thread per macroblock.

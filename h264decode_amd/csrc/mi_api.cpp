@@ -1365,17 +1365,17 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     for (size_t w = 0; w < g.waves.size(); w++) {
         const uint32_t n = static_cast<uint32_t>(g.waves[w].size()), ni = g.wave_p_n[w], nbp = g.wave_b_n[w];
         if (!n) continue;
-        int mbs_log2 = 0; // K4 workgroups per picture: the largest picture's macroblock count rounded up to a power of two
-        while ((1 << mbs_log2) < g.mbs_max) mbs_log2++;
+        int grp_log2 = 0; // K4 workgroups per picture: the largest picture's count of four-macroblock groups, rounded up to a power of two
+        while ((4 << grp_log2) < g.mbs_max) grp_log2++;
         if (ni) {
-            const uint32_t nb = ni << mbs_log2;
-            hipLaunchKernelGGL(k_inter, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_p_off[w], g.d_pics, g.d_slices, d->d_pools,
-                               d->d_tables, mbrec, coef, mbs_log2, static_cast<int>(nb));
+            const uint32_t nb = ni << grp_log2;
+            hipLaunchKernelGGL(k_inter, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_p_off[w], g.d_pics, g.d_slices, d->d_tables, mbrec, coef, grp_log2,
+                               static_cast<int>(nb));
             mark(1);
         }
         if (nbp) {
-            const uint32_t nb = nbp << mbs_log2;
-            hipLaunchKernelGGL(k_inter_b, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_b_off[w], g.d_pics, g.d_slices, d->d_tables, mbrec, coef, mbs_log2,
+            const uint32_t nb = nbp << grp_log2;
+            hipLaunchKernelGGL(k_inter_b, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_b_off[w], g.d_pics, g.d_slices, d->d_tables, mbrec, coef, grp_log2,
                                static_cast<int>(nb), g.d_bext, d->d_mv1[set]);
             mark(1);
         }

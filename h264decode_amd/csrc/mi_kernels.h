@@ -11,14 +11,14 @@ extern "C" __global__ void k_entropy_b(const SliceDesc *slices, const PicDesc *p
                                        uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status, uint32_t *toprows, int wmb_max, uint32_t slice_base,
                                        const BSliceExt *bexts, MbMv1 *mbmv1);
 #define MI_TOPROW_BYTES 72 /* per macroblock column per slice (the B kernel's TopInfo; the I/P kernel uses 48 of them) */
-// K4: inter macroblocks of a set of pictures (one per stream), one macroblock per wavefront.
-// n_blocks = #pictures << mbs_per_pic_log2 (the largest picture's macroblock count rounded up to a power of two: no division in
-// the kernel); grid = n_blocks rounded up to a multiple of 8 (XCD-aware block order)
-extern "C" __global__ void k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const FramePool *pools, const DevTables *tab,
-                                   const MbRec *mbrec, const int16_t *coefs, int mbs_per_pic_log2, int n_blocks);
-// K4 for pictures with B slices: two lists per 8x8 quadrant (MbRec::refslot1, MbMv1), default / explicit / implicit weighting
+// K4 (k_inter.hip): inter macroblocks of a set of pictures (one per stream), one lane per 4x4 block, four macroblocks per wavefront.
+// n_blocks = #pictures << groups_per_pic_log2 (groups of four macroblocks per picture, rounded up to a power of two: no division in the kernel);
+// grid = n_blocks rounded up to a multiple of 8 (XCD-aware block order), block = 64
+extern "C" __global__ void k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec, const int16_t *coefs,
+                                   int groups_per_pic_log2, int n_blocks);
+// K4 for pictures with B slices: two lists per block (MbRec::refslot1, MbMv1), default / explicit / implicit weighting
 extern "C" __global__ void k_inter_b(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
-                                     const int16_t *coefs, int mbs_per_pic_log2, int n_blocks, const BSliceExt *bexts, const MbMv1 *mbmv1);
+                                     const int16_t *coefs, int groups_per_pic_log2, int n_blocks, const BSliceExt *bexts, const MbMv1 *mbmv1);
 // ColRec of a list of pictures (their motion, for the direct prediction of later B pictures); grid = (ceil(mbs_per_pic_max / 64), pictures), block = 64
 extern "C" __global__ void k_colsave(const uint32_t *pic_list, const PicDesc *pics, const MbRec *mbrec, const MbMv1 *mbmv1);
 // K3: intra macroblocks, one workgroup per picture, one wavefront per macroblock row (2-D wavefront order).

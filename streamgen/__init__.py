@@ -19,7 +19,8 @@ class Params(ctypes.Structure):
         "sub8x8_permille", "weighted_pred", "scaling_matrix", "noise")] + [("seed", ctypes.c_uint32),
         ("long_start_code", ctypes.c_int), ("poc_type", ctypes.c_int), ("rplm", ctypes.c_int), ("mmco", ctypes.c_int),
         ("idr_long_term", ctypes.c_int), ("nonref_period", ctypes.c_int), ("slice_qp_delta", ctypes.c_int), ("bframes", ctypes.c_int),
-        ("direct_temporal", ctypes.c_int), ("weighted_bipred", ctypes.c_int), ("bskip_permille", ctypes.c_int), ("b_pyramid", ctypes.c_int)]
+        ("direct_temporal", ctypes.c_int), ("weighted_bipred", ctypes.c_int), ("bskip_permille", ctypes.c_int),
+        ("motion_x4", ctypes.c_int), ("motion_y4", ctypes.c_int), ("b_pyramid", ctypes.c_int)]
 
 
 def build(force=False):

@@ -56,6 +56,8 @@ typedef struct {
     int direct_temporal;    /* 0: direct_spatial_mv_pred_flag = 1; 1: temporal direct */
     int weighted_bipred;    /* weighted_bipred_idc: 0 default average, 1 explicit, 2 implicit */
     int bskip_permille;     /* probability of B_Skip; B_Direct_16x16 gets half of it on top */
+    int motion_x4, motion_y4; /* motion of the synthetic scene per frame in quarter samples (default 12, -8 = whole samples (3, -2));
+                             * anything not a multiple of 4 makes fractional motion vectors the rule (6-tap interpolation) */
     int b_pyramid;          /* with bframes >= 2: the middle B picture of a group is coded first, as a REFERENCE picture (nal_ref_idc 2);
                              * the other B pictures of the group may predict from it and take it as their co-located picture */
 } sg_params;

@@ -72,6 +72,7 @@ void sg_default_params(sg_params *p) {
     p->width = 176, p->height = 144, p->frames = 2, p->profile_idc = 66, p->qp = 28, p->idr_period = 1, p->slices = 1;
     p->num_ref_frames = 1, p->cabac_init_idc = 0, p->noise = 8, p->seed = 1, p->long_start_code = 1;
     p->intra_in_p_permille = 50, p->skip_permille = 250, p->sub8x8_permille = 100;
+    p->motion_x4 = 12, p->motion_y4 = -8;
 }
 
 /* ------------------------------------------------------------------ PRNG + source */
@@ -86,23 +87,36 @@ static uint32_t hash32(uint32_t a) {
     a ^= a >> 16, a *= 0x7feb352du, a ^= a >> 15, a *= 0x846ca68bu, a ^= a >> 16;
     return a;
 }
-/* Y(x,y,t) = clip(128 + 64 sin((x+3t)/37) + 48 cos((y-2t)/23) + n), n ~ U[-noise,noise]; chroma analogous.
- * The noise field moves with the picture (3,-2) px/frame so that motion compensation is meaningful. */
+/* Y(x,y,t) = clip(128 + 64 sin((x+mx t)/37) + 48 cos((y+my t)/23) + n), n ~ U[-noise,noise]; chroma analogous.
+ * The picture -- its noise field included -- moves (mx, my) = (motion_x4, motion_y4) / 4 samples per frame ((3, -2) by default),
+ * so that motion compensation is meaningful; at fractional positions the noise field is interpolated bilinearly. */
+static double noise_at(double xs, double ys, uint32_t mulx, uint32_t muly, uint32_t seed, uint32_t range, int bias) {
+    double fx = floor(xs), fy = floor(ys), ax = xs - fx, ay = ys - fy, acc = 0;
+    int xi = (int)fx, yi = (int)fy;
+    for (int dy = 0; dy < 2; dy++)
+        for (int dx = 0; dx < 2; dx++) {
+            double w = (dx ? ax : 1 - ax) * (dy ? ay : 1 - ay);
+            if (w == 0) continue;
+            acc += w * ((int)(hash32((uint32_t)((xi + dx) * (int)mulx + (yi + dy) * (int)muly) ^ seed) % range) - bias);
+        }
+    return acc;
+}
 void sg_source_frame(const sg_params *p, int t, uint8_t *dst) {
     int W = (p->width + 15) & ~15, H = (p->height + 15) & ~15;
     uint8_t *y = dst, *cb = dst + W * H, *cr = cb + W * H / 4;
+    const double mx = p->motion_x4 * t / 4.0, my = p->motion_y4 * t / 4.0;
     for (int j = 0; j < H; j++)
         for (int i = 0; i < W; i++) {
-            int xs = i + 3 * t, ys = j - 2 * t;
+            double xs = i + mx, ys = j + my;
             double v = 128 + 64 * sin(xs / 37.0) + 48 * cos(ys / 23.0);
-            int n = p->noise ? (int)(hash32((uint32_t)(xs * 7919 + ys * 104729) ^ p->seed) % (uint32_t)(2 * p->noise + 1)) - p->noise : 0;
+            int n = p->noise ? (int)floor(noise_at(xs, ys, 7919u, 104729u, p->seed, (uint32_t)(2 * p->noise + 1), p->noise) + 0.5) : 0;
             int q = (int)floor(v + 0.5) + n;
             y[j * W + i] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
         }
     for (int j = 0; j < H / 2; j++)
         for (int i = 0; i < W / 2; i++) {
-            int xs = 2 * i + 3 * t, ys = 2 * j - 2 * t;
-            int n = p->noise ? (int)(hash32((uint32_t)(xs * 31337 + ys * 15485863) ^ (p->seed * 3u)) % (uint32_t)(p->noise + 1)) - p->noise / 2 : 0;
+            double xs = 2 * i + mx, ys = 2 * j + my;
+            int n = p->noise ? (int)floor(noise_at(xs, ys, 31337u, 15485863u, p->seed * 3u, (uint32_t)(p->noise + 1), p->noise / 2) + 0.5) : 0;
             int a = (int)floor(128 + 40 * sin(xs / 53.0 + 1.0) + 24 * cos(ys / 41.0) + 0.5) + n;
             int b = (int)floor(128 + 36 * cos(xs / 47.0) + 30 * sin(ys / 29.0 + 2.0) + 0.5) - n;
             cb[j * (W / 2) + i] = (uint8_t)(a < 0 ? 0 : (a > 255 ? 255 : a));
@@ -1056,9 +1070,10 @@ static void pick_mv(enc *e, int x, int y, int w, int h, sg_pic *ref, const int m
     int cand[6][2], n = 0, best = 0, bs = 1 << 30;
     uint8_t tmp[256];
     cand[n][0] = mvp[0], cand[n++][1] = mvp[1];
-    cand[n][0] = 12, cand[n++][1] = -8; /* true motion of the synthetic scene per frame */
-    cand[n][0] = 12 + rnd_range(e, -6, 6), cand[n++][1] = -8 + rnd_range(e, -6, 6);
-    cand[n][0] = 12 + rnd_range(e, -3, 3), cand[n++][1] = -8 + rnd_range(e, -3, 3);
+    const int tmx = e->p.motion_x4, tmy = e->p.motion_y4;
+    cand[n][0] = tmx, cand[n++][1] = tmy; /* true motion of the synthetic scene per frame */
+    cand[n][0] = tmx + rnd_range(e, -6, 6), cand[n++][1] = tmy + rnd_range(e, -6, 6);
+    cand[n][0] = tmx + rnd_range(e, -3, 3), cand[n++][1] = tmy + rnd_range(e, -3, 3);
     cand[n][0] = rnd_range(e, -64, 64), cand[n++][1] = rnd_range(e, -64, 64);
     cand[n][0] = 0, cand[n++][1] = 0;
     if (rnd(e) % 100 < 25)

@@ -92,6 +92,10 @@ MATRIX = {
     "weighted_pred": dict(BASE, frames=5, profile_idc=77, cabac=1, weighted_pred=1, num_ref_frames=2),
     # both weight denominators 7: the inferred default weight of an entry without a flag is 128, outside the coded range
     "weighted_pred_denom7": dict(BASE, frames=5, profile_idc=77, cabac=0, weighted_pred=2, num_ref_frames=3, seed=61),
+    # scene motion that is not a whole number of samples per frame: fractional vectors are the rule (every class of 8.4.2.2.1)
+    "frac_motion_cabac": dict(BASE, frames=5, profile_idc=77, cabac=1, motion_x4=11, motion_y4=-6, seed=63),
+    "frac_motion_sub8x8": dict(BASE, frames=5, profile_idc=66, cabac=0, sub8x8_permille=500, motion_x4=9, motion_y4=-7, num_ref_frames=2, seed=64),
+    "frac_motion_high8x8": dict(BASE, frames=5, profile_idc=100, cabac=1, transform8x8=1, motion_x4=2, motion_y4=3, qp=24, seed=66),
     "constrained_intra": dict(BASE, profile_idc=77, cabac=1, constrained_intra=1, intra_in_p_permille=300),
     "no_deblock": dict(BASE, profile_idc=77, cabac=1, deblock_idc=1),
     "dbf_offsets_cqp": dict(BASE, profile_idc=77, cabac=1, alpha_off_div2=3, beta_off_div2=-2, chroma_qp_offset=4),
@@ -123,6 +127,7 @@ MATRIX = {
     "b_temporal_cavlc": dict(BASE, frames=13, profile_idc=77, cabac=0, bframes=3, num_ref_frames=3, direct_temporal=1, bskip_permille=300, seed=46),
     "b_wp_explicit": dict(BASE, frames=10, profile_idc=77, cabac=1, bframes=2, num_ref_frames=3, weighted_bipred=1, weighted_pred=1, seed=47),
     "b_wp_explicit_denom7": dict(BASE, frames=10, profile_idc=77, cabac=1, bframes=2, num_ref_frames=3, weighted_bipred=1, weighted_pred=2, seed=62),
+    "b_frac_motion": dict(BASE, frames=10, profile_idc=77, cabac=1, bframes=2, num_ref_frames=3, motion_x4=10, motion_y4=-5, weighted_bipred=2, seed=65),
     "b_wp_implicit": dict(BASE, frames=10, profile_idc=77, cabac=0, bframes=2, num_ref_frames=4, weighted_bipred=2, direct_temporal=1, seed=48),
     "b_high8x8_slices": dict(BASE, frames=10, profile_idc=100, cabac=1, transform8x8=1, bframes=2, num_ref_frames=2, slices=3, sub8x8_permille=400,
                              cabac_init_idc=-1, seed=49),

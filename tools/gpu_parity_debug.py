@@ -91,6 +91,22 @@ def compare(name, kw, dec_cache={}):
             dy = (out[f][:W * H_] != rec[f][:W * H_]).reshape(H_ // 16, 16, W // 16, 16).any(axis=(1, 3))
             bad_mbs = np.nonzero(dy.reshape(-1))[0]
             print(f"   luma-mismatching MBs ({len(bad_mbs)}): {[(int(b), MBT[typ[b]] if typ[b] < 13 else int(typ[b])) for b in bad_mbs[:12]]}")
+            if os.environ.get("DEBUG_MB"):  # sample-level picture of the first few macroblocks that differ (luma, then Cb)
+                Yg, Yr = out[f][:W * H_].reshape(H_, W), rec[f][:W * H_].reshape(H_, W)
+                Cg, Cr_ = out[f][W * H_:W * H_ * 5 // 4].reshape(H_ // 2, W // 2), rec[f][W * H_:W * H_ * 5 // 4].reshape(H_ // 2, W // 2)
+                dc = (Cg != Cr_).reshape(H_ // 16, 8, W // 16, 8).any(axis=(1, 3)).reshape(-1)
+                for bmb in list(bad_mbs[:2]) + [int(x) for x in np.nonzero(dc)[0][:1]]:
+                    mx, my = bmb % (W // 16), bmb // (W // 16)
+                    r_ = recs[bmb]
+                    print(f"   mb {bmb} ({mx},{my}) type {typ[bmb]} t8x8 {t8[bmb]} cbp {cbp[bmb]:#x} qp {qp[bmb]} mv0 {r_[48:112].copy().view(np.int16).reshape(16, 2)[:4].tolist()}.. refslot {r_[36:44].copy().view(np.int16).tolist()} cmask {int(r_[116:120].copy().view(np.uint32)[0]):#x}")
+                    g_, w_ = Yg[my * 16:my * 16 + 16, mx * 16:mx * 16 + 16].astype(int), Yr[my * 16:my * 16 + 16, mx * 16:mx * 16 + 16].astype(int)
+                    print("   luma got - want:")
+                    for rr in range(16):
+                        print("     " + " ".join("%4d" % v for v in (g_ - w_)[rr]))
+                    g_, w_ = Cg[my * 8:my * 8 + 8, mx * 8:mx * 8 + 8].astype(int), Cr_[my * 8:my * 8 + 8, mx * 8:mx * 8 + 8].astype(int)
+                    print("   Cb got - want:")
+                    for rr in range(8):
+                        print("     " + " ".join("%4d" % v for v in (g_ - w_)[rr]))
             break
     dec.close()
     return False
