@@ -100,9 +100,33 @@ def extra_configs(H, streams, F, W, Hc, device, args):
     out["single_stream"] = r
     dec.close()
     del dec
+    # K4 on FRACTIONAL motion (SURVEY 8d C3 asks for quarter-sample vectors; the default scene moves whole samples): the same
+    # recipe with the scene moving (2.75, -1.5) samples per frame, 8 distinct streams replicated to the batch size of `value`
+    import streamgen
+    nf = 8
+    with ThreadPoolExecutor(max_workers=max(1, min(nf, (os.cpu_count() or 8) - 1))) as ex:
+        fgen = list(ex.map(lambda sd: streamgen.encode(want_recon=True, **streamgen.recipe("C3", frames=F, idr_period=F, seed=sd, width=W, height=args.height,
+                                                                                         motion_x4=11, motion_y4=-6)), range(2000, 2000 + nf)))
+    fstreams = [fgen[i % nf][0] for i in range(S)]
+    dec = H.Decoder(max_streams=S, max_width=W, max_height=Hc, max_frames_per_batch=F, max_slices_per_frame=1, device=device,
+                    max_bitstream_bytes=int(sum(len(s) for s in fstreams) * 1.1) + (1 << 20))
+    r = timed_fps(dec, fstreams, S * F, steps=max(2, min(args.steps, 5)))
+    got = dec.read_frames(S - 1, crop=False)
+    r["parity"] = "bit-exact vs streamgen recon (stream %d, all frames)" % (S - 1) if np.array_equal(got, fgen[(S - 1) % nf][1]) else "MISMATCH"
+    dec.set_profiling(True)
+    dec.execute()
+    dec.sync()
+    lt = np.array(dec.launch_times_ms("inter"))
+    dec.set_profiling(False)
+    fsz = W * Hc * 3 // 2
+    r["k_inter"] = {"ms": round(float(lt.mean()), 4), "GB/s": round(2.0 * fsz * S / (float(lt.mean()) * 1e-3) / 1e9, 2),
+                    "frac": round(2.0 * fsz * S / (float(lt.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    r["workload"] = "%d streams (%d distinct) x %d frames, scene motion (2.75, -1.5) samples per frame: fractional vectors are the rule" % (S, nf, F)
+    out["fractional_motion"] = r
+    dec.close()
+    del dec
     # B pictures: the same recipe coded I B B P ... (two B pictures between the anchors, three reference
     # frames, spatial direct), through k_entropy_b / k_inter_b / k_deblock_b.  16 distinct streams, each used twice.
-    import streamgen
     nb = 16
     with ThreadPoolExecutor(max_workers=max(1, min(nb, (os.cpu_count() or 8) - 1))) as ex:
         gen = list(ex.map(lambda sd: streamgen.encode(want_recon=True, **dict(streamgen.recipe("C3", frames=F, idr_period=F, seed=sd, width=W, height=args.height),
@@ -329,6 +353,7 @@ def main():
     hip_stream = torch.cuda.current_stream().cuda_stream
     dec = H.Decoder(max_streams=S, max_width=W, max_height=Hc, max_frames_per_batch=F, max_slices_per_frame=1, device=local_rank,
                     max_bitstream_bytes=int(sum(len(s) for s in streams) * 1.1) + (1 << 20), hip_stream=hip_stream)
+    hbm_bytes = dec.device_bytes()
     # ---- stage 1: inputs -> HBM (not timed) ----
     tp = time.time()
     info = dec.prepare(streams)
@@ -529,6 +554,7 @@ def main():
         "pipelined_ingest_fps": round(pipelined_fps, 2),
         "pipelined_ingest_note": "prepare(k+1) (host parse + H2D, second staging set) overlapped with execute(k); rank 0's own rate",
         "host_prepare_ms": round(prepare_s * 1e3, 2),
+        "hbm_bytes": {"decoder": hbm_bytes, "per_stream": int(hbm_bytes / S), "note": "device memory of the %d-stream decoder (I/P streams: what only B pictures need is allocated on demand)" % S},
         "parity": parity,
         "stream_gen_s": round(gen_s, 1),
     }

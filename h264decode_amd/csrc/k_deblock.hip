@@ -608,15 +608,21 @@ struct PrepSub {
     MbRec rec[3]; // current, left, upper macroblock
     MbMv1 mv1[3]; // their list-1 vectors (pictures with B slices)
     DbPrm out;
+    ColRec col;   // what later B pictures need of this macroblock's motion (pictures flagged save_col)
 };
 // grid = (ceil(macroblocks of the largest picture / MI_DBPREP_MBS), pictures), block = 256: a wavefront works on 4 macroblocks at a
 // time, 16 lanes each -- lane li computes the strength of segment li & 3 of vertical edge li >> 2 and of horizontal edge li >> 2
 // (the same division of labour K5 had when it did this itself), lanes 0..8 the parameters of (plane, edge kind) li / 3, li % 3.
-extern "C" __global__ void __launch_bounds__(256) k_dbprep(const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1, DbPrm *out) {
+// The same pass leaves the ColRec array of the pictures a later B picture (or batch) may take as co-located picture
+// (8.4.1.2.1: per 4x4 block the vector of the list the block uses -- list 0 if it uses it, otherwise list 1 --, per 8x8 the
+// reference index and the frame slot of the picture it points to; -1: intra): the records are staged here anyway.
+// col_only: the one-off back-fill of ColRec arrays for a batch whose DbPrm records are already in use (mi_api.cpp: ensure_b_buffers).
+extern "C" __global__ void __launch_bounds__(256) k_dbprep(const uint32_t *pic_list, const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1,
+                                                           DbPrm *out, int col_only) {
     __shared__ PrepSub subs[4][4];
     __shared__ uint8_t s_alpha[52], s_beta[52], s_tc0[52][4];
     const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63, sub = lane >> 4, li = lane & 15;
-    const PicDesc *pd = &pics[blockIdx.y];
+    const PicDesc *pd = &pics[pic_list[blockIdx.y]];
     const int wmb = static_cast<int>(pd->wmb), nmb = wmb * static_cast<int>(pd->hmb);
     const int mb_first = static_cast<int>(blockIdx.x) * MI_DBPREP_MBS;
     if (mb_first >= nmb) return;
@@ -687,9 +693,23 @@ extern "C" __global__ void __launch_bounds__(256) k_dbprep(const PicDesc *pics, 
                 ss->out.pl[plane].tc[kind][0] = s_tc0[ia][1], ss->out.pl[plane].tc[kind][1] = s_tc0[ia][2], ss->out.pl[plane].tc[kind][2] = s_tc0[ia][3];
                 if (kind == 0) ss->out.pl[plane].pad = 0;
             }
+            if (pd->save_col) { // lane li: block li's vector; lanes 0..3 also the reference of 8x8 quadrant li
+                const bool inter = MB_IS_INTER(mq->type);
+                const int q = ((li >> 3) << 1) | ((li & 3) >> 1);
+                const bool l0 = inter && mq->ref[q] >= 0, l1 = inter && !l0 && two && mq->refslot1[q] >= 0;
+                ss->col.mv[li][0] = l0 ? mq->mv[li][0] : (l1 ? ss->mv1[0].mv[li][0] : static_cast<int16_t>(0));
+                ss->col.mv[li][1] = l0 ? mq->mv[li][1] : (l1 ? ss->mv1[0].mv[li][1] : static_cast<int16_t>(0));
+                if (li < 4) {
+                    const bool q0 = inter && mq->ref[li] >= 0, q1 = inter && !q0 && two && mq->refslot1[li] >= 0;
+                    ss->col.refslot[li] = q0 ? mq->refslot[li] : (q1 ? mq->refslot1[li] : static_cast<int16_t>(-1));
+                    ss->col.ref[li] = q0 ? mq->ref[li] : (q1 ? MBREC_REF1(mq)[li] : static_cast<int8_t>(-1));
+                    ss->col.pad[li] = 0;
+                }
+            }
         }
         WAVE_SYNC();
-        if (valid && li < 5) reinterpret_cast<v4u *>(outs + mb)[li] = reinterpret_cast<const v4u *>(&ss->out)[li];
+        if (valid && !col_only && li < 5) reinterpret_cast<v4u *>(outs + mb)[li] = reinterpret_cast<const v4u *>(&ss->out)[li];
+        if (valid && pd->save_col && li < 5) reinterpret_cast<v4u *>(reinterpret_cast<ColRec *>(pd->col_out) + mb)[li] = reinterpret_cast<const v4u *>(&ss->col)[li];
         WAVE_SYNC();
     }
 }

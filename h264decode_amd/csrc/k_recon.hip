@@ -1,4 +1,4 @@
-// h264decode_amd/csrc/k_recon.hip -- K3 (intra reconstruction), k_colsave and K6 (crop + pack), gfx950.  (K4 is k_inter.hip.)
+// h264decode_amd/csrc/k_recon.hip -- K3 (intra reconstruction) and K6 (crop + pack), gfx950.  (K4 is k_inter.hip.)
 //
 // Everything here is byte / int16 work bounded by HBM traffic and LDS latency (no MFMA):
 //   residual: scaling (8.5.9, 8.5.12.1) + Intra16x16 / chroma DC transforms (8.5.10, 8.5.11) +
@@ -185,35 +185,6 @@ __device__ __forceinline__ void zero_residual(int lane, ResBuf *rb) {
     for (int i = lane; i < 128; i += 64) reinterpret_cast<uint32_t *>(rb->luma)[i] = 0;
     reinterpret_cast<uint32_t *>(rb->chroma)[lane] = 0;
     WAVE_SYNC();
-}
-
-// Motion a picture leaves for the direct prediction of later B pictures (ColRec, 8.4.1.2.1): one thread per macroblock.
-// grid = (ceil(mbs_per_pic_max / 64), pictures)
-extern "C" __global__ void __launch_bounds__(64) k_colsave(const uint32_t *pic_list, const PicDesc *pics, const MbRec *mbrec, const MbMv1 *mbmv1) {
-    const PicDesc *pd = &pics[pic_list[blockIdx.y]];
-    const uint32_t mb = blockIdx.x * 64 + threadIdx.x;
-    if (mb >= pd->wmb * pd->hmb) return;
-    const MbRec *r = mbrec + pd->mb_base + mb;
-    ColRec out;
-    const bool inter = MB_IS_INTER(r->type);
-    const bool need1 = inter && pd->has_b && (r->ref[0] < 0 || r->ref[1] < 0 || r->ref[2] < 0 || r->ref[3] < 0);
-    MbMv1 v1;
-    if (need1)
-        v1 = mbmv1[pd->mb_base + mb];
-    else
-        for (int i = 0; i < 16; i++) v1.mv[i][0] = v1.mv[i][1] = 0;
-    for (int q = 0; q < 4; q++) {
-        const bool l0 = inter && r->ref[q] >= 0, l1 = inter && !l0 && pd->has_b && r->refslot1[q] >= 0;
-        out.refslot[q] = l0 ? r->refslot[q] : (l1 ? r->refslot1[q] : static_cast<int16_t>(-1));
-        out.ref[q] = l0 ? r->ref[q] : (l1 ? MBREC_REF1(r)[q] : static_cast<int8_t>(-1));
-        for (int k = 0; k < 4; k++) {
-            const int b = (q >> 1) * 8 + (q & 1) * 2 + (k >> 1) * 4 + (k & 1);
-            out.mv[b][0] = l0 ? r->mv[b][0] : (l1 ? v1.mv[b][0] : static_cast<int16_t>(0));
-            out.mv[b][1] = l0 ? r->mv[b][1] : (l1 ? v1.mv[b][1] : static_cast<int16_t>(0));
-        }
-    }
-    out.pad[0] = out.pad[1] = out.pad[2] = out.pad[3] = 0;
-    reinterpret_cast<ColRec *>(pd->col_out)[mb] = out;
 }
 
 // ================================================================== K3: intra prediction

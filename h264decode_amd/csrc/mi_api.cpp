@@ -23,7 +23,7 @@
 using namespace mi;
 
 #ifndef MI_SETS
-#define MI_SETS 4
+#define MI_SETS 3 /* record / coefficient sets: a pass may run two passes ahead of the reconstruction that frees its set (a fourth set bought 1 % for 28 GB) */
 #endif
 
 #define HIP_TRY(x)                                                                          \
@@ -158,9 +158,10 @@ struct Stage {
     // first: slices are launched by level -- 0: I and P slices (k_entropy), n: B slices whose co-located picture is of level
     // n - 1 or older than the batch (k_entropy_b) -- and the slice table is ordered by level.
     std::vector<int> pic_level, slice_level; // per picture / per slice of the batch (slice_level in parse order, until the table is sorted)
-    std::vector<uint8_t> pic_save_col;       // the picture's motion is kept for later direct prediction (k_colsave)
+    std::vector<uint8_t> pic_save_col;       // the picture's motion is kept for later direct prediction (k_dbprep writes its ColRec array)
     std::vector<int> level_first;            // first slice of each level in the sorted table (+ end marker)
-    std::vector<uint32_t> colsave_off, colsave_n; // per level: pictures to run k_colsave on, as a range of d_lists
+    std::vector<uint32_t> colsave_n;            // per level: pictures whose ColRec array k_dbprep writes (what the cross-pass fence looks at)
+    std::vector<uint32_t> prep_off, prep_n;     // per level: the pictures whose last slice is of that level (k_dbprep runs on them after the level), as a range of d_lists
     std::vector<uint32_t> wave_b_off, wave_b_n, wave_p_off, wave_p_n, wave_nb_off, wave_nb_n; // per wave: B pictures / inter non-B / non-B
     int n_slices = 0, n_pics = 0, wmb_max = 0, hmb_max = 0, mbs_max = 0;
     uint64_t mb_used = 0;
@@ -204,6 +205,8 @@ struct h264mi_decoder {
     uint64_t pass = 0; // execute() counter
     bool last_pass_had_b = false;
     uint64_t mb_cap = 0;
+    uint64_t dev_bytes = 0;              // device memory this decoder holds (h264mi_decoder_memory)
+    uint32_t *d_backfill = nullptr;      // picture list of the one-off ColRec back-fill (first B slice of a decoder)
     FramePool *d_pools = nullptr;
     std::vector<FramePool> h_pools;
     uint8_t *d_frames = nullptr;
@@ -319,6 +322,7 @@ static void free_all(h264mi_decoder *d) {
     if (d->rec_stream) hipStreamDestroy(d->rec_stream);
     if (d->ev_user) hipEventDestroy(d->ev_user);
     if (d->d_colrec) hipFree(d->d_colrec);
+    if (d->d_backfill) hipFree(d->d_backfill);
     if (d->d_xring) hipFree(d->d_xring);
     if (d->d_xdone) hipFree(d->d_xdone);
     if (d->d_xctl) hipFree(d->d_xctl);
@@ -364,6 +368,12 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
         delete d;
         return code;
     };
+#define DEV_ALLOC(ptr, bytes)                      \
+    do {                                           \
+        const size_t _n = (bytes);                 \
+        TRY_ALLOC(hipMalloc(&(ptr), _n));          \
+        d->dev_bytes += _n;                        \
+    } while (0)
 #define TRY_ALLOC(x)                                                                 \
     do {                                                                             \
         hipError_t _e = (x);                                                         \
@@ -379,17 +389,17 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
         d->own_stream = true;
     }
     for (Stage &g : d->stage) {
-        TRY_ALLOC(hipMalloc(&g.d_bits, d->bits_cap));
+        DEV_ALLOC(g.d_bits, d->bits_cap);
         TRY_ALLOC(hipHostMalloc(&g.h_bits, d->bits_cap));
-        TRY_ALLOC(hipMalloc(&g.d_slices, sizeof(SliceDesc) * d->slices_cap));
+        DEV_ALLOC(g.d_slices, sizeof(SliceDesc) * d->slices_cap);
         TRY_ALLOC(hipHostMalloc(&g.h_slices, sizeof(SliceDesc) * d->slices_cap));
-        TRY_ALLOC(hipMalloc(&g.d_pics, sizeof(PicDesc) * d->pics_cap));
+        DEV_ALLOC(g.d_pics, sizeof(PicDesc) * d->pics_cap);
         TRY_ALLOC(hipHostMalloc(&g.h_pics, sizeof(PicDesc) * d->pics_cap));
-        TRY_ALLOC(hipMalloc(&g.d_status, sizeof(uint32_t) * 8 * d->slices_cap));
+        DEV_ALLOC(g.d_status, sizeof(uint32_t) * 8 * d->slices_cap);
         TRY_ALLOC(hipHostMalloc(&g.h_status, sizeof(uint32_t) * 8 * d->slices_cap));
-        TRY_ALLOC(hipMalloc(&g.d_lists, sizeof(uint32_t) * 5 * d->pics_cap));
-        TRY_ALLOC(hipHostMalloc(&g.h_lists, sizeof(uint32_t) * 5 * d->pics_cap));
-        TRY_ALLOC(hipMalloc(&g.d_bext, sizeof(BSliceExt) * d->slices_cap));
+        DEV_ALLOC(g.d_lists, sizeof(uint32_t) * 6 * d->pics_cap);
+        TRY_ALLOC(hipHostMalloc(&g.h_lists, sizeof(uint32_t) * 6 * d->pics_cap));
+        DEV_ALLOC(g.d_bext, sizeof(BSliceExt) * d->slices_cap);
         TRY_ALLOC(hipHostMalloc(&g.h_bext, sizeof(BSliceExt) * d->slices_cap));
         TRY_ALLOC(hipEventCreateWithFlags(&g.ev_upload, hipEventDisableTiming));
         TRY_ALLOC(hipEventCreateWithFlags(&g.ev_done, hipEventDisableTiming));
@@ -429,41 +439,41 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_user, hipEventDisableTiming));
     }
     for (int i = 0; i < MI_SETS; i++) {
-        TRY_ALLOC(hipMalloc(&d->d_mbrec[i], sizeof(MbRec) * d->mb_cap));
-        TRY_ALLOC(hipMalloc(&d->d_dbprm[i], sizeof(DbPrm) * d->mb_cap));
+        DEV_ALLOC(d->d_mbrec[i], sizeof(MbRec) * d->mb_cap);
+        DEV_ALLOC(d->d_dbprm[i], sizeof(DbPrm) * d->mb_cap);
         if (i == 0) {
             // Pool size.  The worst case is 26 blocks (832 bytes) per macroblock; real streams code a fraction of that (the
-            // 1080p QP 28 bench streams: ~5 blocks per macroblock).  Small decoders get the worst case; large ones 10 blocks
+            // 1080p QP 28 bench streams: ~5 blocks per macroblock).  Small decoders get the worst case; large ones 8 blocks
             // per macroblock, at least 1 GiB -- a batch that needs more fails with H264MI_EDECODE ("coefficient pool
             // exhausted", code 40) instead of reserving 3 x 52 GB for a case that does not occur.  H264MI_COEF_BLOCKS_PER_MB overrides.
             const uint64_t worst = d->mb_cap * MI_COEF_BLOCKS + static_cast<uint64_t>(d->slices_cap + 1) * MI_COEF_CHUNK;
-            uint64_t per_mb = 10;
+            uint64_t per_mb = 8;
             if (const char *e = getenv("H264MI_COEF_BLOCKS_PER_MB")) per_mb = static_cast<uint64_t>(std::min(std::max(atoi(e), 1), MI_COEF_BLOCKS));
             const uint64_t typical = std::max<uint64_t>(d->mb_cap * per_mb, (1ull << 30) / 32) + static_cast<uint64_t>(d->slices_cap + 1) * MI_COEF_CHUNK;
             d->pool_blocks = std::min<uint64_t>(std::min<uint64_t>(worst, typical), 0xFFFF0000ull);
-            TRY_ALLOC(hipMalloc(&d->d_pool_head, sizeof(uint32_t) * MI_SETS));
+            DEV_ALLOC(d->d_pool_head, sizeof(uint32_t) * MI_SETS);
         }
-        TRY_ALLOC(hipMalloc(&d->d_coef[i], d->pool_blocks * 32));
-        TRY_ALLOC(hipMalloc(&d->d_toprows[i], static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * MI_TOPROW_BYTES));
+        DEV_ALLOC(d->d_coef[i], d->pool_blocks * 32);
+        DEV_ALLOC(d->d_toprows[i], static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * MI_TOPROW_BYTES);
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_ent[i], hipEventDisableTiming));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_col[i], hipEventDisableTiming));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_rec[i], hipEventDisableTiming));
     }
-    TRY_ALLOC(hipMalloc(&d->d_pools, sizeof(FramePool) * S));
-    TRY_ALLOC(hipMalloc(&d->d_frames, d->slot_bytes * d->n_slots * S + 256)); // (K4's unaligned dword loads may read 3 bytes past a plane)
+    DEV_ALLOC(d->d_pools, sizeof(FramePool) * S);
+    DEV_ALLOC(d->d_frames, d->slot_bytes * d->n_slots * S + 256); // (K4's unaligned dword loads may read 3 bytes past a plane)
     // 80 bytes per macroblock and frame slot: whatever a later B picture may need of a reference picture's motion (8.4.1.2.1)
     d->colrec_per_slot = static_cast<size_t>(d->Wmax / 16) * (d->Hmax / 16);
-    TRY_ALLOC(hipMalloc(&d->d_colrec, sizeof(ColRec) * d->colrec_per_slot * d->n_slots * S));
-    TRY_ALLOC(hipMalloc(&d->d_tables, sizeof(DevTables)));
+    // (the ColRec arrays themselves -- 12.9 GB for 256 streams of 1080p -- are allocated when the first B slice arrives: ensure_b_buffers)
+    DEV_ALLOC(d->d_tables, sizeof(DevTables));
     TRY_ALLOC(hipHostMalloc(&d->h_tables, sizeof(DevTables)));
     // K5 keeps a whole macroblock row per in-flight group in dynamic LDS (up to 320 columns): opt in beyond 64 KB
     TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
     TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock_x), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
     // cross-workgroup hand-off state of the banded kernels; H264MI_X_WGS = 0 switches them off, n: up to n workgroups per launch
     if (const char *e = getenv("H264MI_X_WGS")) d->x_max_wgs = std::min(std::max(atoi(e), 0), d->x_cap);
-    TRY_ALLOC(hipMalloc(&d->d_xring, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long)));
-    TRY_ALLOC(hipMalloc(&d->d_xdone, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * sizeof(uint32_t)));
-    TRY_ALLOC(hipMalloc(&d->d_xctl, 3 * 128));
+    DEV_ALLOC(d->d_xring, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long));
+    DEV_ALLOC(d->d_xdone, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * sizeof(uint32_t));
+    DEV_ALLOC(d->d_xctl, 3 * 128);
     TRY_ALLOC(hipHostMalloc(&d->h_xstatus, sizeof(uint32_t)));
     *d->h_xstatus = 0;
     TRY_ALLOC(hipMemset(d->d_xring, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long)));
@@ -484,6 +494,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipMemsetAsync(d->d_frames, 128, d->slot_bytes * d->n_slots * S, d->stream));
     TRY_ALLOC(hipStreamSynchronize(d->stream));
 #undef TRY_ALLOC
+#undef DEV_ALLOC
     *out = d;
     return H264MI_OK;
 }
@@ -543,6 +554,11 @@ extern "C" int32_t h264mi_stream_status(h264mi_decoder *d, int32_t stream, int32
 extern "C" int32_t h264mi_decoder_set_isolation(h264mi_decoder *d, int32_t on) {
     if (!d) return H264MI_EINVAL;
     d->isolate = on != 0;
+    return H264MI_OK;
+}
+extern "C" int32_t h264mi_decoder_memory(h264mi_decoder *d, int64_t *device_bytes) {
+    if (!d || !device_bytes) return H264MI_EINVAL;
+    *device_bytes = static_cast<int64_t>(d->dev_bytes);
     return H264MI_OK;
 }
 extern "C" int32_t h264mi_decoder_set_profiling(h264mi_decoder *d, int32_t on) {
@@ -786,7 +802,11 @@ static int scaling_set_for(h264mi_decoder *d, const h264mi_pps &p) {
     return d->n_scaling++;
 }
 
-// The list-1 vector arrays exist only once a B slice has been seen (64 bytes per macroblock and buffer set).
+// What only B pictures need exists once the first B slice has been seen: the list-1 vector arrays (64 bytes per macroblock and
+// buffer set) and the ColRec arrays (80 bytes per macroblock and frame slot: the motion direct prediction reads).  Reference
+// pictures decoded BEFORE that moment have left no ColRec; the ones of the batch before this one -- where RefPicList1[0] of a
+// stream's first B picture can still come from -- are filled in now from that batch's records, which are still resident
+// (MI_STAGES staging sets, MI_SETS record sets).  Older ones cannot be: direct prediction from them sees an intra picture.
 static int ensure_b_buffers(h264mi_decoder *d) {
     for (int i = 0; i < MI_SETS; i++)
         if (!d->d_mv1[i]) {
@@ -795,7 +815,39 @@ static int ensure_b_buffers(h264mi_decoder *d) {
                 set_error("hipMalloc of the list-1 vector array failed: %s", hipGetErrorString(e));
                 return e == hipErrorOutOfMemory ? H264MI_ENOMEM : H264MI_EDEVICE;
             }
+            d->dev_bytes += sizeof(MbMv1) * d->mb_cap;
         }
+    if (d->d_colrec) return H264MI_OK;
+    const size_t S = d->st.size(), bytes = sizeof(ColRec) * d->colrec_per_slot * d->n_slots * S;
+    hipError_t e = hipMalloc(&d->d_colrec, bytes);
+    if (e == hipSuccess) e = hipMalloc(&d->d_backfill, sizeof(uint32_t) * d->pics_cap);
+    if (e != hipSuccess) {
+        set_error("hipMalloc of the co-located motion arrays failed: %s", hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? H264MI_ENOMEM : H264MI_EDEVICE;
+    }
+    d->dev_bytes += bytes + sizeof(uint32_t) * d->pics_cap;
+    hipStream_t up = d->ent_stream[d->pass & 1];
+    HIP_TRY(hipMemsetAsync(d->d_colrec, 0xFF, bytes, up)); // refslot / ref -1 everywhere: "intra" until a picture writes its own
+    Stage &pv = d->stage[(d->prep + MI_STAGES - 1) % MI_STAGES];
+    if (MI_STAGES > 1 && pv.executed && d->pass > 0) {
+        std::vector<uint32_t> list;
+        for (size_t si = 0; si < S; si++)
+            for (const OutFrame &o : pv.out[si])
+                if (d->st[si].slots[o.slot].ref && o.pic >= 0 && o.pic < pv.n_pics) { // still a reference picture: a B picture may point at it
+                    pv.h_pics[o.pic].save_col = 1;
+                    pv.h_pics[o.pic].col_out = reinterpret_cast<uint64_t>(d->d_colrec + (si * d->n_slots + o.slot) * d->colrec_per_slot);
+                    list.push_back(static_cast<uint32_t>(o.pic));
+                }
+        if (!list.empty()) {
+            const int pset = static_cast<int>((d->pass - 1) % MI_SETS);
+            HIP_TRY(hipStreamWaitEvent(up, d->ev_ent[pset], 0)); // that batch's records are complete
+            HIP_TRY(hipMemcpyAsync(pv.d_pics, pv.h_pics, sizeof(PicDesc) * pv.n_pics, hipMemcpyHostToDevice, up));
+            HIP_TRY(hipMemcpyAsync(d->d_backfill, list.data(), sizeof(uint32_t) * list.size(), hipMemcpyHostToDevice, up));
+            HIP_TRY(hipStreamSynchronize(up)); // (`list` is pageable host memory; once per decoder)
+            hipLaunchKernelGGL(k_dbprep, dim3((pv.mbs_max + MI_DBPREP_MBS - 1) / MI_DBPREP_MBS, static_cast<uint32_t>(list.size())), dim3(256), 0, up, d->d_backfill,
+                               pv.d_pics, d->d_tables, d->d_mbrec[pset], d->d_mv1[pset], d->d_dbprm[pset], 1);
+        }
+    }
     return H264MI_OK;
 }
 
@@ -885,7 +937,6 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         pd.stream = si, pd.slot = slot, pd.wmb = wmb, pd.hmb = hmb;
         pd.inv_wmb = static_cast<uint32_t>((1ull << 32) / static_cast<uint32_t>(wmb)) + 1u;
         pd.pool_base = d->h_pools[si].base, pd.slot_bytes = d->slot_bytes, pd.n_slots = static_cast<uint32_t>(d->n_slots);
-        pd.col_out = reinterpret_cast<uint64_t>(d->d_colrec + (static_cast<size_t>(si) * d->n_slots + slot) * d->colrec_per_slot);
         g.pic_level.resize(g.n_pics, 0), g.pic_save_col.resize(g.n_pics, 0);
         g.pic_level[s.cur_pic] = 0, g.pic_save_col[s.cur_pic] = 0;
         pd.mb_base = g.mb_used;
@@ -1232,12 +1283,18 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
             if (!g.h_pics[p].has_b) g.h_lists[pos++] = p;
         g.wave_nb_n[w] = pos - g.wave_nb_off[w];
     }
-    g.colsave_off.assign(n_levels, 0), g.colsave_n.assign(n_levels, 0);
+    g.colsave_n.assign(n_levels, 0), g.prep_off.assign(n_levels, 0), g.prep_n.assign(n_levels, 0);
     for (int l = 0; l < n_levels; l++) {
-        g.colsave_off[l] = pos;
+        g.prep_off[l] = pos;
         for (int i = 0; i < g.n_pics; i++)
-            if (g.pic_save_col[i] && g.pic_level[i] == l) g.h_lists[pos++] = i;
-        g.colsave_n[l] = pos - g.colsave_off[l];
+            if (g.pic_level[i] == l) {
+                g.h_lists[pos++] = i;
+                PicDesc &pd = g.h_pics[i];
+                pd.save_col = g.pic_save_col[i] && d->d_colrec != nullptr; // (no B slice seen yet: nothing to keep, see ensure_b_buffers)
+                pd.col_out = d->d_colrec ? reinterpret_cast<uint64_t>(d->d_colrec + (static_cast<size_t>(pd.stream) * d->n_slots + pd.slot) * d->colrec_per_slot) : 0;
+                g.colsave_n[l] += pd.save_col;
+            }
+        g.prep_n[l] = pos - g.prep_off[l];
     }
     // Uploads go to the entropy stream the next execute will use: in order with that pass's entropy kernel, and not behind
     // the batch that is still executing (the caller's stream waits for its reconstruction).  No stream of their own: the
@@ -1300,15 +1357,13 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     MbRec *mbrec = d->d_mbrec[set];
     int16_t *coef = d->d_coef[set];
     // Entropy decoding, level by level (Stage::level_first): k_entropy for the I / P slices, k_entropy_b for each level of B
-    // slices, and after each level k_colsave for the pictures whose motion a later B picture (or batch) will ask for.
-    // `done`: recorded after the LAST entropy launch -- what the reconstruction kernels wait for; the k_colsave behind it only
-    // matters to later B slices (ev_col), so it does not delay them (its workgroups trickle in between the next pass's
-    // entropy wavefronts and can take tens of milliseconds to drain).
+    // slices, and after each level k_dbprep for the pictures complete with it (K5's parameters; the ColRec arrays later B slices ask for).
+    // `done`: recorded after the last level's k_dbprep -- what the reconstruction kernels wait for.
     auto launch_entropy = [&](hipStream_t st, size_t lds_pad, bool fence_prev_pass, hipEvent_t done) {
         const int n_levels = static_cast<int>(g.level_first.size()) - 1;
         for (int lv = 0; lv < n_levels; lv++) {
             const int first = g.level_first[lv], n = g.level_first[lv + 1] - first;
-            // ColRec arrays cross passes: B slices read what the previous pass's k_colsave wrote, and this pass's k_colsave may
+            // ColRec arrays cross passes: B slices read what the previous pass's k_dbprep wrote, and this pass's k_dbprep may
             // rewrite the record array of a frame slot (released meanwhile) that the previous pass's B slices still read.  So
             // everything after the I/P launch waits for the previous pass's entropy stream -- the I/P launch itself does not,
             // it overlaps the previous pass's B launches; batches without B slices on both sides never wait.
@@ -1324,13 +1379,12 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
                     hipLaunchKernelGGL(k_entropy_b, dim3(n), dim3(64), 0, st, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
                                        static_cast<uint32_t>(d->pool_blocks), g.d_status, d->d_toprows[set], g.wmb_max, static_cast<uint32_t>(first), g.d_bext, d->d_mv1[set]);
             }
-            if (lv == n_levels - 1) { // every record of the batch exists now: K5's strengths and filter parameters, all pictures at once
-                hipLaunchKernelGGL(k_dbprep, dim3((g.mbs_max + MI_DBPREP_MBS - 1) / MI_DBPREP_MBS, g.n_pics), dim3(256), 0, st, g.d_pics, d->d_tables, mbrec, d->d_mv1[set],
-                                   d->d_dbprm[set]);
-                if (done) hipEventRecord(done, st);
-            }
-            if (g.colsave_n[lv])
-                hipLaunchKernelGGL(k_colsave, dim3((g.mbs_max + 63) / 64, g.colsave_n[lv]), dim3(64), 0, st, g.d_lists + g.colsave_off[lv], g.d_pics, mbrec, d->d_mv1[set]);
+            // the pictures complete with this level: K5's strengths and filter parameters, and the motion later B slices (the next
+            // level's, or a later batch's) take their direct prediction from
+            if (g.prep_n[lv])
+                hipLaunchKernelGGL(k_dbprep, dim3((g.mbs_max + MI_DBPREP_MBS - 1) / MI_DBPREP_MBS, g.prep_n[lv]), dim3(256), 0, st, g.d_lists + g.prep_off[lv], g.d_pics,
+                                   d->d_tables, mbrec, d->d_mv1[set], d->d_dbprm[set], 0);
+            if (lv == n_levels - 1 && done) hipEventRecord(done, st);
         }
     };
     if (prof) { // profiling serialises the two stages on one stream so that HIP-event intervals are per kernel
@@ -1341,14 +1395,14 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         mark(0);
     } else {
         HIP_TRY(hipStreamWaitEvent(es, g.ev_upload, 0));
-        if (d->pass >= MI_SETS) { // pass n-MI_SETS finished reading this set: its reconstruction kernels and its k_colsave
+        if (d->pass >= MI_SETS) { // pass n-MI_SETS finished reading this set: its reconstruction kernels and its entropy stream
             HIP_TRY(hipStreamWaitEvent(es, d->ev_rec[set], 0));
             HIP_TRY(hipStreamWaitEvent(es, d->ev_col[set], 0));
         }
         HIP_TRY(hipMemsetAsync(d->d_pool_head + set, 0, sizeof(uint32_t), es));
         launch_entropy(es, d->ent_lds_pad, (g.n_bext || d->last_pass_had_b) && d->pass > 0, d->ev_ent[set]);
         d->last_pass_had_b = g.n_bext > 0;
-        HIP_TRY(hipEventRecord(d->ev_col[set], es)); // entropy stream through with this pass, k_colsave included
+        HIP_TRY(hipEventRecord(d->ev_col[set], es)); // entropy stream through with this pass
         HIP_TRY(hipStreamWaitEvent(d->rec_stream, d->ev_ent[set], 0));
     }
     hipStream_t rs = prof ? d->stream : d->rec_stream;
@@ -1662,7 +1716,7 @@ extern "C" int32_t h264mi_internal_poison(h264mi_decoder *d) {
         HIP_TRY(hipMemset(d->d_toprows[i], 0xFF, static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * MI_TOPROW_BYTES));
         if (d->d_mv1[i]) HIP_TRY(hipMemset(d->d_mv1[i], 0xFF, sizeof(MbMv1) * d->mb_cap));
     }
-    HIP_TRY(hipMemset(d->d_colrec, 0xFF, sizeof(ColRec) * d->colrec_per_slot * d->n_slots * d->st.size()));
+    if (d->d_colrec) HIP_TRY(hipMemset(d->d_colrec, 0xFF, sizeof(ColRec) * d->colrec_per_slot * d->n_slots * d->st.size()));
     HIP_TRY(hipDeviceSynchronize());
     return H264MI_OK;
 }

@@ -19,8 +19,6 @@ extern "C" __global__ void k_inter(const uint32_t *pic_list, const PicDesc *pics
 // K4 for pictures with B slices: two lists per block (MbRec::refslot1, MbMv1), default / explicit / implicit weighting
 extern "C" __global__ void k_inter_b(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
                                      const int16_t *coefs, int groups_per_pic_log2, int n_blocks, const BSliceExt *bexts, const MbMv1 *mbmv1);
-// ColRec of a list of pictures (their motion, for the direct prediction of later B pictures); grid = (ceil(mbs_per_pic_max / 64), pictures), block = 64
-extern "C" __global__ void k_colsave(const uint32_t *pic_list, const PicDesc *pics, const MbRec *mbrec, const MbMv1 *mbmv1);
 // K3: intra macroblocks, one workgroup per picture, one wavefront per macroblock row (2-D wavefront order).
 extern "C" __global__ void k_intra(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
                                    const int16_t *coefs);
@@ -30,9 +28,10 @@ extern "C" __global__ void k_intra_x(const uint32_t *pic_list, const PicDesc *pi
                                      const int16_t *coefs, uint32_t *xdone, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max,
                                      uint32_t *xstatus);
 // k_dbprep: boundary strengths + alpha / beta / tC0 of every macroblock of a batch (DbPrm), so that K5 -- one serial dependency chain per
-// picture -- has none of that work in its steps.  grid = (ceil(mbs_max / MI_DBPREP_MBS), pictures), block = 256; pictures in PicDesc order.
+// picture -- has none of that work in its steps; for the pictures flagged PicDesc::save_col also their ColRec array (the motion later B pictures
+// take their direct prediction from).  grid = (ceil(mbs_max / MI_DBPREP_MBS), pictures of the list), block = 256.
 #define MI_DBPREP_MBS 64
-extern "C" __global__ void k_dbprep(const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1, DbPrm *out);
+extern "C" __global__ void k_dbprep(const uint32_t *pic_list, const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1, DbPrm *out, int col_only);
 // K5: in-loop deblocking, one workgroup per picture, one wavefront per group of 4 macroblock rows (up to 16 groups side by side).
 // block = 64 * nwaves, dynamic LDS = mi_deblock_lds_bytes(nwaves, ring, ring_last); (nwaves, ring, ring_last) from mi_deblock_plan()
 extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring, int ring_last, int last_bufs);

@@ -71,7 +71,7 @@ typedef struct __attribute__((aligned(16))) {
 
 /* Motion a picture leaves behind for the direct prediction of later B pictures (8.4.1.2.1): per 4x4 block the vector of
  * the list the co-located block uses (list 0 if it uses it, otherwise list 1), per 8x8 the reference index and the frame
- * slot of the picture it points to (-1: intra).  One array per frame slot, written by k_colsave. */
+ * slot of the picture it points to (-1: intra).  One array per frame slot, written by k_dbprep. */
 typedef struct __attribute__((aligned(16))) {
     int16_t mv[16][2];
     int16_t refslot[4];
@@ -148,8 +148,9 @@ typedef struct {
     uint64_t pool_base;    /* device address of slot 0 */
     uint64_t slot_bytes;
     uint64_t col_out;      /* ColRec array of this picture's frame slot */
-    uint8_t has_b;         /* the picture has B slices: MbMv1 records exist, K4 / K5 run their two-list variants */
-    uint8_t pad[3];
+    uint8_t has_b;         /* the picture has B slices: MbMv1 records exist, K4 runs its two-list variant */
+    uint8_t save_col;      /* a later B picture (or batch) may ask for this picture's motion: k_dbprep also writes its ColRec array */
+    uint8_t pad[2];
     uint32_t inv_wmb;      /* floor(2^32 / wmb) + 1: mby = mulhi(mb, inv_wmb) is exact for mb < 2^32 / wmb / wmb (wmb <= 512, hmb <= 320) */
 } PicDesc;
 

@@ -208,6 +208,12 @@ class Decoder:
         check(self._L.h264mi_frame_get_info(self._h, stream, frame, ctypes.byref(fi)))
         return fi
 
+    def device_bytes(self):
+        """Device memory the decoder holds right now (h264mi_decoder_memory)."""
+        n = ctypes.c_int64()
+        check(self._L.h264mi_decoder_memory(self._h, ctypes.byref(n)))
+        return int(n.value)
+
     def set_profiling(self, on=True):
         check(self._L.h264mi_decoder_set_profiling(self._h, int(on)))
 

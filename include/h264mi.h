@@ -239,8 +239,15 @@ int32_t h264mi_last_kernel_times(h264mi_decoder *dec, double ms[5]);
  * *n receives the number of launches; at most cap values are written. */
 int32_t h264mi_last_launch_times(h264mi_decoder *dec, int32_t kernel, float *ms, int32_t cap, int32_t *n);
 
+/* Device memory (bytes) the decoder holds right now: everything is sized at create time, except what only B pictures need
+ * (list-1 vectors, co-located motion arrays), which is allocated when a stream's first B slice arrives. */
+int32_t h264mi_decoder_memory(h264mi_decoder *dec, int64_t *device_bytes);
+
 const char *h264mi_last_error_string(void);
 const char *h264mi_version(void);
+
+/* Exported but NOT part of the ABI (test hooks of this repository's own suite, may change or vanish): h264mi_internal_poison,
+ * h264mi_internal_deblock_plan, h264mi_internal_band_plan, h264mi_internal_deblock_phase_clocks. */
 
 #ifdef __cplusplus
 }

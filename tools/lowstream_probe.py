@@ -9,7 +9,8 @@ import h264decode_amd as H
 
 F = 30
 nd = 4
-gen = [streamgen.encode(want_recon=True, **streamgen.recipe("C3", frames=F, idr_period=F, seed=1000 + i, width=1920, height=1080)) for i in range(nd)]
+mot = [int(v) for v in os.environ.get("PROBE_MOTION", "12,-8").split(",")]  # scene motion per frame in quarter samples
+gen = [streamgen.encode(want_recon=True, **streamgen.recipe("C3", frames=F, idr_period=F, seed=1000 + i, width=1920, height=1080, motion_x4=mot[0], motion_y4=mot[1])) for i in range(nd)]
 for S in [int(a) for a in sys.argv[1:]] or [1, 32]:
     gops = 10 if S == 1 else 1
     streams = [b"".join(gen[(i + j) % nd][0] for j in range(gops)) for i in range(S)]
