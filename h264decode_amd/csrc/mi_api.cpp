@@ -117,6 +117,7 @@ struct Slot {
     // (The second half keeps h264mi_batch_execute repeatable: a slot freed by a marking operation in the middle of the
     // batch still holds the samples earlier pictures of the batch predict from.)
     bool held = false;
+    bool nonexisting = false; // a frame inferred by the gaps-in-frame_num process (8.2.5.2): a place in the window, no picture
     int pic = -1; // index into the PicDesc table of the batch being prepared, -1: decoded by an earlier batch
 };
 struct OutFrame { // a decoded picture of the current batch, with the geometry it was coded with
@@ -132,6 +133,7 @@ struct StreamState {
     int wmb = 0, hmb = 0;
     std::vector<Slot> slots;
     int prev_poc_msb = 0, prev_poc_lsb = 0, prev_frame_num = 0, prev_frame_num_offset = 0;
+    int prev_ref_frame_num = 0; // PrevRefFrameNum (7.4.3): frame_num of the previous reference picture; 0 after an IDR picture or operation 5
     // picture under construction
     int cur_slot = -1, cur_pic = -1, cur_slices = 0;
     h264mi_slice_header first_sh;
@@ -523,7 +525,7 @@ static void reset_stream(StreamState &s, bool keep_parameter_sets) {
     for (auto &sl : s.slots) sl = Slot();
     s.cur_slot = s.cur_pic = -1, s.cur_slices = 0;
     s.n_pics_in_batch = 0;
-    s.prev_poc_msb = s.prev_poc_lsb = s.prev_frame_num = s.prev_frame_num_offset = 0;
+    s.prev_poc_msb = s.prev_poc_lsb = s.prev_frame_num = s.prev_frame_num_offset = s.prev_ref_frame_num = 0;
     if (!keep_parameter_sets) {
         memset(s.sps_ok, 0, sizeof(s.sps_ok));
         memset(s.pps_ok, 0, sizeof(s.pps_ok));
@@ -636,7 +638,10 @@ static int build_ref_lists(StreamState &s, const h264mi_sps &sps, const h264mi_s
     } else { // 8.2.4.2.3: by PicOrderCnt relative to the current picture
         const int cur_poc = s.slots[s.cur_slot].poc;
         std::vector<int> before, after;
-        for (int i : st) (s.slots[i].poc < cur_poc ? before : after).push_back(i);
+        for (int i : st) {
+            if (s.slots[i].nonexisting && sps.pic_order_count_type == 0) continue; // 8.2.4.2.3: no PicOrderCnt, not in the lists of B slices
+            (s.slots[i].poc < cur_poc ? before : after).push_back(i);
+        }
         std::sort(before.begin(), before.end(), [&](int a, int b) { return s.slots[a].poc > s.slots[b].poc; });
         std::sort(after.begin(), after.end(), [&](int a, int b) { return s.slots[a].poc < s.slots[b].poc; });
         lists[0] = before;
@@ -703,6 +708,7 @@ static void mark_reference(StreamState &s, const h264mi_sps &sps) {
         cur.ref = 0;
         return;
     }
+    s.prev_ref_frame_num = sh.frame_num; // (operation 5 below: 0)
     if (sh.nal_unit_type == 5) {
         for (auto &sl : s.slots) sl.ref = 0;
         cur.ref = sh.long_term_reference_flag ? 2 : 1;
@@ -737,7 +743,7 @@ static void mark_reference(StreamState &s, const h264mi_sps &sps) {
                 for (auto &sl : s.slots)
                     if (&sl != &cur) sl.ref = 0;
                 cur.frame_num = 0, cur.poc = 0; // 8.2.1: tempPicOrderCnt is subtracted, the picture ends up at PicOrderCnt 0
-                s.prev_frame_num = s.prev_frame_num_offset = s.prev_poc_msb = s.prev_poc_lsb = 0;
+                s.prev_frame_num = s.prev_frame_num_offset = s.prev_poc_msb = s.prev_poc_lsb = s.prev_ref_frame_num = 0;
             } else if (op == 6) {
                 for (auto &o : s.slots)
                     if (o.ref == 2 && o.long_idx == sh.mmco_arg2[k]) o.ref = 0;
@@ -800,6 +806,55 @@ static int scaling_set_for(h264mi_decoder *d, const h264mi_pps &p) {
     d->h_tables->scaling[d->n_scaling] = tmp;
     d->tables_dirty = true;
     return d->n_scaling++;
+}
+
+// 8.2.5.2 decoding process for gaps in frame_num (h264/sps.go:311-312 parses the flag, nothing in the reference uses it): a
+// non-IDR picture whose frame_num is neither PrevRefFrameNum nor its successor says that reference frames are missing.  With
+// gaps_in_frame_num_value_allowed_flag every skipped value becomes a "non-existing" short-term frame that goes through the
+// sliding window like a decoded one -- it pushes older frames out and takes its place in the initial lists, so that the
+// indices of the surviving pictures come out as the encoder meant them.  Without the flag pictures were lost: the stream is
+// refused (H264MI_EBITSTREAM; with isolation it alone leaves the batch and waits for its next IDR picture) rather than
+// predicted from the wrong pictures.
+static int fill_frame_num_gap(h264mi_decoder *d, int si, const h264mi_sps &sps, const h264mi_slice_header &sh) {
+    StreamState &s = d->st[si];
+    if (sh.nal_unit_type == 5) return H264MI_OK;
+    const int max_fn = 1 << (sps.log2_max_frame_num_minus4 + 4), cur_fn = sh.frame_num;
+    const int expect = (s.prev_ref_frame_num + 1) % max_fn;
+    if (cur_fn == s.prev_ref_frame_num || cur_fn == expect) return H264MI_OK;
+    if (!sps.gaps_in_frame_num_value_allowed) {
+        set_error("stream %d: frame_num %d after %d: reference pictures are missing", si, cur_fn, s.prev_ref_frame_num);
+        return H264MI_EBITSTREAM;
+    }
+    const int maxref = std::max(sps.max_num_ref_frames, 1);
+    for (int fn = expect; fn != cur_fn; fn = (fn + 1) % max_fn) {
+        int nref = 0;
+        Slot *oldest = nullptr, *slot = nullptr;
+        for (auto &sl : s.slots) { // 8.2.5.3 with this frame as the current one
+            if (!sl.ref) continue;
+            nref++;
+            if (sl.ref == 1) {
+                sl.frame_num_wrap = sl.frame_num > fn ? sl.frame_num - max_fn : sl.frame_num;
+                if (!oldest || sl.frame_num_wrap < oldest->frame_num_wrap) oldest = &sl;
+            }
+        }
+        if (nref >= maxref && oldest) oldest->ref = 0;
+        for (auto &sl : s.slots)
+            if (!sl.ref && !sl.held && !slot) slot = &sl;
+        if (!slot) {
+            set_error("stream %d: frame pool exhausted", si);
+            return H264MI_ECAPACITY;
+        }
+        *slot = Slot();
+        slot->ref = 1, slot->nonexisting = true, slot->frame_num = fn;
+        if (sps.pic_order_count_type != 0) { // 8.2.1: as a reference frame with this frame_num (keeps FrameNumOffset right across a wrap)
+            h264mi_slice_header f;
+            memset(&f, 0, sizeof(f));
+            f.frame_num = fn, f.nal_ref_idc = 1, f.nal_unit_type = 1;
+            slot->poc = compute_poc(s, sps, f);
+        }
+        s.prev_ref_frame_num = fn;
+    }
+    return H264MI_OK;
 }
 
 // What only B pictures need exists once the first B slice has been seen: the list-1 vector arrays (64 bytes per macroblock and
@@ -907,6 +962,8 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         s.active_sps = pps.sps_id, s.wmb = wmb, s.hmb = hmb;
     }
     if (s.cur_slot < 0) { // first slice of a new picture
+        r = fill_frame_num_gap(d, si, sps, sh);
+        if (r != H264MI_OK) return r;
         if (s.n_pics_in_batch >= d->cfg.max_frames_per_batch || g.n_pics >= d->pics_cap) {
             set_error("stream %d: more than %d frames in one batch", si, d->cfg.max_frames_per_batch);
             return H264MI_ECAPACITY;

@@ -199,6 +199,7 @@ static int build_ref_list(h264o_decoder *d) {
         h264o_pic *before[20], *after[20];
         int nb = 0, na = 0, cur_poc = d->cur->poc;
         for (int i = 0; i < nst; i++) {
+            if (st[i]->nonexisting && d->asps->pic_order_cnt_type == 0) continue; /* 8.2.4.2.3: no PicOrderCnt, not in the lists of B slices */
             if (st[i]->poc < cur_poc)
                 before[nb++] = st[i];
             else
@@ -238,6 +239,7 @@ static void mark_reference(h264o_decoder *d) {
     const h264o_slice_header *sh = &d->first_sh;
     h264o_pic *cur = d->cur;
     int max_fn = 1 << (d->asps->log2_max_frame_num_minus4 + 4);
+    if (sh->nal_ref_idc) d->prev_ref_frame_num = sh->frame_num; /* 7.4.3 (operation 5 below: 0) */
     if (!sh->nal_ref_idc) {
         cur->ref = 0;
         d->feat |= 1u << 12;
@@ -287,6 +289,7 @@ static void mark_reference(h264o_decoder *d) {
                 cur->poc = 0; /* 8.2.1: tempPicOrderCnt is subtracted after decoding */
                 d->prev_frame_num = 0;
                 d->prev_frame_num_offset = 0;
+                d->prev_ref_frame_num = 0;
                 d->prev_poc_msb = 0;
                 d->prev_poc_lsb = 0;
             } else if (op == 6) {
@@ -371,7 +374,51 @@ static int is_new_picture(const h264o_decoder *d, const h264o_slice_header *a, c
     return 0;
 }
 
+/* 8.2.5.2 decoding process for gaps in frame_num (h264/sps.go:311-312 parses the flag, nothing in the reference uses it):
+ * frame_num of a non-IDR picture that is neither PrevRefFrameNum nor its successor means reference frames are missing.
+ * With gaps_in_frame_num_value_allowed_flag every skipped value becomes a "non-existing" short-term frame that goes through
+ * the sliding window like a decoded one (it pushes older frames out and takes its place in the initial lists, so that
+ * the indices of the surviving pictures come out as the encoder meant them); without the flag pictures were lost. */
+static int fill_frame_num_gap(h264o_decoder *d) {
+    const h264o_sps *s = d->asps;
+    const int max_fn = 1 << (s->log2_max_frame_num_minus4 + 4), cur_fn = d->sh.frame_num;
+    if (d->sh.idr_flag) return 0;
+    const int expect = (d->prev_ref_frame_num + 1) % max_fn;
+    if (cur_fn == d->prev_ref_frame_num || cur_fn == expect) return 0;
+    if (!s->gaps_in_frame_num_value_allowed_flag) return h264o_fail(d, "frame_num %d after %d: reference pictures are missing", cur_fn, d->prev_ref_frame_num);
+    const int maxref = s->max_num_ref_frames > 0 ? s->max_num_ref_frames : 1;
+    for (int fn = expect; fn != cur_fn; fn = (fn + 1) % max_fn) {
+        int nref = 0;
+        h264o_pic *oldest = NULL, *slot = NULL;
+        for (int i = 0; i < d->n_pics; i++) { /* 8.2.5.3 with this frame as the current one */
+            h264o_pic *p = &d->pics[i];
+            if (!p->ref) continue;
+            nref++;
+            if (p->ref == 1) {
+                p->frame_num_wrap = p->frame_num > fn ? p->frame_num - max_fn : p->frame_num;
+                if (!oldest || p->frame_num_wrap < oldest->frame_num_wrap) oldest = p;
+            }
+        }
+        if (nref >= maxref && oldest) oldest->ref = 0;
+        for (int i = 0; i < d->n_pics && !slot; i++)
+            if (!d->pics[i].ref && !d->pics[i].in_use) slot = &d->pics[i];
+        if (!slot) return h264o_fail(d, "DPB full");
+        slot->ref = 1, slot->nonexisting = 1, slot->frame_num = fn, slot->id = d->next_pic_id++, slot->n_mbs = 0;
+        slot->poc = 0;
+        if (s->pic_order_cnt_type != 0) { /* 8.2.1: as a reference frame with this frame_num (keeps FrameNumOffset right across a wrap) */
+            h264o_slice_header f;
+            memset(&f, 0, sizeof(f));
+            f.frame_num = fn, f.nal_ref_idc = 1;
+            slot->poc = compute_poc(d, &f);
+        }
+        d->prev_ref_frame_num = fn;
+        d->feat |= 1u << 15;
+    }
+    return 0;
+}
+
 static int start_picture(h264o_decoder *d) {
+    if (fill_frame_num_gap(d) < 0) return -1;
     h264o_pic *p = NULL;
     for (int i = 0; i < d->n_pics; i++)
         if (!d->pics[i].ref && !d->pics[i].in_use) {
@@ -381,6 +428,7 @@ static int start_picture(h264o_decoder *d) {
     if (!p) return h264o_fail(d, "DPB full");
     d->cur = p;
     p->in_use = 1;
+    p->nonexisting = 0;
     p->id = d->next_pic_id++;
     p->frame_num = d->sh.frame_num;
     p->poc = compute_poc(d, &d->sh);

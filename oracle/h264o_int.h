@@ -14,6 +14,7 @@ typedef struct {
     int stride[3];
     int frame_num, frame_num_wrap, pic_num, poc;
     int ref; /* 0 unused, 1 short-term, 2 long-term */
+    int nonexisting; /* a frame inferred by the gaps-in-frame_num process (8.2.5.2): it fills a place in the window, holds no picture */
     int long_term_frame_idx;
     int id; /* unique, increasing */
     int in_use;
@@ -69,6 +70,7 @@ struct h264o_decoder {
     h264o_mb *mb;
     /* POC state (8.2.1) */
     int prev_poc_msb, prev_poc_lsb, prev_frame_num, prev_frame_num_offset, prev_ref_has_mmco5;
+    int prev_ref_frame_num; /* PrevRefFrameNum (7.4.3): frame_num of the previous reference picture, 0 after an IDR picture or operation 5 */
     /* slice state */
     h264o_slice_header sh;
     h264o_slice_header first_sh; /* first slice header of the current picture */

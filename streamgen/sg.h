@@ -58,6 +58,10 @@ typedef struct {
     int bskip_permille;     /* probability of B_Skip; B_Direct_16x16 gets half of it on top */
     int motion_x4, motion_y4; /* motion of the synthetic scene per frame in quarter samples (default 12, -8 = whole samples (3, -2));
                              * anything not a multiple of 4 makes fractional motion vectors the rule (6-tap interpolation) */
+    int fn_gap_period;      /* N > 0 (streams without B pictures / marking scripts): before every N-th picture after an IDR picture
+                             * frame_num skips one or two values (8.2.5.2): the skipped frames enter the window as "non-existing"
+                             * frames and the lists are re-ordered so that only real pictures are predicted from */
+    int fn_gap_declared;    /* gaps_in_frame_num_value_allowed_flag of the SPS; 0 with fn_gap_period set = a stream that lost pictures */
     int b_pyramid;          /* with bframes >= 2: the middle B picture of a group is coded first, as a REFERENCE picture (nal_ref_idc 2);
                              * the other B pictures of the group may predict from it and take it as their co-located picture */
 } sg_params;

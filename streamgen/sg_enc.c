@@ -1746,7 +1746,7 @@ static size_t write_sps(enc *e, uint8_t *dst, size_t cap) {
         sg_put_se(&w, 6);   /* offset_for_ref_frame[1] */
     }
     sg_put_ue(&w, (uint32_t)p->num_ref_frames);
-    sg_put(&w, 0, 1); /* gaps */
+    sg_put(&w, p->fn_gap_declared != 0, 1); /* gaps_in_frame_num_value_allowed_flag */
     sg_put_ue(&w, (uint32_t)(e->wmb - 1));
     sg_put_ue(&w, (uint32_t)(e->hmb - 1));
     sg_put(&w, 1, 1); /* frame_mbs_only */
@@ -1921,16 +1921,25 @@ static void plan_ref_list(enc *e) {
     e->n_rplm = 0;
     sg_pic *final[12];
     int nf = 0;
-    if (e->p.rplm && !(e->p.bframes > 0 && e->p.direct_temporal) && n >= 2 && rnd(e) % 100 < 75) { /* (temporal direct: see above) */
+    /* non-existing frames (frame_num gaps) sit in the window but are never predicted from: when one is among the active
+     * entries the list is re-ordered so that the real pictures come first, and cut behind them */
+    int nreal = 0, force_real = 0;
+    sg_pic *real[12];
+    for (int i = 0; i < n; i++) {
+        if (!init[i]->nonexist) real[nreal++] = init[i];
+        else if (i < e->nref_active) force_real = 1;
+    }
+    if (force_real) e->nref_active = nreal < e->nref_active ? nreal : e->nref_active;
+    if (force_real || (e->p.rplm && !(e->p.bframes > 0 && e->p.direct_temporal) && n >= 2 && rnd(e) % 100 < 75)) { /* (temporal direct: see above) */
         /* the first k entries become k distinct pictures picked from the WHOLE set of reference pictures */
-        int k = 1 + (int)(rnd(e) % (uint32_t)(e->nref_active < 3 ? e->nref_active : 3));
+        int k = force_real ? e->nref_active : 1 + (int)(rnd(e) % (uint32_t)(e->nref_active < 3 ? e->nref_active : 3));
         int pred = cur_fn; /* picNumL0Pred */
         for (int c = 0; c < k; c++) {
             sg_pic *t;
             int dup;
             do {
-                t = init[rnd(e) % (uint32_t)n];
-                dup = 0;
+                t = force_real ? real[c] : init[rnd(e) % (uint32_t)n];
+                dup = t->nonexist;
                 for (int j = 0; j < nf; j++) dup |= final[j] == t;
             } while (dup);
             final[nf++] = t;
@@ -2224,10 +2233,31 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             out += n;
             for (int i = 0; i < 6; i++) e->pics[i].is_ref = 0;
         }
+        /* frame_num gap (8.2.5.2): the skipped values enter the window as non-existing frames, oldest pictures leave */
+        if (p->fn_gap_period > 0 && p->bframes == 0 && !p->mmco && !idr && since_idr > 0 && since_idr % p->fn_gap_period == 0) {
+            const int skip = 1 + (int)(rnd(e) % 2u);
+            for (int k = 0; k < skip; k++) {
+                int n = 0, oldest = -1;
+                for (int i = 0; i < 6; i++) {
+                    if (!e->pics[i].is_ref) continue;
+                    n++;
+                    if (e->pics[i].is_ref == 1 && (oldest < 0 || picnum(&e->pics[i], frame_num) < picnum(&e->pics[oldest], frame_num))) oldest = i;
+                }
+                if (n >= p->num_ref_frames && oldest >= 0) e->pics[oldest].is_ref = 0;
+                sg_pic *ne = NULL;
+                for (int i = 0; i < 6 && !ne; i++)
+                    if (!e->pics[i].is_ref) ne = &e->pics[i];
+                ne->is_ref = 1, ne->nonexist = 1, ne->frame_num = frame_num, ne->id = e->next_id++, ne->poc = 0;
+                frame_num = (frame_num + 1) & (SG_MAX_FN - 1);
+                refs_since_reset++;
+                g_feat |= 1u << 15;
+            }
+        }
         /* current picture buffer */
         e->cur = NULL;
         for (int i = 0; i < 6 && !e->cur; i++)
             if (!e->pics[i].is_ref) e->cur = &e->pics[i];
+        e->cur->nonexist = 0;
         e->cur->id = e->next_id++;
         e->cur->frame_num = frame_num;
         e->cur_frame_num = frame_num;

@@ -42,6 +42,7 @@ typedef struct {
     int is_ref;   /* 0 unused for reference, 1 short-term, 2 long-term */
     int long_idx; /* LongTermFrameIdx when is_ref == 2 */
     int poc;
+    int nonexist; /* a frame that only exists as a skipped frame_num value (8.2.5.2): takes a place in the window, is never predicted from */
     void *motion; /* the picture's macroblock motion (an emb array of sg_enc.c): co-located data of later B pictures */
 } sg_pic;
 

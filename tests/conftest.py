@@ -117,6 +117,11 @@ MATRIX = {
     "poc1_mmco": dict(BASE, frames=20, profile_idc=77, cabac=1, num_ref_frames=4, poc_type=1, mmco=1, rplm=1, nonref_period=4, qp=32, seed=38),
     "slice_qp_delta": dict(BASE, frames=5, profile_idc=77, cabac=1, slices=3, slice_qp_delta=5, qp=27, seed=39),
     "slice_qp_delta_cavlc": dict(BASE, frames=5, profile_idc=66, cabac=0, slices=2, slice_qp_delta=7, qp_jitter=3, qp=30, seed=40),
+    # frame_num gaps (8.2.5.2) with gaps_in_frame_num_value_allowed_flag: "non-existing" frames go through the sliding window, the
+    # lists are re-ordered around them; POC types 0, 2 and 1 (FrameNumOffset must survive the skipped values)
+    "fn_gaps_cabac": dict(BASE, frames=14, profile_idc=77, cabac=1, num_ref_frames=4, fn_gap_period=3, fn_gap_declared=1, qp=30, seed=71),
+    "fn_gaps_cavlc_poc2": dict(BASE, frames=14, idr_period=7, profile_idc=66, cabac=0, num_ref_frames=3, fn_gap_period=3, fn_gap_declared=1, qp=30, poc_type=2, seed=72),
+    "fn_gaps_poc1_nonref": dict(BASE, frames=12, profile_idc=77, cabac=1, num_ref_frames=3, fn_gap_period=4, fn_gap_declared=1, qp=30, poc_type=1, nonref_period=3, seed=73),
     # B pictures: IBP / IBBP / IBBBP coding orders, spatial and temporal direct, B_Skip / B_Direct / all 22
     # inter mb_types and 13 sub_mb_types, default / explicit / implicit bi-prediction weights, list 1
     "b_ibp_cabac": dict(BASE, frames=9, profile_idc=77, cabac=1, bframes=1, num_ref_frames=2, bskip_permille=200, seed=41),

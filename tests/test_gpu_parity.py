@@ -358,6 +358,33 @@ def test_gpu_isolation_keeps_other_streams_alive(H, sg, oracle_mod):
     dec.close()
 
 
+def test_gpu_lost_reference_pictures_are_refused_not_mispredicted(H, sg, oracle_mod):
+    """8.2.5.2 without gaps_in_frame_num_value_allowed_flag: a frame_num that skips values means reference pictures were lost.
+    The stream is refused (H264MI_EBITSTREAM; with isolation it alone leaves the batch) instead of predicting from whatever
+    happens to sit in the lists; the same stream with the flag set decodes (matrix cases fn_gaps_*).  Also the real thing:
+    a reference picture NAL cut out of a healthy stream."""
+    kw = dict(width=176, height=144, frames=8, idr_period=0, profile_idc=77, cabac=1, num_ref_frames=4, fn_gap_period=3, seed=74)
+    lossy = sg.encode(**dict(kw, fn_gap_declared=0))[0]
+    good = sg.encode(**dict(kw, fn_gap_declared=1))
+    with pytest.raises(RuntimeError):
+        oracle_mod.decode(lossy, crop=False)
+    whole = sg.encode(width=176, height=144, frames=6, idr_period=0, profile_idc=66, cabac=0, num_ref_frames=2, seed=75)[0]
+    offs = [n.Offset - 4 for n in H.read_nal_units(whole)] + [len(whole)]
+    cut = whole[:offs[4]] + whole[offs[5]:]  # SPS PPS IDR P | P(frame_num 2) removed | P P ...
+    for bad in (lossy, cut):
+        dec = H.Decoder(max_streams=2, max_width=176, max_height=144, max_frames_per_batch=8)
+        with pytest.raises(H.H264MIError) as ei:
+            dec.decode([bad, good[0]])
+        assert ei.value.code == -2 and "frame_num" in str(ei.value)
+        dec.close()
+        dec = H.Decoder(max_streams=2, max_width=176, max_height=144, max_frames_per_batch=8)
+        dec.set_isolation(True)
+        dec.decode([bad, good[0]])
+        assert dec.stream_status(0) == -2 and dec.frame_count(0) == 0 and dec.stream_status(1) == 0
+        assert np.array_equal(dec.read_frames(1, crop=False), good[1])
+        dec.close()
+
+
 def test_gpu_resolution_change_inside_one_batch(H, sg):
     """Two sequences of different size back to back in ONE chunk of one stream: every picture keeps its own geometry."""
     a = sg.encode(width=176, height=144, frames=3, idr_period=0, profile_idc=77, cabac=1, seed=51)

@@ -54,7 +54,7 @@ def test_matrix_exercises_the_syntax(sg, oracle_mod):
     # picture management: the generator must have emitted, and the oracle executed, every operation the matrix claims
     dpb = {0: 0, 1: 0}
     for name, kw in MATRIX.items():
-        if not any(kw.get(k) for k in ("rplm", "mmco", "idr_long_term", "nonref_period", "slice_qp_delta")) and kw.get("poc_type", 0) != 1:
+        if not any(kw.get(k) for k in ("rplm", "mmco", "idr_long_term", "nonref_period", "slice_qp_delta", "fn_gap_period")) and kw.get("poc_type", 0) != 1:
             continue
         stream, _, _ = sg.encode(**kw)
         emitted = sg.last_features()
@@ -64,7 +64,8 @@ def test_matrix_exercises_the_syntax(sg, oracle_mod):
         dpb[kw.get("cabac", 0)] |= emitted
     for cab in (0, 1):
         for bit, what in [(1, "mmco1"), (2, "mmco2"), (3, "mmco3"), (4, "mmco4"), (6, "mmco6"), (8, "rplm idc0"), (9, "rplm idc1"),
-                          (10, "rplm idc2"), (11, "long-term ref in list"), (12, "non-ref picture"), (13, "slice_qp_delta")]:
+                          (10, "rplm idc2"), (11, "long-term ref in list"), (12, "non-ref picture"), (13, "slice_qp_delta"),
+                          (15, "frame_num gap filled with non-existing frames")]:
             assert dpb[cab] >> bit & 1, (what, cab)
     assert dpb[1] >> 5 & 1 and dpb[1] >> 14 & 1  # mmco5 and POC type 1 with a non-zero delta (CABAC cases)
     for cab in (0, 1):
