@@ -1445,7 +1445,11 @@ FI void decode_mb(Ent &e, int skipped) {
     if (l == 0) r.coef_off = coff, r.coef_mask = cmask;
     if (l < 16) {
         int g = GI(l & 3, l >> 2);
-        r.ipm[l] = (MI_ENT_B && inter && l < 4) ? s->refs8[NL - 1][l] : s->ipm_c[g]; // B: MBREC_REF1 shares the bytes
+        // inter macroblocks have no intra modes: [0..3] = ref_idx_l1 (B; MBREC_REF1), [4] = mb_type as coded (Tables 7-13 / 7-14; 0 when
+        // skipped), [5..8] = sub_mb_type of the four 8x8 quadrants (P_8x8 / B_8x8) -- what h264/slice.go:77-102 SliceData keeps
+        int8_t v = s->ipm_c[g];
+        if (inter) v = (MI_ENT_B && l < 4) ? s->refs8[NL - 1][l] : (l == 4 ? static_cast<int8_t>(raw) : ((l >= 5 && l < 9) ? s->sub_type[l - 5] : static_cast<int8_t>(0)));
+        r.ipm[l] = v;
         r.mv[l][0] = inter ? s->mv_c[0][g][0] : static_cast<int16_t>(0);
         r.mv[l][1] = inter ? s->mv_c[0][g][1] : static_cast<int16_t>(0);
     } else if (l < 20) {

@@ -445,11 +445,11 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
         DEV_ALLOC(d->d_dbprm[i], sizeof(DbPrm) * d->mb_cap);
         if (i == 0) {
             // Pool size.  The worst case is 26 blocks (832 bytes) per macroblock; real streams code a fraction of that (the
-            // 1080p QP 28 bench streams: ~5 blocks per macroblock).  Small decoders get the worst case; large ones 8 blocks
+            // 1080p QP 28 bench streams: ~5 blocks per macroblock).  Small decoders get the worst case; large ones 7 blocks
             // per macroblock, at least 1 GiB -- a batch that needs more fails with H264MI_EDECODE ("coefficient pool
             // exhausted", code 40) instead of reserving 3 x 52 GB for a case that does not occur.  H264MI_COEF_BLOCKS_PER_MB overrides.
             const uint64_t worst = d->mb_cap * MI_COEF_BLOCKS + static_cast<uint64_t>(d->slices_cap + 1) * MI_COEF_CHUNK;
-            uint64_t per_mb = 8;
+            uint64_t per_mb = 7;
             if (const char *e = getenv("H264MI_COEF_BLOCKS_PER_MB")) per_mb = static_cast<uint64_t>(std::min(std::max(atoi(e), 1), MI_COEF_BLOCKS));
             const uint64_t typical = std::max<uint64_t>(d->mb_cap * per_mb, (1ull << 30) / 32) + static_cast<uint64_t>(d->slices_cap + 1) * MI_COEF_CHUNK;
             d->pool_blocks = std::min<uint64_t>(std::min<uint64_t>(worst, typical), 0xFFFF0000ull);
@@ -944,8 +944,15 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         set_error("stream %d: slice_type %d is out of scope (SP / SI slices)", si, sh.slice_type);
         return H264MI_EUNSUPPORTED;
     }
-    if (sps.chroma_format != 1 || sps.bit_depth_luma_minus8 || sps.bit_depth_chroma_minus8 || !sps.frame_mbs_only || sps.qprime_y_zero_transform_bypass) {
-        set_error("stream %d: only 4:2:0 8-bit frame-coded streams are supported (chroma_format_idc %d)", si, sps.chroma_format);
+    if (sps.chroma_format != 1 || sps.bit_depth_luma_minus8 || sps.bit_depth_chroma_minus8 || sps.qprime_y_zero_transform_bypass) {
+        set_error("stream %d: only 4:2:0 8-bit streams are supported (chroma_format_idc %d)", si, sps.chroma_format);
+        return H264MI_EUNSUPPORTED;
+    }
+    // frame_mbs_only_flag = 0 (h264/sps.go:316-322) is fine as long as the pictures are frames and macroblock-adaptive frame/field
+    // coding is off: such a picture decodes like a progressive one (map units are two macroblock rows high, crop units double).
+    // Field pictures (h264/slice.go:867-872) and MBAFF (h264/slice.go:563-568, 624-634) are not implemented.
+    if (!sps.frame_mbs_only && (sps.mb_adaptive_frame_field || sh.field_pic)) {
+        set_error("stream %d: %s is out of scope", si, sh.field_pic ? "a field picture (PAFF)" : "macroblock-adaptive frame/field coding (MBAFF)");
         return H264MI_EUNSUPPORTED;
     }
     const int wmb = sps.pic_width_in_mbs, hmb = sps.pic_height_in_mbs;
@@ -1010,7 +1017,7 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         }
         pd.scaling_set = static_cast<uint8_t>(ss);
         pd.order = s.n_pics_in_batch++;
-        g.out[si].push_back({slot, wmb, hmb, 2 * sps.frame_crop_left_offset, 2 * sps.frame_crop_top_offset, sps.width, sps.height, sl.poc, sh.frame_num,
+        g.out[si].push_back({slot, wmb, hmb, 2 * sps.frame_crop_left_offset, 2 * (2 - sps.frame_mbs_only) * sps.frame_crop_top_offset, sps.width, sps.height, sl.poc, sh.frame_num,
                          sh.nal_ref_idc, sh.nal_unit_type == 5, s.cur_pic, sh.nal_unit_type == 5});
         if (sh.nal_ref_idc && sh.adaptive_ref_pic_marking_mode_flag)
             for (int k = 0; k < sh.n_memory_management_control_operations; k++)
@@ -1753,6 +1760,28 @@ extern "C" int32_t h264mi_frame_read_mbrecs(h264mi_decoder *d, int32_t stream, i
             if (cap < n) return H264MI_ECAPACITY;
             HIP_TRY(hipStreamSynchronize(d->stream));
             HIP_TRY(hipMemcpy(rec, d->d_mbrec[(d->pass + MI_SETS - 1) % MI_SETS] + pd.mb_base, n, hipMemcpyDeviceToHost));
+            return H264MI_OK;
+        }
+    }
+    return H264MI_EINVAL;
+}
+
+extern "C" int32_t h264mi_frame_read_mbmv1(h264mi_decoder *d, int32_t stream, int32_t frame, uint8_t *mv1, size_t cap) {
+    if (!d || !mv1 || stream < 0 || stream >= static_cast<int>(d->st.size())) return H264MI_EINVAL;
+    GUARD(d);
+    Stage &g = d->stage[d->exec];
+    const int set = static_cast<int>((d->pass + MI_SETS - 1) % MI_SETS);
+    for (int i = 0; i < g.n_pics; i++) {
+        const PicDesc &pd = g.h_pics[i];
+        if (static_cast<int>(pd.stream) == stream && static_cast<int>(pd.order) == frame) {
+            size_t n = static_cast<size_t>(pd.wmb) * pd.hmb * sizeof(MbMv1);
+            if (cap < n) return H264MI_ECAPACITY;
+            HIP_TRY(hipStreamSynchronize(d->stream));
+            if (!pd.has_b || !d->d_mv1[set]) { // no B slice in the picture: there are no list-1 vectors
+                memset(mv1, 0, n);
+                return H264MI_OK;
+            }
+            HIP_TRY(hipMemcpy(mv1, d->d_mv1[set] + pd.mb_base, n, hipMemcpyDeviceToHost));
             return H264MI_OK;
         }
     }

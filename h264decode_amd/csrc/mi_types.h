@@ -7,7 +7,8 @@
  *   slices      SliceDesc[]        one per slice (host-built)            -> entropy kernels
  *   pics        PicDesc[]          one per picture (host-built)          -> all kernels
  *   mbrec       MbRec[]            128 B per macroblock (entropy -> recon/deblock)
- *   coef        int16[416] per MB  dequantisation input, raster order inside each block
+ *   coef        packed pool        32-byte blocks (16 int16, raster order inside the block), only the blocks with a non-zero coefficient
+ *   dbprm       DbPrm[]            80 B per macroblock (k_dbprep -> K5): boundary strengths, alpha / beta / tC0
  *   frames      per stream: `slots` frames of (coded W x H luma + 2 x W/2 x H/2 chroma), pitch = W
  *   tables      DevTables          CABAC/CAVLC/deblock tables + per-PPS LevelScale sets
  */
@@ -53,7 +54,8 @@ typedef struct __attribute__((aligned(16))) {
     uint8_t dbf_idc;  /* disable_deblocking_filter_idc of the slice */
     int8_t alpha_off, beta_off; /* FilterOffsetA / FilterOffsetB */
     uint16_t slice_in_pic;      /* slice ordinal inside the picture (deblock idc 2, intra availability) */
-    int8_t ipm[16];   /* Intra4x4/8x8PredMode per 4x4 block, raster; inter macroblocks of B slices: [0..3] = ref_idx_l1 per 8x8 */
+    int8_t ipm[16];   /* Intra4x4/8x8PredMode per 4x4 block, raster; inter macroblocks: [0..3] = ref_idx_l1 per 8x8 (B slices), [4] = mb_type as
+                       * coded (Tables 7-13 / 7-14), [5..8] = sub_mb_type per 8x8 (P_8x8 / B_8x8), rest 0 */
     int8_t ref[4];    /* ref_idx_l0 per 8x8 */
     int16_t refslot[4]; /* frame-pool slot of the referenced picture per 8x8 (-1 none) */
     uint32_t slice_idx; /* index into SliceDesc[] (weighted prediction tables) */

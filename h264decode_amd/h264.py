@@ -319,6 +319,12 @@ class Decoder:
         check(self._L.h264mi_frame_read_mbrecs(self._h, stream, frame, buf.ctypes.data, buf.nbytes))
         return buf.reshape(n_mbs, 128)
 
+    def read_mbmv1(self, stream, frame, n_mbs):
+        """List-1 motion vectors of a picture (int16 [n_mbs, 16, 2]; zeros for pictures without B slices)."""
+        buf = np.zeros(n_mbs * 64, dtype=np.uint8)
+        check(self._L.h264mi_frame_read_mbmv1(self._h, stream, frame, buf.ctypes.data, buf.nbytes))
+        return buf.view(np.int16).reshape(n_mbs, 16, 2)
+
 
 # ---------------------------------------------------------------------------------------------------
 # Stream front-end (SURVEY 8f rank 2): the reference's ByteStreamReader / handleConnection / readNalUnit

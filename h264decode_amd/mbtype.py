@@ -160,15 +160,18 @@ def PreCtxState(m: int, n: int, sliceQPy: int) -> int:  # h264/cabac.go:118 (9-5
 
 
 # ---------------------------------------------------------------------------------------------------
-_MBT = {0: "none", 1: "I4x4", 2: "I8x8", 3: "I16x16", 4: "IPCM", 5: "P16x16", 6: "P16x8", 7: "P8x16", 8: "P8x8", 9: "PSKIP"}  # mi_types.h MBT_*
+_MBT = {0: "none", 1: "I4x4", 2: "I8x8", 3: "I16x16", 4: "IPCM", 5: "P16x16", 6: "P16x8", 7: "P8x16", 8: "P8x8", 9: "PSKIP", 10: "B", 11: "BDIRECT",
+        12: "BSKIP"}  # mi_types.h MBT_*
 
 
 class SliceData:
     """One macroblock as the reference's SliceData would hold it (h264/slice.go:77-102), filled from the 128-byte MbRec
-    the GPU entropy kernel wrote (mi_types.h).  Final motion vectors replace the reference's MvdL0 (the kernel adds the
-    prediction of 8.4.1.3 right away); residual coefficients stay on the device."""
+    the GPU entropy kernel wrote (mi_types.h) and, for B slices, the macroblock's list-1 vectors.  Final motion vectors
+    replace the reference's MvdL0 / MvdL1 (the kernel adds the prediction of 8.4.1.3 right away); residual coefficients
+    stay on the device.  mb_type is the value as coded (Tables 7-11 / 7-13 / 7-14): the record carries it for inter
+    macroblocks, intra ones are rebuilt from prediction mode and coded block pattern."""
 
-    def __init__(self, rec: np.ndarray, sliceType: str):
+    def __init__(self, rec: np.ndarray, sliceType: str, mv1=None):
         t = int(rec[0])
         self.SliceTypeName = sliceType
         self.TransformSize8x8Flag = bool(rec[1])
@@ -177,28 +180,37 @@ class SliceData:
         self.CodedBlockPattern = cbp
         self.IntraChromaPredMode = int(rec[6])
         i16mode = int(rec[7])
+        intra, inter = 1 <= t <= 4, t >= 5
         if t in (1, 2):
             raw = 0
         elif t == 3:
             raw = 1 + i16mode + 4 * (cbp >> 4) + (12 if (cbp & 15) else 0)
         elif t == 4:
             raw = 25
+        elif t in (9, 12):
+            raw = MB_TYPE_INFERRED  # P_Skip / B_Skip: mb_type is inferred, nothing is coded
         else:
-            raw = {5: 0, 6: 1, 7: 2, 8: 3, 9: MB_TYPE_INFERRED}.get(t, 0)
-        intra = 1 <= t <= 4
-        self.MbType = raw + (5 if (intra and sliceType in ("P", "SP")) else 0)
+            raw = int(rec[20])  # ipm[4]: mb_type as coded (B_Direct_16x16 = 0)
+        # intra macroblocks of P / B slices: mb_type = 5 / 23 + the I-slice value (7.3.5)
+        self.MbType = raw + ((5 if sliceType in ("P", "SP") else 23 if sliceType == "B" else 0) if intra else 0)
         self.MbTypeName = MbTypeName(sliceType, self.MbType) if t else "NotDecoded"
-        self.MbSkipFlag = t == 9
+        self.MbSkipFlag = t in (9, 12)
+        self.SubMbType = rec[21:25].view(np.int8).tolist() if (inter and not self.MbSkipFlag and raw == (3 if sliceType != "B" else 22)) else []
         self.Intra4x4PredMode = rec[16:32].view(np.int8).tolist() if t in (1, 2) else []
-        self.RefIdxL0 = rec[32:36].view(np.int8).tolist() if t >= 5 else []
-        self.MvL0 = rec[48:112].view(np.int16).reshape(16, 2).tolist() if t >= 5 else []
+        self.RefIdxL0 = rec[32:36].view(np.int8).tolist() if inter else []
+        self.MvL0 = rec[48:112].view(np.int16).reshape(16, 2).tolist() if inter else []
+        # list 1 exists in B slices only: reference indices share the bytes of the intra modes, -1 = the 8x8 block does not use the list
+        isb = inter and sliceType == "B"
+        self.RefIdxL1 = [r if s >= 0 else -1 for r, s in zip(rec[16:20].view(np.int8).tolist(), rec[120:128].view(np.int16).tolist())] if isb else []
+        self.MvL1 = np.asarray(mv1).reshape(16, 2).tolist() if (isb and mv1 is not None) else []
         self.CodedBlockFlagsLuma4x4 = int(rec[8:10].view(np.uint16)[0])
 
 
 def NewSliceData(sliceContext, b=None, decoder=None, stream: int = 0, frame: int = 0):
     """h264/slice.go:570 NewSliceData(sliceContext, bitReader).  There is no CPU macroblock parser in this package (the
     macroblock layer is decoded by the HIP entropy kernel), so instead of a bit reader this takes the Decoder that
-    decoded the stream and returns the picture's macroblocks as a list of SliceData, in macroblock address order."""
+    decoded the stream and returns the picture's macroblocks as a list of SliceData, in macroblock address order.
+    (The slice type is taken from the given slice: for pictures that mix slice types call it once per slice.)"""
     if decoder is None:
         raise NotImplementedError("slice_data() is decoded on the GPU: pass decoder=, stream=, frame= of a decoded batch "
                                   "(there is no CPU fallback for the macroblock layer)")
@@ -206,10 +218,16 @@ def NewSliceData(sliceContext, b=None, decoder=None, stream: int = 0, frame: int
     n = PicSizeInMbs(sps, sliceContext.Slice.Header)
     recs = decoder.read_mbrecs(stream, frame, n)
     st = {0: "P", 1: "B", 2: "I", 3: "SP", 4: "SI"}[sliceContext.Slice.Header.SliceType % 5]
-    return [SliceData(recs[i], st) for i in range(n)]
+    mv1 = decoder.read_mbmv1(stream, frame, n) if st == "B" else None
+    return [SliceData(recs[i], st, None if mv1 is None else mv1[i]) for i in range(n)]
 
 
-def MbPred(sliceContext, b=None, rbsp=None):
-    """h264/slice.go:252 MbPred: mb_pred() is part of the GPU entropy kernel (k_entropy.hip decode_mb); its results are
-    the RefIdxL0 / MvL0 / Intra4x4PredMode fields of the SliceData objects NewSliceData returns."""
-    raise NotImplementedError(MbPred.__doc__)
+def MbPred(sliceData, b=None, rbsp=None):
+    """h264/slice.go:252 MbPred fills the mb_pred() fields of a SliceData from the bit stream.  Here mb_pred() / sub_mb_pred() are
+    decoded by the GPU entropy kernel (k_entropy.hip decode_mb) together with the rest of the macroblock, so this returns those
+    fields of an already decoded SliceData (from NewSliceData): the prediction modes of an intra macroblock, the reference indices
+    and final vectors of an inter one."""
+    if not isinstance(sliceData, SliceData):
+        raise TypeError("MbPred takes a SliceData returned by NewSliceData(..., decoder=...): mb_pred() is decoded on the GPU")
+    return {"Intra4x4PredMode": sliceData.Intra4x4PredMode, "IntraChromaPredMode": sliceData.IntraChromaPredMode, "SubMbType": sliceData.SubMbType,
+            "RefIdxL0": sliceData.RefIdxL0, "RefIdxL1": sliceData.RefIdxL1, "MvL0": sliceData.MvL0, "MvL1": sliceData.MvL1}

@@ -228,6 +228,9 @@ int32_t h264mi_batch_pack_device(h264mi_decoder *dec, int32_t stream, void *dst_
 /* Debug / test access to the intermediate macroblock records of a frame (host copy).
  * rec: 128 bytes per MB (layout: h264decode_amd/csrc/mi_types.h struct MbRec). */
 int32_t h264mi_frame_read_mbrecs(h264mi_decoder *dec, int32_t stream, int32_t frame, uint8_t *rec, size_t cap);
+/* ... and to the list-1 motion vectors of a picture with B slices: 64 bytes per MB, int16 (x, y) per 4x4 block in raster order
+ * (zeros for pictures without B slices).  Together they are what h264/slice.go:77-102 SliceData holds per macroblock. */
+int32_t h264mi_frame_read_mbmv1(h264mi_decoder *dec, int32_t stream, int32_t frame, uint8_t *mv1, size_t cap);
 
 /* Time (ms) spent by the kernels of the last execute, measured with HIP events on the decoder's
  * stream: [0] entropy, [1] inter recon, [2] intra recon, [3] deblock, [4] total.  Valid after sync

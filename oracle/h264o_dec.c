@@ -45,10 +45,12 @@ void h264o_set_mb_trace(h264o_decoder *d, int32_t *trace, size_t cap) {
 static int activate(h264o_decoder *d, const h264o_pps *pps) {
     const h264o_sps *s = &d->sps[pps->seq_parameter_set_id];
     if (!s->valid) return h264o_fail(d, "PPS %d refers to missing SPS %d", pps->pic_parameter_set_id, pps->seq_parameter_set_id);
-    if (s->chroma_format_idc != 1 || s->bit_depth_luma_minus8 || s->bit_depth_chroma_minus8 || !s->frame_mbs_only_flag ||
+    /* frame_mbs_only_flag = 0 is accepted as long as every picture is a frame and macroblock-adaptive coding is off (h264/sps.go:316-322,
+     * h264/slice.go:867-872): such pictures decode like progressive ones, only the map units are two macroblock rows high */
+    if (s->chroma_format_idc != 1 || s->bit_depth_luma_minus8 || s->bit_depth_chroma_minus8 || (!s->frame_mbs_only_flag && s->mb_adaptive_frame_field_flag) ||
         s->qpprime_y_zero_transform_bypass_flag)
-        return h264o_fail(d, "unsupported SPS (need 4:2:0 8-bit frame_mbs_only; chroma_format_idc=%d)", s->chroma_format_idc);
-    int wmb = s->pic_width_in_mbs_minus1 + 1, hmb = s->pic_height_in_map_units_minus1 + 1;
+        return h264o_fail(d, "unsupported SPS (need 4:2:0 8-bit, no MBAFF; chroma_format_idc=%d)", s->chroma_format_idc);
+    int wmb = s->pic_width_in_mbs_minus1 + 1, hmb = (s->pic_height_in_map_units_minus1 + 1) * (2 - s->frame_mbs_only_flag); /* h264/slice.go:159-176 */
     if (d->asps != s || wmb != d->wmb || hmb != d->hmb || !d->mb) {
         free_pics(d);
         d->wmb = wmb;
@@ -71,7 +73,7 @@ static int activate(h264o_decoder *d, const h264o_pps *pps) {
     d->info.coded_width = wmb * 16;
     d->info.coded_height = hmb * 16;
     d->info.width = wmb * 16 - 2 * (s->frame_crop_left_offset + s->frame_crop_right_offset);
-    d->info.height = hmb * 16 - 2 * (s->frame_crop_top_offset + s->frame_crop_bottom_offset);
+    d->info.height = hmb * 16 - 2 * (2 - s->frame_mbs_only_flag) * (s->frame_crop_top_offset + s->frame_crop_bottom_offset); /* CropUnitY = SubHeightC * (2 - frame_mbs_only_flag) */
     d->asps = s;
     d->apps = pps;
     h264o_build_level_scale(d);
@@ -325,7 +327,7 @@ static void emit_frame(h264o_decoder *d) {
     const h264o_sps *s = d->asps;
     int cw = d->info.coded_width, ch = d->info.coded_height;
     int w = d->crop ? d->info.width : cw, h = d->crop ? d->info.height : ch;
-    int x0 = d->crop ? 2 * s->frame_crop_left_offset : 0, y0 = d->crop ? 2 * s->frame_crop_top_offset : 0;
+    int x0 = d->crop ? 2 * s->frame_crop_left_offset : 0, y0 = d->crop ? 2 * (2 - s->frame_mbs_only_flag) * s->frame_crop_top_offset : 0;
     size_t need = (size_t)w * h * 3 / 2;
     if (d->out && d->out_pos + need <= d->out_cap) {
         uint8_t *o = d->out + d->out_pos;

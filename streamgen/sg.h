@@ -58,6 +58,8 @@ typedef struct {
     int bskip_permille;     /* probability of B_Skip; B_Direct_16x16 gets half of it on top */
     int motion_x4, motion_y4; /* motion of the synthetic scene per frame in quarter samples (default 12, -8 = whole samples (3, -2));
                              * anything not a multiple of 4 makes fractional motion vectors the rule (6-tap interpolation) */
+    int interlace_sps;      /* 1: frame_mbs_only_flag = 0 in the SPS (mb_adaptive_frame_field_flag = 0), every picture still a frame
+                             * (field_pic_flag = 0): the syntax of a PAFF-capable stream that never uses a field picture */
     int fn_gap_period;      /* N > 0 (streams without B pictures / marking scripts): before every N-th picture after an IDR picture
                              * frame_num skips one or two values (8.2.5.2): the skipped frames enter the window as "non-existing"
                              * frames and the lists are re-ordered so that only real pictures are predicted from */

@@ -1748,10 +1748,16 @@ static size_t write_sps(enc *e, uint8_t *dst, size_t cap) {
     sg_put_ue(&w, (uint32_t)p->num_ref_frames);
     sg_put(&w, p->fn_gap_declared != 0, 1); /* gaps_in_frame_num_value_allowed_flag */
     sg_put_ue(&w, (uint32_t)(e->wmb - 1));
-    sg_put_ue(&w, (uint32_t)(e->hmb - 1));
-    sg_put(&w, 1, 1); /* frame_mbs_only */
+    if (p->interlace_sps) { /* map units of two macroblock rows; crop units of four luma rows (7.4.2.1.1) */
+        sg_put_ue(&w, (uint32_t)(e->hmb / 2 - 1));
+        sg_put(&w, 0, 1); /* frame_mbs_only_flag */
+        sg_put(&w, 0, 1); /* mb_adaptive_frame_field_flag */
+    } else {
+        sg_put_ue(&w, (uint32_t)(e->hmb - 1));
+        sg_put(&w, 1, 1); /* frame_mbs_only */
+    }
     sg_put(&w, 1, 1); /* direct_8x8_inference */
-    int cr = (e->W - p->width) / 2, cb = (e->H - p->height) / 2;
+    int cr = (e->W - p->width) / 2, cb = (e->H - p->height) / (p->interlace_sps ? 4 : 2);
     sg_put(&w, cr || cb, 1);
     if (cr || cb) {
         sg_put_ue(&w, 0);
@@ -1800,6 +1806,7 @@ static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int
     sg_put_ue(w, is_b ? 6 : (is_p ? 5 : 7)); /* slice_type: all slices of the picture alike */
     sg_put_ue(w, 0);
     sg_put(w, (uint32_t)frame_num, 8);
+    if (p->interlace_sps) sg_put(w, 0, 1); /* field_pic_flag */
     if (idr) sg_put_ue(w, (uint32_t)idr_id);
     if (p->poc_type == 0) sg_put(w, (uint32_t)poc_lsb, 8);
     if (p->poc_type == 1) sg_put_se(w, e->delta_poc0); /* delta_pic_order_cnt[0] (delta_pic_order_always_zero_flag = 0) */
@@ -2164,6 +2171,10 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         p->b_pyramid = 0;
     e->W = (p->width + 15) & ~15, e->H = (p->height + 15) & ~15;
     e->wmb = e->W / 16, e->hmb = e->H / 16;
+    if (p->interlace_sps && ((e->hmb & 1) || ((e->H - p->height) & 3))) {
+        snprintf(g_err, sizeof(g_err), "interlace_sps needs an even number of macroblock rows and a height whose padding is a multiple of 4");
+        return 0;
+    }
     if (p->slices > e->hmb) p->slices = e->hmb;
     e->rng = 0x9E3779B97F4A7C15ull ^ ((uint64_t)p->seed * 0xD1B54A32D192ED03ull);
     if (!e->rng) e->rng = 1;

@@ -122,6 +122,11 @@ MATRIX = {
     "fn_gaps_cabac": dict(BASE, frames=14, profile_idc=77, cabac=1, num_ref_frames=4, fn_gap_period=3, fn_gap_declared=1, qp=30, seed=71),
     "fn_gaps_cavlc_poc2": dict(BASE, frames=14, idr_period=7, profile_idc=66, cabac=0, num_ref_frames=3, fn_gap_period=3, fn_gap_declared=1, qp=30, poc_type=2, seed=72),
     "fn_gaps_poc1_nonref": dict(BASE, frames=12, profile_idc=77, cabac=1, num_ref_frames=3, fn_gap_period=4, fn_gap_declared=1, qp=30, poc_type=1, nonref_period=3, seed=73),
+    # frame_mbs_only_flag = 0 with mb_adaptive_frame_field_flag = 0 and field_pic_flag = 0 everywhere (first step):
+    # the SPS / slice header syntax of a PAFF-capable stream whose pictures are all frames; crop units of four rows
+    "interlace_sps_cabac": dict(width=176, height=120, frames=5, idr_period=0, profile_idc=77, cabac=1, interlace_sps=1, num_ref_frames=2, seed=81),
+    "interlace_sps_cavlc_b": dict(width=176, height=128, frames=8, idr_period=0, profile_idc=77, cabac=0, interlace_sps=1, bframes=2, num_ref_frames=3,
+                                  direct_temporal=1, seed=82),
     # B pictures: IBP / IBBP / IBBBP coding orders, spatial and temporal direct, B_Skip / B_Direct / all 22
     # inter mb_types and 13 sub_mb_types, default / explicit / implicit bi-prediction weights, list 1
     "b_ibp_cabac": dict(BASE, frames=9, profile_idc=77, cabac=1, bframes=1, num_ref_frames=2, bskip_permille=200, seed=41),

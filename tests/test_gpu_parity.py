@@ -481,6 +481,57 @@ def test_gpu_b_and_p_streams_side_by_side_1080p(H, sg):
     dec.close()
 
 
+@pytest.mark.parametrize("name", ["b_ibbp_cabac", "b_gop_intra_pcm", "sub8x8_heavy", "b_pyramid_cavlc"])
+def test_gpu_slice_data_carries_the_coded_mb_type(name, H, sg, oracle_mod):
+    """NewSliceData (h264/slice.go:570): mb_type as coded -- every value of Tables 7-11 / 7-13 / 7-14, the intra types inside P
+    and B slices with their offsets 5 / 23, P_Skip / B_Skip as inferred -- against what the oracle parsed, macroblock by
+    macroblock; list-1 fields of B macroblocks; MbPred returns the mb_pred() fields."""
+    kw = MATRIX[name]
+    stream, _, _ = sg.encode(**kw)
+    _, info, tr = oracle_mod.decode(stream, crop=False, trace=True)
+    W, Hc = (kw["width"] + 15) // 16 * 16, (kw["height"] + 15) // 16 * 16
+    nmb = (W // 16) * (Hc // 16)
+    tr = tr.reshape(-1, nmb, 8)
+    dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=kw["frames"], max_slices_per_frame=kw.get("slices", 1))
+    dec.decode([stream])
+    nals = H.read_nal_units(stream)
+    sps = H.NewSPS(nals[0].RBSP())
+    vs = H.VideoStream(sps, H.NewPPS(sps, nals[1].RBSP()))
+    seen, f = set(), -1
+    for n in nals:
+        if n.Type == 7:
+            sps = H.NewSPS(n.RBSP())
+        elif n.Type == 8:
+            vs = H.VideoStream(sps, H.NewPPS(sps, n.RBSP()))
+        if n.Type not in (1, 5):
+            continue
+        ctx = H.NewSliceContext(vs, n, n.RBSP())
+        if ctx.Slice.Header.FirstMbInSlice != 0:
+            continue  # (one call per picture; the cases here have one slice type per picture)
+        f += 1
+        st = ctx.Slice.Header.SliceType % 5
+        sds = H.NewSliceData(ctx, decoder=dec, stream=0, frame=f)
+        assert len(sds) == nmb
+        for m, sd in enumerate(sds):
+            raw = int(tr[f, m, 0])
+            if raw == -1:
+                assert sd.MbSkipFlag and sd.MbType == H.MB_TYPE_INFERRED and sd.MbTypeName in ("P_Skip", "B_Skip"), (f, m)
+            else:
+                assert not sd.MbSkipFlag and sd.MbType == raw, (f, m, sd.MbType, raw, sd.MbTypeName)
+            seen.add((st, sd.MbTypeName))
+            mp = H.MbPred(sd)
+            if st == 1 and sd.RefIdxL0:
+                assert len(sd.RefIdxL1) == 4 and len(sd.MvL1) == 16 and mp["MvL1"] == sd.MvL1
+                assert all((r0 >= 0 or r1 >= 0) for r0, r1 in zip(sd.RefIdxL0, sd.RefIdxL1)), (f, m)  # every 8x8 block of an inter macroblock predicts from something
+            if sd.SubMbType:
+                assert sd.MbTypeName in ("P_8x8", "B_8x8") and all(0 <= t <= (12 if st == 1 else 3) for t in sd.SubMbType)
+    assert f + 1 == kw["frames"]
+    if kw.get("bframes"):
+        names = {n for s_, n in seen if s_ == 1}
+        assert {"B_Skip", "B_Direct_16x16", "B_8x8"} <= names and len(names) >= 15, sorted(names)
+    dec.close()
+
+
 def test_gpu_output_order_of_b_streams(H, sg):
     kw = MATRIX["b_gop_intra_pcm"]  # two IDR periods, three B pictures between the anchors
     stream, _, _ = sg.encode(**kw)
