@@ -139,6 +139,7 @@ struct StreamState {
     h264mi_slice_header first_sh;
     int n_pics_in_batch = 0;
     int status = H264MI_OK; // of this stream in the current batch (h264mi_stream_status)
+    const void *status_batch = nullptr; // the batch whose entropy kernels set `status` (harvest_status)
     bool need_idr = false;  // after an error: nothing is decodable before the next IDR picture
 };
 
@@ -171,6 +172,7 @@ struct Stage {
     std::vector<uint32_t> wave_off, wave_inter_off;
     std::vector<std::vector<OutFrame>> out; // per stream: frames of this batch in decoding order
     bool prepared = false, executed = false;
+    bool harvested = true; // the entropy kernels' per-slice status words of the last execute have been looked at (harvest_status)
     h264mi_batch_info info;
     hipEvent_t ev_upload = nullptr; // H2D copies of this batch are complete
     hipEvent_t ev_done = nullptr;   // the last pass over this batch has finished (nothing reads or writes its buffers any more)
@@ -1132,6 +1134,32 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
     return H264MI_OK;
 }
 
+// What the entropy kernels reported for the slices of an executed batch (its status copy has arrived: the caller waited for
+// ev_done or synchronised the streams).  A failed slice marks its stream: the pictures from there on are damaged, its references
+// are dropped and nothing of it is decoded before its next IDR picture.  Called from h264mi_batch_sync for every batch that
+// has been executed since the last look, and from h264mi_batch_prepare when it takes a staging set back -- so in the pipelined
+// pattern (execute(k); prepare(k + 1); execute(k + 1); ...) a failure of batch k is acted upon before batch k + 2 is parsed.
+static int harvest_status(h264mi_decoder *d, Stage &g) {
+    if (!g.executed || g.harvested) return H264MI_OK;
+    g.harvested = true;
+    int result = H264MI_OK;
+    for (int i = 0; i < g.n_slices; i++)
+        if (g.h_status[8 * i]) {
+            const SliceDesc &sd = g.h_slices[i];
+            StreamState &s = d->st[g.h_pics[sd.pic_idx].stream];
+            if (result == H264MI_OK)
+                set_error("entropy kernel: slice %d (picture %u, stream %u) failed with code %u after %u macroblocks", i, sd.pic_idx, g.h_pics[sd.pic_idx].stream,
+                          g.h_status[8 * i], g.h_status[8 * i + 1]);
+            if (s.status == H264MI_OK || s.status_batch != &g) { // first failure of the stream in this batch
+                s.status = H264MI_EDECODE, s.status_batch = &g;
+                for (auto &sl : s.slots) sl.ref = 0;
+                s.need_idr = true;
+            }
+            result = H264MI_EDECODE;
+        }
+    return result;
+}
+
 extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, const uint8_t *const *bufs, const size_t *lens, h264mi_batch_info *info) {
     if (!d || n_streams < 0 || n_streams > static_cast<int>(d->st.size()) || (n_streams && (!bufs || !lens))) return H264MI_EINVAL;
     GUARD(d);
@@ -1141,7 +1169,10 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     const int prev_stage = d->prep;
     d->prep = (d->prep + 1) % MI_STAGES;
     Stage &g = d->stage[d->prep];
-    if (g.executed) HIP_TRY(hipEventSynchronize(g.ev_done));
+    if (g.executed) {
+        HIP_TRY(hipEventSynchronize(g.ev_done));
+        (void)harvest_status(d, g); // a batch nobody synchronised on: its failures still mark their streams (need_idr) before this parse
+    }
     g.prepared = false, g.executed = false;
     g.n_slices = g.n_pics = 0;
     g.bits_used = 0, g.mb_used = 0, g.wmb_max = 0, g.hmb_max = 0, g.mbs_max = 0;
@@ -1528,7 +1559,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     HIP_TRY(hipMemcpyAsync(g.h_status, g.d_status, sizeof(uint32_t) * 8 * g.n_slices, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipMemcpyAsync(d->h_xstatus, d->d_xctl + 64, sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipEventRecord(g.ev_done, d->stream)); // d->stream has waited for the reconstruction kernels: the batch's buffers are idle after this
-    g.executed = true;
+    g.executed = true, g.harvested = false;
     d->ev_used = prof ? ei : 0;
     return H264MI_OK;
 }
@@ -1569,21 +1600,12 @@ extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
         HIP_TRY(hipMemset(d->d_xctl + 64, 0, sizeof(uint32_t)));
         return H264MI_EDEVICE;
     }
+    // every batch executed since the last look (pipelined callers synchronise once for several), the most recent one last
     int result = H264MI_OK;
-    for (int i = 0; i < g.n_slices; i++)
-        if (g.h_status[8 * i]) {
-            const SliceDesc &sd = g.h_slices[i];
-            StreamState &s = d->st[g.h_pics[sd.pic_idx].stream];
-            if (result == H264MI_OK)
-                set_error("entropy kernel: slice %d (picture %u, stream %u) failed with code %u after %u macroblocks", i, sd.pic_idx, g.h_pics[sd.pic_idx].stream,
-                          g.h_status[8 * i], g.h_status[8 * i + 1]);
-            if (s.status == H264MI_OK) { // the stream's pictures from here on are damaged: nothing is decodable before its next IDR
-                s.status = H264MI_EDECODE;
-                for (auto &sl : s.slots) sl.ref = 0;
-                s.need_idr = true;
-            }
-            result = H264MI_EDECODE;
-        }
+    for (int k = 1; k <= MI_STAGES; k++) {
+        const int r = harvest_status(d, d->stage[(d->exec + k) % MI_STAGES]);
+        if (r != H264MI_OK) result = r;
+    }
     return d->isolate ? H264MI_OK : result;
 }
 

@@ -180,7 +180,12 @@ int32_t h264mi_stream_reset(h264mi_decoder *dec, int32_t stream);
  * normally.  A marked stream resumes at its next IDR picture. */
 int32_t h264mi_decoder_set_isolation(h264mi_decoder *dec, int32_t on);
 /* Status of a stream in the current batch: H264MI_OK or the H264MI_E* that took it out (valid after prepare; entropy
- * kernel failures appear after sync). */
+ * kernel failures appear after sync).  Pipelined callers (execute(k); prepare(k + 1); execute(k + 1); ... one sync for
+ * several batches): h264mi_batch_sync looks at every batch executed since the last sync, and h264mi_batch_prepare at the
+ * batch whose staging set it takes back, so a failure in batch k marks its stream (references dropped, nothing decoded
+ * before its next IDR picture) before batch k + 2 is parsed at the latest; batch k + 1 of that stream, prepared before the
+ * failure was known, is decoded from the damaged pictures.  The status VALUE is reset by every prepare: read it after
+ * the sync that follows an execute if it matters. */
 int32_t h264mi_stream_status(h264mi_decoder *dec, int32_t stream, int32_t *status);
 
 /* Stage 1 (host + H2D): scan and parse each stream's Annex-B chunk (whole access units), run

@@ -385,6 +385,44 @@ def test_gpu_lost_reference_pictures_are_refused_not_mispredicted(H, sg, oracle_
         dec.close()
 
 
+def test_gpu_pipelined_batches_do_not_lose_a_failure(H, sg):
+    """execute(k); prepare(k + 1); execute(k + 1); ... with ONE sync at the end: a slice that fails in the entropy kernel in
+    batch 2 must still take its stream out (nothing decodable before the next IDR picture) -- its status words used to be
+    looked at only for the batch executed last."""
+    good = sg.encode(width=176, height=144, frames=12, idr_period=0, profile_idc=66, cabac=0, seed=91)
+    other = sg.encode(width=176, height=144, frames=12, idr_period=0, profile_idc=66, cabac=0, seed=92)[0]
+
+    def chunks(stream):
+        nals = H.read_nal_units(stream)
+        offs = [n.Offset - 4 for n in nals] + [len(stream)]
+        pic = [i for i, n in enumerate(nals) if n.Type in (1, 5)]
+        cuts = [0] + [offs[pic[k]] for k in (3, 6, 9)] + [len(stream)]
+        return [stream[cuts[i]:cuts[i + 1]] for i in range(4)], nals, offs
+    gch, _, _ = chunks(good[0])
+    och, nals, offs = chunks(other)
+    # the first P picture of chunk 2 (picture 3): slice header kept, slice data replaced by 00000001 bytes -> an mb_skip_run / mb_type of 127 within the first two syntax elements
+    k = [i for i, n in enumerate(nals) if n.Type in (1, 5)][3]
+    sps = H.NewSPS(nals[0].RBSP())
+    hdr = H.NewSliceContext(H.VideoStream(sps, H.NewPPS(sps, nals[1].RBSP())), nals[k], nals[k].RBSP()).Slice.Header
+    keep = 4 + 1 + (hdr.slice_data_bit_offset + 7) // 8  # start code, NAL header byte, every byte the slice header has bits in
+    broken = other[offs[k]:offs[k] + keep] + b"\x01" * 24
+    och[1] = broken + other[offs[k + 1]:offs[[i for i, n in enumerate(nals) if n.Type in (1, 5)][6]]]
+    dec = H.Decoder(max_streams=2, max_width=176, max_height=144, max_frames_per_batch=3)
+    dec.set_isolation(True)
+    dec.prepare([gch[0], och[0]])
+    dec.execute()
+    dec.prepare([gch[1], och[1]])
+    dec.execute()
+    dec.prepare([gch[2], och[2]])  # takes the first batch's staging set back; batch 2's failure is not known yet
+    dec.execute()
+    dec.sync()                     # looks at batch 2 and batch 3
+    assert dec.stream_status(1) == -8 and dec.stream_status(0) == 0
+    assert np.array_equal(dec.read_frames(0, crop=False), good[1][6:9])
+    dec.decode([gch[3], och[3]])   # P pictures only: the marked stream waits for an IDR picture
+    assert dec.frame_count(1) == 0 and dec.frame_count(0) == 3 and np.array_equal(dec.read_frames(0, crop=False), good[1][9:12])
+    dec.close()
+
+
 def test_gpu_resolution_change_inside_one_batch(H, sg):
     """Two sequences of different size back to back in ONE chunk of one stream: every picture keeps its own geometry."""
     a = sg.encode(width=176, height=144, frames=3, idr_period=0, profile_idc=77, cabac=1, seed=51)
@@ -528,7 +566,11 @@ def test_gpu_slice_data_carries_the_coded_mb_type(name, H, sg, oracle_mod):
     assert f + 1 == kw["frames"]
     if kw.get("bframes"):
         names = {n for s_, n in seen if s_ == 1}
-        assert {"B_Skip", "B_Direct_16x16", "B_8x8"} <= names and len(names) >= 15, sorted(names)
+        assert {"B_Skip", "B_Direct_16x16"} <= names and len(names) >= 8, sorted(names)
+        if name == "b_ibbp_cabac":
+            assert "B_8x8" in names and len(names) >= 15, sorted(names)
+        if name == "b_gop_intra_pcm":
+            assert any(n.startswith("I_") for n in names), sorted(names)  # intra macroblocks inside B slices: mb_type 23 + the I-slice value
     dec.close()
 
 
