@@ -3,7 +3,8 @@
 //
 // UNVERIFIED: the build image has no Go toolchain; this file was written against the cgo rules and
 // the C header include/h264mi.h but has never been compiled.  The same ABI is exercised from
-// Python ctypes by the test-suite.
+// Python ctypes by the test-suite.  The parameter-set and slice-header structs carry EVERY field of the
+// C structs (structs_gen.go, generated from the header by tools/gen_go_structs.py).
 package h264
 
 /*
@@ -83,17 +84,10 @@ func ReadNalUnits(stream []byte) ([]*NalUnit, error) {
 	}
 }
 
-// SPS mirrors h264/sps.go:9-103 (subset shown; the remaining fields copy the same way).
+// SPS mirrors h264/sps.go:9-103: every field the C ABI carries, under the reference's names (SPSFields, structs_gen.go).
 type SPS struct {
-	c                                                C.h264mi_sps
-	Profile, Level, ID, ChromaFormat                 int
-	Log2MaxFrameNumMinus4, PicOrderCountType         int
-	Log2MaxPicOrderCntLSBMin4, MaxNumRefFrames       int
-	PicWidthInMbsMinus1, PicHeightInMapUnitsMinus1   int
-	FrameMbsOnly, Direct8x8Inference, FrameCropping  bool
-	FrameCropLeftOffset, FrameCropRightOffset        int
-	FrameCropTopOffset, FrameCropBottomOffset        int
-	Width, Height                                    int
+	c C.h264mi_sps
+	SPSFields
 }
 
 func NewSPS(rbsp []byte, showPacket bool) *SPS { // h264/sps.go:192
@@ -102,28 +96,14 @@ func NewSPS(rbsp []byte, showPacket bool) *SPS { // h264/sps.go:192
 		logger.Printf("NewSPS: %v", err)
 		return s
 	}
-	c := &s.c
-	s.Profile, s.Level, s.ID, s.ChromaFormat = int(c.profile), int(c.level), int(c.id), int(c.chroma_format)
-	s.Log2MaxFrameNumMinus4, s.PicOrderCountType = int(c.log2_max_frame_num_minus4), int(c.pic_order_count_type)
-	s.Log2MaxPicOrderCntLSBMin4, s.MaxNumRefFrames = int(c.log2_max_pic_order_cnt_lsb_min4), int(c.max_num_ref_frames)
-	s.PicWidthInMbsMinus1, s.PicHeightInMapUnitsMinus1 = int(c.pic_width_in_mbs_minus1), int(c.pic_height_in_map_units_minus1)
-	s.FrameMbsOnly, s.Direct8x8Inference, s.FrameCropping = c.frame_mbs_only != 0, c.direct_8x8_inference != 0, c.frame_cropping != 0
-	s.FrameCropLeftOffset, s.FrameCropRightOffset = int(c.frame_crop_left_offset), int(c.frame_crop_right_offset)
-	s.FrameCropTopOffset, s.FrameCropBottomOffset = int(c.frame_crop_top_offset), int(c.frame_crop_bottom_offset)
-	s.Width, s.Height = int(c.width), int(c.height)
+	s.SPSFields = copySPSFields(&s.c)
 	return s
 }
 
-// PPS mirrors h264/pps.go:10-38.
+// PPS mirrors h264/pps.go:10-38 (PPSFields, structs_gen.go).
 type PPS struct {
-	c                                              C.h264mi_pps
-	ID, SPSID, EntropyCodingMode                   int
-	NumRefIdxL0DefaultActiveMinus1                 int
-	WeightedPred                                   bool
-	PicInitQpMinus26, ChromaQpIndexOffset          int
-	DeblockingFilterControlPresent                 bool
-	ConstrainedIntraPred                           bool
-	Transform8x8Mode, SecondChromaQpIndexOffset    int
+	c C.h264mi_pps
+	PPSFields
 }
 
 func NewPPS(sps *SPS, rbsp []byte, showPacket bool) *PPS { // h264/pps.go:40
@@ -132,22 +112,12 @@ func NewPPS(sps *SPS, rbsp []byte, showPacket bool) *PPS { // h264/pps.go:40
 		logger.Printf("NewPPS: %v", err)
 		return p
 	}
-	c := &p.c
-	p.ID, p.SPSID, p.EntropyCodingMode = int(c.id), int(c.sps_id), int(c.entropy_coding_mode)
-	p.NumRefIdxL0DefaultActiveMinus1, p.WeightedPred = int(c.num_ref_idx_l0_default_active_minus1), c.weighted_pred != 0
-	p.PicInitQpMinus26, p.ChromaQpIndexOffset = int(c.pic_init_qp_minus26), int(c.chroma_qp_index_offset)
-	p.DeblockingFilterControlPresent, p.ConstrainedIntraPred = c.deblocking_filter_control_present != 0, c.constrained_intra_pred != 0
-	p.Transform8x8Mode, p.SecondChromaQpIndexOffset = int(c.transform_8x8_mode), int(c.second_chroma_qp_index_offset)
+	p.PPSFields = copyPPSFields(&p.c)
 	return p
 }
 
-// SliceHeader mirrors h264/slice.go:23-75 (subset).
-type SliceHeader struct {
-	FirstMbInSlice, SliceType, PPSID, FrameNum, IDRPicID, PicOrderCntLsb int
-	NumRefIdxL0ActiveMinus1, CabacInit, SliceQpDelta                     int
-	DisableDeblockingFilter, SliceAlphaC0OffsetDiv2, SliceBetaOffsetDiv2 int
-	SliceQPy                                                             int
-}
+// SliceHeader mirrors h264/slice.go:23-75 incl. the list-1 / direct / weighted-prediction fields of B slices (SliceHeaderFields).
+type SliceHeader struct{ SliceHeaderFields }
 type Slice struct{ Header *SliceHeader }
 type VideoStream struct { // h264/slice.go:8-12
 	SPS    *SPS
@@ -167,11 +137,127 @@ func NewSliceContext(vs *VideoStream, nal *NalUnit, rbsp []byte, showPacket bool
 		logger.Printf("NewSliceContext: %v", err)
 		return &SliceContext{NalUnit: nal, SPS: vs.SPS, PPS: vs.PPS, Slice: &Slice{Header: &SliceHeader{}}}
 	}
-	h := &SliceHeader{FirstMbInSlice: int(c.first_mb_in_slice), SliceType: int(c.slice_type), PPSID: int(c.pps_id), FrameNum: int(c.frame_num),
-		IDRPicID: int(c.idr_pic_id), PicOrderCntLsb: int(c.pic_order_cnt_lsb), NumRefIdxL0ActiveMinus1: int(c.num_ref_idx_l0_active_minus1),
-		CabacInit: int(c.cabac_init), SliceQpDelta: int(c.slice_qp_delta), DisableDeblockingFilter: int(c.disable_deblocking_filter),
-		SliceAlphaC0OffsetDiv2: int(c.slice_alpha_c0_offset_div2), SliceBetaOffsetDiv2: int(c.slice_beta_offset_div2), SliceQPy: int(c.slice_qp_y)}
-	return &SliceContext{NalUnit: nal, SPS: vs.SPS, PPS: vs.PPS, Slice: &Slice{Header: h}}
+	return &SliceContext{NalUnit: nal, SPS: vs.SPS, PPS: vs.PPS, Slice: &Slice{Header: &SliceHeader{copySliceHeaderFields(&c)}}}
+}
+
+// ---- macroblock layer (h264/slice.go:77-102 SliceData, :570 NewSliceData, h264/mbType.go:75 MbTypeName) ----
+// slice_data() is decoded by the GPU entropy kernel; NewSliceData reads the records it left (128 bytes per macroblock,
+// h264decode_amd/csrc/mi_types.h MbRec) back through h264mi_frame_read_mbrecs / h264mi_frame_read_mbmv1.
+
+const MbTypeInferred = 1000 // h264/mbType.go:5 MB_TYPE_INFERRED
+
+type SliceData struct {
+	MbType                                    int // as coded: Tables 7-11 / 7-13 / 7-14 (intra types in P / B slices: + 5 / + 23)
+	MbTypeName                                string
+	MbSkipFlag, TransformSize8x8Flag          bool
+	QPY, CodedBlockPattern, IntraChromaPredMode int
+	Intra4x4PredMode                          []int8
+	SubMbType                                 []int8
+	RefIdxL0, RefIdxL1                        []int8
+	MvL0, MvL1                                [][2]int16 // final vectors per 4x4 block (the kernel adds the prediction of 8.4.1.3)
+}
+
+// MbTypeName: h264/mbType.go:75-88.  The names follow the rule of Tables 7-11 / 7-13 / 7-14; only the frequent ones are spelled
+// out here, the complete tables live in the Python mirror (h264decode_amd/mbtype.py), which the tests check against the reference.
+func MbTypeName(sliceType string, mbType int) string {
+	if mbType == MbTypeInferred {
+		if sliceType == "B" {
+			return "B_Skip"
+		}
+		return "P_Skip"
+	}
+	off := map[string]int{"I": 0, "P": 5, "SP": 5, "B": 23}[sliceType]
+	if mbType >= off {
+		switch it := mbType - off; {
+		case it == 0:
+			return "I_NxN"
+		case it == 25:
+			return "I_PCM"
+		default:
+			return fmt.Sprintf("I_16x16_%d_%d_%d", (it-1)&3, ((it-1)>>2)%3, (it-1)/12)
+		}
+	}
+	if sliceType == "B" {
+		return [...]string{"B_Direct_16x16", "B_L0_16x16", "B_L1_16x16", "B_Bi_16x16", "B_L0_L0_16x8", "B_L0_L0_8x16", "B_L1_L1_16x8", "B_L1_L1_8x16",
+			"B_L0_L1_16x8", "B_L0_L1_8x16", "B_L1_L0_16x8", "B_L1_L0_8x16", "B_L0_Bi_16x8", "B_L0_Bi_8x16", "B_L1_Bi_16x8", "B_L1_Bi_8x16",
+			"B_Bi_L0_16x8", "B_Bi_L0_8x16", "B_Bi_L1_16x8", "B_Bi_L1_8x16", "B_Bi_Bi_16x8", "B_Bi_Bi_8x16", "B_8x8"}[mbType]
+	}
+	return [...]string{"P_L0_16x16", "P_L0_L0_16x8", "P_L0_L0_8x16", "P_8x8", "P_8x8ref0"}[mbType]
+}
+
+// NewSliceData: h264/slice.go:570, with the Decoder that decoded the picture in the place of the bit reader.
+func NewSliceData(sc *SliceContext, d *Decoder, stream, frame int) ([]SliceData, error) {
+	n := int(sc.SPS.PicWidthInMbs) * int(sc.SPS.PicHeightInMbs)
+	rec := make([]byte, n*128)
+	if err := status(C.h264mi_frame_read_mbrecs(d.h, C.int32_t(stream), C.int32_t(frame), bptr(rec), C.size_t(len(rec)))); err != nil {
+		return nil, err
+	}
+	st := [...]string{"P", "B", "I", "SP", "SI"}[sc.Slice.Header.SliceType%5]
+	var mv1 []byte
+	if st == "B" {
+		mv1 = make([]byte, n*64)
+		if err := status(C.h264mi_frame_read_mbmv1(d.h, C.int32_t(stream), C.int32_t(frame), bptr(mv1), C.size_t(len(mv1)))); err != nil {
+			return nil, err
+		}
+	}
+	i16 := func(b []byte, i int) int16 { return int16(uint16(b[2*i]) | uint16(b[2*i+1])<<8) }
+	out := make([]SliceData, n)
+	for m := range out {
+		r := rec[m*128 : m*128+128]
+		t, cbp := int(r[0]), int(r[5])
+		sd := SliceData{TransformSize8x8Flag: r[1] != 0, QPY: int(r[2]), CodedBlockPattern: cbp, IntraChromaPredMode: int(r[6]), MbSkipFlag: t == 9 || t == 12}
+		intra, inter := t >= 1 && t <= 4, t >= 5
+		raw := 0
+		switch {
+		case t == 3:
+			raw = 1 + int(r[7]) + 4*(cbp>>4)
+			if cbp&15 != 0 {
+				raw += 12
+			}
+		case t == 4:
+			raw = 25
+		case sd.MbSkipFlag:
+			raw = MbTypeInferred
+		case inter:
+			raw = int(r[20]) // MbRec.ipm[4]: mb_type as coded
+		}
+		if intra {
+			raw += map[string]int{"P": 5, "SP": 5, "B": 23}[st]
+		}
+		sd.MbType, sd.MbTypeName = raw, MbTypeName(st, raw)
+		if t == 1 || t == 2 {
+			for k := 0; k < 16; k++ {
+				sd.Intra4x4PredMode = append(sd.Intra4x4PredMode, int8(r[16+k]))
+			}
+		}
+		if inter {
+			for k := 0; k < 4; k++ {
+				sd.RefIdxL0 = append(sd.RefIdxL0, int8(r[32+k]))
+			}
+			for k := 0; k < 16; k++ {
+				sd.MvL0 = append(sd.MvL0, [2]int16{i16(r[48:], 2*k), i16(r[48:], 2*k+1)})
+			}
+			if !sd.MbSkipFlag && (raw == 3 && st != "B" || raw == 22 && st == "B") {
+				for k := 0; k < 4; k++ {
+					sd.SubMbType = append(sd.SubMbType, int8(r[21+k]))
+				}
+			}
+			if st == "B" {
+				for k := 0; k < 4; k++ {
+					ref := int8(-1)
+					if i16(r[120:], k) >= 0 {
+						ref = int8(r[16+k])
+					}
+					sd.RefIdxL1 = append(sd.RefIdxL1, ref)
+				}
+				for k := 0; k < 16; k++ {
+					sd.MvL1 = append(sd.MvL1, [2]int16{i16(mv1[m*64:], 2*k), i16(mv1[m*64:], 2*k+1)})
+				}
+			}
+		}
+		out[m] = sd
+	}
+	return out, nil
 }
 
 // ---- additive API: batched GPU decode (the reference has no pixel type) ----
