@@ -42,6 +42,9 @@
 // by agent-scope loads until every tag shows this launch's epoch: the data is its own flag, so no fence, no separate
 // flag and no assumption about which CU or XCD a band runs on.  A band only ever waits for the band above it, and bands
 // take their (picture, band) from a ticket counter in that order, so whoever a workgroup waits for is already running.
+// In the banded build a group can also be worked on by TWO wavefronts, one filtering luma and one chroma (`roles` = 2): the two
+// planes share nothing but the boundary strengths, which both wavefronts read from the macroblock's DbPrm, so each is an
+// instruction stream about two thirds / one third as long -- and a lone wavefront's step time is its instruction count.
 #ifndef MI_DB_BANDS
 #define MI_DB_BANDS 0
 #endif
@@ -71,8 +74,8 @@ struct GroupSlot { // rows 12..15 of one macroblock column handed to the group b
     alignas(8) uint8_t c[2][2][8];
 };
 struct DbShared { // followed in dynamic LDS by DbWave[nwaves] and the hand-off rings
-    int prog[96]; // per group: macroblock columns of its LAST row that are final (rows 12..15 complete)
-    int cons[96]; // per group: hand-off slots consumed by its FIRST row
+    int prog[192]; // per group (x role): macroblock columns of its LAST row that are final (rows 12..15 complete)
+    int cons[192]; // per group (x role): hand-off slots consumed by its FIRST row
     uint32_t ticket; // banded builds: which (picture, band) this workgroup drew
 };
 static_assert(sizeof(DbShared) <= MI_DEBLOCK_HDR_BYTES && sizeof(DbWave) == MI_DEBLOCK_WAVE_BYTES && sizeof(GroupSlot) == MI_DEBLOCK_SLOT_BYTES,
@@ -164,7 +167,7 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
 
 #if MI_DB_BANDS
 typedef __attribute__((address_space(1))) unsigned long long gu64;
-#define XARGS , unsigned long long *xring_, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus
+#define XARGS , unsigned long long *xring_, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus, int roles
 #define KNAME k_deblock_x
 #else
 #define XARGS
@@ -193,7 +196,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
     const int W = wmb * 16, H = hmb * 16, Wc = W / 2; // the picture's own geometry
     g8 *const py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes); // luma plane; Cb at +W*H, Cr at +W*H*5/4
     const uint32_t cb_off = static_cast<uint32_t>(W) * H, cr_off = cb_off + cb_off / 4;
-    for (int i = tid; i < 96; i += nthreads) sh.prog[i] = 0, sh.cons[i] = 0;
+    for (int i = tid; i < 192; i += nthreads) sh.prog[i] = 0, sh.cons[i] = 0;
     __syncthreads();
     const DbPrm *prms = dbprm + pd->mb_base;
     const int ngroups = (hmb + 3) >> 2;
@@ -203,13 +206,17 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
     // band b owns the groups [b * ngroups / nbands, (b + 1) * ngroups / nbands), one wavefront each (the host launches
     // enough wavefronts for the largest band); rings: region w of LDS is written by wavefront w, also by the band's last one
     const int g0 = band * ngroups / nbands, g1 = (band + 1) * ngroups / nbands;
-    GroupSlot *const in_stage = rings + nwaves * ring; // the slot of the band above, copied from the global ring
+    GroupSlot *const in_stage = rings + nwaves * ring; // the slot of the band above, copied from the global ring (the two roles write disjoint parts of it)
     int pband = band - 1;                               // the band that owns group g0 - 1 (bands of small pictures can be empty)
     while (pband > 0 && pband * ngroups / nbands == (pband + 1) * ngroups / nbands) pband--;
     gu64 *const xin = (gu64 *)xring_ + (static_cast<size_t>(pic_i) * nbands + (pband > 0 ? pband : 0)) * static_cast<size_t>(wmb_max) * 24;
     gu64 *const xout = (gu64 *)xring_ + (static_cast<size_t>(pic_i) * nbands + band) * static_cast<size_t>(wmb_max) * 24;
-    for (int g = g0 + wave; g < g1; g += ngroups) { // at most one iteration
+    // roles == 2: wavefront 2k filters the luma of the band's k-th group, wavefront 2k + 1 its chroma
+    const int role = roles == 2 ? (wave & 1) : -1, gw = roles == 2 ? wave >> 1 : wave;
+    const bool do_l = role != 1, do_c = role != 0;
+    for (int g = g0 + gw; g < g1; g += ngroups) { // at most one iteration
 #else
+    const bool do_l = true, do_c = true;
     for (int g = wave; g < ngroups; g += nwaves) {
 #endif
         int lane = lane_v;
@@ -222,16 +229,19 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
         // hand-off rings: the one this group writes (region `wave`) and the one it reads (written by group g - 1)
         // (the last wavefront's region holds whole rows and, from three rounds on, one buffer per round parity: see mi_deblock_plan)
 #if MI_DB_BANDS
-        const bool band_first = wave == 0 && g > 0;            // the rows above come from another workgroup
+        const bool band_first = gw == 0 && g > 0;              // the rows above come from another workgroup
+        const int pc = roles == 2 ? 2 * g + role : g, pc_up = roles == 2 ? 2 * (g - 1) + role : g - 1, pc_dn = roles == 2 ? 2 * (g + 1) + role : g + 1; // counters of this / the upper / the lower group
         const bool to_global = feeds_group && g == g1 - 1;     // the bottom rows go to another workgroup
         const int out_depth = ring;
         GroupSlot *out_ring = rings + wave * ring;
         const int in_depth = band_first ? 1 : ring;
-        const GroupSlot *in_ring = band_first ? in_stage : rings + (wave > 0 ? wave - 1 : 0) * ring;
+        const GroupSlot *in_ring = band_first ? in_stage : rings + (gw > 0 ? wave - (roles == 2 ? 2 : 1) : 0) * ring;
         // this lane's granule of the slot of column 0 (lanes 0..23: the 24 dwords of a GroupSlot), re-read until its tag matches
         unsigned long long pf = 0;
-        if (band_first && lane < 24) pf = __hip_atomic_load(xin + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool gran = lane < 24 && (lane < 16 ? do_l : do_c); // the granules of this wavefront's planes: 16 luma dwords, 8 chroma dwords
+        if (band_first && gran) pf = __hip_atomic_load(xin + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
+        const int pc = g, pc_up = g - 1, pc_dn = g + 1;
         const bool out_last = wave == nwaves - 1;
         const int out_depth = out_last ? ring_last : ring;
         GroupSlot *out_ring = rings + wave * ring + (out_last ? ((g / nwaves) % last_bufs) * ring_last : 0);
@@ -252,10 +262,18 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             const uint32_t yb = yrow0 + gb * 16, cb = crow0 + gb * 8;
             const int left = wmb - gb;
             const int j0 = (0 - sub) & 3, j1 = (1 - sub) & 3, j2 = (2 - sub) & 3, j3 = (3 - sub) & 3; // position inside the group of slot s
-            if (j0 < left) P0 = GLD16(py, yb + j0 * 16), Q0 = GLD8(py, cb + j0 * 8);
-            if (j1 < left) P1 = GLD16(py, yb + j1 * 16), Q1 = GLD8(py, cb + j1 * 8);
-            if (j2 < left) P2 = GLD16(py, yb + j2 * 16), Q2 = GLD8(py, cb + j2 * 8);
-            if (j3 < left) P3 = GLD16(py, yb + j3 * 16), Q3 = GLD8(py, cb + j3 * 8);
+            if (do_l) {
+                if (j0 < left) P0 = GLD16(py, yb + j0 * 16);
+                if (j1 < left) P1 = GLD16(py, yb + j1 * 16);
+                if (j2 < left) P2 = GLD16(py, yb + j2 * 16);
+                if (j3 < left) P3 = GLD16(py, yb + j3 * 16);
+            }
+            if (do_c) {
+                if (j0 < left) Q0 = GLD8(py, cb + j0 * 8);
+                if (j1 < left) Q1 = GLD8(py, cb + j1 * 8);
+                if (j2 < left) Q2 = GLD8(py, cb + j2 * 8);
+                if (j3 < left) Q3 = GLD8(py, cb + j3 * 8);
+            }
         };
         auto prefetch_rec = [&](int mbx) { // lanes 0..4 of a sub-row: the five 16-byte pieces of the macroblock's DbPrm
             if (!row_ok || mbx < 0 || mbx >= wmb || li >= 5) return;
@@ -275,14 +293,14 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
         const uint32_t cout = upc_lane && has_top ? crow0 - 8u * Wc : crow0;
         auto flush = [&](int first_mb, int n_mb) { // columns first_mb .. first_mb + n_mb - 1 (an aligned group, or its start)
             const int j0 = (0 - sub) & 3, j1 = (1 - sub) & 3, j2 = (2 - sub) & 3, j3 = (3 - sub) & 3;
-            if (y_stores) {
+            if (y_stores && do_l) {
                 const uint32_t yb = yout + first_mb * 16;
                 if (j0 < n_mb) GST16(py, yb + j0 * 16, R0);
                 if (j1 < n_mb) GST16(py, yb + j1 * 16, R1);
                 if (j2 < n_mb) GST16(py, yb + j2 * 16, R2);
                 if (j3 < n_mb) GST16(py, yb + j3 * 16, R3);
             }
-            if (c_stores) {
+            if (c_stores && do_c) {
                 const uint32_t cb = cout + first_mb * 8;
                 if (j0 < n_mb) GST8(py, cb + j0 * 8, S0);
                 if (j1 < n_mb) GST8(py, cb + j1 * 8, S1);
@@ -332,7 +350,8 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             uint32_t Vbs[2] = {0, 0}, Vab[2] = {0, 0}, Vtc[2] = {0, 0}, Hbs[2] = {0, 0}, Hab[2] = {0, 0}, Htc[2] = {0, 0};
             if (active) {
                 const v4u bv = *reinterpret_cast<const v4u *>(ss->prm.bs[0][0]), bh = *reinterpret_cast<const v4u *>(ss->prm.bs[1][0]);
-                const v4u blk_l = *reinterpret_cast<const v4u *>(&ss->prm.pl[0]), blk_c = *reinterpret_cast<const v4u *>(&ss->prm.pl[1 + (li >> 3)]);
+                const v4u z4p = v4u{0u, 0u, 0u, 0u};
+                const v4u blk_l = do_l ? *reinterpret_cast<const v4u *>(&ss->prm.pl[0]) : z4p, blk_c = do_c ? *reinterpret_cast<const v4u *>(&ss->prm.pl[1 + (li >> 3)]) : z4p;
                 auto pick = [](v4u w, int sh8, bool chroma) {
                     const uint32_t b0 = (w.x >> sh8) & 255u, b1 = (w.y >> sh8) & 255u, b2 = (w.z >> sh8) & 255u, b3 = (w.w >> sh8) & 255u;
                     return chroma ? (b0 | (b2 << 16)) : (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
@@ -347,10 +366,14 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                     vtc = sel(tw0, vbs) | (sel(tw1, vbs >> 8) << 8) | (sel(tw1, vbs >> 16) << 16) | (sel(tw1, vbs >> 24) << 24);
                     htc = sel(tw2, hbs) | (sel(tw1, hbs >> 8) << 8) | (sel(tw1, hbs >> 16) << 16) | (sel(tw1, hbs >> 24) << 24);
                 };
-                Vbs[0] = pick(bv, 8 * (li >> 2), false), Vbs[1] = pick(bv, 8 * ((li & 7) >> 1), true);
-                Hbs[0] = pick(bh, 8 * (li >> 2), false), Hbs[1] = pick(bh, 8 * ((li & 7) >> 1), true);
-                params(blk_l, Vbs[0], Hbs[0], Vab[0], Vtc[0], Hab[0], Htc[0]);
-                params(blk_c, Vbs[1], Hbs[1], Vab[1], Vtc[1], Hab[1], Htc[1]);
+                if (do_l) {
+                    Vbs[0] = pick(bv, 8 * (li >> 2), false), Hbs[0] = pick(bh, 8 * (li >> 2), false);
+                    params(blk_l, Vbs[0], Hbs[0], Vab[0], Vtc[0], Hab[0], Htc[0]);
+                }
+                if (do_c) {
+                    Vbs[1] = pick(bv, 8 * ((li & 7) >> 1), true), Hbs[1] = pick(bh, 8 * ((li & 7) >> 1), true);
+                    params(blk_c, Vbs[1], Hbs[1], Vab[1], Vtc[1], Hab[1], Htc[1]);
+                }
             }
             STAMP(0);
             // ---- 2. vertical edges: lane li = luma row li, then chroma (plane li >> 3, row li & 7) ----
@@ -359,11 +382,11 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                 uint32_t w0 = 0, w1 = in_y.x, w2 = in_y.y, w3 = in_y.z, w4 = in_y.w; // w0 = columns -4..-1
                 uint32_t c0 = 0, c1 = in_c.x, c2 = in_c.y;
                 if (active && mbx > 0) {
-                    w0 = *reinterpret_cast<const uint32_t *>(&ss->y[4 + li][28]); // columns 12..15 of the previous macroblock, after its horizontal pass
-                    c0 = *reinterpret_cast<const uint32_t *>(&ss->c[li >> 3][4 + (li & 7)][12]);
+                    if (do_l) w0 = *reinterpret_cast<const uint32_t *>(&ss->y[4 + li][28]); // columns 12..15 of the previous macroblock, after its horizontal pass
+                    if (do_c) c0 = *reinterpret_cast<const uint32_t *>(&ss->c[li >> 3][4 + (li & 7)][12]);
                 }
                 if (__builtin_amdgcn_ballot_w64(any) != 0) {
-                    {
+                    if (do_l) {
                         int px[20];
                         unpack4(w0, px[0], px[1], px[2], px[3]);
                         unpack4(w1, px[4], px[5], px[6], px[7]);
@@ -380,7 +403,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                         w3 = pack4(px[12], px[13], px[14], px[15]), w4 = pack4(px[16], px[17], px[18], px[19]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    { // chroma: luma edges 0 and 2
+                    if (do_c) { // chroma: luma edges 0 and 2
                         int px[12];
                         unpack4(c0, px[0], px[1], px[2], px[3]);
                         unpack4(c1, px[4], px[5], px[6], px[7]);
@@ -392,11 +415,15 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                     }
                 }
                 if (active) { // the line goes into the tile for the horizontal pass
-                    *reinterpret_cast<uint32_t *>(&ss->y[4 + li][12]) = w0;
-                    *reinterpret_cast<v4u *>(&ss->y[4 + li][16]) = v4u{w1, w2, w3, w4};
-                    uint8_t *cr = &ss->c[li >> 3][4 + (li & 7)][4];
-                    *reinterpret_cast<uint32_t *>(cr) = c0;
-                    *reinterpret_cast<v2u *>(cr + 4) = v2u{c1, c2};
+                    if (do_l) {
+                        *reinterpret_cast<uint32_t *>(&ss->y[4 + li][12]) = w0;
+                        *reinterpret_cast<v4u *>(&ss->y[4 + li][16]) = v4u{w1, w2, w3, w4};
+                    }
+                    if (do_c) {
+                        uint8_t *cr = &ss->c[li >> 3][4 + (li & 7)][4];
+                        *reinterpret_cast<uint32_t *>(cr) = c0;
+                        *reinterpret_cast<v2u *>(cr + 4) = v2u{c1, c2};
+                    }
                 }
             }
             WAVE_SYNC();
@@ -405,7 +432,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             // 3a. columns 12..15 of the previous macroblock are final now: complete its bottom rows where they wait
             //     (the buffer for the sub-row below, or the ring slot for the group below), then publish the column
             const bool to_ring = sub == last_sub; // the group's last row feeds the next group, the others the sub-row below
-            if (active && mbx > 0 && !last_row && li < 8) {
+            if (active && mbx > 0 && !last_row && li < 8 && (li < 4 ? do_l : do_c)) {
                 const int cpl = (li >> 1) & 1, r = li & 1;
                 GroupSlot *gl = &out_ring[(mbx - 1) % out_depth];
                 uint32_t *dst;
@@ -421,13 +448,13 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                 const int xl = t - last_sub; // column of the group's last row in this step: columns 0 .. xl - 1 are final now
 #if MI_DB_BANDS
                 if (to_global) { // the finished slot of column xl - 1 leaves as 24 granules
-                    if (xl >= 1 && xl < wmb && lane < 24)
+                    if (xl >= 1 && xl < wmb && gran)
                         __hip_atomic_store(xout + (xl - 1) * 24 + lane,
                                            (static_cast<unsigned long long>(epoch) << 32) | reinterpret_cast<const uint32_t *>(&out_ring[(xl - 1) % out_depth])[lane],
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 } else
 #endif
-                if (xl >= 1 && xl < wmb && lane == 0) __hip_atomic_store(&sh.prog[g], xl, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (xl >= 1 && xl < wmb && lane == 0) __hip_atomic_store(&sh.prog[pc], xl, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             // 3b. rows above this macroblock: from the sub-row above (same wavefront, written in the previous step and just
             //     completed), or -- sub-row 0 -- from the group above through its ring, once it says the column is final
@@ -437,24 +464,24 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                     // every granule of column t must carry this launch's epoch (the data is the flag); stragglers are re-read
                     const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
                     for (;;) {
-                        const bool ok = lane >= 24 || static_cast<uint32_t>(pf >> 32) == epoch;
+                        const bool ok = !gran || static_cast<uint32_t>(pf >> 32) == epoch;
                         if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
                         __builtin_amdgcn_s_sleep(2);
-                        if (lane < 24) pf = __hip_atomic_load(xin + t * 24 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (gran) pf = __hip_atomic_load(xin + t * 24 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (__builtin_amdgcn_s_memrealtime() - t_start > 400000000ull) { // 4 s at 100 MHz: report instead of hanging the GPU
                             if (lane == 0) atomicExch(xstatus, 0x5D000000u | static_cast<uint32_t>(g));
                             break;
                         }
                     }
-                    if (lane < 24) reinterpret_cast<uint32_t *>(in_stage)[lane] = static_cast<uint32_t>(pf);
-                    if (t + 1 < wmb && lane < 24) pf = __hip_atomic_load(xin + (t + 1) * 24 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // next step's slot
+                    if (gran) reinterpret_cast<uint32_t *>(in_stage)[lane] = static_cast<uint32_t>(pf);
+                    if (t + 1 < wmb && gran) pf = __hip_atomic_load(xin + (t + 1) * 24 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // next step's slot
                 }
             } else
 #endif
             if (g > 0 && t < wmb)
-                while (__hip_atomic_load(&sh.prog[g - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
+                while (__hip_atomic_load(&sh.prog[pc_up], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
             WAVE_SYNC();
-            if (active && has_top && li < 8) {
+            if (active && has_top && li < 8 && (li < 4 ? do_l : do_c)) {
                 const int cpl = (li >> 1) & 1, r = li & 1;
                 const GroupSlot *gs = &in_ring[(mbx > 0 ? mbx : 0) % in_depth];
                 if (li < 4)
@@ -464,14 +491,14 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             }
             WAVE_SYNC();
             if (g > 0 && t < wmb && lane == 0) // the hand-off slot of column t has been copied: the group above may reuse it
-                __hip_atomic_store(&sh.cons[g], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&sh.cons[pc], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             STAMP(2);
             // ---- 4. horizontal edges: lane li = luma column li, then chroma (plane li >> 3, column li & 7) ----
             {
                 const bool any = (Hbs[0] | Hbs[1]) != 0;
                 if (__builtin_amdgcn_ballot_w64(any) != 0) {
                     if (any) {
-                        {
+                        if (do_l) {
                             int px[20];
 #pragma unroll
                             for (int r = 0; r < 20; r++) px[r] = ss->y[r][16 + li];
@@ -485,7 +512,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                             for (int r = 1; r < 19; r++) ss->y[r][16 + li] = static_cast<uint8_t>(px[r]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        {
+                        if (do_c) {
                             const int cpl = li >> 3, i = li & 7;
                             int px[12];
                             px[0] = px[1] = 0;
@@ -512,37 +539,49 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
 #endif
                 const int xl = t - last_sub;
                 if (xl >= out_depth && xl < wmb)
-                    while (__hip_atomic_load(&sh.cons[g + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < xl - out_depth + 1) __builtin_amdgcn_s_sleep(1);
+                    while (__hip_atomic_load(&sh.cons[pc_dn], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < xl - out_depth + 1) __builtin_amdgcn_s_sleep(1);
             }
             if (active) {
                 const bool row_end = mbx == wmb - 1;
                 // finished bytes of this step.  Own rows: columns 12..15 of the macroblock to the left complete ITS register
                 // slot, columns 0..11 of this one open a new slot.  Rows of the macroblock above (up lanes): all 16 columns.
-                const uint32_t l4 = *reinterpret_cast<const uint32_t *>(&ss->y[4 + li][12]);
-                const v4u own = *reinterpret_cast<const v4u *>(&ss->y[up_lane ? li - 12 : 4 + li][16]); // up lanes: tile rows 1..3 = rows -3..-1
-                const uint8_t *crp = &ss->c[li >> 3][upc_lane ? 3 : 4 + (li & 7)][4];                     // chroma up lanes: row -1
-                const uint32_t cl4 = *reinterpret_cast<const uint32_t *>(crp);
-                const v2u cown = *reinterpret_cast<const v2u *>(crp + 4);
+                uint32_t l4 = 0, cl4 = 0;
+                v4u own = z4;
+                v2u cown = z2;
+                if (do_l) {
+                    l4 = *reinterpret_cast<const uint32_t *>(&ss->y[4 + li][12]);
+                    own = *reinterpret_cast<const v4u *>(&ss->y[up_lane ? li - 12 : 4 + li][16]); // up lanes: tile rows 1..3 = rows -3..-1
+                }
+                if (do_c) {
+                    const uint8_t *crp = &ss->c[li >> 3][upc_lane ? 3 : 4 + (li & 7)][4]; // chroma up lanes: row -1
+                    cl4 = *reinterpret_cast<const uint32_t *>(crp);
+                    cown = *reinterpret_cast<const v2u *>(crp + 4);
+                }
                 const int ps = (t + 3) & 3; // slot of the previous column
                 if (mbx > 0) {
-                    if (!up_lane) {
+                    if (!up_lane && do_l) {
                         if (ps == 0) R0.w = l4; else if (ps == 1) R1.w = l4; else if (ps == 2) R2.w = l4; else R3.w = l4;
                     }
-                    if (!upc_lane) {
+                    if (!upc_lane && do_c) {
                         if (ps == 0) S0.y = cl4; else if (ps == 1) S1.y = cl4; else if (ps == 2) S2.y = cl4; else S3.y = cl4;
                     }
                     if ((mbx & 3) == 0) flush(mbx - 4, 4); // that completed the previous aligned group
                 }
-                if (ts == 0) R0 = own, S0 = cown; else if (ts == 1) R1 = own, S1 = cown; else if (ts == 2) R2 = own, S2 = cown; else R3 = own, S3 = cown;
+                if (do_l) {
+                    if (ts == 0) R0 = own; else if (ts == 1) R1 = own; else if (ts == 2) R2 = own; else R3 = own;
+                }
+                if (do_c) {
+                    if (ts == 0) S0 = cown; else if (ts == 1) S1 = cown; else if (ts == 2) S2 = cown; else S3 = cown;
+                }
                 if (row_end) flush(mbx & ~3, (mbx & 3) + 1); // no macroblock to the right: the last columns are final too
                 if (last_row && has_top) { // the up lanes own rows 13..15 here: rows -3..-1 of the macroblock above go out directly
-                    if (li < 3)
+                    if (li < 3 && do_l)
                         GST16(py, static_cast<uint32_t>(mby * 16 - 3 + li) * W + mbx * 16, *reinterpret_cast<const v4u *>(&ss->y[1 + li][16]));
-                    else if (li >= 8 && li < 10)
+                    else if (li >= 8 && li < 10 && do_c)
                         GST8(py, (li == 8 ? cb_off : cr_off) + static_cast<uint32_t>(mby * 8 - 1) * Wc + mbx * 8, *reinterpret_cast<const v2u *>(&ss->c[li - 8][3][8]));
                 }
                 // bottom rows of this macroblock (columns 12..15 still provisional unless the row ends here) for whoever is below
-                if (!last_row && li < 8) {
+                if (!last_row && li < 8 && (li < 4 ? do_l : do_c)) {
                     const int cpl = (li >> 1) & 1, r = li & 1;
                     GroupSlot *gs = &out_ring[mbx % out_depth];
                     if (li < 4)
@@ -554,14 +593,14 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             WAVE_SYNC();
 #if MI_DB_BANDS
             if (to_global) {
-                if (t - last_sub == wmb - 1 && lane < 24)
+                if (t - last_sub == wmb - 1 && gran)
                     __hip_atomic_store(xout + (wmb - 1) * 24 + lane,
                                        (static_cast<unsigned long long>(epoch) << 32) | reinterpret_cast<const uint32_t *>(&out_ring[(wmb - 1) % out_depth])[lane],
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else
 #endif
             if (feeds_group && t - last_sub == wmb - 1 && lane == 0) // the last column of the group's last row is final without a right neighbour
-                __hip_atomic_store(&sh.prog[g], wmb, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&sh.prog[pc], wmb, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             STAMP(4);
         }
 #if defined(MI_DB_STATS) && MI_DB_BANDS

@@ -1539,11 +1539,11 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         } else
             hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, g.d_lists + g.wave_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, coef);
         mark(2);
-        int dbw = 1, dbring = 16, dbring_last = 16, dbbufs = 1, nb5 = 1;
-        mi_deblock_bands(static_cast<int>(n), g.wmb_max, g.hmb_max, d->x_max_wgs, &nb5, &dbw, &dbring);
+        int dbw = 1, dbring = 16, dbring_last = 16, dbbufs = 1, nb5 = 1, roles = 1;
+        mi_deblock_bands(static_cast<int>(n), g.wmb_max, g.hmb_max, d->x_max_wgs, &nb5, &dbw, &dbring, &roles);
         if (nb5 > 1) {
             hipLaunchKernelGGL(k_deblock_x, dim3(n * nb5), dim3(dbw * 64), mi_deblock_lds_bytes_banded(dbw, dbring), rs, g.d_lists + g.wave_off[w], g.d_pics,
-                               d->d_dbprm[set], dbring, 0, 1, d->d_xring, next_epoch(), nb5, d->d_xctl, d->x_tk5, g.wmb_max, d->d_xctl + 64);
+                               d->d_dbprm[set], dbring, 0, 1, d->d_xring, next_epoch(), nb5, d->d_xctl, d->x_tk5, g.wmb_max, d->d_xctl + 64, roles);
             d->x_tk5 += n * nb5;
         } else {
             mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
@@ -1854,10 +1854,11 @@ extern "C" int32_t h264mi_internal_deblock_phase_clocks(h264mi_decoder *d, uint3
 extern "C" int32_t h264mi_internal_band_plan(int32_t n_pics, int32_t wmb, int32_t hmb, int32_t max_wgs, int32_t *k5_bands, int32_t *k5_waves, int32_t *k5_ring,
                                              int64_t *k5_lds, int32_t *k3_bands, int32_t *k3_waves) {
     if (!k5_bands || !k5_waves || !k5_ring || !k5_lds || !k3_bands || !k3_waves || n_pics < 1 || wmb < 1 || hmb < 1) return H264MI_EINVAL;
-    int nb = 1, nw = 1, ring = 1, b3 = 1, w3 = 1;
-    mi_deblock_bands(n_pics, wmb, hmb, max_wgs, &nb, &nw, &ring);
+    int nb = 1, nw = 1, ring = 1, b3 = 1, w3 = 1, roles = 1;
+    mi_deblock_bands(n_pics, wmb, hmb, max_wgs, &nb, &nw, &ring, &roles);
     mi_intra_bands(n_pics, hmb, max_wgs, &b3, &w3);
-    *k5_bands = nb, *k5_waves = nw, *k5_ring = ring, *k5_lds = static_cast<int64_t>(mi_deblock_lds_bytes_banded(nw, ring));
+    // (the model test works on groups: the kernel runs `roles` wavefronts on each, which follow the same protocol side by side)
+    *k5_bands = nb, *k5_waves = nw / roles, *k5_ring = ring, *k5_lds = static_cast<int64_t>(mi_deblock_lds_bytes_banded(nw, ring));
     *k3_bands = b3, *k3_waves = w3;
     return H264MI_OK;
 }

@@ -39,11 +39,12 @@ extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pi
 // dynamic LDS = mi_deblock_lds_bytes_banded().  xring: pictures * nbands * wmb_max * 24 granules of 8 bytes; epoch: a value no earlier
 // launch on this ring has used (never 0); ticket / ticket_base: a counter that only ever grows and its value before this launch.
 extern "C" __global__ void k_deblock_x(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring, int ring_last, int last_bufs,
-                                       unsigned long long *xring, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus);
+                                       unsigned long long *xring, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus,
+                                       int roles);
 #ifndef MI_DEBLOCK_MAX_WAVES
 #define MI_DEBLOCK_MAX_WAVES 12    /* 1024 threads; LDS: 6 KB of row state per wavefront + its hand-off ring */
 #endif
-#define MI_DEBLOCK_HDR_BYTES 784   /* sizeof(DbShared) rounded up to 16 */
+#define MI_DEBLOCK_HDR_BYTES 1552  /* sizeof(DbShared) rounded up to 16 */
 #define MI_DEBLOCK_WAVE_BYTES 4800 /* 4 sub-rows: sample tiles, the macroblock's DbPrm, the bottom rows for the sub-row below */
 #define MI_DEBLOCK_SLOT_BYTES 96
 #define MI_DEBLOCK_LDS_MAX (160 * 1024)
@@ -58,13 +59,16 @@ static inline size_t mi_deblock_lds_bytes_banded(int nwaves, int ring, int wave_
 // How a launch of n_pics pictures of up to wmb x hmb macroblocks is spread over the chip.  nbands = 1: the one-workgroup kernels.
 // Otherwise every band is one round of at most MI_DEBLOCK_MAX_WAVES groups, and pictures * bands stays within `max_wgs`
 // workgroups (all of them can be resident at once; the ticket order makes the hand-off safe even if they are not).
-static inline void mi_deblock_bands(int n_pics, int wmb, int hmb, int max_wgs, int *nbands, int *nwaves, int *ring) {
+static inline void mi_deblock_bands(int n_pics, int wmb, int hmb, int max_wgs, int *nbands, int *nwaves, int *ring, int *roles) {
     const int ngroups = (hmb + 3) / 4;
     int nb = n_pics > 0 ? max_wgs / n_pics : 1;
     if (nb > ngroups) nb = ngroups;
     if (nb < 2 || (ngroups + nb - 1) / nb > MI_DEBLOCK_MAX_WAVES) nb = 1;
+    const int per_band = (ngroups + nb - 1) / nb;
+    // two wavefronts per group (luma | chroma) while every wavefront of the launch can still have a SIMD to itself (1024 of them)
+    *roles = (nb > 1 && 2 * per_band <= MI_DEBLOCK_MAX_WAVES && 2 * n_pics * ngroups <= 1280) ? 2 : 1;
     *nbands = nb;
-    *nwaves = (ngroups + nb - 1) / nb;
+    *nwaves = per_band * *roles;
     *ring = wmb < 16 ? (wmb > 0 ? wmb : 1) : 16;
 }
 // Wavefront count and hand-off ring depths for pictures of wmb x hmb macroblocks.  Wavefront w runs the 4-row groups

@@ -241,7 +241,7 @@ def test_deblock_launch_plan_cannot_deadlock(H):
             groups = (hmb + 3) // 4
             rounds = (groups + nw.value - 1) // nw.value
             assert 1 <= nw.value <= min(maxw, groups) and lds.value <= 160 * 1024, (wmb, hmb, nw.value, lds.value)
-            assert lds.value == 784 + nw.value * 4800 + ((nw.value - 1) * ring.value + ring_last.value * nb.value) * 96
+            assert lds.value == 1552 + nw.value * 4800 + ((nw.value - 1) * ring.value + ring_last.value * nb.value) * 96
             assert nb.value == (2 if rounds > 2 else 1)  # a single whole-row buffer deadlocks from three rounds on (test_deblock_schedule_model)
             assert 1 <= ring.value <= wmb and ring.value >= min(wmb, 16)
             assert ring_last.value == (wmb if rounds > 1 else ring.value), (wmb, hmb, nw.value, ring.value, ring_last.value)
