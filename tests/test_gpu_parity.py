@@ -566,7 +566,9 @@ def test_gpu_slice_data_carries_the_coded_mb_type(name, H, sg, oracle_mod):
     assert f + 1 == kw["frames"]
     if kw.get("bframes"):
         names = {n for s_, n in seen if s_ == 1}
-        assert {"B_Skip", "B_Direct_16x16"} <= names and len(names) >= 8, sorted(names)
+        assert len(names) >= 8, sorted(names)
+        if kw.get("bskip_permille"):
+            assert {"B_Skip", "B_Direct_16x16"} <= names, sorted(names)
         if name == "b_ibbp_cabac":
             assert "B_8x8" in names and len(names) >= 15, sorted(names)
         if name == "b_gop_intra_pcm":
