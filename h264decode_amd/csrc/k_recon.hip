@@ -581,7 +581,10 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
 // (picture, band) from a ticket counter in that order, so the workgroup being waited for is always running.
 extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab,
                                                                             const MbRec *mbrec, const int16_t *coefs, uint32_t *xdone_, uint32_t epoch, int nbands,
-                                                                            uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus) {
+                                                                            uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus, int wpr) {
+    // wpr ("wavefronts per row"): the intra macroblocks of a row are dealt round-robin to wpr wavefronts.  In P / B pictures they are
+    // few and mostly independent of each other, so the busiest row -- which bounds the kernel -- finishes wpr times sooner; a
+    // macroblock whose left neighbour is an intra one too waits for that neighbour's bit like it waits for the row above.
     __shared__ IntraShared sh;
     __shared__ uint32_t s_ticket;
     const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6, nthreads = static_cast<int>(blockDim.x), nwaves = nthreads >> 6;
@@ -617,17 +620,28 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(cons
         }
     __syncthreads();
     IntraWave *ws = &sh.w[wave];
-    for (int mby = r0 + wave; mby < r1; mby += nwaves) {
+    const int row_slot = wave / wpr, turn = wave - row_slot * wpr, row_slots = nwaves / wpr;
+    for (int mby = r0 + row_slot; mby < r1; mby += row_slots) {
         const MbRec *row = recs + static_cast<uint64_t>(mby) * wmb;
         const bool publish = mby == r1 - 1 && r1 < hmb; // the band below waits for this row
+        int nth = 0; // ordinal of the intra macroblock inside the row
         for (int c = 0; c < nchunks; c++) {
-            unsigned long long mask = sh.pend[mby][c];
+            const unsigned long long row_mask = sh.pend[mby][c]; // as pass 1 left it (bits are cleared as macroblocks finish)
+            unsigned long long mask = row_mask;
             while (mask) {
                 const int k = __ffsll(static_cast<long long>(mask)) - 1;
                 mask &= mask - 1;
+                if (wpr > 1 && (nth++ % wpr) != turn) continue; // another wavefront's macroblock
                 const int mbx = c * 64 + k;
                 if (lane < 32) reinterpret_cast<uint32_t *>(&ws->rec)[lane] = reinterpret_cast<const uint32_t *>(row + mbx)[lane];
                 WAVE_SYNC();
+                if (wpr > 1 && mbx > 0) { // the left neighbour, if it is an intra macroblock, belongs to another wavefront of this row
+                    const int xl = mbx - 1;
+                    const unsigned long long bit = 1ull << (xl & 63);
+                    const bool left_intra = (xl >> 6) == c ? (row_mask & bit) != 0 : (sh.pend[mby][xl >> 6] & bit) != 0; // (a set bit there: intra and not finished)
+                    if (left_intra)
+                        while (__hip_atomic_load(&sh.pend[mby][xl >> 6], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) __builtin_amdgcn_s_sleep(1);
+                }
                 if (mby > 0) {
                     const int xl = max(mbx - 1, 0), xr = min(mbx + 1, wmb - 1);
                     const int c0 = xl >> 6, c1 = xr >> 6;

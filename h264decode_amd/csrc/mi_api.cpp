@@ -231,7 +231,7 @@ struct h264mi_decoder {
     uint32_t *d_xdone = nullptr;           // K3: x_cap * (Wmax / 16) flag words
     uint32_t *d_xctl = nullptr, *h_xstatus = nullptr; // [0] K5 tickets, [32] K3 tickets, [64] give-up code (128-byte lines of their own)
     uint32_t x_epoch = 0, x_tk5 = 0, x_tk3 = 0;
-    int x_max_wgs = 256, x_cap = 512;
+    int x_max_wgs = 256, x_cap = 512, x_cap3 = 512; // workgroups per launch: default; capacity of the K5 ring; of the K3 flag array
     PackDesc *h_pack = nullptr, *d_pack = nullptr; // K6 descriptor table
     size_t pack_cap = 0;
     std::vector<float> launch_ms[4]; // duration of every launch of the last profiled pass, per kernel
@@ -476,12 +476,12 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     // cross-workgroup hand-off state of the banded kernels; H264MI_X_WGS = 0 switches them off, n: up to n workgroups per launch
     if (const char *e = getenv("H264MI_X_WGS")) d->x_max_wgs = std::min(std::max(atoi(e), 0), d->x_cap);
     DEV_ALLOC(d->d_xring, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long));
-    DEV_ALLOC(d->d_xdone, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * sizeof(uint32_t));
+    DEV_ALLOC(d->d_xdone, static_cast<size_t>(d->x_cap3) * (d->Wmax / 16) * sizeof(uint32_t));
     DEV_ALLOC(d->d_xctl, 3 * 128);
     TRY_ALLOC(hipHostMalloc(&d->h_xstatus, sizeof(uint32_t)));
     *d->h_xstatus = 0;
     TRY_ALLOC(hipMemset(d->d_xring, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long)));
-    TRY_ALLOC(hipMemset(d->d_xdone, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * sizeof(uint32_t)));
+    TRY_ALLOC(hipMemset(d->d_xdone, 0, static_cast<size_t>(d->x_cap3) * (d->Wmax / 16) * sizeof(uint32_t)));
     TRY_ALLOC(hipMemset(d->d_xctl, 0, 3 * 128));
     build_tables(d->h_tables);
     d->h_pools.resize(S);
@@ -1506,7 +1506,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     auto next_epoch = [&]() {
         if (++d->x_epoch == 0) {
             hipMemsetAsync(d->d_xring, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long), rs);
-            hipMemsetAsync(d->d_xdone, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * sizeof(uint32_t), rs);
+            hipMemsetAsync(d->d_xdone, 0, static_cast<size_t>(d->x_cap3) * (d->Wmax / 16) * sizeof(uint32_t), rs);
             d->x_epoch = 1;
         }
         return d->x_epoch;
@@ -1530,11 +1530,15 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         }
         // K3 / K5 keep a picture inside one workgroup when the launch has pictures enough to fill the chip; otherwise the
         // banded kernels spread each picture over up to x_max_wgs / pictures workgroups (mi_intra_bands / mi_deblock_bands)
-        int nb3 = 1, nw3 = MI_INTRA_WAVES;
-        mi_intra_bands(static_cast<int>(n), g.hmb_max, d->x_max_wgs, &nb3, &nw3);
+        // (K3 of a launch WITHOUT intra-only pictures -- the few intra macroblocks of P / B pictures -- is bound by the row with the most
+        // of them: there the banded kernel also puts several wavefronts on a row)
+        int nb3 = 1, nw3 = MI_INTRA_WAVES, wpr3 = 1;
+        bool has_ipic = false;
+        for (uint32_t pi : g.waves[w]) has_ipic |= g.h_pics[pi].is_intra_only != 0;
+        mi_intra_bands(static_cast<int>(n), g.hmb_max, d->x_max_wgs, !has_ipic, &nb3, &nw3, &wpr3);
         if (nb3 > 1) {
             hipLaunchKernelGGL(k_intra_x, dim3(n * nb3), dim3(nw3 * 64), 0, rs, g.d_lists + g.wave_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, coef, d->d_xdone,
-                               next_epoch(), nb3, d->d_xctl + 32, d->x_tk3, g.wmb_max, d->d_xctl + 64);
+                               next_epoch(), nb3, d->d_xctl + 32, d->x_tk3, g.wmb_max, d->d_xctl + 64, wpr3);
             d->x_tk3 += n * nb3;
         } else
             hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, g.d_lists + g.wave_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, coef);
@@ -1856,7 +1860,8 @@ extern "C" int32_t h264mi_internal_band_plan(int32_t n_pics, int32_t wmb, int32_
     if (!k5_bands || !k5_waves || !k5_ring || !k5_lds || !k3_bands || !k3_waves || n_pics < 1 || wmb < 1 || hmb < 1) return H264MI_EINVAL;
     int nb = 1, nw = 1, ring = 1, b3 = 1, w3 = 1, roles = 1;
     mi_deblock_bands(n_pics, wmb, hmb, max_wgs, &nb, &nw, &ring, &roles);
-    mi_intra_bands(n_pics, hmb, max_wgs, &b3, &w3);
+    int wpr = 1;
+    mi_intra_bands(n_pics, hmb, max_wgs, false, &b3, &w3, &wpr);
     // (the model test works on groups: the kernel runs `roles` wavefronts on each, which follow the same protocol side by side)
     *k5_bands = nb, *k5_waves = nw / roles, *k5_ring = ring, *k5_lds = static_cast<int64_t>(mi_deblock_lds_bytes_banded(nw, ring));
     *k3_bands = b3, *k3_waves = w3;

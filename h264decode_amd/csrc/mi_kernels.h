@@ -26,7 +26,7 @@ extern "C" __global__ void k_intra(const uint32_t *pic_list, const PicDesc *pics
 // xdone: pictures * nbands * wmb_max flag words; epoch / ticket as for k_deblock_x
 extern "C" __global__ void k_intra_x(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
                                      const int16_t *coefs, uint32_t *xdone, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max,
-                                     uint32_t *xstatus);
+                                     uint32_t *xstatus, int waves_per_row);
 // k_dbprep: boundary strengths + alpha / beta / tC0 of every macroblock of a batch (DbPrm), so that K5 -- one serial dependency chain per
 // picture -- has none of that work in its steps; for the pictures flagged PicDesc::save_col also their ColRec array (the motion later B pictures
 // take their direct prediction from).  grid = (ceil(mbs_max / MI_DBPREP_MBS), pictures of the list), block = 256.
@@ -108,13 +108,18 @@ extern "C" __global__ void k_pack(const PackDesc *descs, uint8_t *dst, int rows_
 #endif
 
 // K3 over several workgroups per picture: bands of about 4 macroblock rows, as many as keep pictures * bands within max_wgs;
-// nbands = 1: the one-workgroup kernel
-static inline void mi_intra_bands(int n_pics, int hmb, int max_wgs, int *nbands, int *nwaves) {
+// nbands = 1: the one-workgroup kernel.  p_only (no intra-only picture in the launch): bands of 3 rows with up to 4 wavefronts
+// per row -- the few intra macroblocks of a P / B picture are dealt round-robin to them (k_intra_x, waves_per_row).
+static inline void mi_intra_bands(int n_pics, int hmb, int max_wgs, bool p_only, int *nbands, int *nwaves, int *wpr) {
     int nb = n_pics > 0 ? max_wgs / n_pics : 1;
-    const int want = (hmb + 3) / 4;
+    const int want = (hmb + (p_only ? 2 : 3)) / (p_only ? 3 : 4);
     if (nb > want) nb = want;
     if (nb < 2) nb = 1;
-    const int rows = (hmb + nb - 1) / nb;
+    const int rows = (hmb + nb - 1) / nb, slots = rows < MI_INTRA_WAVES ? rows : MI_INTRA_WAVES;
+    int w = (nb > 1 && p_only) ? MI_INTRA_WAVES / slots : 1;
+    if (w > 4) w = 4;
+    if (w < 1) w = 1;
     *nbands = nb;
-    *nwaves = nb > 1 ? (rows < MI_INTRA_WAVES ? rows : MI_INTRA_WAVES) : MI_INTRA_WAVES;
+    *wpr = w;
+    *nwaves = nb > 1 ? slots * w : MI_INTRA_WAVES;
 }
