@@ -586,6 +586,7 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(cons
     // few and mostly independent of each other, so the busiest row -- which bounds the kernel -- finishes wpr times sooner; a
     // macroblock whose left neighbour is an intra one too waits for that neighbour's bit like it waits for the row above.
     __shared__ IntraShared sh;
+    __shared__ unsigned long long s_intra[MI_INTRA_MAX_ROWS][MI_INTRA_MAX_CHUNKS]; // sh.pend as pass 1 left it: which macroblocks K3 owns
     __shared__ uint32_t s_ticket;
     const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6, nthreads = static_cast<int>(blockDim.x), nwaves = nthreads >> 6;
     if (tid == 0) s_ticket = atomicAdd(ticket, 1u) - ticket_base;
@@ -616,7 +617,7 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(cons
             const int x = c * 64 + lane;
             const int t = x < wmb ? recs[static_cast<size_t>(mby) * wmb + x].type : -1;
             const unsigned long long m = __ballot(MB_IS_INTRA(t) || t == MBT_NONE);
-            if (lane == 0) sh.pend[mby][c] = m;
+            if (lane == 0) sh.pend[mby][c] = m, s_intra[mby][c] = m;
         }
     __syncthreads();
     IntraWave *ws = &sh.w[wave];
@@ -626,7 +627,7 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(cons
         const bool publish = mby == r1 - 1 && r1 < hmb; // the band below waits for this row
         int nth = 0; // ordinal of the intra macroblock inside the row
         for (int c = 0; c < nchunks; c++) {
-            const unsigned long long row_mask = sh.pend[mby][c]; // as pass 1 left it (bits are cleared as macroblocks finish)
+            const unsigned long long row_mask = s_intra[mby][c]; // (sh.pend loses bits as the row's other wavefronts finish macroblocks)
             unsigned long long mask = row_mask;
             while (mask) {
                 const int k = __ffsll(static_cast<long long>(mask)) - 1;
@@ -638,8 +639,7 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(cons
                 if (wpr > 1 && mbx > 0) { // the left neighbour, if it is an intra macroblock, belongs to another wavefront of this row
                     const int xl = mbx - 1;
                     const unsigned long long bit = 1ull << (xl & 63);
-                    const bool left_intra = (xl >> 6) == c ? (row_mask & bit) != 0 : (sh.pend[mby][xl >> 6] & bit) != 0; // (a set bit there: intra and not finished)
-                    if (left_intra)
+                    if (s_intra[mby][xl >> 6] & bit)
                         while (__hip_atomic_load(&sh.pend[mby][xl >> 6], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) __builtin_amdgcn_s_sleep(1);
                 }
                 if (mby > 0) {
