@@ -68,7 +68,9 @@ def timed_fps(dec, streams, n_frames, steps, warmup=1):
     dec.decode(streams)
     torch.cuda.synchronize()
     e2e = time.perf_counter() - t0
-    return {"fps": round(n_frames / dt, 2), "ms_per_step": round(dt * 1e3, 3), "end_to_end_fps": round(n_frames / e2e, 2)}
+    used, cap = dec.coef_pool()
+    return {"fps": round(n_frames / dt, 2), "ms_per_step": round(dt * 1e3, 3), "end_to_end_fps": round(n_frames / e2e, 2),
+            "coef_pool_used": round(used / cap, 3)}
 
 
 def extra_configs(H, streams, F, W, Hc, device, args):
@@ -454,6 +456,7 @@ def main():
     dec.sync()
     torch.cuda.synchronize()
     pipelined_fps = S * F * args.steps / (time.perf_counter() - tpipe)
+    pool_used, pool_cap = dec.coef_pool()
 
     dec.close()
     del dec
@@ -554,7 +557,7 @@ def main():
         "pipelined_ingest_fps": round(pipelined_fps, 2),
         "pipelined_ingest_note": "prepare(k+1) (host parse + H2D, second staging set) overlapped with execute(k); rank 0's own rate",
         "host_prepare_ms": round(prepare_s * 1e3, 2),
-        "hbm_bytes": {"decoder": hbm_bytes, "per_stream": int(hbm_bytes / S), "note": "device memory of the %d-stream decoder (I/P streams: what only B pictures need is allocated on demand)" % S},
+        "hbm_bytes": {"decoder": hbm_bytes, "per_stream": int(hbm_bytes / S), "coef_pool_used": round(pool_used / pool_cap, 3), "note": "device memory of the %d-stream decoder (I/P streams: what only B pictures need is allocated on demand)" % S},
         "parity": parity,
         "stream_gen_s": round(gen_s, 1),
     }

@@ -447,11 +447,11 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
         DEV_ALLOC(d->d_dbprm[i], sizeof(DbPrm) * d->mb_cap);
         if (i == 0) {
             // Pool size.  The worst case is 26 blocks (832 bytes) per macroblock; real streams code a fraction of that (the
-            // 1080p QP 28 bench streams: ~5 blocks per macroblock).  Small decoders get the worst case; large ones 7 blocks
+            // 1080p QP 28 bench streams: ~5 blocks per macroblock).  Small decoders get the worst case; large ones 8 blocks
             // per macroblock, at least 1 GiB -- a batch that needs more fails with H264MI_EDECODE ("coefficient pool
             // exhausted", code 40) instead of reserving 3 x 52 GB for a case that does not occur.  H264MI_COEF_BLOCKS_PER_MB overrides.
             const uint64_t worst = d->mb_cap * MI_COEF_BLOCKS + static_cast<uint64_t>(d->slices_cap + 1) * MI_COEF_CHUNK;
-            uint64_t per_mb = 7;
+            uint64_t per_mb = 8;
             if (const char *e = getenv("H264MI_COEF_BLOCKS_PER_MB")) per_mb = static_cast<uint64_t>(std::min(std::max(atoi(e), 1), MI_COEF_BLOCKS));
             const uint64_t typical = std::max<uint64_t>(d->mb_cap * per_mb, (1ull << 30) / 32) + static_cast<uint64_t>(d->slices_cap + 1) * MI_COEF_CHUNK;
             d->pool_blocks = std::min<uint64_t>(std::min<uint64_t>(worst, typical), 0xFFFF0000ull);
@@ -563,6 +563,15 @@ extern "C" int32_t h264mi_decoder_set_isolation(h264mi_decoder *d, int32_t on) {
 extern "C" int32_t h264mi_decoder_memory(h264mi_decoder *d, int64_t *device_bytes) {
     if (!d || !device_bytes) return H264MI_EINVAL;
     *device_bytes = static_cast<int64_t>(d->dev_bytes);
+    return H264MI_OK;
+}
+extern "C" int32_t h264mi_decoder_coef_pool(h264mi_decoder *d, int64_t *used_blocks, int64_t *capacity_blocks) {
+    if (!d || !used_blocks || !capacity_blocks) return H264MI_EINVAL;
+    uint32_t heads[MI_SETS] = {0};
+    HIP_TRY(hipMemcpy(heads, d->d_pool_head, sizeof(heads), hipMemcpyDeviceToHost));
+    uint32_t m = 0;
+    for (int i = 0; i < MI_SETS; i++) m = std::max(m, heads[i]);
+    *used_blocks = static_cast<int64_t>(m), *capacity_blocks = static_cast<int64_t>(d->pool_blocks);
     return H264MI_OK;
 }
 extern "C" int32_t h264mi_decoder_set_profiling(h264mi_decoder *d, int32_t on) {

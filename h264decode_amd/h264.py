@@ -214,6 +214,12 @@ class Decoder:
         check(self._L.h264mi_decoder_memory(self._h, ctypes.byref(n)))
         return int(n.value)
 
+    def coef_pool(self):
+        """(used, capacity) of the residual-coefficient pool in 32-byte blocks (h264mi_decoder_coef_pool); call after sync()."""
+        u, c = ctypes.c_int64(), ctypes.c_int64()
+        check(self._L.h264mi_decoder_coef_pool(self._h, ctypes.byref(u), ctypes.byref(c)))
+        return int(u.value), int(c.value)
+
     def set_profiling(self, on=True):
         check(self._L.h264mi_decoder_set_profiling(self._h, int(on)))
 

@@ -251,6 +251,12 @@ int32_t h264mi_last_launch_times(h264mi_decoder *dec, int32_t kernel, float *ms,
  * (list-1 vectors, co-located motion arrays), which is allocated when a stream's first B slice arrives. */
 int32_t h264mi_decoder_memory(h264mi_decoder *dec, int64_t *device_bytes);
 
+/* Residual-coefficient pool: blocks (32 bytes each) the fullest of the pipelined batches still on the device took, and the
+ * capacity.  Large decoders reserve 8 blocks per macroblock, not the worst case of 26 (a batch that needs more fails with
+ * H264MI_EDECODE, "code 40"); the environment variable H264MI_COEF_BLOCKS_PER_MB, read at create time, sizes it.  Call after
+ * h264mi_batch_sync. */
+int32_t h264mi_decoder_coef_pool(h264mi_decoder *dec, int64_t *used_blocks, int64_t *capacity_blocks);
+
 const char *h264mi_last_error_string(void);
 const char *h264mi_version(void);
 
