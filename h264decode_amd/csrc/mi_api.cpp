@@ -273,6 +273,19 @@ extern "C" int32_t h264mi_annexb_scan(const uint8_t *buf, size_t len, h264mi_nal
 extern "C" int32_t h264mi_nal_parse(const uint8_t *nal, size_t len, h264mi_nal *hdr, uint8_t *rbsp, size_t *rbsp_len) { return nal_parse(nal, len, hdr, rbsp, rbsp_len); }
 extern "C" int32_t h264mi_sps_parse(const uint8_t *rbsp, size_t len, h264mi_sps *sps) { return parse_sps(rbsp, len, sps); }
 extern "C" int32_t h264mi_pps_parse(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi_pps *pps) { return parse_pps(sps, rbsp, len, pps); }
+extern "C" int32_t h264mi_pps_slice_group_ids(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, uint8_t *ids, size_t cap, size_t *n) {
+    h264mi_pps tmp;
+    return parse_pps_ids(sps, rbsp, len, &tmp, ids, cap, n);
+}
+extern "C" int32_t h264mi_map_unit_to_slice_group_map(const h264mi_sps *sps, const h264mi_pps *pps, const uint8_t *ids, size_t n_ids, int32_t cycle, uint8_t *map, size_t cap,
+                                                      size_t *n) {
+    return map_unit_to_slice_group_map(sps, pps, ids, n_ids, cycle, map, cap, n);
+}
+extern "C" int32_t h264mi_mb_to_slice_group_map(const h264mi_sps *sps, const h264mi_pps *pps, const uint8_t *ids, size_t n_ids, int32_t cycle, int32_t field_pic, uint8_t *map,
+                                                size_t cap, size_t *n) {
+    return mb_to_slice_group_map(sps, pps, ids, n_ids, cycle, field_pic, map, cap, n);
+}
+extern "C" int32_t h264mi_next_mb_address(const uint8_t *map, size_t n_mbs, size_t n) { return next_mb_address(map, n_mbs, n); }
 extern "C" int32_t h264mi_slice_header_parse(const h264mi_sps *sps, const h264mi_pps *pps, int32_t nal_ref_idc, int32_t nal_unit_type, const uint8_t *rbsp,
                                              size_t len, h264mi_slice_header *sh) {
     return parse_slice_header(sps, pps, nal_ref_idc, nal_unit_type, rbsp, len, sh);

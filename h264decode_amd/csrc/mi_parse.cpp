@@ -5,7 +5,9 @@
 #include "mi_parse.hpp"
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
+#include <vector>
 #include "mi_tables.h"
 
 namespace mi {
@@ -346,18 +348,72 @@ int parse_sps(const uint8_t *rbsp, size_t len, h264mi_sps *s) {
 }
 
 // NewPPS (h264/pps.go:40-133)
-int parse_pps(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi_pps *p) {
+static int ceil_log2(uint32_t v) { // Ceil(Log2(v)), v >= 1
+    int n = 0;
+    while ((1u << n) < v) n++;
+    return n;
+}
+
+int parse_pps(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi_pps *p) { return parse_pps_ids(sps, rbsp, len, p, nullptr, 0, nullptr); }
+
+// `ids` (optional, `cap` entries): slice_group_id[] of slice_group_map_type 6 -- too long for the POD (one byte per map unit)
+int parse_pps_ids(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi_pps *p, uint8_t *ids, size_t cap, size_t *n_ids) {
     if (!rbsp || !p || !sps) return H264MI_EINVAL;
     BitReader b(rbsp, len);
     memset(p, 0, sizeof(*p));
+    if (n_ids) *n_ids = 0;
     p->id = b.ue();
     p->sps_id = b.ue();
     p->entropy_coding_mode = b.u(1);
     p->bottom_field_pic_order_in_frame_present = b.u(1);
     p->num_slice_groups_minus1 = b.ue();
-    if (p->num_slice_groups_minus1 > 0) {
-        set_error("PPS: FMO (slice groups) is out of scope");
-        return H264MI_EUNSUPPORTED;
+    if (p->num_slice_groups_minus1 > 7) { // A.2: at most 8 slice groups in any profile
+        set_error("PPS: num_slice_groups_minus1 %d out of range", p->num_slice_groups_minus1);
+        return H264MI_EBITSTREAM;
+    }
+    if (p->num_slice_groups_minus1 > 0) { // 7.3.2.2 (h264/pps.go:57-80)
+        const int ng = p->num_slice_groups_minus1 + 1;
+        const uint32_t map_units = static_cast<uint32_t>(sps->pic_width_in_mbs_minus1 + 1) * static_cast<uint32_t>(sps->pic_height_in_map_units_minus1 + 1);
+        p->slice_group_map_type = b.ue();
+        if (p->slice_group_map_type == 0) {
+            for (int i = 0; i < ng; i++) p->run_length_minus1[i] = b.ue();
+        } else if (p->slice_group_map_type == 2) {
+            for (int i = 0; i < ng - 1; i++) {
+                p->top_left[i] = b.ue(), p->bottom_right[i] = b.ue();
+                // 7.4.2.2: top_left <= bottom_right, and its column not to the right of bottom_right's
+                if (p->top_left[i] > p->bottom_right[i] || static_cast<uint32_t>(p->bottom_right[i]) >= map_units ||
+                    p->top_left[i] % (sps->pic_width_in_mbs_minus1 + 1) > p->bottom_right[i] % (sps->pic_width_in_mbs_minus1 + 1)) {
+                    set_error("PPS: slice group rectangle %d is malformed", i);
+                    return H264MI_EBITSTREAM;
+                }
+            }
+        } else if (p->slice_group_map_type >= 3 && p->slice_group_map_type <= 5) {
+            p->slice_group_change_direction = b.u(1);
+            p->slice_group_change_rate_minus1 = b.ue();
+            if (ng != 2 || static_cast<uint32_t>(p->slice_group_change_rate_minus1) >= map_units) {
+                set_error("PPS: slice_group_map_type %d needs two slice groups and a change rate below the picture size", p->slice_group_map_type);
+                return H264MI_EBITSTREAM;
+            }
+        } else if (p->slice_group_map_type == 6) {
+            p->pic_size_in_map_units_minus1 = b.ue();
+            if (static_cast<uint32_t>(p->pic_size_in_map_units_minus1) + 1 != map_units) {
+                set_error("PPS: pic_size_in_map_units_minus1 %d does not match the SPS (%u map units)", p->pic_size_in_map_units_minus1, map_units);
+                return H264MI_EBITSTREAM;
+            }
+            const int bits = ceil_log2(static_cast<uint32_t>(ng));
+            for (uint32_t i = 0; i < map_units && !b.overrun(); i++) {
+                const uint32_t v = b.u(bits);
+                if (v >= static_cast<uint32_t>(ng)) {
+                    set_error("PPS: slice_group_id[%u] = %u out of range", i, v);
+                    return H264MI_EBITSTREAM;
+                }
+                if (ids && i < cap) ids[i] = static_cast<uint8_t>(v);
+            }
+            if (n_ids) *n_ids = map_units;
+        } else if (p->slice_group_map_type != 1) {
+            set_error("PPS: slice_group_map_type %d out of range", p->slice_group_map_type);
+            return H264MI_EBITSTREAM;
+        }
     }
     p->num_ref_idx_l0_default_active_minus1 = b.ue();
     p->num_ref_idx_l1_default_active_minus1 = b.ue();
@@ -516,6 +572,16 @@ int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc
             sh->slice_beta_offset_div2 < -6 || sh->slice_beta_offset_div2 > 6)
             return H264MI_EBITSTREAM;
     }
+    if (p->num_slice_groups_minus1 > 0 && p->slice_group_map_type >= 3 && p->slice_group_map_type <= 5) {
+        // Ceil(Log2(PicSizeInMapUnits / SliceGroupChangeRate + 1)) bits, "/" exact (7.4.3; h264/slice.go:1028-1031 divides the
+        // minus1 values as integers): the smallest n with (2^n - 1) * rate >= map units
+        const uint64_t units = static_cast<uint64_t>(s->pic_width_in_mbs_minus1 + 1) * static_cast<uint64_t>(s->pic_height_in_map_units_minus1 + 1);
+        const uint64_t rate = static_cast<uint64_t>(p->slice_group_change_rate_minus1) + 1;
+        int n = 0;
+        while (((1ull << n) - 1) * rate < units) n++;
+        sh->slice_group_change_cycle = n ? static_cast<int32_t>(b.u(n)) : 0;
+        if (static_cast<uint64_t>(sh->slice_group_change_cycle) > (units + rate - 1) / rate) return H264MI_EBITSTREAM; // 7.4.3 range
+    }
     sh->slice_qp_y = 26 + p->pic_init_qp_minus26 + sh->slice_qp_delta; // (7-30), h264/cabac.go:113
     sh->slice_data_bit_offset = b.pos();
     if (b.overrun() || sh->slice_qp_y < 0 || sh->slice_qp_y > 51) {
@@ -523,6 +589,113 @@ int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc
         return H264MI_EBITSTREAM;
     }
     return H264MI_OK;
+}
+
+// ---------------------------------------------------------------- slice groups (FMO), 8.2.2
+// MapUnitToSliceGroupMap (h264/slice.go:457-529; types 3-6 are TODO there, type 0 / type 2 index past their arrays).
+int map_unit_to_slice_group_map(const h264mi_sps *s, const h264mi_pps *p, const uint8_t *ids, size_t n_ids, int cycle, uint8_t *map, size_t cap, size_t *n_out) {
+    if (!s || !p || !map) return H264MI_EINVAL;
+    const int W = s->pic_width_in_mbs_minus1 + 1, Hm = s->pic_height_in_map_units_minus1 + 1;
+    const size_t units = static_cast<size_t>(W) * Hm;
+    if (n_out) *n_out = units;
+    if (cap < units) return H264MI_ECAPACITY;
+    const int ng = p->num_slice_groups_minus1 + 1;
+    if (ng == 1) {
+        memset(map, 0, units);
+        return H264MI_OK;
+    }
+    const int flag = p->slice_group_change_direction ? 1 : 0;
+    const size_t rate = static_cast<size_t>(p->slice_group_change_rate_minus1) + 1;
+    const size_t in_group0 = std::min(static_cast<size_t>(cycle > 0 ? cycle : 0) * rate, units); // MapUnitsInSliceGroup0 (7-33)
+    const size_t upper_left = flag ? units - in_group0 : in_group0;                              // sizeOfUpperLeftGroup (8-14)
+    switch (p->slice_group_map_type) {
+    case 0: { // 8.2.2.1 interleaved
+        size_t i = 0;
+        do {
+            for (int g = 0; g < ng && i < units; i += static_cast<size_t>(p->run_length_minus1[g++]) + 1)
+                for (size_t j = 0; j <= static_cast<size_t>(p->run_length_minus1[g]) && i + j < units; j++) map[i + j] = static_cast<uint8_t>(g);
+        } while (i < units);
+        break;
+    }
+    case 1: // 8.2.2.2 dispersed
+        for (size_t i = 0; i < units; i++) map[i] = static_cast<uint8_t>(((i % W) + (((i / W) * ng) / 2)) % ng);
+        break;
+    case 2: // 8.2.2.3 foreground rectangles and a left-over group
+        memset(map, ng - 1, units);
+        for (int g = ng - 2; g >= 0; g--) {
+            const int y0 = p->top_left[g] / W, x0 = p->top_left[g] % W, y1 = p->bottom_right[g] / W, x1 = p->bottom_right[g] % W;
+            for (int y = y0; y <= y1 && y < Hm; y++)
+                for (int x = x0; x <= x1; x++) map[static_cast<size_t>(y) * W + x] = static_cast<uint8_t>(g);
+        }
+        break;
+    case 3: { // 8.2.2.4 box-out
+        memset(map, 1, units);
+        int x = (W - flag) / 2, y = (Hm - flag) / 2;
+        int left = x, top = y, right = x, bottom = y, xd = flag - 1, yd = flag;
+        for (size_t k = 0; k < in_group0;) {
+            uint8_t &m = map[static_cast<size_t>(y) * W + x];
+            const bool vacant = m == 1;
+            if (vacant) m = 0, k++;
+            if (xd == -1 && x == left) {
+                left = std::max(left - 1, 0), x = left, xd = 0, yd = 2 * flag - 1;
+            } else if (xd == 1 && x == right) {
+                right = std::min(right + 1, W - 1), x = right, xd = 0, yd = 1 - 2 * flag;
+            } else if (yd == -1 && y == top) {
+                top = std::max(top - 1, 0), y = top, xd = 1 - 2 * flag, yd = 0;
+            } else if (yd == 1 && y == bottom) {
+                bottom = std::min(bottom + 1, Hm - 1), y = bottom, xd = 2 * flag - 1, yd = 0;
+            } else
+                x += xd, y += yd;
+        }
+        break;
+    }
+    case 4: // 8.2.2.5 raster scan
+        for (size_t i = 0; i < units; i++) map[i] = static_cast<uint8_t>(i < upper_left ? flag : 1 - flag);
+        break;
+    case 5: { // 8.2.2.6 wipe
+        size_t k = 0;
+        for (int j = 0; j < W; j++)
+            for (int i = 0; i < Hm; i++) map[static_cast<size_t>(i) * W + j] = static_cast<uint8_t>(k++ < upper_left ? flag : 1 - flag);
+        break;
+    }
+    case 6: // 8.2.2.7 explicit
+        if (!ids || n_ids < units) {
+            set_error("slice_group_map_type 6 needs the slice_group_id array of the PPS (h264mi_pps_slice_group_ids)");
+            return H264MI_EINVAL;
+        }
+        memcpy(map, ids, units);
+        break;
+    default:
+        return H264MI_EBITSTREAM;
+    }
+    return H264MI_OK;
+}
+
+// MbToSliceGroupMap 8.2.2.8 (h264/slice.go:134-158) for the pictures this library decodes: frames of frame_mbs_only streams
+// and frame pictures of non-MBAFF interlace streams (a map unit = two macroblock rows); field_pic: a field picture of such a stream.
+int mb_to_slice_group_map(const h264mi_sps *s, const h264mi_pps *p, const uint8_t *ids, size_t n_ids, int cycle, int field_pic, uint8_t *map, size_t cap, size_t *n_out) {
+    if (!s || !p || !map) return H264MI_EINVAL;
+    const int W = s->pic_width_in_mbs_minus1 + 1, Hm = s->pic_height_in_map_units_minus1 + 1;
+    const size_t units = static_cast<size_t>(W) * Hm;
+    const bool mbaff = s->mb_adaptive_frame_field && !field_pic;
+    const bool direct = s->frame_mbs_only || field_pic; // one map unit per macroblock
+    const size_t n_mbs = direct ? units : 2 * units;
+    if (n_out) *n_out = n_mbs;
+    if (cap < n_mbs) return H264MI_ECAPACITY;
+    if (direct) return map_unit_to_slice_group_map(s, p, ids, n_ids, cycle, map, cap, nullptr);
+    std::vector<uint8_t> mu(units);
+    const int r = map_unit_to_slice_group_map(s, p, ids, n_ids, cycle, mu.data(), units, nullptr);
+    if (r != H264MI_OK) return r;
+    for (size_t i = 0; i < n_mbs; i++) map[i] = mbaff ? mu[i / 2] : mu[(i / (2 * static_cast<size_t>(W))) * W + (i % W)];
+    return H264MI_OK;
+}
+
+// nextMbAddress (8-17; h264/slice.go:530-552 compares an entry with itself): the next macroblock of n's slice group, or n_mbs
+int next_mb_address(const uint8_t *map, size_t n_mbs, size_t n) {
+    if (!map || n >= n_mbs) return static_cast<int>(n_mbs);
+    size_t i = n + 1;
+    while (i < n_mbs && map[i] != map[n]) i++;
+    return static_cast<int>(i);
 }
 
 } // namespace mi

@@ -34,6 +34,11 @@ int nal_parse(const uint8_t *nal, size_t len, h264mi_nal *hdr, uint8_t *rbsp, si
 size_t unescape(const uint8_t *src, size_t n, uint8_t *dst);
 int parse_sps(const uint8_t *rbsp, size_t len, h264mi_sps *s);
 int parse_pps(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi_pps *p);
+int parse_pps_ids(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi_pps *p, uint8_t *ids, size_t cap, size_t *n_ids);
+// 8.2.2 (h264/slice.go:134-158, :457-552)
+int map_unit_to_slice_group_map(const h264mi_sps *s, const h264mi_pps *p, const uint8_t *ids, size_t n_ids, int cycle, uint8_t *map, size_t cap, size_t *n_out);
+int mb_to_slice_group_map(const h264mi_sps *s, const h264mi_pps *p, const uint8_t *ids, size_t n_ids, int cycle, int field_pic, uint8_t *map, size_t cap, size_t *n_out);
+int next_mb_address(const uint8_t *map, size_t n_mbs, size_t n);
 int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc, int nal_unit_type, const uint8_t *rbsp, size_t len,
                        h264mi_slice_header *sh);
 void set_error(const char *fmt, ...);

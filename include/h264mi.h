@@ -108,10 +108,17 @@ typedef struct {
     int32_t transform_8x8_mode, pic_scaling_matrix_present, second_chroma_qp_index_offset;
     uint8_t scaling_list_4x4[6][16];
     uint8_t scaling_list_8x8[2][64];
+    /* slice groups (num_slice_groups_minus1 > 0; h264/pps.go:16-23, :57-80).  slice_group_id[] of map type 6 is one entry
+     * per map unit and does not live in this struct: h264mi_pps_slice_group_ids() */
+    int32_t slice_group_map_type, run_length_minus1[8], top_left[8], bottom_right[8];
+    int32_t slice_group_change_direction, slice_group_change_rate_minus1, pic_size_in_map_units_minus1;
 } h264mi_pps;
 /* replaces NewPPS(sps, rbsp, showPacket) (h264/pps.go:40).  `sps` is the SPS the PPS refers to
  * (the reference passes "the last SPS": h264/server.go:155). */
 int32_t h264mi_pps_parse(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi_pps *pps);
+/* PPS.SliceGroupId (h264/pps.go:23, :72-78): slice_group_id[i] of a PPS with slice_group_map_type 6, one byte per map unit.
+ * *n receives pic_size_in_map_units_minus1 + 1 (0 for any other PPS); at most cap entries are written. */
+int32_t h264mi_pps_slice_group_ids(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, uint8_t *ids, size_t cap, size_t *n);
 
 /* ---- slice header: h264/slice.go:23-75, NewSliceContext :835-1048 ---- */
 typedef struct {
@@ -134,6 +141,7 @@ typedef struct {
     int32_t memory_management_control_operation[66], mmco_arg1[66], mmco_arg2[66];
     int32_t cabac_init, slice_qp_delta, sp_for_switch, slice_qs_delta;
     int32_t disable_deblocking_filter, slice_alpha_c0_offset_div2, slice_beta_offset_div2;
+    int32_t slice_group_change_cycle; /* slice group map types 3..5 (h264/slice.go:1028-1031) */
     /* derived */
     int32_t nal_ref_idc, nal_unit_type, slice_qp_y; /* SliceQPy (h264/cabac.go:113) */
     int64_t slice_data_bit_offset;                  /* where slice_data() starts inside the RBSP */
@@ -141,6 +149,18 @@ typedef struct {
 /* replaces NewSliceContext's header part (h264/slice.go:857-1032) */
 int32_t h264mi_slice_header_parse(const h264mi_sps *sps, const h264mi_pps *pps, int32_t nal_ref_idc, int32_t nal_unit_type,
                                   const uint8_t *rbsp, size_t len, h264mi_slice_header *sh);
+
+/* ---- slice groups (FMO, 8.2.2): h264/slice.go:134-158, :457-552 ----
+ * MapUnitToSliceGroupMap(sps, pps, header) (h264/slice.go:457): map types 0..6 (the reference stops at 2).  ids / n_ids: the
+ * slice_group_id array of a type-6 PPS (NULL / 0 otherwise); slice_group_change_cycle: the slice header's field (types 3..5).
+ * *n receives PicSizeInMapUnits; H264MI_ECAPACITY if cap is smaller. */
+int32_t h264mi_map_unit_to_slice_group_map(const h264mi_sps *sps, const h264mi_pps *pps, const uint8_t *ids, size_t n_ids,
+                                           int32_t slice_group_change_cycle, uint8_t *map, size_t cap, size_t *n);
+/* MbToSliceGroupMap(sps, pps, header) (h264/slice.go:134): 8.2.2.8, one entry per macroblock of the picture. */
+int32_t h264mi_mb_to_slice_group_map(const h264mi_sps *sps, const h264mi_pps *pps, const uint8_t *ids, size_t n_ids,
+                                     int32_t slice_group_change_cycle, int32_t field_pic, uint8_t *map, size_t cap, size_t *n);
+/* nextMbAddress(n, ...) (h264/slice.go:530): the next macroblock of n's slice group in `map`, n_mbs if there is none. */
+int32_t h264mi_next_mb_address(const uint8_t *map, size_t n_mbs, size_t n);
 
 /* ---- GPU decode: replaces NewSliceData / MbPred and the absent L7 reconstruction
  *      (h264/slice.go:570-830, :252-454; README.md:8-10 TODO items) ---- */

@@ -101,10 +101,19 @@ typedef struct {
     int transform_8x8_mode_flag, pic_scaling_matrix_present_flag, second_chroma_qp_index_offset;
     uint8_t scaling4x4[6][16]; /* resolved against the SPS, zig-zag order */
     uint8_t scaling8x8[2][64];
+    /* slice groups (h264/pps.go:16-23, :57-80); slice_group_id[] of map type 6 is returned separately (h264o_parse_pps_ids) */
+    int slice_group_map_type, run_length_minus1[8], top_left[8], bottom_right[8];
+    int slice_group_change_direction_flag, slice_group_change_rate_minus1, pic_size_in_map_units_minus1;
 } h264o_pps;
 
 int h264o_parse_sps(const uint8_t *rbsp, size_t len, h264o_sps *sps);
 int h264o_parse_pps(const uint8_t *rbsp, size_t len, const h264o_sps *sps_table, h264o_pps *pps);
+/* the same, plus slice_group_id[] of a slice_group_map_type-6 PPS (one byte per map unit; *n_ids = 0 otherwise) */
+int h264o_parse_pps_ids(const uint8_t *rbsp, size_t len, const h264o_sps *sps_table, h264o_pps *pps, uint8_t *ids, size_t cap, size_t *n_ids);
+/* 8.2.2 (h264/slice.go:134-158, :457-552): mapUnitToSliceGroupMap / mbToSliceGroupMap of a picture, nextMbAddress */
+int h264o_map_unit_to_slice_group_map(const h264o_sps *sps, const h264o_pps *pps, const uint8_t *ids, int slice_group_change_cycle, uint8_t *map);
+int h264o_mb_to_slice_group_map(const h264o_sps *sps, const h264o_pps *pps, const uint8_t *ids, int slice_group_change_cycle, int field_pic, uint8_t *map);
+int h264o_next_mb_address(const uint8_t *map, int n_mbs, int n);
 
 /* ---------- slice header (h264/slice.go:23-75, 835-1048) ---------- */
 typedef struct {
@@ -123,6 +132,7 @@ typedef struct {
     int mmco_op[66], mmco_arg1[66], mmco_arg2[66];
     int cabac_init_idc, slice_qp_delta, sp_for_switch_flag, slice_qs_delta;
     int disable_deblocking_filter_idc, slice_alpha_c0_offset_div2, slice_beta_offset_div2;
+    int slice_group_change_cycle;
     /* B slices: list 1 (h264/slice.go:924-936 modification, :940-984 weights) */
     int ref_pic_list_modification_flag_l1, n_rplm1;
     int rplm1_idc[66];

@@ -34,6 +34,8 @@ void h264o_decoder_destroy(h264o_decoder *d) {
     if (!d) return;
     free_pics(d);
     free(d->rbsp);
+    free(d->sgmap);
+    for (int i = 0; i < 256; i++) free(d->sg_ids[i]);
     free(d);
 }
 void h264o_set_mb_trace(h264o_decoder *d, int32_t *trace, size_t cap) {
@@ -441,6 +443,15 @@ static int start_picture(h264o_decoder *d) {
     memset(p->plane[0], 128, (size_t)d->wmb * 16 * d->hmb * 16 * 3 / 2);
     d->first_sh = d->sh;
     d->slice_id = 0;
+    d->pic_has_mb0 = 0;
+    /* slice groups: the macroblock-to-slice-group map of this picture (8.2.2; h264/slice.go:134-158) */
+    free(d->sgmap);
+    d->sgmap = NULL;
+    if (d->apps->num_slice_groups_minus1 > 0) {
+        d->sgmap = (uint8_t *)malloc((size_t)d->wmb * d->hmb);
+        if (h264o_mb_to_slice_group_map(d->asps, d->apps, d->sg_ids[d->apps->pic_parameter_set_id], d->sh.slice_group_change_cycle, 0, d->sgmap) != d->wmb * d->hmb)
+            return h264o_fail(d, "slice group map: bad PPS %d", d->apps->pic_parameter_set_id);
+    }
     return 0;
 }
 
@@ -453,7 +464,9 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
     if (sh.slice_type > 2) return h264o_fail(d, "slice_type %d out of scope (I, P and B only)", sh.slice_type);
     if (sh.redundant_pic_cnt > 0) return 0; /* redundant coded pictures are ignored */
     const h264o_pps *pps = &d->pps[sh.pic_parameter_set_id];
-    if (d->cur && (sh.first_mb_in_slice == 0 || is_new_picture(d, &d->first_sh, &sh))) finish_picture(d);
+    /* (a second slice that starts at macroblock 0 begins a new picture whatever the headers say; with arbitrary slice order the
+     * first one may come late) */
+    if (d->cur && ((sh.first_mb_in_slice == 0 && d->pic_has_mb0) || is_new_picture(d, &d->first_sh, &sh))) finish_picture(d);
     if (activate(d, pps) < 0) return -1;
     d->sh = sh;
     if (sh.slice_qp_delta) d->feat |= 1u << 13;
@@ -463,6 +476,7 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
         d->slice_id++;
     if (sh.slice_type != 2 && build_ref_list(d) < 0) return -1;
     if (sh.first_mb_in_slice >= d->wmb * d->hmb) return h264o_fail(d, "first_mb_in_slice out of range");
+    if (sh.first_mb_in_slice == 0) d->pic_has_mb0 = 1;
     return h264o_decode_slice_data(d) < 0 ? -1 : 0;
 }
 
@@ -504,12 +518,22 @@ int h264o_decode_stream(h264o_decoder *d, const uint8_t *buf, size_t len, int cr
         }
         case 8: {
             h264o_pps p;
-            int r = h264o_parse_pps(d->rbsp, rlen, d->sps, &p);
-            if (r == 0) {
+            size_t n_ids = 0, cap = 1 << 20;
+            uint8_t *ids = (uint8_t *)malloc(cap);
+            int r = h264o_parse_pps_ids(d->rbsp, rlen, d->sps, &p, ids, cap, &n_ids);
+            if (r == 0 && n_ids <= cap) {
                 if (d->cur) finish_picture(d);
                 d->pps[p.pic_parameter_set_id] = p;
-            } else
+                free(d->sg_ids[p.pic_parameter_set_id]);
+                d->sg_ids[p.pic_parameter_set_id] = n_ids ? ids : NULL;
+                if (!n_ids) free(ids);
+            } else if (r == 0) {
+                free(ids);
+                h264o_fail(d, "PPS: slice group map too large");
+            } else {
+                free(ids);
                 h264o_fail(d, "PPS parse error %d", r);
+            }
             break;
         }
         case 1:

@@ -1127,7 +1127,7 @@ static int decode_mb(h264o_decoder *d, int addr) {
 
 /* ------------------------------------------------------------------ slice_data() 7.3.4 */
 /* h264/slice.go:570-830.  Differences: mb_skip_flag / end_of_slice_flag are ae(v) (A23), mb_type
- * is tracked per MB (A22), residual() is parsed (A24), next MB address is n+1 (no FMO). */
+ * is tracked per MB (A22), residual() is parsed (A24), nextMbAddress follows the slice group map (8.2.2). */
 int h264o_decode_slice_data(h264o_decoder *d) {
     h264o_br *b = &d->br;
     int cabac = d->apps->entropy_coding_mode_flag;
@@ -1151,8 +1151,11 @@ int h264o_decode_slice_data(h264o_decoder *d) {
             if (!cabac) {
                 uint32_t run = h264o_ue(b);
                 if (run > (uint32_t)(total - addr)) return h264o_fail(d, "mb_skip_run %u too long", run);
-                for (uint32_t i = 0; i < run; i++)
-                    if ((bslice ? decode_bskip(d, addr++) : decode_pskip(d, addr++)) < 0) return -1;
+                for (uint32_t i = 0; i < run; i++) {
+                    if (addr >= total) return h264o_fail(d, "mb_skip_run runs past the slice group");
+                    if ((bslice ? decode_bskip(d, addr) : decode_pskip(d, addr)) < 0) return -1;
+                    addr = d->sgmap ? h264o_next_mb_address(d->sgmap, total, addr) : addr + 1; /* nextMbAddress, h264/slice.go:530 */
+                }
                 if (run > 0) more = h264o_more_rbsp_data(b);
                 if (!more) break;
                 if (addr >= total) return h264o_fail(d, "slice runs past the picture after skip run");
@@ -1173,7 +1176,7 @@ int h264o_decode_slice_data(h264o_decoder *d) {
             more = h264o_more_rbsp_data(b);
         else
             more = !cabac_terminate(d);
-        addr++;
+        addr = d->sgmap ? h264o_next_mb_address(d->sgmap, total, addr) : addr + 1;
         if (b->err) return h264o_fail(d, "slice data overrun at mb %d", addr);
     }
     d->info.n_bits += (uint64_t)(b->pos - start_bits);

@@ -5,6 +5,7 @@
  * Field order follows h264/sps.go:192-437, h264/pps.go:40-133 and h264/slice.go:835-1048 where
  * those are right; divergences follow the spec and are marked.
  */
+#include <stdlib.h>
 #include <string.h>
 #include "h264o.h"
 
@@ -189,9 +190,20 @@ int h264o_parse_sps(const uint8_t *rbsp, size_t len, h264o_sps *s) {
 }
 
 int h264o_parse_pps(const uint8_t *rbsp, size_t len, const h264o_sps *sps_table, h264o_pps *p) {
+    return h264o_parse_pps_ids(rbsp, len, sps_table, p, NULL, 0, NULL);
+}
+
+static int bits_for(unsigned v) { /* Ceil(Log2(v)) */
+    int n = 0;
+    while ((1u << n) < v) n++;
+    return n;
+}
+
+int h264o_parse_pps_ids(const uint8_t *rbsp, size_t len, const h264o_sps *sps_table, h264o_pps *p, uint8_t *ids, size_t cap, size_t *n_ids) {
     h264o_br br, *b = &br;
     h264o_br_init(b, rbsp, len);
     memset(p, 0, sizeof(*p));
+    if (n_ids) *n_ids = 0;
     p->pic_parameter_set_id = h264o_ue(b);
     p->seq_parameter_set_id = h264o_ue(b);
     if (p->pic_parameter_set_id > 255 || p->seq_parameter_set_id > 31) return -1;
@@ -200,7 +212,45 @@ int h264o_parse_pps(const uint8_t *rbsp, size_t len, const h264o_sps *sps_table,
     p->entropy_coding_mode_flag = h264o_u(b, 1);
     p->bottom_field_pic_order_in_frame_present_flag = h264o_u(b, 1);
     p->num_slice_groups_minus1 = h264o_ue(b);
-    if (p->num_slice_groups_minus1 > 0) return -3; /* FMO: out of scope */
+    if (p->num_slice_groups_minus1 > 7) return -3;
+    if (p->num_slice_groups_minus1 > 0) { /* 7.3.2.2; h264/pps.go:57-80 */
+        int ng = p->num_slice_groups_minus1 + 1, wmb = s->pic_width_in_mbs_minus1 + 1;
+        unsigned units = (unsigned)wmb * (unsigned)(s->pic_height_in_map_units_minus1 + 1);
+        p->slice_group_map_type = h264o_ue(b);
+        switch (p->slice_group_map_type) {
+        case 0:
+            for (int g = 0; g < ng; g++) p->run_length_minus1[g] = h264o_ue(b);
+            break;
+        case 1: break;
+        case 2:
+            for (int g = 0; g < ng - 1; g++) {
+                p->top_left[g] = h264o_ue(b);
+                p->bottom_right[g] = h264o_ue(b);
+                if (p->top_left[g] > p->bottom_right[g] || (unsigned)p->bottom_right[g] >= units || p->top_left[g] % wmb > p->bottom_right[g] % wmb) return -3;
+            }
+            break;
+        case 3:
+        case 4:
+        case 5:
+            p->slice_group_change_direction_flag = h264o_u(b, 1);
+            p->slice_group_change_rate_minus1 = h264o_ue(b);
+            if (ng != 2 || (unsigned)p->slice_group_change_rate_minus1 >= units) return -3;
+            break;
+        case 6: {
+            p->pic_size_in_map_units_minus1 = h264o_ue(b);
+            if ((unsigned)p->pic_size_in_map_units_minus1 + 1 != units) return -3;
+            int nb = bits_for((unsigned)ng);
+            for (unsigned i = 0; i < units && !b->err; i++) {
+                unsigned v = h264o_u(b, nb);
+                if (v >= (unsigned)ng) return -3;
+                if (ids && i < cap) ids[i] = (uint8_t)v;
+            }
+            if (n_ids) *n_ids = units;
+            break;
+        }
+        default: return -3;
+        }
+    }
     p->num_ref_idx_l0_default_active_minus1 = h264o_ue(b);
     p->num_ref_idx_l1_default_active_minus1 = h264o_ue(b);
     p->weighted_pred_flag = h264o_u(b, 1);
@@ -381,12 +431,114 @@ int h264o_parse_slice_header(h264o_br *b, int nal_ref_idc, int nal_unit_type, co
             sh->slice_beta_offset_div2 = h264o_se(b);
         }
     }
-    /* slice_group_change_cycle: only with FMO types 3-5, rejected in parse_pps */
+    if (p->num_slice_groups_minus1 > 0 && p->slice_group_map_type >= 3 && p->slice_group_map_type <= 5) {
+        /* Ceil(Log2(PicSizeInMapUnits / SliceGroupChangeRate + 1)) bits with an exact quotient (7.4.3; h264/slice.go:1028-1031) */
+        unsigned long long units = (unsigned long long)(s->pic_width_in_mbs_minus1 + 1) * (unsigned long long)(s->pic_height_in_map_units_minus1 + 1);
+        unsigned long long rate = (unsigned long long)p->slice_group_change_rate_minus1 + 1;
+        int n = 0;
+        while (((1ull << n) - 1) * rate < units) n++;
+        sh->slice_group_change_cycle = n ? (int)h264o_u(b, n) : 0;
+        if ((unsigned long long)sh->slice_group_change_cycle > (units + rate - 1) / rate) return -1;
+    }
     sh->slice_qp_y = 26 + p->pic_init_qp_minus26 + sh->slice_qp_delta; /* (7-30), h264/cabac.go:113 */
     sh->slice_data_bit_offset = b->pos;
     if (b->err) return -1;
     if (sh->slice_qp_y < 0 || sh->slice_qp_y > 51) return -1;
     return 0;
+}
+
+/* ------------------------------------------------------------------ slice groups 8.2.2 */
+/* MapUnitToSliceGroupMap (h264/slice.go:457-529: types 0-2 only there).  map: PicSizeInMapUnits bytes. */
+int h264o_map_unit_to_slice_group_map(const h264o_sps *s, const h264o_pps *p, const uint8_t *ids, int cycle, uint8_t *map) {
+    int W = s->pic_width_in_mbs_minus1 + 1, H = s->pic_height_in_map_units_minus1 + 1, units = W * H, ng = p->num_slice_groups_minus1 + 1;
+    if (ng == 1) {
+        memset(map, 0, (size_t)units);
+        return units;
+    }
+    int dir = p->slice_group_change_direction_flag, rate = p->slice_group_change_rate_minus1 + 1;
+    long long g0 = (long long)cycle * rate; /* MapUnitsInSliceGroup0 (7-33) */
+    if (g0 > units) g0 = units;
+    long long upper_left = dir ? units - g0 : g0; /* (8-14) */
+    switch (p->slice_group_map_type) {
+    case 0: { /* 8.2.2.1 */
+        int i = 0;
+        while (i < units)
+            for (int g = 0; g < ng && i < units; g++) {
+                for (int j = 0; j <= p->run_length_minus1[g] && i + j < units; j++) map[i + j] = (uint8_t)g;
+                i += p->run_length_minus1[g] + 1;
+            }
+        break;
+    }
+    case 1: /* 8.2.2.2 */
+        for (int i = 0; i < units; i++) map[i] = (uint8_t)(((i % W) + (((i / W) * ng) / 2)) % ng);
+        break;
+    case 2: /* 8.2.2.3 */
+        memset(map, ng - 1, (size_t)units);
+        for (int g = ng - 2; g >= 0; g--)
+            for (int y = p->top_left[g] / W; y <= p->bottom_right[g] / W; y++)
+                for (int x = p->top_left[g] % W; x <= p->bottom_right[g] % W; x++) map[y * W + x] = (uint8_t)g;
+        break;
+    case 3: { /* 8.2.2.4 */
+        memset(map, 1, (size_t)units);
+        int x = (W - dir) / 2, y = (H - dir) / 2, lb = x, tb = y, rb = x, bb = y, xd = dir - 1, yd = dir;
+        for (long long k = 0; k < g0;) {
+            int vacant = map[y * W + x] == 1;
+            if (vacant) map[y * W + x] = 0;
+            if (xd == -1 && x == lb) {
+                lb = lb - 1 < 0 ? 0 : lb - 1;
+                x = lb, xd = 0, yd = 2 * dir - 1;
+            } else if (xd == 1 && x == rb) {
+                rb = rb + 1 > W - 1 ? W - 1 : rb + 1;
+                x = rb, xd = 0, yd = 1 - 2 * dir;
+            } else if (yd == -1 && y == tb) {
+                tb = tb - 1 < 0 ? 0 : tb - 1;
+                y = tb, xd = 1 - 2 * dir, yd = 0;
+            } else if (yd == 1 && y == bb) {
+                bb = bb + 1 > H - 1 ? H - 1 : bb + 1;
+                y = bb, xd = 2 * dir - 1, yd = 0;
+            } else
+                x += xd, y += yd;
+            k += vacant;
+        }
+        break;
+    }
+    case 4: /* 8.2.2.5 */
+        for (int i = 0; i < units; i++) map[i] = (uint8_t)(i < upper_left ? dir : 1 - dir);
+        break;
+    case 5: { /* 8.2.2.6 */
+        long long k = 0;
+        for (int j = 0; j < W; j++)
+            for (int i = 0; i < H; i++) map[i * W + j] = (uint8_t)(k++ < upper_left ? dir : 1 - dir);
+        break;
+    }
+    case 6: /* 8.2.2.7 */
+        if (!ids) return -1;
+        memcpy(map, ids, (size_t)units);
+        break;
+    default: return -1;
+    }
+    return units;
+}
+
+/* MbToSliceGroupMap 8.2.2.8 (h264/slice.go:134-158).  map: PicSizeInMbs bytes; returns PicSizeInMbs. */
+int h264o_mb_to_slice_group_map(const h264o_sps *s, const h264o_pps *p, const uint8_t *ids, int cycle, int field_pic, uint8_t *map) {
+    int W = s->pic_width_in_mbs_minus1 + 1, units = W * (s->pic_height_in_map_units_minus1 + 1);
+    if (s->frame_mbs_only_flag || field_pic) return h264o_map_unit_to_slice_group_map(s, p, ids, cycle, map);
+    uint8_t *mu = (uint8_t *)malloc((size_t)units);
+    if (h264o_map_unit_to_slice_group_map(s, p, ids, cycle, mu) < 0) {
+        free(mu);
+        return -1;
+    }
+    for (int i = 0; i < 2 * units; i++) map[i] = s->mb_adaptive_frame_field_flag ? mu[i / 2] : mu[(i / (2 * W)) * W + (i % W)];
+    free(mu);
+    return 2 * units;
+}
+
+/* nextMbAddress (8-17; h264/slice.go:530-552) */
+int h264o_next_mb_address(const uint8_t *map, int n_mbs, int n) {
+    int i = n + 1;
+    while (i < n_mbs && map[i] != map[n]) i++;
+    return i;
 }
 
 int h264o_sizeof_sps(void) { return (int)sizeof(h264o_sps); }

@@ -66,6 +66,11 @@ typedef struct {
     int fn_gap_declared;    /* gaps_in_frame_num_value_allowed_flag of the SPS; 0 with fn_gap_period set = a stream that lost pictures */
     int b_pyramid;          /* with bframes >= 2: the middle B picture of a group is coded first, as a REFERENCE picture (nal_ref_idc 2);
                              * the other B pictures of the group may predict from it and take it as their co-located picture */
+    /* Baseline extras (7.3.2.2, 8.2.2): slice_groups n >= 2 puts every picture's macroblocks into n slice groups by map type
+     * fmo_type 0..6 (types 3..5: two groups, slice_group_change_cycle moves from picture to picture; 6: an explicit pseudo-random
+     * map); `slices` then counts the slices PER GROUP.  aso: the slices of a picture leave in a shuffled order (arbitrary slice
+     * order; needs more than one slice per picture to show) */
+    int slice_groups, fmo_type, aso;
 } sg_params;
 
 void sg_default_params(sg_params *p);

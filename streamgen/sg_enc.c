@@ -62,6 +62,9 @@ typedef struct {
     uint16_t done;
     int16_t i16dc[16], luma[16][16], luma8[4][64], cdc[2][4], cac[2][4][16];
     uint8_t pcm[384];
+    /* slice groups (sg_params::slice_groups): PPS contents and the macroblock-to-slice-group map of the current picture */
+    uint8_t *sgmap, *sg_ids;
+    int sg_rl[8], sg_tl[8], sg_br[8], sg_dir, sg_rate, sg_cycle, sg_cycle_bits;
 } enc;
 
 static char g_err[256];
@@ -1769,16 +1772,121 @@ static size_t write_sps(enc *e, uint8_t *dst, size_t cap) {
     sg_trailing(&w);
     return sg_write_nal(dst, cap, 1, 3, 7, buf, sg_bw_bytes(&w));
 }
-static size_t write_pps(enc *e, uint8_t *dst, size_t cap) {
-    uint8_t buf[64];
-    sg_bw w;
+/* ------------------------------------------------------------------ slice groups (7.3.2.2, 8.2.2) */
+static int sg_map_units(const enc *e) { return e->wmb * (e->p.interlace_sps ? e->hmb / 2 : e->hmb); }
+/* what the PPS will say, chosen from the seed so that every map type gets awkward shapes */
+static void plan_slice_groups(enc *e) {
     const sg_params *p = &e->p;
-    sg_bw_init(&w, buf, sizeof(buf));
+    int W = e->wmb, Hm = sg_map_units(e) / W, units = W * Hm, ng = p->slice_groups;
+    for (int g = 0; g < 8; g++) {
+        e->sg_rl[g] = (int)((p->seed * 5u + 7u * (unsigned)g) % (unsigned)(W + 3)); /* run_length_minus1: runs that straddle rows */
+        int x0 = (2 * g + 1) % (W > 2 ? W / 2 : 1), y0 = (g + 1) % (Hm > 2 ? Hm / 2 : 1);
+        int x1 = x0 + W / 3, y1 = y0 + Hm / 3;
+        if (x1 > W - 1) x1 = W - 1;
+        if (y1 > Hm - 1) y1 = Hm - 1;
+        e->sg_tl[g] = y0 * W + x0, e->sg_br[g] = y1 * W + x1;
+    }
+    e->sg_dir = (int)(p->seed & 1u);
+    e->sg_rate = W / 2 + 1; /* SliceGroupChangeRate: half a row and a bit */
+    e->sg_cycle_bits = 0;
+    while (((1ll << e->sg_cycle_bits) - 1) * e->sg_rate < units) e->sg_cycle_bits++; /* Ceil(Log2(units / rate + 1)), exact quotient */
+    e->sg_ids = (uint8_t *)malloc((size_t)units);
+    uint32_t h = p->seed * 2654435761u + 12345u;
+    for (int i = 0; i < units; i++) { /* explicit map: mostly the neighbour's group, sometimes a new one -- ragged blobs */
+        h = h * 1664525u + 1013904223u;
+        e->sg_ids[i] = (uint8_t)((i > 0 && (h >> 24) % 3 != 0) ? e->sg_ids[i - 1] : (h >> 16) % (unsigned)ng);
+    }
+    e->sgmap = (uint8_t *)malloc((size_t)e->wmb * e->hmb);
+}
+/* mapUnitToSliceGroupMap for slice_group_change_cycle `cycle`, then mbToSliceGroupMap (8.2.2.8) into e->sgmap */
+static void build_slice_group_map(enc *e, int cycle) {
+    const sg_params *p = &e->p;
+    int W = e->wmb, Hm = sg_map_units(e) / W, units = W * Hm, ng = p->slice_groups;
+    uint8_t *mu = (uint8_t *)malloc((size_t)units);
+    int in0 = cycle * e->sg_rate < units ? cycle * e->sg_rate : units;
+    int upper_left = e->sg_dir ? units - in0 : in0;
+    switch (p->fmo_type) {
+    case 0:
+        for (int i = 0, g = 0; i < units; g = (g + 1) % ng)
+            for (int j = 0; j <= e->sg_rl[g] && i < units; j++) mu[i++] = (uint8_t)g;
+        break;
+    case 1:
+        for (int y = 0; y < Hm; y++)
+            for (int x = 0; x < W; x++) mu[y * W + x] = (uint8_t)((x + ((y * ng) >> 1)) % ng);
+        break;
+    case 2:
+        for (int i = 0; i < units; i++) {
+            int x = i % W, y = i / W, g = ng - 1;
+            for (int k = ng - 2; k >= 0; k--) /* the lowest-numbered rectangle that holds the unit wins */
+                if (x >= e->sg_tl[k] % W && x <= e->sg_br[k] % W && y >= e->sg_tl[k] / W && y <= e->sg_br[k] / W) g = k;
+            mu[i] = (uint8_t)g;
+        }
+        break;
+    case 3: { /* box-out: a spiral from the centre, clockwise or counter-clockwise, claims the first in0 units for group 0 */
+        memset(mu, 1, (size_t)units);
+        int d = e->sg_dir, x = (W - d) / 2, y = (Hm - d) / 2, l = x, r = x, t = y, b = y, dx = d - 1, dy = d;
+        for (int k = 0; k < in0;) {
+            if (mu[y * W + x]) mu[y * W + x] = 0, k++;
+            if (dx == -1 && x == l) {
+                l = l > 0 ? l - 1 : 0, x = l, dx = 0, dy = 2 * d - 1;
+            } else if (dx == 1 && x == r) {
+                r = r < W - 1 ? r + 1 : W - 1, x = r, dx = 0, dy = 1 - 2 * d;
+            } else if (dy == -1 && y == t) {
+                t = t > 0 ? t - 1 : 0, y = t, dx = 1 - 2 * d, dy = 0;
+            } else if (dy == 1 && y == b) {
+                b = b < Hm - 1 ? b + 1 : Hm - 1, y = b, dx = 2 * d - 1, dy = 0;
+            } else
+                x += dx, y += dy;
+        }
+        break;
+    }
+    case 4:
+        for (int i = 0; i < units; i++) mu[i] = (uint8_t)(i < upper_left ? e->sg_dir : 1 - e->sg_dir);
+        break;
+    case 5:
+        for (int x = 0, k = 0; x < W; x++)
+            for (int y = 0; y < Hm; y++, k++) mu[y * W + x] = (uint8_t)(k < upper_left ? e->sg_dir : 1 - e->sg_dir);
+        break;
+    default: memcpy(mu, e->sg_ids, (size_t)units); break;
+    }
+    for (int i = 0; i < e->wmb * e->hmb; i++) /* frame pictures of an interlace SPS: a map unit is two macroblock rows high */
+        e->sgmap[i] = p->interlace_sps ? mu[(i / (2 * W)) * W + i % W] : mu[i];
+    free(mu);
+}
+static int sg_next_mb(const enc *e, int addr) {
+    if (!e->sgmap) return addr + 1;
+    int i = addr + 1, n = e->wmb * e->hmb;
+    while (i < n && e->sgmap[i] != e->sgmap[addr]) i++;
+    return i;
+}
+
+static size_t write_pps(enc *e, uint8_t *dst, size_t cap) {
+    const sg_params *p = &e->p;
+    size_t bcap = 64 + (p->slice_groups > 1 ? (size_t)sg_map_units(e) : 0);
+    uint8_t *buf = (uint8_t *)malloc(bcap);
+    sg_bw w;
+    sg_bw_init(&w, buf, bcap);
     sg_put_ue(&w, 0);
     sg_put_ue(&w, 0);
     sg_put(&w, (uint32_t)p->cabac, 1);
     sg_put(&w, 0, 1);
-    sg_put_ue(&w, 0); /* slice groups */
+    sg_put_ue(&w, p->slice_groups > 1 ? (uint32_t)(p->slice_groups - 1) : 0); /* num_slice_groups_minus1 */
+    if (p->slice_groups > 1) {
+        int ng = p->slice_groups;
+        sg_put_ue(&w, (uint32_t)p->fmo_type);
+        if (p->fmo_type == 0)
+            for (int g = 0; g < ng; g++) sg_put_ue(&w, (uint32_t)e->sg_rl[g]);
+        else if (p->fmo_type == 2)
+            for (int g = 0; g < ng - 1; g++) sg_put_ue(&w, (uint32_t)e->sg_tl[g]), sg_put_ue(&w, (uint32_t)e->sg_br[g]);
+        else if (p->fmo_type >= 3 && p->fmo_type <= 5)
+            sg_put(&w, (uint32_t)e->sg_dir, 1), sg_put_ue(&w, (uint32_t)(e->sg_rate - 1));
+        else if (p->fmo_type == 6) {
+            int bits = 0, units = sg_map_units(e);
+            while ((1 << bits) < ng) bits++;
+            sg_put_ue(&w, (uint32_t)(units - 1));
+            for (int i = 0; i < units; i++) sg_put(&w, e->sg_ids[i], bits);
+        }
+    }
     sg_put_ue(&w, (uint32_t)(p->num_ref_frames - 1));
     sg_put_ue(&w, 0);
     sg_put(&w, p->weighted_pred != 0, 1);
@@ -1795,7 +1903,9 @@ static size_t write_pps(enc *e, uint8_t *dst, size_t cap) {
         sg_put_se(&w, p->chroma_qp_offset + (p->transform8x8 ? 1 : 0));
     }
     sg_trailing(&w);
-    return sg_write_nal(dst, cap, 1, 3, 8, buf, sg_bw_bytes(&w));
+    size_t n = sg_write_nal(dst, cap, 1, 3, 8, buf, sg_bw_bytes(&w));
+    free(buf);
+    return n;
 }
 
 static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int idr_id, int poc_lsb) {
@@ -1877,6 +1987,7 @@ static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int
         sg_put_se(w, p->alpha_off_div2);
         sg_put_se(w, p->beta_off_div2);
     }
+    if (p->slice_groups > 1 && p->fmo_type >= 3 && p->fmo_type <= 5 && e->sg_cycle_bits) sg_put(w, (uint32_t)e->sg_cycle, e->sg_cycle_bits);
 }
 
 /* ------------------------------------------------------------------ picture management (generator side)
@@ -2176,6 +2287,12 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         return 0;
     }
     if (p->slices > e->hmb) p->slices = e->hmb;
+    if (p->slice_groups < 2) p->slice_groups = 0;
+    if (p->slice_groups > 8) p->slice_groups = 8;
+    if (p->slice_groups && (p->fmo_type < 0 || p->fmo_type > 6)) p->fmo_type = 1;
+    if (p->slice_groups && p->fmo_type >= 3 && p->fmo_type <= 5) p->slice_groups = 2; /* the evolving maps have two groups */
+    if (p->slice_groups && p->slices > 4) p->slices = 4;
+    if (p->slice_groups) plan_slice_groups(e);
     e->rng = 0x9E3779B97F4A7C15ull ^ ((uint64_t)p->seed * 0xD1B54A32D192ED03ull);
     if (!e->rng) e->rng = 1;
     size_t fsz = (size_t)e->W * e->H * 3 / 2;
@@ -2333,9 +2450,39 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             e->wb_w1[0] = 1 << wld, e->wb_o1[0] = 0;
         }
         for (int i = 0; i < e->wmb * e->hmb; i++) e->mb[i].type = T_NONE;
-        for (int s = 0; s < p->slices; s++) {
-            int row0 = e->hmb * s / p->slices, row1 = e->hmb * (s + 1) / p->slices;
-            int first = row0 * e->wmb, last = row1 * e->wmb;
+        /* the slices of this picture: (first macroblock, macroblock count), in the order they will be sent */
+        int sl_first[512], sl_count[512], nsl = 0;
+        if (p->slice_groups > 1) {
+            int maxc = (sg_map_units(e) + e->sg_rate - 1) / e->sg_rate;
+            e->sg_cycle = (3 * t + 1) % (maxc + 1); /* types 3..5: the boundary moves (and, at 0 / max, one group is empty) */
+            build_slice_group_map(e, e->sg_cycle);
+            for (int g = 0; g < p->slice_groups; g++) {
+                int n = 0, first = -1;
+                for (int i = 0; i < e->wmb * e->hmb; i++)
+                    if (e->sgmap[i] == g) {
+                        if (first < 0) first = i;
+                        n++;
+                    }
+                for (int k = 0, a = first, done = 0; k < p->slices && n > 0; k++) { /* the group in p->slices runs of its own order */
+                    int c = n * (k + 1) / p->slices - done;
+                    if (c <= 0) continue;
+                    sl_first[nsl] = a, sl_count[nsl++] = c;
+                    done += c;
+                    for (int i = 0; i < c; i++) a = sg_next_mb(e, a);
+                }
+            }
+        } else
+            for (int s = 0; s < p->slices; s++) {
+                int row0 = e->hmb * s / p->slices, row1 = e->hmb * (s + 1) / p->slices;
+                if (row1 > row0) sl_first[nsl] = row0 * e->wmb, sl_count[nsl++] = (row1 - row0) * e->wmb;
+            }
+        if (p->aso) /* arbitrary slice order: a rotation plus a swap, different for every picture */
+            for (int k = nsl - 1; k > 0; k--) {
+                int j = (int)((p->seed + 7u * (unsigned)t + 3u * (unsigned)k) % (unsigned)(k + 1)), tf = sl_first[k], tc = sl_count[k];
+                sl_first[k] = sl_first[j], sl_count[k] = sl_count[j], sl_first[j] = tf, sl_count[j] = tc;
+            }
+        for (int s = 0; s < nsl; s++) {
+            int first = sl_first[s];
             e->slice_id = s;
             e->init_idc = p->cabac_init_idc >= 0 ? p->cabac_init_idc : (t + s) % 3;
             e->slice_qp = p->qp + p->slice_qp_delta * ((t + s) % 3 - 1);
@@ -2349,7 +2496,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
                 sg_cabac_init_ctx(&e->bw, idr ? 0 : 1 + e->init_idc, e->slice_qp);
                 sg_cabac_start(&e->bw);
             }
-            for (int addr = first; addr < last; addr++) {
+            for (int addr = first, left = sl_count[s]; left > 0; left--, addr = sg_next_mb(e, addr)) {
                 begin_mb(e, addr);
                 if (idr)
                     encode_intra(e, 1);
@@ -2405,7 +2552,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
                         encode_inter(e, kind);
                 }
                 end_mb(e);
-                if (p->cabac) sg_cabac_terminate(&e->bw, addr == last - 1);
+                if (p->cabac) sg_cabac_terminate(&e->bw, left == 1);
             }
             if (p->cabac)
                 while (!sg_bw_aligned(&e->bw)) sg_put(&e->bw, 0, 1);
@@ -2455,6 +2602,8 @@ done:
     free(e->mb);
     free(e->db);
     free(e->src);
+    free(e->sgmap);
+    free(e->sg_ids);
     free(rbsp);
     free(e);
     return out;
