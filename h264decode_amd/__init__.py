@@ -6,7 +6,7 @@ creating a Decoder without a HIP device or without the built libh264mi.so raises
 from ._lib import H264MIError, build, lib, load  # noqa: F401
 from .h264 import (  # noqa: F401
     NALU_TYPE_NAMES, PPS, SPS, Decoder, NalUnit, NewNalUnit, NewPPS, NewSPS, NewSliceContext, SliceContext, SliceHeader,
-    VideoStream, read_nal_units, AccessUnitSplitter, DisplayOrder, H264Reader, handleConnection, ByteStreamReader, BatchServer)
+    VideoStream, read_nal_units, MapUnitToSliceGroupMap, MbToSliceGroupMap, nextMbAddress, AccessUnitSplitter, DisplayOrder, H264Reader, handleConnection, ByteStreamReader, BatchServer)
 from .mbtype import (  # noqa: F401
     MB_TYPE_INFERRED, ISliceMbType, SISliceMbType, PSliceMbType, BSliceMbType, MbTypeName, MbPartPredMode, NumMbPart, PicWidthInMbs,
     PicHeightInMapUnits, PicSizeInMapUnits, FrameHeightInMbs, PicHeightInMbs, PicSizeInMbs, SubWidthC, SubHeightC, MbWidthC, MbHeightC,

@@ -38,9 +38,18 @@
 #ifndef MI_ENT_B
 #define MI_ENT_B 0
 #endif
+// Third build (k_entropy_f.hip: MI_ENT_FMO = 1): the I/P kernel with the slice-group walk (8.2.2) -- launched instead of k_entropy
+// for the launches that hold a picture with more than one slice group, so that the common kernel's register budget does not pay
+// for a Baseline-only feature.  The B build always carries it.
+#ifndef MI_ENT_FMO
+#define MI_ENT_FMO MI_ENT_B
+#endif
 #if MI_ENT_B
 #define NL 2
 #define MI_ENT_KERNEL k_entropy_b
+#elif MI_ENT_FMO
+#define NL 1
+#define MI_ENT_KERNEL k_entropy_f
 #else
 #define NL 1
 #define MI_ENT_KERNEL k_entropy
@@ -64,7 +73,8 @@
 struct TopInfo { // edge state of a decoded MB as seen by its right / lower neighbours (48 bytes; 72 in the B build)
     uint8_t type, t8x8, cbp, chroma_mode, cbf_dc;
     uint8_t dmask;  // B: bit k = the k-th 8x8 block on the edge is predicted in direct mode (ref_idx contexts, 9.3.3.1.1.6)
-    uint8_t pad[2];
+    uint16_t row;   // macroblock row of the entry + 1 (0: never written).  Pictures with slice groups: a slice's previous visit of a column
+                    // need not be the row above, so an entry counts as neighbour B / C / D only if its row is the current one - 1
     int8_t ipm[4];  // bottom row (top[]) or right column (left)
     uint8_t nnz[8]; // luma edge [0..3], Cb edge [4..5], Cr edge [6..7]
     int8_t ref[2][2]; // [list][the two 8x8 blocks on the edge] (the I/P build uses list 0 only; [1] is padding there)
@@ -1474,6 +1484,7 @@ FI void decode_mb(Ent &e, int skipped) {
         dst->cbp = r.cbp;
         dst->chroma_mode = static_cast<uint8_t>(chroma_mode);
         dst->cbf_dc = s->cur_cbf_dc;
+        if (MI_ENT_FMO) dst->row = static_cast<uint16_t>(e.mby + 1);
 #pragma unroll
         for (int L = 0; L < NL; L++) {
             dst->ref[L][0] = inter ? s->refs8[L][l == 0 ? 2 : 1] : static_cast<int8_t>(-1);
@@ -1537,7 +1548,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
                                                            int16_t *coefs, uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status_, uint32_t *toprows_, int wmb_max, uint32_t slice_base,
                                                            const BSliceExt *bexts, MbMv1 *mbmv1) {
 #else
-extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI_ENT_MINWAVES, 8))) k_entropy(const SliceDesc *slices_, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
+extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MI_ENT_MINWAVES, 8))) MI_ENT_KERNEL(const SliceDesc *slices_, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec,
                                                            int16_t *coefs, uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status_, uint32_t *toprows_, int wmb_max, uint32_t slice_base) {
 #endif
     __shared__ Shared sh;
@@ -1647,7 +1658,12 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     const int total = min(e.wmb * e.hmb, RFL(static_cast<int>(sd->end_mb))); // the next slice's territory is out of bounds
     const uint32_t stop_bit = RFL(sd->stop_bit);
     int addr = RFL(static_cast<int>(sd->first_mb));
-    fill_none(e, RFL(static_cast<int>(sd->fill_from)), min(addr, total)); // a gap in front of the first slice of the picture
+    // Slice groups (FMO, 8.2.2; h264/slice.go:134-158, :530-552): the picture's mbToSliceGroupMap follows the slices in the
+    // bitstream buffer; the slice walks the macroblocks of its group (nextMbAddress), the host has zeroed all records.
+    // (only two flags live across the macroblock loop: what the slow path needs beyond them is fetched again where it is used)
+    const bool fmo = MI_ENT_FMO && RFL(static_cast<int>(pd->fmo)) != 0;
+    bool consecutive = false; // FMO: the previous macroblock of the slice is (mbx - 1, mby)
+    if (!fmo) fill_none(e, RFL(static_cast<int>(sd->fill_from)), min(addr, total)); // a gap in front of the first slice of the picture
     e.mbx = addr % e.wmb, e.mby = addr / e.wmb;
     int more = 1, skip_state = 0 /* 0: read mb_skip_run, 1: inside a run, 2: coded MB follows a run */, pending = 0;
     int n_mbs = 0;
@@ -1656,7 +1672,20 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
             e.err = 30;
             break;
         }
-        if (e.mbx == 0 || n_mbs == 0) { // new MB row (or slice start): no left / top-left neighbour; (re)load the row-above window
+        if (fmo) {
+            // The previous macroblock of the slice is the left neighbour only if it is (mbx - 1, mby); the row-above window
+            // cannot slide (the next column is anywhere), so the three entries above are fetched for every macroblock, and an
+            // entry is a neighbour only if this slice wrote it in the row above (TopInfo::row).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wavefront's stores to e.top[] have reached L2
+            if (!consecutive && l < TOP_DW) {
+                reinterpret_cast<uint32_t *>(&sh.nb[NB_LEFT])[l] = 0;
+                reinterpret_cast<uint32_t *>(&sh.nb[NB_TL])[l] = e.mbx > 0 ? top_load(e, e.mbx - 1, l) : 0u;
+            }
+            if (l < 2 * TOP_DW) reinterpret_cast<uint32_t *>(&sh.nb[NB_TOP])[l] = top_load(e, e.mbx + l / TOP_DW, l % TOP_DW);
+            LDS_SYNC();
+            if (l < 3 && sh.nb[NB_TL + l].row != static_cast<uint16_t>(e.mby)) sh.nb[NB_TL + l].type = MBT_NONE;
+            LDS_SYNC();
+        } else if (e.mbx == 0 || n_mbs == 0) { // new MB row (or slice start): no left / top-left neighbour; (re)load the row-above window
             if (l < TOP_DW) reinterpret_cast<uint32_t *>(&sh.nb[NB_LEFT])[l] = 0, reinterpret_cast<uint32_t *>(&sh.nb[NB_TL])[l] = 0;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // stores of the previous row to e.top[] have been issued to L2
             if (l < 2 * TOP_DW) reinterpret_cast<uint32_t *>(&sh.nb[NB_TOP])[l] = top_load(e, e.mbx + l / TOP_DW, l % TOP_DW);
@@ -1705,10 +1734,28 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
             more = bitpos(e) < stop_bit;
             skip_state = 0;
         }
-        addr++;
-        if (++e.mbx == e.wmb) e.mbx = 0, e.mby++;
+        if (fmo) { // nextMbAddress (8-17): 64 candidates at a time
+            const uint8_t *sgmap = bitstream + RFL(e.pd->sgmap_off);
+            const int sgroup = RFL(static_cast<int>(sgmap[RFL(static_cast<int>(e.sd->first_mb))]));
+            const uint32_t inv_wmb = RFL(e.pd->inv_wmb);
+            int next = total;
+            for (int base = addr + 1; base < total; base += 64) {
+                const int i = base + l;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(i < total && sgmap[i] == sgroup);
+                if (m) {
+                    next = base + __builtin_ctzll(m);
+                    break;
+                }
+            }
+            consecutive = next == addr + 1 && e.mbx + 1 < e.wmb;
+            addr = next;
+            e.mby = static_cast<int>(__umulhi(static_cast<uint32_t>(addr), inv_wmb)), e.mbx = addr - e.mby * e.wmb;
+        } else {
+            addr++;
+            if (++e.mbx == e.wmb) e.mbx = 0, e.mby++;
+        }
     }
-    fill_none(e, addr, total); // after an error or an early end of the slice
+    if (!fmo) fill_none(e, addr, total); // after an error or an early end of the slice
     if (l == 0) {
         status[8 * blockIdx.x] = static_cast<uint32_t>(e.err);
         status[8 * blockIdx.x + 1] = static_cast<uint32_t>(n_mbs);

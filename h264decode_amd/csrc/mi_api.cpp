@@ -128,6 +128,8 @@ struct OutFrame { // a decoded picture of the current batch, with the geometry i
 struct StreamState {
     h264mi_sps sps[32];
     h264mi_pps pps[256];
+    std::vector<uint8_t> sg_ids[256]; // slice_group_id[] of the PPSs with slice_group_map_type 6 (h264/pps.go:23)
+    bool cur_has_mb0 = false;          // a slice with first_mb_in_slice 0 has been seen in the current picture
     bool sps_ok[32] = {}, pps_ok[256] = {};
     int active_sps = -1;
     int wmb = 0, hmb = 0;
@@ -152,6 +154,8 @@ struct StreamState {
 struct Stage {
     uint8_t *d_bits = nullptr, *h_bits = nullptr;
     size_t bits_used = 0;
+    size_t map_cursor = 0, bits_end = 0; // slice group maps of FMO pictures follow the slices in the staging buffer; bits_end: what must be uploaded
+    std::vector<uint32_t> fmo_pics;      // pictures whose records are zeroed before the entropy kernels run
     SliceDesc *d_slices = nullptr, *h_slices = nullptr;
     PicDesc *d_pics = nullptr, *h_pics = nullptr;
     uint32_t *d_status = nullptr, *h_status = nullptr, *d_lists = nullptr, *h_lists = nullptr;
@@ -803,11 +807,26 @@ static void finish_picture(h264mi_decoder *d, int si) {
     for (uint32_t i = 0; i < pd.n_slices; i++) idx[i] = pd.first_slice + i;
     std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return g.h_slices[a].first_mb < g.h_slices[b].first_mb; });
     const uint32_t total = pd.wmb * pd.hmb;
-    for (uint32_t i = 0; i < pd.n_slices; i++) {
-        SliceDesc &sd = g.h_slices[idx[i]];
-        sd.fill_from = i == 0 ? 0 : sd.first_mb;
-        sd.end_mb = i + 1 < pd.n_slices ? std::max(g.h_slices[idx[i + 1]].first_mb, sd.first_mb) : total;
-    }
+    if (pd.fmo) {
+        // slice groups: a slice ends where the next slice of ITS group starts; nothing is filled by the wavefronts (the records of
+        // the whole picture are zeroed before the launch: launch_entropy)
+        const uint8_t *map = g.h_bits + pd.sgmap_off;
+        for (uint32_t i = 0; i < pd.n_slices; i++) {
+            SliceDesc &sd = g.h_slices[idx[i]];
+            sd.fill_from = sd.first_mb, sd.end_mb = total;
+            for (uint32_t j = i + 1; j < pd.n_slices; j++)
+                if (map[g.h_slices[idx[j]].first_mb] == map[sd.first_mb]) {
+                    sd.end_mb = std::max(g.h_slices[idx[j]].first_mb, sd.first_mb);
+                    break;
+                }
+        }
+        g.fmo_pics.push_back(static_cast<uint32_t>(s.cur_pic));
+    } else
+        for (uint32_t i = 0; i < pd.n_slices; i++) {
+            SliceDesc &sd = g.h_slices[idx[i]];
+            sd.fill_from = i == 0 ? 0 : sd.first_mb;
+            sd.end_mb = i + 1 < pd.n_slices ? std::max(g.h_slices[idx[i + 1]].first_mb, sd.first_mb) : total;
+        }
     s.cur_slot = s.cur_pic = -1;
 }
 
@@ -984,7 +1003,9 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         set_error("stream %d: %dx%d exceeds the configured maximum %dx%d", si, wmb * 16, hmb * 16, d->Wmax, d->Hmax);
         return H264MI_ECAPACITY;
     }
-    if (s.cur_slot >= 0 && (sh.first_mb_in_slice == 0 || new_picture(sps, s.first_sh, sh))) finish_picture(d, si);
+    // (a second slice that starts at macroblock 0 begins a new picture whatever the headers say; with arbitrary slice order the
+    // first one may come late)
+    if (s.cur_slot >= 0 && ((sh.first_mb_in_slice == 0 && s.cur_has_mb0) || new_picture(sps, s.first_sh, sh))) finish_picture(d, si);
     if (s.active_sps != pps.sps_id || s.wmb != wmb || s.hmb != hmb) { // (re)activate: new sequence geometry
         if (sh.nal_unit_type != 5 && s.active_sps >= 0 && (s.wmb != wmb || s.hmb != hmb)) {
             set_error("stream %d: picture size changes without an IDR", si);
@@ -1013,6 +1034,7 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         s.cur_slot = slot;
         s.cur_pic = g.n_pics++;
         s.cur_slices = 0;
+        s.cur_has_mb0 = false;
         s.first_sh = sh;
         Slot &sl = s.slots[slot];
         sl = Slot();
@@ -1041,6 +1063,18 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         }
         pd.scaling_set = static_cast<uint8_t>(ss);
         pd.order = s.n_pics_in_batch++;
+        if (pps.num_slice_groups_minus1 > 0) { // FMO: this picture's macroblock-to-slice-group map travels with the bitstream (8.2.2; h264/slice.go:134-158)
+            const size_t n_mbs = static_cast<size_t>(wmb) * hmb, moff = (g.map_cursor + 15) & ~static_cast<size_t>(15);
+            if (moff + n_mbs + 4096 > d->bits_cap) {
+                set_error("bitstream staging buffer too small for the slice group maps (%zu bytes)", d->bits_cap);
+                return H264MI_ECAPACITY;
+            }
+            r = mb_to_slice_group_map(&sps, &pps, s.sg_ids[pps_id].data(), s.sg_ids[pps_id].size(), sh.slice_group_change_cycle, 0, g.h_bits + moff, n_mbs, nullptr);
+            if (r != H264MI_OK) return r;
+            pd.fmo = 1, pd.sgmap_off = static_cast<uint32_t>(moff);
+            g.map_cursor = moff + n_mbs;
+            g.bits_end = std::max(g.bits_end, g.map_cursor);
+        }
         g.out[si].push_back({slot, wmb, hmb, 2 * sps.frame_crop_left_offset, 2 * (2 - sps.frame_mbs_only) * sps.frame_crop_top_offset, sps.width, sps.height, sl.poc, sh.frame_num,
                          sh.nal_ref_idc, sh.nal_unit_type == 5, s.cur_pic, sh.nal_unit_type == 5});
         if (sh.nal_ref_idc && sh.adaptive_ref_pic_marking_mode_flag)
@@ -1057,6 +1091,7 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         return H264MI_ECAPACITY;
     }
     if (sh.first_mb_in_slice >= wmb * hmb) return H264MI_EBITSTREAM;
+    if (sh.first_mb_in_slice == 0) s.cur_has_mb0 = true;
     PicDesc &pd = g.h_pics[s.cur_pic];
     SliceDesc &sd = g.h_slices[g.n_slices];
     memset(&sd, 0, sizeof(sd));
@@ -1151,6 +1186,7 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
     g.slice_level.resize(g.n_slices + 1);
     g.slice_level[g.n_slices] = level;
     g.bits_used = std::max(g.bits_used, off + rlen);
+    g.bits_end = std::max(g.bits_end, g.bits_used);
     g.n_slices++;
     s.cur_slices++;
     return H264MI_OK;
@@ -1198,6 +1234,8 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     g.prepared = false, g.executed = false;
     g.n_slices = g.n_pics = 0;
     g.bits_used = 0, g.mb_used = 0, g.wmb_max = 0, g.hmb_max = 0, g.mbs_max = 0;
+    g.map_cursor = g.bits_end = 0;
+    g.fmo_pics.clear();
     g.n_bext = 0;
     g.pic_level.clear(), g.slice_level.clear(), g.pic_save_col.clear();
     memset(&g.info, 0, sizeof(g.info));
@@ -1261,6 +1299,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
                 cursor = off + nal.num_bytes;
             }
         }
+        g.map_cursor = cursor; // slice group maps (FMO pictures) go behind the last slice
     }
     // ---- pass 3 (parallel over slices): remove emulation prevention straight into the pinned staging buffer ----
     parallel_for(static_cast<int>(staged.size()), [&](int k) {
@@ -1308,10 +1347,14 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
                     break;
                 }
                 h264mi_pps pps;
-                r = parse_pps(&s.sps[sid], tmp.data(), rl, &pps);
+                std::vector<uint8_t> ids(static_cast<size_t>(s.sps[sid].pic_width_in_mbs_minus1 + 1) * (s.sps[sid].pic_height_in_map_units_minus1 + 1));
+                size_t n_ids = 0;
+                r = parse_pps_ids(&s.sps[sid], tmp.data(), rl, &pps, ids.data(), ids.size(), &n_ids);
                 if (r == H264MI_OK) {
                     if (s.cur_slot >= 0) finish_picture(d, si);
                     s.pps[pps.id] = pps, s.pps_ok[pps.id] = true;
+                    ids.resize(n_ids);
+                    s.sg_ids[pps.id] = std::move(ids);
                 }
                 break;
             }
@@ -1335,6 +1378,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
             g.n_pics = pics0, g.n_slices = slices0, g.mb_used = mb0, g.info.n_macroblocks = info_mb0;
             g.n_bext = bext0;
             g.pic_level.resize(pics0), g.pic_save_col.resize(pics0), g.slice_level.resize(slices0);
+            while (!g.fmo_pics.empty() && static_cast<int>(g.fmo_pics.back()) >= pics0) g.fmo_pics.pop_back();
             reset_stream(s, true);
             g.out[si].clear();
             s.need_idr = true;
@@ -1419,8 +1463,9 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     // the kernel streams, which serialised entropy decoding and reconstruction of consecutive passes.
     hipStream_t up = d->ent_stream[d->pass & 1];
     if (g.n_slices) {
-        size_t nbytes = std::min(d->bits_cap, ((g.bits_used + 15) & ~static_cast<size_t>(15)) + 4096);
-        memset(g.h_bits + g.bits_used, 0, nbytes - g.bits_used);
+        const size_t end = std::max(g.bits_used, g.bits_end); // (bits_end: behind the slice group maps of FMO pictures, if any)
+        size_t nbytes = std::min(d->bits_cap, ((end + 15) & ~static_cast<size_t>(15)) + 4096);
+        memset(g.h_bits + end, 0, nbytes - end);
         HIP_TRY(hipMemcpyAsync(g.d_bits, g.h_bits, nbytes, hipMemcpyHostToDevice, up));
         HIP_TRY(hipMemcpyAsync(g.d_slices, g.h_slices, sizeof(SliceDesc) * g.n_slices, hipMemcpyHostToDevice, up));
         HIP_TRY(hipMemcpyAsync(g.d_pics, g.h_pics, sizeof(PicDesc) * g.n_pics, hipMemcpyHostToDevice, up));
@@ -1478,6 +1523,9 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     // `done`: recorded after the last level's k_dbprep -- what the reconstruction kernels wait for.
     auto launch_entropy = [&](hipStream_t st, size_t lds_pad, bool fence_prev_pass, hipEvent_t done) {
         const int n_levels = static_cast<int>(g.level_first.size()) - 1;
+        // pictures with slice groups: a slice's macroblocks are scattered, so its wavefront cannot blank "its" range for what it
+        // does not decode (SliceDesc::fill_from) -- all records of such a picture start out as MBT_NONE instead
+        for (uint32_t pi : g.fmo_pics) hipMemsetAsync(mbrec + g.h_pics[pi].mb_base, 0, sizeof(MbRec) * g.h_pics[pi].wmb * g.h_pics[pi].hmb, st);
         for (int lv = 0; lv < n_levels; lv++) {
             const int first = g.level_first[lv], n = g.level_first[lv + 1] - first;
             // ColRec arrays cross passes: B slices read what the previous pass's k_dbprep wrote, and this pass's k_dbprep may
@@ -1490,7 +1538,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
             }
             if (n > 0) {
                 if (lv == 0)
-                    hipLaunchKernelGGL(k_entropy, dim3(n), dim3(64), lds_pad, st, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
+                    hipLaunchKernelGGL(g.fmo_pics.empty() ? k_entropy : k_entropy_f, dim3(n), dim3(64), lds_pad, st, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
                                        static_cast<uint32_t>(d->pool_blocks), g.d_status, d->d_toprows[set], g.wmb_max, static_cast<uint32_t>(first));
                 else
                     hipLaunchKernelGGL(k_entropy_b, dim3(n), dim3(64), 0, st, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,

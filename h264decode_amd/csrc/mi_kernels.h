@@ -6,6 +6,9 @@
 // K1/K2: one slice per wavefront.  grid = #slices, block = 64; toprows = 12 dwords per MB column per slice.
 extern "C" __global__ void k_entropy(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec, int16_t *coefs,
                                      uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status, uint32_t *toprows, int wmb_max, uint32_t slice_base);
+// the same with the slice-group walk of 8.2.2 (k_entropy_f.hip): for launches that hold a picture with more than one slice group
+extern "C" __global__ void k_entropy_f(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec, int16_t *coefs,
+                                       uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status, uint32_t *toprows, int wmb_max, uint32_t slice_base);
 // the same for B slices (k_entropy_b.hip): two reference lists, direct prediction from the ColRec array of RefPicList1[0]; toprows = 18 dwords per column
 extern "C" __global__ void k_entropy_b(const SliceDesc *slices, const PicDesc *pics, const uint8_t *bitstream, const DevTables *tab, MbRec *mbrec, int16_t *coefs,
                                        uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status, uint32_t *toprows, int wmb_max, uint32_t slice_base,

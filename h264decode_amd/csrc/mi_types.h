@@ -152,7 +152,9 @@ typedef struct {
     uint64_t col_out;      /* ColRec array of this picture's frame slot */
     uint8_t has_b;         /* the picture has B slices: MbMv1 records exist, K4 runs its two-list variant */
     uint8_t save_col;      /* a later B picture (or batch) may ask for this picture's motion: k_dbprep also writes its ColRec array */
-    uint8_t pad[2];
+    uint8_t fmo;           /* more than one slice group: sgmap_off is valid, the records are zeroed before the entropy kernels run */
+    uint8_t pad[1];
+    uint32_t sgmap_off;    /* byte offset of the picture's mbToSliceGroupMap (8.2.2.8, one byte per macroblock) in the bitstream buffer */
     uint32_t inv_wmb;      /* floor(2^32 / wmb) + 1: mby = mulhi(mb, inv_wmb) is exact for mb < 2^32 / wmb / wmb (wmb <= 512, hmb <= 320) */
 } PicDesc;
 

@@ -75,11 +75,14 @@ class SPS(_Mirror):
 
 
 class PPS(_Mirror):
-    def __init__(self, c):
+    def __init__(self, c, slice_group_id=None):
         self._c = c
+        self._ids = slice_group_id if slice_group_id is not None else np.zeros(0, dtype=np.uint8)
 
     SPSID = property(lambda s: s._c.sps_id)
     ID = property(lambda s: s._c.id)
+    SliceGroupChangeDirection = property(lambda s: bool(s._c.slice_group_change_direction))
+    SliceGroupId = property(lambda s: s._ids.copy())  # h264/pps.go:23 (slice_group_map_type 6: one entry per map unit)
 
 
 class SliceHeader(_Mirror):
@@ -123,8 +126,44 @@ def NewSPS(rbsp: bytes, showPacket: bool = False) -> SPS:
 
 def NewPPS(sps: SPS, rbsp: bytes, showPacket: bool = False) -> PPS:
     c = _lib.Pps()
-    check(_lib.load().h264mi_pps_parse(ctypes.byref(sps._c), rbsp, len(rbsp), ctypes.byref(c)))
-    return PPS(c)
+    L = _lib.load()
+    check(L.h264mi_pps_parse(ctypes.byref(sps._c), rbsp, len(rbsp), ctypes.byref(c)))
+    ids = None
+    if c.num_slice_groups_minus1 > 0 and c.slice_group_map_type == 6:
+        ids = np.zeros(c.pic_size_in_map_units_minus1 + 1, dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        check(L.h264mi_pps_slice_group_ids(ctypes.byref(sps._c), rbsp, len(rbsp), ids.ctypes.data, ids.size, ctypes.byref(n)))
+    return PPS(c, ids)
+
+
+def _sg_args(pps, header):
+    ids = pps._ids
+    cycle = header.SliceGroupChangeCycle if header is not None else 0
+    return (ids.ctypes.data if ids.size else None), ids.size, int(cycle)
+
+
+def MapUnitToSliceGroupMap(sps: SPS, pps: PPS, header=None) -> np.ndarray:
+    """mapUnitToSliceGroupMap, 8.2.2.1-8.2.2.7 (h264/slice.go:457-529; the reference implements types 0-2)."""
+    out = np.zeros((sps.PicWidthInMbsMinus1 + 1) * (sps.PicHeightInMapUnitsMinus1 + 1), dtype=np.uint8)
+    ids, n_ids, cycle = _sg_args(pps, header)
+    check(_lib.load().h264mi_map_unit_to_slice_group_map(ctypes.byref(sps._c), ctypes.byref(pps._c), ids, n_ids, cycle, out.ctypes.data, out.size, None))
+    return out
+
+
+def MbToSliceGroupMap(sps: SPS, pps: PPS, header=None) -> np.ndarray:
+    """mbToSliceGroupMap, 8.2.2.8 (h264/slice.go:134-158)."""
+    field = bool(header.FieldPic) if header is not None else False
+    n = (sps.PicWidthInMbsMinus1 + 1) * (sps.PicHeightInMapUnitsMinus1 + 1) * (1 if (sps.FrameMbsOnly or field) else 2)
+    out = np.zeros(n, dtype=np.uint8)
+    ids, n_ids, cycle = _sg_args(pps, header)
+    check(_lib.load().h264mi_mb_to_slice_group_map(ctypes.byref(sps._c), ctypes.byref(pps._c), ids, n_ids, cycle, int(field), out.ctypes.data, out.size, None))
+    return out
+
+
+def nextMbAddress(n: int, sps: SPS, pps: PPS, header=None) -> int:
+    """(8-17), h264/slice.go:530-552: the next macroblock of n's slice group; PicSizeInMbs when there is none."""
+    m = MbToSliceGroupMap(sps, pps, header)
+    return int(_lib.load().h264mi_next_mb_address(m.ctypes.data, m.size, n))
 
 
 def NewSliceContext(videoStream: VideoStream, nalUnit: NalUnit, rbsp: bytes, showPacket: bool = False) -> SliceContext:

@@ -72,6 +72,18 @@ BASE = dict(width=176, height=144, frames=4, idr_period=0)
 PRODUCT_DECODES_B = True
 
 MATRIX = {
+    # Slice groups (FMO, 8.2.2; h264/slice.go:134-158, :457-552) and arbitrary slice order: all seven map types, one or two slices per
+    # group, the slices of a picture in shuffled order, slice-edge deblocking off (idc 2), map units of two rows (interlace SPS)
+    "fmo_interleaved": dict(BASE, profile_idc=66, cabac=0, slice_groups=3, fmo_type=0, intra_in_p_permille=150, seed=91),
+    "fmo_dispersed_aso": dict(BASE, profile_idc=66, cabac=0, slice_groups=4, fmo_type=1, slices=2, aso=1, intra_in_p_permille=150, seed=92),
+    "fmo_foreground": dict(BASE, profile_idc=66, cabac=0, slice_groups=3, fmo_type=2, aso=1, sub8x8_permille=300, seed=93),
+    "fmo_boxout": dict(BASE, frames=6, profile_idc=66, cabac=0, slice_groups=2, fmo_type=3, aso=1, intra_in_p_permille=150, seed=94),
+    "fmo_raster": dict(BASE, frames=6, profile_idc=66, cabac=0, slice_groups=2, fmo_type=4, slices=2, seed=95),
+    "fmo_wipe": dict(BASE, frames=6, profile_idc=66, cabac=0, slice_groups=2, fmo_type=5, aso=1, num_ref_frames=2, seed=96),
+    "fmo_explicit": dict(BASE, profile_idc=66, cabac=0, slice_groups=5, fmo_type=6, slices=2, aso=1, deblock_idc=2, pcm_permille=30, intra_in_p_permille=200, seed=97),
+    "fmo_interlace_sps": dict(width=176, height=160, frames=4, idr_period=0, profile_idc=66, cabac=0, interlace_sps=1, slice_groups=3, fmo_type=1, seed=98),
+    "fmo_explicit_cabac_b": dict(BASE, frames=7, profile_idc=77, cabac=1, slice_groups=3, fmo_type=6, aso=1, bframes=2, num_ref_frames=3, seed=99),
+    "aso_only": dict(BASE, profile_idc=66, cabac=0, slices=4, aso=1, deblock_idc=2, intra_in_p_permille=150, seed=90),
     "cavlc_I": dict(width=64, height=48, frames=2, idr_period=1, profile_idc=66, cabac=0),
     "cabac_I": dict(width=64, height=48, frames=2, idr_period=1, profile_idc=77, cabac=1),
     "cavlc_IPP": dict(BASE, profile_idc=66, cabac=0, qp=24),
