@@ -32,6 +32,11 @@ class _x_wgs:
             os.environ["H264MI_X_WGS"] = self.old
 
 
+def _nslices(kw):
+    """slices per picture of a parity-matrix case (with slice groups: `slices` per group)"""
+    return max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1))
+
+
 def _decode_gpu(H, streams, w, h, frames, slices=1, crop=False, x_wgs=None):
     with _x_wgs(x_wgs):
         return _decode_gpu_(H, streams, w, h, frames, slices, crop)
@@ -56,10 +61,10 @@ def test_gpu_matches_oracle_and_generator(name, H, sg, oracle_mod):
     ref, _ = oracle_mod.decode(stream, crop=False)
     if kw.get("bframes") and not PRODUCT_DECODES_B:
         with pytest.raises(H.H264MIError) as e:
-            _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], kw.get("slices", 1))
+            _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], _nslices(kw))
         assert e.value.code == -3
         return
-    out, info = _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], kw.get("slices", 1))
+    out, info = _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], _nslices(kw))
     assert info.n_frames == kw["frames"]
     assert out[0].shape == ref.shape
     assert np.array_equal(out[0], ref), "GPU != oracle"
@@ -75,7 +80,7 @@ def test_gpu_matrix_with_one_workgroup_per_picture(H, sg):
         kw = MATRIX[name]
         stream, rec, _ = sg.encode(**kw)
         for x in (0, 512):
-            out, _ = _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], kw.get("slices", 1), x_wgs=x)
+            out, _ = _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], _nslices(kw), x_wgs=x)
             assert np.array_equal(out[0], rec), (name, x)
 
 
@@ -86,7 +91,7 @@ def test_gpu_golden_md5(H, sg):
         if kw.get("bframes") and not PRODUCT_DECODES_B:
             continue
         stream, _, _ = sg.encode(**kw)
-        out, _ = _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], kw.get("slices", 1))
+        out, _ = _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], _nslices(kw))
         assert hashlib.md5(out[0].tobytes()).hexdigest() == g["frames_md5"], name
 
 
@@ -489,7 +494,7 @@ def test_gpu_b_stream_split_across_batches(name, chunk, H, sg):
     `chunk` pictures per call -- every B picture's co-located picture then comes from an earlier batch -- decodes like one piece."""
     kw = MATRIX[name]
     stream, rec, sizes = sg.encode(**kw)
-    dec = H.Decoder(max_streams=1, max_width=kw["width"], max_height=kw["height"], max_frames_per_batch=chunk, max_slices_per_frame=kw.get("slices", 1))
+    dec = H.Decoder(max_streams=1, max_width=kw["width"], max_height=kw["height"], max_frames_per_batch=chunk, max_slices_per_frame=_nslices(kw))
     got, pos = [], 0
     for k in range(0, len(sizes), chunk):
         n = int(sizes[k:k + chunk].sum())
@@ -530,7 +535,7 @@ def test_gpu_slice_data_carries_the_coded_mb_type(name, H, sg, oracle_mod):
     W, Hc = (kw["width"] + 15) // 16 * 16, (kw["height"] + 15) // 16 * 16
     nmb = (W // 16) * (Hc // 16)
     tr = tr.reshape(-1, nmb, 8)
-    dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=kw["frames"], max_slices_per_frame=kw.get("slices", 1))
+    dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=kw["frames"], max_slices_per_frame=_nslices(kw))
     dec.decode([stream])
     nals = H.read_nal_units(stream)
     sps = H.NewSPS(nals[0].RBSP())

@@ -13,6 +13,11 @@ import h264decode_amd as H  # noqa: E402
 MBT = ["NONE", "I4x4", "I8x8", "I16x16", "IPCM", "P16x16", "P16x8", "P8x16", "P8x8", "PSKIP", "B", "BDIRECT", "BSKIP"]
 
 
+def _nslices(kw):
+    """slices per picture of a parity-matrix case (with slice groups: `slices` per group)"""
+    return max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1))
+
+
 def gpu_type_from_trace(raw, islice_guess):
     return None
 
@@ -23,7 +28,7 @@ def compare(name, kw, dec_cache={}):
     nmb = (W // 16) * (H_ // 16)
     key = (W, H_)
     t0 = time.time()
-    dec = H.Decoder(max_streams=1, max_width=W, max_height=H_, max_frames_per_batch=kw["frames"], max_slices_per_frame=max(1, kw.get("slices", 1)))
+    dec = H.Decoder(max_streams=1, max_width=W, max_height=H_, max_frames_per_batch=kw["frames"], max_slices_per_frame=max(1, _nslices(kw)))
     try:
         dec.decode([s])
     except Exception as ex:
