@@ -104,6 +104,8 @@ func NewSPS(rbsp []byte, showPacket bool) *SPS { // h264/sps.go:192
 type PPS struct {
 	c C.h264mi_pps
 	PPSFields
+	SliceGroupId []int // h264/pps.go:23: slice_group_map_type 6, one entry per map unit
+	ids          []byte
 }
 
 func NewPPS(sps *SPS, rbsp []byte, showPacket bool) *PPS { // h264/pps.go:40
@@ -113,7 +115,71 @@ func NewPPS(sps *SPS, rbsp []byte, showPacket bool) *PPS { // h264/pps.go:40
 		return p
 	}
 	p.PPSFields = copyPPSFields(&p.c)
+	if p.NumSliceGroupsMinus1 > 0 && p.SliceGroupMapType == 6 {
+		p.ids = make([]byte, p.PicSizeInMapUnitsMinus1+1)
+		var n C.size_t
+		if err := status(C.h264mi_pps_slice_group_ids(&sps.c, bptr(rbsp), C.size_t(len(rbsp)), bptr(p.ids), C.size_t(len(p.ids)), &n)); err != nil {
+			logger.Printf("NewPPS: %v", err)
+			return p
+		}
+		for _, v := range p.ids {
+			p.SliceGroupId = append(p.SliceGroupId, int(v))
+		}
+	}
 	return p
+}
+
+// ---- slice groups, 8.2.2 (h264/slice.go:134-158 MbToSliceGroupMap, :457-529 MapUnitToSliceGroupMap, :530-552 nextMbAddress) ----
+func sliceGroupCycle(header *SliceHeader) C.int32_t {
+	if header == nil {
+		return 0
+	}
+	return C.int32_t(header.SliceGroupChangeCycle)
+}
+
+// MapUnitToSliceGroupMap: all seven map types (the reference stops at type 2).
+func MapUnitToSliceGroupMap(sps *SPS, pps *PPS, header *SliceHeader) []int {
+	buf := make([]byte, (sps.PicWidthInMbsMinus1+1)*(sps.PicHeightInMapUnitsMinus1+1))
+	if err := status(C.h264mi_map_unit_to_slice_group_map(&sps.c, &pps.c, bptr(pps.ids), C.size_t(len(pps.ids)), sliceGroupCycle(header), bptr(buf), C.size_t(len(buf)), nil)); err != nil {
+		logger.Printf("MapUnitToSliceGroupMap: %v", err)
+		return nil
+	}
+	out := make([]int, len(buf))
+	for i, v := range buf {
+		out[i] = int(v)
+	}
+	return out
+}
+
+func MbToSliceGroupMap(sps *SPS, pps *PPS, header *SliceHeader) []int {
+	field := 0
+	if header != nil && header.FieldPic != 0 {
+		field = 1
+	}
+	n := (sps.PicWidthInMbsMinus1 + 1) * (sps.PicHeightInMapUnitsMinus1 + 1)
+	if sps.FrameMbsOnly == 0 && field == 0 {
+		n *= 2
+	}
+	buf := make([]byte, n)
+	if err := status(C.h264mi_mb_to_slice_group_map(&sps.c, &pps.c, bptr(pps.ids), C.size_t(len(pps.ids)), sliceGroupCycle(header), C.int32_t(field), bptr(buf), C.size_t(len(buf)), nil)); err != nil {
+		logger.Printf("MbToSliceGroupMap: %v", err)
+		return nil
+	}
+	out := make([]int, len(buf))
+	for i, v := range buf {
+		out[i] = int(v)
+	}
+	return out
+}
+
+// nextMbAddress: the reference's signature (h264/slice.go:530); PicSizeInMbs when n is the last macroblock of its group.
+func nextMbAddress(n int, sps *SPS, pps *PPS, header *SliceHeader) int {
+	m := MbToSliceGroupMap(sps, pps, header)
+	i := n + 1
+	for i < len(m) && m[i] != m[n] {
+		i++
+	}
+	return i
 }
 
 // SliceHeader mirrors h264/slice.go:23-75 incl. the list-1 / direct / weighted-prediction fields of B slices (SliceHeaderFields).

@@ -147,7 +147,9 @@ def test_gpu_repeated_execute_is_idempotent(H, sg):
 
 
 @pytest.mark.parametrize("extra", [dict(frames=3), dict(frames=7, bframes=2, num_ref_frames=2, direct_temporal=1, weighted_bipred=2),
-                                   dict(frames=7, bframes=2, num_ref_frames=3, cabac=0, sub8x8_permille=400)])
+                                   dict(frames=7, bframes=2, num_ref_frames=3, cabac=0, sub8x8_permille=400),
+                                   dict(frames=4, profile_idc=66, cabac=0, slice_groups=4, fmo_type=6, slices=2, aso=1),
+                                   dict(frames=5, profile_idc=66, cabac=0, slice_groups=2, fmo_type=3, slices=2, aso=1)])
 def test_gpu_corrupt_streams_do_not_hang_or_crash(extra, H, sg):
     kw = dict(dict(width=176, height=144, frames=3, idr_period=0, profile_idc=77, cabac=1, seed=5), **extra)
     stream, _, _ = sg.encode(**kw)
@@ -336,6 +338,43 @@ def test_gpu_lost_and_broken_slices_leave_defined_pictures(H, sg, oracle_mod):
     assert np.array_equal(outs[0][0][1], rec[1])   # the next IDR picture is complete again
     yb = outs[0][1][0][:W * Hc].reshape(Hc, W)
     assert np.array_equal(yb[:48], ry[:48])        # stream 1: slice 0 intact, the cut slice 1 ends early somewhere
+
+
+def test_gpu_lost_slice_of_a_slice_group(H, sg):
+    """Slice groups scatter a slice over the picture, so its wavefront cannot blank a contiguous range for what it does not deliver:
+    the records of such a picture are zeroed before the entropy kernels run.  One of three slices (groups) of a dispersed map is
+    dropped, the buffers are poisoned first: the other two groups decode exactly (slice-edge deblocking is off), the lost
+    macroblocks -- every third one, staggered from row to row -- are mid-grey."""
+    kw = dict(width=176, height=144, frames=2, idr_period=1, profile_idc=66, cabac=0, slice_groups=3, fmo_type=1, seed=11, deblock_idc=2)
+    stream, rec, _ = sg.encode(**kw)
+    nals = H.read_nal_units(stream)
+    assert [n.Type for n in nals] == [7, 8, 5, 5, 5, 7, 8, 5, 5, 5]
+    offs = [n.Offset - 4 for n in nals] + [len(stream)]
+    lost = b"".join(stream[offs[i]:offs[i + 1]] for i in range(len(nals)) if i != 3)
+    sps = H.NewSPS(nals[0].RBSP())
+    pps = H.NewPPS(sps, nals[1].RBSP())
+    m = H.MbToSliceGroupMap(sps, pps).reshape(9, 11)
+    first = H.NewSliceContext(H.VideoStream(sps, pps), nals[3], nals[3].RBSP()).Slice.Header.FirstMbInSlice
+    gone = m[first // 11][first % 11]
+    dec = H.Decoder(max_streams=1, max_width=352, max_height=288, max_frames_per_batch=4, max_slices_per_frame=4)
+    dec.decode([sg.encode(width=352, height=288, frames=3, idr_period=0, profile_idc=77, cabac=1, seed=3)[0]])
+    _poison(H, dec)
+    dec.reset()
+    dec.decode([lost])
+    out = dec.read_frames(0, crop=False)
+    dec.close()
+    y, ry = out[0][:176 * 144].reshape(144, 176), rec[0][:176 * 144].reshape(144, 176)
+    n_gone = 0
+    for my in range(9):
+        for mx in range(11):
+            blk, rblk = y[my * 16:my * 16 + 16, mx * 16:mx * 16 + 16], ry[my * 16:my * 16 + 16, mx * 16:mx * 16 + 16]
+            if m[my][mx] == gone:
+                assert (blk == 128).all(), (mx, my)
+                n_gone += 1
+            else:
+                assert np.array_equal(blk, rblk), (mx, my)
+    assert n_gone == 33
+    assert np.array_equal(out[1], rec[1])  # the next IDR picture is complete again
 
 
 def test_gpu_isolation_keeps_other_streams_alive(H, sg, oracle_mod):
