@@ -512,6 +512,9 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
 extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab,
                                                                           const MbRec *mbrec, const int16_t *coefs) {
     __shared__ IntraShared sh;
+    __shared__ unsigned long long s_intra[MI_INTRA_MAX_ROWS][MI_INTRA_MAX_CHUNKS]; // sh.pend as pass 1 left it: which macroblocks K3 owns
+    __shared__ uint32_t s_prefix[MI_INTRA_MAX_ROWS + 1];                          // intra macroblocks in the rows before row r
+    __shared__ uint32_t s_next;
     const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6;
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
@@ -525,51 +528,99 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
     const int nchunks = (wmb + 63) >> 6;
     const MbRec *recs = mbrec + pd->mb_base;
     // ---- pass 1: intra masks of every row (one type byte per lane, ballot) ----
-    for (int mby = wave; mby < hmb; mby += MI_INTRA_WAVES)
+    for (int mby = wave; mby < hmb; mby += MI_INTRA_WAVES) {
+        uint32_t cnt = 0;
         for (int c = 0; c < nchunks; c++) {
             const int x = c * 64 + lane;
             const int t = x < wmb ? recs[static_cast<size_t>(mby) * wmb + x].type : -1;
             // macroblocks no slice delivered (type MBT_NONE) take the intra path too: it paints them mid-grey
             const unsigned long long m = __ballot(MB_IS_INTRA(t) || t == MBT_NONE);
-            if (lane == 0) sh.pend[mby][c] = m;
+            if (lane == 0) sh.pend[mby][c] = m, s_intra[mby][c] = m;
+            cnt += static_cast<uint32_t>(__builtin_popcountll(m));
         }
+        if (lane == 0) s_prefix[mby + 1] = cnt; // (a count for now)
+    }
+    if (tid == 0) s_prefix[0] = 0, s_next = 0;
     __syncthreads();
-    // ---- pass 2: wavefront w owns rows w, w+16, ...; left-to-right inside a row ----
+    if (tid == 0) // counts -> running sums (at most 320 rows)
+        for (int r = 1; r <= hmb; r++) s_prefix[r] += s_prefix[r - 1];
+    __syncthreads();
     IntraWave *ws = &sh.w[wave];
-    for (int mby = wave; mby < hmb; mby += MI_INTRA_WAVES) {
-        const MbRec *row = recs + static_cast<uint64_t>(mby) * wmb;
-        for (int c = 0; c < nchunks; c++) {
-            unsigned long long mask = sh.pend[mby][c]; // only this wavefront clears bits of this row
-            while (mask) {
-                const int k = __ffsll(static_cast<long long>(mask)) - 1;
-                mask &= mask - 1;
-                const int mbx = c * 64 + k;
-                if (lane < 32) reinterpret_cast<uint32_t *>(&ws->rec)[lane] = reinterpret_cast<const uint32_t *>(row + mbx)[lane];
-                WAVE_SYNC();
-                if (mby > 0) { // the intra macroblocks among (mbx-1 .. mbx+1, mby-1) must be done
-                    const int xl = max(mbx - 1, 0), xr = min(mbx + 1, wmb - 1);
-                    const int c0 = xl >> 6, c1 = xr >> 6;
-                    const unsigned long long span = ((xr - xl + 1) >= 64 ? ~0ull : ((1ull << (xr - xl + 1)) - 1));
-                    const unsigned long long m0 = span << (xl & 63), m1 = c1 != c0 ? span >> (64 - (xl & 63)) : 0ull;
-                    while ((__hip_atomic_load(&sh.pend[mby - 1][c0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & m0) ||
-                           (m1 && (__hip_atomic_load(&sh.pend[mby - 1][c1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & m1)))
-                        __builtin_amdgcn_s_sleep(1);
-                }
-                { // coefficient blocks of this macroblock: pool -> dense LDS layout (absent blocks are zero)
-                    const uint32_t cmask = ws->rec.coef_mask;
-                    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-                    if (lane < MI_COEF_BLOCKS && ((cmask >> lane) & 1)) {
-                        const uint4 *src = reinterpret_cast<const uint4 *>(coefs) + 2 * (static_cast<size_t>(ws->rec.coef_off) + __builtin_popcount(cmask & ((1u << lane) - 1u)));
-                        c0 = src[0], c1 = src[1];
-                    }
-                    if (lane < MI_COEF_BLOCKS) reinterpret_cast<uint4 *>(ws->coef)[2 * lane] = c0, reinterpret_cast<uint4 *>(ws->coef)[2 * lane + 1] = c1;
-                    WAVE_SYNC();
-                }
-                intra_mb<false>(lane, ws, &ws->rec, ws->coef, &sh.sc, py, pcb, pcr, W, mbx, mby);
-                // done: the release orders this wavefront's sample stores before the bit is cleared
-                if (lane == 0) __hip_atomic_fetch_and(&sh.pend[mby][c], ~(1ull << k), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // ---- pass 2 ----
+    // Dense pictures (I pictures): wavefront w owns rows w, w + MI_INTRA_WAVES, ...; left-to-right inside a row.
+    // Sparse pictures (the intra macroblocks of P / B pictures): dealt out one by one in raster order from a counter.  Rows hold
+    // very different numbers of them, so whole rows per wavefront leave most wavefronts idle behind the busiest; a macroblock only
+    // ever waits for macroblocks before it in raster order -- handed out earlier, to wavefronts that are running -- so nobody
+    // waits for work that has not started.  (Dense pictures would serialise on their left neighbours that way.)
+    const uint32_t n_intra = s_prefix[hmb];
+    const bool sparse = n_intra * 4u < static_cast<uint32_t>(wmb * hmb);
+    int row = wave, chunk = -1; // dense: the (row, chunk) whose remaining macroblocks are in `mask`
+    unsigned long long mask = 0;
+    for (;;) { // (one loop, so that the macroblock body is inlined once: twice costs 200 spilled registers)
+        int mbx, mby;
+        if (sparse) {
+            uint32_t n = 0;
+            if (lane == 0) n = atomicAdd(&s_next, 1u);
+            n = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(n)));
+            if (n >= n_intra) break;
+            int lo = 0, hi = hmb; // the row: prefix[lo] <= n < prefix[lo + 1]
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_prefix[mid] <= n) lo = mid; else hi = mid;
             }
+            uint32_t k = n - s_prefix[lo];
+            int c = 0;
+            for (; c < nchunks - 1; c++) {
+                const uint32_t pc = static_cast<uint32_t>(__builtin_popcountll(s_intra[lo][c]));
+                if (k < pc) break;
+                k -= pc;
+            }
+            const unsigned long long m = s_intra[lo][c];
+            const bool mine = ((m >> lane) & 1ull) && static_cast<uint32_t>(__builtin_popcountll(m & ((1ull << lane) - 1ull))) == k;
+            mbx = c * 64 + __builtin_ctzll(__builtin_amdgcn_ballot_w64(mine) | (1ull << 63)), mby = lo;
+        } else {
+            while (!mask) {
+                if (++chunk == nchunks) chunk = 0, row += MI_INTRA_WAVES;
+                if (row >= hmb) break;
+                mask = s_intra[row][chunk];
+            }
+            if (!mask) break;
+            mbx = chunk * 64 + __ffsll(static_cast<long long>(mask)) - 1, mby = row;
+            mask &= mask - 1;
         }
+        mbx = __builtin_amdgcn_readfirstlane(mbx), mby = __builtin_amdgcn_readfirstlane(mby); // (wave-uniform: say so, or every address below is per-ln arithmetic)
+        int ln = lane;
+        asm volatile("" : "+v"(ln)); // (keeps lane-dependent addresses of the body from being hoisted out of the loop and spilled)
+        // one macroblock: wait for the intra macroblocks it predicts from, reconstruct, publish
+        const int c = mbx >> 6, k = mbx & 63;
+        if (ln < 32) reinterpret_cast<uint32_t *>(&ws->rec)[ln] = reinterpret_cast<const uint32_t *>(recs + static_cast<uint64_t>(mby) * wmb + mbx)[ln];
+        WAVE_SYNC();
+        if (sparse && mbx > 0) { // (rows dealt out macroblock by macroblock: the left neighbour may be another wavefront's)
+            const unsigned long long bit = 1ull << ((mbx - 1) & 63);
+            while (__hip_atomic_load(&sh.pend[mby][(mbx - 1) >> 6], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) __builtin_amdgcn_s_sleep(1);
+        }
+        if (mby > 0) { // the intra macroblocks among (mbx-1 .. mbx+1, mby-1) must be done
+            const int xl = max(mbx - 1, 0), xr = min(mbx + 1, wmb - 1);
+            const int c0 = xl >> 6, c1 = xr >> 6;
+            const unsigned long long span = ((xr - xl + 1) >= 64 ? ~0ull : ((1ull << (xr - xl + 1)) - 1));
+            const unsigned long long m0 = span << (xl & 63), m1 = c1 != c0 ? span >> (64 - (xl & 63)) : 0ull;
+            while ((__hip_atomic_load(&sh.pend[mby - 1][c0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & m0) ||
+                   (m1 && (__hip_atomic_load(&sh.pend[mby - 1][c1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & m1)))
+                __builtin_amdgcn_s_sleep(1);
+        }
+        { // coefficient blocks of this macroblock: pool -> dense LDS layout (absent blocks are zero)
+            const uint32_t cmask = ws->rec.coef_mask;
+            uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+            if (ln < MI_COEF_BLOCKS && ((cmask >> ln) & 1)) {
+                const uint4 *src = reinterpret_cast<const uint4 *>(coefs) + 2 * (static_cast<size_t>(ws->rec.coef_off) + __builtin_popcount(cmask & ((1u << ln) - 1u)));
+                c0 = src[0], c1 = src[1];
+            }
+            if (ln < MI_COEF_BLOCKS) reinterpret_cast<uint4 *>(ws->coef)[2 * ln] = c0, reinterpret_cast<uint4 *>(ws->coef)[2 * ln + 1] = c1;
+            WAVE_SYNC();
+        }
+        intra_mb<false>(ln, ws, &ws->rec, ws->coef, &sh.sc, py, pcb, pcr, W, mbx, mby);
+        // done: the release orders this wavefront's sample stores before the bit is cleared
+        if (ln == 0) __hip_atomic_fetch_and(&sh.pend[mby][c], ~(1ull << k), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
@@ -634,7 +685,9 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(cons
                 mask &= mask - 1;
                 if (wpr > 1 && (nth++ % wpr) != turn) continue; // another wavefront's macroblock
                 const int mbx = c * 64 + k;
-                if (lane < 32) reinterpret_cast<uint32_t *>(&ws->rec)[lane] = reinterpret_cast<const uint32_t *>(row + mbx)[lane];
+                int ln = lane;
+                asm volatile("" : "+v"(ln)); // (keeps lane-dependent addresses of the body from being hoisted out of the loops and spilled)
+                if (ln < 32) reinterpret_cast<uint32_t *>(&ws->rec)[ln] = reinterpret_cast<const uint32_t *>(row + mbx)[ln];
                 WAVE_SYNC();
                 if (wpr > 1 && mbx > 0) { // the left neighbour, if it is an intra macroblock, belongs to another wavefront of this row
                     const int xl = mbx - 1;
@@ -651,16 +704,16 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(cons
                         while ((__hip_atomic_load(&sh.pend[mby - 1][c0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & m0) ||
                                (m1 && (__hip_atomic_load(&sh.pend[mby - 1][c1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & m1)))
                             __builtin_amdgcn_s_sleep(1);
-                    } else { // another workgroup's row: lane i watches the flag of column xl + i if that macroblock is an intra one
-                        const int col = xl + lane;
-                        const bool need = lane < 3 && col <= xr && ((sh.pend[mby - 1][col >> 6] >> (col & 63)) & 1ull);
+                    } else { // another workgroup's row: ln i watches the flag of column xl + i if that macroblock is an intra one
+                        const int col = xl + ln;
+                        const bool need = ln < 3 && col <= xr && ((sh.pend[mby - 1][col >> 6] >> (col & 63)) & 1ull);
                         const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
                         for (;;) {
                             const uint32_t v = need ? __hip_atomic_load(xin + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : epoch;
                             if (__builtin_amdgcn_ballot_w64(v != epoch) == 0) break;
                             __builtin_amdgcn_s_sleep(2);
                             if (__builtin_amdgcn_s_memrealtime() - t_start > 400000000ull) { // 4 s: report instead of hanging the GPU
-                                if (lane == 0) atomicExch(xstatus, 0x3D000000u | static_cast<uint32_t>(mby));
+                                if (ln == 0) atomicExch(xstatus, 0x3D000000u | static_cast<uint32_t>(mby));
                                 break;
                             }
                         }
@@ -670,19 +723,19 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(cons
                 {
                     const uint32_t cmask = ws->rec.coef_mask;
                     uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-                    if (lane < MI_COEF_BLOCKS && ((cmask >> lane) & 1)) {
-                        const uint4 *src = reinterpret_cast<const uint4 *>(coefs) + 2 * (static_cast<size_t>(ws->rec.coef_off) + __builtin_popcount(cmask & ((1u << lane) - 1u)));
+                    if (ln < MI_COEF_BLOCKS && ((cmask >> ln) & 1)) {
+                        const uint4 *src = reinterpret_cast<const uint4 *>(coefs) + 2 * (static_cast<size_t>(ws->rec.coef_off) + __builtin_popcount(cmask & ((1u << ln) - 1u)));
                         c0 = src[0], c1 = src[1];
                     }
-                    if (lane < MI_COEF_BLOCKS) reinterpret_cast<uint4 *>(ws->coef)[2 * lane] = c0, reinterpret_cast<uint4 *>(ws->coef)[2 * lane + 1] = c1;
+                    if (ln < MI_COEF_BLOCKS) reinterpret_cast<uint4 *>(ws->coef)[2 * ln] = c0, reinterpret_cast<uint4 *>(ws->coef)[2 * ln + 1] = c1;
                     WAVE_SYNC();
                 }
-                intra_mb<true>(lane, ws, &ws->rec, ws->coef, &sh.sc, py, pcb, pcr, W, mbx, mby);
+                intra_mb<true>(ln, ws, &ws->rec, ws->coef, &sh.sc, py, pcb, pcr, W, mbx, mby);
                 if (publish) { // every sample store of this wavefront has left the CU before the flag does
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0) __hip_atomic_store(xout + mbx, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (ln == 0) __hip_atomic_store(xout + mbx, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (lane == 0) __hip_atomic_fetch_and(&sh.pend[mby][c], ~(1ull << k), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (ln == 0) __hip_atomic_fetch_and(&sh.pend[mby][c], ~(1ull << k), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }

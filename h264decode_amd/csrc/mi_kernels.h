@@ -107,7 +107,7 @@ typedef struct {
 extern "C" __global__ void k_pack(const PackDesc *descs, uint8_t *dst, int rows_per_block);
 
 #ifndef MI_INTRA_WAVES
-#define MI_INTRA_WAVES 12 /* 768 threads: 170 VGPRs per wavefront (16 wavefronts would cap them at 128 and spill) */
+#define MI_INTRA_WAVES 16 /* 1024 threads, 128 VGPRs per wavefront: the kernels need 120 once nothing lane-dependent is hoisted out of the macroblock loop */
 #endif
 
 // K3 over several workgroups per picture: bands of about 4 macroblock rows, as many as keep pictures * bands within max_wgs;
