@@ -3,14 +3,16 @@
 // One slice per wavefront (one 64-thread workgroup per slice).  The arithmetic decoder is a
 // serial dependency chain, so the syntax-element code is written wave-uniformly: every lane
 // executes the same decision sequence, and the lanes fan out only for the wide work --
-//   * bitstream prefetch: 2 KB chunks of the slice RBSP are pulled into a 4 KB LDS ring with
-//     one 32-byte load per lane (coalesced 128-B requests);
-//   * context initialisation: 460 states copied from the (table-set, QP) row of DevTables;
-//   * neighbour caches: top-row / left-column state (modes, nnz, refs, mvs, |mvd|) lives in LDS;
+//   * bitstream: three VGPRs hold 192 consecutive RBSP words, one per lane, and feed a scalar 64-bit look-ahead through
+//     v_readlane; the window slides at macroblock boundaries (no LDS ring, no barrier);
+//   * context initialisation: the states of the (table set, QP) row of DevTables -- macroblock-level ones one per lane in
+//     two VGPRs, residual ones in LDS, gathered into a third VGPR per block category;
+//   * neighbour caches: left / row-above state (modes, nnz, refs, mvs, |mvd|) as 48-byte (B: 72-byte) TopInfo entries, the
+//     row above in global memory behind a two-entry LDS window;
 //   * write-out: the 128-byte MbRec and the coefficient blocks are assembled in LDS; the record leaves with
 //     one dword per lane, and only the 16-coefficient blocks that carry anything go to a packed per-pass pool.
-// CABAC engine state (codIRange, scaled codIOffset, lookahead count) is wave-uniform; context
-// states and a merged rangeTabLPS/transIdx table (one 8-byte LDS read per decision) sit in LDS.
+// CABAC engine state (codIRange, scaled codIOffset, lookahead count) is wave-uniform and lives on the vector side; Tables
+// 9-44 / 9-45 are per-lane tables read with v_readlane (Ent, below).
 //
 // Code-size discipline: the instruction cache is shared, and hundreds of slices run different parts
 // of this kernel at once, so every syntax routine is inlined exactly ONCE: residual blocks, motion

@@ -35,7 +35,7 @@ extern "C" {
 #define H264MI_OK 0
 #define H264MI_EINVAL (-1)      /* bad argument */
 #define H264MI_EBITSTREAM (-2)  /* malformed / truncated syntax */
-#define H264MI_EUNSUPPORTED (-3)/* valid H.264 outside the implemented scope (interlace, FMO, SP/SI slices, 4:4:4 ...) */
+#define H264MI_EUNSUPPORTED (-3)/* valid H.264 outside the implemented scope (field pictures / MBAFF, SP/SI slices, 4:4:4 ...) */
 #define H264MI_ENODEVICE (-4)   /* no usable HIP device / kernel image */
 #define H264MI_ENOMEM (-5)
 #define H264MI_EDEVICE (-6)     /* HIP runtime error */
