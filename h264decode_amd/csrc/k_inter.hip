@@ -508,13 +508,19 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
     }
 }
 
-extern "C" __global__ void __launch_bounds__(64) k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
+// Register budget: MI_K4_WAVES wavefronts per SIMD (512 / n VGPRs each).  The code needs 84 / 90 VGPRs (5 per SIMD); at 80 (6 per SIMD)
+// four registers spill and a launch of 256 pictures still takes 3 % less (1.02 -> 0.99 ms): the short wavefronts are latency-bound.
+#ifndef MI_K4_WAVES
+#define MI_K4_WAVES 6
+#endif
+#define MI_K4_OCC __attribute__((amdgpu_waves_per_eu(MI_K4_WAVES, MI_K4_WAVES)))
+extern "C" __global__ void __launch_bounds__(64) MI_K4_OCC k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
                                                          const int16_t *coefs, int groups_per_pic_log2, int n_blocks) {
     __shared__ InterLds lds[4];
     inter4<false>(lds, pic_list, pics, slices, tab, mbrec, coefs, groups_per_pic_log2, n_blocks, nullptr, nullptr);
 }
 // K4 for the pictures that have B slices: two lists per block (MbRec::refslot1, MbMv1), default / explicit / implicit weighting
-extern "C" __global__ void __launch_bounds__(64) k_inter_b(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
+extern "C" __global__ void __launch_bounds__(64) MI_K4_OCC k_inter_b(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
                                                            const int16_t *coefs, int groups_per_pic_log2, int n_blocks, const BSliceExt *bexts, const MbMv1 *mbmv1) {
     __shared__ InterLds lds[4];
     inter4<true>(lds, pic_list, pics, slices, tab, mbrec, coefs, groups_per_pic_log2, n_blocks, bexts, mbmv1);
