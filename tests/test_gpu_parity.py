@@ -340,6 +340,23 @@ def test_gpu_lost_and_broken_slices_leave_defined_pictures(H, sg, oracle_mod):
     assert np.array_equal(yb[:48], ry[:48])        # stream 1: slice 0 intact, the cut slice 1 ends early somewhere
 
 
+def test_gpu_slice_group_streams_share_a_batch_with_plain_ones(H, sg):
+    """A launch that holds ONE picture with slice groups runs the slice-group build of the entropy kernel for all its slices: plain
+    CABAC / CAVLC streams, a multi-slice one and two slice-group streams (explicit map with arbitrary slice order; evolving box-out) side
+    by side, in one workgroup per picture and banded."""
+    kws = [dict(width=176, height=144, frames=5, idr_period=0, profile_idc=77, cabac=1, seed=21),
+           dict(width=176, height=144, frames=5, idr_period=0, profile_idc=66, cabac=0, slice_groups=4, fmo_type=6, slices=2, aso=1, seed=22),
+           dict(width=176, height=144, frames=5, idr_period=0, profile_idc=100, cabac=1, transform8x8=1, slices=3, seed=23),
+           dict(width=176, height=144, frames=5, idr_period=0, profile_idc=66, cabac=0, slice_groups=2, fmo_type=3, aso=1, seed=24),
+           dict(width=176, height=144, frames=5, idr_period=0, profile_idc=66, cabac=0, seed=25)]
+    gen = [sg.encode(**kw) for kw in kws]
+    for x in (None, 0):
+        out, info = _decode_gpu(H, [g[0] for g in gen], 176, 144, 5, slices=8, x_wgs=x)
+        assert info.n_frames == 25
+        for i, g in enumerate(gen):
+            assert np.array_equal(out[i], g[1]), (i, x)
+
+
 def test_gpu_lost_slice_of_a_slice_group(H, sg):
     """Slice groups scatter a slice over the picture, so its wavefront cannot blank a contiguous range for what it does not deliver:
     the records of such a picture are zeroed before the entropy kernels run.  One of three slices (groups) of a dispersed map is
