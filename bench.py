@@ -33,7 +33,29 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+_GEN_TAG = None
+
+
+def _gen_tag():
+    """Identifies the generator build: cached streams are only valid for the sources that made them."""
+    global _GEN_TAG
+    if _GEN_TAG is None:
+        import hashlib
+        h = hashlib.md5()
+        d = os.path.join(ROOT, "streamgen")
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".c", ".h", ".py")):
+                h.update(open(os.path.join(d, f), "rb").read())
+        _GEN_TAG = h.hexdigest()[:12]
+    return _GEN_TAG
+
+
 def gen_stream(args):
+    """One synthetic input stream (not timed).  Generating 256 distinct 1080p GOPs costs minutes of host time, and the driver runs
+    this script several times on one node (N = 1, 2, 4, 8): the streams are kept in a scratch directory (H264MI_BENCH_CACHE,
+    default /tmp/h264mi_bench_cache; H264MI_BENCH_CACHE=off disables) keyed by recipe, seed and the generator's source hash."""
+    import hashlib
+    import pickle
     import streamgen
     seed, frames, width, height = args
     kw = streamgen.recipe("C3", frames=frames, idr_period=frames, seed=seed, width=width, height=height)
@@ -41,13 +63,32 @@ def gen_stream(args):
         kw["deblock_idc"] = int(os.environ["H264MI_BENCH_DBF"])
     if os.environ.get("H264MI_BENCH_INTRAP"):  # experiments only: share of intra macroblocks in P pictures (per mille)
         kw["intra_in_p_permille"] = int(os.environ["H264MI_BENCH_INTRAP"])
+    cdir = os.environ.get("H264MI_BENCH_CACHE", "/tmp/h264mi_bench_cache")
+    path = None
+    if cdir != "off":
+        key = hashlib.md5(repr(sorted(kw.items())).encode()).hexdigest()[:16]
+        path = os.path.join(cdir, "%s_%s.pkl" % (_gen_tag(), key))
+        try:
+            with open(path, "rb") as f:
+                return pickle.load(f)
+        except Exception:
+            pass
     s, rec, sizes = streamgen.encode(want_recon=True, **kw)
     # keep only what the parity gate needs (host memory: 256 x 30 x 3.1 MB otherwise): all frames of the first two
     # streams, the MD5 of every frame of the others
-    import hashlib
     if seed % 1000 >= 2:
         rec = [hashlib.md5(f.tobytes()).digest() for f in rec]
-    return s, rec, sizes
+    out = (s, rec, sizes)
+    if path:
+        try:
+            os.makedirs(cdir, exist_ok=True)
+            tmp = "%s.%d.tmp" % (path, os.getpid())
+            with open(tmp, "wb") as f:
+                pickle.dump(out, f, protocol=4)
+            os.replace(tmp, path)
+        except Exception:
+            pass  # a scratch directory that cannot be written is not an error
+    return out
 
 
 def timed_fps(dec, streams, n_frames, steps, warmup=1):
