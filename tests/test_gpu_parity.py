@@ -219,6 +219,20 @@ def test_gpu_720p_cavlc_intra(H, sg, oracle_mod):
         assert np.array_equal(out[0], rec), x
 
 
+@pytest.mark.parametrize("kw", [dict(slice_groups=6, fmo_type=1, slices=2), dict(slice_groups=8, fmo_type=6, aso=1), dict(slice_groups=2, fmo_type=3, slices=3, aso=1),
+                                dict(slice_groups=5, fmo_type=2, aso=1, interlace_sps=1, height=704)])
+def test_gpu_720p_slice_groups(kw, H, sg, oracle_mod):
+    """Slice groups at a size where a row is more than one 64-macroblock chunk (80 columns) and a slice visits thousands of scattered
+    macroblocks: GPU == oracle == generator, one workgroup per picture and banded."""
+    kw = dict(dict(width=1280, height=720, frames=3, idr_period=0, profile_idc=66, cabac=0, intra_in_p_permille=100, seed=31), **kw)
+    stream, rec, _ = sg.encode(**kw)
+    ref, _ = oracle_mod.decode(stream, crop=False)
+    assert np.array_equal(ref, rec)
+    for x in (None, 0):
+        out, _ = _decode_gpu(H, [stream], 1280, kw["height"], 3, slices=_nslices(kw), x_wgs=x)
+        assert np.array_equal(out[0], rec), x
+
+
 def test_gpu_4k_high_8_slices(H, sg):
     """BASELINE configs[3]: 3840x2160 High CABAC, 8x8 transform, 8 slices per picture (240 x 135 macroblocks: widest row
     state, 34 deblocking row groups in 3 rounds, slice boundaries inside and across macroblock rows)."""
