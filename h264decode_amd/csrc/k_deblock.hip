@@ -93,6 +93,8 @@ typedef __attribute__((address_space(1))) v2u g_uint2;
 #define GLD8(base, off) (*reinterpret_cast<const g_uint2 *>((base) + (off)))
 #define GST16(base, off, v) (*reinterpret_cast<g_uint4 *>((base) + (off)) = (v))
 #define GST8(base, off, v) (*reinterpret_cast<g_uint2 *>((base) + (off)) = (v))
+typedef __attribute__((address_space(1))) uint32_t g_uint1;
+#define GST4(base, off, v) (*reinterpret_cast<g_uint1 *>((base) + (off)) = (v))
 // keeps lane-dependent values from being hoisted out of the step loop (dozens of loop-invariant addresses would otherwise
 // live in registers for the whole kernel)
 #define OPAQUE(x) asm volatile("" : "+v"(x))
@@ -252,6 +254,31 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
 #endif
         const uint32_t yrow0 = static_cast<uint32_t>((row_ok ? mby : 0) * 16 + li) * W;                                   // this lane's luma row
         const uint32_t crow0 = (li < 8 ? cb_off : cr_off) + static_cast<uint32_t>((row_ok ? mby : 0) * 8 + (li & 7)) * Wc; // and chroma row
+#if MI_DB_BANDS
+        // Banded build: a launch that needs bands has few pictures, so HBM traffic is no concern and the chain's instruction count is
+        // everything -- a lane loads the 16 bytes of its row for the NEXT macroblock one step ahead and stores what a step
+        // finishes straight from the tile (the four columns the vertical pass just completed + this macroblock's first
+        // twelve), instead of moving whole 64-byte lines through four register slots (K5 proper, below): every line then moves four
+        // times, the slot bookkeeping -- a fifth of a step -- is gone.
+        v4u pre_y = z4;
+        v2u pre_c = z2;
+        v4u pre_rec = z4;
+        auto prefetch_mb = [&](int mbx) { // the lane's row of macroblock column mbx (of this lane's sub-row)
+            if (!row_ok || mbx < 0 || mbx >= wmb) return;
+            if (do_l) pre_y = GLD16(py, yrow0 + mbx * 16);
+            if (do_c) pre_c = GLD8(py, crow0 + mbx * 8);
+        };
+        auto prefetch_rec = [&](int mbx) { // lanes 0..4 of a sub-row: the five 16-byte pieces of the macroblock's DbPrm
+            if (!row_ok || mbx < 0 || mbx >= wmb || li >= 5) return;
+            pre_rec = reinterpret_cast<const v4u *>(prms + static_cast<uint32_t>(mby * wmb + mbx))[li];
+        };
+        const bool up_lane = li >= 13 && !last_row;        // luma: this lane stores a row of the macroblock above
+        const bool upc_lane = (li & 7) == 7 && !last_row;  // chroma: rows 7 store row -1 of the macroblock above
+        const bool y_stores = !up_lane || has_top, c_stores = !upc_lane || has_top; // up lanes of the first picture row have nothing above
+        const uint32_t yout = up_lane && has_top ? yrow0 - 16u * W : yrow0; // row li of the MB above = row li - 16
+        const uint32_t cout = upc_lane && has_top ? crow0 - 8u * Wc : crow0;
+        prefetch_mb(-sub);
+#else
         // Input registers.  Slot s of P / Pc holds macroblock column c with (c + sub) % 4 == s, so that at step t every
         // sub-row consumes slot t % 4 (a wave-uniform register index) although the sub-rows are one column apart.
         v4u P0 = z4, P1 = z4, P2 = z4, P3 = z4;
@@ -309,6 +336,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             }
         };
         prefetch_group(0);
+#endif
         prefetch_rec(-sub); // step 0 (only sub-row 0 is active)
         // the ring this group writes was last used by the group `reuse` groups earlier: that group's reader must be through with it
 #if !MI_DB_BANDS
@@ -334,14 +362,23 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             const int mbx = t - sub;
             const bool active = row_ok && mbx >= 0 && mbx < wmb;
             // this step's input registers (wave-uniform slot)
+#if MI_DB_BANDS
+            const v4u in_y = pre_y;
+            const v2u in_c = pre_c;
+#else
             const int ts = t & 3;
             const v4u in_y = ts == 0 ? P0 : (ts == 1 ? P1 : (ts == 2 ? P2 : P3));
             const v2u in_c = ts == 0 ? Q0 : (ts == 1 ? Q1 : (ts == 2 ? Q2 : Q3));
+#endif
             // ---- 1. the macroblock's DbPrm -> LDS -> this lane's strengths and filter parameters ----
             if (active && li < 5) reinterpret_cast<v4u *>(&ss->prm)[li] = pre_rec;
             WAVE_SYNC();
             STAMP(6);
+#if MI_DB_BANDS
+            prefetch_mb(mbx + 1);
+#else
             if (active && (mbx & 3) == 3) prefetch_group(mbx + 1); // the input registers of this sub-row are free again
+#endif
             prefetch_rec(mbx + 1);
             STAMP(7);
             // P*[0] luma, [1] chroma (plane li >> 3): bs = the strengths of this lane's segment of edges 0..3 (edge e in byte e; chroma:
@@ -557,6 +594,34 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                     cl4 = *reinterpret_cast<const uint32_t *>(crp);
                     cown = *reinterpret_cast<const v2u *>(crp + 4);
                 }
+#if MI_DB_BANDS
+                if (do_l && y_stores) {
+                    const uint32_t yb = yout + mbx * 16;
+                    if (up_lane)
+                        GST16(py, yb, own); // a row of the macroblock above: all 16 columns are final
+                    else {
+                        if (mbx > 0)
+                            GST16(py, yb - 4, (v4u{l4, own.x, own.y, own.z}));
+                        else {
+                            GST8(py, yb, (v2u{own.x, own.y}));
+                            GST4(py, yb + 8, own.z);
+                        }
+                        if (row_end) GST4(py, yb + 12, own.w); // no macroblock to the right: the last columns are final too
+                    }
+                }
+                if (do_c && c_stores) {
+                    const uint32_t cb = cout + mbx * 8;
+                    if (upc_lane)
+                        GST8(py, cb, cown);
+                    else {
+                        if (mbx > 0)
+                            GST8(py, cb - 4, (v2u{cl4, cown.x}));
+                        else
+                            GST4(py, cb, cown.x);
+                        if (row_end) GST4(py, cb + 4, cown.y);
+                    }
+                }
+#else
                 const int ps = (t + 3) & 3; // slot of the previous column
                 if (mbx > 0) {
                     if (!up_lane && do_l) {
@@ -574,6 +639,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                     if (ts == 0) S0 = cown; else if (ts == 1) S1 = cown; else if (ts == 2) S2 = cown; else S3 = cown;
                 }
                 if (row_end) flush(mbx & ~3, (mbx & 3) + 1); // no macroblock to the right: the last columns are final too
+#endif
                 if (last_row && has_top) { // the up lanes own rows 13..15 here: rows -3..-1 of the macroblock above go out directly
                     if (li < 3 && do_l)
                         GST16(py, static_cast<uint32_t>(mby * 16 - 3 + li) * W + mbx * 16, *reinterpret_cast<const v4u *>(&ss->y[1 + li][16]));
