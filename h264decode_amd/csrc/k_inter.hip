@@ -508,12 +508,14 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
     }
 }
 
-// Register budget: MI_K4_WAVES wavefronts per SIMD (512 / n VGPRs each).  The code needs 84 / 90 VGPRs (5 per SIMD); at 80 (6 per SIMD)
-// four registers spill and a launch of 256 pictures still takes 3 % less (1.02 -> 0.99 ms): the short wavefronts are latency-bound.
-#ifndef MI_K4_WAVES
-#define MI_K4_WAVES 6
-#endif
+// Register budget: the code needs 84 / 90 VGPRs (5 wavefronts per SIMD).  -DMI_K4_WAVES=6 forces 80: four registers spill, a launch of
+// 256 pictures takes 3 % less (1.02 -> 0.99 ms: the short wavefronts are latency-bound) but moves 0.47 GB of scratch traffic on top of
+// its 2.03 GB -- not worth it (tools/variant_k4.sh).
+#ifdef MI_K4_WAVES
 #define MI_K4_OCC __attribute__((amdgpu_waves_per_eu(MI_K4_WAVES, MI_K4_WAVES)))
+#else
+#define MI_K4_OCC
+#endif
 extern "C" __global__ void __launch_bounds__(64) MI_K4_OCC k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
                                                          const int16_t *coefs, int groups_per_pic_log2, int n_blocks) {
     __shared__ InterLds lds[4];
