@@ -333,6 +333,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the c5_share (32 streams per GPU) and single_stream (C3: 1 stream x 300 frames) measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--max-ref-frames", type=int, default=0, help="h264mi_config.max_ref_frames of the bench decoder (0 = the default of 16 reference slots per stream; "
+                    "the synthetic streams use 1: 4 would save 9.6 GB of the 151 GB)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous check only: every rank joins the process group, the closing all-reduce runs and rank 0 "
                                                            "prints n_gpus / ranks_seen; nothing is decoded (works without a GPU over gloo)")
     args = ap.parse_args()
@@ -401,7 +403,7 @@ def main():
 
     hip_stream = torch.cuda.current_stream().cuda_stream
     dec = H.Decoder(max_streams=S, max_width=W, max_height=Hc, max_frames_per_batch=F, max_slices_per_frame=1, device=local_rank,
-                    max_bitstream_bytes=int(sum(len(s) for s in streams) * 1.1) + (1 << 20), hip_stream=hip_stream)
+                    max_bitstream_bytes=int(sum(len(s) for s in streams) * 1.1) + (1 << 20), hip_stream=hip_stream, max_ref_frames=args.max_ref_frames)
     hbm_bytes = dec.device_bytes()
     # ---- stage 1: inputs -> HBM (not timed) ----
     tp = time.time()

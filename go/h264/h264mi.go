@@ -331,6 +331,7 @@ func NewSliceData(sc *SliceContext, d *Decoder, stream, frame int) ([]SliceData,
 type Config struct {
 	Device, MaxStreams, MaxWidth, MaxHeight, MaxFramesPerBatch, MaxSlicesPerFrame int
 	MaxBitstreamBytes                                                              int64
+	MaxRefFrames, CoefBlocksPerMb                                                  int // 0 = defaults (16 reference slots per stream, 8 residual blocks per macroblock)
 }
 type Decoder struct{ h *C.h264mi_decoder }
 type BatchInfo struct {
@@ -342,7 +343,8 @@ type BatchInfo struct {
 func NewDecoder(cfg Config) (*Decoder, error) {
 	c := C.h264mi_config{device: C.int32_t(cfg.Device), max_streams: C.int32_t(cfg.MaxStreams), max_width: C.int32_t(cfg.MaxWidth),
 		max_height: C.int32_t(cfg.MaxHeight), max_frames_per_batch: C.int32_t(cfg.MaxFramesPerBatch),
-		max_slices_per_frame: C.int32_t(cfg.MaxSlicesPerFrame), max_bitstream_bytes: C.int64_t(cfg.MaxBitstreamBytes)}
+		max_slices_per_frame: C.int32_t(cfg.MaxSlicesPerFrame), max_bitstream_bytes: C.int64_t(cfg.MaxBitstreamBytes),
+		max_ref_frames: C.int32_t(cfg.MaxRefFrames), coef_blocks_per_mb: C.int32_t(cfg.CoefBlocksPerMb)}
 	d := &Decoder{}
 	if err := status(C.h264mi_decoder_create(&c, &d.h)); err != nil {
 		return nil, err

@@ -374,7 +374,8 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     }
     // frame slots per stream: the outputs of the batch being prepared and of the one before it (still being read or executed:
     // MI_STAGES batches are in flight), up to 16 reference pictures, and the picture under construction
-    d->n_slots = MI_STAGES * cfg->max_frames_per_batch + MI_MAX_REFS + 1;
+    if (d->cfg.max_ref_frames < 1 || d->cfg.max_ref_frames > MI_MAX_REFS) d->cfg.max_ref_frames = MI_MAX_REFS;
+    d->n_slots = MI_STAGES * cfg->max_frames_per_batch + d->cfg.max_ref_frames + 1;
     d->slot_bytes = (static_cast<size_t>(d->Wmax) * d->Hmax * 3 / 2 + 255) & ~static_cast<size_t>(255);
     const int S = cfg->max_streams;
     d->st.resize(S);
@@ -470,6 +471,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
             const uint64_t worst = d->mb_cap * MI_COEF_BLOCKS + static_cast<uint64_t>(d->slices_cap + 1) * MI_COEF_CHUNK;
             uint64_t per_mb = 8;
             if (const char *e = getenv("H264MI_COEF_BLOCKS_PER_MB")) per_mb = static_cast<uint64_t>(std::min(std::max(atoi(e), 1), MI_COEF_BLOCKS));
+            if (d->cfg.coef_blocks_per_mb > 0) per_mb = static_cast<uint64_t>(std::min<int>(d->cfg.coef_blocks_per_mb, MI_COEF_BLOCKS));
             const uint64_t typical = std::max<uint64_t>(d->mb_cap * per_mb, (1ull << 30) / 32) + static_cast<uint64_t>(d->slices_cap + 1) * MI_COEF_CHUNK;
             d->pool_blocks = std::min<uint64_t>(std::min<uint64_t>(worst, typical), 0xFFFF0000ull);
             DEV_ALLOC(d->d_pool_head, sizeof(uint32_t) * MI_SETS);
@@ -997,6 +999,10 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
     if (!sps.frame_mbs_only && (sps.mb_adaptive_frame_field || sh.field_pic)) {
         set_error("stream %d: %s is out of scope", si, sh.field_pic ? "a field picture (PAFF)" : "macroblock-adaptive frame/field coding (MBAFF)");
         return H264MI_EUNSUPPORTED;
+    }
+    if (sps.max_num_ref_frames > d->cfg.max_ref_frames) {
+        set_error("stream %d: max_num_ref_frames %d exceeds the configured max_ref_frames %d", si, sps.max_num_ref_frames, d->cfg.max_ref_frames);
+        return H264MI_ECAPACITY;
     }
     const int wmb = sps.pic_width_in_mbs, hmb = sps.pic_height_in_mbs;
     if (wmb * 16 > d->Wmax || hmb * 16 > d->Hmax || hmb > 320) {

@@ -199,12 +199,13 @@ class Decoder:
     """Batched GPU decoder: N independent Annex-B streams side by side on one MI355X."""
 
     def __init__(self, max_streams=1, max_width=1920, max_height=1088, max_frames_per_batch=32, max_slices_per_frame=8, device=0,
-                 max_bitstream_bytes=0, hip_stream=None):
+                 max_bitstream_bytes=0, hip_stream=None, max_ref_frames=0, coef_blocks_per_mb=0):
         L = _lib.load()
         cfg = _lib.Config()
         cfg.device, cfg.max_streams, cfg.max_width, cfg.max_height = device, max_streams, max_width, max_height
         cfg.max_frames_per_batch, cfg.max_slices_per_frame, cfg.max_bitstream_bytes = max_frames_per_batch, max_slices_per_frame, max_bitstream_bytes
         cfg.hip_stream = hip_stream
+        cfg.max_ref_frames, cfg.coef_blocks_per_mb = max_ref_frames, coef_blocks_per_mb  # 0: defaults (16 reference slots, 8 blocks per macroblock)
         self._h = ctypes.c_void_p()
         check(L.h264mi_decoder_create(ctypes.byref(cfg), ctypes.byref(self._h)))
         self._L = L

@@ -174,6 +174,11 @@ typedef struct {
     int32_t max_slices_per_frame;
     int64_t max_bitstream_bytes;   /* per batch, summed over streams */
     void *hip_stream;              /* hipStream_t to launch on; NULL = a private stream */
+    /* Sizing knobs, 0 = default.  max_ref_frames: the largest max_num_ref_frames (h264/sps.go:61) the streams will carry; the frame
+     * pool holds that many reference slots per stream (default 16, the limit of any level; a 1080p slot is 3.1 MB per stream) and
+     * a stream that declares more is refused with H264MI_ECAPACITY.  coef_blocks_per_mb: residual pool size in 32-byte blocks per
+     * macroblock (default 8 of at most 26; see h264mi_decoder_coef_pool). */
+    int32_t max_ref_frames, coef_blocks_per_mb;
 } h264mi_config;
 
 typedef struct {

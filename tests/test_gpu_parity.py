@@ -244,6 +244,28 @@ def test_gpu_4k_high_8_slices(H, sg):
         assert np.array_equal(out[0], rec), x
 
 
+def test_gpu_sizing_knobs(H, sg):
+    """h264mi_config.max_ref_frames / coef_blocks_per_mb: a smaller frame pool and residual pool decode what fits, bit-exactly, and refuse
+    what does not with H264MI_ECAPACITY / a reported pool exhaustion -- never with a fault."""
+    kw = dict(width=176, height=144, frames=6, idr_period=0, profile_idc=77, cabac=1, num_ref_frames=2, seed=51)
+    stream, rec, _ = sg.encode(**kw)
+    big = H.Decoder(max_streams=1, max_width=176, max_height=144, max_frames_per_batch=6)
+    small = H.Decoder(max_streams=1, max_width=176, max_height=144, max_frames_per_batch=6, max_ref_frames=2)
+    assert small.device_bytes() < big.device_bytes()
+    assert big.device_bytes() - small.device_bytes() >= 14 * 176 * 144 * 3 // 2
+    small.decode([stream])
+    assert np.array_equal(small.read_frames(0, crop=False), rec)
+    used, cap = small.coef_pool()
+    assert 0 < used <= cap
+    big.close()
+    small.close()
+    tight = H.Decoder(max_streams=1, max_width=176, max_height=144, max_frames_per_batch=6, max_ref_frames=1)
+    with pytest.raises(H.H264MIError) as e:
+        tight.decode([stream])  # the SPS declares two reference frames
+    assert e.value.code == -7
+    tight.close()
+
+
 def test_gpu_rejects_out_of_scope_profile(H):
     """A third-party High 4:4:4 Predictive stream (chroma_format_idc 3) must be refused with a clear status, not mis-decoded."""
     import os
