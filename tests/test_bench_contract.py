@@ -1,0 +1,48 @@
+"""The bench line's contract (driver prompt, "Measurement"): the newest committed line under profiles/ carries every key the driver and
+the judge read, with consistent arithmetic -- checked on the CPU, so that a refactoring of bench.py cannot silently drop one."""
+import glob
+import json
+import os
+import re
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def _latest():
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")) if re.match(r"r\d+[a-z]?_bench\.json$", os.path.basename(f))]
+    assert files, "no bench line committed under profiles/"
+    return max(files, key=lambda f: re.match(r"r(\d+)([a-z]?)_bench", os.path.basename(f)).groups())
+
+
+def test_committed_bench_line_follows_the_contract():
+    d = json.load(open(_latest()))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == base.get("unit", d["unit"]) and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "u8"
+    assert d["vs_baseline"] is None  # BASELINE.md holds no published number for this metric
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # achieved = algorithmic bytes per launch / launch duration (both in the line)
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
+    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]  # counters cannot show less than the algorithm needs
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    # value is frames of the whole job over the step time
+    frames = d["config"]["frames_per_step_per_gpu"] * d["n_gpus"]
+    assert abs(d["value"] - frames / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.02
+    assert "bit-exact" in d["parity"]
+
+
+def test_bench_defaults_finish_in_minutes_by_construction():
+    """bench.py with no flags: N = 1 and small K / W (the driver's default invocation)."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    m = {k: int(v) for k, v in re.findall(r'add_argument\("--(gpus|steps|warmup)", type=int, default=(\d+)', src)}
+    assert m["gpus"] == 1 and 1 <= m["steps"] <= 20 and m["warmup"] <= 5
