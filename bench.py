@@ -123,72 +123,99 @@ def timed_fps(dec, streams, n_frames, steps, warmup=1):
 def extra_configs(H, streams, F, W, Hc, device, args):
     """The contract's own configurations next to `value`: C5's per-GPU share -- 32 distinct streams, one GOP
     each and 8 GOPs each -- and C3 proper: ONE stream of 300 frames.  Longer streams are concatenations of the 30-frame
-    GOP streams already generated (each starts with SPS + PPS + IDR, so the result is a valid multi-GOP stream)."""
+    GOP streams already generated (each starts with SPS + PPS + IDR, so the result is a valid multi-GOP stream).
+    A configuration that fails reports {"error": ...} under its key: the headline measurement has been taken by then and its
+    line must still be printed."""
+    import streamgen
     out = {}
     S = len(streams)
-    n32 = min(32, S)
-    gops = max(1, min(8, S // n32))
-    dec = H.Decoder(max_streams=n32, max_width=W, max_height=Hc, max_frames_per_batch=F * gops, max_slices_per_frame=1, device=device,
-                    max_bitstream_bytes=int(sum(len(s) for s in streams[:n32 * gops]) * 1.1) + (1 << 20))
-    r = timed_fps(dec, streams[:n32], n32 * F, steps=max(2, args.steps))
-    r["workload"] = "%d distinct streams x %d frames" % (n32, F)
-    out["c5_share"] = {"one_gop": r}
-    if gops > 1:
-        deep = [b"".join(streams[i * gops:(i + 1) * gops]) for i in range(n32)]
-        r = timed_fps(dec, deep, n32 * F * gops, steps=4)
-        r["workload"] = "%d distinct streams x %d frames (%d GOPs each)" % (n32, F * gops, gops)
-        out["c5_share"]["deep"] = r
-    dec.close()
-    del dec
-    g1 = max(1, min(10, S))
-    one = b"".join(streams[:g1])
-    dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=F * g1, max_slices_per_frame=1, device=device,
-                    max_bitstream_bytes=int(len(one) * 1.1) + (1 << 20))
-    r = timed_fps(dec, [one], F * g1, steps=6)  # (the first pass's entropy stage is not hidden behind a previous pass: amortise it)
-    r["workload"] = "C3: 1 stream x %d frames (%d GOPs)" % (F * g1, g1)
-    out["single_stream"] = r
-    dec.close()
-    del dec
-    # K4 on FRACTIONAL motion (SURVEY 8d C3 asks for quarter-sample vectors; the default scene moves whole samples): the same
-    # recipe with the scene moving (2.75, -1.5) samples per frame, 8 distinct streams replicated to the batch size of `value`
-    import streamgen
-    nf = 8
-    with ThreadPoolExecutor(max_workers=max(1, min(nf, (os.cpu_count() or 8) - 1))) as ex:
-        fgen = list(ex.map(lambda sd: streamgen.encode(want_recon=True, **streamgen.recipe("C3", frames=F, idr_period=F, seed=sd, width=W, height=args.height,
-                                                                                         motion_x4=11, motion_y4=-6)), range(2000, 2000 + nf)))
-    fstreams = [fgen[i % nf][0] for i in range(S)]
-    dec = H.Decoder(max_streams=S, max_width=W, max_height=Hc, max_frames_per_batch=F, max_slices_per_frame=1, device=device,
-                    max_bitstream_bytes=int(sum(len(s) for s in fstreams) * 1.1) + (1 << 20))
-    r = timed_fps(dec, fstreams, S * F, steps=max(2, min(args.steps, 5)))
-    got = dec.read_frames(S - 1, crop=False)
-    r["parity"] = "bit-exact vs streamgen recon (stream %d, all frames)" % (S - 1) if np.array_equal(got, fgen[(S - 1) % nf][1]) else "MISMATCH"
-    dec.set_profiling(True)
-    dec.execute()
-    dec.sync()
-    lt = np.array(dec.launch_times_ms("inter"))
-    dec.set_profiling(False)
-    fsz = W * Hc * 3 // 2
-    r["k_inter"] = {"ms": round(float(lt.mean()), 4), "GB/s": round(2.0 * fsz * S / (float(lt.mean()) * 1e-3) / 1e9, 2),
-                    "frac": round(2.0 * fsz * S / (float(lt.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-    r["workload"] = "%d streams (%d distinct) x %d frames, scene motion (2.75, -1.5) samples per frame: fractional vectors are the rule" % (S, nf, F)
-    out["fractional_motion"] = r
-    dec.close()
-    del dec
-    # B pictures (SURVEY 8f rank 1): the same recipe coded I B B P ... (two B pictures between the anchors, three reference
-    # frames, spatial direct), through k_entropy_b / k_inter_b / k_deblock_b.  16 distinct streams, each used twice.
-    nb = 16
-    with ThreadPoolExecutor(max_workers=max(1, min(nb, (os.cpu_count() or 8) - 1))) as ex:
-        gen = list(ex.map(lambda sd: streamgen.encode(want_recon=True, **dict(streamgen.recipe("C3", frames=F, idr_period=F, seed=sd, width=W, height=args.height),
-                                                                                  bframes=2, num_ref_frames=3, bskip_permille=300)), range(3000, 3000 + nb)))
-    bstreams = [g[0] for g in gen] * 2
-    dec = H.Decoder(max_streams=len(bstreams), max_width=W, max_height=Hc, max_frames_per_batch=F, max_slices_per_frame=1, device=device,
-                    max_bitstream_bytes=int(sum(len(s) for s in bstreams) * 1.1) + (1 << 20))
-    r = timed_fps(dec, bstreams, len(bstreams) * F, steps=max(2, args.steps))
-    got = dec.read_frames(nb + 1, crop=False)
-    r["parity"] = "bit-exact vs streamgen recon (stream %d, all frames)" % (nb + 1) if np.array_equal(got, gen[1][1]) else "MISMATCH"
-    r["workload"] = "%d streams (%d distinct) x %d frames, I B B P coding order, 3 reference frames" % (len(bstreams), nb, F)
-    out["b_pictures"] = r
-    dec.close()
+
+    def guarded(key, fn):
+        try:
+            out[key] = fn()
+        except Exception as e:  # noqa: BLE001 -- reported in the line, not swallowed
+            out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+    def c5_share():
+        n32 = min(32, S)
+        gops = max(1, min(8, S // n32))
+        dec = H.Decoder(max_streams=n32, max_width=W, max_height=Hc, max_frames_per_batch=F * gops, max_slices_per_frame=1, device=device,
+                        max_bitstream_bytes=int(sum(len(s) for s in streams[:n32 * gops]) * 1.1) + (1 << 20))
+        try:
+            r = timed_fps(dec, streams[:n32], n32 * F, steps=max(2, args.steps))
+            r["workload"] = "%d distinct streams x %d frames" % (n32, F)
+            res = {"one_gop": r}
+            if gops > 1:
+                deep = [b"".join(streams[i * gops:(i + 1) * gops]) for i in range(n32)]
+                r = timed_fps(dec, deep, n32 * F * gops, steps=4)
+                r["workload"] = "%d distinct streams x %d frames (%d GOPs each)" % (n32, F * gops, gops)
+                res["deep"] = r
+            return res
+        finally:
+            dec.close()
+
+    def single_stream():
+        g1 = max(1, min(10, S))
+        one = b"".join(streams[:g1])
+        dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=F * g1, max_slices_per_frame=1, device=device,
+                        max_bitstream_bytes=int(len(one) * 1.1) + (1 << 20))
+        try:
+            r = timed_fps(dec, [one], F * g1, steps=6)  # (the first pass's entropy stage is not hidden behind a previous pass: amortise it)
+            r["workload"] = "C3: 1 stream x %d frames (%d GOPs)" % (F * g1, g1)
+            return r
+        finally:
+            dec.close()
+
+    def fractional_motion():
+        # K4 on FRACTIONAL motion (SURVEY 8d C3 asks for quarter-sample vectors; the default scene moves whole samples): the same
+        # recipe with the scene moving (2.75, -1.5) samples per frame, 8 distinct streams replicated to the batch size of `value`
+        nf = 8
+        with ThreadPoolExecutor(max_workers=max(1, min(nf, (os.cpu_count() or 8) - 1))) as ex:
+            fgen = list(ex.map(lambda sd: streamgen.encode(want_recon=True, **streamgen.recipe("C3", frames=F, idr_period=F, seed=sd, width=W, height=args.height,
+                                                                                             motion_x4=11, motion_y4=-6)), range(2000, 2000 + nf)))
+        fstreams = [fgen[i % nf][0] for i in range(S)]
+        dec = H.Decoder(max_streams=S, max_width=W, max_height=Hc, max_frames_per_batch=F, max_slices_per_frame=1, device=device,
+                        max_bitstream_bytes=int(sum(len(s) for s in fstreams) * 1.1) + (1 << 20))
+        try:
+            r = timed_fps(dec, fstreams, S * F, steps=max(2, min(args.steps, 5)))
+            got = dec.read_frames(S - 1, crop=False)
+            r["parity"] = "bit-exact vs streamgen recon (stream %d, all frames)" % (S - 1) if np.array_equal(got, fgen[(S - 1) % nf][1]) else "MISMATCH"
+            dec.set_profiling(True)
+            dec.execute()
+            dec.sync()
+            lt = np.array(dec.launch_times_ms("inter"))
+            dec.set_profiling(False)
+            fsz = W * Hc * 3 // 2
+            r["k_inter"] = {"ms": round(float(lt.mean()), 4), "GB/s": round(2.0 * fsz * S / (float(lt.mean()) * 1e-3) / 1e9, 2),
+                            "frac": round(2.0 * fsz * S / (float(lt.mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            r["workload"] = "%d streams (%d distinct) x %d frames, scene motion (2.75, -1.5) samples per frame: fractional vectors are the rule" % (S, nf, F)
+            return r
+        finally:
+            dec.close()
+
+    def b_pictures():
+        # B pictures (SURVEY 8f rank 1): the same recipe coded I B B P ... (two B pictures between the anchors, three reference
+        # frames, spatial direct), through k_entropy_b / k_inter_b.  16 distinct streams, each used twice.
+        nb = 16
+        with ThreadPoolExecutor(max_workers=max(1, min(nb, (os.cpu_count() or 8) - 1))) as ex:
+            gen = list(ex.map(lambda sd: streamgen.encode(want_recon=True, **dict(streamgen.recipe("C3", frames=F, idr_period=F, seed=sd, width=W, height=args.height),
+                                                                                      bframes=2, num_ref_frames=3, bskip_permille=300)), range(3000, 3000 + nb)))
+        bstreams = [g[0] for g in gen] * 2
+        dec = H.Decoder(max_streams=len(bstreams), max_width=W, max_height=Hc, max_frames_per_batch=F, max_slices_per_frame=1, device=device,
+                        max_bitstream_bytes=int(sum(len(s) for s in bstreams) * 1.1) + (1 << 20))
+        try:
+            r = timed_fps(dec, bstreams, len(bstreams) * F, steps=max(2, args.steps))
+            got = dec.read_frames(nb + 1, crop=False)
+            r["parity"] = "bit-exact vs streamgen recon (stream %d, all frames)" % (nb + 1) if np.array_equal(got, gen[1][1]) else "MISMATCH"
+            r["workload"] = "%d streams (%d distinct) x %d frames, I B B P coding order, 3 reference frames" % (len(bstreams), nb, F)
+            return r
+        finally:
+            dec.close()
+
+    guarded("c5_share", c5_share)
+    guarded("single_stream", single_stream)
+    guarded("fractional_motion", fractional_motion)
+    guarded("b_pictures", b_pictures)
     return out
 
 
