@@ -2270,6 +2270,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
     if (p->num_ref_frames < 1) p->num_ref_frames = 1;
     if (p->num_ref_frames > 4) p->num_ref_frames = 4;
     if (p->slices < 1) p->slices = 1;
+    if (p->fn_gap_period > 0 && p->num_ref_frames < 3) p->num_ref_frames = 3; /* up to two non-existing frames enter the window: a real picture must survive them */
     if (p->profile_idc != 100) p->transform8x8 = 0, p->scaling_matrix = 0;
     if (p->profile_idc == 66) p->cabac = 0, p->weighted_pred = 0, p->bframes = 0;
     if (p->bframes > 0) { /* B pictures: two anchors must be referable, and the output order differs from the coding order */
@@ -2277,6 +2278,8 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         p->poc_type = 0, p->nonref_period = 0, p->mmco = 0, p->idr_long_term = 0;
         if (p->bframes > 3) p->bframes = 3;
         if (p->bframes < 2) p->b_pyramid = 0;
+        /* the coding-order planner below puts an anchor every (bframes + 1) pictures: an IDR picture must be one of them */
+        if (p->idr_period > 0 && p->idr_period % (p->bframes + 1)) p->idr_period += (p->bframes + 1) - p->idr_period % (p->bframes + 1);
         if (p->b_pyramid) p->num_ref_frames = 4; /* two anchors, the reference B picture of this group and the one of the group before */
     } else
         p->b_pyramid = 0;

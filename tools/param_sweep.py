@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised sweep over the generator's feature space (not a test: a bug hunt).  Every trial draws a stream recipe -- profile, entropy
+coder, slices, slice groups, references, picture management, B pictures, weights, motion, sizes -- and compares decoder output with the
+generator's reconstruction bit for bit.  Usage: param_sweep.py [trials] [--gpu] [--seed N]
+  without --gpu: the oracle (CPU);  with --gpu: the product through the C ABI, one workgroup per picture and banded."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import streamgen
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+N = int(args[0]) if args else 100
+GPU = "--gpu" in sys.argv
+seed0 = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 1
+rng = np.random.default_rng(seed0)
+
+
+def draw():
+    r = lambda lo, hi: int(rng.integers(lo, hi + 1))
+    pick = lambda *xs: xs[int(rng.integers(0, len(xs)))]
+    prof = pick(66, 77, 77, 100, 100)
+    kw = dict(width=16 * r(2, 13) - pick(0, 0, 4, 10), height=16 * r(2, 10) - pick(0, 0, 2, 6), frames=r(2, 9), profile_idc=prof, seed=r(1, 1 << 20),
+              qp=r(10, 44), qp_jitter=pick(0, 0, 2, 5), idr_period=pick(0, 0, 1, 3, 5), slices=pick(1, 1, 2, 3), num_ref_frames=r(1, 4),
+              deblock_idc=pick(0, 0, 1, 2), alpha_off_div2=r(-3, 3), beta_off_div2=r(-3, 3), constrained_intra=pick(0, 0, 1), chroma_qp_offset=r(-4, 4),
+              pcm_permille=pick(0, 0, 20), intra_in_p_permille=pick(20, 50, 200), skip_permille=pick(100, 250, 500), sub8x8_permille=pick(50, 100, 400),
+              noise=pick(2, 8, 20), long_start_code=pick(0, 1), motion_x4=r(-20, 20), motion_y4=r(-20, 20), slice_qp_delta=pick(0, 0, 3))
+    kw["cabac"] = 0 if prof == 66 else pick(0, 1, 1)
+    if kw["cabac"]:
+        kw["cabac_init_idc"] = pick(-1, 0, 1, 2)
+    if prof == 100:
+        kw["transform8x8"], kw["scaling_matrix"] = pick(0, 1, 1), pick(0, 1)
+    if prof != 66:
+        kw["weighted_pred"] = pick(0, 0, 1, 2)
+        if rng.random() < 0.4 and kw["frames"] >= 4:
+            kw.update(bframes=r(1, 3), direct_temporal=pick(0, 1), weighted_bipred=pick(0, 1, 2), bskip_permille=pick(100, 300), b_pyramid=pick(0, 1))
+            kw["num_ref_frames"] = max(kw["num_ref_frames"], 2)
+    if not kw.get("bframes"):
+        kw["poc_type"] = pick(0, 0, 1, 2)
+        kw["rplm"], kw["mmco"], kw["idr_long_term"] = pick(0, 0, 1), pick(0, 0, 1), pick(0, 0, 1)
+        kw["nonref_period"] = pick(0, 0, 3)
+        if not (kw["rplm"] or kw["mmco"] or kw["idr_long_term"] or kw["nonref_period"]) and rng.random() < 0.3:
+            kw.update(fn_gap_period=r(2, 4), fn_gap_declared=1)
+    if rng.random() < 0.3:
+        kw.update(slice_groups=r(2, 6), fmo_type=r(0, 6), aso=pick(0, 1))
+        kw["slices"] = min(kw["slices"], 2)
+    elif kw["slices"] > 1:
+        kw["aso"] = pick(0, 1)
+    if rng.random() < 0.15:
+        kw["interlace_sps"] = 1
+        kw["height"] = max(32, (kw["height"] + 31) // 32 * 32 - pick(0, 4, 8))
+    return kw
+
+
+if GPU:
+    import h264decode_amd as H
+else:
+    import oracle
+bad = 0
+t0 = time.time()
+for t in range(N):
+    kw = draw()
+    try:
+        s, rec, _ = streamgen.encode(**kw)
+    except RuntimeError as e:
+        print("trial %d: generator refused %s (%s)" % (t, kw, e))
+        continue
+    W, Hc = (kw["width"] + 15) // 16 * 16, (kw["height"] + 15) // 16 * 16
+    ok = True
+    try:
+        if GPU:
+            nsl = max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1))
+            for x in ("256", "0"):
+                os.environ["H264MI_X_WGS"] = x
+                dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=kw["frames"], max_slices_per_frame=nsl)
+                dec.decode([s])
+                out = dec.read_frames(0, crop=False)
+                dec.close()
+                ok = ok and out.shape == rec.shape and np.array_equal(out, rec)
+        else:
+            out, _ = oracle.decode(s, crop=False)
+            ok = out.shape == rec.shape and np.array_equal(out, rec)
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        print("trial %d: %s" % (t, repr(e)[:300]))
+    if not ok:
+        bad += 1
+        print("MISMATCH trial %d: %s" % (t, kw), flush=True)
+    if (t + 1) % 25 == 0:
+        print("trial %d, %d mismatches, %.1fs" % (t + 1, bad, time.time() - t0), flush=True)
+print("sweep %s: %d trials, %d mismatches" % ("GPU" if GPU else "oracle", N, bad))
+sys.exit(1 if bad else 0)
