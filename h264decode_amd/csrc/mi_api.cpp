@@ -129,7 +129,7 @@ struct StreamState {
     h264mi_sps sps[32];
     h264mi_pps pps[256];
     std::vector<uint8_t> sg_ids[256]; // slice_group_id[] of the PPSs with slice_group_map_type 6 (h264/pps.go:23)
-    bool cur_has_mb0 = false;          // a slice with first_mb_in_slice 0 has been seen in the current picture
+    std::vector<int32_t> cur_first_mbs; // first_mb_in_slice of the slices of the current picture
     bool sps_ok[32] = {}, pps_ok[256] = {};
     int active_sps = -1;
     int wmb = 0, hmb = 0;
@@ -1009,9 +1009,12 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         set_error("stream %d: %dx%d exceeds the configured maximum %dx%d", si, wmb * 16, hmb * 16, d->Wmax, d->Hmax);
         return H264MI_ECAPACITY;
     }
-    // (a second slice that starts at macroblock 0 begins a new picture whatever the headers say; with arbitrary slice order the
-    // first one may come late)
-    if (s.cur_slot >= 0 && ((sh.first_mb_in_slice == 0 && s.cur_has_mb0) || new_picture(sps, s.first_sh, sh))) finish_picture(d, si);
+    // (7.4.1.2.4 cannot tell two pictures apart whose headers agree -- e.g. POC type 2 and the frame_num 1 that follows a memory
+    // management operation 5 in a picture with frame_num 1 --: a slice that starts where a slice of the current picture already
+    // started begins a new picture whatever the headers say.  Not "first_mb_in_slice == 0": with slice groups or arbitrary slice
+    // order that slice may come late.)
+    const bool restarts = std::find(s.cur_first_mbs.begin(), s.cur_first_mbs.end(), sh.first_mb_in_slice) != s.cur_first_mbs.end();
+    if (s.cur_slot >= 0 && (restarts || new_picture(sps, s.first_sh, sh))) finish_picture(d, si);
     if (s.active_sps != pps.sps_id || s.wmb != wmb || s.hmb != hmb) { // (re)activate: new sequence geometry
         if (sh.nal_unit_type != 5 && s.active_sps >= 0 && (s.wmb != wmb || s.hmb != hmb)) {
             set_error("stream %d: picture size changes without an IDR", si);
@@ -1040,7 +1043,7 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         s.cur_slot = slot;
         s.cur_pic = g.n_pics++;
         s.cur_slices = 0;
-        s.cur_has_mb0 = false;
+        s.cur_first_mbs.clear();
         s.first_sh = sh;
         Slot &sl = s.slots[slot];
         sl = Slot();
@@ -1097,7 +1100,7 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         return H264MI_ECAPACITY;
     }
     if (sh.first_mb_in_slice >= wmb * hmb) return H264MI_EBITSTREAM;
-    if (sh.first_mb_in_slice == 0) s.cur_has_mb0 = true;
+    s.cur_first_mbs.push_back(sh.first_mb_in_slice);
     PicDesc &pd = g.h_pics[s.cur_pic];
     SliceDesc &sd = g.h_slices[g.n_slices];
     memset(&sd, 0, sizeof(sd));

@@ -443,7 +443,7 @@ static int start_picture(h264o_decoder *d) {
     memset(p->plane[0], 128, (size_t)d->wmb * 16 * d->hmb * 16 * 3 / 2);
     d->first_sh = d->sh;
     d->slice_id = 0;
-    d->pic_has_mb0 = 0;
+    d->n_first_mbs = 0;
     /* slice groups: the macroblock-to-slice-group map of this picture (8.2.2; h264/slice.go:134-158) */
     free(d->sgmap);
     d->sgmap = NULL;
@@ -464,9 +464,12 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
     if (sh.slice_type > 2) return h264o_fail(d, "slice_type %d out of scope (I, P and B only)", sh.slice_type);
     if (sh.redundant_pic_cnt > 0) return 0; /* redundant coded pictures are ignored */
     const h264o_pps *pps = &d->pps[sh.pic_parameter_set_id];
-    /* (a second slice that starts at macroblock 0 begins a new picture whatever the headers say; with arbitrary slice order the
-     * first one may come late) */
-    if (d->cur && ((sh.first_mb_in_slice == 0 && d->pic_has_mb0) || is_new_picture(d, &d->first_sh, &sh))) finish_picture(d);
+    /* (a slice that starts where a slice of the current picture already started begins a new picture whatever the headers say:
+     * 7.4.1.2.4 cannot separate pictures whose headers agree, e.g. POC type 2 and equal frame_num after operation 5; with slice
+     * groups or arbitrary slice order the slice of macroblock 0 may come late, so that one alone is no criterion) */
+    int restarts = 0;
+    for (int i = 0; i < d->n_first_mbs; i++) restarts |= d->first_mbs[i] == sh.first_mb_in_slice;
+    if (d->cur && (restarts || is_new_picture(d, &d->first_sh, &sh))) finish_picture(d);
     if (activate(d, pps) < 0) return -1;
     d->sh = sh;
     if (sh.slice_qp_delta) d->feat |= 1u << 13;
@@ -476,7 +479,7 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
         d->slice_id++;
     if (sh.slice_type != 2 && build_ref_list(d) < 0) return -1;
     if (sh.first_mb_in_slice >= d->wmb * d->hmb) return h264o_fail(d, "first_mb_in_slice out of range");
-    if (sh.first_mb_in_slice == 0) d->pic_has_mb0 = 1;
+    if (d->n_first_mbs < 1024) d->first_mbs[d->n_first_mbs++] = sh.first_mb_in_slice;
     return h264o_decode_slice_data(d) < 0 ? -1 : 0;
 }
 

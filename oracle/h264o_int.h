@@ -62,7 +62,7 @@ struct h264o_decoder {
     h264o_pps pps[256];
     uint8_t *sg_ids[256]; /* slice_group_id[] of the PPSs with slice_group_map_type 6 */
     uint8_t *sgmap;       /* mbToSliceGroupMap of the current picture (NULL: one slice group) */
-    int pic_has_mb0;      /* a slice with first_mb_in_slice 0 has been seen in the current picture */
+    int first_mbs[1024], n_first_mbs; /* first_mb_in_slice of the slices of the current picture */
     const h264o_sps *asps;
     const h264o_pps *apps;
     int wmb, hmb;

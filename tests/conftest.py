@@ -84,6 +84,12 @@ MATRIX = {
     "fmo_interlace_sps": dict(width=176, height=160, frames=4, idr_period=0, profile_idc=66, cabac=0, interlace_sps=1, slice_groups=3, fmo_type=1, seed=98),
     "fmo_explicit_cabac_b": dict(BASE, frames=7, profile_idc=77, cabac=1, slice_groups=3, fmo_type=6, aso=1, bframes=2, num_ref_frames=3, seed=99),
     "aso_only": dict(BASE, profile_idc=66, cabac=0, slices=4, aso=1, deblock_idc=2, intra_in_p_permille=150, seed=90),
+    # found by tools/param_sweep.py: POC type 2, and a picture with frame_num 1 that carries memory management operation 5 -- the next picture has
+    # frame_num 1 again, nothing in 7.4.1.2.4 separates the two, and with foreground slice groups the slice of macroblock 0 is not the first one
+    "fmo_mmco5_equal_frame_num": dict(width=156, height=48, frames=6, profile_idc=77, seed=301113, qp=26, qp_jitter=2, idr_period=5, slices=2, num_ref_frames=2,
+                                      constrained_intra=1, sub8x8_permille=400, noise=20, long_start_code=0, motion_x4=12, motion_y4=2, cabac=1, cabac_init_idc=-1,
+                                      weighted_pred=2, poc_type=2, mmco=1, idr_long_term=1, slice_groups=3, fmo_type=2, alpha_off_div2=-1, beta_off_div2=3,
+                                      skip_permille=100),
     "cavlc_I": dict(width=64, height=48, frames=2, idr_period=1, profile_idc=66, cabac=0),
     "cabac_I": dict(width=64, height=48, frames=2, idr_period=1, profile_idc=77, cabac=1),
     "cavlc_IPP": dict(BASE, profile_idc=66, cabac=0, qp=24),
