@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised sweep over the generator's feature space (not a test: a bug hunt).  Every trial draws a stream recipe -- profile, entropy
 coder, slices, slice groups, references, picture management, B pictures, weights, motion, sizes -- and compares decoder output with the
-generator's reconstruction bit for bit.  Usage: param_sweep.py [trials] [--gpu] [--seed N]
-  without --gpu: the oracle (CPU);  with --gpu: the product through the C ABI, one workgroup per picture and banded."""
+generator's reconstruction bit for bit.  Usage: param_sweep.py [trials] [--gpu] [--seed N] [--batch B]
+  without --gpu: the oracle (CPU);  with --gpu: the product through the C ABI, one workgroup per picture and banded;
+  --batch B (GPU): B streams of different recipes and sizes side by side in one decoder per trial."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -12,6 +13,8 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 N = int(args[0]) if args else 100
 GPU = "--gpu" in sys.argv
 seed0 = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 1
+BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1
+args = [a for a in args if a not in (str(seed0), str(BATCH))] or args[:1]
 rng = np.random.default_rng(seed0)
 
 
@@ -57,7 +60,7 @@ else:
     import oracle
 bad = 0
 t0 = time.time()
-for t in range(N):
+for t in range(N if BATCH == 1 else 0):
     kw = draw()
     try:
         s, rec, _ = streamgen.encode(**kw)
@@ -85,6 +88,37 @@ for t in range(N):
     if not ok:
         bad += 1
         print("MISMATCH trial %d: %s" % (t, kw), flush=True)
+    if (t + 1) % 25 == 0:
+        print("trial %d, %d mismatches, %.1fs" % (t + 1, bad, time.time() - t0), flush=True)
+for t in range(N if BATCH > 1 else 0):  # several streams per decoder
+    kws, gen = [], []
+    while len(gen) < BATCH:
+        kw = draw()
+        try:
+            gen.append(streamgen.encode(**kw))
+            kws.append(kw)
+        except RuntimeError:
+            pass
+    W = max((kw["width"] + 15) // 16 * 16 for kw in kws)
+    Hc = max((kw["height"] + 15) // 16 * 16 for kw in kws)
+    ok = True
+    try:
+        for x in ("256", "0"):
+            os.environ["H264MI_X_WGS"] = x
+            dec = H.Decoder(max_streams=BATCH, max_width=W, max_height=Hc, max_frames_per_batch=max(kw["frames"] for kw in kws),
+                            max_slices_per_frame=max(max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1)) for kw in kws))
+            dec.decode([g[0] for g in gen])
+            for i, (kw, g) in enumerate(zip(kws, gen)):
+                w, h = (kw["width"] + 15) // 16 * 16, (kw["height"] + 15) // 16 * 16
+                out = dec.read_frames(i, crop=False, size=w * h * 3 // 2)
+                if out.shape != g[1].shape or not np.array_equal(out, g[1]):
+                    ok = False
+                    print("MISMATCH trial %d stream %d (x_wgs %s): %s" % (t, i, x, kw), flush=True)
+            dec.close()
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        print("trial %d: %s\n  %s" % (t, repr(e)[:300], kws), flush=True)
+    bad += not ok
     if (t + 1) % 25 == 0:
         print("trial %d, %d mismatches, %.1fs" % (t + 1, bad, time.time() - t0), flush=True)
 print("sweep %s: %d trials, %d mismatches" % ("GPU" if GPU else "oracle", N, bad))
