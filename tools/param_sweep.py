@@ -3,7 +3,9 @@
 coder, slices, slice groups, references, picture management, B pictures, weights, motion, sizes -- and compares decoder output with the
 generator's reconstruction bit for bit.  Usage: param_sweep.py [trials] [--gpu] [--seed N] [--batch B]
   without --gpu: the oracle (CPU);  with --gpu: the product through the C ABI, one workgroup per picture and banded;
-  --batch B (GPU): B streams of different recipes and sizes side by side in one decoder per trial."""
+  --batch B (GPU): B streams of different recipes and sizes side by side in one decoder per trial;
+  --split (GPU): every stream is fed in several calls, a random number of access units at a time (state that must survive a batch boundary:
+  reference pictures and their marking, picture order counts, co-located motion, frame_num gap bookkeeping, parameter sets)."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -14,6 +16,7 @@ N = int(args[0]) if args else 100
 GPU = "--gpu" in sys.argv
 seed0 = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 1
 BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1
+SPLIT = "--split" in sys.argv
 args = [a for a in args if a not in (str(seed0), str(BATCH))] or args[:1]
 rng = np.random.default_rng(seed0)
 
@@ -63,7 +66,7 @@ t0 = time.time()
 for t in range(N if BATCH == 1 else 0):
     kw = draw()
     try:
-        s, rec, _ = streamgen.encode(**kw)
+        s, rec, sizes = streamgen.encode(**kw)
     except RuntimeError as e:
         print("trial %d: generator refused %s (%s)" % (t, kw, e))
         continue
@@ -75,8 +78,18 @@ for t in range(N if BATCH == 1 else 0):
             for x in ("256", "0"):
                 os.environ["H264MI_X_WGS"] = x
                 dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=kw["frames"], max_slices_per_frame=nsl)
-                dec.decode([s])
-                out = dec.read_frames(0, crop=False)
+                if SPLIT:
+                    got, pos, k = [], 0, 0
+                    while k < len(sizes):
+                        n = int(rng.integers(1, len(sizes) - k + 1))
+                        nbytes = int(sizes[k:k + n].sum())
+                        dec.decode([s[pos:pos + nbytes]])
+                        got.append(dec.read_frames(0, crop=False))
+                        pos, k = pos + nbytes, k + n
+                    out = np.concatenate([g for g in got if g.size])
+                else:
+                    dec.decode([s])
+                    out = dec.read_frames(0, crop=False)
                 dec.close()
                 ok = ok and out.shape == rec.shape and np.array_equal(out, rec)
         else:
