@@ -839,6 +839,13 @@ static bool new_picture(const h264mi_sps &sps, const h264mi_slice_header &a, con
     if (a.nal_unit_type == 5 && a.idr_pic_id != b.idr_pic_id) return true;
     if (sps.pic_order_count_type == 0 && (a.pic_order_cnt_lsb != b.pic_order_cnt_lsb || a.delta_pic_order_cnt_bottom != b.delta_pic_order_cnt_bottom)) return true;
     if (sps.pic_order_count_type == 1 && (a.delta_pic_order_cnt[0] != b.delta_pic_order_cnt[0] || a.delta_pic_order_cnt[1] != b.delta_pic_order_cnt[1])) return true;
+    // not in the list of 7.4.1.2.4, but a consequence of 7.4.3: all slices of a picture carry the same slice_group_change_cycle (the map is the
+    // picture's), the same marking script and the same long_term_reference_flag -- a difference means another picture even when frame_num and the
+    // picture order count agree (they do after memory management operation 5 resets both)
+    if (a.slice_group_change_cycle != b.slice_group_change_cycle) return true;
+    if (a.adaptive_ref_pic_marking_mode_flag != b.adaptive_ref_pic_marking_mode_flag || a.n_memory_management_control_operations != b.n_memory_management_control_operations) return true;
+    for (int k = 0; k < a.n_memory_management_control_operations; k++)
+        if (a.memory_management_control_operation[k] != b.memory_management_control_operation[k] || a.mmco_arg1[k] != b.mmco_arg1[k] || a.mmco_arg2[k] != b.mmco_arg2[k]) return true;
     return false;
 }
 

@@ -375,6 +375,12 @@ static int is_new_picture(const h264o_decoder *d, const h264o_slice_header *a, c
     if (d->asps->pic_order_cnt_type == 1 &&
         (a->delta_pic_order_cnt[0] != b->delta_pic_order_cnt[0] || a->delta_pic_order_cnt[1] != b->delta_pic_order_cnt[1]))
         return 1;
+    /* beyond the list of 7.4.1.2.4: what 7.4.3 requires to be the same in all slice headers of a picture -- the slice group change
+     * cycle and the marking script; they separate pictures whose frame_num and picture order count agree (after operation 5) */
+    if (a->slice_group_change_cycle != b->slice_group_change_cycle) return 1;
+    if (a->adaptive_ref_pic_marking_mode_flag != b->adaptive_ref_pic_marking_mode_flag || a->n_mmco != b->n_mmco) return 1;
+    for (int k = 0; k < a->n_mmco; k++)
+        if (a->mmco_op[k] != b->mmco_op[k] || a->mmco_arg1[k] != b->mmco_arg1[k] || a->mmco_arg2[k] != b->mmco_arg2[k]) return 1;
     return 0;
 }
 

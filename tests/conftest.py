@@ -86,6 +86,11 @@ MATRIX = {
     "aso_only": dict(BASE, profile_idc=66, cabac=0, slices=4, aso=1, deblock_idc=2, intra_in_p_permille=150, seed=90),
     # found by tools/param_sweep.py: POC type 2, and a picture with frame_num 1 that carries memory management operation 5 -- the next picture has
     # frame_num 1 again, nothing in 7.4.1.2.4 separates the two, and with foreground slice groups the slice of macroblock 0 is not the first one
+    # the same trap with POC type 0 (operation 5 in the picture with frame_num 1 / POC 2: the next picture has both again) and an evolving map whose first
+    # macroblock moves: only slice_group_change_cycle and the marking script tell the two pictures apart
+    "fmo_boxout_mmco5_equal_headers": dict(width=92, height=128, frames=4, profile_idc=77, seed=252101, qp=31, qp_jitter=2, idr_period=0, slices=2, num_ref_frames=3,
+                                           alpha_off_div2=-3, beta_off_div2=2, chroma_qp_offset=-1, skip_permille=500, sub8x8_permille=400, noise=2, motion_x4=1, motion_y4=-14,
+                                           cabac=1, cabac_init_idc=1, weighted_pred=2, mmco=1, slice_groups=2, fmo_type=3),
     "fmo_mmco5_equal_frame_num": dict(width=156, height=48, frames=6, profile_idc=77, seed=301113, qp=26, qp_jitter=2, idr_period=5, slices=2, num_ref_frames=2,
                                       constrained_intra=1, sub8x8_permille=400, noise=20, long_start_code=0, motion_x4=12, motion_y4=2, cabac=1, cabac_init_idc=-1,
                                       weighted_pred=2, poc_type=2, mmco=1, idr_long_term=1, slice_groups=3, fmo_type=2, alpha_off_div2=-1, beta_off_div2=3,
