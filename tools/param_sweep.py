@@ -17,6 +17,7 @@ GPU = "--gpu" in sys.argv
 seed0 = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 1
 BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1
 SPLIT = "--split" in sys.argv
+CONCAT = "--concat" in sys.argv  # two recipes back to back in one stream: new parameter sets, entropy coder, slice groups, picture size at the second IDR picture
 args = [a for a in args if a not in (str(seed0), str(BATCH))] or args[:1]
 rng = np.random.default_rng(seed0)
 
@@ -63,7 +64,7 @@ else:
     import oracle
 bad = 0
 t0 = time.time()
-for t in range(N if BATCH == 1 else 0):
+for t in range(N if BATCH == 1 and not CONCAT else 0):
     kw = draw()
     try:
         s, rec, sizes = streamgen.encode(**kw)
@@ -101,6 +102,41 @@ for t in range(N if BATCH == 1 else 0):
     if not ok:
         bad += 1
         print("MISMATCH trial %d: %s" % (t, kw), flush=True)
+    if (t + 1) % 25 == 0:
+        print("trial %d, %d mismatches, %.1fs" % (t + 1, bad, time.time() - t0), flush=True)
+for t in range(N if CONCAT else 0):
+    parts = []
+    while len(parts) < 2:
+        kw = draw()
+        try:
+            parts.append((kw, streamgen.encode(**kw)))
+        except RuntimeError:
+            pass
+    stream = parts[0][1][0] + parts[1][1][0]
+    dims = [((kw["width"] + 15) // 16 * 16, (kw["height"] + 15) // 16 * 16) for kw, _ in parts]
+    want = [f[:w * h * 3 // 2] for (kw, g), (w, h) in zip(parts, dims) for f in g[1]]
+    ok = True
+    try:
+        if GPU:
+            for x in ("256", "0"):
+                os.environ["H264MI_X_WGS"] = x
+                dec = H.Decoder(max_streams=1, max_width=max(d[0] for d in dims), max_height=max(d[1] for d in dims), max_frames_per_batch=sum(kw["frames"] for kw, _ in parts),
+                                max_slices_per_frame=max(max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1)) for kw, _ in parts))
+                dec.decode([stream])
+                n = dec.frame_count(0)
+                got = [dec.read_frame(0, f, False) for f in range(n)]
+                dec.close()
+                ok = ok and n == len(want) and all(np.array_equal(a[:b.size], b) for a, b in zip(got, want))
+        else:
+            if dims[0] == dims[1]:
+                out, _ = oracle.decode(stream, crop=False)
+                ok = len(out) == len(want) and all(np.array_equal(a, b) for a, b in zip(out, want))
+    except Exception as e:  # noqa: BLE001
+        ok = False
+        print("trial %d: %s" % (t, repr(e)[:300]))
+    if not ok:
+        bad += 1
+        print("MISMATCH trial %d: %s\n  + %s" % (t, parts[0][0], parts[1][0]), flush=True)
     if (t + 1) % 25 == 0:
         print("trial %d, %d mismatches, %.1fs" % (t + 1, bad, time.time() - t0), flush=True)
 for t in range(N if BATCH > 1 else 0):  # several streams per decoder
