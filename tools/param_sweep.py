@@ -17,6 +17,7 @@ GPU = "--gpu" in sys.argv
 seed0 = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 1
 BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1
 SPLIT = "--split" in sys.argv
+BIG = "--big" in sys.argv  # pictures wider than 64 macroblocks (rows of more than one 64-macroblock chunk), more slices
 CONCAT = "--concat" in sys.argv  # two recipes back to back in one stream: new parameter sets, entropy coder, slice groups, picture size at the second IDR picture
 args = [a for a in args if a not in (str(seed0), str(BATCH))] or args[:1]
 rng = np.random.default_rng(seed0)
@@ -52,6 +53,9 @@ def draw():
         kw["slices"] = min(kw["slices"], 2)
     elif kw["slices"] > 1:
         kw["aso"] = pick(0, 1)
+    if BIG:
+        kw["width"], kw["height"], kw["frames"] = 16 * r(62, 84) - pick(0, 6), 16 * r(3, 9) - pick(0, 2), r(2, 4)
+        kw["slices"] = pick(1, 2, 3, min(5, (kw["height"] + 15) // 16)) if not kw.get("slice_groups") else kw["slices"]
     if rng.random() < 0.15:
         kw["interlace_sps"] = 1
         kw["height"] = max(32, (kw["height"] + 31) // 32 * 32 - pick(0, 4, 8))
