@@ -78,6 +78,7 @@ def load():
         "h264mi_sps_parse": [u8p, SZ, P(Sps)],
         "h264mi_pps_parse": [P(Sps), u8p, SZ, P(Pps)],
         "h264mi_slice_header_parse": [P(Sps), P(Pps), I32, I32, u8p, SZ, P(SliceHdr)],
+        "h264mi_slice_starts_picture": [P(Sps), P(SliceHdr), P(SliceHdr)],
         "h264mi_pps_slice_group_ids": [P(Sps), u8p, SZ, vp, SZ, P(SZ)],
         "h264mi_map_unit_to_slice_group_map": [P(Sps), P(Pps), vp, SZ, I32, vp, SZ, P(SZ)],
         "h264mi_mb_to_slice_group_map": [P(Sps), P(Pps), vp, SZ, I32, I32, vp, SZ, P(SZ)],
@@ -134,4 +135,4 @@ EXPORTS = ["h264mi_annexb_scan", "h264mi_nal_parse", "h264mi_sps_parse", "h264mi
            "h264mi_frame_device_planes", "h264mi_frame_read", "h264mi_frame_pack_device", "h264mi_frame_read_mbrecs",
            "h264mi_decoder_set_profiling", "h264mi_last_kernel_times", "h264mi_last_error_string", "h264mi_version",
            "h264mi_last_launch_times", "h264mi_batch_pack_device", "h264mi_stream_reset", "h264mi_stream_status", "h264mi_decoder_set_isolation", "h264mi_frame_get_info", "h264mi_stream_output_order", "h264mi_decoder_memory", "h264mi_frame_read_mbmv1", "h264mi_decoder_coef_pool",
-           "h264mi_pps_slice_group_ids", "h264mi_map_unit_to_slice_group_map", "h264mi_mb_to_slice_group_map", "h264mi_next_mb_address"]
+           "h264mi_slice_starts_picture", "h264mi_pps_slice_group_ids", "h264mi_map_unit_to_slice_group_map", "h264mi_mb_to_slice_group_map", "h264mi_next_mb_address"]

@@ -849,6 +849,11 @@ static bool new_picture(const h264mi_sps &sps, const h264mi_slice_header &a, con
     return false;
 }
 
+extern "C" int32_t h264mi_slice_starts_picture(const h264mi_sps *sps, const h264mi_slice_header *prev, const h264mi_slice_header *cur) {
+    if (!sps || !prev || !cur) return H264MI_EINVAL;
+    return new_picture(*sps, *prev, *cur) ? 1 : 0;
+}
+
 static int scaling_set_for(h264mi_decoder *d, const h264mi_pps &p) {
     ScalingSet tmp;
     build_scaling(p.scaling_list_4x4, p.scaling_list_8x8, &tmp);

@@ -73,6 +73,8 @@ class SPS(_Mirror):
     def __init__(self, c):
         self._c = c
 
+    ID = property(lambda s: s._c.id)  # h264/sps.go:12
+
 
 class PPS(_Mirror):
     def __init__(self, c, slice_group_id=None):
@@ -410,13 +412,17 @@ class DisplayOrder:
 
 class AccessUnitSplitter:
     """Incremental Annex-B splitter: feed() arbitrary byte chunks, get back byte strings that end on an
-    access-unit boundary (7.4.1.2.3/4, simplified: a new access unit starts at an access unit delimiter, at an
-    SPS / PPS / SEI that follows a slice, or at a slice with first_mb_in_slice == 0).  3- and 4-byte start
-    codes are accepted (Annex B.1); the tail that may still grow is held back until flush()."""
+    access-unit boundary (7.4.1.2.3/4): a new access unit starts at an access unit delimiter, at an SPS / PPS / SEI that follows
+    a slice, or at the first slice of a new picture.  That last test is the decoder's own (h264mi_slice_starts_picture on the
+    parsed slice headers, plus "a slice starts where a slice of this picture already started"): with slice groups or arbitrary
+    slice order the slice of macroblock 0 is not the first of its picture, so `first_mb_in_slice == 0` -- what this class used
+    to look at, and still does for slices whose parameter sets it has not seen -- would cut such pictures in the middle.
+    3- and 4-byte start codes are accepted (Annex B.1); the tail that may still grow is held back until flush()."""
 
     def __init__(self, max_units_per_chunk=30):
         self._buf = bytearray()
         self._max = max(1, int(max_units_per_chunk))
+        self._sps, self._pps = {}, {}  # parameter sets in force at the START of the buffer (those inside it are applied while scanning)
 
     @staticmethod
     def _nal_starts(buf):
@@ -429,31 +435,93 @@ class AccessUnitSplitter:
             out.append(j - 1 if j > 0 and buf[j - 1] == 0 else j)
             i = j + 3
 
+    @staticmethod
+    def _parameter_set(nal, sps, pps):
+        """apply an SPS / PPS NAL (bytes from its header byte on) to the tables; unparsable ones are ignored"""
+        try:
+            nu = NewNalUnit(bytes(nal))
+            if nu.Type == 7:
+                s = NewSPS(nu.RBSP())
+                sps[s.ID] = s
+            elif nu.Type == 8 and len(nu.RBSP()) > 1:
+                br = nu.RBSP()
+                # seq_parameter_set_id is the second ue(v): parse against every known SPS until one accepts it (ids are small)
+                for cand in list(sps.values()):
+                    try:
+                        q = NewPPS(cand, br)
+                        if q.SPSID == cand.ID:
+                            pps[q.ID] = q
+                            break
+                    except H264MIError:
+                        continue
+        except H264MIError:
+            pass
+
+    @staticmethod
+    def _slice_header(nal, sps, pps):
+        """(first_mb_in_slice, header, sps) of a slice NAL, or None if its parameter sets are unknown / it does not parse"""
+        for n in (min(len(nal), 768), len(nal)):  # the header nearly always ends within the first bytes
+            try:
+                nu = NewNalUnit(bytes(nal[:n]))
+                rb = nu.RBSP()
+                # pic_parameter_set_id: third ue(v) of the header -- let every known PPS try (a stream rarely has more than one)
+                for q in list(pps.values()):
+                    sp = sps.get(q.SPSID)
+                    if sp is None:
+                        continue
+                    try:
+                        h = NewSliceContext(VideoStream(sp, q), nu, rb).Slice.Header
+                        if h.PPSID == q.ID:
+                            return h.FirstMbInSlice, h, sp
+                    except H264MIError:
+                        continue
+            except H264MIError:
+                pass
+        return None
+
     def _boundaries(self, final):
         """offsets at which a new access unit starts (excluding 0), in order"""
         buf = self._buf
         starts = self._nal_starts(buf)
+        sps, pps = dict(self._sps), dict(self._pps)
         cuts, seen_vcl = [], False
+        first_hdr, first_mbs = None, set()
+        L = _lib.load()
         for k, off in enumerate(starts):
             j = buf.find(b"\x00\x00\x01", off) + 3
             if j >= len(buf):
                 break  # header byte not here yet
+            end = starts[k + 1] if k + 1 < len(starts) else len(buf)
+            complete = k + 1 < len(starts) or final
             t = buf[j] & 31
             if t in (1, 5):
-                if j + 1 >= len(buf) and not final:
-                    break
-                first_mb_zero = j + 1 < len(buf) and (buf[j + 1] & 0x80) != 0  # ue(v) == 0 <=> leading 1 bit
-                if first_mb_zero and seen_vcl:
+                if not complete:
+                    break  # the slice header may still be arriving
+                parsed = self._slice_header(buf[j:end], sps, pps)
+                if parsed is None:  # parameter sets unknown: the old rule
+                    new_pic = j + 1 < len(buf) and (buf[j + 1] & 0x80) != 0
+                    first_mb, hdr = (0 if new_pic else -1), None
+                else:
+                    first_mb, hdr, sp = parsed
+                    new_pic = first_mb in first_mbs or (first_hdr is not None and L.h264mi_slice_starts_picture(ctypes.byref(sp._c), ctypes.byref(first_hdr._c), ctypes.byref(hdr._c)) == 1)
+                if seen_vcl and new_pic:
                     cuts.append(off)
+                    first_hdr, first_mbs = None, set()
+                if first_hdr is None:
+                    first_hdr = hdr
+                first_mbs.add(first_mb)
                 seen_vcl = True
-            elif t in (6, 7, 8, 9) and seen_vcl:
-                cuts.append(off)
-                seen_vcl = False
+            elif t in (6, 7, 8, 9):
+                if seen_vcl:
+                    cuts.append(off)
+                    seen_vcl, first_hdr, first_mbs = False, None, set()
+                if t in (7, 8) and complete:
+                    self._parameter_set(buf[j:end], sps, pps)
             elif t in (10, 11) and seen_vcl:  # end of sequence / stream belong to the access unit they follow
                 nxt = starts[k + 1] if k + 1 < len(starts) else None
                 if nxt is not None:
                     cuts.append(nxt)
-                    seen_vcl = False
+                    seen_vcl, first_hdr, first_mbs = False, None, set()
         # de-duplicate while keeping order
         out = []
         for c in cuts:
@@ -481,6 +549,13 @@ class AccessUnitSplitter:
             if end > prev:
                 chunks.append(bytes(self._buf[prev:end]))
             prev, k = end, k + take
+        if prev:  # the parameter sets inside what leaves are in force for what stays
+            head = self._buf[:prev]
+            st = self._nal_starts(head)
+            for k, off in enumerate(st):
+                j = head.find(b"\x00\x00\x01", off) + 3
+                if j < len(head) and (head[j] & 31) in (7, 8):
+                    self._parameter_set(head[j:st[k + 1] if k + 1 < len(st) else len(head)], self._sps, self._pps)
         del self._buf[:prev]
         return chunks
 

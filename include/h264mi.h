@@ -150,6 +150,13 @@ typedef struct {
 int32_t h264mi_slice_header_parse(const h264mi_sps *sps, const h264mi_pps *pps, int32_t nal_ref_idc, int32_t nal_unit_type,
                                   const uint8_t *rbsp, size_t len, h264mi_slice_header *sh);
 
+/* First slice of a new picture?  7.4.1.2.4 on two slice headers of one stream (`prev`: the first slice of the current picture), plus what
+ * 7.4.3 makes constant over the slices of a picture (slice_group_change_cycle, the marking script) -- memory management operation 5
+ * resets frame_num and the picture order count, so the headers of the next picture may agree with it in everything 7.4.1.2.4 lists.
+ * Returns 1 / 0 (negative: H264MI_EINVAL).  What h264mi_batch_prepare applies itself; exported for front-ends that cut a byte stream
+ * into access units (the reference reads NAL by NAL and never needs it: h264/server.go:113-166). */
+int32_t h264mi_slice_starts_picture(const h264mi_sps *sps, const h264mi_slice_header *prev, const h264mi_slice_header *cur);
+
 /* ---- slice groups (FMO, 8.2.2): h264/slice.go:134-158, :457-552 ----
  * MapUnitToSliceGroupMap(sps, pps, header) (h264/slice.go:457): map types 0..6 (the reference stops at 2).  ids / n_ids: the
  * slice_group_id array of a type-6 PPS (NULL / 0 otherwise); slice_group_change_cycle: the slice header's field (types 3..5).

@@ -106,6 +106,18 @@ def test_gpu_handle_connection_reads_file_objects(H, sg, oracle_mod):
 
 
 @pytest.mark.gpu
+def test_gpu_handle_connection_with_slice_groups_and_arbitrary_slice_order(H, sg):
+    """The connection handler cuts access units with the decoder's own picture-boundary test: a Baseline stream with an explicit slice
+    group map, two slices per group in shuffled order, and one whose box-out map moves from picture to picture, read 211 bytes at a time."""
+    for kw in (dict(width=176, height=144, frames=7, idr_period=3, profile_idc=66, cabac=0, slice_groups=3, fmo_type=6, slices=2, aso=1, seed=61),
+               dict(width=176, height=144, frames=6, idr_period=0, profile_idc=66, cabac=0, slice_groups=2, fmo_type=3, slices=2, aso=1, num_ref_frames=2, seed=62)):
+        stream, rec, _ = sg.encode(**kw)
+        got = []
+        assert H.handleConnection(io.BytesIO(stream), on_frames=got.append, max_width=176, max_height=144, frames_per_batch=2, read_size=211) == kw["frames"]
+        assert np.array_equal(np.concatenate(got), rec)
+
+
+@pytest.mark.gpu
 def test_gpu_batch_server_decodes_several_connections_side_by_side(H, sg, oracle_mod):
     cfgs = [dict(width=176, height=144, frames=7, idr_period=3, profile_idc=77, cabac=1, seed=31),
             dict(width=64, height=48, frames=5, idr_period=0, profile_idc=66, cabac=0, long_start_code=0, seed=32),
@@ -178,3 +190,22 @@ def test_gpu_reader_delivers_b_streams_in_display_order(H, sg):
     if (W, Hc) != (kw["width"], kw["height"]):  # the reader delivers cropped frames
         pytest.skip("cropped geometry")
     assert np.array_equal(got, want)
+
+
+def test_splitter_cuts_slice_group_and_aso_streams_at_picture_boundaries(H, sg):
+    """With slice groups or arbitrary slice order the slice of macroblock 0 is not the first of its picture, and after memory management
+    operation 5 two pictures can agree in frame_num and picture order count: the splitter applies the decoder's own test (parsed slice
+    headers, h264mi_slice_starts_picture) and must find exactly the generator's access units, whatever the feeding pattern."""
+    from conftest import MATRIX
+    names = [n for n, kw in MATRIX.items() if kw.get("slice_groups") or kw.get("aso")] + ["slices3_cabac" if "slices3_cabac" in MATRIX else "cabac_IPP"]
+    assert len(names) >= 12
+    for name in names:
+        stream, _, sizes = sg.encode(**MATRIX[name])
+        for piece in (1 << 20, 97):
+            sp = H.AccessUnitSplitter(max_units_per_chunk=1)
+            chunks = []
+            for i in range(0, len(stream), piece):
+                chunks += sp.feed(stream[i:i + piece])
+            chunks += sp.flush()
+            assert b"".join(chunks) == stream
+            assert [len(c) for c in chunks] == [int(x) for x in sizes], (name, piece)
