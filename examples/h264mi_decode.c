@@ -7,7 +7,9 @@
  * stream at access units, hand whole access units to h264mi_decode_batch, read the frames back.
  * The access-unit cut below is the same rule as AccessUnitSplitter in h264decode_amd/h264.py
  * (a new picture starts at an access unit delimiter, at a parameter set / SEI that follows a
- * slice, or at a slice whose first_mb_in_slice is 0).
+ * slice, or at the first slice of a new picture: h264mi_slice_starts_picture on the parsed slice
+ * headers, or a slice that starts where a slice of the current picture already started -- with
+ * slice groups or arbitrary slice order "first_mb_in_slice == 0" is not that test).
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -70,15 +72,57 @@ int main(int argc, char **argv) {
     size_t frame_cap = 0;
     long total = 0;
     int start = 0, pics = 0, seen_vcl = 0;
+    /* parameter sets by id and the slices of the current picture, for the picture-boundary test */
+    static h264mi_sps sps_tab[32];
+    static h264mi_pps pps_tab[256];
+    static uint8_t sps_ok[32], pps_ok[256];
+    static h264mi_slice_header first_hdr, hdr;
+    static int32_t first_mbs[1024];
+    int n_first = 0, have_first = 0;
+    uint8_t *rb = (uint8_t *)malloc((size_t)len + 16);
     for (int i = 0; i <= n; i++) {
         int cut = i == n;
         if (!cut) {
             const int t = nals[i].type;
             const uint8_t *p = buf + nals[i].offset;
+            size_t rl = 0;
+            h264mi_nal nh;
+            if (t == 7 || t == 8) {
+                if (h264mi_nal_parse(p, (size_t)nals[i].num_bytes, &nh, rb, &rl) == H264MI_OK) {
+                    if (t == 7) {
+                        h264mi_sps tmp;
+                        if (h264mi_sps_parse(rb, rl, &tmp) == H264MI_OK && tmp.id >= 0 && tmp.id < 32) sps_tab[tmp.id] = tmp, sps_ok[tmp.id] = 1;
+                    } else
+                        for (int k = 0; k < 32; k++) { /* seq_parameter_set_id is inside: let every SPS try */
+                            h264mi_pps tmp;
+                            if (sps_ok[k] && h264mi_pps_parse(&sps_tab[k], rb, rl, &tmp) == H264MI_OK && tmp.sps_id == k && tmp.id >= 0 && tmp.id < 256) {
+                                pps_tab[tmp.id] = tmp, pps_ok[tmp.id] = 1;
+                                break;
+                            }
+                        }
+                }
+            }
             if (t == 1 || t == 5) {
-                if ((p[1] & 0x80) && seen_vcl) cut = 1; /* first_mb_in_slice == 0: next picture */
+                int new_pic = -1;
+                if (h264mi_nal_parse(p, (size_t)nals[i].num_bytes, &nh, rb, &rl) == H264MI_OK)
+                    for (int k = 0; k < 256 && new_pic < 0; k++) /* pic_parameter_set_id is inside: let every PPS try */
+                        if (pps_ok[k] && sps_ok[pps_tab[k].sps_id] &&
+                            h264mi_slice_header_parse(&sps_tab[pps_tab[k].sps_id], &pps_tab[k], nh.ref_idc, nh.type, rb, rl, &hdr) == H264MI_OK && hdr.pps_id == k) {
+                            new_pic = 0;
+                            for (int m = 0; m < n_first; m++) new_pic |= first_mbs[m] == hdr.first_mb_in_slice;
+                            if (have_first && h264mi_slice_starts_picture(&sps_tab[pps_tab[k].sps_id], &first_hdr, &hdr) == 1) new_pic = 1;
+                        }
+                if (new_pic < 0) { /* parameter sets unknown: first_mb_in_slice == 0 */
+                    new_pic = (p[1] & 0x80) != 0;
+                    memset(&hdr, 0, sizeof(hdr));
+                    hdr.first_mb_in_slice = new_pic ? 0 : -1;
+                }
+                if (new_pic && seen_vcl) cut = 1;
+                if (cut || !seen_vcl) n_first = 0, have_first = 0;
+                if (!have_first) first_hdr = hdr, have_first = 1;
+                if (n_first < 1024) first_mbs[n_first++] = hdr.first_mb_in_slice;
             } else if ((t >= 6 && t <= 9) && seen_vcl)
-                cut = 1;
+                cut = 1, n_first = 0, have_first = 0;
         }
         if (cut && seen_vcl) {
             pics++;

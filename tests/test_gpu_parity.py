@@ -286,13 +286,16 @@ def test_gpu_c_program_through_the_abi(H, sg, oracle_mod, tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     subprocess.check_call(["make", "-s", "-C", os.path.join(root, "examples")])
-    stream = sg.encode(width=180, height=100, frames=8, idr_period=3, profile_idc=100, cabac=1, transform8x8=1, slices=2, long_start_code=0, seed=77)[0]
-    ref, info = oracle_mod.decode(stream, crop=True)
-    src, dst = tmp_path / "in.h264", tmp_path / "out.yuv"
-    src.write_bytes(stream)
-    subprocess.check_call([os.path.join(root, "examples", "h264mi_decode"), str(src), str(dst), "3"])
-    got = np.frombuffer(dst.read_bytes(), dtype=np.uint8).reshape(-1, info.width * info.height * 3 // 2)
-    assert np.array_equal(got, ref)
+    for kw in (dict(width=180, height=100, frames=8, idr_period=3, profile_idc=100, cabac=1, transform8x8=1, slices=2, long_start_code=0, seed=77),
+               # slice groups in shuffled slice order: the program must not cut pictures at "first_mb_in_slice == 0"
+               dict(width=176, height=144, frames=7, idr_period=4, profile_idc=66, cabac=0, slice_groups=3, fmo_type=6, slices=2, aso=1, seed=78)):
+        stream = sg.encode(**kw)[0]
+        ref, info = oracle_mod.decode(stream, crop=True)
+        src, dst = tmp_path / "in.h264", tmp_path / "out.yuv"
+        src.write_bytes(stream)
+        subprocess.check_call([os.path.join(root, "examples", "h264mi_decode"), str(src), str(dst), "3"])
+        got = np.frombuffer(dst.read_bytes(), dtype=np.uint8).reshape(-1, info.width * info.height * 3 // 2)
+        assert np.array_equal(got, ref)
 
 
 
