@@ -126,11 +126,21 @@ for t in range(N if CONCAT else 0):
                 os.environ["H264MI_X_WGS"] = x
                 dec = H.Decoder(max_streams=1, max_width=max(d[0] for d in dims), max_height=max(d[1] for d in dims), max_frames_per_batch=sum(kw["frames"] for kw, _ in parts),
                                 max_slices_per_frame=max(max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1)) for kw, _ in parts))
-                dec.decode([stream])
-                n = dec.frame_count(0)
-                got = [dec.read_frame(0, f, False) for f in range(n)]
+                got = []
+                if SPLIT:  # ... and in pieces of whole access units: the change may fall on a batch boundary or inside a batch
+                    sizes = np.concatenate([g[2] for _, g in parts])
+                    pos, k = 0, 0
+                    while k < len(sizes):
+                        m = int(rng.integers(1, len(sizes) - k + 1))
+                        nbytes = int(sizes[k:k + m].sum())
+                        dec.decode([stream[pos:pos + nbytes]])
+                        got += [dec.read_frame(0, f, False) for f in range(dec.frame_count(0))]
+                        pos, k = pos + nbytes, k + m
+                else:
+                    dec.decode([stream])
+                    got = [dec.read_frame(0, f, False) for f in range(dec.frame_count(0))]
                 dec.close()
-                ok = ok and n == len(want) and all(np.array_equal(a[:b.size], b) for a, b in zip(got, want))
+                ok = ok and len(got) == len(want) and all(np.array_equal(a[:b.size], b) for a, b in zip(got, want))
         else:
             if dims[0] == dims[1]:
                 out, _ = oracle.decode(stream, crop=False)
