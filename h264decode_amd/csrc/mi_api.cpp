@@ -130,6 +130,7 @@ struct StreamState {
     h264mi_pps pps[256];
     std::vector<uint8_t> sg_ids[256]; // slice_group_id[] of the PPSs with slice_group_map_type 6 (h264/pps.go:23)
     std::vector<int32_t> cur_first_mbs; // first_mb_in_slice of the slices of the current picture
+    uint32_t epoch = 0;                 // bumped by every reset of the stream: failures of batches prepared before it are nobody's business any more
     bool sps_ok[32] = {}, pps_ok[256] = {};
     int active_sps = -1;
     int wmb = 0, hmb = 0;
@@ -156,6 +157,7 @@ struct Stage {
     size_t bits_used = 0;
     size_t map_cursor = 0, bits_end = 0; // slice group maps of FMO pictures follow the slices in the staging buffer; bits_end: what must be uploaded
     std::vector<uint32_t> fmo_pics;      // pictures whose records are zeroed before the entropy kernels run
+    std::vector<uint32_t> epochs;        // StreamState::epoch of every stream when this batch was prepared
     SliceDesc *d_slices = nullptr, *h_slices = nullptr;
     PicDesc *d_pics = nullptr, *h_pics = nullptr;
     uint32_t *d_status = nullptr, *h_status = nullptr, *d_lists = nullptr, *h_lists = nullptr;
@@ -544,6 +546,7 @@ extern "C" int32_t h264mi_decoder_set_stream(h264mi_decoder *d, void *s) {
 // Forget everything about a stream: parameter sets, reference pictures, POC / frame_num history, outputs.
 static void reset_stream(StreamState &s, bool keep_parameter_sets) {
     for (auto &sl : s.slots) sl = Slot();
+    s.epoch++;
     s.cur_slot = s.cur_pic = -1, s.cur_slices = 0;
     s.n_pics_in_batch = 0;
     s.prev_poc_msb = s.prev_poc_lsb = s.prev_frame_num = s.prev_frame_num_offset = s.prev_ref_frame_num = 0;
@@ -1226,6 +1229,9 @@ static int harvest_status(h264mi_decoder *d, Stage &g) {
         if (g.h_status[8 * i]) {
             const SliceDesc &sd = g.h_slices[i];
             StreamState &s = d->st[g.h_pics[sd.pic_idx].stream];
+            // the stream was reset (h264mi_decoder_reset / h264mi_stream_reset: a new connection took the slot, or the caller started over) after this
+            // batch was prepared: what failed in it is not a property of what the slot decodes now
+            if (g.h_pics[sd.pic_idx].stream < g.epochs.size() && g.epochs[g.h_pics[sd.pic_idx].stream] != s.epoch) continue;
             if (result == H264MI_OK)
                 set_error("entropy kernel: slice %d (picture %u, stream %u) failed with code %u after %u macroblocks", i, sd.pic_idx, g.h_pics[sd.pic_idx].stream,
                           g.h_status[8 * i], g.h_status[8 * i + 1]);
@@ -1257,6 +1263,8 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     g.bits_used = 0, g.mb_used = 0, g.wmb_max = 0, g.hmb_max = 0, g.mbs_max = 0;
     g.map_cursor = g.bits_end = 0;
     g.fmo_pics.clear();
+    g.epochs.resize(d->st.size());
+    for (size_t si = 0; si < d->st.size(); si++) g.epochs[si] = d->st[si].epoch;
     g.n_bext = 0;
     g.pic_level.clear(), g.slice_level.clear(), g.pic_save_col.clear();
     memset(&g.info, 0, sizeof(g.info));

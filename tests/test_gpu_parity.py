@@ -523,6 +523,27 @@ def test_gpu_pipelined_batches_do_not_lose_a_failure(H, sg):
     dec.close()
 
 
+def test_gpu_reset_discards_failures_of_abandoned_batches(H, sg):
+    """Found by tools/api_fuzz.py: a batch that failed is executed again without a sync, then the caller resets the decoder (or the stream:
+    a new connection takes the slot) and decodes something else -- the abandoned batch's failure must not be reported against the new
+    stream, neither by h264mi_batch_sync nor in its status."""
+    bad = sg.encode(width=96, height=80, frames=4, idr_period=2, profile_idc=66, cabac=0, slice_groups=3, fmo_type=1, aso=1, seed=2)[0]
+    good, rec, _ = sg.encode(width=176, height=144, frames=5, idr_period=0, profile_idc=77, cabac=1, seed=1)
+    for how in ("decoder", "stream"):
+        dec = H.Decoder(max_streams=2, max_width=176, max_height=144, max_frames_per_batch=6, max_slices_per_frame=8)
+        with pytest.raises(H.H264MIError):
+            dec.decode([bad[:len(bad) * 2 // 3], b""])  # a slice cut short: entropy failure
+        dec.execute()  # the same batch again, nobody synchronises on it
+        if how == "decoder":
+            dec.reset()
+        else:
+            dec.reset_stream(0)
+        dec.decode([good, good])  # must not raise
+        assert dec.stream_status(0) == 0 and dec.stream_status(1) == 0
+        assert np.array_equal(dec.read_frames(0, crop=False), rec) and np.array_equal(dec.read_frames(1, crop=False), rec)
+        dec.close()
+
+
 def test_gpu_resolution_change_inside_one_batch(H, sg):
     """Two sequences of different size back to back in ONE chunk of one stream: every picture keeps its own geometry."""
     a = sg.encode(width=176, height=144, frames=3, idr_period=0, profile_idc=77, cabac=1, seed=51)

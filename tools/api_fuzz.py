@@ -19,8 +19,11 @@ t0 = time.time()
 for r in range(N):
     dec = H.Decoder(max_streams=2, max_width=176, max_height=144, max_frames_per_batch=6, max_slices_per_frame=8)
     L, h = dec._L, dec._h
+    log = []
     for step in range(int(rng.integers(3, 25))):
         op = int(rng.integers(0, 14))
+        state = rng.bit_generator.state["state"]["state"]  # (to replay the draws of this step)
+        log.append((op, state))
         try:
             if op == 0:
                 dec.prepare([good[int(rng.integers(0, 3))][0], good[int(rng.integers(0, 3))][0]])
@@ -58,13 +61,17 @@ for r in range(N):
         except (IndexError, ValueError):
             codes["py"] = codes.get("py", 0) + 1
     # whatever happened: a clean decode afterwards is exact
-    dec.reset()
-    dec.set_isolation(False)
     k = int(rng.integers(0, 3))
-    dec.decode([good[k][0], good[(k + 1) % 3][0]])
-    for i, g in ((0, good[k]), (1, good[(k + 1) % 3])):
-        w, hh = [(176, 144), (96, 80), (176, 144)][(k + i) % 3]
-        assert np.array_equal(dec.read_frames(i, crop=False, size=w * hh * 3 // 2), g[1]), (r, i)
+    try:
+        dec.reset()
+        dec.set_isolation(False)
+        dec.decode([good[k][0], good[(k + 1) % 3][0]])
+        for i, g in ((0, good[k]), (1, good[(k + 1) % 3])):
+            w, hh = [(176, 144), (96, 80), (176, 144)][(k + i) % 3]
+            assert np.array_equal(dec.read_frames(i, crop=False, size=w * hh * 3 // 2), g[1]), (r, i)
+    except Exception as e:  # noqa: BLE001
+        print("FAILED round %d k=%d after ops %s: %s" % (r, k, [o for o, _ in log], repr(e)[:200]), flush=True)
+        raise
     dec.close()
     if (r + 1) % 50 == 0:
         print("round %d codes %s %.1fs" % (r + 1, codes, time.time() - t0), flush=True)
