@@ -496,6 +496,8 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock_x), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
     // cross-workgroup hand-off state of the banded kernels; H264MI_X_WGS = 0 switches them off, n: up to n workgroups per launch
     if (const char *e = getenv("H264MI_X_WGS")) d->x_max_wgs = std::min(std::max(atoi(e), 0), d->x_cap);
+    // (test hook: where the launch epoch and the ticket counters start, so that a test can cross their 32-bit wrap)
+    if (const char *e = getenv("H264MI_X_EPOCH0")) d->x_epoch = d->x_tk5 = d->x_tk3 = static_cast<uint32_t>(strtoul(e, nullptr, 0));
     DEV_ALLOC(d->d_xring, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long));
     DEV_ALLOC(d->d_xdone, static_cast<size_t>(d->x_cap3) * (d->Wmax / 16) * sizeof(uint32_t));
     DEV_ALLOC(d->d_xctl, 3 * 128);
@@ -504,6 +506,10 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipMemset(d->d_xring, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long)));
     TRY_ALLOC(hipMemset(d->d_xdone, 0, static_cast<size_t>(d->x_cap3) * (d->Wmax / 16) * sizeof(uint32_t)));
     TRY_ALLOC(hipMemset(d->d_xctl, 0, 3 * 128));
+    if (d->x_tk5) { // (H264MI_X_EPOCH0: the device-side ticket counters start where the host's bases do)
+        TRY_ALLOC(hipMemcpy(d->d_xctl, &d->x_tk5, sizeof(uint32_t), hipMemcpyHostToDevice));
+        TRY_ALLOC(hipMemcpy(d->d_xctl + 32, &d->x_tk3, sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     build_tables(d->h_tables);
     d->h_pools.resize(S);
     for (int si = 0; si < S; si++) { // static per stream (kernels take the geometry of a picture from its PicDesc)

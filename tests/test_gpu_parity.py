@@ -544,6 +544,60 @@ def test_gpu_reset_discards_failures_of_abandoned_batches(H, sg):
         dec.close()
 
 
+def test_gpu_banded_kernels_across_the_epoch_wrap(H, sg, monkeypatch):
+    """The banded kernels tag their hand-off words with a 32-bit launch epoch and draw tickets from 32-bit counters: a decoder that starts
+    a few launches before the wrap (test hook H264MI_X_EPOCH0) must decode exactly -- tickets are compared modulo 2^32, the rings are
+    zeroed when the epoch restarts at 1."""
+    kw = dict(width=176, height=144, frames=8, idr_period=0, profile_idc=77, cabac=1, num_ref_frames=2, intra_in_p_permille=150, seed=85)
+    stream, rec, _ = sg.encode(**kw)
+    for start in ("0xFFFFFFF0", "0xFFFFFFFE", "0xFFFFFF00"):
+        monkeypatch.setenv("H264MI_X_EPOCH0", start)
+        dec = H.Decoder(max_streams=1, max_width=176, max_height=144, max_frames_per_batch=8)
+        for _ in range(3):  # 3 x 8 pictures x 2 banded launches: crosses the wrap for the first two start values
+            dec.decode([stream])
+            assert np.array_equal(dec.read_frames(0, crop=False), rec), start
+        dec.close()
+    monkeypatch.delenv("H264MI_X_EPOCH0")
+
+
+def test_gpu_decoders_in_several_threads(H, sg):
+    """include/h264mi.h, "Threading": a handle is used by one thread at a time, distinct handles are independent.  Four threads, each with
+    its own decoder and its own kind of stream (CABAC, CAVLC with slice groups, B pictures, High 8x8 multi-slice), decode side by side for a
+    few rounds; every thread's frames are its generator's, and an error raised in one thread carries that thread's message."""
+    import threading
+    kws = [dict(width=176, height=144, frames=6, idr_period=0, profile_idc=77, cabac=1, seed=81),
+           dict(width=96, height=80, frames=5, idr_period=2, profile_idc=66, cabac=0, slice_groups=3, fmo_type=6, aso=1, seed=82),
+           dict(width=176, height=144, frames=7, idr_period=0, profile_idc=77, cabac=1, bframes=2, num_ref_frames=3, seed=83),
+           dict(width=180, height=100, frames=4, idr_period=0, profile_idc=100, cabac=1, transform8x8=1, slices=3, seed=84)]
+    gen = [sg.encode(**kw) for kw in kws]
+    results, errors = {}, {}
+
+    def worker(i):
+        try:
+            kw, (stream, rec, _) = kws[i], gen[i]
+            W, Hc = (kw["width"] + 15) // 16 * 16, (kw["height"] + 15) // 16 * 16
+            dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=kw["frames"], max_slices_per_frame=8)
+            ok = True
+            for _ in range(6):
+                dec.decode([stream])
+                ok = ok and np.array_equal(dec.read_frames(0, crop=False), rec)
+            try:
+                dec.decode([stream[:len(stream) // 2 + i]])  # every thread ends with a failure of its own
+            except H.H264MIError as e:
+                errors[i] = str(e)
+            dec.close()
+            results[i] = ok
+        except Exception as e:  # noqa: BLE001
+            results[i] = repr(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert results == {0: True, 1: True, 2: True, 3: True}, results
+
+
 def test_gpu_resolution_change_inside_one_batch(H, sg):
     """Two sequences of different size back to back in ONE chunk of one stream: every picture keeps its own geometry."""
     a = sg.encode(width=176, height=144, frames=3, idr_period=0, profile_idc=77, cabac=1, seed=51)
