@@ -17,6 +17,7 @@ GPU = "--gpu" in sys.argv
 seed0 = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 1
 BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1
 SPLIT = "--split" in sys.argv
+XR = "--xwgs" in sys.argv  # a random workgroup budget per trial (band plans of every shape) instead of the two standard ones
 BIG = "--big" in sys.argv  # pictures wider than 64 macroblocks (rows of more than one 64-macroblock chunk), more slices
 CONCAT = "--concat" in sys.argv  # two recipes back to back in one stream: new parameter sets, entropy coder, slice groups, picture size at the second IDR picture
 args = [a for a in args if a not in (str(seed0), str(BATCH))] or args[:1]
@@ -80,7 +81,7 @@ for t in range(N if BATCH == 1 and not CONCAT else 0):
     try:
         if GPU:
             nsl = max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1))
-            for x in ("256", "0"):
+            for x in ((str([2, 3, 4, 5, 7, 9, 13, 31, 64, 100, 512][int(rng.integers(0, 11))]),) if XR else ("256", "0")):
                 os.environ["H264MI_X_WGS"] = x
                 dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=kw["frames"], max_slices_per_frame=nsl)
                 if SPLIT:
