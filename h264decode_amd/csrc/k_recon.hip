@@ -509,8 +509,17 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
     }
 }
 
+// 64 bits of the batch's intra mask (k_dbprep: one bit per macroblock, index = position in the record array) from bit `first` on, the first `n` of them
+__device__ __forceinline__ unsigned long long intra_bits(const unsigned long long *mask, unsigned long long first, int n) {
+    const unsigned long long w = first >> 6;
+    const int sh = static_cast<int>(first & 63);
+    unsigned long long m = mask[w] >> sh;
+    if (sh) m |= mask[w + 1] << (64 - sh);
+    return n >= 64 ? m : (m & ((1ull << n) - 1ull));
+}
+
 extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab,
-                                                                          const MbRec *mbrec, const int16_t *coefs) {
+                                                                          const MbRec *mbrec, const int16_t *coefs, const unsigned long long *intramask) {
     __shared__ IntraShared sh;
     __shared__ unsigned long long s_intra[MI_INTRA_MAX_ROWS][MI_INTRA_MAX_CHUNKS]; // sh.pend as pass 1 left it: which macroblocks K3 owns
     __shared__ uint32_t s_prefix[MI_INTRA_MAX_ROWS + 1];                          // intra macroblocks in the rows before row r
@@ -527,23 +536,23 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
     }
     const int nchunks = (wmb + 63) >> 6;
     const MbRec *recs = mbrec + pd->mb_base;
-    // ---- pass 1: intra masks of every row (one type byte per lane, ballot) ----
-    for (int mby = wave; mby < hmb; mby += MI_INTRA_WAVES) {
-        uint32_t cnt = 0;
-        for (int c = 0; c < nchunks; c++) {
-            const int x = c * 64 + lane;
-            const int t = x < wmb ? recs[static_cast<size_t>(mby) * wmb + x].type : -1;
-            // macroblocks no slice delivered (type MBT_NONE) take the intra path too: it paints them mid-grey
-            const unsigned long long m = __ballot(MB_IS_INTRA(t) || t == MBT_NONE);
-            if (lane == 0) sh.pend[mby][c] = m, s_intra[mby][c] = m;
-            cnt += static_cast<uint32_t>(__builtin_popcountll(m));
-        }
-        if (lane == 0) s_prefix[mby + 1] = cnt; // (a count for now)
+    // ---- pass 1: intra masks of every row, cut out of the batch's bit mask (k_dbprep; macroblocks no slice delivered -- type MBT_NONE -- are in
+    // it too: the intra path paints them mid-grey).  One thread per (row, 64-macroblock chunk). ----
+    for (int i = tid; i < hmb * nchunks; i += MI_INTRA_WAVES * 64) {
+        const int mby = i / nchunks, c = i - mby * nchunks;
+        const unsigned long long m = intra_bits(intramask, pd->mb_base + static_cast<unsigned long long>(mby) * wmb + c * 64, wmb - c * 64);
+        sh.pend[mby][c] = m, s_intra[mby][c] = m;
     }
-    if (tid == 0) s_prefix[0] = 0, s_next = 0;
+    if (tid == 0) s_next = 0;
     __syncthreads();
-    if (tid == 0) // counts -> running sums (at most 320 rows)
-        for (int r = 1; r <= hmb; r++) s_prefix[r] += s_prefix[r - 1];
+    if (tid == 0) { // running sums of the rows' counts (at most 320 rows)
+        uint32_t acc = 0;
+        s_prefix[0] = 0;
+        for (int r = 0; r < hmb; r++) {
+            for (int c = 0; c < nchunks; c++) acc += static_cast<uint32_t>(__builtin_popcountll(s_intra[r][c]));
+            s_prefix[r + 1] = acc;
+        }
+    }
     __syncthreads();
     IntraWave *ws = &sh.w[wave];
     // ---- pass 2 ----
@@ -632,7 +641,8 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
 // (picture, band) from a ticket counter in that order, so the workgroup being waited for is always running.
 extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab,
                                                                             const MbRec *mbrec, const int16_t *coefs, uint32_t *xdone_, uint32_t epoch, int nbands,
-                                                                            uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus, int wpr) {
+                                                                            uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus, int wpr,
+                                                                            const unsigned long long *intramask) {
     // wpr ("wavefronts per row"): the intra macroblocks of a row are dealt round-robin to wpr wavefronts.  In P / B pictures they are
     // few and mostly independent of each other, so the busiest row -- which bounds the kernel -- finishes wpr times sooner; a
     // macroblock whose left neighbour is an intra one too waits for that neighbour's bit like it waits for the row above.
@@ -663,13 +673,14 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(cons
     gflag *const xin = (gflag *)xdone_ + (static_cast<size_t>(pic_i) * nbands + (pband > 0 ? pband : 0)) * static_cast<size_t>(wmb_max);
     gflag *const xout = (gflag *)xdone_ + (static_cast<size_t>(pic_i) * nbands + band) * static_cast<size_t>(wmb_max);
     // ---- pass 1: intra masks of the band's rows and of the row above it (that one is never cleared here: it says which flags to wait for) ----
-    for (int mby = (r0 > 0 ? r0 - 1 : 0) + wave; mby < r1; mby += nwaves)
-        for (int c = 0; c < nchunks; c++) {
-            const int x = c * 64 + lane;
-            const int t = x < wmb ? recs[static_cast<size_t>(mby) * wmb + x].type : -1;
-            const unsigned long long m = __ballot(MB_IS_INTRA(t) || t == MBT_NONE);
-            if (lane == 0) sh.pend[mby][c] = m, s_intra[mby][c] = m;
+    {
+        const int rf = r0 > 0 ? r0 - 1 : 0;
+        for (int i = tid; i < (r1 - rf) * nchunks; i += nthreads) {
+            const int mby = rf + i / nchunks, c = i % nchunks;
+            const unsigned long long m = intra_bits(intramask, pd->mb_base + static_cast<unsigned long long>(mby) * wmb + c * 64, wmb - c * 64);
+            sh.pend[mby][c] = m, s_intra[mby][c] = m;
         }
+    }
     __syncthreads();
     IntraWave *ws = &sh.w[wave];
     const int row_slot = wave / wpr, turn = wave - row_slot * wpr, row_slots = nwaves / wpr;

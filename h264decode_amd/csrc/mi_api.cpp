@@ -202,6 +202,7 @@ struct h264mi_decoder {
     // MbRec / coefficient buffer sets, fenced by events.
     MbRec *d_mbrec[MI_SETS] = {};
     DbPrm *d_dbprm[MI_SETS] = {};        // k_dbprep -> K5: boundary strengths and filter parameters, same indexing as d_mbrec
+    unsigned long long *d_imask[MI_SETS] = {}; // k_dbprep -> K3: one bit per macroblock of the batch (same indexing), set for what K3 reconstructs
     MbMv1 *d_mv1[MI_SETS] = {};          // list-1 vectors, same indexing as d_mbrec; allocated when the first B slice arrives
     ColRec *d_colrec = nullptr;          // per stream and frame slot: the motion a picture leaves for later direct prediction
     size_t colrec_per_slot = 0;          // ColRecs per frame slot
@@ -333,6 +334,7 @@ static void free_all(h264mi_decoder *d) {
         if (d->d_mbrec[i]) hipFree(d->d_mbrec[i]);
         if (d->d_mv1[i]) hipFree(d->d_mv1[i]);
         if (d->d_dbprm[i]) hipFree(d->d_dbprm[i]);
+        if (d->d_imask[i]) hipFree(d->d_imask[i]);
         if (d->d_coef[i]) hipFree(d->d_coef[i]);
         if (i == 0 && d->d_pool_head) hipFree(d->d_pool_head);
         if (d->d_toprows[i]) hipFree(d->d_toprows[i]);
@@ -465,6 +467,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     for (int i = 0; i < MI_SETS; i++) {
         DEV_ALLOC(d->d_mbrec[i], sizeof(MbRec) * d->mb_cap);
         DEV_ALLOC(d->d_dbprm[i], sizeof(DbPrm) * d->mb_cap);
+        DEV_ALLOC(d->d_imask[i], sizeof(unsigned long long) * (d->mb_cap / 64 + 2));
         if (i == 0) {
             // Pool size.  The worst case is 26 blocks (832 bytes) per macroblock; real streams code a fraction of that (the
             // 1080p QP 28 bench streams: ~5 blocks per macroblock).  Small decoders get the worst case; large ones 8 blocks
@@ -966,7 +969,7 @@ static int ensure_b_buffers(h264mi_decoder *d) {
             HIP_TRY(hipMemcpyAsync(d->d_backfill, list.data(), sizeof(uint32_t) * list.size(), hipMemcpyHostToDevice, up));
             HIP_TRY(hipStreamSynchronize(up)); // (`list` is pageable host memory; once per decoder)
             hipLaunchKernelGGL(k_dbprep, dim3((pv.mbs_max + MI_DBPREP_MBS - 1) / MI_DBPREP_MBS, static_cast<uint32_t>(list.size())), dim3(256), 0, up, d->d_backfill,
-                               pv.d_pics, d->d_tables, d->d_mbrec[pset], d->d_mv1[pset], d->d_dbprm[pset], 1);
+                               pv.d_pics, d->d_tables, d->d_mbrec[pset], d->d_mv1[pset], d->d_dbprm[pset], 1, d->d_imask[pset]);
         }
     }
     return H264MI_OK;
@@ -1561,6 +1564,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         // pictures with slice groups: a slice's macroblocks are scattered, so its wavefront cannot blank "its" range for what it
         // does not decode (SliceDesc::fill_from) -- all records of such a picture start out as MBT_NONE instead
         for (uint32_t pi : g.fmo_pics) hipMemsetAsync(mbrec + g.h_pics[pi].mb_base, 0, sizeof(MbRec) * g.h_pics[pi].wmb * g.h_pics[pi].hmb, st);
+        hipMemsetAsync(d->d_imask[set], 0, sizeof(unsigned long long) * (g.mb_used / 64 + 2), st); // k_dbprep ORs K3's work list into it
         for (int lv = 0; lv < n_levels; lv++) {
             const int first = g.level_first[lv], n = g.level_first[lv + 1] - first;
             // ColRec arrays cross passes: B slices read what the previous pass's k_dbprep wrote, and this pass's k_dbprep may
@@ -1583,7 +1587,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
             // level's, or a later batch's) take their direct prediction from
             if (g.prep_n[lv])
                 hipLaunchKernelGGL(k_dbprep, dim3((g.mbs_max + MI_DBPREP_MBS - 1) / MI_DBPREP_MBS, g.prep_n[lv]), dim3(256), 0, st, g.d_lists + g.prep_off[lv], g.d_pics,
-                                   d->d_tables, mbrec, d->d_mv1[set], d->d_dbprm[set], 0);
+                                   d->d_tables, mbrec, d->d_mv1[set], d->d_dbprm[set], 0, d->d_imask[set]);
             if (lv == n_levels - 1 && done) hipEventRecord(done, st);
         }
     };
@@ -1643,10 +1647,10 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         mi_intra_bands(static_cast<int>(n), g.hmb_max, d->x_max_wgs, !has_ipic, &nb3, &nw3, &wpr3);
         if (nb3 > 1) {
             hipLaunchKernelGGL(k_intra_x, dim3(n * nb3), dim3(nw3 * 64), 0, rs, g.d_lists + g.wave_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, coef, d->d_xdone,
-                               next_epoch(), nb3, d->d_xctl + 32, d->x_tk3, g.wmb_max, d->d_xctl + 64, wpr3);
+                               next_epoch(), nb3, d->d_xctl + 32, d->x_tk3, g.wmb_max, d->d_xctl + 64, wpr3, d->d_imask[set]);
             d->x_tk3 += n * nb3;
         } else
-            hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, g.d_lists + g.wave_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, coef);
+            hipLaunchKernelGGL(k_intra, dim3(n), dim3(MI_INTRA_WAVES * 64), 0, rs, g.d_lists + g.wave_off[w], g.d_pics, d->d_pools, d->d_tables, mbrec, coef, d->d_imask[set]);
         mark(2);
         int dbw = 1, dbring = 16, dbring_last = 16, dbbufs = 1, nb5 = 1, roles = 1;
         mi_deblock_bands(static_cast<int>(n), g.wmb_max, g.hmb_max, d->x_max_wgs, &nb5, &dbw, &dbring, &roles);

@@ -24,17 +24,17 @@ extern "C" __global__ void k_inter_b(const uint32_t *pic_list, const PicDesc *pi
                                      const int16_t *coefs, int groups_per_pic_log2, int n_blocks, const BSliceExt *bexts, const MbMv1 *mbmv1);
 // K3: intra macroblocks, one workgroup per picture, one wavefront per macroblock row (2-D wavefront order).
 extern "C" __global__ void k_intra(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
-                                   const int16_t *coefs);
+                                   const int16_t *coefs, const unsigned long long *intramask);
 // K3 spread over `nbands` workgroups per picture: grid = pictures * nbands, block = 64 * wavefronts per band (<= MI_INTRA_WAVES);
 // xdone: pictures * nbands * wmb_max flag words; epoch / ticket as for k_deblock_x
 extern "C" __global__ void k_intra_x(const uint32_t *pic_list, const PicDesc *pics, const FramePool *pools, const DevTables *tab, const MbRec *mbrec,
                                      const int16_t *coefs, uint32_t *xdone, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max,
-                                     uint32_t *xstatus, int waves_per_row);
+                                     uint32_t *xstatus, int waves_per_row, const unsigned long long *intramask);
 // k_dbprep: boundary strengths + alpha / beta / tC0 of every macroblock of a batch (DbPrm), so that K5 -- one serial dependency chain per
 // picture -- has none of that work in its steps; for the pictures flagged PicDesc::save_col also their ColRec array (the motion later B pictures
 // take their direct prediction from).  grid = (ceil(mbs_max / MI_DBPREP_MBS), pictures of the list), block = 256.
 #define MI_DBPREP_MBS 64
-extern "C" __global__ void k_dbprep(const uint32_t *pic_list, const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1, DbPrm *out, int col_only);
+extern "C" __global__ void k_dbprep(const uint32_t *pic_list, const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1, DbPrm *out, int col_only, unsigned long long *intramask);
 // K5: in-loop deblocking, one workgroup per picture, one wavefront per group of 4 macroblock rows (up to 16 groups side by side).
 // block = 64 * nwaves, dynamic LDS = mi_deblock_lds_bytes(nwaves, ring, ring_last); (nwaves, ring, ring_last) from mi_deblock_plan()
 extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring, int ring_last, int last_bufs);
