@@ -18,6 +18,7 @@ seed0 = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else
 BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1
 SPLIT = "--split" in sys.argv
 XR = "--xwgs" in sys.argv  # a random workgroup budget per trial (band plans of every shape) instead of the two standard ones
+EXTREME = "--extreme" in sys.argv  # the corners of the value ranges: QP 0..51, chroma offsets -12..12, filter offsets -6..6, loud noise (escape-coded levels)
 BIG = "--big" in sys.argv  # pictures wider than 64 macroblocks (rows of more than one 64-macroblock chunk), more slices
 CONCAT = "--concat" in sys.argv  # two recipes back to back in one stream: new parameter sets, entropy coder, slice groups, picture size at the second IDR picture
 args = [a for a in args if a not in (str(seed0), str(BATCH))] or args[:1]
@@ -54,6 +55,9 @@ def draw():
         kw["slices"] = min(kw["slices"], 2)
     elif kw["slices"] > 1:
         kw["aso"] = pick(0, 1)
+    if EXTREME:
+        kw.update(qp=pick(0, 1, 2, 5, 48, 50, 51, r(0, 51)), chroma_qp_offset=pick(-12, -9, 9, 12, r(-12, 12)), alpha_off_div2=pick(-6, 6, r(-6, 6)), beta_off_div2=pick(-6, 6, r(-6, 6)),
+                  noise=pick(0, 40, 60, 100), qp_jitter=pick(0, 5, 8, 12), slice_qp_delta=pick(0, 3, 8))
     if BIG:
         kw["width"], kw["height"], kw["frames"] = 16 * r(62, 84) - pick(0, 6), 16 * r(3, 9) - pick(0, 2), r(2, 4)
         kw["slices"] = pick(1, 2, 3, min(5, (kw["height"] + 15) // 16)) if not kw.get("slice_groups") else kw["slices"]
