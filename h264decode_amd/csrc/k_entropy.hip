@@ -653,6 +653,7 @@ FI void parse_residual_cabac(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
         const int own = static_cast<int>((d >> 12) & 63);
         const int dst = cat == 5 ? (step - 1) * 16 : static_cast<int>((d >> 18) & 255) * 4;
         const int inc = static_cast<int>((nzm >> (d & 63)) & 1) + 2 * static_cast<int>((nzm >> ((d >> 6) & 63)) & 1);
+        slide_window(e); // (see cavlc: a macroblock_layer() beyond A.3.1's 3200 bits must not run off the window; one block is at most 92 words)
         if (cabac_residual(e, s->coef + dst, cat, inc)) nzm |= (cat == 5 ? 0xC3ull : 1ull) << own;
     }
     // results: deblocking mask (raster 4x4), DC flags and the 0/1 "coded" grids the neighbours will read
@@ -715,6 +716,10 @@ FI void parse_residual_cavlc(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
             dst = s->coef + MI_COEF_CAC + j * 16;
             na = s->nnzc_c[c][(by + 1) * 3 + bx], nb = s->nnzc_c[c][by * 3 + bx + 1];
         }
+        // The window holds 128 words beyond the one it last slid at, and it slides at macroblock boundaries -- enough for the 3200 bits A.3.1 allows
+        // a macroblock_layer().  Encoders that ignore the limit exist (very low QP on noisy content: 8000 bits and more), so it also slides here,
+        // block by block (a block is at most 25 words): one compare for conforming streams.
+        slide_window(e);
         const int n = cavlc_residual(e, dst, kind, kind == 2 ? -1 : nc_of(na, nb));
         // ---- bookkeeping per block kind ----
         if (step == 0) {

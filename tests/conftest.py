@@ -83,6 +83,10 @@ MATRIX = {
     "fmo_explicit": dict(BASE, profile_idc=66, cabac=0, slice_groups=5, fmo_type=6, slices=2, aso=1, deblock_idc=2, pcm_permille=30, intra_in_p_permille=200, seed=97),
     "fmo_interlace_sps": dict(width=176, height=160, frames=4, idr_period=0, profile_idc=66, cabac=0, interlace_sps=1, slice_groups=3, fmo_type=1, seed=98),
     "fmo_explicit_cabac_b": dict(BASE, frames=7, profile_idc=77, cabac=1, slice_groups=3, fmo_type=6, aso=1, bframes=2, num_ref_frames=3, seed=99),
+    # found by tools/param_sweep.py --extreme: macroblocks far beyond the 3200 bits A.3.1 allows a macroblock_layer() (QP 1 on loud noise: 8000 and more;
+    # a conforming encoder would send I_PCM) must not run off the entropy kernels' bit window -- CAVLC and CABAC, escape-coded levels throughout
+    "oversized_mbs_cavlc": dict(BASE, frames=3, profile_idc=66, cabac=0, qp=1, noise=100, qp_jitter=5, seed=101),
+    "oversized_mbs_cabac_8x8": dict(BASE, frames=3, profile_idc=100, cabac=1, transform8x8=1, qp=0, noise=100, chroma_qp_offset=-12, seed=102),
     "aso_only": dict(BASE, profile_idc=66, cabac=0, slices=4, aso=1, deblock_idc=2, intra_in_p_permille=150, seed=90),
     # found by tools/param_sweep.py: POC type 2, and a picture with frame_num 1 that carries memory management operation 5 -- the next picture has
     # frame_num 1 again, nothing in 7.4.1.2.4 separates the two, and with foreground slice groups the slice of macroblock 0 is not the first one

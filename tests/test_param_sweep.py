@@ -19,11 +19,12 @@ def _sweep(*args):
 def test_sweep_oracle_equals_generator():
     _sweep("400", "--seed", "3")
     _sweep("150", "--seed", "5", "--concat")
+    _sweep("300", "--seed", "61", "--extreme")
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [("300", "--seed", "11"), ("200", "--seed", "31", "--split"), ("40", "--seed", "23", "--batch", "6"),
                                   ("150", "--seed", "5", "--concat"), ("150", "--seed", "13", "--concat", "--split"), ("40", "--seed", "9", "--big"),
-                                  ("250", "--seed", "41", "--xwgs")])
+                                  ("250", "--seed", "41", "--xwgs"), ("300", "--seed", "61", "--extreme")])
 def test_gpu_sweep_equals_generator(args):
     _sweep(*args, "--gpu")
