@@ -104,7 +104,7 @@ static void scale4x4(const h264o_decoder *d, const int16_t *scan, int list, int 
     for (int k = 0; k < 16; k++) {
         int r = h264o_zigzag4x4[k], c = scan[k];
         if (qp >= 24)
-            out[r] = (c * ls[r]) << (sh - 4);
+            out[r] = (c * ls[r]) * (1 << (sh - 4));
         else
             out[r] = (c * ls[r] + (1 << (3 - sh))) >> (4 - sh);
     }
@@ -536,7 +536,7 @@ static void recon_chroma_residual(h264o_decoder *d, h264o_mb *m, int intra) {
         int f[4] = {c0 + c1 + c2 + c3, c0 - c1 + c2 - c3, c0 + c1 - c2 - c3, c0 - c1 - c2 + c3};
         uint8_t *base = d->cur->plane[1 + cc] + (c->mby * 8) * d->cur->stride[1 + cc] + c->mbx * 8;
         for (int b = 0; b < 4; b++) {
-            int dc = ((f[b] * ls00) << (qp / 6)) >> 5;
+            int dc = ((f[b] * ls00) * (1 << (qp / 6))) >> 5;
             int blk[16], res[16];
             static const int16_t zero16[16] = {0};
             scale4x4(d, (c->cbp_chroma & 2) ? c->cac[cc][b] : zero16, list, qp, 1, dc, blk);
@@ -559,7 +559,7 @@ static void recon_luma_residual_blocks(h264o_decoder *d, h264o_mb *m, int intra)
             int sh = m->qp / 6;
             for (int k = 0; k < 64; k++) {
                 int r = h264o_zigzag8x8[k], v = c->luma8[b8][k];
-                blk[r] = m->qp >= 36 ? (v * ls[r]) << (sh - 6) : (v * ls[r] + (1 << (5 - sh))) >> (6 - sh);
+                blk[r] = m->qp >= 36 ? (v * ls[r]) * (1 << (sh - 6)) : (v * ls[r] + (1 << (5 - sh))) >> (6 - sh);
             }
             idct8x8(blk, res);
             add_block(base + (b8 >> 1) * 8 * stride + (b8 & 1) * 8, stride, res, 8);
@@ -611,7 +611,7 @@ void h264o_recon_mb(h264o_decoder *d, h264o_mb *m) {
                 int sh = m->qp / 6;
                 for (int k = 0; k < 64; k++) {
                     int r = h264o_zigzag8x8[k], v = c->luma8[b8][k];
-                    blk[r] = m->qp >= 36 ? (v * ls[r]) << (sh - 6) : (v * ls[r] + (1 << (5 - sh))) >> (6 - sh);
+                    blk[r] = m->qp >= 36 ? (v * ls[r]) * (1 << (sh - 6)) : (v * ls[r] + (1 << (5 - sh))) >> (6 - sh);
                 }
                 idct8x8(blk, res);
                 add_block(dst, sy, res, 8);
@@ -640,7 +640,7 @@ void h264o_recon_mb(h264o_decoder *d, h264o_mb *m) {
         int qp = m->qp, ls00 = d->level_scale4[0][qp % 6][0];
         for (int idx = 0; idx < 16; idx++) {
             int r = h264o_blk_raster(idx), bx = r & 3, by = r >> 2;
-            int dc = qp >= 36 ? (f[r] * ls00) << (qp / 6 - 6) : (f[r] * ls00 + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+            int dc = qp >= 36 ? (f[r] * ls00) * (1 << (qp / 6 - 6)) : (f[r] * ls00 + (1 << (5 - qp / 6))) >> (6 - qp / 6);
             int blk[16], res[16];
             static const int16_t zero16[16] = {0};
             scale4x4(d, (c->cbp_luma & (1 << (idx >> 2))) ? c->luma[idx] : zero16, 0, qp, 1, dc, blk);
@@ -677,7 +677,7 @@ static void filter_line(uint8_t *pix, int xs, int bS, int alpha, int beta, int t
             if (ap < beta) pix[-2 * xs] = (uint8_t)(p1 + h264o_clip3(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1));
             if (aq < beta) pix[xs] = (uint8_t)(q1 + h264o_clip3(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1));
         }
-        int delta = h264o_clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+        int delta = h264o_clip3(-tc, tc, (((q0 - p0) * 4) + (p1 - q1) + 4) >> 3);
         pix[-xs] = (uint8_t)h264o_clip1(p0 + delta);
         pix[0] = (uint8_t)h264o_clip1(q0 - delta);
     } else if (chroma) {
