@@ -53,10 +53,11 @@ static int activate(h264o_decoder *d, const h264o_pps *pps) {
         s->qpprime_y_zero_transform_bypass_flag)
         return h264o_fail(d, "unsupported SPS (need 4:2:0 8-bit, no MBAFF; chroma_format_idc=%d)", s->chroma_format_idc);
     int wmb = s->pic_width_in_mbs_minus1 + 1, hmb = (s->pic_height_in_map_units_minus1 + 1) * (2 - s->frame_mbs_only_flag); /* h264/slice.go:159-176 */
-    if (d->asps != s || wmb != d->wmb || hmb != d->hmb || !d->mb) {
+    if (d->asps != s || wmb != d->wmb || hmb != d->fhmb || !d->mb) {
         free_pics(d);
         d->wmb = wmb;
-        d->hmb = hmb;
+        d->hmb = d->fhmb = hmb;
+        d->pend = NULL;
         d->mb = (h264o_mb *)calloc((size_t)wmb * hmb, sizeof(h264o_mb));
         int n = (s->max_num_ref_frames > 0 ? s->max_num_ref_frames : 1) + 2;
         if (n > 20) n = 20;
@@ -69,6 +70,7 @@ static int activate(h264o_decoder *d, const h264o_pps *pps) {
             p->plane[2] = p->plane[1] + ysz / 4;
             p->stride[0] = wmb * 16;
             p->stride[1] = p->stride[2] = wmb * 8;
+            p->parity = -1;
         }
         d->n_pics = n;
     }
@@ -97,7 +99,7 @@ static int compute_poc(h264o_decoder *d, const h264o_slice_header *sh) {
         else
             msb = prev_msb;
         int top = msb + sh->pic_order_cnt_lsb, bot = top + sh->delta_pic_order_cnt_bottom;
-        poc = top < bot ? top : bot;
+        poc = sh->field_pic_flag ? top /* 8-4 / 8-5: a field has the one count */ : (top < bot ? top : bot);
         if (sh->nal_ref_idc) {
             d->prev_poc_msb = msb;
             d->prev_poc_lsb = sh->pic_order_cnt_lsb;
@@ -123,7 +125,10 @@ static int compute_poc(h264o_decoder *d, const h264o_slice_header *sh) {
             }
             if (!sh->nal_ref_idc) expected += s->offset_for_non_ref_pic;
             int top = expected + sh->delta_pic_order_cnt[0], bot = top + s->offset_for_top_to_bottom_field + sh->delta_pic_order_cnt[1];
-            poc = top < bot ? top : bot;
+            if (sh->field_pic_flag) /* 8-10: a bottom field is expected + offset_for_top_to_bottom_field + delta_pic_order_cnt[0] */
+                poc = sh->bottom_field_flag ? expected + s->offset_for_top_to_bottom_field + sh->delta_pic_order_cnt[0] : top;
+            else
+                poc = top < bot ? top : bot;
         } else
             poc = sh->idr_flag ? 0 : (sh->nal_ref_idc ? 2 * (fno + sh->frame_num) : 2 * (fno + sh->frame_num) - 1);
         d->prev_frame_num_offset = fno;
@@ -182,7 +187,7 @@ static int build_ref_list(h264o_decoder *d) {
     int nst = 0, nlt = 0;
     for (int i = 0; i < d->n_pics; i++) {
         h264o_pic *p = &d->pics[i];
-        if (p == d->cur) continue;
+        if (p == d->curf && !(d->field_pic && d->second_field && p->ref == 1)) continue; /* (a second field may predict from the first field of its frame) */
         if (p->ref == 1) {
             p->frame_num_wrap = p->frame_num > sh->frame_num ? p->frame_num - max_fn : p->frame_num;
             p->pic_num = p->frame_num_wrap;
@@ -196,6 +201,39 @@ static int build_ref_list(h264o_decoder *d) {
     memset(d->rpl1, 0, sizeof(d->rpl1));
     if (nst + nlt == 0) return h264o_fail(d, "P/B slice without reference pictures");
     int n0 = 0, n1 = 0;
+    if (d->field_pic) {
+        /* 8.2.4.2.2 + 8.2.4.2.5: frames by FrameNumWrap (long-term: LongTermFrameIdx), then their fields alternately, the parity
+         * of the current field first; a missing field is passed over, and when one parity is used up the other one follows in order */
+        if (sh->slice_type == 1) return h264o_fail(d, "B field pictures are out of scope");
+        if (sh->ref_pic_list_modification_flag_l0) return h264o_fail(d, "ref_pic_list_modification in field pictures is out of scope");
+        for (int i = 0; i < nst; i++)
+            for (int j = i + 1; j < nst; j++)
+                if (st[j]->frame_num_wrap > st[i]->frame_num_wrap) {
+                    h264o_pic *t = st[i];
+                    st[i] = st[j], st[j] = t;
+                }
+        for (int grp = 0; grp < 2; grp++) {
+            h264o_pic **fr = grp ? lt : st;
+            const int nfr = grp ? nlt : nst;
+            int a = 0, b = 0; /* next frame to look at for the same / the opposite parity */
+            for (int want_same = 1;; want_same ^= 1) {
+                int *cursor = want_same ? &a : &b;
+                const int par = want_same ? d->bottom : !d->bottom;
+                while (*cursor < nfr && !(fr[*cursor]->fields >> par & 1)) (*cursor)++;
+                if (*cursor == nfr) { /* this parity is used up: the rest of the other one */
+                    cursor = want_same ? &b : &a;
+                    const int opar = !par;
+                    for (; *cursor < nfr; (*cursor)++)
+                        if ((fr[*cursor]->fields >> opar & 1) && n0 < 32) d->rpl0[n0++] = &d->fviews[fr[*cursor] - d->pics][opar];
+                    break;
+                }
+                if (n0 < 32) d->rpl0[n0++] = &d->fviews[fr[*cursor] - d->pics][par];
+                (*cursor)++;
+            }
+        }
+        for (int i = nact0; i < 33; i++) d->rpl0[i] = NULL;
+        return 0;
+    }
     if (sh->slice_type != 1) { /* 8.2.4.2.1: P / SP -- PicNum descending, then LongTermPicNum ascending */
         qsort(st, nst, sizeof(st[0]), cmp_picnum_desc);
         for (int i = 0; i < nst && n0 < 32; i++) d->rpl0[n0++] = st[i];
@@ -241,9 +279,11 @@ static int build_ref_list(h264o_decoder *d) {
 /* ------------------------------------------------------------------ 8.2.5 decoded reference picture marking */
 static void mark_reference(h264o_decoder *d) {
     const h264o_slice_header *sh = &d->first_sh;
-    h264o_pic *cur = d->cur;
+    h264o_pic *cur = d->curf;
     int max_fn = 1 << (d->asps->log2_max_frame_num_minus4 + 4);
-    if (sh->nal_ref_idc) d->prev_ref_frame_num = sh->frame_num; /* 7.4.3 (operation 5 below: 0) */
+    if (sh->nal_ref_idc) d->prev_ref_frame_num = sh->frame_num;
+    /* 8.2.5.3: the second field of a frame whose first field is a short-term reference joins it, nothing leaves the window */
+    if (d->field_pic && d->second_field && cur->ref) return; /* 7.4.3 (operation 5 below: 0) */
     if (!sh->nal_ref_idc) {
         cur->ref = 0;
         d->feat |= 1u << 12;
@@ -323,9 +363,10 @@ static void mark_reference(h264o_decoder *d) {
     }
 }
 
+static h264o_pic *make_view(h264o_decoder *d, h264o_pic *p, int parity, int poc);
+
 /* ------------------------------------------------------------------ picture output */
-static void emit_frame(h264o_decoder *d) {
-    h264o_pic *p = d->cur;
+static void emit_frame(h264o_decoder *d, h264o_pic *p) {
     const h264o_sps *s = d->asps;
     int cw = d->info.coded_width, ch = d->info.coded_height;
     int w = d->crop ? d->info.width : cw, h = d->crop ? d->info.height : ch;
@@ -350,23 +391,51 @@ static void finish_picture(h264o_decoder *d) {
     /* conceal MBs never covered by a slice (not expected in scope): copy nothing, leave as is */
     h264o_deblock_picture(d);
     mark_reference(d);
-    if (d->cur->ref) { /* a later B picture may use this one as its co-located picture (RefPicList1[0]) */
-        if (d->cur->n_mbs != d->wmb * d->hmb) {
-            free(d->cur->mbs);
-            d->cur->mbs = (h264o_mb *)malloc(sizeof(h264o_mb) * (size_t)d->wmb * d->hmb);
-            d->cur->n_mbs = d->wmb * d->hmb;
-        }
-        memcpy(d->cur->mbs, d->mb, sizeof(h264o_mb) * (size_t)d->wmb * d->hmb);
+    h264o_pic *f = d->curf;
+    if (d->field_pic) {
+        /* a field: the frame goes out when its second field is done -- or, for a field that stays single, when the next picture starts */
+        f->fields |= 1 << d->bottom;
+        f->fpoc[d->bottom] = d->cur->poc;
+        f->n_mbs = 0; /* (no co-located motion kept: B pictures cannot take a field-coded frame as RefPicList1[0] here) */
+        d->cur = d->curf = NULL;
+        if (f->fields == 3) {
+            f->poc = f->fpoc[0] < f->fpoc[1] ? f->fpoc[0] : f->fpoc[1];
+            emit_frame(d, f);
+            f->in_use = 0;
+            d->pend = NULL;
+        } else
+            d->pend = f;
+        return;
     }
-    emit_frame(d);
-    d->cur->in_use = 0;
-    d->cur = NULL;
+    f->fields = 3, f->fpoc[0] = f->fpoc[1] = f->poc;
+    if (!d->asps->frame_mbs_only_flag) make_view(d, f, 0, f->poc), make_view(d, f, 1, f->poc); /* later field pictures may predict from its fields */
+    if (f->ref) { /* a later B picture may use this one as its co-located picture (RefPicList1[0]) */
+        if (f->n_mbs != d->wmb * d->hmb) {
+            free(f->mbs);
+            f->mbs = (h264o_mb *)malloc(sizeof(h264o_mb) * (size_t)d->wmb * d->hmb);
+            f->n_mbs = d->wmb * d->hmb;
+        }
+        memcpy(f->mbs, d->mb, sizeof(h264o_mb) * (size_t)d->wmb * d->hmb);
+    }
+    emit_frame(d, f);
+    f->in_use = 0;
+    d->cur = d->curf = NULL;
+}
+/* a first field whose second field did not come: the frame goes out with one field decoded (the other half keeps the grey it was given) */
+static void flush_pending_field(h264o_decoder *d) {
+    h264o_pic *f = d->pend;
+    if (!f) return;
+    f->poc = f->fpoc[f->fields == 2];
+    emit_frame(d, f);
+    f->in_use = 0;
+    d->pend = NULL;
 }
 
 /* 7.4.1.2.4 first VCL NAL of a new primary coded picture */
 static int is_new_picture(const h264o_decoder *d, const h264o_slice_header *a, const h264o_slice_header *b) {
     if (a->frame_num != b->frame_num || a->pic_parameter_set_id != b->pic_parameter_set_id) return 1;
     if ((a->nal_ref_idc == 0) != (b->nal_ref_idc == 0)) return 1;
+    if (a->field_pic_flag != b->field_pic_flag || a->bottom_field_flag != b->bottom_field_flag) return 1;
     if (a->idr_flag != b->idr_flag) return 1;
     if (a->idr_flag && a->idr_pic_id != b->idr_pic_id) return 1;
     if (d->asps->pic_order_cnt_type == 0 &&
@@ -427,26 +496,60 @@ static int fill_frame_num_gap(h264o_decoder *d) {
     return 0;
 }
 
+/* the rows of one parity of a frame store as a picture of their own (h264o_decoder::fviews) */
+static h264o_pic *make_view(h264o_decoder *d, h264o_pic *p, int parity, int poc) {
+    h264o_pic *v = &d->fviews[p - d->pics][parity];
+    memset(v, 0, sizeof(*v));
+    for (int i = 0; i < 3; i++) v->plane[i] = p->plane[i] + (size_t)parity * p->stride[i], v->stride[i] = 2 * p->stride[i];
+    v->parity = parity, v->poc = poc, v->frame_num = p->frame_num, v->ref = 1;
+    v->id = d->next_pic_id++;
+    return v;
+}
+
 static int start_picture(h264o_decoder *d) {
-    if (fill_frame_num_gap(d) < 0) return -1;
+    const h264o_slice_header *sh = &d->sh;
+    d->field_pic = sh->field_pic_flag, d->bottom = sh->bottom_field_flag;
+    d->hmb = d->field_pic ? d->fhmb / 2 : d->fhmb;
+    d->scan4 = d->field_pic ? h264o_fieldscan4x4 : h264o_zigzag4x4;
+    d->scan8 = d->field_pic ? h264o_fieldscan8x8 : h264o_zigzag8x8;
+    /* the second field of the frame whose first field was the previous picture (7.4.1.2.4, 3.30 / 3.31): opposite parity, same frame_num,
+     * not an IDR picture, reference or not like the first one */
     h264o_pic *p = NULL;
-    for (int i = 0; i < d->n_pics; i++)
-        if (!d->pics[i].ref && !d->pics[i].in_use) {
-            p = &d->pics[i];
-            break;
-        }
-    if (!p) return h264o_fail(d, "DPB full");
-    d->cur = p;
-    p->in_use = 1;
-    p->nonexisting = 0;
-    p->id = d->next_pic_id++;
-    p->frame_num = d->sh.frame_num;
-    p->poc = compute_poc(d, &d->sh);
+    d->second_field = 0;
+    if (d->pend) {
+        h264o_pic *f = d->pend;
+        if (d->field_pic && !sh->idr_flag && f->fields == (d->bottom ? 1 : 2) && f->frame_num == sh->frame_num && (f->ref != 0) == (sh->nal_ref_idc != 0)) {
+            p = f;
+            d->second_field = 1;
+            d->pend = NULL;
+        } else
+            flush_pending_field(d);
+    }
+    if (!p) {
+        if (fill_frame_num_gap(d) < 0) return -1;
+        for (int i = 0; i < d->n_pics; i++)
+            if (!d->pics[i].ref && !d->pics[i].in_use) {
+                p = &d->pics[i];
+                break;
+            }
+        if (!p) return h264o_fail(d, "DPB full");
+        p->in_use = 1;
+        p->nonexisting = 0;
+        p->fields = 0;
+        p->id = d->next_pic_id++;
+        p->frame_num = sh->frame_num;
+        /* deterministic content for MBs that no slice covers (and for the field that may never come) */
+        memset(p->plane[0], 128, (size_t)d->wmb * 16 * d->fhmb * 16 * 3 / 2);
+    }
+    d->curf = d->cur = p;
+    const int poc = compute_poc(d, sh);
+    if (d->field_pic) /* reconstruct through the view of this parity */
+        d->cur = make_view(d, p, d->bottom, poc);
+    else
+        p->poc = poc;
     if (d->sh.slice_qp_delta) d->feat |= 1u << 13;
     if (d->asps->pic_order_cnt_type == 1 && d->sh.delta_pic_order_cnt[0]) d->feat |= 1u << 14;
     for (int i = 0; i < d->wmb * d->hmb; i++) d->mb[i].type = MBT_NONE;
-    /* deterministic content for MBs that no slice covers */
-    memset(p->plane[0], 128, (size_t)d->wmb * 16 * d->hmb * 16 * 3 / 2);
     d->first_sh = d->sh;
     d->slice_id = 0;
     d->n_first_mbs = 0;
@@ -455,7 +558,7 @@ static int start_picture(h264o_decoder *d) {
     d->sgmap = NULL;
     if (d->apps->num_slice_groups_minus1 > 0) {
         d->sgmap = (uint8_t *)malloc((size_t)d->wmb * d->hmb);
-        if (h264o_mb_to_slice_group_map(d->asps, d->apps, d->sg_ids[d->apps->pic_parameter_set_id], d->sh.slice_group_change_cycle, 0, d->sgmap) != d->wmb * d->hmb)
+        if (h264o_mb_to_slice_group_map(d->asps, d->apps, d->sg_ids[d->apps->pic_parameter_set_id], d->sh.slice_group_change_cycle, d->field_pic, d->sgmap) != d->wmb * d->hmb)
             return h264o_fail(d, "slice group map: bad PPS %d", d->apps->pic_parameter_set_id);
     }
     return 0;
@@ -466,7 +569,12 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
     h264o_slice_header sh;
     int r = h264o_parse_slice_header(&d->br, nal->nal_ref_idc, nal->nal_unit_type, d->sps, d->pps, &sh);
     if (r < 0) return h264o_fail(d, "slice header parse error %d", r);
-    if (sh.field_pic_flag) return h264o_fail(d, "field pictures are out of scope");
+    /* field pictures (PAFF): I and P fields, CAVLC, sliding-window marking and initial lists.  Out of scope for now: CABAC (the context
+     * tables of field-coded blocks, ctxIdx 277..398 and 436..459, are not in this tree), B fields, list modification and marking scripts */
+    if (sh.field_pic_flag) {
+        if (d->pps[sh.pic_parameter_set_id].entropy_coding_mode_flag) return h264o_fail(d, "field pictures with CABAC are out of scope");
+        if (sh.adaptive_ref_pic_marking_mode_flag) return h264o_fail(d, "marking scripts in field pictures are out of scope");
+    }
     if (sh.slice_type > 2) return h264o_fail(d, "slice_type %d out of scope (I, P and B only)", sh.slice_type);
     if (sh.redundant_pic_cnt > 0) return 0; /* redundant coded pictures are ignored */
     const h264o_pps *pps = &d->pps[sh.pic_parameter_set_id];
@@ -476,6 +584,7 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
     int restarts = 0;
     for (int i = 0; i < d->n_first_mbs; i++) restarts |= d->first_mbs[i] == sh.first_mb_in_slice;
     if (d->cur && (restarts || is_new_picture(d, &d->first_sh, &sh))) finish_picture(d);
+    if (!d->cur && d->pend && (d->asps != &d->sps[pps->seq_parameter_set_id])) flush_pending_field(d); /* (before the frame store may be rebuilt) */
     if (activate(d, pps) < 0) return -1;
     d->sh = sh;
     if (sh.slice_qp_delta) d->feat |= 1u << 13;
@@ -503,8 +612,8 @@ int h264o_decode_stream(h264o_decoder *d, const uint8_t *buf, size_t len, int cr
     d->out_pos = 0;
     d->trace_pos = 0;
     d->feat = 0, d->n_pocs = 0;
-    for (int i = 0; i < d->n_pics; i++) d->pics[i].ref = 0, d->pics[i].in_use = 0;
-    d->cur = NULL;
+    for (int i = 0; i < d->n_pics; i++) d->pics[i].ref = 0, d->pics[i].in_use = 0, d->pics[i].fields = 0;
+    d->cur = d->curf = d->pend = NULL;
     for (int i = 0; i < n && !d->info.error; i++) {
         const h264o_nal *nal = &nals[i];
         if (nal->size > d->rbsp_cap) {
@@ -556,6 +665,7 @@ int h264o_decode_stream(h264o_decoder *d, const uint8_t *buf, size_t len, int cr
         }
     }
     if (d->cur && !d->info.error) finish_picture(d);
+    if (!d->info.error) flush_pending_field(d);
     free(nals);
     if (info) *info = d->info;
     if (d->info.error) return -1;

@@ -18,6 +18,9 @@ typedef struct {
     int long_term_frame_idx;
     int id; /* unique, increasing */
     int in_use;
+    /* field pictures (PAFF): which fields of the frame are decoded (bit 0 top, bit 1 bottom; a frame picture sets both) and their
+     * PicOrderCnt; parity = -1 for a frame, 0 / 1 for the field views (h264o_decoder::fviews) that the lists of field pictures hold */
+    int fields, fpoc[2], parity;
     struct h264o_mb_s *mbs; /* motion of the decoded picture (co-located data for direct prediction, 8.4.1.2) */
     int n_mbs;
 } h264o_pic;
@@ -65,10 +68,19 @@ struct h264o_decoder {
     int first_mbs[1024], n_first_mbs; /* first_mb_in_slice of the slices of the current picture */
     const h264o_sps *asps;
     const h264o_pps *apps;
-    int wmb, hmb;
+    int wmb, hmb;   /* of the current PICTURE: hmb = fhmb for a frame, fhmb / 2 for a field */
+    int fhmb;       /* macroblock rows of a frame */
     h264o_pic pics[20];
+    /* field views of pics[]: the same samples with the rows of one parity only (plane + parity * stride, stride * 2), their own
+     * id and PicOrderCnt -- a field picture is decoded, and predicted from, through these, so that the reconstruction code sees
+     * an ordinary picture of half the height */
+    h264o_pic fviews[20][2];
     int n_pics;
-    h264o_pic *cur;
+    h264o_pic *cur;  /* what is being reconstructed: the frame, or the view of the current field */
+    h264o_pic *curf; /* the frame it belongs to (== cur for a frame picture): what marking, lists and output deal with */
+    h264o_pic *pend; /* a frame whose first field is decoded and whose second may follow */
+    int field_pic, bottom, second_field; /* of the current picture */
+    const uint8_t *scan4, *scan8; /* coefficient scans of the current picture: zig-zag or field (8.5.6, 8.5.7) */
     int next_pic_id;
     h264o_mb *mb;
     /* POC state (8.2.1) */
@@ -107,6 +119,8 @@ struct h264o_decoder {
     int n_pocs;
 };
 
+/* field scans (Table 8-12 / 8-13, field columns) as raster positions (recon.c) */
+extern const uint8_t h264o_fieldscan4x4[16], h264o_fieldscan8x8[64];
 /* entropy.c */
 int h264o_decode_slice_data(h264o_decoder *d);
 void h264o_cabac_init_engine(h264o_decoder *d);

@@ -102,7 +102,7 @@ static void scale4x4(const h264o_decoder *d, const int16_t *scan, int list, int 
     const int *ls = d->level_scale4[list][qp % 6];
     int sh = qp / 6;
     for (int k = 0; k < 16; k++) {
-        int r = h264o_zigzag4x4[k], c = scan[k];
+        int r = d->scan4[k], c = scan[k];
         if (qp >= 24)
             out[r] = (c * ls[r]) * (1 << (sh - 4));
         else
@@ -471,6 +471,9 @@ static void inter_pred_mb(h264o_decoder *d, h264o_mb *m) {
                 for (int x = 0; x < 4; x++)
                     py[l][y * 4 + x] = luma_sample(rp[l]->plane[0], rp[l]->stride[0], W, H, x0 + x + (mvx >> 2), y0 + y + (mvy >> 2), mvx & 3, mvy & 3);
             /* chroma 8.4.2.2.2: 2x2 samples per 4x4 luma block, mv in 1/8 chroma sample units */
+            /* field pictures (Table 8-9): a reference field of the other parity lies half a frame row away -- the chroma vector moves by
+             * a quarter chroma sample, down when the bottom field predicts from a top field, up the other way round */
+            if (d->field_pic && rp[l]->parity >= 0 && rp[l]->parity != d->bottom) mvy += d->bottom ? 2 : -2;
             int xf = mvx & 7, yf = mvy & 7;
             for (int pl = 1; pl < 3; pl++) {
                 const uint8_t *rc = rp[l]->plane[pl];
@@ -558,7 +561,7 @@ static void recon_luma_residual_blocks(h264o_decoder *d, h264o_mb *m, int intra)
             const int *ls = d->level_scale8[intra ? 0 : 1][m->qp % 6];
             int sh = m->qp / 6;
             for (int k = 0; k < 64; k++) {
-                int r = h264o_zigzag8x8[k], v = c->luma8[b8][k];
+                int r = d->scan8[k], v = c->luma8[b8][k];
                 blk[r] = m->qp >= 36 ? (v * ls[r]) * (1 << (sh - 6)) : (v * ls[r] + (1 << (5 - sh))) >> (6 - sh);
             }
             idct8x8(blk, res);
@@ -610,7 +613,7 @@ void h264o_recon_mb(h264o_decoder *d, h264o_mb *m) {
                 const int *ls = d->level_scale8[0][m->qp % 6];
                 int sh = m->qp / 6;
                 for (int k = 0; k < 64; k++) {
-                    int r = h264o_zigzag8x8[k], v = c->luma8[b8][k];
+                    int r = d->scan8[k], v = c->luma8[b8][k];
                     blk[r] = m->qp >= 36 ? (v * ls[r]) * (1 << (sh - 6)) : (v * ls[r] + (1 << (5 - sh))) >> (6 - sh);
                 }
                 idct8x8(blk, res);
@@ -622,7 +625,7 @@ void h264o_recon_mb(h264o_decoder *d, h264o_mb *m) {
         if (intra16x16_pred(d, Y, sy, c->i16mode) < 0) h264o_fail(d, "mb %d: Intra16x16 mode %d needs unavailable samples", c->addr, c->i16mode);
         /* 8.5.10: DC Hadamard + scaling */
         int cm[16], f[16], t[16];
-        for (int k = 0; k < 16; k++) cm[h264o_zigzag4x4[k]] = c->i16dc[k];
+        for (int k = 0; k < 16; k++) cm[d->scan4[k]] = c->i16dc[k];
         for (int i = 0; i < 4; i++) { /* rows: A * c */
             int a = cm[i * 4 + 0], b = cm[i * 4 + 1], cc = cm[i * 4 + 2], dd = cm[i * 4 + 3];
             t[i * 4 + 0] = a + b + cc + dd;
@@ -705,9 +708,12 @@ static void filter_line(uint8_t *pix, int xs, int bS, int alpha, int beta, int t
 }
 
 /* 8.7.2.1 bS for the 4-sample segment between 4x4 blocks pb (in MB mp) and qb (in MB mq) */
-static int mv_far(const int16_t *a, const int16_t *b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
-static int edge_bs(const h264o_mb *mp, int pb, const h264o_mb *mq, int qb, int mb_edge) {
-    if (MB_IS_INTRA(mp->type) || MB_IS_INTRA(mq->type)) return mb_edge ? 4 : 3;
+/* (field macroblocks: the vertical limit of 4 quarter FRAME samples is 2 quarter field samples) */
+static int g_mvy_limit = 4;
+static int mv_far(const int16_t *a, const int16_t *b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= g_mvy_limit; }
+static int edge_bs(const h264o_mb *mp, int pb, const h264o_mb *mq, int qb, int mb_edge, int field_horizontal) {
+    /* bS 4 needs a macroblock edge that is vertical, or lies between frame macroblocks: the horizontal edges of a field picture get 3 */
+    if (MB_IS_INTRA(mp->type) || MB_IS_INTRA(mq->type)) return mb_edge && !field_horizontal ? 4 : 3;
     if (((mp->nzmask >> pb) & 1) || ((mq->nzmask >> qb) & 1)) return 2;
     /* different reference pictures or a different number of motion vectors; which list a picture is referenced through does not matter */
     int p8 = (pb >> 3) * 2 + ((pb & 3) >> 1), q8 = (qb >> 3) * 2 + ((qb & 3) >> 1);
@@ -745,7 +751,7 @@ static void deblock_mb(h264o_decoder *d, int mbx, int mby) {
             for (int k = 0; k < 4; k++) {
                 int qb = dir == 0 ? k * 4 + e : e * 4 + k;
                 int pb = dir == 0 ? k * 4 + (e == 0 ? 3 : e - 1) : (e == 0 ? 3 : e - 1) * 4 + k;
-                bS[k] = edge_bs(mp, pb, mq, qb, e == 0);
+                bS[k] = edge_bs(mp, pb, mq, qb, e == 0, d->field_pic && dir == 1);
             }
             if (!(bS[0] | bS[1] | bS[2] | bS[3])) continue;
             /* luma */
@@ -785,6 +791,22 @@ static void deblock_mb(h264o_decoder *d, int mbx, int mby) {
  * NOTE: in an MB with transform_size_8x8_flag the odd luma edges are skipped above, but the chroma
  * edge at chroma sample 4 (luma edge 2) is still filtered. */
 void h264o_deblock_picture(h264o_decoder *d) {
+    g_mvy_limit = d->field_pic ? 2 : 4;
     for (int mby = 0; mby < d->hmb; mby++)
         for (int mbx = 0; mbx < d->wmb; mbx++) deblock_mb(d, mbx, mby);
 }
+
+/* Table 8-12, field scan: down the first column, then column by column with the first two rows leading */
+const uint8_t h264o_fieldscan4x4[16] = {0, 4, 1, 8, 12, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15};
+#define P8(r, c) ((r) * 8 + (c))
+/* Table 8-13, field scan: idx -> position, written as (row, column) */
+const uint8_t h264o_fieldscan8x8[64] = {
+    P8(0, 0), P8(1, 0), P8(2, 0), P8(0, 1), P8(1, 1), P8(3, 0), P8(4, 0), P8(2, 1),
+    P8(0, 2), P8(3, 1), P8(5, 0), P8(6, 0), P8(7, 0), P8(4, 1), P8(1, 2), P8(0, 3),
+    P8(2, 2), P8(5, 1), P8(6, 1), P8(7, 1), P8(3, 2), P8(1, 3), P8(0, 4), P8(2, 3),
+    P8(4, 2), P8(5, 2), P8(6, 2), P8(7, 2), P8(3, 3), P8(1, 4), P8(0, 5), P8(2, 4),
+    P8(4, 3), P8(5, 3), P8(6, 3), P8(7, 3), P8(3, 4), P8(1, 5), P8(0, 6), P8(2, 5),
+    P8(4, 4), P8(5, 4), P8(6, 4), P8(7, 4), P8(3, 5), P8(1, 6), P8(2, 6), P8(4, 5),
+    P8(5, 5), P8(6, 5), P8(7, 5), P8(3, 6), P8(0, 7), P8(1, 7), P8(4, 6), P8(5, 6),
+    P8(6, 6), P8(7, 6), P8(2, 7), P8(3, 7), P8(4, 7), P8(5, 7), P8(6, 7), P8(7, 7)};
+#undef P8

@@ -36,7 +36,8 @@ typedef struct {
 typedef struct {
     sg_params p;
     int wmb, hmb, W, H;
-    sg_pic pics[6];
+    sg_pic pics[12];  /* frame pictures use the first 6; field pictures (two per frame) all of them */
+    int field, bottom, fH; /* field_pics: coding a field picture, its parity, the coded FRAME height (W x H is then one field) */
     sg_pic *cur, *refs[4];
     sg_pic *refs1[4];             /* RefPicList1 of a B picture */
     int nref1_active, cur_poc;
@@ -1099,7 +1100,9 @@ static void mc_part(enc *e, int bx, int by, int w, int h, uint8_t *py, uint8_t p
     sg_pic *rp = e->refs[ref];
     int mvx = m->mv[by * 4 + bx][0], mvy = m->mv[by * 4 + bx][1];
     sg_mc_luma(rp, e->mbx * 16 + bx * 4, e->mby * 16 + by * 4, w * 4, h * 4, mvx, mvy, py + by * 4 * 16 + bx * 4, 16);
-    for (int c = 0; c < 2; c++) sg_mc_chroma(rp, 1 + c, e->mbx * 8 + bx * 2, e->mby * 8 + by * 2, w * 2, h * 2, mvx, mvy, pc[c] + by * 2 * 8 + bx * 2, 8);
+    /* Table 8-9: predicting from a field of the other parity shifts the chroma vector by a quarter chroma sample */
+    const int cofs = !e->field || rp->parity == e->bottom ? 0 : (e->bottom ? 2 : -2);
+    for (int c = 0; c < 2; c++) sg_mc_chroma(rp, 1 + c, e->mbx * 8 + bx * 2, e->mby * 8 + by * 2, w * 2, h * 2, mvx, mvy + cofs, pc[c] + by * 2 * 8 + bx * 2, 8);
     if (e->p.weighted_pred) {
         int ld = e->wp_ld, w0 = e->wp_w[ref], o0 = e->wp_o[ref];
         for (int y = by * 4; y < (by + h) * 4; y++)
@@ -1720,7 +1723,7 @@ static size_t write_sps(enc *e, uint8_t *dst, size_t cap) {
     sg_bw_init(&w, buf, sizeof(buf));
     sg_put(&w, (uint32_t)p->profile_idc, 8);
     sg_put(&w, p->profile_idc == 66 ? 0xC0 : (p->profile_idc == 77 ? 0x40 : 0), 8); /* constraint_set flags */
-    sg_put(&w, e->W * e->H > 1920 * 1088 ? 51 : 40, 8);                            /* level_idc */
+    sg_put(&w, e->W * (p->field_pics ? e->fH : e->H) > 1920 * 1088 ? 51 : 40, 8);                            /* level_idc */
     sg_put_ue(&w, 0);                                                              /* sps id */
     if (p->profile_idc == 100) {
         sg_put_ue(&w, 1); /* chroma_format_idc */
@@ -1752,7 +1755,7 @@ static size_t write_sps(enc *e, uint8_t *dst, size_t cap) {
     sg_put(&w, p->fn_gap_declared != 0, 1); /* gaps_in_frame_num_value_allowed_flag */
     sg_put_ue(&w, (uint32_t)(e->wmb - 1));
     if (p->interlace_sps) { /* map units of two macroblock rows; crop units of four luma rows (7.4.2.1.1) */
-        sg_put_ue(&w, (uint32_t)(e->hmb / 2 - 1));
+        sg_put_ue(&w, (uint32_t)(e->p.field_pics ? e->hmb - 1 : e->hmb / 2 - 1)); /* (field_pics: e->hmb counts the rows of one field) */
         sg_put(&w, 0, 1); /* frame_mbs_only_flag */
         sg_put(&w, 0, 1); /* mb_adaptive_frame_field_flag */
     } else {
@@ -1760,7 +1763,7 @@ static size_t write_sps(enc *e, uint8_t *dst, size_t cap) {
         sg_put(&w, 1, 1); /* frame_mbs_only */
     }
     sg_put(&w, 1, 1); /* direct_8x8_inference */
-    int cr = (e->W - p->width) / 2, cb = (e->H - p->height) / (p->interlace_sps ? 4 : 2);
+    int cr = (e->W - p->width) / 2, cb = ((p->field_pics ? e->fH : e->H) - p->height) / (p->interlace_sps ? 4 : 2);
     sg_put(&w, cr || cb, 1);
     if (cr || cb) {
         sg_put_ue(&w, 0);
@@ -1916,7 +1919,8 @@ static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int
     sg_put_ue(w, is_b ? 6 : (is_p ? 5 : 7)); /* slice_type: all slices of the picture alike */
     sg_put_ue(w, 0);
     sg_put(w, (uint32_t)frame_num, 8);
-    if (p->interlace_sps) sg_put(w, 0, 1); /* field_pic_flag */
+    if (p->interlace_sps) sg_put(w, (uint32_t)e->field, 1); /* field_pic_flag */
+    if (e->field) sg_put(w, (uint32_t)e->bottom, 1);    /* bottom_field_flag */
     if (idr) sg_put_ue(w, (uint32_t)idr_id);
     if (p->poc_type == 0) sg_put(w, (uint32_t)poc_lsb, 8);
     if (p->poc_type == 1) sg_put_se(w, e->delta_poc0); /* delta_pic_order_cnt[0] (delta_pic_order_always_zero_flag = 0) */
@@ -2260,6 +2264,60 @@ static void apply_marking(enc *e, const mark_state *m, int idr) {
     e->cur->is_ref = 1;
 }
 
+/* ------------------------------------------------------------------ field pictures (sg_params::field_pics)
+ * RefPicList0 of a P field (8.2.4.2.2 + 8.2.4.2.5): the reference FRAMES in descending FrameNumWrap order -- the frame of
+ * the current field included when its first field is a reference --, then fields taken from them alternately, starting with
+ * the parity of the current field; a frame that lacks the wanted parity is passed over, and when one parity runs out the
+ * rest of the other follows in order. */
+static void plan_field_list(enc *e) {
+    sg_pic *same[12], *opp[12], *all[12];
+    int n = 0, ns = 0, no = 0, cur_fn = e->cur_frame_num;
+    for (int i = 0; i < 12; i++)
+        if (&e->pics[i] != e->cur && e->pics[i].is_ref == 1) all[n++] = &e->pics[i];
+    for (int i = 0; i < n; i++) /* frames by FrameNumWrap, most recent first (both fields of a frame carry the same frame_num) */
+        for (int j = i + 1; j < n; j++)
+            if (picnum(all[j], cur_fn) > picnum(all[i], cur_fn)) {
+                sg_pic *t = all[i];
+                all[i] = all[j], all[j] = t;
+            }
+    for (int i = 0; i < n; i++)
+        if (all[i]->parity == e->bottom) same[ns++] = all[i];
+        else opp[no++] = all[i];
+    sg_pic *list[24];
+    int nl = 0, a = 0, b = 0;
+    while (a < ns && b < no) list[nl++] = same[a++], list[nl++] = opp[b++];
+    while (a < ns) list[nl++] = same[a++];
+    while (b < no) list[nl++] = opp[b++];
+    e->nrefs = nl;
+    e->nref_active = nl < 4 ? nl : 4;
+    if (e->nref_active > 1 && rnd(e) % 4 == 0) e->nref_active = 1 + (int)(rnd(e) % (uint32_t)e->nref_active); /* a shorter list now and then */
+    e->n_rplm = 0;
+    for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? list[i] : NULL;
+}
+/* Sliding window with fields (8.2.5.3): the window counts FRAMES; the first field of a frame pushes the oldest frame out
+ * (both its fields), the second field of a reference frame just joins its first field. */
+static void apply_field_marking(enc *e, int second, int idr) {
+    if (idr)
+        for (int i = 0; i < 12; i++) e->pics[i].is_ref = 0;
+    else if (!second) {
+        int fids[12], nf = 0, oldest = -1;
+        for (int i = 0; i < 12; i++) {
+            sg_pic *q = &e->pics[i];
+            if (q == e->cur || !q->is_ref) continue;
+            int seen = 0;
+            for (int k = 0; k < nf; k++) seen |= fids[k] == q->fid;
+            if (!seen) fids[nf++] = q->fid;
+            if (oldest < 0 || picnum(q, e->cur_frame_num) < picnum(&e->pics[oldest], e->cur_frame_num)) oldest = i;
+        }
+        if (nf >= e->p.num_ref_frames && oldest >= 0) {
+            const int fid = e->pics[oldest].fid;
+            for (int i = 0; i < 12; i++)
+                if (e->pics[i].fid == fid && &e->pics[i] != e->cur) e->pics[i].is_ref = 0;
+        }
+    }
+    e->cur->is_ref = 1;
+}
+
 /* ------------------------------------------------------------------ top level */
 size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *recon, size_t recon_cap, uint32_t *frame_sizes) {
     enc *e = (enc *)calloc(1, sizeof(enc));
@@ -2283,12 +2341,26 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         if (p->b_pyramid) p->num_ref_frames = 4; /* two anchors, the reference B picture of this group and the one of the group before */
     } else
         p->b_pyramid = 0;
+    if (p->field_pics) { /* PAFF, every frame as two fields: see sg.h for what that excludes */
+        if (p->cabac || p->profile_idc == 66) {
+            snprintf(g_err, sizeof(g_err), "field_pics needs Main or High profile with cabac = 0 (the field-coded CABAC context tables are not in this tree)");
+            free(e);
+            return 0;
+        }
+        p->interlace_sps = 1, p->bframes = 0, p->b_pyramid = 0, p->mmco = 0, p->rplm = 0, p->idr_long_term = 0, p->nonref_period = 0;
+        p->fn_gap_period = 0, p->slice_groups = 0, p->aso = 0;
+    }
     e->W = (p->width + 15) & ~15, e->H = (p->height + 15) & ~15;
     e->wmb = e->W / 16, e->hmb = e->H / 16;
     if (p->interlace_sps && ((e->hmb & 1) || ((e->H - p->height) & 3))) {
         snprintf(g_err, sizeof(g_err), "interlace_sps needs an even number of macroblock rows and a height whose padding is a multiple of 4");
+        free(e);
         return 0;
     }
+    e->fH = e->H;
+    const size_t frame_bytes = (size_t)e->W * e->fH * 3 / 2;
+    if (p->field_pics) e->H /= 2, e->hmb /= 2; /* from here on a "picture" is one field: W x H, hmb macroblock rows */
+    sg_set_field_mode(p->field_pics != 0);
     if (p->slices > e->hmb) p->slices = e->hmb;
     if (p->slice_groups < 2) p->slice_groups = 0;
     if (p->slice_groups > 8) p->slice_groups = 8;
@@ -2299,15 +2371,16 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
     e->rng = 0x9E3779B97F4A7C15ull ^ ((uint64_t)p->seed * 0xD1B54A32D192ED03ull);
     if (!e->rng) e->rng = 1;
     size_t fsz = (size_t)e->W * e->H * 3 / 2;
-    for (int i = 0; i < 6; i++) {
+    for (int i = 0; i < 12; i++) {
         e->pics[i].pl[0] = (uint8_t *)malloc(fsz);
         e->pics[i].pl[1] = e->pics[i].pl[0] + e->W * e->H;
         e->pics[i].pl[2] = e->pics[i].pl[1] + e->W * e->H / 4;
-        e->pics[i].w = e->W, e->pics[i].h = e->H;
+        e->pics[i].w = e->W, e->pics[i].h = e->H, e->pics[i].fid = -1;
     }
     e->mb = (emb *)calloc((size_t)e->wmb * e->hmb, sizeof(emb));
     e->db = (sg_dbmb *)calloc((size_t)e->wmb * e->hmb, sizeof(sg_dbmb));
     e->src = (uint8_t *)malloc(fsz);
+    uint8_t *frame_src = p->field_pics ? (uint8_t *)malloc(frame_bytes) : NULL;
     size_t slice_cap = fsz * 2 + 4096;
     uint8_t *rbsp = (uint8_t *)malloc(slice_cap);
     /* scaling lists: flat, or the spec's Default_* lists when scaling_matrix is set */
@@ -2352,9 +2425,26 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
     for (int t = 0; t < p->frames; t++) {
         size_t au_start = out;
         const int dsp = disp[t], bpic = is_b[t];
-        int idr = dsp == 0 || (p->idr_period > 0 && dsp % p->idr_period == 0);
-        sg_source_frame(p, dsp, e->src);
-        if (idr) idr_disp = dsp;
+        const int idr_frame = dsp == 0 || (p->idr_period > 0 && dsp % p->idr_period == 0);
+        if (idr_frame) idr_disp = dsp;
+        mark_state ms;
+        sg_pic *first_field = NULL;
+      for (int fld = 0; fld < (p->field_pics ? 2 : 1); fld++) { /* the picture(s) of frame t: the frame, or its two fields */
+        /* only the first field of an IDR frame is an IDR picture; the second one is a P field (it may predict from the first) or an I field */
+        const int idr = idr_frame && fld == 0, intra_pic = idr || (idr_frame && fld == 1 && (p->seed + (unsigned)t) % 3 == 0);
+        e->field = p->field_pics != 0, e->bottom = p->field_pics ? (p->field_pics == 2) ^ fld : 0;
+        if (!e->field)
+            sg_source_frame(p, dsp, e->src);
+        else { /* the lines of this parity, planes back to back at field size */
+            if (fld == 0) sg_source_frame(p, dsp, frame_src);
+            const uint8_t *fs = frame_src;
+            uint8_t *o = e->src;
+            for (int pl = 0; pl < 3; pl++) {
+                const int pw = pl ? e->W / 2 : e->W, ph = pl ? e->fH / 2 : e->fH;
+                for (int y = e->bottom; y < ph; y += 2, o += pw) memcpy(o, fs + (size_t)y * pw, (size_t)pw);
+                fs += (size_t)pw * ph;
+            }
+        }
         if (p->bframes > 0) poc = 2 * (dsp - idr_disp);
         if (idr) {
             frame_num = 0, poc = 0, e->nrefs = 0, refs_since_reset = 0, since_idr = 0;
@@ -2362,7 +2452,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             out += n;
             n = write_pps(e, stream + out, cap - out);
             out += n;
-            for (int i = 0; i < 6; i++) e->pics[i].is_ref = 0;
+            for (int i = 0; i < 12; i++) e->pics[i].is_ref = 0;
         }
         /* frame_num gap (8.2.5.2): the skipped values enter the window as non-existing frames, oldest pictures leave */
         if (p->fn_gap_period > 0 && p->bframes == 0 && !p->mmco && !idr && since_idr > 0 && since_idr % p->fn_gap_period == 0) {
@@ -2386,23 +2476,26 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         }
         /* current picture buffer */
         e->cur = NULL;
-        for (int i = 0; i < 6 && !e->cur; i++)
-            if (!e->pics[i].is_ref) e->cur = &e->pics[i];
+        for (int i = 0; i < (e->field ? 12 : 6) && !e->cur; i++)
+            if (!e->pics[i].is_ref && &e->pics[i] != first_field) e->cur = &e->pics[i];
+        e->cur->w = e->W, e->cur->h = e->H, e->cur->parity = e->bottom, e->cur->fid = t;
         e->cur->nonexist = 0;
         e->cur->id = e->next_id++;
         e->cur->frame_num = frame_num;
         e->cur_frame_num = frame_num;
-        e->slice_type = idr ? 2 : (bpic ? 1 : 0);
-        e->cur->poc = e->cur_poc = poc;
+        e->slice_type = intra_pic ? 2 : (bpic ? 1 : 0);
+        const int pic_poc = poc + fld; /* field pictures: the second field one later */
+        e->cur->poc = e->cur_poc = pic_poc;
         e->nal_ref_idc = bpic ? (b_ref[t] ? 2 : 0) : ((!idr && p->nonref_period > 1 && since_idr % p->nonref_period == p->nonref_period - 1) ? 0 : 3);
         if (!e->nal_ref_idc) g_feat |= 1u << 12;
         e->idr_lt = idr && p->idr_long_term;
         e->n_rplm = e->n_mmco = 0;
-        mark_state ms;
         memset(&ms, 0, sizeof(ms));
         if (bpic)
             plan_b_lists(e);
-        else if (!idr) {
+        else if (e->field) {
+            if (!intra_pic) plan_field_list(e);
+        } else if (!idr) {
             plan_ref_list(e);
             if (e->nal_ref_idc) plan_marking(e, &ms);
         }
@@ -2423,10 +2516,10 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             if (idr) abs_fn = 0;
             for (int i = 0; i < abs_fn; i++) expected += poc1_offsets[i % 2];
             if (!e->nal_ref_idc) expected += -1; /* offset_for_non_ref_pic */
-            e->delta_poc0 = poc - expected;
+            e->delta_poc0 = pic_poc - expected - (e->field && e->bottom ? 1 : 0); /* bottom fields: + offset_for_top_to_bottom_field */
             if (e->delta_poc0) g_feat |= 1u << 14;
         }
-        if (g_npocs < 8192) /* pic_order_cnt_type 2 leaves no choice: 2 * FrameNum, minus 1 for non-reference pictures (8.2.1.3) */
+        if (g_npocs < 8192 && fld == 0) /* (per frame: the smaller of its fields' counts)  pic_order_cnt_type 2 leaves no choice: 2 * FrameNum, minus 1 for non-reference pictures (8.2.1.3) */
             g_pocs[g_npocs++] = p->poc_type == 2 ? (idr ? 0 : 2 * refs_since_reset - (e->nal_ref_idc ? 0 : 1)) : poc;
         /* weighted_pred 2: both denominators 7, so that the DEFAULT weight of an entry without a flag is 128 -- outside the
          * range of a coded weight (-128..127); coded weights stay below it */
@@ -2492,16 +2585,16 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             e->slice_qp = e->slice_qp < 0 ? 0 : (e->slice_qp > 51 ? 51 : e->slice_qp);
             if (e->slice_qp != p->qp) g_feat |= 1u << 13;
             sg_bw_init(&e->bw, rbsp, slice_cap);
-            write_slice_header(e, first, idr, frame_num, idr_id, poc & 255);
+            write_slice_header(e, first, idr, frame_num, idr_id, pic_poc & 255);
             e->qp = e->slice_qp, e->prev_dqp_nz = 0, e->skip_run = 0;
             if (p->cabac) {
                 while (!sg_bw_aligned(&e->bw)) sg_put(&e->bw, 1, 1);
-                sg_cabac_init_ctx(&e->bw, idr ? 0 : 1 + e->init_idc, e->slice_qp);
+                sg_cabac_init_ctx(&e->bw, intra_pic ? 0 : 1 + e->init_idc, e->slice_qp);
                 sg_cabac_start(&e->bw);
             }
             for (int addr = first, left = sl_count[s]; left > 0; left--, addr = sg_next_mb(e, addr)) {
                 begin_mb(e, addr);
-                if (idr)
+                if (intra_pic)
                     encode_intra(e, 1);
                 else if (bpic) {
                     int r = (int)(rnd(e) % 1000), kind, sk = p->bskip_permille;
@@ -2577,12 +2670,26 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             out += n;
         }
         sg_deblock(e->cur, e->db, e->wmb, e->hmb);
+        if (e->field) { /* weave the field into the frame of recon[] */
+            if (recon && (size_t)(t + 1) * frame_bytes <= recon_cap) {
+                uint8_t *o = recon + (size_t)t * frame_bytes;
+                for (int pl = 0; pl < 3; pl++) {
+                    const int pw = pl ? e->W / 2 : e->W, ph = pl ? e->fH / 2 : e->fH;
+                    for (int y = e->bottom; y < ph; y += 2) memcpy(o + (size_t)y * pw, e->cur->pl[pl] + (size_t)(y >> 1) * pw, (size_t)pw);
+                    o += (size_t)pw * ph;
+                }
+            }
+            apply_field_marking(e, fld, idr);
+            first_field = e->cur;
+            continue; /* the frame-level counters move after the second field, below */
+        }
         if (recon && (size_t)(t + 1) * fsz <= recon_cap) memcpy(recon + (size_t)t * fsz, e->cur->pl[0], fsz);
         apply_marking(e, &ms, idr);
         if (e->cur->is_ref && p->bframes > 0) { /* a later B picture may take this one as its co-located picture */
             if (!e->cur->motion) e->cur->motion = malloc(sizeof(emb) * (size_t)e->wmb * e->hmb);
             memcpy(e->cur->motion, e->mb, sizeof(emb) * (size_t)e->wmb * e->hmb);
         }
+      } /* fld */
         since_idr++;
         poc += 2;
         if (e->nal_ref_idc) {
@@ -2594,17 +2701,18 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             frame_num = 1, refs_since_reset = 1, poc = 2;
             g_pocs[g_npocs - 1] = 0;
         }
-        if (idr) idr_id = (idr_id + 1) & 0xFFFF;
+        if (idr_frame) idr_id = (idr_id + 1) & 0xFFFF;
         if (frame_sizes) frame_sizes[t] = (uint32_t)(out - au_start);
     }
 done:
     free(disp);
     free(is_b);
     free(b_ref);
-    for (int i = 0; i < 6; i++) free(e->pics[i].pl[0]), free(e->pics[i].motion);
+    for (int i = 0; i < 12; i++) free(e->pics[i].pl[0]), free(e->pics[i].motion);
     free(e->mb);
     free(e->db);
     free(e->src);
+    free(frame_src);
     free(e->sgmap);
     free(e->sg_ids);
     free(rbsp);

@@ -43,6 +43,7 @@ typedef struct {
     int long_idx; /* LongTermFrameIdx when is_ref == 2 */
     int poc;
     int nonexist; /* a frame that only exists as a skipped frame_num value (8.2.5.2): takes a place in the window, is never predicted from */
+    int parity, fid; /* field pictures (sg_params::field_pics): 0 top / 1 bottom, and the frame the field belongs to */
     void *motion; /* the picture's macroblock motion (an emb array of sg_enc.c): co-located data of later B pictures */
 } sg_pic;
 
@@ -79,5 +80,8 @@ typedef struct {
     int32_t refid1[4];
 } sg_dbmb;
 void sg_deblock(sg_pic *p, const sg_dbmb *mbs, int wmb, int hmb);
+/* field pictures: coefficients in field scan order (8.5.6, 8.5.7); deblocking with the rules for field macroblocks (8.7.2.1:
+ * horizontal edges of intra macroblocks get bS 3, vertical vector differences count from 4 quarter FRAME samples = 2 field ones) */
+void sg_set_field_mode(int on);
 
 #endif

@@ -285,6 +285,24 @@ void sg_mc_chroma(const sg_pic *ref, int plane, int x, int y, int w, int h, int 
     }
 }
 
+/* ------------------------------------------------------------------ frame / field mode (sg_set_field_mode) */
+/* field scans (Table 8-12 / 8-13 field columns), as raster positions x + 4 * y and x + 8 * y */
+static const uint8_t field_scan4x4[16] = {0, 4, 1, 8, 12, 5, 9, 13, 2, 6, 10, 14, 3, 7, 11, 15};
+#define P8(x, y) ((x) + 8 * (y))
+static const uint8_t field_scan8x8[64] = {
+    P8(0, 0), P8(0, 1), P8(0, 2), P8(1, 0), P8(1, 1), P8(0, 3), P8(0, 4), P8(1, 2), P8(2, 0), P8(1, 3), P8(0, 5), P8(0, 6), P8(0, 7), P8(1, 4), P8(2, 1), P8(3, 0),
+    P8(2, 2), P8(1, 5), P8(1, 6), P8(1, 7), P8(2, 3), P8(3, 1), P8(4, 0), P8(3, 2), P8(2, 4), P8(2, 5), P8(2, 6), P8(2, 7), P8(3, 3), P8(4, 1), P8(5, 0), P8(4, 2),
+    P8(3, 4), P8(3, 5), P8(3, 6), P8(3, 7), P8(4, 3), P8(5, 1), P8(6, 0), P8(5, 2), P8(4, 4), P8(4, 5), P8(4, 6), P8(4, 7), P8(5, 3), P8(6, 1), P8(6, 2), P8(5, 4),
+    P8(5, 5), P8(5, 6), P8(5, 7), P8(6, 3), P8(7, 0), P8(7, 1), P8(6, 4), P8(6, 5), P8(6, 6), P8(6, 7), P8(7, 2), P8(7, 3), P8(7, 4), P8(7, 5), P8(7, 6), P8(7, 7)};
+#undef P8
+static const uint8_t *g_scan4 = sg_zigzag4x4, *g_scan8 = sg_zigzag8x8;
+static int g_field;
+void sg_set_field_mode(int on) {
+    g_field = on != 0;
+    g_scan4 = on ? field_scan4x4 : sg_zigzag4x4;
+    g_scan8 = on ? field_scan8x8 : sg_zigzag8x8;
+}
+
 /* ------------------------------------------------------------------ scaling + inverse transforms */
 static void inv4(int *m) { /* m raster 4x4, in place: 8.5.12.2 */
     for (int pass = 0; pass < 2; pass++) {
@@ -326,7 +344,7 @@ static void inv8(int *m) { /* 8.5.13 */
 void sg_residual4(const int16_t *lev, const int *ls, int qp, int have_dc, int dc, int *res) {
     int per = qp / 6;
     for (int k = 0; k < 16; k++) {
-        int pos = sg_zigzag4x4[k], v = lev[k] * ls[pos];
+        int pos = g_scan4[k], v = lev[k] * ls[pos];
         res[pos] = per >= 4 ? v << (per - 4) : (v + (1 << (3 - per))) >> (4 - per);
     }
     if (have_dc) res[0] = dc;
@@ -335,7 +353,7 @@ void sg_residual4(const int16_t *lev, const int *ls, int qp, int have_dc, int dc
 void sg_residual8(const int16_t *lev, const int *ls, int qp, int *res) {
     int per = qp / 6;
     for (int k = 0; k < 64; k++) {
-        int pos = sg_zigzag8x8[k], v = lev[k] * ls[pos];
+        int pos = g_scan8[k], v = lev[k] * ls[pos];
         res[pos] = per >= 6 ? v << (per - 6) : (v + (1 << (5 - per))) >> (6 - per);
     }
     inv8(res);
@@ -361,7 +379,7 @@ static void hadamard4(const int *in, int *out) {
 }
 void sg_luma_dc(const int16_t *lev_scan, int ls00, int qp, int *dc) { /* 8.5.10 */
     int c[16], f[16], per = qp / 6;
-    for (int k = 0; k < 16; k++) c[sg_zigzag4x4[k]] = lev_scan[k];
+    for (int k = 0; k < 16; k++) c[g_scan4[k]] = lev_scan[k];
     hadamard4(c, f);
     for (int i = 0; i < 16; i++) dc[i] = per >= 6 ? (f[i] * ls00) << (per - 6) : (f[i] * ls00 + (1 << (5 - per))) >> (6 - per);
 }
@@ -416,7 +434,7 @@ void sg_quant4(const int *resid, const int *ls, int qp, double dead, int skip_dc
     init_basis();
     double scale = ldexp(1.0, qp / 6 - 4);
     for (int k = 0; k < 16; k++) {
-        int pos = sg_zigzag4x4[k], u = pos & 3, v = pos >> 2;
+        int pos = g_scan4[k], u = pos & 3, v = pos >> 2;
         if (skip_dc && k == 0) {
             lev[0] = 0;
             continue;
@@ -432,7 +450,7 @@ void sg_quant8(const int *resid, const int *ls, int qp, double dead, int16_t *le
     init_basis();
     double scale = ldexp(1.0, qp / 6 - 6);
     for (int k = 0; k < 64; k++) {
-        int pos = sg_zigzag8x8[k], u = pos & 7, v = pos >> 3;
+        int pos = g_scan8[k], u = pos & 7, v = pos >> 3;
         double acc = 0;
         for (int y = 0; y < 8; y++)
             for (int x = 0; x < 8; x++) acc += resid[y * 8 + x] * basis8[v][y] * basis8[u][x];
@@ -445,7 +463,7 @@ void sg_quant_luma_dc(const int *sums, int ls00, int qp, double dead, int16_t *l
     for (int i = 0; i < 16; i++) d4[i] = sums[i];
     hadamard4(d4, f);
     double scale = ls00 * ldexp(1.0, qp / 6 - 6);
-    for (int k = 0; k < 16; k++) lev[k] = dead_round(4.0 * f[sg_zigzag4x4[k]] / 16.0 / scale, dead);
+    for (int k = 0; k < 16; k++) lev[k] = dead_round(4.0 * f[g_scan4[k]] / 16.0 / scale, dead);
 }
 void sg_quant_chroma_dc(const int *s, int ls00, int qpc, double dead, int16_t *lev) {
     int f[4] = {s[0] + s[1] + s[2] + s[3], s[0] - s[1] + s[2] - s[3], s[0] + s[1] - s[2] - s[3], s[0] - s[1] - s[2] + s[3]};
@@ -521,9 +539,9 @@ static blkmotion motion_of(const sg_dbmb *m, int b) {
     if (m->refid1[q] >= 0) r.pic[r.n] = m->refid1[q], r.mvx[r.n] = m->mv1[b][0], r.mvy[r.n] = m->mv1[b][1], r.n++;
     return r;
 }
-static int close_mv(const blkmotion *a, int i, const blkmotion *b, int j) { return abs(a->mvx[i] - b->mvx[j]) < 4 && abs(a->mvy[i] - b->mvy[j]) < 4; }
-static int strength(const sg_dbmb *mp, int bp, const sg_dbmb *mq, int bq, int on_mb_edge) {
-    if (mp->intra || mq->intra) return on_mb_edge ? 4 : 3;
+static int close_mv(const blkmotion *a, int i, const blkmotion *b, int j) { return abs(a->mvx[i] - b->mvx[j]) < 4 && abs(a->mvy[i] - b->mvy[j]) < (g_field ? 2 : 4); }
+static int strength(const sg_dbmb *mp, int bp, const sg_dbmb *mq, int bq, int on_mb_edge, int vertical_edge) {
+    if (mp->intra || mq->intra) return on_mb_edge && (vertical_edge || !g_field) ? 4 : 3;
     if ((mp->nzmask >> bp & 1) || (mq->nzmask >> bq & 1)) return 2;
     blkmotion P = motion_of(mp, bp), Q = motion_of(mq, bq);
     if (P.n != Q.n) return 1;
@@ -553,7 +571,7 @@ void sg_deblock(sg_pic *pic, const sg_dbmb *mbs, int wmb, int hmb) {
                     for (int s = 0; s < 4; s++) {
                         int bq = vertical_edges ? 4 * s + e : 4 * e + s;
                         int bp = vertical_edges ? 4 * s + (e ? e - 1 : 3) : 4 * (e ? e - 1 : 3) + s;
-                        bs[s] = strength(pm, bp, cur, bq, e == 0);
+                        bs[s] = strength(pm, bp, cur, bq, e == 0, vertical_edges);
                         any |= bs[s];
                     }
                     if (!any) continue;
