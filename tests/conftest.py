@@ -177,3 +177,19 @@ MATRIX = {
     "b_gop_intra_pcm": dict(BASE, frames=16, idr_period=8, profile_idc=77, cabac=1, bframes=3, num_ref_frames=3, intra_in_p_permille=200,
                             pcm_permille=100, qp_jitter=5, rplm=1, seed=50),
 }
+
+
+# Field pictures (PAFF: every frame coded as two fields).  Oracle + generator only for now -- the product refuses field pictures
+# with H264MI_EUNSUPPORTED -- so these are NOT part of MATRIX (which the GPU parity tests run in full).  CAVLC only: see sg.h.
+FIELD_BASE = dict(width=176, height=128, frames=5, idr_period=0, profile_idc=77, cabac=0, field_pics=1)
+FIELD_MATRIX = {
+    "field_IP": dict(FIELD_BASE, num_ref_frames=2, seed=301),
+    "field_intra_only": dict(FIELD_BASE, idr_period=1, frames=3, pcm_permille=30, seed=302),
+    "field_bottom_first": dict(FIELD_BASE, field_pics=2, num_ref_frames=3, sub8x8_permille=400, seed=303),
+    "field_refs4_qpel": dict(FIELD_BASE, num_ref_frames=4, frames=7, motion_x4=5, motion_y4=3, sub8x8_permille=300, seed=304),
+    "field_high_8x8": dict(FIELD_BASE, profile_idc=100, transform8x8=1, scaling_matrix=1, num_ref_frames=2, intra_in_p_permille=200, seed=305),
+    "field_slices3_idc2": dict(FIELD_BASE, slices=3, deblock_idc=2, alpha_off_div2=2, beta_off_div2=-1, num_ref_frames=2, seed=306),
+    "field_wp_poc1": dict(FIELD_BASE, weighted_pred=1, poc_type=1, num_ref_frames=3, idr_period=3, frames=7, seed=307),
+    "field_poc2_qpjitter": dict(FIELD_BASE, poc_type=2, qp_jitter=6, slice_qp_delta=2, skip_permille=300, num_ref_frames=2, seed=308),
+    "field_cropped": dict(FIELD_BASE, width=170, height=124, num_ref_frames=2, constrained_intra=1, intra_in_p_permille=150, seed=309),
+}

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(HERE, "..", ".."))
 sys.path.insert(0, os.path.join(HERE, ".."))
 import oracle  # noqa: E402
 import streamgen  # noqa: E402
-from conftest import MATRIX  # noqa: E402
+from conftest import FIELD_MATRIX, MATRIX  # noqa: E402
 
 out = {}
 for name in sorted(MATRIX):
@@ -22,3 +22,13 @@ for name in sorted(MATRIX):
     out[name] = {"stream_md5": hashlib.md5(s).hexdigest(), "frames_md5": hashlib.md5(frames.tobytes()).hexdigest(), "stream_bytes": len(s)}
 json.dump(out, open(os.path.join(HERE, "stream_md5.json"), "w"), indent=1, sort_keys=True)
 print("wrote", len(out), "vectors")
+
+# field pictures (oracle + generator only): their own file, so that the GPU golden test keeps reading stream_md5.json whole
+out = {}
+for name in sorted(FIELD_MATRIX):
+    s, rec, _ = streamgen.encode(**FIELD_MATRIX[name])
+    frames, _ = oracle.decode(s, crop=False)
+    assert (frames == rec).all(), name
+    out[name] = {"stream_md5": hashlib.md5(s).hexdigest(), "frames_md5": hashlib.md5(frames.tobytes()).hexdigest(), "stream_bytes": len(s)}
+json.dump(out, open(os.path.join(HERE, "field_md5.json"), "w"), indent=1, sort_keys=True)
+print("wrote", len(out), "field vectors")

@@ -20,6 +20,7 @@ def test_sweep_oracle_equals_generator():
     _sweep("400", "--seed", "3")
     _sweep("150", "--seed", "5", "--concat")
     _sweep("300", "--seed", "61", "--extreme")
+    _sweep("400", "--seed", "21", "--fields")  # field pictures (PAFF): oracle only
 
 
 @pytest.mark.gpu

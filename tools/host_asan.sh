@@ -15,8 +15,8 @@ python3 - "$out" <<PY
 import sys
 sys.path.insert(0, "$root"); sys.path.insert(0, "$root/tests")
 import streamgen
-from conftest import MATRIX
-for n, k in MATRIX.items():
+from conftest import FIELD_MATRIX, MATRIX
+for n, k in list(MATRIX.items()) + list(FIELD_MATRIX.items()):  # (field pictures: the product must refuse them cleanly)
     open("%s/m_%s.h264" % (sys.argv[1], n), "wb").write(streamgen.encode(**k)[0])
 PY
 "$out/host_asan" "${1:-300}" "${2:-1}" "$out"/m_*.h264

@@ -4,6 +4,7 @@ coder, slices, slice groups, references, picture management, B pictures, weights
 generator's reconstruction bit for bit.  Usage: param_sweep.py [trials] [--gpu] [--seed N] [--batch B]
   without --gpu: the oracle (CPU);  with --gpu: the product through the C ABI, one workgroup per picture and banded;
   --batch B (GPU): B streams of different recipes and sizes side by side in one decoder per trial;
+  --fields: field-picture (PAFF) recipes, oracle only;
   --split (GPU): every stream is fed in several calls, a random number of access units at a time (state that must survive a batch boundary:
   reference pictures and their marking, picture order counts, co-located motion, frame_num gap bookkeeping, parameter sets)."""
 import os, sys, time
@@ -20,6 +21,7 @@ SPLIT = "--split" in sys.argv
 XR = "--xwgs" in sys.argv  # a random workgroup budget per trial (band plans of every shape) instead of the two standard ones
 EXTREME = "--extreme" in sys.argv  # the corners of the value ranges: QP 0..51, chroma offsets -12..12, filter offsets -6..6, loud noise (escape-coded levels)
 BIG = "--big" in sys.argv  # pictures wider than 64 macroblocks (rows of more than one 64-macroblock chunk), more slices
+FIELDS = "--fields" in sys.argv  # PAFF recipes: every frame as two field pictures (oracle only: the product refuses field pictures)
 CONCAT = "--concat" in sys.argv  # two recipes back to back in one stream: new parameter sets, entropy coder, slice groups, picture size at the second IDR picture
 args = [a for a in args if a not in (str(seed0), str(BATCH))] or args[:1]
 rng = np.random.default_rng(seed0)
@@ -61,12 +63,24 @@ def draw():
     if BIG:
         kw["width"], kw["height"], kw["frames"] = 16 * r(62, 84) - pick(0, 6), 16 * r(3, 9) - pick(0, 2), r(2, 4)
         kw["slices"] = pick(1, 2, 3, min(5, (kw["height"] + 15) // 16)) if not kw.get("slice_groups") else kw["slices"]
-    if rng.random() < 0.15:
+    if rng.random() < 0.15 or FIELDS:
         kw["interlace_sps"] = 1
         kw["height"] = max(32, (kw["height"] + 31) // 32 * 32 - pick(0, 4, 8))
+    if FIELDS:  # what sg.h says field recipes may carry: Main / High, CAVLC, no B pictures, marking scripts, list commands or slice groups
+        for k in ("bframes", "direct_temporal", "weighted_bipred", "bskip_permille", "b_pyramid", "rplm", "mmco", "idr_long_term", "nonref_period", "fn_gap_period",
+                  "fn_gap_declared", "slice_groups", "fmo_type", "aso", "cabac_init_idc"):
+            kw.pop(k, None)
+        kw.update(field_pics=pick(1, 1, 2), cabac=0, profile_idc=pick(77, 100), poc_type=pick(0, 0, 1, 2))
+        if kw["profile_idc"] != 100:
+            kw.pop("transform8x8", None), kw.pop("scaling_matrix", None)
+        else:
+            kw["transform8x8"], kw["scaling_matrix"] = pick(0, 1, 1), pick(0, 1)
+        kw["weighted_pred"] = pick(0, 0, 1, 2)
     return kw
 
 
+if GPU and FIELDS:
+    sys.exit("--fields is an oracle sweep: the product refuses field pictures (H264MI_EUNSUPPORTED)")
 if GPU:
     import h264decode_amd as H
 else:
