@@ -71,12 +71,14 @@ typedef struct {
      * map); `slices` then counts the slices PER GROUP.  aso: the slices of a picture leave in a shuffled order (arbitrary slice
      * order; needs more than one slice per picture to show) */
     int slice_groups, fmo_type, aso;
-    /* PAFF: 1 = every frame is coded as two FIELD pictures (field_pic_flag = 1), top field first; 2 = bottom field first.
-     * The first field of an IDR frame is the IDR picture, its second field a P or I field of the same frame_num; all other
-     * fields are P fields whose RefPicList0 alternates between fields of the same and of the opposite parity (8.2.4.2.5)
-     * and may start with the first field of the same frame.  Forces interlace_sps; CAVLC only (the context tables of
-     * field-coded significance maps are not in this tree); sliding-window marking, default lists, no B pictures,
-     * no slice groups.  recon[] holds the woven frames. */
+    /* PAFF: 1 = every frame is coded as two FIELD pictures (field_pic_flag = 1), top field first; 2 = bottom field first;
+     * 3 = picture-adaptive: frame by frame either a frame picture or two field pictures, so that frames predict from
+     * field-coded frames and fields from the fields of frame-coded ones.  The first field of an IDR frame is the IDR
+     * picture, its second field a P or I field of the same frame_num; all other fields are P fields whose RefPicList0
+     * alternates between fields of the same and of the opposite parity (8.2.4.2.5) and may start with the first field of
+     * the same frame.  Forces interlace_sps; CAVLC only (the context tables of field-coded significance maps are not in
+     * this tree); sliding-window marking (counted in frames, 8.2.5.3), default lists, non-reference frames (nonref_period)
+     * allowed, no B pictures, no slice groups.  recon[] holds the woven frames. */
     int field_pics;
 } sg_params;
 

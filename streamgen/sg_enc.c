@@ -36,8 +36,12 @@ typedef struct {
 typedef struct {
     sg_params p;
     int wmb, hmb, W, H;
-    sg_pic pics[12];  /* frame pictures use the first 6; field pictures (two per frame) all of them */
-    int field, bottom, fH; /* field_pics: coding a field picture, its parity, the coded FRAME height (W x H is then one field) */
+    sg_pic pics[6];
+    /* field_pics: the two fields of every frame store as pictures of their own (a frame coded as two fields is woven into pics[i]
+     * afterwards, a frame coded as a frame is split into fpics[i][]), so that either kind of picture finds its references ready */
+    sg_pic fpics[6][2];
+    sg_pic *cur_frame;     /* the frame store the current picture belongs to (== cur for a frame picture) */
+    int field, bottom, fH; /* coding a field picture, its parity; the coded FRAME height (W x H is the current PICTURE: frame or field) */
     sg_pic *cur, *refs[4];
     sg_pic *refs1[4];             /* RefPicList1 of a B picture */
     int nref1_active, cur_poc;
@@ -1723,7 +1727,7 @@ static size_t write_sps(enc *e, uint8_t *dst, size_t cap) {
     sg_bw_init(&w, buf, sizeof(buf));
     sg_put(&w, (uint32_t)p->profile_idc, 8);
     sg_put(&w, p->profile_idc == 66 ? 0xC0 : (p->profile_idc == 77 ? 0x40 : 0), 8); /* constraint_set flags */
-    sg_put(&w, e->W * (p->field_pics ? e->fH : e->H) > 1920 * 1088 ? 51 : 40, 8);                            /* level_idc */
+    sg_put(&w, e->W * e->fH > 1920 * 1088 ? 51 : 40, 8);                            /* level_idc */
     sg_put_ue(&w, 0);                                                              /* sps id */
     if (p->profile_idc == 100) {
         sg_put_ue(&w, 1); /* chroma_format_idc */
@@ -1755,15 +1759,15 @@ static size_t write_sps(enc *e, uint8_t *dst, size_t cap) {
     sg_put(&w, p->fn_gap_declared != 0, 1); /* gaps_in_frame_num_value_allowed_flag */
     sg_put_ue(&w, (uint32_t)(e->wmb - 1));
     if (p->interlace_sps) { /* map units of two macroblock rows; crop units of four luma rows (7.4.2.1.1) */
-        sg_put_ue(&w, (uint32_t)(e->p.field_pics ? e->hmb - 1 : e->hmb / 2 - 1)); /* (field_pics: e->hmb counts the rows of one field) */
+        sg_put_ue(&w, (uint32_t)(e->fH / 32 - 1));
         sg_put(&w, 0, 1); /* frame_mbs_only_flag */
         sg_put(&w, 0, 1); /* mb_adaptive_frame_field_flag */
     } else {
-        sg_put_ue(&w, (uint32_t)(e->hmb - 1));
+        sg_put_ue(&w, (uint32_t)(e->fH / 16 - 1));
         sg_put(&w, 1, 1); /* frame_mbs_only */
     }
     sg_put(&w, 1, 1); /* direct_8x8_inference */
-    int cr = (e->W - p->width) / 2, cb = ((p->field_pics ? e->fH : e->H) - p->height) / (p->interlace_sps ? 4 : 2);
+    int cr = (e->W - p->width) / 2, cb = (e->fH - p->height) / (p->interlace_sps ? 4 : 2);
     sg_put(&w, cr || cb, 1);
     if (cr || cb) {
         sg_put_ue(&w, 0);
@@ -2269,22 +2273,23 @@ static void apply_marking(enc *e, const mark_state *m, int idr) {
  * the current field included when its first field is a reference --, then fields taken from them alternately, starting with
  * the parity of the current field; a frame that lacks the wanted parity is passed over, and when one parity runs out the
  * rest of the other follows in order. */
-static void plan_field_list(enc *e) {
-    sg_pic *same[12], *opp[12], *all[12];
-    int n = 0, ns = 0, no = 0, cur_fn = e->cur_frame_num;
-    for (int i = 0; i < 12; i++)
-        if (&e->pics[i] != e->cur && e->pics[i].is_ref == 1) all[n++] = &e->pics[i];
-    for (int i = 0; i < n; i++) /* frames by FrameNumWrap, most recent first (both fields of a frame carry the same frame_num) */
+static void plan_field_list(enc *e, int second) {
+    int fr[6], n = 0, cur_fn = e->cur_frame_num;
+    for (int i = 0; i < 6; i++)
+        if (e->pics[i].is_ref == 1 && !e->pics[i].nonexist && (&e->pics[i] != e->cur_frame || second)) fr[n++] = i;
+    for (int i = 0; i < n; i++) /* most recent first */
         for (int j = i + 1; j < n; j++)
-            if (picnum(all[j], cur_fn) > picnum(all[i], cur_fn)) {
-                sg_pic *t = all[i];
-                all[i] = all[j], all[j] = t;
+            if (picnum(&e->pics[fr[j]], cur_fn) > picnum(&e->pics[fr[i]], cur_fn)) {
+                int t = fr[i];
+                fr[i] = fr[j], fr[j] = t;
             }
-    for (int i = 0; i < n; i++)
-        if (all[i]->parity == e->bottom) same[ns++] = all[i];
-        else opp[no++] = all[i];
-    sg_pic *list[24];
-    int nl = 0, a = 0, b = 0;
+    sg_pic *same[6], *opp[6], *list[12];
+    int ns = 0, no = 0, nl = 0, a = 0, b = 0;
+    for (int i = 0; i < n; i++) {
+        const int whole = &e->pics[fr[i]] != e->cur_frame; /* of the current frame only the first field exists */
+        if (whole) same[ns++] = &e->fpics[fr[i]][e->bottom];
+        opp[no++] = &e->fpics[fr[i]][!e->bottom];
+    }
     while (a < ns && b < no) list[nl++] = same[a++], list[nl++] = opp[b++];
     while (a < ns) list[nl++] = same[a++];
     while (b < no) list[nl++] = opp[b++];
@@ -2294,28 +2299,22 @@ static void plan_field_list(enc *e) {
     e->n_rplm = 0;
     for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? list[i] : NULL;
 }
-/* Sliding window with fields (8.2.5.3): the window counts FRAMES; the first field of a frame pushes the oldest frame out
- * (both its fields), the second field of a reference frame just joins its first field. */
-static void apply_field_marking(enc *e, int second, int idr) {
-    if (idr)
-        for (int i = 0; i < 12; i++) e->pics[i].is_ref = 0;
-    else if (!second) {
-        int fids[12], nf = 0, oldest = -1;
-        for (int i = 0; i < 12; i++) {
-            sg_pic *q = &e->pics[i];
-            if (q == e->cur || !q->is_ref) continue;
-            int seen = 0;
-            for (int k = 0; k < nf; k++) seen |= fids[k] == q->fid;
-            if (!seen) fids[nf++] = q->fid;
-            if (oldest < 0 || picnum(q, e->cur_frame_num) < picnum(&e->pics[oldest], e->cur_frame_num)) oldest = i;
+/* the finished frame in its other shape: woven from its two fields, or split into them */
+static void weave_or_split(enc *e, int slot, int from_fields) {
+    sg_pic *f = &e->pics[slot];
+    for (int par = 0; par < 2; par++) {
+        sg_pic *q = &e->fpics[slot][par];
+        for (int pl = 0; pl < 3; pl++) {
+            const int pw = pl ? e->W / 2 : e->W, ph = pl ? e->fH / 2 : e->fH;
+            for (int y = par; y < ph; y += 2) {
+                uint8_t *fr = f->pl[pl] + (size_t)y * pw, *fl = q->pl[pl] + (size_t)(y >> 1) * pw;
+                if (from_fields) memcpy(fr, fl, (size_t)pw);
+                else memcpy(fl, fr, (size_t)pw);
+            }
         }
-        if (nf >= e->p.num_ref_frames && oldest >= 0) {
-            const int fid = e->pics[oldest].fid;
-            for (int i = 0; i < 12; i++)
-                if (e->pics[i].fid == fid && &e->pics[i] != e->cur) e->pics[i].is_ref = 0;
-        }
+        if (!from_fields) q->id = e->next_id++, q->frame_num = f->frame_num, q->poc = f->poc, q->parity = par, q->fid = slot;
     }
-    e->cur->is_ref = 1;
+    if (from_fields) f->id = e->next_id++;
 }
 
 /* ------------------------------------------------------------------ top level */
@@ -2347,7 +2346,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             free(e);
             return 0;
         }
-        p->interlace_sps = 1, p->bframes = 0, p->b_pyramid = 0, p->mmco = 0, p->rplm = 0, p->idr_long_term = 0, p->nonref_period = 0;
+        p->interlace_sps = 1, p->bframes = 0, p->b_pyramid = 0, p->mmco = 0, p->rplm = 0, p->idr_long_term = 0;
         p->fn_gap_period = 0, p->slice_groups = 0, p->aso = 0;
     }
     e->W = (p->width + 15) & ~15, e->H = (p->height + 15) & ~15;
@@ -2359,9 +2358,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
     }
     e->fH = e->H;
     const size_t frame_bytes = (size_t)e->W * e->fH * 3 / 2;
-    if (p->field_pics) e->H /= 2, e->hmb /= 2; /* from here on a "picture" is one field: W x H, hmb macroblock rows */
-    sg_set_field_mode(p->field_pics != 0);
-    if (p->slices > e->hmb) p->slices = e->hmb;
+    if (p->slices > (p->field_pics ? e->hmb / 2 : e->hmb)) p->slices = p->field_pics ? e->hmb / 2 : e->hmb;
     if (p->slice_groups < 2) p->slice_groups = 0;
     if (p->slice_groups > 8) p->slice_groups = 8;
     if (p->slice_groups && (p->fmo_type < 0 || p->fmo_type > 6)) p->fmo_type = 1;
@@ -2370,12 +2367,19 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
     if (p->slice_groups) plan_slice_groups(e);
     e->rng = 0x9E3779B97F4A7C15ull ^ ((uint64_t)p->seed * 0xD1B54A32D192ED03ull);
     if (!e->rng) e->rng = 1;
-    size_t fsz = (size_t)e->W * e->H * 3 / 2;
-    for (int i = 0; i < 12; i++) {
+    size_t fsz = frame_bytes;
+    for (int i = 0; i < 6; i++) {
         e->pics[i].pl[0] = (uint8_t *)malloc(fsz);
         e->pics[i].pl[1] = e->pics[i].pl[0] + e->W * e->H;
         e->pics[i].pl[2] = e->pics[i].pl[1] + e->W * e->H / 4;
-        e->pics[i].w = e->W, e->pics[i].h = e->H, e->pics[i].fid = -1;
+        e->pics[i].w = e->W, e->pics[i].h = e->H, e->pics[i].fid = i;
+        for (int par = 0; par < 2 && p->field_pics; par++) { /* its fields: half the rows, planes back to back */
+            sg_pic *q = &e->fpics[i][par];
+            q->pl[0] = (uint8_t *)malloc(fsz / 2);
+            q->pl[1] = q->pl[0] + e->W * e->H / 2;
+            q->pl[2] = q->pl[1] + e->W * e->H / 8;
+            q->w = e->W, q->h = e->H / 2, q->parity = par, q->fid = i;
+        }
     }
     e->mb = (emb *)calloc((size_t)e->wmb * e->hmb, sizeof(emb));
     e->db = (sg_dbmb *)calloc((size_t)e->wmb * e->hmb, sizeof(sg_dbmb));
@@ -2428,11 +2432,15 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         const int idr_frame = dsp == 0 || (p->idr_period > 0 && dsp % p->idr_period == 0);
         if (idr_frame) idr_disp = dsp;
         mark_state ms;
-        sg_pic *first_field = NULL;
-      for (int fld = 0; fld < (p->field_pics ? 2 : 1); fld++) { /* the picture(s) of frame t: the frame, or its two fields */
+        /* field_pics 1 / 2: every frame as two fields; 3: frame by frame, a frame picture or two field pictures (PAFF proper) */
+        const int as_fields = p->field_pics == 3 ? (int)((p->seed * 7u + (unsigned)t * 5u + (unsigned)(t / 3)) % 3u != 0) : p->field_pics != 0;
+        e->cur_frame = NULL;
+      for (int fld = 0; fld < (as_fields ? 2 : 1); fld++) { /* the picture(s) of frame t: the frame, or its two fields */
         /* only the first field of an IDR frame is an IDR picture; the second one is a P field (it may predict from the first) or an I field */
         const int idr = idr_frame && fld == 0, intra_pic = idr || (idr_frame && fld == 1 && (p->seed + (unsigned)t) % 3 == 0);
-        e->field = p->field_pics != 0, e->bottom = p->field_pics ? (p->field_pics == 2) ^ fld : 0;
+        e->field = as_fields, e->bottom = as_fields ? (p->field_pics == 2) ^ fld : 0;
+        e->H = as_fields ? e->fH / 2 : e->fH, e->hmb = e->H / 16; /* the PICTURE: a frame or one field */
+        sg_set_field_mode(as_fields);
         if (!e->field)
             sg_source_frame(p, dsp, e->src);
         else { /* the lines of this parity, planes back to back at field size */
@@ -2452,7 +2460,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             out += n;
             n = write_pps(e, stream + out, cap - out);
             out += n;
-            for (int i = 0; i < 12; i++) e->pics[i].is_ref = 0;
+            for (int i = 0; i < 6; i++) e->pics[i].is_ref = 0;
         }
         /* frame_num gap (8.2.5.2): the skipped values enter the window as non-existing frames, oldest pictures leave */
         if (p->fn_gap_period > 0 && p->bframes == 0 && !p->mmco && !idr && since_idr > 0 && since_idr % p->fn_gap_period == 0) {
@@ -2475,10 +2483,13 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             }
         }
         /* current picture buffer */
-        e->cur = NULL;
-        for (int i = 0; i < (e->field ? 12 : 6) && !e->cur; i++)
-            if (!e->pics[i].is_ref && &e->pics[i] != first_field) e->cur = &e->pics[i];
-        e->cur->w = e->W, e->cur->h = e->H, e->cur->parity = e->bottom, e->cur->fid = t;
+        if (fld == 0) { /* the frame store of this frame */
+            e->cur_frame = NULL;
+            for (int i = 0; i < 6 && !e->cur_frame; i++)
+                if (!e->pics[i].is_ref) e->cur_frame = &e->pics[i];
+            e->cur_frame->nonexist = 0, e->cur_frame->frame_num = frame_num, e->cur_frame->poc = poc;
+        }
+        e->cur = e->field ? &e->fpics[e->cur_frame - e->pics][e->bottom] : e->cur_frame;
         e->cur->nonexist = 0;
         e->cur->id = e->next_id++;
         e->cur->frame_num = frame_num;
@@ -2494,7 +2505,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         if (bpic)
             plan_b_lists(e);
         else if (e->field) {
-            if (!intra_pic) plan_field_list(e);
+            if (!intra_pic) plan_field_list(e, fld);
         } else if (!idr) {
             plan_ref_list(e);
             if (e->nal_ref_idc) plan_marking(e, &ms);
@@ -2670,21 +2681,23 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             out += n;
         }
         sg_deblock(e->cur, e->db, e->wmb, e->hmb);
-        if (e->field) { /* weave the field into the frame of recon[] */
-            if (recon && (size_t)(t + 1) * frame_bytes <= recon_cap) {
-                uint8_t *o = recon + (size_t)t * frame_bytes;
-                for (int pl = 0; pl < 3; pl++) {
-                    const int pw = pl ? e->W / 2 : e->W, ph = pl ? e->fH / 2 : e->fH;
-                    for (int y = e->bottom; y < ph; y += 2) memcpy(o + (size_t)y * pw, e->cur->pl[pl] + (size_t)(y >> 1) * pw, (size_t)pw);
-                    o += (size_t)pw * ph;
-                }
+        if (e->field) {
+            /* marking is the frame's business (8.2.5.3 counts frames): the first field does what a frame picture would do, the second
+             * field of a reference frame just joins it */
+            if (fld == 0) {
+                sg_pic *fieldpic = e->cur;
+                e->cur = e->cur_frame;
+                apply_marking(e, &ms, idr);
+                e->cur = fieldpic;
+                continue;
             }
-            apply_field_marking(e, fld, idr);
-            first_field = e->cur;
-            continue; /* the frame-level counters move after the second field, below */
+            weave_or_split(e, (int)(e->cur_frame - e->pics), 1);
+            e->cur = e->cur_frame;
+        } else {
+            apply_marking(e, &ms, idr);
+            if (p->field_pics) weave_or_split(e, (int)(e->cur_frame - e->pics), 0);
         }
-        if (recon && (size_t)(t + 1) * fsz <= recon_cap) memcpy(recon + (size_t)t * fsz, e->cur->pl[0], fsz);
-        apply_marking(e, &ms, idr);
+        if (recon && (size_t)(t + 1) * fsz <= recon_cap) memcpy(recon + (size_t)t * fsz, e->cur_frame->pl[0], fsz);
         if (e->cur->is_ref && p->bframes > 0) { /* a later B picture may take this one as its co-located picture */
             if (!e->cur->motion) e->cur->motion = malloc(sizeof(emb) * (size_t)e->wmb * e->hmb);
             memcpy(e->cur->motion, e->mb, sizeof(emb) * (size_t)e->wmb * e->hmb);
@@ -2708,7 +2721,7 @@ done:
     free(disp);
     free(is_b);
     free(b_ref);
-    for (int i = 0; i < 12; i++) free(e->pics[i].pl[0]), free(e->pics[i].motion);
+    for (int i = 0; i < 6; i++) free(e->pics[i].pl[0]), free(e->pics[i].motion), free(e->fpics[i][0].pl[0]), free(e->fpics[i][1].pl[0]);
     free(e->mb);
     free(e->db);
     free(e->src);

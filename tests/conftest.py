@@ -191,5 +191,8 @@ FIELD_MATRIX = {
     "field_slices3_idc2": dict(FIELD_BASE, slices=3, deblock_idc=2, alpha_off_div2=2, beta_off_div2=-1, num_ref_frames=2, seed=306),
     "field_wp_poc1": dict(FIELD_BASE, weighted_pred=1, poc_type=1, num_ref_frames=3, idr_period=3, frames=7, seed=307),
     "field_poc2_qpjitter": dict(FIELD_BASE, poc_type=2, qp_jitter=6, slice_qp_delta=2, skip_permille=300, num_ref_frames=2, seed=308),
+    "field_mixed_paff": dict(FIELD_BASE, field_pics=3, frames=10, idr_period=6, num_ref_frames=3, sub8x8_permille=300, seed=310),
+    "field_mixed_nonref_high": dict(FIELD_BASE, field_pics=3, frames=9, nonref_period=3, num_ref_frames=2, profile_idc=100, transform8x8=1, weighted_pred=2, seed=311),
+    "field_nonref_pairs": dict(FIELD_BASE, frames=7, nonref_period=2, num_ref_frames=2, poc_type=2, seed=312),
     "field_cropped": dict(FIELD_BASE, width=170, height=124, num_ref_frames=2, constrained_intra=1, intra_in_p_permille=150, seed=309),
 }
