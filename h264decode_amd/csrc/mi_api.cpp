@@ -846,6 +846,7 @@ static void finish_picture(h264mi_decoder *d, int si) {
 
 static bool new_picture(const h264mi_sps &sps, const h264mi_slice_header &a, const h264mi_slice_header &b) { // 7.4.1.2.4
     if (a.frame_num != b.frame_num || a.pps_id != b.pps_id) return true;
+    if (a.field_pic != b.field_pic || a.bottom_field != b.bottom_field) return true; // (the two fields of a frame are two pictures)
     if ((a.nal_ref_idc == 0) != (b.nal_ref_idc == 0)) return true;
     if ((a.nal_unit_type == 5) != (b.nal_unit_type == 5)) return true;
     if (a.nal_unit_type == 5 && a.idr_pic_id != b.idr_pic_id) return true;

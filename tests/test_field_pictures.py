@@ -86,3 +86,27 @@ def test_single_field_at_the_end(sg, oracle_mod):
 def test_field_recipes_need_cavlc(sg):
     with pytest.raises(RuntimeError, match="cabac = 0"):
         sg.encode(**dict(FIELD_MATRIX["field_IP"], cabac=1))
+
+
+def test_access_units_of_field_streams(H, sg):
+    """7.4.1.2.4: field_pic_flag / bottom_field_flag separate pictures -- the two fields of a frame are two access units even
+    when every other header field agrees (pic_order_cnt_type 2: same frame_num, no POC syntax).  h264mi_slice_starts_picture
+    (the decoder's own test) through the stream front-end's splitter."""
+    for name in ("field_mixed_paff", "field_slices3_idc2", "field_nonref_pairs", "field_poc2_qpjitter"):
+        kw = FIELD_MATRIX[name]
+        stream, _, _ = sg.encode(**kw)
+        nals = H.read_nal_units(stream)
+        sps = H.NewSPS(nals[0].RBSP())
+        vs = H.VideoStream(sps, H.NewPPS(sps, nals[1].RBSP()))
+        pictures, prev = 0, None
+        for n in nals:
+            if n.Type in (1, 5):
+                h = H.NewSliceContext(vs, n, n.RBSP()).Slice.Header
+                key = (h.FrameNum, bool(h.FieldPic), bool(h.BottomField), n.Type, n.RefIdc == 0)
+                pictures += key != prev
+                prev = key
+        sp = H.AccessUnitSplitter(max_units_per_chunk=1)
+        aus = sp.feed(stream) + sp.flush()
+        assert len(aus) == pictures and b"".join(aus) == stream, name
+        if kw["field_pics"] in (1, 2):
+            assert pictures == 2 * kw["frames"]
