@@ -25,7 +25,8 @@ const char *h264o_last_error(h264o_decoder *d) { return d->err; }
 
 h264o_decoder *h264o_decoder_create(void) { return (h264o_decoder *)calloc(1, sizeof(h264o_decoder)); }
 static void free_pics(h264o_decoder *d) {
-    for (int i = 0; i < d->n_pics; i++) free(d->pics[i].plane[0]), free(d->pics[i].mbs);
+    for (int i = 0; i < d->n_pics; i++) free(d->pics[i].plane[0]), free(d->pics[i].mbs), free(d->fviews[i][0].mbs), free(d->fviews[i][1].mbs);
+    memset(d->fviews, 0, sizeof(d->fviews));
     d->n_pics = 0;
     free(d->mb);
     d->mb = NULL;
@@ -202,36 +203,81 @@ static int build_ref_list(h264o_decoder *d) {
     if (nst + nlt == 0) return h264o_fail(d, "P/B slice without reference pictures");
     int n0 = 0, n1 = 0;
     if (d->field_pic) {
-        /* 8.2.4.2.2 + 8.2.4.2.5: frames by FrameNumWrap (long-term: LongTermFrameIdx), then their fields alternately, the parity
+        /* 8.2.4.2.2 / 8.2.4.2.4 + 8.2.4.2.5: the reference frames in order -- P: by FrameNumWrap; B: by PicOrderCnt around the current field,
+         * list 0 the earlier ones first, list 1 the later ones; long-term: by LongTermFrameIdx --, then their fields alternately, the parity
          * of the current field first; a missing field is passed over, and when one parity is used up the other one follows in order */
-        if (sh->slice_type == 1) return h264o_fail(d, "B field pictures are out of scope");
-        if (sh->ref_pic_list_modification_flag_l0) return h264o_fail(d, "ref_pic_list_modification in field pictures is out of scope");
-        for (int i = 0; i < nst; i++)
-            for (int j = i + 1; j < nst; j++)
-                if (st[j]->frame_num_wrap > st[i]->frame_num_wrap) {
-                    h264o_pic *t = st[i];
-                    st[i] = st[j], st[j] = t;
-                }
-        for (int grp = 0; grp < 2; grp++) {
-            h264o_pic **fr = grp ? lt : st;
-            const int nfr = grp ? nlt : nst;
-            int a = 0, b = 0; /* next frame to look at for the same / the opposite parity */
-            for (int want_same = 1;; want_same ^= 1) {
-                int *cursor = want_same ? &a : &b;
-                const int par = want_same ? d->bottom : !d->bottom;
-                while (*cursor < nfr && !(fr[*cursor]->fields >> par & 1)) (*cursor)++;
-                if (*cursor == nfr) { /* this parity is used up: the rest of the other one */
-                    cursor = want_same ? &b : &a;
-                    const int opar = !par;
-                    for (; *cursor < nfr; (*cursor)++)
-                        if ((fr[*cursor]->fields >> opar & 1) && n0 < 32) d->rpl0[n0++] = &d->fviews[fr[*cursor] - d->pics][opar];
-                    break;
-                }
-                if (n0 < 32) d->rpl0[n0++] = &d->fviews[fr[*cursor] - d->pics][par];
-                (*cursor)++;
+        if (sh->ref_pic_list_modification_flag_l0 || (sh->slice_type == 1 && sh->ref_pic_list_modification_flag_l1))
+            return h264o_fail(d, "ref_pic_list_modification in field pictures is out of scope");
+        h264o_pic *ord[2][20];
+        int nord[2] = {0, 0};
+        if (sh->slice_type != 1) {
+            for (int i = 0; i < nst; i++)
+                for (int j = i + 1; j < nst; j++)
+                    if (st[j]->frame_num_wrap > st[i]->frame_num_wrap) {
+                        h264o_pic *t = st[i];
+                        st[i] = st[j], st[j] = t;
+                    }
+            for (int i = 0; i < nst; i++) ord[0][nord[0]++] = st[i];
+        } else {
+            /* PicOrderCnt of a frame of which both fields are references: the smaller one; of the current frame (second field): its first field's */
+            h264o_pic *before[20], *after[20];
+            int nb = 0, na = 0;
+            const int cur_poc = d->cur->poc;
+            for (int i = 0; i < nst; i++) {
+                if (st[i]->nonexisting) continue;
+                const int fp = st[i] == d->curf ? st[i]->fpoc[!d->bottom] : st[i]->poc;
+                st[i]->pic_num = fp; /* (scratch: the sort key) */
+                if (fp <= cur_poc) before[nb++] = st[i];
+                else after[na++] = st[i];
             }
+            for (int i = 0; i < nb; i++)
+                for (int j = i + 1; j < nb; j++)
+                    if (before[j]->pic_num > before[i]->pic_num) {
+                        h264o_pic *t = before[i];
+                        before[i] = before[j], before[j] = t;
+                    }
+            for (int i = 0; i < na; i++)
+                for (int j = i + 1; j < na; j++)
+                    if (after[j]->pic_num < after[i]->pic_num) {
+                        h264o_pic *t = after[i];
+                        after[i] = after[j], after[j] = t;
+                    }
+            for (int i = 0; i < nb; i++) ord[0][nord[0]++] = before[i];
+            for (int i = 0; i < na; i++) ord[0][nord[0]++] = after[i];
+            for (int i = 0; i < na; i++) ord[1][nord[1]++] = after[i];
+            for (int i = 0; i < nb; i++) ord[1][nord[1]++] = before[i];
+        }
+        for (int l = 0; l < (sh->slice_type == 1 ? 2 : 1); l++) {
+            h264o_pic **out = l ? d->rpl1 : d->rpl0;
+            int n = 0;
+            for (int grp = 0; grp < 2; grp++) {
+                h264o_pic **fr = grp ? lt : ord[l];
+                const int nfr = grp ? nlt : nord[l];
+                int a = 0, b = 0; /* next frame to look at for the same / the opposite parity */
+                for (int want_same = 1;; want_same ^= 1) {
+                    int *cursor = want_same ? &a : &b;
+                    const int par = want_same ? d->bottom : !d->bottom;
+                    while (*cursor < nfr && !(fr[*cursor]->fields >> par & 1)) (*cursor)++;
+                    if (*cursor == nfr) { /* this parity is used up: the rest of the other one */
+                        cursor = want_same ? &b : &a;
+                        const int opar = !par;
+                        for (; *cursor < nfr; (*cursor)++)
+                            if ((fr[*cursor]->fields >> opar & 1) && n < 32) out[n++] = &d->fviews[fr[*cursor] - d->pics][opar];
+                        break;
+                    }
+                    if (n < 32) out[n++] = &d->fviews[fr[*cursor] - d->pics][par];
+                    (*cursor)++;
+                }
+            }
+            if (l) n1 = n;
+            else n0 = n;
+        }
+        if (sh->slice_type == 1 && n1 > 1 && n0 == n1 && memcmp(d->rpl0, d->rpl1, sizeof(d->rpl0[0]) * n1) == 0) {
+            h264o_pic *t = d->rpl1[0];
+            d->rpl1[0] = d->rpl1[1], d->rpl1[1] = t;
         }
         for (int i = nact0; i < 33; i++) d->rpl0[i] = NULL;
+        for (int i = nact1; i < 33; i++) d->rpl1[i] = NULL;
         return 0;
     }
     if (sh->slice_type != 1) { /* 8.2.4.2.1: P / SP -- PicNum descending, then LongTermPicNum ascending */
@@ -396,7 +442,13 @@ static void finish_picture(h264o_decoder *d) {
         /* a field: the frame goes out when its second field is done -- or, for a field that stays single, when the next picture starts */
         f->fields |= 1 << d->bottom;
         f->fpoc[d->bottom] = d->cur->poc;
-        f->n_mbs = 0; /* (no co-located motion kept: B pictures cannot take a field-coded frame as RefPicList1[0] here) */
+        f->n_mbs = 0; /* (a B FRAME picture cannot take a field-coded frame as its co-located picture here) */
+        if (f->ref) { /* a later B field may take this field as its co-located picture (RefPicList1[0]) */
+            h264o_pic *v = d->cur;
+            v->mbs = (h264o_mb *)realloc(v->mbs, sizeof(h264o_mb) * (size_t)d->wmb * d->fhmb);
+            v->n_mbs = d->wmb * d->hmb;
+            memcpy(v->mbs, d->mb, sizeof(h264o_mb) * (size_t)v->n_mbs);
+        }
         d->cur = d->curf = NULL;
         if (f->fields == 3) {
             f->poc = f->fpoc[0] < f->fpoc[1] ? f->fpoc[0] : f->fpoc[1];
@@ -499,7 +551,9 @@ static int fill_frame_num_gap(h264o_decoder *d) {
 /* the rows of one parity of a frame store as a picture of their own (h264o_decoder::fviews) */
 static h264o_pic *make_view(h264o_decoder *d, h264o_pic *p, int parity, int poc) {
     h264o_pic *v = &d->fviews[p - d->pics][parity];
+    struct h264o_mb_s *keep = v->mbs; /* the motion array is kept for re-use; n_mbs = 0: nothing valid in it */
     memset(v, 0, sizeof(*v));
+    v->mbs = keep;
     for (int i = 0; i < 3; i++) v->plane[i] = p->plane[i] + (size_t)parity * p->stride[i], v->stride[i] = 2 * p->stride[i];
     v->parity = parity, v->poc = poc, v->frame_num = p->frame_num, v->ref = 1;
     v->id = d->next_pic_id++;
@@ -569,8 +623,9 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
     h264o_slice_header sh;
     int r = h264o_parse_slice_header(&d->br, nal->nal_ref_idc, nal->nal_unit_type, d->sps, d->pps, &sh);
     if (r < 0) return h264o_fail(d, "slice header parse error %d", r);
-    /* field pictures (PAFF): I and P fields, CAVLC, sliding-window marking and initial lists.  Out of scope for now: CABAC (the context
-     * tables of field-coded blocks, ctxIdx 277..398 and 436..459, are not in this tree), B fields, list modification and marking scripts */
+    /* field pictures (PAFF): I, P and B fields, CAVLC, sliding-window marking and initial lists.  Out of scope for now: CABAC (the context
+     * tables of field-coded blocks, ctxIdx 277..398 and 436..459, are not in this tree), list modification and marking scripts, and a
+     * co-located picture of the other shape (a B field whose RefPicList1[0] belongs to a frame-coded frame, or the reverse) */
     if (sh.field_pic_flag) {
         if (d->pps[sh.pic_parameter_set_id].entropy_coding_mode_flag) return h264o_fail(d, "field pictures with CABAC are out of scope");
         if (sh.adaptive_ref_pic_marking_mode_flag) return h264o_fail(d, "marking scripts in field pictures are out of scope");

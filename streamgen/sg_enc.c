@@ -1487,7 +1487,8 @@ static void b_predict(enc *e, uint8_t *py, uint8_t pc[2][64]) {
             if (!use[l]) continue;
             int mvx = EMV(m, l)[blk][0], mvy = EMV(m, l)[blk][1];
             sg_mc_luma(rp[l], e->mbx * 16 + bx * 4, e->mby * 16 + by * 4, 4, 4, mvx, mvy, ty[l], 4);
-            for (int c = 0; c < 2; c++) sg_mc_chroma(rp[l], 1 + c, e->mbx * 8 + bx * 2, e->mby * 8 + by * 2, 2, 2, mvx, mvy, tc[l][c], 2);
+            const int cofs = !e->field || rp[l]->parity == e->bottom ? 0 : (e->bottom ? 2 : -2); /* Table 8-9, as in mc_part() */
+            for (int c = 0; c < 2; c++) sg_mc_chroma(rp[l], 1 + c, e->mbx * 8 + bx * 2, e->mby * 8 + by * 2, 2, 2, mvx, mvy + cofs, tc[l][c], 2);
         }
         int iw[2] = {32, 32};
         if (idc == 2 && use[0] && use[1]) {
@@ -2299,6 +2300,57 @@ static void plan_field_list(enc *e, int second) {
     e->n_rplm = 0;
     for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? list[i] : NULL;
 }
+/* RefPicList0 / RefPicList1 of a B field (8.2.4.2.4 + 8.2.4.2.5): the reference frames by PicOrderCnt around the current field
+ * (list 0: at or before it, nearest first, then the later ones; list 1 the other way round), each list then turned into fields
+ * by the same alternation as for P fields */
+static int alternate_fields(enc *e, const int *fr, int n, sg_pic **list) {
+    int nl = 0, a = 0, b = 0;
+    while (a < n && b < n) list[nl++] = &e->fpics[fr[a++]][e->bottom], list[nl++] = &e->fpics[fr[b++]][!e->bottom];
+    return nl;
+}
+static void plan_b_field_lists(enc *e) {
+    int past[6], future[6], np = 0, nf = 0;
+    for (int i = 0; i < 6; i++) {
+        if (e->pics[i].is_ref != 1 || &e->pics[i] == e->cur_frame) continue;
+        if (e->pics[i].poc <= e->cur_poc) past[np++] = i;
+        else future[nf++] = i;
+    }
+    for (int i = 0; i < np; i++)
+        for (int j = i + 1; j < np; j++)
+            if (e->pics[past[j]].poc > e->pics[past[i]].poc) {
+                int t = past[i];
+                past[i] = past[j], past[j] = t;
+            }
+    for (int i = 0; i < nf; i++)
+        for (int j = i + 1; j < nf; j++)
+            if (e->pics[future[j]].poc < e->pics[future[i]].poc) {
+                int t = future[i];
+                future[i] = future[j], future[j] = t;
+            }
+    int f0[12], f1[12], n = 0;
+    for (int i = 0; i < np; i++) f0[n++] = past[i];
+    for (int i = 0; i < nf; i++) f0[n++] = future[i];
+    n = 0;
+    for (int i = 0; i < nf; i++) f1[n++] = future[i];
+    for (int i = 0; i < np; i++) f1[n++] = past[i];
+    sg_pic *l0[24], *l1[24];
+    const int n0 = alternate_fields(e, f0, n, l0), n1 = alternate_fields(e, f1, n, l1);
+    if (n1 > 1 && n0 == n1) {
+        int same = 1;
+        for (int i = 0; i < n1; i++) same &= l0[i] == l1[i];
+        if (same) {
+            sg_pic *t = l1[0];
+            l1[0] = l1[1], l1[1] = t;
+        }
+    }
+    e->nrefs = n0;
+    e->nref_active = n0 < 4 ? n0 : 4;
+    if (e->nref_active > 1 && rnd(e) % 3 == 0) e->nref_active = 1 + (int)(rnd(e) % (uint32_t)e->nref_active);
+    e->nref1_active = n1 < 2 ? n1 : 1 + (int)(rnd(e) % 3u);
+    for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? l0[i] : NULL, e->refs1[i] = i < e->nref1_active ? l1[i] : NULL;
+    e->n_rplm = 0;
+}
+
 /* the finished frame in its other shape: woven from its two fields, or split into them */
 static void weave_or_split(enc *e, int slot, int from_fields) {
     sg_pic *f = &e->pics[slot];
@@ -2346,8 +2398,10 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             free(e);
             return 0;
         }
-        p->interlace_sps = 1, p->bframes = 0, p->b_pyramid = 0, p->mmco = 0, p->rplm = 0, p->idr_long_term = 0;
+        p->interlace_sps = 1, p->b_pyramid = 0, p->mmco = 0, p->rplm = 0, p->idr_long_term = 0;
         p->fn_gap_period = 0, p->slice_groups = 0, p->aso = 0;
+        if (p->field_pics == 3) p->bframes = 0; /* B fields: only in streams that are all fields (co-located pictures of the same shape) */
+        p->direct_temporal = 0;                /* ... and with spatial direct prediction */
     }
     e->W = (p->width + 15) & ~15, e->H = (p->height + 15) & ~15;
     e->wmb = e->W / 16, e->hmb = e->H / 16;
@@ -2502,7 +2556,9 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         e->idr_lt = idr && p->idr_long_term;
         e->n_rplm = e->n_mmco = 0;
         memset(&ms, 0, sizeof(ms));
-        if (bpic)
+        if (bpic && e->field)
+            plan_b_field_lists(e);
+        else if (bpic)
             plan_b_lists(e);
         else if (e->field) {
             if (!intra_pic) plan_field_list(e, fld);
@@ -2682,6 +2738,11 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         }
         sg_deblock(e->cur, e->db, e->wmb, e->hmb);
         if (e->field) {
+            e->cur->is_ref = e->nal_ref_idc ? 1 : 0; /* (short-term or not: what colZeroFlag asks of RefPicList1[0]; the window lives on the frames) */
+            if (e->nal_ref_idc && p->bframes > 0) { /* a later B field may take this field as its co-located picture */
+                if (!e->cur->motion) e->cur->motion = malloc(sizeof(emb) * (size_t)e->wmb * (size_t)(e->fH / 32));
+                memcpy(e->cur->motion, e->mb, sizeof(emb) * (size_t)e->wmb * e->hmb);
+            }
             /* marking is the frame's business (8.2.5.3 counts frames): the first field does what a frame picture would do, the second
              * field of a reference frame just joins it */
             if (fld == 0) {
@@ -2721,7 +2782,7 @@ done:
     free(disp);
     free(is_b);
     free(b_ref);
-    for (int i = 0; i < 6; i++) free(e->pics[i].pl[0]), free(e->pics[i].motion), free(e->fpics[i][0].pl[0]), free(e->fpics[i][1].pl[0]);
+    for (int i = 0; i < 6; i++) free(e->pics[i].pl[0]), free(e->pics[i].motion), free(e->fpics[i][0].pl[0]), free(e->fpics[i][1].pl[0]), free(e->fpics[i][0].motion), free(e->fpics[i][1].motion);
     free(e->mb);
     free(e->db);
     free(e->src);
