@@ -1461,7 +1461,10 @@ static void b_direct(enc *e, int mask8) {
             r0 = -1;
             for (int i = 0; i < e->nref_active && r0 < 0; i++)
                 if (e->refs[i]->id == cid) r0 = i;
-            if (r0 < 0) r0 = 0, cmv[0] = cmv[1] = 0; /* cannot happen: the anchors' references stay in the DPB */
+            if (r0 < 0) { /* cannot happen: the anchors' references stay in the DPB and within the active entries (plan_ref_list, plan_field_list) */
+                if (getenv("SG_DEBUG")) fprintf(stderr, "temporal direct: the co-located block's reference is not in RefPicList0\n");
+                r0 = 0, cmv[0] = cmv[1] = 0;
+            }
         }
         int dsf = 0, mv0[2], mv1[2];
         if (dist_scale(e->cur_poc, e->refs[r0]->poc, e->refs1[0]->poc, e->refs[r0]->is_ref == 2, &dsf)) {
@@ -2297,6 +2300,10 @@ static void plan_field_list(enc *e, int second) {
     e->nrefs = nl;
     e->nref_active = nl < 4 ? nl : 4;
     if (e->nref_active > 1 && rnd(e) % 4 == 0) e->nref_active = 1 + (int)(rnd(e) % (uint32_t)e->nref_active); /* a shorter list now and then */
+    /* temporal direct maps the field a co-located block predicts from into RefPicList0 of the B field (8.4.1.2.3), whose first four
+     * entries are the two fields of the nearest earlier frame and of the next one: an anchor's first field keeps to the former, its
+     * second field -- whose list holds the first field of its own frame second, which the B field may only find further down -- to entry 0 */
+    if (e->p.bframes > 0 && e->p.direct_temporal) e->nref_active = second ? 1 : (e->nref_active < 2 ? e->nref_active : 2);
     e->n_rplm = 0;
     for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? list[i] : NULL;
 }
@@ -2345,7 +2352,7 @@ static void plan_b_field_lists(enc *e) {
     }
     e->nrefs = n0;
     e->nref_active = n0 < 4 ? n0 : 4;
-    if (e->nref_active > 1 && rnd(e) % 3 == 0) e->nref_active = 1 + (int)(rnd(e) % (uint32_t)e->nref_active);
+    if (e->nref_active > 1 && rnd(e) % 3 == 0 && !e->p.direct_temporal) e->nref_active = 1 + (int)(rnd(e) % (uint32_t)e->nref_active);
     e->nref1_active = n1 < 2 ? n1 : 1 + (int)(rnd(e) % 3u);
     for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? l0[i] : NULL, e->refs1[i] = i < e->nref1_active ? l1[i] : NULL;
     e->n_rplm = 0;
@@ -2401,7 +2408,6 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         p->interlace_sps = 1, p->b_pyramid = 0, p->mmco = 0, p->rplm = 0, p->idr_long_term = 0;
         p->fn_gap_period = 0, p->slice_groups = 0, p->aso = 0;
         if (p->field_pics == 3) p->bframes = 0; /* B fields: only in streams that are all fields (co-located pictures of the same shape) */
-        p->direct_temporal = 0;                /* ... and with spatial direct prediction */
     }
     e->W = (p->width + 15) & ~15, e->H = (p->height + 15) & ~15;
     e->wmb = e->W / 16, e->hmb = e->H / 16;

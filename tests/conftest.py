@@ -197,5 +197,7 @@ FIELD_MATRIX = {
     "field_b_spatial": dict(FIELD_BASE, frames=9, bframes=2, num_ref_frames=2, bskip_permille=250, sub8x8_permille=300, seed=313),
     "field_b_bottom_first_wp": dict(FIELD_BASE, field_pics=2, frames=8, bframes=1, num_ref_frames=3, weighted_bipred=1, intra_in_p_permille=100, seed=314),
     "field_b_implicit_high": dict(FIELD_BASE, frames=9, bframes=3, num_ref_frames=2, weighted_bipred=2, profile_idc=100, transform8x8=1, idr_period=8, slices=2, seed=315),
+    "field_b_temporal": dict(FIELD_BASE, frames=9, bframes=2, direct_temporal=1, num_ref_frames=3, bskip_permille=400, seed=316),
+    "field_b_temporal_implicit_bff": dict(FIELD_BASE, field_pics=2, frames=9, bframes=3, direct_temporal=1, weighted_bipred=2, num_ref_frames=2, bskip_permille=300, idr_period=8, seed=317),
     "field_cropped": dict(FIELD_BASE, width=170, height=124, num_ref_frames=2, constrained_intra=1, intra_in_p_permille=150, seed=309),
 }
