@@ -181,6 +181,44 @@ static int modify_list(h264o_decoder *d, h264o_pic **list, int nact, h264o_pic *
     return 0;
 }
 
+/* 8.2.4.3 for field pictures: the commands name FIELDS -- picNumF of a short-term field is 2 * FrameNumWrap + 1 for a field of the
+ * current parity and 2 * FrameNumWrap for one of the other, LongTermPicNum likewise on LongTermFrameIdx; CurrPicNum = 2 * frame_num + 1,
+ * MaxPicNum = 2 * MaxFrameNum (8.2.4.1).  st / lt: the reference frames (the current one included for a second field). */
+static int modify_field_list(h264o_decoder *d, h264o_pic **list, int nact, h264o_pic **st, int nst, h264o_pic **lt, int nlt, int ncmd, const int *idc, const int *val) {
+    const h264o_slice_header *sh = &d->sh;
+    const int max_pic_num = 2 << (d->asps->log2_max_frame_num_minus4 + 4), cur_pic_num = 2 * sh->frame_num + 1;
+    int pred = cur_pic_num, idx = 0;
+    for (int k = 0; k < ncmd && idx < nact; k++) {
+        h264o_pic *target = NULL;
+        if (idc[k] < 2) {
+            const int diff = val[k] + 1;
+            if (idc[k] == 0) {
+                pred -= diff;
+                if (pred < 0) pred += max_pic_num;
+            } else {
+                pred += diff;
+                if (pred >= max_pic_num) pred -= max_pic_num;
+            }
+            const int picnum = pred > cur_pic_num ? pred - max_pic_num : pred;
+            for (int i = 0; i < nst; i++)
+                for (int par = 0; par < 2; par++)
+                    if ((st[i]->fields >> par & 1) && 2 * st[i]->frame_num_wrap + (par == d->bottom) == picnum) target = &d->fviews[st[i] - d->pics][par];
+        } else {
+            for (int i = 0; i < nlt; i++)
+                for (int par = 0; par < 2; par++)
+                    if ((lt[i]->fields >> par & 1) && 2 * lt[i]->long_term_frame_idx + (par == d->bottom) == val[k]) target = &d->fviews[lt[i] - d->pics][par];
+        }
+        if (!target) return h264o_fail(d, "ref_pic_list_modification names a missing field");
+        d->feat |= 1u << (8 + idc[k]);
+        for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+        list[idx++] = target;
+        int nidx = idx;
+        for (int c = idx; c <= nact; c++)
+            if (list[c] != target) list[nidx++] = list[c];
+    }
+    return 0;
+}
+
 static int build_ref_list(h264o_decoder *d) {
     const h264o_slice_header *sh = &d->sh;
     int max_fn = 1 << (d->asps->log2_max_frame_num_minus4 + 4);
@@ -206,8 +244,6 @@ static int build_ref_list(h264o_decoder *d) {
         /* 8.2.4.2.2 / 8.2.4.2.4 + 8.2.4.2.5: the reference frames in order -- P: by FrameNumWrap; B: by PicOrderCnt around the current field,
          * list 0 the earlier ones first, list 1 the later ones; long-term: by LongTermFrameIdx --, then their fields alternately, the parity
          * of the current field first; a missing field is passed over, and when one parity is used up the other one follows in order */
-        if (sh->ref_pic_list_modification_flag_l0 || (sh->slice_type == 1 && sh->ref_pic_list_modification_flag_l1))
-            return h264o_fail(d, "ref_pic_list_modification in field pictures is out of scope");
         h264o_pic *ord[2][20];
         int nord[2] = {0, 0};
         if (sh->slice_type != 1) {
@@ -276,6 +312,12 @@ static int build_ref_list(h264o_decoder *d) {
             h264o_pic *t = d->rpl1[0];
             d->rpl1[0] = d->rpl1[1], d->rpl1[1] = t;
         }
+        for (int i = nact0; i < 33; i++) d->rpl0[i] = NULL;
+        for (int i = nact1; i < 33; i++) d->rpl1[i] = NULL;
+        if (sh->ref_pic_list_modification_flag_l0 && modify_field_list(d, d->rpl0, nact0, st, nst, lt, nlt, sh->n_rplm, sh->rplm_idc, sh->rplm_val) < 0) return -1;
+        if (sh->slice_type == 1 && sh->ref_pic_list_modification_flag_l1 &&
+            modify_field_list(d, d->rpl1, nact1, st, nst, lt, nlt, sh->n_rplm1, sh->rplm1_idc, sh->rplm1_val) < 0)
+            return -1;
         for (int i = nact0; i < 33; i++) d->rpl0[i] = NULL;
         for (int i = nact1; i < 33; i++) d->rpl1[i] = NULL;
         return 0;
@@ -624,7 +666,7 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
     int r = h264o_parse_slice_header(&d->br, nal->nal_ref_idc, nal->nal_unit_type, d->sps, d->pps, &sh);
     if (r < 0) return h264o_fail(d, "slice header parse error %d", r);
     /* field pictures (PAFF): I, P and B fields, CAVLC, sliding-window marking and initial lists.  Out of scope for now: CABAC (the context
-     * tables of field-coded blocks, ctxIdx 277..398 and 436..459, are not in this tree), list modification and marking scripts, and a
+     * tables of field-coded blocks, ctxIdx 277..398 and 436..459, are not in this tree), marking scripts, and a
      * co-located picture of the other shape (a B field whose RefPicList1[0] belongs to a frame-coded frame, or the reverse) */
     if (sh.field_pic_flag) {
         if (d->pps[sh.pic_parameter_set_id].entropy_coding_mode_flag) return h264o_fail(d, "field pictures with CABAC are out of scope");

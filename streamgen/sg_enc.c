@@ -2305,7 +2305,38 @@ static void plan_field_list(enc *e, int second) {
      * second field -- whose list holds the first field of its own frame second, which the B field may only find further down -- to entry 0 */
     if (e->p.bframes > 0 && e->p.direct_temporal) e->nref_active = second ? 1 : (e->nref_active < 2 ? e->nref_active : 2);
     e->n_rplm = 0;
-    for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? list[i] : NULL;
+    /* list modification (8.2.4.3 on field picture numbers, 8.2.4.1): the first k entries become k distinct fields picked from ALL
+     * reference fields -- picNumF = 2 * FrameNumWrap + 1 for a field of this parity, 2 * FrameNumWrap for one of the other;
+     * CurrPicNum = 2 * frame_num + 1, MaxPicNum = 2 * MaxFrameNum */
+    sg_pic *final[12];
+    int nf = 0;
+    if (e->p.rplm && e->p.bframes == 0 && nl >= 2 && rnd(e) % 100 < 75) {
+        const int k = 1 + (int)(rnd(e) % (uint32_t)(e->nref_active < 3 ? e->nref_active : 3)), max_pic_num = 2 * SG_MAX_FN;
+        int pred = 2 * cur_fn + 1;
+        for (int c = 0; c < k; c++) {
+            sg_pic *t;
+            int dup;
+            do {
+                t = list[rnd(e) % (uint32_t)nl];
+                dup = 0;
+                for (int j = 0; j < nf; j++) dup |= final[j] == t;
+            } while (dup);
+            final[nf++] = t;
+            const int num = 2 * picnum(&e->pics[t->fid], cur_fn) + (t->parity == e->bottom), num_mod = (num + max_pic_num) % max_pic_num;
+            const int down = (pred - num_mod + max_pic_num) % max_pic_num, up = (num_mod - pred + max_pic_num) % max_pic_num;
+            const int use_up = down == 0 || (up != 0 && rnd(e) % 100 < 30);
+            e->rplm[e->n_rplm].idc = use_up ? 1 : 0;
+            e->rplm[e->n_rplm++].val = (use_up ? up : down) - 1;
+            g_feat |= 1u << (use_up ? 9 : 8);
+            pred = num_mod;
+        }
+    }
+    for (int i = 0; i < nl; i++) { /* the rest follows in initial order */
+        int used = 0;
+        for (int j = 0; j < e->n_rplm; j++) used |= final[j] == list[i];
+        if (!used) final[nf++] = list[i];
+    }
+    for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? final[i] : NULL;
 }
 /* RefPicList0 / RefPicList1 of a B field (8.2.4.2.4 + 8.2.4.2.5): the reference frames by PicOrderCnt around the current field
  * (list 0: at or before it, nearest first, then the later ones; list 1 the other way round), each list then turned into fields
@@ -2405,7 +2436,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             free(e);
             return 0;
         }
-        p->interlace_sps = 1, p->b_pyramid = 0, p->mmco = 0, p->rplm = 0, p->idr_long_term = 0;
+        p->interlace_sps = 1, p->b_pyramid = 0, p->mmco = 0, p->idr_long_term = 0;
         p->fn_gap_period = 0, p->slice_groups = 0, p->aso = 0;
         if (p->field_pics == 3) p->bframes = 0; /* B fields: only in streams that are all fields (co-located pictures of the same shape) */
     }

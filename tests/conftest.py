@@ -199,5 +199,7 @@ FIELD_MATRIX = {
     "field_b_implicit_high": dict(FIELD_BASE, frames=9, bframes=3, num_ref_frames=2, weighted_bipred=2, profile_idc=100, transform8x8=1, idr_period=8, slices=2, seed=315),
     "field_b_temporal": dict(FIELD_BASE, frames=9, bframes=2, direct_temporal=1, num_ref_frames=3, bskip_permille=400, seed=316),
     "field_b_temporal_implicit_bff": dict(FIELD_BASE, field_pics=2, frames=9, bframes=3, direct_temporal=1, weighted_bipred=2, num_ref_frames=2, bskip_permille=300, idr_period=8, seed=317),
+    "field_rplm": dict(FIELD_BASE, frames=8, rplm=1, num_ref_frames=3, seed=318),
+    "field_rplm_mixed_nonref": dict(FIELD_BASE, field_pics=3, frames=10, rplm=1, nonref_period=4, num_ref_frames=4, idr_period=7, seed=319),
     "field_cropped": dict(FIELD_BASE, width=170, height=124, num_ref_frames=2, constrained_intra=1, intra_in_p_permille=150, seed=309),
 }
