@@ -712,8 +712,12 @@ static void do_part(h264o_decoder *d, int list, int bx, int by, int w, int h, in
 static int read_ref_idx(h264o_decoder *d, int list, int bx, int by) {
     int nref = list ? d->sh.num_ref_idx_l1_active_minus1 : d->sh.num_ref_idx_l0_active_minus1;
     if (nref == 0) return 0;
-    if (d->apps->entropy_coding_mode_flag) return cabac_ref_idx(d, list, bx, by);
-    return (int)h264o_te(&d->br, nref);
+    const int r = d->apps->entropy_coding_mode_flag ? cabac_ref_idx(d, list, bx, by) : (int)h264o_te(&d->br, nref);
+    if (r < 0 || r > nref) { /* 7.4.5.1: 0 .. num_ref_idx_active_minus1 (damaged streams) */
+        h264o_fail(d, "ref_idx_l%d %d beyond the %d active entries", list, r, nref + 1);
+        return 0;
+    }
+    return r;
 }
 static void set_refids(h264o_decoder *d, h264o_mb *m) {
     for (int l = 0; l < 2; l++)

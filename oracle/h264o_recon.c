@@ -487,7 +487,11 @@ static void inter_pred_mb(h264o_decoder *d, h264o_mb *m) {
                     }
             }
         }
-        if (!used[0] && !used[1]) used[0] = 1, refidx[0] = 0, memset(py[0], 128, sizeof(py[0])), memset(pc[0], 128, sizeof(pc[0])); /* cannot happen */
+        if (!used[0] && !used[1]) { /* no list at all: only in damaged streams -- grey */
+            used[0] = 1, refidx[0] = 0;
+            for (int i = 0; i < 16; i++) py[0][i] = 128;
+            for (int i = 0; i < 4; i++) pc[0][0][i] = pc[0][1][i] = 128;
+        }
         /* weights of this block: luma and the two chroma planes */
         int lw = sh->luma_log2_weight_denom, cw = sh->chroma_log2_weight_denom;
         int iw0 = 32, iw1 = 32;

@@ -40,4 +40,4 @@ def test_host_side_under_asan(tmp_path):
 
 def test_parsers_and_oracle_under_asan(tmp_path):
     out = _run(["bash", "tools/parser_asan.sh", "2000", "3", "4"], tmp_path, 600)
-    assert out.count("parser fuzz:") == 5 and out.count("decoded,") == 5
+    assert out.count("parser fuzz:") == 7 and out.count("decoded,") == 7

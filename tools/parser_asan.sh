@@ -13,10 +13,11 @@ python3 - "$out" <<PY
 import sys
 sys.path.insert(0, "$root"); sys.path.insert(0, "$root/tests")
 import streamgen
-from conftest import MATRIX
-for n in ("fmo_explicit", "fmo_boxout", "b_wp_explicit", "fn_gaps_cabac", "cabac_IPP"):
-    if n in MATRIX:
-        open("%s/%s.h264" % (sys.argv[1], n), "wb").write(streamgen.encode(**MATRIX[n])[0])
+from conftest import FIELD_MATRIX, MATRIX
+ALL = dict(MATRIX, **FIELD_MATRIX)
+for n in ("fmo_explicit", "fmo_boxout", "b_wp_explicit", "fn_gaps_cabac", "cabac_IPP", "field_b_temporal", "field_rplm_mixed_nonref"):
+    if n in ALL:
+        open("%s/%s.h264" % (sys.argv[1], n), "wb").write(streamgen.encode(**ALL[n])[0])
 PY
 for f in "$out"/*.h264; do "$out/parser_asan" "$f" "${1:-20000}" "${2:-1}"; done
 
