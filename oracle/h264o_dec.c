@@ -202,11 +202,11 @@ static int modify_field_list(h264o_decoder *d, h264o_pic **list, int nact, h264o
             const int picnum = pred > cur_pic_num ? pred - max_pic_num : pred;
             for (int i = 0; i < nst; i++)
                 for (int par = 0; par < 2; par++)
-                    if ((st[i]->fields >> par & 1) && 2 * st[i]->frame_num_wrap + (par == d->bottom) == picnum) target = &d->fviews[st[i] - d->pics][par];
+                    if (((st[i]->fields & ~st[i]->funref) >> par & 1) && 2 * st[i]->frame_num_wrap + (par == d->bottom) == picnum) target = &d->fviews[st[i] - d->pics][par];
         } else {
             for (int i = 0; i < nlt; i++)
                 for (int par = 0; par < 2; par++)
-                    if ((lt[i]->fields >> par & 1) && 2 * lt[i]->long_term_frame_idx + (par == d->bottom) == val[k]) target = &d->fviews[lt[i] - d->pics][par];
+                    if (((lt[i]->fields & ~lt[i]->funref) >> par & 1) && 2 * lt[i]->long_term_frame_idx + (par == d->bottom) == val[k]) target = &d->fviews[lt[i] - d->pics][par];
         }
         if (!target) return h264o_fail(d, "ref_pic_list_modification names a missing field");
         d->feat |= 1u << (8 + idc[k]);
@@ -227,6 +227,7 @@ static int build_ref_list(h264o_decoder *d) {
     for (int i = 0; i < d->n_pics; i++) {
         h264o_pic *p = &d->pics[i];
         if (p == d->curf && !(d->field_pic && d->second_field && p->ref == 1)) continue; /* (a second field may predict from the first field of its frame) */
+        if (!d->field_pic && p->funref) continue; /* 8.2.4.2.1: a frame picture predicts from frames of which both fields are marked */
         if (p->ref == 1) {
             p->frame_num_wrap = p->frame_num > sh->frame_num ? p->frame_num - max_fn : p->frame_num;
             p->pic_num = p->frame_num_wrap;
@@ -293,12 +294,12 @@ static int build_ref_list(h264o_decoder *d) {
                 for (int want_same = 1;; want_same ^= 1) {
                     int *cursor = want_same ? &a : &b;
                     const int par = want_same ? d->bottom : !d->bottom;
-                    while (*cursor < nfr && !(fr[*cursor]->fields >> par & 1)) (*cursor)++;
+                    while (*cursor < nfr && !((fr[*cursor]->fields & ~fr[*cursor]->funref) >> par & 1)) (*cursor)++;
                     if (*cursor == nfr) { /* this parity is used up: the rest of the other one */
                         cursor = want_same ? &b : &a;
                         const int opar = !par;
                         for (; *cursor < nfr; (*cursor)++)
-                            if ((fr[*cursor]->fields >> opar & 1) && n < 32) out[n++] = &d->fviews[fr[*cursor] - d->pics][opar];
+                            if (((fr[*cursor]->fields & ~fr[*cursor]->funref) >> opar & 1) && n < 32) out[n++] = &d->fviews[fr[*cursor] - d->pics][opar];
                         break;
                     }
                     if (n < 32) out[n++] = &d->fviews[fr[*cursor] - d->pics][par];
@@ -370,6 +371,30 @@ static void mark_reference(h264o_decoder *d) {
     h264o_pic *cur = d->curf;
     int max_fn = 1 << (d->asps->log2_max_frame_num_minus4 + 4);
     if (sh->nal_ref_idc) d->prev_ref_frame_num = sh->frame_num;
+    if (d->field_pic && sh->nal_ref_idc && !sh->idr_flag && sh->adaptive_ref_pic_marking_mode_flag) {
+        /* 8.2.5.4.1 in a field picture: picNumX names a FIELD (8.2.4.1); the frame stays a reference frame while its other field is one */
+        const int cur_pic_num = 2 * sh->frame_num + 1;
+        for (int k = 0; k < sh->n_mmco; k++) {
+            if (sh->mmco_op[k] != 1) {
+                h264o_fail(d, "memory_management_control_operation %d in a field picture is out of scope", sh->mmco_op[k]);
+                return;
+            }
+            d->feat |= 1u << 1;
+            const int picnum = cur_pic_num - (sh->mmco_arg1[k] + 1);
+            for (int i = 0; i < d->n_pics; i++) {
+                h264o_pic *p = &d->pics[i];
+                if (p->ref != 1) continue;
+                const int wrap = p->frame_num > sh->frame_num ? p->frame_num - max_fn : p->frame_num;
+                for (int par = 0; par < 2; par++)
+                    if (((p->fields & ~p->funref) >> par & 1) && 2 * wrap + (par == d->bottom) == picnum) {
+                        p->funref |= 1 << par;
+                        if (!(p->fields & ~p->funref)) p->ref = 0; /* (the current frame, whose other field is being decoded, is marked just below) */
+                    }
+            }
+        }
+        cur->ref = 1;
+        return;
+    }
     /* 8.2.5.3: the second field of a frame whose first field is a short-term reference joins it, nothing leaves the window */
     if (d->field_pic && d->second_field && cur->ref) return; /* 7.4.3 (operation 5 below: 0) */
     if (!sh->nal_ref_idc) {
@@ -576,7 +601,7 @@ static int fill_frame_num_gap(h264o_decoder *d) {
         for (int i = 0; i < d->n_pics && !slot; i++)
             if (!d->pics[i].ref && !d->pics[i].in_use) slot = &d->pics[i];
         if (!slot) return h264o_fail(d, "DPB full");
-        slot->ref = 1, slot->nonexisting = 1, slot->frame_num = fn, slot->id = d->next_pic_id++, slot->n_mbs = 0;
+        slot->ref = 1, slot->nonexisting = 1, slot->frame_num = fn, slot->id = d->next_pic_id++, slot->n_mbs = 0, slot->funref = 0;
         slot->poc = 0;
         if (s->pic_order_cnt_type != 0) { /* 8.2.1: as a reference frame with this frame_num (keeps FrameNumOffset right across a wrap) */
             h264o_slice_header f;
@@ -631,7 +656,7 @@ static int start_picture(h264o_decoder *d) {
         if (!p) return h264o_fail(d, "DPB full");
         p->in_use = 1;
         p->nonexisting = 0;
-        p->fields = 0;
+        p->fields = 0, p->funref = 0;
         p->id = d->next_pic_id++;
         p->frame_num = sh->frame_num;
         /* deterministic content for MBs that no slice covers (and for the field that may never come) */
@@ -666,11 +691,10 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
     int r = h264o_parse_slice_header(&d->br, nal->nal_ref_idc, nal->nal_unit_type, d->sps, d->pps, &sh);
     if (r < 0) return h264o_fail(d, "slice header parse error %d", r);
     /* field pictures (PAFF): I, P and B fields, CAVLC, sliding-window marking and initial lists.  Out of scope for now: CABAC (the context
-     * tables of field-coded blocks, ctxIdx 277..398 and 436..459, are not in this tree), marking scripts, and a
+     * tables of field-coded blocks, ctxIdx 277..398 and 436..459, are not in this tree), marking operations other than 1, and a
      * co-located picture of the other shape (a B field whose RefPicList1[0] belongs to a frame-coded frame, or the reverse) */
     if (sh.field_pic_flag) {
         if (d->pps[sh.pic_parameter_set_id].entropy_coding_mode_flag) return h264o_fail(d, "field pictures with CABAC are out of scope");
-        if (sh.adaptive_ref_pic_marking_mode_flag) return h264o_fail(d, "marking scripts in field pictures are out of scope");
     }
     if (sh.slice_type > 2) return h264o_fail(d, "slice_type %d out of scope (I, P and B only)", sh.slice_type);
     if (sh.redundant_pic_cnt > 0) return 0; /* redundant coded pictures are ignored */

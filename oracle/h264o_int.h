@@ -21,6 +21,7 @@ typedef struct {
     /* field pictures (PAFF): which fields of the frame are decoded (bit 0 top, bit 1 bottom; a frame picture sets both) and their
      * PicOrderCnt; parity = -1 for a frame, 0 / 1 for the field views (h264o_decoder::fviews) that the lists of field pictures hold */
     int fields, fpoc[2], parity;
+    int funref; /* fields marked "unused for reference" on their own (operation 1 in a field picture) while the other one still is one */
     struct h264o_mb_s *mbs; /* motion of the decoded picture (co-located data for direct prediction, 8.4.1.2) */
     int n_mbs;
 } h264o_pic;

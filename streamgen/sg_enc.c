@@ -105,7 +105,7 @@ static double noise_at(double xs, double ys, uint32_t mulx, uint32_t muly, uint3
         for (int dx = 0; dx < 2; dx++) {
             double w = (dx ? ax : 1 - ax) * (dy ? ay : 1 - ay);
             if (w == 0) continue;
-            acc += w * ((int)(hash32((uint32_t)((xi + dx) * (int)mulx + (yi + dy) * (int)muly) ^ seed) % range) - bias);
+            acc += w * ((int)(hash32(((uint32_t)(xi + dx) * mulx + (uint32_t)(yi + dy) * muly) ^ seed) % range) - bias);
         }
     return acc;
 }
@@ -2024,6 +2024,7 @@ static void plan_ref_list(enc *e) {
     for (int i = 0; i < 6; i++) {
         sg_pic *q = &e->pics[i];
         if (q == e->cur) continue;
+        if (e->p.field_pics && (e->fpics[i][0].dropped || e->fpics[i][1].dropped)) continue; /* only frames with both fields marked (8.2.4.2.1) */
         if (q->is_ref == 1) st[nst++] = q;
         if (q->is_ref == 2) lt[nlt++] = q;
     }
@@ -2289,10 +2290,10 @@ static void plan_field_list(enc *e, int second) {
             }
     sg_pic *same[6], *opp[6], *list[12];
     int ns = 0, no = 0, nl = 0, a = 0, b = 0;
-    for (int i = 0; i < n; i++) {
-        const int whole = &e->pics[fr[i]] != e->cur_frame; /* of the current frame only the first field exists */
-        if (whole) same[ns++] = &e->fpics[fr[i]][e->bottom];
-        opp[no++] = &e->fpics[fr[i]][!e->bottom];
+    for (int i = 0; i < n; i++) { /* a frame that lacks a field -- the current frame its second one, others a field marked unused -- is passed over */
+        const int whole = &e->pics[fr[i]] != e->cur_frame;
+        if (whole && !e->fpics[fr[i]][e->bottom].dropped) same[ns++] = &e->fpics[fr[i]][e->bottom];
+        if (!e->fpics[fr[i]][!e->bottom].dropped) opp[no++] = &e->fpics[fr[i]][!e->bottom];
     }
     while (a < ns && b < no) list[nl++] = same[a++], list[nl++] = opp[b++];
     while (a < ns) list[nl++] = same[a++];
@@ -2338,6 +2339,58 @@ static void plan_field_list(enc *e, int second) {
     }
     for (int i = 0; i < 4; i++) e->refs[i] = i < e->nref_active ? final[i] : NULL;
 }
+/* Marking scripts in field pictures (8.2.5.4.1 on field picture numbers): memory_management_control_operation 1 takes single FIELDS
+ * out of the reference set -- a frame then lacks a field in every later list --, and since a script replaces the sliding window,
+ * the first field of a frame also makes room for its frame when the window is full. */
+typedef struct {
+    int n, slot[8], par[8];
+} field_drops;
+static int field_is_ref(const enc *e, int slot, int par, int second) {
+    if (e->pics[slot].is_ref != 1 || e->fpics[slot][par].dropped) return 0;
+    if (&e->pics[slot] == e->cur_frame) return second && par == !e->bottom; /* of the current frame: its first field, once coded */
+    return 1;
+}
+static void plan_field_marking(enc *e, int second, field_drops *fd) {
+    const int cur_fn = e->cur_frame_num, cur_slot = (int)(e->cur_frame - e->pics);
+    int gone[6][2];
+    memset(gone, 0, sizeof(gone));
+    fd->n = 0, e->n_mmco = 0;
+    if (!e->p.mmco || rnd(e) % 100 < 45) return; /* sliding window */
+#define DROP(s_, p_) (gone[s_][p_] = 1, fd->slot[fd->n] = (s_), fd->par[fd->n++] = (p_), \
+                      add_mmco(e, 1, 2 * cur_fn + 1 - (2 * picnum(&e->pics[s_], cur_fn) + ((p_) == e->bottom)) - 1, 0))
+    if (rnd(e) % 100 < 65) { /* one field, anywhere */
+        int cand[12][2], nc = 0;
+        for (int i = 0; i < 6; i++)
+            for (int par = 0; par < 2; par++)
+                if (field_is_ref(e, i, par, second)) cand[nc][0] = i, cand[nc++][1] = par;
+        if (nc > 1) {
+            const int k = (int)(rnd(e) % (uint32_t)nc);
+            DROP(cand[k][0], cand[k][1]);
+        }
+    }
+    if (!second && e->n_mmco > 0) /* no sliding window now: the oldest frames leave field by field until this frame fits */
+        for (;;) {
+            int nfr = 0, oldest = -1;
+            for (int i = 0; i < 6; i++) {
+                if (i == cur_slot) continue;
+                const int left = (field_is_ref(e, i, 0, 0) && !gone[i][0]) + (field_is_ref(e, i, 1, 0) && !gone[i][1]);
+                if (!left) continue;
+                nfr++;
+                if (oldest < 0 || picnum(&e->pics[i], cur_fn) < picnum(&e->pics[oldest], cur_fn)) oldest = i;
+            }
+            if (nfr < e->p.num_ref_frames || oldest < 0 || fd->n > 5) break;
+            for (int par = 0; par < 2; par++)
+                if (field_is_ref(e, oldest, par, 0) && !gone[oldest][par]) DROP(oldest, par);
+        }
+#undef DROP
+}
+static void apply_field_drops(enc *e, const field_drops *fd) {
+    for (int k = 0; k < fd->n; k++) e->fpics[fd->slot[k]][fd->par[k]].dropped = 1;
+    for (int i = 0; i < 6; i++) /* a frame without a field left is no reference frame any more (the current one is marked right after) */
+        if (e->pics[i].is_ref == 1 && e->fpics[i][0].dropped && e->fpics[i][1].dropped) e->pics[i].is_ref = 0;
+    e->cur_frame->is_ref = 1;
+}
+
 /* RefPicList0 / RefPicList1 of a B field (8.2.4.2.4 + 8.2.4.2.5): the reference frames by PicOrderCnt around the current field
  * (list 0: at or before it, nearest first, then the later ones; list 1 the other way round), each list then turned into fields
  * by the same alternation as for P fields */
@@ -2436,7 +2489,8 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             free(e);
             return 0;
         }
-        p->interlace_sps = 1, p->b_pyramid = 0, p->mmco = 0, p->idr_long_term = 0;
+        p->interlace_sps = 1, p->b_pyramid = 0, p->idr_long_term = 0;
+        if (p->bframes > 0) p->mmco = 0;
         p->fn_gap_period = 0, p->slice_groups = 0, p->aso = 0;
         if (p->field_pics == 3) p->bframes = 0; /* B fields: only in streams that are all fields (co-located pictures of the same shape) */
     }
@@ -2523,12 +2577,15 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         const int idr_frame = dsp == 0 || (p->idr_period > 0 && dsp % p->idr_period == 0);
         if (idr_frame) idr_disp = dsp;
         mark_state ms;
+        field_drops fd;
+        fd.n = 0;
         /* field_pics 1 / 2: every frame as two fields; 3: frame by frame, a frame picture or two field pictures (PAFF proper) */
         const int as_fields = p->field_pics == 3 ? (int)((p->seed * 7u + (unsigned)t * 5u + (unsigned)(t / 3)) % 3u != 0) : p->field_pics != 0;
         e->cur_frame = NULL;
       for (int fld = 0; fld < (as_fields ? 2 : 1); fld++) { /* the picture(s) of frame t: the frame, or its two fields */
         /* only the first field of an IDR frame is an IDR picture; the second one is a P field (it may predict from the first) or an I field */
-        const int idr = idr_frame && fld == 0, intra_pic = idr || (idr_frame && fld == 1 && (p->seed + (unsigned)t) % 3 == 0);
+        const int idr = idr_frame && fld == 0;
+        int intra_pic = idr || (idr_frame && fld == 1 && (p->seed + (unsigned)t) % 3 == 0);
         e->field = as_fields, e->bottom = as_fields ? (p->field_pics == 2) ^ fld : 0;
         e->H = as_fields ? e->fH / 2 : e->fH, e->hmb = e->H / 16; /* the PICTURE: a frame or one field */
         sg_set_field_mode(as_fields);
@@ -2579,6 +2636,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             for (int i = 0; i < 6 && !e->cur_frame; i++)
                 if (!e->pics[i].is_ref) e->cur_frame = &e->pics[i];
             e->cur_frame->nonexist = 0, e->cur_frame->frame_num = frame_num, e->cur_frame->poc = poc;
+            e->fpics[e->cur_frame - e->pics][0].dropped = e->fpics[e->cur_frame - e->pics][1].dropped = 0;
         }
         e->cur = e->field ? &e->fpics[e->cur_frame - e->pics][e->bottom] : e->cur_frame;
         e->cur->nonexist = 0;
@@ -2599,10 +2657,14 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             plan_b_lists(e);
         else if (e->field) {
             if (!intra_pic) plan_field_list(e, fld);
+            if (!idr && e->nal_ref_idc) plan_field_marking(e, fld, &fd);
         } else if (!idr) {
             plan_ref_list(e);
-            if (e->nal_ref_idc) plan_marking(e, &ms);
+            if (e->nal_ref_idc && !p->field_pics) plan_marking(e, &ms); /* (field streams: scripts in the field pictures only) */
         }
+        /* field streams with marking scripts: a frame picture may find no frame with both fields still marked (and a field, in principle,
+         * no field at all) -- such a picture is coded as a non-IDR I picture */
+        if (p->field_pics && !bpic && !intra_pic && e->nref_active == 0) intra_pic = 1, e->slice_type = 2;
         if (getenv("SG_DEBUG")) {
             fprintf(stderr, "t=%d fn=%d ref_idc=%d list:", t, frame_num, e->nal_ref_idc);
             for (int i = 0; i < e->nref_active && !idr; i++) fprintf(stderr, " id%d(fn%d,%s%d)", e->refs[i]->id, e->refs[i]->frame_num, e->refs[i]->is_ref == 2 ? "L" : "s", e->refs[i]->long_idx);
@@ -2782,13 +2844,15 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             }
             /* marking is the frame's business (8.2.5.3 counts frames): the first field does what a frame picture would do, the second
              * field of a reference frame just joins it */
-            if (fld == 0) {
+            if (e->n_mmco > 0 && !idr) /* a script of operation 1 on fields: no sliding window */
+                apply_field_drops(e, &fd);
+            else if (fld == 0) {
                 sg_pic *fieldpic = e->cur;
                 e->cur = e->cur_frame;
                 apply_marking(e, &ms, idr);
                 e->cur = fieldpic;
-                continue;
             }
+            if (fld == 0) continue;
             weave_or_split(e, (int)(e->cur_frame - e->pics), 1);
             e->cur = e->cur_frame;
         } else {

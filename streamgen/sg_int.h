@@ -43,6 +43,7 @@ typedef struct {
     int long_idx; /* LongTermFrameIdx when is_ref == 2 */
     int poc;
     int nonexist; /* a frame that only exists as a skipped frame_num value (8.2.5.2): takes a place in the window, is never predicted from */
+    int dropped;     /* field pictures: this field was marked "unused for reference" on its own (memory_management_control_operation 1) */
     int parity, fid; /* field pictures (sg_params::field_pics): 0 top / 1 bottom, and the frame the field belongs to */
     void *motion; /* the picture's macroblock motion (an emb array of sg_enc.c): co-located data of later B pictures */
 } sg_pic;

@@ -345,7 +345,7 @@ void sg_residual4(const int16_t *lev, const int *ls, int qp, int have_dc, int dc
     int per = qp / 6;
     for (int k = 0; k < 16; k++) {
         int pos = g_scan4[k], v = lev[k] * ls[pos];
-        res[pos] = per >= 4 ? v << (per - 4) : (v + (1 << (3 - per))) >> (4 - per);
+        res[pos] = per >= 4 ? v * (1 << (per - 4)) : (v + (1 << (3 - per))) >> (4 - per);
     }
     if (have_dc) res[0] = dc;
     inv4(res);
@@ -354,7 +354,7 @@ void sg_residual8(const int16_t *lev, const int *ls, int qp, int *res) {
     int per = qp / 6;
     for (int k = 0; k < 64; k++) {
         int pos = g_scan8[k], v = lev[k] * ls[pos];
-        res[pos] = per >= 6 ? v << (per - 6) : (v + (1 << (5 - per))) >> (6 - per);
+        res[pos] = per >= 6 ? v * (1 << (per - 6)) : (v + (1 << (5 - per))) >> (6 - per);
     }
     inv8(res);
 }
@@ -381,11 +381,11 @@ void sg_luma_dc(const int16_t *lev_scan, int ls00, int qp, int *dc) { /* 8.5.10 
     int c[16], f[16], per = qp / 6;
     for (int k = 0; k < 16; k++) c[g_scan4[k]] = lev_scan[k];
     hadamard4(c, f);
-    for (int i = 0; i < 16; i++) dc[i] = per >= 6 ? (f[i] * ls00) << (per - 6) : (f[i] * ls00 + (1 << (5 - per))) >> (6 - per);
+    for (int i = 0; i < 16; i++) dc[i] = per >= 6 ? (f[i] * ls00) * (1 << (per - 6)) : (f[i] * ls00 + (1 << (5 - per))) >> (6 - per);
 }
 void sg_chroma_dc(const int16_t *l, int ls00, int qpc, int *dc) { /* 8.5.11 */
     int f[4] = {l[0] + l[1] + l[2] + l[3], l[0] - l[1] + l[2] - l[3], l[0] + l[1] - l[2] - l[3], l[0] - l[1] - l[2] + l[3]};
-    for (int i = 0; i < 4; i++) dc[i] = ((f[i] * ls00) << (qpc / 6)) >> 5;
+    for (int i = 0; i < 4; i++) dc[i] = ((f[i] * ls00) * (1 << (qpc / 6))) >> 5;
 }
 
 /* ------------------------------------------------------------------ least-squares quantisation */

@@ -201,5 +201,7 @@ FIELD_MATRIX = {
     "field_b_temporal_implicit_bff": dict(FIELD_BASE, field_pics=2, frames=9, bframes=3, direct_temporal=1, weighted_bipred=2, num_ref_frames=2, bskip_permille=300, idr_period=8, seed=317),
     "field_rplm": dict(FIELD_BASE, frames=8, rplm=1, num_ref_frames=3, seed=318),
     "field_rplm_mixed_nonref": dict(FIELD_BASE, field_pics=3, frames=10, rplm=1, nonref_period=4, num_ref_frames=4, idr_period=7, seed=319),
+    "field_mmco1": dict(FIELD_BASE, frames=10, mmco=1, num_ref_frames=3, sub8x8_permille=200, seed=320),
+    "field_mmco1_rplm_mixed": dict(FIELD_BASE, field_pics=3, frames=12, mmco=1, rplm=1, num_ref_frames=2, idr_period=8, seed=321),
     "field_cropped": dict(FIELD_BASE, width=170, height=124, num_ref_frames=2, constrained_intra=1, intra_in_p_permille=150, seed=309),
 }

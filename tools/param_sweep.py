@@ -66,8 +66,8 @@ def draw():
     if rng.random() < 0.15 or FIELDS:
         kw["interlace_sps"] = 1
         kw["height"] = max(32, (kw["height"] + 31) // 32 * 32 - pick(0, 4, 8))
-    if FIELDS:  # what sg.h says field recipes may carry: Main / High, CAVLC, no marking scripts or slice groups; B fields in all-field streams
-        for k in ("b_pyramid", "mmco", "idr_long_term", "fn_gap_period", "fn_gap_declared", "slice_groups", "fmo_type", "aso", "cabac_init_idc"):
+    if FIELDS:  # what sg.h says field recipes may carry: Main / High, CAVLC, no long-term pictures or slice groups; B fields in all-field streams
+        for k in ("b_pyramid", "idr_long_term", "fn_gap_period", "fn_gap_declared", "slice_groups", "fmo_type", "aso", "cabac_init_idc"):
             kw.pop(k, None)
         kw.update(field_pics=pick(1, 2, 3, 3), cabac=0, profile_idc=pick(77, 100))
         if kw["field_pics"] == 3 or not kw.get("bframes"):
@@ -92,6 +92,8 @@ bad = 0
 t0 = time.time()
 for t in range(N if BATCH == 1 and not CONCAT else 0):
     kw = draw()
+    if os.environ.get("SWEEP_VERBOSE"):  # (to find the recipe of a trial that takes the process down)
+        print("trial %d recipe %s" % (t, kw), flush=True)
     try:
         s, rec, sizes = streamgen.encode(**kw)
     except RuntimeError as e:
