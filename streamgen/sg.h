@@ -80,7 +80,7 @@ typedef struct {
      * this tree); sliding-window marking (counted in frames, 8.2.5.3), list modification on field picture numbers
      * (rplm, P fields), marking scripts of operation 1 on single fields (mmco: a frame then lacks a field in later lists, and
      * a frame picture that finds no frame with both fields marked is coded as an I picture), non-reference frames
-     * (nonref_period) allowed, no long-term pictures, no slice groups.  bframes with field_pics 1 / 2 (not 3): every B frame is two non-reference B fields (spatial or
+     * (nonref_period) and slice groups (a map unit is one macroblock of a field, 8.2.2.8) allowed, no long-term pictures.  bframes with field_pics 1 / 2 (not 3): every B frame is two non-reference B fields (spatial or
      * temporal direct prediction from the co-located field), their lists built from the anchors' fields by PicOrderCnt
      * (8.2.4.2.4) and the same alternation.  recon[] holds the woven frames. */
     int field_pics;

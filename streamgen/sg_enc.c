@@ -1784,7 +1784,7 @@ static size_t write_sps(enc *e, uint8_t *dst, size_t cap) {
     return sg_write_nal(dst, cap, 1, 3, 7, buf, sg_bw_bytes(&w));
 }
 /* ------------------------------------------------------------------ slice groups (7.3.2.2, 8.2.2) */
-static int sg_map_units(const enc *e) { return e->wmb * (e->p.interlace_sps ? e->hmb / 2 : e->hmb); }
+static int sg_map_units(const enc *e) { return e->wmb * (e->p.interlace_sps ? e->fH / 32 : e->fH / 16); } /* (of the FRAME: the same for its frame and field pictures) */
 /* what the PPS will say, chosen from the seed so that every map type gets awkward shapes */
 static void plan_slice_groups(enc *e) {
     const sg_params *p = &e->p;
@@ -1860,8 +1860,8 @@ static void build_slice_group_map(enc *e, int cycle) {
         break;
     default: memcpy(mu, e->sg_ids, (size_t)units); break;
     }
-    for (int i = 0; i < e->wmb * e->hmb; i++) /* frame pictures of an interlace SPS: a map unit is two macroblock rows high */
-        e->sgmap[i] = p->interlace_sps ? mu[(i / (2 * W)) * W + i % W] : mu[i];
+    for (int i = 0; i < e->wmb * e->hmb; i++) /* frame pictures of an interlace SPS: a map unit is two macroblock rows high; field pictures: one macroblock (8.2.2.8) */
+        e->sgmap[i] = p->interlace_sps && !e->field ? mu[(i / (2 * W)) * W + i % W] : mu[i];
     free(mu);
 }
 static int sg_next_mb(const enc *e, int addr) {
@@ -2491,7 +2491,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         }
         p->interlace_sps = 1, p->b_pyramid = 0, p->idr_long_term = 0;
         if (p->bframes > 0) p->mmco = 0;
-        p->fn_gap_period = 0, p->slice_groups = 0, p->aso = 0;
+        p->fn_gap_period = 0;
         if (p->field_pics == 3) p->bframes = 0; /* B fields: only in streams that are all fields (co-located pictures of the same shape) */
     }
     e->W = (p->width + 15) & ~15, e->H = (p->height + 15) & ~15;

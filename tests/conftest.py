@@ -203,5 +203,8 @@ FIELD_MATRIX = {
     "field_rplm_mixed_nonref": dict(FIELD_BASE, field_pics=3, frames=10, rplm=1, nonref_period=4, num_ref_frames=4, idr_period=7, seed=319),
     "field_mmco1": dict(FIELD_BASE, frames=10, mmco=1, num_ref_frames=3, sub8x8_permille=200, seed=320),
     "field_mmco1_rplm_mixed": dict(FIELD_BASE, field_pics=3, frames=12, mmco=1, rplm=1, num_ref_frames=2, idr_period=8, seed=321),
+    "field_fmo_dispersed": dict(FIELD_BASE, frames=4, slice_groups=3, fmo_type=1, num_ref_frames=2, seed=322),
+    "field_fmo_boxout_mixed_aso": dict(FIELD_BASE, field_pics=3, frames=8, slice_groups=2, fmo_type=3, slices=2, aso=1, num_ref_frames=2, seed=323),
+    "field_fmo_explicit_bff": dict(FIELD_BASE, field_pics=2, frames=4, slice_groups=4, fmo_type=6, num_ref_frames=2, seed=324),
     "field_cropped": dict(FIELD_BASE, width=170, height=124, num_ref_frames=2, constrained_intra=1, intra_in_p_permille=150, seed=309),
 }

@@ -110,3 +110,43 @@ def test_access_units_of_field_streams(H, sg):
         assert len(aus) == pictures and b"".join(aus) == stream, name
         if kw["field_pics"] in (1, 2):
             assert pictures == 2 * kw["frames"]
+
+
+def test_slice_group_maps_of_field_pictures(H, sg, oracle_mod):
+    """8.2.2.8 (h264/slice.go:134-158): in a field picture a map unit is one macroblock, in a frame picture of the same interlace
+    stream two macroblock rows.  The PRODUCT's h264mi_mb_to_slice_group_map (field_pic = 1) against the oracle's, for every slice
+    of the slice-group field recipes -- host code that is ready before the kernels are."""
+    import ctypes
+    from oracle import lib as olib
+    O = olib()
+    O.h264o_parse_pps_ids.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
+    O.h264o_parse_sps.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+    O.h264o_mb_to_slice_group_map.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    seen = set()
+    for name, kw in FIELD_MATRIX.items():
+        if not kw.get("slice_groups"):
+            continue
+        stream, _, _ = sg.encode(**kw)
+        nals = H.read_nal_units(stream)
+        sps = H.NewSPS(nals[0].RBSP())
+        pps = H.NewPPS(sps, nals[1].RBSP())
+        osps = ctypes.create_string_buffer(O.h264o_sizeof_sps() * 32)
+        opps = ctypes.create_string_buffer(O.h264o_sizeof_pps())
+        assert O.h264o_parse_sps(nals[0].RBSP(), len(nals[0].RBSP()), osps) == 0
+        oids = np.zeros(1 << 16, dtype=np.uint8)
+        n_ids = ctypes.c_size_t(0)
+        assert O.h264o_parse_pps_ids(nals[1].RBSP(), len(nals[1].RBSP()), osps, opps, oids.ctypes.data, oids.size, ctypes.byref(n_ids)) == 0
+        vs = H.VideoStream(sps, pps)
+        frame_mbs = (sps.PicWidthInMbsMinus1 + 1) * (sps.PicHeightInMapUnitsMinus1 + 1) * 2
+        for n in nals[2:]:
+            if n.Type not in (1, 5):
+                continue
+            h = H.NewSliceContext(vs, n, n.RBSP()).Slice.Header
+            m = H.MbToSliceGroupMap(sps, pps, h)
+            assert m.size == (frame_mbs // 2 if h.FieldPic else frame_mbs)
+            om = np.zeros(m.size, dtype=np.uint8)
+            assert O.h264o_mb_to_slice_group_map(osps, opps, oids.ctypes.data, h.SliceGroupChangeCycle, int(bool(h.FieldPic)), om.ctypes.data) == m.size
+            assert np.array_equal(m, om), name
+            assert len(set(m.tolist())) > 1 or 3 <= kw["fmo_type"] <= 5
+            seen.add((kw["fmo_type"], bool(h.FieldPic)))
+    assert {(1, True), (3, True), (3, False), (6, True)} <= seen

@@ -66,8 +66,8 @@ def draw():
     if rng.random() < 0.15 or FIELDS:
         kw["interlace_sps"] = 1
         kw["height"] = max(32, (kw["height"] + 31) // 32 * 32 - pick(0, 4, 8))
-    if FIELDS:  # what sg.h says field recipes may carry: Main / High, CAVLC, no long-term pictures or slice groups; B fields in all-field streams
-        for k in ("b_pyramid", "idr_long_term", "fn_gap_period", "fn_gap_declared", "slice_groups", "fmo_type", "aso", "cabac_init_idc"):
+    if FIELDS:  # what sg.h says field recipes may carry: Main / High, CAVLC, no long-term pictures; B fields in all-field streams
+        for k in ("b_pyramid", "idr_long_term", "fn_gap_period", "fn_gap_declared", "cabac_init_idc"):
             kw.pop(k, None)
         kw.update(field_pics=pick(1, 2, 3, 3), cabac=0, profile_idc=pick(77, 100))
         if kw["field_pics"] == 3 or not kw.get("bframes"):
