@@ -7,7 +7,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 static std::vector<uint8_t> slurp(const char *p) {
@@ -48,15 +50,14 @@ static std::vector<size_t> au_cuts(const std::vector<uint8_t> &s) {
     return cuts;
 }
 
-int main(int argc, char **argv) {
-    if (argc < 4) { fprintf(stderr, "usage: host_asan iterations seed stream.h264...\n"); return 2; }
-    const int iters = atoi(argv[1]);
-    std::mt19937 rng(atoi(argv[2]));
-    std::vector<std::vector<uint8_t>> streams;
-    for (int i = 3; i < argc; i++) { streams.push_back(slurp(argv[i])); if (streams.back().empty()) { fprintf(stderr, "cannot read %s\n", argv[i]); return 2; } }
-    long batches = 0, ok_streams = 0, failed_streams = 0, frames = 0, refused = 0;
+static std::vector<std::vector<uint8_t>> streams;
+static std::atomic<long> batches{0}, ok_streams{0}, failed_streams{0}, frames{0}, refused{0};
+static std::atomic<long> codes[64];
+
+// one client: `iters` decoders one after the other, each fed its own random mix of streams
+static void client(int iters, unsigned seed) {
+    std::mt19937 rng(seed);
     std::vector<uint8_t> pix(4 << 20);
-    long codes[64] = {0};
     for (int it = 0; it < iters; it++) {
         const int ns = 1 + rng() % 4;
         h264mi_config cfg;
@@ -118,7 +119,7 @@ int main(int argc, char **argv) {
             for (int s = 0; s < ns; s++) {
                 int32_t st = 0, nf = 0;
                 h264mi_stream_status(dec, s, &st);
-                (st == 0 ? ok_streams : failed_streams)++;
+                if (st == 0) ok_streams++; else failed_streams++;
                 codes[st <= 0 && st > -64 ? -st : 63]++;
                 if (h264mi_stream_frame_count(dec, s, &nf) != 0) continue;
                 frames += nf;
@@ -135,9 +136,28 @@ int main(int argc, char **argv) {
         }
         h264mi_decoder_destroy(dec);
     }
-    printf("host asan: %d decoders (%ld refused), %ld batches, stream results %ld ok / %ld failed, %ld frames\n", iters, refused, batches, ok_streams, failed_streams, frames);
+}
+
+int main(int argc, char **argv) {
+    // H264MI_HOST_THREADS=N: N clients side by side, each with its own decoders (what the library promises: decoders are independent;
+    // the interesting run is the ThreadSanitizer build, SAN=thread in tools/host_asan.sh)
+    if (argc < 4) { fprintf(stderr, "usage: host_asan iterations seed stream.h264...\n"); return 2; }
+    const int iters = atoi(argv[1]);
+    const unsigned seed = static_cast<unsigned>(atoi(argv[2]));
+    for (int i = 3; i < argc; i++) { streams.push_back(slurp(argv[i])); if (streams.back().empty()) { fprintf(stderr, "cannot read %s\n", argv[i]); return 2; } }
+    const char *nt = getenv("H264MI_HOST_THREADS");
+    const int threads = nt ? std::max(1, atoi(nt)) : 1;
+    if (threads == 1)
+        client(iters, seed);
+    else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; t++) pool.emplace_back(client, (iters + threads - 1) / threads, seed * 7919u + static_cast<unsigned>(t));
+        for (auto &t : pool) t.join();
+    }
+    printf("host asan: %d decoders (%ld refused), %ld batches, stream results %ld ok / %ld failed, %ld frames\n", iters, refused.load(), batches.load(), ok_streams.load(),
+           failed_streams.load(), frames.load());
     printf("stream status histogram:");
-    for (int i = 0; i < 64; i++) if (codes[i]) printf(" %d:%ld", -i, codes[i]);
+    for (int i = 0; i < 64; i++) if (codes[i].load()) printf(" %d:%ld", -i, codes[i].load());
     printf("\n");
     return 0;
 }

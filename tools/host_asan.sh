@@ -2,7 +2,8 @@
 # The host side of libh264mi (mi_api.cpp + mi_parse.cpp: parsing, picture boundaries, DPB / reference lists, slice-group maps,
 # batching, staging layout, error paths) under AddressSanitizer + UBSan + LeakSanitizer on the CPU, against a null device
 # (tools/hoststub: kernels are not run), fed intact and damaged copies of the whole test matrix.  No GPU needed.
-#   bash tools/host_asan.sh [decoders] [seed]          (SAN=thread for ThreadSanitizer: the per-stream prepare threads)
+#   bash tools/host_asan.sh [decoders] [seed]          (SAN=thread for ThreadSanitizer: the per-stream prepare threads;
+#                                                       H264MI_HOST_THREADS=N: N clients side by side, each with its own decoders)
 set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=${TMPDIR:-/tmp}/h264mi_host_asan
