@@ -1483,7 +1483,7 @@ static void b_predict(enc *e, uint8_t *py, uint8_t pc[2][64]) {
     const int idc = e->p.weighted_bipred;
     for (int blk = 0; blk < 16; blk++) {
         int bx = blk & 3, by = blk >> 2, q = (by >> 1) * 2 + (bx >> 1);
-        uint8_t ty[2][16], tc[2][2][4];
+        uint8_t ty[2][16] = {{0}}, tc[2][2][4] = {{{0}}}; /* (a list that is not used is read below, its value dropped) */
         int use[2] = {m->ref[q] >= 0, m->ref1[q] >= 0};
         sg_pic *rp[2] = {use[0] ? e->refs[m->ref[q]] : NULL, use[1] ? e->refs1[m->ref1[q]] : NULL};
         for (int l = 0; l < 2; l++) {

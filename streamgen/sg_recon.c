@@ -232,13 +232,13 @@ void sg_mc_luma(const sg_pic *ref, int x, int y, int w, int h, int mvx, int mvy,
         int sy = iclip(iy + j - 2, 0, ref->h - 1);
         for (int i = 0; i < ww; i++) win[j][i] = ref->pl[0][sy * ref->w + iclip(ix + i - 2, 0, ref->w - 1)];
     }
-    /* hb[j][i]: horizontal 6-tap intermediate at rows j (all window rows), columns i in [0,w] */
+    /* hb[j][i]: horizontal 6-tap intermediate at rows j (all window rows), columns i in [0,w) */
     int hb[26][22], vb[22][26];
     for (int j = 0; j < wh; j++)
-        for (int i = 0; i <= w; i++)
+        for (int i = 0; i < w; i++)
             hb[j][i] = win[j][i] - 5 * win[j][i + 1] + 20 * win[j][i + 2] + 20 * win[j][i + 3] - 5 * win[j][i + 4] + win[j][i + 5];
-    /* vb[j][i]: vertical 6-tap intermediate at rows j in [0,h], all window columns */
-    for (int j = 0; j <= h; j++)
+    /* vb[j][i]: vertical 6-tap intermediate at rows j in [0,h), all window columns */
+    for (int j = 0; j < h; j++)
         for (int i = 0; i < ww; i++)
             vb[j][i] = win[j][i] - 5 * win[j + 1][i] + 20 * win[j + 2][i] + 20 * win[j + 3][i] - 5 * win[j + 4][i] + win[j + 5][i];
     for (int j = 0; j < h; j++)
