@@ -92,9 +92,9 @@ def test_access_units_of_field_streams(H, sg):
     """7.4.1.2.4: field_pic_flag / bottom_field_flag separate pictures -- the two fields of a frame are two access units even
     when every other header field agrees (pic_order_cnt_type 2: same frame_num, no POC syntax).  h264mi_slice_starts_picture
     (the decoder's own test) through the stream front-end's splitter."""
-    for name in ("field_mixed_paff", "field_slices3_idc2", "field_nonref_pairs", "field_poc2_qpjitter"):
+    for name in sorted(FIELD_MATRIX):
         kw = FIELD_MATRIX[name]
-        stream, _, _ = sg.encode(**kw)
+        stream, _, sizes = sg.encode(**kw)
         nals = H.read_nal_units(stream)
         sps = H.NewSPS(nals[0].RBSP())
         vs = H.VideoStream(sps, H.NewPPS(sps, nals[1].RBSP()))
@@ -105,11 +105,18 @@ def test_access_units_of_field_streams(H, sg):
                 key = (h.FrameNum, bool(h.FieldPic), bool(h.BottomField), n.Type, n.RefIdc == 0)
                 pictures += key != prev
                 prev = key
-        sp = H.AccessUnitSplitter(max_units_per_chunk=1)
-        aus = sp.feed(stream) + sp.flush()
-        assert len(aus) == pictures and b"".join(aus) == stream, name
         if kw["field_pics"] in (1, 2):
             assert pictures == 2 * kw["frames"]
+        for piece in (1 << 20, 97):  # whatever the feeding pattern
+            sp = H.AccessUnitSplitter(max_units_per_chunk=1)
+            aus = []
+            for i in range(0, len(stream), piece):
+                aus += sp.feed(stream[i:i + piece])
+            aus += sp.flush()
+            assert len(aus) == pictures and b"".join(aus) == stream, (name, piece)
+            # every frame of the generator (one or two pictures) ends where an access unit ends
+            ends = set(np.cumsum([len(a) for a in aus]).tolist())
+            assert set(np.cumsum(sizes).tolist()) <= ends, (name, piece)
 
 
 def test_slice_group_maps_of_field_pictures(H, sg, oracle_mod):
