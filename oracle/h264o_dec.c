@@ -101,6 +101,7 @@ static int compute_poc(h264o_decoder *d, const h264o_slice_header *sh) {
             msb = prev_msb;
         int top = msb + sh->pic_order_cnt_lsb, bot = top + sh->delta_pic_order_cnt_bottom;
         poc = sh->field_pic_flag ? top /* 8-4 / 8-5: a field has the one count */ : (top < bot ? top : bot);
+        d->poc_top = top, d->poc_bot = sh->field_pic_flag ? top : bot;
         if (sh->nal_ref_idc) {
             d->prev_poc_msb = msb;
             d->prev_poc_lsb = sh->pic_order_cnt_lsb;
@@ -130,8 +131,10 @@ static int compute_poc(h264o_decoder *d, const h264o_slice_header *sh) {
                 poc = sh->bottom_field_flag ? expected + s->offset_for_top_to_bottom_field + sh->delta_pic_order_cnt[0] : top;
             else
                 poc = top < bot ? top : bot;
+            d->poc_top = top, d->poc_bot = sh->field_pic_flag ? poc : bot;
         } else
             poc = sh->idr_flag ? 0 : (sh->nal_ref_idc ? 2 * (fno + sh->frame_num) : 2 * (fno + sh->frame_num) - 1);
+        if (s->pic_order_cnt_type == 2) d->poc_top = d->poc_bot = poc;
         d->prev_frame_num_offset = fno;
     }
     d->prev_frame_num = sh->frame_num;
@@ -526,8 +529,11 @@ static void finish_picture(h264o_decoder *d) {
             d->pend = f;
         return;
     }
-    f->fields = 3, f->fpoc[0] = f->fpoc[1] = f->poc;
-    if (!d->asps->frame_mbs_only_flag) make_view(d, f, 0, f->poc), make_view(d, f, 1, f->poc); /* later field pictures may predict from its fields */
+    /* the two fields of a frame picture have their own counts (8.2.1: bottom = top + delta_pic_order_cnt_bottom, or + offset_for_top_to_bottom_field);
+     * operation 5 has made them relative to the frame's */
+    const int mmco5 = d->first_sh.nal_ref_idc && !d->first_sh.idr_flag && f->poc == 0 && (d->poc_top || d->poc_bot);
+    f->fields = 3, f->fpoc[0] = mmco5 ? d->poc_top - (d->poc_top < d->poc_bot ? d->poc_top : d->poc_bot) : d->poc_top, f->fpoc[1] = mmco5 ? d->poc_bot - (d->poc_top < d->poc_bot ? d->poc_top : d->poc_bot) : d->poc_bot;
+    if (!d->asps->frame_mbs_only_flag) make_view(d, f, 0, f->fpoc[0]), make_view(d, f, 1, f->fpoc[1]); /* later field pictures may predict from its fields */
     if (f->ref) { /* a later B picture may use this one as its co-located picture (RefPicList1[0]) */
         if (f->n_mbs != d->wmb * d->hmb) {
             free(f->mbs);

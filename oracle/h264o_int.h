@@ -86,6 +86,7 @@ struct h264o_decoder {
     h264o_mb *mb;
     /* POC state (8.2.1) */
     int prev_poc_msb, prev_poc_lsb, prev_frame_num, prev_frame_num_offset, prev_ref_has_mmco5;
+    int poc_top, poc_bot; /* TopFieldOrderCnt / BottomFieldOrderCnt of the picture compute_poc() was last asked about */
     int prev_ref_frame_num; /* PrevRefFrameNum (7.4.3): frame_num of the previous reference picture, 0 after an IDR picture or operation 5 */
     /* slice state */
     h264o_slice_header sh;
