@@ -136,6 +136,7 @@ struct StreamState {
     int wmb = 0, hmb = 0;
     std::vector<Slot> slots;
     int prev_poc_msb = 0, prev_poc_lsb = 0, prev_frame_num = 0, prev_frame_num_offset = 0;
+    int top_above_poc = 0; // TopFieldOrderCnt - PicOrderCnt of the picture compute_poc() was last asked about (> 0: its bottom field comes first)
     int prev_ref_frame_num = 0; // PrevRefFrameNum (7.4.3): frame_num of the previous reference picture; 0 after an IDR picture or operation 5
     // picture under construction
     int cur_slot = -1, cur_pic = -1, cur_slices = 0;
@@ -627,6 +628,7 @@ static int compute_poc(StreamState &s, const h264mi_sps &sps, const h264mi_slice
             msb = prev_msb;
         int top = msb + sh.pic_order_cnt_lsb;
         poc = std::min(top, top + sh.delta_pic_order_cnt_bottom);
+        s.top_above_poc = top - poc;
         if (sh.nal_ref_idc) s.prev_poc_msb = msb, s.prev_poc_lsb = sh.pic_order_cnt_lsb;
     } else {
         int fno = idr ? 0 : (s.prev_frame_num > sh.frame_num ? s.prev_frame_num_offset + max_fn : s.prev_frame_num_offset);
@@ -785,7 +787,9 @@ static void mark_reference(StreamState &s, const h264mi_sps &sps) {
                 for (auto &sl : s.slots)
                     if (&sl != &cur) sl.ref = 0;
                 cur.frame_num = 0, cur.poc = 0; // 8.2.1: tempPicOrderCnt is subtracted, the picture ends up at PicOrderCnt 0
-                s.prev_frame_num = s.prev_frame_num_offset = s.prev_poc_msb = s.prev_poc_lsb = s.prev_ref_frame_num = 0;
+                s.prev_frame_num = s.prev_frame_num_offset = s.prev_poc_msb = s.prev_ref_frame_num = 0;
+                // 8.2.1.1: prevPicOrderCntLsb = TopFieldOrderCnt after tempPicOrderCnt was subtracted -- 0 unless the bottom field is the earlier one
+                s.prev_poc_lsb = sps.pic_order_count_type == 0 ? s.top_above_poc : 0;
             } else if (op == 6) {
                 for (auto &o : s.slots)
                     if (o.ref == 2 && o.long_idx == sh.mmco_arg2[k]) o.ref = 0;

@@ -451,7 +451,8 @@ static void mark_reference(h264o_decoder *d) {
                 d->prev_frame_num_offset = 0;
                 d->prev_ref_frame_num = 0;
                 d->prev_poc_msb = 0;
-                d->prev_poc_lsb = 0;
+                /* 8.2.1.1: prevPicOrderCntLsb = TopFieldOrderCnt after tempPicOrderCnt was subtracted: 0 unless the bottom field is the earlier one */
+                d->prev_poc_lsb = d->asps->pic_order_cnt_type == 0 && !d->field_pic && d->poc_bot < d->poc_top ? d->poc_top - d->poc_bot : 0;
             } else if (op == 6) {
                 for (int j = 0; j < d->n_pics; j++)
                     if (d->pics[j].ref == 2 && d->pics[j].long_term_frame_idx == sh->mmco_arg2[k]) d->pics[j].ref = 0;

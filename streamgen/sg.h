@@ -84,6 +84,11 @@ typedef struct {
      * temporal direct prediction from the co-located field), their lists built from the anchors' fields by PicOrderCnt
      * (8.2.4.2.4) and the same alternation.  recon[] holds the woven frames. */
     int field_pics;
+    /* d != 0: bottom_field_pic_order_in_frame_present_flag = 1 and every FRAME picture says where its bottom field sits relative to
+     * its top field (delta_pic_order_cnt_bottom with pic_order_cnt_type 0, delta_pic_order_cnt[1] with type 1): BottomFieldOrderCnt =
+     * TopFieldOrderCnt + d.  PicOrderCnt of a frame is the smaller of the two (8.2.1): a negative d moves every non-IDR picture d
+     * earlier (IDR pictures keep 0 = Min(top, bottom): they send Max(d, 0)).  Ignored with pic_order_cnt_type 2. */
+    int poc_bottom_delta;
 } sg_params;
 
 void sg_default_params(sg_params *p);

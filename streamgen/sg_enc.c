@@ -1880,7 +1880,7 @@ static size_t write_pps(enc *e, uint8_t *dst, size_t cap) {
     sg_put_ue(&w, 0);
     sg_put_ue(&w, 0);
     sg_put(&w, (uint32_t)p->cabac, 1);
-    sg_put(&w, 0, 1);
+    sg_put(&w, p->poc_bottom_delta != 0 && p->poc_type != 2, 1); /* bottom_field_pic_order_in_frame_present_flag */
     sg_put_ue(&w, p->slice_groups > 1 ? (uint32_t)(p->slice_groups - 1) : 0); /* num_slice_groups_minus1 */
     if (p->slice_groups > 1) {
         int ng = p->slice_groups;
@@ -1930,8 +1930,11 @@ static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int
     if (p->interlace_sps) sg_put(w, (uint32_t)e->field, 1); /* field_pic_flag */
     if (e->field) sg_put(w, (uint32_t)e->bottom, 1);    /* bottom_field_flag */
     if (idr) sg_put_ue(w, (uint32_t)idr_id);
+    const int bottom_delta = e->field || p->poc_type == 2 ? 0 : (idr && p->poc_bottom_delta < 0 ? 0 : p->poc_bottom_delta); /* (sent in frame pictures only) */
     if (p->poc_type == 0) sg_put(w, (uint32_t)poc_lsb, 8);
+    if (p->poc_type == 0 && p->poc_bottom_delta != 0 && !e->field) sg_put_se(w, bottom_delta); /* delta_pic_order_cnt_bottom */
     if (p->poc_type == 1) sg_put_se(w, e->delta_poc0); /* delta_pic_order_cnt[0] (delta_pic_order_always_zero_flag = 0) */
+    if (p->poc_type == 1 && p->poc_bottom_delta != 0 && !e->field) sg_put_se(w, bottom_delta - 1); /* delta_pic_order_cnt[1]: on top of offset_for_top_to_bottom_field = 1 */
     if (is_b) sg_put(w, e->p.direct_temporal ? 0 : 1, 1); /* direct_spatial_mv_pred_flag */
     if (is_p) {
         int over = e->nref_active != p->num_ref_frames || (is_b && e->nref1_active != 1);
@@ -2644,8 +2647,12 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         e->cur->frame_num = frame_num;
         e->cur_frame_num = frame_num;
         e->slice_type = intra_pic ? 2 : (bpic ? 1 : 0);
-        const int pic_poc = poc + fld; /* field pictures: the second field one later */
-        e->cur->poc = e->cur_poc = pic_poc;
+        const int pic_poc = poc + fld; /* the count that is SENT (a frame's top field; field pictures: the second field one later) */
+        /* poc_bottom_delta < 0: the bottom field of a frame picture is the earlier one, and PicOrderCnt(frame) = Min(top, bottom) moves with it
+         * (not in IDR pictures, which send Max(d, 0) so that their PicOrderCnt stays 0) */
+        const int early = !e->field && !idr && p->poc_type != 2 && p->poc_bottom_delta < 0 ? p->poc_bottom_delta : 0;
+        e->cur->poc = e->cur_poc = pic_poc + early;
+        if (fld == 0) e->cur_frame->poc = e->cur_poc;
         e->nal_ref_idc = bpic ? (b_ref[t] ? 2 : 0) : ((!idr && p->nonref_period > 1 && since_idr % p->nonref_period == p->nonref_period - 1) ? 0 : 3);
         if (!e->nal_ref_idc) g_feat |= 1u << 12;
         e->idr_lt = idr && p->idr_long_term;
@@ -2686,7 +2693,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             if (e->delta_poc0) g_feat |= 1u << 14;
         }
         if (g_npocs < 8192 && fld == 0) /* (per frame: the smaller of its fields' counts)  pic_order_cnt_type 2 leaves no choice: 2 * FrameNum, minus 1 for non-reference pictures (8.2.1.3) */
-            g_pocs[g_npocs++] = p->poc_type == 2 ? (idr ? 0 : 2 * refs_since_reset - (e->nal_ref_idc ? 0 : 1)) : poc;
+            g_pocs[g_npocs++] = p->poc_type == 2 ? (idr ? 0 : 2 * refs_since_reset - (e->nal_ref_idc ? 0 : 1)) : e->cur_poc;
         /* weighted_pred 2: both denominators 7, so that the DEFAULT weight of an entry without a flag is 128 -- outside the
          * range of a coded weight (-128..127); coded weights stay below it */
         const int wld = p->weighted_pred == 2 ? 7 : 5, wcd = p->weighted_pred == 2 ? 7 : 4;
@@ -2874,6 +2881,7 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         if (ms.clear_all) { /* after operation 5 the picture counts as frame_num 0 / POC 0 (7.4.3, 8.2.1) */
             e->cur->frame_num = 0;
             frame_num = 1, refs_since_reset = 1, poc = 2;
+            if (p->poc_bottom_delta < 0 && p->poc_type != 2) poc -= p->poc_bottom_delta; /* the next frame's bottom field (top + d) comes 2 after this picture's 0 */
             g_pocs[g_npocs - 1] = 0;
         }
         if (idr_frame) idr_id = (idr_id + 1) & 0xFFFF;

@@ -208,3 +208,16 @@ FIELD_MATRIX = {
     "field_fmo_explicit_bff": dict(FIELD_BASE, field_pics=2, frames=4, slice_groups=4, fmo_type=6, num_ref_frames=2, seed=324),
     "field_cropped": dict(FIELD_BASE, width=170, height=124, num_ref_frames=2, constrained_intra=1, intra_in_p_permille=150, seed=309),
 }
+
+
+# Picture order counts with a bottom field that is not at the top field's count (bottom_field_pic_order_in_frame_present_flag = 1:
+# delta_pic_order_cnt_bottom / delta_pic_order_cnt[1]).  Checked on the CPU only: oracle == generator, and the product's HOST side
+# (built against the null device of tools/hoststub) must arrive at the same PicOrderCnt for every picture -- tests/test_host_picture_management.py.
+POC_MATRIX = {
+    "poc_bottom_later": dict(BASE, frames=8, profile_idc=77, cabac=1, num_ref_frames=2, poc_bottom_delta=1, seed=401),
+    "poc_bottom_first": dict(BASE, frames=8, profile_idc=77, cabac=0, num_ref_frames=2, poc_bottom_delta=-1, idr_period=5, seed=402),
+    "poc_bottom_first_b_temporal": dict(BASE, frames=10, profile_idc=77, cabac=1, num_ref_frames=3, poc_bottom_delta=-3, bframes=2, direct_temporal=1, weighted_bipred=2, seed=403),
+    "poc_bottom_first_poc1_mmco": dict(BASE, frames=16, profile_idc=77, cabac=0, num_ref_frames=3, poc_bottom_delta=-1, poc_type=1, mmco=1, seed=404),
+    "poc_bottom_first_mmco5": dict(BASE, frames=24, profile_idc=77, cabac=1, num_ref_frames=3, poc_bottom_delta=-2, mmco=1, seed=21),
+    "poc_bottom_later_interlace_sps": dict(BASE, height=128, frames=6, profile_idc=100, cabac=1, transform8x8=1, num_ref_frames=2, poc_bottom_delta=2, interlace_sps=1, seed=405),
+}

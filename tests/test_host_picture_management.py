@@ -1,0 +1,71 @@
+"""The product's picture management on the CPU: mi_api.cpp + mi_parse.cpp built against the null device of tools/hoststub (kernels are
+not run) prepare every matrix stream, and the PicOrderCnt / frame_num / IDR flag they report per picture (h264mi_frame_get_info) must
+be the generator's -- 8.2.1 for all three pic_order_cnt_types, memory management operation 5, frame_num gaps, B pictures in coding
+order, non-reference pictures, and a bottom field that is not at the top field's count (POC_MATRIX).  The oracle is held to the same
+numbers.  This is the product's own host code, not a restatement: what it cannot show is anything the kernels do."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import MATRIX, POC_MATRIX
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not shutil.which("g++"), reason="g++ not available")
+
+
+@pytest.fixture(scope="module")
+def host_pocs(tmp_path_factory):
+    tmp = tmp_path_factory.mktemp("host_pocs")
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "host_pocs.sh")], env=dict(os.environ, TMPDIR=str(tmp)), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return r.stdout.strip().splitlines()[-1], tmp
+
+
+def _host(prog, tmp, stream, kw):
+    path = os.path.join(str(tmp), "s.h264")
+    open(path, "wb").write(stream)
+    W, Hc = (kw["width"] + 15) & ~15, (kw["height"] + 15) & ~15
+    nsl = max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1))
+    r = subprocess.run([prog, path, str(W), str(Hc), str(kw["frames"]), str(max(8, nsl))], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.array([[int(x) for x in line.split()] for line in r.stdout.splitlines() if line.strip()])
+
+
+def test_host_picture_order_counts_match_the_generator(host_pocs, sg):
+    prog, tmp = host_pocs
+    for name, kw in sorted(dict(MATRIX, **POC_MATRIX).items()):
+        stream, _, _ = sg.encode(want_recon=False, **kw)
+        want = sg.last_pocs()
+        got = _host(prog, tmp, stream, kw)
+        assert got.shape == (kw["frames"], 5), name
+        assert np.array_equal(got[:, 0], want), (name, got[:, 0], want)
+        assert got[0, 3] == 1 and got[0, 4] == 1, name  # the first picture is an IDR picture and starts a sequence
+        # a new sequence exactly where the generator's counts start over: IDR pictures and pictures with operation 5
+        if not kw.get("bframes") and kw.get("poc_type", 0) != 2 and not kw.get("poc_bottom_delta"):
+            restarts = np.flatnonzero(np.diff(want) < 0) + 1
+            assert set(restarts.tolist()) <= set(np.flatnonzero(got[:, 4]).tolist()), name
+
+
+@pytest.mark.parametrize("name", sorted(POC_MATRIX))
+def test_bottom_field_counts_oracle_equals_generator(name, sg, oracle_mod):
+    kw = POC_MATRIX[name]
+    stream, rec, _ = sg.encode(**kw)
+    out, info = oracle_mod.decode(stream, crop=False)
+    assert np.array_equal(out, rec)
+    assert np.array_equal(oracle_mod.last_pocs, sg.last_pocs())
+    # the syntax really is there: the PPS flag, and a non-zero delta in the slice headers of non-IDR pictures
+    import h264decode_amd.h264 as H
+    nals = H.read_nal_units(stream)
+    sps = H.NewSPS(nals[0].RBSP())
+    pps = H.NewPPS(sps, nals[1].RBSP())
+    assert pps.BottomFieldPicOrderInFramePresent
+    vs = H.VideoStream(sps, pps)
+    deltas = set()
+    for n in nals[2:]:
+        if n.Type == 1:
+            h = H.NewSliceContext(vs, n, n.RBSP()).Slice.Header
+            deltas.add(h.DeltaPicOrderCntBottom if kw.get("poc_type", 0) == 0 else h.DeltaPicOrderCnt[1] + 1)
+    assert deltas == {kw["poc_bottom_delta"]}
