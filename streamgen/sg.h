@@ -87,7 +87,7 @@ typedef struct {
     /* d != 0: bottom_field_pic_order_in_frame_present_flag = 1 and every FRAME picture says where its bottom field sits relative to
      * its top field (delta_pic_order_cnt_bottom with pic_order_cnt_type 0, delta_pic_order_cnt[1] with type 1): BottomFieldOrderCnt =
      * TopFieldOrderCnt + d.  PicOrderCnt of a frame is the smaller of the two (8.2.1): a negative d moves every non-IDR picture d
-     * earlier (IDR pictures keep 0 = Min(top, bottom): they send Max(d, 0)).  Ignored with pic_order_cnt_type 2. */
+     * earlier (IDR pictures keep 0 = Min(top, bottom): they send Max(d, 0); a negative d is taken as -1, the value of bottom-field-first material: anything lower would put the first pictures of a sequence before their IDR picture).  Ignored with pic_order_cnt_type 2. */
     int poc_bottom_delta;
 } sg_params;
 

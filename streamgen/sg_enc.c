@@ -2486,6 +2486,9 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
         if (p->b_pyramid) p->num_ref_frames = 4; /* two anchors, the reference B picture of this group and the one of the group before */
     } else
         p->b_pyramid = 0;
+    /* a bottom field that comes first moves every picture but the IDR pictures (their PicOrderCnt is 0 by rule): by one only, so that the picture
+     * sent with top count 2 still follows its IDR picture in output order and no two frames share a PicOrderCnt (8.2.1) */
+    if (p->poc_bottom_delta < 0) p->poc_bottom_delta = -1;
     if (p->field_pics) { /* PAFF, every frame as two fields: see sg.h for what that excludes */
         if (p->cabac || p->profile_idc == 66) {
             snprintf(g_err, sizeof(g_err), "field_pics needs Main or High profile with cabac = 0 (the field-coded CABAC context tables are not in this tree)");

@@ -216,8 +216,8 @@ FIELD_MATRIX = {
 POC_MATRIX = {
     "poc_bottom_later": dict(BASE, frames=8, profile_idc=77, cabac=1, num_ref_frames=2, poc_bottom_delta=1, seed=401),
     "poc_bottom_first": dict(BASE, frames=8, profile_idc=77, cabac=0, num_ref_frames=2, poc_bottom_delta=-1, idr_period=5, seed=402),
-    "poc_bottom_first_b_temporal": dict(BASE, frames=10, profile_idc=77, cabac=1, num_ref_frames=3, poc_bottom_delta=-3, bframes=2, direct_temporal=1, weighted_bipred=2, seed=403),
+    "poc_bottom_first_b_temporal": dict(BASE, frames=10, profile_idc=77, cabac=1, num_ref_frames=3, poc_bottom_delta=-1, bframes=2, direct_temporal=1, weighted_bipred=2, seed=403),
     "poc_bottom_first_poc1_mmco": dict(BASE, frames=16, profile_idc=77, cabac=0, num_ref_frames=3, poc_bottom_delta=-1, poc_type=1, mmco=1, seed=404),
-    "poc_bottom_first_mmco5": dict(BASE, frames=24, profile_idc=77, cabac=1, num_ref_frames=3, poc_bottom_delta=-2, mmco=1, seed=21),
+    "poc_bottom_first_mmco5": dict(BASE, frames=24, profile_idc=77, cabac=1, num_ref_frames=3, poc_bottom_delta=-1, mmco=1, seed=21),
     "poc_bottom_later_interlace_sps": dict(BASE, height=128, frames=6, profile_idc=100, cabac=1, transform8x8=1, num_ref_frames=2, poc_bottom_delta=2, interlace_sps=1, seed=405),
 }

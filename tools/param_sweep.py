@@ -4,7 +4,7 @@ coder, slices, slice groups, references, picture management, B pictures, weights
 generator's reconstruction bit for bit.  Usage: param_sweep.py [trials] [--gpu] [--seed N] [--batch B]
   without --gpu: the oracle (CPU);  with --gpu: the product through the C ABI, one workgroup per picture and banded;
   --batch B (GPU): B streams of different recipes and sizes side by side in one decoder per trial;
-  --fields: field-picture (PAFF) recipes, oracle only;
+  --fields: field-picture (PAFF) recipes, oracle only;  --pocdelta: frame pictures whose bottom field has its own picture order count;
   --split (GPU): every stream is fed in several calls, a random number of access units at a time (state that must survive a batch boundary:
   reference pictures and their marking, picture order counts, co-located motion, frame_num gap bookkeeping, parameter sets)."""
 import os, sys, time
@@ -22,6 +22,7 @@ XR = "--xwgs" in sys.argv  # a random workgroup budget per trial (band plans of 
 EXTREME = "--extreme" in sys.argv  # the corners of the value ranges: QP 0..51, chroma offsets -12..12, filter offsets -6..6, loud noise (escape-coded levels)
 BIG = "--big" in sys.argv  # pictures wider than 64 macroblocks (rows of more than one 64-macroblock chunk), more slices
 FIELDS = "--fields" in sys.argv  # PAFF recipes: every frame as two field pictures (oracle only: the product refuses field pictures)
+POCD = "--pocdelta" in sys.argv  # bottom_field_pic_order_in_frame_present_flag = 1: the bottom field of every frame picture at its own count (before or after the top field)
 CONCAT = "--concat" in sys.argv  # two recipes back to back in one stream: new parameter sets, entropy coder, slice groups, picture size at the second IDR picture
 args = [a for a in args if a not in (str(seed0), str(BATCH))] or args[:1]
 rng = np.random.default_rng(seed0)
@@ -79,6 +80,8 @@ def draw():
         else:
             kw["transform8x8"], kw["scaling_matrix"] = pick(0, 1, 1), pick(0, 1)
         kw["weighted_pred"] = pick(0, 0, 1, 2)
+    if POCD:
+        kw["poc_bottom_delta"] = pick(-1, -1, 1, 2, 4)
     return kw
 
 
