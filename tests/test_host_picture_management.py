@@ -31,7 +31,8 @@ def _host(prog, tmp, stream, kw):
     nsl = max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1))
     r = subprocess.run([prog, path, str(W), str(Hc), str(kw["frames"]), str(max(8, nsl))], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
-    return np.array([[int(x) for x in line.split()] for line in r.stdout.splitlines() if line.strip()])
+    lines = [line.split() for line in r.stdout.splitlines() if line.strip()]
+    return np.array([[int(x) for x in t] for t in lines if t[0] != "order"]), [int(x) for t in lines if t[0] == "order" for x in t[1:]]
 
 
 def test_host_picture_order_counts_match_the_generator(host_pocs, sg):
@@ -39,10 +40,15 @@ def test_host_picture_order_counts_match_the_generator(host_pocs, sg):
     for name, kw in sorted(dict(MATRIX, **POC_MATRIX).items()):
         stream, _, _ = sg.encode(want_recon=False, **kw)
         want = sg.last_pocs()
-        got = _host(prog, tmp, stream, kw)
+        got, order = _host(prog, tmp, stream, kw)
         assert got.shape == (kw["frames"], 5), name
         assert np.array_equal(got[:, 0], want), (name, got[:, 0], want)
         assert got[0, 3] == 1 and got[0, 4] == 1, name  # the first picture is an IDR picture and starts a sequence
+        # h264mi_stream_output_order: a permutation that shows every coded video sequence in ascending PicOrderCnt, the sequences in coding order
+        assert sorted(order) == list(range(kw["frames"])), name
+        seq = np.cumsum(got[:, 4])
+        keys = [(int(seq[i]), int(got[i, 0])) for i in order]
+        assert keys == sorted(keys), (name, keys)
         # a new sequence exactly where the generator's counts start over: IDR pictures and pictures with operation 5
         if not kw.get("bframes") and kw.get("poc_type", 0) != 2 and not kw.get("poc_bottom_delta"):
             restarts = np.flatnonzero(np.diff(want) < 0) + 1

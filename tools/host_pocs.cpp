@@ -1,6 +1,6 @@
 // tools/host_pocs.cpp -- TEST TOOLING: the host side of libh264mi built against tools/hoststub (a null device: kernels are not
 // run) decodes one Annex-B file in a single batch and prints, per frame in decoding order, what its picture management made of
-// it: "pic_order_cnt frame_num nal_ref_idc idr new_sequence".  tests/test_host_picture_management.py holds these against the
+// it: "pic_order_cnt frame_num nal_ref_idc idr new_sequence", then the output order of the batch.  tests/test_host_picture_management.py holds these against the
 // generator's intent on the CPU -- the product's own 8.2.1 code without a GPU.
 #include "h264mi.h"
 #include <cstdio>
@@ -38,6 +38,13 @@ int main(int argc, char **argv) {
         if (h264mi_frame_get_info(dec, 0, i, &fi) != 0) return 1;
         printf("%d %d %d %d %d\n", fi.pic_order_cnt, fi.frame_num, fi.nal_ref_idc, fi.idr, fi.new_sequence);
     }
+    // the output order of the batch (h264mi_stream_output_order): one line "order i j k ..."
+    std::vector<int32_t> order(n > 0 ? n : 1);
+    int32_t no = 0;
+    if (h264mi_stream_output_order(dec, 0, order.data(), n, &no) != 0 || no != n) return 1;
+    printf("order");
+    for (int i = 0; i < no; i++) printf(" %d", order[i]);
+    printf("\n");
     h264mi_decoder_destroy(dec);
     return 0;
 }
