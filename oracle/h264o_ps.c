@@ -361,6 +361,8 @@ int h264o_parse_slice_header(h264o_br *b, int nal_ref_idc, int nal_unit_type, co
     if ((p->weighted_pred_flag && (sh->slice_type == 0 || sh->slice_type == 3)) || (p->weighted_bipred_idc == 1 && sh->slice_type == 1)) {
         sh->luma_log2_weight_denom = h264o_ue(b);
         sh->chroma_log2_weight_denom = h264o_ue(b); /* ChromaArrayType != 0 */
+        if (sh->luma_log2_weight_denom > 7 || sh->chroma_log2_weight_denom > 7) return -1;
+#define WP_BAD(v) ((v) < -128 || (v) > 127) /* 7.4.3.2: coded weights and offsets; the default weight 1 << denom is not coded */
         for (int i = 0; i <= sh->num_ref_idx_l0_active_minus1; i++) {
             sh->luma_weight_l0[i] = 1 << sh->luma_log2_weight_denom;
             sh->chroma_weight_l0[i][0] = sh->chroma_weight_l0[i][1] = 1 << sh->chroma_log2_weight_denom;
@@ -368,12 +370,14 @@ int h264o_parse_slice_header(h264o_br *b, int nal_ref_idc, int nal_unit_type, co
             if (sh->luma_weight_l0_flag[i]) {
                 sh->luma_weight_l0[i] = h264o_se(b);
                 sh->luma_offset_l0[i] = h264o_se(b);
+                if (WP_BAD(sh->luma_weight_l0[i]) || WP_BAD(sh->luma_offset_l0[i])) return -1;
             }
             sh->chroma_weight_l0_flag[i] = h264o_u(b, 1);
             if (sh->chroma_weight_l0_flag[i])
                 for (int j = 0; j < 2; j++) {
                     sh->chroma_weight_l0[i][j] = h264o_se(b);
                     sh->chroma_offset_l0[i][j] = h264o_se(b);
+                    if (WP_BAD(sh->chroma_weight_l0[i][j]) || WP_BAD(sh->chroma_offset_l0[i][j])) return -1;
                 }
         }
         if (sh->slice_type == 1)
@@ -384,12 +388,14 @@ int h264o_parse_slice_header(h264o_br *b, int nal_ref_idc, int nal_unit_type, co
                 if (sh->luma_weight_l1_flag[i]) {
                     sh->luma_weight_l1[i] = h264o_se(b);
                     sh->luma_offset_l1[i] = h264o_se(b);
+                    if (WP_BAD(sh->luma_weight_l1[i]) || WP_BAD(sh->luma_offset_l1[i])) return -1;
                 }
                 sh->chroma_weight_l1_flag[i] = h264o_u(b, 1);
                 if (sh->chroma_weight_l1_flag[i])
                     for (int j = 0; j < 2; j++) {
                         sh->chroma_weight_l1[i][j] = h264o_se(b);
                         sh->chroma_offset_l1[i][j] = h264o_se(b);
+                        if (WP_BAD(sh->chroma_weight_l1[i][j]) || WP_BAD(sh->chroma_offset_l1[i][j])) return -1;
                     }
             }
     }
