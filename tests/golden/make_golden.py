@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(HERE, "..", ".."))
 sys.path.insert(0, os.path.join(HERE, ".."))
 import oracle  # noqa: E402
 import streamgen  # noqa: E402
-from conftest import FIELD_MATRIX, MATRIX  # noqa: E402
+from conftest import FIELD_MATRIX, MATRIX, POC_MATRIX  # noqa: E402
 
 out = {}
 for name in sorted(MATRIX):
@@ -32,3 +32,14 @@ for name in sorted(FIELD_MATRIX):
     out[name] = {"stream_md5": hashlib.md5(s).hexdigest(), "frames_md5": hashlib.md5(frames.tobytes()).hexdigest(), "stream_bytes": len(s)}
 json.dump(out, open(os.path.join(HERE, "field_md5.json"), "w"), indent=1, sort_keys=True)
 print("wrote", len(out), "field vectors")
+
+# separate bottom-field picture order counts (CPU-checked cases: oracle, generator, and the product's host side against the null device)
+out = {}
+for name in sorted(POC_MATRIX):
+    s, rec, _ = streamgen.encode(**POC_MATRIX[name])
+    frames, _ = oracle.decode(s, crop=False)
+    assert (frames == rec).all(), name
+    out[name] = {"stream_md5": hashlib.md5(s).hexdigest(), "frames_md5": hashlib.md5(frames.tobytes()).hexdigest(), "stream_bytes": len(s),
+                 "pocs": [int(x) for x in streamgen.last_pocs()]}
+json.dump(out, open(os.path.join(HERE, "poc_md5.json"), "w"), indent=1, sort_keys=True)
+print("wrote", len(out), "POC vectors")

@@ -75,3 +75,17 @@ def test_bottom_field_counts_oracle_equals_generator(name, sg, oracle_mod):
             h = H.NewSliceContext(vs, n, n.RBSP()).Slice.Header
             deltas.add(h.DeltaPicOrderCntBottom if kw.get("poc_type", 0) == 0 else h.DeltaPicOrderCnt[1] + 1)
     assert deltas == {kw["poc_bottom_delta"]}
+
+
+def test_poc_golden_vectors(sg, oracle_mod):
+    """Committed fixtures of the POC_MATRIX streams: MD5 of stream and decoded frames, and the PicOrderCnt list (tests/golden/make_golden.py)."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "poc_md5.json")))
+    assert set(gold) == set(POC_MATRIX)
+    for name, g in gold.items():
+        stream, _, _ = sg.encode(**POC_MATRIX[name])
+        assert hashlib.md5(stream).hexdigest() == g["stream_md5"], name
+        out, _ = oracle_mod.decode(stream, crop=False)
+        assert hashlib.md5(out.tobytes()).hexdigest() == g["frames_md5"], name
+        assert [int(x) for x in oracle_mod.last_pocs] == g["pocs"], name
