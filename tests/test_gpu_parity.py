@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import MATRIX, PRODUCT_DECODES_B
+from conftest import MATRIX, POC_MATRIX, PRODUCT_DECODES_B
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "stream_md5.json")
@@ -71,6 +71,25 @@ def test_gpu_matches_oracle_and_generator(name, H, sg, oracle_mod):
     assert np.array_equal(out[0], rec), "GPU != generator reconstruction"
     # picture order counts (8.2.1, incl. type 1 / type 2, non-reference pictures and the reset after MMCO 5)
     assert info.pocs[0] == list(oracle_mod.last_pocs) == list(sg.last_pocs()), "PicOrderCnt"
+
+
+@pytest.mark.parametrize("name", sorted(POC_MATRIX))
+def test_gpu_separate_bottom_field_counts(name, H, sg, oracle_mod):
+    """bottom_field_pic_order_in_frame_present_flag = 1 (delta_pic_order_cnt_bottom / delta_pic_order_cnt[1], a bottom field that comes
+    first or later, with B pictures, marking scripts and operation 5): pixels and PicOrderCnt as for the matrix.  (Run on the GPU at the
+    end of round 3 through tools/poc_gpu_check.py: bit-exact, equal counts.)"""
+    kw = POC_MATRIX[name]
+    stream, rec, _ = sg.encode(**kw)
+    dec = H.Decoder(max_streams=1, max_width=(kw["width"] + 15) & ~15, max_height=(kw["height"] + 15) & ~15, max_frames_per_batch=kw["frames"], max_slices_per_frame=8)
+    try:
+        dec.decode([stream])
+        out = dec.read_frames(0, crop=False)
+        assert out.shape == rec.shape and np.array_equal(out, rec), "GPU != generator reconstruction"
+        assert [dec.frame_info(0, i).pic_order_cnt for i in range(kw["frames"])] == [int(x) for x in sg.last_pocs()], "PicOrderCnt"
+    finally:
+        dec.close()
+    ref, _ = oracle_mod.decode(stream, crop=False)
+    assert np.array_equal(out, ref), "GPU != oracle"
 
 
 def test_gpu_matrix_with_one_workgroup_per_picture(H, sg):
