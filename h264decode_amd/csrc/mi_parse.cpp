@@ -362,44 +362,66 @@ int parse_pps_ids(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi
     BitReader b(rbsp, len);
     memset(p, 0, sizeof(*p));
     if (n_ids) *n_ids = 0;
-    p->id = b.ue();
-    p->sps_id = b.ue();
+    // every ue(v) is range-checked as the unsigned value it is BEFORE it lands in an int32 field: a 32-bit Exp-Golomb code (31 leading
+    // zeros) would otherwise turn negative and slip through signed comparisons (ids index tables, run lengths step loops)
+    bool bad = false;
+    auto UE = [&](uint32_t max) -> int32_t {
+        const uint32_t v = b.ue();
+        if (v > max) bad = true;
+        return v > max ? 0 : static_cast<int32_t>(v);
+    };
+    p->id = UE(255);
+    p->sps_id = UE(31);
+    if (bad) {
+        set_error("PPS: pic_parameter_set_id / seq_parameter_set_id out of range");
+        return H264MI_EBITSTREAM;
+    }
     p->entropy_coding_mode = b.u(1);
     p->bottom_field_pic_order_in_frame_present = b.u(1);
-    p->num_slice_groups_minus1 = b.ue();
-    if (p->num_slice_groups_minus1 > 7) { // A.2: at most 8 slice groups in any profile
-        set_error("PPS: num_slice_groups_minus1 %d out of range", p->num_slice_groups_minus1);
+    p->num_slice_groups_minus1 = UE(7);
+    if (bad) { // A.2: at most 8 slice groups in any profile
+        set_error("PPS: num_slice_groups_minus1 out of range");
         return H264MI_EBITSTREAM;
     }
     if (p->num_slice_groups_minus1 > 0) { // 7.3.2.2 (h264/pps.go:57-80)
         const int ng = p->num_slice_groups_minus1 + 1;
-        const uint32_t map_units = static_cast<uint32_t>(sps->pic_width_in_mbs_minus1 + 1) * static_cast<uint32_t>(sps->pic_height_in_map_units_minus1 + 1);
-        p->slice_group_map_type = b.ue();
+        const uint32_t wmbs = static_cast<uint32_t>(sps->pic_width_in_mbs_minus1 + 1);
+        const uint32_t map_units = wmbs * static_cast<uint32_t>(sps->pic_height_in_map_units_minus1 + 1);
+        p->slice_group_map_type = UE(6);
+        if (bad) {
+            set_error("PPS: slice_group_map_type out of range");
+            return H264MI_EBITSTREAM;
+        }
         if (p->slice_group_map_type == 0) {
-            for (int i = 0; i < ng; i++) p->run_length_minus1[i] = b.ue();
+            for (int i = 0; i < ng; i++) p->run_length_minus1[i] = UE(map_units - 1); // 7.4.2.2: 0 .. PicSizeInMapUnits - 1
+            if (bad) {
+                set_error("PPS: run_length_minus1 beyond the picture");
+                return H264MI_EBITSTREAM;
+            }
         } else if (p->slice_group_map_type == 2) {
             for (int i = 0; i < ng - 1; i++) {
-                p->top_left[i] = b.ue(), p->bottom_right[i] = b.ue();
-                // 7.4.2.2: top_left <= bottom_right, and its column not to the right of bottom_right's
-                if (p->top_left[i] > p->bottom_right[i] || static_cast<uint32_t>(p->bottom_right[i]) >= map_units ||
-                    p->top_left[i] % (sps->pic_width_in_mbs_minus1 + 1) > p->bottom_right[i] % (sps->pic_width_in_mbs_minus1 + 1)) {
+                const uint32_t tl = b.ue(), br = b.ue();
+                // 7.4.2.2: top_left <= bottom_right < PicSizeInMapUnits, and its column not to the right of bottom_right's
+                if (tl > br || br >= map_units || tl % wmbs > br % wmbs) {
                     set_error("PPS: slice group rectangle %d is malformed", i);
                     return H264MI_EBITSTREAM;
                 }
+                p->top_left[i] = static_cast<int32_t>(tl), p->bottom_right[i] = static_cast<int32_t>(br);
             }
         } else if (p->slice_group_map_type >= 3 && p->slice_group_map_type <= 5) {
             p->slice_group_change_direction = b.u(1);
-            p->slice_group_change_rate_minus1 = b.ue();
-            if (ng != 2 || static_cast<uint32_t>(p->slice_group_change_rate_minus1) >= map_units) {
+            p->slice_group_change_rate_minus1 = UE(map_units - 1);
+            if (ng != 2 || bad) {
                 set_error("PPS: slice_group_map_type %d needs two slice groups and a change rate below the picture size", p->slice_group_map_type);
                 return H264MI_EBITSTREAM;
             }
         } else if (p->slice_group_map_type == 6) {
-            p->pic_size_in_map_units_minus1 = b.ue();
-            if (static_cast<uint32_t>(p->pic_size_in_map_units_minus1) + 1 != map_units) {
-                set_error("PPS: pic_size_in_map_units_minus1 %d does not match the SPS (%u map units)", p->pic_size_in_map_units_minus1, map_units);
+            const uint32_t psm1 = b.ue();
+            if (psm1 != map_units - 1) {
+                set_error("PPS: pic_size_in_map_units_minus1 %u does not match the SPS (%u map units)", psm1, map_units);
                 return H264MI_EBITSTREAM;
             }
+            p->pic_size_in_map_units_minus1 = static_cast<int32_t>(psm1);
             const int bits = ceil_log2(static_cast<uint32_t>(ng));
             for (uint32_t i = 0; i < map_units && !b.overrun(); i++) {
                 const uint32_t v = b.u(bits);
@@ -410,13 +432,14 @@ int parse_pps_ids(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi
                 if (ids && i < cap) ids[i] = static_cast<uint8_t>(v);
             }
             if (n_ids) *n_ids = map_units;
-        } else if (p->slice_group_map_type != 1) {
-            set_error("PPS: slice_group_map_type %d out of range", p->slice_group_map_type);
-            return H264MI_EBITSTREAM;
         }
     }
-    p->num_ref_idx_l0_default_active_minus1 = b.ue();
-    p->num_ref_idx_l1_default_active_minus1 = b.ue();
+    p->num_ref_idx_l0_default_active_minus1 = UE(31);
+    p->num_ref_idx_l1_default_active_minus1 = UE(31);
+    if (bad) {
+        set_error("PPS: num_ref_idx_default_active_minus1 out of range");
+        return H264MI_EBITSTREAM;
+    }
     p->weighted_pred = b.u(1);
     p->weighted_bipred = b.u(2);
     p->pic_init_qp_minus26 = b.se();
@@ -440,8 +463,9 @@ int parse_pps_ids(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi
         }
         p->second_chroma_qp_index_offset = b.se();
     }
-    if (b.overrun() || p->id > 255 || p->sps_id > 31) {
-        set_error("PPS: truncated or bad id");
+    if (b.overrun() || p->pic_init_qp_minus26 < -26 || p->pic_init_qp_minus26 > 25 || p->chroma_qp_index_offset < -12 || p->chroma_qp_index_offset > 12 ||
+        p->second_chroma_qp_index_offset < -12 || p->second_chroma_qp_index_offset > 12) {
+        set_error("PPS: truncated, or a QP field out of range");
         return H264MI_EBITSTREAM;
     }
     return H264MI_OK;
@@ -456,18 +480,26 @@ int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc
     const bool idr = nal_unit_type == 5;
     sh->nal_ref_idc = nal_ref_idc;
     sh->nal_unit_type = nal_unit_type;
-    sh->first_mb_in_slice = b.ue();
-    sh->slice_type = b.ue();
-    if (sh->slice_type > 9) return H264MI_EBITSTREAM;
+    // (every ue(v) is checked as an unsigned value before it is stored in an int32 field: see parse_pps_ids)
+    bool bad = false;
+    auto UE = [&](uint32_t max) -> int32_t {
+        const uint32_t v = b.ue();
+        if (v > max) bad = true;
+        return v > max ? 0 : static_cast<int32_t>(v);
+    };
+    // PicSizeInMbs of the largest picture the library accepts (8192 x 5120 samples): the caller compares with the picture's own size
+    sh->first_mb_in_slice = UE(512 * 320 - 1);
+    sh->slice_type = UE(9);
+    if (bad) return H264MI_EBITSTREAM;
     const int st = sh->slice_type % 5;
-    sh->pps_id = b.ue();
+    sh->pps_id = UE(255);
     if (s->use_separate_color_plane) sh->color_plane_id = b.u(2);
     sh->frame_num = b.u(s->log2_max_frame_num_minus4 + 4);
     if (!s->frame_mbs_only) {
         sh->field_pic = b.u(1);
         if (sh->field_pic) sh->bottom_field = b.u(1);
     }
-    if (idr) sh->idr_pic_id = b.ue();
+    if (idr) sh->idr_pic_id = UE(65535);
     if (s->pic_order_count_type == 0) {
         sh->pic_order_cnt_lsb = b.u(s->log2_max_pic_order_cnt_lsb_min4 + 4);
         if (p->bottom_field_pic_order_in_frame_present && !sh->field_pic) sh->delta_pic_order_cnt_bottom = b.se();
@@ -476,17 +508,18 @@ int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc
         sh->delta_pic_order_cnt[0] = b.se();
         if (p->bottom_field_pic_order_in_frame_present && !sh->field_pic) sh->delta_pic_order_cnt[1] = b.se();
     }
-    if (p->redundant_pic_cnt_present) sh->redundant_pic_cnt = b.ue();
+    if (p->redundant_pic_cnt_present) sh->redundant_pic_cnt = UE(127);
+    if (bad) return H264MI_EBITSTREAM;
     if (st == 1) sh->direct_spatial_mv_pred = b.u(1);
     sh->num_ref_idx_l0_active_minus1 = p->num_ref_idx_l0_default_active_minus1;
     sh->num_ref_idx_l1_active_minus1 = p->num_ref_idx_l1_default_active_minus1;
     if (st == 0 || st == 3 || st == 1) {
         sh->num_ref_idx_active_override = b.u(1);
         if (sh->num_ref_idx_active_override) {
-            sh->num_ref_idx_l0_active_minus1 = b.ue();
-            if (st == 1) sh->num_ref_idx_l1_active_minus1 = b.ue();
+            sh->num_ref_idx_l0_active_minus1 = UE(31);
+            if (st == 1) sh->num_ref_idx_l1_active_minus1 = UE(31);
         }
-        if (sh->num_ref_idx_l0_active_minus1 > 31 || sh->num_ref_idx_l1_active_minus1 > 31) return H264MI_EBITSTREAM;
+        if (bad || sh->num_ref_idx_l0_active_minus1 > 31 || sh->num_ref_idx_l1_active_minus1 > 31) return H264MI_EBITSTREAM;
     }
     if (st != 2 && st != 4) { // ref_pic_list_modification(): list 0, then list 1 of B slices
         for (int l = 0; l < (st == 1 ? 2 : 1); l++) {
@@ -500,14 +533,15 @@ int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc
                     if (idc == 3) break;
                     if (idc > 3 || n >= 66 || b.overrun()) return H264MI_EBITSTREAM;
                     idcs[n] = idc;
-                    vals[n++] = b.ue();
+                    vals[n++] = UE((2u << 16) - 1); // abs_diff_pic_num_minus1 < MaxPicNum <= 2^17; long_term_pic_num < 32
+                    if (bad) return H264MI_EBITSTREAM;
                 }
         }
     }
     if ((p->weighted_pred && (st == 0 || st == 3)) || (p->weighted_bipred == 1 && st == 1)) { // pred_weight_table()
-        sh->luma_log2_weight_denom = b.ue();
-        sh->chroma_log2_weight_denom = b.ue();
-        if (sh->luma_log2_weight_denom > 7 || sh->chroma_log2_weight_denom > 7) return H264MI_EBITSTREAM;
+        sh->luma_log2_weight_denom = UE(7);
+        sh->chroma_log2_weight_denom = UE(7);
+        if (bad) return H264MI_EBITSTREAM;
         for (int l = 0; l < (st == 1 ? 2 : 1); l++) {
             const int n = l ? sh->num_ref_idx_l1_active_minus1 : sh->num_ref_idx_l0_active_minus1;
             int32_t *lf = l ? sh->luma_weight_l1_flag : sh->luma_weight_l0_flag, *lw = l ? sh->luma_weight_l1 : sh->luma_weight_l0;
@@ -547,23 +581,26 @@ int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc
                     int k = sh->n_memory_management_control_operations;
                     if (op > 6 || k >= 66 || b.overrun()) return H264MI_EBITSTREAM;
                     sh->memory_management_control_operation[k] = op;
-                    if (op == 1 || op == 3 || op == 2 || op == 4) sh->mmco_arg1[k] = b.ue();
-                    if (op == 3 || op == 6) sh->mmco_arg2[k] = b.ue();
+                    if (op == 1 || op == 3 || op == 2 || op == 4) sh->mmco_arg1[k] = UE((2u << 16) - 1);
+                    if (op == 3 || op == 6) sh->mmco_arg2[k] = UE(32);
+                    if (bad) return H264MI_EBITSTREAM;
                     sh->n_memory_management_control_operations++;
                 }
         }
     }
     if (p->entropy_coding_mode && st != 2 && st != 4) {
-        sh->cabac_init = b.ue();
-        if (sh->cabac_init > 2) return H264MI_EBITSTREAM;
+        sh->cabac_init = UE(2);
+        if (bad) return H264MI_EBITSTREAM;
     }
     sh->slice_qp_delta = b.se();
+    if (sh->slice_qp_delta < -87 || sh->slice_qp_delta > 77) return H264MI_EBITSTREAM; // (7-30) keeps SliceQPY in 0..51 for any pic_init_qp
     if (st == 3 || st == 4) {
         if (st == 3) sh->sp_for_switch = b.u(1);
         sh->slice_qs_delta = b.se();
     }
     if (p->deblocking_filter_control_present) {
-        sh->disable_deblocking_filter = b.ue();
+        sh->disable_deblocking_filter = UE(2);
+        if (bad) return H264MI_EBITSTREAM;
         if (sh->disable_deblocking_filter != 1) {
             sh->slice_alpha_c0_offset_div2 = b.se();
             sh->slice_beta_offset_div2 = b.se();
@@ -599,10 +636,25 @@ int map_unit_to_slice_group_map(const h264mi_sps *s, const h264mi_pps *p, const 
     const size_t units = static_cast<size_t>(W) * Hm;
     if (n_out) *n_out = units;
     if (cap < units) return H264MI_ECAPACITY;
+    if (W < 1 || Hm < 1 || W > 512 || Hm > 320) return H264MI_EINVAL;
     const int ng = p->num_slice_groups_minus1 + 1;
+    if (ng < 1 || ng > 8) return H264MI_EBITSTREAM;
     if (ng == 1) {
         memset(map, 0, units);
         return H264MI_OK;
+    }
+    // a public entry point with a caller-supplied PPS (h264mi_map_unit_to_slice_group_map): the fields the loops below step by or
+    // index with are checked again here, as unsigned values (7.4.2.2)
+    if (p->slice_group_map_type == 0) {
+        for (int g = 0; g < ng; g++)
+            if (static_cast<uint32_t>(p->run_length_minus1[g]) >= units) return H264MI_EBITSTREAM;
+    } else if (p->slice_group_map_type == 2) {
+        for (int g = 0; g < ng - 1; g++) {
+            const uint32_t tl = static_cast<uint32_t>(p->top_left[g]), br = static_cast<uint32_t>(p->bottom_right[g]);
+            if (tl > br || br >= units || tl % W > br % W) return H264MI_EBITSTREAM;
+        }
+    } else if (p->slice_group_map_type >= 3 && p->slice_group_map_type <= 5) {
+        if (ng != 2 || static_cast<uint32_t>(p->slice_group_change_rate_minus1) >= units) return H264MI_EBITSTREAM;
     }
     const int flag = p->slice_group_change_direction ? 1 : 0;
     const size_t rate = static_cast<size_t>(p->slice_group_change_rate_minus1) + 1;

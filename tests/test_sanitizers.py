@@ -41,3 +41,6 @@ def test_host_side_under_asan(tmp_path):
 def test_parsers_and_oracle_under_asan(tmp_path):
     out = _run(["bash", "tools/parser_asan.sh", "2000", "3", "4"], tmp_path, 600)
     assert out.count("parser fuzz:") == 7 and out.count("decoded,") == 7
+    # the round-3 advisor reproducers (ue(v) values >= 2^31 in the PPS slice-group syntax and the ids) are refused by the parser AND by the
+    # public map builder, and maximal Exp-Golomb codes spliced in at every bit position leave no negative field behind
+    assert out.count("reproducers: 7 of 7 refused") == 7 and out.count("spliced maximal ue(v) codes") == 7
