@@ -59,8 +59,7 @@ int main(int argc, char **argv) {
         }
     if (!sps.width) return fail("no SPS found", H264MI_EBITSTREAM);
 
-    h264mi_config cfg;
-    memset(&cfg, 0, sizeof(cfg));
+    h264mi_config cfg = H264MI_CONFIG_INIT; /* zero-initialised, struct_size = this build's sizeof */
     cfg.max_streams = 1, cfg.max_width = sps.width, cfg.max_height = sps.height;
     cfg.max_frames_per_batch = per_batch, cfg.max_slices_per_frame = 32, cfg.max_bitstream_bytes = len + (1 << 20);
     h264mi_decoder *dec = NULL;

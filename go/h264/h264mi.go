@@ -341,7 +341,7 @@ type BatchInfo struct {
 }
 
 func NewDecoder(cfg Config) (*Decoder, error) {
-	c := C.h264mi_config{device: C.int32_t(cfg.Device), max_streams: C.int32_t(cfg.MaxStreams), max_width: C.int32_t(cfg.MaxWidth),
+	c := C.h264mi_config{struct_size: C.uint32_t(C.sizeof_h264mi_config), device: C.int32_t(cfg.Device), max_streams: C.int32_t(cfg.MaxStreams), max_width: C.int32_t(cfg.MaxWidth),
 		max_height: C.int32_t(cfg.MaxHeight), max_frames_per_batch: C.int32_t(cfg.MaxFramesPerBatch),
 		max_slices_per_frame: C.int32_t(cfg.MaxSlicesPerFrame), max_bitstream_bytes: C.int64_t(cfg.MaxBitstreamBytes),
 		max_ref_frames: C.int32_t(cfg.MaxRefFrames), coef_blocks_per_mb: C.int32_t(cfg.CoefBlocksPerMb)}

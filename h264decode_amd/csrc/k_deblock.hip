@@ -195,9 +195,12 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
 #endif
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
-    const int W = wmb * 16, H = hmb * 16, Wc = W / 2; // the picture's own geometry
-    g8 *const py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes); // luma plane; Cb at +W*H, Cr at +W*H*5/4
-    const uint32_t cb_off = static_cast<uint32_t>(W) * H, cr_off = cb_off + cb_off / 4;
+    // the picture's place in its frame slot (PicDesc): W = bytes from one luma row of the PICTURE to the next (a field picture lives in the
+    // rows of its parity: twice the frame's pitch, first row y_off bytes in); offsets are relative to the slot's first byte
+    const int W = static_cast<int>(pd->pitch), Wc = W / 2;
+    g8 *const py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes);
+    const uint32_t y_off = pd->field == 2 ? pd->pitch >> 1 : 0u;
+    const uint32_t cb_off = pd->plane + (y_off >> 1), cr_off = cb_off + (pd->plane >> 2);
     for (int i = tid; i < 192; i += nthreads) sh.prog[i] = 0, sh.cons[i] = 0;
     __syncthreads();
     const DbPrm *prms = dbprm + pd->mb_base;
@@ -252,7 +255,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
         const int in_depth = in_last ? ring_last : ring;
         const GroupSlot *in_ring = rings + in_wave * ring + (in_last && g > 0 ? (((g - 1) / nwaves) % last_bufs) * ring_last : 0);
 #endif
-        const uint32_t yrow0 = static_cast<uint32_t>((row_ok ? mby : 0) * 16 + li) * W;                                   // this lane's luma row
+        const uint32_t yrow0 = y_off + static_cast<uint32_t>((row_ok ? mby : 0) * 16 + li) * W;                           // this lane's luma row
         const uint32_t crow0 = (li < 8 ? cb_off : cr_off) + static_cast<uint32_t>((row_ok ? mby : 0) * 8 + (li & 7)) * Wc; // and chroma row
 #if MI_DB_BANDS
         // Banded build: a launch that needs bands has few pictures, so HBM traffic is no concern and the chain's instruction count is
@@ -642,7 +645,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
 #endif
                 if (last_row && has_top) { // the up lanes own rows 13..15 here: rows -3..-1 of the macroblock above go out directly
                     if (li < 3 && do_l)
-                        GST16(py, static_cast<uint32_t>(mby * 16 - 3 + li) * W + mbx * 16, *reinterpret_cast<const v4u *>(&ss->y[1 + li][16]));
+                        GST16(py, y_off + static_cast<uint32_t>(mby * 16 - 3 + li) * W + mbx * 16, *reinterpret_cast<const v4u *>(&ss->y[1 + li][16]));
                     else if (li >= 8 && li < 10 && do_c)
                         GST8(py, (li == 8 ? cb_off : cr_off) + static_cast<uint32_t>(mby * 8 - 1) * Wc + mbx * 8, *reinterpret_cast<const v2u *>(&ss->c[li - 8][3][8]));
                 }
@@ -679,19 +682,21 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
 #if !MI_DB_BANDS
 // ================================================================== k_dbprep: DbPrm of every macroblock of a batch
 // 8.7.2.1 with one list (I / P pictures)
-__device__ __forceinline__ int prep_bs(const MbRec *mp, int pb, const MbRec *mq, int qb, bool mb_edge) {
+// (strong: the bS of an intra macroblock edge -- 4, but 3 on the horizontal macroblock edges of a field picture; vlim: the vertical vector
+// difference that counts as "far" -- 4 quarter frame samples = 2 quarter field samples in a field picture)
+__device__ __forceinline__ int prep_bs(const MbRec *mp, int pb, const MbRec *mq, int qb, int strong, int vlim) {
     // branch-free: every operand is fetched up front (independent LDS reads), the decision is a chain of selects
     const int q8p = ((pb >> 3) << 1) | ((pb & 3) >> 1), q8q = ((qb >> 3) << 1) | ((qb & 3) >> 1);
     const int tp = mp->type, tq = mq->type, nzp = mp->nzmask, nzq = mq->nzmask, rp = mp->refslot[q8p], rq = mq->refslot[q8q];
     const int vpx = mp->mv[pb][0], vpy = mp->mv[pb][1], vqx = mq->mv[qb][0], vqy = mq->mv[qb][1];
-    const bool far = rp != rq || abs(vpx - vqx) >= 4 || abs(vpy - vqy) >= 4;
-    return (MB_IS_INTRA(tp) || MB_IS_INTRA(tq)) ? (mb_edge ? 4 : 3) : ((((nzp >> pb) | (nzq >> qb)) & 1) ? 2 : (far ? 1 : 0));
+    const bool far = rp != rq || abs(vpx - vqx) >= 4 || abs(vpy - vqy) >= vlim;
+    return (MB_IS_INTRA(tp) || MB_IS_INTRA(tq)) ? strong : ((((nzp >> pb) | (nzq >> qb)) & 1) ? 2 : (far ? 1 : 0));
 }
 // 8.7.2.1 with two lists (pictures with B slices): the blocks differ if they use different reference PICTURES (frame slots; the
 // list a picture comes from does not matter) or a different number of vectors, or if the vectors that belong together differ by >= 4
-__device__ __forceinline__ bool mv_far(const int16_t *a, const int16_t *b) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= 4; }
-__device__ __forceinline__ int prep_bs_b(const MbRec *mp, const MbMv1 *vp, int pb, const MbRec *mq, const MbMv1 *vq, int qb, bool mb_edge) {
-    if (MB_IS_INTRA(mp->type) || MB_IS_INTRA(mq->type)) return mb_edge ? 4 : 3;
+__device__ __forceinline__ bool mv_far(const int16_t *a, const int16_t *b, int vlim) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= vlim; }
+__device__ __forceinline__ int prep_bs_b(const MbRec *mp, const MbMv1 *vp, int pb, const MbRec *mq, const MbMv1 *vq, int qb, int strong, int vlim) {
+    if (MB_IS_INTRA(mp->type) || MB_IS_INTRA(mq->type)) return strong;
     if (((mp->nzmask >> pb) & 1) || ((mq->nzmask >> qb) & 1)) return 2;
     const int p8 = ((pb >> 3) << 1) | ((pb & 3) >> 1), q8 = ((qb >> 3) << 1) | ((qb & 3) >> 1);
     const int p0 = mp->refslot[p8], p1 = mp->refslot1[p8], q0 = mq->refslot[q8], q1 = mq->refslot1[q8];
@@ -701,12 +706,12 @@ __device__ __forceinline__ int prep_bs_b(const MbRec *mp, const MbMv1 *vp, int p
     if (np < 2) { // one vector each (or none: corrupt records)
         const int rp = p0 >= 0 ? p0 : p1, rq = q0 >= 0 ? q0 : q1;
         if (rp != rq) return 1;
-        return mv_far(p0 >= 0 ? pv0 : pv1, q0 >= 0 ? qv0 : qv1) ? 1 : 0;
+        return mv_far(p0 >= 0 ? pv0 : pv1, q0 >= 0 ? qv0 : qv1, vlim) ? 1 : 0;
     }
     if (!((p0 == q0 && p1 == q1) || (p0 == q1 && p1 == q0))) return 1;
     if (p0 != p1) // two different pictures: each vector against the one that points to the same picture
-        return (p0 == q0 ? (mv_far(pv0, qv0) || mv_far(pv1, qv1)) : (mv_far(pv0, qv1) || mv_far(pv1, qv0))) ? 1 : 0;
-    return ((mv_far(pv0, qv0) || mv_far(pv1, qv1)) && (mv_far(pv0, qv1) || mv_far(pv1, qv0))) ? 1 : 0; // both vectors into one picture
+        return (p0 == q0 ? (mv_far(pv0, qv0, vlim) || mv_far(pv1, qv1, vlim)) : (mv_far(pv0, qv1, vlim) || mv_far(pv1, qv0, vlim))) ? 1 : 0;
+    return ((mv_far(pv0, qv0, vlim) || mv_far(pv1, qv1, vlim)) && (mv_far(pv0, qv1, vlim) || mv_far(pv1, qv0, vlim))) ? 1 : 0; // both vectors into one picture
 }
 
 struct PrepSub {
@@ -786,11 +791,15 @@ extern "C" __global__ void __launch_bounds__(256) k_dbprep(const uint32_t *pic_l
             const bool ok0 = ok && !(mb_edge && !ml), ok1 = ok && !(mb_edge && !mt);
             const MbRec *mp0 = mb_edge && ml ? ml : mq, *mp1 = mb_edge && mt ? mt : mq; // (no neighbour: any record, the result is masked)
             int bs0, bs1;
+            // 8.7.2.1 in a field picture: bS 4 needs a VERTICAL macroblock edge (horizontal ones get 3), and vectors differ from a
+            // vertical distance of 4 quarter FRAME samples on = 2 quarter field samples
+            const bool fieldpic = pd->field != 0;
+            const int vlim = fieldpic ? 2 : 4, strong0 = mb_edge ? 4 : 3, strong1 = mb_edge && !fieldpic ? 4 : 3;
             if (two) {
-                bs0 = prep_bs_b(mp0, mb_edge && ml ? &ss->mv1[1] : &ss->mv1[0], pb0, mq, &ss->mv1[0], qb0, mb_edge);
-                bs1 = prep_bs_b(mp1, mb_edge && mt ? &ss->mv1[2] : &ss->mv1[0], pb1, mq, &ss->mv1[0], qb1, mb_edge);
+                bs0 = prep_bs_b(mp0, mb_edge && ml ? &ss->mv1[1] : &ss->mv1[0], pb0, mq, &ss->mv1[0], qb0, strong0, vlim);
+                bs1 = prep_bs_b(mp1, mb_edge && mt ? &ss->mv1[2] : &ss->mv1[0], pb1, mq, &ss->mv1[0], qb1, strong1, vlim);
             } else
-                bs0 = prep_bs(mp0, pb0, mq, qb0, mb_edge), bs1 = prep_bs(mp1, pb1, mq, qb1, mb_edge);
+                bs0 = prep_bs(mp0, pb0, mq, qb0, strong0, vlim), bs1 = prep_bs(mp1, pb1, mq, qb1, strong1, vlim);
             ss->out.bs[0][e][k] = static_cast<uint8_t>(ok0 ? bs0 : 0);
             ss->out.bs[1][e][k] = static_cast<uint8_t>(ok1 ? bs1 : 0);
             if (li < 9) { // 8.7.2.2: (plane, edge kind): qPav of the left / no / the upper neighbour, indexA / indexB, the table rows

@@ -1608,17 +1608,19 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         e.v_rlps = rl[0] | (rl[1] << 8) | (rl[2] << 16) | (static_cast<uint32_t>(rl[3]) << 24);
         e.v_trans = (static_cast<uint32_t>(tab->trans_lps[l]) << 1) | (l == 0 ? 1u : 0u);
     }
-    e.v_maps = tab->sig8x8[l] | (tab->last8x8[l] << 8) | (tab->zigzag8[l] << 16) | (static_cast<uint32_t>(tab->zigzag4[l & 15]) << 24);
-    e.v_zzac = tab->zigzag4[(l + 1) & 15];
+    // coefficient scans of the picture (8.5.6, 8.5.7): zig-zag, or the field scan in a field picture (h264/slice.go:867-872 field_pic_flag)
+    const uint8_t *scan4 = pd->field ? tab->fieldscan4 : tab->zigzag4, *scan8 = pd->field ? tab->fieldscan8 : tab->zigzag8;
+    e.v_maps = tab->sig8x8[l] | (tab->last8x8[l] << 8) | (scan8[l] << 16) | (static_cast<uint32_t>(scan4[l & 15]) << 24);
+    e.v_zzac = scan4[(l + 1) & 15];
     e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l);
     e.v_qpc = tab->qpc[l < 52 ? l : 51];
     e.v_step = step_word(l);
     e.nzm = e.unm = 0;
     e.aw = e.bw = 0;
     e.v_ipm = 0;
-    sh.posmap[0][l] = tab->zigzag4[l & 15];
-    sh.posmap[1][l] = tab->zigzag4[(l + 1) & 15];
-    sh.posmap[2][l] = tab->zigzag8[l];
+    sh.posmap[0][l] = scan4[l & 15];
+    sh.posmap[1][l] = scan4[(l + 1) & 15];
+    sh.posmap[2][l] = scan8[l];
     sh.posmap[3][l] = static_cast<uint8_t>(l);
     if (l < MI_MAX_REFS) sh.ref_slot[0][l] = sd->ref_slot[l];
 #if MI_ENT_B

@@ -86,9 +86,13 @@ struct InterLds { // per macroblock of the wavefront
 };
 
 // One list's prediction of this lane's block: P[r] = luma row r (4 samples), C[c] = plane c: row 0 in the low half, row 1 in the high half.
-// base: the stream's frame pool; slot: the reference frame; (px, py): the block's luma position; W x H: the picture.
-__device__ __forceinline__ void predict(const g8 *base, uint32_t slot_off, int px, int py, int mvx, int mvy, int W, int H, uint32_t (&P)[4], uint32_t (&C)[2]) {
-    const g8 *ref = base + slot_off;
+// base: the stream's frame pool; loff / coff: byte offset of the reference picture's first luma / Cb row (a field: the first row of its
+// parity); cr_delta: from a Cb sample to the Cr sample at the same place; pitch: bytes from one luma row of the reference picture to the next
+// (chroma: half); (px, py): the block's luma position; W x H: the picture; mvy_c: the vertical vector chroma uses (8.4.1.4: in field pictures it
+// differs from the luma vector by a quarter sample when the reference field has the other parity).
+__device__ __forceinline__ void predict(const g8 *base, uint32_t loff, uint32_t coff, uint32_t cr_delta, uint32_t pitch, int px, int py, int mvx, int mvy, int mvy_c, int W, int H,
+                                        uint32_t (&P)[4], uint32_t (&C)[2]) {
+    const g8 *ref = base + loff;
     // ---------------- luma (8.4.2.2.1): window slot j = row y0 - 2 + j, byte k = column x0 - 2 + k
     {
         const int fx = mvx & 3, fy = mvy & 3, x0 = px + (mvx >> 2), y0 = py + (mvy >> 2);
@@ -119,7 +123,7 @@ __device__ __forceinline__ void predict(const g8 *base, uint32_t slot_off, int p
             const bool row_needed = (j >= 2 && j <= 5) || needV;
             if (row_needed) {
                 const int y = min(max(y0 - 2 + j, 0), H - 1);
-                const g8 *p = ref + static_cast<uint32_t>(y * W + xb);
+                const g8 *p = ref + (static_cast<uint32_t>(y) * pitch + static_cast<uint32_t>(xb));
                 d0[j] = *reinterpret_cast<const g32 *>(p), d1[j] = *reinterpret_cast<const g32 *>(p + 4);
                 if (needH || fix) d2[j] = *reinterpret_cast<const g32 *>(p + 8);
             }
@@ -227,22 +231,22 @@ __device__ __forceinline__ void predict(const g8 *base, uint32_t slot_off, int p
     // ---------------- chroma (8.4.2.2.2): 2x2 samples per plane, 1/8 bilinear
     {
         const int Wc = W >> 1, Hc = H >> 1;
-        const int xf = mvx & 7, yf = mvy & 7, cx = (px >> 1) + (mvx >> 3), cy = (py >> 1) + (mvy >> 3);
+        const int xf = mvx & 7, yf = mvy_c & 7, cx = (px >> 1) + (mvx >> 3), cy = (py >> 1) + (mvy_c >> 3);
         const int xb = min(max(cx, 0), Wc - 4);
         uint32_t sel = 0;
 #pragma unroll
         for (int k = 0; k < 3; k++) sel |= static_cast<uint32_t>(min(max(cx + k, 0), Wc - 1) - xb) << (8 * k); // window byte k <- span byte
         const uint32_t wts = static_cast<uint32_t>((8 - xf) * (8 - yf)) | (static_cast<uint32_t>(xf * (8 - yf)) << 8) | (static_cast<uint32_t>((8 - xf) * yf) << 16) |
                              (static_cast<uint32_t>(xf * yf) << 24);
-        const uint32_t plane = static_cast<uint32_t>(W) * H;
+        const uint32_t cpitch = pitch >> 1;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
-            const g8 *cp = ref + plane + (c ? plane >> 2 : 0u);
+            const g8 *cp = base + coff + (c ? cr_delta : 0u);
             uint32_t w[3];
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 const int y = min(max(cy + j, 0), Hc - 1);
-                w[j] = __builtin_amdgcn_perm(0u, *reinterpret_cast<const g32 *>(cp + static_cast<uint32_t>(y * Wc + xb)), sel);
+                w[j] = __builtin_amdgcn_perm(0u, *reinterpret_cast<const g32 *>(cp + (static_cast<uint32_t>(y) * cpitch + static_cast<uint32_t>(xb))), sel);
             }
             uint32_t o[4];
 #pragma unroll
@@ -307,6 +311,17 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
     const g8 *pool = (const g8 *)pd->pool_base;
     const uint32_t slot_bytes = static_cast<uint32_t>(pd->slot_bytes);
     const int max_slot = static_cast<int>(pd->n_slots) - 1;
+    // the picture's place in its frame slot (PicDesc): a field picture lives in the rows of its parity, and its references are fields
+    const uint32_t pitch = pd->pitch, plane = pd->plane, cr_delta = plane >> 2;
+    const int fld = static_cast<int>(pd->field);
+    const uint32_t fpitch = fld ? pitch >> 1 : 0u; // bytes from a frame row to the next = where the bottom field starts (0: frame picture, no parities)
+    // byte offsets of a reference picture's first luma / Cb row, and the chroma vector offset of Table 8-9 / 8-10 (reference field of the other parity)
+    auto ref_place = [&](int rs, uint32_t &lo, uint32_t &co, int &cadj) {
+        const uint32_t par = fld ? static_cast<uint32_t>(rs >> 14) & 1u : 0u;
+        const uint32_t so = static_cast<uint32_t>(min(max(fld ? MI_REF_SLOT(rs) : rs, 0), max_slot)) * slot_bytes;
+        lo = so + par * fpitch, co = so + plane + par * (fpitch >> 1);
+        cadj = fld ? (static_cast<int>(par) - (fld - 1)) * -2 : 0; // bottom field from a top field: +2; top from bottom: -2
+    };
     // this block's vectors / reference frames
     const uint32_t mvw0 = rw[12 + b];
     const int s0 = static_cast<int>(static_cast<int16_t>(reinterpret_cast<const uint16_t *>(rw)[18 + q8]));   // refslot[q8] (byte 36)
@@ -318,11 +333,21 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
     }
     const bool u1 = B && s1 >= 0, u0 = s0 >= 0 || !u1; // a record without any usable reference is concealed from list 0
     uint32_t P[4] = {0, 0, 0, 0}, C[2] = {0, 0}, P1[4] = {0, 0, 0, 0}, C1[2] = {0, 0};
-    if (inter && u0)
-        predict(pool, static_cast<uint32_t>(min(max(s0, 0), max_slot)) * slot_bytes, px, py, static_cast<int16_t>(mvw0 & 0xFFFFu), static_cast<int>(mvw0) >> 16, W, H, P, C);
+    if (inter && u0) {
+        uint32_t lo, co;
+        int cadj;
+        ref_place(max(s0, 0), lo, co, cadj);
+        const int mvy = static_cast<int>(mvw0) >> 16;
+        predict(pool, lo, co, cr_delta, pitch, px, py, static_cast<int16_t>(mvw0 & 0xFFFFu), mvy, mvy + cadj, W, H, P, C);
+    }
     if (B && __builtin_amdgcn_ballot_w64(inter && u1) != 0) {
-        if (inter && u1)
-            predict(pool, static_cast<uint32_t>(min(s1, max_slot)) * slot_bytes, px, py, static_cast<int16_t>(mvw1 & 0xFFFFu), static_cast<int>(mvw1) >> 16, W, H, P1, C1);
+        if (inter && u1) {
+            uint32_t lo, co;
+            int cadj;
+            ref_place(s1, lo, co, cadj);
+            const int mvy = static_cast<int>(mvw1) >> 16;
+            predict(pool, lo, co, cr_delta, pitch, px, py, static_cast<int16_t>(mvw1 & 0xFFFFu), mvy, mvy + cadj, W, H, P1, C1);
+        }
     }
     // ---- weighting (8.4.2.3) ----
     {
@@ -483,7 +508,7 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
     }
     // ---- reconstruct + store ----
     if (inter) {
-        g8 *dst = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes);
+        g8 *dst = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes) + (fld == 2 ? fpitch : 0u);
         const bool any_l = has_l || has_8;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -491,17 +516,17 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
             if (any_l)
                 v = pack4(clip255(static_cast<int>(v & 255u) + res[4 * r]), clip255(static_cast<int>((v >> 8) & 255u) + res[4 * r + 1]),
                           clip255(static_cast<int>((v >> 16) & 255u) + res[4 * r + 2]), clip255(static_cast<int>(v >> 24) + res[4 * r + 3]));
-            *reinterpret_cast<g32 *>(dst + static_cast<uint32_t>((py + r) * W + px)) = v;
+            *reinterpret_cast<g32 *>(dst + (static_cast<uint32_t>(py + r) * pitch + static_cast<uint32_t>(px))) = v;
         }
-        const uint32_t plane = static_cast<uint32_t>(W) * H;
-        const int Wc = W >> 1;
+        const uint32_t Wc = pitch >> 1;
+        g8 *cdst = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes) + plane + (fld == 2 ? fpitch >> 1 : 0u);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             uint32_t v = C[c];
             if (has_c)
                 v = pack4(clip255(static_cast<int>(v & 255u) + cr[c][0]), clip255(static_cast<int>((v >> 8) & 255u) + cr[c][1]),
                           clip255(static_cast<int>((v >> 16) & 255u) + cr[c][2]), clip255(static_cast<int>(v >> 24) + cr[c][3]));
-            g8 *cp = dst + plane + (c ? plane >> 2 : 0u) + static_cast<uint32_t>(((py >> 1)) * Wc + (px >> 1));
+            g8 *cp = cdst + (c ? cr_delta : 0u) + (static_cast<uint32_t>(py >> 1) * Wc + static_cast<uint32_t>(px >> 1));
             *reinterpret_cast<g16 *>(cp) = static_cast<uint16_t>(v & 0xFFFFu);
             *reinterpret_cast<g16 *>(cp + Wc) = static_cast<uint16_t>(v >> 16);
         }

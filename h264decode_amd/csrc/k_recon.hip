@@ -527,9 +527,12 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra(const 
     const int tid = static_cast<int>(threadIdx.x), lane = tid & 63, wave = tid >> 6;
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
-    const int W = wmb * 16, H = hmb * 16; // the picture's own geometry
-    g8 *py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes);
-    g8 *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
+    // the picture's place in its frame slot (PicDesc): W = bytes from one luma row of the PICTURE to the next -- twice the frame's
+    // for a field picture, which lives in the rows of its parity
+    const int W = static_cast<int>(pd->pitch);
+    const uint32_t par_off = pd->field == 2 ? pd->pitch >> 1 : 0u;
+    g8 *py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes) + par_off;
+    g8 *pcb = py - par_off + pd->plane + (par_off >> 1), *pcr = pcb + (pd->plane >> 2);
     { // LevelScale tables of this picture's PPS -> LDS (2688 bytes)
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&tab->scaling[pd->scaling_set]);
         for (int i = tid; i < static_cast<int>(sizeof(ScalingSet) / 4); i += MI_INTRA_WAVES * 64) reinterpret_cast<uint32_t *>(&sh.sc)[i] = src[i];
@@ -658,9 +661,10 @@ extern "C" __global__ void __launch_bounds__(MI_INTRA_WAVES * 64) k_intra_x(cons
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
     const int r0 = band * hmb / nbands, r1 = (band + 1) * hmb / nbands;
     if (r0 >= r1) return; // (pictures smaller than the launch's largest can leave bands empty)
-    const int W = wmb * 16, H = hmb * 16;
-    g8 *py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes);
-    g8 *pcb = py + static_cast<size_t>(W) * H, *pcr = pcb + static_cast<size_t>(W) * H / 4;
+    const int W = static_cast<int>(pd->pitch); // (see k_intra)
+    const uint32_t par_off = pd->field == 2 ? pd->pitch >> 1 : 0u;
+    g8 *py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes) + par_off;
+    g8 *pcb = py - par_off + pd->plane + (par_off >> 1), *pcr = pcb + (pd->plane >> 2);
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&tab->scaling[pd->scaling_set]);
         for (int i = tid; i < static_cast<int>(sizeof(ScalingSet) / 4); i += nthreads) reinterpret_cast<uint32_t *>(&sh.sc)[i] = src[i];

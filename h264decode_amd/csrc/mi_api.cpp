@@ -11,6 +11,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -57,6 +58,8 @@ static void build_tables(DevTables *t) {
     memcpy(t->last8x8, mi_last8x8_ctx, 63);
     memcpy(t->zigzag4, mi_zigzag4x4, 16);
     memcpy(t->zigzag8, mi_zigzag8x8, 64);
+    memcpy(t->fieldscan4, mi_fieldscan4x4, 16);
+    memcpy(t->fieldscan8, mi_fieldscan8x8, 64);
     memcpy(t->me_intra, mi_me_intra, 48);
     memcpy(t->me_inter, mi_me_inter, 48);
     memcpy(t->alpha, mi_alpha, 52);
@@ -118,12 +121,21 @@ struct Slot {
     // batch still holds the samples earlier pictures of the batch predict from.)
     bool held = false;
     bool nonexisting = false; // a frame inferred by the gaps-in-frame_num process (8.2.5.2): a place in the window, no picture
-    int pic = -1; // index into the PicDesc table of the batch being prepared, -1: decoded by an earlier batch
+    int pic = -1; // index into the PicDesc table of the batch being prepared, -1: decoded by an earlier batch (field-coded frames: fpic[])
+    // Fields (h264/slice.go:867-872 field_pic_flag / bottom_field_flag; h264/sps.go:316-322).  A frame slot holds both fields of a frame, however
+    // they were coded: a frame picture fills both at once (fields = 3), a field picture the rows of its parity.
+    int fields = 0;          // decoded fields: bit 0 top, bit 1 bottom
+    int funref = 0;          // fields taken out of the reference set one by one (memory_management_control_operation 1 in a field picture, 8.2.5.4.1)
+    int fpoc[2] = {0, 0};    // PicOrderCnt of the top / bottom field (8.2.1); `poc` is the frame's: the smaller one, or that of the only field there is
+    int fpic[2] = {-1, -1};  // PicDesc of the field pictures decoded by the batch being prepared
+    bool field_coded = false;          // coded as field pictures (direct prediction needs a co-located picture of the same structure as the current one)
+    bool col_valid[2] = {false, false}; // the ColRec array of the frame / top field [0], the bottom field [1] holds this picture's motion
 };
 struct OutFrame { // a decoded picture of the current batch, with the geometry it was coded with
     int slot, wmb, hmb, crop_x, crop_y, width, height;
     int poc, frame_num, nal_ref_idc, idr, pic;
     int new_sequence; // IDR picture or memory_management_control_operation 5: picture order counts start over
+    int pic2 = -1;    // a frame coded as two field pictures: `pic` / `pic2` are the first / second field's PicDesc (-1: decoded by an earlier batch, or never)
 };
 struct StreamState {
     h264mi_sps sps[32];
@@ -137,9 +149,18 @@ struct StreamState {
     std::vector<Slot> slots;
     int prev_poc_msb = 0, prev_poc_lsb = 0, prev_frame_num = 0, prev_frame_num_offset = 0;
     int top_above_poc = 0; // TopFieldOrderCnt - PicOrderCnt of the picture compute_poc() was last asked about (> 0: its bottom field comes first)
+    int poc_top = 0, poc_bot = 0; // TopFieldOrderCnt / BottomFieldOrderCnt of that picture (a field picture: both its one count)
     int prev_ref_frame_num = 0; // PrevRefFrameNum (7.4.3): frame_num of the previous reference picture; 0 after an IDR picture or operation 5
     // picture under construction
     int cur_slot = -1, cur_pic = -1, cur_slices = 0;
+    int cur_field = 0;        // the picture under construction is 0 a frame, 1 a top field, 2 a bottom field
+    bool cur_second = false;  // ... and the second field of its frame (it may predict from the first one)
+    // A frame whose first field has been decoded waits here for its second field (the next picture, if it is a field of the other parity
+    // with the same frame_num, 7.4.1.2.4 / 3.30); it goes out -- once -- when that field is complete, or with one field decoded (the rows of
+    // the other one mid-grey) when something else follows: another picture, an end-of-sequence / end-of-stream NAL unit, a reset.  The wait
+    // may span a batch boundary.
+    int pend_slot = -1;
+    OutFrame pend_out;
     h264mi_slice_header first_sh;
     int n_pics_in_batch = 0;
     int status = H264MI_OK; // of this stream in the current batch (h264mi_stream_status)
@@ -158,6 +179,8 @@ struct Stage {
     size_t bits_used = 0;
     size_t map_cursor = 0, bits_end = 0; // slice group maps of FMO pictures follow the slices in the staging buffer; bits_end: what must be uploaded
     std::vector<uint32_t> fmo_pics;      // pictures whose records are zeroed before the entropy kernels run
+    struct GreyFill { uint32_t stream, slot, parity, w, h; }; // a frame that went out with one field decoded: the rows of the other parity are painted mid-grey
+    std::vector<GreyFill> grey;
     std::vector<uint32_t> epochs;        // StreamState::epoch of every stream when this batch was prepared
     SliceDesc *d_slices = nullptr, *h_slices = nullptr;
     PicDesc *d_pics = nullptr, *h_pics = nullptr;
@@ -215,6 +238,7 @@ struct h264mi_decoder {
     hipEvent_t ev_user = nullptr;
     hipEvent_t ev_ent[MI_SETS] = {}, ev_rec[MI_SETS] = {}, ev_col[MI_SETS] = {};
     uint64_t pass = 0; // execute() counter
+    int last_exec_stage = -1, last_exec_set = 0; // staging set and record set of the most recent execute (ensure_b_buffers)
     bool last_pass_had_b = false;
     uint64_t mb_cap = 0;
     uint64_t dev_bytes = 0;              // device memory this decoder holds (h264mi_decoder_memory)
@@ -363,8 +387,20 @@ static void free_all(h264mi_decoder *d) {
     if (d->own_stream && d->stream) hipStreamDestroy(d->stream);
 }
 
-extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decoder **out) {
-    if (!cfg || !out || cfg->max_streams < 1 || cfg->max_width < 16 || cfg->max_height < 16 || cfg->max_frames_per_batch < 1) return H264MI_EINVAL;
+static int ensure_b_buffers(h264mi_decoder *d);
+
+extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg_, h264mi_decoder **out) {
+    if (!cfg_ || !out) return H264MI_EINVAL;
+    // the caller's struct may be shorter (an older header) or longer (a newer one) than this build's: fields beyond either end are 0
+    if (cfg_->struct_size < offsetof(h264mi_config, max_ref_frames) || cfg_->struct_size > 4096) {
+        set_error("h264mi_decoder_create: h264mi_config.struct_size = %u (set it to sizeof(h264mi_config); the struct must be zero-initialised)", cfg_->struct_size);
+        return H264MI_EINVAL;
+    }
+    h264mi_config cfg_copy;
+    memset(&cfg_copy, 0, sizeof(cfg_copy));
+    memcpy(&cfg_copy, cfg_, std::min<size_t>(cfg_->struct_size, sizeof(cfg_copy)));
+    const h264mi_config *cfg = &cfg_copy;
+    if (cfg->max_streams < 1 || cfg->max_width < 16 || cfg->max_height < 16 || cfg->max_frames_per_batch < 1) return H264MI_EINVAL;
     int r = h264mi_init(cfg->device);
     if (r != H264MI_OK) return r;
     h264mi_decoder *d = new h264mi_decoder();
@@ -381,6 +417,11 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     // MI_STAGES batches are in flight), up to 16 reference pictures, and the picture under construction
     if (d->cfg.max_ref_frames < 1 || d->cfg.max_ref_frames > MI_MAX_REFS) d->cfg.max_ref_frames = MI_MAX_REFS;
     d->n_slots = MI_STAGES * cfg->max_frames_per_batch + d->cfg.max_ref_frames + 1;
+    if (d->n_slots >= MI_REF_PARITY) { // (reference entries of field pictures keep the field's parity in bit 14 of the slot number)
+        set_error("h264mi_decoder_create: max_frames_per_batch %d is too large (at most %d)", cfg->max_frames_per_batch, (MI_REF_PARITY - 18) / MI_STAGES);
+        delete d;
+        return H264MI_EINVAL;
+    }
     d->slot_bytes = (static_cast<size_t>(d->Wmax) * d->Hmax * 3 / 2 + 255) & ~static_cast<size_t>(255);
     const int S = cfg->max_streams;
     d->st.resize(S);
@@ -530,6 +571,14 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg, h264mi_decode
     TRY_ALLOC(hipStreamSynchronize(d->stream));
 #undef TRY_ALLOC
 #undef DEV_ALLOC
+    if (d->cfg.b_pictures) { // the caller expects B pictures: their buffers now, motion kept from the first picture on
+        r = ensure_b_buffers(d);
+        if (r != H264MI_OK) {
+            free_all(d);
+            delete d;
+            return r;
+        }
+    }
     *out = d;
     return H264MI_OK;
 }
@@ -558,6 +607,7 @@ static void reset_stream(StreamState &s, bool keep_parameter_sets) {
     for (auto &sl : s.slots) sl = Slot();
     s.epoch++;
     s.cur_slot = s.cur_pic = -1, s.cur_slices = 0;
+    s.cur_field = 0, s.cur_second = false, s.pend_slot = -1;
     s.n_pics_in_batch = 0;
     s.prev_poc_msb = s.prev_poc_lsb = s.prev_frame_num = s.prev_frame_num_offset = s.prev_ref_frame_num = 0;
     if (!keep_parameter_sets) {
@@ -626,9 +676,10 @@ static int compute_poc(StreamState &s, const h264mi_sps &sps, const h264mi_slice
             msb = prev_msb - max_lsb;
         else
             msb = prev_msb;
-        int top = msb + sh.pic_order_cnt_lsb;
-        poc = std::min(top, top + sh.delta_pic_order_cnt_bottom);
+        const int top = msb + sh.pic_order_cnt_lsb, bot = top + sh.delta_pic_order_cnt_bottom; // (8-4 / 8-5: a field picture has the one count, delta is 0)
+        poc = std::min(top, bot);
         s.top_above_poc = top - poc;
+        s.poc_top = top, s.poc_bot = bot;
         if (sh.nal_ref_idc) s.prev_poc_msb = msb, s.prev_poc_lsb = sh.pic_order_cnt_lsb;
     } else {
         int fno = idr ? 0 : (s.prev_frame_num > sh.frame_num ? s.prev_frame_num_offset + max_fn : s.prev_frame_num_offset);
@@ -644,23 +695,146 @@ static int compute_poc(StreamState &s, const h264mi_sps &sps, const h264mi_slice
                 for (int i = 0; i <= in_cyc; i++) expected += sps.offset_for_ref_frame_list[i];
             }
             if (!sh.nal_ref_idc) expected += sps.offset_for_non_ref_pic;
-            int top = expected + sh.delta_pic_order_cnt[0];
-            poc = std::min(top, top + sps.offset_for_top_to_bottom_field + sh.delta_pic_order_cnt[1]);
-        } else
+            const int top = expected + sh.delta_pic_order_cnt[0], bot = top + sps.offset_for_top_to_bottom_field + sh.delta_pic_order_cnt[1];
+            if (sh.field_pic) // 8-10: a bottom field is at expected + offset_for_top_to_bottom_field + delta_pic_order_cnt[0]
+                poc = sh.bottom_field ? expected + sps.offset_for_top_to_bottom_field + sh.delta_pic_order_cnt[0] : top, s.poc_top = s.poc_bot = poc;
+            else
+                poc = std::min(top, bot), s.poc_top = top, s.poc_bot = bot;
+        } else {
             poc = idr ? 0 : (sh.nal_ref_idc ? 2 * (fno + sh.frame_num) : 2 * (fno + sh.frame_num) - 1);
+            s.poc_top = s.poc_bot = poc;
+        }
         s.prev_frame_num_offset = fno;
     }
     s.prev_frame_num = sh.frame_num;
     return poc;
 }
 
+// 8.2.4 for a field picture (8.2.4.2.2 / 8.2.4.2.4 + 8.2.4.2.5, modification 8.2.4.3 with the field picture numbers of 8.2.4.1): the lists hold
+// FIELDS, written as frame slot | parity << 14 (MI_REF_PARITY).  The reference frames are put in order first -- P: by FrameNumWrap, the frame
+// of the current field included when this is its second field and the first one is a reference; B: by PicOrderCnt around the current field,
+// list 0 the earlier ones nearest first and then the later ones, list 1 the other way round; long-term frames by LongTermFrameIdx --, then
+// their fields are taken alternately, the parity of the current field first; a frame that lacks the wanted field is passed over, and when one
+// parity is used up the rest of the other one follows in order.
+static int build_ref_lists_field(StreamState &s, const h264mi_sps &sps, const h264mi_slice_header &sh, bool bslice, int16_t *out0, int16_t *out1) {
+    const int max_fn = 1 << (sps.log2_max_frame_num_minus4 + 4);
+    const int bottom = sh.bottom_field ? 1 : 0;
+    auto usable = [&](int slot, int par) { return ((s.slots[slot].fields & ~s.slots[slot].funref) >> par) & 1; };
+    std::vector<int> st, lt;
+    for (int i = 0; i < static_cast<int>(s.slots.size()); i++) {
+        Slot &sl = s.slots[i];
+        if (i == s.cur_slot && !(s.cur_second && sl.ref == 1)) continue; // (a second field may predict from the first field of its frame)
+        if (sl.ref == 1) {
+            sl.frame_num_wrap = sl.frame_num > sh.frame_num ? sl.frame_num - max_fn : sl.frame_num;
+            st.push_back(i);
+        } else if (sl.ref == 2)
+            lt.push_back(i);
+    }
+    std::sort(lt.begin(), lt.end(), [&](int a, int b) { return s.slots[a].long_idx < s.slots[b].long_idx; });
+    if (st.empty() && lt.empty()) {
+        set_error("P/B slice without reference pictures");
+        return H264MI_EBITSTREAM;
+    }
+    std::vector<int> ord[2];
+    if (!bslice) {
+        std::sort(st.begin(), st.end(), [&](int a, int b) { return s.slots[a].frame_num_wrap > s.slots[b].frame_num_wrap; });
+        ord[0] = st;
+    } else {
+        // PicOrderCnt of a reference frame here: the smaller of its fields' (Slot::poc); of the current frame (second field): its first field's
+        const int cur_poc = s.slots[s.cur_slot].fpoc[bottom];
+        std::vector<std::pair<int, int>> before, after; // (PicOrderCnt, slot)
+        for (int i : st) {
+            if (s.slots[i].nonexisting) continue;
+            const int fp = i == s.cur_slot ? s.slots[i].fpoc[!bottom] : s.slots[i].poc;
+            (fp <= cur_poc ? before : after).push_back({fp, i});
+        }
+        std::stable_sort(before.begin(), before.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first > b.first; });
+        std::stable_sort(after.begin(), after.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first < b.first; });
+        for (auto &e : before) ord[0].push_back(e.second);
+        for (auto &e : after) ord[0].push_back(e.second), ord[1].push_back(e.second);
+        for (auto &e : before) ord[1].push_back(e.second);
+    }
+    std::vector<int> lists[2];
+    for (int l = 0; l < (bslice ? 2 : 1); l++)
+        for (int grp = 0; grp < 2; grp++) { // short-term frames, then long-term frames: each group alternates on its own
+            const std::vector<int> &fr = grp ? lt : ord[l];
+            const int nfr = static_cast<int>(fr.size());
+            int a = 0, b = 0; // next frame to look at for the same / the opposite parity
+            for (int want_same = 1;; want_same ^= 1) {
+                int &cursor = want_same ? a : b;
+                const int par = want_same ? bottom : !bottom;
+                while (cursor < nfr && !usable(fr[cursor], par)) cursor++;
+                if (cursor == nfr) { // this parity is used up: the rest of the other one
+                    int &other = want_same ? b : a;
+                    for (; other < nfr; other++)
+                        if (usable(fr[other], !par)) lists[l].push_back(fr[other] | (!par ? MI_REF_PARITY : 0));
+                    break;
+                }
+                lists[l].push_back(fr[cursor] | (par ? MI_REF_PARITY : 0));
+                cursor++;
+            }
+        }
+    if (bslice && lists[1].size() > 1 && lists[1] == lists[0]) std::swap(lists[1][0], lists[1][1]);
+    const int max_pic_num = 2 * max_fn, cur_pic_num = 2 * sh.frame_num + 1; // 8.2.4.1: MaxPicNum, CurrPicNum of a field
+    for (int l = 0; l < (bslice ? 2 : 1); l++) {
+        std::vector<int> &list = lists[l];
+        const int nact = (l ? sh.num_ref_idx_l1_active_minus1 : sh.num_ref_idx_l0_active_minus1) + 1;
+        if (nact > MI_MAX_REFS) {
+            set_error("num_ref_idx_l%d_active %d > %d reference fields is out of scope", l, nact, MI_MAX_REFS);
+            return H264MI_EUNSUPPORTED;
+        }
+        list.resize(nact, -1);
+        list.resize(nact + 1, -1);
+        const int32_t *idcs = l ? sh.modification_of_pic_nums_l1 : sh.modification_of_pic_nums, *vals = l ? sh.modification_value_l1 : sh.modification_value;
+        const int nmod = l ? sh.n_ref_pic_list_modifications_l1 : sh.n_ref_pic_list_modifications;
+        if (l ? sh.ref_pic_list_modification_flag_l1 : sh.ref_pic_list_modification_flag_l0) { // 8.2.4.3 on field picture numbers
+            int pred = cur_pic_num, idx = 0;
+            for (int k = 0; k < nmod && idx < nact; k++) {
+                int target = -1;
+                if (idcs[k] < 2) {
+                    const int diff = vals[k] + 1;
+                    if (idcs[k] == 0) {
+                        pred -= diff;
+                        if (pred < 0) pred += max_pic_num;
+                    } else {
+                        pred += diff;
+                        if (pred >= max_pic_num) pred -= max_pic_num;
+                    }
+                    const int picnum = pred > cur_pic_num ? pred - max_pic_num : pred;
+                    for (int i : st)
+                        for (int par = 0; par < 2; par++) // picNumF: 2 * FrameNumWrap + 1 for a field of the current parity, 2 * FrameNumWrap for the other
+                            if (usable(i, par) && 2 * s.slots[i].frame_num_wrap + (par == bottom) == picnum) target = i | (par ? MI_REF_PARITY : 0);
+                } else
+                    for (int i : lt)
+                        for (int par = 0; par < 2; par++)
+                            if (usable(i, par) && 2 * s.slots[i].long_idx + (par == bottom) == vals[k]) target = i | (par ? MI_REF_PARITY : 0);
+                if (target < 0) {
+                    set_error("ref_pic_list_modification names a missing field");
+                    return H264MI_EBITSTREAM;
+                }
+                for (int c = nact; c > idx; c--) list[c] = list[c - 1];
+                list[idx++] = target;
+                int nidx = idx;
+                for (int c = idx; c <= nact; c++)
+                    if (list[c] != target) list[nidx++] = list[c];
+            }
+        }
+        int16_t *out = l ? out1 : out0;
+        for (int i = 0; i < MI_MAX_REFS; i++) out[i] = static_cast<int16_t>(i < nact ? list[i] : -1);
+    }
+    return H264MI_OK;
+}
+
 // 8.2.4: RefPicList0 (P and B slices) and RefPicList1 (B slices) as frame-pool slots
 static int build_ref_lists(StreamState &s, const h264mi_sps &sps, const h264mi_slice_header &sh, bool bslice, int16_t *out0 /*MI_MAX_REFS*/, int16_t *out1) {
+    if (sh.field_pic) return build_ref_lists_field(s, sps, sh, bslice, out0, out1);
     const int max_fn = 1 << (sps.log2_max_frame_num_minus4 + 4);
     std::vector<int> st, lt;
     for (int i = 0; i < static_cast<int>(s.slots.size()); i++) {
         Slot &sl = s.slots[i];
         if (i == s.cur_slot) continue;
+        // 8.2.4.2.1: a frame picture predicts from frames (or complementary field pairs) of which BOTH fields are reference fields
+        if (sl.ref && (sl.fields != 3 || sl.funref)) continue;
         if (sl.ref == 1) {
             sl.frame_num_wrap = sl.frame_num > sh.frame_num ? sl.frame_num - max_fn : sl.frame_num;
             sl.pic_num = sl.frame_num_wrap;
@@ -748,11 +922,32 @@ static void mark_reference(StreamState &s, const h264mi_sps &sps) {
     const h264mi_slice_header &sh = s.first_sh;
     Slot &cur = s.slots[s.cur_slot];
     const int max_fn = 1 << (sps.log2_max_frame_num_minus4 + 4);
+    if (sh.nal_ref_idc) s.prev_ref_frame_num = sh.frame_num; // (operation 5 below: 0)
+    if (s.cur_field && sh.nal_ref_idc && sh.nal_unit_type != 5 && sh.adaptive_ref_pic_marking_mode_flag) {
+        // 8.2.5.4.1 in a field picture: picNumX names a FIELD (8.2.4.1); the frame stays in the window while its other field is a reference.
+        // (operations 2..6 on fields were refused when the picture started)
+        const int bottom = s.cur_field == 2, cur_pic_num = 2 * sh.frame_num + 1;
+        for (int k = 0; k < sh.n_memory_management_control_operations; k++) {
+            const int picnum = cur_pic_num - (sh.mmco_arg1[k] + 1);
+            for (auto &sl : s.slots) {
+                if (sl.ref != 1) continue;
+                const int wrap = sl.frame_num > sh.frame_num ? sl.frame_num - max_fn : sl.frame_num;
+                for (int par = 0; par < 2; par++)
+                    if ((((sl.fields & ~sl.funref) >> par) & 1) && 2 * wrap + (par == bottom) == picnum) {
+                        sl.funref |= 1 << par;
+                        if (!(sl.fields & ~sl.funref)) sl.ref = 0; // (the current frame, whose other field is being decoded, is marked just below)
+                    }
+            }
+        }
+        cur.ref = 1;
+        return;
+    }
+    // 8.2.5.3: the second field of a frame whose first field is a reference joins it; nothing leaves the window
+    if (s.cur_field && s.cur_second && cur.ref) return;
     if (!sh.nal_ref_idc) {
         cur.ref = 0;
         return;
     }
-    s.prev_ref_frame_num = sh.frame_num; // (operation 5 below: 0)
     if (sh.nal_unit_type == 5) {
         for (auto &sl : s.slots) sl.ref = 0;
         cur.ref = sh.long_term_reference_flag ? 2 : 1;
@@ -787,6 +982,10 @@ static void mark_reference(StreamState &s, const h264mi_sps &sps) {
                 for (auto &sl : s.slots)
                     if (&sl != &cur) sl.ref = 0;
                 cur.frame_num = 0, cur.poc = 0; // 8.2.1: tempPicOrderCnt is subtracted, the picture ends up at PicOrderCnt 0
+                {
+                    const int m = std::min(cur.fpoc[0], cur.fpoc[1]);
+                    cur.fpoc[0] -= m, cur.fpoc[1] -= m;
+                }
                 s.prev_frame_num = s.prev_frame_num_offset = s.prev_poc_msb = s.prev_ref_frame_num = 0;
                 // 8.2.1.1: prevPicOrderCntLsb = TopFieldOrderCnt after tempPicOrderCnt was subtracted -- 0 unless the bottom field is the earlier one
                 s.prev_poc_lsb = sps.pic_order_count_type == 0 ? s.top_above_poc : 0;
@@ -818,7 +1017,22 @@ static void finish_picture(h264mi_decoder *d, int si) {
     mark_reference(s, s.sps[s.active_sps]);
     PicDesc &pd = g.h_pics[s.cur_pic];
     pd.n_slices = static_cast<uint32_t>(s.cur_slices);
-    if (!g.out[si].empty()) g.out[si].back().poc = s.slots[s.cur_slot].poc; // operation 5 rewrites it
+    if (s.cur_field) {
+        // a field: the frame goes out when its second field is complete -- or, if that never comes, when the next picture starts (flush_pending_field)
+        Slot &cur = s.slots[s.cur_slot];
+        cur.fields |= 1 << (s.cur_field - 1);
+        if (cur.fields == 3) {
+            cur.poc = std::min(cur.fpoc[0], cur.fpoc[1]);
+            s.pend_out.poc = cur.poc;
+            if (s.cur_second) s.pend_out.pic2 = s.cur_pic;
+            g.out[si].push_back(s.pend_out);
+            s.pend_slot = -1;
+        } else {
+            cur.poc = cur.fpoc[s.cur_field - 1];
+            s.pend_slot = s.cur_slot;
+        }
+    } else if (!g.out[si].empty())
+        g.out[si].back().poc = s.slots[s.cur_slot].poc; // operation 5 rewrites it
     // Every macroblock of the picture belongs to exactly one slice wavefront (SliceDesc::fill_from / end_mb): order the
     // slices by first_mb (arbitrary slice order is legal in Baseline); a slice's range ends where the next one starts.
     std::vector<uint32_t> idx(pd.n_slices);
@@ -846,6 +1060,20 @@ static void finish_picture(h264mi_decoder *d, int si) {
             sd.end_mb = i + 1 < pd.n_slices ? std::max(g.h_slices[idx[i + 1]].first_mb, sd.first_mb) : total;
         }
     s.cur_slot = s.cur_pic = -1;
+}
+
+// A first field whose second field did not come: the frame goes out with one field decoded, the rows of the other parity painted mid-grey
+// (at the start of the batch's reconstruction: whatever the slot held before must not show)
+static void flush_pending_field(h264mi_decoder *d, int si) {
+    StreamState &s = d->st[si];
+    if (s.pend_slot < 0) return;
+    Stage &g = d->stage[d->prep];
+    const Slot &f = s.slots[s.pend_slot];
+    OutFrame o = s.pend_out;
+    o.poc = f.poc;
+    g.out[si].push_back(o);
+    g.grey.push_back({static_cast<uint32_t>(si), static_cast<uint32_t>(s.pend_slot), f.fields == 1 ? 1u : 0u, static_cast<uint32_t>(o.wmb * 16), static_cast<uint32_t>(o.hmb * 16)});
+    s.pend_slot = -1;
 }
 
 static bool new_picture(const h264mi_sps &sps, const h264mi_slice_header &a, const h264mi_slice_header &b) { // 7.4.1.2.4
@@ -919,7 +1147,7 @@ static int fill_frame_num_gap(h264mi_decoder *d, int si, const h264mi_sps &sps, 
             return H264MI_ECAPACITY;
         }
         *slot = Slot();
-        slot->ref = 1, slot->nonexisting = true, slot->frame_num = fn;
+        slot->ref = 1, slot->nonexisting = true, slot->frame_num = fn, slot->fields = 3;
         if (sps.pic_order_count_type != 0) { // 8.2.1: as a reference frame with this frame_num (keeps FrameNumOffset right across a wrap)
             h264mi_slice_header f;
             memset(&f, 0, sizeof(f));
@@ -947,29 +1175,45 @@ static int ensure_b_buffers(h264mi_decoder *d) {
             d->dev_bytes += sizeof(MbMv1) * d->mb_cap;
         }
     if (d->d_colrec) return H264MI_OK;
+    // allocate, initialise, and only then publish: a failure half-way must not leave an array behind that the next call takes for ready
     const size_t S = d->st.size(), bytes = sizeof(ColRec) * d->colrec_per_slot * d->n_slots * S;
-    hipError_t e = hipMalloc(&d->d_colrec, bytes);
-    if (e == hipSuccess) e = hipMalloc(&d->d_backfill, sizeof(uint32_t) * d->pics_cap);
+    ColRec *colrec = nullptr;
+    uint32_t *backfill = nullptr;
+    hipError_t e = hipMalloc(&colrec, bytes);
+    if (e == hipSuccess) e = hipMalloc(&backfill, sizeof(uint32_t) * d->pics_cap);
+    hipStream_t up = d->ent_stream[d->pass & 1];
+    if (e == hipSuccess) e = hipMemsetAsync(colrec, 0xFF, bytes, up); // refslot / ref -1 everywhere: "intra" (never read: Slot::col_valid guards every use)
     if (e != hipSuccess) {
-        set_error("hipMalloc of the co-located motion arrays failed: %s", hipGetErrorString(e));
+        if (colrec) hipFree(colrec);
+        if (backfill) hipFree(backfill);
+        set_error("setting up the co-located motion arrays failed: %s", hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? H264MI_ENOMEM : H264MI_EDEVICE;
     }
+    d->d_colrec = colrec, d->d_backfill = backfill;
     d->dev_bytes += bytes + sizeof(uint32_t) * d->pics_cap;
-    hipStream_t up = d->ent_stream[d->pass & 1];
-    HIP_TRY(hipMemsetAsync(d->d_colrec, 0xFF, bytes, up)); // refslot / ref -1 everywhere: "intra" until a picture writes its own
+    // The reference pictures of the batch executed last -- where RefPicList1[0] of a stream's first B picture can still come from -- get their
+    // ColRec arrays now, from that batch's records: only if that batch is the one prepared before this one, its record set is known, and it has
+    // FINISHED (its descriptor table is rewritten here; a pass still in flight would read it).  Anything older stays without (col_valid).
     Stage &pv = d->stage[(d->prep + MI_STAGES - 1) % MI_STAGES];
-    if (MI_STAGES > 1 && pv.executed && d->pass > 0) {
+    if (MI_STAGES > 1 && pv.executed && d->pass > 0 && d->last_exec_stage == (d->prep + MI_STAGES - 1) % MI_STAGES) {
+        HIP_TRY(hipEventSynchronize(pv.ev_done)); // once per decoder
         std::vector<uint32_t> list;
+        auto want = [&](size_t si, const OutFrame &o, int pic, int par) {
+            if (pic < 0 || pic >= pv.n_pics) return;
+            Slot &sl = d->st[si].slots[o.slot];
+            pv.h_pics[pic].save_col = 1;
+            pv.h_pics[pic].col_out = reinterpret_cast<uint64_t>(d->d_colrec + (si * d->n_slots + o.slot) * d->colrec_per_slot + (par ? d->colrec_per_slot / 2 : 0));
+            sl.col_valid[par] = true;
+            list.push_back(static_cast<uint32_t>(pic));
+        };
         for (size_t si = 0; si < S; si++)
             for (const OutFrame &o : pv.out[si])
-                if (d->st[si].slots[o.slot].ref && o.pic >= 0 && o.pic < pv.n_pics) { // still a reference picture: a B picture may point at it
-                    pv.h_pics[o.pic].save_col = 1;
-                    pv.h_pics[o.pic].col_out = reinterpret_cast<uint64_t>(d->d_colrec + (si * d->n_slots + o.slot) * d->colrec_per_slot);
-                    list.push_back(static_cast<uint32_t>(o.pic));
+                if (d->st[si].slots[o.slot].ref) { // still a reference picture: a B picture may point at it
+                    for (int pic : {o.pic, o.pic2})
+                        if (pic >= 0 && pic < pv.n_pics) want(si, o, pic, pv.h_pics[pic].field == 2 ? 1 : 0);
                 }
         if (!list.empty()) {
-            const int pset = static_cast<int>((d->pass - 1) % MI_SETS);
-            HIP_TRY(hipStreamWaitEvent(up, d->ev_ent[pset], 0)); // that batch's records are complete
+            const int pset = d->last_exec_set;
             HIP_TRY(hipMemcpyAsync(pv.d_pics, pv.h_pics, sizeof(PicDesc) * pv.n_pics, hipMemcpyHostToDevice, up));
             HIP_TRY(hipMemcpyAsync(d->d_backfill, list.data(), sizeof(uint32_t) * list.size(), hipMemcpyHostToDevice, up));
             HIP_TRY(hipStreamSynchronize(up)); // (`list` is pageable host memory; once per decoder)
@@ -1022,18 +1266,36 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         set_error("stream %d: only 4:2:0 8-bit streams are supported (chroma_format_idc %d)", si, sps.chroma_format);
         return H264MI_EUNSUPPORTED;
     }
-    // frame_mbs_only_flag = 0 (h264/sps.go:316-322) is fine as long as the pictures are frames and macroblock-adaptive frame/field
-    // coding is off: such a picture decodes like a progressive one (map units are two macroblock rows high, crop units double).
-    // Field pictures (h264/slice.go:867-872) and MBAFF (h264/slice.go:563-568, 624-634) are not implemented.
-    if (!sps.frame_mbs_only && (sps.mb_adaptive_frame_field || sh.field_pic)) {
-        set_error("stream %d: %s is out of scope", si, sh.field_pic ? "a field picture (PAFF)" : "macroblock-adaptive frame/field coding (MBAFF)");
+    // frame_mbs_only_flag = 0 (h264/sps.go:316-322): the pictures are frames (decoded like progressive ones: map units are two macroblock rows
+    // high, crop units double) or field pictures (h264/slice.go:867-872: field_pic_flag / bottom_field_flag; PAFF), in any mix.
+    // Macroblock-adaptive frame/field coding (MBAFF, h264/slice.go:563-568, 624-634) is not implemented.
+    if (!sps.frame_mbs_only && sps.mb_adaptive_frame_field) {
+        set_error("stream %d: macroblock-adaptive frame/field coding (MBAFF) is out of scope", si);
         return H264MI_EUNSUPPORTED;
+    }
+    if (sh.field_pic) {
+        if (pps.entropy_coding_mode) {
+            // ctxIdx 277..398 and 436..459 (significant_coeff_flag / last_significant_coeff_flag of field-coded blocks, Tables 9-19 .. 9-24): their
+            // initialisation values are not in this library's tables -- nothing in this repository or on its build machine pins them -- and a
+            // decoder with guessed tables would produce plausible, wrong pictures
+            set_error("stream %d: field pictures with CABAC are refused: the context initialisation values of field-coded blocks (ctxIdx 277-398, 436-459) are not "
+                      "in this library's tables; CAVLC field pictures are decoded", si);
+            return H264MI_EUNSUPPORTED;
+        }
+        if (ref_idc && type != 5 && sh.adaptive_ref_pic_marking_mode_flag)
+            for (int k = 0; k < sh.n_memory_management_control_operations; k++)
+                if (sh.memory_management_control_operation[k] != 1) {
+                    set_error("stream %d: memory_management_control_operation %d in a field picture is out of scope (operation 1 is implemented)", si,
+                              sh.memory_management_control_operation[k]);
+                    return H264MI_EUNSUPPORTED;
+                }
     }
     if (sps.max_num_ref_frames > d->cfg.max_ref_frames) {
         set_error("stream %d: max_num_ref_frames %d exceeds the configured max_ref_frames %d", si, sps.max_num_ref_frames, d->cfg.max_ref_frames);
         return H264MI_ECAPACITY;
     }
-    const int wmb = sps.pic_width_in_mbs, hmb = sps.pic_height_in_mbs;
+    const int wmb = sps.pic_width_in_mbs, hmb = sps.pic_height_in_mbs; // of the frame
+    const int hmb_pic = sh.field_pic ? hmb / 2 : hmb;                   // of this picture (h264/slice.go:159-176 PicHeightInMbs)
     if (wmb * 16 > d->Wmax || hmb * 16 > d->Hmax || hmb > 320) {
         set_error("stream %d: %dx%d exceeds the configured maximum %dx%d", si, wmb * 16, hmb * 16, d->Wmax, d->Hmax);
         return H264MI_ECAPACITY;
@@ -1049,23 +1311,37 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
             set_error("stream %d: picture size changes without an IDR", si);
             return H264MI_EBITSTREAM;
         }
+        flush_pending_field(d, si); // (a lone first field of the old sequence goes out before anything of the new one)
         s.active_sps = pps.sps_id, s.wmb = wmb, s.hmb = hmb;
     }
     if (s.cur_slot < 0) { // first slice of a new picture
-        r = fill_frame_num_gap(d, si, sps, sh);
-        if (r != H264MI_OK) return r;
+        // the second field of the frame whose first field was the previous picture (7.4.1.2.4, 3.30 / 3.31): opposite parity, same frame_num, not
+        // an IDR picture, reference or not like the first one
+        bool second = false;
+        if (s.pend_slot >= 0) {
+            const Slot &f = s.slots[s.pend_slot];
+            if (sh.field_pic && type != 5 && f.fields == (sh.bottom_field ? 1 : 2) && f.frame_num == sh.frame_num && (f.ref != 0) == (ref_idc != 0))
+                second = true;
+            else
+                flush_pending_field(d, si);
+        }
+        if (!second) {
+            r = fill_frame_num_gap(d, si, sps, sh);
+            if (r != H264MI_OK) return r;
+        }
+        // (a field counts as a picture of its own against max_frames_per_batch: include/h264mi.h)
         if (s.n_pics_in_batch >= d->cfg.max_frames_per_batch || g.n_pics >= d->pics_cap) {
-            set_error("stream %d: more than %d frames in one batch", si, d->cfg.max_frames_per_batch);
+            set_error("stream %d: more than %d pictures in one batch", si, d->cfg.max_frames_per_batch);
             return H264MI_ECAPACITY;
         }
-        int slot = -1;
+        int slot = second ? s.pend_slot : -1;
         for (int i = 0; i < static_cast<int>(s.slots.size()) && slot < 0; i++)
             if (!s.slots[i].ref && !s.slots[i].held) slot = i;
         if (slot < 0) {
             set_error("stream %d: frame pool exhausted", si);
             return H264MI_ECAPACITY;
         }
-        if (g.mb_used + static_cast<uint64_t>(wmb) * hmb > d->mb_cap) {
+        if (g.mb_used + static_cast<uint64_t>(wmb) * hmb_pic > d->mb_cap) {
             set_error("macroblock record pool exhausted");
             return H264MI_ECAPACITY;
         }
@@ -1074,21 +1350,38 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         s.cur_slices = 0;
         s.cur_first_mbs.clear();
         s.first_sh = sh;
+        s.cur_field = sh.field_pic ? 1 + (sh.bottom_field ? 1 : 0) : 0;
+        s.cur_second = second;
+        if (second) s.pend_slot = -1; // (it is the current picture's frame now; back in pend_slot only if it still lacks a field when this picture ends)
         Slot &sl = s.slots[slot];
-        sl = Slot();
-        sl.held = true;
-        sl.frame_num = sh.frame_num;
-        sl.poc = compute_poc(s, sps, sh);
-        sl.pic = s.cur_pic;
+        if (!second) {
+            sl = Slot();
+            sl.held = true;
+            sl.frame_num = sh.frame_num;
+            sl.field_coded = sh.field_pic != 0;
+        }
+        const int pic_poc = compute_poc(s, sps, sh);
+        if (sh.field_pic) {
+            sl.fpoc[sh.bottom_field ? 1 : 0] = pic_poc;
+            sl.fpic[sh.bottom_field ? 1 : 0] = s.cur_pic;
+            if (!second) sl.poc = pic_poc;
+        } else {
+            sl.poc = pic_poc, sl.fpoc[0] = s.poc_top, sl.fpoc[1] = s.poc_bot;
+            sl.fields = 3; // (a frame picture delivers both fields; it is not in its own reference lists)
+            sl.pic = s.cur_pic;
+        }
         PicDesc &pd = g.h_pics[s.cur_pic];
         memset(&pd, 0, sizeof(pd));
-        pd.stream = si, pd.slot = slot, pd.wmb = wmb, pd.hmb = hmb;
+        pd.stream = si, pd.slot = slot, pd.wmb = wmb, pd.hmb = hmb_pic;
+        // where the picture lives in its frame slot: a field picture in the rows of its parity (PicDesc)
+        pd.field = static_cast<uint8_t>(s.cur_field);
+        pd.pitch = static_cast<uint32_t>(wmb * 16 * (sh.field_pic ? 2 : 1)), pd.plane = static_cast<uint32_t>(wmb * 16) * static_cast<uint32_t>(hmb * 16);
         pd.inv_wmb = static_cast<uint32_t>((1ull << 32) / static_cast<uint32_t>(wmb)) + 1u;
         pd.pool_base = d->h_pools[si].base, pd.slot_bytes = d->slot_bytes, pd.n_slots = static_cast<uint32_t>(d->n_slots);
         g.pic_level.resize(g.n_pics, 0), g.pic_save_col.resize(g.n_pics, 0);
         g.pic_level[s.cur_pic] = 0, g.pic_save_col[s.cur_pic] = 0;
         pd.mb_base = g.mb_used;
-        g.mb_used += static_cast<uint64_t>(wmb) * hmb;
+        g.mb_used += static_cast<uint64_t>(wmb) * hmb_pic;
         pd.first_slice = g.n_slices;
         pd.cabac = pps.entropy_coding_mode, pd.t8x8_mode = pps.transform_8x8_mode, pd.cip = pps.constrained_intra_pred;
         pd.weighted_pred = pps.weighted_pred;
@@ -1102,33 +1395,39 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         pd.scaling_set = static_cast<uint8_t>(ss);
         pd.order = s.n_pics_in_batch++;
         if (pps.num_slice_groups_minus1 > 0) { // FMO: this picture's macroblock-to-slice-group map travels with the bitstream (8.2.2; h264/slice.go:134-158)
-            const size_t n_mbs = static_cast<size_t>(wmb) * hmb, moff = (g.map_cursor + 15) & ~static_cast<size_t>(15);
+            const size_t n_mbs = static_cast<size_t>(wmb) * hmb_pic, moff = (g.map_cursor + 15) & ~static_cast<size_t>(15);
             if (moff + n_mbs + 4096 > d->bits_cap) {
                 set_error("bitstream staging buffer too small for the slice group maps (%zu bytes)", d->bits_cap);
                 return H264MI_ECAPACITY;
             }
-            r = mb_to_slice_group_map(&sps, &pps, s.sg_ids[pps_id].data(), s.sg_ids[pps_id].size(), sh.slice_group_change_cycle, 0, g.h_bits + moff, n_mbs, nullptr);
+            r = mb_to_slice_group_map(&sps, &pps, s.sg_ids[pps_id].data(), s.sg_ids[pps_id].size(), sh.slice_group_change_cycle, sh.field_pic ? 1 : 0, g.h_bits + moff, n_mbs, nullptr);
             if (r != H264MI_OK) return r;
             pd.fmo = 1, pd.sgmap_off = static_cast<uint32_t>(moff);
             g.map_cursor = moff + n_mbs;
             g.bits_end = std::max(g.bits_end, g.map_cursor);
         }
-        g.out[si].push_back({slot, wmb, hmb, 2 * sps.frame_crop_left_offset, 2 * (2 - sps.frame_mbs_only) * sps.frame_crop_top_offset, sps.width, sps.height, sl.poc, sh.frame_num,
-                         sh.nal_ref_idc, sh.nal_unit_type == 5, s.cur_pic, sh.nal_unit_type == 5});
-        if (sh.nal_ref_idc && sh.adaptive_ref_pic_marking_mode_flag)
-            for (int k = 0; k < sh.n_memory_management_control_operations; k++)
-                if (sh.memory_management_control_operation[k] == 5) g.out[si].back().new_sequence = 1;
+        if (!second) { // the frame this picture belongs to, as it will be shown: pushed now (frame picture), or when its fields are through (finish_picture / flush_pending_field)
+            OutFrame of{slot, wmb, hmb, 2 * sps.frame_crop_left_offset, 2 * (2 - sps.frame_mbs_only) * sps.frame_crop_top_offset, sps.width, sps.height, sl.poc, sh.frame_num,
+                        sh.nal_ref_idc, sh.nal_unit_type == 5, s.cur_pic, sh.nal_unit_type == 5};
+            if (sh.nal_ref_idc && sh.adaptive_ref_pic_marking_mode_flag)
+                for (int k = 0; k < sh.n_memory_management_control_operations; k++)
+                    if (sh.memory_management_control_operation[k] == 5) of.new_sequence = 1;
+            if (sh.field_pic)
+                s.pend_out = of;
+            else
+                g.out[si].push_back(of);
+        }
         g.wmb_max = std::max(g.wmb_max, wmb);
-        g.hmb_max = std::max(g.hmb_max, hmb);
-        g.mbs_max = std::max(g.mbs_max, wmb * hmb);
-        g.info.n_macroblocks += static_cast<int64_t>(wmb) * hmb;
+        g.hmb_max = std::max(g.hmb_max, hmb_pic);
+        g.mbs_max = std::max(g.mbs_max, wmb * hmb_pic);
+        g.info.n_macroblocks += static_cast<int64_t>(wmb) * hmb_pic;
         if (si == 0) g.info.width = sps.width, g.info.height = sps.height, g.info.coded_width = wmb * 16, g.info.coded_height = hmb * 16;
     }
     if (s.cur_slices >= d->cfg.max_slices_per_frame) {
         set_error("stream %d: more than %d slices in a frame", si, d->cfg.max_slices_per_frame);
         return H264MI_ECAPACITY;
     }
-    if (sh.first_mb_in_slice >= wmb * hmb) return H264MI_EBITSTREAM;
+    if (sh.first_mb_in_slice >= wmb * hmb_pic) return H264MI_EBITSTREAM;
     s.cur_first_mbs.push_back(sh.first_mb_in_slice);
     PicDesc &pd = g.h_pics[s.cur_pic];
     SliceDesc &sd = g.h_slices[g.n_slices];
@@ -1168,7 +1467,11 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
             r = ensure_b_buffers(d);
             if (r != H264MI_OK) return r;
             pd.has_b = 1;
-            const int cur_poc = s.slots[s.cur_slot].poc;
+            // PicOrderCnt of the current picture and of a list entry: a field's own count in a field picture (entries name fields), the frame's otherwise
+            const bool fieldpic = sh.field_pic != 0;
+            const int cur_poc = fieldpic ? s.slots[s.cur_slot].fpoc[sh.bottom_field ? 1 : 0] : s.slots[s.cur_slot].poc;
+            auto entry_slot = [&](int e) -> const Slot & { return s.slots[fieldpic ? MI_REF_SLOT(e) : e]; };
+            auto entry_poc = [&](int e) { return fieldpic ? entry_slot(e).fpoc[(e & MI_REF_PARITY) ? 1 : 0] : entry_slot(e).poc; };
             const int n0 = sh.num_ref_idx_l0_active_minus1 + 1, n1 = sh.num_ref_idx_l1_active_minus1 + 1;
             bx.num_ref_idx_l1_active = static_cast<uint8_t>(n1);
             bx.direct_spatial = static_cast<uint8_t>(sh.direct_spatial_mv_pred), bx.direct_8x8_inference = static_cast<uint8_t>(sps.direct_8x8_inference);
@@ -1181,8 +1484,9 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
             // POC distances: DistScaleFactor of temporal direct prediction (8.4.1.2.3) per refIdxL0 against RefPicList1[0], and the
             // implicit bi-prediction weights (8.4.2.3.1) per (refIdxL0, refIdxL1)
             auto dist_scale = [&](int slot0, int slot1, bool *copy) {
-                const Slot &p0 = s.slots[slot0], &p1 = s.slots[slot1];
-                const int tb = std::min(std::max(cur_poc - p0.poc, -128), 127), td = std::min(std::max(p1.poc - p0.poc, -128), 127);
+                const Slot &p0 = entry_slot(slot0);
+                const int poc0 = entry_poc(slot0), poc1 = entry_poc(slot1);
+                const int tb = std::min(std::max(cur_poc - poc0, -128), 127), td = std::min(std::max(poc1 - poc0, -128), 127);
                 *copy = td == 0 || p0.ref == 2;
                 if (td == 0) return 256;
                 const int tx = (16384 + std::abs(td / 2)) / td;
@@ -1199,8 +1503,8 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
                     if (i < n0 && j < n1 && sd.ref_slot[i] >= 0 && bx.ref_slot1[j] >= 0) {
                         bool cp;
                         const int f = dist_scale(sd.ref_slot[i], bx.ref_slot1[j], &cp) >> 2;
-                        const int td = s.slots[bx.ref_slot1[j]].poc - s.slots[sd.ref_slot[i]].poc;
-                        if (td != 0 && s.slots[sd.ref_slot[i]].ref != 2 && s.slots[bx.ref_slot1[j]].ref != 2 && f >= -64 && f <= 128) w1 = f;
+                        const int td = entry_poc(bx.ref_slot1[j]) - entry_poc(sd.ref_slot[i]);
+                        if (td != 0 && entry_slot(sd.ref_slot[i]).ref != 2 && entry_slot(bx.ref_slot1[j]).ref != 2 && f >= -64 && f <= 128) w1 = f;
                     }
                     bx.implicit_w1[i][j] = static_cast<int16_t>(w1);
                 }
@@ -1208,12 +1512,27 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
             // the co-located picture: its motion record array, and when its slices are entropy-decoded relative to this one
             level = 1;
             if (col_slot >= 0) {
-                const Slot &cs = s.slots[col_slot];
-                bx.col = reinterpret_cast<uint64_t>(d->d_colrec + (static_cast<size_t>(si) * d->n_slots + col_slot) * d->colrec_per_slot);
+                const Slot &cs = entry_slot(col_slot);
+                const int cslot = fieldpic ? MI_REF_SLOT(col_slot) : col_slot, cpar = fieldpic && (col_slot & MI_REF_PARITY) ? 1 : 0;
+                // the co-located picture must have the structure of the current one (8.4.1.2.1's frame-from-field-pair and field-from-frame
+                // cases, with their vertical vector scaling, are not implemented)
+                if (cs.field_coded != fieldpic && !cs.nonexisting) {
+                    set_error("stream %d: a B %s whose RefPicList1[0] was coded as %s is out of scope (direct prediction across picture structures)", si,
+                              fieldpic ? "field" : "frame picture", cs.field_coded ? "field pictures" : "a frame picture");
+                    return H264MI_EUNSUPPORTED;
+                }
+                // a field's motion: the second half of the frame slot's array for the bottom field (a field has half the frame's macroblocks)
+                bx.col = reinterpret_cast<uint64_t>(d->d_colrec + (static_cast<size_t>(si) * d->n_slots + cslot) * d->colrec_per_slot + (cpar ? d->colrec_per_slot / 2 : 0));
                 bx.col_short = cs.ref == 1;
-                if (cs.pic >= 0) {
-                    level = g.pic_level[cs.pic] + 1;
-                    g.pic_save_col[cs.pic] = 1;
+                const int cpic = fieldpic ? cs.fpic[cpar] : cs.pic;
+                if (cpic >= 0) {
+                    level = g.pic_level[cpic] + 1;
+                    g.pic_save_col[cpic] = 1;
+                } else if (!cs.col_valid[cpar] && !cs.nonexisting) {
+                    // decoded by an earlier batch, before this decoder kept motion (the arrays exist from the first B slice on, ensure_b_buffers):
+                    // direct prediction from it would silently see an intra picture
+                    set_error("stream %d: the co-located picture of a B slice was decoded before the decoder's first B slice; its motion was not kept", si);
+                    return H264MI_EUNSUPPORTED;
                 }
             }
             sd.bext = static_cast<uint32_t>(g.n_bext);
@@ -1277,6 +1596,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     g.bits_used = 0, g.mb_used = 0, g.wmb_max = 0, g.hmb_max = 0, g.mbs_max = 0;
     g.map_cursor = g.bits_end = 0;
     g.fmo_pics.clear();
+    g.grey.clear();
     g.epochs.resize(d->st.size());
     for (size_t si = 0; si < d->st.size(); si++) g.epochs[si] = d->st[si].epoch;
     g.n_bext = 0;
@@ -1284,7 +1604,8 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     memset(&g.info, 0, sizeof(g.info));
     for (size_t si = 0; si < d->st.size(); si++) {
         StreamState &s = d->st[si];
-        for (auto &sl : s.slots) sl.held = sl.ref != 0, sl.pic = -1; // reference pictures at batch start stay put for the whole batch
+        for (auto &sl : s.slots) sl.held = sl.ref != 0, sl.pic = sl.fpic[0] = sl.fpic[1] = -1; // reference pictures at batch start stay put for the whole batch
+        if (s.pend_slot >= 0) s.slots[s.pend_slot].held = true, s.pend_out.pic = -1; // a first field waiting for its second one (decoded by an earlier batch now)
         // the frames of the batch prepared before this one stay readable (and, if it is still executing, writable)
         if (MI_STAGES > 1)
             for (const OutFrame &o : d->stage[prev_stage].out[si]) s.slots[o.slot].held = true;
@@ -1411,6 +1732,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
             case 10:
             case 11:
                 if (s.cur_slot >= 0) finish_picture(d, si);
+                if (nal.type != 9) flush_pending_field(d, si); // end of sequence / end of stream: no second field will follow a lone first one
                 break;
             default: break; // SEI, filler, ... (h264/server.go:147-164 ignores them too)
             }
@@ -1422,6 +1744,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
             g.n_bext = bext0;
             g.pic_level.resize(pics0), g.pic_save_col.resize(pics0), g.slice_level.resize(slices0);
             while (!g.fmo_pics.empty() && static_cast<int>(g.fmo_pics.back()) >= pics0) g.fmo_pics.pop_back();
+            g.grey.erase(std::remove_if(g.grey.begin(), g.grey.end(), [&](const Stage::GreyFill &f) { return static_cast<int>(f.stream) == si; }), g.grey.end());
             reset_stream(s, true);
             g.out[si].clear();
             s.need_idr = true;
@@ -1437,7 +1760,9 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     g.pic_level.resize(g.n_pics, 0), g.pic_save_col.resize(g.n_pics, 0), g.slice_level.resize(g.n_slices, 0);
     for (int si = 0; si < n_streams; si++)
         for (const Slot &sl : d->st[si].slots)
-            if (sl.ref && sl.pic >= 0 && sl.pic < g.n_pics) g.pic_save_col[sl.pic] = 1;
+            if (sl.ref)
+                for (int pic : {sl.pic, sl.fpic[0], sl.fpic[1]})
+                    if (pic >= 0 && pic < g.n_pics) g.pic_save_col[pic] = 1;
     // Slice order = launch order: by level (see Stage), and inside a level longest-processing-time-first -- the entropy
     // kernels run one slice per workgroup and workgroups are dispatched in index order, so the biggest slices (I pictures)
     // must start first.
@@ -1495,7 +1820,11 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
                 g.h_lists[pos++] = i;
                 PicDesc &pd = g.h_pics[i];
                 pd.save_col = g.pic_save_col[i] && d->d_colrec != nullptr; // (no B slice seen yet: nothing to keep, see ensure_b_buffers)
-                pd.col_out = d->d_colrec ? reinterpret_cast<uint64_t>(d->d_colrec + (static_cast<size_t>(pd.stream) * d->n_slots + pd.slot) * d->colrec_per_slot) : 0;
+                const int par = pd.field == 2 ? 1 : 0; // (a bottom field's motion: the second half of its frame slot's array)
+                pd.col_out = d->d_colrec ? reinterpret_cast<uint64_t>(d->d_colrec + (static_cast<size_t>(pd.stream) * d->n_slots + pd.slot) * d->colrec_per_slot +
+                                                                      (par ? d->colrec_per_slot / 2 : 0))
+                                         : 0;
+                if (pd.save_col) d->st[pd.stream].slots[pd.slot].col_valid[par] = true; // (the slot is this picture's until the next prepare at least: held)
                 g.colsave_n[l] += pd.save_col;
             }
         g.prep_n[l] = pos - g.prep_off[l];
@@ -1523,7 +1852,9 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
         d->tables_dirty = false;
     }
     HIP_TRY(hipEventRecord(g.ev_upload, up));
-    g.info.n_frames = g.n_pics, g.info.n_slices = g.n_slices, g.info.bitstream_bytes = static_cast<int64_t>(g.bits_used);
+    g.info.n_frames = 0; // frames that go out with this batch (a frame coded as two field pictures counts once, where its second field is)
+    for (const auto &o : g.out) g.info.n_frames += static_cast<int32_t>(o.size());
+    g.info.n_slices = g.n_slices, g.info.bitstream_bytes = static_cast<int64_t>(g.bits_used);
     g.info.host_prepare_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (info) *info = g.info;
     g.prepared = true;
@@ -1547,9 +1878,26 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         return H264MI_EINVAL;
     }
     d->exec = d->prep; // sync and the frame accessors refer to this batch from now on
+    d->last_exec_stage = d->prep, d->last_exec_set = static_cast<int>(d->pass % MI_SETS);
     Stage &g = d->stage[d->exec];
-    if (!g.n_slices) return H264MI_OK;
+    if (!g.n_slices && g.grey.empty()) return H264MI_OK;
     GUARD(d);
+    // frames that went out with one field decoded (flush_pending_field): the rows of the field that never came are painted mid-grey
+    auto grey_fills = [&](hipStream_t st) {
+        for (const Stage::GreyFill &f : g.grey) {
+            uint8_t *base = d->d_frames + (static_cast<size_t>(f.stream) * d->n_slots + f.slot) * d->slot_bytes;
+            const size_t W = f.w, H = f.h, plane = W * H;
+            hipMemset2DAsync(base + f.parity * W, 2 * W, 128, W, H / 2, st);
+            hipMemset2DAsync(base + plane + f.parity * (W / 2), W, 128, W / 2, H / 4, st);
+            hipMemset2DAsync(base + plane + plane / 4 + f.parity * (W / 2), W, 128, W / 2, H / 4, st);
+        }
+    };
+    if (!g.n_slices) { // nothing to decode: a chunk that only ended a sequence and thereby sent a lone first field out
+        grey_fills(d->stream);
+        HIP_TRY(hipEventRecord(g.ev_done, d->stream));
+        g.executed = true, g.harvested = true;
+        return H264MI_OK;
+    }
     size_t ei = 0;
     const bool prof = d->profiling;
     auto mark = [&](int kind) {
@@ -1625,6 +1973,7 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         }
         return d->x_epoch;
     };
+    grey_fills(rs);
     for (size_t w = 0; w < g.waves.size(); w++) {
         const uint32_t n = static_cast<uint32_t>(g.waves[w].size()), ni = g.wave_p_n[w], nbp = g.wave_b_n[w];
         if (!n) continue;

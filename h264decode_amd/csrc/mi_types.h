@@ -156,7 +156,19 @@ typedef struct {
     uint8_t pad[1];
     uint32_t sgmap_off;    /* byte offset of the picture's mbToSliceGroupMap (8.2.2.8, one byte per macroblock) in the bitstream buffer */
     uint32_t inv_wmb;      /* floor(2^32 / wmb) + 1: mby = mulhi(mb, inv_wmb) is exact for mb < 2^32 / wmb / wmb (wmb <= 512, hmb <= 320) */
+    /* Where the picture's samples are in its frame slot.  A frame: pitch = 16 wmb, plane = 16 wmb x 16 hmb.  A field picture
+     * (h264/slice.go:867-872 field_pic_flag / bottom_field_flag) is reconstructed IN PLACE into the rows of its parity of the frame's slot:
+     * hmb counts the field's macroblock rows, pitch is twice the frame's, plane the FRAME's plane size, and the first row starts
+     * (field == 2 ? pitch / 2 : 0) bytes into the luma plane, (field == 2 ? pitch / 4 : 0) into each chroma plane. */
+    uint32_t pitch;        /* luma bytes from one row of the picture to the next (chroma: half) */
+    uint32_t plane;        /* offset of the Cb plane from the slot's first byte = luma bytes of the frame (Cr: plane * 5 / 4) */
+    uint8_t field;         /* 0 frame picture, 1 top field, 2 bottom field */
+    uint8_t pad2[7];
 } PicDesc;
+/* In field pictures a reference "slot" (SliceDesc::ref_slot, BSliceExt::ref_slot1, MbRec::refslot / refslot1, ColRec::refslot) names a FIELD:
+ * the frame slot in the low bits and the field's parity in bit 14 (frame pictures never set it: they predict from whole frames). */
+#define MI_REF_PARITY 0x4000
+#define MI_REF_SLOT(r) ((r) & 0x3FFF)
 
 typedef struct {
     uint64_t base;       /* device address of slot 0 */
@@ -183,6 +195,7 @@ typedef struct {
     uint8_t ctx_init[4][52][464]; /* (pStateIdx<<1)|valMPS for every (table set, SliceQPY, ctxIdx): 9.3.1.1 */
     uint8_t sig8x8[64], last8x8[64];
     uint8_t zigzag4[16], zigzag8[64];
+    uint8_t fieldscan4[16], fieldscan8[64]; /* Tables 8-12 / 8-13, field scan: what a field picture's blocks are scanned in */
     uint8_t me_intra[48], me_inter[48];
     uint8_t alpha[52], beta[52], tc0[52][4];
     uint8_t qpc[52];

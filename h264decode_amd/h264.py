@@ -201,9 +201,11 @@ class Decoder:
     """Batched GPU decoder: N independent Annex-B streams side by side on one MI355X."""
 
     def __init__(self, max_streams=1, max_width=1920, max_height=1088, max_frames_per_batch=32, max_slices_per_frame=8, device=0,
-                 max_bitstream_bytes=0, hip_stream=None, max_ref_frames=0, coef_blocks_per_mb=0):
+                 max_bitstream_bytes=0, hip_stream=None, max_ref_frames=0, coef_blocks_per_mb=0, b_pictures=0):
         L = _lib.load()
         cfg = _lib.Config()
+        cfg.struct_size = ctypes.sizeof(cfg)
+        cfg.b_pictures = b_pictures  # 1: the B-only buffers exist from the start (default: from the first B slice on)
         cfg.device, cfg.max_streams, cfg.max_width, cfg.max_height = device, max_streams, max_width, max_height
         cfg.max_frames_per_batch, cfg.max_slices_per_frame, cfg.max_bitstream_bytes = max_frames_per_batch, max_slices_per_frame, max_bitstream_bytes
         cfg.hip_stream = hip_stream

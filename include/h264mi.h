@@ -174,10 +174,15 @@ int32_t h264mi_next_mb_address(const uint8_t *map, size_t n_mbs, size_t n);
 typedef struct h264mi_decoder h264mi_decoder;
 
 typedef struct {
+    /* sizeof(h264mi_config) as the CALLER was compiled: the struct grows at its end from version to version, and a field that lies beyond
+     * struct_size is taken as 0 (its default) instead of being read from whatever follows a shorter struct.  0 is refused: zero-initialise
+     * the struct and set this field (H264MI_CONFIG_INIT). */
+    uint32_t struct_size;
     int32_t device;                /* HIP device ordinal */
     int32_t max_streams;           /* independent streams decoded side by side */
     int32_t max_width, max_height; /* display size upper bound (coded size is rounded up to 16) */
-    int32_t max_frames_per_batch;  /* per stream and per h264mi_decode_batch call */
+    int32_t max_frames_per_batch;  /* PICTURES per stream and per h264mi_decode_batch call: a frame picture is one, a frame coded as two field
+                                    * pictures (h264/slice.go:867-872 field_pic_flag) is two */
     int32_t max_slices_per_frame;
     int64_t max_bitstream_bytes;   /* per batch, summed over streams */
     void *hip_stream;              /* hipStream_t to launch on; NULL = a private stream */
@@ -186,7 +191,13 @@ typedef struct {
      * a stream that declares more is refused with H264MI_ECAPACITY.  coef_blocks_per_mb: residual pool size in 32-byte blocks per
      * macroblock (default 8 of at most 26; see h264mi_decoder_coef_pool). */
     int32_t max_ref_frames, coef_blocks_per_mb;
+    /* b_pictures: 0 = what only B pictures need (list-1 vectors, the motion of reference pictures kept for direct prediction: 16 GB for 256
+     * streams of 1080p) is allocated when the first B slice arrives -- I / P deployments never pay for it, and the FIRST B picture a decoder
+     * sees must find its co-located picture in the same batch or the one before (otherwise that stream is refused until its next IDR picture);
+     * 1 = allocated at create time, motion kept from the first picture on. */
+    int32_t b_pictures;
 } h264mi_config;
+#define H264MI_CONFIG_INIT {(uint32_t)sizeof(h264mi_config)} /* h264mi_config cfg = H264MI_CONFIG_INIT; then set the fields */
 
 typedef struct {
     int32_t n_frames;         /* frames decoded in this batch */

@@ -230,7 +230,7 @@ static int build_ref_list(h264o_decoder *d) {
     for (int i = 0; i < d->n_pics; i++) {
         h264o_pic *p = &d->pics[i];
         if (p == d->curf && !(d->field_pic && d->second_field && p->ref == 1)) continue; /* (a second field may predict from the first field of its frame) */
-        if (!d->field_pic && p->funref) continue; /* 8.2.4.2.1: a frame picture predicts from frames of which both fields are marked */
+        if (!d->field_pic && p->ref && (p->funref || p->fields != 3)) continue; /* 8.2.4.2.1: a frame picture predicts from frames of which both fields are there and marked */
         if (p->ref == 1) {
             p->frame_num_wrap = p->frame_num > sh->frame_num ? p->frame_num - max_fn : p->frame_num;
             p->pic_num = p->frame_num_wrap;
@@ -608,7 +608,7 @@ static int fill_frame_num_gap(h264o_decoder *d) {
         for (int i = 0; i < d->n_pics && !slot; i++)
             if (!d->pics[i].ref && !d->pics[i].in_use) slot = &d->pics[i];
         if (!slot) return h264o_fail(d, "DPB full");
-        slot->ref = 1, slot->nonexisting = 1, slot->frame_num = fn, slot->id = d->next_pic_id++, slot->n_mbs = 0, slot->funref = 0;
+        slot->ref = 1, slot->nonexisting = 1, slot->frame_num = fn, slot->id = d->next_pic_id++, slot->n_mbs = 0, slot->funref = 0, slot->fields = 3;
         slot->poc = 0;
         if (s->pic_order_cnt_type != 0) { /* 8.2.1: as a reference frame with this frame_num (keeps FrameNumOffset right across a wrap) */
             h264o_slice_header f;

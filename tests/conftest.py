@@ -179,8 +179,10 @@ MATRIX = {
 }
 
 
-# Field pictures (PAFF: every frame coded as two fields).  Oracle + generator only for now -- the product refuses field pictures
-# with H264MI_EUNSUPPORTED -- so these are NOT part of MATRIX (which the GPU parity tests run in full).  CAVLC only: see sg.h.
+# Field pictures (PAFF: every frame coded as two fields, or picture-adaptively as a frame or two fields).  The product decodes them (round 4):
+# the GPU parity tests run FULL_MATRIX = MATRIX + FIELD_MATRIX through every kernel-plan variant.  They are kept apart from MATRIX only because
+# a frame of these streams is two pictures (two access units, two decoder "pictures per batch"), which the CPU tests over MATRIX that count
+# access units or pictures would have to special-case.  CAVLC only: see sg.h (the CABAC context tables of field-coded blocks are not in this tree).
 FIELD_BASE = dict(width=176, height=128, frames=5, idr_period=0, profile_idc=77, cabac=0, field_pics=1)
 FIELD_MATRIX = {
     "field_IP": dict(FIELD_BASE, num_ref_frames=2, seed=301),
@@ -211,8 +213,9 @@ FIELD_MATRIX = {
 
 
 # Picture order counts with a bottom field that is not at the top field's count (bottom_field_pic_order_in_frame_present_flag = 1:
-# delta_pic_order_cnt_bottom / delta_pic_order_cnt[1]).  Checked on the CPU only: oracle == generator, and the product's HOST side
-# (built against the null device of tools/hoststub) must arrive at the same PicOrderCnt for every picture -- tests/test_host_picture_management.py.
+# delta_pic_order_cnt_bottom / delta_pic_order_cnt[1]).  Part of MATRIX (below): every GPU variant, the golden MD5s and the CPU tests see them;
+# on the CPU the product's HOST side (built against the null device of tools/hoststub) must arrive at the same PicOrderCnt for every picture
+# -- tests/test_host_picture_management.py.
 POC_MATRIX = {
     "poc_bottom_later": dict(BASE, frames=8, profile_idc=77, cabac=1, num_ref_frames=2, poc_bottom_delta=1, seed=401),
     "poc_bottom_first": dict(BASE, frames=8, profile_idc=77, cabac=0, num_ref_frames=2, poc_bottom_delta=-1, idr_period=5, seed=402),
@@ -221,3 +224,11 @@ POC_MATRIX = {
     "poc_bottom_first_mmco5": dict(BASE, frames=24, profile_idc=77, cabac=1, num_ref_frames=3, poc_bottom_delta=-1, mmco=1, seed=21),
     "poc_bottom_later_interlace_sps": dict(BASE, height=128, frames=6, profile_idc=100, cabac=1, transform8x8=1, num_ref_frames=2, poc_bottom_delta=2, interlace_sps=1, seed=405),
 }
+
+MATRIX.update(POC_MATRIX)
+FULL_MATRIX = dict(MATRIX, **FIELD_MATRIX)
+
+
+def pictures_of(kw):
+    """Pictures (access units) of a matrix stream: a frame coded as two fields is two of them.  What a decoder's max_frames_per_batch counts."""
+    return kw["frames"] * (2 if kw.get("field_pics") else 1)

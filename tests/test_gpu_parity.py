@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import MATRIX, POC_MATRIX, PRODUCT_DECODES_B
+from conftest import FIELD_MATRIX, FULL_MATRIX, MATRIX, POC_MATRIX, PRODUCT_DECODES_B, pictures_of
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "stream_md5.json")
@@ -54,17 +54,17 @@ def _decode_gpu_(H, streams, w, h, frames, slices=1, crop=False):
     return out, info
 
 
-@pytest.mark.parametrize("name", sorted(MATRIX))
+@pytest.mark.parametrize("name", sorted(FULL_MATRIX))
 def test_gpu_matches_oracle_and_generator(name, H, sg, oracle_mod):
-    kw = MATRIX[name]
+    kw = FULL_MATRIX[name]
     stream, rec, _ = sg.encode(**kw)
     ref, _ = oracle_mod.decode(stream, crop=False)
     if kw.get("bframes") and not PRODUCT_DECODES_B:
         with pytest.raises(H.H264MIError) as e:
-            _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], _nslices(kw))
+            _decode_gpu(H, [stream], kw["width"], kw["height"], pictures_of(kw), _nslices(kw))
         assert e.value.code == -3
         return
-    out, info = _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], _nslices(kw))
+    out, info = _decode_gpu(H, [stream], kw["width"], kw["height"], pictures_of(kw), _nslices(kw))
     assert info.n_frames == kw["frames"]
     assert out[0].shape == ref.shape
     assert np.array_equal(out[0], ref), "GPU != oracle"
@@ -95,22 +95,24 @@ def test_gpu_separate_bottom_field_counts(name, H, sg, oracle_mod):
 def test_gpu_matrix_with_one_workgroup_per_picture(H, sg):
     """The same matrix through k_intra / k_deblock / k_deblock_b (a picture inside ONE workgroup: what a launch that fills the
     chip uses); the default for these one-stream batches is the banded kernels.  Also 512 workgroups per launch."""
-    for name in sorted(MATRIX):
-        kw = MATRIX[name]
+    for name in sorted(FULL_MATRIX):
+        kw = FULL_MATRIX[name]
         stream, rec, _ = sg.encode(**kw)
         for x in (0, 512):
-            out, _ = _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], _nslices(kw), x_wgs=x)
+            out, _ = _decode_gpu(H, [stream], kw["width"], kw["height"], pictures_of(kw), _nslices(kw), x_wgs=x)
             assert np.array_equal(out[0], rec), (name, x)
 
 
 def test_gpu_golden_md5(H, sg):
     gold = json.load(open(GOLDEN))
+    gold.update(json.load(open(os.path.join(os.path.dirname(GOLDEN), "field_md5.json"))))
+    assert set(gold) == set(FULL_MATRIX)
     for name, g in sorted(gold.items()):
-        kw = MATRIX[name]
+        kw = FULL_MATRIX[name]
         if kw.get("bframes") and not PRODUCT_DECODES_B:
             continue
         stream, _, _ = sg.encode(**kw)
-        out, _ = _decode_gpu(H, [stream], kw["width"], kw["height"], kw["frames"], _nslices(kw))
+        out, _ = _decode_gpu(H, [stream], kw["width"], kw["height"], pictures_of(kw), _nslices(kw))
         assert hashlib.md5(out[0].tobytes()).hexdigest() == g["frames_md5"], name
 
 
@@ -786,4 +788,111 @@ def test_gpu_output_order_of_b_streams(H, sg):
     keys = [(seq[i], info[i].pic_order_cnt) for i in order]
     assert keys == sorted(keys) and len(set(keys)) == len(keys)
     assert dec.output_order(1) == list(range(dec.frame_count(1)))  # no B pictures: decoding order
+    dec.close()
+
+
+# ------------------------------------------------------------------ field pictures (PAFF; SURVEY 8f rank 3, h264/slice.go:867-872, h264/sps.go:316-322)
+def _access_units(H, stream):
+    sp = H.AccessUnitSplitter(max_units_per_chunk=1)
+    return sp.feed(stream) + sp.flush()
+
+
+@pytest.mark.parametrize("name", ["field_IP", "field_bottom_first", "field_mixed_paff", "field_b_temporal", "field_mmco1_rplm_mixed", "field_fmo_boxout_mixed_aso"])
+def test_gpu_field_stream_fed_picture_by_picture(name, H, sg):
+    """One access unit (= one picture: a field is one) per batch: the two fields of a frame arrive in DIFFERENT batches.  The frame goes out
+    once, with the batch of its second field; everything equals the generator's reconstruction, PicOrderCnt included."""
+    kw = FIELD_MATRIX[name]
+    stream, rec, _ = sg.encode(**kw)
+    pocs = [int(x) for x in sg.last_pocs()]
+    aus = _access_units(H, stream)
+    assert len(aus) > kw["frames"]
+    # (b_pictures: the co-located field of the stream's first B field lies two batches back here -- its motion must have been kept from the start)
+    dec = H.Decoder(max_streams=1, max_width=(kw["width"] + 15) & ~15, max_height=(kw["height"] + 15) & ~15, max_frames_per_batch=2, max_slices_per_frame=max(8, _nslices(kw)),
+                    b_pictures=1 if kw.get("bframes") else 0)
+    frames, got_pocs, per_batch = [], [], []
+    for au in aus:
+        dec.decode([au])
+        per_batch.append(dec.frame_count(0))
+        for f in range(dec.frame_count(0)):
+            frames.append(dec.read_frame_tight(0, f, crop=False))
+            got_pocs.append(dec.frame_info(0, f).pic_order_cnt)
+    dec.close()
+    assert max(per_batch) == 1 and sum(per_batch) == kw["frames"] and 0 in per_batch  # first fields deliver nothing
+    assert got_pocs == pocs
+    assert np.array_equal(np.stack(frames), rec), "GPU != generator reconstruction"
+
+
+def test_gpu_single_field_at_the_end(H, sg, oracle_mod):
+    """A first field whose second field never comes: held back until something says that it will not come -- here an end-of-stream NAL unit --,
+    then it goes out as a frame with its rows decoded and the other parity mid-grey (what the oracle makes of the cut stream at its end)."""
+    kw = dict(FIELD_MATRIX["field_IP"], slices=1)
+    stream, rec, _ = sg.encode(**kw)
+    cut = stream.rfind(b"\x00\x00\x01")
+    cut -= 1 if stream[cut - 1] == 0 else 0
+    ref, info = oracle_mod.decode(stream[:cut], crop=False)
+    assert info.n_frames == kw["frames"]
+    W, Hc = (kw["width"] + 15) & ~15, (kw["height"] + 15) & ~15
+    dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=2 * kw["frames"], max_slices_per_frame=8)
+    dec.decode([stream[:cut]])
+    assert dec.frame_count(0) == kw["frames"] - 1  # the lone field waits
+    dec.decode([b"\x00\x00\x00\x01\x0b"])           # end of stream
+    assert dec.frame_count(0) == 1
+    last = dec.read_frame_tight(0, 0, crop=False)
+    dec.close()
+    assert np.array_equal(last, ref[-1])
+    y = last[:W * Hc].reshape(Hc, W)
+    assert np.array_equal(y[0::2], rec[-1][:W * Hc].reshape(Hc, W)[0::2]) and (y[1::2] == 128).all()
+    # the same in ONE chunk: the lone field goes out behind the complete frames
+    dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=2 * kw["frames"], max_slices_per_frame=8)
+    dec.decode([stream[:cut] + b"\x00\x00\x00\x01\x0a"])
+    assert dec.frame_count(0) == kw["frames"]
+    assert np.array_equal(dec.read_frames(0, crop=False), ref)
+    dec.close()
+
+
+def test_gpu_1080i_full_size(H, sg, oracle_mod):
+    """1920x1080 interlaced (coded 1920x1088: 68 macroblock rows, 34 per field), every frame two field pictures, top field first, P fields with two
+    reference frames = four reference fields, quarter-sample motion: GPU == generator == oracle, cropped output 1920x1080."""
+    kw = dict(width=1920, height=1080, frames=3, idr_period=0, profile_idc=77, cabac=0, field_pics=1, num_ref_frames=2, motion_x4=5, motion_y4=-3, qp=30, seed=331)
+    stream, rec, _ = sg.encode(**kw)
+    out, info = _decode_gpu(H, [stream], 1920, 1080, 6, 1)
+    assert info.n_frames == 3 and (info.width, info.height, info.coded_width, info.coded_height) == (1920, 1080, 1920, 1088)
+    assert np.array_equal(out[0], rec), "GPU != generator reconstruction"
+    ref, _ = oracle_mod.decode(stream, crop=False)
+    assert np.array_equal(out[0], ref), "GPU != oracle"
+    crop, _ = _decode_gpu(H, [stream], 1920, 1080, 6, 1, crop=True)
+    y = rec[:, :1920 * 1088].reshape(-1, 1088, 1920)[:, :1080]
+    assert np.array_equal(crop[0][:, :1920 * 1080].reshape(-1, 1080, 1920), y)
+    # through the one-workgroup-per-picture kernels as well (what a launch of many streams uses)
+    out0, _ = _decode_gpu(H, [stream], 1920, 1080, 6, 1, x_wgs=0)
+    assert np.array_equal(out0[0], rec)
+
+
+def test_gpu_field_and_frame_streams_share_a_batch(H, sg):
+    """Field-coded, picture-adaptive and progressive streams side by side in one decoder: launches then mix pictures of 9 and of 4 macroblock rows,
+    frame pitches and field pitches."""
+    names = ["field_IP", "cabac_IPP", "field_mixed_paff", "field_b_spatial", "b_ibbp_cavlc", "field_high_8x8"]
+    kws = [FULL_MATRIX[n] for n in names]
+    enc = [sg.encode(**kw) for kw in kws]
+    dec = H.Decoder(max_streams=len(kws), max_width=176, max_height=144, max_frames_per_batch=max(pictures_of(kw) for kw in kws), max_slices_per_frame=8)
+    dec.decode([e[0] for e in enc])
+    for i, (kw, e) in enumerate(zip(kws, enc)):
+        W, Hc = (kw["width"] + 15) & ~15, (kw["height"] + 15) & ~15
+        assert dec.frame_count(i) == kw["frames"], names[i]
+        assert np.array_equal(dec.read_frames(i, crop=False, size=W * Hc * 3 // 2), e[1]), names[i]
+    dec.close()
+
+
+def test_gpu_field_pictures_with_cabac_are_refused_with_a_reason(H, sg):
+    """Field pictures with entropy_coding_mode_flag = 1 need the context initialisation values of field-coded blocks (ctxIdx 277-398, 436-459), which are not
+    in this tree: refused (H264MI_EUNSUPPORTED) with a message that says so -- not decoded with zeros.  The stream: a CAVLC field stream whose PPS is
+    patched to announce CABAC (the refusal comes at the first slice header, before any slice data is looked at)."""
+    stream, _, _ = sg.encode(**FIELD_MATRIX["field_IP"])
+    i = stream.find(b"\x00\x00\x01\x68") + 4  # pic_parameter_set_rbsp: ue(0) ue(0) entropy_coding_mode_flag ...
+    assert i > 4 and stream[i] & 0xC0 == 0xC0 and not stream[i] & 0x20
+    patched = stream[:i] + bytes([stream[i] | 0x20]) + stream[i + 1:]
+    dec = H.Decoder(max_streams=1, max_width=176, max_height=128, max_frames_per_batch=10, max_slices_per_frame=8)
+    with pytest.raises(H.H264MIError) as e:
+        dec.decode([patched])
+    assert e.value.code == -3 and "CABAC" in str(e.value) and "277" in str(e.value)
     dec.close()

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import MATRIX, POC_MATRIX
+from conftest import FULL_MATRIX, MATRIX, POC_MATRIX, pictures_of
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.skipif(not shutil.which("g++"), reason="g++ not available")
@@ -29,7 +29,7 @@ def _host(prog, tmp, stream, kw):
     open(path, "wb").write(stream)
     W, Hc = (kw["width"] + 15) & ~15, (kw["height"] + 15) & ~15
     nsl = max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1))
-    r = subprocess.run([prog, path, str(W), str(Hc), str(kw["frames"]), str(max(8, nsl))], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([prog, path, str(W), str(Hc), str(pictures_of(kw)), str(max(8, nsl))], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [line.split() for line in r.stdout.splitlines() if line.strip()]
     return np.array([[int(x) for x in t] for t in lines if t[0] != "order"]), [int(x) for t in lines if t[0] == "order" for x in t[1:]]
@@ -37,7 +37,7 @@ def _host(prog, tmp, stream, kw):
 
 def test_host_picture_order_counts_match_the_generator(host_pocs, sg):
     prog, tmp = host_pocs
-    for name, kw in sorted(dict(MATRIX, **POC_MATRIX).items()):
+    for name, kw in sorted(FULL_MATRIX.items()):  # (field pictures included: second-field detection, field counts, the lists and marking of 8.2.4.2.5 / 8.2.5.4.1)
         stream, _, _ = sg.encode(want_recon=False, **kw)
         want = sg.last_pocs()
         got, order = _host(prog, tmp, stream, kw)

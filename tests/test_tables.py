@@ -24,6 +24,7 @@ def test_three_table_copies_agree():
     a = _arrays(os.path.join(ROOT, "oracle", "h264o_tables.h"), "h264o_")
     b = _arrays(os.path.join(ROOT, "streamgen", "sg_tables.h"), "sg_")
     c = _arrays(os.path.join(ROOT, "h264decode_amd", "csrc", "mi_tables.h"), "mi_")
+    field = {k: c.pop(k) for k in ("fieldscan4x4", "fieldscan8x8")}  # (oracle and generator keep theirs in C files: checked below)
     assert a and set(a) == set(b) == set(c)
     for k in a:
         assert a[k] == b[k] == c[k], k
@@ -33,6 +34,25 @@ def test_three_table_copies_agree():
         return re.sub(r"h264o_|sg_|mi_|H264O_|SG_|MI_", "", src[src.index("#define Z "):])
     assert mn(os.path.join(ROOT, "oracle", "h264o_cabac_mn.c")) == mn(os.path.join(ROOT, "streamgen", "sg_cabac_mn.c")) == \
         mn(os.path.join(ROOT, "h264decode_amd", "csrc", "mi_cabac_mn.cpp"))
+
+
+def test_field_scans(oracle_mod):
+    """Tables 8-12 / 8-13, field scan: the product's tables (written as x + 8 y) against the oracle's (written as (row, column) pairs) -- two
+    transcriptions --, and the structure the standard's figure shows: a permutation that runs down the first column first and reaches the
+    bottom-left corner long before the top-right one."""
+    from oracle import lib as olib
+    c = _arrays(os.path.join(ROOT, "h264decode_amd", "csrc", "mi_tables.h"), "mi_")
+    src = open(os.path.join(ROOT, "h264decode_amd", "csrc", "mi_tables.h")).read()
+    body = src[src.index("mi_fieldscan8x8[64]"):]
+    body = body[body.index("{") + 1:body.index("}")]
+    f8 = [int(x) + 8 * int(y) for x, y in re.findall(r"(\d) \+ (\d) \* 8", body)]
+    f4 = c["fieldscan4x4"]
+    O = olib()
+    o4 = list((ctypes.c_uint8 * 16).in_dll(O, "h264o_fieldscan4x4"))
+    o8 = list((ctypes.c_uint8 * 64).in_dll(O, "h264o_fieldscan8x8"))
+    assert f4 == o4 and f8 == o8
+    assert sorted(f4) == list(range(16)) and sorted(f8) == list(range(64))
+    assert f4[:2] == [0, 4] and f8[:3] == [0, 8, 16] and f8.index(56) < 16 < f8.index(7)
 
 
 def _prefix_free_and_kraft(codes):

@@ -20,6 +20,7 @@ int main(int argc, char **argv) {
     fclose(f);
     h264mi_config cfg;
     memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg;
     cfg.max_streams = 1, cfg.max_width = atoi(argv[2]), cfg.max_height = atoi(argv[3]), cfg.max_frames_per_batch = atoi(argv[4]);
     cfg.max_slices_per_frame = argc > 5 ? atoi(argv[5]) : 64, cfg.max_bitstream_bytes = len + 4096;
     h264mi_decoder *dec = nullptr;

@@ -71,6 +71,10 @@ static inline hipError_t hipMemcpy2D(void *d, size_t dpitch, const void *s, size
 }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset2DAsync(void *d, size_t pitch, int v, size_t width, size_t height, hipStream_t = nullptr) {
+    for (size_t r = 0; r < height; r++) memset(static_cast<char *>(d) + r * pitch, v, width);
+    return hipSuccess;
+}
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = reinterpret_cast<hipStream_t>(malloc(1)); return hipSuccess; }
 static inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t *s, uint32_t, const uint32_t *) { *s = reinterpret_cast<hipStream_t>(malloc(1)); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
