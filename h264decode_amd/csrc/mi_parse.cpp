@@ -463,7 +463,9 @@ int parse_pps_ids(const h264mi_sps *sps, const uint8_t *rbsp, size_t len, h264mi
         }
         p->second_chroma_qp_index_offset = b.se();
     }
-    if (b.overrun() || p->pic_init_qp_minus26 < -26 || p->pic_init_qp_minus26 > 25 || p->chroma_qp_index_offset < -12 || p->chroma_qp_index_offset > 12 ||
+    // (pic_init_qp_minus26: -(26 + QpBdOffsetY) .. 25 by 7.4.2.2; encoders that lean on slice_qp_delta to come back into range exist -- the bound here only
+    // keeps SliceQPY = 26 + pic_init_qp_minus26 + slice_qp_delta, which IS checked (0..51), free of overflow)
+    if (b.overrun() || p->pic_init_qp_minus26 < -128 || p->pic_init_qp_minus26 > 127 || p->chroma_qp_index_offset < -12 || p->chroma_qp_index_offset > 12 ||
         p->second_chroma_qp_index_offset < -12 || p->second_chroma_qp_index_offset > 12) {
         set_error("PPS: truncated, or a QP field out of range");
         return H264MI_EBITSTREAM;
@@ -593,7 +595,7 @@ int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc
         if (bad) return H264MI_EBITSTREAM;
     }
     sh->slice_qp_delta = b.se();
-    if (sh->slice_qp_delta < -87 || sh->slice_qp_delta > 77) return H264MI_EBITSTREAM; // (7-30) keeps SliceQPY in 0..51 for any pic_init_qp
+    if (sh->slice_qp_delta < -256 || sh->slice_qp_delta > 256) return H264MI_EBITSTREAM; // (SliceQPY itself is checked below: this keeps the sum free of overflow)
     if (st == 3 || st == 4) {
         if (st == 3) sh->sp_for_switch = b.u(1);
         sh->slice_qs_delta = b.se();

@@ -805,7 +805,7 @@ static void begin_mb(enc *e, int addr) {
     memset(e->cac, 0, sizeof(e->cac));
 }
 static void set_qpc(enc *e, emb *m, int qp) {
-    int second = e->p.chroma_qp_offset + ((e->p.profile_idc == 100 && e->p.transform8x8) ? 1 : 0);
+    int second = e->p.chroma_qp_offset + ((e->p.profile_idc == 100 && e->p.transform8x8 && e->p.chroma_qp_offset < 12) ? 1 : 0); /* (7.4.2.2: -12 .. 12) */
     m->qp = (uint8_t)qp;
     m->qpc[0] = (uint8_t)qpc_of(qp + e->p.chroma_qp_offset);
     m->qpc[1] = (uint8_t)qpc_of(qp + second);
@@ -1790,7 +1790,7 @@ static void plan_slice_groups(enc *e) {
     const sg_params *p = &e->p;
     int W = e->wmb, Hm = sg_map_units(e) / W, units = W * Hm, ng = p->slice_groups;
     for (int g = 0; g < 8; g++) {
-        e->sg_rl[g] = (int)((p->seed * 5u + 7u * (unsigned)g) % (unsigned)(W + 3)); /* run_length_minus1: runs that straddle rows */
+        e->sg_rl[g] = (int)((p->seed * 5u + 7u * (unsigned)g) % (unsigned)(W + 3 < units ? W + 3 : units)); /* run_length_minus1: runs that straddle rows; 7.4.2.2: at most PicSizeInMapUnits - 1 */
         int x0 = (2 * g + 1) % (W > 2 ? W / 2 : 1), y0 = (g + 1) % (Hm > 2 ? Hm / 2 : 1);
         int x1 = x0 + W / 3, y1 = y0 + Hm / 3;
         if (x1 > W - 1) x1 = W - 1;
@@ -1911,7 +1911,7 @@ static size_t write_pps(enc *e, uint8_t *dst, size_t cap) {
     if (p->profile_idc == 100) {
         sg_put(&w, (uint32_t)p->transform8x8, 1);
         sg_put(&w, 0, 1); /* pic_scaling_matrix_present */
-        sg_put_se(&w, p->chroma_qp_offset + (p->transform8x8 ? 1 : 0));
+        sg_put_se(&w, p->chroma_qp_offset + (p->transform8x8 && p->chroma_qp_offset < 12 ? 1 : 0));
     }
     sg_trailing(&w);
     size_t n = sg_write_nal(dst, cap, 1, 3, 8, buf, sg_bw_bytes(&w));

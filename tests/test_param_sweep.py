@@ -20,12 +20,14 @@ def test_sweep_oracle_equals_generator():
     _sweep("400", "--seed", "3")
     _sweep("150", "--seed", "5", "--concat")
     _sweep("300", "--seed", "61", "--extreme")
-    _sweep("400", "--seed", "21", "--fields")  # field pictures (PAFF): oracle only
+    _sweep("400", "--seed", "21", "--fields")  # field pictures (PAFF)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("args", [("300", "--seed", "11"), ("200", "--seed", "31", "--split"), ("40", "--seed", "23", "--batch", "6"),
                                   ("150", "--seed", "5", "--concat"), ("150", "--seed", "13", "--concat", "--split"), ("40", "--seed", "9", "--big"),
-                                  ("250", "--seed", "41", "--xwgs"), ("300", "--seed", "61", "--extreme")])
+                                  ("250", "--seed", "41", "--xwgs"), ("300", "--seed", "61", "--extreme"),
+                                  ("250", "--seed", "21", "--fields"), ("200", "--seed", "22", "--fields", "--split"), ("100", "--seed", "23", "--fields", "--xwgs"),
+                                  ("60", "--seed", "24", "--fields", "--big")])
 def test_gpu_sweep_equals_generator(args):
     _sweep(*args, "--gpu")

@@ -4,7 +4,8 @@ coder, slices, slice groups, references, picture management, B pictures, weights
 generator's reconstruction bit for bit.  Usage: param_sweep.py [trials] [--gpu] [--seed N] [--batch B]
   without --gpu: the oracle (CPU);  with --gpu: the product through the C ABI, one workgroup per picture and banded;
   --batch B (GPU): B streams of different recipes and sizes side by side in one decoder per trial;
-  --fields: field-picture (PAFF) recipes, oracle only;  --pocdelta: frame pictures whose bottom field has its own picture order count;
+  --fields: field-picture (PAFF) recipes -- every frame as two field pictures, or picture-adaptively a frame or two fields; with --split the
+  pieces are whole PICTURES, so the two fields of a frame may arrive in different calls;  --pocdelta: frame pictures whose bottom field has its own picture order count;
   --split (GPU): every stream is fed in several calls, a random number of access units at a time (state that must survive a batch boundary:
   reference pictures and their marking, picture order counts, co-located motion, frame_num gap bookkeeping, parameter sets)."""
 import os, sys, time
@@ -21,7 +22,7 @@ SPLIT = "--split" in sys.argv
 XR = "--xwgs" in sys.argv  # a random workgroup budget per trial (band plans of every shape) instead of the two standard ones
 EXTREME = "--extreme" in sys.argv  # the corners of the value ranges: QP 0..51, chroma offsets -12..12, filter offsets -6..6, loud noise (escape-coded levels)
 BIG = "--big" in sys.argv  # pictures wider than 64 macroblocks (rows of more than one 64-macroblock chunk), more slices
-FIELDS = "--fields" in sys.argv  # PAFF recipes: every frame as two field pictures (oracle only: the product refuses field pictures)
+FIELDS = "--fields" in sys.argv  # PAFF recipes: every frame as two field pictures, or a frame / two fields picture by picture
 POCD = "--pocdelta" in sys.argv  # bottom_field_pic_order_in_frame_present_flag = 1: the bottom field of every frame picture at its own count (before or after the top field)
 CONCAT = "--concat" in sys.argv  # two recipes back to back in one stream: new parameter sets, entropy coder, slice groups, picture size at the second IDR picture
 args = [a for a in args if a not in (str(seed0), str(BATCH))] or args[:1]
@@ -85,8 +86,6 @@ def draw():
     return kw
 
 
-if GPU and FIELDS:
-    sys.exit("--fields is an oracle sweep: the product refuses field pictures (H264MI_EUNSUPPORTED)")
 if GPU:
     import h264decode_amd as H
 else:
@@ -109,8 +108,21 @@ for t in range(N if BATCH == 1 and not CONCAT else 0):
             nsl = max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1))
             for x in ((str([2, 3, 4, 5, 7, 9, 13, 31, 64, 100, 512][int(rng.integers(0, 11))]),) if XR else ("256", "0")):
                 os.environ["H264MI_X_WGS"] = x
-                dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=kw["frames"], max_slices_per_frame=nsl)
-                if SPLIT:
+                # (a field is a picture of its own for the decoder's batch limit; fed picture by picture the co-located field of a stream's first B field
+                # can lie more than one call back: its motion must be kept from the start -- b_pictures)
+                dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=kw["frames"] * (2 if kw.get("field_pics") else 1), max_slices_per_frame=nsl,
+                                b_pictures=1 if (SPLIT and kw.get("field_pics") and kw.get("bframes")) else 0)
+                if SPLIT and kw.get("field_pics"):  # pieces of whole pictures (the generator's sizes are per FRAME)
+                    sp = H.AccessUnitSplitter(max_units_per_chunk=1)
+                    aus = sp.feed(s) + sp.flush()
+                    got, k = [], 0
+                    while k < len(aus):
+                        n = int(rng.integers(1, len(aus) - k + 1))
+                        dec.decode([b"".join(aus[k:k + n])])
+                        got.append(dec.read_frames(0, crop=False))
+                        k += n
+                    out = np.concatenate([g for g in got if g.size])
+                elif SPLIT:
                     got, pos, k = [], 0, 0
                     while k < len(sizes):
                         n = int(rng.integers(1, len(sizes) - k + 1))
@@ -151,7 +163,7 @@ for t in range(N if CONCAT else 0):
         if GPU:
             for x in ("256", "0"):
                 os.environ["H264MI_X_WGS"] = x
-                dec = H.Decoder(max_streams=1, max_width=max(d[0] for d in dims), max_height=max(d[1] for d in dims), max_frames_per_batch=sum(kw["frames"] for kw, _ in parts),
+                dec = H.Decoder(max_streams=1, max_width=max(d[0] for d in dims), max_height=max(d[1] for d in dims), max_frames_per_batch=sum(kw["frames"] * (2 if kw.get("field_pics") else 1) for kw, _ in parts),
                                 max_slices_per_frame=max(max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1)) for kw, _ in parts))
                 got = []
                 if SPLIT:  # ... and in pieces of whole access units: the change may fall on a batch boundary or inside a batch
@@ -195,7 +207,7 @@ for t in range(N if BATCH > 1 else 0):  # several streams per decoder
     try:
         for x in ("256", "0"):
             os.environ["H264MI_X_WGS"] = x
-            dec = H.Decoder(max_streams=BATCH, max_width=W, max_height=Hc, max_frames_per_batch=max(kw["frames"] for kw in kws),
+            dec = H.Decoder(max_streams=BATCH, max_width=W, max_height=Hc, max_frames_per_batch=max(kw["frames"] * (2 if kw.get("field_pics") else 1) for kw in kws),
                             max_slices_per_frame=max(max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1)) for kw in kws))
             dec.decode([g[0] for g in gen])
             for i, (kw, g) in enumerate(zip(kws, gen)):
