@@ -112,6 +112,7 @@ struct Shared {
     int8_t sub_type[4];
     uint8_t cur_cbf_dc, pad[3];
     int16_t ref_slot[NL][MI_MAX_REFS]; // frame-pool slot per ref_idx of this slice
+    uint32_t skip_tmpl[32];            // the MbRec of a P_Skip macroblock as far as it is the same for the whole slice (pskip_fast)
 #if MI_ENT_B
     uint32_t col[20];          // ColRec of the co-located macroblock (8.4.1.2.1)
     alignas(4) int16_t dmv[2][16][2]; // direct-predicted sub-macroblocks of a B_8x8 macroblock, until their turn comes (6.4.11.7)
@@ -167,6 +168,7 @@ struct Ent {
     uint32_t aw, bw;         // first dword of the left / upper TopInfo (Nb)
     int v_ipm;               // lanes 0..29: Intra4x4/8x8PredMode grid (same layout and codes as Shared::ipm_c)
     int qp, prev_dqp_nz, mbx, mby, cur_type, err;
+    uint32_t qpw0, qpw1;     // QP_Y << 16 | QP_C(Cb) << 24 and QP_C(Cr) of the current QP_Y: the record's bytes 2..4 (set_qp)
     int cabac, islice, wmb, hmb;
     int cip, t8x8_mode, cqp_off0, cqp_off1, nref;
     uint64_t mb_base;
@@ -333,17 +335,20 @@ FI void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
 FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     MI_COUNT_BIN(e);
     const int idx = RFL(idx_);
+    // A context state is pStateIdx | valMPS << 6: it selects its own table lane as it stands (v_readlane takes the select modulo 64), so the
+    // chain state -> table entries has no scalar instruction in it.
     const uint32_t st = RDL(reg, idx);
-    const uint32_t p = st >> 1;
-    const uint32_t rl4 = RDL(e.v_rlps, p), tr = RDL(e.v_trans, p);
+    const uint32_t rl4 = RDL(e.v_rlps, st), tr = RDL(e.v_trans, st);
     // everything else runs on the vector side (the CU's single scalar ALU is the scarce unit): st is pinned there
     uint32_t vst = st;
     VGPR(vst);
-    const uint32_t mps = vst & 1;
-    // the two candidate successor states (v_trans holds the LPS successor for valMPS 0; bit 0 flips with valMPS)
-    const uint32_t next_lps = tr ^ mps;
-    const uint32_t next_mps = min(vst + 2, 124 | mps);
-    const uint32_t rlps = __builtin_amdgcn_ubfe(rl4, (e.range >> 3) & 24, 8);
+    const uint32_t mps = __builtin_amdgcn_ubfe(vst, 6, 1); // (bits 8 and up of a state register may hold leftovers of the table word: every use masks them)
+    // the two candidate successor states: v_trans holds the LPS successor of valMPS 0 (bit 6 set where the MPS flips: pStateIdx 0) in its low
+    // byte and, one byte up, what the MPS path adds to the state (1; 0 at pStateIdx 62)
+    const uint32_t next_lps = tr ^ (vst & 64u);
+    const uint32_t next_mps = vst + __builtin_amdgcn_alignbyte(0u, tr, 1u); // (tr >> 8 on the vector side: the scalar ALU is the scarce unit)
+    // rangeTabLPS[pStateIdx][(codIRange >> 6) & 3]: codIRange >> 6 is 4..7, which as a v_perm selector picks byte 0..3 of the first operand
+    const uint32_t rlps = __builtin_amdgcn_perm(rl4, 0u, e.range >> 6);
     const uint32_t rmps = e.range - rlps;
     const uint32_t scaled = rmps << e.avail;
     const bool lps = e.value >= scaled;
@@ -397,6 +402,11 @@ FI int cabac_egk(Ent &e, int k) {
     return v;
 }
 
+FI void set_qp(Ent &e, int qp) { // QP_Y and the two chroma QPs it maps to (8.5.8: Table 8-15 on qP_I = Clip3(0, 51, QP_Y + chroma_qp_index_offset))
+    e.qp = qp;
+    e.qpw0 = static_cast<uint32_t>(qp) << 16 | RDL(e.v_qpc, min(max(qp + e.cqp_off0, 0), 51)) << 24;
+    e.qpw1 = RDL(e.v_qpc, min(max(qp + e.cqp_off1, 0), 51));
+}
 // ------------------------------------------------------------------ neighbour MBs
 FI bool nb_ok(const Ent &e, int i) { return e.s->nb[i].type != MBT_NONE && (i != NB_TOP + 1 || e.mbx + 1 < e.wmb); } // macroblock D, A, B, C available
 // the left / upper macroblock's type, transform flag, cbp and chroma mode as one scalar word (first dword of TopInfo)
@@ -796,8 +806,7 @@ FI void set_part(Ent &e, const int L, int bx, int by, int w, int h, int ref, int
 
 // ------------------------------------------------------------------ per-MB neighbour caches
 FI void fill_caches(Ent &e) {
-    Shared *s = e.s;
-    e.aw = RFL(*reinterpret_cast<const uint32_t *>(&s->nb[NB_LEFT])), e.bw = RFL(*reinterpret_cast<const uint32_t *>(&s->nb[NB_TOP]));
+    Shared *s = e.s; // (e.aw / e.bw -- the first dword of the left / upper entry -- were read by the macroblock loop: the skip decision needs only them)
     const bool a_ok = (e.aw & 255) != 0, b_ok = (e.bw & 255) != 0;
     const int cip = e.cip;
     int l = LANE;
@@ -1031,6 +1040,76 @@ FI void read_mv(Ent &e, const int L, int p) {
     predict_mv(e, L, bx, by, w, ref, shape, px, py);
     set_part(e, L, bx, by, w, h, ref, px + d[0], py + d[1], d[0], d[1]);
 }
+
+// ------------------------------------------------------------------ P_Skip without the general machinery
+// A skipped macroblock of a P slice has no syntax: its vector comes from the neighbours A, B, C / D (8.4.1.1, 8.4.1.3 with refIdx 0), its
+// record and its edge entry are that vector sixteen / four times over next to constants.  Everything is taken straight from the four
+// neighbour entries (no neighbour caches are built, no record is staged in LDS): lanes 0..11 hold one dword of the new edge entry, lanes
+// 32..63 one dword of the record.  A quarter of the macroblocks of a typical P picture take this path.
+#if !MI_ENT_B
+FI void pskip_fast(Ent &e) {
+    Shared *s = e.s;
+    int l = LANE;
+    OPAQUE(l);
+    const uint32_t *nbw = reinterpret_cast<const uint32_t *>(s->nb); // TOP_DW dwords per entry: [0] type.., [5] ref_idx, [6..9] vectors
+    const uint32_t tA = e.aw, tB = e.bw, tC = nbw[(NB_TOP + 1) * TOP_DW], tD = nbw[NB_TL * TOP_DW];
+    const uint32_t rA = nbw[NB_LEFT * TOP_DW + 5], rB = nbw[NB_TOP * TOP_DW + 5], rC = nbw[(NB_TOP + 1) * TOP_DW + 5], rD = nbw[NB_TL * TOP_DW + 5];
+    const uint32_t mA = nbw[NB_LEFT * TOP_DW + 6], mB = nbw[NB_TOP * TOP_DW + 6], mC = nbw[(NB_TOP + 1) * TOP_DW + 6], mD = nbw[NB_TL * TOP_DW + 9];
+    // what fill_caches() would enter for the four blocks: refIdx (-2 unavailable, -1 intra) and vector (0 unless inter)
+    auto ref_of = [](uint32_t t, uint32_t r, int byte) {
+        const int type = static_cast<int>(t & 255u);
+        return type == MBT_NONE ? -2 : (MB_IS_INTER(type) ? static_cast<int>(static_cast<int8_t>((r >> (8 * byte)) & 255u)) : -1);
+    };
+    auto mv_of = [](uint32_t t, uint32_t m) { return MB_IS_INTER(static_cast<int>(t & 255u)) ? m : 0u; };
+    const int ra = ref_of(tA, rA, 0), rb = ref_of(tB, rB, 0);
+    const bool c_ok = e.mbx + 1 < e.wmb && (tC & 255u) != MBT_NONE; // C, else D (6.4.11.7)
+    const int rc = c_ok ? ref_of(tC, rC, 0) : ref_of(tD, rD, 1);
+    const uint32_t va = mv_of(tA, mA), vb = mv_of(tB, mB), vc = c_ok ? mv_of(tC, mC) : mv_of(tD, mD);
+    uint32_t mvw = 0;
+    const bool zero = ra == -2 || rb == -2 || (ra == 0 && va == 0) || (rb == 0 && vb == 0); // 8.4.1.1
+    if (!zero) { // 8.4.1.3.1 with refIdx 0: the one neighbour that uses picture 0, else the median
+        const int na = ra == 0, nb_ = rb == 0, nc = rc == 0;
+        if (na + nb_ + nc == 1)
+            mvw = na ? va : (nb_ ? vb : vc);
+        else {
+            const int ax = static_cast<int16_t>(va & 0xffffu), ay = static_cast<int32_t>(va) >> 16, bx = static_cast<int16_t>(vb & 0xffffu), by = static_cast<int32_t>(vb) >> 16;
+            const int cx = static_cast<int16_t>(vc & 0xffffu), cy = static_cast<int32_t>(vc) >> 16;
+            mvw = (static_cast<uint32_t>(median3(ax, bx, cx)) & 0xffffu) | (static_cast<uint32_t>(median3(ay, by, cy)) << 16);
+        }
+    }
+    e.cur_type = MBT_PSKIP;
+    e.prev_dqp_nz = 0;
+    // intra-prediction availability of the record (never looked at for an inter macroblock; kept so that records do not depend on the path taken)
+    int av = 0;
+    {
+        const int cip = e.cip, ta = static_cast<int>(tA & 255u), tb = static_cast<int>(tB & 255u), td = static_cast<int>(tD & 255u), tc = c_ok ? static_cast<int>(tC & 255u) : MBT_NONE;
+        if (ta != MBT_NONE && !(cip && MB_IS_INTER(ta))) av |= MI_AV_LEFT;
+        if (tb != MBT_NONE && !(cip && MB_IS_INTER(tb))) av |= MI_AV_TOP;
+        if (td != MBT_NONE && !(cip && MB_IS_INTER(td))) av |= MI_AV_TOPLEFT;
+        if (tc != MBT_NONE && !(cip && MB_IS_INTER(tc))) av |= MI_AV_TOPRIGHT;
+    }
+    // ---- the new edge entry (the same for the row below and for the macroblock to the right), the window on the row above moves on ----
+    if (l < TOP_DW) {
+        const uint32_t row = MI_ENT_FMO ? static_cast<uint32_t>(e.mby + 1) << 16 : 0u;
+        const uint32_t nw = l == 0 ? static_cast<uint32_t>(MBT_PSKIP) : (l == 1 ? row : (l == 2 ? 0xFFFFFFFFu : ((l >= 6 && l < 10) ? mvw : 0u)));
+        uint32_t *tl = reinterpret_cast<uint32_t *>(&s->nb[NB_TL]), *tp = reinterpret_cast<uint32_t *>(&s->nb[NB_TOP]), *tr = reinterpret_cast<uint32_t *>(&s->nb[NB_TOP + 1]);
+        const uint32_t old_top = tp[l], w1 = tr[l];
+        tl[l] = old_top;
+        tp[l] = w1;
+        tr[l] = e.pre_top;
+        reinterpret_cast<uint32_t *>(&s->nb[NB_LEFT])[l] = nw;
+        reinterpret_cast<uint32_t *>(e.top + e.mbx)[l] = nw;
+        e.pre_top = top_load(e, e.mbx + 3, l);
+    } else if (l >= 32) { // ---- the record: one dword per lane ----
+        const int k = l - 32;
+        const uint32_t t = s->skip_tmpl[k];
+        const uint32_t w = k == 0 ? (static_cast<uint32_t>(MBT_PSKIP) | e.qpw0) : (k == 1 ? e.qpw1 : (k == 2 ? (t | static_cast<uint32_t>(av) << 16) : ((k >= 12 && k < 28) ? mvw : t)));
+        const uint64_t mbi = e.mb_base + static_cast<uint64_t>(e.mby) * e.wmb + e.mbx;
+        reinterpret_cast<uint32_t *>(e.mbrec + mbi)[k] = w;
+    }
+    LDS_SYNC();
+}
+#endif
 
 // ------------------------------------------------------------------ macroblock_layer() 7.3.5
 FI void decode_mb(Ent &e, int skipped) {
@@ -1393,7 +1472,7 @@ FI void decode_mb(Ent &e, int skipped) {
                     dqp = get_se(e);
                 if (dqp < -26 || dqp > 25) e.err = 24, dqp = 0;
                 e.prev_dqp_nz = dqp != 0;
-                e.qp = (e.qp + dqp + 52) % 52;
+                if (dqp) set_qp(e, (e.qp + dqp + 52) % 52);
                 MI_T(e, 1);
                 MI_R0(e);
                 if (cabac)
@@ -1592,7 +1671,6 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     if (e.islice) __builtin_amdgcn_s_setprio(MI_ENT_ISLICE_PRIO);
 #endif
     e.wmb = RFL(static_cast<int>(pd->wmb)), e.hmb = RFL(static_cast<int>(pd->hmb));
-    e.qp = RFL(static_cast<int>(sd->slice_qp));
     e.cip = RFL(static_cast<int>(pd->cip)), e.t8x8_mode = RFL(static_cast<int>(pd->t8x8_mode));
     e.cqp_off0 = RFL(static_cast<int>(pd->cqp_off[0])), e.cqp_off1 = RFL(static_cast<int>(pd->cqp_off[1]));
     e.nref = RFL(static_cast<int>(sd->num_ref_idx_active));
@@ -1606,7 +1684,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
       // (pStateIdx << 1 | valMPS) after an LPS for valMPS 0 -- XOR with valMPS gives the other one (pStateIdx 0 flips the MPS)
         const uint8_t *rl = tab->range_lps[l];
         e.v_rlps = rl[0] | (rl[1] << 8) | (rl[2] << 16) | (static_cast<uint32_t>(rl[3]) << 24);
-        e.v_trans = (static_cast<uint32_t>(tab->trans_lps[l]) << 1) | (l == 0 ? 1u : 0u);
+        e.v_trans = static_cast<uint32_t>(tab->trans_lps[l]) | (l == 0 ? 64u : 0u) | (l < 62 ? 256u : 0u);
     }
     // coefficient scans of the picture (8.5.6, 8.5.7): zig-zag, or the field scan in a field picture (h264/slice.go:867-872 field_pic_flag)
     const uint8_t *scan4 = pd->field ? tab->fieldscan4 : tab->zigzag4, *scan8 = pd->field ? tab->fieldscan8 : tab->zigzag8;
@@ -1614,6 +1692,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     e.v_zzac = scan4[(l + 1) & 15];
     e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l);
     e.v_qpc = tab->qpc[l < 52 ? l : 51];
+    set_qp(e, RFL(static_cast<int>(sd->slice_qp)));
     e.v_step = step_word(l);
     e.nzm = e.unm = 0;
     e.aw = e.bw = 0;
@@ -1652,6 +1731,13 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         sh.rec.slice_in_pic = sd->slice_in_pic;
         sh.rec.slice_idx = slice_no;
         sh.rec.refslot1[0] = sh.rec.refslot1[1] = sh.rec.refslot1[2] = sh.rec.refslot1[3] = -1; // (the B build rewrites them per macroblock)
+    }
+    if (l < 32) { // the record of a P_Skip macroblock, as far as it is a constant of the slice (pskip_fast adds QP, availability and the vector)
+        const uint32_t slot0 = static_cast<uint16_t>(sd->ref_slot[0]);
+        sh.skip_tmpl[l] = l == 2 ? static_cast<uint32_t>(sd->dbf_idc) << 24
+                                 : (l == 3 ? (static_cast<uint32_t>(static_cast<uint8_t>(sd->alpha_off)) | static_cast<uint32_t>(static_cast<uint8_t>(sd->beta_off)) << 8 |
+                                              static_cast<uint32_t>(sd->slice_in_pic) << 16)
+                                           : ((l == 9 || l == 10) ? (slot0 | slot0 << 16) : (l == 11 ? slice_no : (l >= 30 ? 0xFFFFFFFFu : 0u))));
     }
     for (int i = l; i < e.wmb * TOP_DW; i += 64) reinterpret_cast<uint32_t *>(e.top)[i] = 0; // all row-above entries: type NONE
     if (l < TOP_DW) reinterpret_cast<uint32_t *>(&sh.nb[NB_LEFT])[l] = 0, reinterpret_cast<uint32_t *>(&sh.nb[NB_TL])[l] = 0;
@@ -1708,8 +1794,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         // the co-located macroblock's record (80 bytes), consumed by direct_pred(); "intra" when there is no such picture
         e.v_col = (e.col && l < 20) ? e.col[static_cast<size_t>(addr) * 20 + l] : ((l >= 16 && l < 19) ? 0xFFFFFFFFu : 0u);
 #endif
-        fill_caches(e);
-        MI_T(e, 0);
+        e.aw = RFL(*reinterpret_cast<const uint32_t *>(&sh.nb[NB_LEFT])), e.bw = RFL(*reinterpret_cast<const uint32_t *>(&sh.nb[NB_TOP]));
         int skipped = 0;
         if (!e.islice) {
             if (e.cabac) {
@@ -1728,7 +1813,18 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
                 }
             }
         }
-        decode_mb(e, skipped);
+#if !MI_ENT_B
+        if (skipped) {
+            MI_T(e, 1);
+            pskip_fast(e);
+        } else
+#endif
+        {
+            MI_T(e, 1);
+            fill_caches(e);
+            MI_T(e, 0);
+            decode_mb(e, skipped);
+        }
         MI_T(e, 3);
         if (e.err) break; // the record of this macroblock cannot be trusted: it is blanked with the rest of the range
         n_mbs++;

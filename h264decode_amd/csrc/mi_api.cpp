@@ -52,7 +52,8 @@ static void build_tables(DevTables *t) {
             for (int i = 0; i < MI_NCTX; i++) {
                 int pre = ((mi_cabac_mn[set][i][0] * qp) >> 4) + mi_cabac_mn[set][i][1];
                 pre = std::min(std::max(pre, 1), 126);
-                t->ctx_init[set][qp][i] = pre <= 63 ? static_cast<uint8_t>((63 - pre) << 1) : static_cast<uint8_t>(((pre - 64) << 1) | 1);
+                // pStateIdx in bits 0..5, valMPS in bit 6: the state is a lane number as it stands (v_readlane takes its select modulo 64)
+                t->ctx_init[set][qp][i] = pre <= 63 ? static_cast<uint8_t>(63 - pre) : static_cast<uint8_t>((pre - 64) | 64);
             }
     memcpy(t->sig8x8, mi_sig8x8_ctx, 63);
     memcpy(t->last8x8, mi_last8x8_ctx, 63);

@@ -192,7 +192,7 @@ typedef struct {
 typedef struct {
     uint8_t range_lps[64][4]; /* Table 9-44 */
     uint8_t trans_lps[64];    /* Table 9-45 */
-    uint8_t ctx_init[4][52][464]; /* (pStateIdx<<1)|valMPS for every (table set, SliceQPY, ctxIdx): 9.3.1.1 */
+    uint8_t ctx_init[4][52][464]; /* pStateIdx | valMPS << 6 for every (table set, SliceQPY, ctxIdx): 9.3.1.1 */
     uint8_t sig8x8[64], last8x8[64];
     uint8_t zigzag4[16], zigzag8[64];
     uint8_t fieldscan4[16], fieldscan8[64]; /* Tables 8-12 / 8-13, field scan: what a field picture's blocks are scanned in */
