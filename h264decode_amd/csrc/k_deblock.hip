@@ -91,6 +91,8 @@ typedef __attribute__((address_space(1))) v4u g_uint4;
 typedef __attribute__((address_space(1))) v2u g_uint2;
 #define GLD16(base, off) (*reinterpret_cast<const g_uint4 *>((base) + (off)))
 #define GLD8(base, off) (*reinterpret_cast<const g_uint2 *>((base) + (off)))
+// (Streaming / non-temporal stores and DbPrm loads were tried in round 4 to keep the XCD's L2 for the sample lines: no faster, and WRITE_SIZE grew
+// from 0.85 to 1.10 GB per launch -- partial lines leave the L2 before the rest of the line arrives.)
 #define GST16(base, off, v) (*reinterpret_cast<g_uint4 *>((base) + (off)) = (v))
 #define GST8(base, off, v) (*reinterpret_cast<g_uint2 *>((base) + (off)) = (v))
 typedef __attribute__((address_space(1))) uint32_t g_uint1;

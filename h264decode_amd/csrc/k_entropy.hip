@@ -113,6 +113,8 @@ struct Shared {
     uint8_t cur_cbf_dc, pad[3];
     int16_t ref_slot[NL][MI_MAX_REFS]; // frame-pool slot per ref_idx of this slice
     uint32_t skip_tmpl[32];            // the MbRec of a P_Skip macroblock as far as it is the same for the whole slice (pskip_fast)
+    uint32_t role[64];                 // what each lane does in fill_caches (build_role)
+    uint8_t coded[64];                 // CABAC neighbourhood, one entry per bit position of parse_residual_cabac's layout: 1 coded, 2 unavailable (fill_caches)
 #if MI_ENT_B
     uint32_t col[20];          // ColRec of the co-located macroblock (8.4.1.2.1)
     alignas(4) int16_t dmv[2][16][2]; // direct-predicted sub-macroblocks of a B_8x8 macroblock, until their turn comes (6.4.11.7)
@@ -164,7 +166,6 @@ struct Ent {
     uint32_t v_cat0, v_cat1; // lane ctxBlockCat: packed block-category parameters (cat_word0/1)
     uint32_t v_qpc, v_refslot; // lane i: QPc table entry / frame slot of ref_idx i
     uint32_t v_step;         // lane = residual step: step_word()
-    uint64_t nzm, unm;       // coded / unavailable masks of the neighbourhood (parse_residual_cabac)
     uint32_t aw, bw;         // first dword of the left / upper TopInfo (Nb)
     int v_ipm;               // lanes 0..29: Intra4x4/8x8PredMode grid (same layout and codes as Shared::ipm_c)
     int qp, prev_dqp_nz, mbx, mby, cur_type, err;
@@ -624,7 +625,7 @@ FI int cbf_inc_of(const Ent &e, uint8_t a, uint8_t b) { // 9.3.3.1.1.9
 //   bits  0..29  luma 4x4 blocks, 6-wide grid GI(bx, by) (column 0 = left MB, row 0 = MB above)
 //   bits 32..49  chroma AC blocks, two 3x3 grids (32 + 9 * plane + 3 * (by + 1) + bx + 1)
 //   bits 50..52 / 53..55  DC flags (Intra16x16 luma, Cb, Cr) of the left / upper macroblock, 56..58 of this one
-// fill_caches() ballots "coded" (e.nzm) and "unavailable" (e.unm); unavailable counts as coded for intra
+// fill_caches() leaves "coded" (1) / "unavailable" (2) per bit position in Shared::coded; unavailable counts as coded for intra
 // macroblocks.  The schedule is a bit set of steps (0 Intra16x16 DC, 1..16 luma z-order, 17/18 chroma DC,
 // 19..26 chroma AC) and a per-lane descriptor table: A bit | B bit << 6 | own bit << 12 | dst/4 << 18 | kind << 26.
 FI uint32_t step_word(int st) {
@@ -648,7 +649,12 @@ FI uint32_t step_word(int st) {
 FI void parse_residual_cabac(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
     Shared *s = e.s;
     const int i16 = e.cur_type == MBT_I16x16;
-    uint64_t nzm = e.nzm | (MB_IS_INTRA(e.cur_type) ? e.unm : 0);
+    // the neighbourhood as one flag per LANE (lane = bit position of the layout above): a block's two context bits are two v_readlane with the
+    // step word as lane select, a coded block sets its lane -- the scalar ALU, the scarce unit, does none of it
+    int nl = LANE;
+    OPAQUE(nl);
+    const uint32_t cd = s->coded[nl];
+    uint32_t vnz = (cd == 1 || (cd == 2 && MB_IS_INTRA(e.cur_type))) ? 1u : 0u;
     // luma steps of the coded 8x8 blocks: all four 4x4 blocks, or the first one standing for the 8x8 block
     const uint32_t spread = (cbp_luma & 1) | (cbp_luma & 2) << 3 | (cbp_luma & 4) << 6 | (cbp_luma & 8) << 9;
     uint32_t steps = static_cast<uint32_t>(i16) | (spread * (t8x8 ? 1u : 15u)) << 1;
@@ -662,10 +668,14 @@ FI void parse_residual_cabac(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
         const int cat = static_cast<int>((cats >> ((d >> 26) * 4)) & 15);
         const int own = static_cast<int>((d >> 12) & 63);
         const int dst = cat == 5 ? (step - 1) * 16 : static_cast<int>((d >> 18) & 255) * 4;
-        const int inc = static_cast<int>((nzm >> (d & 63)) & 1) + 2 * static_cast<int>((nzm >> ((d >> 6) & 63)) & 1);
+        const int inc = static_cast<int>(RDL(vnz, d) + 2 * RDL(vnz, d >> 6)); // (the lane select is taken modulo 64)
         slide_window(e); // (see cavlc: a macroblock_layer() beyond A.3.1's 3200 bits must not run off the window; one block is at most 92 words)
-        if (cabac_residual(e, s->coef + dst, cat, inc)) nzm |= (cat == 5 ? 0xC3ull : 1ull) << own;
+        if (cabac_residual(e, s->coef + dst, cat, inc)) {
+            const int t = nl - own; // an 8x8 block stands for its four 4x4 positions: own, own + 1, own + 6, own + 7
+            vnz = (t == 0 || (cat == 5 && (t == 1 || t == 6 || t == 7))) ? 1u : vnz;
+        }
     }
+    const uint64_t nzm = __builtin_amdgcn_ballot_w64(vnz != 0);
     // results: deblocking mask (raster 4x4), DC flags and the 0/1 "coded" grids the neighbours will read
     const uint32_t lo = static_cast<uint32_t>(nzm);
     const uint32_t nzmask = ((lo >> GI(0, 0)) & 15) | ((lo >> GI(0, 1)) & 15) << 4 | ((lo >> GI(0, 2)) & 15) << 8 | ((lo >> GI(0, 3)) & 15) << 12;
@@ -673,7 +683,7 @@ FI void parse_residual_cabac(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
     s->cur_cbf_dc = static_cast<uint8_t>((nzm >> 56) & 7);
     int l = LANE;
     OPAQUE(l); // keeps lane-dependent addresses from being hoisted out of the macroblock loop and spilled
-    const int bit = static_cast<int>((nzm >> l) & 1);
+    const int bit = static_cast<int>(vnz);
     if (l < 30) {
         const int gx = l % 6 - 1, gy = l / 6 - 1;
         if (gx >= 0 && gx < 4 && gy >= 0) s->nnz_c[l] = static_cast<uint8_t>(bit);
@@ -804,6 +814,47 @@ FI void set_part(Ent &e, const int L, int bx, int by, int w, int h, int ref, int
 }
 #define PART(bx, by, w, h, shape) static_cast<uint16_t>((bx) | ((by) << 2) | (((w)-1) << 4) | (((h)-1) << 6) | ((shape) << 8))
 
+// What a lane does in fill_caches() never changes: worked out once per slice (build_roles) into Shared::role, so that the macroblock loop
+// reads one word instead of redoing the divisions and comparisons (about 90 instructions per macroblock).
+//   lanes 0..29 (6-wide luma grid): [8:0] byte offset of the neighbour's entry in nb[] (NO_SRC: none) | k << 9 (index in its edge arrays) |
+//                                   edge << 11 (its nnz is an edge value) | interior << 12 | topright << 13 (needs mbx + 1 < wmb)
+//   lanes 32..49 (two 3x3 chroma grids): [8:0] byte offset of the source nnz byte in nb[] (NO_SRC: none) | interior << 12 | from_left << 14 |
+//                                   index in nnzc_c (flat) << 16
+//   lanes 50..55 (DC flags): [8:0] byte offset of the neighbour's cbf_dc byte | bit << 9 | from_left << 14
+#define NO_SRC 0x1FFu
+FI uint32_t build_role(int l) {
+    const uint32_t TB = static_cast<uint32_t>(sizeof(TopInfo));
+    if (l < 30) {
+        const int gx = l % 6 - 1, gy = l / 6 - 1; // block coordinates relative to the macroblock
+        uint32_t off = NO_SRC, k = 0, edge = 0, tr = 0;
+        if (gy < 0 && gx >= 0 && gx < 4)
+            off = NB_TOP * TB, k = static_cast<uint32_t>(gx), edge = 1;
+        else if (gx < 0 && gy >= 0)
+            off = NB_LEFT * TB, k = static_cast<uint32_t>(gy), edge = 1;
+        else if (gy < 0 && gx < 0)
+            off = NB_TL * TB, k = 3;
+        else if (gy < 0 && gx == 4)
+            off = (NB_TOP + 1) * TB, k = 0, tr = 1;
+        const uint32_t interior = gx >= 0 && gx < 4 && gy >= 0;
+        return off | k << 9 | edge << 11 | interior << 12 | tr << 13;
+    }
+    if (l >= 32 && l < 50) {
+        const int i = l - 32, cpl = i / 9, g = i % 9, gx = g % 3 - 1, gy = g / 3 - 1;
+        uint32_t off = NO_SRC, left = 0;
+        if (gy < 0 && gx >= 0)
+            off = NB_TOP * TB + static_cast<uint32_t>(offsetof(TopInfo, nnz)) + 4 + cpl * 2 + gx;
+        else if (gx < 0 && gy >= 0)
+            off = NB_LEFT * TB + static_cast<uint32_t>(offsetof(TopInfo, nnz)) + 4 + cpl * 2 + gy, left = 1;
+        const uint32_t interior = gx >= 0 && gy >= 0;
+        return off | interior << 12 | left << 14 | static_cast<uint32_t>(cpl * 12 + g) << 16;
+    }
+    if (l >= 50 && l < 56) {
+        const uint32_t left = l < 53;
+        return ((left ? NB_LEFT : NB_TOP) * TB + static_cast<uint32_t>(offsetof(TopInfo, cbf_dc))) | static_cast<uint32_t>((l - 50) % 3) << 9 | left << 14;
+    }
+    return NO_SRC;
+}
+
 // ------------------------------------------------------------------ per-MB neighbour caches
 FI void fill_caches(Ent &e) {
     Shared *s = e.s; // (e.aw / e.bw -- the first dword of the left / upper entry -- were read by the macroblock loop: the skip decision needs only them)
@@ -811,28 +862,20 @@ FI void fill_caches(Ent &e) {
     const int cip = e.cip;
     int l = LANE;
     OPAQUE(l); // keeps lane-dependent addresses from being hoisted out of the macroblock loop and spilled
+    const uint32_t role = s->role[l], off = role & NO_SRC;
+    const uint8_t *nbb = reinterpret_cast<const uint8_t *>(s->nb);
     int coded = 0; // this lane's bit of the CABAC neighbourhood masks: 1 coded, 2 unavailable (see parse_residual_cabac)
     if (l < 30) {
-        int gx = l % 6 - 1, gy = l / 6 - 1; // block coordinates relative to the MB
         int8_t ipm = -2;
         uint8_t nnz = 0x80;
-        int ni = -1;
-        int k = 0; // index inside the neighbour's edge arrays
-        int edge = 0;
-        if (gy < 0 && gx >= 0 && gx < 4)
-            ni = NB_TOP, k = gx, edge = 1;
-        else if (gx < 0 && gy >= 0)
-            ni = NB_LEFT, k = gy, edge = 1;
-        else if (gy < 0 && gx < 0)
-            ni = NB_TL, k = 3;
-        else if (gy < 0 && gx == 4 && e.mbx + 1 < e.wmb)
-            ni = NB_TOP + 1, k = 0;
-        const TopInfo *n = &s->nb[ni < 0 ? 0 : ni];
-        const bool n_ok = ni >= 0 && n->type != MBT_NONE;
+        const int k = static_cast<int>((role >> 9) & 3u); // index inside the neighbour's edge arrays
+        const bool has = off != NO_SRC && !((role >> 13) & 1u && e.mbx + 1 >= e.wmb);
+        const TopInfo *n = reinterpret_cast<const TopInfo *>(nbb + (off != NO_SRC ? off : 0u));
+        const bool n_ok = has && n->type != MBT_NONE;
         if (n_ok) {
             const int inter = MB_IS_INTER(n->type);
             if (!(cip && inter)) ipm = (n->type == MBT_I4x4 || n->type == MBT_I8x8) ? n->ipm[k] : static_cast<int8_t>(2);
-            if (edge) nnz = n->nnz[k];
+            if ((role >> 11) & 1u) nnz = n->nnz[k];
         }
 #pragma unroll
         for (int L = 0; L < NL; L++) {
@@ -853,7 +896,7 @@ FI void fill_caches(Ent &e) {
             s->mv_c[L][l][0] = mvx, s->mv_c[L][l][1] = mvy;
             s->mvd_c[L][l][0] = mvdx, s->mvd_c[L][l][1] = mvdy;
         }
-        if (gx >= 0 && gx < 4 && gy >= 0) { // interior: current MB, nothing decoded yet
+        if ((role >> 12) & 1u) { // interior: current MB, nothing decoded yet
             nnz = 0;
             ipm = -1;
         }
@@ -862,30 +905,20 @@ FI void fill_caches(Ent &e) {
         e.v_ipm = ipm;
         s->nnz_c[l] = nnz;
     } else if (l >= 32 && l < 50) {
-        int i = l - 32, cpl = i / 9, g = i % 9, gx = g % 3 - 1, gy = g / 3 - 1;
-        uint8_t v = 0x80;
-        if (gy < 0 && gx >= 0) {
-            if (b_ok) v = s->nb[NB_TOP].nnz[4 + cpl * 2 + gx];
-        } else if (gx < 0 && gy >= 0) {
-            if (a_ok) v = s->nb[NB_LEFT].nnz[4 + cpl * 2 + gy];
-        } else if (gx >= 0 && gy >= 0)
-            v = 0;
+        const bool ok = off != NO_SRC && (((role >> 14) & 1u) ? a_ok : b_ok);
+        const uint8_t v = ((role >> 12) & 1u) ? static_cast<uint8_t>(0) : (ok ? nbb[off != NO_SRC ? off : 0u] : static_cast<uint8_t>(0x80));
         coded = (v & 0x80) ? 2 : (v != 0);
-        s->nnzc_c[cpl][g] = v;
+        (&s->nnzc_c[0][0])[(role >> 16) & 31u] = v;
     } else if (l >= 50 && l < 56) { // DC coded_block_flags of the left (50..52) / upper (53..55) macroblock: Intra16x16 luma, Cb, Cr
-        const bool ok = l < 53 ? a_ok : b_ok;
-        coded = ok ? (s->nb[l < 53 ? NB_LEFT : NB_TOP].cbf_dc >> ((l - 50) % 3)) & 1 : 2;
+        const bool ok = ((role >> 14) & 1u) ? a_ok : b_ok;
+        coded = ok ? (nbb[off] >> ((role >> 9) & 3u)) & 1 : 2;
     } else if (l >= 56) {
         s->refs8[(l - 56) >> 2][l & 3] = -1;
         if (l < 60) s->sub_type[l - 56] = 0;
         if (l == 60) s->cur_cbf_dc = 0;
     }
-    e.nzm = __builtin_amdgcn_ballot_w64(coded == 1);
-    e.unm = __builtin_amdgcn_ballot_w64(coded == 2);
-    { // zero the coefficient staging block: 416 int16 = 208 dwords
-        uint32_t *cz = reinterpret_cast<uint32_t *>(s->coef);
-        for (int i = l; i < MI_COEF_PER_MB / 2; i += 64) cz[i] = 0;
-    }
+    s->coded[l] = static_cast<uint8_t>(coded);
+    // (the coefficient staging block is all zero here: it is zeroed once per slice, and a macroblock clears the blocks it filled when it has stored them)
     LDS_SYNC();
 }
 
@@ -1616,6 +1649,8 @@ FI void decode_mb(Ent &e, int skipped) {
     if (l < MI_COEF_BLOCKS && ((cmask >> l) & 1)) { // present blocks, packed in ascending order: 2 x 16 bytes per lane
         uint4 *dst = reinterpret_cast<uint4 *>(e.coefs) + 2 * (static_cast<size_t>(coff) + __builtin_popcount(cmask & ((1u << l) - 1u)));
         dst[0] = reinterpret_cast<const uint4 *>(s->coef)[2 * l], dst[1] = reinterpret_cast<const uint4 *>(s->coef)[2 * l + 1];
+        // ... and the staging block is all zero again for the next macroblock (only blocks with something in them were ever written)
+        reinterpret_cast<uint4 *>(s->coef)[2 * l] = make_uint4(0, 0, 0, 0), reinterpret_cast<uint4 *>(s->coef)[2 * l + 1] = make_uint4(0, 0, 0, 0);
     }
     LDS_SYNC();
 }
@@ -1694,7 +1729,6 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     e.v_qpc = tab->qpc[l < 52 ? l : 51];
     set_qp(e, RFL(static_cast<int>(sd->slice_qp)));
     e.v_step = step_word(l);
-    e.nzm = e.unm = 0;
     e.aw = e.bw = 0;
     e.v_ipm = 0;
     sh.posmap[0][l] = scan4[l & 15];
@@ -1739,6 +1773,8 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
                                               static_cast<uint32_t>(sd->slice_in_pic) << 16)
                                            : ((l == 9 || l == 10) ? (slot0 | slot0 << 16) : (l == 11 ? slice_no : (l >= 30 ? 0xFFFFFFFFu : 0u))));
     }
+    for (int i = l; i < MI_COEF_PER_MB / 2; i += 64) reinterpret_cast<uint32_t *>(sh.coef)[i] = 0; // the coefficient staging block: zero between macroblocks
+    sh.role[l] = build_role(l);
     for (int i = l; i < e.wmb * TOP_DW; i += 64) reinterpret_cast<uint32_t *>(e.top)[i] = 0; // all row-above entries: type NONE
     if (l < TOP_DW) reinterpret_cast<uint32_t *>(&sh.nb[NB_LEFT])[l] = 0, reinterpret_cast<uint32_t *>(&sh.nb[NB_TL])[l] = 0;
     if (l < 2 * TOP_DW) reinterpret_cast<uint32_t *>(&sh.nb[NB_TOP])[l] = 0;
