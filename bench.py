@@ -50,27 +50,49 @@ def _gen_tag():
     return _GEN_TAG
 
 
+def _cache_dir():
+    """Scratch directory of generated streams: H264MI_BENCH_CACHE, else $XDG_CACHE_HOME/h264mi_bench, else a per-user directory under the
+    temp dir.  Created with mode 0700 and used only if it belongs to this user and nobody else can write to it -- the files in it
+    become the bench's inputs AND its parity reference.  Plain arrays (np.savez, loaded with allow_pickle=False), never pickles."""
+    cdir = os.environ.get("H264MI_BENCH_CACHE")
+    if cdir == "off":
+        return None
+    if not cdir:
+        base = os.environ.get("XDG_CACHE_HOME")
+        cdir = os.path.join(base, "h264mi_bench") if base else os.path.join(os.environ.get("TMPDIR", "/tmp"), "h264mi_bench_cache_%d" % os.getuid())
+    try:
+        os.makedirs(cdir, mode=0o700, exist_ok=True)
+        st = os.stat(cdir)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            return None
+    except OSError:
+        return None
+    return cdir
+
+
 def gen_stream(args):
     """One synthetic input stream (not timed).  Generating 256 distinct 1080p GOPs costs minutes of host time, and the driver runs
-    this script several times on one node (N = 1, 2, 4, 8): the streams are kept in a scratch directory (H264MI_BENCH_CACHE,
-    default /tmp/h264mi_bench_cache; H264MI_BENCH_CACHE=off disables) keyed by recipe, seed and the generator's source hash."""
+    this script several times on one node (N = 1, 2, 4, 8): the streams are kept in a scratch directory (_cache_dir;
+    H264MI_BENCH_CACHE=off disables) keyed by recipe, seed and the generator's source hash."""
     import hashlib
-    import pickle
     import streamgen
-    seed, frames, width, height = args
-    kw = streamgen.recipe("C3", frames=frames, idr_period=frames, seed=seed, width=width, height=height)
+    seed, frames, width, height = args[:4]
+    over = args[4] if len(args) > 4 else {}
+    kw = streamgen.recipe(over.get("recipe", "C3"), frames=frames, idr_period=frames, seed=seed, width=width, height=height)
+    kw.update({k: v for k, v in over.items() if k != "recipe"})
     if os.environ.get("H264MI_BENCH_DBF"):  # experiments only: disable_deblocking_filter_idc of the synthetic streams
         kw["deblock_idc"] = int(os.environ["H264MI_BENCH_DBF"])
     if os.environ.get("H264MI_BENCH_INTRAP"):  # experiments only: share of intra macroblocks in P pictures (per mille)
         kw["intra_in_p_permille"] = int(os.environ["H264MI_BENCH_INTRAP"])
-    cdir = os.environ.get("H264MI_BENCH_CACHE", "/tmp/h264mi_bench_cache")
+    cdir = _cache_dir()
     path = None
-    if cdir != "off":
+    if cdir:
         key = hashlib.md5(repr(sorted(kw.items())).encode()).hexdigest()[:16]
-        path = os.path.join(cdir, "%s_%s.pkl" % (_gen_tag(), key))
+        path = os.path.join(cdir, "%s_%s.npz" % (_gen_tag(), key))
         try:
-            with open(path, "rb") as f:
-                return pickle.load(f)
+            with np.load(path, allow_pickle=False) as z:
+                rec = z["rec"]
+                return (z["stream"].tobytes(), [bytes(r) for r in rec] if rec.shape[1] == 16 else rec, z["sizes"])
         except Exception:
             pass
     s, rec, sizes = streamgen.encode(want_recon=True, **kw)
@@ -81,14 +103,28 @@ def gen_stream(args):
     out = (s, rec, sizes)
     if path:
         try:
-            os.makedirs(cdir, exist_ok=True)
-            tmp = "%s.%d.tmp" % (path, os.getpid())
-            with open(tmp, "wb") as f:
-                pickle.dump(out, f, protocol=4)
+            tmp = "%s.%d.tmp.npz" % (path, os.getpid())
+            np.savez(tmp, stream=np.frombuffer(s, dtype=np.uint8), sizes=np.asarray(sizes),
+                     rec=np.frombuffer(b"".join(rec), dtype=np.uint8).reshape(len(rec), 16) if isinstance(rec, list) else rec)
             os.replace(tmp, path)
         except Exception:
             pass  # a scratch directory that cannot be written is not an error
     return out
+
+
+GEN_CORE_SECONDS_1080P_GOP = 29.0  # measured: one 1080p GOP-30 C3 stream on one host core of the GPU node (round 3: 256 streams, 62 threads, 121 s)
+
+
+def generation_threads(n_distinct, world):
+    """Generator threads of one rank: its share of the host's cores (every rank of an N-GPU run generates on the same host)."""
+    return max(1, min(n_distinct, (os.cpu_count() or 8) // max(1, world) - (2 if world == 1 else 0)))
+
+
+def planned_generation_seconds(n_distinct, world, cores=None, frames=30):
+    """Wall-clock estimate of a rank's input generation (tests/test_bench_contract.py holds the N = 8 plan against the time limit)."""
+    cores = cores or (os.cpu_count() or 8)
+    threads = max(1, min(n_distinct, cores // max(1, world) - (2 if world == 1 else 0)))
+    return -(-n_distinct // threads) * GEN_CORE_SECONDS_1080P_GOP * frames / 30.0
 
 
 def timed_fps(dec, streams, n_frames, steps, warmup=1):
@@ -212,7 +248,66 @@ def extra_configs(H, streams, F, W, Hc, device, args):
         finally:
             dec.close()
 
+    def kernel_ms(dec):
+        dec.set_profiling(True)
+        dec.execute()
+        dec.sync()
+        kt = dec.kernel_times_ms()
+        lt = {k: dec.launch_times_ms(k) for k in ("inter", "intra", "deblock")}
+        dec.set_profiling(False)
+        return kt, lt
+
+    def c2_720p_cavlc_intra():
+        # BASELINE configs[1]: 720p Baseline CAVLC, every frame an IDR picture: per-MB dequant + 4x4 IDCT + intra prediction is the whole reconstruction
+        n, fr = 32, 60
+        gen = args.gen_c2
+        cs = [gen[i % 8][0] for i in range(n)]
+        dec = H.Decoder(max_streams=n, max_width=1280, max_height=720, max_frames_per_batch=fr, max_slices_per_frame=1, device=device,
+                        max_bitstream_bytes=int(sum(len(x) for x in cs) * 1.1) + (1 << 20))
+        try:
+            r = timed_fps(dec, cs, n * fr, steps=max(2, min(args.steps, 5)))
+            rec = gen[(n - 1) % 8][1]
+            got = dec.read_frame(n - 1, fr - 1, crop=False)[:1280 * 720 * 3 // 2]
+            import hashlib
+            same = np.array_equal(got, rec[fr - 1]) if isinstance(rec[fr - 1], np.ndarray) else hashlib.md5(got.tobytes()).digest() == rec[fr - 1]
+            r["parity"] = "bit-exact vs streamgen recon (stream %d, last frame)" % (n - 1) if same else "MISMATCH"
+            kt, lt = kernel_ms(dec)
+            ims = float(np.mean(lt["intra"]))
+            fb = 1280 * 720 * 3 // 2
+            r["k_intra"] = {"ms_per_launch": round(ims, 4), "pictures_per_launch": n, "GB/s": round(fb * n / (ims * 1e-3) / 1e9, 2),
+                            "frac": round(fb * n / (ims * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": fb * n}
+            r["kernel_ms_per_step"] = {k: round(v, 3) for k, v in kt.items()}
+            r["workload"] = "C2: %d streams (8 distinct) x %d frames, 1280x720 Baseline CAVLC, all IDR" % (n, fr)
+            return r
+        finally:
+            dec.close()
+
+    def c4_4k_high_8slices():
+        # BASELINE configs[3]: 4K High profile, 8x8 transform, 8 slices per picture: slice-parallel CABAC (one slice per wavefront)
+        n, fr = 8, 30
+        gen = args.gen_c4
+        cs = [gen[i % 2][0] for i in range(n)]
+        dec = H.Decoder(max_streams=n, max_width=3840, max_height=2160, max_frames_per_batch=fr, max_slices_per_frame=8, device=device,
+                        max_bitstream_bytes=int(sum(len(x) for x in cs) * 1.1) + (1 << 20))
+        try:
+            r = timed_fps(dec, cs, n * fr, steps=max(2, min(args.steps, 5)))
+            rec = gen[(n - 1) % 2][1]
+            got = dec.read_frame(n - 1, fr - 1, crop=False)[:3840 * 2160 * 3 // 2]
+            import hashlib
+            same = np.array_equal(got, rec[fr - 1]) if isinstance(rec[fr - 1], np.ndarray) else hashlib.md5(got.tobytes()).digest() == rec[fr - 1]
+            r["parity"] = "bit-exact vs streamgen recon (stream %d, last frame)" % (n - 1) if same else "MISMATCH"
+            kt, lt = kernel_ms(dec)
+            r["kernel_ms_per_step"] = {k: round(v, 3) for k, v in kt.items()}
+            r["entropy"] = {"kernel_ms": round(kt["entropy"], 3), "slices_in_flight": n * fr * 8,
+                            "bits_per_s": round(sum(len(x) for x in cs) * 8 / (kt["entropy"] * 1e-3), 0)}
+            r["workload"] = "C4: %d streams (2 distinct) x %d frames, 3840x2160 High CABAC, 8x8 transform, 8 slices per picture" % (n, fr)
+            return r
+        finally:
+            dec.close()
+
     guarded("c5_share", c5_share)
+    guarded("c2_720p_cavlc_intra", c2_720p_cavlc_intra)
+    guarded("c4_4k_high_8slices", c4_4k_high_8slices)
     guarded("single_stream", single_stream)
     guarded("fractional_motion", fractional_motion)
     guarded("b_pictures", b_pictures)
@@ -394,7 +489,10 @@ def main():
             dist.init_process_group(os.environ.get("H264MI_BENCH_BACKEND", "nccl" if torch.cuda.is_available() else "gloo"))
         red = allreduce_stats({"frames": 1.0, "ranks": 1.0, "seconds": float(rank)})
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(red["ranks"]), "slowest_rank_seconds": red["seconds"]}))
+            nd_plan = max(1, min(args.distinct or (args.streams if world == 1 else 32), args.streams))
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": int(red["ranks"]), "slowest_rank_seconds": red["seconds"],
+                              "distinct_streams_per_rank": nd_plan, "generator_threads_per_rank": generation_threads(nd_plan, world),
+                              "planned_generation_s": round(planned_generation_seconds(nd_plan, world, frames=args.frames), 1)}))
         if world > 1:
             dist.destroy_process_group()
         return 0
@@ -416,12 +514,21 @@ def main():
     if args.total_streams > 0:
         return run_strong(args, H, torch, dist, rank, world, local_rank)
     S, F = args.streams, args.frames
-    nd = max(1, min(args.distinct or S, S))
+    # Distinct streams per rank: all of them on one GPU.  With N > 1 every rank generates its own inputs on the SAME host: 8 x 256
+    # distinct 1080p GOPs are ~16 core-hours of generator time, more than the bench's time limit on any host -- so a rank generates 32 distinct
+    # streams by default (each used 8 times; --distinct overrides) with its share of the host's cores, and the line says so (config.workload).
+    nd = max(1, min(args.distinct or (S if world == 1 else 32), S))
+    gen_threads = generation_threads(nd, world)
     # ---- synthetic inputs (not timed) ----
     t0 = time.time()
     seeds = [1000 + rank * S + i for i in range(nd)]
-    with ThreadPoolExecutor(max_workers=min(nd, max(1, (os.cpu_count() or 8) - 2))) as ex:
+    # (the inputs of the contract's other configurations -- extra_configs: C2, C4 -- are generated by the same pool, longest jobs first)
+    jobs_x = [] if (args.no_extra or world > 1) else [(4000 + i, 30, 3840, 2160, {"recipe": "C4", "idr_period": 30}) for i in range(2)] + \
+        [(2000 + i, 60, 1280, 720, {"recipe": "C2", "idr_period": 1}) for i in range(8)]
+    with ThreadPoolExecutor(max_workers=gen_threads) as ex:
+        fx = [ex.submit(gen_stream, j) for j in jobs_x]
         gen = list(ex.map(gen_stream, [(sd, F, args.width, args.height) for sd in seeds]))
+        args.gen_c4, args.gen_c2 = [f.result() for f in fx[:2]], [f.result() for f in fx[2:]]
     streams = [gen[i % nd][0] for i in range(S)]
     gen_s = time.time() - t0
     W, Hc = (args.width + 15) // 16 * 16, (args.height + 15) // 16 * 16
@@ -476,6 +583,7 @@ def main():
     from h264decode_amd.dist import allreduce_stats
     red = allreduce_stats({"ranks": 1, "frames": S * F * args.steps, "pixels": S * F * args.steps * args.width * args.height,
                            "bytes_in": sum(len(x) for x in streams) * args.steps, "seconds": elapsed}, device="cuda" if (dist and dist.get_backend() == "nccl") else None)
+    gen_s = allreduce_stats({"seconds": gen_s}, device="cuda" if (dist and dist.get_backend() == "nccl") else None)["seconds"]  # the slowest rank's
     elapsed, total_frames = red["seconds"], red["frames"]
     ranks_seen = int(red.get("ranks", 1))
     fps = total_frames / elapsed
@@ -509,8 +617,29 @@ def main():
         pms = (time.perf_counter() - t0) / 3 * 1e3
         k_pack = {"ms": round(pms, 3), "GB/s": round(2.0 * S * F * disp / (pms * 1e-3) / 1e9, 1), "frac": round(2.0 * S * F * disp / (pms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                   "note": "%d frames in one launch; includes the descriptor-table upload" % (S * F)}
+        # `value` with K6 in the loop: every step ends with the crop + pack launch of the whole batch into a resident buffer (the output side of the
+        # path: what a consumer on the device reads).  Same barrier / synchronize bracket as `value`.
+        for _ in range(args.warmup):
+            dec.execute()
+            dec.pack_batch(pbuf.data_ptr(), pbuf.numel())
+        dec.sync()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            dec.execute()
+            dec.pack_batch(pbuf.data_ptr(), pbuf.numel())
+        dec.sync()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        wp = allreduce_stats({"frames": S * F * args.steps, "seconds": time.perf_counter() - t0}, device="cuda" if (dist and dist.get_backend() == "nccl") else None)
+        k_pack["value_with_pack"] = round(wp["frames"] / wp["seconds"], 2)
         del pbuf
     except RuntimeError as e:  # not enough free HBM for the packed copy of the whole batch
+        if dist:  # (the ranks must still meet at the collectives of the branch they did not all take)
+            raise
         k_pack = {"skipped": str(e)[:80]}
 
     # ---- end-to-end rate including host parse + H2D (reported, never `value`) ----
@@ -620,8 +749,11 @@ def main():
         "vs_baseline": None,
         "dtype": "u8",
         "data": "synthetic",
-        "config": {"workload": "%dx%d Main CABAC IPPP GOP-%d, %d independent streams per GPU (%d distinct), QP 28, 1 slice/frame, 1 ref"
-                               % (args.width, args.height, F, S, nd),
+        "value_with_pack": (k_pack or {}).get("value_with_pack"),
+        "value_note": "`value`: K passes of h264mi_batch_execute over a batch resident in HBM (entropy decode -> reconstruction -> deblocked frames in the frame pool); "
+                      "`value_with_pack` adds the K6 crop + pack launch of the whole batch to every step; host parse + H2D are in `end_to_end_fps` / `pipelined_ingest_fps`",
+        "config": {"workload": "%dx%d Main CABAC IPPP GOP-%d, %d independent streams per GPU (%d distinct%s), QP 28, 1 slice/frame, 1 ref"
+                               % (args.width, args.height, F, S, nd, "" if nd == S else ", each used %d times: %d ranks generate their inputs on one host" % (-(-S // nd), world)),
                    "frames_per_step_per_gpu": S * F, "bytes_per_frame": round(bytes_per_frame, 1), "parallelism": "streams sharded, no collective"},
         "mpixels_per_s": round(fps * args.width * args.height / 1e6, 1),
         "roofline": roofline,
@@ -636,6 +768,7 @@ def main():
         "hbm_bytes": {"decoder": hbm_bytes, "per_stream": int(hbm_bytes / S), "coef_pool_used": round(pool_used / pool_cap, 3), "note": "device memory of the %d-stream decoder (I/P streams: what only B pictures need is allocated on demand)" % S},
         "parity": parity,
         "stream_gen_s": round(gen_s, 1),
+        "stream_gen_note": "slowest rank; %d distinct streams per rank on %d generator threads" % (nd, gen_threads),
     }
     out.update(extra)
     print(json.dumps(out))

@@ -204,6 +204,7 @@ struct Stage {
     std::vector<std::vector<OutFrame>> out; // per stream: frames of this batch in decoding order
     bool prepared = false, executed = false;
     bool harvested = true; // the entropy kernels' per-slice status words of the last execute have been looked at (harvest_status)
+    bool retried = false;  // the batch has been repeated with the whole residual pool (retry_exhausted)
     h264mi_batch_info info;
     hipEvent_t ev_upload = nullptr; // H2D copies of this batch are complete
     hipEvent_t ev_done = nullptr;   // the last pass over this batch has finished (nothing reads or writes its buffers any more)
@@ -265,8 +266,13 @@ struct h264mi_decoder {
     uint32_t *d_xctl = nullptr, *h_xstatus = nullptr; // [0] K5 tickets, [32] K3 tickets, [64] give-up code (128-byte lines of their own)
     uint32_t x_epoch = 0, x_tk5 = 0, x_tk3 = 0;
     int x_max_wgs = 256, x_cap = 512, x_cap3 = 512; // workgroups per launch: default; capacity of the K5 ring; of the K3 flag array
-    PackDesc *h_pack = nullptr, *d_pack = nullptr; // K6 descriptor table
-    size_t pack_cap = 0;
+    // K6 descriptor tables: two of them, used alternately, each fenced by an event -- a pack call does not wait for the stream (the batch it packs
+    // may still be executing, and the next execute may be enqueued right behind it)
+    PackDesc *h_pack[2] = {nullptr, nullptr}, *d_pack[2] = {nullptr, nullptr};
+    size_t pack_cap[2] = {0, 0};
+    hipEvent_t ev_pack[2] = {nullptr, nullptr};
+    int pack_slot = 0;
+    hipEvent_t last_pack = nullptr; // the most recent pack launch: the reconstruction of a later pass may rewrite the frames it reads
     std::vector<float> launch_ms[4]; // duration of every launch of the last profiled pass, per kernel
 };
 
@@ -361,7 +367,7 @@ static void free_all(h264mi_decoder *d) {
         if (d->d_mv1[i]) hipFree(d->d_mv1[i]);
         if (d->d_dbprm[i]) hipFree(d->d_dbprm[i]);
         if (d->d_imask[i]) hipFree(d->d_imask[i]);
-        if (d->d_coef[i]) hipFree(d->d_coef[i]);
+        if (i == 0 && d->d_coef[0]) hipFree(d->d_coef[0]);
         if (i == 0 && d->d_pool_head) hipFree(d->d_pool_head);
         if (d->d_toprows[i]) hipFree(d->d_toprows[i]);
         if (d->ev_ent[i]) hipEventDestroy(d->ev_ent[i]);
@@ -379,8 +385,11 @@ static void free_all(h264mi_decoder *d) {
     if (d->d_xctl) hipFree(d->d_xctl);
     if (d->h_xstatus) hipHostFree(d->h_xstatus);
     if (d->d_pools) hipFree(d->d_pools);
-    if (d->h_pack) hipHostFree(d->h_pack);
-    if (d->d_pack) hipFree(d->d_pack);
+    for (int i = 0; i < 2; i++) {
+        if (d->h_pack[i]) hipHostFree(d->h_pack[i]);
+        if (d->d_pack[i]) hipFree(d->d_pack[i]);
+        if (d->ev_pack[i]) hipEventDestroy(d->ev_pack[i]);
+    }
     if (d->d_frames) hipFree(d->d_frames);
     if (d->d_tables) hipFree(d->d_tables);
     if (d->h_tables) hipHostFree(d->h_tables);
@@ -520,11 +529,15 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg_, h264mi_decod
             uint64_t per_mb = 8;
             if (const char *e = getenv("H264MI_COEF_BLOCKS_PER_MB")) per_mb = static_cast<uint64_t>(std::min(std::max(atoi(e), 1), MI_COEF_BLOCKS));
             if (d->cfg.coef_blocks_per_mb > 0) per_mb = static_cast<uint64_t>(std::min<int>(d->cfg.coef_blocks_per_mb, MI_COEF_BLOCKS));
-            const uint64_t typical = std::max<uint64_t>(d->mb_cap * per_mb, (1ull << 30) / 32) + static_cast<uint64_t>(d->slices_cap + 1) * MI_COEF_CHUNK;
-            d->pool_blocks = std::min<uint64_t>(std::min<uint64_t>(worst, typical), 0xFFFF0000ull);
+            // (an explicit coef_blocks_per_mb is taken at its word; the default has a floor of 1 GiB)
+            const uint64_t typical = (d->cfg.coef_blocks_per_mb > 0 ? d->mb_cap * per_mb : std::max<uint64_t>(d->mb_cap * per_mb, (1ull << 30) / 32)) +
+                                     static_cast<uint64_t>(d->slices_cap + 1) * MI_COEF_CHUNK;
+            d->pool_blocks = std::min<uint64_t>(std::min<uint64_t>(worst, typical), 0xFFFF0000ull / MI_SETS);
             DEV_ALLOC(d->d_pool_head, sizeof(uint32_t) * MI_SETS);
         }
-        DEV_ALLOC(d->d_coef[i], d->pool_blocks * 32);
+        // the MI_SETS pools are ONE allocation: a pass that ran out of residual blocks is repeated on its own with all of it (retry_exhausted)
+        if (i == 0) DEV_ALLOC(d->d_coef[0], d->pool_blocks * 32 * MI_SETS);
+        else d->d_coef[i] = d->d_coef[0] + static_cast<size_t>(i) * d->pool_blocks * 16;
         DEV_ALLOC(d->d_toprows[i], static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * MI_TOPROW_BYTES);
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_ent[i], hipEventDisableTiming));
         TRY_ALLOC(hipEventCreateWithFlags(&d->ev_col[i], hipEventDisableTiming));
@@ -1873,14 +1886,24 @@ static hipEvent_t next_event(h264mi_decoder *d, size_t &idx, int kind) {
     return d->ev[idx++];
 }
 
+// One pass over a prepared batch.  exclusive: the pass runs alone (the caller has drained every stream), serialised on the decoder's stream, with
+// record set 0 and ALL of the residual pool -- how a batch that ran out of residual blocks is repeated (retry_exhausted).
+static int execute_stage(h264mi_decoder *d, int stage_idx, bool exclusive);
+
 extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     if (!d || !d->stage[d->prep].prepared) {
         set_error("h264mi_batch_execute: no prepared batch");
         return H264MI_EINVAL;
     }
     d->exec = d->prep; // sync and the frame accessors refer to this batch from now on
-    d->last_exec_stage = d->prep, d->last_exec_set = static_cast<int>(d->pass % MI_SETS);
-    Stage &g = d->stage[d->exec];
+    d->stage[d->exec].retried = false;
+    return execute_stage(d, d->exec, false);
+}
+
+static int execute_stage(h264mi_decoder *d, int stage_idx, bool exclusive) {
+    if (exclusive) d->pass += (MI_SETS - d->pass % MI_SETS) % MI_SETS; // record set 0
+    d->last_exec_stage = stage_idx, d->last_exec_set = static_cast<int>(d->pass % MI_SETS);
+    Stage &g = d->stage[stage_idx];
     if (!g.n_slices && g.grey.empty()) return H264MI_OK;
     GUARD(d);
     // frames that went out with one field decoded (flush_pending_field): the rows of the field that never came are painted mid-grey
@@ -1900,7 +1923,8 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         return H264MI_OK;
     }
     size_t ei = 0;
-    const bool prof = d->profiling;
+    const bool prof = d->profiling || exclusive; // (an exclusive pass takes the serialised path of the profiling mode; its event marks are harmless)
+    const uint32_t pool_blocks = static_cast<uint32_t>(exclusive ? std::min<uint64_t>(d->pool_blocks * MI_SETS, 0xFFFF0000ull) : d->pool_blocks);
     auto mark = [&](int kind) {
         if (prof) hipEventRecord(next_event(d, ei, kind), d->stream);
     };
@@ -1932,10 +1956,10 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
             if (n > 0) {
                 if (lv == 0)
                     hipLaunchKernelGGL(g.fmo_pics.empty() ? k_entropy : k_entropy_f, dim3(n), dim3(64), lds_pad, st, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
-                                       static_cast<uint32_t>(d->pool_blocks), g.d_status, d->d_toprows[set], g.wmb_max, static_cast<uint32_t>(first));
+                                       pool_blocks, g.d_status, d->d_toprows[set], g.wmb_max, static_cast<uint32_t>(first));
                 else
                     hipLaunchKernelGGL(k_entropy_b, dim3(n), dim3(64), 0, st, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
-                                       static_cast<uint32_t>(d->pool_blocks), g.d_status, d->d_toprows[set], g.wmb_max, static_cast<uint32_t>(first), g.d_bext, d->d_mv1[set]);
+                                       pool_blocks, g.d_status, d->d_toprows[set], g.wmb_max, static_cast<uint32_t>(first), g.d_bext, d->d_mv1[set]);
             }
             // the pictures complete with this level: K5's strengths and filter parameters, and the motion later B slices (the next
             // level's, or a later batch's) take their direct prediction from
@@ -1964,6 +1988,10 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
         HIP_TRY(hipStreamWaitEvent(d->rec_stream, d->ev_ent[set], 0));
     }
     hipStream_t rs = prof ? d->stream : d->rec_stream;
+    if (d->last_pack && !prof) { // a pack launch may still be reading frames this pass rewrites (the same batch executed again)
+        HIP_TRY(hipStreamWaitEvent(rs, d->last_pack, 0));
+        d->last_pack = nullptr;
+    }
     // tag of a banded launch's hand-off words: no earlier launch on the same rings has used it (the rings start out zero, and
     // are zeroed again should the counter ever wrap)
     auto next_epoch = [&]() {
@@ -2028,7 +2056,28 @@ extern "C" int32_t h264mi_batch_execute(h264mi_decoder *d) {
     HIP_TRY(hipMemcpyAsync(d->h_xstatus, d->d_xctl + 64, sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipEventRecord(g.ev_done, d->stream)); // d->stream has waited for the reconstruction kernels: the batch's buffers are idle after this
     g.executed = true, g.harvested = false;
-    d->ev_used = prof ? ei : 0;
+    d->ev_used = d->profiling ? ei : 0;
+    return H264MI_OK;
+}
+
+// A pass whose slices ran out of residual blocks (entropy status 40: the pool holds 8 blocks per macroblock by default, the worst case is 26) is
+// repeated once, alone, with the pools of all record sets as one -- three times the room -- before anything is held against its streams; the
+// batches executed after it (they predicted from its damaged pictures) follow in order.  Called by h264mi_batch_sync with every stream drained.
+static int retry_exhausted(h264mi_decoder *d) {
+    bool redo = false;
+    for (int k = 1; k <= MI_STAGES; k++) { // oldest executed batch first
+        const int si = (d->exec + k) % MI_STAGES;
+        Stage &g = d->stage[si];
+        if (!g.executed || g.harvested) continue;
+        bool exhausted = false;
+        for (int i = 0; i < g.n_slices && !exhausted; i++) exhausted = g.h_status[8 * i] == 40;
+        if (!redo && !(exhausted && !g.retried)) continue;
+        redo = true; // this batch, and every later one
+        g.retried = true;
+        int r = execute_stage(d, si, true);
+        if (r != H264MI_OK) return r;
+        HIP_TRY(hipStreamSynchronize(d->stream));
+    }
     return H264MI_OK;
 }
 
@@ -2067,6 +2116,10 @@ extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
         *d->h_xstatus = 0;
         HIP_TRY(hipMemset(d->d_xctl + 64, 0, sizeof(uint32_t)));
         return H264MI_EDEVICE;
+    }
+    {
+        const int r = retry_exhausted(d); // (leaves every stream drained again)
+        if (r != H264MI_OK) return r;
     }
     // every batch executed since the last look (pipelined callers synchronise once for several), the most recent one last
     int result = H264MI_OK;
@@ -2189,15 +2242,17 @@ extern "C" int32_t h264mi_frame_read(h264mi_decoder *d, int32_t stream, int32_t 
 // K6 over a list of frames: descriptors go through a small pinned table, one launch packs them all.
 static int pack_frames(h264mi_decoder *d, const std::vector<std::pair<int, int>> &frames /* (stream, frame) */, void *dst, size_t cap, size_t *bytes) {
     GUARD(d);
-    if (frames.size() > d->pack_cap) {
-        if (d->h_pack) hipHostFree(d->h_pack);
-        if (d->d_pack) hipFree(d->d_pack);
-        d->h_pack = nullptr, d->d_pack = nullptr;
-        d->pack_cap = std::max<size_t>(frames.size(), 64);
-        HIP_TRY(hipHostMalloc(&d->h_pack, sizeof(PackDesc) * d->pack_cap));
-        HIP_TRY(hipMalloc(&d->d_pack, sizeof(PackDesc) * d->pack_cap));
+    const int ps = d->pack_slot ^= 1;
+    if (!d->ev_pack[ps]) HIP_TRY(hipEventCreateWithFlags(&d->ev_pack[ps], hipEventDisableTiming));
+    else HIP_TRY(hipEventSynchronize(d->ev_pack[ps])); // the launch that used this table (two calls ago) has read it
+    if (frames.size() > d->pack_cap[ps]) {
+        if (d->h_pack[ps]) hipHostFree(d->h_pack[ps]);
+        if (d->d_pack[ps]) hipFree(d->d_pack[ps]);
+        d->h_pack[ps] = nullptr, d->d_pack[ps] = nullptr;
+        d->pack_cap[ps] = std::max<size_t>(frames.size(), 64);
+        HIP_TRY(hipHostMalloc(&d->h_pack[ps], sizeof(PackDesc) * d->pack_cap[ps]));
+        HIP_TRY(hipMalloc(&d->d_pack[ps], sizeof(PackDesc) * d->pack_cap[ps]));
     }
-    HIP_TRY(hipStreamSynchronize(d->stream)); // the table of the previous call is no longer in flight
     size_t off = 0;
     int hmax = 0;
     for (size_t i = 0; i < frames.size(); i++) {
@@ -2207,7 +2262,7 @@ static int pack_frames(h264mi_decoder *d, const std::vector<std::pair<int, int>>
         int r = frame_ptrs(d, frames[i].first, frames[i].second, &p, &of);
         if (r != H264MI_OK) return r;
         crop_rect(of, 1, &x0, &y0, &w, &h);
-        PackDesc &pk = d->h_pack[i];
+        PackDesc &pk = d->h_pack[ps][i];
         pk.src = reinterpret_cast<uint64_t>(p), pk.dst_off = off;
         pk.W = of->wmb * 16, pk.H = of->hmb * 16, pk.x0 = x0, pk.y0 = y0, pk.w = w, pk.h = h;
         off += static_cast<size_t>(w) * h * 3 / 2;
@@ -2216,11 +2271,14 @@ static int pack_frames(h264mi_decoder *d, const std::vector<std::pair<int, int>>
     if (bytes) *bytes = off;
     if (off > cap) return H264MI_ECAPACITY;
     if (frames.empty()) return H264MI_OK;
-    HIP_TRY(hipMemcpyAsync(d->d_pack, d->h_pack, sizeof(PackDesc) * frames.size(), hipMemcpyHostToDevice, d->stream));
+    // (in order on the decoder's stream, which has waited for the reconstruction of the last executed pass: h264mi_batch_execute)
+    HIP_TRY(hipMemcpyAsync(d->d_pack[ps], d->h_pack[ps], sizeof(PackDesc) * frames.size(), hipMemcpyHostToDevice, d->stream));
     const int rows_per_block = 32;
-    hipLaunchKernelGGL(k_pack, dim3(static_cast<uint32_t>(frames.size()), (2 * hmax + rows_per_block - 1) / rows_per_block), dim3(256), 0, d->stream, d->d_pack,
+    hipLaunchKernelGGL(k_pack, dim3(static_cast<uint32_t>(frames.size()), (2 * hmax + rows_per_block - 1) / rows_per_block), dim3(256), 0, d->stream, d->d_pack[ps],
                        static_cast<uint8_t *>(dst), rows_per_block);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(d->ev_pack[ps], d->stream));
+    d->last_pack = d->ev_pack[ps];
     return H264MI_OK;
 }
 
@@ -2288,7 +2346,7 @@ extern "C" int32_t h264mi_internal_poison(h264mi_decoder *d) {
     HIP_TRY(hipStreamSynchronize(d->stream));
     for (int i = 0; i < MI_SETS; i++) {
         HIP_TRY(hipMemset(d->d_mbrec[i], 0xFF, sizeof(MbRec) * d->mb_cap));
-        HIP_TRY(hipMemset(d->d_coef[i], 0xFF, d->pool_blocks * 32));
+        if (i == 0) HIP_TRY(hipMemset(d->d_coef[0], 0xFF, d->pool_blocks * 32 * MI_SETS));
         HIP_TRY(hipMemset(d->d_toprows[i], 0xFF, static_cast<size_t>(d->slices_cap) * (d->Wmax / 16) * MI_TOPROW_BYTES));
         if (d->d_mv1[i]) HIP_TRY(hipMemset(d->d_mv1[i], 0xFF, sizeof(MbMv1) * d->mb_cap));
     }

@@ -46,3 +46,22 @@ def test_bench_defaults_finish_in_minutes_by_construction():
     src = open(os.path.join(ROOT, "bench.py")).read()
     m = {k: int(v) for k, v in re.findall(r'add_argument\("--(gpus|steps|warmup)", type=int, default=(\d+)', src)}
     assert m["gpus"] == 1 and 1 <= m["steps"] <= 20 and m["warmup"] <= 5
+
+
+def test_eight_rank_input_generation_fits_the_time_limit():
+    """N > 1: every rank generates its inputs on the same host.  The plan -- distinct streams per rank x measured core-seconds per stream /
+    the rank's share of the cores -- must stay far below the driver's 600 s limit on any plausible 8-GPU host, and the dry run reports it."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    for cores in (64, 96, 128, 192, 256):
+        assert bench.planned_generation_seconds(32, 8, cores=cores) <= 150, cores  # 8 ranks x 32 distinct 1080p GOPs
+    assert bench.planned_generation_seconds(256, 1, cores=64) <= 160               # N = 1: all 256 distinct (round 3: 121 s measured)
+    assert bench.generation_threads(32, 8) <= max(1, (os.cpu_count() or 8) // 8)   # a rank never takes more than its share of the host
+    env = dict(os.environ, H264MI_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["distinct_streams_per_rank"] == 32
+    assert d["generator_threads_per_rank"] == bench.generation_threads(32, 8)

@@ -235,9 +235,12 @@ def test_gpu_720p_cavlc_intra(H, sg, oracle_mod):
     """BASELINE configs[1]: 720p Baseline CAVLC I-frames."""
     kw = sg.recipe("C2", frames=2)
     stream, rec, _ = sg.encode(**kw)
+    ref, _ = oracle_mod.decode(stream, crop=False)
+    assert np.array_equal(ref, rec), "oracle != generator"
     for x in (None, 0):
         out, _ = _decode_gpu(H, [stream], 1280, 720, 2, x_wgs=x)
         assert np.array_equal(out[0], rec), x
+        assert np.array_equal(out[0], ref), x
 
 
 @pytest.mark.parametrize("kw", [dict(slice_groups=6, fmo_type=1, slices=2), dict(slice_groups=8, fmo_type=6, aso=1), dict(slice_groups=2, fmo_type=3, slices=3, aso=1),
@@ -254,11 +257,14 @@ def test_gpu_720p_slice_groups(kw, H, sg, oracle_mod):
         assert np.array_equal(out[0], rec), x
 
 
-def test_gpu_4k_high_8_slices(H, sg):
+def test_gpu_4k_high_8_slices(H, sg, oracle_mod):
     """BASELINE configs[3]: 3840x2160 High CABAC, 8x8 transform, 8 slices per picture (240 x 135 macroblocks: widest row
     state, 34 deblocking row groups in 3 rounds, slice boundaries inside and across macroblock rows)."""
     kw = sg.recipe("C4", frames=3, idr_period=3)
-    stream, rec, _ = sg.encode(**kw)
+    stream, rec, sizes = sg.encode(**kw)
+    # the oracle on the first two pictures (I, P) of the same stream: the full-size cases are held against BOTH independent implementations
+    ref2, _ = oracle_mod.decode(stream[:int(sizes[:2].sum())], crop=False)
+    assert np.array_equal(ref2, rec[:2]), "oracle != generator"
     for x in (None, 0, 3):  # 34 bands; one workgroup (3 rounds of 12 wavefronts); 3 bands of 12 wavefronts
         out, info = _decode_gpu(H, [stream], 3840, 2160, 3, slices=8, x_wgs=x)
         assert (info.coded_width, info.coded_height) == (3840, 2160)
@@ -285,6 +291,46 @@ def test_gpu_sizing_knobs(H, sg):
         tight.decode([stream])  # the SPS declares two reference frames
     assert e.value.code == -7
     tight.close()
+
+
+def test_gpu_residual_pool_exhaustion_is_recovered(H, sg):
+    """The residual pool holds a configured number of 32-byte blocks per macroblock (default 8; the worst case is 26).  A batch that needs more than a
+    pass's pool is repeated by the library on its own with the pools of all three record sets as one (h264mi_batch_sync: retry_exhausted) -- bit-exact,
+    no stream marked -- and only what does not fit into that either fails (H264MI_EDECODE, entropy status 40), without a fault.  Streams of one
+    batch share the pool: the I B B P stream here sits next to a plain one, which must come through whatever happens to its neighbour."""
+    kws = [dict(width=1280, height=720, frames=7, idr_period=0, profile_idc=77, cabac=1, bframes=2, num_ref_frames=3, qp=18, noise=25, seed=71),
+           dict(width=1280, height=720, frames=7, idr_period=0, profile_idc=77, cabac=1, qp=30, seed=72)]
+    enc = [sg.encode(**kw) for kw in kws]
+    mbs, head = 2 * 80 * 45 * 7, 15 * 2048  # macroblock records of the decoder below; the pool's chunk head-room (slices + 1 chunks of 2048 blocks)
+    roomy = H.Decoder(max_streams=2, max_width=1280, max_height=720, max_frames_per_batch=7, max_slices_per_frame=1)
+    roomy.decode([e[0] for e in enc])
+    used, _ = roomy.coef_pool()
+    roomy.close()
+    # a pool the first pass overruns, while three of them are enough: blocks per macroblock k with k mbs + head < 0.8 used and 3 (k mbs + head) > 1.25 used
+    ks = [k for k in range(1, 27) if k * mbs + head < 0.8 * used and 3 * (k * mbs + head) > 1.25 * used]
+    assert ks, (used, mbs)  # (the test needs a batch with a real appetite)
+    k = ks[0]
+    dec = H.Decoder(max_streams=2, max_width=1280, max_height=720, max_frames_per_batch=7, max_slices_per_frame=1, coef_blocks_per_mb=k)
+    dec.decode([e[0] for e in enc])
+    used2, cap2 = dec.coef_pool()
+    assert used2 > cap2, (used2, cap2)  # more than one set's pool was taken: the pass was repeated with all of it
+    for i in range(2):
+        assert dec.stream_status(i) == 0
+        assert np.array_equal(dec.read_frames(i, crop=False), enc[i][1]), i
+    # ... and again (the repeat leaves the decoder in order): the same batch, then it executed twice in a row
+    dec.decode([e[0] for e in enc])
+    dec.execute()
+    dec.execute()
+    dec.sync()
+    assert np.array_equal(dec.read_frames(0, crop=False), enc[0][1])
+    dec.close()
+    # a pool so small that even the whole allocation falls short: a reported failure, not a fault
+    if 3 * (mbs + head) < 0.8 * used:
+        tiny = H.Decoder(max_streams=2, max_width=1280, max_height=720, max_frames_per_batch=7, max_slices_per_frame=1, coef_blocks_per_mb=1)
+        with pytest.raises(H.H264MIError) as e:
+            tiny.decode([e2[0] for e2 in enc])
+        assert e.value.code == -8 and "40" in str(e.value)
+        tiny.close()
 
 
 def test_gpu_rejects_out_of_scope_profile(H):
@@ -320,7 +366,7 @@ def test_gpu_c_program_through_the_abi(H, sg, oracle_mod, tmp_path):
 
 
 
-def test_gpu_c5_share_32_distinct_1080p_streams(H, sg):
+def test_gpu_c5_share_32_distinct_1080p_streams(H, sg, oracle_mod):
     """BASELINE configs[4], one GPU's share: 32 DISTINCT 1080p Main CABAC streams (seeds 1000..1031), one
     IPPP GOP of 30 frames each, decoded as one batch; every frame of every stream must equal the generator's own
     reconstruction (an implementation independent of the product and of the oracle)."""
@@ -331,6 +377,10 @@ def test_gpu_c5_share_32_distinct_1080p_streams(H, sg):
         gen = list(ex.map(lambda kw: sg.encode(**kw), kws))
     streams = [g[0] for g in gen]
     assert len(set(hashlib.md5(s).hexdigest() for s in streams)) == S, "streams are not distinct"
+    # the oracle on the first two pictures (IDR + P) of four of the streams: generator and oracle agree at this size too
+    for si in (0, 7, 19, 31):
+        ref2, _ = oracle_mod.decode(streams[si][:int(gen[si][2][:2].sum())], crop=False)
+        assert np.array_equal(ref2, gen[si][1][:2]), "oracle != generator (stream %d)" % si
     for x in (None, 0):  # 8 bands per picture (the default for 32 pictures per launch), then one workgroup per picture
         with _x_wgs(x):
             dec = H.Decoder(max_streams=S, max_width=1920, max_height=1088, max_frames_per_batch=F, max_slices_per_frame=1,
