@@ -262,8 +262,10 @@ def extra_configs(H, streams, F, W, Hc, device, args):
         n, fr = 32, 60
         gen = args.gen_c2
         cs = [gen[i % 8][0] for i in range(n)]
+        # (all-intra content at QP 28 fills ~9 residual blocks per macroblock: above the default pool of 8 -- every pass would be repeated with the whole
+        # allocation (h264mi_batch_sync) --, so this decoder is created with room for 16)
         dec = H.Decoder(max_streams=n, max_width=1280, max_height=720, max_frames_per_batch=fr, max_slices_per_frame=1, device=device,
-                        max_bitstream_bytes=int(sum(len(x) for x in cs) * 1.1) + (1 << 20))
+                        max_bitstream_bytes=int(sum(len(x) for x in cs) * 1.1) + (1 << 20), coef_blocks_per_mb=16)
         try:
             r = timed_fps(dec, cs, n * fr, steps=max(2, min(args.steps, 5)))
             rec = gen[(n - 1) % 8][1]

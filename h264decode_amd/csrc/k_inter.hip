@@ -32,9 +32,6 @@ typedef __attribute__((address_space(1))) uint8_t g8;
 typedef __attribute__((address_space(1))) uint16_t g16;
 typedef __attribute__((address_space(1))) uint32_t g32;
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-typedef uint32_t v2u __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) v4u gv4;
-typedef __attribute__((address_space(1))) v2u gv2;
 typedef short s2 __attribute__((ext_vector_type(2)));
 
 // The clamped value is made opaque on purpose: left alone, the compiler fuses "shift, clamp, pack two bytes" into gfx950's
@@ -126,16 +123,14 @@ __device__ __forceinline__ void predict(const g8 *base, uint32_t loff, uint32_t 
             const bool row_needed = (j >= 2 && j <= 5) || needV;
             if (row_needed) {
                 const int y = min(max(y0 - 2 + j, 0), H - 1);
-                // one load per row: 16 bytes where the third dword is needed (the span is 12; the texture-address unit, 70 % busy in this kernel
-                // (profiles/r04_k4_counters.txt), works per instruction and lane, not per byte), 8 bytes otherwise
+                // (Round 4 measured what else could feed the window, profiles/r04_k4_k5_counters.txt -- wavefronts parked at s_waitcnt 61 % of their cycles, texture-
+                // address units 67 % busy --: one unaligned 16- / 8-byte load per row 1.09 -> 1.15 ms (fractional motion 1.13 -> 1.31); one dword-ALIGNED 16- / 12-byte
+                // load + v_alignbyte 1.30 / 1.47 ms; the macroblock's 21 x 21 window staged once through LDS for macroblocks that move as one (0.7 KB instead of 2.1 KB
+                // through the address path) 1.26 / 1.41 ms, bit-exact.  All slower: the kernel is bound by the LATENCY of its chain descriptor -> record -> samples at
+                // five wavefronts per SIMD, and every one of them adds bytes or a stage to that chain; three dword loads per row in flight at once is the shortest.)
                 const g8 *p = ref + (static_cast<uint32_t>(y) * pitch + static_cast<uint32_t>(xb));
-                if (needH || fix) {
-                    const v4u q = *reinterpret_cast<const gv4 *>(p);
-                    d0[j] = q.x, d1[j] = q.y, d2[j] = q.z;
-                } else {
-                    const v2u q = *reinterpret_cast<const gv2 *>(p);
-                    d0[j] = q.x, d1[j] = q.y;
-                }
+                d0[j] = *reinterpret_cast<const g32 *>(p), d1[j] = *reinterpret_cast<const g32 *>(p + 4);
+                if (needH || fix) d2[j] = *reinterpret_cast<const g32 *>(p + 8);
             }
         }
         if (__builtin_amdgcn_ballot_w64(fix) != 0) {
@@ -536,14 +531,9 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
             if (has_c)
                 v = pack4(clip255(static_cast<int>(v & 255u) + cr[c][0]), clip255(static_cast<int>((v >> 8) & 255u) + cr[c][1]),
                           clip255(static_cast<int>((v >> 16) & 255u) + cr[c][2]), clip255(static_cast<int>(v >> 24) + cr[c][3]));
-            // the 2x2 samples of two neighbouring lanes leave as one dword per row from the even lane (half the lanes of a store instruction:
-            // half the work of the texture-address unit); the partner's samples come over by DPP (quad_perm [1,0,3,2])
-            const uint32_t nbv = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(v), 0xB1, 0xF, 0xF, true));
-            if (!(bx & 1)) {
-                g8 *cp = cdst + (c ? cr_delta : 0u) + (static_cast<uint32_t>(py >> 1) * Wc + static_cast<uint32_t>(px >> 1));
-                *reinterpret_cast<g32 *>(cp) = (v & 0xFFFFu) | (nbv << 16);
-                *reinterpret_cast<g32 *>(cp + Wc) = (v >> 16) | (nbv & 0xFFFF0000u);
-            }
+            g8 *cp = cdst + (c ? cr_delta : 0u) + (static_cast<uint32_t>(py >> 1) * Wc + static_cast<uint32_t>(px >> 1));
+            *reinterpret_cast<g16 *>(cp) = static_cast<uint16_t>(v & 0xFFFFu);
+            *reinterpret_cast<g16 *>(cp + Wc) = static_cast<uint16_t>(v >> 16);
         }
     }
 }
