@@ -368,17 +368,24 @@ __device__ void intra_mb(int lane, IntraWave *ws, const MbRec *rec, const int16_
         }
         st_px32<X>(Y + static_cast<size_t>(j) * W + i0, packed);
     } else if (type == MBT_I4x4) {
-        for (int idx = 0; idx < 16; idx++) {
-            const int bx = (idx & 1) + 2 * ((idx >> 2) & 1), by = ((idx >> 1) & 1) + 2 * (idx >> 3);
-            const int mode = rec->ipm[by * 4 + bx];
-            const int has_left = bx > 0 || a_left, has_top = by > 0 || a_top;
-            int has_tr;
-            if (by == 0)
-                has_tr = bx < 3 ? a_top : a_tr;
-            else
-                has_tr = bx == 3 ? 0 : !((bx & 1) && (by & 1));
-            if (lane < 16) {
-                const int x = lane & 3, y = lane >> 2;
+        // The sixteen 4x4 blocks in ten steps instead of sixteen: a block predicts from its left, upper-left, upper and upper-right neighbours, so
+        // the blocks on an anti-diagonal x + 2y = d are independent -- step d reconstructs up to two of them side by side (lanes 0..15 the upper
+        // one, 16..31 the lower one).  Which neighbours count as available stays what the z-order of 6.4.3 makes it (an upper-right block
+        // that comes later in that order is "not available" even though this schedule has already reconstructed it).
+        for (int d = 0; d < 10; d++) {
+            const int half = lane >> 4;                                   // 0: the block with the larger x (or the only one), 1: the one a row further down
+            const int by = (d >= 2 && d <= 7) ? (d & 1 ? (half ? 1 + ((d - 3) >> 1) : (d - 3) >> 1) : (half ? (d >> 1) : (d >> 1) - 1)) : (d < 2 ? 0 : 3);
+            const int bx = d - 2 * by;
+            const bool two = d >= 2 && d <= 7;
+            if (lane < (two ? 32 : 16)) {
+                const int mode = rec->ipm[by * 4 + bx];
+                const int has_left = bx > 0 || a_left, has_top = by > 0 || a_top;
+                int has_tr;
+                if (by == 0)
+                    has_tr = bx < 3 ? a_top : a_tr;
+                else
+                    has_tr = bx == 3 ? 0 : !((bx & 1) && (by & 1));
+                const int x = lane & 3, y = (lane >> 2) & 3;
                 const uint8_t *trow = &ws->tile[by * 4][bx * 4 + 1]; // trow[x] = p[x,-1], trow[-1] = p[-1,-1]
                 auto T = [&](int k) { return static_cast<int>((k >= 4 && !has_tr) ? trow[3] : trow[k]); };
                 auto L = [&](int k) { return k < 0 ? static_cast<int>(trow[-1]) : static_cast<int>(ws->tile[by * 4 + 1 + k][bx * 4]); };
