@@ -35,7 +35,7 @@ extern "C" {
 #define H264MI_OK 0
 #define H264MI_EINVAL (-1)      /* bad argument */
 #define H264MI_EBITSTREAM (-2)  /* malformed / truncated syntax */
-#define H264MI_EUNSUPPORTED (-3)/* valid H.264 outside the implemented scope (field pictures / MBAFF, SP/SI slices, 4:4:4 ...) */
+#define H264MI_EUNSUPPORTED (-3)/* valid H.264 outside the implemented scope (MBAFF, CABAC-coded field pictures, SP/SI slices, 4:4:4 ...): the message says what and why */
 #define H264MI_ENODEVICE (-4)   /* no usable HIP device / kernel image */
 #define H264MI_ENOMEM (-5)
 #define H264MI_EDEVICE (-6)     /* HIP runtime error */
@@ -245,7 +245,10 @@ int32_t h264mi_batch_sync(h264mi_decoder *dec);
 /* prepare + execute + sync */
 int32_t h264mi_decode_batch(h264mi_decoder *dec, int32_t n_streams, const uint8_t *const *bufs, const size_t *lens, h264mi_batch_info *info);
 
-/* Frames of the last batch, in decoding order (== output order unless the stream has B pictures: h264mi_stream_output_order). */
+/* Frames of the last batch, in decoding order (== output order unless the stream has B pictures: h264mi_stream_output_order).  A frame coded as two
+ * field pictures (h264/slice.go:867-872) is ONE frame here: it is reported with the batch that holds its second field -- the first field's batch
+ * reports nothing for it --, or, if the second field never comes, with the batch in which something else follows it (another picture, an
+ * end-of-sequence / end-of-stream NAL unit), the rows of the missing field mid-grey. */
 int32_t h264mi_stream_frame_count(h264mi_decoder *dec, int32_t stream, int32_t *n);
 /* Device pointers + pitches of a decoded frame (coded size; planes are resident in HBM until the
  * next h264mi_batch_prepare). */

@@ -35,7 +35,7 @@ def test_host_side_under_asan(tmp_path):
     assert "host asan: 60 decoders (0 refused)" in out
     frames = int(out.split(" frames")[0].split()[-1])
     assert frames > 100  # the intact third of the runs decodes: this is not a test of rejects only
-    assert " -3:" in out  # the field-picture streams among the inputs are refused with H264MI_EUNSUPPORTED, not mis-decoded
+    assert " 0:" in out  # (the field-picture streams among the inputs go through the host's field picture management since round 4)
 
 
 def test_parsers_and_oracle_under_asan(tmp_path):
