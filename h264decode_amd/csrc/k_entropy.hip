@@ -627,7 +627,8 @@ FI int cbf_inc_of(const Ent &e, uint8_t a, uint8_t b) { // 9.3.3.1.1.9
 //   bits 50..52 / 53..55  DC flags (Intra16x16 luma, Cb, Cr) of the left / upper macroblock, 56..58 of this one
 // fill_caches() leaves "coded" (1) / "unavailable" (2) per bit position in Shared::coded; unavailable counts as coded for intra
 // macroblocks.  The schedule is a bit set of steps (0 Intra16x16 DC, 1..16 luma z-order, 17/18 chroma DC,
-// 19..26 chroma AC) and a per-lane descriptor table: A bit | B bit << 6 | own bit << 12 | dst/4 << 18 | kind << 26.
+// 19..26 chroma AC) and a per-lane descriptor table: A bit | B bit << 6 | own bit << 12 | dst / 4 << 18 (10 bits: the scalar ALU gets the destination and
+// the block category out of it with one bit-field extract each) | kind << 26 (bits 24, 25 stay 0: (word >> 24) & 12 is 4 * kind).
 FI uint32_t step_word(int st) {
     if (st == 0) return 50u | 53u << 6 | 56u << 12 | (MI_COEF_I16DC / 4) << 18 | 0u << 26;
     if (st <= 16) {
@@ -665,7 +666,7 @@ FI void parse_residual_cabac(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
         const int step = __builtin_ctz(steps);
         steps &= steps - 1;
         const uint32_t d = RDL(e.v_step, step);
-        const int cat = static_cast<int>((cats >> ((d >> 26) * 4)) & 15);
+        const int cat = static_cast<int>((cats >> ((d >> 24) & 12u)) & 15);
         const int own = static_cast<int>((d >> 12) & 63);
         const int dst = cat == 5 ? (step - 1) * 16 : static_cast<int>((d >> 18) & 255) * 4;
         const int inc = static_cast<int>(RDL(vnz, d) + 2 * RDL(vnz, d >> 6)); // (the lane select is taken modulo 64)
@@ -1112,15 +1113,7 @@ FI void pskip_fast(Ent &e) {
     }
     e.cur_type = MBT_PSKIP;
     e.prev_dqp_nz = 0;
-    // intra-prediction availability of the record (never looked at for an inter macroblock; kept so that records do not depend on the path taken)
-    int av = 0;
-    {
-        const int cip = e.cip, ta = static_cast<int>(tA & 255u), tb = static_cast<int>(tB & 255u), td = static_cast<int>(tD & 255u), tc = c_ok ? static_cast<int>(tC & 255u) : MBT_NONE;
-        if (ta != MBT_NONE && !(cip && MB_IS_INTER(ta))) av |= MI_AV_LEFT;
-        if (tb != MBT_NONE && !(cip && MB_IS_INTER(tb))) av |= MI_AV_TOP;
-        if (td != MBT_NONE && !(cip && MB_IS_INTER(td))) av |= MI_AV_TOPLEFT;
-        if (tc != MBT_NONE && !(cip && MB_IS_INTER(tc))) av |= MI_AV_TOPRIGHT;
-    }
+    // (MbRec::avail -- the intra-prediction neighbour availability -- is 0 in the record of an inter macroblock: only K3 reads it, for intra ones)
     // ---- the new edge entry (the same for the row below and for the macroblock to the right), the window on the row above moves on ----
     if (l < TOP_DW) {
         const uint32_t row = MI_ENT_FMO ? static_cast<uint32_t>(e.mby + 1) << 16 : 0u;
@@ -1136,7 +1129,7 @@ FI void pskip_fast(Ent &e) {
     } else if (l >= 32) { // ---- the record: one dword per lane ----
         const int k = l - 32;
         const uint32_t t = s->skip_tmpl[k];
-        const uint32_t w = k == 0 ? (static_cast<uint32_t>(MBT_PSKIP) | e.qpw0) : (k == 1 ? e.qpw1 : (k == 2 ? (t | static_cast<uint32_t>(av) << 16) : ((k >= 12 && k < 28) ? mvw : t)));
+        const uint32_t w = k == 0 ? (static_cast<uint32_t>(MBT_PSKIP) | e.qpw0) : (k == 1 ? e.qpw1 : ((k >= 12 && k < 28) ? mvw : t));
         const uint64_t mbi = e.mb_base + static_cast<uint64_t>(e.mby) * e.wmb + e.mbx;
         reinterpret_cast<uint32_t *>(e.mbrec + mbi)[k] = w;
     }
@@ -1534,11 +1527,13 @@ FI void decode_mb(Ent &e, int skipped) {
         // neighbour availability for intra prediction (6.4.x; constrained_intra_pred 8.3.1.2)
         const int cip = e.cip;
         int av = 0;
-        const int td = s->nb[NB_TL].type, tc = nb_ok(e, NB_TOP + 1) ? s->nb[NB_TOP + 1].type : MBT_NONE;
-        if (a.ok() && !(cip && MB_IS_INTER(a.type()))) av |= MI_AV_LEFT;
-        if (b.ok() && !(cip && MB_IS_INTER(b.type()))) av |= MI_AV_TOP;
-        if (td != MBT_NONE && !(cip && MB_IS_INTER(td))) av |= MI_AV_TOPLEFT;
-        if (tc != MBT_NONE && !(cip && MB_IS_INTER(tc))) av |= MI_AV_TOPRIGHT;
+        if (MB_IS_INTRA(type)) { // (only K3 reads it, for intra macroblocks: an inter macroblock's record says 0)
+            const int td = s->nb[NB_TL].type, tc = nb_ok(e, NB_TOP + 1) ? s->nb[NB_TOP + 1].type : MBT_NONE;
+            if (a.ok() && !(cip && MB_IS_INTER(a.type()))) av |= MI_AV_LEFT;
+            if (b.ok() && !(cip && MB_IS_INTER(b.type()))) av |= MI_AV_TOP;
+            if (td != MBT_NONE && !(cip && MB_IS_INTER(td))) av |= MI_AV_TOPLEFT;
+            if (tc != MBT_NONE && !(cip && MB_IS_INTER(tc))) av |= MI_AV_TOPRIGHT;
+        }
         r.avail = static_cast<uint8_t>(av);
     }
     // dbf_idc / alpha_off / beta_off / slice_in_pic / slice_idx of the record are slice constants, written once at slice start

@@ -562,6 +562,9 @@ class AccessUnitSplitter:
         return chunks
 
 
+END_OF_STREAM = b"\x00\x00\x00\x01\x0b"  # nal_unit_type 11: tells the decoder that nothing follows -- a first field still waiting for its second one goes out as it is
+
+
 class H264Reader:
     """Mirror of the reference's H264Reader + handleConnection loop (h264/server.go:113-166): reads a connection
     (anything with recv() or read()), cuts the byte stream at access units and decodes them on the GPU.
@@ -613,7 +616,7 @@ class H264Reader:
             if not data:
                 break
             self._decode(self.splitter.feed(data))
-        self._decode(self.splitter.flush())
+        self._decode(self.splitter.flush() + [END_OF_STREAM])
         if self._reorder:
             rest = self._reorder.flush()
             if self.on_frames and rest:
@@ -678,7 +681,7 @@ class BatchServer:
         if data:
             self.queue[i] += self.split[i].feed(data)
         else:
-            self.queue[i] += self.split[i].flush()
+            self.queue[i] += self.split[i].flush() + [END_OF_STREAM]  # (a lone first field at the end of the connection still goes out)
             self.eof[i] = True
         return True
 

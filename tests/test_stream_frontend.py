@@ -209,3 +209,42 @@ def test_splitter_cuts_slice_group_and_aso_streams_at_picture_boundaries(H, sg):
             chunks += sp.flush()
             assert b"".join(chunks) == stream
             assert [len(c) for c in chunks] == [int(x) for x in sizes], (name, piece)
+
+
+@pytest.mark.gpu
+def test_gpu_reader_and_server_decode_field_streams(H, sg):
+    """Field pictures through the stream front-end (h264/server.go:113-166): access units are PICTURES there -- a field each --, batches cut wherever
+    frames_per_batch says, so the two fields of a frame routinely fall into different batches; every frame must come out once and exact.  A connection
+    that ends on a lone first field still delivers that frame (the reader ends its input with an end-of-stream NAL unit)."""
+    from conftest import FIELD_MATRIX
+    for name, per_batch in (("field_IP", 3), ("field_mixed_paff", 1), ("field_b_spatial", 4), ("field_bottom_first", 5)):
+        kw = FIELD_MATRIX[name]
+        stream, rec, _ = sg.encode(**kw)
+        got = []
+        r = H.H264Reader(io.BytesIO(stream), on_frames=lambda f: got.append(f), max_width=kw["width"], max_height=kw["height"], frames_per_batch=per_batch)
+        assert r.run() == kw["frames"], name
+        assert np.array_equal(np.concatenate(got), rec), name
+    kw = dict(FIELD_MATRIX["field_IP"], slices=1)
+    stream, rec, _ = sg.encode(**kw)
+    cut = stream.rfind(b"\x00\x00\x01")
+    cut -= 1 if stream[cut - 1] == 0 else 0
+    got = []
+    r = H.H264Reader(io.BytesIO(stream[:cut]), on_frames=lambda f: got.append(f), max_width=kw["width"], max_height=kw["height"], frames_per_batch=2)
+    assert r.run() == kw["frames"]
+    out = np.concatenate(got)
+    W, Hc = kw["width"], kw["height"]
+    assert np.array_equal(out[:-1], rec[:-1])
+    y = out[-1][:W * Hc].reshape(Hc, W)
+    assert np.array_equal(y[0::2], rec[-1][:W * Hc].reshape(Hc, W)[0::2]) and (y[1::2] == 128).all()
+    # several connections at once, field-coded and progressive, one batch per tick
+    names = ["field_IP", "cabac_IPP", "field_mixed_paff"]
+    from conftest import FULL_MATRIX
+    enc = [sg.encode(**FULL_MATRIX[n]) for n in names]
+    frames = {}
+    srv = H.BatchServer(max_connections=3, max_width=176, max_height=144, frames_per_batch=2, on_frames=lambda i, f: frames.setdefault(i, []).append(f))
+    for e in enc:
+        assert srv.add(io.BytesIO(e[0])) >= 0
+    counts = srv.run()
+    for i, n in enumerate(names):
+        assert counts[i] == FULL_MATRIX[n]["frames"], n
+        assert np.array_equal(np.concatenate(frames[i]), enc[i][1]), n

@@ -12,12 +12,16 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(3)
 good = [streamgen.encode(width=176, height=144, frames=5, idr_period=0, profile_idc=77, cabac=1, seed=1),
         streamgen.encode(width=96, height=80, frames=4, idr_period=2, profile_idc=66, cabac=0, slice_groups=3, fmo_type=1, aso=1, seed=2),
-        streamgen.encode(width=176, height=144, frames=6, idr_period=0, profile_idc=77, cabac=1, bframes=2, num_ref_frames=3, seed=3)]
+        streamgen.encode(width=176, height=144, frames=6, idr_period=0, profile_idc=77, cabac=1, bframes=2, num_ref_frames=3, seed=3),
+        # field pictures (a frame = two pictures; cut anywhere, the first field of a frame may be left waiting for its second one)
+        streamgen.encode(width=176, height=128, frames=4, idr_period=0, profile_idc=77, cabac=0, field_pics=3, num_ref_frames=2, mmco=1, seed=5)]
+NG = len(good)
+DIMS = [(176, 144), (96, 80), (176, 144), (176, 128)]
 big = streamgen.encode(width=352, height=288, frames=2, idr_period=0, profile_idc=77, cabac=1, seed=4)[0]  # larger than the decoder allows
 codes = {}
 t0 = time.time()
 for r in range(N):
-    dec = H.Decoder(max_streams=2, max_width=176, max_height=144, max_frames_per_batch=6, max_slices_per_frame=8)
+    dec = H.Decoder(max_streams=2, max_width=176, max_height=144, max_frames_per_batch=8, max_slices_per_frame=8)
     L, h = dec._L, dec._h
     log = []
     for step in range(int(rng.integers(3, 25))):
@@ -26,13 +30,13 @@ for r in range(N):
         log.append((op, state))
         try:
             if op == 0:
-                dec.prepare([good[int(rng.integers(0, 3))][0], good[int(rng.integers(0, 3))][0]])
+                dec.prepare([good[int(rng.integers(0, NG))][0], good[int(rng.integers(0, NG))][0]])
             elif op == 1:
                 dec.execute()
             elif op == 2:
                 dec.sync()
             elif op == 3:
-                s = good[int(rng.integers(0, 3))][0]
+                s = good[int(rng.integers(0, NG))][0]
                 dec.decode([s[:int(rng.integers(0, len(s)))], b""])
             elif op == 4:
                 dec.reset()
@@ -61,13 +65,13 @@ for r in range(N):
         except (IndexError, ValueError):
             codes["py"] = codes.get("py", 0) + 1
     # whatever happened: a clean decode afterwards is exact
-    k = int(rng.integers(0, 3))
+    k = int(rng.integers(0, NG))
     try:
         dec.reset()
         dec.set_isolation(False)
-        dec.decode([good[k][0], good[(k + 1) % 3][0]])
-        for i, g in ((0, good[k]), (1, good[(k + 1) % 3])):
-            w, hh = [(176, 144), (96, 80), (176, 144)][(k + i) % 3]
+        dec.decode([good[k][0], good[(k + 1) % NG][0]])
+        for i, g in ((0, good[k]), (1, good[(k + 1) % NG])):
+            w, hh = DIMS[(k + i) % NG]
             assert np.array_equal(dec.read_frames(i, crop=False, size=w * hh * 3 // 2), g[1]), (r, i)
     except Exception as e:  # noqa: BLE001
         print("FAILED round %d k=%d after ops %s: %s" % (r, k, [o for o, _ in log], repr(e)[:200]), flush=True)

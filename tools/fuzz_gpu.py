@@ -15,7 +15,12 @@ cfgs = [dict(width=176, height=144, frames=9, idr_period=0, profile_idc=77, caba
         dict(width=176, height=144, frames=6, idr_period=0, profile_idc=77, cabac=1, num_ref_frames=3, rplm=1, mmco=1, seed=8),
         dict(width=176, height=144, frames=6, idr_period=0, profile_idc=66, cabac=0, slice_groups=4, fmo_type=6, slices=2, aso=1, seed=9),
         dict(width=176, height=144, frames=6, idr_period=0, profile_idc=66, cabac=0, slice_groups=2, fmo_type=3, aso=1, fn_gap_period=3, num_ref_frames=3, seed=10),
-        dict(width=176, height=144, frames=6, idr_period=0, profile_idc=77, cabac=1, slice_groups=3, fmo_type=1, interlace_sps=0, seed=11)]
+        dict(width=176, height=144, frames=6, idr_period=0, profile_idc=77, cabac=1, slice_groups=3, fmo_type=1, interlace_sps=0, seed=11),
+        # field pictures (PAFF): all-field P and B streams, picture-adaptive with marking operations and list modification, slice groups in fields
+        dict(width=176, height=128, frames=5, idr_period=0, profile_idc=77, cabac=0, field_pics=1, num_ref_frames=3, sub8x8_permille=300, seed=12),
+        dict(width=176, height=128, frames=7, idr_period=0, profile_idc=77, cabac=0, field_pics=2, bframes=2, direct_temporal=1, weighted_bipred=2, num_ref_frames=2, seed=13),
+        dict(width=176, height=128, frames=6, idr_period=4, profile_idc=100, cabac=0, transform8x8=1, field_pics=3, mmco=1, rplm=1, num_ref_frames=3, seed=14),
+        dict(width=176, height=128, frames=4, idr_period=0, profile_idc=77, cabac=0, field_pics=3, slice_groups=2, fmo_type=3, slices=2, aso=1, num_ref_frames=2, seed=15)]
 streams = [streamgen.encode(**c)[0] for c in cfgs]
 codes = {}
 t0 = time.time()
@@ -31,7 +36,7 @@ for t in range(N):
     else:  # splice the tail of another stream behind a cut
         o = streams[(t + 1) % len(streams)]
         s = s[:int(rng.integers(200, len(s)))] + o[int(rng.integers(100, len(o))):]
-    dec = H.Decoder(max_streams=2, max_width=176, max_height=144, max_frames_per_batch=12, max_slices_per_frame=8)
+    dec = H.Decoder(max_streams=2, max_width=176, max_height=144, max_frames_per_batch=16, max_slices_per_frame=8, b_pictures=t & 2)
     dec.set_isolation(bool(t & 1))
     code = 0
     try:

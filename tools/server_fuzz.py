@@ -27,9 +27,13 @@ for r in range(N):
     clients = []
     for c in range(rnd.randint(3, 7)):
         while True:
+            g["FIELDS"] = rnd.random() < 0.25  # a quarter of the clients send field pictures (PAFF): a frame is two access units there
             kw = draw()
             kw["width"], kw["height"] = 16 * rnd.randint(2, 13), 16 * rnd.randint(2, 10)  # (cropped output == coded size)
-            kw.pop("interlace_sps", None)
+            if g["FIELDS"]:
+                kw["height"] = 32 * rnd.randint(1, 5)
+            else:
+                kw.pop("interlace_sps", None)
             if max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1)) > 16:
                 continue
             try:
