@@ -153,7 +153,7 @@ struct Ent {
     uint32_t wpos, wbase, rbsp_words; // next word to fetch / first word of `win`
     uint32_t win, winn, winx; // lane i: RBSP word wbase + i / + 64 + i / + 128 + i, byte-swapped to MSB-first
     // CABAC engine
-    uint32_t range, value;
+    uint32_t range, value;   // range: codIRange << avail (renormalisation then only moves avail); value: see the engine below
     int avail;
     uint32_t ca, cb, wk;     // context states, see above; cb lanes 61..63 = ctxIdx 399..401
     int wk_cat;              // ctxBlockCat whose states are in wk (-1: none)
@@ -302,7 +302,7 @@ FI int get_se(Ent &e) {
 }
 
 // ------------------------------------------------------------------ CABAC engine (9.3.1.2, 9.3.3.2)
-// codIOffset is kept scaled: value = (codIOffset << avail) | next `avail` stream bits.
+// codIOffset is kept scaled: value = (codIOffset << avail) | next `avail` stream bits, and so is codIRange: range = codIRange << avail.
 //
 // Issue balance.  A compute unit has ONE scalar ALU (about one SALU instruction per cycle for all of
 // its wavefronts) next to four vector ALUs, and tens of slices share a CU, so a decoder written purely
@@ -311,14 +311,21 @@ FI int get_se(Ent &e) {
 // same value in every lane, while table indices, loop control and branches stay scalar.  VGPR() pins
 // a wave-uniform value to the vector side; UNI() turns a vector-side condition into a scalar branch
 // condition (v_cmp writes the lane mask, one s_cmp tests it).
+// Round 4 re-measured the balance (PMC + variant builds): at 256 streams a SIMD's vector pipe is busy ~90 % of the kernel and the P slices are
+// bound by it, the I slices by their own dependency chain -- which is why handing the successor-state selection and the bin to the scalar ALU
+// (7 vector instructions less per bin, but a vector -> scalar hop behind the compare) lost 3 - 14 %, and why every vector instruction saved
+// without such a hop shows up in the step time.
 #define VGPR(x) asm volatile("" : "+v"(x))
 #define OPAQUE(x) asm volatile("" : "+v"(x))
 #define UNI(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
+// a context state as it sits in a register lane: pStateIdx | valMPS << 6 (the byte kept in LDS and in DevTables::ctx_init) and valMPS once more in bit 31
+FI uint32_t ctx_word(uint32_t b) { return b | (b & 64u) << 25; }
 FI void cabac_refill(Ent &e) {
     if (__builtin_expect(UNI(e.avail < 7), 0)) { // about once per 13 decisions: keep the common path fall-through
         e.value = (e.value << 16) | (peek32(e) >> 16);
         skip(e, 16);
         e.avail += 16;
+        e.range <<= 16;
     }
 }
 FI void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
@@ -336,56 +343,53 @@ FI void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
 FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     MI_COUNT_BIN(e);
     const int idx = RFL(idx_);
-    // A context state is pStateIdx | valMPS << 6: it selects its own table lane as it stands (v_readlane takes the select modulo 64), so the
-    // chain state -> table entries has no scalar instruction in it.
+    // A context state is pStateIdx | valMPS << 6 | valMPS << 31: it selects its own table lane as it stands (v_readlane takes the select modulo
+    // 64), so the chain state -> table entries has no scalar instruction in it.
     const uint32_t st = RDL(reg, idx);
     const uint32_t rl4 = RDL(e.v_rlps, st), tr = RDL(e.v_trans, st);
-    // everything else runs on the vector side (the CU's single scalar ALU is the scarce unit): st is pinned there
+    // everything else runs on the vector side, same value in every lane: st is pinned there
     uint32_t vst = st;
     VGPR(vst);
-    const uint32_t mps = __builtin_amdgcn_ubfe(vst, 6, 1); // (bits 8 and up of a state register may hold leftovers of the table word: every use masks them)
-    // the two candidate successor states: v_trans holds the LPS successor of valMPS 0 (bit 6 set where the MPS flips: pStateIdx 0) in its low
-    // byte and, one byte up, what the MPS path adds to the state (1; 0 at pStateIdx 62)
-    const uint32_t next_lps = tr ^ (vst & 64u);
-    const uint32_t next_mps = vst + __builtin_amdgcn_alignbyte(0u, tr, 1u); // (tr >> 8 on the vector side: the scalar ALU is the scarce unit)
-    // rangeTabLPS[pStateIdx][(codIRange >> 6) & 3]: codIRange >> 6 is 4..7, which as a v_perm selector picks byte 0..3 of the first operand
-    const uint32_t rlps = __builtin_amdgcn_perm(rl4, 0u, e.range >> 6);
+    // the two candidate successor states.  v_trans: pStateIdx ^ (LPS successor), with bits 6 and 31 set where the MPS flips (pStateIdx 0) -- XOR
+    // with the state gives the LPS successor -- and, one byte up, what the MPS path adds to the state (1; 0 at pStateIdx 62): one SDWA add.
+    // (Bits 8..30 of a state register may hold leftovers of the table word; nothing reads them.)
+    uint32_t next_mps;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(next_mps) : "s"(tr), "v"(vst));
+    const uint32_t next_lps = tr ^ vst;
+    // e.range is codIRange << avail.  rangeTabLPS[pStateIdx][(codIRange >> 6) & 3]: codIRange >> 6 is 4..7, which as a v_perm selector picks
+    // byte 0..3 of the first operand
+    const uint32_t rlps = __builtin_amdgcn_perm(rl4, 0u, e.range >> (e.avail + 6)) << e.avail;
     const uint32_t rmps = e.range - rlps;
-    const uint32_t scaled = rmps << e.avail;
-    const bool lps = e.value >= scaled;
-    const uint32_t diff = e.value - scaled; // wraps when value < scaled; both are below 2^31
+    const bool lps = e.value >= rmps;
+    const uint32_t diff = e.value - rmps; // wraps when value < rmps; both are below 2^31
     e.value = min(e.value, diff);
     e.range = lps ? rlps : rmps;
     reg = LANE == idx ? (lps ? next_lps : next_mps) : reg;
-    const uint32_t binv = (diff >> 31) ^ (mps ^ 1); // valMPS on the MPS path (sign bit set), !valMPS otherwise
-    const int n = __builtin_clz(e.range) - 23;
-    e.range <<= n;
-    e.avail -= n;
+    e.avail = 23 - __builtin_clz(e.range); // RenormD: the scaled range stays as it is, only the scale moves
     cabac_refill(e);
-    return binv;
+    return vst ^ diff; // the bin is the complement of the sign: valMPS on the MPS path (diff negative), !valMPS otherwise
 }
-#define BIN_A(e, ctx) UNI(cabac_decide(e, (e).ca, (ctx)) != 0)          /* ctxIdx 0..63 */
-#define BIN_B(e, ctx) UNI(cabac_decide(e, (e).cb, (ctx) - 64) != 0)     /* ctxIdx 64..124 */
-#define BIN_T8(e, inc) UNI(cabac_decide(e, (e).cb, 61 + (inc)) != 0)    /* ctxIdx 399..401 */
-#define BIN_W(e, lane) UNI(cabac_decide(e, (e).wk, (lane)) != 0)        /* residual working set */
-#define BINI_A(e, ctx) static_cast<int>(RFL(cabac_decide(e, (e).ca, (ctx))))
-#define BINI_B(e, ctx) static_cast<int>(RFL(cabac_decide(e, (e).cb, (ctx) - 64)))
-#define BINI_T8(e, inc) static_cast<int>(RFL(cabac_decide(e, (e).cb, 61 + (inc))))
+// a bin as a branch condition (v_cmp + s_cbranch_vcc) / as a scalar integer
+#define BIN_A(e, ctx) UNI(static_cast<int>(cabac_decide(e, (e).ca, (ctx))) >= 0)          /* ctxIdx 0..63 */
+#define BIN_B(e, ctx) UNI(static_cast<int>(cabac_decide(e, (e).cb, (ctx) - 64)) >= 0)     /* ctxIdx 64..124 */
+#define BIN_T8(e, inc) UNI(static_cast<int>(cabac_decide(e, (e).cb, 61 + (inc))) >= 0)    /* ctxIdx 399..401 */
+#define BIN_W(e, lane) UNI(static_cast<int>(cabac_decide(e, (e).wk, (lane))) >= 0)        /* residual working set */
+#define BINI_A(e, ctx) static_cast<int>(RFL(~cabac_decide(e, (e).ca, (ctx)) >> 31))
+#define BINI_B(e, ctx) static_cast<int>(RFL(~cabac_decide(e, (e).cb, (ctx) - 64) >> 31))
+#define BINI_T8(e, inc) static_cast<int>(RFL(~cabac_decide(e, (e).cb, 61 + (inc)) >> 31))
 FI bool cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
     MI_COUNT_BIN(e);
     e.avail -= 1;
-    const uint32_t scaled = e.range << e.avail;
-    const bool one = e.value >= scaled;
-    e.value = min(e.value, e.value - scaled);
+    e.range >>= 1; // (codIRange << avail, with avail one less)
+    const bool one = e.value >= e.range;
+    e.value = min(e.value, e.value - e.range);
     cabac_refill(e);
     return UNI(one);
 }
 FI bool cabac_terminate(Ent &e) { // 9.3.3.2.4
-    e.range -= 2;
-    if (UNI(e.value >= (e.range << e.avail))) return true;
-    const int n = __builtin_clz(e.range) - 23;
-    e.range <<= n;
-    e.avail -= n;
+    e.range -= 2u << e.avail;
+    if (UNI(e.value >= e.range)) return true;
+    e.avail = 23 - __builtin_clz(e.range);
     cabac_refill(e);
     return false;
 }
@@ -448,7 +452,7 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
         e.wk_valid = grp == 0 ? li < nsig : (grp == 1 ? li < nlast : l < 42);
         e.wk_home = home < 464 ? home : 463;
         LDS_SYNC(); // the scatter above may alias the gather below
-        e.wk = e.s->ctx[e.wk_home];
+        e.wk = ctx_word(e.s->ctx[e.wk_home]);
         e.wk_cat = cat, e.wk_c0 = c0n;
     }
     const uint32_t c0 = e.wk_c0;
@@ -1710,11 +1714,10 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     e.mbx = e.mby = 0, e.cur_type = 0;
     const int l = LANE;
     // ---- per-lane tables ----
-    { // Tables 9-44 / 9-45: lane p keeps the entries of pStateIdx p; the transition entry is the complete next state
-      // (pStateIdx << 1 | valMPS) after an LPS for valMPS 0 -- XOR with valMPS gives the other one (pStateIdx 0 flips the MPS)
+    { // Tables 9-44 / 9-45: lane p keeps the entries of pStateIdx p (cabac_decide says how the transition word is laid out)
         const uint8_t *rl = tab->range_lps[l];
         e.v_rlps = rl[0] | (rl[1] << 8) | (rl[2] << 16) | (static_cast<uint32_t>(rl[3]) << 24);
-        e.v_trans = static_cast<uint32_t>(tab->trans_lps[l]) | (l == 0 ? 64u : 0u) | (l < 62 ? 256u : 0u);
+        e.v_trans = (static_cast<uint32_t>(tab->trans_lps[l]) ^ static_cast<uint32_t>(l)) | (l == 0 ? 0x80000040u : 0u) | (l < 62 ? 256u : 0u);
     }
     // coefficient scans of the picture (8.5.6, 8.5.7): zig-zag, or the field scan in a field picture (h264/slice.go:867-872 field_pic_flag)
     const uint8_t *scan4 = pd->field ? tab->fieldscan4 : tab->zigzag4, *scan8 = pd->field ? tab->fieldscan8 : tab->zigzag8;
@@ -1746,8 +1749,8 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     { // context variables 9.3.1.1: macroblock-level states into the two VGPRs, residual states into LDS
         const int set = e.islice ? 0 : 1 + sd->cabac_init_idc;
         const uint8_t *src = tab->ctx_init[set][sd->slice_qp];
-        e.ca = src[l];
-        e.cb = src[l < 61 ? 64 + l : 399 + (l - 61)];
+        e.ca = ctx_word(src[l]);
+        e.cb = ctx_word(src[l < 61 ? 64 + l : 399 + (l - 61)]);
         e.wk = 0;
         e.wk_cat = -1, e.wk_c0 = 0, e.wk_home = 0, e.wk_valid = false;
         for (int i = l; i < 464; i += 64) sh.ctx[i] = src[i];

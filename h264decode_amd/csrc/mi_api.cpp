@@ -1947,12 +1947,14 @@ static int execute_stage(h264mi_decoder *d, int stage_idx, bool exclusive) {
             const int first = g.level_first[lv], n = g.level_first[lv + 1] - first;
             // ColRec arrays cross passes: B slices read what the previous pass's k_dbprep wrote, and this pass's k_dbprep may
             // rewrite the record array of a frame slot (released meanwhile) that the previous pass's B slices still read.  So
-            // everything after the I/P launch waits for the previous pass's entropy stream -- the I/P launch itself does not,
-            // it overlaps the previous pass's B launches; batches without B slices on both sides never wait.
-            if (fence_prev_pass && (lv > 0 || g.colsave_n[lv])) {
-                hipStreamWaitEvent(st, d->ev_col[(d->pass - 1) % MI_SETS], 0);
+            // everything after the I/P launch waits for the previous pass's entropy stream -- the I/P launch itself does not
+            // (it neither reads nor writes ColRec arrays), it overlaps the previous pass's B launches; batches without B slices on
+            // both sides never wait.
+            auto fence = [&] {
+                if (fence_prev_pass) hipStreamWaitEvent(st, d->ev_col[(d->pass - 1) % MI_SETS], 0);
                 fence_prev_pass = false;
-            }
+            };
+            if (lv > 0) fence();
             if (n > 0) {
                 if (lv == 0)
                     hipLaunchKernelGGL(g.fmo_pics.empty() ? k_entropy : k_entropy_f, dim3(n), dim3(64), lds_pad, st, g.d_slices, g.d_pics, g.d_bits, d->d_tables, mbrec, coef, d->d_pool_head + set,
@@ -1963,6 +1965,7 @@ static int execute_stage(h264mi_decoder *d, int stage_idx, bool exclusive) {
             }
             // the pictures complete with this level: K5's strengths and filter parameters, and the motion later B slices (the next
             // level's, or a later batch's) take their direct prediction from
+            if (g.colsave_n[lv]) fence();
             if (g.prep_n[lv])
                 hipLaunchKernelGGL(k_dbprep, dim3((g.mbs_max + MI_DBPREP_MBS - 1) / MI_DBPREP_MBS, g.prep_n[lv]), dim3(256), 0, st, g.d_lists + g.prep_off[lv], g.d_pics,
                                    d->d_tables, mbrec, d->d_mv1[set], d->d_dbprm[set], 0, d->d_imask[set]);

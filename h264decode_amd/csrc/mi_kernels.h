@@ -33,7 +33,9 @@ extern "C" __global__ void k_intra_x(const uint32_t *pic_list, const PicDesc *pi
 // k_dbprep: boundary strengths + alpha / beta / tC0 of every macroblock of a batch (DbPrm), so that K5 -- one serial dependency chain per
 // picture -- has none of that work in its steps; for the pictures flagged PicDesc::save_col also their ColRec array (the motion later B pictures
 // take their direct prediction from).  grid = (ceil(mbs_max / MI_DBPREP_MBS), pictures of the list), block = 256.
+#ifndef MI_DBPREP_MBS
 #define MI_DBPREP_MBS 64
+#endif
 extern "C" __global__ void k_dbprep(const uint32_t *pic_list, const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1, DbPrm *out, int col_only, unsigned long long *intramask);
 // K5: in-loop deblocking, one workgroup per picture, one wavefront per group of 4 macroblock rows (up to 16 groups side by side).
 // block = 64 * nwaves, dynamic LDS = mi_deblock_lds_bytes(nwaves, ring, ring_last); (nwaves, ring, ring_last) from mi_deblock_plan()

@@ -4,6 +4,8 @@ Usage: python tools/b_profile.py [streams] [frames] [key=value generator overrid
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 os.environ.setdefault("H264MI_SLICE_STATS", "1")
+if os.environ["H264MI_SLICE_STATS"] == "0":
+    del os.environ["H264MI_SLICE_STATS"]
 import numpy as np
 import streamgen
 import h264decode_amd as H
@@ -26,7 +28,7 @@ dec.execute(); dec.sync()
 print("kernel ms (entropy, inter, intra, deblock, total):", dec.kernel_times_ms() if hasattr(dec, "kernel_times_ms") else None, file=sys.stderr)
 dec._L.h264mi_decoder_set_profiling(dec._h, 0)
 t0 = time.perf_counter()
-for _ in range(3):
+for _ in range(6):
     dec.execute()
 dec.sync()
-print("ms per pass (pipelined):", (time.perf_counter() - t0) / 3 * 1e3, file=sys.stderr)
+print("ms per pass (pipelined):", (time.perf_counter() - t0) / 6 * 1e3, file=sys.stderr)
