@@ -193,6 +193,7 @@ struct Stage {
     // n - 1 or older than the batch (k_entropy_b) -- and the slice table is ordered by level.
     std::vector<int> pic_level, slice_level; // per picture / per slice of the batch (slice_level in parse order, until the table is sorted)
     std::vector<uint8_t> pic_save_col;       // the picture's motion is kept for later direct prediction (k_dbprep writes its ColRec array)
+    std::vector<int> pic_wave;               // reconstruction wave of the picture: 0 for a picture that reads no picture of this batch, else 1 + the latest wave among its references
     std::vector<int> level_first;            // first slice of each level in the sorted table (+ end marker)
     std::vector<uint32_t> colsave_n;            // per level: pictures whose ColRec array k_dbprep writes (what the cross-pass fence looks at)
     std::vector<uint32_t> prep_off, prep_n;     // per level: the pictures whose last slice is of that level (k_dbprep runs on them after the level), as a range of d_lists
@@ -1392,8 +1393,8 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         pd.pitch = static_cast<uint32_t>(wmb * 16 * (sh.field_pic ? 2 : 1)), pd.plane = static_cast<uint32_t>(wmb * 16) * static_cast<uint32_t>(hmb * 16);
         pd.inv_wmb = static_cast<uint32_t>((1ull << 32) / static_cast<uint32_t>(wmb)) + 1u;
         pd.pool_base = d->h_pools[si].base, pd.slot_bytes = d->slot_bytes, pd.n_slots = static_cast<uint32_t>(d->n_slots);
-        g.pic_level.resize(g.n_pics, 0), g.pic_save_col.resize(g.n_pics, 0);
-        g.pic_level[s.cur_pic] = 0, g.pic_save_col[s.cur_pic] = 0;
+        g.pic_level.resize(g.n_pics, 0), g.pic_save_col.resize(g.n_pics, 0), g.pic_wave.resize(g.n_pics, 0);
+        g.pic_level[s.cur_pic] = 0, g.pic_save_col[s.cur_pic] = 0, g.pic_wave[s.cur_pic] = 0;
         pd.mb_base = g.mb_used;
         g.mb_used += static_cast<uint64_t>(wmb) * hmb_pic;
         pd.first_slice = g.n_slices;
@@ -1470,6 +1471,19 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         memset(&bx, 0, sizeof(bx));
         r = build_ref_lists(s, sps, sh, bslice, sd.ref_slot, bx.ref_slot1);
         if (r != H264MI_OK) return r;
+        { // the pictures of this batch the slice predicts from have to be reconstructed (deblocked) first: Stage::pic_wave
+            int wave = g.pic_wave[s.cur_pic];
+            auto after = [&](int entry) {
+                if (entry < 0) return;
+                const Slot &rs = s.slots[sh.field_pic ? MI_REF_SLOT(entry) : entry];
+                for (int pic : {rs.pic, rs.fpic[0], rs.fpic[1]}) // (a frame, or either field: whichever of them this batch decodes)
+                    if (pic >= 0 && pic != s.cur_pic && pic < static_cast<int>(g.pic_wave.size())) wave = std::max(wave, g.pic_wave[pic] + 1);
+            };
+            for (int i = 0; i <= sh.num_ref_idx_l0_active_minus1 && i < MI_MAX_REFS; i++) after(sd.ref_slot[i]);
+            if (bslice)
+                for (int i = 0; i <= sh.num_ref_idx_l1_active_minus1 && i < MI_MAX_REFS; i++) after(bx.ref_slot1[i]);
+            g.pic_wave[s.cur_pic] = wave;
+        }
         sd.wp_flag = static_cast<uint8_t>(explicit_wp);
         sd.luma_log2_denom = static_cast<uint8_t>(sh.luma_log2_weight_denom), sd.chroma_log2_denom = static_cast<uint8_t>(sh.chroma_log2_weight_denom);
         for (int i = 0; i < MI_MAX_REFS; i++) {
@@ -1614,7 +1628,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     g.epochs.resize(d->st.size());
     for (size_t si = 0; si < d->st.size(); si++) g.epochs[si] = d->st[si].epoch;
     g.n_bext = 0;
-    g.pic_level.clear(), g.slice_level.clear(), g.pic_save_col.clear();
+    g.pic_level.clear(), g.slice_level.clear(), g.pic_save_col.clear(), g.pic_wave.clear();
     memset(&g.info, 0, sizeof(g.info));
     for (size_t si = 0; si < d->st.size(); si++) {
         StreamState &s = d->st[si];
@@ -1756,7 +1770,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
             // (nothing is decodable before its next IDR picture); the other streams are not affected.
             g.n_pics = pics0, g.n_slices = slices0, g.mb_used = mb0, g.info.n_macroblocks = info_mb0;
             g.n_bext = bext0;
-            g.pic_level.resize(pics0), g.pic_save_col.resize(pics0), g.slice_level.resize(slices0);
+            g.pic_level.resize(pics0), g.pic_save_col.resize(pics0), g.pic_wave.resize(pics0), g.slice_level.resize(slices0);
             while (!g.fmo_pics.empty() && static_cast<int>(g.fmo_pics.back()) >= pics0) g.fmo_pics.pop_back();
             g.grey.erase(std::remove_if(g.grey.begin(), g.grey.end(), [&](const Stage::GreyFill &f) { return static_cast<int>(f.stream) == si; }), g.grey.end());
             reset_stream(s, true);
@@ -1771,7 +1785,7 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
     }
     // A reference picture that outlives the batch may become the co-located picture of a B picture of a later batch: its
     // motion is kept too (8.4.1.2.1).
-    g.pic_level.resize(g.n_pics, 0), g.pic_save_col.resize(g.n_pics, 0), g.slice_level.resize(g.n_slices, 0);
+    g.pic_level.resize(g.n_pics, 0), g.pic_save_col.resize(g.n_pics, 0), g.pic_wave.resize(g.n_pics, 0), g.slice_level.resize(g.n_slices, 0);
     for (int si = 0; si < n_streams; si++)
         for (const Slot &sl : d->st[si].slots)
             if (sl.ref)
@@ -1795,15 +1809,18 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
         for (int i = g.n_slices - 1; i >= 0; i--) g.level_first[g.slice_level[i]] = i;
         for (int l = n_levels - 1; l >= 0; l--) g.level_first[l] = std::min(g.level_first[l], g.level_first[l + 1]);
     }
-    // picture "waves": the k-th picture of every stream can be reconstructed side by side.  Per wave: all pictures (K3), the
-    // inter pictures without / the pictures with B slices (K4 / K4 two-list), the pictures without B slices (K5; with: K5 two-list)
+    // picture "waves": pictures that do not predict from one another are reconstructed side by side -- wave 0 holds the pictures that read no
+    // picture of this batch (intra pictures wherever they stand in their stream; pictures whose references an earlier batch decoded), wave n + 1
+    // the pictures whose latest reference is of wave n (Stage::pic_wave; with I P P P ... that is the k-th picture of every stream, with
+    // I B B P ... the B pictures share the wave of the P picture that follows them in decoding order, an all-intra stream is one wave).  Per wave:
+    // all pictures (K3), the inter pictures without / the pictures with B slices (K4 / K4 two-list), the pictures without B slices (K5; with: K5 two-list)
     size_t nw = 0;
-    for (auto &s : d->st) nw = std::max<size_t>(nw, s.n_pics_in_batch);
+    for (int i = 0; i < g.n_pics; i++) nw = std::max<size_t>(nw, static_cast<size_t>(g.pic_wave[i]) + 1);
     g.waves.assign(nw, {});
     g.waves_inter.assign(nw, {});
     for (int i = 0; i < g.n_pics; i++) {
-        g.waves[g.h_pics[i].order].push_back(i);
-        if (!g.h_pics[i].is_intra_only) g.waves_inter[g.h_pics[i].order].push_back(i);
+        g.waves[g.pic_wave[i]].push_back(i);
+        if (!g.h_pics[i].is_intra_only) g.waves_inter[g.pic_wave[i]].push_back(i);
     }
     g.wave_off.clear();
     g.wave_inter_off.clear();
