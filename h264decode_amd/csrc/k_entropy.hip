@@ -323,29 +323,36 @@ FI int get_se(Ent &e) {
 #define UNI(cond) (__builtin_amdgcn_ballot_w64(cond) != 0)
 // a context state as it sits in a register lane: pStateIdx | valMPS << 6 (the byte kept in LDS and in DevTables::ctx_init) and valMPS once more in bit 31
 FI uint32_t ctx_word(uint32_t b) { return b | (b & 64u) << 25; }
+// 16 more stream bits when fewer than 7 are left below codIOffset (avail < 7, i.e. the scaled range is below 2^15), and the scale of the range as
+// it stands now: avail = 23 - clz(range) (codIRange has its bit 8 set after RenormD).  Written this way -- test on the range, avail afterwards -- the
+// common path is: compare, branch not taken, count leading zeros, subtract.
 FI void cabac_refill(Ent &e) {
-    if (__builtin_expect(UNI(e.avail < 7), 0)) { // about once per 13 decisions: keep the common path fall-through
+    if (__builtin_expect(UNI(e.range < 0x8000u), 0)) { // about once per 13 decisions: keep the common path fall-through
         e.value = (e.value << 16) | (peek32(e) >> 16);
         skip(e, 16);
-        e.avail += 16;
         e.range <<= 16;
     }
+    e.avail = 23 - __builtin_clz(e.range);
 }
 FI void cabac_start(Ent &e) { // initDecodingEngine, h264/cabac.go:439-446
     e.range = 510;
     e.value = get_bits(e, 9);
-    e.avail = 0;
     VGPR(e.range);
     VGPR(e.value);
-    VGPR(e.avail);
     cabac_refill(e);
+    VGPR(e.avail);
 }
 // DecodeDecision (h264/cabac.go:521-540) + state transition (:544-553) + RenormD (:503-511) on the
 // context state held in lane `idx_` of `reg`.  The bin comes back on the vector side (same value in every
 // lane): BIN_x() turns it into a branch condition (v_cmp + s_cbranch_vcc), BINI_x() into a scalar integer.
+// SM: the lane of the state is selected by a mask made on the scalar side (1 << idx) instead of a lane compare -- for a context index that is not
+// a compile-time constant the shift fills one of the wait states between the two v_readlane and saves the v_cmp.  Used in the residual loops
+// (196.7 against 200.6 ms); at the macroblock-level sites with computed indices (skip flag, cbp, mvd, coded_block_flag) it measured 1 ms slower.
+template <bool SM = false>
 FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     MI_COUNT_BIN(e);
     const int idx = RFL(idx_);
+    const uint64_t lanemask = 1ull << (idx & 63);
     // A context state is pStateIdx | valMPS << 6 | valMPS << 31: it selects its own table lane as it stands (v_readlane takes the select modulo
     // 64), so the chain state -> table entries has no scalar instruction in it.
     const uint32_t st = RDL(reg, idx);
@@ -381,9 +388,12 @@ FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     const uint32_t diff = e.value - rmps; // wraps when value < rmps; both are below 2^31
     e.value = min(e.value, diff);
     e.range = lps ? rlps : rmps;
-    reg = LANE == idx ? (lps ? next_lps : next_mps) : reg;
-    e.avail = 23 - __builtin_clz(e.range); // RenormD: the scaled range stays as it is, only the scale moves
-    cabac_refill(e);
+    if (SM) {
+        const uint32_t next = lps ? next_lps : next_mps;
+        asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(reg) : "v"(next), "s"(lanemask));
+    } else
+        reg = LANE == idx ? (lps ? next_lps : next_mps) : reg;
+    cabac_refill(e); // RenormD: the scaled range stays as it is, only the scale moves
     return vst ^ diff; // the bin is the complement of the sign: valMPS on the MPS path (diff negative), !valMPS otherwise
 }
 // a bin as a branch condition (v_cmp + s_cbranch_vcc) / as a scalar integer
@@ -399,7 +409,7 @@ FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
 #define BIN_A(e, ctx) UNI(static_cast<int>(cabac_decide(e, (e).ca, (ctx))) >= 0)          /* ctxIdx 0..63 */
 #define BIN_B(e, ctx) UNI(static_cast<int>(cabac_decide(e, (e).cb, (ctx) - 64)) >= 0)     /* ctxIdx 64..124 */
 #define BIN_T8(e, inc) UNI(static_cast<int>(cabac_decide(e, (e).cb, 61 + (inc))) >= 0)    /* ctxIdx 399..401 */
-#define BIN_W(e, lane) UNI(static_cast<int>(cabac_decide(e, (e).wk, (lane))) >= 0)        /* residual working set */
+#define BIN_W(e, lane) UNI(static_cast<int>(cabac_decide<true>(e, (e).wk, (lane))) >= 0)        /* residual working set */
 #define BINI_A(e, ctx) static_cast<int>(RFL(~cabac_decide(e, (e).ca, (ctx)) >> 31))
 #define BINI_B(e, ctx) static_cast<int>(RFL(~cabac_decide(e, (e).cb, (ctx) - 64) >> 31))
 #define BINI_T8(e, inc) static_cast<int>(RFL(~cabac_decide(e, (e).cb, 61 + (inc)) >> 31))
@@ -410,13 +420,17 @@ FI bool cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
     e.range >>= 1; // (codIRange << avail, with avail one less)
     const bool one = e.value >= e.range;
     e.value = min(e.value, e.value - e.range);
-    cabac_refill(e);
+    if (__builtin_expect(UNI(e.range < 0x8000u), 0)) {
+        e.value = (e.value << 16) | (peek32(e) >> 16);
+        skip(e, 16);
+        e.range <<= 16;
+        e.avail += 16;
+    }
     return UNI(one);
 }
 FI bool cabac_terminate(Ent &e) { // 9.3.3.2.4
     e.range -= 2u << e.avail;
     if (UNI(e.value >= e.range)) return true;
-    e.avail = 23 - __builtin_clz(e.range);
     cabac_refill(e);
     return false;
 }
@@ -489,38 +503,41 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
     }
     const int last = static_cast<int>(c0 & 255) - 1; // maxNumCoeff - 1
     const bool is8 = cat == 5;
+    // the significant coefficients as a bit set with the HIGHEST frequency in the LOWEST bit (coefficient i = bit 63 - i): the levels come highest
+    // frequency first (7.3.5.3.3), which is then find-first-one / clear-that-bit
     uint64_t sig = 0;
     int i;
     MI_R(e, 2);
-    // significance map; a set last_significant_coeff_flag ends the loop through the index itself
+    // significance map; a set last_significant_coeff_flag ends the loop through the index itself (a jump out of the loop costs the compiler's
+    // structurizer more than the select), running off the end means the final coefficient is significant by inference.
+    // (ctxIdxInc of a 4x4 / 2x2 block is the scan position itself: Min(numDecod / NumC8x8, 2) only bites with 4:2:2 chroma DC blocks.)
     if (is8) {
         for (i = 0; i < last; i++) {
             const uint32_t m = RDL(e.v_maps, i);
             if (BIN_W(e, m & 255)) {
-                sig |= 1ull << i;
+                sig |= 0x8000000000000000ull >> i;
                 if (BIN_W(e, 16 + ((m >> 8) & 255))) i = 64;
             }
         }
     } else {
-        const int cap = cat == 3 ? 2 : 15;
         for (i = 0; i < last; i++) {
-            const int inc = i < cap ? i : cap;
-            if (BIN_W(e, inc)) {
-                sig |= 1ull << i;
-                if (BIN_W(e, 16 + inc)) i = 64;
+            if (BIN_W(e, i)) {
+                sig |= 0x8000000000000000ull >> i;
+                if (BIN_W(e, 16 + i)) i = 64;
             }
         }
     }
+    if (i == last) sig |= 0x8000000000000000ull >> last;
     MI_R(e, 0);
-    if (i == last) sig |= 1ull << last; // no last flag seen: the final coefficient is significant by inference
     const int n = __builtin_popcountll(sig);
     // levels, highest frequency first (9.3.3.1.3): inc0 / cx are the wk lanes of the two context selections
     int inc0 = 33, cx = 37;
     const int cxmax = 37 + static_cast<int>((c0 >> 16) & 15);
     int lv = 0;
+    const int lrev = 63 - l;
     while (sig) {
-        const int k = 63 - __clzll(static_cast<long long>(sig));
-        sig &= ~(1ull << k);
+        const int k = __builtin_ctzll(sig);
+        asm("s_bitset0_b64 %0, %1" : "+s"(sig) : "s"(k));
         int a = 1;
         if (BIN_W(e, inc0)) {
             a = 2;
@@ -531,7 +548,7 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
         } else if (inc0 != 32)
             inc0 = inc0 < 36 ? inc0 + 1 : 36;
         const int v = cabac_bypass(e) ? -a : a;
-        lv = l == k ? v : lv;
+        lv = lrev == k ? v : lv;
     }
     MI_R(e, 1);
     {
