@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import FIELD_MATRIX, FULL_MATRIX, MATRIX, POC_MATRIX, PRODUCT_DECODES_B, pictures_of
+from conftest import BASE, FIELD_MATRIX, FULL_MATRIX, MATRIX, POC_MATRIX, PRODUCT_DECODES_B, pictures_of
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "stream_md5.json")
@@ -846,6 +846,39 @@ def _access_units(H, stream):
     sp = H.AccessUnitSplitter(max_units_per_chunk=1)
     return sp.feed(stream) + sp.flush()
 
+
+
+
+def test_gpu_reconstruction_waves_follow_the_prediction_dependencies(H, sg):
+    """Pictures that do not predict from one another are reconstructed side by side (mi_api.cpp: Stage::pic_wave): an all-intra stream is ONE
+    launch of K3 / K5 however many pictures it has, two GOPs in one batch share their waves, the B pictures between two anchors share one wave,
+    and a batch that continues a GOP starts at wave 0 again -- with the pictures bit-exact in every case.  (The launch count is read through the
+    profiling accessor: one K3 launch per wave.)"""
+    def waves_and_parity(streams, recs, frames_per_batch, slices=1):
+        W, Hc = (BASE["width"] + 15) & ~15, (BASE["height"] + 15) & ~15
+        dec = H.Decoder(max_streams=len(streams), max_width=W, max_height=Hc, max_frames_per_batch=frames_per_batch, max_slices_per_frame=8)
+        dec.set_profiling(True)
+        dec.decode(streams)
+        n = len(dec.launch_times_ms("intra"))
+        for i, rec in enumerate(recs):
+            assert np.array_equal(dec.read_frames(i, crop=False), rec), "stream %d" % i
+        dec.close()
+        return n
+    base = dict(BASE, profile_idc=77, cabac=1)
+    # all-intra: 6 IDR pictures, one wave
+    s_i, r_i, _ = sg.encode(**dict(base, frames=6, idr_period=1, seed=901))
+    assert waves_and_parity([s_i], [r_i], 6) == 1
+    # I P P P P: five waves; two such GOPs in one batch: still five, the second I picture joins wave 0
+    s_p, r_p, _ = sg.encode(**dict(base, frames=10, idr_period=5, seed=902))
+    assert waves_and_parity([s_p], [r_p], 10) == 5
+    # side by side with the all-intra stream: the longest chain decides
+    assert waves_and_parity([s_p, s_i], [r_p, r_i], 10) == 5
+    # I B B P B B P ...: an anchor per wave, the B pictures ride with the anchor that follows them in decoding order
+    kb = dict(MATRIX["b_ibbp_cabac"])
+    s_b, r_b, _ = sg.encode(**kb)
+    anchors = 1 + (kb["frames"] - 1 + kb["bframes"]) // (kb["bframes"] + 1)
+    dec_order_waves = waves_and_parity([s_b], [r_b], kb["frames"])
+    assert dec_order_waves <= anchors + 1 and dec_order_waves < kb["frames"]
 
 @pytest.mark.parametrize("name", ["field_IP", "field_bottom_first", "field_mixed_paff", "field_b_temporal", "field_mmco1_rplm_mixed", "field_fmo_boxout_mixed_aso"])
 def test_gpu_field_stream_fed_picture_by_picture(name, H, sg):
