@@ -108,8 +108,6 @@ struct Shared {
     int8_t refi_c[NL][32]; // ref_idx as soon as parsed (CABAC ctxIdxInc of ref_idx; 0 for direct-predicted blocks)
     alignas(4) int16_t mv_c[NL][32][2];
     alignas(2) uint8_t mvd_c[NL][32][2];
-    int16_t lvl[16];       // CAVLC level scratch
-    int16_t tmp16[16];     // CAVLC 8x8 interleave scratch
     uint16_t parts[16];    // motion partition schedule: bx | by<<2 | (w-1)<<4 | (h-1)<<6 | shape<<8 | B: Pred_L0 / Pred_L1 bits << 11 (0 = direct)
     int8_t refs8[2][4];    // [list][8x8]
     int8_t sub_type[4];
@@ -117,6 +115,7 @@ struct Shared {
     int16_t ref_slot[NL][MI_MAX_REFS]; // frame-pool slot per ref_idx of this slice
     uint32_t skip_tmpl[32];            // the MbRec of a P_Skip macroblock as far as it is the same for the whole slice (pskip_fast)
     uint32_t role[64];                 // what each lane does in fill_caches (build_role)
+    uint16_t vlc[MI_VLC_N];            // CAVLC slices: the code tables in compact form (mi_types.h: MI_VLC_*), copied in at the start of the slice
     uint8_t coded[64];                 // CABAC neighbourhood, one entry per bit position of parse_residual_cabac's layout: 1 coded, 2 unavailable (fill_caches)
 #if MI_ENT_B
     uint32_t col[20];          // ColRec of the co-located macroblock (8.4.1.2.1)
@@ -561,22 +560,24 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
 }
 
 // residual_block_cavlc 9.2.  kind: 0 = 16 coefficients, 1 = 15 (AC), 2 = chroma DC (4),
-// 3 = 16 coefficients written in scan order (CAVLC + 8x8 transform interleave)
-FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
-    const DevTables *t = e.tab;
+// 3 = 16 coefficients that are every fourth one of an 8x8 block's scan (CAVLC + 8x8 transform interleave: scan index pmul * i + padd)
+FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC, int pmul, int padd) {
+    MI_R(e, 3); // (-DMI_ENT_STATS=2 on a CAVLC slice: [0] coeff_token [1] levels [2] total_zeros, run_before, store [3] rest of residual())
     const int maxnum = kind == 1 ? 15 : (kind == 2 ? 4 : 16);
     uint32_t w = peek32(e);
+    const int wlz = w ? __clz(w) : 32;
     uint32_t ent;
+    // coeff_token: compact tables in LDS, entry chosen by the leading zeros and the bits behind the first one (mi_types.h)
     if (kind == 2)
-        ent = t->vlc_cdc[w >> 24];
+        ent = e.s->vlc[MI_VLC_CDC + MI_VLC_INDEX(w, wlz, MI_VLC_CDC_L, MI_VLC_CDC_S)];
     else if (nC < 2)
-        ent = t->vlc_ct0[w >> (32 - MI_VLC_CT0_BITS)];
+        ent = e.s->vlc[MI_VLC_CT0 + MI_VLC_INDEX(w, wlz, MI_VLC_CT0_L, MI_VLC_CT_S)];
     else if (nC < 4)
-        ent = t->vlc_ct1[w >> (32 - MI_VLC_CT1_BITS)];
+        ent = e.s->vlc[MI_VLC_CT1 + MI_VLC_INDEX(w, wlz, MI_VLC_CT1_L, MI_VLC_CT_S)];
     else if (nC < 8)
-        ent = t->vlc_ct2[w >> (32 - MI_VLC_CT2_BITS)];
+        ent = e.s->vlc[MI_VLC_CT2 + MI_VLC_INDEX(w, wlz, MI_VLC_CT2_L, MI_VLC_CT_S)];
     else
-        ent = t->vlc_ct3[w >> 26];
+        ent = e.s->vlc[MI_VLC_CT3 + (w >> 26)];
     ent = RFL(ent);
     if (!(ent >> 8)) {
         e.err = 6;
@@ -584,12 +585,18 @@ FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
     }
     skip(e, ent >> 8);
     const int total = (ent >> 2) & 31, t1s = ent & 3;
+    MI_R(e, 0);
     if (total == 0) return 0;
     if (total > maxnum) {
         e.err = 7;
         return 0;
     }
     int suffix_len = (total > 10 && t1s < 3) ? 1 : 0;
+    // levels and scan positions are collected in registers, lane i = the i-th coefficient (highest frequency first), and leave with ONE predicated
+    // LDS store at the end -- no scratch array written and read back coefficient by coefficient
+    int l = LANE;
+    OPAQUE(l);
+    int lvv = 0, posv = 0;
     for (int i = 0; i < total; i++) {
         int lv;
         if (i < t1s)
@@ -601,9 +608,12 @@ FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
                 return 0;
             }
             int prefix = __clz(ww);
-            skip(e, prefix + 1);
             int code = (prefix < 15 ? prefix : 15) << suffix_len;
-            if (suffix_len > 0 || prefix >= 14) {
+            if (prefix < 14) { // the common case: prefix, stop bit and suffix come out of the one 32-bit look-ahead (at most 14 + 1 + 6 bits)
+                if (suffix_len > 0) code += static_cast<int>((ww << (prefix + 1)) >> (32 - suffix_len));
+                skip(e, prefix + 1 + suffix_len);
+            } else {
+                skip(e, prefix + 1);
                 int size = (prefix == 14 && suffix_len == 0) ? 4 : (prefix >= 15 ? prefix - 3 : suffix_len);
                 if (size > 0) code += get_bits(e, size);
             }
@@ -615,12 +625,15 @@ FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
             int al = lv < 0 ? -lv : lv;
             if (al > (3 << (suffix_len - 1)) && suffix_len < 6) suffix_len++;
         }
-        e.s->lvl[i] = static_cast<int16_t>(lv);
+        lvv = l == i ? lv : lvv;
     }
+    MI_R(e, 1);
     int zeros_left = 0;
     if (total < maxnum) {
         uint32_t ww = peek32(e);
-        const uint32_t en = RFL(static_cast<uint32_t>(kind == 2 ? t->vlc_cdc_tz[total - 1][ww >> 29] : t->vlc_tz[total - 1][ww >> 23]));
+        const int zlz = ww ? __clz(ww) : 32;
+        const uint32_t en = RFL(static_cast<uint32_t>(kind == 2 ? e.s->vlc[MI_VLC_CDCTZ + 8 * (total - 1) + (ww >> 29)]
+                                                                : e.s->vlc[MI_VLC_TZ + (total - 1) * MI_VLC_TZ_STRIDE + MI_VLC_INDEX(ww, zlz, MI_VLC_TZ_L, MI_VLC_TZ_S)]));
         if (!(en >> 8)) {
             e.err = 9;
             return 0;
@@ -633,14 +646,15 @@ FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
         e.err = 10;
         return 0;
     }
-    const uint8_t *pm = e.s->posmap[kind == 0 ? 0 : (kind == 1 ? 1 : 3)];
+    const uint8_t *pm = e.s->posmap[kind == 0 ? 0 : (kind == 1 ? 1 : (kind == 3 ? 2 : 3))]; // (kind 3: scan index i of this 4x4 part is index 4 i + part of the 8x8 scan)
     for (int i = 0; i < total; i++) {
-        dst[pm[pos]] = e.s->lvl[i];
+        posv = l == i ? pos : posv;
         if (i < total - 1) {
             int run = 0;
             if (zeros_left > 0) {
                 uint32_t ww = peek32(e);
-                const uint32_t en = RFL(static_cast<uint32_t>(t->vlc_run[(zeros_left > 7 ? 7 : zeros_left) - 1][ww >> 21]));
+                const int rlz = ww ? __clz(ww) : 32;
+                const uint32_t en = zeros_left > 6 ? MI_RUN_BEFORE_LONG(ww, rlz) : RDL(e.v_cat0, 8 * (zeros_left - 1) + (ww >> 29)); // (CAVLC slices: v_cat0 = the run_before tables)
                 if (!(en >> 8) || static_cast<int>(en & 255) > zeros_left) {
                     e.err = 11;
                     return 0;
@@ -652,6 +666,8 @@ FI int cavlc_residual(Ent &e, int16_t *dst, int kind, int nC) {
             pos -= run + 1;
         }
     }
+    if (l < total) dst[pm[posv * pmul + padd]] = static_cast<int16_t>(lvv);
+    MI_R(e, 2);
     return total;
 }
 
@@ -745,16 +761,21 @@ FI void parse_residual_cabac(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
 FI void parse_residual_cavlc(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
     Shared *s = e.s;
     const int i16 = e.cur_type == MBT_I16x16;
-    int nzmask = 0;
+    int nzmask = 0, dc = 0;
+    // total_coeff of the neighbourhood, one count per LANE while the macroblock's blocks are parsed (lanes 0..29: the luma grid of Shared::nnz_c,
+    // lanes 32..55: the two chroma grids of Shared::nnzc_c): a block's nA / nB are two v_readlane, its own count one select -- no LDS round trip
+    // per block; the grids go back to LDS once, at the end
+    int nl = LANE;
+    OPAQUE(nl);
+    uint32_t vnn = nl < 30 ? s->nnz_c[nl] : ((nl >= 32 && nl < 56) ? (&s->nnzc_c[0][0])[nl - 32] : 0u);
     for (int step = 0; step < 27; step++) {
-        int kind, bx = 0, by = 0;
-        uint8_t na, nb;
+        int kind, bx = 0, by = 0, la = 0, lb = 0, own = 63, pmul = 1, padd = 0;
         int16_t *dst;
         if (step == 0) {
             if (!i16) continue;
             kind = 0;
             dst = s->coef + MI_COEF_I16DC;
-            na = s->nnz_c[GI(-1, 0)], nb = s->nnz_c[GI(0, -1)];
+            la = GI(-1, 0), lb = GI(0, -1);
         } else if (step <= 16) {
             const int idx = step - 1, b8 = idx >> 2;
             if (!((cbp_luma >> b8) & 1)) {
@@ -762,11 +783,11 @@ FI void parse_residual_cavlc(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
                 continue;
             }
             bx = (idx & 1) + 2 * ((idx >> 2) & 1), by = ((idx >> 1) & 1) + 2 * (idx >> 3);
-            na = s->nnz_c[GI(bx - 1, by)], nb = s->nnz_c[GI(bx, by - 1)];
-            if (t8x8) {
+            la = GI(bx - 1, by), lb = GI(bx, by - 1), own = GI(bx, by);
+            if (t8x8) { // CAVLC + 8x8 transform: 4x4 "block" b4 carries coefficients 4 * i + b4 of the 8x8 scan (7.3.5.3.2): they go straight to their places
                 kind = 3;
-                dst = s->tmp16;
-                for (int i = 0; i < 16; i++) s->tmp16[i] = 0;
+                dst = s->coef + b8 * 64;
+                pmul = 4, padd = idx & 3;
             } else {
                 kind = i16 ? 1 : 0;
                 dst = s->coef + (by * 4 + bx) * 16;
@@ -776,43 +797,43 @@ FI void parse_residual_cavlc(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
             const int c = step - 17;
             kind = 2;
             dst = s->coef + MI_COEF_CDC + 4 * c;
-            na = nb = 0;
         } else {
             if (!(cbp_chroma & 2)) break;
             const int j = step - 19, c = j >> 2, b4 = j & 3;
             bx = b4 & 1, by = b4 >> 1;
             kind = 1;
             dst = s->coef + MI_COEF_CAC + j * 16;
-            na = s->nnzc_c[c][(by + 1) * 3 + bx], nb = s->nnzc_c[c][by * 3 + bx + 1];
+            la = 32 + 12 * c + (by + 1) * 3 + bx, lb = 32 + 12 * c + by * 3 + bx + 1, own = 32 + 12 * c + (by + 1) * 3 + bx + 1;
         }
         // The window holds 128 words beyond the one it last slid at, and it slides at macroblock boundaries -- enough for the 3200 bits A.3.1 allows
         // a macroblock_layer().  Encoders that ignore the limit exist (very low QP on noisy content: 8000 bits and more), so it also slides here,
         // block by block (a block is at most 25 words): one compare for conforming streams.
         slide_window(e);
-        const int n = cavlc_residual(e, dst, kind, kind == 2 ? -1 : nc_of(na, nb));
+        const int nC = kind == 2 ? -1 : nc_of(static_cast<uint8_t>(RDL(vnn, la)), static_cast<uint8_t>(RDL(vnn, lb)));
+        const int n = cavlc_residual(e, dst, kind, nC, pmul, padd);
         // ---- bookkeeping per block kind ----
-        if (step == 0) {
-            if (n) s->cur_cbf_dc |= 1;
-        } else if (step <= 16) {
-            const int idx = step - 1, b8 = idx >> 2, r = by * 4 + bx;
-            {
-                if (kind == 3) // CAVLC + 8x8 transform: 4x4 "block" b4 carries coefficients 4*i + b4 of the 8x8 scan (7.3.5.3.2)
-                    for (int i = 0; i < 16; i++) {
-                        int16_t v = s->tmp16[i];
-                        if (v) s->coef[b8 * 64 + s->posmap[2][4 * i + (idx & 3)]] = v;
-                    }
-                s->nnz_c[GI(bx, by)] = static_cast<uint8_t>(n);
-                if (n) nzmask |= t8x8 ? (0x33 << ((by & 2) * 4 + (bx & 2))) : (1 << r);
-            }
-        } else if (step <= 18) {
-            if (n) s->cur_cbf_dc |= static_cast<uint8_t>(2 << (step - 17));
-        } else
-            s->nnzc_c[(step - 19) >> 2][(by + 1) * 3 + bx + 1] = static_cast<uint8_t>(n);
+        if (step == 0)
+            dc |= n ? 1 : 0;
+        else if (step <= 16) {
+            vnn = nl == own ? static_cast<uint32_t>(n) : vnn;
+            if (n) nzmask |= t8x8 ? (0x33 << ((by & 2) * 4 + (bx & 2))) : (1 << (by * 4 + bx));
+        } else if (step <= 18)
+            dc |= n ? 2 << (step - 17) : 0;
+        else
+            vnn = nl == own ? static_cast<uint32_t>(n) : vnn;
     }
+    if (dc) s->cur_cbf_dc |= static_cast<uint8_t>(dc);
     s->rec.nzmask = static_cast<uint16_t>(nzmask);
+    // the counts of this macroblock's blocks back into the grids (what the edge entries and the next macroblock's caches are made from)
+    if (nl < 30) {
+        const int gx = nl % 6 - 1, gy = nl / 6 - 1;
+        if (gx >= 0 && gx < 4 && gy >= 0) s->nnz_c[nl] = static_cast<uint8_t>(vnn);
+    } else if (nl >= 32 && nl < 56) {
+        const int g = (nl - 32) % 12, gx = g % 3 - 1, gy = g / 3 - 1;
+        if (g < 9 && gx >= 0 && gy >= 0) (&s->nnzc_c[0][0])[nl - 32] = static_cast<uint8_t>(vnn);
+    }
 }
 
-// ------------------------------------------------------------------ motion vector prediction 8.4.1.3
 FI int median3(int a, int b, int c) {
     int mn = a < b ? a : b, mx = a < b ? b : a;
     return c < mn ? mn : (c > mx ? mx : c);
@@ -1767,7 +1788,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     const uint8_t *scan4 = pd->field ? tab->fieldscan4 : tab->zigzag4, *scan8 = pd->field ? tab->fieldscan8 : tab->zigzag8;
     e.v_maps = tab->sig8x8[l] | (tab->last8x8[l] << 8) | (scan8[l] << 16) | (static_cast<uint32_t>(scan4[l & 15]) << 24);
     e.v_zzac = scan4[(l + 1) & 15];
-    e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l);
+    e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l); // (CAVLC slices: v_cat0 is replaced by the run_before tables below, one entry per lane)
     e.v_qpc = tab->qpc[l < 52 ? l : 51];
     set_qp(e, RFL(static_cast<int>(sd->slice_qp)));
     e.v_step = step_word(l);
@@ -1799,8 +1820,11 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         e.wk_cat = -1, e.wk_c0 = 0, e.wk_home = 0, e.wk_valid = false;
         for (int i = l; i < 464; i += 64) sh.ctx[i] = src[i];
     }
+    if (!pd->cabac) // CAVLC: the code tables move into LDS (2.2 KB; a lookup in HBM-resident direct tables was most of a CAVLC slice's time)
+        for (int i = l; i < MI_VLC_N / 2; i += 64) reinterpret_cast<uint32_t *>(sh.vlc)[i] = reinterpret_cast<const uint32_t *>(tab->vlc_c)[i];
     if (l < 32) reinterpret_cast<uint32_t *>(&sh.rec)[l] = 0;
     LDS_SYNC();
+    if (!pd->cabac) e.v_cat0 = l < 48 ? sh.vlc[MI_VLC_RUN + l] : 0u; // run_before for zerosLeft 1..6: 6 x 8 entries, read with v_readlane
     if (l == 0) { // slice constants of every MbRec
         sh.rec.dbf_idc = sd->dbf_idc;
         sh.rec.alpha_off = sd->alpha_off, sh.rec.beta_off = sd->beta_off;

@@ -42,6 +42,78 @@ static void put_vlc(uint16_t *lut, int bits, int len, uint32_t code, uint16_t va
     uint32_t base = code << (bits - len), n = 1u << (bits - len);
     for (uint32_t i = 0; i < n; i++) lut[base + i] = static_cast<uint16_t>((len << 8) | value);
 }
+// The CAVLC tables: direct-indexed first (every window of L bits -> len << 8 | value, from the code lists of mi_tables.h), then folded into the compact
+// form the kernels keep in LDS (mi_types.h: MI_VLC_*).  `mismatches` (h264mi_internal_vlc_selftest): every window of every direct table is looked
+// up in the compact one as the kernels do it, and run_before's closed form for zerosLeft > 6 is compared with its table.
+static void build_vlc(uint16_t *c, int *mismatches) {
+    std::vector<uint16_t> ct[3] = {std::vector<uint16_t>(1u << MI_VLC_CT0_L), std::vector<uint16_t>(1u << MI_VLC_CT1_L), std::vector<uint16_t>(1u << MI_VLC_CT2_L)};
+    std::vector<uint16_t> ct3(64), cdc(1u << MI_VLC_CDC_L), tz(15u << MI_VLC_TZ_L), cdctz(24), run(7u << 11);
+    const int ctl[3] = {MI_VLC_CT0_L, MI_VLC_CT1_L, MI_VLC_CT2_L}, ctbase[3] = {MI_VLC_CT0, MI_VLC_CT1, MI_VLC_CT2};
+    for (int tc = 0; tc <= 16; tc++)
+        for (int t1 = 0; t1 <= std::min(tc, 3); t1++) {
+            const uint16_t v = static_cast<uint16_t>((tc << 2) | t1);
+            for (int k = 0; k < 3; k++) put_vlc(ct[k].data(), ctl[k], mi_coeff_token_len[k][4 * tc + t1], mi_coeff_token_bits[k][4 * tc + t1], v);
+            put_vlc(ct3.data(), 6, mi_coeff_token_len[3][4 * tc + t1], mi_coeff_token_bits[3][4 * tc + t1], v);
+            if (tc <= 4) put_vlc(cdc.data(), MI_VLC_CDC_L, mi_chroma_dc_token_len[4 * tc + t1], mi_chroma_dc_token_bits[4 * tc + t1], v);
+        }
+    for (int tc = 1; tc <= 15; tc++)
+        for (int z = 0; z <= 16 - tc && z < 16; z++)
+            put_vlc(tz.data() + ((tc - 1) << MI_VLC_TZ_L), MI_VLC_TZ_L, mi_total_zeros_len[tc - 1][z], mi_total_zeros_bits[tc - 1][z], static_cast<uint16_t>(z));
+    for (int tc = 1; tc <= 3; tc++)
+        for (int z = 0; z <= 4 - tc; z++) put_vlc(cdctz.data() + 8 * (tc - 1), 3, mi_chroma_dc_total_zeros_len[tc - 1][z], mi_chroma_dc_total_zeros_bits[tc - 1][z], static_cast<uint16_t>(z));
+    for (int zl = 1; zl <= 7; zl++)
+        for (int r = 0; r < 15; r++) put_vlc(run.data() + ((zl - 1) << 11), 11, mi_run_len[zl - 1][r], mi_run_bits[zl - 1][r], static_cast<uint16_t>(r));
+    memset(c, 0, sizeof(uint16_t) * MI_VLC_N);
+    int bad = 0;
+    // fold: the entry of group lz, suffix s is what the direct table says for the window 0^lz 1 s 0...; the code must end inside those bits
+    auto fold = [&](const uint16_t *direct, int L, int S, uint16_t *out) {
+        for (int lz = 0; lz <= L; lz++)
+            for (uint32_t sfx = 0; sfx < (1u << S); sfx++) {
+                uint32_t win = lz < L ? (1u << (31 - lz)) : 0u; // as a 32-bit window, MSB first
+                if (lz + 1 < 32) win |= lz < L ? (sfx << (32 - S)) >> (lz + 1) : 0u;
+                const uint16_t e = direct[win >> (32 - L)];
+                if ((e >> 8) > lz + 1 + S && lz < L) bad++; // a code longer than the bits that select its entry
+                out[(lz << S) | sfx] = e;
+            }
+    };
+    for (int k = 0; k < 3; k++) fold(ct[k].data(), ctl[k], MI_VLC_CT_S, c + ctbase[k]);
+    memcpy(c + MI_VLC_CT3, ct3.data(), 64 * sizeof(uint16_t));
+    fold(cdc.data(), MI_VLC_CDC_L, MI_VLC_CDC_S, c + MI_VLC_CDC);
+    for (int k = 0; k < 15; k++) fold(tz.data() + (k << MI_VLC_TZ_L), MI_VLC_TZ_L, MI_VLC_TZ_S, c + MI_VLC_TZ + k * MI_VLC_TZ_STRIDE);
+    memcpy(c + MI_VLC_CDCTZ, cdctz.data(), 24 * sizeof(uint16_t));
+    for (int zl = 1; zl <= 6; zl++)
+        for (int i = 0; i < 8; i++) c[MI_VLC_RUN + 8 * (zl - 1) + i] = run[((zl - 1) << 11) + (i << 8)];
+    if (!mismatches) return;
+    // every window of every direct table, looked up the way the kernels do it
+    auto check = [&](const uint16_t *direct, int L, int S, const uint16_t *folded) {
+        for (uint32_t i = 0; i < (1u << L); i++) {
+            const uint32_t w = i << (32 - L);
+            const int lz = w ? __builtin_clz(w) : 32;
+            if (folded[MI_VLC_INDEX(w, lz, L, S)] != direct[i]) bad++;
+        }
+    };
+    for (int k = 0; k < 3; k++) check(ct[k].data(), ctl[k], MI_VLC_CT_S, c + ctbase[k]);
+    check(cdc.data(), MI_VLC_CDC_L, MI_VLC_CDC_S, c + MI_VLC_CDC);
+    for (int k = 0; k < 15; k++) check(tz.data() + (k << MI_VLC_TZ_L), MI_VLC_TZ_L, MI_VLC_TZ_S, c + MI_VLC_TZ + k * MI_VLC_TZ_STRIDE);
+    for (int zl = 1; zl <= 6; zl++)
+        for (uint32_t i = 0; i < 2048; i++) {
+            const uint16_t e = run[((zl - 1) << 11) + i];
+            if (e && c[MI_VLC_RUN + 8 * (zl - 1) + (i >> 8)] != e) bad++; // (codes of at most 3 bits; e == 0: a window no code matches)
+            if (!e && c[MI_VLC_RUN + 8 * (zl - 1) + (i >> 8)] != 0) bad++;
+        }
+    for (uint32_t i = 0; i < 2048; i++) {
+        const uint32_t w = i << 21;
+        const int lz = w ? __builtin_clz(w) : 32;
+        if (MI_RUN_BEFORE_LONG(w, lz) != run[(6u << 11) + i]) bad++;
+    }
+    *mismatches = bad;
+}
+extern "C" int32_t h264mi_internal_vlc_selftest(void) {
+    std::vector<uint16_t> c(MI_VLC_N);
+    int bad = -1;
+    build_vlc(c.data(), &bad);
+    return bad;
+}
 static void build_tables(DevTables *t) {
     memset(t, 0, sizeof(*t));
     memcpy(t->range_lps, mi_range_lps, sizeof(t->range_lps));
@@ -69,21 +141,7 @@ static void build_tables(DevTables *t) {
         for (int b = 0; b < 3; b++) t->tc0[i][b + 1] = mi_tc0[i][b];
         t->qpc[i] = i < 30 ? static_cast<uint8_t>(i) : mi_qpc_tab[i - 30];
     }
-    for (int tc = 0; tc <= 16; tc++)
-        for (int t1 = 0; t1 <= std::min(tc, 3); t1++) {
-            uint16_t v = static_cast<uint16_t>((tc << 2) | t1);
-            put_vlc(t->vlc_ct0, MI_VLC_CT0_BITS, mi_coeff_token_len[0][4 * tc + t1], mi_coeff_token_bits[0][4 * tc + t1], v);
-            put_vlc(t->vlc_ct1, MI_VLC_CT1_BITS, mi_coeff_token_len[1][4 * tc + t1], mi_coeff_token_bits[1][4 * tc + t1], v);
-            put_vlc(t->vlc_ct2, MI_VLC_CT2_BITS, mi_coeff_token_len[2][4 * tc + t1], mi_coeff_token_bits[2][4 * tc + t1], v);
-            put_vlc(t->vlc_ct3, 6, mi_coeff_token_len[3][4 * tc + t1], mi_coeff_token_bits[3][4 * tc + t1], v);
-            if (tc <= 4) put_vlc(t->vlc_cdc, 8, mi_chroma_dc_token_len[4 * tc + t1], mi_chroma_dc_token_bits[4 * tc + t1], v);
-        }
-    for (int tc = 1; tc <= 15; tc++)
-        for (int tz = 0; tz <= 16 - tc && tz < 16; tz++) put_vlc(t->vlc_tz[tc - 1], 9, mi_total_zeros_len[tc - 1][tz], mi_total_zeros_bits[tc - 1][tz], static_cast<uint16_t>(tz));
-    for (int tc = 1; tc <= 3; tc++)
-        for (int tz = 0; tz <= 4 - tc; tz++) put_vlc(t->vlc_cdc_tz[tc - 1], 3, mi_chroma_dc_total_zeros_len[tc - 1][tz], mi_chroma_dc_total_zeros_bits[tc - 1][tz], static_cast<uint16_t>(tz));
-    for (int zl = 1; zl <= 7; zl++)
-        for (int r = 0; r < 15; r++) put_vlc(t->vlc_run[zl - 1], 11, mi_run_len[zl - 1][r], mi_run_bits[zl - 1][r], static_cast<uint16_t>(r));
+    build_vlc(t->vlc_c, nullptr);
 }
 static void build_scaling(const uint8_t s4[6][16], const uint8_t s8[2][64], ScalingSet *o) { // 8.5.9
     for (int l = 0; l < 6; l++)

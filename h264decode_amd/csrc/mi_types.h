@@ -185,9 +185,32 @@ typedef struct {
 } ScalingSet;
 
 #define MI_MAX_SCALING_SETS 8
-#define MI_VLC_CT0_BITS 16
-#define MI_VLC_CT1_BITS 14
-#define MI_VLC_CT2_BITS 10
+/* CAVLC code tables in compact form (they live in LDS while a CAVLC slice is decoded): a code word is looked up by the number of its leading
+ * zeros -- capped at the longest code of the table, L -- and the S bits behind its first one: entry [min(clz, L) << S | next S bits] =
+ * len << 8 | value (value: total_coeff << 2 | trailing_ones for coeff_token), 0: no such code.  mi_api.cpp derives the tables from direct-indexed
+ * ones and checks every possible window against those (h264mi_internal_vlc_selftest). */
+#define MI_VLC_CT_S 3                      /* coeff_token: suffix bits */
+#define MI_VLC_CT0_L 16
+#define MI_VLC_CT1_L 14
+#define MI_VLC_CT2_L 10
+#define MI_VLC_CDC_L 8
+#define MI_VLC_CDC_S 2
+#define MI_VLC_TZ_L 9
+#define MI_VLC_TZ_S 2
+#define MI_VLC_CT0 0                                              /* 0 <= nC < 2 */
+#define MI_VLC_CT1 (MI_VLC_CT0 + ((MI_VLC_CT0_L + 1) << MI_VLC_CT_S)) /* 2 <= nC < 4 */
+#define MI_VLC_CT2 (MI_VLC_CT1 + ((MI_VLC_CT1_L + 1) << MI_VLC_CT_S)) /* 4 <= nC < 8 */
+#define MI_VLC_CT3 (MI_VLC_CT2 + ((MI_VLC_CT2_L + 1) << MI_VLC_CT_S)) /* 8 <= nC: 6-bit fixed length, direct */
+#define MI_VLC_CDC (MI_VLC_CT3 + 64)                              /* chroma DC coeff_token (nC = -1) */
+#define MI_VLC_TZ (MI_VLC_CDC + ((MI_VLC_CDC_L + 1) << MI_VLC_CDC_S)) /* total_zeros, tzVlcIndex 1..15 */
+#define MI_VLC_TZ_STRIDE ((MI_VLC_TZ_L + 1) << MI_VLC_TZ_S)
+#define MI_VLC_CDCTZ (MI_VLC_TZ + 15 * MI_VLC_TZ_STRIDE)         /* chroma DC total_zeros: [3][8], 3 bits direct */
+#define MI_VLC_RUN (MI_VLC_CDCTZ + 24)                            /* run_before, zerosLeft 1..6: [6][8], 3 bits direct (zerosLeft > 6: mi_run_before_long) */
+#define MI_VLC_N ((MI_VLC_RUN + 48 + 3) & ~3)
+/* index of a window (next 32 stream bits, MSB first) in a compact table of longest code L and S suffix bits */
+#define MI_VLC_INDEX(w, lz, L, S) ((((lz) < (L) ? (lz) : (L)) << (S)) | ((uint32_t)((w) << (((lz) < (L) ? (lz) : (L)) + 1)) >> (32 - (S))))
+/* run_before for zerosLeft > 6 (Table 9-10, last column: 111 .. 001 = 0 .. 6, then 0001 = 7, 00001 = 8, ...): len << 8 | run, 0 = no such code */
+#define MI_RUN_BEFORE_LONG(w, lz) (((w) >> 29) ? (3u << 8 | (7u - ((w) >> 29))) : ((lz) <= 10 ? ((uint32_t)((lz) + 1) << 8 | (uint32_t)((lz) + 4)) : 0u))
 
 typedef struct {
     uint8_t range_lps[64][4]; /* Table 9-44 */
@@ -199,13 +222,7 @@ typedef struct {
     uint8_t me_intra[48], me_inter[48];
     uint8_t alpha[52], beta[52], tc0[52][4];
     uint8_t qpc[52];
-    /* CAVLC direct lookup tables: entry = (len<<8) | (total_coeff<<2) | trailing_ones, or for the
-     * other codes (len<<8) | value; indexed by the next N bits of the stream */
-    uint16_t vlc_ct0[1 << MI_VLC_CT0_BITS], vlc_ct1[1 << MI_VLC_CT1_BITS], vlc_ct2[1 << MI_VLC_CT2_BITS], vlc_ct3[64];
-    uint16_t vlc_cdc[256];
-    uint16_t vlc_tz[15][512];
-    uint16_t vlc_cdc_tz[3][8];
-    uint16_t vlc_run[7][2048];
+    uint16_t vlc_c[MI_VLC_N]; /* the compact CAVLC tables (see MI_VLC_*) */
     ScalingSet scaling[MI_MAX_SCALING_SETS];
 } DevTables;
 

@@ -307,7 +307,7 @@ const char *h264mi_last_error_string(void);
 const char *h264mi_version(void);
 
 /* Exported but NOT part of the ABI (test hooks of this repository's own suite, may change or vanish): h264mi_internal_poison,
- * h264mi_internal_deblock_plan, h264mi_internal_band_plan, h264mi_internal_deblock_phase_clocks. */
+ * h264mi_internal_deblock_plan, h264mi_internal_band_plan, h264mi_internal_deblock_phase_clocks, h264mi_internal_vlc_selftest. */
 
 #ifdef __cplusplus
 }

@@ -212,3 +212,16 @@ def test_mb_type_names_against_the_reference(H):
     assert (H.PicHeightInMbs(sps, Hdr), H.PicSizeInMbs(sps, Hdr), H.SubWidthC(sps), H.SubHeightC(sps), H.MbWidthC(sps), H.MbHeightC(sps)) == (15, 300, 2, 2, 8, 8)
     assert H.MbaffFrameFlag(sps, Hdr) == 0 and H.Clip3(0, 51, 77) == 51 and H.Clip1y(300) == 255 and H.Clipc(-4) == 0
     assert H.PreCtxState(-46, 127, 28) == max(1, min(126, ((-46 * 28) >> 4) + 127))
+
+
+def test_compact_cavlc_tables_agree_with_the_direct_ones():
+    """The kernels look CAVLC codes up in compact tables (leading zeros x a few suffix bits, kept in LDS; mi_types.h MI_VLC_*).  The library derives
+    them from direct-indexed tables built from the code lists of mi_tables.h and can check itself: every window of every direct table, looked up
+    the kernels' way, and the closed form of run_before for zerosLeft > 6 against its table.  (Host code only: runs without a GPU.)"""
+    import ctypes
+    so = os.path.join(ROOT, "h264decode_amd", "libh264mi.so")
+    if not os.path.exists(so):
+        pytest.skip("libh264mi.so is not built")
+    L = ctypes.CDLL(so)
+    L.h264mi_internal_vlc_selftest.restype = ctypes.c_int32
+    assert L.h264mi_internal_vlc_selftest() == 0
