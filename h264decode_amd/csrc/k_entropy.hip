@@ -161,10 +161,12 @@ struct Ent {
     int wk_cat;              // ctxBlockCat whose states are in wk (-1: none)
     uint32_t wk_c0;          // cat_word0 of that category
     int wk_home;             // per lane: ctxIdx this lane of wk mirrors
-    bool wk_valid;           // per lane: the lane belongs to the category's own contexts
+    int wk_valid;            // per lane: 1 = the lane belongs to the category's own contexts (an int, not a bool: a lane predicate kept in a scalar register pair costs
+                             // three mask instructions per residual block to carry around the loop)
     uint32_t v_rlps, v_trans; // lane p: rangeTabLPS[p][0..3] / next state after an LPS for valMPS 0
     uint32_t v_maps;         // lane i: sig8x8[i] | last8x8[i] << 8 | zigzag8[i] << 16 | zigzag4[i & 15] << 24
-    uint32_t v_zzac;         // lane i: zigzag4[(i + 1) & 15] (AC blocks: scan index i is coefficient i + 1)
+    uint32_t v_pos;          // lane i: where the coefficient of scan index i goes, one byte per position mode: zigzag4[i & 15] | zigzag4[(i + 1) & 15] << 8 (AC blocks: scan index
+                             // i is coefficient i + 1) | zigzag8[i] << 16 | i << 24 (field pictures: the field scans)
     uint32_t v_cat0, v_cat1; // lane ctxBlockCat: packed block-category parameters (cat_word0/1)
     uint32_t v_qpc, v_refslot; // lane i: QPc table entry / frame slot of ref_idx i
     uint32_t v_step;         // lane = residual step: step_word()
@@ -489,7 +491,7 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
         // lanes outside the category's own context ranges would hold copies of other categories' states and must never
         // be written back (for 8x8 blocks ctxIdx 417 appears in both the sig and the last group)
         const int nsig = cat == 5 ? 15 : static_cast<int>(c0n & 255) - 1, nlast = static_cast<int>((c0n >> 24) & 15);
-        e.wk_valid = grp == 0 ? li < nsig : (grp == 1 ? li < nlast : l < 42);
+        e.wk_valid = (grp == 0 ? li < nsig : (grp == 1 ? li < nlast : l < 42)) ? 1 : 0;
         e.wk_home = home < 464 ? home : 463;
         LDS_SYNC(); // the scatter above may alias the gather below
         e.wk = ctx_word(e.s->ctx[e.wk_home]);
@@ -551,8 +553,7 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
     }
     MI_R(e, 1);
     {
-        const int pmode = static_cast<int>((c0 >> 20) & 15);
-        const uint32_t pos = pmode == 3 ? static_cast<uint32_t>(l) : (pmode == 2 ? (e.v_maps >> 16) & 255 : (pmode == 1 ? e.v_zzac : e.v_maps >> 24));
+        const uint32_t pos = __builtin_amdgcn_ubfe(e.v_pos, (c0 >> 17) & 0x18u, 8); // the byte of the category's position mode: one bit-field extract, no branch
         if (lv != 0) dst[pos] = static_cast<int16_t>(lv);
     }
     MI_R(e, 2);
@@ -736,8 +737,9 @@ FI void parse_residual_cabac(Ent &e, int cbp_luma, int cbp_chroma, int t8x8) {
         const int inc = static_cast<int>(RDL(vnz, d) + 2 * RDL(vnz, d >> 6)); // (the lane select is taken modulo 64)
         slide_window(e); // (see cavlc: a macroblock_layer() beyond A.3.1's 3200 bits must not run off the window; one block is at most 92 words)
         if (cabac_residual(e, s->coef + dst, cat, inc)) {
-            const int t = nl - own; // an 8x8 block stands for its four 4x4 positions: own, own + 1, own + 6, own + 7
-            vnz = (t == 0 || (cat == 5 && (t == 1 || t == 6 || t == 7))) ? 1u : vnz;
+            // the block's lane -- an 8x8 block stands for its four 4x4 positions: own, own + 1, own + 6, own + 7 -- through a mask made on the scalar side
+            const uint64_t m = (cat == 5 ? 0xC3ull : 1ull) << own;
+            asm("v_cndmask_b32_e64 %0, %0, 1, %1" : "+v"(vnz) : "s"(m));
         }
     }
     const uint64_t nzm = __builtin_amdgcn_ballot_w64(vnz != 0);
@@ -1787,7 +1789,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     // coefficient scans of the picture (8.5.6, 8.5.7): zig-zag, or the field scan in a field picture (h264/slice.go:867-872 field_pic_flag)
     const uint8_t *scan4 = pd->field ? tab->fieldscan4 : tab->zigzag4, *scan8 = pd->field ? tab->fieldscan8 : tab->zigzag8;
     e.v_maps = tab->sig8x8[l] | (tab->last8x8[l] << 8) | (scan8[l] << 16) | (static_cast<uint32_t>(scan4[l & 15]) << 24);
-    e.v_zzac = scan4[(l + 1) & 15];
+    e.v_pos = scan4[l & 15] | (scan4[(l + 1) & 15] << 8) | (scan8[l] << 16) | (static_cast<uint32_t>(l) << 24);
     e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l); // (CAVLC slices: v_cat0 is replaced by the run_before tables below, one entry per lane)
     e.v_qpc = tab->qpc[l < 52 ? l : 51];
     set_qp(e, RFL(static_cast<int>(sd->slice_qp)));
@@ -1817,7 +1819,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         e.ca = ctx_word(src[l]);
         e.cb = ctx_word(src[l < 61 ? 64 + l : 399 + (l - 61)]);
         e.wk = 0;
-        e.wk_cat = -1, e.wk_c0 = 0, e.wk_home = 0, e.wk_valid = false;
+        e.wk_cat = -1, e.wk_c0 = 0, e.wk_home = 0, e.wk_valid = 0;
         for (int i = l; i < 464; i += 64) sh.ctx[i] = src[i];
     }
     if (!pd->cabac) // CAVLC: the code tables move into LDS (2.2 KB; a lookup in HBM-resident direct tables was most of a CAVLC slice's time)
