@@ -165,8 +165,8 @@ struct Ent {
                              // three mask instructions per residual block to carry around the loop)
     uint32_t v_rlps, v_trans; // lane p: rangeTabLPS[p][0..3] / next state after an LPS for valMPS 0
     uint32_t v_maps;         // lane i: sig8x8[i] | last8x8[i] << 8 | zigzag8[i] << 16 | zigzag4[i & 15] << 24
-    uint32_t v_pos;          // lane 63 - i: where the coefficient of scan index i goes, one byte per position mode: zigzag4[i & 15] | zigzag4[(i + 1) & 15] << 8 (AC blocks: scan
-                             // index i is coefficient i + 1) | zigzag8[i] << 16 | i << 24 (field pictures: the field scans)
+    uint32_t v_pos;          // lane i: where the coefficient of scan index i goes, one byte per position mode: zigzag4[i & 15] | zigzag4[(i + 1) & 15] << 8 (AC blocks: scan index
+                             // i is coefficient i + 1) | zigzag8[i] << 16 | i << 24 (field pictures: the field scans)
     uint32_t v_cat0, v_cat1; // lane ctxBlockCat: packed block-category parameters (cat_word0/1)
     uint32_t v_qpc, v_refslot; // lane i: QPc table entry / frame slot of ref_idx i
     uint32_t v_step;         // lane = residual step: step_word()
@@ -479,11 +479,11 @@ FI uint32_t top_load(const Ent &e, int col, int dw) {
 FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
     MI_R(e, 3);
     const int cat = RFL(cat_);
+    int l = LANE;
+    OPAQUE(l); // keeps lane-dependent addresses from being hoisted out of the macroblock loop and spilled
     // The working set stays in e.wk from block to block (and macroblock to macroblock) as long as the category does
     // not change -- a macroblock has at most four category runs -- so states move between LDS and the VGPR only then.
     if (cat != e.wk_cat) {
-        int l = LANE;
-        OPAQUE(l); // keeps lane-dependent addresses from being hoisted out of the macroblock loop and spilled
         if (e.wk_valid) e.s->ctx[e.wk_home] = static_cast<uint8_t>(e.wk); // masked scatter of the previous category
         const uint32_t c0n = RDL(e.v_cat0, cat), c1n = RDL(e.v_cat1, cat);
         const int grp = l >> 4, li = l & 15;
@@ -534,7 +534,8 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
     // levels, highest frequency first (9.3.3.1.3): inc0 / cx are the wk lanes of the two context selections
     int inc0 = 33, cx = 37;
     const int cxmax = 37 + static_cast<int>((c0 >> 16) & 15);
-    int lv = 0; // the level of scan index i sits in lane 63 - i: the lane number is the bit number of `sig` (Ent::v_pos is laid out the same way)
+    int lv = 0;
+    const int lrev = 63 - l;
     while (sig) {
         const int k = __builtin_ctzll(sig);
         asm("s_bitset0_b64 %0, %1" : "+s"(sig) : "s"(k));
@@ -548,7 +549,7 @@ FI int cabac_residual(Ent &e, int16_t *dst, int cat_, int cbf_inc) {
         } else if (inc0 != 32)
             inc0 = inc0 < 36 ? inc0 + 1 : 36;
         const int v = cabac_bypass(e) ? -a : a;
-        lv = LANE == k ? v : lv;
+        lv = lrev == k ? v : lv;
     }
     MI_R(e, 1);
     {
@@ -1788,10 +1789,7 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     // coefficient scans of the picture (8.5.6, 8.5.7): zig-zag, or the field scan in a field picture (h264/slice.go:867-872 field_pic_flag)
     const uint8_t *scan4 = pd->field ? tab->fieldscan4 : tab->zigzag4, *scan8 = pd->field ? tab->fieldscan8 : tab->zigzag8;
     e.v_maps = tab->sig8x8[l] | (tab->last8x8[l] << 8) | (scan8[l] << 16) | (static_cast<uint32_t>(scan4[l & 15]) << 24);
-    { // (lane l holds the level of scan index 63 - l, see cabac_residual)
-        const int si = 63 - l;
-        e.v_pos = scan4[si & 15] | (scan4[(si + 1) & 15] << 8) | (scan8[si] << 16) | (static_cast<uint32_t>(si) << 24);
-    }
+    e.v_pos = scan4[l & 15] | (scan4[(l + 1) & 15] << 8) | (scan8[l] << 16) | (static_cast<uint32_t>(l) << 24);
     e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l); // (CAVLC slices: v_cat0 is replaced by the run_before tables below, one entry per lane)
     e.v_qpc = tab->qpc[l < 52 ? l : 51];
     set_qp(e, RFL(static_cast<int>(sd->slice_qp)));
