@@ -100,9 +100,9 @@ typedef __attribute__((address_space(1))) uint32_t g_uint1;
 // keeps lane-dependent values from being hoisted out of the step loop (dozens of loop-invariant addresses would otherwise
 // live in registers for the whole kernel)
 #define OPAQUE(x) asm volatile("" : "+v"(x))
-// diagnostic build (-DMI_DB_STATS, banded kernels only): shader clocks per phase of the step loop, summed over one wavefront's
-// steps, added to xstatus[8 + phase] by the wavefront of group 0 (tools/deblock_phase_probe.py)
-#if defined(MI_DB_STATS) && MI_DB_BANDS
+// diagnostic build (-DMI_DB_STATS): shader clocks per phase of the step loop, summed over one wavefront's steps, added to xstatus[8 + phase]
+// by the wavefront of group 0 of every picture (tools/deblock_phase_probe.py); k_deblock gets the status words as an extra argument in that build
+#if defined(MI_DB_STATS)
 #define STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += static_cast<uint32_t>(now_ - st_last); st_last = now_; } while (0)
 #else
 #define STAMP(k) do { } while (0)
@@ -174,7 +174,11 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 #define XARGS , unsigned long long *xring_, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus, int roles
 #define KNAME k_deblock_x
 #else
+#if defined(MI_DB_STATS)
+#define XARGS , uint32_t *xstatus
+#else
 #define XARGS
+#endif
 #define KNAME k_deblock
 #endif
 extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring,
@@ -350,7 +354,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             while (__hip_atomic_load(&sh.cons[g - reuse + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < wmb) __builtin_amdgcn_s_sleep(1);
 #endif
         const int nsteps = wmb + 3;
-#if defined(MI_DB_STATS) && MI_DB_BANDS
+#if defined(MI_DB_STATS)
         uint32_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -674,7 +678,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
                 __hip_atomic_store(&sh.prog[pc], wmb, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             STAMP(4);
         }
-#if defined(MI_DB_STATS) && MI_DB_BANDS
+#if defined(MI_DB_STATS)
         if (g == 0 && lane_v == 0)
             for (int k = 0; k < 12; k++) atomicAdd(xstatus + 8 + k, st_acc[k]);
 #endif

@@ -2121,8 +2121,13 @@ static int execute_stage(h264mi_decoder *d, int stage_idx, bool exclusive) {
             d->x_tk5 += n * nb5;
         } else {
             mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
+#if defined(MI_DB_STATS) /* diagnostic build: the kernel adds the phase clocks of its step loop to the status words */
+            hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_off[w], g.d_pics,
+                               d->d_dbprm[set], dbring, dbring_last, dbbufs, d->d_xctl + 64);
+#else
             hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_off[w], g.d_pics,
                                d->d_dbprm[set], dbring, dbring_last, dbbufs);
+#endif
         }
         mark(3);
     }

@@ -39,7 +39,11 @@ extern "C" __global__ void k_intra_x(const uint32_t *pic_list, const PicDesc *pi
 extern "C" __global__ void k_dbprep(const uint32_t *pic_list, const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1, DbPrm *out, int col_only, unsigned long long *intramask);
 // K5: in-loop deblocking, one workgroup per picture, one wavefront per group of 4 macroblock rows (up to 16 groups side by side).
 // block = 64 * nwaves, dynamic LDS = mi_deblock_lds_bytes(nwaves, ring, ring_last); (nwaves, ring, ring_last) from mi_deblock_plan()
+#if defined(MI_DB_STATS) /* diagnostic build: the phase clocks of the step loop go to the status words (k_deblock.hip) */
+extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring, int ring_last, int last_bufs, uint32_t *xstatus);
+#else
 extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring, int ring_last, int last_bufs);
+#endif
 // K5 spread over `nbands` workgroups per picture (k_deblock_x.hip): grid = pictures * nbands, block = 64 * (largest band's group count),
 // dynamic LDS = mi_deblock_lds_bytes_banded().  xring: pictures * nbands * wmb_max * 24 granules of 8 bytes; epoch: a value no earlier
 // launch on this ring has used (never 0); ticket / ticket_base: a counter that only ever grows and its value before this launch.

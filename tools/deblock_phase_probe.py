@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Where a K5 step spends its time: shader clocks per phase of one wavefront (group 0) of the banded deblocking kernel, from a
--DMI_DB_STATS build.  Build first (no GPU needed):
+"""Where a K5 step spends its time: shader clocks per phase of the wavefront of group 0 of every picture, from a -DMI_DB_STATS build.
+Usage: deblock_phase_probe.py [streams] [frames]   (1 stream: the banded kernel k_deblock_x on one picture; 256 streams: k_deblock proper,
+one workgroup per picture, every CU busy -- the launch shape of the bench).  Build first (no GPU needed):
   make -C h264decode_amd/csrc EXTRA=-DMI_DB_STATS BUILD=_build_stats OUT=../libh264mi_stats.so
 then on the GPU box: H264MI_LIB=h264decode_amd/libh264mi_stats.so python tools/deblock_phase_probe.py"""
 import ctypes, os, sys
@@ -9,21 +10,22 @@ import numpy as np
 import streamgen
 import h264decode_amd as H
 
-F = 8
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 s, rec, _ = streamgen.encode(want_recon=True, **streamgen.recipe("C3", frames=F, idr_period=F, seed=1000, width=1920, height=1080))
-dec = H.Decoder(max_streams=1, max_width=1920, max_height=1088, max_frames_per_batch=F, max_slices_per_frame=1)
+dec = H.Decoder(max_streams=S, max_width=1920, max_height=1088, max_frames_per_batch=F, max_slices_per_frame=1)
 f = H.load().h264mi_internal_deblock_phase_clocks
 f.restype, f.argtypes = ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
 buf = (ctypes.c_uint32 * 12)()
-dec.decode([s])
-assert np.array_equal(dec.read_frames(0, crop=False), rec)
+dec.decode([s] * S)
+assert np.array_equal(dec.read_frames(S - 1, crop=False), rec)
 f(dec._h, buf)
-dec.decode([s])
+dec.decode([s] * S)
 f(dec._h, buf)
 names = ["1c parameters (rest of 1)", "2 vertical edges", "3 hand-off", "4 horizontal edges", "5 results", "loop", "1a DbPrm -> LDS", "1b prefetch issue", "-", "-", "-", "-"]
-steps = F * 123.0
+steps = S * F * 123.0
 tot = sum(buf)
-print("clocks per step of the wavefront of group 0 (1080p, %d pictures, %d steps each):" % (F, 123))
+print("clocks per step of the wavefront of group 0 (1080p, %d streams x %d pictures, %d steps each):" % (S, F, 123))
 for n, v in zip(names, buf):
     print("  %-20s %8.0f  %5.1f %%" % (n, v / steps, 100.0 * v / tot))
 print("  %-20s %8.0f" % ("total", tot / steps))
