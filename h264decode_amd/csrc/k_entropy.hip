@@ -31,9 +31,6 @@
 #ifndef MI_ENT_ISLICE_PRIO
 #define MI_ENT_ISLICE_PRIO 0
 #endif
-#ifndef MI_DEC_T
-#define MI_DEC_T 0
-#endif
 #ifndef MI_ENT_MINWAVES
 #define MI_ENT_MINWAVES 6
 #endif
@@ -358,20 +355,6 @@ FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     // 64), so the chain state -> table entries has no scalar instruction in it.
     const uint32_t st = RDL(reg, idx);
     const uint32_t rl4 = RDL(e.v_rlps, st), tr = RDL(e.v_trans, st);
-#if MI_DEC_T
-    // throughput variant (experiment): successor states and the bin on the scalar side, one vector -> scalar hop behind the compare
-    const uint32_t next_lps_s = tr ^ st, next_mps_s = st + ((tr >> 8) & 1u);
-    const uint32_t rlps_t = __builtin_amdgcn_perm(rl4, 0u, e.range >> (e.avail + 6)) << e.avail;
-    const uint32_t rmps_t = e.range - rlps_t;
-    const bool lps_t = e.value >= rmps_t;
-    e.value = min(e.value, e.value - rmps_t);
-    e.range = lps_t ? rlps_t : rmps_t;
-    const uint32_t slps = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(lps_t)) & 1u; // (every lane holds the same values)
-    reg = static_cast<uint32_t>(mi_writelane(static_cast<int>(slps ? next_lps_s : next_mps_s), idx, static_cast<int>(reg)));
-    e.avail = 23 - __builtin_clz(e.range);
-    cabac_refill(e);
-    return ((st >> 31) ^ slps) << 31 ^ 0x80000000u; // sign clear = bin 1
-#endif
     // everything else runs on the vector side, same value in every lane: st is pinned there
     uint32_t vst = st;
     VGPR(vst);
@@ -398,15 +381,6 @@ FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
     return vst ^ diff; // the bin is the complement of the sign: valMPS on the MPS path (diff negative), !valMPS otherwise
 }
 // a bin as a branch condition (v_cmp + s_cbranch_vcc) / as a scalar integer
-#if MI_DEC_T
-#define BIN_A(e, ctx) (static_cast<int>(cabac_decide(e, (e).ca, (ctx))) >= 0)          /* ctxIdx 0..63 */
-#define BIN_B(e, ctx) (static_cast<int>(cabac_decide(e, (e).cb, (ctx) - 64)) >= 0)     /* ctxIdx 64..124 */
-#define BIN_T8(e, inc) (static_cast<int>(cabac_decide(e, (e).cb, 61 + (inc))) >= 0)    /* ctxIdx 399..401 */
-#define BIN_W(e, lane) (static_cast<int>(cabac_decide(e, (e).wk, (lane))) >= 0)        /* residual working set */
-#define BINI_A(e, ctx) static_cast<int>((~cabac_decide(e, (e).ca, (ctx)) >> 31))
-#define BINI_B(e, ctx) static_cast<int>((~cabac_decide(e, (e).cb, (ctx) - 64) >> 31))
-#define BINI_T8(e, inc) static_cast<int>((~cabac_decide(e, (e).cb, 61 + (inc)) >> 31))
-#else
 #define BIN_A(e, ctx) UNI(static_cast<int>(cabac_decide(e, (e).ca, (ctx))) >= 0)          /* ctxIdx 0..63 */
 #define BIN_B(e, ctx) UNI(static_cast<int>(cabac_decide(e, (e).cb, (ctx) - 64)) >= 0)     /* ctxIdx 64..124 */
 #define BIN_T8(e, inc) UNI(static_cast<int>(cabac_decide(e, (e).cb, 61 + (inc))) >= 0)    /* ctxIdx 399..401 */
@@ -414,7 +388,6 @@ FI uint32_t cabac_decide(Ent &e, uint32_t &reg, int idx_) {
 #define BINI_A(e, ctx) static_cast<int>(RFL(~cabac_decide(e, (e).ca, (ctx)) >> 31))
 #define BINI_B(e, ctx) static_cast<int>(RFL(~cabac_decide(e, (e).cb, (ctx) - 64) >> 31))
 #define BINI_T8(e, inc) static_cast<int>(RFL(~cabac_decide(e, (e).cb, 61 + (inc)) >> 31))
-#endif
 FI bool cabac_bypass(Ent &e) { // 9.3.3.2.3 (A9)
     MI_COUNT_BIN(e);
     e.avail -= 1;
