@@ -1,53 +1,36 @@
-// h264decode_amd/csrc/k_deblock.hip -- K5: in-loop deblocking filter (ITU-T H.264 8.7), gfx950.
+// h264decode_amd/csrc/k_deblock.hip -- K5: in-loop deblocking filter (ITU-T H.264 8.7), gfx950; one workgroup per picture, two lines per lane.
 //
-// 8.7 is specified per macroblock in raster order (vertical edges left to right, then horizontal
-// edges top to bottom), and the left-edge filter of MB(x+1,y) rewrites columns 13..15 of MB(x,y) AFTER
-// MB(x,y)'s horizontal edges were filtered, so a whole-picture "all vertical, then all horizontal"
-// pass is not bit-exact.  Per 4x4 block the order is: left edge, right edge, top edge, bottom edge --
-// except in the last block column of a macroblock, whose right edge belongs to the next macroblock.
-// That exception makes every macroblock row one serial chain (V0..V3 of MB x, its horizontal edges in
-// columns 12..15, V0 of MB x+1, ...), and the top edge of MB(x,y) needs rows 13..15 of MB(x,y-1) after
-// V0 of MB(x+1,y-1).  So a picture is a 2-D wavefront in which row y can trail row y-1 by ONE macroblock,
-// provided the vertical-edge pass of a step runs before the horizontal-edge pass of the same step.
+// 8.7 is specified per macroblock in raster order (vertical edges left to right, then horizontal edges top to bottom), and the
+// left-edge filter of MB(x+1,y) rewrites columns 13..15 of MB(x,y) AFTER MB(x,y)'s horizontal edges were filtered, so a
+// whole-picture "all vertical, then all horizontal" pass is not bit-exact.  Every macroblock row is one serial chain (V0..V3 of MB x,
+// its horizontal edges, V0 of MB x+1, ...), and the top edge of MB(x,y) needs rows 13..15 of MB(x,y-1) after V0 of MB(x+1,y-1).
+// So a picture is a 2-D wavefront in which row y trails row y-1 by ONE macroblock, provided the vertical-edge pass of a step runs
+// before the horizontal-edge pass of the same step.
 //
-// Mapping.  One workgroup owns a picture (no cross-CU hand-off); it has up to 16 wavefronts, and a
-// wavefront owns a GROUP of 4 consecutive macroblock rows ("sub-rows", 16 lanes each).  At step t sub-row k of a
-// group works on macroblock column t - k, so a group trails the one above it by 4 steps and 16 groups (64 of the
-// 68 macroblock rows of a 1080p picture) run side by side.  A step is:
-//   1. commit the prefetched MbRecs, compute the 32 boundary strengths of the macroblock (2 per lane);
-//   2. vertical edges: a lane filters one whole line of 20 samples in registers -- 16 fresh from the
-//      prefetch registers, 4 (columns 12..15 of the macroblock to the left) from the LDS tile;
-//   3. hand-off: those 4 columns are final now, which completes rows 12..15 of the macroblock to the left for the
-//      sub-row below (same wavefront: an LDS buffer; next group: an LDS ring ordered by two counters with
-//      workgroup-scope release / acquire); then every sub-row picks up the rows above its own macroblock;
-//   4. horizontal edges: a lane filters one column of 20 samples;
-//   5. finished samples go to HBM.  Loads and stores move whole 64-byte lines: a lane prefetches the line of its row
-//      for 4 macroblocks at once, and collects its 16 finished bytes per step in registers until the aligned group of
-//      4 macroblocks is complete (rows 13..15 of a macroblock are finished -- and stored -- by the sub-row below).
-//      Fetching / storing 16 bytes per step instead costs 4x the HBM traffic (every line moves four times).
+// Mapping (round 5).  One workgroup owns a picture; a wavefront owns a GROUP of 8 consecutive macroblock rows ("sub-rows"), 8 lanes
+// per macroblock -- 9 wavefronts and ONE round for 1080p.  At step t sub-row s works on macroblock column x = t - s.  The edge filters
+// run on two lines at once in packed 16-bit arithmetic (k_deblock_pk.h): in the vertical-edge pass lane j owns luma rows 2j, 2j + 1 (one
+// boundary-strength segment) and chroma row j of Cb and of Cr (one half each); in the horizontal-edge pass luma columns 2j, 2j + 1 and
+// chroma column j.  The transposition between the passes goes through an LDS window of four macroblock columns per sub-row whose luma
+// dwords are 2x2 sample blocks {Y(2r,2c), Y(2r+1,2c), Y(2r,2c+1), Y(2r+1,2c+1)}: the row-pair lane writes eight of them with two
+// 16-byte stores (one byte permute each), the column-pair lane reads ten with one dword load each (an AND and a byte permute split a
+// block into two packed column pairs).  Chroma dwords are {Cb(r,2k), Cb(r,2k+1), Cr(r,2k), Cr(r,2k+1)}.
+// A step:
+//   1. vertical edges of MB x: 16 fresh columns from the prefetch registers (whole 64-byte lines, four macroblocks at a time, one step
+//      ahead; the slot is a wave-uniform register index), columns 12..15 of MB x-1 from the window; results into the window;
+//   2. MB x-1 is final now but for what the row below will do to its rows 13..15: its rows -4..11 (rows 12..15 of the macroblock above,
+//      out of the sub-row above's window, and its own rows 0..11) leave for HBM straight from the window, 16 bytes per row; the
+//      group's last sub-row copies rows 12..15 of MB x-1 into the LDS ring of the group below and publishes the column
+//      (workgroup-scope release / acquire on two counters, as before), the first sub-row takes column x of the group above;
+//   3. horizontal edges of MB x on the window (rows -4..-1 = rows 12..15 of the sub-row above's window: no copy).
+// Strengths and alpha / beta / tC0 come ready-made from k_dbprep (DbPrm), fetched one step ahead into registers; a lane derives its packed
+// parameters with a handful of byte permutes (a permute IS the table lookup: bS selects its tC0 byte).
 // No HBM access sits on the dependency path, and nothing is stored twice.
 //
 // Absent from the reference (only the slice-header fields are parsed: h264/slice.go:1021-1027).
 #include <hip/hip_runtime.h>
 #include "mi_kernels.h"
-
-// Boundary strengths and alpha / beta / tC0 do not depend on samples: k_dbprep (bottom of this file) works them out for every
-// macroblock of a batch in one fully parallel launch and leaves an 80-byte DbPrm per macroblock; the kernels below -- a serial
-// dependency chain per picture -- only pick their bytes out of it.  (Pictures with B slices differ in the strengths only, so
-// they need no kernel of their own any more.)
-// Second build (k_deblock_x.hip: MI_DB_BANDS = 1): a picture is spread over several workgroups
-// ("bands" of consecutive row groups, one wavefront per group, one round) for launches with fewer pictures than the chip
-// has CUs.  Inside a band nothing changes (LDS rings, workgroup-scope counters).  Between bands the bottom rows travel
-// through a ring in global memory as 8-byte {epoch, data} granules written by ONE agent-scope (sc1) store each and read
-// by agent-scope loads until every tag shows this launch's epoch: the data is its own flag, so no fence, no separate
-// flag and no assumption about which CU or XCD a band runs on.  A band only ever waits for the band above it, and bands
-// take their (picture, band) from a ticket counter in that order, so whoever a workgroup waits for is already running.
-// In the banded build a group can also be worked on by TWO wavefronts, one filtering luma and one chroma (`roles` = 2): the two
-// planes share nothing but the boundary strengths, which both wavefronts read from the macroblock's DbPrm, so each is an
-// instruction stream about two thirds / one third as long -- and a lone wavefront's step time is its instruction count.
-#ifndef MI_DB_BANDS
-#define MI_DB_BANDS 0
-#endif
+#include "k_deblock_pk.h"
 
 #define WAVE_SYNC()                                            \
     do {                                                       \
@@ -56,150 +39,71 @@
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
-struct DbSub { // state of one of the 4 macroblock rows a wavefront works on
-    // luma tile, rows -4..15 of the macroblock: bytes 12..15 of a row = columns -4..-1, bytes 16..31 = columns 0..15
-    alignas(16) uint8_t y[20][32];
-    // chroma tiles, rows -4..7 (-2.. used): bytes 4..7 = columns -4..-1, bytes 8..15 = columns 0..7
-    alignas(16) uint8_t c[2][12][16];
-    DbPrm prm;           // the current macroblock's strengths and filter parameters (k_dbprep)
-    // rows 12..15 (chroma 6..7) of the macroblock this sub-row finished in the previous step, for the sub-row below
-    alignas(16) uint8_t bot_y[4][16];
-    alignas(8) uint8_t bot_c[2][2][8];
+struct Db8Shared { // followed in dynamic LDS by the wavefronts' windows and the hand-off rings
+    int prog[MI_DEBLOCK8_MAX_GROUPS]; // per group: macroblock columns of its LAST row whose rows 12..15 are in the ring
+    int cons[MI_DEBLOCK8_MAX_GROUPS]; // per group: hand-off slots consumed by its FIRST row
 };
-struct DbWave {
-    DbSub sub[4];
-};
-struct GroupSlot { // rows 12..15 of one macroblock column handed to the group below
-    alignas(16) uint8_t y[4][16];
-    alignas(8) uint8_t c[2][2][8];
-};
-struct DbShared { // followed in dynamic LDS by DbWave[nwaves] and the hand-off rings
-    int prog[192]; // per group (x role): macroblock columns of its LAST row that are final (rows 12..15 complete)
-    int cons[192]; // per group (x role): hand-off slots consumed by its FIRST row
-    uint32_t ticket; // banded builds: which (picture, band) this workgroup drew
-};
-static_assert(sizeof(DbShared) <= MI_DEBLOCK_HDR_BYTES && sizeof(DbWave) == MI_DEBLOCK_WAVE_BYTES && sizeof(GroupSlot) == MI_DEBLOCK_SLOT_BYTES,
-              "LDS layout constants");
+static_assert(sizeof(Db8Shared) <= MI_DEBLOCK8_HDR_BYTES, "LDS layout constants");
 
-// Global memory through an explicit address-space-1 pointer with a wave-uniform base and a 32-bit per-lane offset: the
-// frame pointers are built from integers (FramePool::base), which the compiler would otherwise treat as generic (flat_*
-// instructions, two wait counters) and keep as 64-bit per-lane pointers in registers for the whole kernel.
+// Window of one sub-row: four macroblock columns ("slots", column x in slot x & 3).
+//   luma   dword (slot, row pair rp, column pair i) at slot * 256 + rp * 32 + i * 4
+//   chroma dword (slot, row r, column pair k)       at 1024 + slot * 128 + r * 16 + k * 4
+// padded to 1568 bytes so that the windows of a wavefront's sub-rows start 8 banks apart (the column-pair lanes of a sub-row read 8
+// consecutive dwords: eight sub-rows then cover the 32 banks twice).  A wavefront has nine windows: index 0 holds only rows 12..15 of
+// the sub-row ABOVE its first one (taken from the ring), so that "the window above" is the same address arithmetic for every sub-row.
+#define T_CHROMA 1024
+#define T_BYTES MI_DEBLOCK8_TILE_BYTES
+static_assert(MI_DEBLOCK8_WAVE_BYTES == 9 * T_BYTES && T_BYTES >= 1536 && (T_BYTES / 4) % 32 == 8, "LDS layout constants");
+// ring slot: rows 12..15 of one macroblock column in window format: row pairs 6, 7 (32 bytes each), chroma rows 6, 7 (16 bytes each)
+static_assert(MI_DEBLOCK_SLOT_BYTES == 96, "LDS layout constants");
+
 typedef __attribute__((address_space(1))) uint8_t g8;
-typedef uint32_t v4u __attribute__((ext_vector_type(4))); // native vectors: assignable across address spaces (HIP's uint4 is a struct)
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) v4u g_uint4;
 typedef __attribute__((address_space(1))) v2u g_uint2;
 #define GLD16(base, off) (*reinterpret_cast<const g_uint4 *>((base) + (off)))
 #define GLD8(base, off) (*reinterpret_cast<const g_uint2 *>((base) + (off)))
-// (Streaming / non-temporal stores and DbPrm loads were tried in round 4 to keep the XCD's L2 for the sample lines: no faster, and WRITE_SIZE grew
-// from 0.85 to 1.10 GB per launch -- partial lines leave the L2 before the rest of the line arrives.)
 #define GST16(base, off, v) (*reinterpret_cast<g_uint4 *>((base) + (off)) = (v))
 #define GST8(base, off, v) (*reinterpret_cast<g_uint2 *>((base) + (off)) = (v))
-typedef __attribute__((address_space(1))) uint32_t g_uint1;
-#define GST4(base, off, v) (*reinterpret_cast<g_uint1 *>((base) + (off)) = (v))
-// keeps lane-dependent values from being hoisted out of the step loop (dozens of loop-invariant addresses would otherwise
-// live in registers for the whole kernel)
+typedef __attribute__((address_space(3))) uint8_t l8;
+typedef __attribute__((address_space(3))) v4u l_uint4;
+typedef __attribute__((address_space(3))) v2u l_uint2;
+typedef __attribute__((address_space(3))) uint32_t l_uint1;
+#define LLD16(off) (*reinterpret_cast<const l_uint4 *>(lds + (off)))
+#define LLD8(off) (*reinterpret_cast<const l_uint2 *>(lds + (off)))
+#define LLD4(off) (*reinterpret_cast<const l_uint1 *>(lds + (off)))
+#define LST16(off, v) (*reinterpret_cast<l_uint4 *>(lds + (off)) = (v))
+#define LST8(off, v) (*reinterpret_cast<l_uint2 *>(lds + (off)) = (v))
+#define LST4(off, v) (*reinterpret_cast<l_uint1 *>(lds + (off)) = (v))
+#define LST1(off, v) (lds[off] = static_cast<uint8_t>(v))
+// keeps lane-dependent values from being hoisted out of the step loop
 #define OPAQUE(x) asm volatile("" : "+v"(x))
+#define PERM(hi, lo, sel) __builtin_amdgcn_perm(static_cast<uint32_t>(hi), static_cast<uint32_t>(lo), static_cast<uint32_t>(sel))
 // diagnostic build (-DMI_DB_STATS): shader clocks per phase of the step loop, summed over one wavefront's steps, added to xstatus[8 + phase]
-// by the wavefront of group 0 of every picture (tools/deblock_phase_probe.py); k_deblock gets the status words as an extra argument in that build
+// by the wavefront of group 0 of every picture (tools/deblock_phase_probe.py)
 #if defined(MI_DB_STATS)
 #define STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[k] += static_cast<uint32_t>(now_ - st_last); st_last = now_; } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #endif
 
-__device__ __forceinline__ int adiff(int a, int b) { // |a - b| for operands in 0..65535 (one v_sad_u16)
-    return static_cast<int>(__builtin_amdgcn_sad_u16(static_cast<uint32_t>(a), static_cast<uint32_t>(b), 0u));
-}
-__device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
+// byte k of w in both halves
+__device__ __forceinline__ pk2 splat_byte(uint32_t w, int k) { return pk_from(PERM(0u, w, 0x0C000C00u + 0x00010001u * static_cast<uint32_t>(k))); }
+// byte k of lo in the low half, byte k of hi in the high half
+__device__ __forceinline__ pk2 pair_byte(uint32_t hi, uint32_t lo, int k) { return pk_from(PERM(hi, lo, 0x0C040C00u + 0x00010001u * static_cast<uint32_t>(k))); }
+// all ones if byte k of w is not zero
+__device__ __forceinline__ uint32_t byte_on(uint32_t w, int k) { return ((w >> (8 * k)) & 255u) ? ~0u : 0u; }
 
-// filter one edge of a line of samples held in registers (8.7.2.3 / 8.7.2.4); q0 = px[Q].
-// Written without per-lane branches: both filters are evaluated with selects, and the only branches are
-// wave-uniform (ballot) skips -- "no lane filters this edge" and "no lane needs the bS 4 filter".
-template <int Q, bool CHROMA, int N>
-__device__ __forceinline__ void filter_edge(int (&px)[N], int bs, int alpha, int beta, int tc0) {
-    const int p0 = px[Q - 1], p1 = px[Q - 2], q0 = px[Q], q1 = px[Q + 1];
-    const bool on = bs != 0 && adiff(p0, q0) < alpha && adiff(p1, p0) < beta && adiff(q1, q0) < beta;
-    if (__builtin_amdgcn_ballot_w64(on) == 0) return;
-    const bool strong = on && bs == 4;
-    int np0, nq0;
-    if (CHROMA) {
-        const int tc = tc0 + 1;
-        const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-        np0 = clip3(0, 255, p0 + delta), nq0 = clip3(0, 255, q0 - delta);
-        if (__builtin_amdgcn_ballot_w64(strong) != 0) {
-            np0 = strong ? (2 * p1 + p0 + q1 + 2) >> 2 : np0;
-            nq0 = strong ? (2 * q1 + q0 + p1 + 2) >> 2 : nq0;
-        }
-        px[Q - 1] = on ? np0 : p0, px[Q] = on ? nq0 : q0;
-        return;
-    } else {
-        const int p2 = px[Q - 3], q2 = px[Q + 2];
-        const bool ap = adiff(p2, p0) < beta, aq = adiff(q2, q0) < beta;
-        const int tc = tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
-        const int delta = clip3(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-        const int avg = (p0 + q0 + 1) >> 1;
-        np0 = clip3(0, 255, p0 + delta), nq0 = clip3(0, 255, q0 - delta);
-        int np1 = ap ? p1 + clip3(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1) : p1;
-        int nq1 = aq ? q1 + clip3(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1) : q1;
-        int np2 = p2, nq2 = q2;
-        if (__builtin_amdgcn_ballot_w64(strong) != 0) {
-            const int p3 = px[Q - 4], q3 = px[Q + 3];
-            const bool small = adiff(p0, q0) < ((alpha >> 2) + 2);
-            const bool sp = strong && ap && small, sq = strong && aq && small;
-            const int s3 = p0 + q0 + p1 + 2; // shared partial sums of the 4- and 5-tap filters
-            np0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (strong ? (2 * p1 + p0 + q1 + 2) >> 2 : np0);
-            np1 = sp ? (p2 + s3) >> 2 : (strong ? p1 : np1);
-            np2 = sp ? (2 * p3 + 3 * p2 + s3 + 2) >> 3 : p2;
-            const int t3 = p0 + q0 + q1 + 2;
-            nq0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (strong ? (2 * q1 + q0 + p1 + 2) >> 2 : nq0);
-            nq1 = sq ? (q2 + t3) >> 2 : (strong ? q1 : nq1);
-            nq2 = sq ? (2 * q3 + 3 * q2 + t3 + 2) >> 3 : q2;
-        }
-        px[Q - 1] = on ? np0 : p0, px[Q] = on ? nq0 : q0;
-        px[Q - 2] = on ? np1 : p1, px[Q + 1] = on ? nq1 : q1;
-        px[Q - 3] = on ? np2 : p2, px[Q + 2] = on ? nq2 : q2;
-    }
-}
-
-__device__ __forceinline__ void unpack4(uint32_t w, int &a, int &b, int &c, int &d) {
-    a = static_cast<int>(w & 255u), b = static_cast<int>(__builtin_amdgcn_ubfe(w, 8, 8)), c = static_cast<int>(__builtin_amdgcn_ubfe(w, 16, 8)), d = static_cast<int>(w >> 24);
-}
-__device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
-    return static_cast<uint32_t>(a) | (static_cast<uint32_t>(b) << 8) | (static_cast<uint32_t>(c) << 16) | (static_cast<uint32_t>(d) << 24);
-}
-
-#if MI_DB_BANDS
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-#define XARGS , unsigned long long *xring_, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus, int roles
-#define KNAME k_deblock_x
-#else
-#if defined(MI_DB_STATS)
-#define XARGS , uint32_t *xstatus
-#else
-#define XARGS
-#endif
-#define KNAME k_deblock
-#endif
-extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring,
-                                                                              int ring_last, int last_bufs XARGS) {
+extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblock(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring, int ring_last,
+                                                                                   int last_bufs, uint32_t *xstatus) {
     extern __shared__ uint4 dyn_lds[];
+    l8 *const lds = (l8 *)(reinterpret_cast<uint8_t *>(dyn_lds));
     const int nthreads = static_cast<int>(blockDim.x), nwaves = nthreads >> 6;
-    DbShared &sh = *reinterpret_cast<DbShared *>(dyn_lds);
-    DbWave *waves = reinterpret_cast<DbWave *>(reinterpret_cast<uint8_t *>(dyn_lds) + MI_DEBLOCK_HDR_BYTES);
-    GroupSlot *rings = reinterpret_cast<GroupSlot *>(waves + nwaves); // region r (written by the groups of wavefront r) starts at r * ring
+    Db8Shared &sh = *reinterpret_cast<Db8Shared *>(dyn_lds);
     const int tid = static_cast<int>(threadIdx.x), wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane_v = tid & 63;
-#if MI_DB_BANDS
-    if (tid == 0) sh.ticket = atomicAdd(ticket, 1u) - ticket_base; // tickets go out in (picture, band) order: see the header
-    __syncthreads();
-    const uint32_t tk = sh.ticket;
-    const uint32_t pic_i = tk / static_cast<uint32_t>(nbands);
-    const int band = static_cast<int>(tk - pic_i * static_cast<uint32_t>(nbands));
-    const PicDesc *pd = &pics[pic_list[pic_i]];
-#else
     const PicDesc *pd = &pics[pic_list[blockIdx.x]];
-#endif
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
     // the picture's place in its frame slot (PicDesc): W = bytes from one luma row of the PICTURE to the next (a field picture lives in the
     // rows of its parity: twice the frame's pitch, first row y_off bytes in); offsets are relative to the slot's first byte
@@ -207,153 +111,78 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
     g8 *const py = (g8 *)(pd->pool_base + static_cast<uint64_t>(pd->slot) * pd->slot_bytes);
     const uint32_t y_off = pd->field == 2 ? pd->pitch >> 1 : 0u;
     const uint32_t cb_off = pd->plane + (y_off >> 1), cr_off = cb_off + (pd->plane >> 2);
-    for (int i = tid; i < 192; i += nthreads) sh.prog[i] = 0, sh.cons[i] = 0;
+    for (int i = tid; i < MI_DEBLOCK8_MAX_GROUPS; i += nthreads) sh.prog[i] = 0, sh.cons[i] = 0;
     __syncthreads();
-    const DbPrm *prms = dbprm + pd->mb_base;
-    const int ngroups = (hmb + 3) >> 2;
+    const g8 *const prms = (const g8 *)(dbprm + pd->mb_base);
+    const int ngroups = (hmb + 7) >> 3;
+    const uint32_t rings_off = MI_DEBLOCK8_HDR_BYTES + static_cast<uint32_t>(nwaves) * MI_DEBLOCK8_WAVE_BYTES; // region r (written by the groups of wavefront r) starts at r * ring slots
     const v4u z4 = v4u{0u, 0u, 0u, 0u};
     const v2u z2 = v2u{0u, 0u};
-#if MI_DB_BANDS
-    // band b owns the groups [b * ngroups / nbands, (b + 1) * ngroups / nbands), one wavefront each (the host launches
-    // enough wavefronts for the largest band); rings: region w of LDS is written by wavefront w, also by the band's last one
-    const int g0 = band * ngroups / nbands, g1 = (band + 1) * ngroups / nbands;
-    GroupSlot *const in_stage = rings + nwaves * ring; // the slot of the band above, copied from the global ring (the two roles write disjoint parts of it)
-    int pband = band - 1;                               // the band that owns group g0 - 1 (bands of small pictures can be empty)
-    while (pband > 0 && pband * ngroups / nbands == (pband + 1) * ngroups / nbands) pband--;
-    gu64 *const xin = (gu64 *)xring_ + (static_cast<size_t>(pic_i) * nbands + (pband > 0 ? pband : 0)) * static_cast<size_t>(wmb_max) * 24;
-    gu64 *const xout = (gu64 *)xring_ + (static_cast<size_t>(pic_i) * nbands + band) * static_cast<size_t>(wmb_max) * 24;
-    // roles == 2: wavefront 2k filters the luma of the band's k-th group, wavefront 2k + 1 its chroma
-    const int role = roles == 2 ? (wave & 1) : -1, gw = roles == 2 ? wave >> 1 : wave;
-    const bool do_l = role != 1, do_c = role != 0;
-    for (int g = g0 + gw; g < g1; g += ngroups) { // at most one iteration
-#else
-    const bool do_l = true, do_c = true;
     for (int g = wave; g < ngroups; g += nwaves) {
-#endif
         int lane = lane_v;
         OPAQUE(lane);
-        const int sub = lane >> 4, li = lane & 15; // sub-row inside the group, lane inside the macroblock
-        const int mby = g * 4 + sub;
-        const bool row_ok = mby < hmb, has_top = mby > 0, last_row = mby == hmb - 1;
-        const int last_sub = min(3, hmb - 1 - g * 4); // last valid sub-row of this group
+        const int s = lane >> 3, j = lane & 7; // sub-row inside the group, lane inside the macroblock
+        const int mby = g * 8 + s;
+        const bool row_ok = mby < hmb, has_top = mby > 0;
+        const int last_sub = min(7, hmb - 1 - g * 8); // last valid sub-row of this group
         const bool feeds_group = g + 1 < ngroups;     // this group's last row hands its bottom rows to group g + 1
         // hand-off rings: the one this group writes (region `wave`) and the one it reads (written by group g - 1)
-        // (the last wavefront's region holds whole rows and, from three rounds on, one buffer per round parity: see mi_deblock_plan)
-#if MI_DB_BANDS
-        const bool band_first = gw == 0 && g > 0;              // the rows above come from another workgroup
-        const int pc = roles == 2 ? 2 * g + role : g, pc_up = roles == 2 ? 2 * (g - 1) + role : g - 1, pc_dn = roles == 2 ? 2 * (g + 1) + role : g + 1; // counters of this / the upper / the lower group
-        const bool to_global = feeds_group && g == g1 - 1;     // the bottom rows go to another workgroup
-        const int out_depth = ring;
-        GroupSlot *out_ring = rings + wave * ring;
-        const int in_depth = band_first ? 1 : ring;
-        const GroupSlot *in_ring = band_first ? in_stage : rings + (gw > 0 ? wave - (roles == 2 ? 2 : 1) : 0) * ring;
-        // this lane's granule of the slot of column 0 (lanes 0..23: the 24 dwords of a GroupSlot), re-read until its tag matches
-        unsigned long long pf = 0;
-        const bool gran = lane < 24 && (lane < 16 ? do_l : do_c); // the granules of this wavefront's planes: 16 luma dwords, 8 chroma dwords
-        if (band_first && gran) pf = __hip_atomic_load(xin + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-        const int pc = g, pc_up = g - 1, pc_dn = g + 1;
+        // (the last wavefront's region holds whole rows and, from three rounds on, one buffer per round parity: see mi_deblock8_plan)
         const bool out_last = wave == nwaves - 1;
         const int out_depth = out_last ? ring_last : ring;
-        GroupSlot *out_ring = rings + wave * ring + (out_last ? ((g / nwaves) % last_bufs) * ring_last : 0);
+        const uint32_t out_ring = rings_off + static_cast<uint32_t>(wave * ring + (out_last ? ((g / nwaves) % last_bufs) * ring_last : 0)) * MI_DEBLOCK_SLOT_BYTES;
         const int in_wave = (g + nwaves - 1) % nwaves;
         const bool in_last = in_wave == nwaves - 1;
         const int in_depth = in_last ? ring_last : ring;
-        const GroupSlot *in_ring = rings + in_wave * ring + (in_last && g > 0 ? (((g - 1) / nwaves) % last_bufs) * ring_last : 0);
-#endif
-        const uint32_t yrow0 = y_off + static_cast<uint32_t>((row_ok ? mby : 0) * 16 + li) * W;                           // this lane's luma row
-        const uint32_t crow0 = (li < 8 ? cb_off : cr_off) + static_cast<uint32_t>((row_ok ? mby : 0) * 8 + (li & 7)) * Wc; // and chroma row
-#if MI_DB_BANDS
-        // Banded build: a launch that needs bands has few pictures, so HBM traffic is no concern and the chain's instruction count is
-        // everything -- a lane loads the 16 bytes of its row for the NEXT macroblock one step ahead and stores what a step
-        // finishes straight from the tile (the four columns the vertical pass just completed + this macroblock's first
-        // twelve), instead of moving whole 64-byte lines through four register slots (K5 proper, below): every line then moves four
-        // times, the slot bookkeeping -- a fifth of a step -- is gone.
-        v4u pre_y = z4;
-        v2u pre_c = z2;
-        v4u pre_rec = z4;
-        auto prefetch_mb = [&](int mbx) { // the lane's row of macroblock column mbx (of this lane's sub-row)
-            if (!row_ok || mbx < 0 || mbx >= wmb) return;
-            if (do_l) pre_y = GLD16(py, yrow0 + mbx * 16);
-            if (do_c) pre_c = GLD8(py, crow0 + mbx * 8);
-        };
-        auto prefetch_rec = [&](int mbx) { // lanes 0..4 of a sub-row: the five 16-byte pieces of the macroblock's DbPrm
-            if (!row_ok || mbx < 0 || mbx >= wmb || li >= 5) return;
-            pre_rec = reinterpret_cast<const v4u *>(prms + static_cast<uint32_t>(mby * wmb + mbx))[li];
-        };
-        const bool up_lane = li >= 13 && !last_row;        // luma: this lane stores a row of the macroblock above
-        const bool upc_lane = (li & 7) == 7 && !last_row;  // chroma: rows 7 store row -1 of the macroblock above
-        const bool y_stores = !up_lane || has_top, c_stores = !upc_lane || has_top; // up lanes of the first picture row have nothing above
-        const uint32_t yout = up_lane && has_top ? yrow0 - 16u * W : yrow0; // row li of the MB above = row li - 16
-        const uint32_t cout = upc_lane && has_top ? crow0 - 8u * Wc : crow0;
-        prefetch_mb(-sub);
-#else
-        // Input registers.  Slot s of P / Pc holds macroblock column c with (c + sub) % 4 == s, so that at step t every
+        const uint32_t in_ring = rings_off + static_cast<uint32_t>(in_wave * ring + (in_last && g > 0 ? (((g - 1) / nwaves) % last_bufs) * ring_last : 0)) * MI_DEBLOCK_SLOT_BYTES;
+        // where this lane's samples are in HBM: rows 2j, 2j + 1 of the sub-row's macroblocks (input), row pair j - 2 (output: rows -4..11)
+        const uint32_t rowmb = static_cast<uint32_t>(row_ok ? mby : 0);
+        const uint32_t yin = y_off + (rowmb * 16 + 2 * j) * W;                                         // + W: the second row
+        const uint32_t cin = (rowmb * 8 + j) * Wc;                                                     // + cb_off / cr_off
+        const bool fl_ok = row_ok && (j >= 2 || has_top), fc_ok = row_ok && (j >= 1 || has_top);      // lanes whose output rows exist
+        const uint32_t yout = y_off + (rowmb * 16 + 2 * j - (fl_ok ? 4 : 0)) * W;
+        const uint32_t cout = (rowmb * 8 + j - (fc_ok ? 1 : 0)) * Wc;
+        // Input registers.  Slot sl of P* / Q* holds macroblock column c with (c + s) % 4 == sl, so that at step t every
         // sub-row consumes slot t % 4 (a wave-uniform register index) although the sub-rows are one column apart.
-        v4u P0 = z4, P1 = z4, P2 = z4, P3 = z4;
-        v2u Q0 = z2, Q1 = z2, Q2 = z2, Q3 = z2;
-        v4u pre_rec = z4;
+        v4u PA0 = z4, PA1 = z4, PA2 = z4, PA3 = z4, PB0 = z4, PB1 = z4, PB2 = z4, PB3 = z4; // luma rows 2j, 2j + 1: 4 slots x 16 bytes
+        v2u QB0 = z2, QB1 = z2, QB2 = z2, QB3 = z2, QR0 = z2, QR1 = z2, QR2 = z2, QR3 = z2; // chroma row j of Cb, of Cr: 4 slots x 8 bytes
         auto prefetch_group = [&](int gb) { // gb = first macroblock of an aligned group of four
             if (!row_ok || gb >= wmb) return;
-            const uint32_t yb = yrow0 + gb * 16, cb = crow0 + gb * 8;
+            const uint32_t ya = yin + gb * 16, yb = ya + W, ccb = cb_off + cin + gb * 8, ccr = cr_off + cin + gb * 8;
             const int left = wmb - gb;
-            const int j0 = (0 - sub) & 3, j1 = (1 - sub) & 3, j2 = (2 - sub) & 3, j3 = (3 - sub) & 3; // position inside the group of slot s
-            if (do_l) {
-                if (j0 < left) P0 = GLD16(py, yb + j0 * 16);
-                if (j1 < left) P1 = GLD16(py, yb + j1 * 16);
-                if (j2 < left) P2 = GLD16(py, yb + j2 * 16);
-                if (j3 < left) P3 = GLD16(py, yb + j3 * 16);
-            }
-            if (do_c) {
-                if (j0 < left) Q0 = GLD8(py, cb + j0 * 8);
-                if (j1 < left) Q1 = GLD8(py, cb + j1 * 8);
-                if (j2 < left) Q2 = GLD8(py, cb + j2 * 8);
-                if (j3 < left) Q3 = GLD8(py, cb + j3 * 8);
-            }
+            const int j0 = (0 - s) & 3, j1 = (1 - s) & 3, j2 = (2 - s) & 3, j3 = (3 - s) & 3; // position inside the group of slot sl
+            if (j0 < left) PA0 = GLD16(py, ya + j0 * 16), PB0 = GLD16(py, yb + j0 * 16), QB0 = GLD8(py, ccb + j0 * 8), QR0 = GLD8(py, ccr + j0 * 8);
+            if (j1 < left) PA1 = GLD16(py, ya + j1 * 16), PB1 = GLD16(py, yb + j1 * 16), QB1 = GLD8(py, ccb + j1 * 8), QR1 = GLD8(py, ccr + j1 * 8);
+            if (j2 < left) PA2 = GLD16(py, ya + j2 * 16), PB2 = GLD16(py, yb + j2 * 16), QB2 = GLD8(py, ccb + j2 * 8), QR2 = GLD8(py, ccr + j2 * 8);
+            if (j3 < left) PA3 = GLD16(py, ya + j3 * 16), PB3 = GLD16(py, yb + j3 * 16), QB3 = GLD8(py, ccb + j3 * 8), QR3 = GLD8(py, ccr + j3 * 8);
         };
-        auto prefetch_rec = [&](int mbx) { // lanes 0..4 of a sub-row: the five 16-byte pieces of the macroblock's DbPrm
-            if (!row_ok || mbx < 0 || mbx >= wmb || li >= 5) return;
-            pre_rec = reinterpret_cast<const v4u *>(prms + static_cast<uint32_t>(mby * wmb + mbx))[li];
-        };
-        // Output registers: slot s collects the finished bytes of the column with (c + sub) % 4 == s; a group of four
-        // columns leaves as one 64-byte line (32 bytes of chroma).  Lanes 13..15 do not own finished rows (rows 13..15
-        // of a macroblock are completed by the macroblock below): they collect rows -3..-1 of the macroblock ABOVE
-        // instead, which this sub-row completes -- except in the last picture row, where they own rows 13..15 after all
-        // and the three rows above are stored directly.
-        v4u R0 = z4, R1 = z4, R2 = z4, R3 = z4;
-        v2u S0 = z2, S1 = z2, S2 = z2, S3 = z2;
-        const bool up_lane = li >= 13 && !last_row;        // luma: this lane collects a row of the macroblock above
-        const bool upc_lane = (li & 7) == 7 && !last_row;  // chroma: rows 7 collect row -1 of the macroblock above
-        const bool y_stores = !up_lane || has_top, c_stores = !upc_lane || has_top; // up lanes of the first picture row have nothing above
-        const uint32_t yout = up_lane && has_top ? yrow0 - 16u * W : yrow0; // row li of the MB above = row li - 16
-        const uint32_t cout = upc_lane && has_top ? crow0 - 8u * Wc : crow0;
-        auto flush = [&](int first_mb, int n_mb) { // columns first_mb .. first_mb + n_mb - 1 (an aligned group, or its start)
-            const int j0 = (0 - sub) & 3, j1 = (1 - sub) & 3, j2 = (2 - sub) & 3, j3 = (3 - sub) & 3;
-            if (y_stores && do_l) {
-                const uint32_t yb = yout + first_mb * 16;
-                if (j0 < n_mb) GST16(py, yb + j0 * 16, R0);
-                if (j1 < n_mb) GST16(py, yb + j1 * 16, R1);
-                if (j2 < n_mb) GST16(py, yb + j2 * 16, R2);
-                if (j3 < n_mb) GST16(py, yb + j3 * 16, R3);
-            }
-            if (c_stores && do_c) {
-                const uint32_t cb = cout + first_mb * 8;
-                if (j0 < n_mb) GST8(py, cb + j0 * 8, S0);
-                if (j1 < n_mb) GST8(py, cb + j1 * 8, S1);
-                if (j2 < n_mb) GST8(py, cb + j2 * 8, S2);
-                if (j3 < n_mb) GST8(py, cb + j3 * 8, S3);
-            }
+        // the macroblock's DbPrm, one step ahead: this lane's strengths (one dword per direction) and the three planes' parameter blocks
+        v2u pre_bs = z2;
+        v4u pre_p0 = z4, pre_p1 = z4, pre_p2 = z4;
+        auto prefetch_prm = [&](int mbx) {
+            if (!row_ok || mbx < 0 || mbx >= wmb) return;
+            const uint32_t o = static_cast<uint32_t>(mby * wmb + mbx) * static_cast<uint32_t>(sizeof(DbPrm));
+            pre_bs = GLD8(prms, o + (j >> 1) * 8);
+            pre_p0 = GLD16(prms, o + 32), pre_p1 = GLD16(prms, o + 48), pre_p2 = GLD16(prms, o + 64);
         };
         prefetch_group(0);
-#endif
-        prefetch_rec(-sub); // step 0 (only sub-row 0 is active)
+        prefetch_prm(-s); // step 0 (only sub-row 0 is active)
         // the ring this group writes was last used by the group `reuse` groups earlier: that group's reader must be through with it
-#if !MI_DB_BANDS
+        // every wait on another wavefront gives up after 4 s of s_memrealtime and says so through the status word (H264MI_EDECODE) instead of hanging the GPU
+        auto wait_for = [&](int *ctr, int want) {
+            if (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) return;
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__builtin_amdgcn_s_memrealtime() - t_start > 400000000ull) { // 100 MHz
+                    if (lane_v == 0) atomicExch(xstatus, 0x5D800000u | static_cast<uint32_t>(g));
+                    break;
+                }
+            }
+        };
         const int reuse = out_last ? nwaves * last_bufs : nwaves;
-        if (g >= reuse && feeds_group)
-            while (__hip_atomic_load(&sh.cons[g - reuse + 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < wmb) __builtin_amdgcn_s_sleep(1);
-#endif
-        const int nsteps = wmb + 3;
+        if (g >= reuse && feeds_group) wait_for(&sh.cons[g - reuse + 1], wmb);
+        const int nsteps = wmb + 8; // sub-row s: columns in steps s .. s + wmb - 1, the last column's output one step later
 #if defined(MI_DB_STATS)
         uint32_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -362,321 +191,218 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
             STAMP(5); // loop control + whatever the compiler moved across the step boundary
             int lane = lane_v;
             OPAQUE(lane);
-            const int sub = lane >> 4, li = lane & 15;
-            DbSub *ss = &waves[wave].sub[sub];
-            const DbSub *sup = &waves[wave].sub[sub > 0 ? sub - 1 : 0]; // the sub-row above (same wavefront)
-            const int mby = g * 4 + sub;
+            const int s = lane >> 3, j = lane & 7;
+            const int mby = g * 8 + s;
             const bool row_ok = mby < hmb, has_top = mby > 0, last_row = mby == hmb - 1;
-            const bool up_lane = li >= 13 && !last_row, upc_lane = (li & 7) == 7 && !last_row;
-            const int mbx = t - sub;
+            const int mbx = t - s;
             const bool active = row_ok && mbx >= 0 && mbx < wmb;
-            // this step's input registers (wave-uniform slot)
-#if MI_DB_BANDS
-            const v4u in_y = pre_y;
-            const v2u in_c = pre_c;
-#else
+            // LDS addresses: this sub-row's window (index s + 1 of the wavefront's nine), the window above, the slots of columns x and x - 1
+            const uint32_t tile = MI_DEBLOCK8_HDR_BYTES + static_cast<uint32_t>(wave) * MI_DEBLOCK8_WAVE_BYTES + static_cast<uint32_t>(s + 1) * T_BYTES;
+            const uint32_t sx = static_cast<uint32_t>(mbx) & 3u, spv = static_cast<uint32_t>(mbx - 1) & 3u;
+            const uint32_t own_l = tile + sx * 256, prev_l = tile + spv * 256, own_c = tile + T_CHROMA + sx * 128, prev_c = tile + T_CHROMA + spv * 128;
+            // this step's input registers (wave-uniform slot) and parameters
+            // (the unpacking into one register per sample position is written out once per slot behind a wave-uniform switch: selecting the slot's
+            // registers with v_cndmask costs three instructions per dword, indexing them dynamically makes the compiler copy all 48 around the loop)
             const int ts = t & 3;
-            const v4u in_y = ts == 0 ? P0 : (ts == 1 ? P1 : (ts == 2 ? P2 : P3));
-            const v2u in_c = ts == 0 ? Q0 : (ts == 1 ? Q1 : (ts == 2 ? Q2 : Q3));
-#endif
-            // ---- 1. the macroblock's DbPrm -> LDS -> this lane's strengths and filter parameters ----
-            if (active && li < 5) reinterpret_cast<v4u *>(&ss->prm)[li] = pre_rec;
-            WAVE_SYNC();
-            STAMP(6);
-#if MI_DB_BANDS
-            prefetch_mb(mbx + 1);
-#else
-            if (active && (mbx & 3) == 3) prefetch_group(mbx + 1); // the input registers of this sub-row are free again
-#endif
-            prefetch_rec(mbx + 1);
-            STAMP(7);
-            // P*[0] luma, [1] chroma (plane li >> 3): bs = the strengths of this lane's segment of edges 0..3 (edge e in byte e; chroma:
-            // luma edges 0 and 2), ab = alpha(e0) | beta(e0) << 8 | alpha(inner) << 16 | beta(inner) << 24, tc = tC0 per edge.
-            // V: vertical edges, H: horizontal edges.  No table, no record, no division of labour: four 16-byte LDS reads.
-            uint32_t Vbs[2] = {0, 0}, Vab[2] = {0, 0}, Vtc[2] = {0, 0}, Hbs[2] = {0, 0}, Hab[2] = {0, 0}, Htc[2] = {0, 0};
-            if (active) {
-                const v4u bv = *reinterpret_cast<const v4u *>(ss->prm.bs[0][0]), bh = *reinterpret_cast<const v4u *>(ss->prm.bs[1][0]);
-                const v4u z4p = v4u{0u, 0u, 0u, 0u};
-                const v4u blk_l = do_l ? *reinterpret_cast<const v4u *>(&ss->prm.pl[0]) : z4p, blk_c = do_c ? *reinterpret_cast<const v4u *>(&ss->prm.pl[1 + (li >> 3)]) : z4p;
-                auto pick = [](v4u w, int sh8, bool chroma) {
-                    const uint32_t b0 = (w.x >> sh8) & 255u, b1 = (w.y >> sh8) & 255u, b2 = (w.z >> sh8) & 255u, b3 = (w.w >> sh8) & 255u;
-                    return chroma ? (b0 | (b2 << 16)) : (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24));
-                };
-                // a plane's block: a0V b0V a1 b1 | a0H b0H t00 t01 | t02 t10 t11 t12 | t20 t21 t22 pad  (tKb: tC0 of edge kind K -- left /
-                // inner / top -- for bS b + 1).  Rows shifted up by one byte, so that bS 0 (and 4: & 3) selects a zero byte.
-                auto params = [](v4u blk, uint32_t vbs, uint32_t hbs, uint32_t &vab, uint32_t &vtc, uint32_t &hab, uint32_t &htc) {
-                    vab = blk.x;
-                    hab = (blk.y & 0xFFFFu) | (blk.x & 0xFFFF0000u);
-                    const uint32_t tw0 = ((blk.y >> 16) | ((blk.z & 255u) << 16)) << 8, tw1 = blk.z & 0xFFFFFF00u, tw2 = blk.w << 8;
-                    auto sel = [](uint32_t tw, uint32_t bs) { return (tw >> (8u * (bs & 3u))) & 255u; };
-                    vtc = sel(tw0, vbs) | (sel(tw1, vbs >> 8) << 8) | (sel(tw1, vbs >> 16) << 16) | (sel(tw1, vbs >> 24) << 24);
-                    htc = sel(tw2, hbs) | (sel(tw1, hbs >> 8) << 8) | (sel(tw1, hbs >> 16) << 16) | (sel(tw1, hbs >> 24) << 24);
-                };
-                if (do_l) {
-                    Vbs[0] = pick(bv, 8 * (li >> 2), false), Hbs[0] = pick(bh, 8 * (li >> 2), false);
-                    params(blk_l, Vbs[0], Hbs[0], Vab[0], Vtc[0], Hab[0], Htc[0]);
-                }
-                if (do_c) {
-                    Vbs[1] = pick(bv, 8 * ((li & 7) >> 1), true), Hbs[1] = pick(bh, 8 * ((li & 7) >> 1), true);
-                    params(blk_c, Vbs[1], Hbs[1], Vab[1], Vtc[1], Hab[1], Htc[1]);
-                }
+            pk2 v[20];  // luma columns -4..15 of rows 2j | 2j + 1 (vertical pass)
+            pk2 cv[10]; // chroma columns -2..7 of Cb | Cr
+            auto unpack_l = [&](const v4u &a, const v4u &b) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int m = 0; m < 4; m++) v[4 + 4 * k + m] = pair_byte(b[k], a[k], m);
+            };
+            auto unpack_c = [&](const v2u &cb, const v2u &cr) {
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+#pragma unroll
+                    for (int m = 0; m < 4; m++) cv[2 + 4 * k + m] = pair_byte(cr[k], cb[k], m);
+            };
+            switch (ts) {
+            case 0: unpack_l(PA0, PB0), unpack_c(QB0, QR0); break;
+            case 1: unpack_l(PA1, PB1), unpack_c(QB1, QR1); break;
+            case 2: unpack_l(PA2, PB2), unpack_c(QB2, QR2); break;
+            default: unpack_l(PA3, PB3), unpack_c(QB3, QR3); break;
             }
-            STAMP(0);
-            // ---- 2. vertical edges: lane li = luma row li, then chroma (plane li >> 3, row li & 7) ----
-            {
-                const bool any = (Vbs[0] | Vbs[1]) != 0;
-                uint32_t w0 = 0, w1 = in_y.x, w2 = in_y.y, w3 = in_y.z, w4 = in_y.w; // w0 = columns -4..-1
-                uint32_t c0 = 0, c1 = in_c.x, c2 = in_c.y;
-                if (active && mbx > 0) {
-                    if (do_l) w0 = *reinterpret_cast<const uint32_t *>(&ss->y[4 + li][28]); // columns 12..15 of the previous macroblock, after its horizontal pass
-                    if (do_c) c0 = *reinterpret_cast<const uint32_t *>(&ss->c[li >> 3][4 + (li & 7)][12]);
+            const v2u bs = pre_bs;
+            const v4u p0 = pre_p0, p1 = pre_p1, p2 = pre_p2;
+            if (active && (mbx & 3) == 3) prefetch_group(mbx + 1); // the input registers of this sub-row are free again
+            prefetch_prm(mbx + 1);
+            STAMP(7);
+            // ---- 1. vertical edges: lane j = luma rows 2j, 2j + 1, then chroma row j of Cb | Cr ----
+            if (active) {
+                // a plane's block: aL bL aI bI | aT bT tL1 tL2 | tL3 tI1 tI2 tI3 | tT1 tT2 tT3 pad  (a / b: alpha / beta of the left-edge, inner, top-edge QP average; tKb: tC0 for bS b).
+                // bS -> position of its tC0 byte in {y, z}: one permute maps the four strengths, a second one fetches the four bytes.
+                const uint32_t bsv = bs.x;
+                const uint32_t tsel = PERM(0x0403020Cu, 0x0706050Cu, bsv + 4u); // edge 0: the left-edge row (bytes 2..4 of {y, z}), inner edges: bytes 5..7; bS 0: a zero
+                const bool left = mbx > 0;
+                {
+                    uint32_t w6 = 0, w7 = 0;
+                    bool f0 = false;
+                    if (__builtin_amdgcn_ballot_w64(bsv != 0) != 0) {
+                        const uint32_t tc4 = PERM(p0.z, p0.y, tsel);
+                        const pk2 aL = splat_byte(p0.x, 0), bL = splat_byte(p0.x, 1), aI = splat_byte(p0.x, 2), bI = splat_byte(p0.x, 3);
+                        if (left) {
+                            const v2u lw = LLD8(prev_l + j * 32 + 24); // columns 12..15 of the previous macroblock, after its horizontal pass
+                            w6 = lw.x, w7 = lw.y;
+                        }
+                        v[0] = pk_from(PERM(0u, w6, 0x0C010C00u)), v[1] = pk_from(PERM(0u, w6, 0x0C030C02u));
+                        v[2] = pk_from(PERM(0u, w7, 0x0C010C00u)), v[3] = pk_from(PERM(0u, w7, 0x0C030C02u));
+                        f0 = pk_luma_edge<true>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], aL, bL, splat_byte(tc4, 0), byte_on(bsv, 0), (bsv & 255u) == 4u ? ~0u : 0u);
+                        pk_luma_edge<false>(v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], aI, bI, splat_byte(tc4, 1), byte_on(bsv, 1), 0u);
+                        pk_luma_edge<false>(v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15], aI, bI, splat_byte(tc4, 2), byte_on(bsv, 2), 0u);
+                        pk_luma_edge<false>(v[12], v[13], v[14], v[15], v[16], v[17], v[18], v[19], aI, bI, splat_byte(tc4, 3), byte_on(bsv, 3), 0u);
+                        if (f0 && left) LST8(prev_l + j * 32 + 24, (v2u{PERM(pk_bits(v[1]), pk_bits(v[0]), 0x06040200u), PERM(pk_bits(v[3]), pk_bits(v[2]), 0x06040200u)}));
+                    }
+                    v4u o0, o1; // the lines go into the window as 2x2 blocks of the two rows
+#pragma unroll
+                    for (int i = 0; i < 4; i++) o0[i] = PERM(pk_bits(v[5 + 2 * i]), pk_bits(v[4 + 2 * i]), 0x06040200u), o1[i] = PERM(pk_bits(v[13 + 2 * i]), pk_bits(v[12 + 2 * i]), 0x06040200u);
+                    LST16(own_l + j * 32, o0), LST16(own_l + j * 32 + 16, o1);
                 }
-                if (__builtin_amdgcn_ballot_w64(any) != 0) {
-                    if (do_l) {
-                        int px[20];
-                        unpack4(w0, px[0], px[1], px[2], px[3]);
-                        unpack4(w1, px[4], px[5], px[6], px[7]);
-                        unpack4(w2, px[8], px[9], px[10], px[11]);
-                        unpack4(w3, px[12], px[13], px[14], px[15]);
-                        unpack4(w4, px[16], px[17], px[18], px[19]);
-                        const uint32_t bsp = Vbs[0], ab = Vab[0], tc = Vtc[0];
-                        const int a1 = static_cast<int>((ab >> 16) & 255u), be1 = static_cast<int>(ab >> 24);
-                        filter_edge<4, false>(px, static_cast<int>(bsp & 255u), static_cast<int>(ab & 255u), static_cast<int>((ab >> 8) & 255u), static_cast<int>(tc & 255u));
-                        filter_edge<8, false>(px, static_cast<int>((bsp >> 8) & 255u), a1, be1, static_cast<int>((tc >> 8) & 255u));
-                        filter_edge<12, false>(px, static_cast<int>((bsp >> 16) & 255u), a1, be1, static_cast<int>((tc >> 16) & 255u));
-                        filter_edge<16, false>(px, static_cast<int>(bsp >> 24), a1, be1, static_cast<int>(tc >> 24));
-                        w0 = pack4(px[0], px[1], px[2], px[3]), w1 = pack4(px[4], px[5], px[6], px[7]), w2 = pack4(px[8], px[9], px[10], px[11]);
-                        w3 = pack4(px[12], px[13], px[14], px[15]), w4 = pack4(px[16], px[17], px[18], px[19]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (do_c) { // chroma: luma edges 0 and 2
-                        int px[12];
-                        unpack4(c0, px[0], px[1], px[2], px[3]);
-                        unpack4(c1, px[4], px[5], px[6], px[7]);
-                        unpack4(c2, px[8], px[9], px[10], px[11]);
-                        const uint32_t bsp = Vbs[1], ab = Vab[1], tc = Vtc[1];
-                        filter_edge<4, true>(px, static_cast<int>(bsp & 255u), static_cast<int>(ab & 255u), static_cast<int>((ab >> 8) & 255u), static_cast<int>(tc & 255u));
-                        filter_edge<8, true>(px, static_cast<int>((bsp >> 16) & 255u), static_cast<int>((ab >> 16) & 255u), static_cast<int>(ab >> 24), static_cast<int>((tc >> 16) & 255u));
-                        c0 = pack4(px[0], px[1], px[2], px[3]), c1 = pack4(px[4], px[5], px[6], px[7]), c2 = pack4(px[8], px[9], px[10], px[11]);
-                    }
+                __builtin_amdgcn_sched_barrier(0);
+                // chroma: luma edges 0 and 2; the low half is Cb, the high half Cr
+                const uint32_t bsc = bsv & 0x00FF00FFu;
+                if (__builtin_amdgcn_ballot_w64(bsc != 0) != 0) {
+                    const uint32_t tcb4 = PERM(p1.z, p1.y, tsel), tcr4 = PERM(p2.z, p2.y, tsel);
+                    uint32_t w3 = 0;
+                    if (left) w3 = LLD4(prev_c + j * 16 + 12);
+                    cv[0] = pk_from(w3 & 0x00FF00FFu), cv[1] = pk_from(PERM(0u, w3, 0x0C030C01u));
+                    const bool f0 = pk_chroma_edge<true>(cv[0], cv[1], cv[2], cv[3], pair_byte(p2.x, p1.x, 0), pair_byte(p2.x, p1.x, 1), pair_byte(tcr4, tcb4, 0) + pk_splat(1), byte_on(bsv, 0),
+                                                         (bsv & 255u) == 4u ? ~0u : 0u);
+                    pk_chroma_edge<false>(cv[4], cv[5], cv[6], cv[7], pair_byte(p2.x, p1.x, 2), pair_byte(p2.x, p1.x, 3), pair_byte(tcr4, tcb4, 2) + pk_splat(1), byte_on(bsv, 2), 0u);
+                    if (f0 && left) LST4(prev_c + j * 16 + 12, pk_bits(cv[0]) | (pk_bits(cv[1]) << 8));
                 }
-                if (active) { // the line goes into the tile for the horizontal pass
-                    if (do_l) {
-                        *reinterpret_cast<uint32_t *>(&ss->y[4 + li][12]) = w0;
-                        *reinterpret_cast<v4u *>(&ss->y[4 + li][16]) = v4u{w1, w2, w3, w4};
-                    }
-                    if (do_c) {
-                        uint8_t *cr = &ss->c[li >> 3][4 + (li & 7)][4];
-                        *reinterpret_cast<uint32_t *>(cr) = c0;
-                        *reinterpret_cast<v2u *>(cr + 4) = v2u{c1, c2};
-                    }
-                }
+                v4u o;
+#pragma unroll
+                for (int k = 0; k < 4; k++) o[k] = PERM(pk_bits(cv[3 + 2 * k]), pk_bits(cv[2 + 2 * k]), 0x06020400u);
+                LST16(own_c + j * 16, o);
             }
             WAVE_SYNC();
             STAMP(1);
-            // ---- 3. hand-off of the rows above ----
-            // 3a. columns 12..15 of the previous macroblock are final now: complete its bottom rows where they wait
-            //     (the buffer for the sub-row below, or the ring slot for the group below), then publish the column
-            const bool to_ring = sub == last_sub; // the group's last row feeds the next group, the others the sub-row below
-            if (active && mbx > 0 && !last_row && li < 8 && (li < 4 ? do_l : do_c)) {
-                const int cpl = (li >> 1) & 1, r = li & 1;
-                GroupSlot *gl = &out_ring[(mbx - 1) % out_depth];
-                uint32_t *dst;
-                uint32_t v;
-                if (li < 4)
-                    dst = reinterpret_cast<uint32_t *>(to_ring ? &gl->y[li][12] : &ss->bot_y[li][12]), v = *reinterpret_cast<const uint32_t *>(&ss->y[16 + li][12]);
-                else
-                    dst = reinterpret_cast<uint32_t *>(to_ring ? &gl->c[cpl][r][4] : &ss->bot_c[cpl][r][4]), v = *reinterpret_cast<const uint32_t *>(&ss->c[cpl][10 + r][4]);
-                *dst = v;
-            }
-            WAVE_SYNC();
+            // ---- 2. output of column x - 1, hand-off ----
+            // 2a. the group's last row: rows 12..15 of column xl - 1 are final but for the row below -- into the ring of the group below
+            //     (six 16-byte pieces in window format), then the column is published.  Back-pressure first: the slot held column
+            //     xl - 1 - depth, which the group below must have consumed.
             if (feeds_group) {
-                const int xl = t - last_sub; // column of the group's last row in this step: columns 0 .. xl - 1 are final now
-#if MI_DB_BANDS
-                if (to_global) { // the finished slot of column xl - 1 leaves as 24 granules
-                    if (xl >= 1 && xl < wmb && gran)
-                        __hip_atomic_store(xout + (xl - 1) * 24 + lane,
-                                           (static_cast<unsigned long long>(epoch) << 32) | reinterpret_cast<const uint32_t *>(&out_ring[(xl - 1) % out_depth])[lane],
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else
-#endif
-                if (xl >= 1 && xl < wmb && lane == 0) __hip_atomic_store(&sh.prog[pc], xl, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            // 3b. rows above this macroblock: from the sub-row above (same wavefront, written in the previous step and just
-            //     completed), or -- sub-row 0 -- from the group above through its ring, once it says the column is final
-#if MI_DB_BANDS
-            if (band_first) {
-                if (t < wmb) {
-                    // every granule of column t must carry this launch's epoch (the data is the flag); stragglers are re-read
-                    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-                    for (;;) {
-                        const bool ok = !gran || static_cast<uint32_t>(pf >> 32) == epoch;
-                        if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-                        __builtin_amdgcn_s_sleep(2);
-                        if (gran) pf = __hip_atomic_load(xin + t * 24 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (__builtin_amdgcn_s_memrealtime() - t_start > 400000000ull) { // 4 s at 100 MHz: report instead of hanging the GPU
-                            if (lane == 0) atomicExch(xstatus, 0x5D000000u | static_cast<uint32_t>(g));
-                            break;
-                        }
+                const int xl = t - last_sub; // column of the group's last row in this step
+                if (xl >= 1 && xl <= wmb) {
+                    const int c = xl - 1;
+                    if (c >= out_depth) wait_for(&sh.cons[g + 1], c - out_depth + 1);
+                    if (s == last_sub && j < 6) {
+                        const uint32_t src = j < 4 ? tile + spv * 256 + 192 + j * 16 : tile + T_CHROMA + spv * 128 + 96 + (j - 4) * 16;
+                        LST16(out_ring + static_cast<uint32_t>(c % out_depth) * MI_DEBLOCK_SLOT_BYTES + j * 16, LLD16(src));
                     }
-                    if (gran) reinterpret_cast<uint32_t *>(in_stage)[lane] = static_cast<uint32_t>(pf);
-                    if (t + 1 < wmb && gran) pf = __hip_atomic_load(xin + (t + 1) * 24 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // next step's slot
+                    WAVE_SYNC();
+                    if (lane == 0) __hip_atomic_store(&sh.prog[g], xl, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-            } else
-#endif
-            if (g > 0 && t < wmb)
-                while (__hip_atomic_load(&sh.prog[pc_up], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < t + 1) __builtin_amdgcn_s_sleep(1);
-            WAVE_SYNC();
-            if (active && has_top && li < 8 && (li < 4 ? do_l : do_c)) {
-                const int cpl = (li >> 1) & 1, r = li & 1;
-                const GroupSlot *gs = &in_ring[(mbx > 0 ? mbx : 0) % in_depth];
-                if (li < 4)
-                    *reinterpret_cast<v4u *>(&ss->y[li][16]) = *reinterpret_cast<const v4u *>(sub > 0 ? sup->bot_y[li] : gs->y[li]);
-                else
-                    *reinterpret_cast<v2u *>(&ss->c[cpl][2 + r][8]) = *reinterpret_cast<const v2u *>(sub > 0 ? sup->bot_c[cpl][r] : gs->c[cpl][r]);
+            }
+            // 2b. column x - 1 leaves for HBM: rows -4..11 (lane j: row pair j - 2; pairs -2, -1 are rows 12..15 of the window above), chroma rows -1..6
+            if (row_ok && mbx >= 1 && mbx <= wmb) {
+                const uint32_t above = tile - T_BYTES;
+                if (fl_ok) {
+                    const uint32_t src = (j < 2 ? above + 192 + j * 32 : tile + (j - 2) * 32) + spv * 256;
+                    const v4u w0 = LLD16(src), w1 = LLD16(src + 16);
+                    const v4u ra = v4u{PERM(w0.y, w0.x, 0x06040200u), PERM(w0.w, w0.z, 0x06040200u), PERM(w1.y, w1.x, 0x06040200u), PERM(w1.w, w1.z, 0x06040200u)};
+                    const v4u rb = v4u{PERM(w0.y, w0.x, 0x07050301u), PERM(w0.w, w0.z, 0x07050301u), PERM(w1.y, w1.x, 0x07050301u), PERM(w1.w, w1.z, 0x07050301u)};
+                    const uint32_t o = yout + (mbx - 1) * 16;
+                    GST16(py, o, ra), GST16(py, o + W, rb);
+                }
+                if (fc_ok) {
+                    const uint32_t src = (j < 1 ? above + T_CHROMA + 112 : tile + T_CHROMA + (j - 1) * 16) + spv * 128;
+                    const v4u w = LLD16(src);
+                    const uint32_t o = cout + (mbx - 1) * 8;
+                    GST8(py, cb_off + o, (v2u{PERM(w.y, w.x, 0x05040100u), PERM(w.w, w.z, 0x05040100u)}));
+                    GST8(py, cr_off + o, (v2u{PERM(w.y, w.x, 0x07060302u), PERM(w.w, w.z, 0x07060302u)}));
+                }
+                if (last_row) { // nothing below will touch rows 12..15 (chroma row 7): they leave with the rest
+                    if (j < 2) {
+                        const uint32_t src = tile + 192 + j * 32 + spv * 256;
+                        const v4u w0 = LLD16(src), w1 = LLD16(src + 16);
+                        const v4u ra = v4u{PERM(w0.y, w0.x, 0x06040200u), PERM(w0.w, w0.z, 0x06040200u), PERM(w1.y, w1.x, 0x06040200u), PERM(w1.w, w1.z, 0x06040200u)};
+                        const v4u rb = v4u{PERM(w0.y, w0.x, 0x07050301u), PERM(w0.w, w0.z, 0x07050301u), PERM(w1.y, w1.x, 0x07050301u), PERM(w1.w, w1.z, 0x07050301u)};
+                        const uint32_t o = y_off + (static_cast<uint32_t>(mby) * 16 + 12 + 2 * j) * W + (mbx - 1) * 16;
+                        GST16(py, o, ra), GST16(py, o + W, rb);
+                    } else if (j == 2) {
+                        const v4u w = LLD16(tile + T_CHROMA + 112 + spv * 128);
+                        const uint32_t o = (static_cast<uint32_t>(mby) * 8 + 7) * Wc + (mbx - 1) * 8;
+                        GST8(py, cb_off + o, (v2u{PERM(w.y, w.x, 0x05040100u), PERM(w.w, w.z, 0x05040100u)}));
+                        GST8(py, cr_off + o, (v2u{PERM(w.y, w.x, 0x07060302u), PERM(w.w, w.z, 0x07060302u)}));
+                    }
+                }
+            }
+            // 2c. the group's first row takes rows 12..15 of column t of the group above out of its ring, once that says the column is final
+            if (g > 0 && t < wmb) {
+                wait_for(&sh.prog[g - 1], t + 1);
+                if (s == 0 && j < 6) {
+                    const uint32_t above = tile - T_BYTES;
+                    const uint32_t dst = j < 4 ? above + sx * 256 + 192 + j * 16 : above + T_CHROMA + sx * 128 + 96 + (j - 4) * 16;
+                    LST16(dst, LLD16(in_ring + static_cast<uint32_t>(t % in_depth) * MI_DEBLOCK_SLOT_BYTES + j * 16));
+                }
             }
             WAVE_SYNC();
             if (g > 0 && t < wmb && lane == 0) // the hand-off slot of column t has been copied: the group above may reuse it
-                __hip_atomic_store(&sh.cons[pc], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&sh.cons[g], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             STAMP(2);
-            // ---- 4. horizontal edges: lane li = luma column li, then chroma (plane li >> 3, column li & 7) ----
-            {
-                const bool any = (Hbs[0] | Hbs[1]) != 0;
-                if (__builtin_amdgcn_ballot_w64(any) != 0) {
-                    if (any) {
-                        if (do_l) {
-                            int px[20];
+            // ---- 3. horizontal edges: lane j = luma columns 2j, 2j + 1, then chroma column j of Cb | Cr ----
+            if (active) {
+                const uint32_t bsh = bs.y;
+                const uint32_t above = tile - T_BYTES;
+                const uint32_t tsel = PERM(0x0605040Cu, 0x0302010Cu, bsh + 4u); // edge 0: the top-edge row (bytes 0..2 of w), inner edges: bytes 1..3 of z
+                if (__builtin_amdgcn_ballot_w64(bsh != 0) != 0) {
+                    const uint32_t tc4 = PERM(p0.w, p0.z, tsel);
+                    const pk2 aT = splat_byte(p0.y, 0), bT = splat_byte(p0.y, 1), aI = splat_byte(p0.x, 2), bI = splat_byte(p0.x, 3);
+                    pk2 h[20]; // rows -4..15 of columns 2j | 2j + 1
+                    uint32_t wa6 = 0, wa7 = 0;
+                    if (has_top) wa6 = LLD4(above + sx * 256 + 192 + j * 4), wa7 = LLD4(above + sx * 256 + 224 + j * 4);
+                    h[0] = pk_from(wa6 & 0x00FF00FFu), h[1] = pk_from(PERM(0u, wa6, 0x0C030C01u));
+                    h[2] = pk_from(wa7 & 0x00FF00FFu), h[3] = pk_from(PERM(0u, wa7, 0x0C030C01u));
 #pragma unroll
-                            for (int r = 0; r < 20; r++) px[r] = ss->y[r][16 + li];
-                            const uint32_t bsp = Hbs[0], ab = Hab[0], tc = Htc[0];
-                            const int a1 = static_cast<int>((ab >> 16) & 255u), be1 = static_cast<int>(ab >> 24);
-                            filter_edge<4, false>(px, static_cast<int>(bsp & 255u), static_cast<int>(ab & 255u), static_cast<int>((ab >> 8) & 255u), static_cast<int>(tc & 255u));
-                            filter_edge<8, false>(px, static_cast<int>((bsp >> 8) & 255u), a1, be1, static_cast<int>((tc >> 8) & 255u));
-                            filter_edge<12, false>(px, static_cast<int>((bsp >> 16) & 255u), a1, be1, static_cast<int>((tc >> 16) & 255u));
-                            filter_edge<16, false>(px, static_cast<int>(bsp >> 24), a1, be1, static_cast<int>(tc >> 24));
+                    for (int rp = 0; rp < 8; rp++) {
+                        const uint32_t w = LLD4(own_l + rp * 32 + j * 4);
+                        h[4 + 2 * rp] = pk_from(w & 0x00FF00FFu), h[5 + 2 * rp] = pk_from(PERM(0u, w, 0x0C030C01u));
+                    }
+                    const bool f0 = pk_luma_edge<true>(h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], aT, bT, splat_byte(tc4, 0), byte_on(bsh, 0), (bsh & 255u) == 4u ? ~0u : 0u);
+                    const bool f1 = pk_luma_edge<false>(h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], aI, bI, splat_byte(tc4, 1), byte_on(bsh, 1), 0u);
+                    const bool f2 = pk_luma_edge<false>(h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], aI, bI, splat_byte(tc4, 2), byte_on(bsh, 2), 0u);
+                    const bool f3 = pk_luma_edge<false>(h[12], h[13], h[14], h[15], h[16], h[17], h[18], h[19], aI, bI, splat_byte(tc4, 3), byte_on(bsh, 3), 0u);
+                    // edge e changed rows 4e - 3 .. 4e + 2: row pairs 2e - 2 .. 2e + 1 (pair -2, -1 = pairs 6, 7 of the window above)
+                    if (f0 && has_top) {
+                        LST4(above + sx * 256 + 192 + j * 4, pk_bits(h[0]) | (pk_bits(h[1]) << 8));
+                        LST4(above + sx * 256 + 224 + j * 4, pk_bits(h[2]) | (pk_bits(h[3]) << 8));
+                    }
+                    const bool wr[8] = {f0 || f1, f0 || f1, f1 || f2, f1 || f2, f2 || f3, f2 || f3, f3, f3};
 #pragma unroll
-                            for (int r = 1; r < 19; r++) ss->y[r][16 + li] = static_cast<uint8_t>(px[r]);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (do_c) {
-                            const int cpl = li >> 3, i = li & 7;
-                            int px[12];
-                            px[0] = px[1] = 0;
+                    for (int rp = 0; rp < 8; rp++)
+                        if (wr[rp]) LST4(own_l + rp * 32 + j * 4, pk_bits(h[4 + 2 * rp]) | (pk_bits(h[5 + 2 * rp]) << 8));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t bsc = bsh & 0x00FF00FFu;
+                if (__builtin_amdgcn_ballot_w64(bsc != 0) != 0) {
+                    const uint32_t tcb4 = PERM(p1.w, p1.z, tsel), tcr4 = PERM(p2.w, p2.z, tsel);
+                    const uint32_t csel = (j & 1) ? 0x0C030C01u : 0x0C020C00u; // this lane's column of a dword's column pair: Cb | Cr
+                    const uint32_t ca = above + T_CHROMA + sx * 128 + (j >> 1) * 4, co = own_c + (j >> 1) * 4;
+                    pk2 c[10]; // rows -2..7
+                    uint32_t wa = 0, wb = 0;
+                    if (has_top) wa = LLD4(ca + 96), wb = LLD4(ca + 112);
+                    c[0] = pk_from(PERM(0u, wa, csel)), c[1] = pk_from(PERM(0u, wb, csel));
 #pragma unroll
-                            for (int r = 2; r < 12; r++) px[r] = ss->c[cpl][r][8 + i];
-                            const uint32_t bsp = Hbs[1], ab = Hab[1], tc = Htc[1];
-                            filter_edge<4, true>(px, static_cast<int>(bsp & 255u), static_cast<int>(ab & 255u), static_cast<int>((ab >> 8) & 255u), static_cast<int>(tc & 255u));
-                            filter_edge<8, true>(px, static_cast<int>((bsp >> 16) & 255u), static_cast<int>((ab >> 16) & 255u), static_cast<int>(ab >> 24), static_cast<int>((tc >> 16) & 255u));
-#pragma unroll
-                            for (int r = 3; r < 9; r++) ss->c[cpl][r][8 + i] = static_cast<uint8_t>(px[r]);
-                        }
+                    for (int r = 0; r < 8; r++) c[2 + r] = pk_from(PERM(0u, LLD4(co + r * 16), csel));
+                    const bool f0 = pk_chroma_edge<true>(c[0], c[1], c[2], c[3], pair_byte(p2.y, p1.y, 0), pair_byte(p2.y, p1.y, 1), pair_byte(tcr4, tcb4, 0) + pk_splat(1), byte_on(bsh, 0),
+                                                         (bsh & 255u) == 4u ? ~0u : 0u);
+                    const bool f2 = pk_chroma_edge<false>(c[4], c[5], c[6], c[7], pair_byte(p2.x, p1.x, 2), pair_byte(p2.x, p1.x, 3), pair_byte(tcr4, tcb4, 2) + pk_splat(1), byte_on(bsh, 2), 0u);
+                    const uint32_t par = j & 1;
+                    if (f0) {
+                        if (has_top) LST1(ca + 112 + par, c[1].x), LST1(ca + 114 + par, c[1].y);
+                        LST1(co + par, c[2].x), LST1(co + 2 + par, c[2].y);
+                    }
+                    if (f2) {
+                        LST1(co + 48 + par, c[5].x), LST1(co + 50 + par, c[5].y);
+                        LST1(co + 64 + par, c[6].x), LST1(co + 66 + par, c[6].y);
                     }
                 }
             }
             WAVE_SYNC();
             STAMP(3);
-            // ---- 5. results ----
-            // Back-pressure first: the ring slot the group's last row is about to overwrite held column xl - depth of this
-            // group; the group below must have consumed it.
-#if MI_DB_BANDS
-            if (feeds_group && !to_global) { // (a slot that went to the global ring has been copied out: nothing to wait for)
-#else
-            if (feeds_group) {
-#endif
-                const int xl = t - last_sub;
-                if (xl >= out_depth && xl < wmb)
-                    while (__hip_atomic_load(&sh.cons[pc_dn], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < xl - out_depth + 1) __builtin_amdgcn_s_sleep(1);
-            }
-            if (active) {
-                const bool row_end = mbx == wmb - 1;
-                // finished bytes of this step.  Own rows: columns 12..15 of the macroblock to the left complete ITS register
-                // slot, columns 0..11 of this one open a new slot.  Rows of the macroblock above (up lanes): all 16 columns.
-                uint32_t l4 = 0, cl4 = 0;
-                v4u own = z4;
-                v2u cown = z2;
-                if (do_l) {
-                    l4 = *reinterpret_cast<const uint32_t *>(&ss->y[4 + li][12]);
-                    own = *reinterpret_cast<const v4u *>(&ss->y[up_lane ? li - 12 : 4 + li][16]); // up lanes: tile rows 1..3 = rows -3..-1
-                }
-                if (do_c) {
-                    const uint8_t *crp = &ss->c[li >> 3][upc_lane ? 3 : 4 + (li & 7)][4]; // chroma up lanes: row -1
-                    cl4 = *reinterpret_cast<const uint32_t *>(crp);
-                    cown = *reinterpret_cast<const v2u *>(crp + 4);
-                }
-#if MI_DB_BANDS
-                if (do_l && y_stores) {
-                    const uint32_t yb = yout + mbx * 16;
-                    if (up_lane)
-                        GST16(py, yb, own); // a row of the macroblock above: all 16 columns are final
-                    else {
-                        if (mbx > 0)
-                            GST16(py, yb - 4, (v4u{l4, own.x, own.y, own.z}));
-                        else {
-                            GST8(py, yb, (v2u{own.x, own.y}));
-                            GST4(py, yb + 8, own.z);
-                        }
-                        if (row_end) GST4(py, yb + 12, own.w); // no macroblock to the right: the last columns are final too
-                    }
-                }
-                if (do_c && c_stores) {
-                    const uint32_t cb = cout + mbx * 8;
-                    if (upc_lane)
-                        GST8(py, cb, cown);
-                    else {
-                        if (mbx > 0)
-                            GST8(py, cb - 4, (v2u{cl4, cown.x}));
-                        else
-                            GST4(py, cb, cown.x);
-                        if (row_end) GST4(py, cb + 4, cown.y);
-                    }
-                }
-#else
-                const int ps = (t + 3) & 3; // slot of the previous column
-                if (mbx > 0) {
-                    if (!up_lane && do_l) {
-                        if (ps == 0) R0.w = l4; else if (ps == 1) R1.w = l4; else if (ps == 2) R2.w = l4; else R3.w = l4;
-                    }
-                    if (!upc_lane && do_c) {
-                        if (ps == 0) S0.y = cl4; else if (ps == 1) S1.y = cl4; else if (ps == 2) S2.y = cl4; else S3.y = cl4;
-                    }
-                    if ((mbx & 3) == 0) flush(mbx - 4, 4); // that completed the previous aligned group
-                }
-                if (do_l) {
-                    if (ts == 0) R0 = own; else if (ts == 1) R1 = own; else if (ts == 2) R2 = own; else R3 = own;
-                }
-                if (do_c) {
-                    if (ts == 0) S0 = cown; else if (ts == 1) S1 = cown; else if (ts == 2) S2 = cown; else S3 = cown;
-                }
-                if (row_end) flush(mbx & ~3, (mbx & 3) + 1); // no macroblock to the right: the last columns are final too
-#endif
-                if (last_row && has_top) { // the up lanes own rows 13..15 here: rows -3..-1 of the macroblock above go out directly
-                    if (li < 3 && do_l)
-                        GST16(py, y_off + static_cast<uint32_t>(mby * 16 - 3 + li) * W + mbx * 16, *reinterpret_cast<const v4u *>(&ss->y[1 + li][16]));
-                    else if (li >= 8 && li < 10 && do_c)
-                        GST8(py, (li == 8 ? cb_off : cr_off) + static_cast<uint32_t>(mby * 8 - 1) * Wc + mbx * 8, *reinterpret_cast<const v2u *>(&ss->c[li - 8][3][8]));
-                }
-                // bottom rows of this macroblock (columns 12..15 still provisional unless the row ends here) for whoever is below
-                if (!last_row && li < 8 && (li < 4 ? do_l : do_c)) {
-                    const int cpl = (li >> 1) & 1, r = li & 1;
-                    GroupSlot *gs = &out_ring[mbx % out_depth];
-                    if (li < 4)
-                        *reinterpret_cast<v4u *>(to_ring ? gs->y[li] : ss->bot_y[li]) = *reinterpret_cast<const v4u *>(&ss->y[16 + li][16]);
-                    else
-                        *reinterpret_cast<v2u *>(to_ring ? gs->c[cpl][r] : ss->bot_c[cpl][r]) = *reinterpret_cast<const v2u *>(&ss->c[cpl][10 + r][8]);
-                }
-            }
-            WAVE_SYNC();
-#if MI_DB_BANDS
-            if (to_global) {
-                if (t - last_sub == wmb - 1 && gran)
-                    __hip_atomic_store(xout + (wmb - 1) * 24 + lane,
-                                       (static_cast<unsigned long long>(epoch) << 32) | reinterpret_cast<const uint32_t *>(&out_ring[(wmb - 1) % out_depth])[lane],
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else
-#endif
-            if (feeds_group && t - last_sub == wmb - 1 && lane == 0) // the last column of the group's last row is final without a right neighbour
-                __hip_atomic_store(&sh.prog[pc], wmb, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            STAMP(4);
         }
 #if defined(MI_DB_STATS)
         if (g == 0 && lane_v == 0)
@@ -684,161 +410,3 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK_MAX_WAVES * 64) KNAME(co
 #endif
     }
 }
-
-#if !MI_DB_BANDS
-// ================================================================== k_dbprep: DbPrm of every macroblock of a batch
-// 8.7.2.1 with one list (I / P pictures)
-// (strong: the bS of an intra macroblock edge -- 4, but 3 on the horizontal macroblock edges of a field picture; vlim: the vertical vector
-// difference that counts as "far" -- 4 quarter frame samples = 2 quarter field samples in a field picture)
-__device__ __forceinline__ int prep_bs(const MbRec *mp, int pb, const MbRec *mq, int qb, int strong, int vlim) {
-    // branch-free: every operand is fetched up front (independent LDS reads), the decision is a chain of selects
-    const int q8p = ((pb >> 3) << 1) | ((pb & 3) >> 1), q8q = ((qb >> 3) << 1) | ((qb & 3) >> 1);
-    const int tp = mp->type, tq = mq->type, nzp = mp->nzmask, nzq = mq->nzmask, rp = mp->refslot[q8p], rq = mq->refslot[q8q];
-    const int vpx = mp->mv[pb][0], vpy = mp->mv[pb][1], vqx = mq->mv[qb][0], vqy = mq->mv[qb][1];
-    const bool far = rp != rq || abs(vpx - vqx) >= 4 || abs(vpy - vqy) >= vlim;
-    return (MB_IS_INTRA(tp) || MB_IS_INTRA(tq)) ? strong : ((((nzp >> pb) | (nzq >> qb)) & 1) ? 2 : (far ? 1 : 0));
-}
-// 8.7.2.1 with two lists (pictures with B slices): the blocks differ if they use different reference PICTURES (frame slots; the
-// list a picture comes from does not matter) or a different number of vectors, or if the vectors that belong together differ by >= 4
-__device__ __forceinline__ bool mv_far(const int16_t *a, const int16_t *b, int vlim) { return abs(a[0] - b[0]) >= 4 || abs(a[1] - b[1]) >= vlim; }
-__device__ __forceinline__ int prep_bs_b(const MbRec *mp, const MbMv1 *vp, int pb, const MbRec *mq, const MbMv1 *vq, int qb, int strong, int vlim) {
-    if (MB_IS_INTRA(mp->type) || MB_IS_INTRA(mq->type)) return strong;
-    if (((mp->nzmask >> pb) & 1) || ((mq->nzmask >> qb) & 1)) return 2;
-    const int p8 = ((pb >> 3) << 1) | ((pb & 3) >> 1), q8 = ((qb >> 3) << 1) | ((qb & 3) >> 1);
-    const int p0 = mp->refslot[p8], p1 = mp->refslot1[p8], q0 = mq->refslot[q8], q1 = mq->refslot1[q8];
-    const int np = (p0 >= 0) + (p1 >= 0), nq = (q0 >= 0) + (q1 >= 0);
-    if (np != nq) return 1;
-    const int16_t *pv0 = mp->mv[pb], *pv1 = vp->mv[pb], *qv0 = mq->mv[qb], *qv1 = vq->mv[qb];
-    if (np < 2) { // one vector each (or none: corrupt records)
-        const int rp = p0 >= 0 ? p0 : p1, rq = q0 >= 0 ? q0 : q1;
-        if (rp != rq) return 1;
-        return mv_far(p0 >= 0 ? pv0 : pv1, q0 >= 0 ? qv0 : qv1, vlim) ? 1 : 0;
-    }
-    if (!((p0 == q0 && p1 == q1) || (p0 == q1 && p1 == q0))) return 1;
-    if (p0 != p1) // two different pictures: each vector against the one that points to the same picture
-        return (p0 == q0 ? (mv_far(pv0, qv0, vlim) || mv_far(pv1, qv1, vlim)) : (mv_far(pv0, qv1, vlim) || mv_far(pv1, qv0, vlim))) ? 1 : 0;
-    return ((mv_far(pv0, qv0, vlim) || mv_far(pv1, qv1, vlim)) && (mv_far(pv0, qv1, vlim) || mv_far(pv1, qv0, vlim))) ? 1 : 0; // both vectors into one picture
-}
-
-struct PrepSub {
-    MbRec rec[3]; // current, left, upper macroblock
-    MbMv1 mv1[3]; // their list-1 vectors (pictures with B slices)
-    DbPrm out;
-    ColRec col;   // what later B pictures need of this macroblock's motion (pictures flagged save_col)
-};
-// grid = (ceil(macroblocks of the largest picture / MI_DBPREP_MBS), pictures), block = 256: a wavefront works on 4 macroblocks at a
-// time, 16 lanes each -- lane li computes the strength of segment li & 3 of vertical edge li >> 2 and of horizontal edge li >> 2
-// (the same division of labour K5 had when it did this itself), lanes 0..8 the parameters of (plane, edge kind) li / 3, li % 3.
-// The same pass leaves the ColRec array of the pictures a later B picture (or batch) may take as co-located picture
-// (8.4.1.2.1: per 4x4 block the vector of the list the block uses -- list 0 if it uses it, otherwise list 1 --, per 8x8 the
-// reference index and the frame slot of the picture it points to; -1: intra): the records are staged here anyway.
-// (Measured in round 4: issuing the loads of the wavefront's next step before working on the current one -- 7.8 -> 9.3 ms per 7680 pictures; twice the
-// macroblocks per workgroup on top of that -- 8.9 ms.  A million short workgroups hide the dependent loads better than a loop carrying 12 registers.)
-// col_only: the one-off back-fill of ColRec arrays for a batch whose DbPrm records are already in use (mi_api.cpp: ensure_b_buffers).
-extern "C" __global__ void __launch_bounds__(256) k_dbprep(const uint32_t *pic_list, const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1,
-                                                           DbPrm *out, int col_only, unsigned long long *intramask) {
-    __shared__ PrepSub subs[4][4];
-    __shared__ uint8_t s_alpha[52], s_beta[52], s_tc0[52][4];
-    const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63, sub = lane >> 4, li = lane & 15;
-    const PicDesc *pd = &pics[pic_list[blockIdx.y]];
-    const int wmb = static_cast<int>(pd->wmb), nmb = wmb * static_cast<int>(pd->hmb);
-    const int mb_first = static_cast<int>(blockIdx.x) * MI_DBPREP_MBS;
-    if (mb_first >= nmb) return;
-    for (int i = tid; i < 52; i += 256) {
-        s_alpha[i] = tab->alpha[i], s_beta[i] = tab->beta[i];
-        s_tc0[i][0] = 0, s_tc0[i][1] = tab->tc0[i][1], s_tc0[i][2] = tab->tc0[i][2], s_tc0[i][3] = tab->tc0[i][3];
-    }
-    __syncthreads();
-    const bool two = pd->has_b != 0;
-    const MbRec *recs = mbrec + pd->mb_base;
-    const MbMv1 *recs1 = two ? mbmv1 + pd->mb_base : nullptr;
-    DbPrm *outs = out + pd->mb_base;
-    PrepSub *ss = &subs[wave][sub];
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    for (int it = wave; it < MI_DBPREP_MBS / 4; it += 4) {
-        const int mb = mb_first + it * 4 + sub;
-        const bool valid = mb < nmb;
-        const int mby = static_cast<int>(__umulhi(static_cast<uint32_t>(valid ? mb : 0), pd->inv_wmb)), mbx = (valid ? mb : 0) - mby * wmb;
-        const bool has_left = valid && mbx > 0, has_top = valid && mby > 0;
-        if (valid) { // lanes 0-7: the record, lanes 8-15: the record above; then lanes 0-7: the record to the left
-            const v4u z = v4u{0u, 0u, 0u, 0u};
-            const bool up = li >= 8;
-            v4u a = z, b = z;
-            if (!up || has_top) a = reinterpret_cast<const v4u *>(recs + (up ? mb - wmb : mb))[li & 7];
-            if (!up && has_left) b = reinterpret_cast<const v4u *>(recs + mb - 1)[li];
-            reinterpret_cast<v4u *>(&ss->rec[up ? 2 : 0])[li & 7] = a;
-            if (!up) reinterpret_cast<v4u *>(&ss->rec[1])[li] = b;
-            if (two) { // list-1 vectors: lanes 0-3 current, 4-7 left, 8-11 above
-                const int which = li >> 2;
-                if (which < 3) {
-                    const bool ok = which == 0 || (which == 1 ? has_left : has_top);
-                    reinterpret_cast<v4u *>(&ss->mv1[which == 0 ? 0 : (which == 1 ? 1 : 2)])[li & 3] =
-                        ok ? reinterpret_cast<const v4u *>(recs1 + (which == 0 ? mb : (which == 1 ? mb - 1 : mb - wmb)))[li & 3] : z;
-                }
-            }
-        }
-        WAVE_SYNC();
-        // K3's work list: one bit per macroblock of the batch (index = position in the record array), set for intra macroblocks and for
-        // macroblocks no slice delivered -- K3 reads 1 KB per 1080p picture instead of one type byte out of every 128-byte record
-        if (valid && !col_only && li == 0 && (MB_IS_INTRA(ss->rec[0].type) || ss->rec[0].type == MBT_NONE)) {
-            const unsigned long long gmb = pd->mb_base + static_cast<unsigned long long>(mb);
-            atomicOr(&intramask[gmb >> 6], 1ull << (gmb & 63));
-        }
-        if (valid) {
-            const MbRec *mq = &ss->rec[0], *ml = has_left ? &ss->rec[1] : nullptr, *mt = has_top ? &ss->rec[2] : nullptr;
-            const int dbf = mq->dbf_idc;
-            if (dbf == 2) { // no filtering across slice boundaries
-                if (ml && ml->slice_in_pic != mq->slice_in_pic) ml = nullptr;
-                if (mt && mt->slice_in_pic != mq->slice_in_pic) mt = nullptr;
-            }
-            const int e = li >> 2, k = li & 3;
-            const bool mb_edge = e == 0;
-            const int qb0 = k * 4 + e, qb1 = li; // q block of the vertical / horizontal edge segment
-            const int pb0 = mb_edge ? k * 4 + 3 : qb0 - 1, pb1 = mb_edge ? 12 + k : qb1 - 4;
-            const bool ok = dbf != 1 && !((e & 1) && mq->t8x8);
-            const bool ok0 = ok && !(mb_edge && !ml), ok1 = ok && !(mb_edge && !mt);
-            const MbRec *mp0 = mb_edge && ml ? ml : mq, *mp1 = mb_edge && mt ? mt : mq; // (no neighbour: any record, the result is masked)
-            int bs0, bs1;
-            // 8.7.2.1 in a field picture: bS 4 needs a VERTICAL macroblock edge (horizontal ones get 3), and vectors differ from a
-            // vertical distance of 4 quarter FRAME samples on = 2 quarter field samples
-            const bool fieldpic = pd->field != 0;
-            const int vlim = fieldpic ? 2 : 4, strong0 = mb_edge ? 4 : 3, strong1 = mb_edge && !fieldpic ? 4 : 3;
-            if (two) {
-                bs0 = prep_bs_b(mp0, mb_edge && ml ? &ss->mv1[1] : &ss->mv1[0], pb0, mq, &ss->mv1[0], qb0, strong0, vlim);
-                bs1 = prep_bs_b(mp1, mb_edge && mt ? &ss->mv1[2] : &ss->mv1[0], pb1, mq, &ss->mv1[0], qb1, strong1, vlim);
-            } else
-                bs0 = prep_bs(mp0, pb0, mq, qb0, strong0, vlim), bs1 = prep_bs(mp1, pb1, mq, qb1, strong1, vlim);
-            ss->out.bs[0][e][k] = static_cast<uint8_t>(ok0 ? bs0 : 0);
-            ss->out.bs[1][e][k] = static_cast<uint8_t>(ok1 ? bs1 : 0);
-            if (li < 9) { // 8.7.2.2: (plane, edge kind): qPav of the left / no / the upper neighbour, indexA / indexB, the table rows
-                const int plane = li / 3, kind = li - plane * 3;
-                const MbRec *mn = kind == 0 ? ml : (kind == 2 ? mt : nullptr);
-                const int qpq = plane == 0 ? mq->qp : mq->qpc[plane - 1];
-                const int qpn = mn ? (plane == 0 ? mn->qp : mn->qpc[plane - 1]) : qpq;
-                const int qpav = (qpn + qpq + 1) >> 1;
-                const int ia = min(max(qpav + mq->alpha_off, 0), 51), ib = min(max(qpav + mq->beta_off, 0), 51);
-                ss->out.pl[plane].ab[2 * kind] = s_alpha[ia], ss->out.pl[plane].ab[2 * kind + 1] = s_beta[ib];
-                ss->out.pl[plane].tc[kind][0] = s_tc0[ia][1], ss->out.pl[plane].tc[kind][1] = s_tc0[ia][2], ss->out.pl[plane].tc[kind][2] = s_tc0[ia][3];
-                if (kind == 0) ss->out.pl[plane].pad = 0;
-            }
-            if (pd->save_col) { // lane li: block li's vector; lanes 0..3 also the reference of 8x8 quadrant li
-                const bool inter = MB_IS_INTER(mq->type);
-                const int q = ((li >> 3) << 1) | ((li & 3) >> 1);
-                const bool l0 = inter && mq->ref[q] >= 0, l1 = inter && !l0 && two && mq->refslot1[q] >= 0;
-                ss->col.mv[li][0] = l0 ? mq->mv[li][0] : (l1 ? ss->mv1[0].mv[li][0] : static_cast<int16_t>(0));
-                ss->col.mv[li][1] = l0 ? mq->mv[li][1] : (l1 ? ss->mv1[0].mv[li][1] : static_cast<int16_t>(0));
-                if (li < 4) {
-                    const bool q0 = inter && mq->ref[li] >= 0, q1 = inter && !q0 && two && mq->refslot1[li] >= 0;
-                    ss->col.refslot[li] = q0 ? mq->refslot[li] : (q1 ? mq->refslot1[li] : static_cast<int16_t>(-1));
-                    ss->col.ref[li] = q0 ? mq->ref[li] : (q1 ? MBREC_REF1(mq)[li] : static_cast<int8_t>(-1));
-                    ss->col.pad[li] = 0;
-                }
-            }
-        }
-        WAVE_SYNC();
-        if (valid && !col_only && li < 5) reinterpret_cast<v4u *>(outs + mb)[li] = reinterpret_cast<const v4u *>(&ss->out)[li];
-        if (valid && pd->save_col && li < 5) reinterpret_cast<v4u *>(reinterpret_cast<ColRec *>(pd->col_out) + mb)[li] = reinterpret_cast<const v4u *>(&ss->col)[li];
-        WAVE_SYNC();
-    }
-}
-#endif

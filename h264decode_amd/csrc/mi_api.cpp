@@ -2120,14 +2120,9 @@ static int execute_stage(h264mi_decoder *d, int stage_idx, bool exclusive) {
                                d->d_dbprm[set], dbring, 0, 1, d->d_xring, next_epoch(), nb5, d->d_xctl, d->x_tk5, g.wmb_max, d->d_xctl + 64, roles);
             d->x_tk5 += n * nb5;
         } else {
-            mi_deblock_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
-#if defined(MI_DB_STATS) /* diagnostic build: the kernel adds the phase clocks of its step loop to the status words */
-            hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_off[w], g.d_pics,
+            mi_deblock8_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
+            hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock8_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_off[w], g.d_pics,
                                d->d_dbprm[set], dbring, dbring_last, dbbufs, d->d_xctl + 64);
-#else
-            hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_off[w], g.d_pics,
-                               d->d_dbprm[set], dbring, dbring_last, dbbufs);
-#endif
         }
         mark(3);
     }
@@ -2439,12 +2434,12 @@ extern "C" int32_t h264mi_internal_poison(h264mi_decoder *d) {
 }
 
 // Not part of the public ABI: lets the CPU test-suite check the K5 launch plan (wavefronts, hand-off ring depth,
-// dynamic LDS) without a GPU -- a wrong plan would deadlock the kernel, see mi_deblock_plan().
+// dynamic LDS) without a GPU -- a wrong plan would deadlock the kernel, see mi_deblock8_plan().
 extern "C" int32_t h264mi_internal_deblock_plan(int32_t wmb, int32_t hmb, int32_t *nwaves, int32_t *ring, int32_t *ring_last, int32_t *last_bufs, int64_t *lds_bytes) {
     if (!nwaves || !ring || !ring_last || !last_bufs || !lds_bytes || wmb < 1 || hmb < 1) return H264MI_EINVAL;
     int w = 1, r = 1, rl = 1, nb = 1;
-    mi_deblock_plan(wmb, hmb, &w, &r, &rl, &nb);
-    *nwaves = w, *ring = r, *ring_last = rl, *last_bufs = nb, *lds_bytes = static_cast<int64_t>(mi_deblock_lds_bytes(w, r, rl, nb));
+    mi_deblock8_plan(wmb, hmb, &w, &r, &rl, &nb);
+    *nwaves = w, *ring = r, *ring_last = rl, *last_bufs = nb, *lds_bytes = static_cast<int64_t>(mi_deblock8_lds_bytes(w, r, rl, nb));
     return H264MI_OK;
 }
 

@@ -37,13 +37,19 @@ extern "C" __global__ void k_intra_x(const uint32_t *pic_list, const PicDesc *pi
 #define MI_DBPREP_MBS 64
 #endif
 extern "C" __global__ void k_dbprep(const uint32_t *pic_list, const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1, DbPrm *out, int col_only, unsigned long long *intramask);
-// K5: in-loop deblocking, one workgroup per picture, one wavefront per group of 4 macroblock rows (up to 16 groups side by side).
-// block = 64 * nwaves, dynamic LDS = mi_deblock_lds_bytes(nwaves, ring, ring_last); (nwaves, ring, ring_last) from mi_deblock_plan()
-#if defined(MI_DB_STATS) /* diagnostic build: the phase clocks of the step loop go to the status words (k_deblock.hip) */
+// K5 (k_deblock.hip): in-loop deblocking, one workgroup per picture, one wavefront per group of 8 macroblock rows, 8 lanes per macroblock
+// (two lines per lane, packed 16-bit arithmetic).  block = 64 * nwaves, dynamic LDS = mi_deblock8_lds_bytes(nwaves, ring, ring_last, last_bufs);
+// (nwaves, ring, ring_last, last_bufs) from mi_deblock8_plan()
+// xstatus: a wavefront that gives up waiting for its neighbour (4 s) leaves a code there; a -DMI_DB_STATS build adds the phase clocks of its step loop to xstatus[8..19]
 extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring, int ring_last, int last_bufs, uint32_t *xstatus);
-#else
-extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring, int ring_last, int last_bufs);
-#endif
+#define MI_DEBLOCK8_MAX_WAVES 10     /* 640 threads: three wavefronts on a SIMD at most, 168 VGPRs each */
+#define MI_DEBLOCK8_MAX_GROUPS 64    /* hmb <= 320 + slack */
+#define MI_DEBLOCK8_HDR_BYTES 512    /* sizeof(Db8Shared) */
+#define MI_DEBLOCK8_TILE_BYTES 1568  /* the LDS window of a sub-row: four macroblock columns of luma (1024) and chroma (512) + 32 (bank stagger) */
+#define MI_DEBLOCK8_WAVE_BYTES (9 * MI_DEBLOCK8_TILE_BYTES) /* 8 sub-rows + rows 12..15 of the row above the first */
+static inline size_t mi_deblock8_lds_bytes(int nwaves, int ring, int ring_last, int last_bufs) {
+    return MI_DEBLOCK8_HDR_BYTES + static_cast<size_t>(nwaves) * MI_DEBLOCK8_WAVE_BYTES + (static_cast<size_t>(nwaves - 1) * ring + static_cast<size_t>(ring_last) * last_bufs) * 96;
+}
 // K5 spread over `nbands` workgroups per picture (k_deblock_x.hip): grid = pictures * nbands, block = 64 * (largest band's group count),
 // dynamic LDS = mi_deblock_lds_bytes_banded().  xring: pictures * nbands * wmb_max * 24 granules of 8 bytes; epoch: a value no earlier
 // launch on this ring has used (never 0); ticket / ticket_base: a counter that only ever grows and its value before this launch.
@@ -51,16 +57,12 @@ extern "C" __global__ void k_deblock_x(const uint32_t *pic_list, const PicDesc *
                                        unsigned long long *xring, uint32_t epoch, int nbands, uint32_t *ticket, uint32_t ticket_base, int wmb_max, uint32_t *xstatus,
                                        int roles);
 #ifndef MI_DEBLOCK_MAX_WAVES
-#define MI_DEBLOCK_MAX_WAVES 12    /* 1024 threads; LDS: 6 KB of row state per wavefront + its hand-off ring */
+#define MI_DEBLOCK_MAX_WAVES 12    /* the banded kernel: LDS: 6 KB of row state per wavefront + its hand-off ring */
 #endif
 #define MI_DEBLOCK_HDR_BYTES 1552  /* sizeof(DbShared) rounded up to 16 */
 #define MI_DEBLOCK_WAVE_BYTES 4800 /* 4 sub-rows: sample tiles, the macroblock's DbPrm, the bottom rows for the sub-row below */
 #define MI_DEBLOCK_SLOT_BYTES 96
 #define MI_DEBLOCK_LDS_MAX (160 * 1024)
-static inline size_t mi_deblock_lds_bytes(int nwaves, int ring, int ring_last, int last_bufs, int wave_bytes = MI_DEBLOCK_WAVE_BYTES) {
-    return MI_DEBLOCK_HDR_BYTES + static_cast<size_t>(nwaves) * wave_bytes +
-           (static_cast<size_t>(nwaves - 1) * ring + static_cast<size_t>(ring_last) * last_bufs) * MI_DEBLOCK_SLOT_BYTES;
-}
 // banded builds: one ring region per wavefront (the last one stages what goes to the global ring) + the staging slot of the band above
 static inline size_t mi_deblock_lds_bytes_banded(int nwaves, int ring, int wave_bytes = MI_DEBLOCK_WAVE_BYTES) {
     return MI_DEBLOCK_HDR_BYTES + static_cast<size_t>(nwaves) * wave_bytes + (static_cast<size_t>(nwaves) * ring + 1) * MI_DEBLOCK_SLOT_BYTES;
@@ -80,24 +82,25 @@ static inline void mi_deblock_bands(int n_pics, int wmb, int hmb, int max_wgs, i
     *nwaves = per_band * *roles;
     *ring = wmb < 16 ? (wmb > 0 ? wmb : 1) : 16;
 }
-// Wavefront count and hand-off ring depths for pictures of wmb x hmb macroblocks.  Wavefront w runs the 4-row groups
-// w, w + nwaves, ...; group g hands its bottom rows to group g + 1 through the ring region of its wavefront.  A group may
-// run at most `depth` columns ahead of the group below it.  Groups of one round run side by side, 4 steps apart, so a
+// Wavefront count and hand-off ring depths of k_deblock for pictures of wmb x hmb macroblocks.  Wavefront w runs the 8-row groups
+// w, w + nwaves, ...; group g hands rows 12..15 of its last macroblock row to group g + 1 through the ring region of its wavefront.  A group may
+// run at most `depth` columns ahead of the group below it.  Groups of one round run side by side, 8 steps apart, so a
 // short ring is enough between them; but the reader of the LAST wavefront's groups is wavefront 0 in the NEXT round, which
 // only starts when it has finished a whole row -- that ring (ring_last) holds a whole row, otherwise the last wavefront
 // (and through back-pressure every wavefront above it) would wait for wavefront 0.  From three rounds on that ring is
 // double-buffered by round: the last wavefront's group of round r must not wait until wavefront 0 has read ALL of round
 // r - 1's ring, because wavefront 0's group of round r can only finish when the groups below it -- up to the last
 // wavefront's, through the short rings -- make progress: with a single buffer wide pictures deadlock.  As many wavefronts as fit.
-static inline void mi_deblock_plan(int wmb, int hmb, int *nwaves, int *ring, int *ring_last, int *last_bufs, int wave_bytes = MI_DEBLOCK_WAVE_BYTES) {
-    const int ngroups = (hmb + 3) / 4;
+// 1080p: 9 wavefronts, one round.
+static inline void mi_deblock8_plan(int wmb, int hmb, int *nwaves, int *ring, int *ring_last, int *last_bufs) {
+    const int ngroups = (hmb + 7) / 8;
     const int w1 = wmb > 0 ? wmb : 1;
-    for (int nw = ngroups < MI_DEBLOCK_MAX_WAVES ? ngroups : MI_DEBLOCK_MAX_WAVES; nw >= 1; nw--) {
+    for (int nw = ngroups < MI_DEBLOCK8_MAX_WAVES ? ngroups : MI_DEBLOCK8_MAX_WAVES; nw >= 1; nw--) {
         const int rounds = (ngroups + nw - 1) / nw;
         const int r = w1 < 16 ? w1 : 16;
         const int rl = rounds > 1 ? w1 : r;
         const int nb = rounds > 2 ? 2 : 1;
-        if (mi_deblock_lds_bytes(nw, r, rl, nb, wave_bytes) <= MI_DEBLOCK_LDS_MAX) {
+        if (mi_deblock8_lds_bytes(nw, r, rl, nb) <= MI_DEBLOCK_LDS_MAX) {
             *nwaves = nw, *ring = r, *ring_last = rl, *last_bufs = nb;
             return;
         }

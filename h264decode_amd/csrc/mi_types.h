@@ -86,7 +86,8 @@ typedef struct __attribute__((aligned(16))) {
  * strengths (8.7.2.1) and, per colour plane, alpha / beta and the tC0 rows (8.7.2.2, Tables 8-16 / 8-17) of the three QP
  * averages a macroblock's edges use: its left edge, its inner edges, its top edge. */
 typedef struct __attribute__((aligned(16))) {
-    uint8_t bs[2][4][4];      /* [direction: 0 vertical edges, 1 horizontal][edge][segment] */
+    uint8_t bs[4][2][4];      /* [segment: rows (vertical edges) / columns (horizontal edges) 4 seg .. 4 seg + 3][direction: 0 vertical edges, 1 horizontal][edge]:
+                               * what a K5 lane needs -- the strengths of the four edges crossing its line(s) -- is one dword per direction */
     struct {
         uint8_t ab[6];        /* alpha, beta of the left edge | of the inner edges | of the top edge */
         uint8_t tc[3][3];     /* tC0 for bS 1..3 of the left edge | inner edges | top edge */

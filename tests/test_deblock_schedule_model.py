@@ -1,13 +1,18 @@
 """CPU model of K5's inter-wavefront protocol (h264decode_amd/csrc/k_deblock.hip): wavefront w of a picture's workgroup
-runs the 4-row groups w, w + nwaves, ...; group g hands the bottom rows of its last macroblock row to group g + 1 through
-an LDS ring, ordered by two counters (prog: columns final, cons: columns consumed) with back-pressure.  The model replays
-the kernel's waits and ring accesses for the launch plan the library computes (mi_deblock_plan), under adversarial
-wavefront scheduling, and checks: no deadlock, every slot read holds exactly the column the reader expects in its final
-state, and no slot is overwritten before it was read.  A wrong plan or protocol hangs the GPU, so it is checked here."""
+runs the 8-row groups w, w + nwaves, ...; group g hands rows 12..15 of its last macroblock row to group g + 1 through
+an LDS ring, ordered by two counters (prog: columns in the ring, cons: columns consumed) with back-pressure.  A column
+enters the ring ONCE, final (one step after its horizontal pass, when the vertical pass of its right neighbour -- or the
+end of the row -- has completed its last four columns).  The model replays the kernel's waits and ring accesses for the
+launch plan the library computes (mi_deblock8_plan), under adversarial wavefront scheduling, and checks: no deadlock,
+every slot read holds exactly the column the reader expects, and no slot is overwritten before it was read.  A wrong plan
+or protocol hangs the GPU, so it is checked here.  (The banded kernel k_deblock_x keeps round 2's 4-row groups and its
+provisional-then-final slots: second half of this file.)"""
 import ctypes
 import random
 
 import pytest
+
+ROWS = 8  # macroblock rows per group (k_deblock.hip: sub-rows of a wavefront)
 
 
 def _plan(H, wmb, hmb):
@@ -17,14 +22,15 @@ def _plan(H, wmb, hmb):
     f.argtypes = [I32, I32] + [ctypes.POINTER(I32)] * 4 + [ctypes.POINTER(ctypes.c_int64)]
     nw, ring, rl, nb, lds = I32(), I32(), I32(), I32(), ctypes.c_int64()
     assert f(wmb, hmb, ctypes.byref(nw), ctypes.byref(ring), ctypes.byref(rl), ctypes.byref(nb), ctypes.byref(lds)) == 0
+    assert lds.value <= 160 * 1024 and 1 <= nw.value <= 10
     return nw.value, ring.value, rl.value, nb.value
 
 
 def _wave_program(w, nw, ring, ring_last, last_bufs, wmb, hmb, prog, cons, slots):
-    """Generator: yields ('wait', predicate) whenever the kernel would spin; everything else happens between yields."""
-    ngroups = (hmb + 3) // 4
+    """Generator: yields a predicate whenever the kernel would spin; everything else happens between yields."""
+    ngroups = (hmb + ROWS - 1) // ROWS
     for g in range(w, ngroups, nw):
-        last_sub = min(3, hmb - 1 - 4 * g)
+        last_sub = min(ROWS - 1, hmb - 1 - ROWS * g)
         feeds = g + 1 < ngroups
         out_last = w == nw - 1
         out_depth = ring_last if out_last else ring
@@ -36,35 +42,29 @@ def _wave_program(w, nw, ring, ring_last, last_bufs, wmb, hmb, prog, cons, slots
         reuse = nw * last_bufs if out_last else nw
         if g >= reuse and feeds:
             yield lambda g=g, reuse=reuse: cons[g - reuse + 1] >= wmb
-        for t in range(wmb + 3):
+        for t in range(wmb + ROWS):
             xl = t - last_sub
-            # 3a: columns 12..15 of column xl - 1 complete its slot, then the column is published
-            if feeds and 1 <= xl < wmb:
-                key = (out_buf, (xl - 1) % out_depth)
-                assert slots[key][:2] == (g, xl - 1), ("fix-up hits a foreign slot", g, xl, slots[key])
-                slots[key] = (g, xl - 1, True, slots[key][3])
+            # 2a: rows 12..15 of column xl - 1 of the group's last row go into the ring (back-pressure first), then the column is published
+            if feeds and 1 <= xl <= wmb:
+                c = xl - 1
+                if c >= out_depth:
+                    yield lambda g=g, c=c, d=out_depth: cons[g + 1] >= c - d + 1
+                key = (out_buf, c % out_depth)
+                old = slots.get(key)
+                assert old is None or old[2], ("slot overwritten before it was read", g, c, old)
+                slots[key] = (g, c, False)
                 prog[g] = xl
-            # 3b: sub-row 0 takes the rows above column t from the group above
+            # 2c: the group's first row takes the rows above column t from the group above
             if g > 0 and t < wmb:
                 yield lambda g=g, t=t: prog[g - 1] >= t + 1
                 key = (in_buf, t % in_depth)
-                assert slots.get(key, (None,))[:3] == (g - 1, t, True), ("reader finds the wrong column", g, t, slots.get(key))
-                slots[key] = slots[key][:3] + (True,)  # consumed
+                assert slots.get(key, (None,))[:2] == (g - 1, t), ("reader finds the wrong column", g, t, slots.get(key))
+                slots[key] = slots[key][:2] + (True,)  # consumed
                 cons[g] = t + 1
-            # 5: back-pressure, then the group's last row writes its bottom rows into the slot of its column
-            if feeds and out_depth <= xl < wmb:
-                yield lambda g=g, xl=xl, d=out_depth: cons[g + 1] >= xl - d + 1
-            if feeds and 0 <= xl < wmb:
-                key = (out_buf, xl % out_depth)
-                old = slots.get(key)
-                assert old is None or old[3], ("slot overwritten before it was read", g, xl, old)
-                slots[key] = (g, xl, xl == wmb - 1, False)  # final at once only at the end of the row
-                if xl == wmb - 1:
-                    prog[g] = wmb
 
 
 def _simulate(nw, ring, ring_last, last_bufs, wmb, hmb, rng):
-    ngroups = (hmb + 3) // 4
+    ngroups = (hmb + ROWS - 1) // ROWS
     prog, cons, slots = [0] * (ngroups + 1), [0] * (ngroups + 1), {}
     waves = [_wave_program(w, nw, ring, ring_last, last_bufs, wmb, hmb, prog, cons, slots) for w in range(nw)]
     blocked = [None] * nw
@@ -81,7 +81,7 @@ def _simulate(nw, ring, ring_last, last_bufs, wmb, hmb, rng):
         assert cons[g] == wmb and prog[g - 1] == wmb
 
 
-@pytest.mark.parametrize("wmb,hmb", [(1, 1), (2, 9), (11, 9), (20, 15), (45, 45), (80, 45), (120, 68), (240, 135), (17, 200), (300, 320), (512, 100), (512, 320)])
+@pytest.mark.parametrize("wmb,hmb", [(1, 1), (2, 9), (11, 9), (20, 15), (45, 45), (80, 45), (120, 68), (240, 135), (17, 200), (300, 320), (512, 100), (512, 320), (3, 17), (120, 34)])
 def test_deblock_protocol_is_deadlock_free_and_race_free(H, wmb, hmb):
     nw, ring, ring_last, last_bufs = _plan(H, wmb, hmb)
     for seed in range(3):
@@ -93,8 +93,8 @@ def test_model_detects_the_single_buffer_deadlock():
     last wavefront's group of round 2 waits for wavefront 0 to finish reading round 1's buffer, wavefront 0's group cannot
     finish because the groups below it are held back by that very group -- the model must report it."""
     with pytest.raises(AssertionError, match="deadlock"):
-        _simulate(12, 16, 240, 1, 240, 135, random.Random(0))
-    _simulate(12, 16, 240, 2, 240, 135, random.Random(0))
+        _simulate(6, 16, 240, 1, 240, 135, random.Random(0))
+    _simulate(6, 16, 240, 2, 240, 135, random.Random(0))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
