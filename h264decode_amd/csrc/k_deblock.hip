@@ -16,12 +16,13 @@
 // 16-byte stores (one byte permute each), the column-pair lane reads ten with one dword load each (an AND and a byte permute split a
 // block into two packed column pairs).  Chroma dwords are {Cb(r,2k), Cb(r,2k+1), Cr(r,2k), Cr(r,2k+1)}.
 // A step:
+//   0. MB x-2 leaves for HBM straight from the window, 16 bytes per row: its rows -4..11 (rows 12..15 of the macroblock above, out of the
+//      sub-row above's window, and its own rows 0..11); then the loads for the steps to come are issued;
 //   1. vertical edges of MB x: 16 fresh columns from the prefetch registers (whole 64-byte lines, four macroblocks at a time, one step
 //      ahead; the slot is a wave-uniform register index), columns 12..15 of MB x-1 from the window; results into the window;
-//   2. MB x-1 is final now but for what the row below will do to its rows 13..15: its rows -4..11 (rows 12..15 of the macroblock above,
-//      out of the sub-row above's window, and its own rows 0..11) leave for HBM straight from the window, 16 bytes per row; the
-//      group's last sub-row copies rows 12..15 of MB x-1 into the LDS ring of the group below and publishes the column
-//      (workgroup-scope release / acquire on two counters, as before), the first sub-row takes column x of the group above;
+//   2. MB x-1 is final now but for what the row below will do to its rows 13..15: the group's last sub-row copies its rows 12..15 into
+//      the LDS ring of the group below and publishes the column (workgroup-scope release / acquire on two counters, as before), the
+//      first sub-row takes column x of the group above;
 //   3. horizontal edges of MB x on the window (rows -4..-1 = rows 12..15 of the sub-row above's window: no copy).
 // Strengths and alpha / beta / tC0 come ready-made from k_dbprep (DbPrm), fetched one step ahead into registers; a lane derives its packed
 // parameters with a handful of byte permutes (a permute IS the table lookup: bS selects its tC0 byte).
@@ -66,6 +67,13 @@ typedef __attribute__((address_space(1))) v2u g_uint2;
 #define GLD8(base, off) (*reinterpret_cast<const g_uint2 *>((base) + (off)))
 #define GST16(base, off, v) (*reinterpret_cast<g_uint4 *>((base) + (off)) = (v))
 #define GST8(base, off, v) (*reinterpret_cast<g_uint2 *>((base) + (off)) = (v))
+// Prefetch loads are issued through inline assembly and waited for by ONE explicit s_waitcnt at the end of a step: gfx9 counts loads and
+// stores in one in-order counter, and the compiler, which cannot see across the loop's back edge which registers a load may still be
+// writing, guards their every use -- a guard behind freshly issued memory operations puts their whole round trip (18 k clocks
+// measured) into the step.  In-out operands: lanes the load is predicated off for keep the register's value, and the value only
+// ever flows on through the wait's operands, so no compiler-made copy can read a register before its load has landed.
+#define ALD16(dst, base, off) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(static_cast<uint32_t>(off)), "s"(base))
+#define ALD8(dst, base, off) asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(dst) : "v"(static_cast<uint32_t>(off)), "s"(base))
 typedef __attribute__((address_space(3))) uint8_t l8;
 typedef __attribute__((address_space(3))) v4u l_uint4;
 typedef __attribute__((address_space(3))) v2u l_uint2;
@@ -151,22 +159,30 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             const uint32_t ya = yin + gb * 16, yb = ya + W, ccb = cb_off + cin + gb * 8, ccr = cr_off + cin + gb * 8;
             const int left = wmb - gb;
             const int j0 = (0 - s) & 3, j1 = (1 - s) & 3, j2 = (2 - s) & 3, j3 = (3 - s) & 3; // position inside the group of slot sl
-            if (j0 < left) PA0 = GLD16(py, ya + j0 * 16), PB0 = GLD16(py, yb + j0 * 16), QB0 = GLD8(py, ccb + j0 * 8), QR0 = GLD8(py, ccr + j0 * 8);
-            if (j1 < left) PA1 = GLD16(py, ya + j1 * 16), PB1 = GLD16(py, yb + j1 * 16), QB1 = GLD8(py, ccb + j1 * 8), QR1 = GLD8(py, ccr + j1 * 8);
-            if (j2 < left) PA2 = GLD16(py, ya + j2 * 16), PB2 = GLD16(py, yb + j2 * 16), QB2 = GLD8(py, ccb + j2 * 8), QR2 = GLD8(py, ccr + j2 * 8);
-            if (j3 < left) PA3 = GLD16(py, ya + j3 * 16), PB3 = GLD16(py, yb + j3 * 16), QB3 = GLD8(py, ccb + j3 * 8), QR3 = GLD8(py, ccr + j3 * 8);
+            if (j0 < left) { ALD16(PA0, py, ya + j0 * 16); ALD16(PB0, py, yb + j0 * 16); ALD8(QB0, py, ccb + j0 * 8); ALD8(QR0, py, ccr + j0 * 8); }
+            if (j1 < left) { ALD16(PA1, py, ya + j1 * 16); ALD16(PB1, py, yb + j1 * 16); ALD8(QB1, py, ccb + j1 * 8); ALD8(QR1, py, ccr + j1 * 8); }
+            if (j2 < left) { ALD16(PA2, py, ya + j2 * 16); ALD16(PB2, py, yb + j2 * 16); ALD8(QB2, py, ccb + j2 * 8); ALD8(QR2, py, ccr + j2 * 8); }
+            if (j3 < left) { ALD16(PA3, py, ya + j3 * 16); ALD16(PB3, py, yb + j3 * 16); ALD8(QB3, py, ccb + j3 * 8); ALD8(QR3, py, ccr + j3 * 8); }
         };
         // the macroblock's DbPrm, one step ahead: this lane's strengths (one dword per direction) and the three planes' parameter blocks
         v2u pre_bs = z2;
         v4u pre_p0 = z4, pre_p1 = z4, pre_p2 = z4;
-        auto prefetch_prm = [&](int mbx) {
-            if (!row_ok || mbx < 0 || mbx >= wmb) return;
-            const uint32_t o = static_cast<uint32_t>(mby * wmb + mbx) * static_cast<uint32_t>(sizeof(DbPrm));
-            pre_bs = GLD8(prms, o + (j >> 1) * 8);
-            pre_p0 = GLD16(prms, o + 32), pre_p1 = GLD16(prms, o + 48), pre_p2 = GLD16(prms, o + 64);
+        auto prefetch_prm = [&](int mbx) { // unconditional (a clamped address where there is no such macroblock): a predicated load would make the compiler merge old and new registers with copies
+            const uint32_t o = (rowmb * static_cast<uint32_t>(wmb) + static_cast<uint32_t>(min(max(mbx, 0), wmb - 1))) * static_cast<uint32_t>(sizeof(DbPrm));
+            ALD8(pre_bs, prms, o + (j >> 1) * 8);
+            ALD16(pre_p0, prms, o + 32);
+            ALD16(pre_p1, prms, o + 48);
+            ALD16(pre_p2, prms, o + 64);
+        };
+        // every prefetch load issued so far has landed
+        auto loads_landed = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(PA0), "+v"(PA1), "+v"(PA2), "+v"(PA3), "+v"(PB0), "+v"(PB1), "+v"(PB2), "+v"(PB3));
+            asm volatile("" : "+v"(QB0), "+v"(QB1), "+v"(QB2), "+v"(QB3), "+v"(QR0), "+v"(QR1), "+v"(QR2), "+v"(QR3));
+            asm volatile("" : "+v"(pre_bs), "+v"(pre_p0), "+v"(pre_p1), "+v"(pre_p2));
         };
         prefetch_group(0);
         prefetch_prm(-s); // step 0 (only sub-row 0 is active)
+        loads_landed();
         // the ring this group writes was last used by the group `reuse` groups earlier: that group's reader must be through with it
         // every wait on another wavefront gives up after 4 s of s_memrealtime and says so through the status word (H264MI_EDECODE) instead of hanging the GPU
         auto wait_for = [&](int *ctr, int want) {
@@ -182,7 +198,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
         };
         const int reuse = out_last ? nwaves * last_bufs : nwaves;
         if (g >= reuse && feeds_group) wait_for(&sh.cons[g - reuse + 1], wmb);
-        const int nsteps = wmb + 8; // sub-row s: columns in steps s .. s + wmb - 1, the last column's output one step later
+        const int nsteps = wmb + 9; // sub-row s: columns in steps s .. s + wmb - 1, the last column's output two steps later
 #if defined(MI_DB_STATS)
         uint32_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
@@ -198,7 +214,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             const bool active = row_ok && mbx >= 0 && mbx < wmb;
             // LDS addresses: this sub-row's window (index s + 1 of the wavefront's nine), the window above, the slots of columns x and x - 1
             const uint32_t tile = MI_DEBLOCK8_HDR_BYTES + static_cast<uint32_t>(wave) * MI_DEBLOCK8_WAVE_BYTES + static_cast<uint32_t>(s + 1) * T_BYTES;
-            const uint32_t sx = static_cast<uint32_t>(mbx) & 3u, spv = static_cast<uint32_t>(mbx - 1) & 3u;
+            const uint32_t sx = static_cast<uint32_t>(mbx) & 3u, spv = static_cast<uint32_t>(mbx - 1) & 3u, sp2 = static_cast<uint32_t>(mbx - 2) & 3u;
             const uint32_t own_l = tile + sx * 256, prev_l = tile + spv * 256, own_c = tile + T_CHROMA + sx * 128, prev_c = tile + T_CHROMA + spv * 128;
             // this step's input registers (wave-uniform slot) and parameters
             // (the unpacking into one register per sample position is written out once per slot behind a wave-uniform switch: selecting the slot's
@@ -226,9 +242,49 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             }
             const v2u bs = pre_bs;
             const v4u p0 = pre_p0, p1 = pre_p1, p2 = pre_p2;
+            __builtin_amdgcn_sched_barrier(0); // (everything that reads registers written by vector memory loads stays above this line)
+            STAMP(0);
+            // ---- 0. the step's vector memory operations in one burst: loads for the steps to come, then the stores of column x - 2; the one wait for
+            // them is at the end of the step (loads_landed)
             if (active && (mbx & 3) == 3) prefetch_group(mbx + 1); // the input registers of this sub-row are free again
             prefetch_prm(mbx + 1);
             STAMP(7);
+            // column x - 2 leaves for HBM: rows -4..11 (lane j: row pair j - 2; pairs -2, -1 are rows 12..15 of the window above), chroma rows -1..6.
+            // (final since the vertical pass of the previous step)
+            if (row_ok && mbx >= 2 && mbx <= wmb + 1) {
+                const uint32_t above = tile - T_BYTES;
+                if (fl_ok) {
+                    const uint32_t src = (j < 2 ? above + 192 + j * 32 : tile + (j - 2) * 32) + sp2 * 256;
+                    const v4u w0 = LLD16(src), w1 = LLD16(src + 16);
+                    const v4u ra = v4u{PERM(w0.y, w0.x, 0x06040200u), PERM(w0.w, w0.z, 0x06040200u), PERM(w1.y, w1.x, 0x06040200u), PERM(w1.w, w1.z, 0x06040200u)};
+                    const v4u rb = v4u{PERM(w0.y, w0.x, 0x07050301u), PERM(w0.w, w0.z, 0x07050301u), PERM(w1.y, w1.x, 0x07050301u), PERM(w1.w, w1.z, 0x07050301u)};
+                    const uint32_t o = yout + (mbx - 2) * 16;
+                    GST16(py, o, ra), GST16(py, o + W, rb);
+                }
+                if (fc_ok) {
+                    const uint32_t src = (j < 1 ? above + T_CHROMA + 112 : tile + T_CHROMA + (j - 1) * 16) + sp2 * 128;
+                    const v4u w = LLD16(src);
+                    const uint32_t o = cout + (mbx - 2) * 8;
+                    GST8(py, cb_off + o, (v2u{PERM(w.y, w.x, 0x05040100u), PERM(w.w, w.z, 0x05040100u)}));
+                    GST8(py, cr_off + o, (v2u{PERM(w.y, w.x, 0x07060302u), PERM(w.w, w.z, 0x07060302u)}));
+                }
+                if (last_row) { // nothing below will touch rows 12..15 (chroma row 7): they leave with the rest
+                    if (j < 2) {
+                        const uint32_t src = tile + 192 + j * 32 + sp2 * 256;
+                        const v4u w0 = LLD16(src), w1 = LLD16(src + 16);
+                        const v4u ra = v4u{PERM(w0.y, w0.x, 0x06040200u), PERM(w0.w, w0.z, 0x06040200u), PERM(w1.y, w1.x, 0x06040200u), PERM(w1.w, w1.z, 0x06040200u)};
+                        const v4u rb = v4u{PERM(w0.y, w0.x, 0x07050301u), PERM(w0.w, w0.z, 0x07050301u), PERM(w1.y, w1.x, 0x07050301u), PERM(w1.w, w1.z, 0x07050301u)};
+                        const uint32_t o = y_off + (static_cast<uint32_t>(mby) * 16 + 12 + 2 * j) * W + (mbx - 2) * 16;
+                        GST16(py, o, ra), GST16(py, o + W, rb);
+                    } else if (j == 2) {
+                        const v4u w = LLD16(tile + T_CHROMA + 112 + sp2 * 128);
+                        const uint32_t o = (static_cast<uint32_t>(mby) * 8 + 7) * Wc + (mbx - 2) * 8;
+                        GST8(py, cb_off + o, (v2u{PERM(w.y, w.x, 0x05040100u), PERM(w.w, w.z, 0x05040100u)}));
+                        GST8(py, cr_off + o, (v2u{PERM(w.y, w.x, 0x07060302u), PERM(w.w, w.z, 0x07060302u)}));
+                    }
+                }
+            }
+            STAMP(4);
             // ---- 1. vertical edges: lane j = luma rows 2j, 2j + 1, then chroma row j of Cb | Cr ----
             if (active) {
                 // a plane's block: aL bL aI bI | aT bT tL1 tL2 | tL3 tI1 tI2 tI3 | tT1 tT2 tT3 pad  (a / b: alpha / beta of the left-edge, inner, top-edge QP average; tKb: tC0 for bS b).
@@ -279,7 +335,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             }
             WAVE_SYNC();
             STAMP(1);
-            // ---- 2. output of column x - 1, hand-off ----
+            // ---- 2. hand-off ----
             // 2a. the group's last row: rows 12..15 of column xl - 1 are final but for the row below -- into the ring of the group below
             //     (six 16-byte pieces in window format), then the column is published.  Back-pressure first: the slot held column
             //     xl - 1 - depth, which the group below must have consumed.
@@ -294,40 +350,6 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
                     }
                     WAVE_SYNC();
                     if (lane == 0) __hip_atomic_store(&sh.prog[g], xl, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-            // 2b. column x - 1 leaves for HBM: rows -4..11 (lane j: row pair j - 2; pairs -2, -1 are rows 12..15 of the window above), chroma rows -1..6
-            if (row_ok && mbx >= 1 && mbx <= wmb) {
-                const uint32_t above = tile - T_BYTES;
-                if (fl_ok) {
-                    const uint32_t src = (j < 2 ? above + 192 + j * 32 : tile + (j - 2) * 32) + spv * 256;
-                    const v4u w0 = LLD16(src), w1 = LLD16(src + 16);
-                    const v4u ra = v4u{PERM(w0.y, w0.x, 0x06040200u), PERM(w0.w, w0.z, 0x06040200u), PERM(w1.y, w1.x, 0x06040200u), PERM(w1.w, w1.z, 0x06040200u)};
-                    const v4u rb = v4u{PERM(w0.y, w0.x, 0x07050301u), PERM(w0.w, w0.z, 0x07050301u), PERM(w1.y, w1.x, 0x07050301u), PERM(w1.w, w1.z, 0x07050301u)};
-                    const uint32_t o = yout + (mbx - 1) * 16;
-                    GST16(py, o, ra), GST16(py, o + W, rb);
-                }
-                if (fc_ok) {
-                    const uint32_t src = (j < 1 ? above + T_CHROMA + 112 : tile + T_CHROMA + (j - 1) * 16) + spv * 128;
-                    const v4u w = LLD16(src);
-                    const uint32_t o = cout + (mbx - 1) * 8;
-                    GST8(py, cb_off + o, (v2u{PERM(w.y, w.x, 0x05040100u), PERM(w.w, w.z, 0x05040100u)}));
-                    GST8(py, cr_off + o, (v2u{PERM(w.y, w.x, 0x07060302u), PERM(w.w, w.z, 0x07060302u)}));
-                }
-                if (last_row) { // nothing below will touch rows 12..15 (chroma row 7): they leave with the rest
-                    if (j < 2) {
-                        const uint32_t src = tile + 192 + j * 32 + spv * 256;
-                        const v4u w0 = LLD16(src), w1 = LLD16(src + 16);
-                        const v4u ra = v4u{PERM(w0.y, w0.x, 0x06040200u), PERM(w0.w, w0.z, 0x06040200u), PERM(w1.y, w1.x, 0x06040200u), PERM(w1.w, w1.z, 0x06040200u)};
-                        const v4u rb = v4u{PERM(w0.y, w0.x, 0x07050301u), PERM(w0.w, w0.z, 0x07050301u), PERM(w1.y, w1.x, 0x07050301u), PERM(w1.w, w1.z, 0x07050301u)};
-                        const uint32_t o = y_off + (static_cast<uint32_t>(mby) * 16 + 12 + 2 * j) * W + (mbx - 1) * 16;
-                        GST16(py, o, ra), GST16(py, o + W, rb);
-                    } else if (j == 2) {
-                        const v4u w = LLD16(tile + T_CHROMA + 112 + spv * 128);
-                        const uint32_t o = (static_cast<uint32_t>(mby) * 8 + 7) * Wc + (mbx - 1) * 8;
-                        GST8(py, cb_off + o, (v2u{PERM(w.y, w.x, 0x05040100u), PERM(w.w, w.z, 0x05040100u)}));
-                        GST8(py, cr_off + o, (v2u{PERM(w.y, w.x, 0x07060302u), PERM(w.w, w.z, 0x07060302u)}));
-                    }
                 }
             }
             // 2c. the group's first row takes rows 12..15 of column t of the group above out of its ring, once that says the column is final
@@ -403,6 +425,8 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             }
             WAVE_SYNC();
             STAMP(3);
+            loads_landed(); // (issued at the top of this step: a step old)
+            STAMP(6);
         }
 #if defined(MI_DB_STATS)
         if (g == 0 && lane_v == 0)

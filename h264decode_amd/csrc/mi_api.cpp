@@ -1982,17 +1982,19 @@ static int execute_stage(h264mi_decoder *d, int stage_idx, bool exclusive) {
     if (!g.n_slices && g.grey.empty()) return H264MI_OK;
     GUARD(d);
     // frames that went out with one field decoded (flush_pending_field): the rows of the field that never came are painted mid-grey
-    auto grey_fills = [&](hipStream_t st) {
+    auto grey_fills = [&](hipStream_t st) -> hipError_t { // the first error, if any: a frame that was not painted must not go out as if it were
         for (const Stage::GreyFill &f : g.grey) {
             uint8_t *base = d->d_frames + (static_cast<size_t>(f.stream) * d->n_slots + f.slot) * d->slot_bytes;
             const size_t W = f.w, H = f.h, plane = W * H;
-            hipMemset2DAsync(base + f.parity * W, 2 * W, 128, W, H / 2, st);
-            hipMemset2DAsync(base + plane + f.parity * (W / 2), W, 128, W / 2, H / 4, st);
-            hipMemset2DAsync(base + plane + plane / 4 + f.parity * (W / 2), W, 128, W / 2, H / 4, st);
+            hipError_t e = hipMemset2DAsync(base + f.parity * W, 2 * W, 128, W, H / 2, st);
+            if (e == hipSuccess) e = hipMemset2DAsync(base + plane + f.parity * (W / 2), W, 128, W / 2, H / 4, st);
+            if (e == hipSuccess) e = hipMemset2DAsync(base + plane + plane / 4 + f.parity * (W / 2), W, 128, W / 2, H / 4, st);
+            if (e != hipSuccess) return e;
         }
+        return hipSuccess;
     };
     if (!g.n_slices) { // nothing to decode: a chunk that only ended a sequence and thereby sent a lone first field out
-        grey_fills(d->stream);
+        HIP_TRY(grey_fills(d->stream));
         HIP_TRY(hipEventRecord(g.ev_done, d->stream));
         g.executed = true, g.harvested = true;
         return H264MI_OK;
@@ -2080,7 +2082,7 @@ static int execute_stage(h264mi_decoder *d, int stage_idx, bool exclusive) {
         }
         return d->x_epoch;
     };
-    grey_fills(rs);
+    HIP_TRY(grey_fills(rs));
     for (size_t w = 0; w < g.waves.size(); w++) {
         const uint32_t n = static_cast<uint32_t>(g.waves[w].size()), ni = g.wave_p_n[w], nbp = g.wave_b_n[w];
         if (!n) continue;
@@ -2139,23 +2141,22 @@ static int execute_stage(h264mi_decoder *d, int stage_idx, bool exclusive) {
 }
 
 // A pass whose slices ran out of residual blocks (entropy status 40: the pool holds 8 blocks per macroblock by default, the worst case is 26) is
-// repeated once, alone, with the pools of all record sets as one -- three times the room -- before anything is held against its streams; the
-// batches executed after it (they predicted from its damaged pictures) follow in order.  Called by h264mi_batch_sync with every stream drained.
+// repeated once, alone, with the pools of all record sets as one -- three times the room -- before anything is held against its streams.
+// Only the batch executed LAST is repeated: a batch executed after the exhausted one has already written its pictures into frame slots the
+// exhausted batch's first pictures predict from (slots that became free while it ran), so repeating the older batch would predict from the
+// younger one's samples and report success; in that case the exhaustion is held against the streams as any other entropy failure
+// (a caller that pipelines execute(n), prepare(n + 1), execute(n + 1), sync sizes its pool -- h264mi_config.coef_blocks_per_mb -- or
+// synchronises per batch).  Called by h264mi_batch_sync with every stream drained.
 static int retry_exhausted(h264mi_decoder *d) {
-    bool redo = false;
-    for (int k = 1; k <= MI_STAGES; k++) { // oldest executed batch first
-        const int si = (d->exec + k) % MI_STAGES;
-        Stage &g = d->stage[si];
-        if (!g.executed || g.harvested) continue;
-        bool exhausted = false;
-        for (int i = 0; i < g.n_slices && !exhausted; i++) exhausted = g.h_status[8 * i] == 40;
-        if (!redo && !(exhausted && !g.retried)) continue;
-        redo = true; // this batch, and every later one
-        g.retried = true;
-        int r = execute_stage(d, si, true);
-        if (r != H264MI_OK) return r;
-        HIP_TRY(hipStreamSynchronize(d->stream));
-    }
+    Stage &g = d->stage[d->exec]; // the batch executed last
+    if (!g.executed || g.harvested || g.retried) return H264MI_OK;
+    bool exhausted = false;
+    for (int i = 0; i < g.n_slices && !exhausted; i++) exhausted = g.h_status[8 * i] == 40;
+    if (!exhausted) return H264MI_OK;
+    g.retried = true;
+    const int r = execute_stage(d, d->exec, true);
+    if (r != H264MI_OK) return r;
+    HIP_TRY(hipStreamSynchronize(d->stream));
     return H264MI_OK;
 }
 

@@ -176,7 +176,8 @@ typedef struct h264mi_decoder h264mi_decoder;
 typedef struct {
     /* sizeof(h264mi_config) as the CALLER was compiled: the struct grows at its end from version to version, and a field that lies beyond
      * struct_size is taken as 0 (its default) instead of being read from whatever follows a shorter struct.  0 is refused: zero-initialise
-     * the struct and set this field (H264MI_CONFIG_INIT). */
+     * the struct and set this field (H264MI_CONFIG_INIT).  Adding this field in front was a ONE-TIME ABI break (round 4): binaries built against
+     * the header without it do not work with this library; size-based compatibility starts with this version of the struct. */
     uint32_t struct_size;
     int32_t device;                /* HIP device ordinal */
     int32_t max_streams;           /* independent streams decoded side by side */

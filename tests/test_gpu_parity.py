@@ -333,6 +333,44 @@ def test_gpu_residual_pool_exhaustion_is_recovered(H, sg):
         tiny.close()
 
 
+def test_gpu_residual_pool_exhaustion_of_an_older_batch_is_reported_not_repeated(H, sg):
+    """execute(n); prepare(n + 1); execute(n + 1); ONE sync, batch n + 1 continuing the GOP with one reference frame, and batch n overrunning its
+    residual pool: batch n + 1 has by then written into the frame slots batch n's first P pictures predict from, so repeating batch n would
+    predict from the wrong samples and report success (advisor, round 4).  The library repeats only the batch executed LAST; here the
+    exhaustion must surface as a failure of the stream -- never as silently wrong pictures."""
+    kw = dict(width=1280, height=720, frames=8, idr_period=0, profile_idc=77, cabac=1, num_ref_frames=1, qp=18, noise=25, seed=73)
+    stream, rec, _ = sg.encode(**kw)
+    nals = H.read_nal_units(stream)
+    offs = [n.Offset - 4 for n in nals] + [len(stream)]
+    pic = [i for i, n in enumerate(nals) if n.Type in (1, 5)]
+    halves = [stream[:offs[pic[4]]], stream[offs[pic[4]]:]]
+    mbs, head = 80 * 45 * 4, 3 * 2048
+    roomy = H.Decoder(max_streams=1, max_width=1280, max_height=720, max_frames_per_batch=4, max_slices_per_frame=1)
+    roomy.decode([halves[0]])
+    used, _ = roomy.coef_pool()
+    roomy.decode([halves[1]])
+    assert np.array_equal(roomy.read_frames(0, crop=False), rec[4:])
+    roomy.close()
+    ks = [k for k in range(1, 27) if k * mbs + head < 0.8 * used and 3 * (k * mbs + head) > 1.25 * used]
+    assert ks, (used, mbs)
+    dec = H.Decoder(max_streams=1, max_width=1280, max_height=720, max_frames_per_batch=4, max_slices_per_frame=1, coef_blocks_per_mb=ks[0])
+    dec.set_isolation(True)
+    dec.prepare([halves[0]])
+    dec.execute()
+    dec.prepare([halves[1]])
+    dec.execute()
+    dec.sync()
+    assert dec.stream_status(0) == -8, dec.stream_status(0)  # the first batch's exhaustion is held against the stream
+    dec.close()
+    # the same calls with a sync per batch: the first batch is the last one executed when it is looked at, is repeated with the whole pool, and all is well
+    dec = H.Decoder(max_streams=1, max_width=1280, max_height=720, max_frames_per_batch=4, max_slices_per_frame=1, coef_blocks_per_mb=ks[0])
+    dec.decode([halves[0]])
+    assert dec.stream_status(0) == 0 and np.array_equal(dec.read_frames(0, crop=False), rec[:4])
+    dec.decode([halves[1]])
+    assert dec.stream_status(0) == 0 and np.array_equal(dec.read_frames(0, crop=False), rec[4:])
+    dec.close()
+
+
 def test_gpu_rejects_out_of_scope_profile(H):
     """A third-party High 4:4:4 Predictive stream (chroma_format_idc 3) must be refused with a clear status, not mis-decoded."""
     import os

@@ -22,10 +22,15 @@ assert np.array_equal(dec.read_frames(S - 1, crop=False), rec)
 f(dec._h, buf)
 dec.decode([s] * S)
 f(dec._h, buf)
-names = ["1c parameters (rest of 1)", "2 vertical edges", "3 hand-off", "4 horizontal edges", "5 results", "loop", "1a DbPrm -> LDS", "1b prefetch issue", "-", "-", "-", "-"]
-steps = S * F * 123.0
+if S > 1:  # k_deblock proper (round 5: groups of 8 rows, 129 steps)
+    names = ["0a inputs out of the prefetch registers", "1 vertical edges", "2 hand-off", "3 horizontal edges", "0b output of column x - 2", "loop", "-", "0c prefetch issue", "-", "-", "-", "-"]
+    nst = 129
+else:      # the banded kernel k_deblock_x
+    names = ["1c parameters (rest of 1)", "2 vertical edges", "3 hand-off", "4 horizontal edges", "5 results", "loop", "1a DbPrm -> LDS", "1b prefetch issue", "-", "-", "-", "-"]
+    nst = 123
+steps = S * F * float(nst)
 tot = sum(buf)
-print("clocks per step of the wavefront of group 0 (1080p, %d streams x %d pictures, %d steps each):" % (S, F, 123))
+print("clocks per step of the wavefront of group 0 (1080p, %d streams x %d pictures, %d steps each):" % (S, F, nst))
 for n, v in zip(names, buf):
     print("  %-20s %8.0f  %5.1f %%" % (n, v / steps, 100.0 * v / tot))
 print("  %-20s %8.0f" % ("total", tot / steps))

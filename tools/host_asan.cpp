@@ -62,7 +62,7 @@ static void client(int iters, unsigned seed) {
         const int ns = 1 + rng() % 4;
         h264mi_config cfg;
         memset(&cfg, 0, sizeof cfg);
-        cfg.struct_size = rng() % 8 == 0 ? offsetof(h264mi_config, max_ref_frames) : sizeof cfg; // (now and then a caller built against the first header)
+        cfg.struct_size = rng() % 8 == 0 ? offsetof(h264mi_config, b_pictures) : sizeof cfg; // (now and then a caller built against this header before `b_pictures` was added)
         if (rng() % 5 == 0) cfg.b_pictures = 1;
         cfg.max_streams = ns;
         const bool tight = rng() % 3 == 0;  // a decoder sized too small for some of what it will be given
