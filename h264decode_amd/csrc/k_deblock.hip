@@ -54,7 +54,7 @@ static_assert(sizeof(Db8Shared) <= MI_DEBLOCK8_HDR_BYTES, "LDS layout constants"
 // the sub-row ABOVE its first one (taken from the ring), so that "the window above" is the same address arithmetic for every sub-row.
 #define T_CHROMA 1024
 #define T_BYTES MI_DEBLOCK8_TILE_BYTES
-static_assert(MI_DEBLOCK8_WAVE_BYTES == 9 * T_BYTES && T_BYTES >= 1536 && (T_BYTES / 4) % 32 == 8, "LDS layout constants");
+static_assert(MI_DEBLOCK8_WAVE_BYTES == 9 * T_BYTES + 2 * 8 * sizeof(DbPrm) && T_BYTES >= 1536 && (T_BYTES / 4) % 32 == 8, "LDS layout constants");
 // ring slot: rows 12..15 of one macroblock column in window format: row pairs 6, 7 (32 bytes each), chroma rows 6, 7 (16 bytes each)
 static_assert(MI_DEBLOCK_SLOT_BYTES == 96, "LDS layout constants");
 
@@ -67,13 +67,21 @@ typedef __attribute__((address_space(1))) v2u g_uint2;
 #define GLD8(base, off) (*reinterpret_cast<const g_uint2 *>((base) + (off)))
 #define GST16(base, off, v) (*reinterpret_cast<g_uint4 *>((base) + (off)) = (v))
 #define GST8(base, off, v) (*reinterpret_cast<g_uint2 *>((base) + (off)) = (v))
-// Prefetch loads are issued through inline assembly and waited for by ONE explicit s_waitcnt at the end of a step: gfx9 counts loads and
-// stores in one in-order counter, and the compiler, which cannot see across the loop's back edge which registers a load may still be
-// writing, guards their every use -- a guard behind freshly issued memory operations puts their whole round trip (18 k clocks
-// measured) into the step.  In-out operands: lanes the load is predicated off for keep the register's value, and the value only
-// ever flows on through the wait's operands, so no compiler-made copy can read a register before its load has landed.
-#define ALD16(dst, base, off) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(static_cast<uint32_t>(off)), "s"(base))
-#define ALD8(dst, base, off) asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(dst) : "v"(static_cast<uint32_t>(off)), "s"(base))
+// Loads are issued through inline assembly and waited for by ONE explicit s_waitcnt at the end of a step: gfx9 counts loads and stores in one
+// in-order counter, and the compiler, which cannot see across the loop's back edge which registers a load may still be writing, guards their
+// every use -- a guard behind freshly issued memory operations puts their whole round trip (18 k clocks measured) into the step.  The
+// predicate is applied INSIDE the statement (EXEC narrowed and restored around the load), so that the statement sits in straight-line code
+// with its destination as an in-out operand: the compiler then has no merge point at which to copy a register a load is still writing
+// (with the load under an `if`, it did -- and handed the landing registers to other values).
+#define ALD16M(dst, base, off, cond)                                                                                                               \
+    do {                                                                                                                                           \
+        unsigned long long sv_;                                                                                                                    \
+        asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\ts_cbranch_execz 1f\n\tglobal_load_dwordx4 %[d], %[o], %[b]\n1:\n\ts_mov_b64 exec, %[sv]"       \
+                     : [d] "+v"(dst), [sv] "=&s"(sv_)                                                                                              \
+                     : [o] "v"(static_cast<uint32_t>(off)), [b] "s"(base), [m] "s"(__builtin_amdgcn_ballot_w64(cond))                              \
+                     : "scc");                                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0); /* (keeps each predicate's computation next to its statement: scalar register pressure) */              \
+    } while (0)
 typedef __attribute__((address_space(3))) uint8_t l8;
 typedef __attribute__((address_space(3))) v4u l_uint4;
 typedef __attribute__((address_space(3))) v2u l_uint2;
@@ -125,13 +133,9 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
     const int ngroups = (hmb + 7) >> 3;
     const uint32_t rings_off = MI_DEBLOCK8_HDR_BYTES + static_cast<uint32_t>(nwaves) * MI_DEBLOCK8_WAVE_BYTES; // region r (written by the groups of wavefront r) starts at r * ring slots
     const v4u z4 = v4u{0u, 0u, 0u, 0u};
-    const v2u z2 = v2u{0u, 0u};
     for (int g = wave; g < ngroups; g += nwaves) {
         int lane = lane_v;
         OPAQUE(lane);
-        const int s = lane >> 3, j = lane & 7; // sub-row inside the group, lane inside the macroblock
-        const int mby = g * 8 + s;
-        const bool row_ok = mby < hmb, has_top = mby > 0;
         const int last_sub = min(7, hmb - 1 - g * 8); // last valid sub-row of this group
         const bool feeds_group = g + 1 < ngroups;     // this group's last row hands its bottom rows to group g + 1
         // hand-off rings: the one this group writes (region `wave`) and the one it reads (written by group g - 1)
@@ -143,46 +147,44 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
         const bool in_last = in_wave == nwaves - 1;
         const int in_depth = in_last ? ring_last : ring;
         const uint32_t in_ring = rings_off + static_cast<uint32_t>(in_wave * ring + (in_last && g > 0 ? (((g - 1) / nwaves) % last_bufs) * ring_last : 0)) * MI_DEBLOCK_SLOT_BYTES;
-        // where this lane's samples are in HBM: rows 2j, 2j + 1 of the sub-row's macroblocks (input), row pair j - 2 (output: rows -4..11)
-        const uint32_t rowmb = static_cast<uint32_t>(row_ok ? mby : 0);
-        const uint32_t yin = y_off + (rowmb * 16 + 2 * j) * W;                                         // + W: the second row
-        const uint32_t cin = (rowmb * 8 + j) * Wc;                                                     // + cb_off / cr_off
-        const bool fl_ok = row_ok && (j >= 2 || has_top), fc_ok = row_ok && (j >= 1 || has_top);      // lanes whose output rows exist
-        const uint32_t yout = y_off + (rowmb * 16 + 2 * j - (fl_ok ? 4 : 0)) * W;
-        const uint32_t cout = (rowmb * 8 + j - (fc_ok ? 1 : 0)) * Wc;
-        // Input registers.  Slot sl of P* / Q* holds macroblock column c with (c + s) % 4 == sl, so that at step t every
-        // sub-row consumes slot t % 4 (a wave-uniform register index) although the sub-rows are one column apart.
-        v4u PA0 = z4, PA1 = z4, PA2 = z4, PA3 = z4, PB0 = z4, PB1 = z4, PB2 = z4, PB3 = z4; // luma rows 2j, 2j + 1: 4 slots x 16 bytes
-        v2u QB0 = z2, QB1 = z2, QB2 = z2, QB3 = z2, QR0 = z2, QR1 = z2, QR2 = z2, QR3 = z2; // chroma row j of Cb, of Cr: 4 slots x 8 bytes
-        auto prefetch_group = [&](int gb) { // gb = first macroblock of an aligned group of four
-            if (!row_ok || gb >= wmb) return;
-            const uint32_t ya = yin + gb * 16, yb = ya + W, ccb = cb_off + cin + gb * 8, ccr = cr_off + cin + gb * 8;
-            const int left = wmb - gb;
-            const int j0 = (0 - s) & 3, j1 = (1 - s) & 3, j2 = (2 - s) & 3, j3 = (3 - s) & 3; // position inside the group of slot sl
-            if (j0 < left) { ALD16(PA0, py, ya + j0 * 16); ALD16(PB0, py, yb + j0 * 16); ALD8(QB0, py, ccb + j0 * 8); ALD8(QR0, py, ccr + j0 * 8); }
-            if (j1 < left) { ALD16(PA1, py, ya + j1 * 16); ALD16(PB1, py, yb + j1 * 16); ALD8(QB1, py, ccb + j1 * 8); ALD8(QR1, py, ccr + j1 * 8); }
-            if (j2 < left) { ALD16(PA2, py, ya + j2 * 16); ALD16(PB2, py, yb + j2 * 16); ALD8(QB2, py, ccb + j2 * 8); ALD8(QR2, py, ccr + j2 * 8); }
-            if (j3 < left) { ALD16(PA3, py, ya + j3 * 16); ALD16(PB3, py, yb + j3 * 16); ALD8(QB3, py, ccb + j3 * 8); ALD8(QR3, py, ccr + j3 * 8); }
-        };
-        // the macroblock's DbPrm, one step ahead: this lane's strengths (one dword per direction) and the three planes' parameter blocks
-        v2u pre_bs = z2;
-        v4u pre_p0 = z4, pre_p1 = z4, pre_p2 = z4;
-        auto prefetch_prm = [&](int mbx) { // unconditional (a clamped address where there is no such macroblock): a predicated load would make the compiler merge old and new registers with copies
-            const uint32_t o = (rowmb * static_cast<uint32_t>(wmb) + static_cast<uint32_t>(min(max(mbx, 0), wmb - 1))) * static_cast<uint32_t>(sizeof(DbPrm));
-            ALD8(pre_bs, prms, o + (j >> 1) * 8);
-            ALD16(pre_p0, prms, o + 32);
-            ALD16(pre_p1, prms, o + 48);
-            ALD16(pre_p2, prms, o + 64);
-        };
-        // every prefetch load issued so far has landed
+        // ---- memory traffic is COOPERATIVE: a vector memory instruction costs what its lanes touch in distinct cache lines (the CU's L1 looks up one line
+        // per clock: with a lane per row, 64 lines per instruction, 9 wavefronts spent 11 k of a step's 18 k clocks issuing them), so whole
+        // wavefronts move blocks of one sub-row between HBM and its LDS window, four (loads) or two (stores) adjacent lanes per row:
+        //   luma load    G[k], sub-row k, four macroblock columns at once: lane = (row L >> 2, column L & 3), 16 bytes; landed pieces enter the
+        //                window one column per step (the slot of column x + 1 is free from the end of step x on), raw rows -- rows 2j, 2j + 1 are the
+        //                32 bytes of row pair j, so the vertical pass converts its own 32 bytes in place;
+        //   chroma load  GC[k], sub-rows k and k + 4 (they reload in the same step): lane = (sub-row L >> 5, plane / row (L & 31) >> 1, column pair L & 1);
+        //   stores       column pairs {x - 3, x - 2} of the sub-rows whose x is odd: luma lane = (sub-row, row (L & 31) >> 1, column L & 1),
+        //                chroma lane = (sub-row, plane, row), 16 bytes = both columns; a sub-row stores ITS OWN rows 0..15 (what the row below did to
+        //                rows 13..15 happened in this window), the first sub-row also rows 12..15 of the group above out of window 0, the last
+        //                sub-row of a feeding group not its rows 12..15 (they went down the ring);
+        //   DbPrm        40 lanes x 16 bytes = the records of the eight macroblocks of the next step, through a double-buffered LDS stage.
+        const uint32_t tile0 = MI_DEBLOCK8_HDR_BYTES + static_cast<uint32_t>(wave) * MI_DEBLOCK8_WAVE_BYTES; // window k + 1 = sub-row k
+        const uint32_t stage0 = tile0 + 9 * T_BYTES;                                                           // 2 x 8 x sizeof(DbPrm)
+        const int rows_here = min(8, hmb - g * 8);                                                              // valid sub-rows of this group
+        // luma load lane
+        const int ll_row = lane >> 2, ll_col = lane & 3;
+        const uint32_t ll_src = y_off + static_cast<uint32_t>(g * 128 + ll_row) * W + ll_col * 16; // + k * 16 W + column base * 16
+        const uint32_t ll_dst = tile0 + T_BYTES + ll_col * 256 + ll_row * 16;                      // + k * T_BYTES  (slot = column & 3 = ll_col)
+        // chroma load lane
+        const int lc_half = lane >> 5, lc_rr = (lane & 31) >> 1, lc_q = lane & 1;
+        const uint32_t lc_src = (lc_rr >> 3 ? cr_off : cb_off) + static_cast<uint32_t>(g * 64 + lc_half * 32 + (lc_rr & 7)) * Wc + lc_q * 16; // + k * 8 Wc + column base * 8
+        const uint32_t lc_dst = tile0 + T_BYTES + lc_half * 4 * T_BYTES + T_CHROMA + (lc_rr & 7) * 16 + (lc_rr >> 3) * 8;                     // + k * T_BYTES + slot * 128
+        // luma store lane (instruction i: sub-rows par + 4 i and par + 4 i + 2)
+        const int sl_half = lane >> 5, sl_row = (lane & 31) >> 1, sl_col = lane & 1;
+        const uint32_t sl_sel = (sl_row & 1) ? 0x07050301u : 0x06040200u; // this row of a row pair's 2x2 blocks
+        // chroma store lane (sub-rows par, par + 2, par + 4, par + 6)
+        const int sc_q = lane >> 4, sc_plane = (lane >> 3) & 1, sc_row = lane & 7;
+        const uint32_t sc_sel = sc_plane ? 0x07060302u : 0x05040100u;
+        // DbPrm lane
+        const int lp_sub = lane < 40 ? lane / 5 : 7, lp_piece = lane < 40 ? lane % 5 : 0;
+        const uint32_t lp_row = static_cast<uint32_t>(min(g * 8 + lp_sub, hmb - 1)) * static_cast<uint32_t>(wmb);
+        v4u G0 = z4, G1 = z4, G2 = z4, G3 = z4, G4 = z4, G5 = z4, G6 = z4, G7 = z4, GC0 = z4, GC1 = z4, GC2 = z4, GC3 = z4, GP = z4;
+        // every load issued so far has landed (the one wait on vector memory of a step, at its end: what it waits for was issued at the step's top)
         auto loads_landed = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(PA0), "+v"(PA1), "+v"(PA2), "+v"(PA3), "+v"(PB0), "+v"(PB1), "+v"(PB2), "+v"(PB3));
-            asm volatile("" : "+v"(QB0), "+v"(QB1), "+v"(QB2), "+v"(QB3), "+v"(QR0), "+v"(QR1), "+v"(QR2), "+v"(QR3));
-            asm volatile("" : "+v"(pre_bs), "+v"(pre_p0), "+v"(pre_p1), "+v"(pre_p2));
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(G0), "+v"(G1), "+v"(G2), "+v"(G3), "+v"(G4), "+v"(G5), "+v"(G6), "+v"(G7));
+            asm volatile("" : "+v"(GC0), "+v"(GC1), "+v"(GC2), "+v"(GC3), "+v"(GP));
         };
-        prefetch_group(0);
-        prefetch_prm(-s); // step 0 (only sub-row 0 is active)
-        loads_landed();
         // the ring this group writes was last used by the group `reuse` groups earlier: that group's reader must be through with it
         // every wait on another wavefront gives up after 4 s of s_memrealtime and says so through the status word (H264MI_EDECODE) instead of hanging the GPU
         auto wait_for = [&](int *ctr, int want) {
@@ -198,89 +200,90 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
         };
         const int reuse = out_last ? nwaves * last_bufs : nwaves;
         if (g >= reuse && feeds_group) wait_for(&sh.cons[g - reuse + 1], wmb);
-        const int nsteps = wmb + 9; // sub-row s: columns in steps s .. s + wmb - 1, the last column's output two steps later
+        const int t_last = wmb + 9; // sub-row s: loads from step s - 1 on, columns in steps s .. s + wmb - 1, the last column pair's output up to three steps later
 #if defined(MI_DB_STATS)
         uint32_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
-        for (int t = 0; t < nsteps; t++) {
+        for (int t = -1; t <= t_last; t++) {
             STAMP(5); // loop control + whatever the compiler moved across the step boundary
             int lane = lane_v;
             OPAQUE(lane);
             const int s = lane >> 3, j = lane & 7;
             const int mby = g * 8 + s;
-            const bool row_ok = mby < hmb, has_top = mby > 0, last_row = mby == hmb - 1;
+            const bool row_ok = mby < hmb, has_top = mby > 0;
             const int mbx = t - s;
             const bool active = row_ok && mbx >= 0 && mbx < wmb;
             // LDS addresses: this sub-row's window (index s + 1 of the wavefront's nine), the window above, the slots of columns x and x - 1
             const uint32_t tile = MI_DEBLOCK8_HDR_BYTES + static_cast<uint32_t>(wave) * MI_DEBLOCK8_WAVE_BYTES + static_cast<uint32_t>(s + 1) * T_BYTES;
-            const uint32_t sx = static_cast<uint32_t>(mbx) & 3u, spv = static_cast<uint32_t>(mbx - 1) & 3u, sp2 = static_cast<uint32_t>(mbx - 2) & 3u;
+            const uint32_t sx = static_cast<uint32_t>(mbx) & 3u, spv = static_cast<uint32_t>(mbx - 1) & 3u;
             const uint32_t own_l = tile + sx * 256, prev_l = tile + spv * 256, own_c = tile + T_CHROMA + sx * 128, prev_c = tile + T_CHROMA + spv * 128;
-            // this step's input registers (wave-uniform slot) and parameters
-            // (the unpacking into one register per sample position is written out once per slot behind a wave-uniform switch: selecting the slot's
-            // registers with v_cndmask costs three instructions per dword, indexing them dynamically makes the compiler copy all 48 around the loop)
-            const int ts = t & 3;
-            pk2 v[20];  // luma columns -4..15 of rows 2j | 2j + 1 (vertical pass)
-            pk2 cv[10]; // chroma columns -2..7 of Cb | Cr
-            auto unpack_l = [&](const v4u &a, const v4u &b) {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-#pragma unroll
-                    for (int m = 0; m < 4; m++) v[4 + 4 * k + m] = pair_byte(b[k], a[k], m);
-            };
-            auto unpack_c = [&](const v2u &cb, const v2u &cr) {
-#pragma unroll
-                for (int k = 0; k < 2; k++)
-#pragma unroll
-                    for (int m = 0; m < 4; m++) cv[2 + 4 * k + m] = pair_byte(cr[k], cb[k], m);
-            };
-            switch (ts) {
-            case 0: unpack_l(PA0, PB0), unpack_c(QB0, QR0); break;
-            case 1: unpack_l(PA1, PB1), unpack_c(QB1, QR1); break;
-            case 2: unpack_l(PA2, PB2), unpack_c(QB2, QR2); break;
-            default: unpack_l(PA3, PB3), unpack_c(QB3, QR3); break;
-            }
-            const v2u bs = pre_bs;
-            const v4u p0 = pre_p0, p1 = pre_p1, p2 = pre_p2;
-            __builtin_amdgcn_sched_barrier(0); // (everything that reads registers written by vector memory loads stays above this line)
+            // this step's parameters: the macroblock's DbPrm out of the stage the previous step filled -- this lane's strengths (one dword per direction) and the three planes' blocks
+            const uint32_t stage = stage0 + static_cast<uint32_t>(t & 1) * (8 * static_cast<uint32_t>(sizeof(DbPrm))) + s * static_cast<uint32_t>(sizeof(DbPrm));
+            const v2u bs = LLD8(stage + (j >> 1) * 8); // (the planes' blocks are read where a pass needs them: 12 registers less across the step)
             STAMP(0);
-            // ---- 0. the step's vector memory operations in one burst: loads for the steps to come, then the stores of column x - 2; the one wait for
-            // them is at the end of the step (loads_landed)
-            if (active && (mbx & 3) == 3) prefetch_group(mbx + 1); // the input registers of this sub-row are free again
-            prefetch_prm(mbx + 1);
+            // ---- 0. the step's vector memory operations in one burst (the one wait for them is at the end of the step) ----
+            // 0a. loads: the sub-rows whose column x + 1 starts a group of four (two of the eight per step)
+            {
+                auto load_l = [&](v4u &G, int k) { // (two of the eight reload per step: the others' predicate is empty and the statement branches over its load)
+                    const int cb = t - k + 1; // first column of the group
+                    ALD16M(G, py, ll_src + __umul24(k * 16, W) + cb * 16, (cb & 3) == 0 && k < rows_here && cb >= 0 && cb + ll_col < wmb);
+                };
+                auto load_c = [&](v4u &G, int k) {
+                    const int sub = k + 4 * lc_half, cb = t - sub + 1;
+                    ALD16M(G, py, lc_src + __umul24(k * 8, Wc) + cb * 8, (cb & 3) == 0 && sub < rows_here && cb >= 0 && cb + 2 * lc_q < wmb);
+                };
+                load_l(G0, 0), load_l(G1, 1), load_l(G2, 2), load_l(G3, 3), load_l(G4, 4), load_l(G5, 5), load_l(G6, 6), load_l(G7, 7);
+                load_c(GC0, 0), load_c(GC1, 1), load_c(GC2, 2), load_c(GC3, 3);
+                // DbPrm of the next step's macroblocks (a clamped address where there is none: the stage entry is never used then)
+                ALD16M(GP, prms, __umul24(lp_row + static_cast<uint32_t>(min(max(t - lp_sub + 1, 0), wmb - 1)), static_cast<uint32_t>(sizeof(DbPrm))) + lp_piece * 16, lane < 40); // (a picture has at most 2^18 macroblocks)
+            }
             STAMP(7);
-            // column x - 2 leaves for HBM: rows -4..11 (lane j: row pair j - 2; pairs -2, -1 are rows 12..15 of the window above), chroma rows -1..6.
-            // (final since the vertical pass of the previous step)
-            if (row_ok && mbx >= 2 && mbx <= wmb + 1) {
-                const uint32_t above = tile - T_BYTES;
-                if (fl_ok) {
-                    const uint32_t src = (j < 2 ? above + 192 + j * 32 : tile + (j - 2) * 32) + sp2 * 256;
-                    const v4u w0 = LLD16(src), w1 = LLD16(src + 16);
-                    const v4u ra = v4u{PERM(w0.y, w0.x, 0x06040200u), PERM(w0.w, w0.z, 0x06040200u), PERM(w1.y, w1.x, 0x06040200u), PERM(w1.w, w1.z, 0x06040200u)};
-                    const v4u rb = v4u{PERM(w0.y, w0.x, 0x07050301u), PERM(w0.w, w0.z, 0x07050301u), PERM(w1.y, w1.x, 0x07050301u), PERM(w1.w, w1.z, 0x07050301u)};
-                    const uint32_t o = yout + (mbx - 2) * 16;
-                    GST16(py, o, ra), GST16(py, o + W, rb);
-                }
-                if (fc_ok) {
-                    const uint32_t src = (j < 1 ? above + T_CHROMA + 112 : tile + T_CHROMA + (j - 1) * 16) + sp2 * 128;
-                    const v4u w = LLD16(src);
-                    const uint32_t o = cout + (mbx - 2) * 8;
-                    GST8(py, cb_off + o, (v2u{PERM(w.y, w.x, 0x05040100u), PERM(w.w, w.z, 0x05040100u)}));
-                    GST8(py, cr_off + o, (v2u{PERM(w.y, w.x, 0x07060302u), PERM(w.w, w.z, 0x07060302u)}));
-                }
-                if (last_row) { // nothing below will touch rows 12..15 (chroma row 7): they leave with the rest
-                    if (j < 2) {
-                        const uint32_t src = tile + 192 + j * 32 + sp2 * 256;
+            // 0b. stores: the column pairs {x - 3, x - 2} of the sub-rows whose x is odd (final since the vertical pass of step x - 1)
+            {
+                const int par = (t + 1) & 1;
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int k = par + 4 * i + 2 * sl_half, x = t - k, col = x - 3 + sl_col;
+                    const bool ok = k < rows_here && x >= 3 && col < wmb && !(sl_row >= 12 && feeds_group && k == last_sub);
+                    if (ok) {
+                        const uint32_t src = tile0 + static_cast<uint32_t>(k + 1) * T_BYTES + (static_cast<uint32_t>(col) & 3u) * 256 + (sl_row >> 1) * 32;
                         const v4u w0 = LLD16(src), w1 = LLD16(src + 16);
-                        const v4u ra = v4u{PERM(w0.y, w0.x, 0x06040200u), PERM(w0.w, w0.z, 0x06040200u), PERM(w1.y, w1.x, 0x06040200u), PERM(w1.w, w1.z, 0x06040200u)};
-                        const v4u rb = v4u{PERM(w0.y, w0.x, 0x07050301u), PERM(w0.w, w0.z, 0x07050301u), PERM(w1.y, w1.x, 0x07050301u), PERM(w1.w, w1.z, 0x07050301u)};
-                        const uint32_t o = y_off + (static_cast<uint32_t>(mby) * 16 + 12 + 2 * j) * W + (mbx - 2) * 16;
-                        GST16(py, o, ra), GST16(py, o + W, rb);
-                    } else if (j == 2) {
-                        const v4u w = LLD16(tile + T_CHROMA + 112 + sp2 * 128);
-                        const uint32_t o = (static_cast<uint32_t>(mby) * 8 + 7) * Wc + (mbx - 2) * 8;
-                        GST8(py, cb_off + o, (v2u{PERM(w.y, w.x, 0x05040100u), PERM(w.w, w.z, 0x05040100u)}));
-                        GST8(py, cr_off + o, (v2u{PERM(w.y, w.x, 0x07060302u), PERM(w.w, w.z, 0x07060302u)}));
+                        GST16(py, y_off + __umul24((g * 8 + k) * 16 + sl_row, W) + col * 16,
+                              (v4u{PERM(w0.y, w0.x, sl_sel), PERM(w0.w, w0.z, sl_sel), PERM(w1.y, w1.x, sl_sel), PERM(w1.w, w1.z, sl_sel)}));
+                    }
+                }
+                {
+                    const int k = par + 2 * sc_q, x = t - k, col = x - 3;
+                    const bool ok = k < rows_here && x >= 3 && col < wmb && !(sc_row == 7 && feeds_group && k == last_sub);
+                    if (ok) {
+                        const uint32_t src = tile0 + static_cast<uint32_t>(k + 1) * T_BYTES + T_CHROMA + sc_row * 16;
+                        const v4u wa = LLD16(src + (static_cast<uint32_t>(col) & 3u) * 128), wb = LLD16(src + (static_cast<uint32_t>(col + 1) & 3u) * 128);
+                        const uint32_t o = (sc_plane ? cr_off : cb_off) + __umul24((g * 8 + k) * 8 + sc_row, Wc) + col * 8;
+                        if (col + 1 < wmb)
+                            GST16(py, o, (v4u{PERM(wa.y, wa.x, sc_sel), PERM(wa.w, wa.z, sc_sel), PERM(wb.y, wb.x, sc_sel), PERM(wb.w, wb.z, sc_sel)}));
+                        else
+                            GST8(py, o, (v2u{PERM(wa.y, wa.x, sc_sel), PERM(wa.w, wa.z, sc_sel)}));
+                    }
+                }
+                // rows 12..15 (chroma row 7) of the group above, completed in window 0 by this group's first sub-row: lanes 0..7 luma, 8..9 chroma
+                if (g > 0 && par == 0 && t >= 3 && lane < 10) { // (x of the first sub-row = t, odd)
+                    const int col = t - 3 + (lane < 8 ? (lane & 1) : 0);
+                    if (col < wmb) {
+                        if (lane < 8) {
+                            const int r = lane >> 1; // rows -4 + r
+                            const uint32_t src = tile0 + (static_cast<uint32_t>(col) & 3u) * 256 + 192 + (r >> 1) * 32, sel = (r & 1) ? 0x07050301u : 0x06040200u;
+                            const v4u w0 = LLD16(src), w1 = LLD16(src + 16);
+                            GST16(py, y_off + __umul24(g * 128 - 4 + r, W) + col * 16, (v4u{PERM(w0.y, w0.x, sel), PERM(w0.w, w0.z, sel), PERM(w1.y, w1.x, sel), PERM(w1.w, w1.z, sel)}));
+                        } else {
+                            const uint32_t src = tile0 + T_CHROMA + 112, sel = lane == 9 ? 0x07060302u : 0x05040100u;
+                            const v4u wa = LLD16(src + (static_cast<uint32_t>(col) & 3u) * 128), wb = LLD16(src + (static_cast<uint32_t>(col + 1) & 3u) * 128);
+                            const uint32_t o = (lane == 9 ? cr_off : cb_off) + __umul24(g * 64 - 1, Wc) + col * 8;
+                            if (col + 1 < wmb)
+                                GST16(py, o, (v4u{PERM(wa.y, wa.x, sel), PERM(wa.w, wa.z, sel), PERM(wb.y, wb.x, sel), PERM(wb.w, wb.z, sel)}));
+                            else
+                                GST8(py, o, (v2u{PERM(wa.y, wa.x, sel), PERM(wa.w, wa.z, sel)}));
+                        }
                     }
                 }
             }
@@ -293,9 +296,18 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
                 const uint32_t tsel = PERM(0x0403020Cu, 0x0706050Cu, bsv + 4u); // edge 0: the left-edge row (bytes 2..4 of {y, z}), inner edges: bytes 5..7; bS 0: a zero
                 const bool left = mbx > 0;
                 {
+                    pk2 v[20]; // luma columns -4..15 of rows 2j | 2j + 1
+                    {
+                        const v4u in_a = LLD16(own_l + j * 32), in_b = LLD16(own_l + j * 32 + 16); // the raw rows 2j, 2j + 1 (the loads' landing place: the bytes of row pair j)
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+#pragma unroll
+                            for (int m = 0; m < 4; m++) v[4 + 4 * k + m] = pair_byte(in_b[k], in_a[k], m);
+                    }
                     uint32_t w6 = 0, w7 = 0;
                     bool f0 = false;
                     if (__builtin_amdgcn_ballot_w64(bsv != 0) != 0) {
+                        const v4u p0 = LLD16(stage + 32);
                         const uint32_t tc4 = PERM(p0.z, p0.y, tsel);
                         const pk2 aL = splat_byte(p0.x, 0), bL = splat_byte(p0.x, 1), aI = splat_byte(p0.x, 2), bI = splat_byte(p0.x, 3);
                         if (left) {
@@ -318,7 +330,16 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
                 __builtin_amdgcn_sched_barrier(0);
                 // chroma: luma edges 0 and 2; the low half is Cb, the high half Cr
                 const uint32_t bsc = bsv & 0x00FF00FFu;
+                pk2 cv[10]; // chroma columns -2..7 of Cb | Cr
+                {
+                    const v4u in_c = LLD16(own_c + j * 16); // row j as it landed: Cb | Cr
+#pragma unroll
+                    for (int k = 0; k < 2; k++)
+#pragma unroll
+                        for (int m = 0; m < 4; m++) cv[2 + 4 * k + m] = pair_byte(in_c[2 + k], in_c[k], m);
+                }
                 if (__builtin_amdgcn_ballot_w64(bsc != 0) != 0) {
+                    const v4u p1 = LLD16(stage + 48), p2 = LLD16(stage + 64);
                     const uint32_t tcb4 = PERM(p1.z, p1.y, tsel), tcr4 = PERM(p2.z, p2.y, tsel);
                     uint32_t w3 = 0;
                     if (left) w3 = LLD4(prev_c + j * 16 + 12);
@@ -371,6 +392,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
                 const uint32_t above = tile - T_BYTES;
                 const uint32_t tsel = PERM(0x0605040Cu, 0x0302010Cu, bsh + 4u); // edge 0: the top-edge row (bytes 0..2 of w), inner edges: bytes 1..3 of z
                 if (__builtin_amdgcn_ballot_w64(bsh != 0) != 0) {
+                    const v4u p0 = LLD16(stage + 32);
                     const uint32_t tc4 = PERM(p0.w, p0.z, tsel);
                     const pk2 aT = splat_byte(p0.y, 0), bT = splat_byte(p0.y, 1), aI = splat_byte(p0.x, 2), bI = splat_byte(p0.x, 3);
                     pk2 h[20]; // rows -4..15 of columns 2j | 2j + 1
@@ -400,6 +422,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
                 __builtin_amdgcn_sched_barrier(0);
                 const uint32_t bsc = bsh & 0x00FF00FFu;
                 if (__builtin_amdgcn_ballot_w64(bsc != 0) != 0) {
+                    const v4u p1 = LLD16(stage + 48), p2 = LLD16(stage + 64);
                     const uint32_t tcb4 = PERM(p1.w, p1.z, tsel), tcr4 = PERM(p2.w, p2.z, tsel);
                     const uint32_t csel = (j & 1) ? 0x0C030C01u : 0x0C020C00u; // this lane's column of a dword's column pair: Cb | Cr
                     const uint32_t ca = above + T_CHROMA + sx * 128 + (j >> 1) * 4, co = own_c + (j >> 1) * 4;
@@ -423,9 +446,24 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
                     }
                 }
             }
-            WAVE_SYNC();
             STAMP(3);
+            // ---- 4. what the loads brought: column x + 1 of every sub-row into its window slot (free since this step's stores), the next step's DbPrm into the stage ----
             loads_landed(); // (issued at the top of this step: a step old)
+            {
+                auto piece_l = [&](const v4u &G, int k) {
+                    const int c = t - k + 1;
+                    if (k < rows_here && c >= 0 && c < wmb && ll_col == (c & 3)) LST16(ll_dst + static_cast<uint32_t>(k) * T_BYTES, G);
+                };
+                piece_l(G0, 0), piece_l(G1, 1), piece_l(G2, 2), piece_l(G3, 3), piece_l(G4, 4), piece_l(G5, 5), piece_l(G6, 6), piece_l(G7, 7);
+                auto piece_c = [&](const v4u &G, int k) {
+                    const int sub = k + 4 * lc_half, c = t - sub + 1;
+                    if (sub < rows_here && c >= 0 && c < wmb && lc_q == ((c >> 1) & 1))
+                        LST8(lc_dst + static_cast<uint32_t>(k) * T_BYTES + (static_cast<uint32_t>(c) & 3u) * 128, (c & 1) ? (v2u{G.z, G.w}) : (v2u{G.x, G.y}));
+                };
+                piece_c(GC0, 0), piece_c(GC1, 1), piece_c(GC2, 2), piece_c(GC3, 3);
+                if (lane < 40) LST16(stage0 + static_cast<uint32_t>((t + 1) & 1) * (8 * static_cast<uint32_t>(sizeof(DbPrm))) + lane * 16, GP);
+            }
+            WAVE_SYNC();
             STAMP(6);
         }
 #if defined(MI_DB_STATS)

@@ -322,6 +322,7 @@ struct h264mi_decoder {
     // k_deblock_x): hand-off rings / flags in global memory, a ticket counter per kernel family, a give-up word
     unsigned long long *d_xring = nullptr; // K5: x_cap * (Wmax / 16) * 24 granules
     uint32_t *d_xdone = nullptr;           // K3: x_cap * (Wmax / 16) flag words
+    int k5_max_waves = MI_DEBLOCK8_MAX_WAVES;
     uint32_t *d_xctl = nullptr, *h_xstatus = nullptr; // [0] K5 tickets, [32] K3 tickets, [64] give-up code (128-byte lines of their own)
     uint32_t x_epoch = 0, x_tk5 = 0, x_tk3 = 0;
     int x_max_wgs = 256, x_cap = 512, x_cap3 = 512; // workgroups per launch: default; capacity of the K5 ring; of the K3 flag array
@@ -614,6 +615,7 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg_, h264mi_decod
     TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock_x), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
     // cross-workgroup hand-off state of the banded kernels; H264MI_X_WGS = 0 switches them off, n: up to n workgroups per launch
     if (const char *e = getenv("H264MI_X_WGS")) d->x_max_wgs = std::min(std::max(atoi(e), 0), d->x_cap);
+    if (const char *e = getenv("H264MI_K5_WAVES")) d->k5_max_waves = std::min(std::max(atoi(e), 1), MI_DEBLOCK8_MAX_WAVES); // measurement: fewer wavefronts per picture in k_deblock
     // (test hook: where the launch epoch and the ticket counters start, so that a test can cross their 32-bit wrap)
     if (const char *e = getenv("H264MI_X_EPOCH0")) d->x_epoch = d->x_tk5 = d->x_tk3 = static_cast<uint32_t>(strtoul(e, nullptr, 0));
     DEV_ALLOC(d->d_xring, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long));
@@ -2122,7 +2124,7 @@ static int execute_stage(h264mi_decoder *d, int stage_idx, bool exclusive) {
                                d->d_dbprm[set], dbring, 0, 1, d->d_xring, next_epoch(), nb5, d->d_xctl, d->x_tk5, g.wmb_max, d->d_xctl + 64, roles);
             d->x_tk5 += n * nb5;
         } else {
-            mi_deblock8_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs);
+            mi_deblock8_plan(g.wmb_max, g.hmb_max, &dbw, &dbring, &dbring_last, &dbbufs, d->k5_max_waves);
             hipLaunchKernelGGL(k_deblock, dim3(n), dim3(dbw * 64), mi_deblock8_lds_bytes(dbw, dbring, dbring_last, dbbufs), rs, g.d_lists + g.wave_off[w], g.d_pics,
                                d->d_dbprm[set], dbring, dbring_last, dbbufs, d->d_xctl + 64);
         }

@@ -46,7 +46,7 @@ extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pi
 #define MI_DEBLOCK8_MAX_GROUPS 64    /* hmb <= 320 + slack */
 #define MI_DEBLOCK8_HDR_BYTES 512    /* sizeof(Db8Shared) */
 #define MI_DEBLOCK8_TILE_BYTES 1568  /* the LDS window of a sub-row: four macroblock columns of luma (1024) and chroma (512) + 32 (bank stagger) */
-#define MI_DEBLOCK8_WAVE_BYTES (9 * MI_DEBLOCK8_TILE_BYTES) /* 8 sub-rows + rows 12..15 of the row above the first */
+#define MI_DEBLOCK8_WAVE_BYTES (9 * MI_DEBLOCK8_TILE_BYTES + 2 * 8 * 80) /* 8 sub-rows + rows 12..15 of the row above the first; the DbPrm stage (two steps x 8 macroblocks) */
 static inline size_t mi_deblock8_lds_bytes(int nwaves, int ring, int ring_last, int last_bufs) {
     return MI_DEBLOCK8_HDR_BYTES + static_cast<size_t>(nwaves) * MI_DEBLOCK8_WAVE_BYTES + (static_cast<size_t>(nwaves - 1) * ring + static_cast<size_t>(ring_last) * last_bufs) * 96;
 }
@@ -92,10 +92,10 @@ static inline void mi_deblock_bands(int n_pics, int wmb, int hmb, int max_wgs, i
 // r - 1's ring, because wavefront 0's group of round r can only finish when the groups below it -- up to the last
 // wavefront's, through the short rings -- make progress: with a single buffer wide pictures deadlock.  As many wavefronts as fit.
 // 1080p: 9 wavefronts, one round.
-static inline void mi_deblock8_plan(int wmb, int hmb, int *nwaves, int *ring, int *ring_last, int *last_bufs) {
+static inline void mi_deblock8_plan(int wmb, int hmb, int *nwaves, int *ring, int *ring_last, int *last_bufs, int max_waves = MI_DEBLOCK8_MAX_WAVES) {
     const int ngroups = (hmb + 7) / 8;
     const int w1 = wmb > 0 ? wmb : 1;
-    for (int nw = ngroups < MI_DEBLOCK8_MAX_WAVES ? ngroups : MI_DEBLOCK8_MAX_WAVES; nw >= 1; nw--) {
+    for (int nw = ngroups < max_waves ? ngroups : max_waves; nw >= 1; nw--) {
         const int rounds = (ngroups + nw - 1) / nw;
         const int r = w1 < 16 ? w1 : 16;
         const int rl = rounds > 1 ? w1 : r;

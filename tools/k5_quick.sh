@@ -17,3 +17,12 @@ PY
 if [ -f h264decode_amd/libh264mi_stats.so ]; then
   H264MI_LIB=h264decode_amd/libh264mi_stats.so timeout -k 10 300 python tools/deblock_phase_probe.py 256 4 > $out/${tag}_phases.txt 2>&1; cat $out/${tag}_phases.txt
 fi
+for nw in ${K5_WAVES_AB:-}; do
+  H264MI_K5_WAVES=$nw timeout -k 10 400 python bench.py --steps 3 --warmup 1 --no-extra --no-cpu-baseline --distinct 32 --no-parity > $out/${tag}_bench_w$nw.json 2> $out/${tag}_bench_w$nw.err
+  python - <<PY
+import json
+d = json.loads(open("$out/${tag}_bench_w$nw.json").read().strip().splitlines()[-1])
+r = d["roofline"]
+print("K5_WAVES=$nw value", d["value"], "kernels", r["all_kernels_ms_per_step"], "k_deblock ms", r["per_launch"]["k_deblock"]["ms"])
+PY
+done
