@@ -60,6 +60,20 @@ def build(force=False):
 
 
 _lib = None
+_hooks = None
+
+
+def load_hooks():
+    """The hooks build of the same library (csrc/Makefile: mi_api.cpp with -DH264MI_TEST_HOOKS): the h264mi_internal_* entry points the tests and
+    tools use.  They work on decoders of the product library too (plain structs, one HIP runtime per process); the product library itself exports
+    the ABI of include/h264mi.h and nothing else."""
+    global _hooks
+    if _hooks is None:
+        path = os.path.join(_HERE, "libh264mi_hooks.so")
+        if not os.path.exists(path):
+            raise H264MIError(-4, "libh264mi_hooks.so is not built (make -C h264decode_amd/csrc)")
+        _hooks = ctypes.CDLL(path)
+    return _hooks
 
 
 def load():

@@ -80,7 +80,21 @@ typedef __attribute__((address_space(1))) v2u g_uint2;
                      : [d] "+v"(dst), [sv] "=&s"(sv_)                                                                                              \
                      : [o] "v"(static_cast<uint32_t>(off)), [b] "s"(base), [m] "s"(__builtin_amdgcn_ballot_w64(cond))                              \
                      : "scc");                                                                                                                     \
-        __builtin_amdgcn_sched_barrier(0); /* (keeps each predicate's computation next to its statement: scalar register pressure) */              \
+    } while (0)
+// The group loads of one phase (the step's t + 1 = K mod 4: sub-rows K and K + 4 reload, luma each, chroma together): three masked loads behind one
+// scalar branch on the phase -- four such statements stand in a step, one falls through.  Offsets and lane masks are the step's (the same operands
+// in all four); only the destinations differ.
+#define ALD_PHASE(K, ga, gb, gc, kq, oa, ob, oc, ma, mb, mc, base)                                                                                 \
+    do {                                                                                                                                           \
+        unsigned long long sv_;                                                                                                                    \
+        asm volatile("s_cmp_lg_u32 %[q], " #K "\n\ts_cbranch_scc1 9f\n\ts_mov_b64 %[sv], exec\n\t"                                                 \
+                     "s_and_b64 exec, %[sv], %[mA]\n\ts_cbranch_execz 1f\n\tglobal_load_dwordx4 %[dA], %[oA], %[b]\n1:\n\t"                         \
+                     "s_and_b64 exec, %[sv], %[mB]\n\ts_cbranch_execz 2f\n\tglobal_load_dwordx4 %[dB], %[oB], %[b]\n2:\n\t"                         \
+                     "s_and_b64 exec, %[sv], %[mC]\n\ts_cbranch_execz 3f\n\tglobal_load_dwordx4 %[dC], %[oC], %[b]\n3:\n\t"                         \
+                     "s_mov_b64 exec, %[sv]\n9:"                                                                                                   \
+                     : [dA] "+v"(ga), [dB] "+v"(gb), [dC] "+v"(gc), [sv] "=&s"(sv_)                                                                \
+                     : [q] "s"(kq), [oA] "v"(oa), [oB] "v"(ob), [oC] "v"(oc), [mA] "s"(ma), [mB] "s"(mb), [mC] "s"(mc), [b] "s"(base)              \
+                     : "scc");                                                                                                                     \
     } while (0)
 typedef __attribute__((address_space(3))) uint8_t l8;
 typedef __attribute__((address_space(3))) v4u l_uint4;
@@ -225,16 +239,17 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             // ---- 0. the step's vector memory operations in one burst (the one wait for them is at the end of the step) ----
             // 0a. loads: the sub-rows whose column x + 1 starts a group of four (two of the eight per step)
             {
-                auto load_l = [&](v4u &G, int k) { // (two of the eight reload per step: the others' predicate is empty and the statement branches over its load)
-                    const int cb = t - k + 1; // first column of the group
-                    ALD16M(G, py, ll_src + __umul24(k * 16, W) + cb * 16, (cb & 3) == 0 && k < rows_here && cb >= 0 && cb + ll_col < wmb);
-                };
-                auto load_c = [&](v4u &G, int k) {
-                    const int sub = k + 4 * lc_half, cb = t - sub + 1;
-                    ALD16M(G, py, lc_src + __umul24(k * 8, Wc) + cb * 8, (cb & 3) == 0 && sub < rows_here && cb >= 0 && cb + 2 * lc_q < wmb);
-                };
-                load_l(G0, 0), load_l(G1, 1), load_l(G2, 2), load_l(G3, 3), load_l(G4, 4), load_l(G5, 5), load_l(G6, 6), load_l(G7, 7);
-                load_c(GC0, 0), load_c(GC1, 1), load_c(GC2, 2), load_c(GC3, 3);
+                const int kq = (t + 1) & 3, cb_a = t - kq + 1, cb_b = cb_a - 4; // sub-rows kq (first column cb_a of its group) and kq + 4 (cb_b)
+                const bool ok_a = kq < rows_here && cb_a >= 0 && cb_a < wmb, ok_b = kq + 4 < rows_here && cb_b >= 0 && cb_b < wmb;
+                const unsigned long long m_a = ok_a ? __builtin_amdgcn_ballot_w64(ll_col < wmb - cb_a) : 0ull, m_b = ok_b ? __builtin_amdgcn_ballot_w64(ll_col < wmb - cb_b) : 0ull;
+                const int cb_c = lc_half ? cb_b : cb_a;
+                const unsigned long long m_c = __builtin_amdgcn_ballot_w64((lc_half ? ok_b : ok_a) && cb_c + 2 * lc_q < wmb);
+                const uint32_t o_a = ll_src + __umul24(kq * 16, W) + cb_a * 16, o_b = ll_src + __umul24(kq * 16 + 64, W) + cb_b * 16;
+                const uint32_t o_c = lc_src + __umul24(kq * 8, Wc) + cb_c * 8;
+                ALD_PHASE(0, G0, G4, GC0, kq, o_a, o_b, o_c, m_a, m_b, m_c, py);
+                ALD_PHASE(1, G1, G5, GC1, kq, o_a, o_b, o_c, m_a, m_b, m_c, py);
+                ALD_PHASE(2, G2, G6, GC2, kq, o_a, o_b, o_c, m_a, m_b, m_c, py);
+                ALD_PHASE(3, G3, G7, GC3, kq, o_a, o_b, o_c, m_a, m_b, m_c, py);
                 // DbPrm of the next step's macroblocks (a clamped address where there is none: the stage entry is never used then)
                 ALD16M(GP, prms, __umul24(lp_row + static_cast<uint32_t>(min(max(t - lp_sub + 1, 0), wmb - 1)), static_cast<uint32_t>(sizeof(DbPrm))) + lp_piece * 16, lane < 40); // (a picture has at most 2^18 macroblocks)
             }
@@ -242,29 +257,32 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             // 0b. stores: the column pairs {x - 3, x - 2} of the sub-rows whose x is odd (final since the vertical pass of step x - 1)
             {
                 const int par = (t + 1) & 1;
+                // (the window reads of all three instructions first, unpredicated -- their addresses are inside the wavefront's windows whatever x is --,
+                // so that one LDS round trip serves them all; only the stores are predicated)
+                int kl[2], cl[2];
+                v4u wl0[2], wl1[2];
 #pragma unroll
                 for (int i = 0; i < 2; i++) {
-                    const int k = par + 4 * i + 2 * sl_half, x = t - k, col = x - 3 + sl_col;
-                    const bool ok = k < rows_here && x >= 3 && col < wmb && !(sl_row >= 12 && feeds_group && k == last_sub);
-                    if (ok) {
-                        const uint32_t src = tile0 + static_cast<uint32_t>(k + 1) * T_BYTES + (static_cast<uint32_t>(col) & 3u) * 256 + (sl_row >> 1) * 32;
-                        const v4u w0 = LLD16(src), w1 = LLD16(src + 16);
-                        GST16(py, y_off + __umul24((g * 8 + k) * 16 + sl_row, W) + col * 16,
-                              (v4u{PERM(w0.y, w0.x, sl_sel), PERM(w0.w, w0.z, sl_sel), PERM(w1.y, w1.x, sl_sel), PERM(w1.w, w1.z, sl_sel)}));
-                    }
+                    kl[i] = par + 4 * i + 2 * sl_half, cl[i] = t - kl[i] - 3 + sl_col;
+                    const uint32_t src = tile0 + __umul24(kl[i] + 1, T_BYTES) + (static_cast<uint32_t>(cl[i]) & 3u) * 256 + (sl_row >> 1) * 32;
+                    wl0[i] = LLD16(src), wl1[i] = LLD16(src + 16);
                 }
-                {
-                    const int k = par + 2 * sc_q, x = t - k, col = x - 3;
-                    const bool ok = k < rows_here && x >= 3 && col < wmb && !(sc_row == 7 && feeds_group && k == last_sub);
-                    if (ok) {
-                        const uint32_t src = tile0 + static_cast<uint32_t>(k + 1) * T_BYTES + T_CHROMA + sc_row * 16;
-                        const v4u wa = LLD16(src + (static_cast<uint32_t>(col) & 3u) * 128), wb = LLD16(src + (static_cast<uint32_t>(col + 1) & 3u) * 128);
-                        const uint32_t o = (sc_plane ? cr_off : cb_off) + __umul24((g * 8 + k) * 8 + sc_row, Wc) + col * 8;
-                        if (col + 1 < wmb)
-                            GST16(py, o, (v4u{PERM(wa.y, wa.x, sc_sel), PERM(wa.w, wa.z, sc_sel), PERM(wb.y, wb.x, sc_sel), PERM(wb.w, wb.z, sc_sel)}));
-                        else
-                            GST8(py, o, (v2u{PERM(wa.y, wa.x, sc_sel), PERM(wa.w, wa.z, sc_sel)}));
-                    }
+                const int kc = par + 2 * sc_q, cc = t - kc - 3;
+                const uint32_t srcc = tile0 + __umul24(kc + 1, T_BYTES) + T_CHROMA + sc_row * 16;
+                const v4u wa = LLD16(srcc + (static_cast<uint32_t>(cc) & 3u) * 128), wb = LLD16(srcc + (static_cast<uint32_t>(cc + 1) & 3u) * 128);
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const int k = kl[i], col = cl[i];
+                    if (k < rows_here && col - sl_col >= 0 && col < wmb && !(sl_row >= 12 && feeds_group && k == last_sub))
+                        GST16(py, y_off + __umul24((g * 8 + k) * 16 + sl_row, W) + col * 16,
+                              (v4u{PERM(wl0[i].y, wl0[i].x, sl_sel), PERM(wl0[i].w, wl0[i].z, sl_sel), PERM(wl1[i].y, wl1[i].x, sl_sel), PERM(wl1[i].w, wl1[i].z, sl_sel)}));
+                }
+                if (kc < rows_here && cc >= 0 && cc < wmb && !(sc_row == 7 && feeds_group && kc == last_sub)) {
+                    const uint32_t o = (sc_plane ? cr_off : cb_off) + __umul24((g * 8 + kc) * 8 + sc_row, Wc) + cc * 8;
+                    if (cc + 1 < wmb)
+                        GST16(py, o, (v4u{PERM(wa.y, wa.x, sc_sel), PERM(wa.w, wa.z, sc_sel), PERM(wb.y, wb.x, sc_sel), PERM(wb.w, wb.z, sc_sel)}));
+                    else
+                        GST8(py, o, (v2u{PERM(wa.y, wa.x, sc_sel), PERM(wa.w, wa.z, sc_sel)}));
                 }
                 // rows 12..15 (chroma row 7) of the group above, completed in window 0 by this group's first sub-row: lanes 0..7 luma, 8..9 chroma
                 if (g > 0 && par == 0 && t >= 3 && lane < 10) { // (x of the first sub-row = t, odd)
@@ -450,17 +468,27 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             // ---- 4. what the loads brought: column x + 1 of every sub-row into its window slot (free since this step's stores), the next step's DbPrm into the stage ----
             loads_landed(); // (issued at the top of this step: a step old)
             {
-                auto piece_l = [&](const v4u &G, int k) {
+                // (written out once per phase of t + 1 mod 4: in a phase the piece a sub-row is due -- and so the lanes that hold it -- is a constant)
+                const int kq = (t + 1) & 3;
+                auto piece_l = [&](const v4u &G, int k, int ph) {
                     const int c = t - k + 1;
-                    if (k < rows_here && c >= 0 && c < wmb && ll_col == (c & 3)) LST16(ll_dst + static_cast<uint32_t>(k) * T_BYTES, G);
+                    if (k < rows_here && c >= 0 && c < wmb && ll_col == ((ph - k) & 3)) LST16(ll_dst + static_cast<uint32_t>(k) * T_BYTES, G);
                 };
-                piece_l(G0, 0), piece_l(G1, 1), piece_l(G2, 2), piece_l(G3, 3), piece_l(G4, 4), piece_l(G5, 5), piece_l(G6, 6), piece_l(G7, 7);
-                auto piece_c = [&](const v4u &G, int k) {
-                    const int sub = k + 4 * lc_half, c = t - sub + 1;
-                    if (sub < rows_here && c >= 0 && c < wmb && lc_q == ((c >> 1) & 1))
-                        LST8(lc_dst + static_cast<uint32_t>(k) * T_BYTES + (static_cast<uint32_t>(c) & 3u) * 128, (c & 1) ? (v2u{G.z, G.w}) : (v2u{G.x, G.y}));
+                auto piece_c = [&](const v4u &G, int k, int ph) { // column c = t + 1 - sub: c & 3 = (ph - sub) & 3 = (ph - k) & 3 for both halves
+                    const int sub = k + 4 * lc_half, c = t - sub + 1, p = (ph - k) & 3;
+                    if (sub < rows_here && c >= 0 && c < wmb && lc_q == (p >> 1))
+                        LST8(lc_dst + static_cast<uint32_t>(k) * T_BYTES + p * 128, (p & 1) ? (v2u{G.z, G.w}) : (v2u{G.x, G.y}));
                 };
-                piece_c(GC0, 0), piece_c(GC1, 1), piece_c(GC2, 2), piece_c(GC3, 3);
+#define PIECES(ph)                                                                                                                                \
+    piece_l(G0, 0, ph), piece_l(G1, 1, ph), piece_l(G2, 2, ph), piece_l(G3, 3, ph), piece_l(G4, 4, ph), piece_l(G5, 5, ph), piece_l(G6, 6, ph), \
+        piece_l(G7, 7, ph), piece_c(GC0, 0, ph), piece_c(GC1, 1, ph), piece_c(GC2, 2, ph), piece_c(GC3, 3, ph)
+                switch (kq) {
+                case 0: PIECES(0); break;
+                case 1: PIECES(1); break;
+                case 2: PIECES(2); break;
+                default: PIECES(3); break;
+                }
+#undef PIECES
                 if (lane < 40) LST16(stage0 + static_cast<uint32_t>((t + 1) & 1) * (8 * static_cast<uint32_t>(sizeof(DbPrm))) + lane * 16, GP);
             }
             WAVE_SYNC();

@@ -3,7 +3,7 @@
 // position), 16 bits each, and every operation is a packed 16-bit instruction (v_pk_add_u16 / v_pk_sub_i16 / v_pk_max_i16 /
 // v_pk_min_i16 / v_pk_mad_i16 / v_pk_ashrrev_i16; conditions are sign masks, selects are v_bfi_b32, the rounding average is v_lerp_u8).
 // The four edges of a line are a dependency chain (edge 8 reads what edge 4 wrote), so the two halves have to be two LINES, not two edges.
-// Absent from the reference (only the slice-header fields are parsed: h264/slice.go:1021-1027); arithmetic as in oracle/h264o_recon.c.
+// Absent from the reference (only the slice-header fields are parsed: h264/slice.go:1021-1027); the arithmetic is 8.7.2.3 / 8.7.2.4 as written in the standard.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -108,12 +108,14 @@ static void build_vlc(uint16_t *c, int *mismatches) {
     }
     *mismatches = bad;
 }
+#if defined(H264MI_TEST_HOOKS)
 extern "C" int32_t h264mi_internal_vlc_selftest(void) {
     std::vector<uint16_t> c(MI_VLC_N);
     int bad = -1;
     build_vlc(c.data(), &bad);
     return bad;
 }
+#endif
 static void build_tables(DevTables *t) {
     memset(t, 0, sizeof(*t));
     memcpy(t->range_lps, mi_range_lps, sizeof(t->range_lps));
@@ -552,8 +554,10 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg_, h264mi_decod
         TRY_ALLOC(hipGetDeviceProperties(&prop, cfg->device));
         const int ncu = prop.multiProcessorCount;
         int ent_cus = 0;
+#if defined(H264MI_TEST_HOOKS) /* measurement switches of the hooks build (libh264mi_hooks.so) */
         if (const char *e = getenv("H264MI_ENT_LDS_PAD")) d->ent_lds_pad = static_cast<size_t>(atoi(e));
         if (const char *e = getenv("H264MI_ENT_CUS")) ent_cus = atoi(e);
+#endif
         const int words = (ncu + 31) / 32;
         std::vector<uint32_t> me(words, 0), mr(words, 0);
         bool split = ent_cus > 0 && ent_cus < ncu;
@@ -615,9 +619,10 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg_, h264mi_decod
     TRY_ALLOC(hipFuncSetAttribute(reinterpret_cast<const void *>(k_deblock_x), hipFuncAttributeMaxDynamicSharedMemorySize, MI_DEBLOCK_LDS_MAX));
     // cross-workgroup hand-off state of the banded kernels; H264MI_X_WGS = 0 switches them off, n: up to n workgroups per launch
     if (const char *e = getenv("H264MI_X_WGS")) d->x_max_wgs = std::min(std::max(atoi(e), 0), d->x_cap);
+#if defined(H264MI_TEST_HOOKS)
     if (const char *e = getenv("H264MI_K5_WAVES")) d->k5_max_waves = std::min(std::max(atoi(e), 1), MI_DEBLOCK8_MAX_WAVES); // measurement: fewer wavefronts per picture in k_deblock
+#endif
     // (test hook: where the launch epoch and the ticket counters start, so that a test can cross their 32-bit wrap)
-    if (const char *e = getenv("H264MI_X_EPOCH0")) d->x_epoch = d->x_tk5 = d->x_tk3 = static_cast<uint32_t>(strtoul(e, nullptr, 0));
     DEV_ALLOC(d->d_xring, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long));
     DEV_ALLOC(d->d_xdone, static_cast<size_t>(d->x_cap3) * (d->Wmax / 16) * sizeof(uint32_t));
     DEV_ALLOC(d->d_xctl, 3 * 128);
@@ -2165,7 +2170,6 @@ static int retry_exhausted(h264mi_decoder *d) {
 extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
     if (!d) return H264MI_EINVAL;
     GUARD(d);
-    Stage &g = d->stage[d->exec];
     for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(d->ent_stream[i]));
     HIP_TRY(hipStreamSynchronize(d->rec_stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
@@ -2184,7 +2188,9 @@ extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
         for (int k = 0; k < 4; k++) d->k_ms[k] = acc[k];
         d->k_ms[4] = tot;
     }
+#if defined(H264MI_TEST_HOOKS)
     if (getenv("H264MI_SLICE_STATS")) { // diagnostics: per-slice entropy time (100 MHz ticks) and bin count (MI_ENT_STATS builds)
+        Stage &g = d->stage[d->exec];
         for (int i = 0; i < g.n_slices && i < 64; i++)
             fprintf(stderr, "slice %d type %d bytes %u mbs %u us %.1f bins %u | Mclk fill %.1f syntax %.1f residual %.1f writeout %.1f\n", i, g.h_slices[i].slice_type,
                     g.h_slices[i].rbsp_size, g.h_status[8 * i + 1], g.h_status[8 * i + 2] * 0.01, g.h_status[8 * i + 3], g.h_status[8 * i + 4] * 16e-6,
@@ -2192,6 +2198,7 @@ extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
         fprintf(stderr, "last slice type %d bytes %u mbs %u us %.1f bins %u\n", g.h_slices[g.n_slices - 1].slice_type, g.h_slices[g.n_slices - 1].rbsp_size,
                 g.h_status[8 * (g.n_slices - 1) + 1], g.h_status[8 * (g.n_slices - 1) + 2] * 0.01, g.h_status[8 * (g.n_slices - 1) + 3]);
     }
+#endif
     if (*d->h_xstatus) { // a banded kernel gave up waiting for its neighbour workgroup: the pictures of that launch are wrong
         set_error("reconstruction hand-off timed out (code 0x%08x)", *d->h_xstatus);
         *d->h_xstatus = 0;
@@ -2417,6 +2424,8 @@ extern "C" int32_t h264mi_frame_read_mbmv1(h264mi_decoder *d, int32_t stream, in
     return H264MI_EINVAL;
 }
 
+#if defined(H264MI_TEST_HOOKS)
+// ---- test and measurement hooks: built into libh264mi_hooks.so only (csrc/Makefile); the product library exports the ABI of include/h264mi.h and nothing else ----
 // Not part of the public ABI: fills every intermediate buffer (macroblock records, coefficient blocks, row state) with
 // 0xFF so that a test can prove that no kernel depends on what an earlier batch -- or the allocator -- left there.
 extern "C" int32_t h264mi_internal_poison(h264mi_decoder *d) {
@@ -2470,3 +2479,13 @@ extern "C" int32_t h264mi_internal_band_plan(int32_t n_pics, int32_t wmb, int32_
     *k3_bands = b3, *k3_waves = w3;
     return H264MI_OK;
 }
+
+// Not part of the public ABI: the epoch / ticket counters of the banded kernels set to a value shortly before their 32-bit wrap
+// (tests/test_gpu_parity.py::test_gpu_banded_kernels_across_the_epoch_wrap)
+extern "C" int32_t h264mi_internal_set_epoch(h264mi_decoder *d, uint32_t v) {
+    if (!d) return H264MI_EINVAL;
+    GUARD(d);
+    d->x_epoch = d->x_tk5 = d->x_tk3 = v;
+    return H264MI_OK;
+}
+#endif /* H264MI_TEST_HOOKS */

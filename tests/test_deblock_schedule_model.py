@@ -16,7 +16,7 @@ ROWS = 8  # macroblock rows per group (k_deblock.hip: sub-rows of a wavefront)
 
 
 def _plan(H, wmb, hmb):
-    f = H.load().h264mi_internal_deblock_plan
+    f = H.load_hooks().h264mi_internal_deblock_plan
     I32 = ctypes.c_int32
     f.restype = I32
     f.argtypes = [I32, I32] + [ctypes.POINTER(I32)] * 4 + [ctypes.POINTER(ctypes.c_int64)]
@@ -105,7 +105,7 @@ def test_model_detects_the_single_buffer_deadlock():
 # workgroups than the grid has (a workgroup only becomes resident when another one has exited) and adversarial scheduling:
 # it must still finish, because a band only waits for the band above it, which drew an earlier ticket and is running.
 def _band_plan(H, n_pics, wmb, hmb, max_wgs=256):
-    f = H.load().h264mi_internal_band_plan
+    f = H.load_hooks().h264mi_internal_band_plan
     I32 = ctypes.c_int32
     f.restype = I32
     f.argtypes = [I32] * 4 + [ctypes.POINTER(I32)] * 3 + [ctypes.POINTER(ctypes.c_int64)] + [ctypes.POINTER(I32)] * 2

@@ -438,7 +438,7 @@ def test_gpu_c5_share_32_distinct_1080p_streams(H, sg, oracle_mod):
 
 def _poison(H, dec):
     import ctypes
-    f = H.load().h264mi_internal_poison
+    f = H.load_hooks().h264mi_internal_poison
     f.restype, f.argtypes = ctypes.c_int32, [ctypes.c_void_p]
     assert f(dec._h) == 0
 
@@ -653,20 +653,22 @@ def test_gpu_reset_discards_failures_of_abandoned_batches(H, sg):
         dec.close()
 
 
-def test_gpu_banded_kernels_across_the_epoch_wrap(H, sg, monkeypatch):
-    """The banded kernels tag their hand-off words with a 32-bit launch epoch and draw tickets from 32-bit counters: a decoder that starts
-    a few launches before the wrap (test hook H264MI_X_EPOCH0) must decode exactly -- tickets are compared modulo 2^32, the rings are
-    zeroed when the epoch restarts at 1."""
+def test_gpu_banded_kernels_across_the_epoch_wrap(H, sg):
+    """The banded kernels tag their hand-off words with a 32-bit launch epoch and draw tickets from 32-bit counters: a decoder whose counters
+    stand a few launches before the wrap (test hook h264mi_internal_set_epoch of the hooks build) must decode exactly -- tickets are compared
+    modulo 2^32, the rings are zeroed when the epoch restarts at 1."""
+    import ctypes
     kw = dict(width=176, height=144, frames=8, idr_period=0, profile_idc=77, cabac=1, num_ref_frames=2, intra_in_p_permille=150, seed=85)
     stream, rec, _ = sg.encode(**kw)
-    for start in ("0xFFFFFFF0", "0xFFFFFFFE", "0xFFFFFF00"):
-        monkeypatch.setenv("H264MI_X_EPOCH0", start)
+    f = H.load_hooks().h264mi_internal_set_epoch
+    f.restype, f.argtypes = ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32]
+    for start in (0xFFFFFFF0, 0xFFFFFFFE, 0xFFFFFF00):
         dec = H.Decoder(max_streams=1, max_width=176, max_height=144, max_frames_per_batch=8)
+        assert f(dec._h, start) == 0
         for _ in range(3):  # 3 x 8 pictures x 2 banded launches: crosses the wrap for the first two start values
             dec.decode([stream])
             assert np.array_equal(dec.read_frames(0, crop=False), rec), start
         dec.close()
-    monkeypatch.delenv("H264MI_X_EPOCH0")
 
 
 def test_gpu_decoders_in_several_threads(H, sg):

@@ -21,6 +21,11 @@ def test_library_exports_every_declared_symbol(H):
         assert hasattr(L, name), "missing export " + name
     from h264decode_amd import _lib
     assert declared == set(_lib.EXPORTS)
+    # ... and nothing else: no test hook, no C++ internal, no kernel stub (csrc/exports.map; the hooks live in libh264mi_hooks.so)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "h264decode_amd", "libh264mi.so")], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-2] in ("T", "D", "B", "R")}
+    assert exported == declared, sorted(exported ^ declared)
 
 
 def test_no_gpu_means_error_not_fallback(H):
@@ -220,33 +225,36 @@ def test_malformed_inputs_return_status_codes(H):
 
 
 def test_deblock_launch_plan_cannot_deadlock(H):
-    """K5 hands rows from one group of 4 macroblock rows to the next through bounded LDS rings with back-pressure.  The
+    """K5 hands rows from one group of 8 macroblock rows to the next through bounded LDS rings with back-pressure.  The
     groups of one round run side by side; the ring written by the LAST wavefront is read by wavefront 0 one round later, so
     it must hold a whole macroblock row (otherwise every wavefront would end up waiting for wavefront 0's previous group).
     The plan must fit the 160 KB of LDS and use as many wavefronts as there are groups, up to the kernel's limit."""
     import ctypes
-    L = H.load()
-    f = L.h264mi_internal_deblock_plan
+    f = H.load_hooks().h264mi_internal_deblock_plan
     f.restype = ctypes.c_int32
     I32 = ctypes.c_int32
     f.argtypes = [I32, I32, ctypes.POINTER(I32), ctypes.POINTER(I32), ctypes.POINTER(I32), ctypes.POINTER(I32), ctypes.POINTER(ctypes.c_int64)]
     nw, ring, ring_last, nb, lds = I32(), I32(), I32(), I32(), ctypes.c_int64()
     assert f(8, 320, ctypes.byref(nw), ctypes.byref(ring), ctypes.byref(ring_last), ctypes.byref(nb), ctypes.byref(lds)) == 0
-    maxw = nw.value  # the kernel's wavefront limit (register budget): 80 groups of a narrow picture use all of them
-    assert 8 <= maxw <= 16
+    maxw = nw.value  # the kernel's wavefront limit (LDS windows, register budget): 40 groups of a narrow picture use all of them
+    assert 8 <= maxw <= 12
+    wave_bytes = 9 * 1568 + 2 * 8 * 80  # nine windows + the DbPrm stage (mi_kernels.h: MI_DEBLOCK8_WAVE_BYTES)
     for wmb in list(range(1, 40)) + [45, 80, 120, 128, 240, 256, 300, 512]:
         for hmb in list(range(1, 80)) + [135, 136, 160, 320]:
             nw, ring, ring_last, nb, lds = I32(), I32(), I32(), I32(), ctypes.c_int64()
             assert f(wmb, hmb, ctypes.byref(nw), ctypes.byref(ring), ctypes.byref(ring_last), ctypes.byref(nb), ctypes.byref(lds)) == 0
-            groups = (hmb + 3) // 4
+            groups = (hmb + 7) // 8
             rounds = (groups + nw.value - 1) // nw.value
             assert 1 <= nw.value <= min(maxw, groups) and lds.value <= 160 * 1024, (wmb, hmb, nw.value, lds.value)
-            assert lds.value == 1552 + nw.value * 4800 + ((nw.value - 1) * ring.value + ring_last.value * nb.value) * 96
+            assert lds.value == 512 + nw.value * wave_bytes + ((nw.value - 1) * ring.value + ring_last.value * nb.value) * 96
             assert nb.value == (2 if rounds > 2 else 1)  # a single whole-row buffer deadlocks from three rounds on (test_deblock_schedule_model)
             assert 1 <= ring.value <= wmb and ring.value >= min(wmb, 16)
             assert ring_last.value == (wmb if rounds > 1 else ring.value), (wmb, hmb, nw.value, ring.value, ring_last.value)
-            if wmb <= 240:
-                assert nw.value == min(maxw, groups), (wmb, hmb, nw.value)
+            if groups <= 9:
+                assert nw.value == groups, (wmb, hmb, nw.value)  # one round whenever nine wavefronts are enough (with whole-row rings fewer fit)
+    assert f(120, 68, ctypes.byref(nw), ctypes.byref(ring), ctypes.byref(ring_last), ctypes.byref(nb), ctypes.byref(lds)) == 0
+    assert (nw.value, nb.value) == (9, 1)  # 1080p: one round of nine wavefronts
+
 
 class _Bits:
     """MSB-first bit writer for hand-assembled parameter sets."""

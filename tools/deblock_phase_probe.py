@@ -2,7 +2,7 @@
 """Where a K5 step spends its time: shader clocks per phase of the wavefront of group 0 of every picture, from a -DMI_DB_STATS build.
 Usage: deblock_phase_probe.py [streams] [frames]   (1 stream: the banded kernel k_deblock_x on one picture; 256 streams: k_deblock proper,
 one workgroup per picture, every CU busy -- the launch shape of the bench).  Build first (no GPU needed):
-  make -C h264decode_amd/csrc EXTRA=-DMI_DB_STATS BUILD=_build_stats OUT=../libh264mi_stats.so
+  make -C h264decode_amd/csrc EXTRA="-DMI_DB_STATS -DH264MI_TEST_HOOKS" BUILD=_build_stats OUT=../libh264mi_stats.so
 then on the GPU box: H264MI_LIB=h264decode_amd/libh264mi_stats.so python tools/deblock_phase_probe.py"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -14,7 +14,7 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 F = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 s, rec, _ = streamgen.encode(want_recon=True, **streamgen.recipe("C3", frames=F, idr_period=F, seed=1000, width=1920, height=1080))
 dec = H.Decoder(max_streams=S, max_width=1920, max_height=1088, max_frames_per_batch=F, max_slices_per_frame=1)
-f = H.load().h264mi_internal_deblock_phase_clocks
+f = H.load().h264mi_internal_deblock_phase_clocks  # (H264MI_LIB = the -DMI_DB_STATS -DH264MI_TEST_HOOKS build)
 f.restype, f.argtypes = ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
 buf = (ctypes.c_uint32 * 12)()
 dec.decode([s] * S)
