@@ -458,6 +458,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the c5_share (32 streams per GPU) and single_stream (C3: 1 stream x 300 frames) measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--serialized", action="store_true", help="profiling aid: the timed passes run in the library's profiling mode (stages back to back on one stream), so that "
+                                                              "a kernel trace of this command shows uncontended kernel durations -- the quantity `roofline.launch_ms` is; `value` is then not the contract's")
     ap.add_argument("--max-ref-frames", type=int, default=0, help="h264mi_config.max_ref_frames of the bench decoder (0 = the default of 16 reference slots per stream; "
                     "the synthetic streams use 1: 4 would save 9.6 GB of the 151 GB)")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous check only: every rank joins the process group, the closing all-reduce runs and rank 0 "
@@ -567,7 +569,7 @@ def main():
 
     # ---- timed region: K passes enqueued back to back; inside the library the entropy kernels of
     # pass n+1 (own HIP stream, second MbRec/coefficient buffer set) overlap reconstruction of pass n ----
-    dec.set_profiling(False)
+    dec.set_profiling(bool(args.serialized))
     for _ in range(args.warmup):
         dec.execute()
     dec.sync()
@@ -715,7 +717,7 @@ def main():
                                    "frac": round(v[1] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if v[0] > 0 else 0.0} for k, v in per_launch.items()},
                 "k_intra_note": "I-picture launch only (launch 0 of the GOP); its P-picture launches take %.3f ms each" % float(np.mean(lt["intra"][1:])) if len(lt["intra"]) > 1 else ""}
 
-    cpu_baseline = None
+    cpu_baseline, bins_per_frame = None, None
     if not args.no_cpu_baseline and world == 1:  # reported on rank 0 at N=1 only
         import oracle
         sample = streams[0]
@@ -737,6 +739,7 @@ def main():
         tmt = time.perf_counter() - t1
         cpu_baseline["all_cores"] = {"value": round(ncore * F / tmt, 2), "unit": "frames/s", "cores": ncore,
                                      "sample": "%d streams (one per core) x %d frames" % (ncore, F)}
+        bins_per_frame = float(sinfo.n_bins) / max(1, int(sinfo.n_frames))  # the checker's count of the CABAC bins of stream 0 (bins/s beside bits/s)
 
     out = {
         "metric": "1080p Main CABAC frames/sec",
@@ -762,7 +765,12 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "entropy_stage": {"bits_per_s": round(bytes_per_frame * 8 * S * F / (kt["entropy"] * 1e-3), 0), "slices_in_flight": S * F,
-                          "kernel_ms": round(kt["entropy"], 3), "note": "k_entropy alone, one slice per wavefront; latency of the I slice bounds it"},
+                          "bins_per_s": round(bins_per_frame * S * F / (kt["entropy"] * 1e-3), 0) if bins_per_frame else None,
+                          "bins_per_s_per_wavefront": round(bins_per_frame / (kt["entropy"] * 1e-3), 0) if bins_per_frame else None,
+                          "bits_per_s_per_wavefront": round(bytes_per_frame * 8 / (kt["entropy"] * 1e-3), 0),
+                          "kernel_ms": round(kt["entropy"], 3),
+                          "note": "k_entropy + k_dbprep of a pass, one slice per wavefront, every slice resident for the whole kernel (the I slice's latency bounds it): per-wavefront rates are "
+                                  "the average slice's; bins: the checker's count for stream 0 in the cpu_baseline leg x streams (null without that leg)"},
         "end_to_end_fps": round(S * F / e2e_s, 2),
         "k_pack": k_pack,
         "pipelined_ingest_fps": round(pipelined_fps, 2),

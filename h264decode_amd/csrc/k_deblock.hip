@@ -177,19 +177,11 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
         const uint32_t stage0 = tile0 + 9 * T_BYTES;                                                           // 2 x 8 x sizeof(DbPrm)
         const int rows_here = min(8, hmb - g * 8);                                                              // valid sub-rows of this group
         // luma load lane
-        const int ll_row = lane >> 2, ll_col = lane & 3;
-        const uint32_t ll_src = y_off + static_cast<uint32_t>(g * 128 + ll_row) * W + ll_col * 16; // + k * 16 W + column base * 16
-        const uint32_t ll_dst = tile0 + T_BYTES + ll_col * 256 + ll_row * 16;                      // + k * T_BYTES  (slot = column & 3 = ll_col)
+        const uint32_t ll_src = y_off + static_cast<uint32_t>(g * 128 + (lane >> 2)) * W + (lane & 3) * 16; // + k * 16 W + column base * 16
         // chroma load lane
-        const int lc_half = lane >> 5, lc_rr = (lane & 31) >> 1, lc_q = lane & 1;
-        const uint32_t lc_src = (lc_rr >> 3 ? cr_off : cb_off) + static_cast<uint32_t>(g * 64 + lc_half * 32 + (lc_rr & 7)) * Wc + lc_q * 16; // + k * 8 Wc + column base * 8
-        const uint32_t lc_dst = tile0 + T_BYTES + lc_half * 4 * T_BYTES + T_CHROMA + (lc_rr & 7) * 16 + (lc_rr >> 3) * 8;                     // + k * T_BYTES + slot * 128
+        const uint32_t lc_src = ((lane & 16) ? cr_off : cb_off) + static_cast<uint32_t>(g * 64 + (lane >> 5) * 32 + ((lane >> 1) & 7)) * Wc + (lane & 1) * 16; // + k * 8 Wc + column base * 8
         // luma store lane (instruction i: sub-rows par + 4 i and par + 4 i + 2)
-        const int sl_half = lane >> 5, sl_row = (lane & 31) >> 1, sl_col = lane & 1;
-        const uint32_t sl_sel = (sl_row & 1) ? 0x07050301u : 0x06040200u; // this row of a row pair's 2x2 blocks
         // chroma store lane (sub-rows par, par + 2, par + 4, par + 6)
-        const int sc_q = lane >> 4, sc_plane = (lane >> 3) & 1, sc_row = lane & 7;
-        const uint32_t sc_sel = sc_plane ? 0x07060302u : 0x05040100u;
         // DbPrm lane
         const int lp_sub = lane < 40 ? lane / 5 : 7, lp_piece = lane < 40 ? lane % 5 : 0;
         const uint32_t lp_row = static_cast<uint32_t>(min(g * 8 + lp_sub, hmb - 1)) * static_cast<uint32_t>(wmb);
@@ -227,6 +219,16 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             const int mby = g * 8 + s;
             const bool row_ok = mby < hmb, has_top = mby > 0;
             const int mbx = t - s;
+            // (the lanes' roles in the cooperative transfers are re-derived from the lane number in every step: as loop invariants their predicates would sit in scalar
+            // register pairs for the whole kernel -- which the compiler then spills into VGPR lanes)
+            const int ll_row = lane >> 2, ll_col = lane & 3;
+            const uint32_t ll_dst = tile0 + T_BYTES + ll_col * 256 + ll_row * 16;                      // + k * T_BYTES  (slot = column & 3 = ll_col)
+            const int lc_half = lane >> 5, lc_rr = (lane & 31) >> 1, lc_q = lane & 1;
+            const uint32_t lc_dst = tile0 + T_BYTES + lc_half * 4 * T_BYTES + T_CHROMA + (lc_rr & 7) * 16 + (lc_rr >> 3) * 8;                     // + k * T_BYTES + slot * 128
+            const int sl_half = lane >> 5, sl_row = (lane & 31) >> 1, sl_col = lane & 1;
+            const uint32_t sl_sel = (sl_row & 1) ? 0x07050301u : 0x06040200u; // this row of a row pair's 2x2 blocks
+            const int sc_q = lane >> 4, sc_plane = (lane >> 3) & 1, sc_row = lane & 7;
+            const uint32_t sc_sel = sc_plane ? 0x07060302u : 0x05040100u;
             const bool active = row_ok && mbx >= 0 && mbx < wmb;
             // LDS addresses: this sub-row's window (index s + 1 of the wavefront's nine), the window above, the slots of columns x and x - 1
             const uint32_t tile = MI_DEBLOCK8_HDR_BYTES + static_cast<uint32_t>(wave) * MI_DEBLOCK8_WAVE_BYTES + static_cast<uint32_t>(s + 1) * T_BYTES;
