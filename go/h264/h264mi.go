@@ -333,6 +333,7 @@ type Config struct {
 	MaxBitstreamBytes                                                              int64
 	MaxRefFrames, CoefBlocksPerMb                                                  int // 0 = defaults (16 reference slots per stream, 8 residual blocks per macroblock)
 	BPictures                                                                      int // 1 = the buffers only B pictures need exist from the start (h264mi_config.b_pictures)
+	AllowUnpinnedFieldCabac                                                        int // 1 = CABAC field pictures are decoded with the unpinned context tables (h264mi_config.allow_unpinned_field_cabac)
 }
 type Decoder struct{ h *C.h264mi_decoder }
 type BatchInfo struct {
@@ -345,7 +346,7 @@ func NewDecoder(cfg Config) (*Decoder, error) {
 	c := C.h264mi_config{struct_size: C.uint32_t(C.sizeof_h264mi_config), device: C.int32_t(cfg.Device), max_streams: C.int32_t(cfg.MaxStreams), max_width: C.int32_t(cfg.MaxWidth),
 		max_height: C.int32_t(cfg.MaxHeight), max_frames_per_batch: C.int32_t(cfg.MaxFramesPerBatch),
 		max_slices_per_frame: C.int32_t(cfg.MaxSlicesPerFrame), max_bitstream_bytes: C.int64_t(cfg.MaxBitstreamBytes),
-		max_ref_frames: C.int32_t(cfg.MaxRefFrames), coef_blocks_per_mb: C.int32_t(cfg.CoefBlocksPerMb), b_pictures: C.int32_t(cfg.BPictures)}
+		max_ref_frames: C.int32_t(cfg.MaxRefFrames), coef_blocks_per_mb: C.int32_t(cfg.CoefBlocksPerMb), b_pictures: C.int32_t(cfg.BPictures), allow_unpinned_field_cabac: C.int32_t(cfg.AllowUnpinnedFieldCabac)}
 	d := &Decoder{}
 	if err := status(C.h264mi_decoder_create(&c, &d.h)); err != nil {
 		return nil, err

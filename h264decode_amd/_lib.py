@@ -121,6 +121,7 @@ def load():
         "h264mi_decoder_set_profiling": [vp, I32],
         "h264mi_decoder_memory": [vp, P(ctypes.c_int64)],
         "h264mi_decoder_coef_pool": [vp, P(ctypes.c_int64), P(ctypes.c_int64)],
+        "h264mi_decoder_unpinned_failures": [vp, P(ctypes.c_int64)],
         "h264mi_last_kernel_times": [vp, P(ctypes.c_double)],
         "h264mi_last_launch_times": [vp, I32, P(ctypes.c_float), I32, P(I32)],
     }
@@ -148,5 +149,5 @@ EXPORTS = ["h264mi_annexb_scan", "h264mi_nal_parse", "h264mi_sps_parse", "h264mi
            "h264mi_batch_prepare", "h264mi_batch_execute", "h264mi_batch_sync", "h264mi_decode_batch", "h264mi_stream_frame_count",
            "h264mi_frame_device_planes", "h264mi_frame_read", "h264mi_frame_pack_device", "h264mi_frame_read_mbrecs",
            "h264mi_decoder_set_profiling", "h264mi_last_kernel_times", "h264mi_last_error_string", "h264mi_version",
-           "h264mi_last_launch_times", "h264mi_batch_pack_device", "h264mi_stream_reset", "h264mi_stream_status", "h264mi_decoder_set_isolation", "h264mi_frame_get_info", "h264mi_stream_output_order", "h264mi_decoder_memory", "h264mi_frame_read_mbmv1", "h264mi_decoder_coef_pool",
+           "h264mi_last_launch_times", "h264mi_batch_pack_device", "h264mi_stream_reset", "h264mi_stream_status", "h264mi_decoder_set_isolation", "h264mi_frame_get_info", "h264mi_stream_output_order", "h264mi_decoder_memory", "h264mi_frame_read_mbmv1", "h264mi_decoder_coef_pool", "h264mi_decoder_unpinned_failures",
            "h264mi_slice_starts_picture", "h264mi_pps_slice_group_ids", "h264mi_map_unit_to_slice_group_map", "h264mi_mb_to_slice_group_map", "h264mi_next_mb_address"]

@@ -172,6 +172,7 @@ struct Ent {
     int qp, prev_dqp_nz, mbx, mby, cur_type, err;
     uint32_t qpw0, qpw1;     // QP_Y << 16 | QP_C(Cb) << 24 and QP_C(Cr) of the current QP_Y: the record's bytes 2..4 (set_qp)
     int cabac, islice, wmb, hmb;
+    int mono;                // chroma_format_idc 0 (h264/sps.go:226-243): no chroma syntax; the reconstruction's chroma planes are 128 by construction
     int cip, t8x8_mode, cqp_off0, cqp_off1, nref;
     uint64_t mb_base;
 #if MI_ENT_B
@@ -226,10 +227,12 @@ FI uint32_t cat_word0(int c) {
     c = c < 6 ? c : 0;
     return maxnum[c] | (cbf[c] - 64) << 8 | lim[c] << 16 | pm[c] << 20 | nlast[c] << 24;
 }
-FI uint32_t cat_word1(int c) {
+// (field pictures: the significance contexts of field-coded blocks -- ctxIdxOffset 277 / 338, 8x8 blocks 436 / 451; h264/slice.go:867-872 field_pic_flag)
+FI uint32_t cat_word1(int c, int field) {
     const uint32_t sig[6] = {105, 120, 134, 149, 152, 402}, last[6] = {166, 181, 195, 210, 213, 417}, ab[6] = {227, 237, 247, 257, 266, 426};
+    const uint32_t sigf[6] = {277, 292, 306, 321, 324, 436}, lastf[6] = {338, 353, 367, 382, 385, 451};
     c = c < 6 ? c : 0;
-    return sig[c] | last[c] << 10 | ab[c] << 20;
+    return (field ? sigf[c] : sig[c]) | (field ? lastf[c] : last[c]) << 10 | ab[c] << 20;
 }
 
 // ------------------------------------------------------------------ bit reader
@@ -1285,6 +1288,7 @@ FI void decode_mb(Ent &e, int skipped) {
             i16mode = (it - 1) & 3;
             cbp_chroma = ((it - 1) >> 2) % 3;
             cbp_luma = it >= 13 ? 15 : 0;
+            if (cbp_chroma && e.mono) e.err = 25, cbp_chroma = 0; // (no such mb_type in a monochrome stream)
         } else if (it == 25)
             type = MBT_IPCM;
         else {
@@ -1299,7 +1303,7 @@ FI void decode_mb(Ent &e, int skipped) {
             if (cabac) pos -= static_cast<uint32_t>(RFL(e.avail));
             seek(e, (pos + 7) & ~7u);
             uint32_t *pcm = reinterpret_cast<uint32_t *>(s->coef);
-            for (int i = 0; i < 96; i++) pcm[i] = __builtin_bswap32(get_bits(e, 32)); // 384 sample bytes in stream order
+            for (int i = 0; i < 96; i++) pcm[i] = (e.mono && i >= 64) ? 0x80808080u : __builtin_bswap32(get_bits(e, 32)); // 384 sample bytes in stream order (monochrome: 256; chroma 128)
             if (cabac) cabac_start(e);
             for (int i = 0; i < 16; i++) {
                 s->nnz_c[GI(i & 3, i >> 2)] = 16, s->ref_c[0][GI(i & 3, i >> 2)] = -1;
@@ -1473,7 +1477,9 @@ FI void decode_mb(Ent &e, int skipped) {
                     }
                     if (LANE < 30) s->ipm_c[LANE] = static_cast<int8_t>(e.v_ipm); // for the record / neighbour write-out
                 }
-                if (cabac) {
+                if (e.mono)
+                    chroma_mode = 0; // ChromaArrayType 0: no intra_chroma_pred_mode (K3 predicts the DC of planes that are 128 everywhere)
+                else if (cabac) {
                     int inc = (a.ok() && MB_IS_INTRA(a.type()) && a.type() != MBT_IPCM && a.chroma_mode() != 0) +
                               (b.ok() && MB_IS_INTRA(b.type()) && b.type() != MBT_IPCM && b.chroma_mode() != 0);
                     chroma_mode = 0;
@@ -1503,14 +1509,15 @@ FI void decode_mb(Ent &e, int skipped) {
                         cbp |= BINI_B(e, 73 + (!ca) + 2 * (!cb)) << b8;
                     }
                     int ca = a.ok() && (a.type() == MBT_IPCM || (a.cbp() >> 4) != 0), cb = b.ok() && (b.type() == MBT_IPCM || (b.cbp() >> 4) != 0);
-                    if (BIN_B(e, 77 + ca + 2 * cb)) {
+                    if (!e.mono && BIN_B(e, 77 + ca + 2 * cb)) { // (ChromaArrayType 0: the prefix only)
                         ca = a.ok() && (a.type() == MBT_IPCM || (a.cbp() >> 4) == 2);
                         cb = b.ok() && (b.type() == MBT_IPCM || (b.cbp() >> 4) == 2);
                         cbp |= (1 + BINI_B(e, 77 + 4 + ca + 2 * cb)) << 4;
                     }
                 } else {
                     uint32_t k = get_ue(e);
-                    if (k > 47) e.err = 23, k = 0;
+                    if (k > (e.mono ? 15u : 47u)) e.err = 23, k = 0;
+                    if (e.mono) k += 48; // the ChromaArrayType 0 column of Table 9-4 (h264/bit_reader.go:118-135) sits behind the 48 entries of the other
                     cbp = RFL(static_cast<int>(MB_IS_INTRA(type) ? e.tab->me_intra[k] : e.tab->me_inter[k]));
                 }
                 cbp_luma = cbp & 15, cbp_chroma = cbp >> 4;
@@ -1761,9 +1768,10 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
     }
     // coefficient scans of the picture (8.5.6, 8.5.7): zig-zag, or the field scan in a field picture (h264/slice.go:867-872 field_pic_flag)
     const uint8_t *scan4 = pd->field ? tab->fieldscan4 : tab->zigzag4, *scan8 = pd->field ? tab->fieldscan8 : tab->zigzag8;
-    e.v_maps = tab->sig8x8[l] | (tab->last8x8[l] << 8) | (scan8[l] << 16) | (static_cast<uint32_t>(scan4[l & 15]) << 24);
+    e.v_maps = (pd->field ? tab->sig8x8_field[l] : tab->sig8x8[l]) | (tab->last8x8[l] << 8) | (scan8[l] << 16) | (static_cast<uint32_t>(scan4[l & 15]) << 24);
     e.v_pos = scan4[l & 15] | (scan4[(l + 1) & 15] << 8) | (scan8[l] << 16) | (static_cast<uint32_t>(l) << 24);
-    e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l); // (CAVLC slices: v_cat0 is replaced by the run_before tables below, one entry per lane)
+    e.mono = RFL(static_cast<int>(pd->mono));
+    e.v_cat0 = cat_word0(l), e.v_cat1 = cat_word1(l, pd->field != 0); // (CAVLC slices: v_cat0 is replaced by the run_before tables below, one entry per lane)
     e.v_qpc = tab->qpc[l < 52 ? l : 51];
     set_qp(e, RFL(static_cast<int>(sd->slice_qp)));
     e.v_step = step_word(l);

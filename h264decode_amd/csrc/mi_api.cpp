@@ -130,13 +130,14 @@ static void build_tables(DevTables *t) {
                 t->ctx_init[set][qp][i] = pre <= 63 ? static_cast<uint8_t>(63 - pre) : static_cast<uint8_t>((pre - 64) | 64);
             }
     memcpy(t->sig8x8, mi_sig8x8_ctx, 63);
+    memcpy(t->sig8x8_field, mi_sig8x8_field_ctx, 63);
     memcpy(t->last8x8, mi_last8x8_ctx, 63);
     memcpy(t->zigzag4, mi_zigzag4x4, 16);
     memcpy(t->zigzag8, mi_zigzag8x8, 64);
     memcpy(t->fieldscan4, mi_fieldscan4x4, 16);
     memcpy(t->fieldscan8, mi_fieldscan8x8, 64);
-    memcpy(t->me_intra, mi_me_intra, 48);
-    memcpy(t->me_inter, mi_me_inter, 48);
+    memcpy(t->me_intra, mi_me_intra, 48), memcpy(t->me_intra + 48, mi_me_intra0, 16);
+    memcpy(t->me_inter, mi_me_inter, 48), memcpy(t->me_inter + 48, mi_me_inter0, 16);
     memcpy(t->alpha, mi_alpha, 52);
     memcpy(t->beta, mi_beta, 52);
     for (int i = 0; i < 52; i++) {
@@ -325,6 +326,7 @@ struct h264mi_decoder {
     unsigned long long *d_xring = nullptr; // K5: x_cap * (Wmax / 16) * 24 granules
     uint32_t *d_xdone = nullptr;           // K3: x_cap * (Wmax / 16) flag words
     int k5_max_waves = MI_DEBLOCK8_MAX_WAVES;
+    int64_t unpinned_failures = 0; // slices of CABAC field pictures that failed in the entropy kernel (h264mi_decoder_unpinned_failures)
     uint32_t *d_xctl = nullptr, *h_xstatus = nullptr; // [0] K5 tickets, [32] K3 tickets, [64] give-up code (128-byte lines of their own)
     uint32_t x_epoch = 0, x_tk5 = 0, x_tk3 = 0;
     int x_max_wgs = 256, x_cap = 512, x_cap3 = 512; // workgroups per launch: default; capacity of the K5 ring; of the K3 flag array
@@ -631,10 +633,6 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg_, h264mi_decod
     TRY_ALLOC(hipMemset(d->d_xring, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long)));
     TRY_ALLOC(hipMemset(d->d_xdone, 0, static_cast<size_t>(d->x_cap3) * (d->Wmax / 16) * sizeof(uint32_t)));
     TRY_ALLOC(hipMemset(d->d_xctl, 0, 3 * 128));
-    if (d->x_tk5) { // (H264MI_X_EPOCH0: the device-side ticket counters start where the host's bases do)
-        TRY_ALLOC(hipMemcpy(d->d_xctl, &d->x_tk5, sizeof(uint32_t), hipMemcpyHostToDevice));
-        TRY_ALLOC(hipMemcpy(d->d_xctl + 32, &d->x_tk3, sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
     build_tables(d->h_tables);
     d->h_pools.resize(S);
     for (int si = 0; si < S; si++) { // static per stream (kernels take the geometry of a picture from its PicDesc)
@@ -727,6 +725,13 @@ extern "C" int32_t h264mi_decoder_memory(h264mi_decoder *d, int64_t *device_byte
     *device_bytes = static_cast<int64_t>(d->dev_bytes);
     return H264MI_OK;
 }
+extern "C" int32_t h264mi_decoder_unpinned_failures(h264mi_decoder *d, int64_t *n) {
+    if (!d || !n) return H264MI_EINVAL;
+    GUARD(d);
+    *n = d->unpinned_failures;
+    return H264MI_OK;
+}
+
 extern "C" int32_t h264mi_decoder_coef_pool(h264mi_decoder *d, int64_t *used_blocks, int64_t *capacity_blocks) {
     if (!d || !used_blocks || !capacity_blocks) return H264MI_EINVAL;
     uint32_t heads[MI_SETS] = {0};
@@ -1342,8 +1347,11 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         set_error("stream %d: slice_type %d is out of scope (SP / SI slices)", si, sh.slice_type);
         return H264MI_EUNSUPPORTED;
     }
-    if (sps.chroma_format != 1 || sps.bit_depth_luma_minus8 || sps.bit_depth_chroma_minus8 || sps.qprime_y_zero_transform_bypass) {
-        set_error("stream %d: only 4:2:0 8-bit streams are supported (chroma_format_idc %d)", si, sps.chroma_format);
+    // chroma_format_idc 0 (monochrome; h264/sps.go:226-243 ChromaFormat, h264/slice.go:179-219 SubWidthC / SubHeightC): the entropy kernels leave out the
+    // chroma syntax (PicDesc::mono), and nothing else changes -- the frame pool starts out at 128, intra chroma prediction is the DC of planes that are
+    // 128 everywhere, inter prediction copies 128, the residual is zero and the filters leave constants alone: the chroma planes a 4:2:0 display expects
+    if (sps.chroma_format > 1 || sps.bit_depth_luma_minus8 || sps.bit_depth_chroma_minus8 || sps.qprime_y_zero_transform_bypass) {
+        set_error("stream %d: only 4:2:0 and monochrome 8-bit streams are supported (chroma_format_idc %d; 4:2:2 / 4:4:4 and more than 8 bits are out of scope)", si, sps.chroma_format);
         return H264MI_EUNSUPPORTED;
     }
     // frame_mbs_only_flag = 0 (h264/sps.go:316-322): the pictures are frames (decoded like progressive ones: map units are two macroblock rows
@@ -1354,12 +1362,12 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         return H264MI_EUNSUPPORTED;
     }
     if (sh.field_pic) {
-        if (pps.entropy_coding_mode) {
-            // ctxIdx 277..398 and 436..459 (significant_coeff_flag / last_significant_coeff_flag of field-coded blocks, Tables 9-19 .. 9-24): their
-            // initialisation values are not in this library's tables -- nothing in this repository or on its build machine pins them -- and a
-            // decoder with guessed tables would produce plausible, wrong pictures
-            set_error("stream %d: field pictures with CABAC are refused: the context initialisation values of field-coded blocks (ctxIdx 277-398, 436-459) are not "
-                      "in this library's tables; CAVLC field pictures are decoded", si);
+        if (pps.entropy_coding_mode && !d->cfg.allow_unpinned_field_cabac) {
+            // ctxIdx 277..398 and 436..459 (significant_coeff_flag / last_significant_coeff_flag of field-coded blocks, Tables 9-19 .. 9-24): the values in
+            // this library's tables were written down without the standard at hand and nothing on its build machine pins them (mi_cabac_mn.cpp) -- a
+            // decoder with wrong tables produces plausible, wrong pictures, so it takes an explicit request (h264mi_config.allow_unpinned_field_cabac)
+            set_error("stream %d: field pictures with CABAC are refused: the context initialisation values of field-coded blocks (ctxIdx 277-398, 436-459) in "
+                      "this library's tables are unpinned (h264mi_config.allow_unpinned_field_cabac = 1 decodes with them); CAVLC field pictures are decoded", si);
             return H264MI_EUNSUPPORTED;
         }
         if (ref_idc && type != 5 && sh.adaptive_ref_pic_marking_mode_flag)
@@ -1464,6 +1472,7 @@ static int add_slice(h264mi_decoder *d, int si, size_t off, size_t rlen, int ref
         g.mb_used += static_cast<uint64_t>(wmb) * hmb_pic;
         pd.first_slice = g.n_slices;
         pd.cabac = pps.entropy_coding_mode, pd.t8x8_mode = pps.transform_8x8_mode, pd.cip = pps.constrained_intra_pred;
+        pd.mono = sps.chroma_format == 0;
         pd.weighted_pred = pps.weighted_pred;
         pd.cqp_off[0] = static_cast<int8_t>(pps.chroma_qp_index_offset), pd.cqp_off[1] = static_cast<int8_t>(pps.second_chroma_qp_index_offset);
         pd.is_intra_only = 1;
@@ -1658,9 +1667,12 @@ static int harvest_status(h264mi_decoder *d, Stage &g) {
             // the stream was reset (h264mi_decoder_reset / h264mi_stream_reset: a new connection took the slot, or the caller started over) after this
             // batch was prepared: what failed in it is not a property of what the slot decodes now
             if (g.h_pics[sd.pic_idx].stream < g.epochs.size() && g.epochs[g.h_pics[sd.pic_idx].stream] != s.epoch) continue;
+            const bool field_cabac = g.h_pics[sd.pic_idx].field != 0 && g.h_pics[sd.pic_idx].cabac != 0;
+            if (field_cabac) d->unpinned_failures++; // what a wrong value in the unpinned context tables looks like: the slice does not end on end_of_slice_flag where it should
             if (result == H264MI_OK)
-                set_error("entropy kernel: slice %d (picture %u, stream %u) failed with code %u after %u macroblocks", i, sd.pic_idx, g.h_pics[sd.pic_idx].stream,
-                          g.h_status[8 * i], g.h_status[8 * i + 1]);
+                set_error("entropy kernel: slice %d (picture %u, stream %u) failed with code %u after %u macroblocks%s", i, sd.pic_idx, g.h_pics[sd.pic_idx].stream,
+                          g.h_status[8 * i], g.h_status[8 * i + 1],
+                          field_cabac ? " -- a CABAC field picture: the context values of field-coded blocks are unpinned (h264mi_config.allow_unpinned_field_cabac)" : "");
             if (s.status == H264MI_OK || s.status_batch != &g) { // first failure of the stream in this batch
                 s.status = H264MI_EDECODE, s.status_batch = &g;
                 for (auto &sl : s.slots) sl.ref = 0;
@@ -2485,7 +2497,13 @@ extern "C" int32_t h264mi_internal_band_plan(int32_t n_pics, int32_t wmb, int32_
 extern "C" int32_t h264mi_internal_set_epoch(h264mi_decoder *d, uint32_t v) {
     if (!d) return H264MI_EINVAL;
     GUARD(d);
+    for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(d->ent_stream[i]));
+    HIP_TRY(hipStreamSynchronize(d->rec_stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
     d->x_epoch = d->x_tk5 = d->x_tk3 = v;
+    // the device-side ticket counters stand where the host's bases do
+    HIP_TRY(hipMemcpy(d->d_xctl, &d->x_tk5, sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d->d_xctl + 32, &d->x_tk3, sizeof(uint32_t), hipMemcpyHostToDevice));
     return H264MI_OK;
 }
 #endif /* H264MI_TEST_HOOKS */

@@ -541,8 +541,9 @@ int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc
         }
     }
     if ((p->weighted_pred && (st == 0 || st == 3)) || (p->weighted_bipred == 1 && st == 1)) { // pred_weight_table()
+        const bool chroma = s->chroma_format != 0; // ChromaArrayType != 0: chroma_log2_weight_denom and the chroma weights are there (monochrome: h264/sps.go:226-243)
         sh->luma_log2_weight_denom = UE(7);
-        sh->chroma_log2_weight_denom = UE(7);
+        sh->chroma_log2_weight_denom = chroma ? UE(7) : 0;
         if (bad) return H264MI_EBITSTREAM;
         for (int l = 0; l < (st == 1 ? 2 : 1); l++) {
             const int n = l ? sh->num_ref_idx_l1_active_minus1 : sh->num_ref_idx_l0_active_minus1;
@@ -559,7 +560,7 @@ int parse_slice_header(const h264mi_sps *s, const h264mi_pps *p, int nal_ref_idc
                     lo[i] = b.se();
                     if (lw[i] < -128 || lw[i] > 127 || lo[i] < -128 || lo[i] > 127) return H264MI_EBITSTREAM;
                 }
-                cf[i] = b.u(1);
+                cf[i] = chroma ? b.u(1) : 0;
                 if (cf[i])
                     for (int j = 0; j < 2; j++) {
                         cw[i][j] = b.se();

@@ -154,7 +154,7 @@ typedef struct {
     uint8_t has_b;         /* the picture has B slices: MbMv1 records exist, K4 runs its two-list variant */
     uint8_t save_col;      /* a later B picture (or batch) may ask for this picture's motion: k_dbprep also writes its ColRec array */
     uint8_t fmo;           /* more than one slice group: sgmap_off is valid, the records are zeroed before the entropy kernels run */
-    uint8_t pad[1];
+    uint8_t mono;          /* chroma_format_idc 0: the entropy kernels parse no chroma syntax (h264/sps.go:226-243) */
     uint32_t sgmap_off;    /* byte offset of the picture's mbToSliceGroupMap (8.2.2.8, one byte per macroblock) in the bitstream buffer */
     uint32_t inv_wmb;      /* floor(2^32 / wmb) + 1: mby = mulhi(mb, inv_wmb) is exact for mb < 2^32 / wmb / wmb (wmb <= 512, hmb <= 320) */
     /* Where the picture's samples are in its frame slot.  A frame: pitch = 16 wmb, plane = 16 wmb x 16 hmb.  A field picture
@@ -218,9 +218,10 @@ typedef struct {
     uint8_t trans_lps[64];    /* Table 9-45 */
     uint8_t ctx_init[4][52][464]; /* pStateIdx | valMPS << 6 for every (table set, SliceQPY, ctxIdx): 9.3.1.1 */
     uint8_t sig8x8[64], last8x8[64];
+    uint8_t sig8x8_field[64]; /* Table 9-43, field-coded 8x8 blocks (field pictures) */
     uint8_t zigzag4[16], zigzag8[64];
     uint8_t fieldscan4[16], fieldscan8[64]; /* Tables 8-12 / 8-13, field scan: what a field picture's blocks are scanned in */
-    uint8_t me_intra[48], me_inter[48];
+    uint8_t me_intra[64], me_inter[64]; /* Table 9-4: [0..47] ChromaArrayType 1 / 2, [48..63] ChromaArrayType 0 / 3 */
     uint8_t alpha[52], beta[52], tc0[52][4];
     uint8_t qpc[52];
     uint16_t vlc_c[MI_VLC_N]; /* the compact CAVLC tables (see MI_VLC_*) */

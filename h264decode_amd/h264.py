@@ -201,11 +201,12 @@ class Decoder:
     """Batched GPU decoder: N independent Annex-B streams side by side on one MI355X."""
 
     def __init__(self, max_streams=1, max_width=1920, max_height=1088, max_frames_per_batch=32, max_slices_per_frame=8, device=0,
-                 max_bitstream_bytes=0, hip_stream=None, max_ref_frames=0, coef_blocks_per_mb=0, b_pictures=0):
+                 max_bitstream_bytes=0, hip_stream=None, max_ref_frames=0, coef_blocks_per_mb=0, b_pictures=0, allow_unpinned_field_cabac=0):
         L = _lib.load()
         cfg = _lib.Config()
         cfg.struct_size = ctypes.sizeof(cfg)
         cfg.b_pictures = b_pictures  # 1: the B-only buffers exist from the start (default: from the first B slice on)
+        cfg.allow_unpinned_field_cabac = allow_unpinned_field_cabac  # 1: CABAC field pictures are decoded with the unpinned context tables of field-coded blocks (default: refused)
         cfg.device, cfg.max_streams, cfg.max_width, cfg.max_height = device, max_streams, max_width, max_height
         cfg.max_frames_per_batch, cfg.max_slices_per_frame, cfg.max_bitstream_bytes = max_frames_per_batch, max_slices_per_frame, max_bitstream_bytes
         cfg.hip_stream = hip_stream
@@ -257,6 +258,12 @@ class Decoder:
         n = ctypes.c_int64()
         check(self._L.h264mi_decoder_memory(self._h, ctypes.byref(n)))
         return int(n.value)
+
+    def unpinned_failures(self):
+        """Slices of CABAC field pictures that failed in the entropy kernels so far (h264mi_decoder_unpinned_failures)."""
+        n = ctypes.c_int64()
+        check(self._L.h264mi_decoder_unpinned_failures(self._h, ctypes.byref(n)))
+        return n.value
 
     def coef_pool(self):
         """(used, capacity) of the residual-coefficient pool in 32-byte blocks (h264mi_decoder_coef_pool); call after sync()."""

@@ -197,6 +197,12 @@ typedef struct {
      * sees must find its co-located picture in the same batch or the one before (otherwise that stream is refused until its next IDR picture);
      * 1 = allocated at create time, motion kept from the first picture on. */
     int32_t b_pictures;
+    /* allow_unpinned_field_cabac: 1 = field pictures (h264/slice.go:867-872 field_pic_flag) coded with CABAC are decoded.  The default is a refusal
+     * (H264MI_EUNSUPPORTED): the initialisation values of the contexts only field-coded blocks use (ctxIdx 277-398, 436-459; four sets) were entered
+     * into this library's tables without the standard at hand and nothing pins them -- no third-party field-coded stream, no reference table on the
+     * build machine.  With a wrong value a slice loses synchronisation and does not end on end_of_slice_flag at the picture's last macroblock: such
+     * slices fail (H264MI_EDECODE, the stream waits for its next IDR picture) and are counted: h264mi_decoder_unpinned_failures. */
+    int32_t allow_unpinned_field_cabac;
 } h264mi_config;
 #define H264MI_CONFIG_INIT {(uint32_t)sizeof(h264mi_config)} /* h264mi_config cfg = H264MI_CONFIG_INIT; then set the fields */
 
@@ -303,6 +309,9 @@ int32_t h264mi_decoder_memory(h264mi_decoder *dec, int64_t *device_bytes);
  * H264MI_EDECODE, "code 40"); the environment variable H264MI_COEF_BLOCKS_PER_MB, read at create time, sizes it.  Call after
  * h264mi_batch_sync. */
 int32_t h264mi_decoder_coef_pool(h264mi_decoder *dec, int64_t *used_blocks, int64_t *capacity_blocks);
+/* Slices of CABAC field pictures (h264mi_config.allow_unpinned_field_cabac) that failed in the entropy kernels since the decoder was created: what a wrong
+ * value in the unpinned context tables of field-coded blocks looks like (a damaged stream looks the same). */
+int32_t h264mi_decoder_unpinned_failures(h264mi_decoder *dec, int64_t *n);
 
 const char *h264mi_last_error_string(void);
 const char *h264mi_version(void);

@@ -50,9 +50,11 @@ static int activate(h264o_decoder *d, const h264o_pps *pps) {
     if (!s->valid) return h264o_fail(d, "PPS %d refers to missing SPS %d", pps->pic_parameter_set_id, pps->seq_parameter_set_id);
     /* frame_mbs_only_flag = 0 is accepted as long as every picture is a frame and macroblock-adaptive coding is off (h264/sps.go:316-322,
      * h264/slice.go:867-872): such pictures decode like progressive ones, only the map units are two macroblock rows high */
-    if (s->chroma_format_idc != 1 || s->bit_depth_luma_minus8 || s->bit_depth_chroma_minus8 || (!s->frame_mbs_only_flag && s->mb_adaptive_frame_field_flag) ||
+    /* chroma_format_idc 0 (monochrome, h264/sps.go:226-243): decoded as 4:2:0 whose chroma planes are 128 -- nothing of them is in the stream, their intra
+     * prediction is the DC of planes that are 128 everywhere, their residual is zero */
+    if (s->chroma_format_idc > 1 || s->bit_depth_luma_minus8 || s->bit_depth_chroma_minus8 || (!s->frame_mbs_only_flag && s->mb_adaptive_frame_field_flag) ||
         s->qpprime_y_zero_transform_bypass_flag)
-        return h264o_fail(d, "unsupported SPS (need 4:2:0 8-bit, no MBAFF; chroma_format_idc=%d)", s->chroma_format_idc);
+        return h264o_fail(d, "unsupported SPS (need 4:2:0 or monochrome, 8-bit, no MBAFF; chroma_format_idc=%d)", s->chroma_format_idc);
     int wmb = s->pic_width_in_mbs_minus1 + 1, hmb = (s->pic_height_in_map_units_minus1 + 1) * (2 - s->frame_mbs_only_flag); /* h264/slice.go:159-176 */
     if (d->asps != s || wmb != d->wmb || hmb != d->fhmb || !d->mb) {
         free_pics(d);
@@ -697,12 +699,9 @@ static int decode_slice_nal(h264o_decoder *d, const h264o_nal *nal, const uint8_
     h264o_slice_header sh;
     int r = h264o_parse_slice_header(&d->br, nal->nal_ref_idc, nal->nal_unit_type, d->sps, d->pps, &sh);
     if (r < 0) return h264o_fail(d, "slice header parse error %d", r);
-    /* field pictures (PAFF): I, P and B fields, CAVLC, sliding-window marking and initial lists.  Out of scope for now: CABAC (the context
-     * tables of field-coded blocks, ctxIdx 277..398 and 436..459, are not in this tree), marking operations other than 1, and a
+    /* field pictures (PAFF): I, P and B fields, CAVLC and CABAC (the context values of field-coded blocks, ctxIdx 277..398 and 436..459, are UNPINNED:
+     * h264o_cabac_mn.c), sliding-window marking and initial lists.  Out of scope for now: marking operations other than 1, and a
      * co-located picture of the other shape (a B field whose RefPicList1[0] belongs to a frame-coded frame, or the reverse) */
-    if (sh.field_pic_flag) {
-        if (d->pps[sh.pic_parameter_set_id].entropy_coding_mode_flag) return h264o_fail(d, "field pictures with CABAC are out of scope");
-    }
     if (sh.slice_type > 2) return h264o_fail(d, "slice_type %d out of scope (I, P and B only)", sh.slice_type);
     if (sh.redundant_pic_cnt > 0) return 0; /* redundant coded pictures are ignored */
     const h264o_pps *pps = &d->pps[sh.pic_parameter_set_id];

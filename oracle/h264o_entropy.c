@@ -385,6 +385,7 @@ static int cabac_cbp(h264o_decoder *d) {
         int inc = (!ca) + 2 * (!cb);
         cbp |= h264o_cabac_decision(d, 73 + inc) << b8;
     }
+    if (!d->asps->chroma_format_idc) return cbp; /* ChromaArrayType 0: the prefix only */
     /* chroma: condTermFlagN = N available && (I_PCM || cbp_chroma != 0) */
     int ca = a && (a->type == MBT_IPCM || a->cbp_chroma != 0), cb = b && (b->type == MBT_IPCM || b->cbp_chroma != 0);
     if (h264o_cabac_decision(d, 77 + ca + 2 * cb)) {
@@ -452,13 +453,15 @@ static int cabac_residual(h264o_decoder *d, int16_t *coef, int cat, int maxnum, 
     int pos[64], n = 0, last = 0;
     for (int i = 0; i < maxnum - 1; i++) {
         int sctx, lctx;
+        /* field-coded blocks (field pictures, h264/slice.go:867-872) have significance contexts of their own: ctxIdxOffset 277 / 338 (436 / 451 for 8x8 blocks) and,
+         * for 8x8 blocks, the field column of Table 9-43 */
         if (cat == 5) {
-            sctx = 402 + h264o_sig8x8_ctx[i];
-            lctx = 417 + h264o_last8x8_ctx[i];
+            sctx = (d->field_pic ? 436 + h264o_sig8x8_field_ctx[i] : 402 + h264o_sig8x8_ctx[i]);
+            lctx = (d->field_pic ? 451 : 417) + h264o_last8x8_ctx[i];
         } else {
             int inc = cat == 3 ? (i < 2 ? i : 2) : i;
-            sctx = 105 + sig_off[cat] + inc;
-            lctx = 166 + sig_off[cat] + inc;
+            sctx = (d->field_pic ? 277 : 105) + sig_off[cat] + inc;
+            lctx = (d->field_pic ? 338 : 166) + sig_off[cat] + inc;
         }
         if (h264o_cabac_decision(d, sctx)) {
             pos[n++] = i;
@@ -972,6 +975,7 @@ static int decode_mb(h264o_decoder *d, int addr) {
         c->i16mode = (it - 1) & 3;
         c->cbp_chroma = ((it - 1) >> 2) % 3;
         c->cbp_luma = it >= 13 ? 15 : 0;
+        if (c->cbp_chroma && !d->asps->chroma_format_idc) return h264o_fail(d, "mb %d: Intra16x16 mb_type with chroma coefficients in a monochrome stream", addr);
     } else if (it == 25)
         c->type = MBT_IPCM;
     else
@@ -983,7 +987,8 @@ static int decode_mb(h264o_decoder *d, int addr) {
          * flush wrote, including its final '1' (9.3.4.5): 9 + #renorm-shifts bits were read for
          * (#shifts - 1) + 7 + 1 + 2 written.  pcm_alignment_zero_bit(s) follow directly. */
         while (b->pos & 7) h264o_u(b, 1);
-        for (int i = 0; i < 384; i++) c->pcm[i] = (uint8_t)h264o_u(b, 8);
+        const int mono = !d->asps->chroma_format_idc; /* 256 luma samples only; the chroma samples of the reconstruction are 128 */
+        for (int i = 0; i < 384; i++) c->pcm[i] = mono && i >= 256 ? 128 : (uint8_t)h264o_u(b, 8);
         if (cabac) h264o_cabac_init_engine(d);
         memset(m->nnz, 16, sizeof(m->nnz));
         m->nzmask = 0xFFFF;
@@ -1090,7 +1095,7 @@ static int decode_mb(h264o_decoder *d, int addr) {
                 if (n == 4) m->ipm[r + 1] = m->ipm[r + 4] = m->ipm[r + 5] = (int8_t)mode;
             }
         }
-        c->chroma_mode = cabac ? cabac_intra_chroma_mode(d) : (int)h264o_ue(b);
+        c->chroma_mode = !d->asps->chroma_format_idc ? 0 /* no intra_chroma_pred_mode: DC */ : (cabac ? cabac_intra_chroma_mode(d) : (int)h264o_ue(b));
         if (c->chroma_mode > 3) return h264o_fail(d, "mb %d: bad intra_chroma_pred_mode", addr);
         m->chroma_mode = (uint8_t)c->chroma_mode;
     }
@@ -1102,8 +1107,11 @@ static int decode_mb(h264o_decoder *d, int addr) {
             cbp = cabac_cbp(d);
         else {
             uint32_t k = h264o_ue(b);
-            if (k > 47) return h264o_fail(d, "mb %d: bad coded_block_pattern", addr);
-            cbp = MB_IS_INTRA(c->type) ? h264o_me_intra[k] : h264o_me_inter[k];
+            if (k > (d->asps->chroma_format_idc ? 47u : 15u)) return h264o_fail(d, "mb %d: bad coded_block_pattern", addr);
+            if (d->asps->chroma_format_idc)
+                cbp = MB_IS_INTRA(c->type) ? h264o_me_intra[k] : h264o_me_inter[k];
+            else
+                cbp = MB_IS_INTRA(c->type) ? h264o_me_intra0[k] : h264o_me_inter0[k];
         }
         c->cbp_luma = cbp & 15;
         c->cbp_chroma = cbp >> 4;

@@ -360,7 +360,7 @@ int h264o_parse_slice_header(h264o_br *b, int nal_ref_idc, int nal_unit_type, co
     /* pred_weight_table() 7.3.3.2 */
     if ((p->weighted_pred_flag && (sh->slice_type == 0 || sh->slice_type == 3)) || (p->weighted_bipred_idc == 1 && sh->slice_type == 1)) {
         sh->luma_log2_weight_denom = h264o_ue(b);
-        sh->chroma_log2_weight_denom = h264o_ue(b); /* ChromaArrayType != 0 */
+        sh->chroma_log2_weight_denom = s->chroma_format_idc ? h264o_ue(b) : 0; /* ChromaArrayType != 0 (monochrome: no chroma weights, h264/sps.go:226-243) */
         if (sh->luma_log2_weight_denom > 7 || sh->chroma_log2_weight_denom > 7) return -1;
 #define WP_BAD(v) ((v) < -128 || (v) > 127) /* 7.4.3.2: coded weights and offsets; the default weight 1 << denom is not coded */
         for (int i = 0; i <= sh->num_ref_idx_l0_active_minus1; i++) {
@@ -372,7 +372,7 @@ int h264o_parse_slice_header(h264o_br *b, int nal_ref_idc, int nal_unit_type, co
                 sh->luma_offset_l0[i] = h264o_se(b);
                 if (WP_BAD(sh->luma_weight_l0[i]) || WP_BAD(sh->luma_offset_l0[i])) return -1;
             }
-            sh->chroma_weight_l0_flag[i] = h264o_u(b, 1);
+            sh->chroma_weight_l0_flag[i] = s->chroma_format_idc ? h264o_u(b, 1) : 0;
             if (sh->chroma_weight_l0_flag[i])
                 for (int j = 0; j < 2; j++) {
                     sh->chroma_weight_l0[i][j] = h264o_se(b);
@@ -390,7 +390,7 @@ int h264o_parse_slice_header(h264o_br *b, int nal_ref_idc, int nal_unit_type, co
                     sh->luma_offset_l1[i] = h264o_se(b);
                     if (WP_BAD(sh->luma_weight_l1[i]) || WP_BAD(sh->luma_offset_l1[i])) return -1;
                 }
-                sh->chroma_weight_l1_flag[i] = h264o_u(b, 1);
+                sh->chroma_weight_l1_flag[i] = s->chroma_format_idc ? h264o_u(b, 1) : 0;
                 if (sh->chroma_weight_l1_flag[i])
                     for (int j = 0; j < 2; j++) {
                         sh->chroma_weight_l1[i][j] = h264o_se(b);

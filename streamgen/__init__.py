@@ -21,7 +21,7 @@ class Params(ctypes.Structure):
         ("idr_long_term", ctypes.c_int), ("nonref_period", ctypes.c_int), ("slice_qp_delta", ctypes.c_int), ("bframes", ctypes.c_int),
         ("direct_temporal", ctypes.c_int), ("weighted_bipred", ctypes.c_int), ("bskip_permille", ctypes.c_int),
         ("motion_x4", ctypes.c_int), ("motion_y4", ctypes.c_int), ("interlace_sps", ctypes.c_int), ("fn_gap_period", ctypes.c_int), ("fn_gap_declared", ctypes.c_int),
-        ("b_pyramid", ctypes.c_int), ("slice_groups", ctypes.c_int), ("fmo_type", ctypes.c_int), ("aso", ctypes.c_int), ("field_pics", ctypes.c_int), ("poc_bottom_delta", ctypes.c_int)]
+        ("b_pyramid", ctypes.c_int), ("slice_groups", ctypes.c_int), ("fmo_type", ctypes.c_int), ("aso", ctypes.c_int), ("field_pics", ctypes.c_int), ("poc_bottom_delta", ctypes.c_int), ("mono", ctypes.c_int)]
 
 
 def build(force=False):

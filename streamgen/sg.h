@@ -76,8 +76,8 @@ typedef struct {
      * field-coded frames and fields from the fields of frame-coded ones.  The first field of an IDR frame is the IDR
      * picture, its second field a P or I field of the same frame_num; all other fields are P fields whose RefPicList0
      * alternates between fields of the same and of the opposite parity (8.2.4.2.5) and may start with the first field of
-     * the same frame.  Forces interlace_sps; CAVLC only (the context tables of field-coded significance maps are not in
-     * this tree); sliding-window marking (counted in frames, 8.2.5.3), list modification on field picture numbers
+     * the same frame.  Forces interlace_sps; with cabac = 1 the field-coded blocks use the UNPINNED context values of sg_cabac_mn.c (ctxIdx 277..398,
+     * 436..459: written down without the standard at hand); sliding-window marking (counted in frames, 8.2.5.3), list modification on field picture numbers
      * (rplm, P fields), marking scripts of operation 1 on single fields (mmco: a frame then lacks a field in later lists, and
      * a frame picture that finds no frame with both fields marked is coded as an I picture), non-reference frames
      * (nonref_period) and slice groups (a map unit is one macroblock of a field, 8.2.2.8) allowed, no long-term pictures.  bframes with field_pics 1 / 2 (not 3): every B frame is two non-reference B fields (spatial or
@@ -89,6 +89,10 @@ typedef struct {
      * TopFieldOrderCnt + d.  PicOrderCnt of a frame is the smaller of the two (8.2.1): a negative d moves every non-IDR picture d
      * earlier (IDR pictures keep 0 = Min(top, bottom): they send Max(d, 0); a negative d is taken as -1, the value of bottom-field-first material: anything lower would put the first pictures of a sequence before their IDR picture).  Ignored with pic_order_cnt_type 2. */
     int poc_bottom_delta;
+    /* 1: chroma_format_idc 0 (monochrome; h264/sps.go:226-243 ChromaFormat; High profile only): no intra_chroma_pred_mode, coded_block_pattern by the
+     * ChromaArrayType 0 column of Table 9-4 (CABAC: no chroma bins), no chroma residual, 256 samples per I_PCM macroblock, no chroma weights.  The
+     * reconstruction carries chroma planes of 128 (what a decoder puts out for a 4:2:0 display). */
+    int mono;
 } sg_params;
 
 void sg_default_params(sg_params *p);

@@ -130,6 +130,7 @@ void sg_source_frame(const sg_params *p, int t, uint8_t *dst) {
             cb[j * (W / 2) + i] = (uint8_t)(a < 0 ? 0 : (a > 255 ? 255 : a));
             cr[j * (W / 2) + i] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
         }
+    if (p->mono) memset(cb, 128, (size_t)(W * H / 2)); /* monochrome: the chroma a decoder puts out, so that prediction and residual of the (uncoded) planes are trivially 128 and 0 */
 }
 
 /* ------------------------------------------------------------------ helpers */
@@ -306,11 +307,12 @@ static void cabac_block(enc *e, const int16_t *coef, int cat, int maxnum, int cb
     while (lastpos > 0 && !coef[lastpos]) lastpos--;
     for (int i = 0; i < maxnum - 1; i++) {
         int sctx, lctx;
+        /* field pictures: the significance contexts of field-coded blocks (ctxIdxOffset 277 / 338, 8x8 blocks 436 / 451 with the field column of Table 9-43) */
         if (cat == 5)
-            sctx = 402 + sg_sig8x8_ctx[i], lctx = 417 + sg_last8x8_ctx[i];
+            sctx = e->field ? 436 + sg_sig8x8_field_ctx[i] : 402 + sg_sig8x8_ctx[i], lctx = (e->field ? 451 : 417) + sg_last8x8_ctx[i];
         else {
             int inc = cat == 3 ? (i < 2 ? i : 2) : i;
-            sctx = 105 + sig_off[cat] + inc, lctx = 166 + sig_off[cat] + inc;
+            sctx = (e->field ? 277 : 105) + sig_off[cat] + inc, lctx = (e->field ? 338 : 166) + sig_off[cat] + inc;
         }
         sg_cabac_bin(w, sctx, coef[i] != 0);
         if (coef[i]) {
@@ -496,6 +498,7 @@ static void cabac_cbp(enc *e, int cbp) {
         int lb = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cb_ >> (b8 + 2)) & 1;
         sg_cabac_bin(w, 73 + (!la) + 2 * (!lb), (cbp >> b8) & 1);
     }
+    if (e->p.mono) return; /* ChromaArrayType 0: the prefix only */
     int cc = cbp >> 4;
     int fa = a && (a->type == T_PCM || a->cbp_chroma), fb = b && (b->type == T_PCM || b->cbp_chroma);
     sg_cabac_bin(w, 77 + fa + 2 * fb, cc != 0);
@@ -884,7 +887,7 @@ static void encode_intra(enc *e, int islice) {
         } else
             sg_put_ue(w, islice ? 25 : (e->slice_type == 1 ? 48 : 30));
         while (!sg_bw_aligned(w)) sg_put(w, 0, 1);
-        for (int i = 0; i < 384; i++) sg_put(w, e->pcm[i], 8);
+        for (int i = 0; i < (e->p.mono ? 256 : 384); i++) sg_put(w, e->pcm[i], 8);
         if (cabac) sg_cabac_start(w);
         set_qpc(e, m, e->qp); /* QP_Y unchanged across I_PCM */
         memset(m->nnz, 16, sizeof(m->nnz));
@@ -977,7 +980,7 @@ static void encode_intra(enc *e, int islice) {
     {
         uint8_t pred[2][64], tmp[2][64];
         int bs = 1 << 30, bm = 0;
-        for (int mode = 0; mode < 4; mode++) {
+        for (int mode = 0; mode < (e->p.mono ? 1 : 4); mode++) { /* (monochrome: no intra_chroma_pred_mode -- DC of planes that are 128 everywhere) */
             if (!sg_intra_mode_allowed(0, mode, &ma)) continue;
             int s = (int)(rnd(e) % 32);
             for (int c = 0; c < 2; c++) {
@@ -1037,7 +1040,9 @@ static void encode_intra(enc *e, int islice) {
             }
         }
     }
-    if (cabac) {
+    if (e->p.mono)
+        ; /* ChromaArrayType 0: no intra_chroma_pred_mode */
+    else if (cabac) {
         emb *a = MBA(e), *b = MBB(e);
         int inc = (a && IS_INTRA(a->type) && a->type != T_PCM && a->chroma_mode) + (b && IS_INTRA(b->type) && b->type != T_PCM && b->chroma_mode);
         sg_cabac_bin(w, 64 + inc, m->chroma_mode != 0);
@@ -1053,7 +1058,7 @@ static void encode_intra(enc *e, int islice) {
             cabac_cbp(e, cbp);
         else {
             int k = 0;
-            while (sg_me_intra[k] != cbp) k++;
+            while ((e->p.mono ? sg_me_intra0[k] : sg_me_intra[k]) != cbp) k++;
             sg_put_ue(w, (uint32_t)k);
         }
     }
@@ -1281,7 +1286,7 @@ static void encode_inter(enc *e, int kind) {
         cabac_cbp(e, cbp);
     else {
         int k = 0;
-        while (sg_me_inter[k] != cbp) k++;
+        while ((e->p.mono ? sg_me_inter0[k] : sg_me_inter[k]) != cbp) k++;
         sg_put_ue(w, (uint32_t)k);
     }
     if (m->cbp_luma && e->p.transform8x8 && all8) {
@@ -1693,7 +1698,7 @@ static void encode_b(enc *e, int kind) {
         cabac_cbp(e, cbp);
     else {
         int k = 0;
-        while (sg_me_inter[k] != cbp) k++;
+        while ((e->p.mono ? sg_me_inter0[k] : sg_me_inter[k]) != cbp) k++;
         sg_put_ue(w, (uint32_t)k);
     }
     if (m->cbp_luma && e->p.transform8x8 && all8) {
@@ -1734,7 +1739,7 @@ static size_t write_sps(enc *e, uint8_t *dst, size_t cap) {
     sg_put(&w, e->W * e->fH > 1920 * 1088 ? 51 : 40, 8);                            /* level_idc */
     sg_put_ue(&w, 0);                                                              /* sps id */
     if (p->profile_idc == 100) {
-        sg_put_ue(&w, 1); /* chroma_format_idc */
+        sg_put_ue(&w, p->mono ? 0 : 1); /* chroma_format_idc */
         sg_put_ue(&w, 0);
         sg_put_ue(&w, 0);
         sg_put(&w, 0, 1); /* qpprime_y_zero_transform_bypass */
@@ -1954,13 +1959,13 @@ static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int
         if (is_b) sg_put(w, 0, 1); /* ref_pic_list_modification_flag_l1 */
         if ((p->weighted_pred && !is_b) || (is_b && p->weighted_bipred == 1)) {
             sg_put_ue(w, (uint32_t)e->wp_ld);
-            sg_put_ue(w, (uint32_t)e->wp_cd);
+            if (!p->mono) sg_put_ue(w, (uint32_t)e->wp_cd); /* chroma_log2_weight_denom and the chroma weights: ChromaArrayType != 0 only */
             for (int i = 0; i < e->nref_active; i++) {
                 int lf = e->wp_w[i] != (1 << e->wp_ld) || e->wp_o[i];
                 sg_put(w, (uint32_t)lf, 1);
                 if (lf) sg_put_se(w, e->wp_w[i]), sg_put_se(w, e->wp_o[i]);
                 int cf = e->wp_cw[i][0] != (1 << e->wp_cd) || e->wp_co[i][0] || e->wp_cw[i][1] != (1 << e->wp_cd) || e->wp_co[i][1];
-                sg_put(w, (uint32_t)cf, 1);
+                if (!p->mono) sg_put(w, (uint32_t)cf, 1);
                 if (cf)
                     for (int c = 0; c < 2; c++) sg_put_se(w, e->wp_cw[i][c]), sg_put_se(w, e->wp_co[i][c]);
             }
@@ -1969,7 +1974,7 @@ static void write_slice_header(enc *e, int first_mb, int idr, int frame_num, int
                 sg_put(w, (uint32_t)lf, 1);
                 if (lf) sg_put_se(w, e->wb_w1[i]), sg_put_se(w, e->wb_o1[i]);
                 int cf = e->wb_cw1[i][0] != (1 << e->wp_cd) || e->wb_co1[i][0] || e->wb_cw1[i][1] != (1 << e->wp_cd) || e->wb_co1[i][1];
-                sg_put(w, (uint32_t)cf, 1);
+                if (!p->mono) sg_put(w, (uint32_t)cf, 1);
                 if (cf)
                     for (int c = 0; c < 2; c++) sg_put_se(w, e->wb_cw1[i][c]), sg_put_se(w, e->wb_co1[i][c]);
             }
@@ -2489,9 +2494,14 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
     /* a bottom field that comes first moves every picture but the IDR pictures (their PicOrderCnt is 0 by rule): by one only, so that the picture
      * sent with top count 2 still follows its IDR picture in output order and no two frames share a PicOrderCnt (8.2.1) */
     if (p->poc_bottom_delta < 0) p->poc_bottom_delta = -1;
+    if (p->mono && p->profile_idc != 100) {
+        snprintf(g_err, sizeof(g_err), "mono (chroma_format_idc 0) needs High profile");
+        free(e);
+        return 0;
+    }
     if (p->field_pics) { /* PAFF, every frame as two fields: see sg.h for what that excludes */
-        if (p->cabac || p->profile_idc == 66) {
-            snprintf(g_err, sizeof(g_err), "field_pics needs Main or High profile with cabac = 0 (the field-coded CABAC context tables are not in this tree)");
+        if (p->profile_idc == 66) { /* (with cabac = 1 the field-coded blocks use the UNPINNED context values of sg_cabac_mn.c: ctxIdx 277..398, 436..459) */
+            snprintf(g_err, sizeof(g_err), "field_pics needs Main or High profile");
             free(e);
             return 0;
         }
@@ -2721,6 +2731,9 @@ size_t sg_encode(const sg_params *pp, uint8_t *stream, size_t cap, uint8_t *reco
             }
             e->wb_w1[0] = 1 << wld, e->wb_o1[0] = 0;
         }
+        if (p->mono) /* no chroma weights in the stream: the planes of 128 stay 128 under the inferred unit weights */
+            for (int i = 0; i < 4; i++)
+                for (int c = 0; c < 2; c++) e->wp_cw[i][c] = e->wb_cw1[i][c] = 1 << e->wp_cd, e->wp_co[i][c] = e->wb_co1[i][c] = 0;
         for (int i = 0; i < e->wmb * e->hmb; i++) e->mb[i].type = T_NONE;
         /* the slices of this picture: (first macroblock, macroblock count), in the order they will be sent */
         int sl_first[512], sl_count[512], nsl = 0;

@@ -182,7 +182,7 @@ MATRIX = {
 # Field pictures (PAFF: every frame coded as two fields, or picture-adaptively as a frame or two fields).  The product decodes them (round 4):
 # the GPU parity tests run FULL_MATRIX = MATRIX + FIELD_MATRIX through every kernel-plan variant.  They are kept apart from MATRIX only because
 # a frame of these streams is two pictures (two access units, two decoder "pictures per batch"), which the CPU tests over MATRIX that count
-# access units or pictures would have to special-case.  CAVLC only: see sg.h (the CABAC context tables of field-coded blocks are not in this tree).
+# access units or pictures would have to special-case.  CAVLC here; the same recipes with CABAC: FIELD_CABAC_MATRIX below.
 FIELD_BASE = dict(width=176, height=128, frames=5, idr_period=0, profile_idc=77, cabac=0, field_pics=1)
 FIELD_MATRIX = {
     "field_IP": dict(FIELD_BASE, num_ref_frames=2, seed=301),
@@ -226,7 +226,26 @@ POC_MATRIX = {
 }
 
 MATRIX.update(POC_MATRIX)
+
+# Monochrome (chroma_format_idc 0; h264/sps.go:226-243 ChromaFormat, h264/slice.go:179-219 SubWidthC / SubHeightC; round 5, SURVEY 8f rank 4 first step): High
+# profile streams without any chroma syntax -- no intra_chroma_pred_mode, coded_block_pattern by the ChromaArrayType 0 column of Table 9-4
+# (h264/bit_reader.go:118-135; CABAC: the prefix only), 256 samples per I_PCM macroblock, no chroma weights.  Decoded pictures carry chroma planes of 128.
+MONO_MATRIX = {
+    "mono_cabac_8x8_pcm_wp": dict(BASE, profile_idc=100, mono=1, cabac=1, transform8x8=1, pcm_permille=30, weighted_pred=1, num_ref_frames=2, frames=5, seed=501),
+    "mono_cavlc_slices_pcm": dict(BASE, profile_idc=100, mono=1, cabac=0, pcm_permille=30, num_ref_frames=2, slices=2, deblock_idc=0, intra_in_p_permille=200, seed=502),
+    "mono_b_explicit_cabac": dict(BASE, profile_idc=100, mono=1, cabac=1, bframes=2, weighted_bipred=1, num_ref_frames=3, frames=8, bskip_permille=300, seed=503),
+    "mono_b_implicit_cavlc": dict(BASE, profile_idc=100, mono=1, cabac=0, bframes=1, weighted_bipred=2, frames=7, intra_in_p_permille=300, transform8x8=1, seed=504),
+    "mono_intra_only_scaling": dict(BASE, profile_idc=100, mono=1, cabac=1, idr_period=1, frames=3, scaling_matrix=1, transform8x8=1, pcm_permille=20, seed=505),
+    "mono_cropped_cavlc_qpel": dict(BASE, width=170, height=138, profile_idc=100, mono=1, cabac=0, motion_x4=5, motion_y4=-3, sub8x8_permille=300, num_ref_frames=2, seed=506),
+}
+MATRIX.update(MONO_MATRIX)
 FULL_MATRIX = dict(MATRIX, **FIELD_MATRIX)
+
+# The same 24 field recipes with CABAC (round 5).  Field-coded blocks have significance contexts of their own (ctxIdx 277-398, 436-459, the field column of
+# Table 9-43); their initialisation values in the three *_cabac_mn.* copies are UNPINNED (entered without the standard at hand, no third-party stream), so
+# the product decodes such pictures only with h264mi_config.allow_unpinned_field_cabac = 1.  What these cases pin: generator == oracle == GPU, i.e. the
+# mechanism (context offsets, field map, field scans under CABAC) -- not the values.
+FIELD_CABAC_MATRIX = {name + "_cabac": dict(kw, cabac=1) for name, kw in FIELD_MATRIX.items()}
 
 
 def pictures_of(kw):

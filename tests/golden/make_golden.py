@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(HERE, "..", ".."))
 sys.path.insert(0, os.path.join(HERE, ".."))
 import oracle  # noqa: E402
 import streamgen  # noqa: E402
-from conftest import FIELD_MATRIX, MATRIX, POC_MATRIX  # noqa: E402
+from conftest import FIELD_CABAC_MATRIX, FIELD_MATRIX, MATRIX, POC_MATRIX  # noqa: E402
 
 out = {}
 for name in sorted(MATRIX):
@@ -32,6 +32,16 @@ for name in sorted(FIELD_MATRIX):
     out[name] = {"stream_md5": hashlib.md5(s).hexdigest(), "frames_md5": hashlib.md5(frames.tobytes()).hexdigest(), "stream_bytes": len(s)}
 json.dump(out, open(os.path.join(HERE, "field_md5.json"), "w"), indent=1, sort_keys=True)
 print("wrote", len(out), "field vectors")
+
+# the same recipes with CABAC (unpinned context values of field-coded blocks: these vectors pin the mechanism and guard against drift, nothing more)
+out = {}
+for name in sorted(FIELD_CABAC_MATRIX):
+    s, rec, _ = streamgen.encode(**FIELD_CABAC_MATRIX[name])
+    frames, _ = oracle.decode(s, crop=False)
+    assert (frames == rec).all(), name
+    out[name] = {"stream_md5": hashlib.md5(s).hexdigest(), "frames_md5": hashlib.md5(frames.tobytes()).hexdigest(), "stream_bytes": len(s)}
+json.dump(out, open(os.path.join(HERE, "field_cabac_md5.json"), "w"), indent=1, sort_keys=True)
+print("wrote", len(out), "CABAC field vectors")
 
 # separate bottom-field picture order counts (CPU-checked cases: oracle, generator, and the product's host side against the null device)
 out = {}

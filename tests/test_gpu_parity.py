@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import BASE, FIELD_MATRIX, FULL_MATRIX, MATRIX, POC_MATRIX, PRODUCT_DECODES_B, pictures_of
+from conftest import BASE, FIELD_CABAC_MATRIX, FIELD_MATRIX, FULL_MATRIX, MATRIX, POC_MATRIX, PRODUCT_DECODES_B, pictures_of
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "stream_md5.json")
@@ -37,15 +37,15 @@ def _nslices(kw):
     return max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1))
 
 
-def _decode_gpu(H, streams, w, h, frames, slices=1, crop=False, x_wgs=None):
+def _decode_gpu(H, streams, w, h, frames, slices=1, crop=False, x_wgs=None, **cfg):
     with _x_wgs(x_wgs):
-        return _decode_gpu_(H, streams, w, h, frames, slices, crop)
+        return _decode_gpu_(H, streams, w, h, frames, slices, crop, **cfg)
 
 
-def _decode_gpu_(H, streams, w, h, frames, slices=1, crop=False):
+def _decode_gpu_(H, streams, w, h, frames, slices=1, crop=False, **cfg):
     W, Hc = (w + 15) // 16 * 16, (h + 15) // 16 * 16
     dec = H.Decoder(max_streams=len(streams), max_width=W, max_height=Hc, max_frames_per_batch=frames, max_slices_per_frame=max(1, slices),
-                    max_bitstream_bytes=sum(len(s) for s in streams) * 2 + (1 << 20))
+                    max_bitstream_bytes=sum(len(s) for s in streams) * 2 + (1 << 20), **cfg)
     info = dec.decode(streams)
     size = (w * h if crop else W * Hc) * 3 // 2
     out = [dec.read_frames(i, crop=crop, size=size) for i in range(len(streams))]
@@ -1006,10 +1006,43 @@ def test_gpu_field_and_frame_streams_share_a_batch(H, sg):
     dec.close()
 
 
+def test_gpu_cabac_field_pictures_on_request(H, sg, oracle_mod):
+    """CABAC field pictures with h264mi_config.allow_unpinned_field_cabac = 1: all 24 field recipes coded with CABAC, GPU == oracle == generator in both
+    kernel families (a picture inside one workgroup; banded), equal PicOrderCnt lists, the committed MD5s, and no slice counted as failed.  What this
+    pins is the mechanism -- the field contexts' offsets, the field column of Table 9-43, the field scans under CABAC --: the context VALUES are unpinned
+    (mi_cabac_mn.cpp), generator and oracle share them."""
+    gold = json.load(open(os.path.join(os.path.dirname(GOLDEN), "field_cabac_md5.json")))
+    assert set(gold) == set(FIELD_CABAC_MATRIX)
+    for name in sorted(FIELD_CABAC_MATRIX):
+        kw = FIELD_CABAC_MATRIX[name]
+        stream, rec, _ = sg.encode(**kw)
+        gen_pocs = sg.last_pocs().tolist()
+        ref, _ = oracle_mod.decode(stream, crop=False)
+        assert np.array_equal(ref, rec), name
+        for x in (None, 0, 512):
+            out, info = _decode_gpu(H, [stream], kw["width"], kw["height"], pictures_of(kw), _nslices(kw), x_wgs=x, allow_unpinned_field_cabac=1)
+            assert np.array_equal(out[0], rec), (name, x)
+            assert info.pocs[0] == gen_pocs, (name, x)
+        assert hashlib.md5(out[0].tobytes()).hexdigest() == gold[name]["frames_md5"], name
+    # the failure counter: a CABAC field slice cut short fails, is counted, and says why
+    kw = FIELD_CABAC_MATRIX["field_IP_cabac"]
+    stream, rec, _ = sg.encode(**dict(kw, slices=1))
+    nals = H.read_nal_units(stream)
+    last = nals[-1].Offset
+    broken = stream[:last + 8] + bytes(len(stream) - last - 8)  # the last field: slice header kept, slice data zeroed
+    dec = H.Decoder(max_streams=1, max_width=176, max_height=128, max_frames_per_batch=2 * kw["frames"], max_slices_per_frame=1, allow_unpinned_field_cabac=1)
+    assert dec.unpinned_failures() == 0
+    with pytest.raises(H.H264MIError) as e:
+        dec.decode([broken])
+    assert e.value.code == -8 and "unpinned" in str(e.value)
+    assert dec.unpinned_failures() == 1
+    dec.close()
+
+
 def test_gpu_field_pictures_with_cabac_are_refused_with_a_reason(H, sg):
-    """Field pictures with entropy_coding_mode_flag = 1 need the context initialisation values of field-coded blocks (ctxIdx 277-398, 436-459), which are not
-    in this tree: refused (H264MI_EUNSUPPORTED) with a message that says so -- not decoded with zeros.  The stream: a CAVLC field stream whose PPS is
-    patched to announce CABAC (the refusal comes at the first slice header, before any slice data is looked at)."""
+    """Field pictures with entropy_coding_mode_flag = 1 need the context initialisation values of field-coded blocks (ctxIdx 277-398, 436-459), which are
+    UNPINNED in this tree: without h264mi_config.allow_unpinned_field_cabac they are refused (H264MI_EUNSUPPORTED) with a message that says so.  The stream:
+    a CAVLC field stream whose PPS is patched to announce CABAC (the refusal comes at the first slice header, before any slice data is looked at)."""
     stream, _, _ = sg.encode(**FIELD_MATRIX["field_IP"])
     i = stream.find(b"\x00\x00\x01\x68") + 4  # pic_parameter_set_rbsp: ue(0) ue(0) entropy_coding_mode_flag ...
     assert i > 4 and stream[i] & 0xC0 == 0xC0 and not stream[i] & 0x20

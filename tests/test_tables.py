@@ -36,6 +36,42 @@ def test_three_table_copies_agree():
         mn(os.path.join(ROOT, "h264decode_amd", "csrc", "mi_cabac_mn.cpp"))
 
 
+def test_field_context_values_are_in_range_and_not_zero():
+    """ctxIdx 277..398 and 436..459 (field-coded blocks; UNPINNED values, see the head of mi_cabac_mn.cpp): none left at the {0, 0} placeholder, every
+    (m, n) gives a preCtxState = ((m * QP) >> 4) + n that the clip to 1..126 trims by no more than it trims the steepest frame-coded contexts, m in -50..81 and n in -80..127 like every entry of Tables 9-12 ... 9-33, and the four
+    sets differ from one another.  (The three copies being identical is test_three_table_copies_agree.)"""
+    src = open(os.path.join(ROOT, "h264decode_amd", "csrc", "mi_cabac_mn.cpp")).read()
+    body = src[src.index("const int8_t mi_cabac_mn"):]
+    # expand the few macros the file uses
+    macros = dict(re.findall(r"#define (\w+) (.*)", src))
+    def expand(t):
+        for _ in range(6):
+            t2 = re.sub(r"\b(Z16|Z4|Z|CTX_0_10|CTX_60_69)\b", lambda m: macros[m.group(1)], t)
+            if t2 == t:
+                break
+            t = t2
+        return t
+    sets = re.split(r"/\* -+ [^*]* -+ \*/", body)[1:]
+    assert len(sets) == 4
+    tables = []
+    for st in sets:
+        pairs = [(int(a), int(b)) for a, b in re.findall(r"\{\s*(-?\d+),\s*(-?\d+)\s*\}", expand(st))]
+        assert len(pairs) == 460, len(pairs)
+        tables.append(pairs)
+    field = list(range(277, 399)) + list(range(436, 460))
+    for t in tables:
+        for i in field:
+            m, n = t[i]
+            assert (m, n) != (0, 0), i
+            assert -50 <= m <= 81 and -80 <= n <= 127, (i, m, n)
+            lo = min(((m * qp) >> 4) + n for qp in range(52))
+            hi = max(((m * qp) >> 4) + n for qp in range(52))
+            assert -100 <= lo and hi <= 260, (i, m, n, lo, hi)  # (steep I-slice contexts saturate at both ends of the QP range, as the frame-coded ones do)
+    for a in range(4):
+        for b in range(a + 1, 4):
+            assert [tables[a][i] for i in field[:122]] != [tables[b][i] for i in field[:122]]
+
+
 def test_field_scans(oracle_mod):
     """Tables 8-12 / 8-13, field scan: the product's tables (written as x + 8 y) against the oracle's (written as (row, column) pairs) -- two
     transcriptions --, and the structure the standard's figure shows: a permutation that runs down the first column first and reaches the

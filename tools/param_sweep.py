@@ -68,10 +68,12 @@ def draw():
     if rng.random() < 0.15 or FIELDS:
         kw["interlace_sps"] = 1
         kw["height"] = max(32, (kw["height"] + 31) // 32 * 32 - pick(0, 4, 8))
-    if FIELDS:  # what sg.h says field recipes may carry: Main / High, CAVLC, no long-term pictures; B fields in all-field streams
-        for k in ("b_pyramid", "idr_long_term", "fn_gap_period", "fn_gap_declared", "cabac_init_idc"):
+    if FIELDS:  # what sg.h says field recipes may carry: Main / High, no long-term pictures; B fields in all-field streams; CABAC with the unpinned field contexts
+        for k in ("b_pyramid", "idr_long_term", "fn_gap_period", "fn_gap_declared"):
             kw.pop(k, None)
-        kw.update(field_pics=pick(1, 2, 3, 3), cabac=0, profile_idc=pick(77, 100))
+        kw.update(field_pics=pick(1, 2, 3, 3), cabac=pick(0, 1), profile_idc=pick(77, 100))
+        if not kw["cabac"]:
+            kw.pop("cabac_init_idc", None)
         if kw["field_pics"] == 3 or not kw.get("bframes"):
             for k in ("bframes", "weighted_bipred", "bskip_permille", "direct_temporal"):
                 kw.pop(k, None)
@@ -110,7 +112,7 @@ for t in range(N if BATCH == 1 and not CONCAT else 0):
                 os.environ["H264MI_X_WGS"] = x
                 # (a field is a picture of its own for the decoder's batch limit; fed picture by picture the co-located field of a stream's first B field
                 # can lie more than one call back: its motion must be kept from the start -- b_pictures)
-                dec = H.Decoder(max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=kw["frames"] * (2 if kw.get("field_pics") else 1), max_slices_per_frame=nsl,
+                dec = H.Decoder(allow_unpinned_field_cabac=1, max_streams=1, max_width=W, max_height=Hc, max_frames_per_batch=kw["frames"] * (2 if kw.get("field_pics") else 1), max_slices_per_frame=nsl,
                                 b_pictures=1 if (SPLIT and kw.get("field_pics") and kw.get("bframes")) else 0)
                 if SPLIT and kw.get("field_pics"):  # pieces of whole pictures (the generator's sizes are per FRAME)
                     sp = H.AccessUnitSplitter(max_units_per_chunk=1)
@@ -163,7 +165,7 @@ for t in range(N if CONCAT else 0):
         if GPU:
             for x in ("256", "0"):
                 os.environ["H264MI_X_WGS"] = x
-                dec = H.Decoder(max_streams=1, max_width=max(d[0] for d in dims), max_height=max(d[1] for d in dims), max_frames_per_batch=sum(kw["frames"] * (2 if kw.get("field_pics") else 1) for kw, _ in parts),
+                dec = H.Decoder(allow_unpinned_field_cabac=1, max_streams=1, max_width=max(d[0] for d in dims), max_height=max(d[1] for d in dims), max_frames_per_batch=sum(kw["frames"] * (2 if kw.get("field_pics") else 1) for kw, _ in parts),
                                 max_slices_per_frame=max(max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1)) for kw, _ in parts))
                 got = []
                 if SPLIT:  # ... and in pieces of whole access units: the change may fall on a batch boundary or inside a batch
@@ -207,7 +209,7 @@ for t in range(N if BATCH > 1 else 0):  # several streams per decoder
     try:
         for x in ("256", "0"):
             os.environ["H264MI_X_WGS"] = x
-            dec = H.Decoder(max_streams=BATCH, max_width=W, max_height=Hc, max_frames_per_batch=max(kw["frames"] * (2 if kw.get("field_pics") else 1) for kw in kws),
+            dec = H.Decoder(allow_unpinned_field_cabac=1, max_streams=BATCH, max_width=W, max_height=Hc, max_frames_per_batch=max(kw["frames"] * (2 if kw.get("field_pics") else 1) for kw in kws),
                             max_slices_per_frame=max(max(1, kw.get("slices", 1)) * max(1, kw.get("slice_groups", 1)) for kw in kws))
             dec.decode([g[0] for g in gen])
             for i, (kw, g) in enumerate(zip(kws, gen)):
