@@ -43,6 +43,7 @@ def draw():
         kw["cabac_init_idc"] = pick(-1, 0, 1, 2)
     if prof == 100:
         kw["transform8x8"], kw["scaling_matrix"] = pick(0, 1, 1), pick(0, 1)
+        kw["mono"] = pick(0, 0, 0, 1)  # chroma_format_idc 0 now and then
     if prof != 66:
         kw["weighted_pred"] = pick(0, 0, 1, 2)
         if rng.random() < 0.4 and kw["frames"] >= 4:
@@ -79,7 +80,7 @@ def draw():
                 kw.pop(k, None)
             kw["poc_type"] = pick(0, 0, 1, 2)
         if kw["profile_idc"] != 100:
-            kw.pop("transform8x8", None), kw.pop("scaling_matrix", None)
+            kw.pop("transform8x8", None), kw.pop("scaling_matrix", None), kw.pop("mono", None)
         else:
             kw["transform8x8"], kw["scaling_matrix"] = pick(0, 1, 1), pick(0, 1)
         kw["weighted_pred"] = pick(0, 0, 1, 2)
