@@ -166,6 +166,13 @@ def test_tables_against_reference_where_it_is_right():
         badi = [k for k in range(48) if me[k][0] != t["me_intra"][k]]
         badp = [k for k in range(48) if me[k][1] != t["me_inter"][k]]
         assert badi == [18] and badp == []                                   # A4
+    # ... and the ChromaArrayType 0 / 3 column (monochrome streams, round 5): the reference's map is right there
+    chunk = src[src.index("var meChroma0or3"):]
+    chunk = chunk[:chunk.index("\n}\n")]
+    me0 = {int(k): (int(a), int(b)) for k, a, b in re.findall(pat, chunk)}
+    assert len(me0) == 16
+    assert [me0[k][0] for k in range(16)] == t["me_intra0"] and [me0[k][1] for k in range(16)] == t["me_inter0"]
+    assert sorted(t["me_intra0"]) == sorted(t["me_inter0"]) == list(range(16))
 
 
 def test_exp_golomb_kat(oracle_mod):
