@@ -308,6 +308,16 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
                 }
             }
             STAMP(4);
+            // ---- hand-off, first half: the group's first row takes rows 12..15 of column t of the group above out of its ring, once that says the column is final (the group
+            // above is eight steps ahead: no wait in the steady state); the copy needs no synchronisation of its own -- the one behind the vertical pass stands between it and its readers
+            if (g > 0 && t >= 0 && t < wmb) {
+                wait_for(&sh.prog[g - 1], t + 1);
+                if (s == 0 && j < 6) {
+                    const uint32_t above = tile - T_BYTES;
+                    const uint32_t dst = j < 4 ? above + sx * 256 + 192 + j * 16 : above + T_CHROMA + sx * 128 + 96 + (j - 4) * 16;
+                    LST16(dst, LLD16(in_ring + static_cast<uint32_t>(t % in_depth) * MI_DEBLOCK_SLOT_BYTES + j * 16));
+                }
+            }
             // ---- 1. vertical edges: lane j = luma rows 2j, 2j + 1, then chroma row j of Cb | Cr ----
             if (active) {
                 // a plane's block: aL bL aI bI | aT bT tL1 tL2 | tL3 tI1 tI2 tI3 | tT1 tT2 tT3 pad  (a / b: alpha / beta of the left-edge, inner, top-edge QP average; tKb: tC0 for bS b).
@@ -376,10 +386,11 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             }
             WAVE_SYNC();
             STAMP(1);
-            // ---- 2. hand-off ----
-            // 2a. the group's last row: rows 12..15 of column xl - 1 are final but for the row below -- into the ring of the group below
-            //     (six 16-byte pieces in window format), then the column is published.  Back-pressure first: the slot held column
-            //     xl - 1 - depth, which the group below must have consumed.
+            // ---- 2. hand-off, second half: the group's last row -- rows 12..15 of column xl - 1 are final but for the row below: into the ring of the group below
+            //     (six 16-byte pieces in window format), then the column is published (the release store waits for the wavefront's LDS writes).  Back-pressure
+            //     first: the slot held column xl - 1 - depth, which the group below must have consumed.
+            if (g > 0 && t >= 0 && t < wmb && lane == 0) // (the slot of column t was copied at the top of the step: the group above may reuse it)
+                __hip_atomic_store(&sh.cons[g], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (feeds_group) {
                 const int xl = t - last_sub; // column of the group's last row in this step
                 if (xl >= 1 && xl <= wmb) {
@@ -389,22 +400,10 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
                         const uint32_t src = j < 4 ? tile + spv * 256 + 192 + j * 16 : tile + T_CHROMA + spv * 128 + 96 + (j - 4) * 16;
                         LST16(out_ring + static_cast<uint32_t>(c % out_depth) * MI_DEBLOCK_SLOT_BYTES + j * 16, LLD16(src));
                     }
-                    WAVE_SYNC();
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the copy above is other lanes' work: keep it in front of lane 0's store)
                     if (lane == 0) __hip_atomic_store(&sh.prog[g], xl, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
-            // 2c. the group's first row takes rows 12..15 of column t of the group above out of its ring, once that says the column is final
-            if (g > 0 && t < wmb) {
-                wait_for(&sh.prog[g - 1], t + 1);
-                if (s == 0 && j < 6) {
-                    const uint32_t above = tile - T_BYTES;
-                    const uint32_t dst = j < 4 ? above + sx * 256 + 192 + j * 16 : above + T_CHROMA + sx * 128 + 96 + (j - 4) * 16;
-                    LST16(dst, LLD16(in_ring + static_cast<uint32_t>(t % in_depth) * MI_DEBLOCK_SLOT_BYTES + j * 16));
-                }
-            }
-            WAVE_SYNC();
-            if (g > 0 && t < wmb && lane == 0) // the hand-off slot of column t has been copied: the group above may reuse it
-                __hip_atomic_store(&sh.cons[g], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             STAMP(2);
             // ---- 3. horizontal edges: lane j = luma columns 2j, 2j + 1, then chroma column j of Cb | Cr ----
             if (active) {

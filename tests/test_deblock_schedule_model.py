@@ -44,7 +44,15 @@ def _wave_program(w, nw, ring, ring_last, last_bufs, wmb, hmb, prog, cons, slots
             yield lambda g=g, reuse=reuse: cons[g - reuse + 1] >= wmb
         for t in range(wmb + ROWS):
             xl = t - last_sub
-            # 2a: rows 12..15 of column xl - 1 of the group's last row go into the ring (back-pressure first), then the column is published
+            # top of the step: the group's first row takes the rows above column t from the group above (the copy), ...
+            if g > 0 and t < wmb:
+                yield lambda g=g, t=t: prog[g - 1] >= t + 1
+                key = (in_buf, t % in_depth)
+                assert slots.get(key, (None,))[:2] == (g - 1, t), ("reader finds the wrong column", g, t, slots.get(key))
+                slots[key] = slots[key][:2] + (True,)  # consumed
+                # ... says so behind the vertical pass
+                cons[g] = t + 1
+            # then rows 12..15 of column xl - 1 of the group's last row go into the ring (back-pressure first) and the column is published
             if feeds and 1 <= xl <= wmb:
                 c = xl - 1
                 if c >= out_depth:
@@ -54,13 +62,6 @@ def _wave_program(w, nw, ring, ring_last, last_bufs, wmb, hmb, prog, cons, slots
                 assert old is None or old[2], ("slot overwritten before it was read", g, c, old)
                 slots[key] = (g, c, False)
                 prog[g] = xl
-            # 2c: the group's first row takes the rows above column t from the group above
-            if g > 0 and t < wmb:
-                yield lambda g=g, t=t: prog[g - 1] >= t + 1
-                key = (in_buf, t % in_depth)
-                assert slots.get(key, (None,))[:2] == (g - 1, t), ("reader finds the wrong column", g, t, slots.get(key))
-                slots[key] = slots[key][:2] + (True,)  # consumed
-                cons[g] = t + 1
 
 
 def _simulate(nw, ring, ring_last, last_bufs, wmb, hmb, rng):
