@@ -209,6 +209,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
         const int t_last = wmb + 9; // sub-row s: loads from step s - 1 on, columns in steps s .. s + wmb - 1, the last column pair's output up to three steps later
 #if defined(MI_DB_STATS)
         uint32_t st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const uint32_t st_t0 = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
         for (int t = -1; t <= t_last; t++) {
@@ -498,6 +499,8 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
 #if defined(MI_DB_STATS)
         if (g == 0 && lane_v == 0)
             for (int k = 0; k < 12; k++) atomicAdd(xstatus + 8 + k, st_acc[k]);
+        if (blockIdx.x == 0 && lane_v == 0 && g < 15) // when the groups of the launch's first picture ran (100 MHz ticks): the last launch's values stay
+            xstatus[32 + 2 * g] = st_t0, xstatus[33 + 2 * g] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
 #endif
     }
 }

@@ -1953,6 +1953,9 @@ extern "C" __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per
         status[8 * blockIdx.x + 3] = MI_BINS(e);
 #if MI_ENT_STATS
         for (int k = 0; k < 4; k++) status[8 * blockIdx.x + 4 + k] = static_cast<uint32_t>(e.tacc[k] >> 4); // shader clocks / 16
+#if MI_ENT_STATS == 3 /* when the wavefront ran (100 MHz ticks, low 32 bits): the launch's timeline by slice type (H264MI_SLICE_TIMELINE) */
+        status[8 * blockIdx.x + 4] = static_cast<uint32_t>(t_begin), status[8 * blockIdx.x + 5] = static_cast<uint32_t>(wall_clock64());
+#endif
 #endif
     }
 }

@@ -627,12 +627,12 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg_, h264mi_decod
     // (test hook: where the launch epoch and the ticket counters start, so that a test can cross their 32-bit wrap)
     DEV_ALLOC(d->d_xring, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long));
     DEV_ALLOC(d->d_xdone, static_cast<size_t>(d->x_cap3) * (d->Wmax / 16) * sizeof(uint32_t));
-    DEV_ALLOC(d->d_xctl, 3 * 128);
+    DEV_ALLOC(d->d_xctl, 4 * 128);
     TRY_ALLOC(hipHostMalloc(&d->h_xstatus, sizeof(uint32_t)));
     *d->h_xstatus = 0;
     TRY_ALLOC(hipMemset(d->d_xring, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long)));
     TRY_ALLOC(hipMemset(d->d_xdone, 0, static_cast<size_t>(d->x_cap3) * (d->Wmax / 16) * sizeof(uint32_t)));
-    TRY_ALLOC(hipMemset(d->d_xctl, 0, 3 * 128));
+    TRY_ALLOC(hipMemset(d->d_xctl, 0, 4 * 128));
     build_tables(d->h_tables);
     d->h_pools.resize(S);
     for (int si = 0; si < S; si++) { // static per stream (kernels take the geometry of a picture from its PicDesc)
@@ -2210,6 +2210,21 @@ extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
         fprintf(stderr, "last slice type %d bytes %u mbs %u us %.1f bins %u\n", g.h_slices[g.n_slices - 1].slice_type, g.h_slices[g.n_slices - 1].rbsp_size,
                 g.h_status[8 * (g.n_slices - 1) + 1], g.h_status[8 * (g.n_slices - 1) + 2] * 0.01, g.h_status[8 * (g.n_slices - 1) + 3]);
     }
+    if (getenv("H264MI_SLICE_TIMELINE")) { // diagnostics (-DMI_ENT_STATS=3 builds): when the slices of each type started and ended within the pass
+        Stage &g = d->stage[d->exec];
+        uint32_t t0 = 0xFFFFFFFFu;
+        for (int i = 0; i < g.n_slices; i++) t0 = std::min(t0, g.h_status[8 * i + 4]);
+        for (int ty = 0; ty < 3; ty++) {
+            int n = 0;
+            double first_end = 1e30, last_start = 0, last_end = 0, sum = 0;
+            for (int i = 0; i < g.n_slices; i++)
+                if (g.h_slices[i].slice_type % 5 == ty) {
+                    const double a = (g.h_status[8 * i + 4] - t0) * 0.01, b = (g.h_status[8 * i + 5] - t0) * 0.01;
+                    n++, sum += b - a, first_end = std::min(first_end, b), last_start = std::max(last_start, a), last_end = std::max(last_end, b);
+                }
+            if (n) fprintf(stderr, "timeline: slice type %d: %d slices, mean %.1f us, first end %.1f, last start %.1f, last end %.1f us\n", ty, n, sum / n, first_end, last_start, last_end);
+        }
+    }
 #endif
     if (*d->h_xstatus) { // a banded kernel gave up waiting for its neighbour workgroup: the pictures of that launch are wrong
         set_error("reconstruction hand-off timed out (code 0x%08x)", *d->h_xstatus);
@@ -2475,6 +2490,15 @@ extern "C" int32_t h264mi_internal_deblock_phase_clocks(h264mi_decoder *d, uint3
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out, d->d_xctl + 64 + 8, 12 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(d->d_xctl + 64 + 8, 0, 12 * sizeof(uint32_t)));
+    return H264MI_OK;
+}
+
+// Not part of the public ABI: start and end (100 MHz ticks) of the row groups of the first picture of the last K5 launch (-DMI_DB_STATS builds)
+extern "C" int32_t h264mi_internal_deblock_group_times(h264mi_decoder *d, uint32_t out[32]) {
+    if (!d || !out) return H264MI_EINVAL;
+    GUARD(d);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d->d_xctl + 64 + 32, 32 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return H264MI_OK;
 }
 

@@ -34,3 +34,10 @@ print("clocks per step of the wavefront of group 0 (1080p, %d streams x %d pictu
 for n, v in zip(names, buf):
     print("  %-20s %8.0f  %5.1f %%" % (n, v / steps, 100.0 * v / tot))
 print("  %-20s %8.0f" % ("total", tot / steps))
+if S > 1 and hasattr(H.load(), "h264mi_internal_deblock_group_times"):
+    g = H.load().h264mi_internal_deblock_group_times
+    g.restype, g.argtypes = ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
+    tb = (ctypes.c_uint32 * 32)()
+    g(dec._h, tb)
+    t0 = min(tb[2 * k] for k in range(9))
+    print("row groups of the first picture of the last launch, start .. end in us:", ", ".join("%.0f..%.0f" % ((tb[2 * k] - t0) * 0.01, (tb[2 * k + 1] - t0) * 0.01) for k in range(9)))
