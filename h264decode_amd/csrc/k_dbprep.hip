@@ -64,13 +64,19 @@ struct PrepSub {
 // macroblocks per workgroup on top of that -- 8.9 ms.  A million short workgroups hide the dependent loads better than a loop carrying 12 registers.)
 // col_only: the one-off back-fill of ColRec arrays for a batch whose DbPrm records are already in use (mi_api.cpp: ensure_b_buffers).
 extern "C" __global__ void __launch_bounds__(256) k_dbprep(const uint32_t *pic_list, const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1,
-                                                           DbPrm *out, int col_only, unsigned long long *intramask) {
+                                                           DbPrm *out, int col_only, unsigned long long *intramask, int n_pics) {
     __shared__ PrepSub subs[4][4];
     __shared__ uint8_t s_alpha[52], s_beta[52], s_tc0[52][4];
     const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63, sub = lane >> 4, li = lane & 15;
-    const PicDesc *pd = &pics[pic_list[blockIdx.y]];
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and a macroblock's upper neighbour is a record another
+    // workgroup of the picture loads as its own -- so an XCD takes WHOLE pictures (picture p goes to XCD p mod 8; grid.y is a multiple of 8), and the row
+    // above comes out of the L2 that fetched it a moment ago
+    const uint32_t w = blockIdx.y * gridDim.x + blockIdx.x, in_xcd = w >> 3;
+    const uint32_t pic = (in_xcd / gridDim.x) * 8u + (w & 7u), blk = in_xcd % gridDim.x;
+    if (pic >= static_cast<uint32_t>(n_pics)) return;
+    const PicDesc *pd = &pics[pic_list[pic]];
     const int wmb = static_cast<int>(pd->wmb), nmb = wmb * static_cast<int>(pd->hmb);
-    const int mb_first = static_cast<int>(blockIdx.x) * MI_DBPREP_MBS;
+    const int mb_first = static_cast<int>(blk) * MI_DBPREP_MBS;
     if (mb_first >= nmb) return;
     for (int i = tid; i < 52; i += 256) {
         s_alpha[i] = tab->alpha[i], s_beta[i] = tab->beta[i];

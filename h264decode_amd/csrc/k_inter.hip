@@ -50,6 +50,15 @@ __device__ __forceinline__ uint32_t pack4(int a, int b, int c, int d) {
 __device__ __forceinline__ s2 as_s2(uint32_t v) { return __builtin_bit_cast(s2, v); }
 __device__ __forceinline__ uint32_t as_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
 
+// Clip1(prediction + residual) of four packed samples, two at a time in 16-bit halves: the residuals are narrowed with saturation (v_cvt_pk_i16_i32: a residual
+// beyond +-32767 ends at 0 or 255 either way; tools/ubench/intrin_probe.hip shows the instruction saturating), the sums cannot leave 16 bits.
+__device__ __forceinline__ uint32_t add_clip4(uint32_t p, int r0, int r1, int r2, int r3) {
+    const s2 z = {0, 0}, m = {255, 255};
+    const s2 lo = __builtin_elementwise_add_sat(as_s2(__builtin_amdgcn_perm(0u, p, 0x0c010c00u)), __builtin_bit_cast(s2, __builtin_amdgcn_cvt_pk_i16(r0, r1)));
+    const s2 hi = __builtin_elementwise_add_sat(as_s2(__builtin_amdgcn_perm(0u, p, 0x0c030c02u)), __builtin_bit_cast(s2, __builtin_amdgcn_cvt_pk_i16(r2, r3)));
+    return __builtin_amdgcn_perm(as_u32(__builtin_elementwise_min(__builtin_elementwise_max(hi, z), m)), as_u32(__builtin_elementwise_min(__builtin_elementwise_max(lo, z), m)), 0x06040200u);
+}
+
 // ------------------------------------------------------------------ 1-D inverse transforms / scaling (8.5.12, 8.5.13)
 __device__ __forceinline__ void inv4(int d0, int d1, int d2, int d3, int &o0, int &o1, int &o2, int &o3) {
     int e0 = d0 + d2, e1 = d0 - d2, e2 = (d1 >> 1) - d3, e3 = d1 + (d3 >> 1);
@@ -67,6 +76,16 @@ __device__ __forceinline__ int scale4(int c, int ls, int qp) { // 8.5.12.1
     int per = qp / 6;
     return per >= 4 ? (c * ls) << (per - 4) : (c * ls + (1 << (3 - per))) >> (4 - per);
 }
+// The same with the case distinction taken out of the per-coefficient work: ((c * ls + rnd) >> sr) << sl with (sl, sr, rnd) = (per - 4, 0, 0) or
+// (0, 4 - per, 1 << (3 - per)) -- one multiply-add and two shifts by a per-lane amount, no select (one of the shifts is by 0).
+struct Scale4 {
+    int sl, sr, rnd;
+    __device__ __forceinline__ explicit Scale4(int qp) {
+        const int per = qp / 6;
+        sl = max(per - 4, 0), sr = max(4 - per, 0), rnd = (1 << sr) >> 1;
+    }
+    __device__ __forceinline__ int operator()(int c, int ls) const { return ((c * ls + rnd) >> sr) << sl; }
+};
 __device__ __forceinline__ int scale8(int c, int ls, int qp) { // 8.5.13
     int per = qp / 6;
     return per >= 6 ? (c * ls) << (per - 6) : (c * ls + (1 << (5 - per))) >> (6 - per);
@@ -328,7 +347,11 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
         cadj = fld ? (static_cast<int>(par) - (fld - 1)) * -2 : 0; // bottom field from a top field: +2; top from bottom: -2
     };
     // this block's vectors / reference frames
+#if defined(K4_EXP) && (K4_EXP & 4)
+    const uint32_t mvw0 = rw[12 + b] & 0xFFFCFFFCu;
+#else
     const uint32_t mvw0 = rw[12 + b];
+#endif
     const int s0 = static_cast<int>(static_cast<int16_t>(reinterpret_cast<const uint16_t *>(rw)[18 + q8]));   // refslot[q8] (byte 36)
     int s1 = -1;
     uint32_t mvw1 = 0;
@@ -394,17 +417,22 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
     int res[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) res[i] = 0;
+#if defined(K4_EXP) && (K4_EXP & 1) /* instruction-budget experiments (tools/k4_budget.sh; wrong pictures): 1 no luma residual, 2 no chroma residual, 4 integer vectors only */
+    const bool has_l = false;
+#else
     const bool has_l = inter && !t8x8 && ((cmask >> b) & 1u);
+#endif
     if (__builtin_amdgcn_ballot_w64(has_l) != 0) {
         if (has_l) {
             int c[16];
             load_block(coefs, coef_off + __builtin_popcount(cmask & ((1u << b) - 1u)), c);
             const uint16_t *ls = sc->ls4[3][qp % 6]; // inter Y
             int t[16];
+            const Scale4 sq(qp);
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                inv4(scale4(c[4 * r], ls[4 * r], qp), scale4(c[4 * r + 1], ls[4 * r + 1], qp), scale4(c[4 * r + 2], ls[4 * r + 2], qp), scale4(c[4 * r + 3], ls[4 * r + 3], qp),
-                     t[4 * r], t[4 * r + 1], t[4 * r + 2], t[4 * r + 3]);
+                inv4(sq(c[4 * r], ls[4 * r]), sq(c[4 * r + 1], ls[4 * r + 1]), sq(c[4 * r + 2], ls[4 * r + 2]), sq(c[4 * r + 3], ls[4 * r + 3]), t[4 * r], t[4 * r + 1], t[4 * r + 2],
+                     t[4 * r + 3]);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int o0, o1, o2, o3;
@@ -463,9 +491,32 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
     }
     // chroma: lanes 0..7 of a macroblock transform its eight 4x4 chroma blocks, every lane then picks up the 2x2 residual under it
     const int cbp_c = cbp >> 4;
+#if defined(K4_EXP) && (K4_EXP & 2)
+    const bool has_c = false;
+#else
     const bool has_c = inter && cbp_c != 0;
+#endif
     int cr[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    if (__builtin_amdgcn_ballot_w64(has_c) != 0) {
+    if (__builtin_amdgcn_ballot_w64(has_c) != 0 && __builtin_amdgcn_ballot_w64(has_c && (cbp_c & 2)) == 0) {
+        // No macroblock of the wavefront has chroma AC coefficients (the rule: coded_block_pattern says 1 for most macroblocks with chroma residual at all).  A block
+        // with its DC coefficient only transforms into sixteen times (dcC + 32) >> 6, so every lane works out the DC of the chroma block its 2x2 samples lie in, for
+        // both planes: no 4x4 transform, no LDS exchange.
+        const uint32_t db = MI_COEF_CDC / 16;
+        if (has_c && ((cmask >> db) & 1u)) {
+            const uint32_t *dcw = reinterpret_cast<const uint32_t *>(coefs) + 8 * static_cast<size_t>(coef_off + __builtin_popcount(cmask & ((1u << db) - 1u)));
+            const v4u w = *reinterpret_cast<const v4u *>(dcw);
+            const int blk = (by & 2) | (bx >> 1);
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const uint32_t w0 = c ? w.z : w.x, w1 = c ? w.w : w.y;
+                const int qpc = static_cast<int>(c ? (h1 & 255u) : (h0 >> 24));
+                const int c0 = static_cast<int16_t>(w0 & 0xFFFFu), c1 = static_cast<int>(w0) >> 16, c2 = static_cast<int16_t>(w1 & 0xFFFFu), c3 = static_cast<int>(w1) >> 16;
+                const int f = (c0 + ((blk & 2) ? -c2 : c2)) + ((blk & 1) ? -1 : 1) * (c1 + ((blk & 2) ? -c3 : c3)); // 8.5.11.1: c0 +- c1 +- c2 +- c3
+                const int r = ((((f * sc->ls4[4 + c][qpc % 6][0]) << (qpc / 6)) >> 5) + 32) >> 6;
+                cr[c][0] = cr[c][1] = cr[c][2] = cr[c][3] = r;
+            }
+        }
+    } else if (__builtin_amdgcn_ballot_w64(has_c) != 0) {
         if (has_c && b < 8) {
             const int c = b >> 2, blk = b & 3;
             const int qpc = static_cast<int>(c ? (h1 & 255u) : (h0 >> 24));
@@ -518,9 +569,7 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             uint32_t v = P[r];
-            if (any_l)
-                v = pack4(clip255(static_cast<int>(v & 255u) + res[4 * r]), clip255(static_cast<int>((v >> 8) & 255u) + res[4 * r + 1]),
-                          clip255(static_cast<int>((v >> 16) & 255u) + res[4 * r + 2]), clip255(static_cast<int>(v >> 24) + res[4 * r + 3]));
+            if (any_l) v = add_clip4(v, res[4 * r], res[4 * r + 1], res[4 * r + 2], res[4 * r + 3]);
             *reinterpret_cast<g32 *>(dst + (static_cast<uint32_t>(py + r) * pitch + static_cast<uint32_t>(px))) = v;
         }
         const uint32_t Wc = pitch >> 1;
@@ -528,9 +577,7 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             uint32_t v = C[c];
-            if (has_c)
-                v = pack4(clip255(static_cast<int>(v & 255u) + cr[c][0]), clip255(static_cast<int>((v >> 8) & 255u) + cr[c][1]),
-                          clip255(static_cast<int>((v >> 16) & 255u) + cr[c][2]), clip255(static_cast<int>(v >> 24) + cr[c][3]));
+            if (has_c) v = add_clip4(v, cr[c][0], cr[c][1], cr[c][2], cr[c][3]);
             g8 *cp = cdst + (c ? cr_delta : 0u) + (static_cast<uint32_t>(py >> 1) * Wc + static_cast<uint32_t>(px >> 1));
             *reinterpret_cast<g16 *>(cp) = static_cast<uint16_t>(v & 0xFFFFu);
             *reinterpret_cast<g16 *>(cp + Wc) = static_cast<uint16_t>(v >> 16);

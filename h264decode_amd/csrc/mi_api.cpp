@@ -1302,8 +1302,8 @@ static int ensure_b_buffers(h264mi_decoder *d) {
             HIP_TRY(hipMemcpyAsync(pv.d_pics, pv.h_pics, sizeof(PicDesc) * pv.n_pics, hipMemcpyHostToDevice, up));
             HIP_TRY(hipMemcpyAsync(d->d_backfill, list.data(), sizeof(uint32_t) * list.size(), hipMemcpyHostToDevice, up));
             HIP_TRY(hipStreamSynchronize(up)); // (`list` is pageable host memory; once per decoder)
-            hipLaunchKernelGGL(k_dbprep, dim3((pv.mbs_max + MI_DBPREP_MBS - 1) / MI_DBPREP_MBS, static_cast<uint32_t>(list.size())), dim3(256), 0, up, d->d_backfill,
-                               pv.d_pics, d->d_tables, d->d_mbrec[pset], d->d_mv1[pset], d->d_dbprm[pset], 1, d->d_imask[pset]);
+            hipLaunchKernelGGL(k_dbprep, dim3((pv.mbs_max + MI_DBPREP_MBS - 1) / MI_DBPREP_MBS, (static_cast<uint32_t>(list.size()) + 7u) & ~7u), dim3(256), 0, up, d->d_backfill,
+                               pv.d_pics, d->d_tables, d->d_mbrec[pset], d->d_mv1[pset], d->d_dbprm[pset], 1, d->d_imask[pset], static_cast<int>(list.size()));
         }
     }
     return H264MI_OK;
@@ -2063,8 +2063,8 @@ static int execute_stage(h264mi_decoder *d, int stage_idx, bool exclusive) {
             // level's, or a later batch's) take their direct prediction from
             if (g.colsave_n[lv]) fence();
             if (g.prep_n[lv])
-                hipLaunchKernelGGL(k_dbprep, dim3((g.mbs_max + MI_DBPREP_MBS - 1) / MI_DBPREP_MBS, g.prep_n[lv]), dim3(256), 0, st, g.d_lists + g.prep_off[lv], g.d_pics,
-                                   d->d_tables, mbrec, d->d_mv1[set], d->d_dbprm[set], 0, d->d_imask[set]);
+                hipLaunchKernelGGL(k_dbprep, dim3((g.mbs_max + MI_DBPREP_MBS - 1) / MI_DBPREP_MBS, (g.prep_n[lv] + 7u) & ~7u), dim3(256), 0, st, g.d_lists + g.prep_off[lv], g.d_pics,
+                                   d->d_tables, mbrec, d->d_mv1[set], d->d_dbprm[set], 0, d->d_imask[set], static_cast<int>(g.prep_n[lv]));
             if (lv == n_levels - 1 && done) hipEventRecord(done, st);
         }
     };
@@ -2223,6 +2223,19 @@ extern "C" int32_t h264mi_batch_sync(h264mi_decoder *d) {
                     n++, sum += b - a, first_end = std::min(first_end, b), last_start = std::max(last_start, a), last_end = std::max(last_end, b);
                 }
             if (n) fprintf(stderr, "timeline: slice type %d: %d slices, mean %.1f us, first end %.1f, last start %.1f, last end %.1f us\n", ty, n, sum / n, first_end, last_start, last_end);
+            if (n > 64) { // slices in 20 ms buckets of their end, split into those that started with the launch and the late ones, with their mean durations
+                int cnt[2][16] = {};
+                double dur[2][16] = {};
+                for (int i = 0; i < g.n_slices; i++)
+                    if (g.h_slices[i].slice_type % 5 == ty) {
+                        const double a = (g.h_status[8 * i + 4] - t0) * 0.01, b = (g.h_status[8 * i + 5] - t0) * 0.01;
+                        const int late = a > 5000.0, k = std::min(15, static_cast<int>(b / 20000.0));
+                        cnt[late][k]++, dur[late][k] += b - a;
+                    }
+                for (int late = 0; late < 2; late++)
+                    for (int k = 0; k < 16; k++)
+                        if (cnt[late][k]) fprintf(stderr, "timeline:   %s, end in %3d..%3d ms: %5d slices, mean duration %.1f ms\n", late ? "late start" : "first wave", 20 * k, 20 * k + 20, cnt[late][k], dur[late][k] / cnt[late][k] * 1e-3);
+            }
         }
     }
 #endif

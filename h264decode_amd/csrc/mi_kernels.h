@@ -36,7 +36,7 @@ extern "C" __global__ void k_intra_x(const uint32_t *pic_list, const PicDesc *pi
 #ifndef MI_DBPREP_MBS
 #define MI_DBPREP_MBS 64
 #endif
-extern "C" __global__ void k_dbprep(const uint32_t *pic_list, const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1, DbPrm *out, int col_only, unsigned long long *intramask);
+extern "C" __global__ void k_dbprep(const uint32_t *pic_list, const PicDesc *pics, const DevTables *tab, const MbRec *mbrec, const MbMv1 *mbmv1, DbPrm *out, int col_only, unsigned long long *intramask, int n_pics);
 // K5 (k_deblock.hip): in-loop deblocking, one workgroup per picture, one wavefront per group of 8 macroblock rows, 8 lanes per macroblock
 // (two lines per lane, packed 16-bit arithmetic).  block = 64 * nwaves, dynamic LDS = mi_deblock8_lds_bytes(nwaves, ring, ring_last, last_bufs);
 // (nwaves, ring, ring_last, last_bufs) from mi_deblock8_plan()

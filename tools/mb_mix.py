@@ -22,3 +22,13 @@ for f in (1, F - 1):
           "chroma cbp 0/1/2:", [int((((cbp >> 4) == k) & coded).sum()) for k in range(3)])
     sub = collections.Counter(int(x) for x in r[r[:, 0] == 8][:, 16 + 5:16 + 9].reshape(-1)) if (r[:, 0] == 8).any() else {}
     print("   sub_mb_type of P8x8 quadrants:", dict(sub))
+    # K4's view: inter macroblocks by vector shape (record bytes 48..111: sixteen (mvx, mvy) int16 pairs)
+    inter = np.isin(r[:, 0], (5, 6, 7, 8, 9))
+    mv = r[:, 48:112].copy().view(np.int16).reshape(-1, 16, 2)
+    uni = (mv == mv[:, :1, :]).all(axis=(1, 2))
+    integer = ((mv & 3) == 0).all(axis=(1, 2))
+    cbp0 = cbp == 0
+    n = int(inter.sum())
+    print("   inter MBs %d: one vector %.1f %%, integer vectors %.1f %%, both %.1f %%, both and no residual %.1f %%, no residual %.1f %%, 8x8 transform %.1f %%" % (
+        n, 100.0 * (uni & inter).sum() / n, 100.0 * (integer & inter).sum() / n, 100.0 * (uni & integer & inter).sum() / n, 100.0 * (uni & integer & inter & cbp0).sum() / n,
+        100.0 * (inter & cbp0).sum() / n, 100.0 * (inter & (r[:, 1] != 0)).sum() / n))

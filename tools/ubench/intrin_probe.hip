@@ -24,14 +24,18 @@ __global__ void probe(const uint32_t *in, uint32_t *out) {
     out[k++] = __builtin_bit_cast(uint32_t, cl);
     s2 neg = __builtin_bit_cast(s2, 0xFF00FFF0u); // (-16, -256)
     out[k++] = __builtin_bit_cast(uint32_t, (neg + static_cast<short>(16)) >> 5);
+    // v_cvt_pk_i16_i32 narrows with saturation (K4's add_clip4 relies on it): (70000, -70000) -> 7fff 8000, (300, -300) -> 012c fed4
+    out[k++] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(static_cast<int>(in[3]), -static_cast<int>(in[3])));
+    out[k++] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(300, -300));
+    out[k++] = __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(s2, 0x7FF00010u), __builtin_bit_cast(s2, static_cast<uint32_t>(in[3] & 0xFFu) * 0x00010001u))); // + (0x70, 0x70): 7fff 0080
 }
 int main() {
-    uint32_t h[3] = {0x44332211u, 0x88776655u, 0x04030201u}, *d_in, *d_out, o[32] = {0};
-    hipMalloc(&d_in, 12), hipMalloc(&d_out, 128);
-    hipMemcpy(d_in, h, 12, hipMemcpyHostToDevice);
+    uint32_t h[4] = {0x44332211u, 0x88776655u, 0x04030201u, 70000u}, *d_in, *d_out, o[32] = {0};
+    hipMalloc(&d_in, 16), hipMalloc(&d_out, 128);
+    hipMemcpy(d_in, h, 16, hipMemcpyHostToDevice);
     probe<<<1, 1>>>(d_in, d_out);
     hipMemcpy(o, d_out, 128, hipMemcpyDeviceToHost);
-    const char *n[] = {"align0", "align1", "align2", "align3", "perm 0c010c00", "perm 0c030c02", "perm 06040200", "perm 06050201", "perm(0,a,0c030c02)", "lerp", "sdot4 T0", "sdot4 T1", "udot4", "pk tap", "pk clip", "pk ashr"};
-    for (int i = 0; i < 16; i++) printf("%-20s %08x\n", n[i], o[i]);
+    const char *n[] = {"align0", "align1", "align2", "align3", "perm 0c010c00", "perm 0c030c02", "perm 06040200", "perm 06050201", "perm(0,a,0c030c02)", "lerp", "sdot4 T0", "sdot4 T1", "udot4", "pk tap", "pk clip", "pk ashr", "cvt_pk_i16 sat", "cvt_pk_i16", "pk add sat"};
+    for (int i = 0; i < 19; i++) printf("%-20s %08x\n", n[i], o[i]);
     return 0;
 }
