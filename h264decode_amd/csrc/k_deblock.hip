@@ -163,11 +163,11 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
         const uint32_t in_ring = rings_off + static_cast<uint32_t>(in_wave * ring + (in_last && g > 0 ? (((g - 1) / nwaves) % last_bufs) * ring_last : 0)) * MI_DEBLOCK_SLOT_BYTES;
         // ---- memory traffic is COOPERATIVE: a vector memory instruction costs what its lanes touch in distinct cache lines (the CU's L1 looks up one line
         // per clock: with a lane per row, 64 lines per instruction, 9 wavefronts spent 11 k of a step's 18 k clocks issuing them), so whole
-        // wavefronts move blocks of one sub-row between HBM and its LDS window, four (loads) or two (stores) adjacent lanes per row:
-        //   luma load    G[k], sub-row k, four macroblock columns at once: lane = (row L >> 2, column L & 3), 16 bytes; landed pieces enter the
-        //                window one column per step (the slot of column x + 1 is free from the end of step x on), raw rows -- rows 2j, 2j + 1 are the
-        //                32 bytes of row pair j, so the vertical pass converts its own 32 bytes in place;
-        //   chroma load  GC[k], sub-rows k and k + 4 (they reload in the same step): lane = (sub-row L >> 5, plane / row (L & 31) >> 1, column pair L & 1);
+        // wavefronts move blocks of one sub-row between HBM and its LDS window, eight / four (loads) or two (stores) adjacent lanes per row:
+        //   luma load    GA[k] / GB[k], rows 0..7 / 8..15 of sub-row k, EIGHT macroblock columns at once = whole 128-byte lines: lane = (row L >> 3, column L & 7),
+        //                16 bytes; landed pieces enter the window one column per step (the slot of column x + 1 is free from the end of step x on), raw rows --
+        //                rows 2j, 2j + 1 are the 32 bytes of row pair j, so the vertical pass converts its own 32 bytes in place;
+        //   chroma load  GC[k], sub-row k, the same eight columns: lane = (plane L >> 5, row (L >> 2) & 7, column pair L & 3), 16 bytes = two macroblocks' eight samples;
         //   stores       column pairs {x - 3, x - 2} of the sub-rows whose x is odd: luma lane = (sub-row, row (L & 31) >> 1, column L & 1),
         //                chroma lane = (sub-row, plane, row), 16 bytes = both columns; a sub-row stores ITS OWN rows 0..15 (what the row below did to
         //                rows 13..15 happened in this window), the first sub-row also rows 12..15 of the group above out of window 0, the last
@@ -177,19 +177,22 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
         const uint32_t stage0 = tile0 + 9 * T_BYTES;                                                           // 2 x 8 x sizeof(DbPrm)
         const int rows_here = min(8, hmb - g * 8);                                                              // valid sub-rows of this group
         // luma load lane
-        const uint32_t ll_src = y_off + static_cast<uint32_t>(g * 128 + (lane >> 2)) * W + (lane & 3) * 16; // + k * 16 W + column base * 16
+        const uint32_t ll_src = y_off + static_cast<uint32_t>(g * 128 + (lane >> 3)) * W + (lane & 7) * 16; // + (k * 16 [+ 8]) W + column base * 16
         // chroma load lane
-        const uint32_t lc_src = ((lane & 16) ? cr_off : cb_off) + static_cast<uint32_t>(g * 64 + (lane >> 5) * 32 + ((lane >> 1) & 7)) * Wc + (lane & 1) * 16; // + k * 8 Wc + column base * 8
+        const uint32_t lc_src = ((lane & 32) ? cr_off : cb_off) + static_cast<uint32_t>(g * 64 + ((lane >> 2) & 7)) * Wc + (lane & 3) * 16; // + k * 8 Wc + column base * 8
         // luma store lane (instruction i: sub-rows par + 4 i and par + 4 i + 2)
         // chroma store lane (sub-rows par, par + 2, par + 4, par + 6)
         // DbPrm lane
         const int lp_sub = lane < 40 ? lane / 5 : 7, lp_piece = lane < 40 ? lane % 5 : 0;
         const uint32_t lp_row = static_cast<uint32_t>(min(g * 8 + lp_sub, hmb - 1)) * static_cast<uint32_t>(wmb);
-        v4u G0 = z4, G1 = z4, G2 = z4, G3 = z4, G4 = z4, G5 = z4, G6 = z4, G7 = z4, GC0 = z4, GC1 = z4, GC2 = z4, GC3 = z4, GP = z4;
+        v4u GA0 = z4, GA1 = z4, GA2 = z4, GA3 = z4, GA4 = z4, GA5 = z4, GA6 = z4, GA7 = z4; // sub-row k: rows 0..7 of eight macroblock columns (whole 128-byte lines)
+        v4u GB0 = z4, GB1 = z4, GB2 = z4, GB3 = z4, GB4 = z4, GB5 = z4, GB6 = z4, GB7 = z4; // ... rows 8..15
+        v4u GC0 = z4, GC1 = z4, GC2 = z4, GC3 = z4, GC4 = z4, GC5 = z4, GC6 = z4, GC7 = z4, GP = z4; // sub-row k: both chroma planes' eight rows of the same eight columns (64 bytes a row)
         // every load issued so far has landed (the one wait on vector memory of a step, at its end: what it waits for was issued at the step's top)
         auto loads_landed = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(G0), "+v"(G1), "+v"(G2), "+v"(G3), "+v"(G4), "+v"(G5), "+v"(G6), "+v"(G7));
-            asm volatile("" : "+v"(GC0), "+v"(GC1), "+v"(GC2), "+v"(GC3), "+v"(GP));
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(GA0), "+v"(GA1), "+v"(GA2), "+v"(GA3), "+v"(GA4), "+v"(GA5), "+v"(GA6), "+v"(GA7), "+v"(GB0), "+v"(GB1), "+v"(GB2), "+v"(GB3), "+v"(GB4),
+                         "+v"(GB5), "+v"(GB6), "+v"(GB7));
+            asm volatile("" : "+v"(GC0), "+v"(GC1), "+v"(GC2), "+v"(GC3), "+v"(GC4), "+v"(GC5), "+v"(GC6), "+v"(GC7), "+v"(GP));
         };
         // the ring this group writes was last used by the group `reuse` groups earlier: that group's reader must be through with it
         // every wait on another wavefront gives up after 4 s of s_memrealtime and says so through the status word (H264MI_EDECODE) instead of hanging the GPU
@@ -222,10 +225,10 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             const int mbx = t - s;
             // (the lanes' roles in the cooperative transfers are re-derived from the lane number in every step: as loop invariants their predicates would sit in scalar
             // register pairs for the whole kernel -- which the compiler then spills into VGPR lanes)
-            const int ll_row = lane >> 2, ll_col = lane & 3;
-            const uint32_t ll_dst = tile0 + T_BYTES + ll_col * 256 + ll_row * 16;                      // + k * T_BYTES  (slot = column & 3 = ll_col)
-            const int lc_half = lane >> 5, lc_rr = (lane & 31) >> 1, lc_q = lane & 1;
-            const uint32_t lc_dst = tile0 + T_BYTES + lc_half * 4 * T_BYTES + T_CHROMA + (lc_rr & 7) * 16 + (lc_rr >> 3) * 8;                     // + k * T_BYTES + slot * 128
+            const int ll_row = lane >> 3, ll_col = lane & 7;
+            const uint32_t ll_dst = tile0 + T_BYTES + (ll_col & 3) * 256 + ll_row * 16;                // + k * T_BYTES [+ 128: rows 8..15]  (slot = column & 3)
+            const int lc_rr = lane >> 2, lc_q = lane & 3; // (plane, row) 0..15, column pair 0..3 of the eight
+            const uint32_t lc_dst = tile0 + T_BYTES + T_CHROMA + (lc_rr & 7) * 16 + (lc_rr >> 3) * 8;                                             // + k * T_BYTES + slot * 128
             const int sl_half = lane >> 5, sl_row = (lane & 31) >> 1, sl_col = lane & 1;
             const uint32_t sl_sel = (sl_row & 1) ? 0x07050301u : 0x06040200u; // this row of a row pair's 2x2 blocks
             const int sc_q = lane >> 4, sc_plane = (lane >> 3) & 1, sc_row = lane & 7;
@@ -240,19 +243,23 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             const v2u bs = LLD8(stage + (j >> 1) * 8); // (the planes' blocks are read where a pass needs them: 12 registers less across the step)
             STAMP(0);
             // ---- 0. the step's vector memory operations in one burst (the one wait for them is at the end of the step) ----
-            // 0a. loads: the sub-rows whose column x + 1 starts a group of four (two of the eight per step)
+            // 0a. loads: the ONE sub-row whose column x + 1 starts a group of eight.  Luma: whole 128-byte lines, so that a line is fetched once (with groups of four the
+            // halves of a line were asked for four steps apart, and the 32 pictures of an XCD keep more lines in flight than its 4 MB of L2 hold: 2.2 x the bytes);
+            // chroma: 64 of a line's 128 bytes (32 before: a line was fetched four times).
             {
-                const int kq = (t + 1) & 3, cb_a = t - kq + 1, cb_b = cb_a - 4; // sub-rows kq (first column cb_a of its group) and kq + 4 (cb_b)
-                const bool ok_a = kq < rows_here && cb_a >= 0 && cb_a < wmb, ok_b = kq + 4 < rows_here && cb_b >= 0 && cb_b < wmb;
-                const unsigned long long m_a = ok_a ? __builtin_amdgcn_ballot_w64(ll_col < wmb - cb_a) : 0ull, m_b = ok_b ? __builtin_amdgcn_ballot_w64(ll_col < wmb - cb_b) : 0ull;
-                const int cb_c = lc_half ? cb_b : cb_a;
-                const unsigned long long m_c = __builtin_amdgcn_ballot_w64((lc_half ? ok_b : ok_a) && cb_c + 2 * lc_q < wmb);
-                const uint32_t o_a = ll_src + __umul24(kq * 16, W) + cb_a * 16, o_b = ll_src + __umul24(kq * 16 + 64, W) + cb_b * 16;
-                const uint32_t o_c = lc_src + __umul24(kq * 8, Wc) + cb_c * 8;
-                ALD_PHASE(0, G0, G4, GC0, kq, o_a, o_b, o_c, m_a, m_b, m_c, py);
-                ALD_PHASE(1, G1, G5, GC1, kq, o_a, o_b, o_c, m_a, m_b, m_c, py);
-                ALD_PHASE(2, G2, G6, GC2, kq, o_a, o_b, o_c, m_a, m_b, m_c, py);
-                ALD_PHASE(3, G3, G7, GC3, kq, o_a, o_b, o_c, m_a, m_b, m_c, py);
+                const int k8 = (t + 1) & 7, cb8 = t - k8 + 1;
+                const bool ok8 = k8 < rows_here && cb8 >= 0 && cb8 < wmb;
+                const unsigned long long m_l = ok8 ? __builtin_amdgcn_ballot_w64(ll_col < wmb - cb8) : 0ull, m_c = ok8 ? __builtin_amdgcn_ballot_w64(2 * lc_q < wmb - cb8) : 0ull;
+                const uint32_t o_l = ll_src + __umul24(k8 * 16, W) + cb8 * 16, o_h = o_l + 8 * static_cast<uint32_t>(W);
+                const uint32_t o_c = lc_src + __umul24(k8 * 8, Wc) + cb8 * 8;
+                ALD_PHASE(0, GA0, GB0, GC0, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
+                ALD_PHASE(1, GA1, GB1, GC1, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
+                ALD_PHASE(2, GA2, GB2, GC2, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
+                ALD_PHASE(3, GA3, GB3, GC3, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
+                ALD_PHASE(4, GA4, GB4, GC4, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
+                ALD_PHASE(5, GA5, GB5, GC5, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
+                ALD_PHASE(6, GA6, GB6, GC6, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
+                ALD_PHASE(7, GA7, GB7, GC7, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
                 // DbPrm of the next step's macroblocks (a clamped address where there is none: the stage entry is never used then)
                 ALD16M(GP, prms, __umul24(lp_row + static_cast<uint32_t>(min(max(t - lp_sub + 1, 0), wmb - 1)), static_cast<uint32_t>(sizeof(DbPrm))) + lp_piece * 16, lane < 40); // (a picture has at most 2^18 macroblocks)
             }
@@ -470,25 +477,30 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             // ---- 4. what the loads brought: column x + 1 of every sub-row into its window slot (free since this step's stores), the next step's DbPrm into the stage ----
             loads_landed(); // (issued at the top of this step: a step old)
             {
-                // (written out once per phase of t + 1 mod 4: in a phase the piece a sub-row is due -- and so the lanes that hold it -- is a constant)
-                const int kq = (t + 1) & 3;
-                auto piece_l = [&](const v4u &G, int k, int ph) {
+                // (written out once per phase of t + 1 mod 8: in a phase the piece a sub-row is due -- and so the lanes that hold it -- is a constant)
+                const int kq = (t + 1) & 7;
+                auto piece_l = [&](const v4u &Ga, const v4u &Gb, int k, int ph) {
                     const int c = t - k + 1;
-                    if (k < rows_here && c >= 0 && c < wmb && ll_col == ((ph - k) & 3)) LST16(ll_dst + static_cast<uint32_t>(k) * T_BYTES, G);
+                    if (k < rows_here && c >= 0 && c < wmb && ll_col == ((ph - k) & 7)) LST16(ll_dst + static_cast<uint32_t>(k) * T_BYTES, Ga), LST16(ll_dst + static_cast<uint32_t>(k) * T_BYTES + 128, Gb);
                 };
-                auto piece_c = [&](const v4u &G, int k, int ph) { // column c = t + 1 - sub: c & 3 = (ph - sub) & 3 = (ph - k) & 3 for both halves
-                    const int sub = k + 4 * lc_half, c = t - sub + 1, p = (ph - k) & 3;
-                    if (sub < rows_here && c >= 0 && c < wmb && lc_q == (p >> 1))
-                        LST8(lc_dst + static_cast<uint32_t>(k) * T_BYTES + p * 128, (p & 1) ? (v2u{G.z, G.w}) : (v2u{G.x, G.y}));
+                auto piece_c = [&](const v4u &G, int k, int ph) { // column c = t + 1 - k: place in the group of eight p = c & 7 = (ph - k) & 7
+                    const int c = t - k + 1, p = (ph - k) & 7;
+                    if (k < rows_here && c >= 0 && c < wmb && lc_q == (p >> 1))
+                        LST8(lc_dst + static_cast<uint32_t>(k) * T_BYTES + (p & 3) * 128, (p & 1) ? (v2u{G.z, G.w}) : (v2u{G.x, G.y}));
                 };
-#define PIECES(ph)                                                                                                                                \
-    piece_l(G0, 0, ph), piece_l(G1, 1, ph), piece_l(G2, 2, ph), piece_l(G3, 3, ph), piece_l(G4, 4, ph), piece_l(G5, 5, ph), piece_l(G6, 6, ph), \
-        piece_l(G7, 7, ph), piece_c(GC0, 0, ph), piece_c(GC1, 1, ph), piece_c(GC2, 2, ph), piece_c(GC3, 3, ph)
+#define PIECES(ph)                                                                                                                                          \
+    piece_l(GA0, GB0, 0, ph), piece_l(GA1, GB1, 1, ph), piece_l(GA2, GB2, 2, ph), piece_l(GA3, GB3, 3, ph), piece_l(GA4, GB4, 4, ph), piece_l(GA5, GB5, 5, ph), \
+        piece_l(GA6, GB6, 6, ph), piece_l(GA7, GB7, 7, ph), piece_c(GC0, 0, ph), piece_c(GC1, 1, ph), piece_c(GC2, 2, ph), piece_c(GC3, 3, ph), piece_c(GC4, 4, ph),      \
+        piece_c(GC5, 5, ph), piece_c(GC6, 6, ph), piece_c(GC7, 7, ph)
                 switch (kq) {
                 case 0: PIECES(0); break;
                 case 1: PIECES(1); break;
                 case 2: PIECES(2); break;
-                default: PIECES(3); break;
+                case 3: PIECES(3); break;
+                case 4: PIECES(4); break;
+                case 5: PIECES(5); break;
+                case 6: PIECES(6); break;
+                default: PIECES(7); break;
                 }
 #undef PIECES
                 if (lane < 40) LST16(stage0 + static_cast<uint32_t>((t + 1) & 1) * (8 * static_cast<uint32_t>(sizeof(DbPrm))) + lane * 16, GP);

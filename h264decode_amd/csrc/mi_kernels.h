@@ -42,7 +42,7 @@ extern "C" __global__ void k_dbprep(const uint32_t *pic_list, const PicDesc *pic
 // (nwaves, ring, ring_last, last_bufs) from mi_deblock8_plan()
 // xstatus: a wavefront that gives up waiting for its neighbour (4 s) leaves a code there; a -DMI_DB_STATS build adds the phase clocks of its step loop to xstatus[8..19]
 extern "C" __global__ void k_deblock(const uint32_t *pic_list, const PicDesc *pics, const DbPrm *dbprm, int ring, int ring_last, int last_bufs, uint32_t *xstatus);
-#define MI_DEBLOCK8_MAX_WAVES 10     /* 640 threads: three wavefronts on a SIMD at most, 168 VGPRs each */
+#define MI_DEBLOCK8_MAX_WAVES 8      /* 512 threads: two wavefronts on a SIMD, up to 256 VGPRs each (the kernel holds 84 of them as landing registers of its loads) */
 #define MI_DEBLOCK8_MAX_GROUPS 64    /* hmb <= 320 + slack */
 #define MI_DEBLOCK8_HDR_BYTES 512    /* sizeof(Db8Shared) */
 #define MI_DEBLOCK8_TILE_BYTES 1568  /* the LDS window of a sub-row: four macroblock columns of luma (1024) and chroma (512) + 32 (bank stagger) */
