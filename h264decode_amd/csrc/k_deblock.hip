@@ -216,7 +216,20 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
         unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #endif
         for (int t = -1; t <= t_last; t++) {
+#if defined(MI_DB_PRIO)
+            // Measured, not on (profiles/r05_k5_group_timeline.txt).  Two wavefronts share a SIMD, and its arbiter serves the OLDER one first: the wavefronts of groups
+            // 0..3 take 4.6 us a step, those of groups 4..7 7 us -- and a picture is a chain of groups.  Taking turns at the higher issue priority (a step up, a step
+            // down, the SIMD's two wavefronts in opposite phase) does share the SIMD evenly (5.2 / 6.0 us; group 7 ends at 1048 instead of 1140 us), but wavefront 0 then
+            // comes to the ninth group of a 1080p picture 50 us later, and that group's 131 steps, not the chain, end the launch (1.17 against 1.13 ms).
+            if ((t + (wave >> 2)) & 1)
+                __builtin_amdgcn_s_setprio(2);
+            else
+                __builtin_amdgcn_s_setprio(0);
+#endif
             STAMP(5); // loop control + whatever the compiler moved across the step boundary
+#if defined(MI_DB_STATS)
+            if (blockIdx.x == 0 && lane_v == 0 && g < 12 && t >= 0 && (t & 15) == 0 && (t >> 4) < 8) xstatus[64 + 8 * g + (t >> 4)] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
+#endif
             int lane = lane_v;
             OPAQUE(lane);
             const int s = lane >> 3, j = lane & 7;

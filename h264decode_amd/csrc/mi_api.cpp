@@ -627,12 +627,12 @@ extern "C" int32_t h264mi_decoder_create(const h264mi_config *cfg_, h264mi_decod
     // (test hook: where the launch epoch and the ticket counters start, so that a test can cross their 32-bit wrap)
     DEV_ALLOC(d->d_xring, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long));
     DEV_ALLOC(d->d_xdone, static_cast<size_t>(d->x_cap3) * (d->Wmax / 16) * sizeof(uint32_t));
-    DEV_ALLOC(d->d_xctl, 4 * 128);
+    DEV_ALLOC(d->d_xctl, 8 * 128);
     TRY_ALLOC(hipHostMalloc(&d->h_xstatus, sizeof(uint32_t)));
     *d->h_xstatus = 0;
     TRY_ALLOC(hipMemset(d->d_xring, 0, static_cast<size_t>(d->x_cap) * (d->Wmax / 16) * 24 * sizeof(unsigned long long)));
     TRY_ALLOC(hipMemset(d->d_xdone, 0, static_cast<size_t>(d->x_cap3) * (d->Wmax / 16) * sizeof(uint32_t)));
-    TRY_ALLOC(hipMemset(d->d_xctl, 0, 4 * 128));
+    TRY_ALLOC(hipMemset(d->d_xctl, 0, 8 * 128));
     build_tables(d->h_tables);
     d->h_pools.resize(S);
     for (int si = 0; si < S; si++) { // static per stream (kernels take the geometry of a picture from its PicDesc)
@@ -2507,11 +2507,11 @@ extern "C" int32_t h264mi_internal_deblock_phase_clocks(h264mi_decoder *d, uint3
 }
 
 // Not part of the public ABI: start and end (100 MHz ticks) of the row groups of the first picture of the last K5 launch (-DMI_DB_STATS builds)
-extern "C" int32_t h264mi_internal_deblock_group_times(h264mi_decoder *d, uint32_t out[32]) {
+extern "C" int32_t h264mi_internal_deblock_group_times(h264mi_decoder *d, uint32_t out[128]) { // [0..31] start / end per group, [32 + 8 g + i] when group g began step 16 i
     if (!d || !out) return H264MI_EINVAL;
     GUARD(d);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out, d->d_xctl + 64 + 32, 32 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d->d_xctl + 64 + 32, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return H264MI_OK;
 }
 

@@ -37,7 +37,9 @@ print("  %-20s %8.0f" % ("total", tot / steps))
 if S > 1 and hasattr(H.load(), "h264mi_internal_deblock_group_times"):
     g = H.load().h264mi_internal_deblock_group_times
     g.restype, g.argtypes = ctypes.c_int32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
-    tb = (ctypes.c_uint32 * 32)()
+    tb = (ctypes.c_uint32 * 128)()
     g(dec._h, tb)
     t0 = min(tb[2 * k] for k in range(9))
     print("row groups of the first picture of the last launch, start .. end in us:", ", ".join("%.0f..%.0f" % ((tb[2 * k] - t0) * 0.01, (tb[2 * k + 1] - t0) * 0.01) for k in range(9)))
+    for k in range(9):
+        print("  group %d begins step 0, 16, 32, ... at us:" % k, " ".join("%5.0f" % ((tb[32 + 8 * k + i] - t0) * 0.01) for i in range(8)))
