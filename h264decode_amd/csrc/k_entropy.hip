@@ -191,7 +191,13 @@ struct Ent {
 #define MI_COUNT_BIN(e) ((e).bins++)
 #define MI_TT0(e) ((e).tmark = __builtin_readcyclecounter())
 #define MI_TT(e, k) do { const uint64_t now_ = __builtin_readcyclecounter(); (e).tacc[k] += now_ - (e).tmark; (e).tmark = now_; } while (0)
-#if MI_ENT_STATS == 2 /* [0] significance map [1] levels [2] rest of residual_block_cabac [3] rest of residual() */
+#if MI_ENT_STATS == 4 /* the syntax of a coded macroblock: [0] mb_type and partition schedule [1] ref_idx, mvd, vector prediction [2] intra modes, cbp, mb_qp_delta [3] everything else */
+#define MI_T0(e) ((void)0) /* ([3] counts from one macroblock's last stamp to the next one's first: residual, write-out, skip flag, caches) */
+#define MI_T(e, k) ((void)0)
+#define MI_R0(e) ((void)0)
+#define MI_R(e, k) ((void)0)
+#define MI_S(e, k) MI_TT(e, k)
+#elif MI_ENT_STATS == 2 /* [0] significance map [1] levels [2] rest of residual_block_cabac [3] rest of residual() */
 #define MI_T0(e) ((void)0)
 #define MI_T(e, k) ((void)0)
 #define MI_R0(e) ((void)0)
@@ -211,6 +217,9 @@ struct Ent {
 #define MI_T(e, k) ((void)0)
 #define MI_R0(e) ((void)0)
 #define MI_R(e, k) ((void)0)
+#endif
+#ifndef MI_S
+#define MI_S(e, k) ((void)0)
 #endif
 #define RFL(x) __builtin_amdgcn_readfirstlane(x)
 #define RDL(v, i) static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(i)))
@@ -1216,6 +1225,7 @@ FI void decode_mb(Ent &e, int skipped) {
 #endif
         e.prev_dqp_nz = 0;
     } else {
+        MI_S(e, 3);
         // ---- mb_type (Tables 9-36 / 9-37) ----
         int intra_prefix = 1; // in P slices: bin 0 of mb_type says "intra"
         if (cabac) {
@@ -1296,6 +1306,7 @@ FI void decode_mb(Ent &e, int skipped) {
             type = MBT_I4x4;
         }
         e.cur_type = type;
+        MI_S(e, 0);
         if (type == MBT_IPCM) {
             // after the terminate bin the arithmetic decoder has consumed exactly what the encoder's
             // flush wrote (9.3.1.2 / 9.3.4.5): stream position = bits fetched - lookahead
@@ -1496,6 +1507,7 @@ FI void decode_mb(Ent &e, int skipped) {
                     if (MI_ENT_B) s->ref_c[NL - 1][GI(LANE & 3, LANE >> 2)] = -1;
                 }
             }
+            MI_S(e, MB_IS_INTER(type) ? 1 : 2);
             // ---- coded_block_pattern ----
             if (type != MBT_I16x16) {
                 int cbp;
@@ -1550,6 +1562,7 @@ FI void decode_mb(Ent &e, int skipped) {
                 if (dqp < -26 || dqp > 25) e.err = 24, dqp = 0;
                 e.prev_dqp_nz = dqp != 0;
                 if (dqp) set_qp(e, (e.qp + dqp + 52) % 52);
+                MI_S(e, 2);
                 MI_T(e, 1);
                 MI_R0(e);
                 if (cabac)
