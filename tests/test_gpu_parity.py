@@ -103,6 +103,20 @@ def test_gpu_matrix_with_one_workgroup_per_picture(H, sg):
             assert np.array_equal(out[0], rec), (name, x)
 
 
+@pytest.mark.parametrize("w,h", [(64, 2176), (48, 1120), (32, 4096), (2048, 48)])
+def test_gpu_tall_and_wide_pictures_inside_one_workgroup(w, h, H, sg):
+    """k_deblock hands rows from one group of eight macroblock rows to the next through LDS rings; a picture of more than 64 rows takes its eight wavefronts
+    two rounds (1120 rows: 70 macroblock rows, 9 groups), more than 128 rows three and more -- there the ring of the last wavefront has a second buffer
+    (2176 rows: 17 groups; 4096 rows: 32 groups, four rounds).  K3 walks the same pictures with one wavefront per macroblock row.  A wide, flat picture for
+    the other extreme (128 macroblock columns, whole-row ring).  With and without B pictures' second list; both kernel families."""
+    for kw in (dict(profile_idc=77, cabac=1, frames=3), dict(profile_idc=100, cabac=0, transform8x8=1, frames=4, bframes=1, num_ref_frames=2)):
+        kw = dict(kw, width=w, height=h, idr_period=0, seed=77 + w)
+        stream, rec, _ = sg.encode(**kw)
+        for x in (0, 256):
+            out, _ = _decode_gpu(H, [stream, stream], w, h, kw["frames"], x_wgs=x)
+            assert np.array_equal(out[0], rec) and np.array_equal(out[1], rec), (w, h, kw["profile_idc"], x)
+
+
 def test_gpu_golden_md5(H, sg):
     gold = json.load(open(GOLDEN))
     gold.update(json.load(open(os.path.join(os.path.dirname(GOLDEN), "field_md5.json"))))
