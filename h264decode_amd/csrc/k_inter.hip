@@ -310,11 +310,12 @@ __device__ __forceinline__ uint32_t weigh4(uint32_t a, uint32_t b, bool u0, bool
 template <bool B>
 __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
                                        const int16_t *coefs, int groups_per_pic_log2, int n_blocks, const BSliceExt *bexts, const MbMv1 *mbmv1) {
-    const int lane = static_cast<int>(threadIdx.x), sub = lane >> 4, b = lane & 15, bx = b & 3, by = b >> 2, q8 = ((by >> 1) << 1) | (bx >> 1);
+    const int lane = static_cast<int>(threadIdx.x) & 63, sub = lane >> 4, b = lane & 15, bx = b & 3, by = b >> 2, q8 = ((by >> 1) << 1) | (bx >> 1);
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2; an XCD gets a contiguous run of
     // macroblock groups (whole pictures), so that the reference rows neighbouring blocks share come from the same L2
-    const uint32_t per_xcd = gridDim.x >> 3;
-    const uint32_t lb = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t per_xcd = gridDim.x >> 3, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t lb = ((blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3)) * MI_K4_WG + wave;
+    lds += 4 * wave;
     if (lb >= static_cast<uint32_t>(n_blocks)) return;
     const PicDesc *pd = &pics[pic_list[lb >> groups_per_pic_log2]];
     const int wmb = static_cast<int>(pd->wmb), hmb = static_cast<int>(pd->hmb);
@@ -593,14 +594,14 @@ __device__ __forceinline__ void inter4(InterLds *lds, const uint32_t *pic_list, 
 #else
 #define MI_K4_OCC
 #endif
-extern "C" __global__ void __launch_bounds__(64) MI_K4_OCC k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
+extern "C" __global__ void __launch_bounds__(64 * MI_K4_WG) MI_K4_OCC k_inter(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
                                                          const int16_t *coefs, int groups_per_pic_log2, int n_blocks) {
-    __shared__ InterLds lds[4];
+    __shared__ InterLds lds[4 * MI_K4_WG];
     inter4<false>(lds, pic_list, pics, slices, tab, mbrec, coefs, groups_per_pic_log2, n_blocks, nullptr, nullptr);
 }
 // K4 for the pictures that have B slices: two lists per block (MbRec::refslot1, MbMv1), default / explicit / implicit weighting
-extern "C" __global__ void __launch_bounds__(64) MI_K4_OCC k_inter_b(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
+extern "C" __global__ void __launch_bounds__(64 * MI_K4_WG) MI_K4_OCC k_inter_b(const uint32_t *pic_list, const PicDesc *pics, const SliceDesc *slices, const DevTables *tab, const MbRec *mbrec,
                                                            const int16_t *coefs, int groups_per_pic_log2, int n_blocks, const BSliceExt *bexts, const MbMv1 *mbmv1) {
-    __shared__ InterLds lds[4];
+    __shared__ InterLds lds[4 * MI_K4_WG];
     inter4<true>(lds, pic_list, pics, slices, tab, mbrec, coefs, groups_per_pic_log2, n_blocks, bexts, mbmv1);
 }

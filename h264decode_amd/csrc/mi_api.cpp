@@ -2109,13 +2109,13 @@ static int execute_stage(h264mi_decoder *d, int stage_idx, bool exclusive) {
         while ((4 << grp_log2) < g.mbs_max) grp_log2++;
         if (ni) {
             const uint32_t nb = ni << grp_log2;
-            hipLaunchKernelGGL(k_inter, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_p_off[w], g.d_pics, g.d_slices, d->d_tables, mbrec, coef, grp_log2,
+            hipLaunchKernelGGL(k_inter, dim3(((nb + MI_K4_WG - 1) / MI_K4_WG + 7) & ~7u), dim3(64 * MI_K4_WG), 0, rs, g.d_lists + g.wave_p_off[w], g.d_pics, g.d_slices, d->d_tables, mbrec, coef, grp_log2,
                                static_cast<int>(nb));
             mark(1);
         }
         if (nbp) {
             const uint32_t nb = nbp << grp_log2;
-            hipLaunchKernelGGL(k_inter_b, dim3((nb + 7) & ~7u), dim3(64), 0, rs, g.d_lists + g.wave_b_off[w], g.d_pics, g.d_slices, d->d_tables, mbrec, coef, grp_log2,
+            hipLaunchKernelGGL(k_inter_b, dim3(((nb + MI_K4_WG - 1) / MI_K4_WG + 7) & ~7u), dim3(64 * MI_K4_WG), 0, rs, g.d_lists + g.wave_b_off[w], g.d_pics, g.d_slices, d->d_tables, mbrec, coef, grp_log2,
                                static_cast<int>(nb), g.d_bext, d->d_mv1[set]);
             mark(1);
         }

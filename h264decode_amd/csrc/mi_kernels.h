@@ -14,6 +14,9 @@ extern "C" __global__ void k_entropy_b(const SliceDesc *slices, const PicDesc *p
                                        uint32_t *pool_head, uint32_t pool_blocks, uint32_t *status, uint32_t *toprows, int wmb_max, uint32_t slice_base,
                                        const BSliceExt *bexts, MbMv1 *mbmv1);
 #define MI_TOPROW_BYTES 72 /* per macroblock column per slice (the B kernel's TopInfo; the I/P kernel uses 48 of them) */
+#ifndef MI_K4_WG
+#define MI_K4_WG 1 /* wavefronts (groups of four macroblocks) per workgroup of k_inter / k_inter_b: grid = ceil(n_blocks / MI_K4_WG) rounded up to a multiple of 8 (measured: 2 and 4 are slower, profiles/r05_k4_budget.txt) */
+#endif
 // K4 (k_inter.hip): inter macroblocks of a set of pictures (one per stream), one lane per 4x4 block, four macroblocks per wavefront.
 // n_blocks = #pictures << groups_per_pic_log2 (groups of four macroblocks per picture, rounded up to a power of two: no division in the kernel);
 // grid = n_blocks rounded up to a multiple of 8 (XCD-aware block order), block = 64
