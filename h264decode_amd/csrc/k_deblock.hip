@@ -81,19 +81,19 @@ typedef __attribute__((address_space(1))) v2u g_uint2;
                      : [o] "v"(static_cast<uint32_t>(off)), [b] "s"(base), [m] "s"(__builtin_amdgcn_ballot_w64(cond))                              \
                      : "scc");                                                                                                                     \
     } while (0)
-// The group loads of one phase (the step's t + 1 = K mod 4: sub-rows K and K + 4 reload, luma each, chroma together): three masked loads behind one
-// scalar branch on the phase -- four such statements stand in a step, one falls through.  Offsets and lane masks are the step's (the same operands
-// in all four); only the destinations differ.
-#define ALD_PHASE(K, ga, gb, gc, kq, oa, ob, oc, ma, mb, mc, base)                                                                                 \
+// The group loads of one phase (the step's t + 1 = K mod 8: sub-row K reloads -- its luma rows 0..7 and 8..15, the two halves of its chroma lines): four masked loads behind
+// one scalar branch on the phase -- eight such statements stand in a step, one falls through.  Offsets and lane masks are the step's (the same operands in all
+// eight); only the destinations differ.
+#define ALD_PHASE(K, ga, gb, gc, gd, kq, oa, ob, oc, od, ml, mc, md, base)                                                                         \
     do {                                                                                                                                           \
         unsigned long long sv_;                                                                                                                    \
         asm volatile("s_cmp_lg_u32 %[q], " #K "\n\ts_cbranch_scc1 9f\n\ts_mov_b64 %[sv], exec\n\t"                                                 \
-                     "s_and_b64 exec, %[sv], %[mA]\n\ts_cbranch_execz 1f\n\tglobal_load_dwordx4 %[dA], %[oA], %[b]\n1:\n\t"                         \
-                     "s_and_b64 exec, %[sv], %[mB]\n\ts_cbranch_execz 2f\n\tglobal_load_dwordx4 %[dB], %[oB], %[b]\n2:\n\t"                         \
-                     "s_and_b64 exec, %[sv], %[mC]\n\ts_cbranch_execz 3f\n\tglobal_load_dwordx4 %[dC], %[oC], %[b]\n3:\n\t"                         \
+                     "s_and_b64 exec, %[sv], %[mL]\n\ts_cbranch_execz 1f\n\tglobal_load_dwordx4 %[dA], %[oA], %[b]\n\tglobal_load_dwordx4 %[dB], %[oB], %[b]\n1:\n\t" \
+                     "s_and_b64 exec, %[sv], %[mC]\n\ts_cbranch_execz 2f\n\tglobal_load_dwordx4 %[dC], %[oC], %[b]\n2:\n\t"                         \
+                     "s_and_b64 exec, %[sv], %[mD]\n\ts_cbranch_execz 3f\n\tglobal_load_dwordx4 %[dD], %[oD], %[b]\n3:\n\t"                         \
                      "s_mov_b64 exec, %[sv]\n9:"                                                                                                   \
-                     : [dA] "+v"(ga), [dB] "+v"(gb), [dC] "+v"(gc), [sv] "=&s"(sv_)                                                                \
-                     : [q] "s"(kq), [oA] "v"(oa), [oB] "v"(ob), [oC] "v"(oc), [mA] "s"(ma), [mB] "s"(mb), [mC] "s"(mc), [b] "s"(base)              \
+                     : [dA] "+v"(ga), [dB] "+v"(gb), [dC] "+v"(gc), [dD] "+v"(gd), [sv] "=&s"(sv_)                                                 \
+                     : [q] "s"(kq), [oA] "v"(oa), [oB] "v"(ob), [oC] "v"(oc), [oD] "v"(od), [mL] "s"(ml), [mC] "s"(mc), [mD] "s"(md), [b] "s"(base) \
                      : "scc");                                                                                                                     \
     } while (0)
 typedef __attribute__((address_space(3))) uint8_t l8;
@@ -167,7 +167,8 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
         //   luma load    GA[k] / GB[k], rows 0..7 / 8..15 of sub-row k, EIGHT macroblock columns at once = whole 128-byte lines: lane = (row L >> 3, column L & 7),
         //                16 bytes; landed pieces enter the window one column per step (the slot of column x + 1 is free from the end of step x on), raw rows --
         //                rows 2j, 2j + 1 are the 32 bytes of row pair j, so the vertical pass converts its own 32 bytes in place;
-        //   chroma load  GC[k], sub-row k, the same eight columns: lane = (plane L >> 5, row (L >> 2) & 7, column pair L & 3), 16 bytes = two macroblocks' eight samples;
+        //   chroma load  GC[k] / GD[k], both planes' eight rows of sub-row k, SIXTEEN columns at once = whole lines, as two instructions of half lines in the same step:
+        //                lane = (plane L >> 5, row (L >> 2) & 7, column pair L & 3), 16 bytes = two macroblocks' eight samples; issued with every other luma group;
         //   stores       column pairs {x - 3, x - 2} of the sub-rows whose x is odd: luma lane = (sub-row, row (L & 31) >> 1, column L & 1),
         //                chroma lane = (sub-row, plane, row), 16 bytes = both columns; a sub-row stores ITS OWN rows 0..15 (what the row below did to
         //                rows 13..15 happened in this window), the first sub-row also rows 12..15 of the group above out of window 0, the last
@@ -179,7 +180,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
         // luma load lane
         const uint32_t ll_src = y_off + static_cast<uint32_t>(g * 128 + (lane >> 3)) * W + (lane & 7) * 16; // + (k * 16 [+ 8]) W + column base * 16
         // chroma load lane
-        const uint32_t lc_src = ((lane & 32) ? cr_off : cb_off) + static_cast<uint32_t>(g * 64 + ((lane >> 2) & 7)) * Wc + (lane & 3) * 16; // + k * 8 Wc + column base * 8
+        const uint32_t lc_src = ((lane & 32) ? cr_off : cb_off) + static_cast<uint32_t>(g * 64 + ((lane >> 2) & 7)) * Wc + (lane & 3) * 16; // + k * 8 Wc + column base * 8 [+ 64: the line's other half]
         // luma store lane (instruction i: sub-rows par + 4 i and par + 4 i + 2)
         // chroma store lane (sub-rows par, par + 2, par + 4, par + 6)
         // DbPrm lane
@@ -187,12 +188,15 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
         const uint32_t lp_row = static_cast<uint32_t>(min(g * 8 + lp_sub, hmb - 1)) * static_cast<uint32_t>(wmb);
         v4u GA0 = z4, GA1 = z4, GA2 = z4, GA3 = z4, GA4 = z4, GA5 = z4, GA6 = z4, GA7 = z4; // sub-row k: rows 0..7 of eight macroblock columns (whole 128-byte lines)
         v4u GB0 = z4, GB1 = z4, GB2 = z4, GB3 = z4, GB4 = z4, GB5 = z4, GB6 = z4, GB7 = z4; // ... rows 8..15
-        v4u GC0 = z4, GC1 = z4, GC2 = z4, GC3 = z4, GC4 = z4, GC5 = z4, GC6 = z4, GC7 = z4, GP = z4; // sub-row k: both chroma planes' eight rows of the same eight columns (64 bytes a row)
+        v4u GC0 = z4, GC1 = z4, GC2 = z4, GC3 = z4, GC4 = z4, GC5 = z4, GC6 = z4, GC7 = z4; // sub-row k: both chroma planes' eight rows, columns 0..7 of SIXTEEN (the first half of the 128-byte lines)
+        v4u GD0 = z4, GD1 = z4, GD2 = z4, GD3 = z4, GD4 = z4, GD5 = z4, GD6 = z4, GD7 = z4; // ... columns 8..15 (the other half, asked for in the same step)
+        v4u GP = z4;
         // every load issued so far has landed (the one wait on vector memory of a step, at its end: what it waits for was issued at the step's top)
         auto loads_landed = [&]() {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(GA0), "+v"(GA1), "+v"(GA2), "+v"(GA3), "+v"(GA4), "+v"(GA5), "+v"(GA6), "+v"(GA7), "+v"(GB0), "+v"(GB1), "+v"(GB2), "+v"(GB3), "+v"(GB4),
                          "+v"(GB5), "+v"(GB6), "+v"(GB7));
-            asm volatile("" : "+v"(GC0), "+v"(GC1), "+v"(GC2), "+v"(GC3), "+v"(GC4), "+v"(GC5), "+v"(GC6), "+v"(GC7), "+v"(GP));
+            asm volatile("" : "+v"(GC0), "+v"(GC1), "+v"(GC2), "+v"(GC3), "+v"(GC4), "+v"(GC5), "+v"(GC6), "+v"(GC7), "+v"(GD0), "+v"(GD1), "+v"(GD2), "+v"(GD3), "+v"(GD4), "+v"(GD5),
+                         "+v"(GD6), "+v"(GD7), "+v"(GP));
         };
         // the ring this group writes was last used by the group `reuse` groups earlier: that group's reader must be through with it
         // every wait on another wavefront gives up after 4 s of s_memrealtime and says so through the status word (H264MI_EDECODE) instead of hanging the GPU
@@ -240,7 +244,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             // register pairs for the whole kernel -- which the compiler then spills into VGPR lanes)
             const int ll_row = lane >> 3, ll_col = lane & 7;
             const uint32_t ll_dst = tile0 + T_BYTES + (ll_col & 3) * 256 + ll_row * 16;                // + k * T_BYTES [+ 128: rows 8..15]  (slot = column & 3)
-            const int lc_rr = lane >> 2, lc_q = lane & 3; // (plane, row) 0..15, column pair 0..3 of the eight
+            const int lc_rr = lane >> 2, lc_q = lane & 3; // (plane, row) 0..15, column pair 0..3 of a half line's eight columns
             const uint32_t lc_dst = tile0 + T_BYTES + T_CHROMA + (lc_rr & 7) * 16 + (lc_rr >> 3) * 8;                                             // + k * T_BYTES + slot * 128
             const int sl_half = lane >> 5, sl_row = (lane & 31) >> 1, sl_col = lane & 1;
             const uint32_t sl_sel = (sl_row & 1) ? 0x07050301u : 0x06040200u; // this row of a row pair's 2x2 blocks
@@ -256,23 +260,25 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             const v2u bs = LLD8(stage + (j >> 1) * 8); // (the planes' blocks are read where a pass needs them: 12 registers less across the step)
             STAMP(0);
             // ---- 0. the step's vector memory operations in one burst (the one wait for them is at the end of the step) ----
-            // 0a. loads: the ONE sub-row whose column x + 1 starts a group of eight.  Luma: whole 128-byte lines, so that a line is fetched once (with groups of four the
-            // halves of a line were asked for four steps apart, and the 32 pictures of an XCD keep more lines in flight than its 4 MB of L2 hold: 2.2 x the bytes);
-            // chroma: 64 of a line's 128 bytes (32 before: a line was fetched four times).
+            // 0a. loads: the ONE sub-row whose column x + 1 starts a group of eight -- whole 128-byte lines, so that a line is fetched once (with groups of four the halves of
+            // a luma line, the quarters of a chroma line, were asked for four steps apart, and the 32 pictures of an XCD keep more lines in flight than its 4 MB of L2 hold:
+            // 2.2 x the bytes).  Luma: eight columns = a line; chroma: SIXTEEN columns = a line, every other time.
             {
                 const int k8 = (t + 1) & 7, cb8 = t - k8 + 1;
                 const bool ok8 = k8 < rows_here && cb8 >= 0 && cb8 < wmb;
-                const unsigned long long m_l = ok8 ? __builtin_amdgcn_ballot_w64(ll_col < wmb - cb8) : 0ull, m_c = ok8 ? __builtin_amdgcn_ballot_w64(2 * lc_q < wmb - cb8) : 0ull;
+                const unsigned long long m_l = ok8 ? __builtin_amdgcn_ballot_w64(ll_col < wmb - cb8) : 0ull;
+                const bool okc = ok8 && !(cb8 & 8);
+                const unsigned long long m_c = okc ? __builtin_amdgcn_ballot_w64(2 * lc_q < wmb - cb8) : 0ull, m_d = okc ? __builtin_amdgcn_ballot_w64(2 * lc_q + 8 < wmb - cb8) : 0ull;
                 const uint32_t o_l = ll_src + __umul24(k8 * 16, W) + cb8 * 16, o_h = o_l + 8 * static_cast<uint32_t>(W);
-                const uint32_t o_c = lc_src + __umul24(k8 * 8, Wc) + cb8 * 8;
-                ALD_PHASE(0, GA0, GB0, GC0, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
-                ALD_PHASE(1, GA1, GB1, GC1, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
-                ALD_PHASE(2, GA2, GB2, GC2, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
-                ALD_PHASE(3, GA3, GB3, GC3, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
-                ALD_PHASE(4, GA4, GB4, GC4, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
-                ALD_PHASE(5, GA5, GB5, GC5, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
-                ALD_PHASE(6, GA6, GB6, GC6, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
-                ALD_PHASE(7, GA7, GB7, GC7, k8, o_l, o_h, o_c, m_l, m_l, m_c, py);
+                const uint32_t o_c = lc_src + __umul24(k8 * 8, Wc) + cb8 * 8, o_d = o_c + 64;
+                ALD_PHASE(0, GA0, GB0, GC0, GD0, k8, o_l, o_h, o_c, o_d, m_l, m_c, m_d, py);
+                ALD_PHASE(1, GA1, GB1, GC1, GD1, k8, o_l, o_h, o_c, o_d, m_l, m_c, m_d, py);
+                ALD_PHASE(2, GA2, GB2, GC2, GD2, k8, o_l, o_h, o_c, o_d, m_l, m_c, m_d, py);
+                ALD_PHASE(3, GA3, GB3, GC3, GD3, k8, o_l, o_h, o_c, o_d, m_l, m_c, m_d, py);
+                ALD_PHASE(4, GA4, GB4, GC4, GD4, k8, o_l, o_h, o_c, o_d, m_l, m_c, m_d, py);
+                ALD_PHASE(5, GA5, GB5, GC5, GD5, k8, o_l, o_h, o_c, o_d, m_l, m_c, m_d, py);
+                ALD_PHASE(6, GA6, GB6, GC6, GD6, k8, o_l, o_h, o_c, o_d, m_l, m_c, m_d, py);
+                ALD_PHASE(7, GA7, GB7, GC7, GD7, k8, o_l, o_h, o_c, o_d, m_l, m_c, m_d, py);
                 // DbPrm of the next step's macroblocks (a clamped address where there is none: the stage entry is never used then)
                 ALD16M(GP, prms, __umul24(lp_row + static_cast<uint32_t>(min(max(t - lp_sub + 1, 0), wmb - 1)), static_cast<uint32_t>(sizeof(DbPrm))) + lp_piece * 16, lane < 40); // (a picture has at most 2^18 macroblocks)
             }
@@ -496,15 +502,19 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
                     const int c = t - k + 1;
                     if (k < rows_here && c >= 0 && c < wmb && ll_col == ((ph - k) & 7)) LST16(ll_dst + static_cast<uint32_t>(k) * T_BYTES, Ga), LST16(ll_dst + static_cast<uint32_t>(k) * T_BYTES + 128, Gb);
                 };
-                auto piece_c = [&](const v4u &G, int k, int ph) { // column c = t + 1 - k: place in the group of eight p = c & 7 = (ph - k) & 7
+                auto piece_c = [&](const v4u &Gc, const v4u &Gd, int k, int ph) { // column c = t + 1 - k: place in its half line p = c & 7 = (ph - k) & 7, half (c >> 3) & 1
                     const int c = t - k + 1, p = (ph - k) & 7;
-                    if (k < rows_here && c >= 0 && c < wmb && lc_q == (p >> 1))
-                        LST8(lc_dst + static_cast<uint32_t>(k) * T_BYTES + (p & 3) * 128, (p & 1) ? (v2u{G.z, G.w}) : (v2u{G.x, G.y}));
+                    if (k < rows_here && c >= 0 && c < wmb && lc_q == (p >> 1)) {
+                        if (c & 8)
+                            LST8(lc_dst + static_cast<uint32_t>(k) * T_BYTES + (p & 3) * 128, (p & 1) ? (v2u{Gd.z, Gd.w}) : (v2u{Gd.x, Gd.y}));
+                        else
+                            LST8(lc_dst + static_cast<uint32_t>(k) * T_BYTES + (p & 3) * 128, (p & 1) ? (v2u{Gc.z, Gc.w}) : (v2u{Gc.x, Gc.y}));
+                    }
                 };
 #define PIECES(ph)                                                                                                                                          \
     piece_l(GA0, GB0, 0, ph), piece_l(GA1, GB1, 1, ph), piece_l(GA2, GB2, 2, ph), piece_l(GA3, GB3, 3, ph), piece_l(GA4, GB4, 4, ph), piece_l(GA5, GB5, 5, ph), \
-        piece_l(GA6, GB6, 6, ph), piece_l(GA7, GB7, 7, ph), piece_c(GC0, 0, ph), piece_c(GC1, 1, ph), piece_c(GC2, 2, ph), piece_c(GC3, 3, ph), piece_c(GC4, 4, ph),      \
-        piece_c(GC5, 5, ph), piece_c(GC6, 6, ph), piece_c(GC7, 7, ph)
+        piece_l(GA6, GB6, 6, ph), piece_l(GA7, GB7, 7, ph), piece_c(GC0, GD0, 0, ph), piece_c(GC1, GD1, 1, ph), piece_c(GC2, GD2, 2, ph), piece_c(GC3, GD3, 3, ph),           \
+        piece_c(GC4, GD4, 4, ph), piece_c(GC5, GD5, 5, ph), piece_c(GC6, GD6, 6, ph), piece_c(GC7, GD7, 7, ph)
                 switch (kq) {
                 case 0: PIECES(0); break;
                 case 1: PIECES(1); break;
