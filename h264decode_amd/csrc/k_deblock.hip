@@ -495,6 +495,7 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
             STAMP(3);
             // ---- 4. what the loads brought: column x + 1 of every sub-row into its window slot (free since this step's stores), the next step's DbPrm into the stage ----
             loads_landed(); // (issued at the top of this step: a step old)
+            STAMP(8);
             {
                 // (written out once per phase of t + 1 mod 8: in a phase the piece a sub-row is due -- and so the lanes that hold it -- is a constant)
                 const int kq = (t + 1) & 7;
@@ -526,6 +527,9 @@ extern "C" __global__ void __launch_bounds__(MI_DEBLOCK8_MAX_WAVES * 64) k_deblo
                 default: PIECES(7); break;
                 }
 #undef PIECES
+                // (measured: with the lanes' columns rotated by the sub-row, so that all due pieces sit in the same lanes and leave under ONE lane mask -- a fifth of the
+                // instructions here --, this phase and the launch take the same time: it is the LDS draining, not the issue)
+                STAMP(9);
                 if (lane < 40) LST16(stage0 + static_cast<uint32_t>((t + 1) & 1) * (8 * static_cast<uint32_t>(sizeof(DbPrm))) + lane * 16, GP);
             }
             WAVE_SYNC();

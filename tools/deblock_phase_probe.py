@@ -23,7 +23,7 @@ f(dec._h, buf)
 dec.decode([s] * S)
 f(dec._h, buf)
 if S > 1:  # k_deblock proper (round 5: groups of 8 rows, 129 steps)
-    names = ["0a inputs out of the prefetch registers", "1 vertical edges", "2 hand-off", "3 horizontal edges", "0b output of column x - 2", "loop", "-", "0c prefetch issue", "-", "-", "-", "-"]
+    names = ["0a inputs out of the prefetch registers", "1 vertical edges", "2 hand-off", "3 horizontal edges", "0b output of column x - 2", "loop", "4c DbPrm stage + sync", "0c prefetch issue", "4a wait for the loads", "4b pieces into the window", "-", "-"]
     nst = 129
 else:      # the banded kernel k_deblock_x
     names = ["1c parameters (rest of 1)", "2 vertical edges", "3 hand-off", "4 horizontal edges", "5 results", "loop", "1a DbPrm -> LDS", "1b prefetch issue", "-", "-", "-", "-"]
