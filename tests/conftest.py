@@ -251,3 +251,48 @@ FIELD_CABAC_MATRIX = {name + "_cabac": dict(kw, cabac=1) for name, kw in FIELD_M
 def pictures_of(kw):
     """Pictures (access units) of a matrix stream: a frame coded as two fields is two of them.  What a decoder's max_frames_per_batch counts."""
     return kw["frames"] * (2 if kw.get("field_pics") else 1)
+
+
+def with_extension_nals(stream, seed=1):
+    """The Annex-B stream with the NAL units of an SVC / MVC / 3D-AVC stream around its own (Annex G / H / J: prefix NAL unit 14 in front of every
+    slice, subset SPS 15 behind every SPS, coded slice extension 20 / 21 behind every slice), an SEI and filler data.  A decoder of the base layer / base
+    view ignores all of them (h264/nalUnit.go:39-71 parses their header extension; h264/server.go:147-164 looks at types 1, 5, 7, 8 only)."""
+    import random
+    rnd = random.Random(seed)
+    # split at start codes (3- or 4-byte), keep each unit with its start code
+    units, i, n = [], 0, len(stream)
+    starts = []
+    while i + 3 <= n:
+        if stream[i] == 0 and stream[i + 1] == 0 and stream[i + 2] == 1:
+            starts.append(i - 1 if i > 0 and stream[i - 1] == 0 else i)
+            i += 3
+        else:
+            i += 1
+    starts.append(n)
+    for a, b in zip(starts, starts[1:]):
+        units.append(bytes(stream[a:b]))
+
+    def ext(nal_type, ref_idc, n_bytes, svc=True):
+        body = bytes(rnd.choice((0x55, 0xAA, 0x7F, 0x33, 0x81)) for _ in range(n_bytes))  # (no 00 00 0x inside)
+        hdr = bytes([(ref_idc << 5) | nal_type])
+        if nal_type in (14, 20, 21):
+            hdr += bytes([0x80 | rnd.randrange(64) if svc else rnd.randrange(64), 0x80 | rnd.randrange(128), 0x07 | (rnd.randrange(32) << 3)])
+        return b"\x00\x00\x01" + hdr + body + b"\x80"
+    out = []
+    for u in units:
+        k = 4 if u[:4] == b"\x00\x00\x00\x01" else 3
+        t = u[k] & 31
+        if t in (1, 5):
+            out.append(ext(14, (u[k] >> 5) & 3, 0))
+        out.append(u)
+        if t == 7:
+            out.append(ext(15, 3, 24))
+        if t in (1, 5):
+            out.append(ext(20, (u[k] >> 5) & 3, rnd.randrange(8, 200), svc=rnd.random() < 0.5))
+            if rnd.random() < 0.3:
+                out.append(ext(21, 0, rnd.randrange(8, 60)))
+            if rnd.random() < 0.3:
+                out.append(b"\x00\x00\x01\x06\x05\x04\x55\x55\x55\x55\x80")  # an SEI
+            if rnd.random() < 0.3:
+                out.append(b"\x00\x00\x01\x0c" + b"\xff" * rnd.randrange(1, 40) + b"\x80")  # filler data
+    return b"".join(out)

@@ -215,6 +215,21 @@ def test_gpu_real_stream_matches_oracle(H, real_stream, oracle_mod):
     assert np.array_equal(out[0], ref)
 
 
+def test_gpu_base_layer_of_streams_with_extension_nal_units(H, sg):
+    """SVC / MVC / 3D-AVC streams (Annex G / H / J) carry their enhancement in NAL units of types 14, 15, 20, 21 around the base layer's own; the decoder
+    decodes the base layer / base view and passes over the rest (h264/nalUnit.go:39-71 parses their header extension, h264/server.go:147-164 dispatches on
+    types 1, 5, 7, 8 only)."""
+    from conftest import with_extension_nals
+    for kw in (dict(width=176, height=144, frames=6, idr_period=3, profile_idc=77, cabac=1, slices=2, seed=41),
+               dict(width=176, height=144, frames=7, idr_period=0, profile_idc=100, cabac=0, transform8x8=1, bframes=2, num_ref_frames=3, seed=42),
+               dict(width=320, height=192, frames=5, idr_period=0, profile_idc=66, cabac=0, slice_groups=3, fmo_type=1, slices=3, seed=43)):
+        stream, rec, _ = sg.encode(**kw)
+        ext = with_extension_nals(stream, seed=kw["seed"])
+        out, info = _decode_gpu(H, [ext, stream], kw["width"], kw["height"], kw["frames"], _nslices(kw))
+        assert info.n_frames == 2 * kw["frames"]
+        assert np.array_equal(out[0], rec) and np.array_equal(out[1], rec), kw["seed"]
+
+
 def test_gpu_1080p_full_size_properties(H, sg, oracle_mod):
     """BASELINE config at full size: 1080p Main CABAC IPPP, cropping 1088 -> 1080, two streams."""
     kw = sg.recipe("C3", frames=4, idr_period=4)

@@ -55,6 +55,21 @@ def test_host_picture_order_counts_match_the_generator(host_pocs, sg):
             assert set(restarts.tolist()) <= set(np.flatnonzero(got[:, 4]).tolist()), name
 
 
+def test_host_passes_over_extension_nal_units(host_pocs, sg):
+    """The base layer / base view of an SVC / MVC stream: the product's host code sees the same pictures with and without the NAL units of types 14, 15, 20, 21
+    (and SEI, filler data) between them."""
+    from conftest import with_extension_nals
+    prog, tmp = host_pocs
+    for name in ("cabac_IPP", "b_pyramid_cabac", "field_mixed_paff", "fmo_dispersed_aso"):
+        kw = FULL_MATRIX[name]
+        stream, _, _ = sg.encode(want_recon=False, **kw)
+        want = sg.last_pocs()
+        plain, order = _host(prog, tmp, stream, kw)
+        got, order2 = _host(prog, tmp, with_extension_nals(stream, seed=7), kw)
+        assert np.array_equal(got, plain) and order2 == order, name
+        assert np.array_equal(got[:, 0], want), name
+
+
 @pytest.mark.parametrize("name", sorted(POC_MATRIX))
 def test_bottom_field_counts_oracle_equals_generator(name, sg, oracle_mod):
     kw = POC_MATRIX[name]

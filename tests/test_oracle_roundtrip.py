@@ -126,3 +126,15 @@ def test_real_x264_stream_self_synchronises(real_stream, oracle_mod):
     on_edge = gx[:, 15::16].mean()
     interior = np.delete(gx, np.s_[15::16], axis=1).mean()
     assert on_edge < 1.5 * interior + 1.0, (on_edge, interior)
+
+
+def test_extension_nal_units_are_passed_over(sg, oracle_mod):
+    """An SVC / MVC stream is its base layer / base view plus NAL units of types 14, 15, 20, 21: the checker decodes the base and ignores the rest."""
+    from conftest import with_extension_nals
+    for kw in (dict(width=176, height=144, frames=6, idr_period=3, profile_idc=77, cabac=1, slices=2, seed=41),
+               dict(width=176, height=144, frames=7, idr_period=0, profile_idc=100, cabac=0, transform8x8=1, bframes=2, num_ref_frames=3, seed=42)):
+        stream, rec, _ = sg.encode(**kw)
+        ext = with_extension_nals(stream, seed=kw["seed"])
+        assert len(ext) > len(stream)
+        out, _ = oracle_mod.decode(ext, crop=False)
+        assert np.array_equal(out, rec)
