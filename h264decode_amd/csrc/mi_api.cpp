@@ -1839,7 +1839,13 @@ extern "C" int32_t h264mi_batch_prepare(h264mi_decoder *d, int32_t n_streams, co
                 if (s.cur_slot >= 0) finish_picture(d, si);
                 if (nal.type != 9) flush_pending_field(d, si); // end of sequence / end of stream: no second field will follow a lone first one
                 break;
-            default: break; // SEI, filler, ... (h264/server.go:147-164 ignores them too)
+            case 2:
+            case 3:
+            case 4: // slice data partitions A / B / C (Extended profile; h264/nalUnit.go:14-16 names them): ignoring them would drop pictures without a word
+                set_error("stream %d: slice data partitioning (nal_unit_type %d, Extended profile) is out of scope", si, nal.type);
+                r = H264MI_EUNSUPPORTED;
+                break;
+            default: break; // SEI, filler, the extension units of SVC / MVC / 3D-AVC streams (14, 15, 20, 21: the base layer is decoded) ... (h264/server.go:147-164 ignores them too)
             }
         }
         if (r != H264MI_OK) {

@@ -415,6 +415,20 @@ def test_gpu_rejects_out_of_scope_profile(H):
     dec.close()
 
 
+def test_gpu_data_partitioning_is_refused_with_a_reason(H, sg):
+    """Slice data partitions (NAL unit types 2, 3, 4; Extended profile) are not decoded: a stream that carries one is refused with a status and a message --
+    passing them over like SEI would silently drop its pictures."""
+    stream, _, _ = sg.encode(width=176, height=144, frames=3, idr_period=0, profile_idc=66, cabac=0, seed=9)
+    part = stream + b"\x00\x00\x01\x22" + b"\x9a\x55\xaa\x80"  # nal_ref_idc 1, nal_unit_type 2
+    dec = H.Decoder(max_streams=2, max_width=176, max_height=144, max_frames_per_batch=4)
+    try:
+        with pytest.raises(H.H264MIError) as ei:
+            dec.decode([part])
+        assert ei.value.code == -3 and "partition" in str(ei.value)
+    finally:
+        dec.close()
+
+
 def test_gpu_c_program_through_the_abi(H, sg, oracle_mod, tmp_path):
     """examples/h264mi_decode.c (plain C, only include/h264mi.h): file in, raw I420 out, several batches."""
     import subprocess
