@@ -35,7 +35,9 @@ extern "C" {
 #define H264MI_OK 0
 #define H264MI_EINVAL (-1)      /* bad argument */
 #define H264MI_EBITSTREAM (-2)  /* malformed / truncated syntax */
-#define H264MI_EUNSUPPORTED (-3)/* valid H.264 outside the implemented scope (MBAFF, CABAC-coded field pictures, SP/SI slices, 4:4:4 ...): the message says what and why */
+#define H264MI_EUNSUPPORTED (-3)/* valid H.264 outside the implemented scope (MBAFF, CABAC-coded field pictures unless asked for, SP/SI slices, data partitioning,
+                                 * 4:2:2 / 4:4:4, more than 8 bits ...): the message says what and why.  Of SVC / MVC / 3D-AVC streams the base layer / base view
+                                 * is decoded; their extension NAL units (14, 15, 20, 21) are passed over */
 #define H264MI_ENODEVICE (-4)   /* no usable HIP device / kernel image */
 #define H264MI_ENOMEM (-5)
 #define H264MI_EDEVICE (-6)     /* HIP runtime error */
